@@ -1,0 +1,380 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE (build container only).
+
+    python oracle/gen_golden.py            # needs /root/reference; writes tests/golden/*.npz
+
+Fixtures are data only: inputs, every RNG draw the reference consumed, and the reference's
+outputs.  Nothing from the reference's sources is stored.
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_shim  # noqa: E402
+
+qinfer = ref_shim.install()
+from qinfer.tomography import TomographyModel, pauli_basis  # noqa: E402
+import np_oracle as orc  # noqa: E402  (only for the restated Ginibre prior; qutip is absent)
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+
+
+# ------------------------------------------------------------------------------------------
+class Recorder:
+    """Wraps the global legacy RNG entry points the hot path uses and logs every draw."""
+
+    def __init__(self):
+        self.kinds, self.shapes, self.data = [], [], []
+        self.enabled = True
+        self._random = np.random.random
+        self._randn = np.random.randn
+
+    def random(self, size=None):
+        r = self._random(size)
+        if self.enabled:
+            shape = tuple(np.shape(r))
+            self.kinds.append(0)
+            self.shapes.append(shape)
+            self.data.append(np.asarray(r, dtype=np.float64).ravel().copy())
+        return r
+
+    def randn(self, *shape):
+        r = self._randn(*shape)
+        if self.enabled:
+            self.kinds.append(1)
+            self.shapes.append(tuple(np.shape(r)))
+            self.data.append(np.asarray(r, dtype=np.float64).ravel().copy())
+        return r
+
+    def __enter__(self):
+        np.random.random = self.random
+        return self
+
+    def __exit__(self, *a):
+        np.random.random = self._random
+
+    def arrays(self):
+        shp = -np.ones((len(self.shapes), 2), dtype=np.int64)
+        for i, s in enumerate(self.shapes):
+            shp[i, :len(s)] = s
+        data = np.concatenate(self.data) if self.data else np.zeros(0)
+        return dict(draw_kinds=np.array(self.kinds, dtype=np.int8), draw_shapes=shp, draw_data=data)
+
+
+def run_trajectory(name, model, prior, n_particles, expparams, outcomes_fn, seed=0,
+                   batch_interval=None, **lw_kwargs):
+    """Run reference SMCUpdater over a schedule, recording draws and the per-datum state."""
+    np.random.seed(seed)
+    rec = Recorder()
+    means, covs, esss, rcs, norms = [], [], [], [], []
+    outcomes = []
+    with rec, warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        resampler = qinfer.LiuWestResampler(kernel=rec.randn, default_n_particles=n_particles,
+                                            **lw_kwargs)
+        upd = qinfer.SMCUpdater(model, n_particles, prior, resampler=resampler)
+        x0 = upd.particle_locations.copy()
+        n_prior_draws = len(rec.kinds)
+        for k in range(expparams.shape[0]):
+            ep = expparams[k:k + 1]
+            rec.enabled = False
+            o = outcomes_fn(k, ep)
+            rec.enabled = True
+            outcomes.append(o)
+            if batch_interval is None:
+                upd.update(o, ep)
+            else:
+                upd.update(o, ep, check_for_resample=False)
+                if (k + 1) % batch_interval == 0:
+                    upd._maybe_resample()
+            means.append(upd.est_mean())
+            covs.append(upd.est_covariance_mtx())
+            esss.append(upd.n_ess)
+            rcs.append(upd.resample_count)
+            norms.append(upd.normalization_record[-1])
+    out = dict(seed=seed, n_particles=n_particles, x0=x0, outcomes=np.array(outcomes),
+               means=np.array(means), covs=np.array(covs), n_ess=np.array(esss),
+               resample_count=np.array(rcs), norms=np.array(norms),
+               final_locs=upd.particle_locations, final_weights=upd.particle_weights,
+               min_n_ess=upd.min_n_ess, n_prior_draws=n_prior_draws, **rec.arrays())
+    for fname in (expparams.dtype.names or ()):
+        out["ep_" + fname] = expparams[fname]
+    if expparams.dtype.names is None:
+        out["ep_t"] = expparams
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("%-28s resamples=%d mean=%s size=%.0f KB" % (
+        name, upd.resample_count, np.array2string(upd.est_mean()[:3], precision=8),
+        os.path.getsize(path) / 1024))
+
+
+# ------------------------------------------------------------------------------------------
+def g1_precession():
+    m = qinfer.SimplePrecessionModel()
+    true = np.array([[0.3]])
+    ts = (9 / 8) ** np.arange(200.0)
+    sim = lambda k, ep: m.simulate_experiment(true, ep)
+    for n in (1000, 256):
+        run_trajectory("g1_precession_n%d" % n, m, qinfer.UniformDistribution([0, 1]), n, ts, sim)
+    # batch_update semantics (ESS check every 5 data), smc.py:484-487
+    run_trajectory("g1_precession_batch5", m, qinfer.UniformDistribution([0, 1]), 512, ts[:100],
+                   sim, batch_interval=5, seed=3)
+
+
+def g1_binomial():
+    m = qinfer.BinomialModel(qinfer.SimplePrecessionModel())
+    true = np.array([[0.3]])
+    ep = np.empty((60,), dtype=m.expparams_dtype)
+    ep['x'] = (9 / 8) ** np.arange(60.0)
+    ep['n_meas'] = 25
+    sim = lambda k, e: int(np.random.binomial(25, np.sin(0.3 * e['x'][0] / 2) ** 2))
+    run_trajectory("g1_binomial_n1000", m, qinfer.UniformDistribution([0, 1]), 1000, ep, sim)
+
+
+def g1_rb():
+    m = qinfer.RandomizedBenchmarkingModel()
+    prior = qinfer.PostselectedDistribution(
+        qinfer.UniformDistribution([[0.8, 1], [0, 1], [0, 1]]), m)
+    true = np.array([[0.95, 0.3, 0.5]])
+    ep = np.empty((100,), dtype=m.expparams_dtype)
+    ep['m'] = 1 + 5 * np.arange(100)
+    sim = lambda k, e: m.simulate_experiment(true, e)
+    run_trajectory("g1_rb_n2000", m, prior, 2000, ep, sim)
+
+
+class FixedPrior(qinfer.Distribution):
+    def __init__(self, samples):
+        self._s = samples
+
+    @property
+    def n_rvs(self):
+        return self._s.shape[1]
+
+    def sample(self, n=1):
+        assert n == self._s.shape[0]
+        return self._s.copy()
+
+
+def g1_tomography():
+    basis = pauli_basis(2)
+    m = TomographyModel(basis)
+    rng = np.random.RandomState(7)
+    x0 = orc.ginibre_prior_sample(300, basis.data, rng)
+    true = orc.ginibre_prior_sample(1, basis.data, rng)
+    ep = np.zeros((40,), dtype=m.expparams_dtype)
+    paulis = rng.randint(1, 16, size=40)
+    # In the orthonormal Pauli basis B_a = P_a / 2 the projector (I + P)/2 = B_0 + B_p, so its
+    # coefficient vector is e_0 + e_p (RandomPauliHeuristic, tomography/expdesign.py:134-160).
+    for k, p in enumerate(paulis):
+        ep['meas'][k, 0] = 1.0
+        ep['meas'][k, p] = 1.0
+    sim = lambda k, e: m.simulate_experiment(true, e)
+    run_trajectory("g1_tomography_n300", m, FixedPrior(x0), 300, ep, sim)
+
+
+# ------------------------------------------------------------------------------------------
+def g2_likelihoods():
+    out = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        # precession
+        m = qinfer.SimplePrecessionModel()
+        omega = np.concatenate([np.linspace(0, 1, 257), [1e-300, 0.3, 0.29999981]])[:, None]
+        ts = (9 / 8) ** np.array([0.0, 50, 100, 150, 199])
+        out['prec_x'], out['prec_t'] = omega, ts
+        out['prec_L'] = m.likelihood(np.array([0, 1]), omega, ts)
+        # binomial
+        bm = qinfer.BinomialModel(m)
+        ep = np.empty((3,), dtype=bm.expparams_dtype)
+        ep['x'] = [1.0, (9 / 8) ** 30, (9 / 8) ** 120]
+        ep['n_meas'] = [25, 25, 7]
+        out['bin_x'], out['bin_t'], out['bin_n'] = omega, ep['x'], ep['n_meas']
+        out['bin_L'] = bm.likelihood(np.arange(26), omega, ep)
+        # RB
+        rb = qinfer.RandomizedBenchmarkingModel()
+        g = np.array([0.0, 0.35, 0.9, 1.0])
+        P, A, B = np.meshgrid(np.array([0.0, 0.8, 0.95, 0.999, 1.0]), g, g, indexing='ij')
+        x = np.stack([P.ravel(), A.ravel(), B.ravel()], axis=1)
+        ep = np.empty((5,), dtype=rb.expparams_dtype)
+        ep['m'] = [0, 1, 10, 800, 100000]
+        out['rb_x'], out['rb_m'] = x, ep['m']
+        out['rb_L'] = rb.likelihood(np.array([0, 1]), x, ep)
+        out['rb_valid'] = rb.are_models_valid(x + np.array([0, 0.02, -0.01]))
+        out['rb_valid_x'] = x + np.array([0, 0.02, -0.01])
+        rbi = qinfer.RandomizedBenchmarkingModel(interleaved=True)
+        rs = np.random.RandomState(5)
+        xi = rs.uniform(0, 1.1, size=(64, 4))
+        ep = np.empty((4,), dtype=rbi.expparams_dtype)
+        ep['m'] = [1, 7, 50, 400]
+        ep['reference'] = [True, False, True, False]
+        out['rbi_x'], out['rbi_m'], out['rbi_ref'] = xi, ep['m'], ep['reference']
+        out['rbi_L'] = rbi.likelihood(np.array([0, 1]), xi, ep)
+        out['rbi_valid'] = rbi.are_models_valid(xi)
+        # tomography
+        basis = pauli_basis(2)
+        tm = TomographyModel(basis)
+        rs = np.random.RandomState(11)
+        xt = orc.ginibre_prior_sample(64, basis.data, rs)
+        xt[::7] *= 1.3                               # some unphysical ones: exercises the clip
+        ep = np.zeros((15,), dtype=tm.expparams_dtype)
+        for p in range(1, 16):
+            ep['meas'][p - 1, 0] = 1.0
+            ep['meas'][p - 1, p] = 1.0
+        out['tomo_x'], out['tomo_meas'] = xt, ep['meas']
+        out['tomo_L'] = tm.likelihood(np.array([0, 1]), xt, ep)
+        out['pauli2_basis'] = basis.data
+        out['gell_mann3_basis'] = qinfer.tomography.gell_mann_basis(3).data
+    np.savez_compressed(os.path.join(OUT, "g2_likelihoods.npz"), **out)
+    print("g2_likelihoods")
+
+
+def g3_moments():
+    out = {}
+    rs = np.random.RandomState(21)
+    cases = []
+    for d, n in [(1, 1), (1, 7), (1, 1000), (1, 65537), (3, 1), (3, 7), (3, 1000), (3, 20011),
+                 (16, 1), (16, 7), (16, 1000), (16, 4099)]:
+        if True:
+            x = rs.randn(n, d) * rs.uniform(0.1, 2, size=d) + rs.uniform(-1, 1, size=d)
+            w = rs.random_sample(n) ** 3
+            w /= w.sum()
+            cases.append(("d%d_n%d" % (d, n), w, x))
+    x = 0.3 + 2e-6 * rs.randn(5000, 1)
+    w = np.ones(5000) / 5000
+    cases.append(("tight", w, x))
+    cases.append(("zerocov", np.ones(16) / 16, np.full((16, 2), 0.25)))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for tag, w, x in cases:
+            pd = qinfer.ParticleDistribution(particle_locations=x, particle_weights=w)
+            out[tag + "_w"], out[tag + "_x"] = pd.particle_weights, x
+            out[tag + "_mean"] = pd.est_mean()
+            cov = pd.est_covariance_mtx()
+            out[tag + "_cov"] = cov
+            out[tag + "_ess"] = pd.n_ess
+            S, err = qinfer.utils.sqrtm_psd(cov)
+            out[tag + "_sqrt"], out[tag + "_sqrt_err"] = S, err
+    out['tags'] = np.array([c[0] for c in cases])
+    np.savez_compressed(os.path.join(OUT, "g3_moments.npz"), **out)
+    print("g3_moments")
+
+
+def g4_liu_west():
+    """Single LiuWestResampler calls incl. Q1 (forced invalid particles) and n_particles != N."""
+    out = {}
+    tags = []
+
+    def one(tag, model, w, x, seed, n_particles=None, **kw):
+        np.random.seed(seed)
+        rec = Recorder()
+        with rec, warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            res = qinfer.LiuWestResampler(kernel=rec.randn, **kw)
+            pd = qinfer.ParticleDistribution(particle_locations=x, particle_weights=w)
+            new = res(model, pd, n_particles=n_particles)
+        out[tag + "_w"], out[tag + "_x"] = pd.particle_weights, x
+        out[tag + "_new"] = new.particle_locations
+        for k, v in rec.arrays().items():
+            out[tag + "_" + k] = v
+        out[tag + "_a"] = kw.get('a', 0.98)
+        out[tag + "_h"] = kw.get('h', np.nan) if kw.get('h') is not None else np.nan
+        out[tag + "_n_out"] = new.particle_locations.shape[0]
+        tags.append(tag)
+
+    rs = np.random.RandomState(31)
+    prec = qinfer.SimplePrecessionModel()
+    # Q1: 8 particles near zero so several land invalid (SURVEY Appendix B example, seed 1)
+    x = np.abs(rs.randn(8, 1)) * 0.3
+    w = rs.random_sample(8)
+    one("q1_small", prec, w, x, seed=1, a=0.9)
+    x = np.abs(0.05 + 0.05 * rs.randn(2000, 1))
+    w = rs.random_sample(2000) ** 2
+    one("prec_d1", prec, w, x, seed=2)
+    one("prec_d1_grow", prec, w, x, seed=3, n_particles=3000)
+    one("prec_d1_a1", prec, w, x, seed=4, a=1.0, h=0.005)
+    rb = qinfer.RandomizedBenchmarkingModel()
+    x = np.stack([rs.uniform(0.9, 1, 1500), rs.uniform(0.2, 0.5, 1500), rs.uniform(0.4, 0.6, 1500)], 1)
+    w = rs.random_sample(1500)
+    one("rb_d3", rb, w, x, seed=5, a=0.9)
+    basis = pauli_basis(2)
+    tm = TomographyModel(basis)
+    x = orc.ginibre_prior_sample(400, basis.data, rs)
+    w = rs.random_sample(400)
+    one("tomo_d16", tm, w, x, seed=6)
+    out['tags'] = np.array(tags)
+    np.savez_compressed(os.path.join(OUT, "g4_liu_west.npz"), **out)
+    print("g4_liu_west", tags)
+
+
+def g5_canonicalize():
+    basis = pauli_basis(2)
+    tm = TomographyModel(basis)
+    rs = np.random.RandomState(41)
+    x = orc.ginibre_prior_sample(256, basis.data, rs)
+    x[:, 1:] += 0.15 * rs.randn(256, 15)          # many become non-PSD
+    x[:, 0] = 0.5 + 0.01 * rs.randn(256)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        y = tm.canonicalize(x.copy())
+        tm2 = TomographyModel(basis, allow_subnormalized=True)
+        y2 = tm2.canonicalize(x.copy())
+    np.savez_compressed(os.path.join(OUT, "g5_canonicalize.npz"), x=x, y=y, y_subnorm=y2,
+                        basis=basis.data)
+    print("g5_canonicalize")
+
+
+def g6_guards():
+    """Mirrors tests/test_smc.py:98-137 on a DecimationModel-style likelihood (0.5 / 0 step)."""
+    out = {}
+
+    class Decimation(qinfer.FiniteOutcomeModel):
+        n_modelparams = 1
+        expparams_dtype = [('alpha', float)]
+        is_n_outcomes_constant = True
+
+        def n_outcomes(self, e):
+            return 2
+
+        def are_models_valid(self, mp):
+            return np.ones(mp.shape[0], dtype=bool)
+
+        def likelihood(self, outcomes, mp, ep):
+            pr0 = np.ones((mp.shape[0], 1)) / 2
+            pr0[int(np.ceil(ep['alpha'][0] * mp.shape[0])):, :] = 0
+            return qinfer.FiniteOutcomeModel.pr0_to_likelihood_array(outcomes, pr0)
+
+    np.random.seed(0)
+    n_updates = 6
+    N = 4 ** n_updates
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        upd = qinfer.SMCUpdater(Decimation(), N, qinfer.UniformDistribution([0, 1]),
+                                resample_thresh=0.0)
+        ep = np.empty((1,), dtype=[('alpha', float)])
+        mins, esss = [], []
+        for k in range(n_updates):
+            ep['alpha'][0] = 4.0 ** -(k + 1)
+            upd.update(np.array([0]), ep)
+            mins.append(upd.min_n_ess)
+            esss.append(upd.n_ess)
+    out['min_n_ess'], out['n_ess'], out['N'] = np.array(mins), np.array(esss), N
+    np.savez_compressed(os.path.join(OUT, "g6_guards.npz"), **out)
+    print("g6_guards", mins)
+
+
+if __name__ == "__main__":
+    g1_precession()
+    g1_binomial()
+    g1_rb()
+    g1_tomography()
+    g2_likelihoods()
+    g3_moments()
+    g4_liu_west()
+    g5_canonicalize()
+    g6_guards()
+    print("total bytes:", sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT)))

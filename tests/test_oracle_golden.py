@@ -1,0 +1,244 @@
+"""Pins the CPU oracle (oracle/np_oracle.py) against golden vectors produced by running the
+reference itself (oracle/gen_golden.py): likelihood KATs (G2), moments (G3), Liu-West incl.
+quirk Q1 (G4), tomography canonicalize (G5), guards (G6) and full seeded trajectories (G1)."""
+import warnings
+
+import numpy as np
+import pytest
+
+import np_oracle as orc
+import parity_tols as tol
+
+
+def _replay(g, prefix=""):
+    return orc.ReplayRNG(g[prefix + "draw_kinds"], g[prefix + "draw_shapes"], g[prefix + "draw_data"])
+
+
+# ------------------------------------------------------------------ G2
+def test_g2_precession(golden):
+    g = golden("g2_likelihoods")
+    L = orc.lik_precession([0, 1], g["prec_x"], g["prec_t"])
+    np.testing.assert_array_equal(L, g["prec_L"])      # same NumPy cos on the same machine class
+
+
+def test_g2_binomial(golden):
+    g = golden("g2_likelihoods")
+    L = orc.lik_binomial_precession(np.arange(26), g["bin_x"], g["bin_t"], g["bin_n"])
+    ref = g["bin_L"]
+    # closed form vs SciPy/Boost: rtol 1e-12 with an absolute floor for denormal-range values
+    np.testing.assert_allclose(L, ref, rtol=1e-12, atol=1e-300)
+
+
+def test_g2_rb(golden):
+    g = golden("g2_likelihoods")
+    np.testing.assert_array_equal(orc.lik_rb([0, 1], g["rb_x"], g["rb_m"]), g["rb_L"])
+    np.testing.assert_array_equal(orc.valid_rb(g["rb_valid_x"]), g["rb_valid"])
+    np.testing.assert_array_equal(orc.lik_rb([0, 1], g["rbi_x"], g["rbi_m"], g["rbi_ref"]), g["rbi_L"])
+    np.testing.assert_array_equal(orc.valid_rb(g["rbi_x"]), g["rbi_valid"])
+
+
+def test_g2_tomography_and_bases(golden):
+    g = golden("g2_likelihoods")
+    np.testing.assert_allclose(orc.pauli_data(2), g["pauli2_basis"], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(orc.gell_mann_data(3), g["gell_mann3_basis"], rtol=0, atol=1e-15)
+    L = orc.lik_tomography([0, 1], g["tomo_x"], g["tomo_meas"])
+    np.testing.assert_allclose(L, g["tomo_L"], rtol=0, atol=4e-16)
+
+
+# ------------------------------------------------------------------ G3
+def test_g3_moments(golden):
+    g = golden("g3_moments")
+    for tag in g["tags"]:
+        w, x = g[tag + "_w"], g[tag + "_x"]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            mean, cov = orc.particle_mean(w, x), orc.particle_cov(w, x)
+        scale = np.abs(mean).max() ** 2 + np.einsum('i,ij->', w, x * x)
+        np.testing.assert_allclose(mean, g[tag + "_mean"], rtol=1e-14, atol=1e-16)
+        np.testing.assert_allclose(cov, g[tag + "_cov"], rtol=0, atol=8 * orc.EPS * scale)
+        np.testing.assert_allclose(orc.n_ess(w), g[tag + "_ess"], rtol=1e-14)
+        S, err = orc.sqrtm_psd(cov)
+        np.testing.assert_allclose(S, g[tag + "_sqrt"], rtol=1e-12, atol=1e-15)
+        assert abs(err - g[tag + "_sqrt_err"]) <= 1e-12 * max(1.0, abs(err))
+
+
+# ------------------------------------------------------------------ G4
+def _model_for(tag, g):
+    if tag.startswith("rb"):
+        return orc.valid_rb
+    if tag.startswith("tomo"):
+        return lambda x: np.ones(x.shape[0], dtype=bool)
+    return orc.valid_precession
+
+
+def test_g4_liu_west(golden):
+    g = golden("g4_liu_west")
+    for tag in g["tags"]:
+        rng = _replay(g, tag + "_")
+        h = g[tag + "_h"]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            new, w = orc.liu_west(g[tag + "_w"], g[tag + "_x"], _model_for(tag, g), rng,
+                                  a=float(g[tag + "_a"]), h=None if np.isnan(h) else float(h),
+                                  n_out=int(g[tag + "_n_out"]))
+        assert rng.exhausted, tag
+        np.testing.assert_allclose(new, g[tag + "_new"], rtol=1e-13, atol=1e-15, err_msg=tag)
+
+
+def test_g4_q1_quirk_is_exercised(golden):
+    """The fixed (non-legacy) redraw centres give a different answer on the Q1 fixture."""
+    g = golden("g4_liu_west")
+    tag = "q1_small"
+    rng = _replay(g, tag + "_")
+    n_rounds = int(np.sum(g[tag + "_draw_kinds"] == 1))
+    assert n_rounds >= 2, "fixture must contain at least one redraw round"
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        new, _ = orc.liu_west(g[tag + "_w"], g[tag + "_x"], orc.valid_precession, rng,
+                              a=float(g[tag + "_a"]), legacy_mus_truncation=False)
+    assert not np.allclose(new, g[tag + "_new"])
+
+
+# ------------------------------------------------------------------ G5
+def test_g5_canonicalize(golden):
+    g = golden("g5_canonicalize")
+    y = orc.tomo_canonicalize(g["x"], g["basis"])
+    np.testing.assert_allclose(y, g["y"], rtol=0, atol=1e-13)
+    y2 = orc.tomo_canonicalize(g["x"], g["basis"], allow_subnormalized=True)
+    np.testing.assert_allclose(y2, g["y_subnorm"], rtol=0, atol=1e-13)
+
+
+# ------------------------------------------------------------------ G1 trajectories
+def _traj(g, model, ep_of, cond, batch=None):
+    rng = _replay(g)
+    n = int(g["n_particles"])
+    x0 = g["x0"]
+    def prior(nn):
+        # the reference's prior draws are the first n_prior_draws entries of the log
+        for _ in range(int(g["n_prior_draws"])):
+            (rng.random if rng.kinds[rng.pos] == 0 else rng.randn)(*([rng.shapes[rng.pos]] if rng.kinds[rng.pos] == 0 else rng.shapes[rng.pos]))
+        return x0
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        smc = orc.OracleSMC(model, n, prior, rng=rng, canonicalize=False)
+        smc.x[:, :] = x0
+        K = len(g["outcomes"])
+        checked = -1
+        for k in range(K):
+            if not tol.well_conditioned(float(cond(k))):
+                break               # see parity_tols.HORIZON_RTOL: compare only while well conditioned
+            o = g["outcomes"][k]
+            if batch is None:
+                smc.update(o, ep_of(k))
+            else:
+                smc.update(o, ep_of(k), check_for_resample=False)
+                if (k + 1) % batch == 0:
+                    smc._maybe_resample()
+            c = float(cond(k))
+            checked = k
+            assert smc.resample_count == g["resample_count"][k], "datum %d" % k
+            np.testing.assert_allclose(smc.normalization_record[-1], g["norms"][k],
+                                       rtol=tol.rtol_norm(c), err_msg="datum %d" % k)
+            np.testing.assert_allclose(smc.n_ess, g["n_ess"][k], rtol=tol.rtol_ess(c))
+            np.testing.assert_allclose(smc.est_mean(), g["means"][k], rtol=0,
+                                       atol=tol.atol_mean(g["means"][k]))
+    assert checked >= min(K - 1, 60), "horizon too short to be a meaningful check"
+    if checked == K - 1:
+        assert rng.exhausted
+        np.testing.assert_allclose(smc.x, g["final_locs"], rtol=1e-9, atol=1e-13)
+    return smc
+
+
+@pytest.mark.parametrize("name", ["g1_precession_n1000", "g1_precession_n256"])
+def test_g1_precession(golden, name):
+    g = golden(name)
+    _traj(g, orc.precession_model(), lambda k: {"t": g["ep_t"][k:k + 1]}, lambda k: g["ep_t"][k])
+
+
+def test_g1_precession_batch5(golden):
+    g = golden("g1_precession_batch5")
+    _traj(g, orc.precession_model(), lambda k: {"t": g["ep_t"][k:k + 1]}, lambda k: g["ep_t"][k],
+          batch=5)
+
+
+def test_g1_binomial(golden):
+    g = golden("g1_binomial_n1000")
+    _traj(g, orc.binomial_precession_model(),
+          lambda k: {"t": g["ep_x"][k:k + 1], "n_meas": g["ep_n_meas"][k:k + 1]},
+          lambda k: 25 * g["ep_x"][k])
+
+
+def test_g1_rb(golden):
+    g = golden("g1_rb_n2000")
+    _traj(g, orc.rb_model(), lambda k: {"m": g["ep_m"][k:k + 1]}, lambda k: g["ep_m"][k])
+
+
+def test_g1_tomography(golden):
+    g = golden("g1_tomography_n300")
+    basis = orc.pauli_data(2)
+    model = orc.tomography_model(basis)
+    rng = _replay(g)
+    n = int(g["n_particles"])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        smc = orc.OracleSMC(model, n, lambda nn: g["x0"], rng=rng, canonicalize=True)
+        np.testing.assert_allclose(smc.x, g["x0"], atol=1e-13)
+        for k in range(len(g["outcomes"])):
+            smc.update(g["outcomes"][k], {"meas": g["ep_meas"][k:k + 1]})
+            assert smc.resample_count == g["resample_count"][k]
+            at = tol.atol_sqrtm_psd(g["covs"][k])
+            np.testing.assert_allclose(smc.est_mean(), g["means"][k], rtol=0, atol=at)
+    np.testing.assert_allclose(smc.x, g["final_locs"], rtol=0, atol=10 * at)
+
+
+# ------------------------------------------------------------------ G6
+def test_g6_min_ness(golden):
+    g = golden("g6_guards")
+    N = int(g["N"])
+    dec = orc.OracleModel("decimation", 1, None, lambda x: np.ones(x.shape[0], dtype=bool))
+
+    def lik(o, x, e):
+        pr0 = np.ones((x.shape[0], 1)) / 2
+        pr0[int(np.ceil(e["alpha"][0] * x.shape[0])):, :] = 0
+        return orc._two_outcome(o, pr0)
+    dec.lik = lik
+    np.random.seed(0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        smc = orc.OracleSMC(dec, N, lambda n: np.random.random((n, 1)), resample_thresh=0.0)
+        for k in range(6):
+            smc.update(0, {"alpha": np.array([4.0 ** -(k + 1)])})
+            assert smc.min_n_ess == g["min_n_ess"][k]
+            assert smc.n_ess == g["n_ess"][k]
+
+
+def test_guards_zero_weight_policies():
+    """smc.py:423-436 policy table on an impossible datum."""
+    impossible = orc.OracleModel("imp", 1, lambda o, x, e: np.zeros((1, x.shape[0], 1)),
+                                 lambda x: np.ones(x.shape[0], dtype=bool))
+    mk = lambda pol: orc.OracleSMC(impossible, 16, lambda n: np.zeros((n, 1)), zero_weight_policy=pol)
+    with pytest.raises(RuntimeError):
+        mk("error").update(0, {})
+    s = mk("skip")
+    s.update(0, {})
+    assert np.all(s.w == 1 / 16) and s.normalization_record == []
+    with pytest.warns(orc.ApproximationWarning):
+        mk("warn").update(0, {})
+    with pytest.raises(ValueError):
+        mk("bogus").update(0, {})
+
+
+def test_c1_statistical_full_run():
+    """Config C1 end to end on the oracle with the legacy global RNG (tests/test_precession_model.py
+    style acceptance: mean to 2 decimals, small covariance)."""
+    np.random.seed(0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        smc = orc.OracleSMC(orc.precession_model(), 1000, lambda n: np.random.random((n, 1)))
+        for k in range(200):
+            t = np.array([(9 / 8) ** k])
+            o = int(np.random.random() >= np.cos(0.3 * t[0] / 2) ** 2)
+            smc.update(o, {"t": t})
+    assert abs(smc.est_mean()[0] - 0.3) < 1e-5
+    assert smc.est_covariance_mtx()[0, 0] < 1e-9
+    assert 25 <= smc.resample_count <= 60
