@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""bench.py -- particle-updates/sec of the SMC hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE config 2 = SURVEY C2): SimplePrecessionModel, 1e7 particles PER GPU, fp64,
+LiuWestResampler(a=0.98), resample_thresh 0.5, prior U[0,1], true omega = 0.3, experiment
+schedule t_k = (9/8)^k (k = 0..199, wrapping with a prior reset), outcomes simulated once on the
+host from a fixed seed (they do not depend on N).  A "step" is one `SMCUpdater.update(outcome_k,
+t_k)` -- exactly what the reference's perf_test times (perf_testing.py:250-251) -- INCLUDING any
+resample it triggers.  The cloud is resident in HBM before the timed region; device RNG (Philox).
+
+One JSON line on rank 0 with `value` = N_total * K / wall, plus
+  roofline:     the fused update kernel's achieved algorithmic HBM bytes/s (24 B/particle: read x,
+                read w, write w) from HIP-event kernel durations measured inside the timed region;
+  cpu_baseline: the CPU oracle (NumPy restatement of the reference, oracle/np_oracle.py) timed
+                here on the host on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import warnings
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "python-qinfer_amd"))
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+BYTES_PER_PARTICLE_UPDATE = 24  # 16 + 8 d, d = 1
+N_SCHEDULE = 200
+
+
+def schedule():
+    ts = (9.0 / 8.0) ** np.arange(N_SCHEDULE, dtype=np.float64)
+    rs = np.random.RandomState(0)
+    pr0 = np.cos(0.3 * ts / 2) ** 2
+    outcomes = (rs.random_sample(N_SCHEDULE) >= pr0).astype(np.int64)
+    return ts, outcomes
+
+
+def cpu_baseline(n_particles, n_data):
+    """Time the oracle (kind 'port': NumPy restatement of the reference path) on this host."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import np_oracle as orc
+    ts, outcomes = schedule()
+    np.random.seed(0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        smc = orc.OracleSMC(orc.precession_model(), n_particles, lambda n: np.random.random((n, 1)))
+        t0 = time.perf_counter()
+        for k in range(n_data):
+            smc.update(int(outcomes[k]), {"t": ts[k:k + 1]})
+        wall = time.perf_counter() - t0
+    return {"value": n_particles * n_data / wall, "unit": "particle-updates/s", "cores": 1, "kind": "port",
+            "sample": "oracle/np_oracle.py OracleSMC, SimplePrecession, N=%d, first %d data of the same "
+                      "schedule (%d resamples), %.1f s wall, single-threaded NumPy" % (
+                          n_particles, n_data, smc.resample_count, wall)}
+
+
+def load_traffic():
+    """HBM bytes per launch of the update kernel from a committed rocprofv3 --pmc pass, if any."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(path):
+        try:
+            return json.load(open(path)).get("update_kernel_bytes_per_launch")
+        except Exception:  # noqa: BLE001
+            return None
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--particles", type=float, default=1e7, help="particles PER GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-particles", type=float, default=2e6)
+    ap.add_argument("--cpu-data", type=int, default=40)
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    comm = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        from qinfer_amd.parallel import ParticleShardGroup
+        comm = ParticleShardGroup()
+
+    import qinfer_amd as qi
+    from qinfer_amd.engine import get_engine
+    eng = get_engine()
+    n = int(args.particles)
+    ts, outcomes = schedule()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        upd = qi.SMCUpdater(qi.SimplePrecessionModel(), n, qi.UniformDistribution([0, 1]),
+                            device_rng=True, seed=0, comm=comm)
+        for k in range(args.warmup):                       # untimed: first W data of a throwaway pass
+            upd.update(int(outcomes[k % N_SCHEDULE]), ts[k % N_SCHEDULE:k % N_SCHEDULE + 1])
+        upd.reset()
+        upd._resample_count = 0
+        eng.set_profiling(True)
+        kernel_ms = []
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            k = i % N_SCHEDULE
+            if i and k == 0:
+                upd.reset()
+            upd.update(int(outcomes[k]), ts[k:k + 1])
+            kernel_ms.append(eng.last_update_kernel_ms())  # stream already synchronised by update()
+        barrier()
+        wall = time.perf_counter() - t0
+        eng.set_profiling(False)
+
+    wall_t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+    if world > 1:
+        torch.distributed.all_reduce(wall_t, op=torch.distributed.ReduceOp.MAX)
+    wall = float(wall_t.item())
+
+    if rank == 0:
+        n_total = n * world
+        avg_kernel_s = float(np.mean(kernel_ms)) * 1e-3
+        achieved = BYTES_PER_PARTICLE_UPDATE * n / avg_kernel_s / 1e9
+        line = {
+            "metric": "particle-updates/sec", "value": n_total * args.steps / wall,
+            "unit": "particle-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "SimplePrecessionModel SMCUpdater.update, %.0e particles/GPU, fp64, "
+                                   "Liu-West a=0.98, t_k=(9/8)^k" % n,
+                       "particles_per_gpu": n, "particles_total": n_total,
+                       "resamples_in_timed_region": upd.resample_count, "rng": "philox4x32-10 (device)",
+                       "parallelism": "particle-shard x%d" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(),
+                         "kernel": "k_update_fused<PRECESSION,2>", "avg_kernel_us": avg_kernel_s * 1e6,
+                         "algorithmic_bytes_per_launch": BYTES_PER_PARTICLE_UPDATE * n},
+            "posterior_mean": float(upd.est_mean()[0]),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(int(args.cpu_particles), args.cpu_data)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,206 @@
+/* qsmc.h -- C ABI of libqsmc_hip.so: the MI355X (gfx950) sequential-Monte-Carlo hot path.
+ *
+ * QInfer (the reference) is pure Python and has no FFI; the boundary this library sits behind is
+ * the Python class surface of SMCUpdater / LiuWestResampler / Model.
+ * Each entry point below names the reference code it replaces (paths relative to
+ * /root/reference/src/qinfer/).  INTEGRATION.md shows the ctypes stub a QInfer maintainer
+ * would add to bind them.
+ *
+ * Conventions
+ *  - every function returns 0 on success, <0 on error (qsmc_strerror); nothing throws;
+ *  - all particle buffers are CALLER-OWNED DEVICE memory, float64;
+ *  - particle locations are SoA: x[m * ldx + i] is parameter m of particle i (0 <= m < d);
+ *  - `stream` is a hipStream_t passed as void*; calls are asynchronous on it unless they return
+ *    host values (documented per function), in which case they synchronise that stream;
+ *  - weights are kept UNNORMALISED on the device: the true weight of particle i is
+ *    w[i] / norm, where norm is the running normaliser (sum of w) the caller carries as a host
+ *    double; this is QInfer's `hyp_weights / norm_scale` (smc.py:354-373) with the division
+ *    deferred to the next read, so no extra pass over HBM is spent on renormalising;
+ *  - no hidden global state: scratch lives in the opaque handle (one handle per device/stream).
+ */
+#ifndef QSMC_H
+#define QSMC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QSMC_ABI_VERSION 1
+#define QSMC_MAX_D 16            /* largest n_modelparams with a native kernel (2-qubit tomography) */
+
+typedef struct qsmc_ctx *qsmc_handle_t;
+typedef void *qsmc_stream_t;     /* hipStream_t */
+
+enum qsmc_status {
+    QSMC_OK = 0,
+    QSMC_ERR_INVALID = -1,       /* bad argument (null pointer, d out of range, unknown model kind) */
+    QSMC_ERR_HIP = -2,           /* a HIP runtime call failed; see qsmc_last_hip_error */
+    QSMC_ERR_ALLOC = -3,
+    QSMC_ERR_UNSUPPORTED = -4
+};
+
+/* Model kinds with a native likelihood kernel. */
+enum qsmc_model_kind {
+    QSMC_MODEL_PRECESSION = 1,          /* test_models.py:64-213  SimpleInversion/SimplePrecession  */
+    QSMC_MODEL_BINOMIAL_PRECESSION = 2, /* derived_models.py:222-360 BinomialModel(SimplePrecession) */
+    QSMC_MODEL_RB = 3,                  /* rb.py:81-195 RandomizedBenchmarkingModel()                */
+    QSMC_MODEL_RB_INTERLEAVED = 4,      /* rb.py:81-195 (interleaved=True)                           */
+    QSMC_MODEL_TOMOGRAPHY = 5           /* tomography/models.py:82-226 TomographyModel               */
+};
+
+typedef struct qsmc_model {
+    int32_t kind;                /* enum qsmc_model_kind */
+    int32_t d;                   /* n_modelparams */
+    double  min_freq;            /* precession validity: omega > min_freq (test_models.py:109-110) */
+    int32_t postselect_all_valid;/* 1: are_models_valid == True everywhere (tomography :143-147) */
+    int32_t reserved;
+} qsmc_model_t;
+
+/* One experiment (one row of the model's `expparams` record array). */
+typedef struct qsmc_expparam {
+    double   t;                  /* precession: evolution time (expparams['t'] / scalar)          */
+    double   w_;                 /* inversion model reference frequency (0 for SimplePrecession)   */
+    uint64_t n_meas;             /* binomial: expparams['n_meas']                                  */
+    uint64_t m;                  /* RB: sequence length expparams['m']                             */
+    int32_t  reference;          /* RB interleaved: expparams['reference']                         */
+    int32_t  reserved;
+    double   meas[QSMC_MAX_D];   /* tomography: expparams['meas'] (length d)                       */
+} qsmc_expparam_t;
+
+/* Per-update reduction results (all over the UNNORMALISED new weights w' = (w/norm) * L). */
+typedef struct qsmc_update_stats {
+    double sum;                  /* sum_i w'_i          == norm_scale of smc.py:357                */
+    double sumsq;                /* sum_i w'_i^2        -> n_ess = sum^2 / sumsq (distributions.py:307) */
+    double min;                  /* min_i w'_i          -> negative-weight guard smc.py:416-418    */
+    double n_bad;                /* #{i : !(w'_i >= 0)} (counts NaN too, like np.all(w >= 0))      */
+} qsmc_update_stats_t;
+
+/* ---- library ---------------------------------------------------------------------------- */
+int         qsmc_abi_version(void);
+const char *qsmc_strerror(int status);
+const char *qsmc_last_hip_error(qsmc_handle_t h);
+int         qsmc_create(qsmc_handle_t *out, int device);
+int         qsmc_destroy(qsmc_handle_t h);
+
+/* Kernel timing for bench.py's roofline line: when enabled, qsmc_update_fused brackets its main
+ * kernel (not the finalize/copy) with hipEvents on `stream`; after the stream has been
+ * synchronised qsmc_last_update_kernel_ms returns that kernel's duration in milliseconds. */
+int         qsmc_set_profiling(qsmc_handle_t h, int enabled);
+int         qsmc_last_update_kernel_ms(qsmc_handle_t h, float *ms_out);
+
+/* ---- likelihood, contract form (abstract_model.py:444-468 + :666-686; a6-a10) ------------ */
+/* L_out[(o * n_e + e) * n + i] = Pr(outcomes[o] | x_i ; exps[e]).  This is the
+ * (outcomes, experiments, particles) layout smc.py:353 transposes to.  `exps`/`outcomes` are HOST. */
+int qsmc_likelihood(qsmc_handle_t h, const qsmc_model_t *model,
+                    const double *x, int64_t ldx, int64_t n,
+                    const qsmc_expparam_t *exps, int32_t n_e,
+                    const int64_t *outcomes, int32_t n_o,
+                    double *L_out, qsmc_stream_t stream);
+
+/* Model.are_models_valid (test_models.py:109-110, rb.py:149-176, tomography/models.py:143-147). */
+int qsmc_are_models_valid(qsmc_handle_t h, const qsmc_model_t *model,
+                          const double *x, int64_t ldx, int64_t n,
+                          uint8_t *valid_out, qsmc_stream_t stream);
+
+/* ---- fused Bayes update (smc.py:388-457 = hypothetical_update :324-386 + n_ess; a1-a3) --- */
+/* w_out[i] = (w_in[i] / prev_norm) * Pr(outcome | x_i ; exp);  stats reduced in the same pass.
+ * w_out may alias w_in.  If stats_host != NULL the call synchronises `stream` and fills it;
+ * stats_dev (4 doubles, device) is always written and may be consumed by later async calls. */
+int qsmc_update_fused(qsmc_handle_t h, const qsmc_model_t *model,
+                      const double *x, int64_t ldx, int64_t n,
+                      const double *w_in, double *w_out, double prev_norm,
+                      const qsmc_expparam_t *exp, int64_t outcome,
+                      double *stats_dev, qsmc_update_stats_t *stats_host,
+                      qsmc_stream_t stream);
+
+/* Same update for a model without a native kernel: L[i] was produced by the user's
+ * Model.likelihood on the host and uploaded (plugin slow path). */
+int qsmc_update_from_likelihood(qsmc_handle_t h, const double *L, int64_t n,
+                                const double *w_in, double *w_out, double prev_norm,
+                                double *stats_dev, qsmc_update_stats_t *stats_host,
+                                qsmc_stream_t stream);
+
+/* Negative-weight guard (smc.py:416-418): w[i] = clip(w[i] / norm, 0, 1), stats recomputed. */
+int qsmc_clip_weights(qsmc_handle_t h, double *w, int64_t n, double norm,
+                      double *stats_dev, qsmc_update_stats_t *stats_host, qsmc_stream_t stream);
+
+/* Reduction only: stats of w / norm without writing (n_ess of an arbitrary cloud,
+ * distributions.py:299-307). */
+int qsmc_weight_stats(qsmc_handle_t h, const double *w, int64_t n, double norm,
+                      double *stats_dev, qsmc_update_stats_t *stats_host, qsmc_stream_t stream);
+
+/* Materialise normalised weights: w_out[i] = w_in[i] / norm (particle_weights property). */
+int qsmc_normalize_weights(qsmc_handle_t h, const double *w_in, double *w_out, int64_t n,
+                           double norm, qsmc_stream_t stream);
+
+/* w[i] = value (reset smc.py:307; resamplers.py:390). */
+int qsmc_fill(qsmc_handle_t h, double *w, int64_t n, double value, qsmc_stream_t stream);
+
+/* ---- weighted moments (distributions.py:337-399, utils.py:216-287; a11-a12) --------------- */
+/* out_host / out_dev: [ sum w~, sum w~ x_m (d), sum w~ x_m x_n for m <= n row-major (d(d+1)/2) ]
+ * with w~ = w / norm.  Synchronises if out_host != NULL. */
+int qsmc_moments(qsmc_handle_t h, const double *x, int64_t ldx, int64_t n, int32_t d,
+                 const double *w, double norm, double *out_dev, double *out_host,
+                 qsmc_stream_t stream);
+
+/* utils.py:593-607 sqrtm_psd on the HOST (d x d row-major): S = scale * V sqrt(max(lambda,0)) V^T,
+ * err = ||S S / scale^2 - A||_F.  Cyclic Jacobi; no device work. */
+int qsmc_sqrtm_psd(const double *A, int32_t d, double scale, double *S_out, double *err_out);
+
+/* ---- Liu-West resampling (resamplers.py:256-392; a15) ------------------------------------ */
+/* cdf[i] = sum_{j<=i} w[j]/norm   (np.cumsum, resamplers.py:308) */
+int qsmc_cumsum(qsmc_handle_t h, const double *w, int64_t n, double norm, double *cdf,
+                qsmc_stream_t stream);
+
+/* js[i] = min(#{j : cdf[j] <= u[i]}, n_in - 1)  (searchsorted side='right', :318-321, clamped as
+ * distributions.py:330-333 does; the reference raises IndexError on the unclamped overflow, Q2). */
+int qsmc_lw_ancestors(qsmc_handle_t h, const double *cdf, int64_t n_in,
+                      const double *u, int64_t n_out, int64_t *js, qsmc_stream_t stream);
+
+/* mus[m][i] = a * x_in[m][js[i]] + (1 - a) * mean[m]   (:325).  mean is HOST (d). */
+int qsmc_lw_centres(qsmc_handle_t h, const double *x_in, int64_t ldx_in, int32_t d,
+                    const int64_t *js, int64_t n_out, double a, const double *mean,
+                    double *mus, int64_t ld_mus, qsmc_stream_t stream);
+
+/* One postselection round (:327-372):  for r in [0, k):
+ *     dst = idxs ? idxs[r] : r
+ *     c   = centre_by_idx ? dst : r          (r = the reference's `mus[:k]` truncation, quirk Q1)
+ *     x_out[:, dst] = mus[:, c] + S @ z[:, r]        z is DEVICE [d][k] (param-major, :332)
+ *     valid_out[r]  = model.are_models_valid(x_out[:, dst])   (1 if !postselect)
+ * S is HOST d x d row-major (already scaled by h, :300). */
+int qsmc_lw_perturb(qsmc_handle_t h, const qsmc_model_t *model, int32_t postselect,
+                    const double *mus, int64_t ld_mus, const int64_t *idxs, int64_t k,
+                    int32_t centre_by_idx, const double *S, const double *z, int64_t ldz,
+                    double *x_out, int64_t ldx_out, uint8_t *valid_out, qsmc_stream_t stream);
+
+/* Device-RNG resample in ONE launch (Philox4x32-10, counter = (particle, epoch, round)):
+ * draw u -> ancestor -> centre -> Box-Muller z -> perturb -> validity; an invalid particle redraws
+ * (ancestor and z) in-thread up to maxiter times.  *n_failed_host = particles still invalid. */
+int qsmc_lw_resample_philox(qsmc_handle_t h, const qsmc_model_t *model, int32_t postselect,
+                            const double *x_in, int64_t ldx_in, int64_t n_in, int32_t d,
+                            const double *cdf, double a, const double *mean, const double *S,
+                            int64_t n_out, uint64_t seed, uint64_t epoch, int32_t maxiter,
+                            double *x_out, int64_t ldx_out, int64_t *n_failed_host,
+                            qsmc_stream_t stream);
+
+/* Device-RNG uniform-box prior (distributions.py:792-827 + :1304-1350 postselection):
+ * x[m][i] = lo[m] + U * (hi[m] - lo[m]), redrawn in-thread while invalid (<= maxiter). */
+int qsmc_prior_uniform_philox(qsmc_handle_t h, const qsmc_model_t *model, int32_t postselect,
+                              const double *lo, const double *hi, int32_t d, int64_t n,
+                              uint64_t seed, uint64_t epoch, int32_t maxiter,
+                              double *x_out, int64_t ldx_out, int64_t *n_failed_host,
+                              qsmc_stream_t stream);
+
+/* ---- tomography canonicalize (tomography/models.py:149-209; a10) -------------------------- */
+/* basis: DEVICE complex128 (d, dim, dim) row-major as interleaved (re, im), d = dim*dim, dim<=4.
+ * In place: clamp negative eigenvalues of rho(x), then x /= x_0 sqrt(dim) unless allow_subnormalized. */
+int qsmc_tomo_canonicalize(qsmc_handle_t h, const double *basis, int32_t dim,
+                           double *x, int64_t ldx, int64_t n, int32_t allow_subnormalized,
+                           qsmc_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QSMC_H */

@@ -1,0 +1,367 @@
+// qsmc_device.h -- device-side building blocks shared by the gfx950 kernels.
+//
+// Everything here is written for CDNA4: 64-lane wavefronts (hard-coded, never warpSize-agnostic),
+// 256-thread workgroups (4 waves, one per SIMD), float64 arithmetic with contraction OFF so that
+// products and sums round exactly like the NumPy expressions they replace.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/qsmc.h"
+
+#define QSMC_BLOCK 256
+#define QSMC_WAVE 64
+#define QSMC_WAVES_PER_BLOCK (QSMC_BLOCK / QSMC_WAVE)
+#define QSMC_GRID_CAP 2048            // 256 CUs x 8 resident 256-thread blocks
+
+namespace qsmc {
+
+// ---------------------------------------------------------------------------------------------
+// Experiment parameters as the kernels see them (by value in the kernarg segment -> SGPRs).
+// ---------------------------------------------------------------------------------------------
+struct ExpArgs {
+    double t, w_;            // precession
+    double n_meas;           // binomial: n as double
+    double comb;             // C(n_meas, k) rounded to double (inf -> use log_comb)
+    double log_comb;
+    double m;                // RB sequence length as double (NumPy: float64 ** uint64 -> pow(double))
+    int32_t reference;       // RB interleaved
+    int32_t d;
+    double meas[QSMC_MAX_D]; // tomography
+};
+
+// ---------------------------------------------------------------------------------------------
+// Likelihood of ONE outcome for one particle.  p[] holds the particle's d parameters.
+// Each follows the reference expression operation by operation (see qsmc.h for file:line).
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ double two_outcome(double pr0, int64_t outcome) {
+    // abstract_model.py:666-686: outcome 0 -> pr0, else 1 - pr0
+    return outcome == 0 ? pr0 : 1.0 - pr0;
+}
+
+__host__ __device__ __forceinline__ double precession_pr0(double omega, const ExpArgs &e) {
+    // test_models.py:134-141: cos(t * dw / 2) ** 2
+    const double dw = omega - e.w_;
+    const double c = cos(e.t * dw / 2.0);
+    return c * c;
+}
+
+template <int KIND> struct Model;
+
+template <> struct Model<QSMC_MODEL_PRECESSION> {
+    static constexpr int D = 1;
+    static __host__ __device__ __forceinline__ double lik(const double *p, const ExpArgs &e, int64_t o) {
+        return two_outcome(precession_pr0(p[0], e), o);
+    }
+    static __host__ __device__ __forceinline__ bool valid(const double *p, double min_freq) {
+        return p[0] > min_freq;
+    }
+};
+
+template <> struct Model<QSMC_MODEL_BINOMIAL_PRECESSION> {
+    static constexpr int D = 1;
+    static __host__ __device__ __forceinline__ double lik(const double *p, const ExpArgs &e, int64_t o) {
+        // derived_models.py:317-325: pr1 = L_underlying(outcome 1) = 1 - pr0;  Binom(n, pr1).pmf(k)
+        const double pr1 = 1.0 - precession_pr0(p[0], e);
+        const double k = (double)o;
+        if (o < 0 || k > e.n_meas) return 0.0;
+        if (isfinite(e.comb))
+            return e.comb * pow(pr1, k) * pow(1.0 - pr1, e.n_meas - k);
+        // huge n_meas: C(n,k) overflows float64 -> log space
+        const double lp = (k > 0.0 ? k * log(pr1) : 0.0) +
+                          (e.n_meas - k > 0.0 ? (e.n_meas - k) * log1p(-pr1) : 0.0);
+        return exp(e.log_comb + lp);
+    }
+    static __host__ __device__ __forceinline__ bool valid(const double *p, double min_freq) {
+        return p[0] > min_freq;
+    }
+};
+
+template <> struct Model<QSMC_MODEL_RB> {
+    static constexpr int D = 3;
+    static __host__ __device__ __forceinline__ double lik(const double *p, const ExpArgs &e, int64_t o) {
+        // rb.py:190-193: pr0 = 1 - (A * p**m + B)
+        const double pr0 = 1.0 - (p[1] * pow(p[0], e.m) + p[2]);
+        return two_outcome(pr0, o);
+    }
+    static __host__ __device__ __forceinline__ bool valid(const double *p, double) {
+        // rb.py:165-176
+        const double P = p[0], A = p[1], B = p[2];
+        return 0.0 <= P && P <= 1.0 && 0.0 <= A && A <= 1.0 && 0.0 <= B && B <= 1.0 &&
+               A + B <= 1.0 && A * P + B <= 1.0;
+    }
+};
+
+template <> struct Model<QSMC_MODEL_RB_INTERLEAVED> {
+    static constexpr int D = 4;
+    static __host__ __device__ __forceinline__ double lik(const double *p, const ExpArgs &e, int64_t o) {
+        // rb.py:181-186: p_C = p_tilde * p; p = where(reference, p, p_C)
+        const double pe = e.reference ? p[1] : p[0] * p[1];
+        const double pr0 = 1.0 - (p[2] * pow(pe, e.m) + p[3]);
+        return two_outcome(pr0, o);
+    }
+    static __host__ __device__ __forceinline__ bool valid(const double *p, double) {
+        // rb.py:150-163 (first column is named p_C there)
+        const double C = p[0], P = p[1], A = p[2], B = p[3];
+        return 0.0 <= P && P <= 1.0 && 0.0 <= C && C <= 1.0 && 0.0 <= A && A <= 1.0 &&
+               0.0 <= B && B <= 1.0 && A + B <= 1.0 && A * P + B <= 1.0 && A * C + B <= 1.0;
+    }
+};
+
+template <> struct Model<QSMC_MODEL_TOMOGRAPHY> {
+    static constexpr int D = QSMC_MAX_D;
+    static __host__ __device__ __forceinline__ double lik(const double *p, const ExpArgs &e, int64_t o) {
+        // tomography/models.py:216-226: pr1 = clip(sum_i meas_i x_i, 0, 1); pr0 = 1 - pr1
+        double s = 0.0;
+        for (int i = 0; i < e.d; ++i) s += e.meas[i] * p[i];
+        const double pr1 = fmin(fmax(s, 0.0), 1.0);
+        return two_outcome(1.0 - pr1, o);
+    }
+    static __host__ __device__ __forceinline__ bool valid(const double *, double) { return true; }
+};
+
+// Runtime-dispatched validity (used by kernels that are not templated on the model).
+__host__ __device__ __forceinline__ bool model_valid(int kind, const double *p, double min_freq) {
+    switch (kind) {
+        case QSMC_MODEL_PRECESSION:
+        case QSMC_MODEL_BINOMIAL_PRECESSION: return p[0] > min_freq;
+        case QSMC_MODEL_RB: return Model<QSMC_MODEL_RB>::valid(p, 0.0);
+        case QSMC_MODEL_RB_INTERLEAVED: return Model<QSMC_MODEL_RB_INTERLEAVED>::valid(p, 0.0);
+        default: return true;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Wave64 / workgroup reductions.  Deterministic: fixed shuffle tree, then wave 0..3 in order.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = QSMC_WAVE / 2; off > 0; off >>= 1) v += __shfl_down(v, off, QSMC_WAVE);
+    return v;
+}
+
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+    for (int off = QSMC_WAVE / 2; off > 0; off >>= 1) v = fmin(v, __shfl_down(v, off, QSMC_WAVE));
+    return v;
+}
+
+// Reduce K per-thread sums over the 256-thread block; thread 0 gets the totals in v[].
+// lds must hold QSMC_WAVES_PER_BLOCK * K doubles.
+template <int K>
+__device__ __forceinline__ void block_sum(double (&v)[K], double *lds) {
+    const int lane = threadIdx.x & (QSMC_WAVE - 1);
+    const int wave = threadIdx.x / QSMC_WAVE;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        v[k] = wave_sum(v[k]);
+        if (lane == 0) lds[wave * K + k] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            double s = lds[k];
+#pragma unroll
+            for (int wv = 1; wv < QSMC_WAVES_PER_BLOCK; ++wv) s += lds[wv * K + k];
+            v[k] = s;
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ double block_min(double v, double *lds) {
+    const int lane = threadIdx.x & (QSMC_WAVE - 1);
+    const int wave = threadIdx.x / QSMC_WAVE;
+    v = wave_min(v);
+    if (lane == 0) lds[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int wv = 1; wv < QSMC_WAVES_PER_BLOCK; ++wv) v = fmin(v, lds[wv]);
+    }
+    __syncthreads();
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 counter RNG (Salmon et al. 2011).  One call -> 128 bits -> two 53-bit uniforms.
+// Counter layout: (particle_lo, particle_hi, epoch * 2^16 + round, slot); key = seed.
+// ---------------------------------------------------------------------------------------------
+struct U4 { uint32_t x, y, z, w; };
+
+__host__ __device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) {
+    return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32);
+}
+
+__host__ __device__ __forceinline__ U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = mulhi32(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        const uint32_t hi1 = mulhi32(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        c = U4{hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0};
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c;
+}
+
+// NumPy's random_sample construction: (a >> 5) * 2^26 + (b >> 6)) / 2^53  in [0, 1)
+__host__ __device__ __forceinline__ double u53(uint32_t a, uint32_t b) {
+    return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) / 9007199254740992.0;
+}
+
+struct PhiloxStream {
+    uint64_t particle;
+    uint32_t epoch_round;     // (epoch << 16) | round  (epoch < 65536 per seed bump; host advances seed)
+    uint32_t k0, k1;
+    __device__ __forceinline__ void uniforms(uint32_t slot, double &u0, double &u1) const {
+        const U4 r = philox4x32_10(U4{(uint32_t)particle, (uint32_t)(particle >> 32), epoch_round, slot},
+                                   k0, k1);
+        u0 = u53(r.x, r.y);
+        u1 = u53(r.z, r.w);
+    }
+    // Box-Muller pair from one Philox block.
+    __device__ __forceinline__ void normals(uint32_t slot, double &z0, double &z1) const {
+        double u0, u1;
+        uniforms(slot, u0, u1);
+        const double r = sqrt(-2.0 * log(1.0 - u0));       // 1 - u0 in (0, 1]
+        double s, c;
+        sincospi(2.0 * u1, &s, &c);
+        z0 = r * c;
+        z1 = r * s;
+    }
+};
+
+
+// ---------------------------------------------------------------------------------------------
+// Tomography canonicalize for ONE particle (tomography/models.py:149-209): rho = sum_a p_a B_a,
+// complex-Hermitian cyclic Jacobi, clamp negative eigenvalues, re-expand, renormalise trace.
+// Returns true if p[] was modified.  basis: (D, DIM, DIM) complex128 interleaved (re, im).
+// ---------------------------------------------------------------------------------------------
+template <int DIM>
+__host__ __device__ inline bool tomo_canon_particle(const double *__restrict__ basis, double *p,
+                                                    bool allow_subnormalized) {
+    constexpr int D = DIM * DIM;
+    // rho = sum_a x_a B_a (Hermitian)
+    double Ar[DIM][DIM], Ai[DIM][DIM];
+#pragma unroll
+    for (int r = 0; r < DIM; ++r)
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) {
+            double sr = 0.0, si = 0.0;
+            for (int a = 0; a < D; ++a) {
+                sr += p[a] * basis[2 * ((a * DIM + r) * DIM + c)];
+                si += p[a] * basis[2 * ((a * DIM + r) * DIM + c) + 1];
+            }
+            Ar[r][c] = sr;
+            Ai[r][c] = si;
+        }
+    // keep the original for reconstruction scale; V = I
+    double Vr[DIM][DIM], Vi[DIM][DIM];
+#pragma unroll
+    for (int r = 0; r < DIM; ++r)
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) {
+            Vr[r][c] = (r == c) ? 1.0 : 0.0;
+            Vi[r][c] = 0.0;
+        }
+    // cyclic complex Jacobi sweeps
+    for (int sweep = 0; sweep < 12; ++sweep) {
+        double off = 0.0, diag2 = 0.0;
+#pragma unroll
+        for (int r = 0; r < DIM; ++r) diag2 += Ar[r][r] * Ar[r][r];
+#pragma unroll
+        for (int r = 0; r < DIM; ++r)
+#pragma unroll
+            for (int c = r + 1; c < DIM; ++c) off += Ar[r][c] * Ar[r][c] + Ai[r][c] * Ai[r][c];
+        if (off <= 1e-34 * diag2) break;
+#pragma unroll
+        for (int pI = 0; pI < DIM; ++pI)
+#pragma unroll
+            for (int q = pI + 1; q < DIM; ++q) {
+                const double hr = Ar[pI][q], hi = Ai[pI][q];
+                const double mag = sqrt(hr * hr + hi * hi);
+                if (mag < 1e-300) continue;
+                // phase e^{i phi} = h / |h|
+                const double er = hr / mag, ei = hi / mag;
+                const double app = Ar[pI][pI], aqq = Ar[q][q];
+                const double tau = (aqq - app) / (2.0 * mag);
+                const double tt = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                const double cs = 1.0 / sqrt(1.0 + tt * tt);
+                const double sn = tt * cs;
+                // Rotation: columns p,q of A and V:  col_p' = c col_p - s e^{-i phi} col_q ... applied as
+                // A <- J^H A J with J = [[c, s e^{i phi}], [-s e^{-i phi}, c]] on (p, q)
+                // update columns
+#pragma unroll
+                for (int r = 0; r < DIM; ++r) {
+                    const double apr = Ar[r][pI], api = Ai[r][pI], aqr = Ar[r][q], aqi = Ai[r][q];
+                    // col_p' = c*col_p - s*conj(e)*col_q ; col_q' = s*e*col_p + c*col_q
+                    Ar[r][pI] = cs * apr - sn * (er * aqr + ei * aqi);
+                    Ai[r][pI] = cs * api - sn * (er * aqi - ei * aqr);
+                    Ar[r][q] = sn * (er * apr - ei * api) + cs * aqr;
+                    Ai[r][q] = sn * (er * api + ei * apr) + cs * aqi;
+                    const double vpr = Vr[r][pI], vpi = Vi[r][pI], vqr = Vr[r][q], vqi = Vi[r][q];
+                    Vr[r][pI] = cs * vpr - sn * (er * vqr + ei * vqi);
+                    Vi[r][pI] = cs * vpi - sn * (er * vqi - ei * vqr);
+                    Vr[r][q] = sn * (er * vpr - ei * vpi) + cs * vqr;
+                    Vi[r][q] = sn * (er * vpi + ei * vpr) + cs * vqi;
+                }
+                // update rows: row_p' = c*row_p - s*e*row_q ; row_q' = s*conj(e)*row_p + c*row_q
+#pragma unroll
+                for (int c2 = 0; c2 < DIM; ++c2) {
+                    const double apr = Ar[pI][c2], api = Ai[pI][c2], aqr = Ar[q][c2], aqi = Ai[q][c2];
+                    Ar[pI][c2] = cs * apr - sn * (er * aqr - ei * aqi);
+                    Ai[pI][c2] = cs * api - sn * (er * aqi + ei * aqr);
+                    Ar[q][c2] = sn * (er * apr + ei * api) + cs * aqr;
+                    Ai[q][c2] = sn * (er * api - ei * apr) + cs * aqi;
+                }
+            }
+    }
+    bool any_neg = false;
+    double lam[DIM];
+#pragma unroll
+    for (int r = 0; r < DIM; ++r) {
+        lam[r] = Ar[r][r];
+        any_neg |= !(lam[r] >= 0.0);
+    }
+    if (any_neg) {                                        // tomography/models.py:185-192
+#pragma unroll
+        for (int r = 0; r < DIM; ++r) lam[r] = lam[r] < 0.0 ? 0.0 : lam[r];
+        // rho+ = V diag(lam) V^H ;  x_a = Re tr(B_a^H rho+) = Re sum_{rc} conj(B_a[r][c]) rho+[r][c]
+        double Rr[DIM][DIM], Ri[DIM][DIM];
+#pragma unroll
+        for (int r = 0; r < DIM; ++r)
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) {
+                double sr = 0.0, si = 0.0;
+#pragma unroll
+                for (int k = 0; k < DIM; ++k) {
+                    // V[r][k] * lam[k] * conj(V[c][k])
+                    sr += lam[k] * (Vr[r][k] * Vr[c][k] + Vi[r][k] * Vi[c][k]);
+                    si += lam[k] * (Vi[r][k] * Vr[c][k] - Vr[r][k] * Vi[c][k]);
+                }
+                Rr[r][c] = sr;
+                Ri[r][c] = si;
+            }
+        for (int a = 0; a < D; ++a) {
+            double s = 0.0;
+#pragma unroll
+            for (int r = 0; r < DIM; ++r)
+#pragma unroll
+                for (int c = 0; c < DIM; ++c)
+                    s += basis[2 * ((a * DIM + r) * DIM + c)] * Rr[r][c] +
+                         basis[2 * ((a * DIM + r) * DIM + c) + 1] * Ri[r][c];
+            p[a] = s;
+        }
+    }
+    if (!allow_subnormalized) {                           // :194-209
+        const double nrm = p[0] * sqrt((double)DIM);
+#pragma unroll
+        for (int a = 0; a < D; ++a) p[a] = p[a] / nrm;
+    }
+    return any_neg || !allow_subnormalized;
+}
+
+}  // namespace qsmc

@@ -1,0 +1,1117 @@
+// qsmc_kernels.hip -- gfx950 kernels + C ABI (include/qsmc.h) for the SMC hot path.
+//
+// All kernels are HBM-bound streaming passes (elementwise + reductions + one scan + one gather);
+// none is matmul-shaped at d <= 4, so there is no MFMA here.  Design points:
+//   * SoA particle layout -> every global access is a unit-stride wave-wide load/store;
+//   * two doubles (16 B) per lane per access where alignment allows (template VEC = 2);
+//   * reductions are two-level and deterministic: per-thread registers -> wave64 shuffle tree ->
+//     LDS across the 4 waves -> one partial per workgroup -> a one-workgroup finalize kernel that
+//     sums the partials in index order (bitwise reproducible for a given n);
+//   * weights stay unnormalised in HBM; the normaliser is a scalar folded into the next read.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "qsmc_device.h"
+
+using namespace qsmc;
+
+// =============================================================================================
+// context
+// =============================================================================================
+struct qsmc_ctx {
+    int device;
+    double *partials;      // device scratch for per-workgroup partial sums
+    size_t partials_cap;   // in doubles
+    double *scratch;       // device scratch (scan partials, small outputs)
+    size_t scratch_cap;
+    double *pinned;        // host pinned staging for small read-backs
+    size_t pinned_cap;
+    long long *counter;    // device int64 counter (failed-particle count)
+    int profiling;
+    hipEvent_t ev0, ev1;
+    int ev_valid;
+    char hip_err[256];
+};
+
+#define HIP_TRY(h, expr)                                                                        \
+    do {                                                                                        \
+        hipError_t e__ = (expr);                                                                \
+        if (e__ != hipSuccess) {                                                                \
+            if (h) snprintf((h)->hip_err, sizeof((h)->hip_err), "%s: %s", #expr,                \
+                            hipGetErrorString(e__));                                            \
+            return QSMC_ERR_HIP;                                                                \
+        }                                                                                       \
+    } while (0)
+
+static int ensure_partials(qsmc_ctx *h, size_t n) {
+    if (h->partials_cap >= n) return QSMC_OK;
+    if (h->partials) HIP_TRY(h, hipFree(h->partials));
+    h->partials = nullptr;
+    h->partials_cap = 0;
+    HIP_TRY(h, hipMalloc(&h->partials, n * sizeof(double)));
+    h->partials_cap = n;
+    return QSMC_OK;
+}
+
+static int ensure_scratch(qsmc_ctx *h, size_t n) {
+    if (h->scratch_cap >= n) return QSMC_OK;
+    if (h->scratch) HIP_TRY(h, hipFree(h->scratch));
+    h->scratch = nullptr;
+    h->scratch_cap = 0;
+    HIP_TRY(h, hipMalloc(&h->scratch, n * sizeof(double)));
+    h->scratch_cap = n;
+    return QSMC_OK;
+}
+
+static int ensure_pinned(qsmc_ctx *h, size_t n) {
+    if (h->pinned_cap >= n) return QSMC_OK;
+    if (h->pinned) HIP_TRY(h, hipHostFree(h->pinned));
+    h->pinned = nullptr;
+    h->pinned_cap = 0;
+    HIP_TRY(h, hipHostMalloc(&h->pinned, n * sizeof(double), hipHostMallocDefault));
+    h->pinned_cap = n;
+    return QSMC_OK;
+}
+
+// device -> host read-back of a few doubles; synchronises the stream
+static int read_back(qsmc_ctx *h, const double *dev, double *host, size_t n, hipStream_t s) {
+    int rc = ensure_pinned(h, n);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpyAsync(h->pinned, dev, n * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    memcpy(host, h->pinned, n * sizeof(double));
+    return QSMC_OK;
+}
+
+static inline int grid_for(int64_t n, int per_block) {
+    int64_t g = (n + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > QSMC_GRID_CAP) g = QSMC_GRID_CAP;
+    return (int)g;
+}
+
+static inline bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
+
+// =============================================================================================
+// fused Bayes update
+// =============================================================================================
+constexpr int UPD_UNROLL = 4;
+
+// Per-element body shared by the native-model and from-likelihood kernels.
+struct UpdAcc {
+    double sum = 0.0, sumsq = 0.0, mn = INFINITY, bad = 0.0;
+    __device__ __forceinline__ void add(double w) {
+        sum += w;
+        sumsq += w * w;
+        mn = fmin(mn, w);         // fmin drops NaN; `bad` records it
+        bad += (w >= 0.0) ? 0.0 : 1.0;
+    }
+};
+
+__device__ __forceinline__ void upd_finish(UpdAcc &a, double *partials) {
+    __shared__ double lds[QSMC_WAVES_PER_BLOCK * 3];
+    double v[3] = {a.sum, a.sumsq, a.bad};
+    block_sum<3>(v, lds);
+    const double mn = block_min(a.mn, lds);
+    if (threadIdx.x == 0) {
+        double *p = partials + 4 * (size_t)blockIdx.x;
+        p[0] = v[0];
+        p[1] = v[1];
+        p[2] = mn;
+        p[3] = v[2];
+    }
+}
+
+template <int KIND, int VEC>
+__global__ __launch_bounds__(QSMC_BLOCK) void k_update_fused(
+    const double *__restrict__ x, int64_t ldx, int64_t n, const double *__restrict__ w_in,
+    double *__restrict__ w_out, double prev_norm, ExpArgs e, int64_t outcome,
+    double *__restrict__ partials) {
+    constexpr int D = Model<KIND>::D;
+    const int d = (KIND == QSMC_MODEL_TOMOGRAPHY) ? e.d : D;
+    constexpr int64_t TILE = (int64_t)QSMC_BLOCK * VEC * UPD_UNROLL;
+    UpdAcc acc;
+    for (int64_t base = (int64_t)blockIdx.x * TILE; base < n; base += (int64_t)gridDim.x * TILE) {
+#pragma unroll
+        for (int u = 0; u < UPD_UNROLL; ++u) {
+            const int64_t i = base + ((int64_t)u * QSMC_BLOCK + threadIdx.x) * VEC;
+            if (VEC == 2) {
+                if (i + 1 < n) {
+                    const double2 wi = *reinterpret_cast<const double2 *>(w_in + i);
+                    double p0[D], p1[D];
+#pragma unroll
+                    for (int m = 0; m < D; ++m) {
+                        if (m < d) {
+                            const double2 xv = *reinterpret_cast<const double2 *>(x + m * ldx + i);
+                            p0[m] = xv.x;
+                            p1[m] = xv.y;
+                        }
+                    }
+                    double2 wo;
+                    wo.x = (wi.x / prev_norm) * Model<KIND>::lik(p0, e, outcome);
+                    wo.y = (wi.y / prev_norm) * Model<KIND>::lik(p1, e, outcome);
+                    *reinterpret_cast<double2 *>(w_out + i) = wo;
+                    acc.add(wo.x);
+                    acc.add(wo.y);
+                } else if (i < n) {
+                    double p0[D];
+#pragma unroll
+                    for (int m = 0; m < D; ++m)
+                        if (m < d) p0[m] = x[m * ldx + i];
+                    const double wo = (w_in[i] / prev_norm) * Model<KIND>::lik(p0, e, outcome);
+                    w_out[i] = wo;
+                    acc.add(wo);
+                }
+            } else {
+                if (i < n) {
+                    double p0[D];
+#pragma unroll
+                    for (int m = 0; m < D; ++m)
+                        if (m < d) p0[m] = x[m * ldx + i];
+                    const double wo = (w_in[i] / prev_norm) * Model<KIND>::lik(p0, e, outcome);
+                    w_out[i] = wo;
+                    acc.add(wo);
+                }
+            }
+        }
+    }
+    upd_finish(acc, partials);
+}
+
+// mode 0: w_out = (w_in / norm) * L   (generic-model slow path)
+// mode 1: w_out = clip(w_in / norm, 0, 1)   (negative-weight guard)
+// mode 2: w_out = w_in / norm               (materialise; stats still produced)
+// mode 3: stats of w_in / norm only (no store)
+template <int MODE>
+__global__ __launch_bounds__(QSMC_BLOCK) void k_weights_pass(const double *__restrict__ L, int64_t n,
+                                                             const double *__restrict__ w_in,
+                                                             double *__restrict__ w_out, double norm,
+                                                             double *__restrict__ partials) {
+    UpdAcc acc;
+    for (int64_t i = (int64_t)blockIdx.x * QSMC_BLOCK + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * QSMC_BLOCK) {
+        double w = w_in[i] / norm;
+        if (MODE == 0) w = w * L[i];
+        if (MODE == 1 && w == w) w = fmin(fmax(w, 0.0), 1.0);   // np.clip keeps NaN as NaN
+        if (MODE != 3) w_out[i] = w;
+        acc.add(w);
+    }
+    upd_finish(acc, partials);
+}
+
+// Sum the per-workgroup partials in index order.  layout: partials[g * 4 + {sum, sumsq, min, bad}]
+__global__ __launch_bounds__(QSMC_BLOCK) void k_update_finalize(const double *__restrict__ partials,
+                                                                int nblocks, double *__restrict__ stats) {
+    __shared__ double lds[QSMC_WAVES_PER_BLOCK * 3];
+    double v[3] = {0.0, 0.0, 0.0};
+    double mn = INFINITY;
+    for (int g = threadIdx.x; g < nblocks; g += QSMC_BLOCK) {
+        const double *p = partials + 4 * (size_t)g;
+        v[0] += p[0];
+        v[1] += p[1];
+        mn = fmin(mn, p[2]);
+        v[2] += p[3];
+    }
+    block_sum<3>(v, lds);
+    mn = block_min(mn, lds);
+    if (threadIdx.x == 0) {
+        stats[0] = v[0];
+        stats[1] = v[1];
+        stats[2] = mn;
+        stats[3] = v[2];
+    }
+}
+
+// =============================================================================================
+// contract likelihood / validity
+// =============================================================================================
+template <int KIND>
+__global__ __launch_bounds__(QSMC_BLOCK) void k_likelihood(const double *__restrict__ x, int64_t ldx,
+                                                           int64_t n, ExpArgs e, int64_t outcome,
+                                                           double *__restrict__ L) {
+    constexpr int D = Model<KIND>::D;
+    const int d = (KIND == QSMC_MODEL_TOMOGRAPHY) ? e.d : D;
+    for (int64_t i = (int64_t)blockIdx.x * QSMC_BLOCK + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * QSMC_BLOCK) {
+        double p[D];
+#pragma unroll
+        for (int m = 0; m < D; ++m)
+            if (m < d) p[m] = x[m * ldx + i];
+        L[i] = Model<KIND>::lik(p, e, outcome);
+    }
+}
+
+__global__ __launch_bounds__(QSMC_BLOCK) void k_valid(const double *__restrict__ x, int64_t ldx,
+                                                      int64_t n, int kind, int d, double min_freq,
+                                                      uint8_t *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * QSMC_BLOCK + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * QSMC_BLOCK) {
+        double p[4] = {0, 0, 0, 0};
+        const int dd = d < 4 ? d : 4;
+        for (int m = 0; m < dd; ++m) p[m] = x[m * ldx + i];
+        out[i] = model_valid(kind, p, min_freq) ? 1 : 0;
+    }
+}
+
+__global__ __launch_bounds__(QSMC_BLOCK) void k_fill(double *__restrict__ w, int64_t n, double v) {
+    for (int64_t i = (int64_t)blockIdx.x * QSMC_BLOCK + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * QSMC_BLOCK)
+        w[i] = v;
+}
+
+// =============================================================================================
+// weighted moments:  [sum w, sum w x_m, sum w x_m x_n (m <= n)]
+// =============================================================================================
+template <int D>
+__global__ __launch_bounds__(QSMC_BLOCK) void k_moments_small(const double *__restrict__ x, int64_t ldx,
+                                                              int64_t n, const double *__restrict__ w,
+                                                              double norm, double *__restrict__ partials) {
+    constexpr int K = 1 + D + D * (D + 1) / 2;
+    __shared__ double lds[QSMC_WAVES_PER_BLOCK * K];
+    double acc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * QSMC_BLOCK + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * QSMC_BLOCK) {
+        const double wi = w[i] / norm;
+        double p[D];
+#pragma unroll
+        for (int m = 0; m < D; ++m) p[m] = x[m * ldx + i];
+        acc[0] += wi;
+        int k = 1 + D;
+#pragma unroll
+        for (int m = 0; m < D; ++m) {
+            const double wx = wi * p[m];
+            acc[1 + m] += wx;
+#pragma unroll
+            for (int q = m; q < D; ++q) acc[k++] += wx * p[q];
+        }
+    }
+    block_sum<K>(acc, lds);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) partials[(size_t)blockIdx.x * K + k] = acc[k];
+    }
+}
+
+// General d (<= QSMC_MAX_D): blockIdx.y = row m; the block accumulates sum w x_m and
+// sum w x_m x_q for q >= m (<= 16 accumulators), row 0 also sum w.
+// TODO(perf, config 5): X^T diag(w) X is a genuine (d x N)(N x d) contraction -> v_mfma_f64_16x16x4.
+__global__ __launch_bounds__(QSMC_BLOCK) void k_moments_rows(const double *__restrict__ x, int64_t ldx,
+                                                             int64_t n, int d, const double *__restrict__ w,
+                                                             double norm, double *__restrict__ partials) {
+    constexpr int K = 2 + QSMC_MAX_D;       // [sum w, sum w x_m, sum w x_m x_q (q = m..d-1, padded)]
+    __shared__ double lds[QSMC_WAVES_PER_BLOCK * K];
+    const int m = blockIdx.y;
+    double acc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * QSMC_BLOCK + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * QSMC_BLOCK) {
+        const double wi = w[i] / norm;
+        const double wx = wi * x[m * ldx + i];
+        acc[0] += wi;
+        acc[1] += wx;
+#pragma unroll
+        for (int q = 0; q < QSMC_MAX_D; ++q)
+            if (q >= m && q < d) acc[2 + q] += wx * x[q * ldx + i];
+    }
+    block_sum<K>(acc, lds);
+    if (threadIdx.x == 0) {
+        double *p = partials + ((size_t)m * gridDim.x + blockIdx.x) * K;
+#pragma unroll
+        for (int k = 0; k < K; ++k) p[k] = acc[k];
+    }
+}
+
+// out[k] = sum_g partials[g * K + k], summed in g order by thread k's ... (one block, K <= 256)
+__global__ __launch_bounds__(QSMC_BLOCK) void k_sum_partials(const double *__restrict__ partials,
+                                                             int nblocks, int K, double *__restrict__ out) {
+    // each wave handles a set of k; lanes stride over g; fixed shuffle tree -> deterministic
+    const int lane = threadIdx.x & (QSMC_WAVE - 1);
+    const int wave = threadIdx.x / QSMC_WAVE;
+    for (int k = wave; k < K; k += QSMC_WAVES_PER_BLOCK) {
+        double s = 0.0;
+        for (int g = lane; g < nblocks; g += QSMC_WAVE) s += partials[(size_t)g * K + k];
+        s = wave_sum(s);
+        if (lane == 0) out[k] = s;
+    }
+}
+
+// =============================================================================================
+// inclusive scan of w / norm  (three launches: chunk sums, scan of chunk sums, chunk scans)
+// =============================================================================================
+constexpr int SCAN_PER_LANE = 2;                                   // double2 per lane per tile
+constexpr int SCAN_WAVE_TILE = QSMC_WAVE * SCAN_PER_LANE;          // 128 elements
+constexpr int SCAN_TILES_PER_WAVE = 8;
+constexpr int SCAN_WAVE_CHUNK = SCAN_WAVE_TILE * SCAN_TILES_PER_WAVE;   // 1024
+constexpr int SCAN_CHUNK = SCAN_WAVE_CHUNK * QSMC_WAVES_PER_BLOCK;      // 4096 per workgroup
+
+__device__ __forceinline__ double wave_inclusive_scan(double v, int lane) {
+#pragma unroll
+    for (int off = 1; off < QSMC_WAVE; off <<= 1) {
+        const double t = __shfl_up(v, off, QSMC_WAVE);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(QSMC_BLOCK) void k_chunk_sums(const double *__restrict__ w, int64_t n,
+                                                           double norm, double *__restrict__ sums) {
+    __shared__ double lds[QSMC_WAVES_PER_BLOCK];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK;
+    double v[1] = {0.0};
+#pragma unroll
+    for (int u = 0; u < SCAN_CHUNK / QSMC_BLOCK; ++u) {
+        const int64_t i = base + (int64_t)u * QSMC_BLOCK + threadIdx.x;
+        if (i < n) v[0] += w[i] / norm;
+    }
+    block_sum<1>(v, lds);
+    if (threadIdx.x == 0) sums[blockIdx.x] = v[0];
+}
+
+// exclusive scan of `sums` in place (single workgroup, sequential over 256-wide slabs with carry)
+__global__ __launch_bounds__(QSMC_BLOCK) void k_scan_sums(double *__restrict__ sums, int64_t m) {
+    __shared__ double wave_tot[QSMC_WAVES_PER_BLOCK];
+    __shared__ double carry_s;
+    const int lane = threadIdx.x & (QSMC_WAVE - 1);
+    const int wave = threadIdx.x / QSMC_WAVE;
+    if (threadIdx.x == 0) carry_s = 0.0;
+    __syncthreads();
+    for (int64_t base = 0; base < m; base += QSMC_BLOCK) {
+        const int64_t i = base + threadIdx.x;
+        const double v = i < m ? sums[i] : 0.0;
+        double inc = wave_inclusive_scan(v, lane);
+        if (lane == QSMC_WAVE - 1) wave_tot[wave] = inc;
+        __syncthreads();
+        double off = carry_s;
+        for (int wv = 0; wv < wave; ++wv) off += wave_tot[wv];
+        if (i < m) sums[i] = off + (inc - v);
+        __syncthreads();
+        if (threadIdx.x == QSMC_BLOCK - 1) carry_s = off + inc;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(QSMC_BLOCK) void k_chunk_scan(const double *__restrict__ w, int64_t n,
+                                                           double norm, const double *__restrict__ offsets,
+                                                           double *__restrict__ cdf) {
+    __shared__ double wave_tot[QSMC_WAVES_PER_BLOCK];
+    const int lane = threadIdx.x & (QSMC_WAVE - 1);
+    const int wave = threadIdx.x / QSMC_WAVE;
+    const int64_t wbase = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)wave * SCAN_WAVE_CHUNK;
+    double r[SCAN_TILES_PER_WAVE][SCAN_PER_LANE];
+    double carry = 0.0;
+#pragma unroll
+    for (int t = 0; t < SCAN_TILES_PER_WAVE; ++t) {
+        const int64_t i = wbase + (int64_t)t * SCAN_WAVE_TILE + lane * SCAN_PER_LANE;
+        const double a = i < n ? w[i] / norm : 0.0;
+        const double b = i + 1 < n ? w[i + 1] / norm : 0.0;
+        const double pair = a + b;
+        const double inc = wave_inclusive_scan(pair, lane);
+        const double excl = carry + (inc - pair);
+        r[t][0] = excl + a;
+        r[t][1] = excl + pair;
+        carry += __shfl(inc, QSMC_WAVE - 1, QSMC_WAVE);
+    }
+    if (lane == 0) wave_tot[wave] = carry;
+    __syncthreads();
+    double off = offsets[blockIdx.x];
+    for (int wv = 0; wv < wave; ++wv) off += wave_tot[wv];
+#pragma unroll
+    for (int t = 0; t < SCAN_TILES_PER_WAVE; ++t) {
+        const int64_t i = wbase + (int64_t)t * SCAN_WAVE_TILE + lane * SCAN_PER_LANE;
+        if (i < n) cdf[i] = off + r[t][0];
+        if (i + 1 < n) cdf[i + 1] = off + r[t][1];
+    }
+}
+
+// =============================================================================================
+// Liu-West pieces
+// =============================================================================================
+// upper bound: number of entries <= u, clamped to n - 1
+__device__ __forceinline__ int64_t search_right(const double *__restrict__ cdf, int64_t n, double u) {
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
+    }
+    return lo < n - 1 ? lo : n - 1;
+}
+
+__global__ __launch_bounds__(QSMC_BLOCK) void k_ancestors(const double *__restrict__ cdf, int64_t n_in,
+                                                          const double *__restrict__ u, int64_t n_out,
+                                                          int64_t *__restrict__ js) {
+    for (int64_t i = (int64_t)blockIdx.x * QSMC_BLOCK + threadIdx.x; i < n_out;
+         i += (int64_t)gridDim.x * QSMC_BLOCK)
+        js[i] = search_right(cdf, n_in, u[i]);
+}
+
+struct LWArgs {
+    double a;
+    double mean[QSMC_MAX_D];
+    double S[QSMC_MAX_D * QSMC_MAX_D];   // row-major d x d (already times h)
+};
+
+__global__ __launch_bounds__(QSMC_BLOCK) void k_centres(const double *__restrict__ x_in, int64_t ldx_in,
+                                                        int d, const int64_t *__restrict__ js,
+                                                        int64_t n_out, double a, LWArgs lw,
+                                                        double *__restrict__ mus, int64_t ld_mus) {
+    for (int64_t i = (int64_t)blockIdx.x * QSMC_BLOCK + threadIdx.x; i < n_out;
+         i += (int64_t)gridDim.x * QSMC_BLOCK) {
+        const int64_t j = js[i];
+        for (int m = 0; m < d; ++m)
+            mus[m * ld_mus + i] = a * x_in[m * ldx_in + j] + (1.0 - a) * lw.mean[m];   // :325
+    }
+}
+
+__global__ __launch_bounds__(QSMC_BLOCK) void k_perturb(int kind, int d, double min_freq, int postselect,
+                                                        const double *__restrict__ mus, int64_t ld_mus,
+                                                        const int64_t *__restrict__ idxs, int64_t k,
+                                                        int centre_by_idx, LWArgs lw,
+                                                        const double *__restrict__ z, int64_t ldz,
+                                                        double *__restrict__ x_out, int64_t ldx_out,
+                                                        uint8_t *__restrict__ valid) {
+    for (int64_t r = (int64_t)blockIdx.x * QSMC_BLOCK + threadIdx.x; r < k;
+         r += (int64_t)gridDim.x * QSMC_BLOCK) {
+        const int64_t dst = idxs ? idxs[r] : r;
+        const int64_t c = centre_by_idx ? dst : r;
+        double p[QSMC_MAX_D];
+        for (int m = 0; m < d; ++m) {
+            double s = 0.0;                     // (S @ z)[m, r], summed in column order like np.dot
+            for (int q = 0; q < d; ++q) s += lw.S[m * d + q] * z[q * ldz + r];
+            p[m] = mus[m * ld_mus + c] + s;
+            x_out[m * ldx_out + dst] = p[m];
+        }
+        valid[r] = (!postselect || model_valid(kind, p, min_freq)) ? 1 : 0;
+    }
+}
+
+// One-launch device-RNG resample.
+__global__ __launch_bounds__(QSMC_BLOCK) void k_resample_philox(
+    int kind, int d, double min_freq, int postselect, const double *__restrict__ x_in, int64_t ldx_in,
+    int64_t n_in, const double *__restrict__ cdf, LWArgs lw, int64_t n_out, uint32_t k0, uint32_t k1,
+    uint32_t epoch, int maxiter, double *__restrict__ x_out, int64_t ldx_out,
+    unsigned long long *__restrict__ n_failed) {
+    unsigned long long failed = 0;
+    for (int64_t i = (int64_t)blockIdx.x * QSMC_BLOCK + threadIdx.x; i < n_out;
+         i += (int64_t)gridDim.x * QSMC_BLOCK) {
+        double p[QSMC_MAX_D];
+        bool ok = false;
+        for (int round = 0; round < maxiter && !ok; ++round) {
+            PhiloxStream rng{(uint64_t)i, (epoch << 16) | (uint32_t)round, k0, k1};
+            double u, unused;
+            rng.uniforms(0, u, unused);
+            const int64_t j = search_right(cdf, n_in, u);
+            double zz[QSMC_MAX_D];
+            for (int q = 0; q < d; q += 2) {
+                double z0, z1;
+                rng.normals(1 + (q >> 1), z0, z1);
+                zz[q] = z0;
+                if (q + 1 < d) zz[q + 1] = z1;
+            }
+            for (int m = 0; m < d; ++m) {
+                double s = 0.0;
+                for (int q = 0; q < d; ++q) s += lw.S[m * d + q] * zz[q];
+                p[m] = (lw.a * x_in[m * ldx_in + j] + (1.0 - lw.a) * lw.mean[m]) + s;
+            }
+            ok = !postselect || model_valid(kind, p, min_freq);
+        }
+        for (int m = 0; m < d; ++m) x_out[m * ldx_out + i] = p[m];
+        if (!ok) ++failed;
+    }
+    if (failed) atomicAdd(n_failed, failed);
+}
+
+__global__ __launch_bounds__(QSMC_BLOCK) void k_prior_uniform_philox(
+    int kind, int d, double min_freq, int postselect, LWArgs box /* mean = lo, S[0..d) = hi - lo */,
+    int64_t n, uint32_t k0, uint32_t k1, uint32_t epoch, int maxiter, double *__restrict__ x_out,
+    int64_t ldx_out, unsigned long long *__restrict__ n_failed) {
+    unsigned long long failed = 0;
+    for (int64_t i = (int64_t)blockIdx.x * QSMC_BLOCK + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * QSMC_BLOCK) {
+        double p[QSMC_MAX_D];
+        bool ok = false;
+        for (int round = 0; round < maxiter && !ok; ++round) {
+            PhiloxStream rng{(uint64_t)i, (epoch << 16) | (uint32_t)round, k0, k1};
+            for (int q = 0; q < d; q += 2) {
+                double u0, u1;
+                rng.uniforms(q >> 1, u0, u1);
+                p[q] = box.mean[q] + u0 * box.S[q];                         // lo + z * delta (:818-819)
+                if (q + 1 < d) p[q + 1] = box.mean[q + 1] + u1 * box.S[q + 1];
+            }
+            ok = !postselect || model_valid(kind, p, min_freq);
+        }
+        for (int m = 0; m < d; ++m) x_out[m * ldx_out + i] = p[m];
+        if (!ok) ++failed;
+    }
+    if (failed) atomicAdd(n_failed, failed);
+}
+
+// =============================================================================================
+// tomography canonicalize: per-particle dim x dim complex Hermitian Jacobi, clamp, re-expand
+// =============================================================================================
+template <int DIM>
+__global__ __launch_bounds__(QSMC_BLOCK) void k_tomo_canon(const double *__restrict__ basis,
+                                                           double *__restrict__ x, int64_t ldx, int64_t n,
+                                                           int allow_subnormalized) {
+    constexpr int D = DIM * DIM;
+    for (int64_t i = (int64_t)blockIdx.x * QSMC_BLOCK + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * QSMC_BLOCK) {
+        double p[D];
+#pragma unroll
+        for (int a = 0; a < D; ++a) p[a] = x[a * ldx + i];
+        if (tomo_canon_particle<DIM>(basis, p, allow_subnormalized != 0)) {
+#pragma unroll
+            for (int a = 0; a < D; ++a) x[a * ldx + i] = p[a];
+        }
+    }
+}
+
+// =============================================================================================
+// host-side helpers
+// =============================================================================================
+static int make_exp_args(const qsmc_model_t *model, const qsmc_expparam_t *ep, int64_t outcome,
+                         ExpArgs *out) {
+    memset(out, 0, sizeof(*out));
+    out->t = ep->t;
+    out->w_ = ep->w_;
+    out->n_meas = (double)ep->n_meas;
+    out->m = (double)ep->m;
+    out->reference = ep->reference;
+    out->d = model->d;
+    for (int i = 0; i < QSMC_MAX_D; ++i) out->meas[i] = ep->meas[i];
+    out->comb = 1.0;
+    out->log_comb = 0.0;
+    if (model->kind == QSMC_MODEL_BINOMIAL_PRECESSION) {
+        const double n = (double)ep->n_meas, k = (double)outcome;
+        if (outcome >= 0 && k <= n) {
+            out->log_comb = lgamma(n + 1.0) - lgamma(k + 1.0) - lgamma(n - k + 1.0);
+            // exact integer binomial coefficient while it fits a double exactly-ish
+            long double c = 1.0L;
+            const int64_t kk = (outcome < (int64_t)(ep->n_meas - (uint64_t)outcome))
+                                   ? outcome : (int64_t)(ep->n_meas - (uint64_t)outcome);
+            bool finite = true;
+            for (int64_t j = 1; j <= kk; ++j) {
+                c = c * (long double)(ep->n_meas - (uint64_t)kk + (uint64_t)j) / (long double)j;
+                if (c > 1.0e300L) { finite = false; break; }
+            }
+            out->comb = finite ? (double)c : INFINITY;
+        }
+    }
+    return QSMC_OK;
+}
+
+static int check_model(const qsmc_model_t *m) {
+    if (!m) return QSMC_ERR_INVALID;
+    switch (m->kind) {
+        case QSMC_MODEL_PRECESSION:
+        case QSMC_MODEL_BINOMIAL_PRECESSION: return m->d == 1 ? QSMC_OK : QSMC_ERR_INVALID;
+        case QSMC_MODEL_RB: return m->d == 3 ? QSMC_OK : QSMC_ERR_INVALID;
+        case QSMC_MODEL_RB_INTERLEAVED: return m->d == 4 ? QSMC_OK : QSMC_ERR_INVALID;
+        case QSMC_MODEL_TOMOGRAPHY: return (m->d >= 1 && m->d <= QSMC_MAX_D) ? QSMC_OK : QSMC_ERR_INVALID;
+        default: return QSMC_ERR_INVALID;
+    }
+}
+
+static int finish_stats(qsmc_ctx *h, int grid, double *stats_dev, qsmc_update_stats_t *stats_host,
+                        hipStream_t s) {
+    double *dst = stats_dev ? stats_dev : h->scratch;
+    if (!stats_dev) {
+        int rc = ensure_scratch(h, 4);
+        if (rc) return rc;
+        dst = h->scratch;
+    }
+    hipLaunchKernelGGL(k_update_finalize, dim3(1), dim3(QSMC_BLOCK), 0, s, h->partials, grid, dst);
+    HIP_TRY(h, hipGetLastError());
+    if (stats_host) {
+        double tmp[4];
+        int rc = read_back(h, dst, tmp, 4, s);
+        if (rc) return rc;
+        stats_host->sum = tmp[0];
+        stats_host->sumsq = tmp[1];
+        stats_host->min = tmp[2];
+        stats_host->n_bad = tmp[3];
+    }
+    return QSMC_OK;
+}
+
+template <int KIND>
+static void launch_update(bool vec2, int grid, hipStream_t s, const double *x, int64_t ldx, int64_t n,
+                          const double *w_in, double *w_out, double prev_norm, const ExpArgs &e,
+                          int64_t outcome, double *partials) {
+    if (vec2)
+        hipLaunchKernelGGL((k_update_fused<KIND, 2>), dim3(grid), dim3(QSMC_BLOCK), 0, s, x, ldx, n, w_in,
+                           w_out, prev_norm, e, outcome, partials);
+    else
+        hipLaunchKernelGGL((k_update_fused<KIND, 1>), dim3(grid), dim3(QSMC_BLOCK), 0, s, x, ldx, n, w_in,
+                           w_out, prev_norm, e, outcome, partials);
+}
+
+template <int MODE>
+static int weights_pass(qsmc_ctx *h, const double *L, int64_t n, const double *w_in, double *w_out,
+                        double norm, double *stats_dev, qsmc_update_stats_t *stats_host, hipStream_t s) {
+    const int grid = grid_for(n, QSMC_BLOCK * 4);
+    int rc = ensure_partials(h, (size_t)grid * 4);
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_weights_pass<MODE>), dim3(grid), dim3(QSMC_BLOCK), 0, s, L, n, w_in, w_out, norm,
+                       h->partials);
+    HIP_TRY(h, hipGetLastError());
+    return finish_stats(h, grid, stats_dev, stats_host, s);
+}
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+int qsmc_abi_version(void) { return QSMC_ABI_VERSION; }
+
+const char *qsmc_strerror(int status) {
+    switch (status) {
+        case QSMC_OK: return "ok";
+        case QSMC_ERR_INVALID: return "invalid argument";
+        case QSMC_ERR_HIP: return "HIP runtime error";
+        case QSMC_ERR_ALLOC: return "allocation failed";
+        case QSMC_ERR_UNSUPPORTED: return "unsupported configuration";
+        default: return "unknown status";
+    }
+}
+
+const char *qsmc_last_hip_error(qsmc_handle_t h) { return h ? h->hip_err : ""; }
+
+int qsmc_create(qsmc_handle_t *out, int device) {
+    if (!out) return QSMC_ERR_INVALID;
+    qsmc_ctx *h = new (std::nothrow) qsmc_ctx();
+    if (!h) return QSMC_ERR_ALLOC;
+    memset(h, 0, sizeof(*h));
+    h->device = device;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipMalloc(&h->counter, sizeof(long long));
+    if (e == hipSuccess) e = hipEventCreate(&h->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev1);
+    if (e != hipSuccess) {
+        delete h;
+        return QSMC_ERR_HIP;
+    }
+    *out = h;
+    return QSMC_OK;
+}
+
+int qsmc_destroy(qsmc_handle_t h) {
+    if (!h) return QSMC_OK;
+    if (h->partials) (void)hipFree(h->partials);
+    if (h->scratch) (void)hipFree(h->scratch);
+    if (h->pinned) (void)hipHostFree(h->pinned);
+    if (h->counter) (void)hipFree(h->counter);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    delete h;
+    return QSMC_OK;
+}
+
+int qsmc_set_profiling(qsmc_handle_t h, int enabled) {
+    if (!h) return QSMC_ERR_INVALID;
+    h->profiling = enabled ? 1 : 0;
+    h->ev_valid = 0;
+    return QSMC_OK;
+}
+
+int qsmc_last_update_kernel_ms(qsmc_handle_t h, float *ms_out) {
+    if (!h || !ms_out || !h->ev_valid) return QSMC_ERR_INVALID;
+    HIP_TRY(h, hipEventSynchronize(h->ev1));
+    HIP_TRY(h, hipEventElapsedTime(ms_out, h->ev0, h->ev1));
+    return QSMC_OK;
+}
+
+int qsmc_likelihood(qsmc_handle_t h, const qsmc_model_t *model, const double *x, int64_t ldx, int64_t n,
+                    const qsmc_expparam_t *exps, int32_t n_e, const int64_t *outcomes, int32_t n_o,
+                    double *L_out, qsmc_stream_t stream) {
+    if (!h || !x || !exps || !outcomes || !L_out || n < 0 || n_e < 0 || n_o < 0) return QSMC_ERR_INVALID;
+    int rc = check_model(model);
+    if (rc) return rc;
+    if (n == 0) return QSMC_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = grid_for(n, QSMC_BLOCK);
+    for (int o = 0; o < n_o; ++o)
+        for (int e = 0; e < n_e; ++e) {
+            ExpArgs ea;
+            make_exp_args(model, &exps[e], outcomes[o], &ea);
+            double *L = L_out + ((size_t)o * n_e + e) * (size_t)n;
+            switch (model->kind) {
+#define LAUNCH_L(K)                                                                                   \
+    case K:                                                                                           \
+        hipLaunchKernelGGL((k_likelihood<K>), dim3(grid), dim3(QSMC_BLOCK), 0, s, x, ldx, n, ea,       \
+                           outcomes[o], L);                                                           \
+        break;
+                LAUNCH_L(QSMC_MODEL_PRECESSION)
+                LAUNCH_L(QSMC_MODEL_BINOMIAL_PRECESSION)
+                LAUNCH_L(QSMC_MODEL_RB)
+                LAUNCH_L(QSMC_MODEL_RB_INTERLEAVED)
+                LAUNCH_L(QSMC_MODEL_TOMOGRAPHY)
+#undef LAUNCH_L
+            }
+        }
+    HIP_TRY(h, hipGetLastError());
+    return QSMC_OK;
+}
+
+int qsmc_are_models_valid(qsmc_handle_t h, const qsmc_model_t *model, const double *x, int64_t ldx,
+                          int64_t n, uint8_t *valid_out, qsmc_stream_t stream) {
+    if (!h || !x || !valid_out || n < 0) return QSMC_ERR_INVALID;
+    int rc = check_model(model);
+    if (rc) return rc;
+    if (n == 0) return QSMC_OK;
+    hipLaunchKernelGGL(k_valid, dim3(grid_for(n, QSMC_BLOCK)), dim3(QSMC_BLOCK), 0, (hipStream_t)stream, x,
+                       ldx, n, model->kind, model->d, model->min_freq, valid_out);
+    HIP_TRY(h, hipGetLastError());
+    return QSMC_OK;
+}
+
+int qsmc_update_fused(qsmc_handle_t h, const qsmc_model_t *model, const double *x, int64_t ldx, int64_t n,
+                      const double *w_in, double *w_out, double prev_norm, const qsmc_expparam_t *exp,
+                      int64_t outcome, double *stats_dev, qsmc_update_stats_t *stats_host,
+                      qsmc_stream_t stream) {
+    if (!h || !x || !w_in || !w_out || !exp || n <= 0) return QSMC_ERR_INVALID;
+    int rc = check_model(model);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const bool vec2 = aligned16(x) && aligned16(w_in) && aligned16(w_out) && (ldx % 2 == 0);
+    const int per_block = QSMC_BLOCK * (vec2 ? 2 : 1) * UPD_UNROLL;
+    const int grid = grid_for(n, per_block);
+    rc = ensure_partials(h, (size_t)grid * 4);
+    if (rc) return rc;
+    ExpArgs ea;
+    make_exp_args(model, exp, outcome, &ea);
+    if (h->profiling) HIP_TRY(h, hipEventRecord(h->ev0, s));
+    switch (model->kind) {
+#define LAUNCH_U(K)                                                                                   \
+    case K:                                                                                           \
+        launch_update<K>(vec2, grid, s, x, ldx, n, w_in, w_out, prev_norm, ea, outcome, h->partials);  \
+        break;
+        LAUNCH_U(QSMC_MODEL_PRECESSION)
+        LAUNCH_U(QSMC_MODEL_BINOMIAL_PRECESSION)
+        LAUNCH_U(QSMC_MODEL_RB)
+        LAUNCH_U(QSMC_MODEL_RB_INTERLEAVED)
+        LAUNCH_U(QSMC_MODEL_TOMOGRAPHY)
+#undef LAUNCH_U
+    }
+    HIP_TRY(h, hipGetLastError());
+    if (h->profiling) {
+        HIP_TRY(h, hipEventRecord(h->ev1, s));
+        h->ev_valid = 1;
+    }
+    return finish_stats(h, grid, stats_dev, stats_host, s);
+}
+
+int qsmc_update_from_likelihood(qsmc_handle_t h, const double *L, int64_t n, const double *w_in,
+                                double *w_out, double prev_norm, double *stats_dev,
+                                qsmc_update_stats_t *stats_host, qsmc_stream_t stream) {
+    if (!h || !L || !w_in || !w_out || n <= 0) return QSMC_ERR_INVALID;
+    return weights_pass<0>(h, L, n, w_in, w_out, prev_norm, stats_dev, stats_host, (hipStream_t)stream);
+}
+
+int qsmc_clip_weights(qsmc_handle_t h, double *w, int64_t n, double norm, double *stats_dev,
+                      qsmc_update_stats_t *stats_host, qsmc_stream_t stream) {
+    if (!h || !w || n <= 0) return QSMC_ERR_INVALID;
+    return weights_pass<1>(h, nullptr, n, w, w, norm, stats_dev, stats_host, (hipStream_t)stream);
+}
+
+int qsmc_weight_stats(qsmc_handle_t h, const double *w, int64_t n, double norm, double *stats_dev,
+                      qsmc_update_stats_t *stats_host, qsmc_stream_t stream) {
+    if (!h || !w || n <= 0) return QSMC_ERR_INVALID;
+    return weights_pass<3>(h, nullptr, n, w, nullptr, norm, stats_dev, stats_host, (hipStream_t)stream);
+}
+
+int qsmc_normalize_weights(qsmc_handle_t h, const double *w_in, double *w_out, int64_t n, double norm,
+                           qsmc_stream_t stream) {
+    if (!h || !w_in || !w_out || n < 0) return QSMC_ERR_INVALID;
+    if (n == 0) return QSMC_OK;
+    return weights_pass<2>(h, nullptr, n, w_in, w_out, norm, nullptr, nullptr, (hipStream_t)stream);
+}
+
+int qsmc_fill(qsmc_handle_t h, double *w, int64_t n, double value, qsmc_stream_t stream) {
+    if (!h || !w || n < 0) return QSMC_ERR_INVALID;
+    if (n == 0) return QSMC_OK;
+    hipLaunchKernelGGL(k_fill, dim3(grid_for(n, QSMC_BLOCK * 4)), dim3(QSMC_BLOCK), 0, (hipStream_t)stream, w,
+                       n, value);
+    HIP_TRY(h, hipGetLastError());
+    return QSMC_OK;
+}
+
+int qsmc_moments(qsmc_handle_t h, const double *x, int64_t ldx, int64_t n, int32_t d, const double *w,
+                 double norm, double *out_dev, double *out_host, qsmc_stream_t stream) {
+    if (!h || !x || !w || n <= 0 || d < 1 || d > QSMC_MAX_D) return QSMC_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const int K = 1 + d + d * (d + 1) / 2;
+    int rc = ensure_scratch(h, 256 + (size_t)QSMC_MAX_D * (2 + QSMC_MAX_D));
+    if (rc) return rc;
+    double *dst = out_dev ? out_dev : h->scratch;
+    const int grid = grid_for(n, QSMC_BLOCK * 4);
+    if (d <= 4) {
+        rc = ensure_partials(h, (size_t)grid * K);
+        if (rc) return rc;
+        switch (d) {
+#define LAUNCH_M(DD)                                                                                  \
+    case DD:                                                                                          \
+        hipLaunchKernelGGL((k_moments_small<DD>), dim3(grid), dim3(QSMC_BLOCK), 0, s, x, ldx, n, w, norm, \
+                           h->partials);                                                              \
+        break;
+            LAUNCH_M(1) LAUNCH_M(2) LAUNCH_M(3) LAUNCH_M(4)
+#undef LAUNCH_M
+        }
+        HIP_TRY(h, hipGetLastError());
+        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(QSMC_BLOCK), 0, s, h->partials, grid, K, dst);
+        HIP_TRY(h, hipGetLastError());
+        if (out_host) return read_back(h, dst, out_host, K, s);
+        return QSMC_OK;
+    }
+    // d > 4: row-split kernel; per-row results land in scratch[256 + m * KR + ...], packed on host
+    constexpr int KR = 2 + QSMC_MAX_D;
+    const int gridx = grid_for(n, QSMC_BLOCK * 4) / 4 > 0 ? grid_for(n, QSMC_BLOCK * 4) / 4 : 1;
+    rc = ensure_partials(h, (size_t)gridx * d * KR);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_moments_rows, dim3(gridx, d), dim3(QSMC_BLOCK), 0, s, x, ldx, n, d, w, norm,
+                       h->partials);
+    HIP_TRY(h, hipGetLastError());
+    double *rows = h->scratch + 256;
+    for (int m = 0; m < d; ++m) {
+        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(QSMC_BLOCK), 0, s,
+                           h->partials + (size_t)m * gridx * KR, gridx, KR, rows + (size_t)m * KR);
+    }
+    HIP_TRY(h, hipGetLastError());
+    // pack on host (needs a sync); if the caller wants device output we upload the packed vector
+    double hostrows[QSMC_MAX_D * KR];
+    rc = read_back(h, rows, hostrows, (size_t)d * KR, s);
+    if (rc) return rc;
+    double packed[1 + QSMC_MAX_D + QSMC_MAX_D * (QSMC_MAX_D + 1) / 2];
+    packed[0] = hostrows[0];
+    int k = 1 + d;
+    for (int m = 0; m < d; ++m) {
+        packed[1 + m] = hostrows[m * KR + 1];
+        for (int q = m; q < d; ++q) packed[k++] = hostrows[m * KR + 2 + q];
+    }
+    if (out_host) memcpy(out_host, packed, K * sizeof(double));
+    if (out_dev) {
+        HIP_TRY(h, hipMemcpyAsync(out_dev, packed, K * sizeof(double), hipMemcpyHostToDevice, s));
+        HIP_TRY(h, hipStreamSynchronize(s));
+    }
+    return QSMC_OK;
+}
+
+int qsmc_cumsum(qsmc_handle_t h, const double *w, int64_t n, double norm, double *cdf,
+                qsmc_stream_t stream) {
+    if (!h || !w || !cdf || n <= 0) return QSMC_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t chunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    int rc = ensure_partials(h, (size_t)chunks);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_chunk_sums, dim3((unsigned)chunks), dim3(QSMC_BLOCK), 0, s, w, n, norm, h->partials);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(QSMC_BLOCK), 0, s, h->partials, chunks);
+    hipLaunchKernelGGL(k_chunk_scan, dim3((unsigned)chunks), dim3(QSMC_BLOCK), 0, s, w, n, norm, h->partials,
+                       cdf);
+    HIP_TRY(h, hipGetLastError());
+    return QSMC_OK;
+}
+
+int qsmc_lw_ancestors(qsmc_handle_t h, const double *cdf, int64_t n_in, const double *u, int64_t n_out,
+                      int64_t *js, qsmc_stream_t stream) {
+    if (!h || !cdf || !u || !js || n_in <= 0 || n_out < 0) return QSMC_ERR_INVALID;
+    if (n_out == 0) return QSMC_OK;
+    hipLaunchKernelGGL(k_ancestors, dim3(grid_for(n_out, QSMC_BLOCK)), dim3(QSMC_BLOCK), 0,
+                       (hipStream_t)stream, cdf, n_in, u, n_out, js);
+    HIP_TRY(h, hipGetLastError());
+    return QSMC_OK;
+}
+
+static void fill_lw(LWArgs *lw, int d, double a, const double *mean, const double *S) {
+    memset(lw, 0, sizeof(*lw));
+    lw->a = a;
+    if (mean) for (int m = 0; m < d; ++m) lw->mean[m] = mean[m];
+    if (S) for (int k = 0; k < d * d; ++k) lw->S[k] = S[k];
+}
+
+int qsmc_lw_centres(qsmc_handle_t h, const double *x_in, int64_t ldx_in, int32_t d, const int64_t *js,
+                    int64_t n_out, double a, const double *mean, double *mus, int64_t ld_mus,
+                    qsmc_stream_t stream) {
+    if (!h || !x_in || !js || !mean || !mus || d < 1 || d > QSMC_MAX_D || n_out < 0) return QSMC_ERR_INVALID;
+    if (n_out == 0) return QSMC_OK;
+    LWArgs lw;
+    fill_lw(&lw, d, a, mean, nullptr);
+    hipLaunchKernelGGL(k_centres, dim3(grid_for(n_out, QSMC_BLOCK)), dim3(QSMC_BLOCK), 0, (hipStream_t)stream,
+                       x_in, ldx_in, d, js, n_out, a, lw, mus, ld_mus);
+    HIP_TRY(h, hipGetLastError());
+    return QSMC_OK;
+}
+
+int qsmc_lw_perturb(qsmc_handle_t h, const qsmc_model_t *model, int32_t postselect, const double *mus,
+                    int64_t ld_mus, const int64_t *idxs, int64_t k, int32_t centre_by_idx, const double *S,
+                    const double *z, int64_t ldz, double *x_out, int64_t ldx_out, uint8_t *valid_out,
+                    qsmc_stream_t stream) {
+    if (!h || !model || !mus || !S || !z || !x_out || !valid_out || k < 0) return QSMC_ERR_INVALID;
+    if (model->d < 1 || model->d > QSMC_MAX_D) return QSMC_ERR_INVALID;
+    if (k == 0) return QSMC_OK;
+    LWArgs lw;
+    fill_lw(&lw, model->d, 0.0, nullptr, S);
+    hipLaunchKernelGGL(k_perturb, dim3(grid_for(k, QSMC_BLOCK)), dim3(QSMC_BLOCK), 0, (hipStream_t)stream,
+                       model->kind, model->d, model->min_freq, postselect, mus, ld_mus, idxs, k, centre_by_idx,
+                       lw, z, ldz, x_out, ldx_out, valid_out);
+    HIP_TRY(h, hipGetLastError());
+    return QSMC_OK;
+}
+
+static int read_counter(qsmc_ctx *h, int64_t *out, hipStream_t s) {
+    int rc = ensure_pinned(h, 1);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpyAsync(h->pinned, h->counter, sizeof(long long), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    long long v;
+    memcpy(&v, h->pinned, sizeof(v));
+    *out = (int64_t)v;
+    return QSMC_OK;
+}
+
+int qsmc_lw_resample_philox(qsmc_handle_t h, const qsmc_model_t *model, int32_t postselect,
+                            const double *x_in, int64_t ldx_in, int64_t n_in, int32_t d, const double *cdf,
+                            double a, const double *mean, const double *S, int64_t n_out, uint64_t seed,
+                            uint64_t epoch, int32_t maxiter, double *x_out, int64_t ldx_out,
+                            int64_t *n_failed_host, qsmc_stream_t stream) {
+    if (!h || !model || !x_in || !cdf || !mean || !S || !x_out || n_in <= 0 || n_out <= 0) return QSMC_ERR_INVALID;
+    if (d != model->d || d < 1 || d > QSMC_MAX_D || maxiter < 1) return QSMC_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    LWArgs lw;
+    fill_lw(&lw, d, a, mean, S);
+    HIP_TRY(h, hipMemsetAsync(h->counter, 0, sizeof(long long), s));
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32) ^ (uint32_t)(epoch >> 16);
+    hipLaunchKernelGGL(k_resample_philox, dim3(grid_for(n_out, QSMC_BLOCK)), dim3(QSMC_BLOCK), 0, s,
+                       model->kind, d, model->min_freq, postselect, x_in, ldx_in, n_in, cdf, lw, n_out, k0, k1,
+                       (uint32_t)(epoch & 0xFFFFu), maxiter, x_out, ldx_out,
+                       reinterpret_cast<unsigned long long *>(h->counter));
+    HIP_TRY(h, hipGetLastError());
+    if (n_failed_host) return read_counter(h, n_failed_host, s);
+    return QSMC_OK;
+}
+
+int qsmc_prior_uniform_philox(qsmc_handle_t h, const qsmc_model_t *model, int32_t postselect,
+                              const double *lo, const double *hi, int32_t d, int64_t n, uint64_t seed,
+                              uint64_t epoch, int32_t maxiter, double *x_out, int64_t ldx_out,
+                              int64_t *n_failed_host, qsmc_stream_t stream) {
+    if (!h || !model || !lo || !hi || !x_out || n <= 0 || d < 1 || d > QSMC_MAX_D || maxiter < 1)
+        return QSMC_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    LWArgs box;
+    memset(&box, 0, sizeof(box));
+    for (int m = 0; m < d; ++m) {
+        box.mean[m] = lo[m];
+        box.S[m] = hi[m] - lo[m];
+    }
+    HIP_TRY(h, hipMemsetAsync(h->counter, 0, sizeof(long long), s));
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32) ^ (uint32_t)(epoch >> 16);
+    hipLaunchKernelGGL(k_prior_uniform_philox, dim3(grid_for(n, QSMC_BLOCK)), dim3(QSMC_BLOCK), 0, s,
+                       model->kind, d, model->min_freq, postselect, box, n, k0, k1,
+                       (uint32_t)(epoch & 0xFFFFu), maxiter, x_out, ldx_out,
+                       reinterpret_cast<unsigned long long *>(h->counter));
+    HIP_TRY(h, hipGetLastError());
+    if (n_failed_host) return read_counter(h, n_failed_host, s);
+    return QSMC_OK;
+}
+
+int qsmc_tomo_canonicalize(qsmc_handle_t h, const double *basis, int32_t dim, double *x, int64_t ldx,
+                           int64_t n, int32_t allow_subnormalized, qsmc_stream_t stream) {
+    if (!h || !basis || !x || n < 0) return QSMC_ERR_INVALID;
+    if (n == 0) return QSMC_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = grid_for(n, QSMC_BLOCK);
+    switch (dim) {
+        case 2:
+            hipLaunchKernelGGL((k_tomo_canon<2>), dim3(grid), dim3(QSMC_BLOCK), 0, s, basis, x, ldx, n,
+                               allow_subnormalized);
+            break;
+        case 3:
+            return QSMC_ERR_UNSUPPORTED;   // d = 9 fits QSMC_MAX_D but no config needs it yet
+        case 4:
+            hipLaunchKernelGGL((k_tomo_canon<4>), dim3(grid), dim3(QSMC_BLOCK), 0, s, basis, x, ldx, n,
+                               allow_subnormalized);
+            break;
+        default: return QSMC_ERR_UNSUPPORTED;
+    }
+    HIP_TRY(h, hipGetLastError());
+    return QSMC_OK;
+}
+
+// ---- host: sqrtm_psd by cyclic Jacobi (utils.py:593-607) --------------------------------------
+int qsmc_sqrtm_psd(const double *A, int32_t d, double scale, double *S_out, double *err_out) {
+    if (!A || !S_out || d < 1 || d > 64) return QSMC_ERR_INVALID;
+    const int n = d;
+    double *a = (double *)malloc(sizeof(double) * n * n * 3);
+    if (!a) return QSMC_ERR_ALLOC;
+    double *v = a + n * n, *sq = v + n * n;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            a[i * n + j] = 0.5 * (A[i * n + j] + A[j * n + i]);   // eigh reads one triangle; symmetrise
+            v[i * n + j] = (i == j) ? 1.0 : 0.0;
+        }
+    for (int sweep = 0; sweep < 64; ++sweep) {
+        double off = 0.0, diag = 0.0;
+        for (int i = 0; i < n; ++i) {
+            diag += a[i * n + i] * a[i * n + i];
+            for (int j = i + 1; j < n; ++j) off += a[i * n + j] * a[i * n + j];
+        }
+        if (off == 0.0 || off <= 1e-34 * diag) break;
+        for (int p = 0; p < n; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                const double apq = a[p * n + q];
+                if (apq == 0.0) continue;
+                const double tau = (a[q * n + q] - a[p * n + p]) / (2.0 * apq);
+                const double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                const double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
+                for (int k = 0; k < n; ++k) {
+                    const double akp = a[k * n + p], akq = a[k * n + q];
+                    a[k * n + p] = c * akp - s * akq;
+                    a[k * n + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double apk = a[p * n + k], aqk = a[q * n + k];
+                    a[p * n + k] = c * apk - s * aqk;
+                    a[q * n + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double vkp = v[k * n + p], vkq = v[k * n + q];
+                    v[k * n + p] = c * vkp - s * vkq;
+                    v[k * n + q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    // S = V sqrt(max(lambda, 0)) V^T
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < n; ++k) {
+                const double lam = a[k * n + k];
+                const double r = lam <= 0.0 ? 0.0 : sqrt(lam);
+                s += v[i * n + k] * r * v[j * n + k];
+            }
+            sq[i * n + j] = s;
+        }
+    if (err_out) {
+        double e2 = 0.0;
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) {
+                double s = 0.0;
+                for (int k = 0; k < n; ++k) s += sq[i * n + k] * sq[k * n + j];
+                const double dlt = s - A[i * n + j];
+                e2 += dlt * dlt;
+            }
+        *err_out = sqrt(e2);
+    }
+    for (int k = 0; k < n * n; ++k) S_out[k] = scale * sq[k];
+    free(a);
+    return QSMC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,124 @@
+"""ctypes binding of libqsmc_hip.so (the C ABI declared in include/qsmc.h).
+
+The HIP library IS the product: if it cannot be loaded, or no GPU is visible when a compute
+entry point is called, this module raises -- it never falls back to a CPU implementation.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from ._exceptions import NativeLibraryError
+
+QSMC_MAX_D = 16
+MODEL_PRECESSION, MODEL_BINOMIAL_PRECESSION, MODEL_RB, MODEL_RB_INTERLEAVED, MODEL_TOMOGRAPHY = 1, 2, 3, 4, 5
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libqsmc_hip.so")
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("d", C.c_int32), ("min_freq", C.c_double),
+                ("postselect_all_valid", C.c_int32), ("reserved", C.c_int32)]
+
+
+class ExpParam(C.Structure):
+    _fields_ = [("t", C.c_double), ("w_", C.c_double), ("n_meas", C.c_uint64), ("m", C.c_uint64),
+                ("reference", C.c_int32), ("reserved", C.c_int32), ("meas", C.c_double * QSMC_MAX_D)]
+
+
+class UpdateStats(C.Structure):
+    _fields_ = [("sum", C.c_double), ("sumsq", C.c_double), ("min", C.c_double), ("n_bad", C.c_double)]
+
+
+_P = C.c_void_p          # device pointers and streams travel as integers
+_I64, _I32, _F64, _U64 = C.c_int64, C.c_int32, C.c_double, C.c_uint64
+
+# name -> argtypes; every symbol of include/qsmc.h (tests/test_abi.py checks the two agree)
+SIGNATURES = {
+    "qsmc_abi_version": [],
+    "qsmc_strerror": [C.c_int],
+    "qsmc_last_hip_error": [_P],
+    "qsmc_create": [C.POINTER(_P), C.c_int],
+    "qsmc_destroy": [_P],
+    "qsmc_set_profiling": [_P, C.c_int],
+    "qsmc_last_update_kernel_ms": [_P, C.POINTER(C.c_float)],
+    "qsmc_likelihood": [_P, C.POINTER(ModelDesc), _P, _I64, _I64, C.POINTER(ExpParam), _I32,
+                        C.POINTER(_I64), _I32, _P, _P],
+    "qsmc_are_models_valid": [_P, C.POINTER(ModelDesc), _P, _I64, _I64, _P, _P],
+    "qsmc_update_fused": [_P, C.POINTER(ModelDesc), _P, _I64, _I64, _P, _P, _F64, C.POINTER(ExpParam),
+                          _I64, _P, C.POINTER(UpdateStats), _P],
+    "qsmc_update_from_likelihood": [_P, _P, _I64, _P, _P, _F64, _P, C.POINTER(UpdateStats), _P],
+    "qsmc_clip_weights": [_P, _P, _I64, _F64, _P, C.POINTER(UpdateStats), _P],
+    "qsmc_weight_stats": [_P, _P, _I64, _F64, _P, C.POINTER(UpdateStats), _P],
+    "qsmc_normalize_weights": [_P, _P, _P, _I64, _F64, _P],
+    "qsmc_fill": [_P, _P, _I64, _F64, _P],
+    "qsmc_moments": [_P, _P, _I64, _I64, _I32, _P, _F64, _P, C.POINTER(_F64), _P],
+    "qsmc_sqrtm_psd": [C.POINTER(_F64), _I32, _F64, C.POINTER(_F64), C.POINTER(_F64)],
+    "qsmc_cumsum": [_P, _P, _I64, _F64, _P, _P],
+    "qsmc_lw_ancestors": [_P, _P, _I64, _P, _I64, _P, _P],
+    "qsmc_lw_centres": [_P, _P, _I64, _I32, _P, _I64, _F64, C.POINTER(_F64), _P, _I64, _P],
+    "qsmc_lw_perturb": [_P, C.POINTER(ModelDesc), _I32, _P, _I64, _P, _I64, _I32, C.POINTER(_F64), _P,
+                        _I64, _P, _I64, _P, _P],
+    "qsmc_lw_resample_philox": [_P, C.POINTER(ModelDesc), _I32, _P, _I64, _I64, _I32, _P, _F64,
+                                C.POINTER(_F64), C.POINTER(_F64), _I64, _U64, _U64, _I32, _P, _I64,
+                                C.POINTER(_I64), _P],
+    "qsmc_prior_uniform_philox": [_P, C.POINTER(ModelDesc), _I32, C.POINTER(_F64), C.POINTER(_F64), _I32,
+                                  _I64, _U64, _U64, _I32, _P, _I64, C.POINTER(_I64), _P],
+    "qsmc_tomo_canonicalize": [_P, _P, _I32, _P, _I64, _I64, _I32, _P],
+}
+_RESTYPE = {"qsmc_strerror": C.c_char_p, "qsmc_last_hip_error": C.c_char_p}
+
+_lib = None
+
+
+def load():
+    """Load libqsmc_hip.so (once).  Raises NativeLibraryError -- no fallback exists."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise NativeLibraryError(
+            "libqsmc_hip.so not found at {}; build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.".format(_LIB_PATH))
+    try:
+        lib = C.CDLL(_LIB_PATH)
+    except OSError as e:
+        raise NativeLibraryError("cannot load {}: {}".format(_LIB_PATH, e))
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = _RESTYPE.get(name, C.c_int)
+    if lib.qsmc_abi_version() != 1:
+        raise NativeLibraryError("ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def check(handle, rc, what):
+    if rc != 0:
+        lib = load()
+        msg = lib.qsmc_strerror(rc).decode()
+        detail = lib.qsmc_last_hip_error(handle).decode() if handle else ""
+        raise RuntimeError("{} failed: {} {}".format(what, msg, detail))
+
+
+def f64_ptr(a):
+    """Pointer to a C-contiguous float64 NumPy array (kept alive by the caller)."""
+    assert a.dtype == np.float64 and a.flags.c_contiguous
+    return a.ctypes.data_as(C.POINTER(_F64))
+
+
+def make_expparam(t=0.0, w_=0.0, n_meas=0, m=0, reference=0, meas=None):
+    ep = ExpParam()
+    ep.t, ep.w_, ep.n_meas, ep.m, ep.reference = float(t), float(w_), int(n_meas), int(m), int(reference)
+    if meas is not None:
+        meas = np.asarray(meas, dtype=np.float64).ravel()
+        if meas.size > QSMC_MAX_D:
+            raise ValueError("native tomography kernels support at most {} model parameters".format(QSMC_MAX_D))
+        for i, v in enumerate(meas):
+            ep.meas[i] = float(v)
+    return ep

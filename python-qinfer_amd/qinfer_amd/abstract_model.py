@@ -1,0 +1,254 @@
+"""Model plugin surface of the SMC engine.
+
+Same class names, method names, argument meaning and array shapes as the reference's
+`qinfer/abstract_model.py` (Simulatable :66, Model :397, FiniteOutcomeModel :544), restated so a
+user's `Model` subclass written against QInfer drops in unchanged:
+
+    likelihood(outcomes, modelparams, expparams) -> float64 L[n_outcomes, n_models, n_experiments]
+    are_models_valid(modelparams)                -> bool  [n_models]
+    simulate_experiment(modelparams, expparams, repeat=1)
+    update_timestep(modelparams, expparams)      -> [n_models, n_modelparams, n_experiments]
+    canonicalize(modelparams)                    -> [n_models, n_modelparams]
+
+Models that additionally implement the *native* hooks
+
+    _native_desc()                -> _native.ModelDesc         (which HIP kernel family)
+    _native_expparams(expparams)  -> list of _native.ExpParam  (one per experiment)
+
+are served entirely by the HIP kernels; `NativeModelMixin` then also routes the NumPy-contract
+`likelihood` / `are_models_valid` through the same kernels, so there is a single source of truth
+for the model arithmetic.  A model without the hooks still works with `SMCUpdater` through the
+plugin slow path (its own `likelihood` runs on the host, the weight update stays on the GPU).
+"""
+import abc
+
+import numpy as np
+
+from .domains import IntegerDomain
+
+__all__ = ["Simulatable", "Model", "FiniteOutcomeModel", "NativeModelMixin"]
+
+
+def safe_shape(arr, idx=0, default=1):
+    shape = np.shape(arr)
+    return shape[idx] if idx < len(shape) else default
+
+
+class Simulatable(metaclass=abc.ABCMeta):
+    """Something that produces data given model parameters and experiment parameters."""
+
+    def __init__(self):
+        self._sim_count = 0
+        self._Q = np.ones((self.n_modelparams,))
+
+    # -- abstract ------------------------------------------------------------------------
+    @property
+    @abc.abstractmethod
+    def n_modelparams(self):
+        """Number of real model parameters."""
+
+    @property
+    @abc.abstractmethod
+    def expparams_dtype(self):
+        """NumPy dtype (scalar name or record spec) of one experiment."""
+
+    @abc.abstractmethod
+    def n_outcomes(self, expparams):
+        """Number of outcomes per experiment (a scalar if constant)."""
+
+    @abc.abstractmethod
+    def domain(self, expparams):
+        """List of outcome domains, one per experiment (or one Domain for expparams=None)."""
+
+    @abc.abstractmethod
+    def are_models_valid(self, modelparams):
+        """bool[n_models]: which parameter vectors are admissible."""
+
+    @abc.abstractmethod
+    def simulate_experiment(self, modelparams, expparams, repeat=1):
+        self._sim_count += modelparams.shape[0] * expparams.shape[0] * repeat
+        assert self.are_expparam_dtypes_consistent(expparams)
+
+    # -- concrete ------------------------------------------------------------------------
+    @property
+    def is_n_outcomes_constant(self):
+        return True
+
+    @property
+    def model_chain(self):
+        return ()
+
+    @property
+    def base_model(self):
+        return self
+
+    @property
+    def underlying_model(self):
+        chain = self.model_chain
+        return chain[-1] if chain else None
+
+    @property
+    def sim_count(self):
+        return self._sim_count
+
+    @property
+    def Q(self):
+        return self._Q
+
+    @property
+    def modelparam_names(self):
+        return ["x_{{{}}}".format(i) for i in range(self.n_modelparams)]
+
+    def are_expparam_dtypes_consistent(self, expparams):
+        if self.is_n_outcomes_constant:
+            return True
+        if expparams.size == 0:
+            return True
+        doms = self.domain(expparams)
+        return all(dm.dtype == doms[0].dtype for dm in doms[1:])
+
+    def clear_cache(self):
+        """Nothing cached by default."""
+
+    def experiment_cost(self, expparams):
+        return np.ones(expparams.shape)
+
+    def distance(self, a, b):
+        return np.sum(np.abs(self.Q * (a - b)), axis=1)
+
+    def update_timestep(self, modelparams, expparams):
+        """Static parameters: x(t_{k+1}) = x(t_k), shape (n_models, n_modelparams, n_experiments)."""
+        return np.repeat(np.asarray(modelparams)[:, :, np.newaxis], expparams.shape[0], axis=2)
+
+    def canonicalize(self, modelparams):
+        return modelparams
+
+
+class Model(Simulatable):
+    """A Simulatable that can also evaluate likelihoods."""
+
+    def __init__(self, allow_identical_outcomes=False, outcome_warning_threshold=0.99):
+        super().__init__()
+        self._call_count = 0
+        self._allow_identical_outcomes = allow_identical_outcomes
+        self._outcome_warning_threshold = outcome_warning_threshold
+
+    @property
+    def call_count(self):
+        return self._call_count
+
+    @property
+    def allow_identical_outcomes(self):
+        return self._allow_identical_outcomes
+
+    @allow_identical_outcomes.setter
+    def allow_identical_outcomes(self, value):
+        self._allow_identical_outcomes = value
+
+    @property
+    def outcome_warning_threshold(self):
+        return self._outcome_warning_threshold
+
+    @outcome_warning_threshold.setter
+    def outcome_warning_threshold(self, value):
+        self._outcome_warning_threshold = value
+
+    @abc.abstractmethod
+    def likelihood(self, outcomes, modelparams, expparams):
+        """L[i, j, k] = Pr(outcomes[i] | modelparams[j]; expparams[k]).  Subclasses call this
+        base implementation to keep `call_count` (abstract_model.py:466-468) meaningful."""
+        self._call_count += safe_shape(outcomes) * safe_shape(modelparams) * safe_shape(expparams)
+
+    def is_model_valid(self, modelparams):
+        return bool(self.are_models_valid(np.asarray(modelparams)[np.newaxis, :])[0])
+
+
+class FiniteOutcomeModel(Model):
+    """Models whose outcomes are integers 0 .. n_outcomes-1."""
+
+    def __init__(self, allow_identical_outcomes=False, outcome_warning_threshold=0.99,
+                 n_outcomes_cutoff=None):
+        super().__init__(allow_identical_outcomes=allow_identical_outcomes,
+                         outcome_warning_threshold=outcome_warning_threshold)
+        self._n_outcomes_cutoff = n_outcomes_cutoff
+        if self.is_n_outcomes_constant:
+            self._domain = IntegerDomain(min=0, max=self.n_outcomes(None) - 1)
+
+    @property
+    def n_outcomes_cutoff(self):
+        return self._n_outcomes_cutoff
+
+    @n_outcomes_cutoff.setter
+    def n_outcomes_cutoff(self, value):
+        self._n_outcomes_cutoff = value
+
+    def domain(self, expparams):
+        if self.is_n_outcomes_constant:
+            return self._domain if expparams is None else [self._domain for _ in expparams]
+        return [IntegerDomain(min=0, max=int(n) - 1) for n in self.n_outcomes(expparams)]
+
+    def simulate_experiment(self, modelparams, expparams, repeat=1):
+        """Inverse-CDF sampling of outcomes with the global legacy RNG, one uniform per
+        (repeat, model, experiment) exactly as abstract_model.py:632-658 consumes them."""
+        super().simulate_experiment(modelparams, expparams, repeat)
+        n_m, n_e = modelparams.shape[0], expparams.shape[0]
+        if self.is_n_outcomes_constant:
+            values = self.domain(None).values
+            cdf = np.cumsum(self.likelihood(values, modelparams, expparams), axis=0)
+            rnd = np.random.random((repeat, 1, n_m, n_e))
+            outcomes = values[np.argmax(cdf > rnd, axis=1)]
+        else:
+            dtype = self.domain(expparams[0, np.newaxis])[0].dtype
+            outcomes = np.empty((repeat, n_m, n_e), dtype=dtype)
+            for k in range(n_e):
+                one = expparams[k:k + 1]
+                values = self.domain(one)[0].values
+                cdf = np.cumsum(self.likelihood(values, modelparams, one), axis=0)[..., 0]
+                rnd = np.random.random((repeat, 1, n_m))
+                outcomes[:, :, k] = values[np.argmax(cdf > rnd, axis=1)]
+        if repeat == 1 and n_e == 1 and n_m == 1:
+            return outcomes[0, 0, 0]
+        return outcomes
+
+    @staticmethod
+    def pr0_to_likelihood_array(outcomes, pr0):
+        """(n_models, n_experiments) Pr(0) -> L[n_outcomes, n_models, n_experiments]."""
+        pr0 = np.asarray(pr0)[np.newaxis, ...]
+        pr1 = 1 - pr0
+        outcomes = np.atleast_1d(np.asarray(outcomes))
+        return np.concatenate([pr0 if outcomes[i] == 0 else pr1 for i in range(outcomes.shape[0])])
+
+
+class NativeModelMixin:
+    """Routes the NumPy-contract methods of a model through its HIP kernels.
+
+    Subclasses provide `_native_desc()` and `_native_expparams(expparams)`.
+    """
+
+    _native = True
+
+    def _engine(self):
+        from .engine import get_engine
+        return get_engine()
+
+    def _native_expparams(self, expparams):  # pragma: no cover - abstract hook
+        raise NotImplementedError
+
+    def _native_desc(self):  # pragma: no cover - abstract hook
+        raise NotImplementedError
+
+    def _native_likelihood(self, outcomes, modelparams, expparams):
+        eng = self._engine()
+        mp = np.asarray(modelparams, dtype=np.float64)
+        if mp.ndim == 1:
+            mp = mp[:, np.newaxis]
+        outcomes = np.atleast_1d(np.asarray(outcomes)).astype(np.int64).ravel()
+        x = eng.locs_to_soa(mp)
+        L = eng.likelihood(self._native_desc(), x, self._native_expparams(expparams), outcomes)
+        return np.ascontiguousarray(L.cpu().numpy().transpose(0, 2, 1))      # (n_o, N, n_e)
+
+    def _native_are_models_valid(self, modelparams):
+        eng = self._engine()
+        mp = np.asarray(modelparams, dtype=np.float64)
+        x = eng.locs_to_soa(mp)
+        return eng.are_models_valid(self._native_desc(), x).cpu().numpy().astype(bool)

@@ -1,0 +1,304 @@
+"""Priors and the device-resident particle cloud.
+
+    Distribution (ABC), UniformDistribution, ProductDistribution, MultivariateNormalDistribution,
+    PostselectedDistribution        reference distributions.py:101-127, 753-827, 882-908, 1304-1350
+    ParticleDistribution            reference distributions.py:261-464
+
+Priors run once (at `reset`) on the host with NumPy's legacy global RNG -- the same stream the
+reference consumes -- or, for a uniform box, optionally on the device with Philox
+(`sample_device`).  `ParticleDistribution` is where the data lives: SoA float64 locations
+`x[d, N]` and unnormalised weights `w[N]` in HBM, with the normaliser carried as a host scalar.
+Its `particle_locations` / `particle_weights` properties materialise NumPy copies in the
+reference's layout ((N, d) C-order, normalised weights) only when somebody asks.
+"""
+import abc
+import warnings
+
+import numpy as np
+
+from ._exceptions import ApproximationWarning
+
+__all__ = ["Distribution", "UniformDistribution", "ProductDistribution",
+           "MultivariateNormalDistribution", "PostselectedDistribution", "ParticleDistribution"]
+
+
+class Distribution(metaclass=abc.ABCMeta):
+    """A probability distribution over `n_rvs` real random variables."""
+
+    @property
+    @abc.abstractmethod
+    def n_rvs(self):
+        pass
+
+    @abc.abstractmethod
+    def sample(self, n=1):
+        """(n, n_rvs) array of draws."""
+
+
+class UniformDistribution(Distribution):
+    """Uniform on a box; `ranges` has shape (n_rvs, 2) (or (2,) for one variable)."""
+
+    def __init__(self, ranges=((0, 1),)):
+        ranges = np.array(ranges, dtype=float)
+        if ranges.ndim == 1:
+            ranges = ranges[np.newaxis, ...]
+        self._ranges = ranges
+        self._n_rvs = ranges.shape[0]
+        self._delta = ranges[:, 1] - ranges[:, 0]
+
+    @property
+    def n_rvs(self):
+        return self._n_rvs
+
+    def sample(self, n=1):
+        z = np.random.random((n, self._n_rvs))
+        return self._ranges[:, 0] + z * self._delta
+
+    def sample_device(self, engine, n, seed, epoch, model_desc=None, postselect=False, maxiter=100):
+        """Philox draw straight into HBM (SoA); used by SMCUpdater(device_rng=True)."""
+        from . import _native
+        desc = model_desc if model_desc is not None else _native.ModelDesc(
+            _native.MODEL_TOMOGRAPHY, self._n_rvs, 0.0, 1, 0)
+        return engine.prior_uniform_philox(desc, postselect, self._ranges[:, 0], self._ranges[:, 1],
+                                           n, seed, epoch, maxiter)
+
+    def grad_log_pdf(self, var):
+        if var.shape[0] == 1:
+            return 12 / (self._delta) ** 2
+        return np.zeros(var.shape)
+
+
+class ProductDistribution(Distribution):
+    """Cartesian product of independent factor distributions."""
+
+    def __init__(self, *factors):
+        if len(factors) == 1 and not isinstance(factors[0], Distribution):
+            factors = tuple(factors[0])
+        self._factors = list(factors)
+
+    @property
+    def n_rvs(self):
+        return sum(f.n_rvs for f in self._factors)
+
+    def sample(self, n=1):
+        return np.hstack([f.sample(n) for f in self._factors])
+
+
+class MultivariateNormalDistribution(Distribution):
+    def __init__(self, mean, cov):
+        import scipy.linalg as la
+        self.mean = np.array(mean, dtype=float).flatten()
+        self.cov = np.asarray(cov, dtype=float)
+        self.invcov = la.inv(self.cov)
+        self._sqrt = np.real(la.sqrtm(self.cov))
+
+    @property
+    def n_rvs(self):
+        return self.mean.shape[0]
+
+    def sample(self, n=1):
+        return np.einsum("ij,nj->ni", self._sqrt, np.random.randn(n, self.n_rvs)) + self.mean
+
+    def grad_log_pdf(self, x):
+        return -np.dot(self.invcov, (x - self.mean).transpose()).transpose()
+
+
+class PostselectedDistribution(Distribution):
+    """Redraws samples of `distribution` until `model.are_models_valid` accepts them."""
+
+    def __init__(self, distribution, model, maxiters=100):
+        self._dist = distribution
+        self._model = model
+        self._maxiters = maxiters
+
+    @property
+    def n_rvs(self):
+        return self._dist.n_rvs
+
+    def sample(self, n=1):
+        samples = np.empty((n, self.n_rvs))
+        todo = np.arange(n)
+        iters = 0
+        while todo.size and iters < self._maxiters:
+            samples[todo] = self._dist.sample(len(todo))
+            ok = np.asarray(self._model.are_models_valid(samples[todo, :]), dtype=bool)
+            todo = todo[np.logical_not(ok)]
+            iters += 1
+        if todo.size:
+            raise RuntimeError("Did not successfully postselect within {} iterations.".format(self._maxiters))
+        return samples
+
+    def sample_device(self, engine, n, seed, epoch, maxiter=None):
+        if not hasattr(self._dist, "sample_device") or not getattr(self._model, "_native", False):
+            raise NotImplementedError
+        x, failed = self._dist.sample_device(engine, n, seed, epoch, self._model._native_desc(), True,
+                                             self._maxiters if maxiter is None else maxiter)
+        if failed:
+            raise RuntimeError("Did not successfully postselect within {} iterations.".format(self._maxiters))
+        return x, failed
+
+    def grad_log_pdf(self, x):
+        return self._dist.grad_log_pdf(x)
+
+
+class ParticleDistribution(Distribution):
+    """A weighted particle cloud resident on the GPU.
+
+    Public constructor signature as the reference's (`n_mps` XOR locations+weights, NumPy in).
+    """
+
+    def __init__(self, n_mps=None, particle_locations=None, particle_weights=None):
+        from .engine import get_engine
+        self._eng = get_engine()
+        self._moments_cache = None
+        if particle_locations is None or particle_weights is None:
+            locs = np.zeros((1, n_mps))
+            w = np.ones((1,))
+        elif n_mps is None:
+            locs = np.asarray(particle_locations, dtype=np.float64)
+            w = np.abs(np.asarray(particle_weights, dtype=np.float64))
+            w = w / np.sum(w) if w.size else w
+        else:
+            raise ValueError('Either the dimension of parameter space, `n_mps`, or the particles, '
+                             '`particle_locations` and `particle_weights` must be specified.')
+        self._set_host(locs, w)
+
+    # ---------------------------------------------------------------- device state plumbing
+    @classmethod
+    def _from_device(cls, engine, x, w, norm=1.0, sumsq=None):
+        self = cls.__new__(cls)
+        self._eng = engine
+        self._x, self._w, self._norm, self._sumsq = x, w, float(norm), sumsq
+        self._w_alt = None
+        self._moments_cache = None
+        return self
+
+    def _set_host(self, locs, w):
+        locs = np.asarray(locs, dtype=np.float64)
+        if locs.ndim != 2:
+            raise ValueError("particle_locations must have shape (n_particles, n_modelparams)")
+        self._x = self._eng.locs_to_soa(locs)
+        self._w = self._eng.to_device(np.asarray(w, dtype=np.float64))
+        self._w_alt = None
+        self._norm = 1.0
+        self._sumsq = None
+        self._moments_cache = None
+
+    def _invalidate(self):
+        self._moments_cache = None
+
+    def _scratch_weights(self):
+        if self._w_alt is None or self._w_alt.shape != self._w.shape:
+            self._w_alt = self._eng.empty(self._w.shape[0])
+        return self._w_alt
+
+    # ---------------------------------------------------------------- reference attributes
+    @property
+    def particle_locations(self):
+        """(N, d) NumPy COPY of the cloud (D2H).  Assign a whole array to change it."""
+        return np.ascontiguousarray(self._x.cpu().numpy().T)
+
+    @particle_locations.setter
+    def particle_locations(self, locs):
+        locs = np.asarray(locs, dtype=np.float64)
+        self._x = self._eng.locs_to_soa(locs)
+        self._invalidate()
+
+    @property
+    def particle_weights(self):
+        """(N,) NumPy COPY of the normalised weights (D2H)."""
+        if self._w.shape[0] == 0:
+            return np.zeros((0,))
+        return self._eng.normalized_weights(self._w, self._norm).cpu().numpy()
+
+    @particle_weights.setter
+    def particle_weights(self, w):
+        self._w = self._eng.to_device(np.asarray(w, dtype=np.float64))
+        self._w_alt = None
+        self._norm = 1.0
+        self._sumsq = None
+        self._invalidate()
+
+    @property
+    def n_particles(self):
+        return int(self._x.shape[1])
+
+    @property
+    def n_rvs(self):
+        return int(self._x.shape[0])
+
+    @property
+    def n_ess(self):
+        """1 / sum_i w_i^2 of the normalised weights."""
+        if self._sumsq is None:
+            st = self._eng.weight_stats(self._w, self._norm)
+            self._sumsq = st.sumsq * self._norm * self._norm     # keep it in unnormalised units
+        return self._ess_from(self._sumsq)
+
+    def _ess_from(self, sumsq_unnormalised):
+        with np.errstate(divide='ignore'):
+            return np.float64(self._norm) * np.float64(self._norm) / np.float64(sumsq_unnormalised)
+
+    # ---------------------------------------------------------------- moments
+    def _moments(self):
+        if self._moments_cache is None:
+            s0, s1, s2 = self._eng.moments(self._x, self._w, self._norm)
+            self._moments_cache = (s0, s1, s2)
+        return self._moments_cache
+
+    @staticmethod
+    def particle_mean(weights, locations):
+        """Weighted mean of host arrays, evaluated on the GPU."""
+        from .engine import get_engine
+        eng = get_engine()
+        x = eng.locs_to_soa(np.asarray(locations, dtype=np.float64))
+        w = eng.to_device(np.asarray(weights, dtype=np.float64))
+        return eng.moments(x, w, 1.0)[1]
+
+    @classmethod
+    def particle_covariance_mtx(cls, weights, locations):
+        from .engine import get_engine
+        eng = get_engine()
+        x = eng.locs_to_soa(np.asarray(locations, dtype=np.float64))
+        w = eng.to_device(np.asarray(weights, dtype=np.float64))
+        _, s1, s2 = eng.moments(x, w, 1.0)
+        return cls._cov_from_sums(s1, s2)
+
+    @staticmethod
+    def _cov_from_sums(s1, s2):
+        cov = s2 - np.outer(s1, s1)                       # E[x x^T] - mu mu^T (distributions.py:386-390)
+        assert np.all(np.isfinite(cov))
+        if not np.all(np.linalg.eigvals(cov) >= 0):
+            warnings.warn('Numerical error in covariance estimation causing positive semidefinite '
+                          'violation.', ApproximationWarning)
+        return cov
+
+    def est_mean(self):
+        return self._moments()[1].copy()
+
+    def est_covariance_mtx(self, corr=False):
+        _, s1, s2 = self._moments()
+        cov = self._cov_from_sums(s1, s2)
+        if corr:
+            dstd = np.sqrt(np.diag(cov))
+            cov = cov / np.outer(dstd, dstd)
+        return cov
+
+    def est_meanfn(self, fn):
+        """E[fn(x)] for a host-vectorised fn (plugin slow path: evaluates fn on a host copy)."""
+        vals = np.asarray(fn(self.particle_locations))
+        return np.einsum('i...,i...', self.particle_weights, vals)
+
+    def est_entropy(self):
+        t = self._eng.torch
+        w = self._eng.normalized_weights(self._w, self._norm)
+        nz = w[w > 0]
+        return float(-(t.log(nz) * nz).sum().item())
+
+    # ---------------------------------------------------------------- sampling
+    def sample(self, n=1):
+        """n draws from the cloud by inverse CDF (uniforms from the legacy global RNG)."""
+        cdf = self._eng.cumsum(self._w, self._norm)
+        u = self._eng.to_device(np.random.random((n,)))
+        js = self._eng.lw_ancestors(cdf, u)
+        return np.ascontiguousarray(self._x[:, js].cpu().numpy().T)

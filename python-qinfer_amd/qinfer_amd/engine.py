@@ -1,0 +1,231 @@
+"""Device engine: owns the libqsmc_hip handle for one GPU and wraps each C-ABI entry point so
+that it takes PyTorch-ROCm tensors (used ONLY as device-memory owners + stream providers).
+
+Layout contract: particle locations are SoA `x[d, N]` float64 contiguous,
+weights `w[N]` float64, kept unnormalised with a host-side normaliser.
+"""
+import ctypes as C
+import threading
+
+import numpy as np
+
+from . import _native
+from ._exceptions import NativeLibraryError
+
+_engines = {}
+_lock = threading.Lock()
+
+
+def get_engine(device=None):
+    """Engine for `device` (int index, torch.device or None = current)."""
+    import torch
+    if not torch.cuda.is_available():
+        raise NativeLibraryError(
+            "qinfer_amd needs an AMD GPU (torch.cuda.is_available() is False). The SMC path runs "
+            "only on the HIP kernels in libqsmc_hip.so; there is no CPU fallback.")
+    if device is None:
+        idx = torch.cuda.current_device()
+    elif isinstance(device, int):
+        idx = device
+    else:
+        dev = torch.device(device)
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    with _lock:
+        if idx not in _engines:
+            _engines[idx] = Engine(idx)
+        return _engines[idx]
+
+
+class Engine:
+    def __init__(self, index):
+        import torch
+        self.torch = torch
+        self.lib = _native.load()
+        self.index = index
+        self.device = torch.device("cuda", index)
+        h = C.c_void_p()
+        _native.check(None, self.lib.qsmc_create(C.byref(h), index), "qsmc_create")
+        self.h = h
+        self._stats = torch.empty(4, dtype=torch.float64, device=self.device)
+
+    # ------------------------------------------------------------------ memory / streams
+    def stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def empty(self, *shape, dtype=None):
+        return self.torch.empty(*shape, dtype=dtype or self.torch.float64, device=self.device)
+
+    def to_device(self, arr, dtype=None):
+        t = self.torch.from_numpy(np.ascontiguousarray(arr))
+        if dtype is not None:
+            t = t.to(dtype)
+        return t.to(self.device)
+
+    def locs_to_soa(self, locs):
+        """(N, d) host AoS -> (d, N) device SoA."""
+        locs = np.asarray(locs, dtype=np.float64)
+        return self.to_device(np.ascontiguousarray(locs.T))
+
+    @staticmethod
+    def _p(t):
+        return C.c_void_p(t.data_ptr())
+
+    def _chk(self, rc, what):
+        _native.check(self.h, rc, what)
+
+    # ------------------------------------------------------------------ profiling hooks (bench.py)
+    def set_profiling(self, enabled):
+        self._chk(self.lib.qsmc_set_profiling(self.h, int(bool(enabled))), "qsmc_set_profiling")
+
+    def last_update_kernel_ms(self):
+        ms = C.c_float()
+        self._chk(self.lib.qsmc_last_update_kernel_ms(self.h, C.byref(ms)), "qsmc_last_update_kernel_ms")
+        return ms.value
+
+    # ------------------------------------------------------------------ likelihood / validity
+    def likelihood(self, desc, x, exps, outcomes):
+        """L[n_o, n_e, N] on device for SoA x; `exps` list of ExpParam, `outcomes` int sequence."""
+        n = x.shape[1]
+        n_e, n_o = len(exps), len(outcomes)
+        out = self.empty(n_o, n_e, n)
+        if n == 0 or n_e == 0 or n_o == 0:
+            return out
+        ep = (_native.ExpParam * n_e)(*exps)
+        oc = (C.c_int64 * n_o)(*[int(o) for o in outcomes])
+        self._chk(self.lib.qsmc_likelihood(self.h, C.byref(desc), self._p(x), x.stride(0), n, ep, n_e,
+                                           oc, n_o, self._p(out), self.stream()), "qsmc_likelihood")
+        return out
+
+    def are_models_valid(self, desc, x):
+        n = x.shape[1]
+        out = self.empty(n, dtype=self.torch.uint8)
+        if n:
+            self._chk(self.lib.qsmc_are_models_valid(self.h, C.byref(desc), self._p(x), x.stride(0), n,
+                                                     self._p(out), self.stream()), "qsmc_are_models_valid")
+        return out
+
+    # ------------------------------------------------------------------ weight passes
+    def update_fused(self, desc, x, w_in, w_out, prev_norm, exp, outcome, sync=True):
+        st = _native.UpdateStats()
+        self._chk(self.lib.qsmc_update_fused(
+            self.h, C.byref(desc), self._p(x), x.stride(0), x.shape[1], self._p(w_in), self._p(w_out),
+            float(prev_norm), C.byref(exp), int(outcome), self._p(self._stats),
+            C.byref(st) if sync else None, self.stream()), "qsmc_update_fused")
+        return st if sync else None
+
+    def update_from_likelihood(self, L, w_in, w_out, prev_norm):
+        st = _native.UpdateStats()
+        self._chk(self.lib.qsmc_update_from_likelihood(
+            self.h, self._p(L), w_in.shape[0], self._p(w_in), self._p(w_out), float(prev_norm),
+            self._p(self._stats), C.byref(st), self.stream()), "qsmc_update_from_likelihood")
+        return st
+
+    def clip_weights(self, w, norm):
+        st = _native.UpdateStats()
+        self._chk(self.lib.qsmc_clip_weights(self.h, self._p(w), w.shape[0], float(norm),
+                                             self._p(self._stats), C.byref(st), self.stream()),
+                  "qsmc_clip_weights")
+        return st
+
+    def weight_stats(self, w, norm):
+        st = _native.UpdateStats()
+        self._chk(self.lib.qsmc_weight_stats(self.h, self._p(w), w.shape[0], float(norm),
+                                             self._p(self._stats), C.byref(st), self.stream()),
+                  "qsmc_weight_stats")
+        return st
+
+    def normalized_weights(self, w, norm):
+        out = self.empty(w.shape[0])
+        self._chk(self.lib.qsmc_normalize_weights(self.h, self._p(w), self._p(out), w.shape[0],
+                                                  float(norm), self.stream()), "qsmc_normalize_weights")
+        return out
+
+    def fill(self, w, value):
+        self._chk(self.lib.qsmc_fill(self.h, self._p(w), w.shape[0], float(value), self.stream()),
+                  "qsmc_fill")
+
+    # ------------------------------------------------------------------ moments
+    def moments(self, x, w, norm):
+        """Returns host (sum_w, S1[d], S2[d, d]) of the normalised weights."""
+        d, n = x.shape
+        k = 1 + d + d * (d + 1) // 2
+        out = np.empty(k, dtype=np.float64)
+        self._chk(self.lib.qsmc_moments(self.h, self._p(x), x.stride(0), n, d, self._p(w), float(norm),
+                                        None, _native.f64_ptr(out), self.stream()), "qsmc_moments")
+        s1 = out[1:1 + d].copy()
+        s2 = np.zeros((d, d))
+        iu = np.triu_indices(d)
+        s2[iu] = out[1 + d:]
+        s2 = s2 + np.triu(s2, 1).T
+        return float(out[0]), s1, s2
+
+    def sqrtm_psd(self, A, scale=1.0):
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        d = A.shape[0]
+        S = np.empty((d, d))
+        err = C.c_double()
+        self._chk(self.lib.qsmc_sqrtm_psd(_native.f64_ptr(A), d, float(scale), _native.f64_ptr(S),
+                                          C.byref(err)), "qsmc_sqrtm_psd")
+        return S, err.value
+
+    # ------------------------------------------------------------------ Liu-West pieces
+    def cumsum(self, w, norm):
+        cdf = self.empty(w.shape[0])
+        self._chk(self.lib.qsmc_cumsum(self.h, self._p(w), w.shape[0], float(norm), self._p(cdf),
+                                       self.stream()), "qsmc_cumsum")
+        return cdf
+
+    def lw_ancestors(self, cdf, u):
+        js = self.empty(u.shape[0], dtype=self.torch.int64)
+        self._chk(self.lib.qsmc_lw_ancestors(self.h, self._p(cdf), cdf.shape[0], self._p(u), u.shape[0],
+                                             self._p(js), self.stream()), "qsmc_lw_ancestors")
+        return js
+
+    def lw_centres(self, x_in, js, a, mean):
+        d = x_in.shape[0]
+        mus = self.empty(d, js.shape[0])
+        mean = np.ascontiguousarray(mean, dtype=np.float64)
+        self._chk(self.lib.qsmc_lw_centres(self.h, self._p(x_in), x_in.stride(0), d, self._p(js),
+                                           js.shape[0], float(a), _native.f64_ptr(mean), self._p(mus),
+                                           mus.stride(0), self.stream()), "qsmc_lw_centres")
+        return mus
+
+    def lw_perturb(self, desc, postselect, mus, idxs, k, centre_by_idx, S, z, x_out):
+        valid = self.empty(k, dtype=self.torch.uint8)
+        S = np.ascontiguousarray(S, dtype=np.float64)
+        self._chk(self.lib.qsmc_lw_perturb(
+            self.h, C.byref(desc), int(bool(postselect)), self._p(mus), mus.stride(0),
+            self._p(idxs) if idxs is not None else None, k, int(bool(centre_by_idx)), _native.f64_ptr(S),
+            self._p(z), z.stride(0), self._p(x_out), x_out.stride(0), self._p(valid), self.stream()),
+            "qsmc_lw_perturb")
+        return valid
+
+    def lw_resample_philox(self, desc, postselect, x_in, cdf, a, mean, S, n_out, seed, epoch, maxiter):
+        d = x_in.shape[0]
+        x_out = self.empty(d, n_out)
+        mean = np.ascontiguousarray(mean, dtype=np.float64)
+        S = np.ascontiguousarray(S, dtype=np.float64)
+        failed = C.c_int64()
+        self._chk(self.lib.qsmc_lw_resample_philox(
+            self.h, C.byref(desc), int(bool(postselect)), self._p(x_in), x_in.stride(0), x_in.shape[1], d,
+            self._p(cdf), float(a), _native.f64_ptr(mean), _native.f64_ptr(S), n_out,
+            C.c_uint64(seed & (2 ** 64 - 1)), C.c_uint64(epoch), int(maxiter), self._p(x_out),
+            x_out.stride(0), C.byref(failed), self.stream()), "qsmc_lw_resample_philox")
+        return x_out, failed.value
+
+    def prior_uniform_philox(self, desc, postselect, lo, hi, n, seed, epoch, maxiter=100):
+        d = len(lo)
+        x_out = self.empty(d, n)
+        lo = np.ascontiguousarray(lo, dtype=np.float64)
+        hi = np.ascontiguousarray(hi, dtype=np.float64)
+        failed = C.c_int64()
+        self._chk(self.lib.qsmc_prior_uniform_philox(
+            self.h, C.byref(desc), int(bool(postselect)), _native.f64_ptr(lo), _native.f64_ptr(hi), d, n,
+            C.c_uint64(seed & (2 ** 64 - 1)), C.c_uint64(epoch), int(maxiter), self._p(x_out),
+            x_out.stride(0), C.byref(failed), self.stream()), "qsmc_prior_uniform_philox")
+        return x_out, failed.value
+
+    def tomo_canonicalize(self, basis_dev, dim, x, allow_subnormalized):
+        self._chk(self.lib.qsmc_tomo_canonicalize(self.h, self._p(basis_dev), dim, self._p(x), x.stride(0),
+                                                  x.shape[1], int(bool(allow_subnormalized)), self.stream()),
+                  "qsmc_tomo_canonicalize")

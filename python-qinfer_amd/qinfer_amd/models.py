@@ -1,0 +1,276 @@
+"""Concrete models on the SMC hot path, each backed by a HIP likelihood kernel.
+
+    SimpleInversionModel / SimplePrecessionModel   reference test_models.py:64-213
+    DerivedModel / BinomialModel                   reference derived_models.py:82-144, 222-360
+    RandomizedBenchmarkingModel                    reference rb.py:81-195
+
+Class names, constructor arguments, `expparams_dtype` record layouts, `modelparam_names`, validity
+rules and the `likelihood` tensor shape are the reference's.  The arithmetic lives in
+`csrc/qsmc_device.h` (one `Model<KIND>` specialisation per class); the methods here only translate
+NumPy `expparams` into the C-ABI's `qsmc_expparam_t`.
+"""
+import numpy as np
+
+from . import _native
+from .abstract_model import FiniteOutcomeModel, Model, NativeModelMixin
+from .domains import IntegerDomain
+
+__all__ = ["SimpleInversionModel", "SimplePrecessionModel", "DerivedModel", "BinomialModel",
+           "RandomizedBenchmarkingModel"]
+
+
+def _field(expparams, name):
+    return np.atleast_1d(expparams[name])
+
+
+class SimpleInversionModel(NativeModelMixin, FiniteOutcomeModel):
+    r"""Qubit precessing under H = omega sigma_z / 2, inverted by w_ before measurement:
+    Pr(0 | omega; t, w_) = cos^2(t (omega - w_) / 2).  Valid iff omega > min_freq."""
+
+    def __init__(self, min_freq=0):
+        super().__init__()
+        self._min_freq = min_freq
+
+    @property
+    def n_modelparams(self):
+        return 1
+
+    @property
+    def modelparam_names(self):
+        return [r'\omega']
+
+    @property
+    def expparams_dtype(self):
+        return [('t', 'float'), ('w_', 'float')]
+
+    @property
+    def is_n_outcomes_constant(self):
+        return True
+
+    def n_outcomes(self, expparams):
+        return 2
+
+    # native hooks
+    def _native_desc(self):
+        return _native.ModelDesc(_native.MODEL_PRECESSION, 1, float(self._min_freq), 0, 0)
+
+    def _native_expparams(self, expparams):
+        expparams = np.atleast_1d(expparams)
+        ts, ws = _field(expparams, 't'), _field(expparams, 'w_')
+        return [_native.make_expparam(t=t, w_=w) for t, w in zip(ts, ws)]
+
+    # NumPy contract, served by the kernels
+    def are_models_valid(self, modelparams):
+        return self._native_are_models_valid(modelparams)
+
+    def likelihood(self, outcomes, modelparams, expparams):
+        super().likelihood(outcomes, modelparams, expparams)
+        return self._native_likelihood(outcomes, modelparams, expparams)
+
+
+class SimplePrecessionModel(SimpleInversionModel):
+    r"""SimpleInversionModel with w_ = 0 and a scalar experiment parameter t."""
+
+    @property
+    def expparams_dtype(self):
+        return 'float'
+
+    def _native_expparams(self, expparams):
+        expparams = np.atleast_1d(expparams)
+        ts = expparams['t'] if expparams.dtype.names else expparams
+        return [_native.make_expparam(t=t, w_=0.0) for t in np.atleast_1d(ts).astype(np.float64)]
+
+
+class DerivedModel(Model):
+    """Base for models that decorate another model: passes everything through by default."""
+
+    _underlying_model = None
+
+    def __init__(self, underlying_model):
+        self._underlying_model = underlying_model
+        super().__init__()
+
+    @property
+    def underlying_model(self):
+        return self._underlying_model
+
+    @property
+    def base_model(self):
+        return self._underlying_model.base_model
+
+    @property
+    def model_chain(self):
+        return self._underlying_model.model_chain + (self._underlying_model,)
+
+    @property
+    def n_modelparams(self):
+        return self._underlying_model.n_modelparams
+
+    @property
+    def expparams_dtype(self):
+        return self._underlying_model.expparams_dtype
+
+    @property
+    def modelparam_names(self):
+        return self._underlying_model.modelparam_names
+
+    @property
+    def Q(self):
+        return self._underlying_model.Q
+
+    def clear_cache(self):
+        self._underlying_model.clear_cache()
+
+    def n_outcomes(self, expparams):
+        return self._underlying_model.n_outcomes(expparams)
+
+    def are_models_valid(self, modelparams):
+        return self._underlying_model.are_models_valid(modelparams)
+
+    def domain(self, expparams):
+        return self._underlying_model.domain(expparams)
+
+    def are_expparam_dtypes_consistent(self, expparams):
+        return self._underlying_model.are_expparam_dtypes_consistent(expparams)
+
+    def update_timestep(self, modelparams, expparams):
+        return self._underlying_model.update_timestep(modelparams, expparams)
+
+    def canonicalize(self, modelparams):
+        return self._underlying_model.canonicalize(modelparams)
+
+    def simulate_experiment(self, modelparams, expparams, repeat=1):
+        return self._underlying_model.simulate_experiment(modelparams, expparams, repeat)
+
+
+class BinomialModel(NativeModelMixin, DerivedModel):
+    """n_meas i.i.d. shots of a two-outcome model: L[k] = Binom(n_meas, pr1).pmf(k), where pr1 is
+    the underlying model's likelihood of outcome 1.  Adds the `n_meas` experiment field (and names
+    a scalar underlying experiment parameter `x`).
+
+    Native (fully on the GPU) when the decorated model is a SimplePrecessionModel -- the
+    BASELINE config-3 model.  Other two-outcome models go through the plugin slow path.
+    """
+
+    def __init__(self, underlying_model):
+        super().__init__(underlying_model)
+        if not (underlying_model.is_n_outcomes_constant and underlying_model.n_outcomes(None) == 2):
+            raise ValueError("Decorated model must be a two-outcome model.")
+        if isinstance(underlying_model.expparams_dtype, str):
+            self._expparams_scalar = True
+            self._expparams_dtype = [('x', underlying_model.expparams_dtype), ('n_meas', 'uint')]
+        else:
+            self._expparams_scalar = False
+            self._expparams_dtype = underlying_model.expparams_dtype + [('n_meas', 'uint')]
+        self._native = type(underlying_model) is SimplePrecessionModel
+
+    @property
+    def decorated_model(self):
+        return self.underlying_model
+
+    @property
+    def expparams_dtype(self):
+        return self._expparams_dtype
+
+    @property
+    def is_n_outcomes_constant(self):
+        return False
+
+    def n_outcomes(self, expparams):
+        return expparams['n_meas'] + 1
+
+    def domain(self, expparams):
+        return [IntegerDomain(min=0, max=int(n) - 1) for n in np.atleast_1d(self.n_outcomes(expparams))]
+
+    def are_expparam_dtypes_consistent(self, expparams):
+        return True
+
+    def _underlying_expparams(self, expparams):
+        return expparams['x'] if self._expparams_scalar else expparams
+
+    # native hooks
+    def _native_desc(self):
+        um = self.underlying_model
+        return _native.ModelDesc(_native.MODEL_BINOMIAL_PRECESSION, 1, float(um._min_freq), 0, 0)
+
+    def _native_expparams(self, expparams):
+        expparams = np.atleast_1d(expparams)
+        return [_native.make_expparam(t=t, w_=0.0, n_meas=n)
+                for t, n in zip(_field(expparams, 'x'), _field(expparams, 'n_meas'))]
+
+    def likelihood(self, outcomes, modelparams, expparams):
+        Model.likelihood(self, outcomes, modelparams, expparams)
+        if self._native:
+            return self._native_likelihood(outcomes, modelparams, expparams)
+        # plugin slow path for an arbitrary decorated model (host arithmetic, like any user Model)
+        from scipy.stats import binom
+        pr1 = self.underlying_model.likelihood(np.array([1], dtype='uint'), modelparams,
+                                               self._underlying_expparams(expparams))
+        outcomes = np.atleast_1d(outcomes)
+        return np.concatenate([binom(expparams['n_meas'][np.newaxis, :], pr1).pmf(outcomes[i])
+                               for i in range(outcomes.shape[0])])
+
+    def are_models_valid(self, modelparams):
+        if self._native:
+            return self._native_are_models_valid(modelparams)
+        return self.underlying_model.are_models_valid(modelparams)
+
+    def simulate_experiment(self, modelparams, expparams, repeat=1):
+        """Binomial draws from pr1 (legacy global RNG, like derived_models.py:331-355)."""
+        pr1 = self.underlying_model.likelihood(np.array([1], dtype='uint'), modelparams,
+                                               self._underlying_expparams(expparams))[0]
+        n = expparams['n_meas'].astype('int')[np.newaxis, :]
+        os_ = np.stack([np.random.binomial(np.broadcast_to(n, pr1.shape), pr1) for _ in range(repeat)])
+        return os_[0, 0, 0] if os_.size == 1 else os_
+
+    def update_timestep(self, modelparams, expparams):
+        return self.underlying_model.update_timestep(modelparams, self._underlying_expparams(expparams))
+
+
+class RandomizedBenchmarkingModel(NativeModelMixin, FiniteOutcomeModel):
+    r"""Zeroth-order (interleaved) randomized benchmarking: Pr(0) = 1 - (A p^m + B).
+
+    Model parameters (p, A, B), or (p_tilde, p_ref, A, B) when `interleaved=True`, in which case
+    the experiment field `reference` selects p_ref (True) or p_tilde * p_ref (False)."""
+
+    def __init__(self, interleaved=False, order=0):
+        self._il = bool(interleaved)
+        if order != 0:
+            raise NotImplementedError("Only zeroth-order is currently implemented.")
+        super().__init__()
+
+    @property
+    def n_modelparams(self):
+        return 4 if self._il else 3
+
+    @property
+    def modelparam_names(self):
+        return [r'\tilde{p}', 'p', 'A', 'B'] if self._il else ['p', 'A', 'B']
+
+    @property
+    def is_n_outcomes_constant(self):
+        return True
+
+    @property
+    def expparams_dtype(self):
+        return [('m', 'uint')] + ([('reference', bool)] if self._il else [])
+
+    def n_outcomes(self, expparams):
+        return 2
+
+    def _native_desc(self):
+        kind = _native.MODEL_RB_INTERLEAVED if self._il else _native.MODEL_RB
+        return _native.ModelDesc(kind, self.n_modelparams, 0.0, 0, 0)
+
+    def _native_expparams(self, expparams):
+        expparams = np.atleast_1d(expparams)
+        ms = _field(expparams, 'm')
+        refs = _field(expparams, 'reference') if self._il else np.zeros(ms.shape, dtype=bool)
+        return [_native.make_expparam(m=m, reference=int(bool(r))) for m, r in zip(ms, refs)]
+
+    def are_models_valid(self, modelparams):
+        return self._native_are_models_valid(modelparams)
+
+    def likelihood(self, outcomes, modelparams, expparams):
+        super().likelihood(outcomes, modelparams, expparams)
+        return self._native_likelihood(outcomes, modelparams, expparams)

@@ -1,0 +1,161 @@
+"""Resamplers.  `Resampler` ABC and `LiuWestResampler` with the reference's constructor and call
+signatures (resamplers.py:73-95, 171-392); the work runs in HIP kernels:
+
+    moments (one fused pass) -> host sqrtm_psd (d x d) -> device scan of the weights ->
+    ancestor search + Liu-West centres + Gaussian kick + validity mask -> uniform weights.
+
+Two RNG modes:
+
+* legacy (default, `device_rng=False`): uniforms come from `np.random.random` and normals from
+  `kernel(d, k)` on the host, in exactly the order and shapes the reference draws them, and are
+  uploaded.  Seed-for-seed comparable with QInfer (incl. quirk Q1: on a postselection retry the
+  reference re-uses the FIRST k centres, `mus = mus[:k]`, resamplers.py:371-372).
+* device (`device_rng=True`): Philox4x32-10 inside a single kernel launch; an invalid particle
+  redraws its ancestor and kick in-thread.  Statistically equivalent, not stream-identical.
+"""
+import abc
+import warnings
+
+import numpy as np
+
+from ._exceptions import ResamplerError, ResamplerWarning
+from .distributions import ParticleDistribution
+
+__all__ = ["Resampler", "LiuWestResampler"]
+
+
+class Resampler(metaclass=abc.ABCMeta):
+    @abc.abstractmethod
+    def __call__(self, model, particle_dist, n_particles=None, precomputed_mean=None,
+                 precomputed_cov=None):
+        """Return a resampled ParticleDistribution with `n_particles` particles."""
+
+
+class LiuWestResampler(Resampler):
+    r"""Liu & West (2001) kernel-shrinkage resampler: x_i' ~ N(a x_j + (1-a) mu, h^2 Sigma).
+
+    :param float a: shrinkage; `h` defaults to sqrt(1 - a^2) (moment preserving).
+    :param int maxiter: postselection retries before giving up with a ResamplerWarning.
+    :param bool postselect: redraw particles the model declares invalid.
+    :param float zero_cov_comp: diagonal added when the covariance has exactly zero norm.
+    :param callable kernel: host `kernel(d, k)` -> zero-mean unit-variance draws (legacy mode).
+    :param int default_n_particles: output cloud size (None = same as the input).
+    :param bool device_rng: use the on-device Philox generator (see module docstring).
+    :param int seed: Philox key for `device_rng=True`.
+    :param bool legacy_mus_truncation: reproduce quirk Q1 in legacy mode (default True).
+    """
+
+    _override_h = False
+
+    def __init__(self, a=0.98, h=None, maxiter=1000, debug=False, postselect=True, zero_cov_comp=1e-10,
+                 default_n_particles=None, kernel=np.random.randn, device_rng=False, seed=0,
+                 legacy_mus_truncation=True):
+        self._default_n_particles = default_n_particles
+        self.a = a
+        if h is not None:
+            self._override_h = True
+            self._h = h
+        self._maxiter = maxiter
+        self._debug = debug
+        self._postselect = postselect
+        self._zero_cov_comp = zero_cov_comp
+        self._kernel = kernel
+        self._device_rng = bool(device_rng)
+        self._seed = int(seed)
+        self._epoch = 0
+        self._legacy_q1 = bool(legacy_mus_truncation)
+
+    @property
+    def a(self):
+        return self._a
+
+    @a.setter
+    def a(self, new_a):
+        self._a = new_a
+        if not self._override_h:
+            self._h = np.sqrt(1 - new_a ** 2)
+
+    @property
+    def h(self):
+        return self._h
+
+    # ------------------------------------------------------------------------------------------
+    def __call__(self, model, particle_dist, n_particles=None, precomputed_mean=None,
+                 precomputed_cov=None):
+        if not isinstance(particle_dist, ParticleDistribution):
+            raise TypeError("particle_dist must be a qinfer_amd ParticleDistribution")
+        eng = particle_dist._eng
+        mean = particle_dist.est_mean() if precomputed_mean is None else np.asarray(precomputed_mean, float)
+        cov = particle_dist.est_covariance_mtx() if precomputed_cov is None else np.asarray(precomputed_cov, float)
+        if n_particles is None:
+            n_particles = (particle_dist.n_particles if self._default_n_particles is None
+                           else self._default_n_particles)
+        n_particles = int(n_particles)
+        d = particle_dist.n_rvs
+        a, h = self._a, self._h
+        if np.linalg.norm(cov, 'fro') == 0:
+            warnings.warn("Covariance has zero norm; adding in small covariance in resampler. "
+                          "Consider increasing n_particles to improve covariance estimates.",
+                          ResamplerWarning)
+            cov = self._zero_cov_comp * np.eye(d)
+        S, S_err = eng.sqrtm_psd(cov, scale=h)
+        if not np.isfinite(S_err):
+            raise ResamplerError("Infinite error in computing the square root of the covariance "
+                                 "matrix. Check that n_ess is not too small.")
+
+        native = bool(getattr(model, "_native", False))
+        desc = model._native_desc() if native else None
+        x_in, w_in, norm = particle_dist._x, particle_dist._w, particle_dist._norm
+        cdf = eng.cumsum(w_in, norm)
+
+        if self._device_rng and native:
+            self._epoch += 1
+            x_new, n_failed = eng.lw_resample_philox(desc, self._postselect, x_in, cdf, a, mean, S,
+                                                     n_particles, self._seed, self._epoch, self._maxiter)
+        else:
+            x_new, n_failed = self._legacy_draw(eng, model, desc, x_in, cdf, a, mean, S, n_particles)
+        if n_failed:
+            warnings.warn("Liu-West resampling failed to find valid models for {} particles within "
+                          "{} iterations.".format(n_failed, self._maxiter), ResamplerWarning)
+
+        w_new = eng.empty(n_particles)
+        uniform = np.float64(1.0) / np.float64(n_particles)          # np.ones(n) / n
+        eng.fill(w_new, uniform)
+        return ParticleDistribution._from_device(eng, x_new, w_new, norm=1.0,
+                                                 sumsq=float(n_particles * uniform * uniform))
+
+    # ------------------------------------------------------------------------------------------
+    def _legacy_draw(self, eng, model, desc, x_in, cdf, a, mean, S, n_out):
+        """Host-RNG path: same draw order / shapes as resamplers.py:318-372."""
+        from . import _native
+        t = eng.torch
+        d = x_in.shape[0]
+        u = eng.to_device(np.random.random((n_out,)))
+        js = eng.lw_ancestors(cdf, u)
+        mus = eng.lw_centres(x_in, js, a, mean)
+        x_new = eng.empty(d, n_out)
+        kernel_desc = desc if desc is not None else _native.ModelDesc(_native.MODEL_TOMOGRAPHY, d, 0.0, 1, 0)
+        device_valid = desc is not None
+        idxs = None                      # None = identity (first round)
+        k = n_out
+        n_iters = 0
+        while k and n_iters < self._maxiter:
+            n_iters += 1
+            z = eng.to_device(np.asarray(self._kernel(d, k), dtype=np.float64).reshape(d, k))
+            centre_by_idx = (idxs is not None) and (not self._legacy_q1)
+            valid = eng.lw_perturb(kernel_desc, self._postselect and device_valid, mus, idxs, k,
+                                   centre_by_idx, S, z, x_new)
+            if self._postselect and not device_valid:
+                # plugin slow path: the user's are_models_valid decides, on a host copy
+                cols = x_new if idxs is None else x_new[:, idxs]
+                ok = np.asarray(model.are_models_valid(np.ascontiguousarray(cols.cpu().numpy().T)), dtype=bool)
+                assert ok.ndim == 1, "are_models_valid returned tensor, expected vector."
+                valid = eng.to_device(ok.astype(np.uint8))
+            bad = (valid == 0).nonzero(as_tuple=False).reshape(-1)      # ascending, like np.nonzero
+            if bad.numel() == 0:
+                k = 0
+                break
+            idxs = bad if idxs is None else idxs[bad]
+            idxs = idxs.contiguous()
+            k = int(idxs.shape[0])
+        return x_new, k

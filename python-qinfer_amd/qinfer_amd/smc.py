@@ -1,0 +1,365 @@
+"""SMCUpdater: sequential Monte Carlo Bayes updates on a GPU-resident particle cloud.
+
+Drop-in for the reference's `qinfer.smc.SMCUpdater` (smc.py:97-551): same constructor, methods,
+properties, warnings and exceptions.  Differences are under the hood:
+
+* one fused kernel per datum: likelihood x weight multiply x (sum, sum of squares, min, #bad)
+  reductions -- the reference does ~25 NumPy passes for the same thing;
+* weights live unnormalised in HBM (`true w = w / norm`); every quantity the reference derives
+  from normalised weights (norm record, n_ess, zero-weight test) comes from the in-kernel sums;
+* `particle_locations` / `particle_weights` are properties returning NumPy copies -- mutate by
+  assigning a whole array.
+
+Extension kwargs (all default to reference behaviour): `device_rng`/`seed` switch prior sampling
+and the default resampler to the on-device Philox generator; `comm` shards the cloud across ranks
+(see parallel.py).
+"""
+import warnings
+
+import numpy as np
+
+from . import _native
+from ._exceptions import ApproximationWarning, ResamplerWarning
+from .abstract_model import Simulatable
+from .distributions import ParticleDistribution
+from .resamplers import LiuWestResampler
+
+__all__ = ["SMCUpdater"]
+
+_EPS = float(np.spacing(1))
+
+
+def _as_int_outcome(outcome):
+    arr = np.asarray(outcome)
+    if arr.size != 1:
+        raise ValueError("update() takes a single outcome; use batch_update for several")
+    return int(arr.reshape(-1)[0])
+
+
+class SMCUpdater(ParticleDistribution):
+    def __init__(self, model, n_particles, prior, resample_a=None, resampler=None, resample_thresh=0.5,
+                 debug_resampling=False, track_resampling_divergence=False, zero_weight_policy='error',
+                 zero_weight_thresh=None, canonicalize=True, device_rng=False, seed=0, comm=None):
+        from .engine import get_engine
+        self._eng = get_engine()
+        self._comm = comm
+        self._moments_cache = None
+        self._x = self._eng.empty(model.n_modelparams, 0)
+        self._w = self._eng.empty(0)
+        self._w_alt = None
+        self._norm, self._sumsq = 1.0, None
+
+        self._resample_count = 0
+        self._min_n_ess = n_particles if comm is None else n_particles * comm.world_size
+        self.model = model
+        self.prior = prior
+        self._canonicalize = bool(canonicalize)
+        self._device_rng = bool(device_rng)
+        self._seed = int(seed)
+        self._prior_epoch = 0
+
+        self._debug_resampling = debug_resampling
+        if resample_a is not None:
+            warnings.warn("The 'resample_a' keyword argument is deprecated; use "
+                          "'resampler=LiuWestResampler(a)' instead.", DeprecationWarning)
+            if resampler is not None:
+                raise ValueError("Both a resample_a and an explicit resampler were provided; please "
+                                 "provide only one.")
+            self.resampler = LiuWestResampler(a=resample_a, device_rng=device_rng, seed=seed)
+        elif resampler is None:
+            self.resampler = LiuWestResampler(default_n_particles=n_particles, device_rng=device_rng,
+                                              seed=seed)
+        else:
+            self.resampler = resampler
+        self.resample_thresh = resample_thresh
+
+        self._just_resampled = False
+        self._data_record = []
+        self._normalization_record = []
+        self._resampling_divergences = [] if track_resampling_divergence else None
+        if track_resampling_divergence:
+            warnings.warn("track_resampling_divergence needs an O(N^2) kernel-density estimate and "
+                          "is not supported on the GPU path; divergences will not be recorded.",
+                          ApproximationWarning)
+        self._zero_weight_policy = zero_weight_policy
+        self._zero_weight_thresh = (zero_weight_thresh if zero_weight_thresh is not None
+                                    else 10 * np.spacing(1))
+        self._native = bool(getattr(model, "_native", False))
+        self._desc = model._native_desc() if self._native else None
+        self.reset(n_particles)
+
+    # ------------------------------------------------------------------ bookkeeping properties
+    @property
+    def resample_count(self):
+        return self._resample_count
+
+    @property
+    def just_resampled(self):
+        return self._just_resampled
+
+    @property
+    def normalization_record(self):
+        return self._normalization_record
+
+    @property
+    def log_total_likelihood(self):
+        return np.sum(np.log(self.normalization_record))
+
+    @property
+    def min_n_ess(self):
+        return self._min_n_ess
+
+    @property
+    def data_record(self):
+        return self._data_record[:]
+
+    @property
+    def resampling_divergences(self):
+        return self._resampling_divergences
+
+    @property
+    def n_particles_global(self):
+        n = self.n_particles
+        return n if self._comm is None else n * self._comm.world_size
+
+    # ------------------------------------------------------------------ sharding hooks
+    def _reduce_stats(self, st):
+        """Combine per-shard update sums across ranks (RCCL all-reduce of 4 doubles)."""
+        if self._comm is None:
+            return st.sum, st.sumsq, st.min, st.n_bad
+        s = self._comm.allreduce_update_stats(self._eng, st.sum, st.sumsq, st.min, st.n_bad)
+        return s
+
+    def _moments(self):
+        if self._moments_cache is None:
+            if self._comm is None:
+                self._moments_cache = self._eng.moments(self._x, self._w, self._norm)
+            else:
+                self._moments_cache = self._comm.allreduce_moments(
+                    self._eng, *self._eng.moments(self._x, self._w, self._norm))
+        return self._moments_cache
+
+    @property
+    def n_ess(self):
+        if self._sumsq is None:
+            st = self._eng.weight_stats(self._w, self._norm)
+            sumsq = st.sumsq * self._norm * self._norm
+            if self._comm is not None:
+                sumsq = self._comm.allreduce_scalar(self._eng, sumsq)
+            self._sumsq = sumsq
+        return self._ess_from(self._sumsq)
+
+    # ------------------------------------------------------------------ initialisation
+    def reset(self, n_particles=None, only_params=None, reset_weights=True):
+        """Redraw locations (and weights) from the prior (smc.py:281-320)."""
+        if n_particles is not None and only_params is not None:
+            raise ValueError("Cannot set both n_particles and only_params.")
+        if n_particles is None:
+            n_particles = self.n_particles
+        eng = self._eng
+        d = self.model.n_modelparams
+        n_total = n_particles if self._comm is None else n_particles * self._comm.world_size
+        if reset_weights:
+            self._w = eng.empty(n_particles)
+            uniform = np.float64(1.0) / np.float64(n_total)
+            eng.fill(self._w, uniform)
+            self._w_alt = None
+            self._norm = 1.0
+            self._sumsq = float(n_total * uniform * uniform)
+        x_new = None
+        if self._device_rng and hasattr(self.prior, "sample_device"):
+            try:
+                self._prior_epoch += 1
+                rank = 0 if self._comm is None else self._comm.rank
+                x_new, _ = self.prior.sample_device(eng, n_particles, self._seed + 0x9E3779B97F4A7C15 * (rank + 1),
+                                                    self._prior_epoch)
+            except NotImplementedError:
+                x_new = None
+        if x_new is None:
+            x_new = eng.locs_to_soa(np.asarray(self.prior.sample(n=n_particles), dtype=np.float64))
+        if only_params is None:
+            self._x = x_new
+            rows = slice(None)
+        else:
+            rows = only_params
+            self._x[rows, :] = x_new[rows, :]
+        self._invalidate()
+        if self._canonicalize:
+            self._canonicalize_device(rows)
+
+    @staticmethod
+    def _canonicalize_is_identity(model):
+        from .models import DerivedModel
+        m = model
+        while m is not None:
+            fn = type(m).canonicalize
+            if fn is Simulatable.canonicalize:
+                return True
+            if fn is DerivedModel.canonicalize:
+                m = m.underlying_model
+                continue
+            return False
+        return True
+
+    def _canonicalize_device(self, rows=slice(None)):
+        model = self.model
+        if self._canonicalize_is_identity(model):
+            return                                    # every hot-path model except tomography
+        if getattr(model, "_native", False) and hasattr(model, "_native_canonicalize_") and rows == slice(None):
+            model._native_canonicalize_(self._eng, self._x)
+        else:                                         # plugin slow path
+            locs = self.particle_locations
+            locs[:, rows] = model.canonicalize(locs[:, rows])
+            self._x = self._eng.locs_to_soa(locs)
+        self._invalidate()
+
+    # ------------------------------------------------------------------ updates
+    def hypothetical_update(self, outcomes, expparams, return_likelihood=False, return_normalization=False):
+        """Posterior weights for hypothetical data: arrays of shape (n_outcomes, n_expparams,
+        n_particles) on the HOST, as in smc.py:324-386."""
+        if not isinstance(outcomes, np.ndarray):
+            outcomes = np.array([outcomes])
+        eng, t = self._eng, self._eng.torch
+        L = self._device_likelihood(outcomes, expparams)               # (n_o, n_e, N) device
+        w = eng.normalized_weights(self._w, self._norm)
+        hyp = w * L
+        norm_scale = hyp.sum(dim=2, keepdim=True)
+        if self._comm is not None:
+            norm_scale = self._comm.allreduce_tensor(norm_scale)
+        fixed = t.where(norm_scale.abs() < _EPS, t.ones_like(norm_scale), norm_scale)
+        out = [(hyp / fixed).cpu().numpy()]
+        if return_likelihood:
+            out.append(L.cpu().numpy())
+        if return_normalization:
+            out.append(norm_scale.cpu().numpy())
+        return out[0] if len(out) == 1 else tuple(out)
+
+    def _device_likelihood(self, outcomes, expparams):
+        outcomes = np.atleast_1d(np.asarray(outcomes)).ravel()
+        if self._native:
+            return self._eng.likelihood(self._desc, self._x, self.model._native_expparams(expparams),
+                                        outcomes.astype(np.int64))
+        L = np.asarray(self.model.likelihood(outcomes, self.particle_locations, expparams), dtype=np.float64)
+        return self._eng.to_device(np.ascontiguousarray(L.transpose(0, 2, 1)))
+
+    def update(self, outcome, expparams, check_for_resample=True):
+        """One Bayes step (smc.py:388-457)."""
+        self._data_record.append(outcome)
+        self._just_resampled = False
+        eng = self._eng
+        w_out = self._scratch_weights()
+        if self._native:
+            exps = self.model._native_expparams(expparams)
+            if len(exps) != 1:
+                raise ValueError("update() takes exactly one experiment")
+            st = eng.update_fused(self._desc, self._x, self._w, w_out, self._norm, exps[0],
+                                  _as_int_outcome(outcome))
+        else:
+            L = self._device_likelihood(outcome, expparams)
+            if L.shape[0] != 1 or L.shape[1] != 1:
+                raise ValueError("update() takes exactly one outcome and one experiment")
+            st = eng.update_from_likelihood(L.reshape(-1), self._w, w_out, self._norm)
+        norm, sumsq, wmin, n_bad = self._reduce_stats(st)
+        fixed = 1.0 if abs(norm) < _EPS else norm                    # smc.py:369-370
+        new_norm = fixed
+
+        if n_bad > 0:                                                # smc.py:416-418
+            warnings.warn("Negative weights occured in particle approximation. Smallest weight observed "
+                          "== {}. Clipping weights.".format(wmin / fixed), ApproximationWarning)
+            cst = eng.clip_weights(w_out, fixed)
+            sum_w, sumsq, _, _ = self._reduce_stats(cst)
+            new_norm = 1.0                                           # clipped weights are stored as-is
+        else:
+            sum_w = norm / fixed
+
+        if sum_w <= self._zero_weight_thresh or not (sum_w == sum_w):   # smc.py:423-436
+            pol = self._zero_weight_policy
+            if pol == 'ignore':
+                pass
+            elif pol == 'skip':
+                return
+            elif pol == 'warn':
+                warnings.warn("All particle weights are zero. This will very likely fail quite badly.",
+                              ApproximationWarning)
+            elif pol == 'error':
+                raise RuntimeError("All particle weights are zero.")
+            elif pol == 'reset':
+                warnings.warn("All particle weights are zero. Resetting from initial prior.",
+                              ApproximationWarning)
+                self.reset(reset_weights=False)
+            else:
+                raise ValueError("Invalid zero-weight policy {} encountered.".format(pol))
+
+        # commit: swap the weight buffers (smc.py:441)
+        self._w, self._w_alt = w_out, self._w
+        self._norm = float(new_norm)
+        self._sumsq = float(sumsq)
+        self._invalidate()
+        self._normalization_record.append(norm)                      # smc.py:444
+
+        if not self._native and type(self.model).update_timestep is not Simulatable.update_timestep:
+            # plugin slow path: a user model that moves particles between data (smc.py:447-449)
+            locs = self.model.update_timestep(self.particle_locations, expparams)[:, :, 0]
+            self._x = self._eng.locs_to_soa(locs)
+            self._invalidate()
+
+        ess = self.n_ess                                             # smc.py:452-453
+        if ess <= self._min_n_ess:
+            self._min_n_ess = ess
+        if check_for_resample:
+            self._maybe_resample()
+
+    def batch_update(self, outcomes, expparams, resample_interval=5):
+        """Loop of `update` with the ESS test every `resample_interval` data (smc.py:459-487)."""
+        outcomes = np.asarray(outcomes)
+        n_exps = outcomes.shape[0]
+        if expparams.shape[0] != n_exps:
+            raise ValueError("The number of outcomes and experiments must match.")
+        if len(expparams.shape) == 1:
+            expparams = expparams[:, None]
+        for idx, (outcome, experiment) in enumerate(zip(iter(outcomes), iter(expparams))):
+            self.update(outcome, experiment, check_for_resample=False)
+            if (idx + 1) % resample_interval == 0:
+                self._maybe_resample()
+
+    # ------------------------------------------------------------------ resampling
+    def _maybe_resample(self):
+        ess = self.n_ess
+        if ess <= 10:
+            warnings.warn("Extremely small n_ess encountered ({}). Resampling is likely to fail. "
+                          "Consider adding particles, or resampling more often.".format(ess),
+                          ApproximationWarning)
+        if ess < self.n_particles_global * self.resample_thresh:
+            self.resample()
+
+    def resample(self):
+        """Force a resampling step now (smc.py:491-551)."""
+        if self.just_resampled:
+            warnings.warn("Resampling without additional data; this may not perform as desired.",
+                          ResamplerWarning)
+        self._just_resampled = True
+        self._resample_count += 1
+        if self._debug_resampling:
+            old_mean, old_cov = self.est_mean(), self.est_covariance_mtx()
+
+        if self._comm is not None:
+            new = self._comm.resample(self, self.resampler)
+        else:
+            new = self.resampler(self.model, self)
+        if isinstance(new, ParticleDistribution):
+            self._x, self._w, self._norm, self._sumsq = new._x, new._w, new._norm, new._sumsq
+        else:                                           # foreign resampler returning host arrays
+            self._set_host(new.particle_locations, new.particle_weights)
+        self._w_alt = None
+        self._invalidate()
+        if self._canonicalize:
+            self._canonicalize_device()
+        try:
+            self.model.clear_cache()
+        except Exception as e:  # noqa: BLE001  (reference demotes these to warnings, smc.py:533-536)
+            warnings.warn("Exception raised when clearing model cache: {}. Ignoring.".format(e))
+        if self._debug_resampling:
+            import logging
+            new_mean, new_cov = self.est_mean(), self.est_covariance_mtx()
+            logging.getLogger(__name__).debug("Resampling changed mean by {}. Norm change in cov: {}.".format(
+                old_mean - new_mean, np.linalg.norm(new_cov - old_cov)))

@@ -1,0 +1,217 @@
+"""Quantum-state tomography model on the SMC path (reference `qinfer/tomography/`):
+
+    TomographyBasis, gell_mann_basis, pauli_basis, tensor_product_basis   bases.py:71-154, 180-374
+    TomographyModel (likelihood / canonicalize / renormalize)             models.py:82-226
+    GinibreDistribution                                                   distributions.py:168-196
+
+States are real coefficient vectors x in an orthonormal Hermitian operator basis {B_a} whose
+element 0 is identity / sqrt(dim); Pr(1 | x; meas) = clip(meas . x, 0, 1).  `canonicalize` clamps
+negative eigenvalues of rho(x) = sum_a x_a B_a and renormalises the trace -- on the GPU this is a
+per-particle complex-Hermitian Jacobi (csrc/qsmc_device.h `tomo_canon_particle`), replacing the
+reference's per-particle Python `np.linalg.eig` loop.
+
+QuTiP is not required: the reference uses it only to convert to/from `Qobj`, and for
+`rand_dm_ginibre`, which is restated here directly (X = randn + i randn, rho = X X^+ / tr).
+"""
+import itertools as it
+from functools import reduce
+
+import numpy as np
+
+from . import _native
+from .abstract_model import FiniteOutcomeModel, NativeModelMixin
+from .distributions import Distribution
+
+__all__ = ["TomographyBasis", "gell_mann_basis", "pauli_basis", "tensor_product_basis",
+           "TomographyModel", "GinibreDistribution"]
+
+
+class TomographyBasis:
+    """Orthonormal Hermitian operator basis; `data[a, i, j]` is element (i, j) of B_a."""
+
+    def __init__(self, data, dims, labels=None, superrep=None, name=None):
+        self.data = np.asarray(data, dtype=complex)
+        self.dims = list(dims)
+        self.superrep = superrep
+        self._name = name if name is not None else "(unnamed)"
+        n = self.dim ** 2
+        if isinstance(labels, str):
+            self.labels = ["{}_{{{}}}".format(labels, i) for i in range(n)]
+        elif labels is None:
+            self.labels = ["B_{}".format(i) for i in range(n)]
+        else:
+            self.labels = list(labels)
+        self._flat = self.data.reshape((self.data.shape[0], -1))
+
+    def __repr__(self):
+        return "<TomographyBasis {} dims={} at 0x{:0x}>".format(self._name, self.dims, id(self))
+
+    def __len__(self):
+        return self.dim ** 2
+
+    @property
+    def dim(self):
+        return int(np.prod(self.dims))
+
+    @property
+    def name(self):
+        return self._name
+
+    def flat(self):
+        return self._flat
+
+    def state_to_modelparams(self, state):
+        """Density matrix (dim x dim array-like) -> real coefficient vector."""
+        rho = np.asarray(getattr(state, "full", lambda: state)(), dtype=complex)
+        return np.real(np.dot(self._flat.conj(), rho.flatten()))
+
+    def modelparams_to_state(self, modelparams):
+        """Coefficient vector(s) -> dim x dim complex array(s)."""
+        modelparams = np.asarray(modelparams)
+        if modelparams.ndim == 1:
+            return np.tensordot(modelparams, self.data, 1)
+        return [self.modelparams_to_state(mp) for mp in modelparams]
+
+    def covariance_mtx_to_superop(self, mtx):
+        M = self._flat
+        return np.dot(np.dot(M.conj().T, mtx), M)
+
+
+def gell_mann_basis(dim):
+    """Generalised Gell-Mann matrices, normalised to tr(B_a B_b) = delta_ab; B_0 = 1/sqrt(dim)."""
+    data = np.zeros((dim * dim, dim, dim), dtype=complex)
+    data[0] = np.eye(dim) / np.sqrt(dim)
+    for r in range(1, dim):                                  # diagonal family
+        diag = np.concatenate([np.ones(r), [-r], np.zeros(dim - r - 1)])
+        data[r] = np.diag(diag) / np.sqrt(r + r * r)
+    n_pairs = dim * (dim - 1) // 2
+    for i in range(1, dim):                                  # symmetric / antisymmetric families
+        for j in range(i):
+            k = (i - 1) * i // 2 + j + dim
+            data[k, i, j] = data[k, j, i] = 1 / np.sqrt(2)
+            data[k + n_pairs, i, j] = 1j / np.sqrt(2)
+            data[k + n_pairs, j, i] = -1j / np.sqrt(2)
+    return TomographyBasis(data, [dim], r'\gamma', name='gell_mann_basis')
+
+
+def tensor_product_basis(*bases):
+    """Basis of all tensor products of elements of the factor bases (row-major over factors)."""
+    dim = int(np.prod([b.data.shape[1] for b in bases]))
+    data = np.zeros((dim * dim, dim, dim), dtype=complex)
+    for k, factors in enumerate(it.product(*[b.data for b in bases])):
+        data[k] = reduce(np.kron, factors)
+    labels = [r"\otimes".join(ls) for ls in it.product(*[b.labels for b in bases])]
+    return TomographyBasis(data, sum((b.dims for b in bases), []), labels)
+
+
+def pauli_basis(nq=1):
+    """Normalised n-qubit Pauli basis, ordered (I, X, Y, Z) per qubit."""
+    single = TomographyBasis(gell_mann_basis(2).data[[0, 2, 3, 1]], [2],
+                             [u'\U0001D7D9', r'\sigma_x', r'\sigma_y', r'\sigma_z'])
+    basis = tensor_product_basis(*([single] * nq))
+    basis._name = 'pauli_basis'
+    return basis
+
+
+class TomographyModel(NativeModelMixin, FiniteOutcomeModel):
+    """Two-outcome tomography: outcome 1 has probability <<meas | rho>> clipped to [0, 1]."""
+
+    def __init__(self, basis, allow_subnormalized=False):
+        self._dim = basis.dim
+        self._basis = basis
+        self._allow_subnormalized = bool(allow_subnormalized)
+        self._basis_dev = None
+        super().__init__()
+        self._native = self.n_modelparams <= _native.QSMC_MAX_D
+
+    @property
+    def dim(self):
+        return self._dim
+
+    @property
+    def basis(self):
+        return self._basis
+
+    @property
+    def n_modelparams(self):
+        return self._dim ** 2
+
+    @property
+    def modelparam_names(self):
+        return [r'\langle\!\langle{} | \rho\rangle\!\rangle'.format(lbl) for lbl in self._basis.labels]
+
+    @property
+    def is_n_outcomes_constant(self):
+        return True
+
+    @property
+    def expparams_dtype(self):
+        return [(str('meas'), float, self._dim ** 2)]
+
+    def n_outcomes(self, expparams):
+        return 2
+
+    # native hooks
+    def _native_desc(self):
+        return _native.ModelDesc(_native.MODEL_TOMOGRAPHY, self.n_modelparams, 0.0, 1, 0)
+
+    def _native_expparams(self, expparams):
+        expparams = np.atleast_1d(expparams)
+        meas = np.asarray(expparams['meas'], dtype=np.float64).reshape(-1, self.n_modelparams)
+        return [_native.make_expparam(meas=row) for row in meas]
+
+    def _device_basis(self, eng):
+        if self._basis_dev is None or self._basis_dev.device != eng.device:
+            inter = np.ascontiguousarray(self._basis.data).view(np.float64)     # (d, dim, 2 dim)
+            self._basis_dev = eng.to_device(inter.reshape(-1))
+        return self._basis_dev
+
+    def _native_canonicalize_(self, eng, x):
+        """In-place canonicalize of a device SoA cloud."""
+        if self._dim not in (2, 4):
+            raise NotImplementedError("native canonicalize supports dim 2 and 4 (1 or 2 qubits)")
+        eng.tomo_canonicalize(self._device_basis(eng), self._dim, x, self._allow_subnormalized)
+
+    # NumPy contract
+    def are_models_valid(self, modelparams):
+        # tomography/models.py:143-147: deliberately always true
+        return np.ones((np.asarray(modelparams).shape[0],), dtype=bool)
+
+    def likelihood(self, outcomes, modelparams, expparams):
+        super().likelihood(outcomes, modelparams, expparams)
+        return self._native_likelihood(outcomes, modelparams, expparams)
+
+    def canonicalize(self, modelparams):
+        eng = self._engine()
+        x = eng.locs_to_soa(np.asarray(modelparams, dtype=np.float64))
+        self._native_canonicalize_(eng, x)
+        return np.ascontiguousarray(x.cpu().numpy().T)
+
+    def renormalize(self, modelparams):
+        modelparams = np.asarray(modelparams, dtype=np.float64)
+        norm = modelparams[:, 0] * np.sqrt(self._dim)
+        assert not np.sum(norm == 0)
+        return modelparams / norm[:, None]
+
+
+class GinibreDistribution(Distribution):
+    """Ginibre-ensemble prior over density operators of a given rank, as coefficient vectors."""
+
+    def __init__(self, basis, rank=None):
+        self._basis = basis
+        self._dim = basis.dim
+        self._rank = self._dim if rank is None else int(rank)
+
+    @property
+    def n_rvs(self):
+        return self._dim ** 2
+
+    def sample(self, n=1):
+        flat = self._basis.flat()
+        out = np.empty((n, self.n_rvs))
+        for i in range(n):
+            g = np.random.randn(self._dim, self._rank) + 1j * np.random.randn(self._dim, self._rank)
+            rho = g @ g.conj().T
+            rho /= np.trace(rho).real
+            out[i] = np.real(flat.conj() @ rho.flatten())
+        return out

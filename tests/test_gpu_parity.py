@@ -1,0 +1,709 @@
+"""GPU parity tests: every HIP kernel, called through the product API (ctypes -> C ABI), against
+the CPU oracle and the committed golden vectors.  Tolerances are the stated fp64 ones
+(tests/parity_tols.py).  Run with `pytest -m gpu` on an MI355X."""
+import warnings
+
+import numpy as np
+import pytest
+
+import np_oracle as orc
+import parity_tols as tol
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def qi():
+    import qinfer_amd
+    return qinfer_amd
+
+
+@pytest.fixture(scope="module")
+def eng(qi):
+    from qinfer_amd.engine import get_engine
+    return get_engine()
+
+
+class Replay:
+    """Monkeypatches np.random.random and provides `kernel` so the product consumes recorded draws."""
+
+    def __init__(self, g, prefix=""):
+        self.rng = orc.ReplayRNG(g[prefix + "draw_kinds"], g[prefix + "draw_shapes"], g[prefix + "draw_data"])
+
+    def __enter__(self):
+        self._orig = np.random.random
+        np.random.random = lambda size=None: self.rng.random(size if isinstance(size, tuple) else (size,))
+        return self
+
+    def __exit__(self, *a):
+        np.random.random = self._orig
+
+    def kernel(self, *shape):
+        return self.rng.randn(*shape)
+
+
+def fixed_prior(qi, x0):
+    class Fixed(qi.Distribution):
+        n_rvs = x0.shape[1]
+
+        def sample(self, n=1):
+            assert n == x0.shape[0]
+            return x0.copy()
+    return Fixed()
+
+
+# ================================================================== likelihood KATs (G2)
+ULP4 = 4 * tol.EPS
+
+
+def test_likelihood_precession_g2(qi, golden):
+    g = golden("g2_likelihoods")
+    L = qi.SimplePrecessionModel().likelihood(np.array([0, 1]), g["prec_x"], g["prec_t"])
+    assert L.shape == g["prec_L"].shape
+    # |dL| <= 4 ulp(1): OCML cos vs libm cos, full-range argument reduction (t up to 1.5e10)
+    np.testing.assert_allclose(L, g["prec_L"], rtol=0, atol=1e-15)
+
+
+def test_likelihood_binomial_g2(qi, golden):
+    g = golden("g2_likelihoods")
+    m = qi.BinomialModel(qi.SimplePrecessionModel())
+    ep = np.empty((3,), dtype=m.expparams_dtype)
+    ep["x"], ep["n_meas"] = g["bin_t"], g["bin_n"]
+    L = m.likelihood(np.arange(26), g["bin_x"], ep)
+    ref = g["bin_L"]
+    # pmf error = n * |d pr1| relative; pr1 carries <= 1e-15 absolute from cos
+    np.testing.assert_allclose(L, ref, rtol=1e-12, atol=30 * 1e-15)
+
+
+def test_likelihood_rb_g2(qi, golden):
+    g = golden("g2_likelihoods")
+    m = qi.RandomizedBenchmarkingModel()
+    ep = np.empty((len(g["rb_m"]),), dtype=m.expparams_dtype)
+    ep["m"] = g["rb_m"]
+    L = m.likelihood(np.array([0, 1]), g["rb_x"], ep)
+    np.testing.assert_allclose(L, g["rb_L"], rtol=0, atol=ULP4)
+    np.testing.assert_array_equal(m.are_models_valid(g["rb_valid_x"]), g["rb_valid"])
+    mi = qi.RandomizedBenchmarkingModel(interleaved=True)
+    ep = np.empty((len(g["rbi_m"]),), dtype=mi.expparams_dtype)
+    ep["m"], ep["reference"] = g["rbi_m"], g["rbi_ref"]
+    L = mi.likelihood(np.array([0, 1]), g["rbi_x"], ep)
+    np.testing.assert_allclose(L, g["rbi_L"], rtol=1e-13, atol=ULP4)
+    np.testing.assert_array_equal(mi.are_models_valid(g["rbi_x"]), g["rbi_valid"])
+
+
+def test_likelihood_tomography_g2(qi, golden):
+    g = golden("g2_likelihoods")
+    basis = qi.tomography.pauli_basis(2)
+    np.testing.assert_allclose(basis.data, g["pauli2_basis"], atol=1e-15)
+    m = qi.TomographyModel(basis)
+    ep = np.zeros((15,), dtype=m.expparams_dtype)
+    ep["meas"] = g["tomo_meas"]
+    L = m.likelihood(np.array([0, 1]), g["tomo_x"], ep)
+    np.testing.assert_allclose(L, g["tomo_L"], rtol=0, atol=ULP4)
+
+
+def test_likelihood_shapes_and_call_count(qi):
+    """Contract of tests/base_test.py:423-435: L has shape (n_outcomes, n_models, n_experiments)."""
+    m = qi.SimplePrecessionModel()
+    x = np.random.RandomState(0).random_sample((9, 1))
+    L = m.likelihood(np.array([0, 1]), x, np.array([0.5, 1.5, 2.5]))
+    assert L.shape == (2, 9, 3) and L.dtype == np.float64
+    assert m.call_count == 2 * 9 * 3
+    np.testing.assert_allclose(L.sum(axis=0), 1.0, atol=1e-15)
+    assert m.are_models_valid(np.array([[-0.1], [0.0], [0.2]])).tolist() == [False, False, True]
+    d = m.simulate_experiment(x, np.array([0.5, 1.5]), repeat=3)
+    assert d.shape == (3, 9, 2)
+
+
+# ================================================================== fused update vs oracle
+@pytest.mark.parametrize("n", [1, 2, 7, 255, 256, 1000, 4097, 65537, 1 << 20])
+def test_update_fused_precession_sizes(qi, eng, n):
+    rs = np.random.RandomState(n)
+    x = rs.random_sample((n, 1))
+    w = rs.random_sample(n) ** 2
+    w /= w.sum()
+    pd = qi.ParticleDistribution(particle_locations=x, particle_weights=w)
+    w = pd.particle_weights
+    desc = qi.SimplePrecessionModel()._native_desc()
+    from qinfer_amd import _native
+    out = eng.empty(n)
+    for outcome in (0, 1):
+        st = eng.update_fused(desc, pd._x, pd._w, out, 1.0, _native.make_expparam(t=37.5), outcome)
+        L = orc.lik_precession([outcome], x, [37.5])
+        hyp, norm = orc.hypothetical_update(w, L)
+        raw = w * L[0, :, 0]
+        np.testing.assert_allclose(out.cpu().numpy(), raw, rtol=1e-13, atol=1e-17)
+        np.testing.assert_allclose(st.sum, norm[0, 0, 0], rtol=1e-12)
+        np.testing.assert_allclose(st.sumsq, np.sum(raw ** 2), rtol=1e-12)
+        np.testing.assert_allclose(st.min, raw.min(), rtol=1e-13, atol=1e-17)
+        assert st.n_bad == 0
+
+
+def test_update_all_models_one_step(qi, golden):
+    """One update through SMCUpdater for each model vs the oracle from the same state."""
+    rs = np.random.RandomState(4)
+    cases = []
+    x = rs.random_sample((3001, 1))
+    cases.append((qi.SimplePrecessionModel(), orc.precession_model(), x, np.array([12.5]), {"t": np.array([12.5])}, 1))
+    bm = qi.BinomialModel(qi.SimplePrecessionModel())
+    ep = np.empty((1,), dtype=bm.expparams_dtype)
+    ep["x"], ep["n_meas"] = 3.3, 25
+    cases.append((bm, orc.binomial_precession_model(), x, ep, {"t": np.array([3.3]), "n_meas": np.array([25])}, 9))
+    rb = qi.RandomizedBenchmarkingModel()
+    xr = np.stack([rs.uniform(0.8, 1, 3001), rs.uniform(0, 0.5, 3001), rs.uniform(0, 0.5, 3001)], 1)
+    ep = np.empty((1,), dtype=rb.expparams_dtype)
+    ep["m"] = 41
+    cases.append((rb, orc.rb_model(), xr, ep, {"m": np.array([41])}, 0))
+    basis = qi.tomography.pauli_basis(2)
+    tm = qi.TomographyModel(basis)
+    xt = orc.ginibre_prior_sample(500, basis.data, rs)
+    ep = np.zeros((1,), dtype=tm.expparams_dtype)
+    ep["meas"][0, 0] = 1
+    ep["meas"][0, 7] = 1
+    cases.append((tm, orc.tomography_model(orc.pauli_data(2)), xt, ep, {"meas": ep["meas"]}, 1))
+    for model, omodel, x0, ep, oep, outcome in cases:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            upd = qi.SMCUpdater(model, x0.shape[0], fixed_prior(qi, x0), resample_thresh=0.0, canonicalize=False)
+            ref = orc.OracleSMC(omodel, x0.shape[0], lambda n: x0.copy(), resample_thresh=0.0, canonicalize=False)
+            upd.update(outcome, ep)
+            ref.update(outcome, oep)
+        np.testing.assert_allclose(upd.normalization_record[-1], ref.normalization_record[-1], rtol=1e-12)
+        np.testing.assert_allclose(upd.n_ess, ref.n_ess, rtol=1e-11)
+        np.testing.assert_allclose(upd.particle_weights, ref.w, rtol=1e-11, atol=1e-18)
+        np.testing.assert_allclose(upd.est_mean(), ref.est_mean(), rtol=0, atol=tol.atol_mean(ref.est_mean()))
+        np.testing.assert_allclose(upd.min_n_ess, ref.min_n_ess, rtol=1e-11)
+
+
+# ================================================================== moments (G3)
+def test_moments_g3(qi, golden):
+    g = golden("g3_moments")
+    for tag in g["tags"]:
+        w, x = g[tag + "_w"], g[tag + "_x"]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            pd = qi.ParticleDistribution(particle_locations=x, particle_weights=w)
+            mean, cov = pd.est_mean(), pd.est_covariance_mtx()
+        np.testing.assert_allclose(mean, g[tag + "_mean"], rtol=0, atol=tol.atol_mean(g[tag + "_mean"]), err_msg=tag)
+        m2 = float(np.einsum('i,ij->', w, x * x))
+        np.testing.assert_allclose(cov, g[tag + "_cov"], rtol=0,
+                                   atol=tol.atol_cov(g[tag + "_mean"], m2, x.shape[0]), err_msg=tag)
+        np.testing.assert_allclose(pd.n_ess, g[tag + "_ess"], rtol=1e-12)
+
+
+def test_particle_distribution_contract(qi):
+    """tests/test_distributions.py:622-706: init rectifies+normalises; n_ess = N uniform, 1 delta."""
+    n = 1000
+    rs = np.random.RandomState(2)
+    x = rs.randn(n, 3)
+    pd = qi.ParticleDistribution(particle_locations=x, particle_weights=-2 * np.ones(n))
+    np.testing.assert_allclose(pd.particle_weights, np.ones(n) / n, rtol=1e-15)
+    np.testing.assert_allclose(pd.n_ess, n, rtol=1e-12)
+    assert pd.n_particles == n and pd.n_rvs == 3
+    np.testing.assert_array_equal(pd.particle_locations, x)
+    w = np.zeros(n)
+    w[17] = 1.0
+    pd = qi.ParticleDistribution(particle_locations=x, particle_weights=w)
+    assert pd.n_ess == 1.0
+    np.testing.assert_allclose(pd.est_mean(), x[17], rtol=1e-15)
+    pd = qi.ParticleDistribution(n_mps=4)
+    assert pd.n_particles == 1 and pd.n_rvs == 4 and pd.particle_weights.tolist() == [1.0]
+    with pytest.raises(ValueError):
+        qi.ParticleDistribution(n_mps=2, particle_locations=x, particle_weights=w)
+    pd = qi.ParticleDistribution(particle_locations=x, particle_weights=np.ones(n))
+    np.testing.assert_allclose(pd.est_entropy(), np.log(n), rtol=1e-12)
+    s = pd.sample(50)
+    assert s.shape == (50, 3)
+    fn = pd.est_meanfn(lambda z: z ** 2)
+    np.testing.assert_allclose(fn, (x ** 2).mean(axis=0), rtol=1e-12)
+
+
+# ================================================================== scan + search
+@pytest.mark.parametrize("n", [1, 5, 127, 128, 129, 4095, 4096, 4097, 100003, 1 << 21])
+def test_cumsum_and_ancestors(qi, eng, n):
+    rs = np.random.RandomState(n % 1000)
+    w = rs.random_sample(n) ** 4
+    w[rs.random_sample(n) < 0.1] = 0.0            # runs of zero-weight particles
+    if w.sum() == 0:
+        w[0] = 1.0
+    stored = w * 3.7                               # unnormalised storage with a pending normaliser
+    norm = stored.sum()
+    cdf = eng.cumsum(eng.to_device(stored), norm).cpu().numpy()
+    ref = np.cumsum(stored / norm)
+    np.testing.assert_allclose(cdf, ref, rtol=0, atol=8 * tol.EPS * np.sqrt(n))
+    assert np.all(np.diff(cdf) >= 0), "CDF must be monotone"
+    u = rs.random_sample(min(n * 2, 200000))
+    js = eng.lw_ancestors(eng.to_device(cdf), eng.to_device(u)).cpu().numpy()
+    ref_js = np.minimum(np.searchsorted(cdf, u, side='right'), n - 1)
+    np.testing.assert_array_equal(js, ref_js)      # same CDF array -> identical indices
+    # against the sequential cumsum only CDF-boundary flips are allowed
+    ref_js2 = np.minimum(np.searchsorted(ref, u, side='right'), n - 1)
+    assert np.sum(js != ref_js2) <= tol.max_js_flips(len(u)) + 3
+
+
+# ================================================================== Liu-West, legacy RNG (G4)
+def _model_for(qi, tag):
+    if tag.startswith("rb"):
+        return qi.RandomizedBenchmarkingModel()
+    if tag.startswith("tomo"):
+        return qi.TomographyModel(qi.tomography.pauli_basis(2))
+    return qi.SimplePrecessionModel()
+
+
+def test_liu_west_g4(qi, golden):
+    g = golden("g4_liu_west")
+    for tag in g["tags"]:
+        h = g[tag + "_h"]
+        with Replay(g, tag + "_") as rp, warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            res = qi.LiuWestResampler(a=float(g[tag + "_a"]), h=None if np.isnan(h) else float(h),
+                                      kernel=rp.kernel)
+            pd = qi.ParticleDistribution(particle_locations=g[tag + "_x"], particle_weights=g[tag + "_w"])
+            new = res(_model_for(qi, tag), pd, n_particles=int(g[tag + "_n_out"]))
+        assert rp.rng.exhausted, tag
+        ref = g[tag + "_new"]
+        got = new.particle_locations
+        assert got.shape == ref.shape
+        cov = orc.particle_cov(g[tag + "_w"], g[tag + "_x"], warn=False)
+        at = 1e-13 + tol.atol_sqrtm_psd(cov) * 10 if tag.startswith("tomo") else 1e-13
+        bad = np.abs(got - ref).max(axis=1) > at + 1e-12 * np.abs(ref).max()
+        assert bad.sum() <= tol.max_js_flips(ref.shape[0]), (tag, int(bad.sum()))
+        np.testing.assert_allclose(new.particle_weights, 1.0 / ref.shape[0], rtol=1e-15)
+        np.testing.assert_allclose(new.n_ess, ref.shape[0], rtol=1e-12)
+
+
+def test_liu_west_q1_switch(qi, golden):
+    """legacy_mus_truncation=False gives the 'intended' centres, which differ on the Q1 fixture."""
+    g = golden("g4_liu_west")
+    tag = "q1_small"
+    with Replay(g, tag + "_") as rp, warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = qi.LiuWestResampler(a=float(g[tag + "_a"]), kernel=rp.kernel, legacy_mus_truncation=False)
+        pd = qi.ParticleDistribution(particle_locations=g[tag + "_x"], particle_weights=g[tag + "_w"])
+        new = res(qi.SimplePrecessionModel(), pd)
+    rng = orc.ReplayRNG(g[tag + "_draw_kinds"], g[tag + "_draw_shapes"], g[tag + "_draw_data"])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref, _ = orc.liu_west(pd.particle_weights, g[tag + "_x"], orc.valid_precession, rng,
+                              a=float(g[tag + "_a"]), legacy_mus_truncation=False)
+    np.testing.assert_allclose(new.particle_locations, ref, rtol=1e-12, atol=1e-14)
+    assert not np.allclose(new.particle_locations, g[tag + "_new"])
+
+
+# ================================================================== Liu-West, device RNG
+@pytest.mark.parametrize("case", ["prec", "rb", "tomo"])
+def test_liu_west_philox_vs_oracle(qi, case):
+    import philox as ph
+    rs = np.random.RandomState(11)
+    if case == "prec":
+        model, valid = qi.SimplePrecessionModel(), orc.valid_precession
+        x = np.abs(0.04 + 0.05 * rs.randn(5000, 1))
+    elif case == "rb":
+        model, valid = qi.RandomizedBenchmarkingModel(), orc.valid_rb
+        x = np.stack([rs.uniform(0.9, 1, 5000), rs.uniform(0.2, 0.5, 5000), rs.uniform(0.4, 0.6, 5000)], 1)
+    else:
+        basis = qi.tomography.pauli_basis(2)
+        model, valid = qi.TomographyModel(basis), (lambda z: np.ones(z.shape[0], dtype=bool))
+        x = orc.ginibre_prior_sample(2000, basis.data, rs)
+    w = rs.random_sample(x.shape[0]) ** 2
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        pd = qi.ParticleDistribution(particle_locations=x, particle_weights=w)
+        res = qi.LiuWestResampler(a=0.9, device_rng=True, seed=1234)
+        new = res(model, pd, n_particles=6000)
+        wn = pd.particle_weights
+        ref, failed = ph.liu_west_philox(wn, x, valid, 0.9, np.sqrt(1 - 0.81), 1234, 1, 6000)
+    got = new.particle_locations
+    cov = orc.particle_cov(wn, x, warn=False)
+    at = 1e-12 + (tol.atol_sqrtm_psd(cov) * 10 if case == "tomo" else 0)
+    bad = np.abs(got - ref).max(axis=1) > at
+    assert bad.sum() <= tol.max_js_flips(6000), int(bad.sum())
+    assert np.all(valid(got))
+    # determinism: same seed/epoch -> bitwise identical; next epoch differs
+    res2 = qi.LiuWestResampler(a=0.9, device_rng=True, seed=1234)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        again = res2(model, pd, n_particles=6000).particle_locations
+        other = res2(model, pd, n_particles=6000).particle_locations
+    np.testing.assert_array_equal(got, again)
+    assert not np.array_equal(got, other)
+
+
+def test_prior_uniform_philox(qi, eng):
+    import philox as ph
+    model = qi.RandomizedBenchmarkingModel()
+    prior = qi.PostselectedDistribution(qi.UniformDistribution([[0.8, 1], [0, 1], [0, 1]]), model)
+    x, failed = prior.sample_device(eng, 20000, seed=99, epoch=3)
+    x = x.cpu().numpy().T
+    assert failed == 0 and x.shape == (20000, 3)
+    assert np.all(orc.valid_rb(x))
+    # round-0 draws of particles that were valid immediately match the emulation
+    u0, u1 = ph.uniforms(np.arange(20000), 99, 3, 0, 0)
+    u2, _ = ph.uniforms(np.arange(20000), 99, 3, 0, 1)
+    cand = np.stack([0.8 + u0 * (1 - 0.8), 0 + u1 * 1.0, 0 + u2 * 1.0], 1)
+    ok = orc.valid_rb(cand)
+    np.testing.assert_allclose(x[ok], cand[ok], rtol=1e-15)
+    assert 0.3 < ok.mean() < 0.9
+
+
+# ================================================================== canonicalize (G5)
+def test_tomo_canonicalize_g5(qi, golden):
+    g = golden("g5_canonicalize")
+    basis = qi.tomography.pauli_basis(2)
+    y = qi.TomographyModel(basis).canonicalize(g["x"])
+    np.testing.assert_allclose(y, g["y"], rtol=0, atol=1e-12)
+    y2 = qi.TomographyModel(basis, allow_subnormalized=True).canonicalize(g["x"])
+    np.testing.assert_allclose(y2, g["y_subnorm"], rtol=0, atol=1e-12)
+    # invariants: trace one, PSD
+    rho = np.tensordot(y, basis.data, 1)
+    np.testing.assert_allclose(np.trace(rho, axis1=1, axis2=2).real, 1.0, atol=1e-12)
+    assert np.linalg.eigvalsh(rho).min() > -1e-12
+    # single-qubit kernel instantiation
+    b1 = qi.tomography.pauli_basis(1)
+    x1 = np.array([[0.70710678, 0.9, 0.1, 0.2], [0.70710678, 0.1, 0.1, 0.1]])
+    y1 = qi.TomographyModel(b1).canonicalize(x1)
+    np.testing.assert_allclose(y1, orc.tomo_canonicalize(x1, orc.pauli_data(1)), atol=1e-12)
+
+
+# ================================================================== trajectories (G1)
+def _run_traj(qi, g, model, ep_of, cond, batch=None, canonicalize=False):
+    n = int(g["n_particles"])
+    with Replay(g) as rp, warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for _ in range(int(g["n_prior_draws"])):          # skip the reference's prior draws
+            k = rp.rng.kinds[rp.rng.pos]
+            (rp.rng.random if k == 0 else rp.rng.randn)(*([rp.rng.shapes[rp.rng.pos]] if k == 0 else rp.rng.shapes[rp.rng.pos]))
+        res = qi.LiuWestResampler(kernel=rp.kernel, default_n_particles=n)
+        upd = qi.SMCUpdater(model, n, fixed_prior(qi, g["x0"]), resampler=res, canonicalize=canonicalize)
+        K = len(g["outcomes"])
+        checked = -1
+        for k in range(K):
+            c = float(cond(k))
+            if not tol.well_conditioned(c):
+                break
+            if batch is None:
+                upd.update(g["outcomes"][k], ep_of(k))
+            else:
+                upd.update(g["outcomes"][k], ep_of(k), check_for_resample=False)
+                if (k + 1) % batch == 0:
+                    upd._maybe_resample()
+            checked = k
+            assert upd.resample_count == g["resample_count"][k], "datum %d" % k
+            np.testing.assert_allclose(upd.normalization_record[-1], g["norms"][k], rtol=tol.rtol_norm(c),
+                                       err_msg="datum %d" % k)
+            np.testing.assert_allclose(upd.n_ess, g["n_ess"][k], rtol=tol.rtol_ess(c))
+            np.testing.assert_allclose(upd.est_mean(), g["means"][k], rtol=0,
+                                       atol=max(tol.atol_mean(g["means"][k]),
+                                                tol.atol_sqrtm_psd(g["covs"][k]) if canonicalize else 0))
+    assert checked >= min(K - 1, 60)
+    return upd, checked
+
+
+@pytest.mark.parametrize("name", ["g1_precession_n1000", "g1_precession_n256"])
+def test_traj_precession(qi, golden, name):
+    g = golden(name)
+    upd, checked = _run_traj(qi, g, qi.SimplePrecessionModel(), lambda k: g["ep_t"][k:k + 1], lambda k: g["ep_t"][k])
+    assert upd.data_record[:3] == [g["outcomes"][i] for i in range(3)]
+
+
+def test_traj_precession_batch5(qi, golden):
+    g = golden("g1_precession_batch5")
+    _run_traj(qi, g, qi.SimplePrecessionModel(), lambda k: g["ep_t"][k:k + 1], lambda k: g["ep_t"][k], batch=5)
+
+
+def test_traj_binomial(qi, golden):
+    g = golden("g1_binomial_n1000")
+    m = qi.BinomialModel(qi.SimplePrecessionModel())
+
+    def ep_of(k):
+        ep = np.empty((1,), dtype=m.expparams_dtype)
+        ep["x"], ep["n_meas"] = g["ep_x"][k], g["ep_n_meas"][k]
+        return ep
+    _run_traj(qi, g, m, ep_of, lambda k: 25 * g["ep_x"][k])
+
+
+def test_traj_rb(qi, golden):
+    g = golden("g1_rb_n2000")
+    m = qi.RandomizedBenchmarkingModel()
+
+    def ep_of(k):
+        ep = np.empty((1,), dtype=m.expparams_dtype)
+        ep["m"] = g["ep_m"][k]
+        return ep
+    upd, checked = _run_traj(qi, g, m, ep_of, lambda k: g["ep_m"][k])
+    assert checked == len(g["outcomes"]) - 1
+    np.testing.assert_allclose(upd.particle_locations, g["final_locs"], rtol=1e-9, atol=1e-12)
+
+
+def test_traj_tomography(qi, golden):
+    g = golden("g1_tomography_n300")
+    m = qi.TomographyModel(qi.tomography.pauli_basis(2))
+
+    def ep_of(k):
+        ep = np.zeros((1,), dtype=m.expparams_dtype)
+        ep["meas"][0] = g["ep_meas"][k]
+        return ep
+    upd, checked = _run_traj(qi, g, m, ep_of, lambda k: 1.0, canonicalize=True)
+    at = tol.atol_sqrtm_psd(g["covs"][-1])
+    np.testing.assert_allclose(upd.particle_locations, g["final_locs"], rtol=0, atol=10 * at)
+
+
+def test_batch_update_api(qi, golden):
+    """batch_update(outcomes, expparams, resample_interval) == the manual loop of the fixture."""
+    g = golden("g1_precession_batch5")
+    n = int(g["n_particles"])
+    K = 60
+    with Replay(g) as rp, warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        rp.rng.random(rp.rng.shapes[0])
+        res = qi.LiuWestResampler(kernel=rp.kernel, default_n_particles=n)
+        upd = qi.SMCUpdater(qi.SimplePrecessionModel(), n, fixed_prior(qi, g["x0"]), resampler=res)
+        upd.batch_update(g["outcomes"][:K].reshape(K, 1), g["ep_t"][:K], resample_interval=5)
+    assert upd.resample_count == g["resample_count"][K - 1]
+    np.testing.assert_allclose(upd.est_mean(), g["means"][K - 1], atol=1e-10)
+    with pytest.raises(ValueError):
+        upd.batch_update(np.zeros((3, 1), dtype=int), g["ep_t"][:4])
+
+
+# ================================================================== every-step teacher forcing
+def test_every_step_from_oracle_state(qi):
+    """All 200 data of config C1, one step at a time FROM THE ORACLE'S STATE, so chaotic
+    amplification (parity_tols docstring) cannot hide a per-step discrepancy at large t."""
+    n = 1000
+    np.random.seed(5)
+    x0 = np.random.random((n, 1))
+    ts = (9 / 8) ** np.arange(200.0)
+    outcomes = (np.random.random(200) >= np.cos(0.3 * ts / 2) ** 2).astype(int)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = orc.OracleSMC(orc.precession_model(), n, lambda m: x0.copy(), resample_thresh=0.0)
+        upd = qi.SMCUpdater(qi.SimplePrecessionModel(), n, fixed_prior(qi, x0), resample_thresh=0.0)
+        for k in range(200):
+            upd.particle_locations = ref.x
+            upd.particle_weights = ref.w
+            w_before, x_before = ref.w.copy(), ref.x.copy()
+            try:
+                ref.update(int(outcomes[k]), {"t": ts[k:k + 1]})
+            except RuntimeError:
+                with pytest.raises(RuntimeError):
+                    upd.update(int(outcomes[k]), ts[k:k + 1])
+                break
+            upd.update(int(outcomes[k]), ts[k:k + 1])
+            # likelihood differs by <= 1e-15 abs per particle (cos ulp) -> weights by that, relative to L
+            np.testing.assert_allclose(upd.normalization_record[-1], ref.normalization_record[-1],
+                                       rtol=1e-12, atol=1e-15, err_msg="datum %d" % k)
+            np.testing.assert_allclose(upd.particle_weights, ref.w, rtol=1e-11,
+                                       atol=2e-15 * ref.w.max() / max(ref.normalization_record[-1], 1e-3) + 1e-18)
+            np.testing.assert_allclose(upd.n_ess, ref.n_ess, rtol=1e-10)
+            if ref.n_ess < n / 2:          # resample on the oracle with the legacy stream, adopt it
+                ref.resample()
+
+
+# ================================================================== guards (G6 / tests/test_smc.py)
+def _decimation_model(qi):
+    class DecimationModel(qi.FiniteOutcomeModel):
+        """User-defined (non-native) model: exercises the plugin slow path."""
+        n_modelparams = 1
+        expparams_dtype = [('alpha', float)]
+        is_n_outcomes_constant = True
+
+        def n_outcomes(self, e):
+            return 2
+
+        def are_models_valid(self, mp):
+            return np.ones(mp.shape[0], dtype=bool)
+
+        def likelihood(self, outcomes, mp, ep):
+            super().likelihood(outcomes, mp, ep)
+            pr0 = np.ones((mp.shape[0], 1)) / 2
+            pr0[int(np.ceil(ep['alpha'][0] * mp.shape[0])):, :] = 0
+            return qi.FiniteOutcomeModel.pr0_to_likelihood_array(outcomes, pr0)
+    return DecimationModel()
+
+
+def test_guards_min_n_ess_g6(qi, golden):
+    g = golden("g6_guards")
+    N = int(g["N"])
+    np.random.seed(0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        upd = qi.SMCUpdater(_decimation_model(qi), N, qi.UniformDistribution([0, 1]), resample_thresh=0.0)
+        ep = np.empty((1,), dtype=[('alpha', float)])
+        for k in range(6):
+            ep['alpha'][0] = 4.0 ** -(k + 1)
+            upd.update(np.array([0]), ep)
+            assert upd.min_n_ess == g["min_n_ess"][k]
+            assert upd.n_ess == g["n_ess"][k]
+        upd.resample()
+        assert upd.min_n_ess == g["min_n_ess"][5]
+
+
+def test_guards_warnings_and_resample_count(qi):
+    model = _decimation_model(qi)
+    ep = np.ones((1,), dtype=model.expparams_dtype)
+    upd = qi.SMCUpdater(model, 1000, qi.UniformDistribution([0, 1]), resample_thresh=0.0)
+    ep['alpha'][0] = 2 / 1000
+    with pytest.warns(qi.ApproximationWarning):          # ESS <= 10 (tests/test_smc.py:98-107)
+        upd.update(np.array([0]), ep)
+    upd = qi.SMCUpdater(model, 1000, qi.UniformDistribution([0, 1]), resample_thresh=0.5)
+    ep['alpha'][0] = 0.3
+    for i in range(10):                                   # tests/test_smc.py:109-120
+        upd.update(np.array([0]), ep)
+        assert upd.resample_count == 1 + i
+    with pytest.warns(qi.ResamplerWarning):
+        upd.resample()                                    # resampling twice without data
+
+
+def test_guards_zero_weight_policies(qi):
+    class Impossible(qi.SimplePrecessionModel):
+        _native = False                                   # force the plugin path with L == 0
+
+        def likelihood(self, outcomes, mp, ep):
+            return np.zeros((1, mp.shape[0], 1))
+
+        def are_models_valid(self, mp):
+            return np.ones(mp.shape[0], dtype=bool)
+    mk = lambda pol: qi.SMCUpdater(Impossible(), 64, qi.UniformDistribution([0, 1]), zero_weight_policy=pol)
+    with pytest.raises(RuntimeError, match="All particle weights are zero"):
+        mk("error").update(0, np.array([1.0]))
+    u = mk("skip")
+    u.update(0, np.array([1.0]))
+    np.testing.assert_allclose(u.particle_weights, 1 / 64)
+    assert u.normalization_record == [] and u.data_record == [0]
+    with pytest.warns(qi.ApproximationWarning):
+        mk("warn").update(0, np.array([1.0]), check_for_resample=False)
+    with pytest.raises(ValueError):
+        mk("bogus").update(0, np.array([1.0]))
+    u = mk("ignore")
+    u.update(0, np.array([1.0]), check_for_resample=False)
+    assert np.all(u.particle_weights == 0)
+    # native path: outcome impossible for every particle (omega = 0 -> pr0 = 1, outcome 1 -> L = 0)
+    upd = qi.SMCUpdater(qi.SimplePrecessionModel(), 32, fixed_prior(qi, np.zeros((32, 1))))
+    with pytest.raises(RuntimeError):
+        upd.update(1, np.array([1.0]))
+
+
+def test_guards_negative_weights(qi):
+    class Negative(qi.SimplePrecessionModel):
+        _native = False
+
+        def likelihood(self, outcomes, mp, ep):
+            L = np.ones((1, mp.shape[0], 1))
+            L[0, :3, 0] = -0.5
+            return L
+
+        def are_models_valid(self, mp):
+            return np.ones(mp.shape[0], dtype=bool)
+    upd = qi.SMCUpdater(Negative(), 100, qi.UniformDistribution([0, 1]))
+    ref_w = np.ones(100) / 100
+    hyp = ref_w * np.r_[-0.5 * np.ones(3), np.ones(97)]
+    expect = np.clip(hyp / hyp.sum(), 0, 1)
+    with pytest.warns(qi.ApproximationWarning, match="Negative weights"):
+        upd.update(0, np.array([1.0]), check_for_resample=False)
+    np.testing.assert_allclose(upd.particle_weights, expect, rtol=1e-14)
+    np.testing.assert_allclose(upd.n_ess, 1 / np.sum(expect ** 2), rtol=1e-12)
+
+
+# ================================================================== API odds and ends
+def test_hypothetical_update_matches_oracle(qi):
+    rs = np.random.RandomState(8)
+    x0 = rs.random_sample((500, 1))
+    upd = qi.SMCUpdater(qi.SimplePrecessionModel(), 500, fixed_prior(qi, x0))
+    ts = np.array([0.7, 3.0, 11.0])
+    w, L, nrm = upd.hypothetical_update(np.array([0, 1]), ts, return_likelihood=True, return_normalization=True)
+    Lref = orc.lik_precession([0, 1], x0, ts)
+    wref, nref = orc.hypothetical_update(np.ones(500) / 500, Lref)
+    assert w.shape == (2, 3, 500) and nrm.shape == (2, 3, 1)
+    np.testing.assert_allclose(L, Lref.transpose(0, 2, 1), atol=1e-15)
+    np.testing.assert_allclose(w, wref, rtol=1e-12, atol=1e-18)
+    np.testing.assert_allclose(nrm, nref, rtol=1e-12)
+
+
+def test_reset_and_setters(qi):
+    np.random.seed(3)
+    upd = qi.SMCUpdater(qi.RandomizedBenchmarkingModel(), 400,
+                        qi.PostselectedDistribution(qi.UniformDistribution([[0.8, 1], [0, 1], [0, 1]]),
+                                                    qi.RandomizedBenchmarkingModel()))
+    assert upd.particle_locations.shape == (400, 3)
+    assert np.all(orc.valid_rb(upd.particle_locations))
+    before = upd.particle_locations
+    upd.reset(only_params=np.s_[1:2])
+    after = upd.particle_locations
+    assert np.array_equal(before[:, 0], after[:, 0]) and not np.array_equal(before[:, 1], after[:, 1])
+    with pytest.raises(ValueError):
+        upd.reset(n_particles=10, only_params=np.s_[0:1])
+    upd.reset(50)
+    assert upd.n_particles == 50 and upd.n_ess == pytest.approx(50)
+    with pytest.raises(ValueError):
+        qi.SMCUpdater(qi.SimplePrecessionModel(), 10, qi.UniformDistribution([0, 1]), resample_a=0.9,
+                      resampler=qi.LiuWestResampler())
+
+
+def test_smc_fitting_statistical(qi):
+    """tests/test_precession_model.py:86-110: N = 10 000, 100 times in linspace(1, 10)."""
+    np.random.seed(0)
+    m = qi.SimplePrecessionModel()
+    true = np.array([[1.0]])
+    ts = np.linspace(1, 10, 100)
+    data = m.simulate_experiment(true, ts, repeat=1).reshape(-1)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        upd = qi.SMCUpdater(m, 10000, qi.UniformDistribution([0, 2]))
+        upd.batch_update(data, ts, resample_interval=5)
+    np.testing.assert_almost_equal(upd.est_mean()[0], 1.0, 2)
+    assert upd.est_covariance_mtx()[0, 0] < 0.01
+
+
+def test_device_rng_end_to_end(qi):
+    """Config-C1-shaped run entirely on device RNG (Philox prior + Philox Liu-West)."""
+    n = 200000
+    rs = np.random.RandomState(1)
+    ts = (9 / 8) ** np.arange(60.0)
+    outcomes = (rs.random_sample(60) >= np.cos(0.3 * ts / 2) ** 2).astype(int)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        upd = qi.SMCUpdater(qi.SimplePrecessionModel(), n, qi.UniformDistribution([0, 1]), device_rng=True, seed=7)
+        x0 = upd.particle_locations
+        assert 0.49 < x0.mean() < 0.51 and x0.min() > 0 and x0.max() < 1
+        for k in range(60):
+            upd.update(int(outcomes[k]), ts[k:k + 1])
+        # same data through the oracle (its own RNG): posterior means agree to a few posterior sigmas
+        np.random.seed(2)
+        ref = orc.OracleSMC(orc.precession_model(), 20000, lambda m: np.random.random((m, 1)))
+        for k in range(60):
+            ref.update(int(outcomes[k]), {"t": ts[k:k + 1]})
+    sd = np.sqrt(ref.est_covariance_mtx()[0, 0])
+    assert abs(upd.est_mean()[0] - ref.est_mean()[0]) < 5 * sd / np.sqrt(ref.n_ess) + 0.2 * sd
+    assert abs(upd.resample_count - ref.resample_count) <= 3
+
+
+# ================================================================== full-size properties (1e7)
+def test_full_size_properties(qi, eng):
+    """BASELINE config-2 size: size-independent invariants of the kernels at N = 1e7."""
+    n = 10_000_000
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        upd = qi.SMCUpdater(qi.SimplePrecessionModel(), n, qi.UniformDistribution([0, 1]), device_rng=True, seed=3)
+    assert upd.n_ess == pytest.approx(n, rel=1e-12)
+    mean0, cov0 = upd.est_mean(), upd.est_covariance_mtx()
+    assert abs(mean0[0] - 0.5) < 5e-4 and abs(cov0[0, 0] - 1 / 12) < 5e-4
+    upd.update(0, np.array([1.0]), check_for_resample=False)
+    # closed form: E_x~U[0,1] cos^2(x/2) = 1/2 + sin(1)/2
+    assert upd.normalization_record[-1] == pytest.approx(0.5 + np.sin(1.0) / 2, abs=2e-4)
+    w = eng.normalized_weights(upd._w, upd._norm)
+    assert float(w.sum().item()) == pytest.approx(1.0, abs=1e-12)
+    cdf = eng.cumsum(upd._w, upd._norm)
+    assert float(cdf[-1].item()) == pytest.approx(1.0, abs=1e-11)
+    assert bool((cdf[1:] >= cdf[:-1]).all().item())
+    # linearity of the update in the weights: two half-strength clouds sum to the full one
+    st_full = eng.weight_stats(upd._w, upd._norm)
+    st_half = eng.weight_stats(upd._w, 2 * upd._norm)
+    assert st_half.sum == pytest.approx(st_full.sum / 2, rel=1e-14)
+    # Liu-West preserves the first two moments (a^2 + h^2 = 1) up to Monte-Carlo error
+    m1, c1 = upd.est_mean(), upd.est_covariance_mtx()
+    upd.resample()
+    m2, c2 = upd.est_mean(), upd.est_covariance_mtx()
+    assert abs(m2[0] - m1[0]) < 6 * np.sqrt(c1[0, 0] / n)
+    assert abs(c2[0, 0] / c1[0, 0] - 1) < 5e-3
+    assert upd.n_ess == pytest.approx(n, rel=1e-12)
+    assert float(upd._x.min().item()) > 0.0                  # postselection held at full size

@@ -1,0 +1,175 @@
+"""CPU tests of the host-side mirror of the reference interface (no GPU compute): class
+surface, expparams translation into the C ABI structs, priors, bases, resampler parameters."""
+import numpy as np
+import pytest
+
+import np_oracle as orc
+import qinfer_amd as qi
+from qinfer_amd import _native
+
+
+def test_public_surface_matches_reference_names():
+    for name in ["SMCUpdater", "LiuWestResampler", "Resampler", "Model", "Simulatable", "FiniteOutcomeModel",
+                 "SimplePrecessionModel", "SimpleInversionModel", "BinomialModel", "DerivedModel",
+                 "RandomizedBenchmarkingModel", "TomographyModel", "Distribution", "UniformDistribution",
+                 "PostselectedDistribution", "ProductDistribution", "MultivariateNormalDistribution",
+                 "ParticleDistribution", "ResamplerError", "ResamplerWarning", "ApproximationWarning"]:
+        assert hasattr(qi, name), name
+    assert issubclass(qi.ResamplerError, RuntimeError)
+    assert issubclass(qi.ResamplerWarning, RuntimeWarning)
+    assert issubclass(qi.ApproximationWarning, RuntimeWarning)
+    assert issubclass(qi.SMCUpdater, qi.ParticleDistribution)
+    import inspect
+    sig = inspect.signature(qi.SMCUpdater.__init__)
+    ref_args = ["model", "n_particles", "prior", "resample_a", "resampler", "resample_thresh", "debug_resampling",
+                "track_resampling_divergence", "zero_weight_policy", "zero_weight_thresh", "canonicalize"]
+    assert list(sig.parameters)[1:1 + len(ref_args)] == ref_args
+    sig = inspect.signature(qi.LiuWestResampler.__init__)
+    assert list(sig.parameters)[1:9] == ["a", "h", "maxiter", "debug", "postselect", "zero_cov_comp",
+                                         "default_n_particles", "kernel"]
+    for meth in ["update", "batch_update", "hypothetical_update", "resample", "reset", "est_mean",
+                 "est_covariance_mtx", "est_meanfn", "est_entropy", "sample"]:
+        assert callable(getattr(qi.SMCUpdater, meth))
+    for prop in ["resample_count", "just_resampled", "normalization_record", "log_total_likelihood",
+                 "min_n_ess", "data_record", "resampling_divergences", "n_particles", "n_ess", "n_rvs",
+                 "particle_locations", "particle_weights"]:
+        assert isinstance(getattr(qi.SMCUpdater, prop), property), prop
+
+
+def test_model_metadata():
+    m = qi.SimplePrecessionModel()
+    assert m.n_modelparams == 1 and m.expparams_dtype == 'float' and m.n_outcomes(None) == 2
+    assert m.is_n_outcomes_constant and m.modelparam_names == [r'\omega']
+    assert qi.SimpleInversionModel().expparams_dtype == [('t', 'float'), ('w_', 'float')]
+    assert m.domain(None).values.tolist() == [0, 1]
+    b = qi.BinomialModel(m)
+    assert b.expparams_dtype == [('x', 'float'), ('n_meas', 'uint')]
+    assert not b.is_n_outcomes_constant and b.underlying_model is m and b.base_model is m
+    assert b.model_chain == (m,) and b.decorated_model is m
+    ep = np.empty((2,), dtype=b.expparams_dtype)
+    ep['x'], ep['n_meas'] = [1.0, 2.0], [25, 7]
+    assert b.n_outcomes(ep).tolist() == [26, 8]
+    assert [d.max for d in b.domain(ep)] == [25, 7]
+    rb = qi.RandomizedBenchmarkingModel()
+    assert rb.n_modelparams == 3 and rb.modelparam_names == ['p', 'A', 'B']
+    assert rb.expparams_dtype == [('m', 'uint')]
+    rbi = qi.RandomizedBenchmarkingModel(interleaved=True)
+    assert rbi.n_modelparams == 4 and rbi.expparams_dtype == [('m', 'uint'), ('reference', bool)]
+    with pytest.raises(NotImplementedError):
+        qi.RandomizedBenchmarkingModel(order=1)
+    with pytest.raises(ValueError):
+        qi.BinomialModel(b)                      # not a two-outcome model
+    tm = qi.TomographyModel(qi.tomography.pauli_basis(2))
+    assert tm.n_modelparams == 16 and tm.dim == 4
+    assert np.dtype(tm.expparams_dtype)['meas'].shape == (16,)
+    assert tm.are_models_valid(np.zeros((5, 16))).all()
+    assert np.array_equal(m.update_timestep(np.ones((3, 1)), np.zeros(2)), np.ones((3, 1, 2)))
+    assert m.Q.tolist() == [1.0] and m.experiment_cost(np.zeros(3)).tolist() == [1, 1, 1]
+
+
+def test_expparam_translation():
+    m = qi.SimplePrecessionModel()
+    eps = m._native_expparams(np.array([0.5, 2.0]))
+    assert [e.t for e in eps] == [0.5, 2.0] and all(e.w_ == 0 for e in eps)
+    rec = np.array([(3.0, 0.25)], dtype=qi.SimpleInversionModel().expparams_dtype)
+    e = qi.SimpleInversionModel()._native_expparams(rec)[0]
+    assert (e.t, e.w_) == (3.0, 0.25)
+    e = m._native_expparams(np.array([(4.0, 0.0)], dtype=[('t', float), ('w_', float)]))[0]
+    assert e.t == 4.0
+    b = qi.BinomialModel(m)
+    ep = np.empty((1,), dtype=b.expparams_dtype)
+    ep['x'], ep['n_meas'] = 1.5, 25
+    e = b._native_expparams(ep)[0]
+    assert (e.t, e.n_meas) == (1.5, 25)
+    assert b._native_desc().kind == _native.MODEL_BINOMIAL_PRECESSION
+    rbi = qi.RandomizedBenchmarkingModel(interleaved=True)
+    ep = np.empty((2,), dtype=rbi.expparams_dtype)
+    ep['m'], ep['reference'] = [5, 9], [True, False]
+    es = rbi._native_expparams(ep)
+    assert [(e.m, e.reference) for e in es] == [(5, 1), (9, 0)]
+    assert rbi._native_desc().d == 4
+    tm = qi.TomographyModel(qi.tomography.pauli_basis(1))
+    ep = np.zeros((1,), dtype=tm.expparams_dtype)
+    ep['meas'][0] = [1, 0, 0, 1]
+    e = tm._native_expparams(ep)[0]
+    assert list(e.meas)[:4] == [1, 0, 0, 1]
+    with pytest.raises(ValueError):
+        _native.make_expparam(meas=np.zeros(17))
+    big = qi.TomographyModel(qi.tomography.gell_mann_basis(5))   # d = 25 > QSMC_MAX_D: plugin path
+    assert big._native is False
+
+
+def test_bases_match_oracle():
+    np.testing.assert_allclose(qi.tomography.gell_mann_basis(3).data, orc.gell_mann_data(3), atol=1e-15)
+    np.testing.assert_allclose(qi.tomography.pauli_basis(2).data, orc.pauli_data(2), atol=1e-15)
+    b = qi.tomography.pauli_basis(2)
+    gram = np.einsum('aij,bij->ab', b.data.conj(), b.data)
+    np.testing.assert_allclose(gram, np.eye(16), atol=1e-14)            # orthonormal
+    np.testing.assert_allclose(b.data[0], np.eye(4) / 2, atol=1e-15)    # B_0 = 1 / sqrt(dim)
+    rho = np.diag([0.4, 0.3, 0.2, 0.1]).astype(complex)
+    x = b.state_to_modelparams(rho)
+    np.testing.assert_allclose(b.modelparams_to_state(x), rho, atol=1e-14)
+    assert x[0] == pytest.approx(0.5)
+    assert len(b) == 16 and b.dim == 4 and "pauli_basis" in repr(b)
+    tp = qi.tomography.tensor_product_basis(qi.tomography.gell_mann_basis(2), qi.tomography.gell_mann_basis(3))
+    assert tp.data.shape == (36, 6, 6) and tp.dims == [2, 3]
+
+
+def test_priors():
+    np.random.seed(0)
+    u = qi.UniformDistribution([[0, 1], [2, 4]])
+    s = u.sample(1000)
+    assert s.shape == (1000, 2) and s[:, 1].min() >= 2 and s[:, 1].max() <= 4 and u.n_rvs == 2
+    np.random.seed(0)
+    ref = np.random.random((1000, 2)) * np.array([1, 2]) + np.array([0, 2])
+    np.testing.assert_array_equal(s, ref)                   # same stream consumption as the reference
+    assert qi.UniformDistribution([0, 2]).n_rvs == 1
+    p = qi.ProductDistribution(qi.UniformDistribution([0, 1]), u)
+    assert p.n_rvs == 3 and p.sample(7).shape == (7, 3)
+    assert qi.ProductDistribution([u, u]).n_rvs == 4
+    mvn = qi.MultivariateNormalDistribution(np.array([1.0, -1.0]), np.array([[2.0, 0.3], [0.3, 1.0]]))
+    s = mvn.sample(20000)
+    np.testing.assert_allclose(s.mean(axis=0), [1, -1], atol=0.05)
+    np.testing.assert_allclose(np.cov(s.T), mvn.cov, atol=0.08)
+
+    class Half:
+        def are_models_valid(self, mp):
+            return mp[:, 0] > 0.5
+    ps = qi.PostselectedDistribution(qi.UniformDistribution([0, 1]), Half())
+    s = ps.sample(500)
+    assert s.min() > 0.5 and ps.n_rvs == 1
+
+    class Never:
+        def are_models_valid(self, mp):
+            return np.zeros(mp.shape[0], dtype=bool)
+    with pytest.raises(RuntimeError):
+        qi.PostselectedDistribution(qi.UniformDistribution([0, 1]), Never(), maxiters=3).sample(4)
+    g = qi.GinibreDistribution(qi.tomography.pauli_basis(2))
+    x = g.sample(20)
+    assert x.shape == (20, 16)
+    np.testing.assert_allclose(x[:, 0], 0.5, atol=1e-14)    # trace one
+    rho = np.tensordot(x, qi.tomography.pauli_basis(2).data, 1)
+    assert np.linalg.eigvalsh(rho).min() > -1e-14
+
+
+def test_liu_west_parameters():
+    r = qi.LiuWestResampler()
+    assert r.a == 0.98 and r.h == pytest.approx(np.sqrt(1 - 0.98 ** 2))
+    r.a = 0.9
+    assert r.h == pytest.approx(np.sqrt(1 - 0.81))
+    r = qi.LiuWestResampler(a=1.0, h=0.005)
+    r.a = 0.5
+    assert r.h == 0.005                                     # an explicit h is never overridden
+    assert isinstance(r, qi.Resampler)
+    with pytest.raises(TypeError):
+        qi.Resampler()
+
+
+def test_pr0_to_likelihood_array_and_domain():
+    pr0 = np.array([[0.2, 0.7]])
+    L = qi.FiniteOutcomeModel.pr0_to_likelihood_array(np.array([0, 1, 1]), pr0)
+    assert L.shape == (3, 1, 2)
+    np.testing.assert_allclose(L[0], pr0)
+    np.testing.assert_allclose(L[1], 1 - pr0)
+    d = qi.IntegerDomain(min=0, max=3)
+    assert d.n_members == 4 and d.values.tolist() == [0, 1, 2, 3] and d.in_domain([1, 2]) and not d.in_domain([4])
