@@ -375,7 +375,19 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_chunk_sums(const double *__restr
     if (threadIdx.x == 0) sums[blockIdx.x] = v[0];
 }
 
-// exclusive scan of `sums` in place (single workgroup, sequential over 256-wide slabs with carry)
+__device__ __forceinline__ double wave_inclusive_max(double v, int lane) {
+#pragma unroll
+    for (int off = 1; off < QSMC_WAVE; off <<= 1) {
+        const double t = __shfl_up(v, off, QSMC_WAVE);
+        if (lane >= off) v = fmax(v, t);
+    }
+    return v;
+}
+
+// Exclusive scan of the chunk sums, in place, plus the grand total at sums[m]  (m + 1 outputs).
+// Single workgroup, 256-wide slabs with a carry.  Floating-point tree sums are not guaranteed
+// monotone in the index, so a second exact pass (prefix MAX -- no rounding) makes the offsets
+// non-decreasing; k_chunk_scan relies on that to emit a monotone CDF.
 __global__ __launch_bounds__(QSMC_BLOCK) void k_scan_sums(double *__restrict__ sums, int64_t m) {
     __shared__ double wave_tot[QSMC_WAVES_PER_BLOCK];
     __shared__ double carry_s;
@@ -386,18 +398,43 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_scan_sums(double *__restrict__ s
     for (int64_t base = 0; base < m; base += QSMC_BLOCK) {
         const int64_t i = base + threadIdx.x;
         const double v = i < m ? sums[i] : 0.0;
-        double inc = wave_inclusive_scan(v, lane);
+        const double inc = wave_inclusive_scan(v, lane);
+        double excl = __shfl_up(inc, 1, QSMC_WAVE);
+        if (lane == 0) excl = 0.0;
         if (lane == QSMC_WAVE - 1) wave_tot[wave] = inc;
         __syncthreads();
         double off = carry_s;
         for (int wv = 0; wv < wave; ++wv) off += wave_tot[wv];
-        if (i < m) sums[i] = off + (inc - v);
+        if (i < m) sums[i] = off + excl;
         __syncthreads();
         if (threadIdx.x == QSMC_BLOCK - 1) carry_s = off + inc;
         __syncthreads();
     }
+    if (threadIdx.x == 0) sums[m] = carry_s;
+    __syncthreads();
+    // exact prefix max over sums[0..m]
+    if (threadIdx.x == 0) carry_s = 0.0;
+    __syncthreads();
+    for (int64_t base = 0; base <= m; base += QSMC_BLOCK) {
+        const int64_t i = base + threadIdx.x;
+        const double v = i <= m ? sums[i] : 0.0;
+        const double mx = wave_inclusive_max(v, lane);
+        if (lane == QSMC_WAVE - 1) wave_tot[wave] = mx;
+        __syncthreads();
+        double run = carry_s;
+        for (int wv = 0; wv < wave; ++wv) run = fmax(run, wave_tot[wv]);
+        const double out = fmax(mx, run);
+        if (i <= m) sums[i] = out;
+        __syncthreads();
+        if (threadIdx.x == QSMC_BLOCK - 1) carry_s = out;
+        __syncthreads();
+    }
 }
 
+// Per-chunk scan.  offsets[] has chunks + 1 monotone entries (exclusive offsets + total).
+// Every value is clamped into its wave's [lo, hi] offset window and then passed through an exact
+// prefix max, so cdf[] is non-decreasing everywhere (searchsorted on it is well defined) while
+// differing from the sequential np.cumsum only by rounding.
 __global__ __launch_bounds__(QSMC_BLOCK) void k_chunk_scan(const double *__restrict__ w, int64_t n,
                                                            double norm, const double *__restrict__ offsets,
                                                            double *__restrict__ cdf) {
@@ -414,20 +451,34 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_chunk_scan(const double *__restr
         const double b = i + 1 < n ? w[i + 1] / norm : 0.0;
         const double pair = a + b;
         const double inc = wave_inclusive_scan(pair, lane);
-        const double excl = carry + (inc - pair);
+        double excl = __shfl_up(inc, 1, QSMC_WAVE);
+        if (lane == 0) excl = 0.0;
+        excl += carry;
         r[t][0] = excl + a;
         r[t][1] = excl + pair;
         carry += __shfl(inc, QSMC_WAVE - 1, QSMC_WAVE);
     }
     if (lane == 0) wave_tot[wave] = carry;
     __syncthreads();
-    double off = offsets[blockIdx.x];
-    for (int wv = 0; wv < wave; ++wv) off += wave_tot[wv];
+    const double blo = offsets[blockIdx.x], bhi = offsets[blockIdx.x + 1];
+    double lo = blo;
+    for (int wv = 0; wv < wave; ++wv) lo = fmin(lo + wave_tot[wv], bhi);
+    const double hi = (wave == QSMC_WAVES_PER_BLOCK - 1) ? bhi : fmin(lo + wave_tot[wave], bhi);
+    double run = lo;
 #pragma unroll
     for (int t = 0; t < SCAN_TILES_PER_WAVE; ++t) {
         const int64_t i = wbase + (int64_t)t * SCAN_WAVE_TILE + lane * SCAN_PER_LANE;
-        if (i < n) cdf[i] = off + r[t][0];
-        if (i + 1 < n) cdf[i + 1] = off + r[t][1];
+        double a0 = fmin(fmax(lo + r[t][0], lo), hi);
+        double a1 = fmin(fmax(lo + r[t][1], lo), hi);
+        a1 = fmax(a1, a0);
+        const double m = wave_inclusive_max(a1, lane);
+        double prev = __shfl_up(m, 1, QSMC_WAVE);
+        prev = (lane == 0) ? run : fmax(prev, run);
+        a0 = fmax(a0, prev);
+        a1 = fmax(m, run);
+        run = fmax(run, __shfl(m, QSMC_WAVE - 1, QSMC_WAVE));
+        if (i < n) cdf[i] = a0;
+        if (i + 1 < n) cdf[i + 1] = a1;
     }
 }
 
@@ -909,7 +960,7 @@ int qsmc_cumsum(qsmc_handle_t h, const double *w, int64_t n, double norm, double
     if (!h || !w || !cdf || n <= 0) return QSMC_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
     const int64_t chunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
-    int rc = ensure_partials(h, (size_t)chunks);
+    int rc = ensure_partials(h, (size_t)chunks + 1);
     if (rc) return rc;
     hipLaunchKernelGGL(k_chunk_sums, dim3((unsigned)chunks), dim3(QSMC_BLOCK), 0, s, w, n, norm, h->partials);
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(QSMC_BLOCK), 0, s, h->partials, chunks);

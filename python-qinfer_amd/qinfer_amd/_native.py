@@ -76,6 +76,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own HIP runtime; it must be in the process BEFORE libqsmc_hip.so is dlopen'ed
+    # so that both resolve to ONE libamdhip64 (streams / device pointers are shared with torch).
+    import torch  # noqa: F401
     if not os.path.exists(_LIB_PATH):
         raise NativeLibraryError(
             "libqsmc_hip.so not found at {}; build it with `python -c 'import __graft_entry__ as g; "

@@ -389,9 +389,10 @@ def _run_traj(qi, g, model, ep_of, cond, batch=None, canonicalize=False):
                     upd._maybe_resample()
             checked = k
             assert upd.resample_count == g["resample_count"][k], "datum %d" % k
-            np.testing.assert_allclose(upd.normalization_record[-1], g["norms"][k], rtol=tol.rtol_norm(c),
-                                       err_msg="datum %d" % k)
-            np.testing.assert_allclose(upd.n_ess, g["n_ess"][k], rtol=tol.rtol_ess(c))
+            extra = 10 * tol.atol_sqrtm_psd(g["covs"][k]) if canonicalize else 0.0   # singular-cov noise
+            np.testing.assert_allclose(upd.normalization_record[-1], g["norms"][k],
+                                       rtol=tol.rtol_norm(c) + extra, err_msg="datum %d" % k)
+            np.testing.assert_allclose(upd.n_ess, g["n_ess"][k], rtol=tol.rtol_ess(c) + 4 * extra)
             np.testing.assert_allclose(upd.est_mean(), g["means"][k], rtol=0,
                                        atol=max(tol.atol_mean(g["means"][k]),
                                                 tol.atol_sqrtm_psd(g["covs"][k]) if canonicalize else 0))
@@ -490,10 +491,12 @@ def test_every_step_from_oracle_state(qi):
                 break
             upd.update(int(outcomes[k]), ts[k:k + 1])
             # likelihood differs by <= 1e-15 abs per particle (cos ulp) -> weights by that, relative to L
-            np.testing.assert_allclose(upd.normalization_record[-1], ref.normalization_record[-1],
+            rnorm = float(np.ravel(ref.normalization_record[-1])[0])
+            np.testing.assert_allclose(upd.normalization_record[-1], rnorm,
                                        rtol=1e-12, atol=1e-15, err_msg="datum %d" % k)
             np.testing.assert_allclose(upd.particle_weights, ref.w, rtol=1e-11,
-                                       atol=2e-15 * ref.w.max() / max(ref.normalization_record[-1], 1e-3) + 1e-18)
+                                       atol=float(2e-15 * w_before.max() / max(rnorm, 1e-3) + 1e-18),
+                                       err_msg="datum %d" % k)
             np.testing.assert_allclose(upd.n_ess, ref.n_ess, rtol=1e-10)
             if ref.n_ess < n / 2:          # resample on the oracle with the legacy stream, adopt it
                 ref.resample()
@@ -699,11 +702,17 @@ def test_full_size_properties(qi, eng):
     st_full = eng.weight_stats(upd._w, upd._norm)
     st_half = eng.weight_stats(upd._w, 2 * upd._norm)
     assert st_half.sum == pytest.approx(st_full.sum / 2, rel=1e-14)
-    # Liu-West preserves the first two moments (a^2 + h^2 = 1) up to Monte-Carlo error
+    # Liu-West preserves the first two moments (a^2 + h^2 = 1) up to Monte-Carlo error -- when no
+    # postselection truncates the kernel (with the omega > 0 boundary inside the cloud the
+    # reference, too, renormalises ~sigma/sqrt(2 pi) of the mass: measured +0.0106 on the mean)
     m1, c1 = upd.est_mean(), upd.est_covariance_mtx()
-    upd.resample()
-    m2, c2 = upd.est_mean(), upd.est_covariance_mtx()
+    free = qi.LiuWestResampler(a=0.98, postselect=False, device_rng=True, seed=11)
+    new = free(upd.model, upd)
+    m2, c2 = new.est_mean(), new.est_covariance_mtx()
     assert abs(m2[0] - m1[0]) < 6 * np.sqrt(c1[0, 0] / n)
     assert abs(c2[0, 0] / c1[0, 0] - 1) < 5e-3
+    upd.resample()                                           # default resampler: postselect=True
     assert upd.n_ess == pytest.approx(n, rel=1e-12)
     assert float(upd._x.min().item()) > 0.0                  # postselection held at full size
+    m3 = upd.est_mean()
+    assert 0.005 < m3[0] - m1[0] < 0.02                      # the truncation shift described above
