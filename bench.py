@@ -81,7 +81,7 @@ def main():
     ap.add_argument("--particles", type=float, default=1e7, help="particles PER GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-particles", type=float, default=2e6)
-    ap.add_argument("--cpu-data", type=int, default=40)
+    ap.add_argument("--cpu-data", type=int, default=120)
     args = ap.parse_args()
 
     import torch

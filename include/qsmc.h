@@ -185,6 +185,23 @@ int qsmc_lw_resample_philox(qsmc_handle_t h, const qsmc_model_t *model, int32_t 
                             double *x_out, int64_t ldx_out, int64_t *n_failed_host,
                             qsmc_stream_t stream);
 
+/* Sharded resampling, step 1: draw `n_draw` ancestors from THIS shard's CDF
+ * (u from Philox, counter = draw index) and gather their rows: anc_out[m][t] = x_in[m][j_t].
+ * `cdf` must be the scan of w / norm_local (last entry ~ 1). */
+int qsmc_lw_draw_gather_philox(qsmc_handle_t h, const double *x_in, int64_t ldx_in, int64_t n_in,
+                               int32_t d, const double *cdf, int64_t n_draw, uint64_t seed,
+                               uint64_t epoch, double *anc_out, int64_t ld_anc, qsmc_stream_t stream);
+
+/* Sharded resampling, step 2: Liu-West kick of already-gathered ancestors (after the all-to-all):
+ * x_out[:, i] = a * anc[:, c] + (1 - a) * mean + S z, c = i on the first try; an invalid particle
+ * retries with a fresh z and the centre of another (Philox-chosen) local ancestor -- the
+ * reference's effective behaviour under quirk Q1 (`mus = mus[:k]`, resamplers.py:371-372). */
+int qsmc_lw_perturb_philox(qsmc_handle_t h, const qsmc_model_t *model, int32_t postselect,
+                           const double *anc, int64_t ld_anc, int64_t n, int32_t d, double a,
+                           const double *mean, const double *S, uint64_t seed, uint64_t epoch,
+                           int32_t maxiter, double *x_out, int64_t ldx_out, int64_t *n_failed_host,
+                           qsmc_stream_t stream);
+
 /* Device-RNG uniform-box prior (distributions.py:792-827 + :1304-1350 postselection):
  * x[m][i] = lo[m] + U * (hi[m] - lo[m]), redrawn in-thread while invalid (<= maxiter). */
 int qsmc_prior_uniform_philox(qsmc_handle_t h, const qsmc_model_t *model, int32_t postselect,

@@ -9,6 +9,7 @@
 //     sums the partials in index order (bitwise reproducible for a given n);
 //   * weights stay unnormalised in HBM; the normaliser is a scalar folded into the next read.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cmath>
 #include <cstdio>
@@ -579,6 +580,60 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_resample_philox(
     if (failed) atomicAdd(n_failed, failed);
 }
 
+__global__ __launch_bounds__(QSMC_BLOCK) void k_draw_gather_philox(const double *__restrict__ x_in,
+                                                                    int64_t ldx_in, int64_t n_in, int d,
+                                                                    const double *__restrict__ cdf,
+                                                                    int64_t n_draw, uint32_t k0, uint32_t k1,
+                                                                    uint32_t epoch, double *__restrict__ anc,
+                                                                    int64_t ld_anc) {
+    for (int64_t t = (int64_t)blockIdx.x * QSMC_BLOCK + threadIdx.x; t < n_draw;
+         t += (int64_t)gridDim.x * QSMC_BLOCK) {
+        PhiloxStream rng{(uint64_t)t, (epoch << 16), k0, k1};
+        double u, unused;
+        rng.uniforms(0, u, unused);
+        const int64_t j = search_right(cdf, n_in, u);
+        for (int m = 0; m < d; ++m) anc[m * ld_anc + t] = x_in[m * ldx_in + j];
+    }
+}
+
+__global__ __launch_bounds__(QSMC_BLOCK) void k_perturb_philox(
+    int kind, int d, double min_freq, int postselect, const double *__restrict__ anc, int64_t ld_anc,
+    int64_t n, LWArgs lw, uint32_t k0, uint32_t k1, uint32_t epoch, int maxiter,
+    double *__restrict__ x_out, int64_t ldx_out, unsigned long long *__restrict__ n_failed) {
+    unsigned long long failed = 0;
+    for (int64_t i = (int64_t)blockIdx.x * QSMC_BLOCK + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * QSMC_BLOCK) {
+        double p[QSMC_MAX_D];
+        bool ok = false;
+        for (int round = 0; round < maxiter && !ok; ++round) {
+            PhiloxStream rng{(uint64_t)i, (epoch << 16) | (uint32_t)round, k0, k1};
+            int64_t c = i;
+            if (round > 0) {                      // centre of another local ancestor (quirk-Q1 behaviour)
+                double u, unused;
+                rng.uniforms(0, u, unused);
+                c = (int64_t)(u * (double)n);
+                if (c >= n) c = n - 1;
+            }
+            double zz[QSMC_MAX_D];
+            for (int q = 0; q < d; q += 2) {
+                double z0, z1;
+                rng.normals(1 + (q >> 1), z0, z1);
+                zz[q] = z0;
+                if (q + 1 < d) zz[q + 1] = z1;
+            }
+            for (int m = 0; m < d; ++m) {
+                double s = 0.0;
+                for (int q = 0; q < d; ++q) s += lw.S[m * d + q] * zz[q];
+                p[m] = (lw.a * anc[m * ld_anc + c] + (1.0 - lw.a) * lw.mean[m]) + s;
+            }
+            ok = !postselect || model_valid(kind, p, min_freq);
+        }
+        for (int m = 0; m < d; ++m) x_out[m * ldx_out + i] = p[m];
+        if (!ok) ++failed;
+    }
+    if (failed) atomicAdd(n_failed, failed);
+}
+
 __global__ __launch_bounds__(QSMC_BLOCK) void k_prior_uniform_philox(
     int kind, int d, double min_freq, int postselect, LWArgs box /* mean = lo, S[0..d) = hi - lo */,
     int64_t n, uint32_t k0, uint32_t k1, uint32_t epoch, int maxiter, double *__restrict__ x_out,
@@ -693,15 +748,18 @@ static int finish_stats(qsmc_ctx *h, int grid, double *stats_dev, qsmc_update_st
 }
 
 template <int KIND>
-static void launch_update(bool vec2, int grid, hipStream_t s, const double *x, int64_t ldx, int64_t n,
-                          const double *w_in, double *w_out, double prev_norm, const ExpArgs &e,
+static void launch_update(qsmc_ctx *h, bool vec2, int grid, hipStream_t s, const double *x, int64_t ldx,
+                          int64_t n, const double *w_in, double *w_out, double prev_norm, const ExpArgs &e,
                           int64_t outcome, double *partials) {
+    // In profiling mode the launch carries start/stop events, so the elapsed time is the kernel's
+    // own execution (what rocprofv3 --kernel-trace reports), not launch latency.
+    hipEvent_t e0 = h->profiling ? h->ev0 : nullptr, e1 = h->profiling ? h->ev1 : nullptr;
     if (vec2)
-        hipLaunchKernelGGL((k_update_fused<KIND, 2>), dim3(grid), dim3(QSMC_BLOCK), 0, s, x, ldx, n, w_in,
-                           w_out, prev_norm, e, outcome, partials);
+        hipExtLaunchKernelGGL((k_update_fused<KIND, 2>), dim3(grid), dim3(QSMC_BLOCK), 0, s, e0, e1, 0, x, ldx,
+                              n, w_in, w_out, prev_norm, e, outcome, partials);
     else
-        hipLaunchKernelGGL((k_update_fused<KIND, 1>), dim3(grid), dim3(QSMC_BLOCK), 0, s, x, ldx, n, w_in,
-                           w_out, prev_norm, e, outcome, partials);
+        hipExtLaunchKernelGGL((k_update_fused<KIND, 1>), dim3(grid), dim3(QSMC_BLOCK), 0, s, e0, e1, 0, x, ldx,
+                              n, w_in, w_out, prev_norm, e, outcome, partials);
 }
 
 template <int MODE>
@@ -839,11 +897,10 @@ int qsmc_update_fused(qsmc_handle_t h, const qsmc_model_t *model, const double *
     if (rc) return rc;
     ExpArgs ea;
     make_exp_args(model, exp, outcome, &ea);
-    if (h->profiling) HIP_TRY(h, hipEventRecord(h->ev0, s));
     switch (model->kind) {
 #define LAUNCH_U(K)                                                                                   \
     case K:                                                                                           \
-        launch_update<K>(vec2, grid, s, x, ldx, n, w_in, w_out, prev_norm, ea, outcome, h->partials);  \
+        launch_update<K>(h, vec2, grid, s, x, ldx, n, w_in, w_out, prev_norm, ea, outcome, h->partials); \
         break;
         LAUNCH_U(QSMC_MODEL_PRECESSION)
         LAUNCH_U(QSMC_MODEL_BINOMIAL_PRECESSION)
@@ -853,10 +910,7 @@ int qsmc_update_fused(qsmc_handle_t h, const qsmc_model_t *model, const double *
 #undef LAUNCH_U
     }
     HIP_TRY(h, hipGetLastError());
-    if (h->profiling) {
-        HIP_TRY(h, hipEventRecord(h->ev1, s));
-        h->ev_valid = 1;
-    }
+    if (h->profiling) h->ev_valid = 1;
     return finish_stats(h, grid, stats_dev, stats_host, s);
 }
 
@@ -1043,6 +1097,39 @@ int qsmc_lw_resample_philox(qsmc_handle_t h, const qsmc_model_t *model, int32_t 
                        model->kind, d, model->min_freq, postselect, x_in, ldx_in, n_in, cdf, lw, n_out, k0, k1,
                        (uint32_t)(epoch & 0xFFFFu), maxiter, x_out, ldx_out,
                        reinterpret_cast<unsigned long long *>(h->counter));
+    HIP_TRY(h, hipGetLastError());
+    if (n_failed_host) return read_counter(h, n_failed_host, s);
+    return QSMC_OK;
+}
+
+int qsmc_lw_draw_gather_philox(qsmc_handle_t h, const double *x_in, int64_t ldx_in, int64_t n_in, int32_t d,
+                               const double *cdf, int64_t n_draw, uint64_t seed, uint64_t epoch,
+                               double *anc_out, int64_t ld_anc, qsmc_stream_t stream) {
+    if (!h || !x_in || !cdf || !anc_out || n_in <= 0 || n_draw < 0 || d < 1 || d > QSMC_MAX_D)
+        return QSMC_ERR_INVALID;
+    if (n_draw == 0) return QSMC_OK;
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32) ^ (uint32_t)(epoch >> 16);
+    hipLaunchKernelGGL(k_draw_gather_philox, dim3(grid_for(n_draw, QSMC_BLOCK)), dim3(QSMC_BLOCK), 0,
+                       (hipStream_t)stream, x_in, ldx_in, n_in, d, cdf, n_draw, k0, k1,
+                       (uint32_t)(epoch & 0xFFFFu), anc_out, ld_anc);
+    HIP_TRY(h, hipGetLastError());
+    return QSMC_OK;
+}
+
+int qsmc_lw_perturb_philox(qsmc_handle_t h, const qsmc_model_t *model, int32_t postselect, const double *anc,
+                           int64_t ld_anc, int64_t n, int32_t d, double a, const double *mean, const double *S,
+                           uint64_t seed, uint64_t epoch, int32_t maxiter, double *x_out, int64_t ldx_out,
+                           int64_t *n_failed_host, qsmc_stream_t stream) {
+    if (!h || !model || !anc || !mean || !S || !x_out || n <= 0) return QSMC_ERR_INVALID;
+    if (d != model->d || d < 1 || d > QSMC_MAX_D || maxiter < 1) return QSMC_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    LWArgs lw;
+    fill_lw(&lw, d, a, mean, S);
+    HIP_TRY(h, hipMemsetAsync(h->counter, 0, sizeof(long long), s));
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32) ^ (uint32_t)(epoch >> 16);
+    hipLaunchKernelGGL(k_perturb_philox, dim3(grid_for(n, QSMC_BLOCK)), dim3(QSMC_BLOCK), 0, s, model->kind, d,
+                       model->min_freq, postselect, anc, ld_anc, n, lw, k0, k1, (uint32_t)(epoch & 0xFFFFu),
+                       maxiter, x_out, ldx_out, reinterpret_cast<unsigned long long *>(h->counter));
     HIP_TRY(h, hipGetLastError());
     if (n_failed_host) return read_counter(h, n_failed_host, s);
     return QSMC_OK;

@@ -213,6 +213,29 @@ class Engine:
             x_out.stride(0), C.byref(failed), self.stream()), "qsmc_lw_resample_philox")
         return x_out, failed.value
 
+    def lw_draw_gather_philox(self, x_in, cdf, n_draw, seed, epoch):
+        d = x_in.shape[0]
+        anc = self.empty(d, n_draw)
+        if n_draw:
+            self._chk(self.lib.qsmc_lw_draw_gather_philox(
+                self.h, self._p(x_in), x_in.stride(0), x_in.shape[1], d, self._p(cdf), n_draw,
+                C.c_uint64(seed & (2 ** 64 - 1)), C.c_uint64(epoch), self._p(anc), anc.stride(0),
+                self.stream()), "qsmc_lw_draw_gather_philox")
+        return anc
+
+    def lw_perturb_philox(self, desc, postselect, anc, a, mean, S, seed, epoch, maxiter):
+        d, n = anc.shape
+        x_out = self.empty(d, n)
+        mean = np.ascontiguousarray(mean, dtype=np.float64)
+        S = np.ascontiguousarray(S, dtype=np.float64)
+        failed = C.c_int64()
+        self._chk(self.lib.qsmc_lw_perturb_philox(
+            self.h, C.byref(desc), int(bool(postselect)), self._p(anc), anc.stride(0), n, d, float(a),
+            _native.f64_ptr(mean), _native.f64_ptr(S), C.c_uint64(seed & (2 ** 64 - 1)), C.c_uint64(epoch),
+            int(maxiter), self._p(x_out), x_out.stride(0), C.byref(failed), self.stream()),
+            "qsmc_lw_perturb_philox")
+        return x_out, failed.value
+
     def prior_uniform_philox(self, desc, postselect, lo, hi, n, seed, epoch, maxiter=100):
         d = len(lo)
         x_out = self.empty(d, n)

@@ -1,0 +1,163 @@
+"""Particle sharding across the GPUs of a node: one process per GPU, `torch.distributed`
+(backend "nccl" = RCCL over xGMI on ROCm; "gloo" on CPU for the tests).
+
+The reference's only data-parallel mechanism is `DirectViewParallelizedModel` (parallel.py:76-288):
+split the particle axis over ipyparallel engines for the likelihood call, gather `L` back, keep the
+weights and the resampler on the client.  Here every rank OWNS a contiguous block of N/G particles
+(locations and weights never leave its HBM), and only O(1)-sized reductions cross xGMI:
+
+  per datum      all-gather of 4 doubles/rank  [sum w', sum w'^2, min w', #bad]  -> every rank forms
+                 the same global normaliser, n_ess and resample decision (summed in rank order, so
+                 bitwise identical everywhere);
+  per resample   all-gather of 1 + d + d(d+1)/2 doubles/rank (weighted moments) -> identical global
+                 mean/cov -> identical host sqrtm on every rank; then the only bandwidth step:
+                 an all-to-all(v) of ancestor rows (8 d bytes each).
+
+Exact global multinomial resampling without a global CDF: ancestors for destination rank r come
+from source rank h with probability W_h / W, so the G x G count matrix C[r, h] ~ Multinomial(N/G;
+W/W_tot) is drawn IDENTICALLY on every rank from a shared-seed host generator; rank h then draws
+C[., h] ancestors from its LOCAL CDF (conditionally i.i.d. -- exact), and the rows travel by one
+`all_to_all_single`.  The Liu-West kick and postselection are local.  xGMI is point-to-point, so
+the all-to-all is a direct exchange (worst case 7/8 of the rows leave the rank), not a ring.
+
+The collectives take whatever tensors they are given (CUDA under nccl, CPU under gloo), so the
+protocol is testable on CPU with world_size 2 (tests/test_parallel_gloo.py).
+"""
+import numpy as np
+
+__all__ = ["ParticleShardGroup"]
+
+
+class ParticleShardGroup:
+    def __init__(self, group=None, seed=0):
+        import torch
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised (launch with torch.distributed.run)")
+        self.torch, self.dist, self.group = torch, dist, group
+        self.rank = dist.get_rank(group)
+        self.world_size = dist.get_world_size(group)
+        self.backend = dist.get_backend(group)
+        self.seed = int(seed)
+        self._epoch = 0
+
+    # ------------------------------------------------------------------ small collectives
+    def _comm_tensor(self, t):
+        """Tensor on the device this backend communicates from."""
+        if self.backend == "nccl":
+            return t if t.is_cuda else t.cuda()
+        return t.cpu() if t.is_cuda else t
+
+    def gather_rows(self, vec):
+        """All-gather a 1-D float64 tensor: returns a HOST (world, len) ndarray, rank-ordered."""
+        t = self.torch
+        v = self._comm_tensor(vec.reshape(-1).to(t.float64)).contiguous()
+        out = t.empty(self.world_size * v.shape[0], dtype=t.float64, device=v.device)
+        self.dist.all_gather_into_tensor(out, v, group=self.group)       # flat: accepted by nccl and gloo
+        return out.cpu().numpy().reshape(self.world_size, v.shape[0])
+
+    def combine_update_stats(self, stats):
+        """stats: tensor [sum, sumsq, min, n_bad] of this shard -> global (sum, sumsq, min, n_bad)."""
+        rows = self.gather_rows(stats)
+        tot = np.zeros(2)
+        bad = 0.0
+        for r in range(self.world_size):            # fixed order: identical on every rank
+            tot[0] += rows[r, 0]
+            tot[1] += rows[r, 1]
+            bad += rows[r, 3]
+        return float(tot[0]), float(tot[1]), float(rows[:, 2].min()), float(bad)
+
+    def allreduce_update_stats(self, eng, s, ss, mn, n_bad):
+        t = self.torch
+        return self.combine_update_stats(t.tensor([s, ss, mn, n_bad], dtype=t.float64))
+
+    def allreduce_scalar(self, eng, value):
+        t = self.torch
+        rows = self.gather_rows(t.tensor([value], dtype=t.float64))
+        tot = 0.0
+        for r in range(self.world_size):
+            tot += rows[r, 0]
+        return float(tot)
+
+    def allreduce_moments(self, eng, s0, s1, s2):
+        """Global [sum w, sum w x, sum w x x^T] from per-shard sums (already divided by the GLOBAL norm)."""
+        t = self.torch
+        d = len(s1)
+        packed = np.concatenate([[s0], s1, s2.reshape(-1)])
+        rows = self.gather_rows(t.from_numpy(packed))
+        tot = np.zeros_like(packed)
+        for r in range(self.world_size):
+            tot += rows[r]
+        return float(tot[0]), tot[1:1 + d].copy(), tot[1 + d:].reshape(d, d).copy()
+
+    def allreduce_tensor(self, tensor):
+        v = self._comm_tensor(tensor).contiguous()
+        self.dist.all_reduce(v, op=self.dist.ReduceOp.SUM, group=self.group)
+        return v.to(tensor.device)
+
+    # ------------------------------------------------------------------ resampling protocol
+    def plan_counts(self, shard_weights, n_out_per_rank, epoch):
+        """C[r, h] = how many ancestors destination r takes from source h; identical on all ranks."""
+        p = np.asarray(shard_weights, dtype=np.float64)
+        p = p / p.sum()
+        gen = np.random.Generator(np.random.Philox(key=self.seed & (2 ** 64 - 1), counter=[int(epoch), 0, 0, 0]))
+        return gen.multinomial(int(n_out_per_rank), p, size=self.world_size).astype(np.int64)
+
+    def exchange_rows(self, send_rows, counts):
+        """send_rows: (T_h, d) tensor ordered by destination rank, T_h = counts[:, rank].sum().
+        Returns the (n_local, d) rows this rank receives, ordered by source rank."""
+        t = self.torch
+        send_split = [int(c) for c in counts[:, self.rank]]
+        recv_split = [int(c) for c in counts[self.rank, :]]
+        v = self._comm_tensor(send_rows).contiguous()
+        assert v.shape[0] == sum(send_split)
+        out = t.empty((sum(recv_split), v.shape[1]), dtype=v.dtype, device=v.device)
+        self.dist.all_to_all_single(out, v, output_split_sizes=recv_split, input_split_sizes=send_split,
+                                    group=self.group)
+        return out
+
+    def resample(self, updater, resampler):
+        """Sharded Liu-West step for `updater` (an SMCUpdater with comm=self).  Device RNG only."""
+        import warnings
+        from ._exceptions import ResamplerError, ResamplerWarning
+        from .distributions import ParticleDistribution
+        eng = updater._eng
+        model = updater.model
+        if not getattr(model, "_native", False):
+            raise NotImplementedError("sharded resampling needs a model with native kernels")
+        self._epoch += 1
+        epoch = self._epoch
+        d = updater.n_rvs
+        n_local = updater.n_particles
+        mean = updater.est_mean()                                   # global (all-reduced) moments
+        cov = updater.est_covariance_mtx()
+        a, h = resampler.a, resampler.h
+        if np.linalg.norm(cov, 'fro') == 0:
+            warnings.warn("Covariance has zero norm; adding in small covariance in resampler. "
+                          "Consider increasing n_particles to improve covariance estimates.", ResamplerWarning)
+            cov = resampler._zero_cov_comp * np.eye(d)
+        S, S_err = eng.sqrtm_psd(cov, scale=h)
+        if not np.isfinite(S_err):
+            raise ResamplerError("Infinite error in computing the square root of the covariance "
+                                 "matrix. Check that n_ess is not too small.")
+        # shard weight totals (unnormalised sums are fine: only ratios matter)
+        st = eng.weight_stats(updater._w, 1.0)
+        W = self.gather_rows(self.torch.tensor([st.sum], dtype=self.torch.float64))[:, 0]
+        counts = self.plan_counts(W, n_local, epoch)
+        n_draw = int(counts[:, self.rank].sum())
+        cdf = eng.cumsum(updater._w, st.sum)                         # local CDF, normalised locally
+        seed_r = resampler._seed + 0x9E3779B97F4A7C15 * (self.rank + 1)
+        anc = eng.lw_draw_gather_philox(updater._x, cdf, n_draw, seed_r, epoch)      # (d, T_h)
+        recv = self.exchange_rows(anc.t().contiguous(), counts)                      # (n_local, d)
+        anc_local = recv.to(eng.device).t().contiguous()
+        x_new, n_failed = eng.lw_perturb_philox(model._native_desc(), resampler._postselect, anc_local, a,
+                                                mean, S, seed_r ^ 0xA5A5A5A5, epoch, resampler._maxiter)
+        if n_failed:
+            warnings.warn("Liu-West resampling failed to find valid models for {} particles within {} "
+                          "iterations.".format(n_failed, resampler._maxiter), ResamplerWarning)
+        n_total = n_local * self.world_size
+        w_new = eng.empty(n_local)
+        uniform = np.float64(1.0) / np.float64(n_total)
+        eng.fill(w_new, uniform)
+        return ParticleDistribution._from_device(eng, x_new, w_new, norm=1.0,
+                                                 sumsq=float(n_total * uniform * uniform))

@@ -124,11 +124,10 @@ class SMCUpdater(ParticleDistribution):
 
     # ------------------------------------------------------------------ sharding hooks
     def _reduce_stats(self, st):
-        """Combine per-shard update sums across ranks (RCCL all-reduce of 4 doubles)."""
+        """Combine per-shard update sums across ranks (one all-gather of 4 doubles per rank)."""
         if self._comm is None:
             return st.sum, st.sumsq, st.min, st.n_bad
-        s = self._comm.allreduce_update_stats(self._eng, st.sum, st.sumsq, st.min, st.n_bad)
-        return s
+        return self._comm.allreduce_update_stats(self._eng, st.sum, st.sumsq, st.min, st.n_bad)
 
     def _moments(self):
         if self._moments_cache is None:
