@@ -77,3 +77,60 @@ def liu_west_philox(w, x, valid_fn, a, h, seed, epoch, n_out, maxiter=1000, post
         ok = valid_fn(out[todo]) if postselect else np.ones(todo.size, dtype=bool)
         todo = todo[~ok]
     return out, todo.size
+
+
+BUCKET_CHUNK = 4096
+
+
+def liu_west_philox_bucketed(w, x, valid_fn, a, h, seed, epoch, n_out, maxiter=1000, postselect=True,
+                             mean=None, cov=None, zero_cov_comp=1e-10, cdf=None):
+    """Oracle of the bucketed device-RNG resampler (k_bucket_count / _plan / _sample): outputs are
+    ordered by ancestor CHUNK; counts come from word 0 of each output's Philox block, the position
+    inside the chunk from word 1 (independent), retries redraw a global ancestor."""
+    import np_oracle as orc
+    N, d = x.shape
+    mean = orc.particle_mean(w, x) if mean is None else mean
+    cov = orc.particle_cov(w, x, warn=False) if cov is None else cov
+    if np.linalg.norm(cov, 'fro') == 0:
+        cov = zero_cov_comp * np.eye(d)
+    S = h * orc.sqrtm_psd(cov)[0]
+    cdf = np.cumsum(w) if cdf is None else cdf
+    chunks = (N + BUCKET_CHUNK - 1) // BUCKET_CHUNK
+    edge_idx = np.minimum((np.arange(chunks) + 1) * BUCKET_CHUNK, N) - 1
+    edges = cdf[edge_idx]
+    ids = np.arange(n_out)
+    u0, _ = uniforms(ids, seed, epoch, 0, 0)
+    chunk_of = np.minimum(np.searchsorted(edges, u0, side='right'), chunks - 1)
+    counts = np.bincount(chunk_of, minlength=chunks)
+    slot_off = np.concatenate([[0], np.cumsum(counts)])
+    c_of_slot = np.repeat(np.arange(chunks), counts)                 # chunk of every output slot
+    _, u1 = uniforms(ids, seed, epoch, 0, 0)
+    lo = np.where(c_of_slot == 0, 0.0, edges[np.maximum(c_of_slot - 1, 0)])
+    hi = edges[c_of_slot]
+    u = lo + u1 * (hi - lo)
+    base = c_of_slot * BUCKET_CHUNK
+    end = np.minimum(base + BUCKET_CHUNK, N)
+    js = np.minimum(np.maximum(np.searchsorted(cdf, u, side='right'), base), end - 1)
+    out = np.empty((n_out, d))
+
+    def kick(todo, rnd, centres):
+        z = np.empty((d, todo.size))
+        for q in range(0, d, 2):
+            z0, z1 = normals(todo, seed, epoch, rnd, 1 + q // 2)
+            z[q] = z0
+            if q + 1 < d:
+                z[q + 1] = z1
+        return (a * centres + (1 - a) * mean) + (S @ z).T
+
+    out[:] = kick(ids, 0, x[js])
+    ok = valid_fn(out) if postselect else np.ones(n_out, dtype=bool)
+    todo = ids[~ok]
+    for rnd in range(1, maxiter):
+        if not todo.size:
+            break
+        ur, _ = uniforms(todo, seed, epoch, rnd, 0)
+        jr = np.minimum(cdf.searchsorted(ur, side='right'), N - 1)
+        out[todo] = kick(todo, rnd, x[jr])
+        okr = valid_fn(out[todo]) if postselect else np.ones(todo.size, dtype=bool)
+        todo = todo[~okr]
+    return out, todo.size, js, counts

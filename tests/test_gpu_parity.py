@@ -329,6 +329,49 @@ def test_liu_west_philox_vs_oracle(qi, case):
     assert not np.array_equal(got, other)
 
 
+@pytest.mark.parametrize("case", ["prec", "rb", "tomo"])
+def test_liu_west_philox_bucketed_vs_oracle(qi, eng, case):
+    """The bucketed (count -> plan -> LDS-staged sample) resampler on identical Philox numbers."""
+    import philox as ph
+    rs = np.random.RandomState(12)
+    n = 70001
+    if case == "prec":
+        model, valid = qi.SimplePrecessionModel(), orc.valid_precession
+        x = np.abs(0.04 + 0.05 * rs.randn(n, 1))
+    elif case == "rb":
+        model, valid = qi.RandomizedBenchmarkingModel(), orc.valid_rb
+        x = np.stack([rs.uniform(0.9, 1, n), rs.uniform(0.2, 0.5, n), rs.uniform(0.4, 0.6, n)], 1)
+    else:
+        basis = qi.tomography.pauli_basis(2)
+        model, valid = qi.TomographyModel(basis), (lambda z: np.ones(z.shape[0], dtype=bool))
+        n = 30011
+        x = orc.ginibre_prior_sample(n, basis.data, rs)
+    w = rs.random_sample(n) ** 2
+    w[5000:9200] = 0.0                                   # an (almost) empty chunk
+    w[20000:20100] *= 400.0                              # a heavy chunk -> split into several work items
+    n_out = 90000
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        pd = qi.ParticleDistribution(particle_locations=x, particle_weights=w)
+        res = qi.LiuWestResampler(a=0.9, device_rng=True, seed=4321)
+        new = res(model, pd, n_particles=n_out)
+        wn = pd.particle_weights
+        cdf = eng.cumsum(pd._w, 1.0).cpu().numpy()       # the device CDF: same chunk edges as the kernel
+        ref, failed, js, counts = ph.liu_west_philox_bucketed(wn, x, valid, 0.9, np.sqrt(1 - 0.81), 4321, 1,
+                                                              n_out, cdf=cdf)
+    got = new.particle_locations
+    assert counts.max() > 2 * 8192, "fixture must exercise the heavy-chunk split"
+    cov = orc.particle_cov(wn, x, warn=False)
+    at = 1e-12 + (tol.atol_sqrtm_psd(cov) * 10 if case == "tomo" else 0)
+    bad = np.abs(got - ref).max(axis=1) > at
+    assert bad.sum() <= tol.max_js_flips(n_out), int(bad.sum())
+    assert np.all(valid(got))
+    # statistical sanity on top of the exact comparison: ancestor frequencies follow the weights
+    freq = np.bincount(js // 4096, minlength=len(counts)) / n_out
+    mass = np.add.reduceat(wn, np.arange(0, n, 4096))
+    assert np.abs(freq - mass).max() < 6 * np.sqrt(mass.max() / n_out)
+
+
 def test_prior_uniform_philox(qi, eng):
     import philox as ph
     model = qi.RandomizedBenchmarkingModel()
