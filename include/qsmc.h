@@ -105,14 +105,18 @@ int qsmc_are_models_valid(qsmc_handle_t h, const qsmc_model_t *model,
                           uint8_t *valid_out, qsmc_stream_t stream);
 
 /* ---- fused Bayes update (smc.py:388-457 = hypothetical_update :324-386 + n_ess; a1-a3) --- */
-/* w_out[i] = (w_in[i] / prev_norm) * Pr(outcome | x_i ; exp);  stats reduced in the same pass.
- * w_out may alias w_in.  If stats_host != NULL the call synchronises `stream` and fills it;
- * stats_dev (4 doubles, device) is always written and may be consumed by later async calls. */
+/* w_out[i] = (w_in[i] / prev_norm) * Pr(outcome | x_i ; exp);  stats reduced in the same pass
+ * (per-workgroup partials, then a one-workgroup kernel sums them in index order: deterministic).
+ * w_out may alias w_in.  stats_dev (4 doubles, device, qsmc_update_stats_t order) is written if
+ * non-NULL.  If stats_host or moments_host is non-NULL the call synchronises `stream`.
+ * moments_host (d <= 4 only): [sum w' x_m (d), sum w' x_m x_n for m <= n row-major (d(d+1)/2)] of the
+ * NEW unnormalised weights -- divide by stats.sum to get E[x], E[x x^T] (distributions.py:337-399)
+ * without another pass over HBM. */
 int qsmc_update_fused(qsmc_handle_t h, const qsmc_model_t *model,
                       const double *x, int64_t ldx, int64_t n,
                       const double *w_in, double *w_out, double prev_norm,
                       const qsmc_expparam_t *exp, int64_t outcome,
-                      double *stats_dev, qsmc_update_stats_t *stats_host,
+                      double *stats_dev, qsmc_update_stats_t *stats_host, double *moments_host,
                       qsmc_stream_t stream);
 
 /* Same update for a model without a native kernel: L[i] was produced by the user's

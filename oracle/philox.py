@@ -82,11 +82,27 @@ def liu_west_philox(w, x, valid_fn, a, h, seed, epoch, n_out, maxiter=1000, post
 BUCKET_CHUNK = 4096
 
 
+def _pair_word(ids, seed, epoch, slot):
+    """word (id & 1) of Philox block (id >> 1, round 0, slot): two outputs share one block."""
+    ids = np.asarray(ids, dtype=np.int64)
+    ua, ub = uniforms(ids >> 1, seed, epoch, 0, slot)
+    return np.where(ids & 1, ub, ua)
+
+
+def _pair_normal(n_idx, seed, epoch, slot):
+    """Box-Muller component (n & 1) of block (n >> 1, round 0, slot)."""
+    n_idx = np.asarray(n_idx, dtype=np.int64)
+    za, zb = normals(n_idx >> 1, seed, epoch, 0, slot)
+    return np.where(n_idx & 1, zb, za)
+
+
 def liu_west_philox_bucketed(w, x, valid_fn, a, h, seed, epoch, n_out, maxiter=1000, postselect=True,
                              mean=None, cov=None, zero_cov_comp=1e-10, cdf=None):
-    """Oracle of the bucketed device-RNG resampler (k_bucket_count / _plan / _sample): outputs are
-    ordered by ancestor CHUNK; counts come from word 0 of each output's Philox block, the position
-    inside the chunk from word 1 (independent), retries redraw a global ancestor."""
+    """Oracle of the bucketed device-RNG resampler (k_bucket_count / _plan / _sample).  Outputs are
+    ordered by ancestor CHUNK.  Stream layout (round 0, two outputs per Philox block):
+      slot 0: chunk draw of output i; slot 1: within-chunk position of slot o (independent);
+      slot 2: normal n = o * d + q.  Retries (round r >= 1) are per output and redraw a GLOBAL
+      ancestor from block (o, r, 0) and normals from (o, r, 1 + q // 2)."""
     import np_oracle as orc
     N, d = x.shape
     mean = orc.particle_mean(w, x) if mean is None else mean
@@ -99,30 +115,19 @@ def liu_west_philox_bucketed(w, x, valid_fn, a, h, seed, epoch, n_out, maxiter=1
     edge_idx = np.minimum((np.arange(chunks) + 1) * BUCKET_CHUNK, N) - 1
     edges = cdf[edge_idx]
     ids = np.arange(n_out)
-    u0, _ = uniforms(ids, seed, epoch, 0, 0)
-    chunk_of = np.minimum(np.searchsorted(edges, u0, side='right'), chunks - 1)
+    u_chunk = _pair_word(ids, seed, epoch, 0)
+    chunk_of = np.minimum(np.searchsorted(edges, u_chunk, side='right'), chunks - 1)
     counts = np.bincount(chunk_of, minlength=chunks)
-    slot_off = np.concatenate([[0], np.cumsum(counts)])
     c_of_slot = np.repeat(np.arange(chunks), counts)                 # chunk of every output slot
-    _, u1 = uniforms(ids, seed, epoch, 0, 0)
+    u_pos = _pair_word(ids, seed, epoch, 1)
     lo = np.where(c_of_slot == 0, 0.0, edges[np.maximum(c_of_slot - 1, 0)])
     hi = edges[c_of_slot]
-    u = lo + u1 * (hi - lo)
+    u = lo + u_pos * (hi - lo)
     base = c_of_slot * BUCKET_CHUNK
     end = np.minimum(base + BUCKET_CHUNK, N)
     js = np.minimum(np.maximum(np.searchsorted(cdf, u, side='right'), base), end - 1)
-    out = np.empty((n_out, d))
-
-    def kick(todo, rnd, centres):
-        z = np.empty((d, todo.size))
-        for q in range(0, d, 2):
-            z0, z1 = normals(todo, seed, epoch, rnd, 1 + q // 2)
-            z[q] = z0
-            if q + 1 < d:
-                z[q + 1] = z1
-        return (a * centres + (1 - a) * mean) + (S @ z).T
-
-    out[:] = kick(ids, 0, x[js])
+    z = np.stack([_pair_normal(ids * d + q, seed, epoch, 2) for q in range(d)])      # (d, n_out)
+    out = (a * x[js] + (1 - a) * mean) + (S @ z).T
     ok = valid_fn(out) if postselect else np.ones(n_out, dtype=bool)
     todo = ids[~ok]
     for rnd in range(1, maxiter):
@@ -130,7 +135,13 @@ def liu_west_philox_bucketed(w, x, valid_fn, a, h, seed, epoch, n_out, maxiter=1
             break
         ur, _ = uniforms(todo, seed, epoch, rnd, 0)
         jr = np.minimum(cdf.searchsorted(ur, side='right'), N - 1)
-        out[todo] = kick(todo, rnd, x[jr])
+        zr = np.empty((d, todo.size))
+        for q in range(0, d, 2):
+            z0, z1 = normals(todo, seed, epoch, rnd, 1 + q // 2)
+            zr[q] = z0
+            if q + 1 < d:
+                zr[q + 1] = z1
+        out[todo] = (a * x[jr] + (1 - a) * mean) + (S @ zr).T
         okr = valid_fn(out[todo]) if postselect else np.ones(todo.size, dtype=bool)
         todo = todo[~okr]
     return out, todo.size, js, counts

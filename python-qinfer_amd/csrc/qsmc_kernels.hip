@@ -33,6 +33,9 @@ struct qsmc_ctx {
     double *pinned;        // host pinned staging for small read-backs
     size_t pinned_cap;
     long long *counter;    // device int64 counter (failed-particle count)
+    double *red_out;       // device [REDUCE_OUT_MAX] totals of the last grid reduction
+    double *mapped;        // pinned host memory the reducing workgroup writes directly ...
+    double *mapped_dev;    // ... and its device alias
     unsigned int *iscratch; // device integer scratch for the bucketed resampler
     size_t iscratch_cap;    // in bytes
     int profiling;
@@ -50,6 +53,8 @@ struct qsmc_ctx {
             return QSMC_ERR_HIP;                                                                \
         }                                                                                       \
     } while (0)
+
+constexpr int REDUCE_OUT_MAX = 64;
 
 static int ensure_partials(qsmc_ctx *h, size_t n) {
     if (h->partials_cap >= n) return QSMC_OK;
@@ -115,40 +120,109 @@ static inline bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; 
 // =============================================================================================
 constexpr int UPD_UNROLL = 4;
 
-// Per-element body shared by the native-model and from-likelihood kernels.
-struct UpdAcc {
-    double sum = 0.0, sumsq = 0.0, mn = INFINITY, bad = 0.0;
-    __device__ __forceinline__ void add(double w) {
-        sum += w;
-        sumsq += w * w;
-        mn = fmin(mn, w);         // fmin drops NaN; `bad` records it
-        bad += (w >= 0.0) ? 0.0 : 1.0;
-    }
+// ---------------------------------------------------------------------------------------------
+// Two-level deterministic reduction.  Each workgroup writes NS sums + 1 min (block_publish); a
+// one-workgroup kernel (k_reduce_partials) sums the per-workgroup partials in INDEX order and writes
+// the totals to device memory AND straight into pinned host memory (no D2H copy command).
+// out layout: [sum_0 .. sum_{NS-1}, min].
+//
+// Measured alternative (round-1 profile c): doing the second level inside the same launch with an
+// agent-scope arrival ticket cost +11 us on the 44 us update kernel -- 2048 workgroups finishing
+// together saturate one atomic word (~88 arrivals/us) -- versus 4.9 us + one launch boundary here.
+// ---------------------------------------------------------------------------------------------
+struct ReduceOut {
+    double *partials;        // [grid][NS + 1]
+    double *out_dev;         // [NS + 1] device (always written)
+    double *out_mapped;      // [NS + 1] device alias of pinned host memory (nullable)
+    double *stats4;          // optional caller buffer in qsmc_update_stats_t order (nullable)
 };
 
-__device__ __forceinline__ void upd_finish(UpdAcc &a, double *partials) {
-    __shared__ double lds[QSMC_WAVES_PER_BLOCK * 3];
-    double v[3] = {a.sum, a.sumsq, a.bad};
-    block_sum<3>(v, lds);
-    const double mn = block_min(a.mn, lds);
+template <int NS>
+__device__ __forceinline__ void block_publish(double (&v)[NS], double mn, const ReduceOut &ro) {
+    __shared__ double lds[QSMC_WAVES_PER_BLOCK * NS];
+    block_sum<NS>(v, lds);
+    mn = block_min(mn, lds);
     if (threadIdx.x == 0) {
-        double *p = partials + 4 * (size_t)blockIdx.x;
-        p[0] = v[0];
-        p[1] = v[1];
-        p[2] = mn;
-        p[3] = v[2];
+        double *p = ro.partials + (size_t)blockIdx.x * (NS + 1);
+#pragma unroll
+        for (int k = 0; k < NS; ++k) p[k] = v[k];
+        p[NS] = mn;
     }
 }
+
+template <int NS>
+__global__ __launch_bounds__(QSMC_BLOCK) void k_reduce_partials(int nblocks, ReduceOut ro) {
+    __shared__ double lds[QSMC_WAVES_PER_BLOCK * NS];
+    double acc[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) acc[k] = 0.0;
+    double m2 = INFINITY;
+#pragma unroll 4
+    for (int g = threadIdx.x; g < nblocks; g += QSMC_BLOCK) {
+        const double *p = ro.partials + (size_t)g * (NS + 1);
+#pragma unroll
+        for (int k = 0; k < NS; ++k) acc[k] += p[k];
+        m2 = fmin(m2, p[NS]);
+    }
+    block_sum<NS>(acc, lds);
+    m2 = block_min(m2, lds);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            ro.out_dev[k] = acc[k];
+            if (ro.out_mapped) ro.out_mapped[k] = acc[k];
+        }
+        ro.out_dev[NS] = m2;
+        if (ro.out_mapped) ro.out_mapped[NS] = m2;
+        if (ro.stats4) {
+            ro.stats4[0] = acc[0];
+            ro.stats4[1] = acc[1];
+            ro.stats4[2] = m2;
+            ro.stats4[3] = acc[2];
+        }
+    }
+}
+
+// Per-particle accumulation of the update: [sum w', sum w'^2, #bad, sum w' x_m (DMOM),
+// sum w' x_m x_q (m <= q)] and min w'.  DMOM > 0 folds the weighted moments of the NEW weights
+// into the same pass (x is already in registers): est_mean / est_covariance_mtx and the
+// resampler's moments then cost no extra sweep over HBM.
+template <int DMOM>
+struct UpdAcc {
+    static constexpr int NS = 3 + DMOM + DMOM * (DMOM + 1) / 2;
+    double s[NS];
+    double mn;
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) s[k] = 0.0;
+        mn = INFINITY;
+    }
+    __device__ __forceinline__ void add(double w, const double *p) {
+        s[0] += w;
+        s[1] += w * w;
+        s[2] += (w >= 0.0) ? 0.0 : 1.0;       // counts NaN too, like np.all(w >= 0)
+        mn = fmin(mn, w);                      // fmin drops NaN; s[2] records it
+        int k = 3 + DMOM;
+#pragma unroll
+        for (int m = 0; m < DMOM; ++m) {
+            const double wx = w * p[m];
+            s[3 + m] += wx;
+#pragma unroll
+            for (int q = m; q < DMOM; ++q) s[k++] += wx * p[q];
+        }
+    }
+};
 
 template <int KIND, int VEC>
 __global__ __launch_bounds__(QSMC_BLOCK) void k_update_fused(
     const double *__restrict__ x, int64_t ldx, int64_t n, const double *__restrict__ w_in,
-    double *__restrict__ w_out, double prev_norm, ExpArgs e, int64_t outcome,
-    double *__restrict__ partials) {
+    double *__restrict__ w_out, double prev_norm, ExpArgs e, int64_t outcome, ReduceOut ro) {
     constexpr int D = Model<KIND>::D;
+    constexpr int DMOM = D <= 4 ? D : 0;           // moments ride along for d <= 4
     const int d = (KIND == QSMC_MODEL_TOMOGRAPHY) ? e.d : D;
     constexpr int64_t TILE = (int64_t)QSMC_BLOCK * VEC * UPD_UNROLL;
-    UpdAcc acc;
+    UpdAcc<DMOM> acc;
+    acc.init();
     for (int64_t base = (int64_t)blockIdx.x * TILE; base < n; base += (int64_t)gridDim.x * TILE) {
 #pragma unroll
         for (int u = 0; u < UPD_UNROLL; ++u) {
@@ -169,8 +243,8 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_update_fused(
                     wo.x = (wi.x / prev_norm) * Model<KIND>::lik(p0, e, outcome);
                     wo.y = (wi.y / prev_norm) * Model<KIND>::lik(p1, e, outcome);
                     *reinterpret_cast<double2 *>(w_out + i) = wo;
-                    acc.add(wo.x);
-                    acc.add(wo.y);
+                    acc.add(wo.x, p0);
+                    acc.add(wo.y, p1);
                 } else if (i < n) {
                     double p0[D];
 #pragma unroll
@@ -178,7 +252,7 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_update_fused(
                         if (m < d) p0[m] = x[m * ldx + i];
                     const double wo = (w_in[i] / prev_norm) * Model<KIND>::lik(p0, e, outcome);
                     w_out[i] = wo;
-                    acc.add(wo);
+                    acc.add(wo, p0);
                 }
             } else {
                 if (i < n) {
@@ -188,12 +262,12 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_update_fused(
                         if (m < d) p0[m] = x[m * ldx + i];
                     const double wo = (w_in[i] / prev_norm) * Model<KIND>::lik(p0, e, outcome);
                     w_out[i] = wo;
-                    acc.add(wo);
+                    acc.add(wo, p0);
                 }
             }
         }
     }
-    upd_finish(acc, partials);
+    block_publish<UpdAcc<DMOM>::NS>(acc.s, acc.mn, ro);
 }
 
 // mode 0: w_out = (w_in / norm) * L   (generic-model slow path)
@@ -204,40 +278,18 @@ template <int MODE>
 __global__ __launch_bounds__(QSMC_BLOCK) void k_weights_pass(const double *__restrict__ L, int64_t n,
                                                              const double *__restrict__ w_in,
                                                              double *__restrict__ w_out, double norm,
-                                                             double *__restrict__ partials) {
-    UpdAcc acc;
+                                                             ReduceOut ro) {
+    UpdAcc<0> acc;
+    acc.init();
     for (int64_t i = (int64_t)blockIdx.x * QSMC_BLOCK + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * QSMC_BLOCK) {
         double w = w_in[i] / norm;
         if (MODE == 0) w = w * L[i];
         if (MODE == 1 && w == w) w = fmin(fmax(w, 0.0), 1.0);   // np.clip keeps NaN as NaN
         if (MODE != 3) w_out[i] = w;
-        acc.add(w);
+        acc.add(w, nullptr);
     }
-    upd_finish(acc, partials);
-}
-
-// Sum the per-workgroup partials in index order.  layout: partials[g * 4 + {sum, sumsq, min, bad}]
-__global__ __launch_bounds__(QSMC_BLOCK) void k_update_finalize(const double *__restrict__ partials,
-                                                                int nblocks, double *__restrict__ stats) {
-    __shared__ double lds[QSMC_WAVES_PER_BLOCK * 3];
-    double v[3] = {0.0, 0.0, 0.0};
-    double mn = INFINITY;
-    for (int g = threadIdx.x; g < nblocks; g += QSMC_BLOCK) {
-        const double *p = partials + 4 * (size_t)g;
-        v[0] += p[0];
-        v[1] += p[1];
-        mn = fmin(mn, p[2]);
-        v[2] += p[3];
-    }
-    block_sum<3>(v, lds);
-    mn = block_min(mn, lds);
-    if (threadIdx.x == 0) {
-        stats[0] = v[0];
-        stats[1] = v[1];
-        stats[2] = mn;
-        stats[3] = v[2];
-    }
+    block_publish<3>(acc.s, acc.mn, ro);
 }
 
 // =============================================================================================
@@ -283,9 +335,8 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_fill(double *__restrict__ w, int
 template <int D>
 __global__ __launch_bounds__(QSMC_BLOCK) void k_moments_small(const double *__restrict__ x, int64_t ldx,
                                                               int64_t n, const double *__restrict__ w,
-                                                              double norm, double *__restrict__ partials) {
+                                                              double norm, ReduceOut ro) {
     constexpr int K = 1 + D + D * (D + 1) / 2;
-    __shared__ double lds[QSMC_WAVES_PER_BLOCK * K];
     double acc[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) acc[k] = 0.0;
@@ -305,11 +356,7 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_moments_small(const double *__re
             for (int q = m; q < D; ++q) acc[k++] += wx * p[q];
         }
     }
-    block_sum<K>(acc, lds);
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int k = 0; k < K; ++k) partials[(size_t)blockIdx.x * K + k] = acc[k];
-    }
+    block_publish<K>(acc, 0.0, ro);
 }
 
 // General d (<= QSMC_MAX_D): blockIdx.y = row m; the block accumulates sum w x_m and
@@ -615,7 +662,7 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_resample_philox(
 // =============================================================================================
 constexpr int BUCKET_CHUNK = SCAN_CHUNK;            // 4096 source particles per bucket
 constexpr int BUCKET_CAP = 2 * BUCKET_CHUNK;        // outputs per work item
-constexpr int BUCKET_MAX_CHUNKS = 5120;             // edges (40 KB) + counters (20 KB) of dynamic LDS
+constexpr int BUCKET_MAX_CHUNKS = 5000;             // skewed edges (~41 KB) + counters (20 KB) of dynamic LDS
 constexpr int BUCKET_COUNT_BLOCKS = 256;            // one resident workgroup per CU
 constexpr int BUCKET_COUNT_THREADS = 1024;
 
@@ -636,25 +683,52 @@ __device__ __forceinline__ int upper_bound_i32(const double *a, int m, double u)
     return lo;
 }
 
+// LDS index skew: binary-search midpoints of a power-of-two table are multiples of 2048, 1024, ...
+// elements, i.e. ONE bank for every lane (measured: 88 % of the sample kernel's LDS cycles were bank
+// conflicts).  j + (j >> 5) + (j >> 10) sends those strides to distinct banks.
+__device__ __forceinline__ int lds_skew(int j) { return j + (j >> 5) + (j >> 10); }
+constexpr int BUCKET_CHUNK_LDS = BUCKET_CHUNK + (BUCKET_CHUNK >> 5) + (BUCKET_CHUNK >> 10) + 4;
+
+// number of entries of the SKEWED LDS table a[skew(0..m)) that are <= u
+__device__ __forceinline__ int upper_bound_skew(const double *a, int m, double u) {
+    int lo = 0, hi = m;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[lds_skew(mid)] <= u) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// Philox stream layout of the bucketed resampler (round 0), two outputs per Philox block:
+//   slot 0: block (i >> 1), word (i & 1)          chunk draw of output i          (k_bucket_count)
+//   slot 1: block (o >> 1), word (o & 1)          within-chunk position of slot o (k_bucket_sample)
+//   slot 2: block (n >> 1), Box-Muller comp (n&1) n = o * d + q, q-th normal of slot o
+// retries (round r >= 1) are per output: block (o, r, 0).u0 = global ancestor, (o, r, 1 + q/2) normals.
 __global__ __launch_bounds__(BUCKET_COUNT_THREADS) void k_bucket_count(
     const double *__restrict__ cdf, int64_t n_in, int chunks, int64_t n_out, uint32_t k0, uint32_t k1,
     uint32_t epoch, unsigned int *__restrict__ hist /* [gridDim.x][chunks] */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double *edges = reinterpret_cast<double *>(smem);                       // edges[c] = upper edge of chunk c
-    unsigned int *cnt = reinterpret_cast<unsigned int *>(edges + chunks);
+    double *edges = reinterpret_cast<double *>(smem);                       // skewed: upper edge of chunk c
+    unsigned int *cnt = reinterpret_cast<unsigned int *>(edges + lds_skew(chunks) + 4);
     for (int c = threadIdx.x; c < chunks; c += blockDim.x) {
-        edges[c] = chunk_edge(cdf, n_in, (int64_t)c + 1);
+        edges[lds_skew(c)] = chunk_edge(cdf, n_in, (int64_t)c + 1);
         cnt[c] = 0u;
     }
     __syncthreads();
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_out;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        PhiloxStream rng{(uint64_t)i, (epoch << 16), k0, k1};
-        double u, unused;
-        rng.uniforms(0, u, unused);
-        int c = upper_bound_i32(edges, chunks, u);        // #edges <= u  == chunk index
-        if (c > chunks - 1) c = chunks - 1;               // u beyond cdf[n-1] (rounding): last chunk (Q2 clamp)
-        atomicAdd(&cnt[c], 1u);
+    const int64_t n_pairs = (n_out + 1) >> 1;
+    for (int64_t pr = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pr < n_pairs;
+         pr += (int64_t)gridDim.x * blockDim.x) {
+        PhiloxStream rng{(uint64_t)pr, (epoch << 16), k0, k1};
+        double u[2];
+        rng.uniforms(0, u[0], u[1]);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            if (2 * pr + e < n_out) {
+                int c = upper_bound_skew(edges, chunks, u[e]);   // #edges <= u  == chunk index
+                if (c > chunks - 1) c = chunks - 1;              // u beyond cdf[n-1] (rounding): Q2 clamp
+                atomicAdd(&cnt[c], 1u);
+            }
+        }
     }
     __syncthreads();
     unsigned int *row = hist + (size_t)blockIdx.x * chunks;
@@ -678,7 +752,8 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_bucket_reduce(const unsigned int
 // ceil(counts / BUCKET_CAP); slot_off[chunks] = n_out, item_off[chunks] = #work items
 __global__ __launch_bounds__(1024) void k_bucket_plan(const unsigned int *__restrict__ counts, int chunks,
                                                       long long *__restrict__ slot_off,
-                                                      int *__restrict__ item_off) {
+                                                      int *__restrict__ item_off,
+                                                      int *__restrict__ item_chunk) {
     __shared__ long long tot_s[1024];
     __shared__ int tot_i[1024];
     const int per = (chunks + 1023) / 1024;
@@ -710,8 +785,10 @@ __global__ __launch_bounds__(1024) void k_bucket_plan(const unsigned int *__rest
     for (int c = c0; c < c1; ++c) {
         slot_off[c] = so;
         item_off[c] = io;
+        const int items = (int)((counts[c] + BUCKET_CAP - 1) / BUCKET_CAP);
+        for (int k = 0; k < items; ++k) item_chunk[io + k] = c;     // work item -> chunk map
         so += counts[c];
-        io += (int)((counts[c] + BUCKET_CAP - 1) / BUCKET_CAP);
+        io += items;
     }
     if (threadIdx.x == 1023) {
         slot_off[chunks] = tot_s[1023];
@@ -719,84 +796,122 @@ __global__ __launch_bounds__(1024) void k_bucket_plan(const unsigned int *__rest
     }
 }
 
-template <int D>   // D = 0: runtime d
-__global__ __launch_bounds__(QSMC_BLOCK) void k_bucket_sample(
+constexpr int BUCKET_SAMPLE_THREADS = 1024;          // 16 waves share one 32 KB CDF chunk in LDS
+
+// One output particle: search the staged chunk, gather, kick, postselect (retries are rare and take
+// the global path).  z[] holds the d round-0 normals of this output.
+template <int DM, bool STAGE_X>
+__device__ __forceinline__ bool bucket_one_output(
+    int kind, int d, double min_freq, int postselect, const double *__restrict__ x_in, int64_t ldx_in,
+    int64_t n_in, const double *__restrict__ cdf, const double *lcdf, const double *lx, int64_t base, int len,
+    double lo_edge, double hi_edge, const LWArgs &lw, uint32_t k0, uint32_t k1, uint32_t epoch, int maxiter,
+    int64_t o, double upos, const double *z, double *__restrict__ x_out, int64_t ldx_out) {
+    double p[DM], xa[DM], zz[DM];
+    const double u = lo_edge + upos * (hi_edge - lo_edge);   // given the counts: uniform inside the chunk
+    int jl = upper_bound_skew(lcdf, len, u);
+    if (jl > len - 1) jl = len - 1;
+#pragma unroll
+    for (int m = 0; m < DM; ++m)
+        if (m < d) {
+            xa[m] = STAGE_X ? lx[m * BUCKET_CHUNK + jl] : x_in[m * ldx_in + base + jl];
+            zz[m] = z[m];
+        }
+    bool ok = false;
+    for (int round = 0;; ++round) {
+#pragma unroll
+        for (int m = 0; m < DM; ++m) {
+            if (m < d) {
+                double s = 0.0;
+#pragma unroll
+                for (int q = 0; q < DM; ++q)
+                    if (q < d) s += lw.S[m * d + q] * zz[q];
+                p[m] = (lw.a * xa[m] + (1.0 - lw.a) * lw.mean[m]) + s;
+            }
+        }
+        ok = !postselect || model_valid(kind, p, min_freq);
+        if (ok || round + 1 >= maxiter) break;
+        // rare: redraw a GLOBAL ancestor and a fresh kick from this output's own retry stream
+        PhiloxStream rng{(uint64_t)o, (epoch << 16) | (uint32_t)(round + 1), k0, k1};
+        double u0, unused;
+        rng.uniforms(0, u0, unused);
+        const int64_t j = search_right(cdf, n_in, u0);
+#pragma unroll
+        for (int m = 0; m < DM; ++m)
+            if (m < d) xa[m] = x_in[m * ldx_in + j];
+#pragma unroll
+        for (int q = 0; q < DM; q += 2) {
+            if (q < d) {
+                double z0, z1;
+                rng.normals(1 + (q >> 1), z0, z1);
+                zz[q] = z0;
+                if (q + 1 < DM) zz[q + 1] = z1;
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < DM; ++m)
+        if (m < d) x_out[m * ldx_out + o] = p[m];
+    return ok;
+}
+
+// STAGE_X: also stage the chunk's x rows in LDS (d <= 2) so the gather never leaves the CU.
+template <int D, bool STAGE_X, int BT>   // D = 0: runtime d; BT = threads per workgroup
+__global__ __launch_bounds__(BT) void k_bucket_sample(
     int kind, int d_rt, double min_freq, int postselect, const double *__restrict__ x_in, int64_t ldx_in,
     int64_t n_in, const double *__restrict__ cdf, int chunks, const long long *__restrict__ slot_off,
-    const int *__restrict__ item_off, LWArgs lw, uint32_t k0, uint32_t k1, uint32_t epoch, int maxiter,
-    double *__restrict__ x_out, int64_t ldx_out, unsigned long long *__restrict__ n_failed) {
+    const int *__restrict__ item_off, const int *__restrict__ item_chunk, LWArgs lw, uint32_t k0, uint32_t k1,
+    uint32_t epoch, int maxiter, double *__restrict__ x_out, int64_t ldx_out,
+    unsigned long long *__restrict__ n_failed) {
     constexpr int DM = D > 0 ? D : QSMC_MAX_D;
+    constexpr int DX = STAGE_X ? DM : 1;
     const int d = D > 0 ? D : d_rt;
-    __shared__ __attribute__((aligned(16))) double lcdf[BUCKET_CHUNK];
-    __shared__ int s_chunk;
-    const int n_items = item_off[chunks];
-    if ((int)blockIdx.x >= n_items) return;
-    if (threadIdx.x == 0) {
-        // chunk = last c with item_off[c] <= blockIdx.x  (item_off is non-decreasing; empty chunks repeat)
-        int lo = 0, hi = chunks;                         // invariant: item_off[lo] <= b < item_off[hi]
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (item_off[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
-        }
-        s_chunk = lo;
-    }
-    __syncthreads();
-    const int c = s_chunk;
+    __shared__ __attribute__((aligned(16))) double lcdf[BUCKET_CHUNK_LDS];
+    __shared__ __attribute__((aligned(16))) double lx[STAGE_X ? DX * BUCKET_CHUNK : 2];
+    if ((int)blockIdx.x >= item_off[chunks]) return;
+    const int c = item_chunk[blockIdx.x];
     const int part = (int)blockIdx.x - item_off[c];
     const long long slot0 = slot_off[c], n_c = slot_off[c + 1] - slot0;
     const long long t0 = (long long)part * BUCKET_CAP;
     const long long t1 = t0 + BUCKET_CAP < n_c ? t0 + BUCKET_CAP : n_c;
     const int64_t base = (int64_t)c * BUCKET_CHUNK;
     const int len = (int)((n_in - base) < BUCKET_CHUNK ? (n_in - base) : BUCKET_CHUNK);
-    for (int j = threadIdx.x; j < BUCKET_CHUNK; j += QSMC_BLOCK) lcdf[j] = j < len ? cdf[base + j] : INFINITY;
+    for (int j = threadIdx.x; j < BUCKET_CHUNK; j += BT) {
+        lcdf[lds_skew(j)] = j < len ? cdf[base + j] : INFINITY;
+        if (STAGE_X) {
+#pragma unroll
+            for (int m = 0; m < DX; ++m) lx[m * BUCKET_CHUNK + j] = j < len ? x_in[m * ldx_in + base + j] : 0.0;
+        }
+    }
     __syncthreads();
     const double lo_edge = chunk_edge(cdf, n_in, c);
-    const double hi_edge = lcdf[len - 1];
+    const double hi_edge = lcdf[lds_skew(len - 1)];
+    const int64_t o_begin = slot0 + t0, o_end = slot0 + t1;         // this item's output slots
     unsigned long long failed = 0;
-    for (long long t = t0 + threadIdx.x; t < t1; t += QSMC_BLOCK) {
-        const int64_t o = slot0 + t;                       // output slot == Philox particle id
-        double p[DM];
-        bool ok = false;
-        for (int round = 0; round < maxiter && !ok; ++round) {
-            PhiloxStream rng{(uint64_t)o, (epoch << 16) | (uint32_t)round, k0, k1};
-            double u0, u1;
-            rng.uniforms(0, u0, u1);
-            int64_t j;
-            if (round == 0) {
-                // position inside this chunk: given the counts, uniform on [lo_edge, hi_edge)
-                const double u = lo_edge + u1 * (hi_edge - lo_edge);
-                int jl = upper_bound_i32(lcdf, len, u);
-                if (jl > len - 1) jl = len - 1;
-                j = base + jl;
-            } else {
-                j = search_right(cdf, n_in, u0);           // rare: fresh global ancestor
-            }
-            double zz[DM];
+    // pairs of output slots (2P, 2P+1) share their Philox blocks; a pair straddling two work items is
+    // evaluated by both, each writing only its own half
+    for (int64_t P = (o_begin >> 1) + threadIdx.x; 2 * P < o_end; P += BT) {
+        PhiloxStream rng{(uint64_t)P, (epoch << 16), k0, k1};
+        double upos[2];
+        rng.uniforms(1, upos[0], upos[1]);
+        double z[2 * DM];
+        PhiloxStream nrm{0, (epoch << 16), k0, k1};
 #pragma unroll
-            for (int q = 0; q < DM; q += 2) {
-                if (q < d) {
-                    double z0, z1;
-                    rng.normals(1 + (q >> 1), z0, z1);
-                    zz[q] = z0;
-                    if (q + 1 < DM) zz[q + 1] = z1;
-                }
+        for (int k = 0; k < DM; ++k) {
+            if (k < d) {
+                nrm.particle = (uint64_t)P * (uint64_t)d + (uint64_t)k;
+                nrm.normals(2, z[2 * k], z[2 * k + 1]);
             }
-#pragma unroll
-            for (int m = 0; m < DM; ++m) {
-                if (m < d) {
-                    double s = 0.0;
-#pragma unroll
-                    for (int q = 0; q < DM; ++q)
-                        if (q < d) s += lw.S[m * d + q] * zz[q];
-                    p[m] = (lw.a * x_in[m * ldx_in + j] + (1.0 - lw.a) * lw.mean[m]) + s;
-                }
-            }
-            ok = !postselect || model_valid(kind, p, min_freq);
         }
 #pragma unroll
-        for (int m = 0; m < DM; ++m)
-            if (m < d) x_out[m * ldx_out + o] = p[m];
-        if (!ok) ++failed;
+        for (int e = 0; e < 2; ++e) {
+            const int64_t o = 2 * P + e;
+            if (o >= o_begin && o < o_end) {
+                const bool ok = bucket_one_output<DM, STAGE_X>(
+                    kind, d, min_freq, postselect, x_in, ldx_in, n_in, cdf, lcdf, lx, base, len, lo_edge, hi_edge,
+                    lw, k0, k1, epoch, maxiter, o, upos[e], z + e * d, x_out, ldx_out);
+                if (!ok) ++failed;
+            }
+        }
     }
     if (failed) atomicAdd(n_failed, failed);
 }
@@ -946,41 +1061,58 @@ static int check_model(const qsmc_model_t *m) {
     }
 }
 
-static int finish_stats(qsmc_ctx *h, int grid, double *stats_dev, qsmc_update_stats_t *stats_host,
-                        hipStream_t s) {
-    double *dst = stats_dev ? stats_dev : h->scratch;
-    if (!stats_dev) {
-        int rc = ensure_scratch(h, 4);
-        if (rc) return rc;
-        dst = h->scratch;
+static ReduceOut make_reduce(qsmc_ctx *h, bool want_host, double *stats4) {
+    ReduceOut ro;
+    ro.partials = h->partials;
+    ro.out_dev = h->red_out;
+    ro.out_mapped = want_host ? h->mapped_dev : nullptr;
+    ro.stats4 = stats4;
+    return ro;
+}
+
+static int launch_reduce(qsmc_ctx *h, int ns, int grid, const ReduceOut &ro, hipStream_t s) {
+    switch (ns) {
+#define LR(N)                                                                                   \
+    case N:                                                                                     \
+        hipLaunchKernelGGL((k_reduce_partials<N>), dim3(1), dim3(QSMC_BLOCK), 0, s, grid, ro);  \
+        break;
+        LR(3) LR(5) LR(6) LR(8) LR(10) LR(12) LR(15) LR(17)
+#undef LR
+        default: return QSMC_ERR_INVALID;
     }
-    hipLaunchKernelGGL(k_update_finalize, dim3(1), dim3(QSMC_BLOCK), 0, s, h->partials, grid, dst);
     HIP_TRY(h, hipGetLastError());
+    return QSMC_OK;
+}
+
+// After a grid-reducing launch: synchronise and hand the totals (already in pinned memory) back.
+// out layout [sum, sumsq, bad, extra..., min] with `ns` sums.
+static int collect_stats(qsmc_ctx *h, int ns, qsmc_update_stats_t *stats_host, double *extra_host, int n_extra,
+                         hipStream_t s) {
+    if (!stats_host && !extra_host) return QSMC_OK;
+    HIP_TRY(h, hipStreamSynchronize(s));
     if (stats_host) {
-        double tmp[4];
-        int rc = read_back(h, dst, tmp, 4, s);
-        if (rc) return rc;
-        stats_host->sum = tmp[0];
-        stats_host->sumsq = tmp[1];
-        stats_host->min = tmp[2];
-        stats_host->n_bad = tmp[3];
+        stats_host->sum = h->mapped[0];
+        stats_host->sumsq = h->mapped[1];
+        stats_host->n_bad = h->mapped[2];
+        stats_host->min = h->mapped[ns];
     }
+    if (extra_host) memcpy(extra_host, h->mapped + 3, (size_t)n_extra * sizeof(double));
     return QSMC_OK;
 }
 
 template <int KIND>
 static void launch_update(qsmc_ctx *h, bool vec2, int grid, hipStream_t s, const double *x, int64_t ldx,
                           int64_t n, const double *w_in, double *w_out, double prev_norm, const ExpArgs &e,
-                          int64_t outcome, double *partials) {
+                          int64_t outcome, const ReduceOut &ro) {
     // In profiling mode the launch carries start/stop events, so the elapsed time is the kernel's
     // own execution (what rocprofv3 --kernel-trace reports), not launch latency.
     hipEvent_t e0 = h->profiling ? h->ev0 : nullptr, e1 = h->profiling ? h->ev1 : nullptr;
     if (vec2)
         hipExtLaunchKernelGGL((k_update_fused<KIND, 2>), dim3(grid), dim3(QSMC_BLOCK), 0, s, e0, e1, 0, x, ldx,
-                              n, w_in, w_out, prev_norm, e, outcome, partials);
+                              n, w_in, w_out, prev_norm, e, outcome, ro);
     else
         hipExtLaunchKernelGGL((k_update_fused<KIND, 1>), dim3(grid), dim3(QSMC_BLOCK), 0, s, e0, e1, 0, x, ldx,
-                              n, w_in, w_out, prev_norm, e, outcome, partials);
+                              n, w_in, w_out, prev_norm, e, outcome, ro);
 }
 
 template <int MODE>
@@ -989,10 +1121,12 @@ static int weights_pass(qsmc_ctx *h, const double *L, int64_t n, const double *w
     const int grid = grid_for(n, QSMC_BLOCK * 4);
     int rc = ensure_partials(h, (size_t)grid * 4);
     if (rc) return rc;
-    hipLaunchKernelGGL((k_weights_pass<MODE>), dim3(grid), dim3(QSMC_BLOCK), 0, s, L, n, w_in, w_out, norm,
-                       h->partials);
+    const ReduceOut ro = make_reduce(h, stats_host != nullptr, stats_dev);
+    hipLaunchKernelGGL((k_weights_pass<MODE>), dim3(grid), dim3(QSMC_BLOCK), 0, s, L, n, w_in, w_out, norm, ro);
     HIP_TRY(h, hipGetLastError());
-    return finish_stats(h, grid, stats_dev, stats_host, s);
+    rc = launch_reduce(h, 3, grid, ro, s);
+    if (rc) return rc;
+    return collect_stats(h, 3, stats_host, nullptr, 0, s);
 }
 
 // =============================================================================================
@@ -1023,6 +1157,9 @@ int qsmc_create(qsmc_handle_t *out, int device) {
     h->device = device;
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipMalloc(&h->counter, sizeof(long long));
+    if (e == hipSuccess) e = hipMalloc(&h->red_out, REDUCE_OUT_MAX * sizeof(double));
+    if (e == hipSuccess) e = hipHostMalloc(&h->mapped, REDUCE_OUT_MAX * sizeof(double), hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&h->mapped_dev, h->mapped, 0);
     if (e == hipSuccess) e = hipEventCreate(&h->ev0);
     if (e == hipSuccess) e = hipEventCreate(&h->ev1);
     if (e != hipSuccess) {
@@ -1040,6 +1177,8 @@ int qsmc_destroy(qsmc_handle_t h) {
     if (h->pinned) (void)hipHostFree(h->pinned);
     if (h->counter) (void)hipFree(h->counter);
     if (h->iscratch) (void)hipFree(h->iscratch);
+    if (h->red_out) (void)hipFree(h->red_out);
+    if (h->mapped) (void)hipHostFree(h->mapped);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     delete h;
@@ -1106,23 +1245,29 @@ int qsmc_are_models_valid(qsmc_handle_t h, const qsmc_model_t *model, const doub
 
 int qsmc_update_fused(qsmc_handle_t h, const qsmc_model_t *model, const double *x, int64_t ldx, int64_t n,
                       const double *w_in, double *w_out, double prev_norm, const qsmc_expparam_t *exp,
-                      int64_t outcome, double *stats_dev, qsmc_update_stats_t *stats_host,
+                      int64_t outcome, double *stats_dev, qsmc_update_stats_t *stats_host, double *moments_host,
                       qsmc_stream_t stream) {
     if (!h || !x || !w_in || !w_out || !exp || n <= 0) return QSMC_ERR_INVALID;
     int rc = check_model(model);
     if (rc) return rc;
+    const int d = model->d;
+    const int dmom = d <= 4 ? d : 0;
+    if (moments_host && !dmom) return QSMC_ERR_UNSUPPORTED;      // d > 4: use qsmc_moments
+    const int n_mom = dmom + dmom * (dmom + 1) / 2;
+    const int ns = 3 + n_mom;
     hipStream_t s = (hipStream_t)stream;
     const bool vec2 = aligned16(x) && aligned16(w_in) && aligned16(w_out) && (ldx % 2 == 0);
     const int per_block = QSMC_BLOCK * (vec2 ? 2 : 1) * UPD_UNROLL;
     const int grid = grid_for(n, per_block);
-    rc = ensure_partials(h, (size_t)grid * 4);
+    rc = ensure_partials(h, (size_t)grid * (ns + 1));
     if (rc) return rc;
     ExpArgs ea;
     make_exp_args(model, exp, outcome, &ea);
+    const ReduceOut ro = make_reduce(h, stats_host || moments_host, stats_dev);
     switch (model->kind) {
-#define LAUNCH_U(K)                                                                                   \
-    case K:                                                                                           \
-        launch_update<K>(h, vec2, grid, s, x, ldx, n, w_in, w_out, prev_norm, ea, outcome, h->partials); \
+#define LAUNCH_U(K)                                                                             \
+    case K:                                                                                     \
+        launch_update<K>(h, vec2, grid, s, x, ldx, n, w_in, w_out, prev_norm, ea, outcome, ro); \
         break;
         LAUNCH_U(QSMC_MODEL_PRECESSION)
         LAUNCH_U(QSMC_MODEL_BINOMIAL_PRECESSION)
@@ -1133,7 +1278,9 @@ int qsmc_update_fused(qsmc_handle_t h, const qsmc_model_t *model, const double *
     }
     HIP_TRY(h, hipGetLastError());
     if (h->profiling) h->ev_valid = 1;
-    return finish_stats(h, grid, stats_dev, stats_host, s);
+    rc = launch_reduce(h, ns, grid, ro, s);
+    if (rc) return rc;
+    return collect_stats(h, ns, stats_host, moments_host, n_mom, s);
 }
 
 int qsmc_update_from_likelihood(qsmc_handle_t h, const double *L, int64_t n, const double *w_in,
@@ -1181,21 +1328,26 @@ int qsmc_moments(qsmc_handle_t h, const double *x, int64_t ldx, int64_t n, int32
     double *dst = out_dev ? out_dev : h->scratch;
     const int grid = grid_for(n, QSMC_BLOCK * 4);
     if (d <= 4) {
-        rc = ensure_partials(h, (size_t)grid * K);
+        rc = ensure_partials(h, (size_t)grid * (K + 1));
         if (rc) return rc;
+        const ReduceOut ro = make_reduce(h, out_host != nullptr, nullptr);
         switch (d) {
 #define LAUNCH_M(DD)                                                                                  \
     case DD:                                                                                          \
-        hipLaunchKernelGGL((k_moments_small<DD>), dim3(grid), dim3(QSMC_BLOCK), 0, s, x, ldx, n, w, norm, \
-                           h->partials);                                                              \
+        hipLaunchKernelGGL((k_moments_small<DD>), dim3(grid), dim3(QSMC_BLOCK), 0, s, x, ldx, n, w, norm, ro); \
         break;
             LAUNCH_M(1) LAUNCH_M(2) LAUNCH_M(3) LAUNCH_M(4)
 #undef LAUNCH_M
         }
         HIP_TRY(h, hipGetLastError());
-        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(QSMC_BLOCK), 0, s, h->partials, grid, K, dst);
-        HIP_TRY(h, hipGetLastError());
-        if (out_host) return read_back(h, dst, out_host, K, s);
+        rc = launch_reduce(h, K, grid, ro, s);
+        if (rc) return rc;
+        if (out_dev)
+            HIP_TRY(h, hipMemcpyAsync(out_dev, h->red_out, K * sizeof(double), hipMemcpyDeviceToDevice, s));
+        if (out_host) {
+            HIP_TRY(h, hipStreamSynchronize(s));
+            memcpy(out_host, h->mapped, K * sizeof(double));
+        }
         return QSMC_OK;
     }
     // d > 4: row-split kernel; per-row results land in scratch[256 + m * KR + ...], packed on host
@@ -1330,32 +1482,36 @@ int qsmc_lw_resample_philox(qsmc_handle_t h, const qsmc_model_t *model, int32_t 
         const size_t counts_b = ((size_t)chunks * sizeof(unsigned int) + 15) & ~(size_t)15;
         const size_t slot_b = ((size_t)(chunks + 1) * sizeof(long long) + 15) & ~(size_t)15;
         const size_t item_b = ((size_t)(chunks + 1) * sizeof(int) + 15) & ~(size_t)15;
-        int rc = ensure_iscratch(h, hist_b + counts_b + slot_b + item_b);
+        const int max_items = chunks + (int)(n_out / BUCKET_CAP) + 1;
+        const size_t map_b = ((size_t)max_items * sizeof(int) + 15) & ~(size_t)15;
+        int rc = ensure_iscratch(h, hist_b + counts_b + slot_b + item_b + map_b);
         if (rc) return rc;
         unsigned char *basep = reinterpret_cast<unsigned char *>(h->iscratch);
         unsigned int *hist = reinterpret_cast<unsigned int *>(basep);
         unsigned int *counts = reinterpret_cast<unsigned int *>(basep + hist_b);
         long long *slot_off = reinterpret_cast<long long *>(basep + hist_b + counts_b);
         int *item_off = reinterpret_cast<int *>(basep + hist_b + counts_b + slot_b);
+        int *item_chunk = reinterpret_cast<int *>(basep + hist_b + counts_b + slot_b + item_b);
         HIP_TRY(h, hipMemsetAsync(counts, 0, counts_b, s));
-        const size_t lds = (size_t)chunks * (sizeof(double) + sizeof(unsigned int));
+        const size_t lds = (size_t)(chunks + (chunks >> 5) + (chunks >> 10) + 8) * sizeof(double) +
+                           (size_t)chunks * sizeof(unsigned int);
         hipLaunchKernelGGL(k_bucket_count, dim3(BUCKET_COUNT_BLOCKS), dim3(BUCKET_COUNT_THREADS), lds, s, cdf, n_in,
                            chunks, n_out, k0, k1, ep, hist);
         hipLaunchKernelGGL(k_bucket_reduce, dim3((chunks + QSMC_BLOCK - 1) / QSMC_BLOCK, 8), dim3(QSMC_BLOCK), 0, s,
                            hist, BUCKET_COUNT_BLOCKS, chunks, counts);
-        hipLaunchKernelGGL(k_bucket_plan, dim3(1), dim3(1024), 0, s, counts, chunks, slot_off, item_off);
-        const int max_items = chunks + (int)(n_out / BUCKET_CAP) + 1;
+        hipLaunchKernelGGL(k_bucket_plan, dim3(1), dim3(1024), 0, s, counts, chunks, slot_off, item_off,
+                           item_chunk);
         unsigned long long *nf = reinterpret_cast<unsigned long long *>(h->counter);
-#define LAUNCH_B(DD)                                                                                       \
-    hipLaunchKernelGGL((k_bucket_sample<DD>), dim3(max_items), dim3(QSMC_BLOCK), 0, s, model->kind, d,      \
-                       model->min_freq, postselect, x_in, ldx_in, n_in, cdf, chunks, slot_off, item_off, lw, \
-                       k0, k1, ep, maxiter, x_out, ldx_out, nf)
+#define LAUNCH_B(DD, SX, BT)                                                                               \
+    hipLaunchKernelGGL((k_bucket_sample<DD, SX, BT>), dim3(max_items), dim3(BT), 0, s,                          \
+                       model->kind, d, model->min_freq, postselect, x_in, ldx_in, n_in, cdf, chunks, slot_off,   \
+                       item_off, item_chunk, lw, k0, k1, ep, maxiter, x_out, ldx_out, nf)
         switch (d) {
-            case 1: LAUNCH_B(1); break;
-            case 2: LAUNCH_B(2); break;
-            case 3: LAUNCH_B(3); break;
-            case 4: LAUNCH_B(4); break;
-            default: LAUNCH_B(0); break;
+            case 1: LAUNCH_B(1, true, BUCKET_SAMPLE_THREADS); break;
+            case 2: LAUNCH_B(2, true, BUCKET_SAMPLE_THREADS); break;
+            case 3: LAUNCH_B(3, false, BUCKET_SAMPLE_THREADS); break;
+            case 4: LAUNCH_B(4, false, BUCKET_SAMPLE_THREADS); break;
+            default: LAUNCH_B(0, false, QSMC_BLOCK); break;   // d up to 16: 512-VGPR budget
         }
 #undef LAUNCH_B
     }

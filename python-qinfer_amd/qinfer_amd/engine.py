@@ -105,13 +105,28 @@ class Engine:
         return out
 
     # ------------------------------------------------------------------ weight passes
-    def update_fused(self, desc, x, w_in, w_out, prev_norm, exp, outcome, sync=True):
+    def update_fused(self, desc, x, w_in, w_out, prev_norm, exp, outcome, sync=True, moments=False):
+        """Returns UpdateStats (or (UpdateStats, s1, s2) with moments=True, d <= 4: UNNORMALISED
+        sum w' x and sum w' x x^T of the new weights, produced by the same kernel)."""
         st = _native.UpdateStats()
+        d = x.shape[0]
+        mom = None
+        if moments:
+            mom = np.empty(d + d * (d + 1) // 2, dtype=np.float64)
         self._chk(self.lib.qsmc_update_fused(
             self.h, C.byref(desc), self._p(x), x.stride(0), x.shape[1], self._p(w_in), self._p(w_out),
             float(prev_norm), C.byref(exp), int(outcome), self._p(self._stats),
-            C.byref(st) if sync else None, self.stream()), "qsmc_update_fused")
-        return st if sync else None
+            C.byref(st) if sync else None, _native.f64_ptr(mom) if moments else None, self.stream()),
+            "qsmc_update_fused")
+        if not sync:
+            return None
+        if not moments:
+            return st
+        s1 = mom[:d].copy()
+        s2 = np.zeros((d, d))
+        s2[np.triu_indices(d)] = mom[d:]
+        s2 = s2 + np.triu(s2, 1).T
+        return st, s1, s2
 
     def update_from_likelihood(self, L, w_in, w_out, prev_norm):
         st = _native.UpdateStats()

@@ -247,12 +247,20 @@ class SMCUpdater(ParticleDistribution):
         self._just_resampled = False
         eng = self._eng
         w_out = self._scratch_weights()
+        fused_moments = None
         if self._native:
             exps = self.model._native_expparams(expparams)
             if len(exps) != 1:
                 raise ValueError("update() takes exactly one experiment")
-            st = eng.update_fused(self._desc, self._x, self._w, w_out, self._norm, exps[0],
-                                  _as_int_outcome(outcome))
+            if self._comm is None and self._x.shape[0] <= 4:
+                # the kernel also returns sum w'x, sum w'xx^T of the new weights (x is in registers
+                # anyway): est_mean / est_covariance_mtx / the resampler need no further pass
+                st, m1, m2 = eng.update_fused(self._desc, self._x, self._w, w_out, self._norm, exps[0],
+                                              _as_int_outcome(outcome), moments=True)
+                fused_moments = (m1, m2)
+            else:
+                st = eng.update_fused(self._desc, self._x, self._w, w_out, self._norm, exps[0],
+                                      _as_int_outcome(outcome))
         else:
             L = self._device_likelihood(outcome, expparams)
             if L.shape[0] != 1 or L.shape[1] != 1:
@@ -294,6 +302,8 @@ class SMCUpdater(ParticleDistribution):
         self._norm = float(new_norm)
         self._sumsq = float(sumsq)
         self._invalidate()
+        if fused_moments is not None and n_bad == 0 and new_norm != 0:
+            self._moments_cache = (sum_w, fused_moments[0] / new_norm, fused_moments[1] / new_norm)
         self._normalization_record.append(norm)                      # smc.py:444
 
         if not self._native and type(self.model).update_timestep is not Simulatable.update_timestep:
