@@ -181,13 +181,22 @@ int qsmc_lw_perturb(qsmc_handle_t h, const qsmc_model_t *model, int32_t postsele
 
 /* Device-RNG resample in ONE launch (Philox4x32-10, counter = (particle, epoch, round)):
  * draw u -> ancestor -> centre -> Box-Muller z -> perturb -> validity; an invalid particle redraws
- * (ancestor and z) in-thread up to maxiter times.  *n_failed_host = particles still invalid. */
+ * (ancestor and z) in-thread up to maxiter times.  *n_failed_host = particles still invalid
+ * (synchronises); pass NULL to stay asynchronous and use qsmc_last_resample_failed.
+ * For 4*4096 <= n_out and n_in <= 3.3e7 the bucketed path is used: outputs are
+ * then ordered by ancestor chunk -- particles are exchangeable, the joint law is the same. */
 int qsmc_lw_resample_philox(qsmc_handle_t h, const qsmc_model_t *model, int32_t postselect,
                             const double *x_in, int64_t ldx_in, int64_t n_in, int32_t d,
                             const double *cdf, double a, const double *mean, const double *S,
                             int64_t n_out, uint64_t seed, uint64_t epoch, int32_t maxiter,
                             double *x_out, int64_t ldx_out, int64_t *n_failed_host,
                             qsmc_stream_t stream);
+
+/* qsmc_lw_resample_philox with n_failed_host == NULL does not synchronise: the failed-particle count
+ * is written to pinned host memory by the stream; read it here once `stream` has been synchronised by
+ * any later call (synchronize = 0), or force the wait (synchronize = 1). */
+int qsmc_last_resample_failed(qsmc_handle_t h, int64_t *n_failed_out, int32_t synchronize,
+                              qsmc_stream_t stream);
 
 /* Sharded resampling, step 1: draw `n_draw` ancestors from THIS shard's CDF
  * (u from Philox, counter = draw index) and gather their rows: anc_out[m][t] = x_in[m][j_t].

@@ -268,7 +268,8 @@ class ParticleDistribution(Distribution):
     def _cov_from_sums(s1, s2):
         cov = s2 - np.outer(s1, s1)                       # E[x x^T] - mu mu^T (distributions.py:386-390)
         assert np.all(np.isfinite(cov))
-        if not np.all(np.linalg.eigvals(cov) >= 0):
+        psd = (cov[0, 0] >= 0) if cov.shape == (1, 1) else np.all(np.linalg.eigvals(cov) >= 0)
+        if not psd:
             warnings.warn('Numerical error in covariance estimation causing positive semidefinite '
                           'violation.', ApproximationWarning)
         return cov

@@ -70,6 +70,20 @@ class Engine:
     def _p(t):
         return C.c_void_p(t.data_ptr())
 
+    _triu_cache = {}
+
+    @classmethod
+    def _unpack_upper(cls, packed, d):
+        """Row-major upper triangle (d(d+1)/2) -> symmetric (d, d)."""
+        if d == 1:
+            return np.array([[packed[0]]])
+        idx = cls._triu_cache.get(d)
+        if idx is None:
+            idx = cls._triu_cache[d] = np.triu_indices(d)
+        s2 = np.zeros((d, d))
+        s2[idx] = packed
+        return s2 + np.triu(s2, 1).T
+
     def _chk(self, rc, what):
         _native.check(self.h, rc, what)
 
@@ -122,11 +136,7 @@ class Engine:
             return None
         if not moments:
             return st
-        s1 = mom[:d].copy()
-        s2 = np.zeros((d, d))
-        s2[np.triu_indices(d)] = mom[d:]
-        s2 = s2 + np.triu(s2, 1).T
-        return st, s1, s2
+        return st, mom[:d].copy(), self._unpack_upper(mom[d:], d)
 
     def update_from_likelihood(self, L, w_in, w_out, prev_norm):
         st = _native.UpdateStats()
@@ -167,12 +177,7 @@ class Engine:
         out = np.empty(k, dtype=np.float64)
         self._chk(self.lib.qsmc_moments(self.h, self._p(x), x.stride(0), n, d, self._p(w), float(norm),
                                         None, _native.f64_ptr(out), self.stream()), "qsmc_moments")
-        s1 = out[1:1 + d].copy()
-        s2 = np.zeros((d, d))
-        iu = np.triu_indices(d)
-        s2[iu] = out[1 + d:]
-        s2 = s2 + np.triu(s2, 1).T
-        return float(out[0]), s1, s2
+        return float(out[0]), out[1:1 + d].copy(), self._unpack_upper(out[1 + d:], d)
 
     def sqrtm_psd(self, A, scale=1.0):
         A = np.ascontiguousarray(A, dtype=np.float64)
@@ -215,7 +220,10 @@ class Engine:
             "qsmc_lw_perturb")
         return valid
 
-    def lw_resample_philox(self, desc, postselect, x_in, cdf, a, mean, S, n_out, seed, epoch, maxiter):
+    def lw_resample_philox(self, desc, postselect, x_in, cdf, a, mean, S, n_out, seed, epoch, maxiter,
+                           sync=True):
+        """Returns (x_out, n_failed); with sync=False n_failed is None and the count is available
+        from `last_resample_failed()` after the next stream synchronisation."""
         d = x_in.shape[0]
         x_out = self.empty(d, n_out)
         mean = np.ascontiguousarray(mean, dtype=np.float64)
@@ -225,8 +233,14 @@ class Engine:
             self.h, C.byref(desc), int(bool(postselect)), self._p(x_in), x_in.stride(0), x_in.shape[1], d,
             self._p(cdf), float(a), _native.f64_ptr(mean), _native.f64_ptr(S), n_out,
             C.c_uint64(seed & (2 ** 64 - 1)), C.c_uint64(epoch), int(maxiter), self._p(x_out),
-            x_out.stride(0), C.byref(failed), self.stream()), "qsmc_lw_resample_philox")
-        return x_out, failed.value
+            x_out.stride(0), C.byref(failed) if sync else None, self.stream()), "qsmc_lw_resample_philox")
+        return x_out, (failed.value if sync else None)
+
+    def last_resample_failed(self, synchronize=False):
+        out = C.c_int64()
+        self._chk(self.lib.qsmc_last_resample_failed(self.h, C.byref(out), int(bool(synchronize)), self.stream()),
+                  "qsmc_last_resample_failed")
+        return out.value
 
     def lw_draw_gather_philox(self, x_in, cdf, n_draw, seed, epoch):
         d = x_in.shape[0]

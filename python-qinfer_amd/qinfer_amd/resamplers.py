@@ -93,7 +93,7 @@ class LiuWestResampler(Resampler):
         n_particles = int(n_particles)
         d = particle_dist.n_rvs
         a, h = self._a, self._h
-        if np.linalg.norm(cov, 'fro') == 0:
+        if not cov.any():                                  # la.norm(cov, 'fro') == 0  (resamplers.py:283)
             warnings.warn("Covariance has zero norm; adding in small covariance in resampler. "
                           "Consider increasing n_particles to improve covariance estimates.",
                           ResamplerWarning)
@@ -110,8 +110,13 @@ class LiuWestResampler(Resampler):
 
         if self._device_rng and native:
             self._epoch += 1
+            defer = bool(getattr(self, "_defer_failed_check", False))
             x_new, n_failed = eng.lw_resample_philox(desc, self._postselect, x_in, cdf, a, mean, S,
-                                                     n_particles, self._seed, self._epoch, self._maxiter)
+                                                     n_particles, self._seed, self._epoch, self._maxiter,
+                                                     sync=not defer)
+            if defer:                  # stay asynchronous: the count is read at the caller's next sync
+                self._pending_failed = eng
+                n_failed = 0
         else:
             x_new, n_failed = self._legacy_draw(eng, model, desc, x_in, cdf, a, mean, S, n_particles)
         if n_failed:
@@ -123,6 +128,17 @@ class LiuWestResampler(Resampler):
         eng.fill(w_new, uniform)
         return ParticleDistribution._from_device(eng, x_new, w_new, norm=1.0,
                                                  sumsq=float(n_particles * uniform * uniform))
+
+    def _flush_failed_warning(self, synchronize=False):
+        """Emit the deferred 'failed to find valid models' ResamplerWarning, if one is due."""
+        eng = getattr(self, "_pending_failed", None)
+        if eng is None:
+            return
+        self._pending_failed = None
+        n_failed = eng.last_resample_failed(synchronize)
+        if n_failed:
+            warnings.warn("Liu-West resampling failed to find valid models for {} particles within "
+                          "{} iterations.".format(n_failed, self._maxiter), ResamplerWarning)
 
     # ------------------------------------------------------------------------------------------
     def _legacy_draw(self, eng, model, desc, x_in, cdf, a, mean, S, n_out):

@@ -267,6 +267,9 @@ class SMCUpdater(ParticleDistribution):
                 raise ValueError("update() takes exactly one outcome and one experiment")
             st = eng.update_from_likelihood(L.reshape(-1), self._w, w_out, self._norm)
         norm, sumsq, wmin, n_bad = self._reduce_stats(st)
+        flush = getattr(self.resampler, "_flush_failed_warning", None)
+        if flush is not None:
+            flush()                       # the stream was just synchronised: deferred resampler warning
         fixed = 1.0 if abs(norm) < _EPS else norm                    # smc.py:369-370
         new_norm = fixed
 
@@ -339,10 +342,15 @@ class SMCUpdater(ParticleDistribution):
                           "Consider adding particles, or resampling more often.".format(ess),
                           ApproximationWarning)
         if ess < self.n_particles_global * self.resample_thresh:
-            self.resample()
+            self.resample(_defer_warning=True)
 
-    def resample(self):
-        """Force a resampling step now (smc.py:491-551)."""
+    def resample(self, _defer_warning=False):
+        """Force a resampling step now (smc.py:491-551).
+
+        When triggered from `update` with the device RNG, the step is fully asynchronous: nothing
+        is read back, so the host queues the next update while the GPU resamples; the (rare)
+        'failed to find valid models' warning is then issued at the next update's synchronisation.
+        A direct call waits and warns immediately, like the reference."""
         if self.just_resampled:
             warnings.warn("Resampling without additional data; this may not perform as desired.",
                           ResamplerWarning)
@@ -354,7 +362,16 @@ class SMCUpdater(ParticleDistribution):
         if self._comm is not None:
             new = self._comm.resample(self, self.resampler)
         else:
-            new = self.resampler(self.model, self)
+            can_defer = _defer_warning and hasattr(self.resampler, "_flush_failed_warning")
+            if can_defer:
+                self.resampler._defer_failed_check = True
+            try:
+                new = self.resampler(self.model, self)
+            finally:
+                if can_defer:
+                    self.resampler._defer_failed_check = False
+            if not _defer_warning and hasattr(self.resampler, "_flush_failed_warning"):
+                self.resampler._flush_failed_warning(synchronize=True)
         if isinstance(new, ParticleDistribution):
             self._x, self._w, self._norm, self._sumsq = new._x, new._w, new._norm, new._sumsq
         else:                                           # foreign resampler returning host arrays
