@@ -14,7 +14,8 @@ resample it triggers.  The cloud is resident in HBM before the timed region; dev
 
 One JSON line on rank 0 with `value` = N_total * K / wall, plus
   roofline:     the fused update kernel's achieved algorithmic HBM bytes/s (24 B/particle: read x,
-                read w, write w) from HIP-event kernel durations measured inside the timed region;
+                read w, write w; 16 B for the first update after a resample, whose uniform weights
+                are implicit) from HIP-event kernel durations measured inside the timed region;
   cpu_baseline: the CPU oracle (NumPy restatement of the reference, oracle/np_oracle.py) timed
                 here on the host on a bounded sample of the same workload.
 """
@@ -120,13 +121,15 @@ def main():
         upd.reset()
         upd._resample_count = 0
         eng.set_profiling(True)
-        kernel_ms = []
+        kernel_ms, kernel_bytes = [], []
         barrier()
         t0 = time.perf_counter()
         for i in range(args.steps):
             k = i % N_SCHEDULE
             if i and k == 0:
                 upd.reset()
+            # the first update after a reset/resample consumes implicit uniform weights: no w read
+            kernel_bytes.append((16 if upd._w is None else BYTES_PER_PARTICLE_UPDATE) * n)
             upd.update(int(outcomes[k]), ts[k:k + 1])
             kernel_ms.append(eng.last_update_kernel_ms())  # stream already synchronised by update()
         barrier()
@@ -141,7 +144,7 @@ def main():
     if rank == 0:
         n_total = n * world
         avg_kernel_s = float(np.mean(kernel_ms)) * 1e-3
-        achieved = BYTES_PER_PARTICLE_UPDATE * n / avg_kernel_s / 1e9
+        achieved = float(np.sum(kernel_bytes)) / (float(np.sum(kernel_ms)) * 1e-3) / 1e9
         line = {
             "metric": "particle-updates/sec", "value": n_total * args.steps / wall,
             "unit": "particle-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -155,7 +158,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(),
                          "kernel": "k_update_fused<PRECESSION,2>", "avg_kernel_us": avg_kernel_s * 1e6,
-                         "algorithmic_bytes_per_launch": BYTES_PER_PARTICLE_UPDATE * n},
+                         "algorithmic_bytes_per_launch": float(np.mean(kernel_bytes)),
+                         "launches_24B_per_particle": int(np.sum(np.array(kernel_bytes) == 24 * n)),
+                         "launches_16B_per_particle": int(np.sum(np.array(kernel_bytes) == 16 * n))},
             "posterior_mean": float(upd.est_mean()[0]),
         }
         if world == 1 and not args.no_cpu_baseline:

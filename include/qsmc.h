@@ -107,7 +107,9 @@ int qsmc_are_models_valid(qsmc_handle_t h, const qsmc_model_t *model,
 /* ---- fused Bayes update (smc.py:388-457 = hypothetical_update :324-386 + n_ess; a1-a3) --- */
 /* w_out[i] = (w_in[i] / prev_norm) * Pr(outcome | x_i ; exp);  stats reduced in the same pass
  * (per-workgroup partials, then a one-workgroup kernel sums them in index order: deterministic).
- * w_out may alias w_in.  stats_dev (4 doubles, device, qsmc_update_stats_t order) is written if
+ * w_out may alias w_in.  w_in == NULL stands for all-ones weights (uniform cloud after a resample or
+ * reset, with prev_norm = N): the fill pass and 8 B/particle of reads are skipped, same arithmetic.
+ * stats_dev (4 doubles, device, qsmc_update_stats_t order) is written if
  * non-NULL.  If stats_host or moments_host is non-NULL the call synchronises `stream`.
  * moments_host (d <= 4 only): [sum w' x_m (d), sum w' x_m x_n for m <= n row-major (d(d+1)/2)] of the
  * NEW unnormalised weights -- divide by stats.sum to get E[x], E[x x^T] (distributions.py:337-399)

@@ -213,7 +213,7 @@ struct UpdAcc {
     }
 };
 
-template <int KIND, int VEC>
+template <int KIND, int VEC, bool ONES>   // ONES: w_in == nullptr stands for all-ones weights
 __global__ __launch_bounds__(QSMC_BLOCK) void k_update_fused(
     const double *__restrict__ x, int64_t ldx, int64_t n, const double *__restrict__ w_in,
     double *__restrict__ w_out, double prev_norm, ExpArgs e, int64_t outcome, ReduceOut ro) {
@@ -229,7 +229,8 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_update_fused(
             const int64_t i = base + ((int64_t)u * QSMC_BLOCK + threadIdx.x) * VEC;
             if (VEC == 2) {
                 if (i + 1 < n) {
-                    const double2 wi = *reinterpret_cast<const double2 *>(w_in + i);
+                    double2 wi;
+                    if (ONES) { wi.x = 1.0; wi.y = 1.0; } else wi = *reinterpret_cast<const double2 *>(w_in + i);
                     double p0[D], p1[D];
 #pragma unroll
                     for (int m = 0; m < D; ++m) {
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_update_fused(
 #pragma unroll
                     for (int m = 0; m < D; ++m)
                         if (m < d) p0[m] = x[m * ldx + i];
-                    const double wo = (w_in[i] / prev_norm) * Model<KIND>::lik(p0, e, outcome);
+                    const double wo = ((ONES ? 1.0 : w_in[i]) / prev_norm) * Model<KIND>::lik(p0, e, outcome);
                     w_out[i] = wo;
                     acc.add(wo, p0);
                 }
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_update_fused(
 #pragma unroll
                     for (int m = 0; m < D; ++m)
                         if (m < d) p0[m] = x[m * ldx + i];
-                    const double wo = (w_in[i] / prev_norm) * Model<KIND>::lik(p0, e, outcome);
+                    const double wo = ((ONES ? 1.0 : w_in[i]) / prev_norm) * Model<KIND>::lik(p0, e, outcome);
                     w_out[i] = wo;
                     acc.add(wo, p0);
                 }
@@ -445,49 +446,58 @@ __device__ __forceinline__ double wave_inclusive_max(double v, int lane) {
 }
 
 // Exclusive scan of the chunk sums, in place, plus the grand total at sums[m]  (m + 1 outputs).
-// Single workgroup, 256-wide slabs with a carry.  Floating-point tree sums are not guaranteed
-// monotone in the index, so a second exact pass (prefix MAX -- no rounding) makes the offsets
-// non-decreasing; k_chunk_scan relies on that to emit a monotone CDF.
-__global__ __launch_bounds__(QSMC_BLOCK) void k_scan_sums(double *__restrict__ sums, int64_t m) {
-    __shared__ double wave_tot[QSMC_WAVES_PER_BLOCK];
-    __shared__ double carry_s;
+// Single 1024-thread workgroup; thread t owns a contiguous run of ceil(m / 1024) entries (serial,
+// in registers), the 1024 run totals are scanned with wave shuffles + 16 wave totals.  Floating-point
+// tree sums are not guaranteed monotone in the index, so the result goes through an exact prefix MAX
+// (no rounding) in the same pass structure; k_chunk_scan relies on monotone offsets.
+constexpr int SCAN_SUMS_THREADS = 1024;
+constexpr int SCAN_SUMS_MAX_PER = 16;              // m <= 16384 chunks (N <= 6.7e7) in registers
+
+__global__ __launch_bounds__(SCAN_SUMS_THREADS) void k_scan_sums(double *__restrict__ sums, int64_t m) {
+    __shared__ double wtot[SCAN_SUMS_THREADS / QSMC_WAVE];
     const int lane = threadIdx.x & (QSMC_WAVE - 1);
     const int wave = threadIdx.x / QSMC_WAVE;
-    if (threadIdx.x == 0) carry_s = 0.0;
-    __syncthreads();
-    for (int64_t base = 0; base < m; base += QSMC_BLOCK) {
-        const int64_t i = base + threadIdx.x;
-        const double v = i < m ? sums[i] : 0.0;
-        const double inc = wave_inclusive_scan(v, lane);
-        double excl = __shfl_up(inc, 1, QSMC_WAVE);
-        if (lane == 0) excl = 0.0;
-        if (lane == QSMC_WAVE - 1) wave_tot[wave] = inc;
-        __syncthreads();
-        double off = carry_s;
-        for (int wv = 0; wv < wave; ++wv) off += wave_tot[wv];
-        if (i < m) sums[i] = off + excl;
-        __syncthreads();
-        if (threadIdx.x == QSMC_BLOCK - 1) carry_s = off + inc;
-        __syncthreads();
+    const int per = (int)((m + SCAN_SUMS_THREADS - 1) / SCAN_SUMS_THREADS);
+    const int64_t i0 = (int64_t)threadIdx.x * per;
+    double v[SCAN_SUMS_MAX_PER];
+    double run = 0.0;
+#pragma unroll
+    for (int q = 0; q < SCAN_SUMS_MAX_PER; ++q) {
+        v[q] = (q < per && i0 + q < m) ? sums[i0 + q] : 0.0;
+        run += v[q];
     }
-    if (threadIdx.x == 0) sums[m] = carry_s;
+    // exclusive offset of this thread's run
+    double inc = wave_inclusive_scan(run, lane);
+    if (lane == QSMC_WAVE - 1) wtot[wave] = inc;
     __syncthreads();
-    // exact prefix max over sums[0..m]
-    if (threadIdx.x == 0) carry_s = 0.0;
+    double off = inc - run;
+    for (int wv = 0; wv < wave; ++wv) off += wtot[wv];
+    double total = 0.0;
+    for (int wv = 0; wv < SCAN_SUMS_THREADS / QSMC_WAVE; ++wv) total += wtot[wv];
     __syncthreads();
-    for (int64_t base = 0; base <= m; base += QSMC_BLOCK) {
-        const int64_t i = base + threadIdx.x;
-        const double v = i <= m ? sums[i] : 0.0;
-        const double mx = wave_inclusive_max(v, lane);
-        if (lane == QSMC_WAVE - 1) wave_tot[wave] = mx;
-        __syncthreads();
-        double run = carry_s;
-        for (int wv = 0; wv < wave; ++wv) run = fmax(run, wave_tot[wv]);
-        const double out = fmax(mx, run);
-        if (i <= m) sums[i] = out;
-        __syncthreads();
-        if (threadIdx.x == QSMC_BLOCK - 1) carry_s = out;
-        __syncthreads();
+    // exclusive values of my entries, then make everything monotone with an exact prefix max
+    double e[SCAN_SUMS_MAX_PER];
+    double acc = off, mx = 0.0;
+#pragma unroll
+    for (int q = 0; q < SCAN_SUMS_MAX_PER; ++q) {
+        e[q] = acc;
+        acc += v[q];
+        mx = fmax(mx, e[q]);
+        e[q] = mx;                                  // local running max (values are >= 0)
+    }
+    double wmx = wave_inclusive_max(mx, lane);
+    if (lane == QSMC_WAVE - 1) wtot[wave] = wmx;
+    __syncthreads();
+    double before = __shfl_up(wmx, 1, QSMC_WAVE);   // max over earlier lanes of this wave
+    if (lane == 0) before = 0.0;
+    for (int wv = 0; wv < wave; ++wv) before = fmax(before, wtot[wv]);
+#pragma unroll
+    for (int q = 0; q < SCAN_SUMS_MAX_PER; ++q)
+        if (q < per && i0 + q < m) sums[i0 + q] = fmax(e[q], before);
+    if (threadIdx.x == SCAN_SUMS_THREADS - 1) {
+        double gmax = 0.0;
+        for (int wv = 0; wv < SCAN_SUMS_THREADS / QSMC_WAVE; ++wv) gmax = fmax(gmax, wtot[wv]);
+        sums[m] = fmax(total, gmax);
     }
 }
 
@@ -1181,12 +1191,14 @@ static void launch_update(qsmc_ctx *h, bool vec2, int grid, hipStream_t s, const
     // In profiling mode the launch carries start/stop events, so the elapsed time is the kernel's
     // own execution (what rocprofv3 --kernel-trace reports), not launch latency.
     hipEvent_t e0 = h->profiling ? h->ev0 : nullptr, e1 = h->profiling ? h->ev1 : nullptr;
-    if (vec2)
-        hipExtLaunchKernelGGL((k_update_fused<KIND, 2>), dim3(grid), dim3(QSMC_BLOCK), 0, s, e0, e1, 0, x, ldx,
-                              n, w_in, w_out, prev_norm, e, outcome, ro);
-    else
-        hipExtLaunchKernelGGL((k_update_fused<KIND, 1>), dim3(grid), dim3(QSMC_BLOCK), 0, s, e0, e1, 0, x, ldx,
-                              n, w_in, w_out, prev_norm, e, outcome, ro);
+#define LU(V, O)                                                                                          \
+    hipExtLaunchKernelGGL((k_update_fused<KIND, V, O>), dim3(grid), dim3(QSMC_BLOCK), 0, s, e0, e1, 0, x, ldx, \
+                          n, w_in, w_out, prev_norm, e, outcome, ro)
+    if (vec2 && w_in) LU(2, false);
+    else if (vec2) LU(2, true);
+    else if (w_in) LU(1, false);
+    else LU(1, true);
+#undef LU
 }
 
 template <int MODE>
@@ -1321,7 +1333,7 @@ int qsmc_update_fused(qsmc_handle_t h, const qsmc_model_t *model, const double *
                       const double *w_in, double *w_out, double prev_norm, const qsmc_expparam_t *exp,
                       int64_t outcome, double *stats_dev, qsmc_update_stats_t *stats_host, double *moments_host,
                       qsmc_stream_t stream) {
-    if (!h || !x || !w_in || !w_out || !exp || n <= 0) return QSMC_ERR_INVALID;
+    if (!h || !x || !w_out || !exp || n <= 0) return QSMC_ERR_INVALID;      // w_in == NULL: all-ones weights
     int rc = check_model(model);
     if (rc) return rc;
     const int d = model->d;
@@ -1330,7 +1342,7 @@ int qsmc_update_fused(qsmc_handle_t h, const qsmc_model_t *model, const double *
     const int n_mom = dmom + dmom * (dmom + 1) / 2;
     const int ns = 3 + n_mom;
     hipStream_t s = (hipStream_t)stream;
-    const bool vec2 = aligned16(x) && aligned16(w_in) && aligned16(w_out) && (ldx % 2 == 0);
+    const bool vec2 = aligned16(x) && (!w_in || aligned16(w_in)) && aligned16(w_out) && (ldx % 2 == 0);
     const int per_block = QSMC_BLOCK * (vec2 ? 2 : 1) * UPD_UNROLL;
     const int grid = grid_for(n, per_block);
     rc = ensure_partials(h, (size_t)grid * (ns + 1));
@@ -1465,7 +1477,8 @@ int qsmc_cumsum(qsmc_handle_t h, const double *w, int64_t n, double norm, double
     int rc = ensure_partials(h, (size_t)chunks + 1);
     if (rc) return rc;
     hipLaunchKernelGGL(k_chunk_sums, dim3((unsigned)chunks), dim3(QSMC_BLOCK), 0, s, w, n, norm, h->partials);
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(QSMC_BLOCK), 0, s, h->partials, chunks);
+    if (chunks > (int64_t)SCAN_SUMS_THREADS * SCAN_SUMS_MAX_PER) return QSMC_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_SUMS_THREADS), 0, s, h->partials, chunks);
     hipLaunchKernelGGL(k_chunk_scan, dim3((unsigned)chunks), dim3(QSMC_BLOCK), 0, s, w, n, norm, h->partials,
                        cdf);
     HIP_TRY(h, hipGetLastError());

@@ -187,9 +187,19 @@ class ParticleDistribution(Distribution):
     def _invalidate(self):
         self._moments_cache = None
 
+    def _weights(self):
+        """Explicit unnormalised weights.  `_w is None` encodes an all-ones cloud (uniform weights
+        after a reset / resample, true weight 1 / _norm): the fused update consumes that form
+        directly (w_in = NULL), everything else materialises it here on first use."""
+        if self._w is None:
+            self._w = self._eng.empty(self.n_particles)
+            self._eng.fill(self._w, 1.0)
+        return self._w
+
     def _scratch_weights(self):
-        if self._w_alt is None or self._w_alt.shape != self._w.shape:
-            self._w_alt = self._eng.empty(self._w.shape[0])
+        n = self.n_particles
+        if self._w_alt is None or self._w_alt.shape[0] != n:
+            self._w_alt = self._eng.empty(n)
         return self._w_alt
 
     # ---------------------------------------------------------------- reference attributes
@@ -207,9 +217,9 @@ class ParticleDistribution(Distribution):
     @property
     def particle_weights(self):
         """(N,) NumPy COPY of the normalised weights (D2H)."""
-        if self._w.shape[0] == 0:
+        if self.n_particles == 0:
             return np.zeros((0,))
-        return self._eng.normalized_weights(self._w, self._norm).cpu().numpy()
+        return self._eng.normalized_weights(self._weights(), self._norm).cpu().numpy()
 
     @particle_weights.setter
     def particle_weights(self, w):
@@ -231,7 +241,7 @@ class ParticleDistribution(Distribution):
     def n_ess(self):
         """1 / sum_i w_i^2 of the normalised weights."""
         if self._sumsq is None:
-            st = self._eng.weight_stats(self._w, self._norm)
+            st = self._eng.weight_stats(self._weights(), self._norm)
             self._sumsq = st.sumsq * self._norm * self._norm     # keep it in unnormalised units
         return self._ess_from(self._sumsq)
 
@@ -242,7 +252,7 @@ class ParticleDistribution(Distribution):
     # ---------------------------------------------------------------- moments
     def _moments(self):
         if self._moments_cache is None:
-            s0, s1, s2 = self._eng.moments(self._x, self._w, self._norm)
+            s0, s1, s2 = self._eng.moments(self._x, self._weights(), self._norm)
             self._moments_cache = (s0, s1, s2)
         return self._moments_cache
 
@@ -292,14 +302,14 @@ class ParticleDistribution(Distribution):
 
     def est_entropy(self):
         t = self._eng.torch
-        w = self._eng.normalized_weights(self._w, self._norm)
+        w = self._eng.normalized_weights(self._weights(), self._norm)
         nz = w[w > 0]
         return float(-(t.log(nz) * nz).sum().item())
 
     # ---------------------------------------------------------------- sampling
     def sample(self, n=1):
         """n draws from the cloud by inverse CDF (uniforms from the legacy global RNG)."""
-        cdf = self._eng.cumsum(self._w, self._norm)
+        cdf = self._eng.cumsum(self._weights(), self._norm)
         u = self._eng.to_device(np.random.random((n,)))
         js = self._eng.lw_ancestors(cdf, u)
         return np.ascontiguousarray(self._x[:, js].cpu().numpy().T)

@@ -128,7 +128,8 @@ class Engine:
         if moments:
             mom = np.empty(d + d * (d + 1) // 2, dtype=np.float64)
         self._chk(self.lib.qsmc_update_fused(
-            self.h, C.byref(desc), self._p(x), x.stride(0), x.shape[1], self._p(w_in), self._p(w_out),
+            self.h, C.byref(desc), self._p(x), x.stride(0), x.shape[1],
+            self._p(w_in) if w_in is not None else None, self._p(w_out),
             float(prev_norm), C.byref(exp), int(outcome), self._p(self._stats),
             C.byref(st) if sync else None, _native.f64_ptr(mom) if moments else None, self.stream()),
             "qsmc_update_fused")

@@ -141,11 +141,11 @@ class ParticleShardGroup:
             raise ResamplerError("Infinite error in computing the square root of the covariance "
                                  "matrix. Check that n_ess is not too small.")
         # shard weight totals (unnormalised sums are fine: only ratios matter)
-        st = eng.weight_stats(updater._w, 1.0)
+        st = eng.weight_stats(updater._weights(), 1.0)
         W = self.gather_rows(self.torch.tensor([st.sum], dtype=self.torch.float64))[:, 0]
         counts = self.plan_counts(W, n_local, epoch)
         n_draw = int(counts[:, self.rank].sum())
-        cdf = eng.cumsum(updater._w, st.sum)                         # local CDF, normalised locally
+        cdf = eng.cumsum(updater._weights(), st.sum)                 # local CDF, normalised locally
         seed_r = resampler._seed + 0x9E3779B97F4A7C15 * (self.rank + 1)
         anc = eng.lw_draw_gather_philox(updater._x, cdf, n_draw, seed_r, epoch)      # (d, T_h)
         recv = self.exchange_rows(anc.t().contiguous(), counts)                      # (n_local, d)
@@ -156,8 +156,4 @@ class ParticleShardGroup:
             warnings.warn("Liu-West resampling failed to find valid models for {} particles within {} "
                           "iterations.".format(n_failed, resampler._maxiter), ResamplerWarning)
         n_total = n_local * self.world_size
-        w_new = eng.empty(n_local)
-        uniform = np.float64(1.0) / np.float64(n_total)
-        eng.fill(w_new, uniform)
-        return ParticleDistribution._from_device(eng, x_new, w_new, norm=1.0,
-                                                 sumsq=float(n_total * uniform * uniform))
+        return ParticleDistribution._from_device(eng, x_new, None, norm=float(n_total), sumsq=float(n_total))

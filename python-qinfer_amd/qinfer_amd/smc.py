@@ -132,16 +132,16 @@ class SMCUpdater(ParticleDistribution):
     def _moments(self):
         if self._moments_cache is None:
             if self._comm is None:
-                self._moments_cache = self._eng.moments(self._x, self._w, self._norm)
+                self._moments_cache = self._eng.moments(self._x, self._weights(), self._norm)
             else:
                 self._moments_cache = self._comm.allreduce_moments(
-                    self._eng, *self._eng.moments(self._x, self._w, self._norm))
+                    self._eng, *self._eng.moments(self._x, self._weights(), self._norm))
         return self._moments_cache
 
     @property
     def n_ess(self):
         if self._sumsq is None:
-            st = self._eng.weight_stats(self._w, self._norm)
+            st = self._eng.weight_stats(self._weights(), self._norm)
             sumsq = st.sumsq * self._norm * self._norm
             if self._comm is not None:
                 sumsq = self._comm.allreduce_scalar(self._eng, sumsq)
@@ -159,12 +159,11 @@ class SMCUpdater(ParticleDistribution):
         d = self.model.n_modelparams
         n_total = n_particles if self._comm is None else n_particles * self._comm.world_size
         if reset_weights:
-            self._w = eng.empty(n_particles)
-            uniform = np.float64(1.0) / np.float64(n_total)
-            eng.fill(self._w, uniform)
+            # uniform weights 1/N (smc.py:307), held implicitly: all-ones with normaliser N
+            self._w = None
             self._w_alt = None
-            self._norm = 1.0
-            self._sumsq = float(n_total * uniform * uniform)
+            self._norm = float(n_total)
+            self._sumsq = float(n_particles) if self._comm is None else float(n_total)
         x_new = None
         if self._device_rng and hasattr(self.prior, "sample_device"):
             try:
@@ -220,7 +219,7 @@ class SMCUpdater(ParticleDistribution):
             outcomes = np.array([outcomes])
         eng, t = self._eng, self._eng.torch
         L = self._device_likelihood(outcomes, expparams)               # (n_o, n_e, N) device
-        w = eng.normalized_weights(self._w, self._norm)
+        w = eng.normalized_weights(self._weights(), self._norm)
         hyp = w * L
         norm_scale = hyp.sum(dim=2, keepdim=True)
         if self._comm is not None:
@@ -265,7 +264,7 @@ class SMCUpdater(ParticleDistribution):
             L = self._device_likelihood(outcome, expparams)
             if L.shape[0] != 1 or L.shape[1] != 1:
                 raise ValueError("update() takes exactly one outcome and one experiment")
-            st = eng.update_from_likelihood(L.reshape(-1), self._w, w_out, self._norm)
+            st = eng.update_from_likelihood(L.reshape(-1), self._weights(), w_out, self._norm)
         norm, sumsq, wmin, n_bad = self._reduce_stats(st)
         flush = getattr(self.resampler, "_flush_failed_warning", None)
         if flush is not None:

@@ -219,7 +219,7 @@ def test_particle_distribution_contract(qi):
 
 
 # ================================================================== scan + search
-@pytest.mark.parametrize("n", [1, 5, 127, 128, 129, 4095, 4096, 4097, 100003, 1 << 21])
+@pytest.mark.parametrize("n", [1, 5, 127, 128, 129, 4095, 4096, 4097, 100003, 1 << 21, 12345677])
 def test_cumsum_and_ancestors(qi, eng, n):
     rs = np.random.RandomState(n % 1000)
     w = rs.random_sample(n) ** 4
@@ -387,6 +387,23 @@ def test_prior_uniform_philox(qi, eng):
     ok = orc.valid_rb(cand)
     np.testing.assert_allclose(x[ok], cand[ok], rtol=1e-15)
     assert 0.3 < ok.mean() < 0.9
+
+
+def test_deferred_failed_warning(qi):
+    """Device-RNG resampling triggered from update() is asynchronous; its ResamplerWarning ('failed to
+    find valid models', resamplers.py:374-381) surfaces at the next synchronisation instead."""
+    n = 40000
+    model = qi.SimplePrecessionModel(min_freq=0.9999)          # almost nothing is valid
+    res = qi.LiuWestResampler(a=0.98, maxiter=2, device_rng=True, seed=3)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        upd = qi.SMCUpdater(model, n, qi.UniformDistribution([0, 1]), resampler=res, device_rng=True,
+                            resample_thresh=1.1)               # resample after every datum
+        upd.update(0, np.array([1.0]))                          # triggers the (deferred) resample
+    with pytest.warns(qi.ResamplerWarning, match="failed to find valid models"):
+        upd.update(0, np.array([1.0]), check_for_resample=False)
+    with pytest.warns(qi.ResamplerWarning, match="failed to find valid models"):
+        upd.resample()                                          # a direct call warns immediately
 
 
 # ================================================================== canonicalize (G5)
