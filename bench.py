@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-particles", type=float, default=2e6)
     ap.add_argument("--cpu-data", type=int, default=120)
+    ap.add_argument("--force-comm", action="store_true",
+                    help="run the sharded code path even with one rank (validation on a 1-GPU box)")
     args = ap.parse_args()
 
     import torch
@@ -93,8 +95,12 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     comm = None
-    if world > 1:
+    if world > 1 or args.force_comm:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29513")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         from qinfer_amd.parallel import ParticleShardGroup
@@ -166,7 +172,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(int(args.cpu_particles), args.cpu_data)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or args.force_comm:
         torch.distributed.destroy_process_group()
 
 

@@ -109,8 +109,9 @@ int qsmc_are_models_valid(qsmc_handle_t h, const qsmc_model_t *model,
  * (per-workgroup partials, then a one-workgroup kernel sums them in index order: deterministic).
  * w_out may alias w_in.  w_in == NULL stands for all-ones weights (uniform cloud after a resample or
  * reset, with prev_norm = N): the fill pass and 8 B/particle of reads are skipped, same arithmetic.
- * stats_dev (4 doubles, device, qsmc_update_stats_t order) is written if
- * non-NULL.  If stats_host or moments_host is non-NULL the call synchronises `stream`.
+ * stats_dev (device, non-NULL to use): 4 doubles in qsmc_update_stats_t order followed, for d <= 4,
+ * by the d + d(d+1)/2 moment sums described below (so a sharded caller can all-gather one device
+ * vector per datum without a host round trip).  If stats_host or moments_host is non-NULL the call synchronises `stream`.
  * moments_host (d <= 4 only): [sum w' x_m (d), sum w' x_m x_n for m <= n row-major (d(d+1)/2)] of the
  * NEW unnormalised weights -- divide by stats.sum to get E[x], E[x x^T] (distributions.py:337-399)
  * without another pass over HBM. */
@@ -200,22 +201,20 @@ int qsmc_lw_resample_philox(qsmc_handle_t h, const qsmc_model_t *model, int32_t 
 int qsmc_last_resample_failed(qsmc_handle_t h, int64_t *n_failed_out, int32_t synchronize,
                               qsmc_stream_t stream);
 
-/* Sharded resampling, step 1: draw `n_draw` ancestors from THIS shard's CDF
- * (u from Philox, counter = draw index) and gather their rows: anc_out[m][t] = x_in[m][j_t].
- * `cdf` must be the scan of w / norm_local (last entry ~ 1). */
-int qsmc_lw_draw_gather_philox(qsmc_handle_t h, const double *x_in, int64_t ldx_in, int64_t n_in,
-                               int32_t d, const double *cdf, int64_t n_draw, uint64_t seed,
-                               uint64_t epoch, double *anc_out, int64_t ld_anc, qsmc_stream_t stream);
-
-/* Sharded resampling, step 2: Liu-West kick of already-gathered ancestors (after the all-to-all):
- * x_out[:, i] = a * anc[:, c] + (1 - a) * mean + S z, c = i on the first try; an invalid particle
- * retries with a fresh z and the centre of another (Philox-chosen) local ancestor -- the
- * reference's effective behaviour under quirk Q1 (`mus = mus[:k]`, resamplers.py:371-372). */
-int qsmc_lw_perturb_philox(qsmc_handle_t h, const qsmc_model_t *model, int32_t postselect,
-                           const double *anc, int64_t ld_anc, int64_t n, int32_t d, double a,
-                           const double *mean, const double *S, uint64_t seed, uint64_t epoch,
-                           int32_t maxiter, double *x_out, int64_t ldx_out, int64_t *n_failed_host,
-                           qsmc_stream_t stream);
+/* Sharded resampling: THIS rank produces the finished Liu-West particles for every
+ * destination rank -- the kick needs only the ancestor and the (already all-reduced) global mean /
+ * covariance, so nothing about the destination enters -- and they leave by one all-to-all.
+ * dest_counts[r] (HOST, n_dest <= 16) = how many particles rank r takes from this shard (column of
+ * the shared count matrix); rows_out is AoS [sum(dest_counts)][d], grouped by destination rank.
+ * Inside each group the rows are an even round-robin deal of the chunk-sorted sample, so shards stay
+ * exchangeable.  `cdf` is the scan of this shard's w / (its local sum).  A postselection retry
+ * redraws its ancestor from this shard (exact for exchangeable shards). */
+int qsmc_lw_resample_philox_sharded(qsmc_handle_t h, const qsmc_model_t *model, int32_t postselect,
+                                    const double *x_in, int64_t ldx_in, int64_t n_in, int32_t d,
+                                    const double *cdf, double a, const double *mean, const double *S,
+                                    const int64_t *dest_counts, int32_t n_dest, uint64_t seed,
+                                    uint64_t epoch, int32_t maxiter, double *rows_out,
+                                    int64_t *n_failed_host, qsmc_stream_t stream);
 
 /* Device-RNG uniform-box prior (distributions.py:792-827 + :1304-1350 postselection):
  * x[m][i] = lo[m] + U * (hi[m] - lo[m]), redrawn in-thread while invalid (<= maxiter). */

@@ -174,11 +174,13 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_reduce_partials(int nblocks, Red
         }
         ro.out_dev[NS] = m2;
         if (ro.out_mapped) ro.out_mapped[NS] = m2;
-        if (ro.stats4) {
+        if (ro.stats4) {                 // caller layout: qsmc_update_stats_t order, then the extra sums
             ro.stats4[0] = acc[0];
             ro.stats4[1] = acc[1];
             ro.stats4[2] = m2;
             ro.stats4[3] = acc[2];
+#pragma unroll
+            for (int k = 3; k < NS; ++k) ro.stats4[4 + (k - 3)] = acc[k];
         }
     }
 }
@@ -613,11 +615,40 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_perturb(int kind, int d, double 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Output placement.  Single GPU: slot o -> column o of the SoA cloud.  Sharded: this
+// rank produces the finished particles for EVERY destination rank and they leave by one
+// all_to_all, so rows must be grouped by destination, AoS.  The bucketed sampler emits slots sorted
+// by ancestor chunk; dealing them to destinations round-robin (skipping a destination once its
+// quota is full -- exact quotas, closed form below) gives every destination an even, stratified
+// share of all chunks, so the shards stay statistically exchangeable.
+// ---------------------------------------------------------------------------------------------
+#define QSMC_MAX_DEST 16
+struct OutPlace {
+    int n_dest;                            // 0: identity placement
+    int64_t ld_m, ld_s;                    // element (m, row) lives at x_out[m * ld_m + row * ld_s]
+    int order[QSMC_MAX_DEST];              // destination ids by ascending quota
+    int64_t quota[QSMC_MAX_DEST];          // ascending quotas c_(0) <= ... <= c_(G-1)
+    int64_t seg_start[QSMC_MAX_DEST + 1];  // first slot of dealing segment s (rounds c_(s-1) .. c_(s)-1)
+    int64_t dest_base[QSMC_MAX_DEST];      // first row of destination r
+};
+
+__device__ __forceinline__ int64_t place_row(const OutPlace &pl, int64_t o) {
+    if (pl.n_dest == 0) return o;
+    int s = 0;
+    while (s + 1 < pl.n_dest && o >= pl.seg_start[s + 1]) ++s;
+    const int active = pl.n_dest - s;
+    const int64_t rel = o - pl.seg_start[s];
+    const int64_t round = (s ? pl.quota[s - 1] : 0) + rel / active;
+    const int dest = pl.order[s + (int)(rel % active)];
+    return pl.dest_base[dest] + round;
+}
+
 // One-launch device-RNG resample.
 __global__ __launch_bounds__(QSMC_BLOCK) void k_resample_philox(
     int kind, int d, double min_freq, int postselect, const double *__restrict__ x_in, int64_t ldx_in,
     int64_t n_in, const double *__restrict__ cdf, LWArgs lw, int64_t n_out, uint32_t k0, uint32_t k1,
-    uint32_t epoch, int maxiter, double *__restrict__ x_out, int64_t ldx_out,
+    uint32_t epoch, int maxiter, double *__restrict__ x_out, OutPlace pl,
     unsigned long long *__restrict__ n_failed) {
     unsigned long long failed = 0;
     for (int64_t i = (int64_t)blockIdx.x * QSMC_BLOCK + threadIdx.x; i < n_out;
@@ -643,7 +674,8 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_resample_philox(
             }
             ok = !postselect || model_valid(kind, p, min_freq);
         }
-        for (int m = 0; m < d; ++m) x_out[m * ldx_out + i] = p[m];
+        const int64_t row = place_row(pl, i);
+        for (int m = 0; m < d; ++m) x_out[m * pl.ld_m + row * pl.ld_s] = p[m];
         if (!ok) ++failed;
     }
     if (failed) atomicAdd(n_failed, failed);
@@ -878,7 +910,7 @@ __device__ __forceinline__ bool bucket_one_output(
     int kind, int d, double min_freq, int postselect, const double *__restrict__ x_in, int64_t ldx_in,
     int64_t n_in, const double *__restrict__ cdf, const double *lcdf, const double *lx, const int *G,
     double gscale, int64_t base, int len, double lo_edge, double hi_edge, const LWArgs &lw, uint32_t k0, uint32_t k1, uint32_t epoch, int maxiter,
-    int64_t o, double upos, const double *z, double *__restrict__ x_out, int64_t ldx_out) {
+    int64_t o, double upos, const double *z, double *__restrict__ x_out, const OutPlace &pl) {
     double p[DM], xa[DM], zz[DM];
     const double u = lo_edge + upos * (hi_edge - lo_edge);   // given the counts: uniform inside the chunk
     int jl = G ? guided_upper_bound(lcdf, len, G, guide_cell(u, lo_edge, gscale), u) : upper_bound_skew(lcdf, len, u);
@@ -921,9 +953,10 @@ __device__ __forceinline__ bool bucket_one_output(
             }
         }
     }
+    const int64_t row = place_row(pl, o);
 #pragma unroll
     for (int m = 0; m < DM; ++m)
-        if (m < d) x_out[m * ldx_out + o] = p[m];
+        if (m < d) x_out[m * pl.ld_m + row * pl.ld_s] = p[m];
     return ok;
 }
 
@@ -933,7 +966,7 @@ __global__ __launch_bounds__(BT) void k_bucket_sample(
     int kind, int d_rt, double min_freq, int postselect, const double *__restrict__ x_in, int64_t ldx_in,
     int64_t n_in, const double *__restrict__ cdf, int chunks, const long long *__restrict__ slot_off,
     const int *__restrict__ item_off, const int *__restrict__ item_chunk, LWArgs lw, uint32_t k0, uint32_t k1,
-    uint32_t epoch, int maxiter, double *__restrict__ x_out, int64_t ldx_out,
+    uint32_t epoch, int maxiter, double *__restrict__ x_out, OutPlace pl,
     unsigned long long *__restrict__ n_failed) {
     constexpr int DM = D > 0 ? D : QSMC_MAX_D;
     constexpr int DX = STAGE_X ? DM : 1;
@@ -987,7 +1020,7 @@ __global__ __launch_bounds__(BT) void k_bucket_sample(
             if (o >= o_begin && o < o_end) {
                 const bool ok = bucket_one_output<DM, STAGE_X>(
                     kind, d, min_freq, postselect, x_in, ldx_in, n_in, cdf, lcdf, lx, G, gscale, base, len, lo_edge, hi_edge,
-                    lw, k0, k1, epoch, maxiter, o, upos[e], z + e * d, x_out, ldx_out);
+                    lw, k0, k1, epoch, maxiter, o, upos[e], z + e * d, x_out, pl);
                 if (!ok) ++failed;
             }
         }
@@ -998,60 +1031,6 @@ __global__ __launch_bounds__(BT) void k_bucket_sample(
 // copies the failed-particle counter into pinned host memory (read later, after any stream sync)
 __global__ void k_publish_counter(const unsigned long long *__restrict__ counter, double *__restrict__ mapped_slot) {
     if (threadIdx.x == 0 && blockIdx.x == 0) *mapped_slot = (double)*counter;
-}
-
-__global__ __launch_bounds__(QSMC_BLOCK) void k_draw_gather_philox(const double *__restrict__ x_in,
-                                                                    int64_t ldx_in, int64_t n_in, int d,
-                                                                    const double *__restrict__ cdf,
-                                                                    int64_t n_draw, uint32_t k0, uint32_t k1,
-                                                                    uint32_t epoch, double *__restrict__ anc,
-                                                                    int64_t ld_anc) {
-    for (int64_t t = (int64_t)blockIdx.x * QSMC_BLOCK + threadIdx.x; t < n_draw;
-         t += (int64_t)gridDim.x * QSMC_BLOCK) {
-        PhiloxStream rng{(uint64_t)t, (epoch << 16), k0, k1};
-        double u, unused;
-        rng.uniforms(0, u, unused);
-        const int64_t j = search_right(cdf, n_in, u);
-        for (int m = 0; m < d; ++m) anc[m * ld_anc + t] = x_in[m * ldx_in + j];
-    }
-}
-
-__global__ __launch_bounds__(QSMC_BLOCK) void k_perturb_philox(
-    int kind, int d, double min_freq, int postselect, const double *__restrict__ anc, int64_t ld_anc,
-    int64_t n, LWArgs lw, uint32_t k0, uint32_t k1, uint32_t epoch, int maxiter,
-    double *__restrict__ x_out, int64_t ldx_out, unsigned long long *__restrict__ n_failed) {
-    unsigned long long failed = 0;
-    for (int64_t i = (int64_t)blockIdx.x * QSMC_BLOCK + threadIdx.x; i < n;
-         i += (int64_t)gridDim.x * QSMC_BLOCK) {
-        double p[QSMC_MAX_D];
-        bool ok = false;
-        for (int round = 0; round < maxiter && !ok; ++round) {
-            PhiloxStream rng{(uint64_t)i, (epoch << 16) | (uint32_t)round, k0, k1};
-            int64_t c = i;
-            if (round > 0) {                      // centre of another local ancestor (quirk-Q1 behaviour)
-                double u, unused;
-                rng.uniforms(0, u, unused);
-                c = (int64_t)(u * (double)n);
-                if (c >= n) c = n - 1;
-            }
-            double zz[QSMC_MAX_D];
-            for (int q = 0; q < d; q += 2) {
-                double z0, z1;
-                rng.normals(1 + (q >> 1), z0, z1);
-                zz[q] = z0;
-                if (q + 1 < d) zz[q + 1] = z1;
-            }
-            for (int m = 0; m < d; ++m) {
-                double s = 0.0;
-                for (int q = 0; q < d; ++q) s += lw.S[m * d + q] * zz[q];
-                p[m] = (lw.a * anc[m * ld_anc + c] + (1.0 - lw.a) * lw.mean[m]) + s;
-            }
-            ok = !postselect || model_valid(kind, p, min_freq);
-        }
-        for (int m = 0; m < d; ++m) x_out[m * ldx_out + i] = p[m];
-        if (!ok) ++failed;
-    }
-    if (failed) atomicAdd(n_failed, failed);
 }
 
 __global__ __launch_bounds__(QSMC_BLOCK) void k_prior_uniform_philox(
@@ -1542,11 +1521,11 @@ static int read_counter(qsmc_ctx *h, int64_t *out, hipStream_t s) {
     return QSMC_OK;
 }
 
-int qsmc_lw_resample_philox(qsmc_handle_t h, const qsmc_model_t *model, int32_t postselect,
-                            const double *x_in, int64_t ldx_in, int64_t n_in, int32_t d, const double *cdf,
-                            double a, const double *mean, const double *S, int64_t n_out, uint64_t seed,
-                            uint64_t epoch, int32_t maxiter, double *x_out, int64_t ldx_out,
-                            int64_t *n_failed_host, qsmc_stream_t stream) {
+static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int32_t postselect,
+                                const double *x_in, int64_t ldx_in, int64_t n_in, int32_t d, const double *cdf,
+                                double a, const double *mean, const double *S, int64_t n_out, uint64_t seed,
+                                uint64_t epoch, int32_t maxiter, double *x_out, const OutPlace &pl,
+                                int64_t *n_failed_host, qsmc_stream_t stream) {
     if (!h || !model || !x_in || !cdf || !mean || !S || !x_out || n_in <= 0 || n_out <= 0) return QSMC_ERR_INVALID;
     if (d != model->d || d < 1 || d > QSMC_MAX_D || maxiter < 1) return QSMC_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
@@ -1561,7 +1540,7 @@ int qsmc_lw_resample_philox(qsmc_handle_t h, const qsmc_model_t *model, int32_t 
     if (!bucketed) {
         hipLaunchKernelGGL(k_resample_philox, dim3(grid_for(n_out, QSMC_BLOCK)), dim3(QSMC_BLOCK), 0, s,
                            model->kind, d, model->min_freq, postselect, x_in, ldx_in, n_in, cdf, lw, n_out, k0,
-                           k1, ep, maxiter, x_out, ldx_out, reinterpret_cast<unsigned long long *>(h->counter));
+                           k1, ep, maxiter, x_out, pl, reinterpret_cast<unsigned long long *>(h->counter));
     } else {
         const int chunks = (int)chunks64;
         // integer scratch: hist[256][chunks] u32 | counts[chunks] u32 | slot_off[chunks+1] i64 | item_off[chunks+1] i32
@@ -1594,7 +1573,7 @@ int qsmc_lw_resample_philox(qsmc_handle_t h, const qsmc_model_t *model, int32_t 
 #define LAUNCH_B(DD, SX, BT)                                                                               \
     hipLaunchKernelGGL((k_bucket_sample<DD, SX, BT>), dim3(max_items), dim3(BT), 0, s,                          \
                        model->kind, d, model->min_freq, postselect, x_in, ldx_in, n_in, cdf, chunks, slot_off,   \
-                       item_off, item_chunk, lw, k0, k1, ep, maxiter, x_out, ldx_out, nf)
+                       item_off, item_chunk, lw, k0, k1, ep, maxiter, x_out, pl, nf)
         switch (d) {
             // 512-thread workgroups, CDF chunk + guide in LDS (49 KB -> 3 resident workgroups per CU, so
             // one workgroup's staging/guide-build phases overlap another's sampling loop); x is gathered
@@ -1617,43 +1596,61 @@ int qsmc_lw_resample_philox(qsmc_handle_t h, const qsmc_model_t *model, int32_t 
     return QSMC_OK;
 }
 
+int qsmc_lw_resample_philox(qsmc_handle_t h, const qsmc_model_t *model, int32_t postselect,
+                            const double *x_in, int64_t ldx_in, int64_t n_in, int32_t d, const double *cdf,
+                            double a, const double *mean, const double *S, int64_t n_out, uint64_t seed,
+                            uint64_t epoch, int32_t maxiter, double *x_out, int64_t ldx_out,
+                            int64_t *n_failed_host, qsmc_stream_t stream) {
+    OutPlace pl;
+    memset(&pl, 0, sizeof(pl));
+    pl.ld_m = ldx_out;
+    pl.ld_s = 1;
+    return resample_philox_impl(h, model, postselect, x_in, ldx_in, n_in, d, cdf, a, mean, S, n_out, seed, epoch,
+                                maxiter, x_out, pl, n_failed_host, stream);
+}
+
+int qsmc_lw_resample_philox_sharded(qsmc_handle_t h, const qsmc_model_t *model, int32_t postselect,
+                                    const double *x_in, int64_t ldx_in, int64_t n_in, int32_t d,
+                                    const double *cdf, double a, const double *mean, const double *S,
+                                    const int64_t *dest_counts, int32_t n_dest, uint64_t seed, uint64_t epoch,
+                                    int32_t maxiter, double *rows_out, int64_t *n_failed_host,
+                                    qsmc_stream_t stream) {
+    if (!dest_counts || n_dest < 1 || n_dest > QSMC_MAX_DEST) return QSMC_ERR_INVALID;
+    OutPlace pl;
+    memset(&pl, 0, sizeof(pl));
+    pl.n_dest = n_dest;
+    pl.ld_m = 1;                 // AoS rows [n_out][d], grouped by destination rank
+    pl.ld_s = d;
+    int64_t n_out = 0;
+    for (int r = 0; r < n_dest; ++r) {
+        if (dest_counts[r] < 0) return QSMC_ERR_INVALID;
+        pl.dest_base[r] = n_out;
+        n_out += dest_counts[r];
+        pl.order[r] = r;
+    }
+    for (int i = 1; i < n_dest; ++i)                       // insertion sort by quota (stable)
+        for (int j = i; j > 0 && dest_counts[pl.order[j - 1]] > dest_counts[pl.order[j]]; --j) {
+            const int t = pl.order[j];
+            pl.order[j] = pl.order[j - 1];
+            pl.order[j - 1] = t;
+        }
+    int64_t start = 0, prev = 0;
+    for (int sidx = 0; sidx < n_dest; ++sidx) {
+        pl.quota[sidx] = dest_counts[pl.order[sidx]];
+        pl.seg_start[sidx] = start;
+        start += (pl.quota[sidx] - prev) * (int64_t)(n_dest - sidx);
+        prev = pl.quota[sidx];
+    }
+    pl.seg_start[n_dest] = start;
+    if (n_out == 0) return QSMC_OK;
+    return resample_philox_impl(h, model, postselect, x_in, ldx_in, n_in, d, cdf, a, mean, S, n_out, seed, epoch,
+                                maxiter, rows_out, pl, n_failed_host, stream);
+}
+
 int qsmc_last_resample_failed(qsmc_handle_t h, int64_t *n_failed_out, int32_t synchronize, qsmc_stream_t stream) {
     if (!h || !n_failed_out) return QSMC_ERR_INVALID;
     if (synchronize) HIP_TRY(h, hipStreamSynchronize((hipStream_t)stream));
     *n_failed_out = (int64_t)h->mapped[REDUCE_OUT_MAX - 1];
-    return QSMC_OK;
-}
-
-int qsmc_lw_draw_gather_philox(qsmc_handle_t h, const double *x_in, int64_t ldx_in, int64_t n_in, int32_t d,
-                               const double *cdf, int64_t n_draw, uint64_t seed, uint64_t epoch,
-                               double *anc_out, int64_t ld_anc, qsmc_stream_t stream) {
-    if (!h || !x_in || !cdf || !anc_out || n_in <= 0 || n_draw < 0 || d < 1 || d > QSMC_MAX_D)
-        return QSMC_ERR_INVALID;
-    if (n_draw == 0) return QSMC_OK;
-    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32) ^ (uint32_t)(epoch >> 16);
-    hipLaunchKernelGGL(k_draw_gather_philox, dim3(grid_for(n_draw, QSMC_BLOCK)), dim3(QSMC_BLOCK), 0,
-                       (hipStream_t)stream, x_in, ldx_in, n_in, d, cdf, n_draw, k0, k1,
-                       (uint32_t)(epoch & 0xFFFFu), anc_out, ld_anc);
-    HIP_TRY(h, hipGetLastError());
-    return QSMC_OK;
-}
-
-int qsmc_lw_perturb_philox(qsmc_handle_t h, const qsmc_model_t *model, int32_t postselect, const double *anc,
-                           int64_t ld_anc, int64_t n, int32_t d, double a, const double *mean, const double *S,
-                           uint64_t seed, uint64_t epoch, int32_t maxiter, double *x_out, int64_t ldx_out,
-                           int64_t *n_failed_host, qsmc_stream_t stream) {
-    if (!h || !model || !anc || !mean || !S || !x_out || n <= 0) return QSMC_ERR_INVALID;
-    if (d != model->d || d < 1 || d > QSMC_MAX_D || maxiter < 1) return QSMC_ERR_INVALID;
-    hipStream_t s = (hipStream_t)stream;
-    LWArgs lw;
-    fill_lw(&lw, d, a, mean, S);
-    HIP_TRY(h, hipMemsetAsync(h->counter, 0, sizeof(long long), s));
-    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32) ^ (uint32_t)(epoch >> 16);
-    hipLaunchKernelGGL(k_perturb_philox, dim3(grid_for(n, QSMC_BLOCK)), dim3(QSMC_BLOCK), 0, s, model->kind, d,
-                       model->min_freq, postselect, anc, ld_anc, n, lw, k0, k1, (uint32_t)(epoch & 0xFFFFu),
-                       maxiter, x_out, ldx_out, reinterpret_cast<unsigned long long *>(h->counter));
-    HIP_TRY(h, hipGetLastError());
-    if (n_failed_host) return read_counter(h, n_failed_host, s);
     return QSMC_OK;
 }
 

@@ -46,7 +46,7 @@ class Engine:
         h = C.c_void_p()
         _native.check(None, self.lib.qsmc_create(C.byref(h), index), "qsmc_create")
         self.h = h
-        self._stats = torch.empty(4, dtype=torch.float64, device=self.device)
+        self._stats = torch.empty(4 + 4 + 10, dtype=torch.float64, device=self.device)   # stats + moments (d <= 4)
 
     # ------------------------------------------------------------------ memory / streams
     def stream(self):
@@ -243,28 +243,23 @@ class Engine:
                   "qsmc_last_resample_failed")
         return out.value
 
-    def lw_draw_gather_philox(self, x_in, cdf, n_draw, seed, epoch):
+    def lw_resample_philox_sharded(self, desc, postselect, x_in, cdf, a, mean, S, dest_counts, seed, epoch,
+                                   maxiter, sync=True):
+        """Finished particles for every destination rank: AoS rows (sum(dest_counts), d), grouped by rank."""
         d = x_in.shape[0]
-        anc = self.empty(d, n_draw)
-        if n_draw:
-            self._chk(self.lib.qsmc_lw_draw_gather_philox(
-                self.h, self._p(x_in), x_in.stride(0), x_in.shape[1], d, self._p(cdf), n_draw,
-                C.c_uint64(seed & (2 ** 64 - 1)), C.c_uint64(epoch), self._p(anc), anc.stride(0),
-                self.stream()), "qsmc_lw_draw_gather_philox")
-        return anc
-
-    def lw_perturb_philox(self, desc, postselect, anc, a, mean, S, seed, epoch, maxiter):
-        d, n = anc.shape
-        x_out = self.empty(d, n)
+        counts = np.ascontiguousarray(dest_counts, dtype=np.int64)
+        n_out = int(counts.sum())
+        rows = self.empty(n_out, d)
         mean = np.ascontiguousarray(mean, dtype=np.float64)
         S = np.ascontiguousarray(S, dtype=np.float64)
         failed = C.c_int64()
-        self._chk(self.lib.qsmc_lw_perturb_philox(
-            self.h, C.byref(desc), int(bool(postselect)), self._p(anc), anc.stride(0), n, d, float(a),
-            _native.f64_ptr(mean), _native.f64_ptr(S), C.c_uint64(seed & (2 ** 64 - 1)), C.c_uint64(epoch),
-            int(maxiter), self._p(x_out), x_out.stride(0), C.byref(failed), self.stream()),
-            "qsmc_lw_perturb_philox")
-        return x_out, failed.value
+        self._chk(self.lib.qsmc_lw_resample_philox_sharded(
+            self.h, C.byref(desc), int(bool(postselect)), self._p(x_in), x_in.stride(0), x_in.shape[1], d,
+            self._p(cdf), float(a), _native.f64_ptr(mean), _native.f64_ptr(S),
+            counts.ctypes.data_as(C.POINTER(C.c_int64)), len(counts), C.c_uint64(seed & (2 ** 64 - 1)),
+            C.c_uint64(epoch), int(maxiter), self._p(rows), C.byref(failed) if sync else None, self.stream()),
+            "qsmc_lw_resample_philox_sharded")
+        return rows, (failed.value if sync else None)
 
     def prior_uniform_philox(self, desc, postselect, lo, hi, n, seed, epoch, maxiter=100):
         d = len(lo)

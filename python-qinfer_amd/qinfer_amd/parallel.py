@@ -16,9 +16,11 @@ weights and the resampler on the client.  Here every rank OWNS a contiguous bloc
 Exact global multinomial resampling without a global CDF: ancestors for destination rank r come
 from source rank h with probability W_h / W, so the G x G count matrix C[r, h] ~ Multinomial(N/G;
 W/W_tot) is drawn IDENTICALLY on every rank from a shared-seed host generator; rank h then draws
-C[., h] ancestors from its LOCAL CDF (conditionally i.i.d. -- exact), and the rows travel by one
-`all_to_all_single`.  The Liu-West kick and postselection are local.  xGMI is point-to-point, so
-the all-to-all is a direct exchange (worst case 7/8 of the rows leave the rank), not a ring.
+C[., h] ancestors from its LOCAL CDF (conditionally i.i.d. -- exact) with the same LDS-bucketed
+sampler the single-GPU path uses, applies the Liu-West kick and postselection there (they need only
+the ancestor and the global mean/covariance), and the finished rows travel by one
+`all_to_all_single`.  xGMI is point-to-point, so the all-to-all is a direct exchange (worst case 7/8
+of the rows leave the rank), not a ring.
 
 The collectives take whatever tensors they are given (CUDA under nccl, CPU under gloo), so the
 protocol is testable on CPU with world_size 2 (tests/test_parallel_gloo.py).
@@ -57,19 +59,22 @@ class ParticleShardGroup:
         return out.cpu().numpy().reshape(self.world_size, v.shape[0])
 
     def combine_update_stats(self, stats):
-        """stats: tensor [sum, sumsq, min, n_bad] of this shard -> global (sum, sumsq, min, n_bad)."""
+        """stats: tensor [sum, sumsq, min, n_bad, extra...] of this shard -> global
+        (sum, sumsq, min, n_bad).  Extra entries (e.g. the fused moment sums) are summed too and kept,
+        with the per-rank weight sums, in `last_extra` / `last_shard_sums`: ONE collective per datum
+        serves the normaliser, n_ess, the guards, est_mean/est_covariance and the next resample plan."""
         rows = self.gather_rows(stats)
-        tot = np.zeros(2)
-        bad = 0.0
+        tot = np.zeros(rows.shape[1])
         for r in range(self.world_size):            # fixed order: identical on every rank
-            tot[0] += rows[r, 0]
-            tot[1] += rows[r, 1]
-            bad += rows[r, 3]
-        return float(tot[0]), float(tot[1]), float(rows[:, 2].min()), float(bad)
+            tot += rows[r]
+        self.last_shard_sums = rows[:, 0].copy()
+        self.last_extra = tot[4:].copy()
+        return float(tot[0]), float(tot[1]), float(rows[:, 2].min()), float(tot[3])
 
-    def allreduce_update_stats(self, eng, s, ss, mn, n_bad):
+    def allreduce_update_stats(self, eng, s, ss, mn, n_bad, extra=None):
         t = self.torch
-        return self.combine_update_stats(t.tensor([s, ss, mn, n_bad], dtype=t.float64))
+        vec = [s, ss, mn, n_bad] + ([] if extra is None else [float(v) for v in extra])
+        return self.combine_update_stats(t.tensor(vec, dtype=t.float64))
 
     def allreduce_scalar(self, eng, value):
         t = self.torch
@@ -132,7 +137,7 @@ class ParticleShardGroup:
         mean = updater.est_mean()                                   # global (all-reduced) moments
         cov = updater.est_covariance_mtx()
         a, h = resampler.a, resampler.h
-        if np.linalg.norm(cov, 'fro') == 0:
+        if not cov.any():
             warnings.warn("Covariance has zero norm; adding in small covariance in resampler. "
                           "Consider increasing n_particles to improve covariance estimates.", ResamplerWarning)
             cov = resampler._zero_cov_comp * np.eye(d)
@@ -140,18 +145,24 @@ class ParticleShardGroup:
         if not np.isfinite(S_err):
             raise ResamplerError("Infinite error in computing the square root of the covariance "
                                  "matrix. Check that n_ess is not too small.")
-        # shard weight totals (unnormalised sums are fine: only ratios matter)
-        st = eng.weight_stats(updater._weights(), 1.0)
-        W = self.gather_rows(self.torch.tensor([st.sum], dtype=self.torch.float64))[:, 0]
+        # shard weight totals (unnormalised sums are fine: only ratios matter); normally known from the
+        # last update's all-gather, so the resample needs no collective besides the all-to-all
+        W = getattr(updater, "_shard_sums", None)
+        if W is None:
+            st = eng.weight_stats(updater._weights(), 1.0)
+            W = self.gather_rows(self.torch.tensor([st.sum], dtype=self.torch.float64))[:, 0]
         counts = self.plan_counts(W, n_local, epoch)
-        n_draw = int(counts[:, self.rank].sum())
-        cdf = eng.cumsum(updater._weights(), st.sum)                 # local CDF, normalised locally
+        cdf = eng.cumsum(updater._weights(), float(W[self.rank]))    # local CDF, normalised locally
         seed_r = resampler._seed + 0x9E3779B97F4A7C15 * (self.rank + 1)
-        anc = eng.lw_draw_gather_philox(updater._x, cdf, n_draw, seed_r, epoch)      # (d, T_h)
-        recv = self.exchange_rows(anc.t().contiguous(), counts)                      # (n_local, d)
-        anc_local = recv.to(eng.device).t().contiguous()
-        x_new, n_failed = eng.lw_perturb_philox(model._native_desc(), resampler._postselect, anc_local, a,
-                                                mean, S, seed_r ^ 0xA5A5A5A5, epoch, resampler._maxiter)
+        # this shard draws, kicks and postselects the particles every destination takes from it
+        defer = hasattr(resampler, "_flush_failed_warning")       # stay asynchronous; warn at the next sync
+        rows, n_failed = eng.lw_resample_philox_sharded(model._native_desc(), resampler._postselect, updater._x,
+                                                        cdf, a, mean, S, counts[:, self.rank], seed_r, epoch,
+                                                        resampler._maxiter, sync=not defer)
+        if defer:
+            resampler._pending_failed = eng
+        recv = self.exchange_rows(rows, counts)                      # (n_local, d), the only bandwidth step
+        x_new = recv.to(eng.device).t().contiguous()                 # back to SoA
         if n_failed:
             warnings.warn("Liu-West resampling failed to find valid models for {} particles within {} "
                           "iterations.".format(n_failed, resampler._maxiter), ResamplerWarning)

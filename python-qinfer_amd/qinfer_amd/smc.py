@@ -123,11 +123,13 @@ class SMCUpdater(ParticleDistribution):
         return n if self._comm is None else n * self._comm.world_size
 
     # ------------------------------------------------------------------ sharding hooks
-    def _reduce_stats(self, st):
-        """Combine per-shard update sums across ranks (one all-gather of 4 doubles per rank)."""
+    def _reduce_stats(self, st, extra=None):
+        """Combine per-shard update sums across ranks (one all-gather per datum; see parallel.py)."""
         if self._comm is None:
             return st.sum, st.sumsq, st.min, st.n_bad
-        return self._comm.allreduce_update_stats(self._eng, st.sum, st.sumsq, st.min, st.n_bad)
+        out = self._comm.allreduce_update_stats(self._eng, st.sum, st.sumsq, st.min, st.n_bad, extra)
+        self._shard_sums = self._comm.last_shard_sums
+        return out
 
     def _moments(self):
         if self._moments_cache is None:
@@ -164,6 +166,7 @@ class SMCUpdater(ParticleDistribution):
             self._w_alt = None
             self._norm = float(n_total)
             self._sumsq = float(n_particles) if self._comm is None else float(n_total)
+            self._shard_sums = None if self._comm is None else np.full(self._comm.world_size, float(n_particles))
         x_new = None
         if self._device_rng and hasattr(self.prior, "sample_device"):
             try:
@@ -251,7 +254,19 @@ class SMCUpdater(ParticleDistribution):
             exps = self.model._native_expparams(expparams)
             if len(exps) != 1:
                 raise ValueError("update() takes exactly one experiment")
-            if self._comm is None and self._x.shape[0] <= 4:
+            d = self._x.shape[0]
+            if self._comm is not None:
+                # sharded: leave the sums on the device and all-gather them (one collective, one sync)
+                eng.update_fused(self._desc, self._x, self._w, w_out, self._norm, exps[0],
+                                 _as_int_outcome(outcome), sync=False)
+                n_mom = d + d * (d + 1) // 2 if d <= 4 else 0
+                norm, sumsq, wmin, n_bad = self._comm.combine_update_stats(eng._stats[:4 + n_mom])
+                self._shard_sums = self._comm.last_shard_sums
+                if n_mom:
+                    g = self._comm.last_extra
+                    fused_moments = (g[:d].copy(), eng._unpack_upper(g[d:], d))
+                st = None
+            elif d <= 4:
                 # the kernel also returns sum w'x, sum w'xx^T of the new weights (x is in registers
                 # anyway): est_mean / est_covariance_mtx / the resampler need no further pass
                 st, m1, m2 = eng.update_fused(self._desc, self._x, self._w, w_out, self._norm, exps[0],
@@ -265,7 +280,8 @@ class SMCUpdater(ParticleDistribution):
             if L.shape[0] != 1 or L.shape[1] != 1:
                 raise ValueError("update() takes exactly one outcome and one experiment")
             st = eng.update_from_likelihood(L.reshape(-1), self._weights(), w_out, self._norm)
-        norm, sumsq, wmin, n_bad = self._reduce_stats(st)
+        if st is not None:
+            norm, sumsq, wmin, n_bad = self._reduce_stats(st)
         flush = getattr(self.resampler, "_flush_failed_warning", None)
         if flush is not None:
             flush()                       # the stream was just synchronised: deferred resampler warning
@@ -373,6 +389,8 @@ class SMCUpdater(ParticleDistribution):
                 self.resampler._flush_failed_warning(synchronize=True)
         if isinstance(new, ParticleDistribution):
             self._x, self._w, self._norm, self._sumsq = new._x, new._w, new._norm, new._sumsq
+            if self._comm is not None:
+                self._shard_sums = np.full(self._comm.world_size, float(self.n_particles))
         else:                                           # foreign resampler returning host arrays
             self._set_host(new.particle_locations, new.particle_weights)
         self._w_alt = None
