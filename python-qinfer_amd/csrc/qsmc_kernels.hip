@@ -1583,7 +1583,8 @@ static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int3
             case 2: LAUNCH_B(2, false, 512); break;
             case 3: LAUNCH_B(3, false, 512); break;
             case 4: LAUNCH_B(4, false, 512); break;
-            default: LAUNCH_B(0, false, QSMC_BLOCK); break;   // d up to 16: 512-VGPR budget
+            case 16: LAUNCH_B(16, false, QSMC_BLOCK); break;  // 2-qubit tomography: all indices static
+            default: LAUNCH_B(0, false, QSMC_BLOCK); break;   // other d up to 16: runtime-d kernel
         }
 #undef LAUNCH_B
     }
