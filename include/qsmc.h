@@ -122,6 +122,19 @@ int qsmc_update_fused(qsmc_handle_t h, const qsmc_model_t *model,
                       double *stats_dev, qsmc_update_stats_t *stats_host, double *moments_host,
                       qsmc_stream_t stream);
 
+/* batch_update fast path (smc.py:459-487): k <= 8 data applied in ONE pass over the cloud,
+ * w_out[i] = (w_in[i] / prev_norm) * prod_j Pr(outcomes[j] | x_i ; exps[j]).
+ * stats_host[j] holds the cumulative sums after datum j: sum = S_j, sumsq = Q_j, n_bad = #{!(w >= 0)}
+ * at that datum (min is the minimum over the whole window), from which the caller forms
+ * normalization_record[j] = S_j / S_{j-1} and n_ess_j = S_j^2 / Q_j exactly as the per-datum loop
+ * would.  moments_host as in qsmc_update_fused (of the final weights).  Synchronises.  w_out must
+ * not alias w_in if the caller wants to be able to discard the window (guards tripped). */
+int qsmc_update_multi(qsmc_handle_t h, const qsmc_model_t *model,
+                      const double *x, int64_t ldx, int64_t n,
+                      const double *w_in, double *w_out, double prev_norm,
+                      const qsmc_expparam_t *exps, const int64_t *outcomes, int32_t k,
+                      qsmc_update_stats_t *stats_host, double *moments_host, qsmc_stream_t stream);
+
 /* Same update for a model without a native kernel: L[i] was produced by the user's
  * Model.likelihood on the host and uploaded (plugin slow path). */
 int qsmc_update_from_likelihood(qsmc_handle_t h, const double *L, int64_t n,

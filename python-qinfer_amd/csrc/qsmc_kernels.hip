@@ -273,6 +273,63 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_update_fused(
     block_publish<UpdAcc<DMOM>::NS>(acc.s, acc.mn, ro);
 }
 
+// ---------------------------------------------------------------------------------------------
+// K data in ONE pass (batch_update between two ESS checks, smc.py:459-487): the reference
+// renormalises after every datum, but the normaliser is a scalar, so
+//     w_K = w_0 * prod_k L_k / S_K,   S_k = sum_i w_0,i prod_{j<=k} L_j,i,
+// normalization_record[k] = S_k / S_{k-1} and n_ess after datum k = S_k^2 / Q_k (Q_k the sum of
+// squares).  The cloud crosses HBM once per K data instead of K times; per datum the kernel keeps
+// [S_k, Q_k, #bad_k] so the host can replay every guard / record of the reference.
+// ---------------------------------------------------------------------------------------------
+constexpr int MULTI_KMAX = 8;
+struct MultiArgs {
+    int k;
+    ExpArgs e[MULTI_KMAX];
+    int64_t outcome[MULTI_KMAX];
+};
+
+template <int KIND>
+__global__ __launch_bounds__(QSMC_BLOCK) void k_update_multi(
+    const double *__restrict__ x, int64_t ldx, int64_t n, const double *__restrict__ w_in,
+    double *__restrict__ w_out, double prev_norm, MultiArgs ma, ReduceOut ro) {
+    constexpr int D = Model<KIND>::D;
+    constexpr int DMOM = D <= 4 ? D : 0;
+    constexpr int NS = 3 * MULTI_KMAX + DMOM + DMOM * (DMOM + 1) / 2;
+    const int d = (KIND == QSMC_MODEL_TOMOGRAPHY) ? ma.e[0].d : D;
+    double s[NS];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) s[q] = 0.0;
+    double mn = INFINITY;
+    for (int64_t i = (int64_t)blockIdx.x * QSMC_BLOCK + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * QSMC_BLOCK) {
+        double p[D];
+#pragma unroll
+        for (int m = 0; m < D; ++m)
+            if (m < d) p[m] = x[m * ldx + i];
+        double w = (w_in ? w_in[i] : 1.0) / prev_norm;
+#pragma unroll
+        for (int k = 0; k < MULTI_KMAX; ++k) {
+            if (k < ma.k) {
+                w = w * Model<KIND>::lik(p, ma.e[k], ma.outcome[k]);
+                s[3 * k] += w;
+                s[3 * k + 1] += w * w;
+                s[3 * k + 2] += (w >= 0.0) ? 0.0 : 1.0;
+                mn = fmin(mn, w);
+            }
+        }
+        w_out[i] = w;
+        int q = 3 * MULTI_KMAX + DMOM;
+#pragma unroll
+        for (int m = 0; m < DMOM; ++m) {
+            const double wx = w * p[m];
+            s[3 * MULTI_KMAX + m] += wx;
+#pragma unroll
+            for (int m2 = m; m2 < DMOM; ++m2) s[q++] += wx * p[m2];
+        }
+    }
+    block_publish<NS>(s, mn, ro);
+}
+
 // mode 0: w_out = (w_in / norm) * L   (generic-model slow path)
 // mode 1: w_out = clip(w_in / norm, 0, 1)   (negative-weight guard)
 // mode 2: w_out = w_in / norm               (materialise; stats still produced)
@@ -500,6 +557,49 @@ __global__ __launch_bounds__(SCAN_SUMS_THREADS) void k_scan_sums(double *__restr
         double gmax = 0.0;
         for (int wv = 0; wv < SCAN_SUMS_THREADS / QSMC_WAVE; ++wv) gmax = fmax(gmax, wtot[wv]);
         sums[m] = fmax(total, gmax);
+    }
+}
+
+// Fallback for m > 16384 chunk sums (N > 6.7e7): same contract, 256-wide slabs with a carry.
+__global__ __launch_bounds__(QSMC_BLOCK) void k_scan_sums_big(double *__restrict__ sums, int64_t m) {
+    __shared__ double wave_tot[QSMC_WAVES_PER_BLOCK];
+    __shared__ double carry_s;
+    const int lane = threadIdx.x & (QSMC_WAVE - 1);
+    const int wave = threadIdx.x / QSMC_WAVE;
+    if (threadIdx.x == 0) carry_s = 0.0;
+    __syncthreads();
+    for (int64_t base = 0; base < m; base += QSMC_BLOCK) {
+        const int64_t i = base + threadIdx.x;
+        const double v = i < m ? sums[i] : 0.0;
+        const double inc = wave_inclusive_scan(v, lane);
+        double excl = __shfl_up(inc, 1, QSMC_WAVE);
+        if (lane == 0) excl = 0.0;
+        if (lane == QSMC_WAVE - 1) wave_tot[wave] = inc;
+        __syncthreads();
+        double off = carry_s;
+        for (int wv = 0; wv < wave; ++wv) off += wave_tot[wv];
+        if (i < m) sums[i] = off + excl;
+        __syncthreads();
+        if (threadIdx.x == QSMC_BLOCK - 1) carry_s = off + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) sums[m] = carry_s;
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s = 0.0;
+    __syncthreads();
+    for (int64_t base = 0; base <= m; base += QSMC_BLOCK) {      // exact prefix max over sums[0..m]
+        const int64_t i = base + threadIdx.x;
+        const double v = i <= m ? sums[i] : 0.0;
+        const double mx = wave_inclusive_max(v, lane);
+        if (lane == QSMC_WAVE - 1) wave_tot[wave] = mx;
+        __syncthreads();
+        double run = carry_s;
+        for (int wv = 0; wv < wave; ++wv) run = fmax(run, wave_tot[wv]);
+        const double out = fmax(mx, run);
+        if (i <= m) sums[i] = out;
+        __syncthreads();
+        if (threadIdx.x == QSMC_BLOCK - 1) carry_s = out;
+        __syncthreads();
     }
 }
 
@@ -1139,7 +1239,7 @@ static int launch_reduce(qsmc_ctx *h, int ns, int grid, const ReduceOut &ro, hip
     case N:                                                                                     \
         hipLaunchKernelGGL((k_reduce_partials<N>), dim3(1), dim3(QSMC_BLOCK), 0, s, grid, ro);  \
         break;
-        LR(3) LR(5) LR(6) LR(8) LR(10) LR(12) LR(15) LR(17)
+        LR(3) LR(5) LR(6) LR(8) LR(10) LR(12) LR(15) LR(17) LR(24) LR(26) LR(29) LR(33) LR(38)
 #undef LR
         default: return QSMC_ERR_INVALID;
     }
@@ -1348,6 +1448,58 @@ int qsmc_update_fused(qsmc_handle_t h, const qsmc_model_t *model, const double *
     return collect_stats(h, ns, stats_host, moments_host, n_mom, s);
 }
 
+int qsmc_update_multi(qsmc_handle_t h, const qsmc_model_t *model, const double *x, int64_t ldx, int64_t n,
+                      const double *w_in, double *w_out, double prev_norm, const qsmc_expparam_t *exps,
+                      const int64_t *outcomes, int32_t k, qsmc_update_stats_t *stats_host, double *moments_host,
+                      qsmc_stream_t stream) {
+    if (!h || !x || !w_out || !exps || !outcomes || !stats_host || n <= 0 || k < 1 || k > MULTI_KMAX)
+        return QSMC_ERR_INVALID;
+    int rc = check_model(model);
+    if (rc) return rc;
+    const int d = model->d;
+    const int dmom = d <= 4 ? d : 0;
+    if (moments_host && !dmom) return QSMC_ERR_UNSUPPORTED;
+    const int n_mom = dmom + dmom * (dmom + 1) / 2;
+    const int ns = 3 * MULTI_KMAX + n_mom;
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = grid_for(n, QSMC_BLOCK * 4);
+    rc = ensure_partials(h, (size_t)grid * (ns + 1));
+    if (rc) return rc;
+    MultiArgs ma;
+    memset(&ma, 0, sizeof(ma));
+    ma.k = k;
+    for (int j = 0; j < k; ++j) {
+        make_exp_args(model, &exps[j], outcomes[j], &ma.e[j]);
+        ma.outcome[j] = outcomes[j];
+    }
+    const ReduceOut ro = make_reduce(h, true, nullptr);
+    switch (model->kind) {
+#define LAUNCH_MU(K)                                                                                   \
+    case K:                                                                                            \
+        hipLaunchKernelGGL((k_update_multi<K>), dim3(grid), dim3(QSMC_BLOCK), 0, s, x, ldx, n, w_in, w_out, \
+                           prev_norm, ma, ro);                                                         \
+        break;
+        LAUNCH_MU(QSMC_MODEL_PRECESSION)
+        LAUNCH_MU(QSMC_MODEL_BINOMIAL_PRECESSION)
+        LAUNCH_MU(QSMC_MODEL_RB)
+        LAUNCH_MU(QSMC_MODEL_RB_INTERLEAVED)
+        LAUNCH_MU(QSMC_MODEL_TOMOGRAPHY)
+#undef LAUNCH_MU
+    }
+    HIP_TRY(h, hipGetLastError());
+    rc = launch_reduce(h, ns, grid, ro, s);
+    if (rc) return rc;
+    HIP_TRY(h, hipStreamSynchronize(s));
+    for (int j = 0; j < k; ++j) {
+        stats_host[j].sum = h->mapped[3 * j];
+        stats_host[j].sumsq = h->mapped[3 * j + 1];
+        stats_host[j].n_bad = h->mapped[3 * j + 2];
+        stats_host[j].min = h->mapped[ns];
+    }
+    if (moments_host) memcpy(moments_host, h->mapped + 3 * MULTI_KMAX, (size_t)n_mom * sizeof(double));
+    return QSMC_OK;
+}
+
 int qsmc_update_from_likelihood(qsmc_handle_t h, const double *L, int64_t n, const double *w_in,
                                 double *w_out, double prev_norm, double *stats_dev,
                                 qsmc_update_stats_t *stats_host, qsmc_stream_t stream) {
@@ -1456,8 +1608,10 @@ int qsmc_cumsum(qsmc_handle_t h, const double *w, int64_t n, double norm, double
     int rc = ensure_partials(h, (size_t)chunks + 1);
     if (rc) return rc;
     hipLaunchKernelGGL(k_chunk_sums, dim3((unsigned)chunks), dim3(QSMC_BLOCK), 0, s, w, n, norm, h->partials);
-    if (chunks > (int64_t)SCAN_SUMS_THREADS * SCAN_SUMS_MAX_PER) return QSMC_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_SUMS_THREADS), 0, s, h->partials, chunks);
+    if (chunks > (int64_t)SCAN_SUMS_THREADS * SCAN_SUMS_MAX_PER)
+        hipLaunchKernelGGL(k_scan_sums_big, dim3(1), dim3(QSMC_BLOCK), 0, s, h->partials, chunks);
+    else
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_SUMS_THREADS), 0, s, h->partials, chunks);
     hipLaunchKernelGGL(k_chunk_scan, dim3((unsigned)chunks), dim3(QSMC_BLOCK), 0, s, w, n, norm, h->partials,
                        cdf);
     HIP_TRY(h, hipGetLastError());

@@ -139,6 +139,25 @@ class Engine:
             return st
         return st, mom[:d].copy(), self._unpack_upper(mom[d:], d)
 
+    MULTI_KMAX = 8
+
+    def update_multi(self, desc, x, w_in, w_out, prev_norm, exps, outcomes):
+        """K <= 8 data in one pass.  Returns (list of UpdateStats per datum, s1, s2) -- s1/s2 are the
+        unnormalised moment sums of the final weights (None for d > 4)."""
+        k = len(exps)
+        d = x.shape[0]
+        ep = (_native.ExpParam * k)(*exps)
+        oc = (C.c_int64 * k)(*[int(o) for o in outcomes])
+        st = (_native.UpdateStats * k)()
+        mom = np.empty(d + d * (d + 1) // 2, dtype=np.float64) if d <= 4 else None
+        self._chk(self.lib.qsmc_update_multi(
+            self.h, C.byref(desc), self._p(x), x.stride(0), x.shape[1],
+            self._p(w_in) if w_in is not None else None, self._p(w_out), float(prev_norm), ep, oc, k, st,
+            _native.f64_ptr(mom) if mom is not None else None, self.stream()), "qsmc_update_multi")
+        if mom is None:
+            return list(st), None, None
+        return list(st), mom[:d].copy(), self._unpack_upper(mom[d:], d)
+
     def update_from_likelihood(self, L, w_in, w_out, prev_norm):
         st = _native.UpdateStats()
         self._chk(self.lib.qsmc_update_from_likelihood(

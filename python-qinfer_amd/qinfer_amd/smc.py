@@ -337,17 +337,79 @@ class SMCUpdater(ParticleDistribution):
             self._maybe_resample()
 
     def batch_update(self, outcomes, expparams, resample_interval=5):
-        """Loop of `update` with the ESS test every `resample_interval` data (smc.py:459-487)."""
+        """Update on a batch of data with the ESS test every `resample_interval` data
+        (smc.py:459-487).
+
+        The reference loops `update(..., check_for_resample=False)`.  Between two ESS tests nothing
+        but a scalar renormalisation separates consecutive data, so for native models the data of
+        one window are applied in ONE pass over the cloud (`qsmc_update_multi`, up to 8 per launch)
+        and every per-datum record (normalization_record, min_n_ess, data_record) is rebuilt from the
+        per-datum sums the kernel returns.  If any guard would have fired inside a window (negative
+        weights, all-zero weights) the window is discarded -- the weights are double-buffered -- and
+        replayed datum by datum, so warnings/exceptions/policies behave exactly as in the loop."""
         outcomes = np.asarray(outcomes)
         n_exps = outcomes.shape[0]
         if expparams.shape[0] != n_exps:
             raise ValueError("The number of outcomes and experiments must match.")
         if len(expparams.shape) == 1:
             expparams = expparams[:, None]
-        for idx, (outcome, experiment) in enumerate(zip(iter(outcomes), iter(expparams))):
-            self.update(outcome, experiment, check_for_resample=False)
-            if (idx + 1) % resample_interval == 0:
+        fast = (self._native and self._comm is None and self._batch_fast_path
+                and type(self.model).update_timestep is not None)
+        idx = 0
+        kmax = self._eng.MULTI_KMAX
+        while idx < n_exps:
+            window_end = min(n_exps, (idx // resample_interval + 1) * resample_interval)
+            stop = min(window_end, idx + kmax)
+            # a single datum is served best by the dedicated one-datum kernel (16 B/lane loads)
+            if not (fast and stop - idx >= 2 and self._fused_window(outcomes[idx:stop], expparams[idx:stop])):
+                for j in range(idx, stop):
+                    self.update(outcomes[j], expparams[j], check_for_resample=False)
+            idx = stop
+            if idx % resample_interval == 0:
                 self._maybe_resample()
+
+    _batch_fast_path = True
+
+    def _fused_window(self, outcomes, expparams):
+        """Apply len(outcomes) <= 8 data in one kernel pass.  Returns False (state untouched) if a
+        guard of the per-datum loop would have fired, so the caller can replay it faithfully."""
+        eng = self._eng
+        k = len(outcomes)
+        exps, outs = [], []
+        for j in range(k):
+            e = self.model._native_expparams(expparams[j])
+            if len(e) != 1:
+                return False
+            exps.append(e[0])
+            outs.append(_as_int_outcome(outcomes[j]))
+        w_out = self._scratch_weights()
+        stats, m1, m2 = eng.update_multi(self._desc, self._x, self._w, w_out, self._norm, exps, outs)
+        flush = getattr(self.resampler, "_flush_failed_warning", None)
+        if flush is not None:
+            flush()
+        prev = None
+        norms = []
+        for st in stats:
+            nk = st.sum if prev is None else (st.sum / prev if prev != 0 else np.nan)
+            if st.n_bad > 0 or not (abs(nk) >= _EPS):      # negative / NaN weights, or the zero-weight test
+                return False
+            norms.append(nk)
+            prev = st.sum
+        # commit the window
+        for j in range(k):
+            self._data_record.append(outcomes[j])
+            self._normalization_record.append(norms[j])
+            ess = np.float64(stats[j].sum) * np.float64(stats[j].sum) / np.float64(stats[j].sumsq)
+            if ess <= self._min_n_ess:
+                self._min_n_ess = ess
+        self._just_resampled = False
+        self._w, self._w_alt = w_out, self._w
+        self._norm = float(stats[-1].sum)
+        self._sumsq = float(stats[-1].sumsq)
+        self._invalidate()
+        if m1 is not None:
+            self._moments_cache = (1.0, m1 / self._norm, m2 / self._norm)
+        return True
 
     # ------------------------------------------------------------------ resampling
     def _maybe_resample(self):

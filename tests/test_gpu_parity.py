@@ -526,6 +526,81 @@ def test_batch_update_api(qi, golden):
         upd.batch_update(np.zeros((3, 1), dtype=int), g["ep_t"][:4])
 
 
+# ================================================================== fused batch_update windows
+@pytest.mark.parametrize("model_name", ["prec", "binomial", "rb"])
+@pytest.mark.parametrize("interval", [1, 3, 5, 11])
+def test_batch_update_fused_vs_loop(qi, model_name, interval):
+    """batch_update's one-pass windows (qsmc_update_multi) == the reference's per-datum loop:
+    same records, same resample decisions, same posterior (oracle = np_oracle batch_update)."""
+    rs = np.random.RandomState(17)
+    n, K = 20000, 46
+    if model_name == "prec":
+        model, omodel = qi.SimplePrecessionModel(), orc.precession_model()
+        x0 = rs.random_sample((n, 1))
+        eps = np.array([(9 / 8) ** k for k in range(K)])
+        oeps = [{"t": eps[k:k + 1]} for k in range(K)]
+        outcomes = (rs.random_sample(K) >= np.cos(0.3 * eps / 2) ** 2).astype(int)
+        cond = lambda k: eps[k]
+    elif model_name == "binomial":
+        model, omodel = qi.BinomialModel(qi.SimplePrecessionModel()), orc.binomial_precession_model()
+        x0 = rs.random_sample((n, 1))
+        eps = np.empty((K,), dtype=model.expparams_dtype)
+        eps["x"], eps["n_meas"] = (9 / 8) ** np.arange(K), 25
+        oeps = [{"t": eps["x"][k:k + 1], "n_meas": eps["n_meas"][k:k + 1]} for k in range(K)]
+        outcomes = rs.binomial(25, np.sin(0.3 * eps["x"] / 2) ** 2)
+        cond = lambda k: 25 * eps["x"][k]
+    else:
+        model, omodel = qi.RandomizedBenchmarkingModel(), orc.rb_model()
+        x0 = np.stack([rs.uniform(0.8, 1, n), rs.uniform(0, 0.5, n), rs.uniform(0, 0.5, n)], 1)
+        eps = np.empty((K,), dtype=model.expparams_dtype)
+        eps["m"] = 1 + 5 * np.arange(K)
+        oeps = [{"m": eps["m"][k:k + 1]} for k in range(K)]
+        outcomes = (rs.random_sample(K) >= 1 - (0.3 * 0.95 ** eps["m"] + 0.5)).astype(int)
+        cond = lambda k: eps["m"][k]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        np.random.seed(4)
+        fused = qi.SMCUpdater(model, n, fixed_prior(qi, x0))
+        fused.batch_update(outcomes, eps, resample_interval=interval)
+        np.random.seed(4)
+        loop = qi.SMCUpdater(model, n, fixed_prior(qi, x0))
+        loop._batch_fast_path = False
+        loop.batch_update(outcomes, eps, resample_interval=interval)
+        np.random.seed(4)
+        ref = orc.OracleSMC(omodel, n, lambda m: x0.copy())
+        ref.batch_update(list(outcomes), oeps, resample_interval=interval)
+    assert fused.resample_count == loop.resample_count == ref.resample_count
+    assert len(fused.normalization_record) == K and fused.data_record == loop.data_record
+    for k in range(K):
+        c = float(cond(k))
+        if not tol.well_conditioned(c):
+            break
+        np.testing.assert_allclose(fused.normalization_record[k], loop.normalization_record[k], rtol=tol.rtol_norm(c))
+        np.testing.assert_allclose(fused.normalization_record[k], np.ravel(ref.normalization_record[k])[0],
+                                   rtol=tol.rtol_norm(c))
+    np.testing.assert_allclose(fused.min_n_ess, loop.min_n_ess, rtol=1e-6)
+    np.testing.assert_allclose(fused.est_mean(), loop.est_mean(), rtol=0, atol=1e-9)
+    np.testing.assert_allclose(fused.est_mean(), ref.est_mean(), rtol=0, atol=1e-9)
+    np.testing.assert_allclose(fused.n_ess, loop.n_ess, rtol=1e-6)
+
+
+def test_batch_update_fused_guard_replay(qi):
+    """A window that contains an impossible datum is discarded and replayed datum by datum:
+    the exception comes from the same datum as in the reference's loop, earlier data are applied."""
+    x0 = np.zeros((64, 1))                                 # omega = 0 -> outcome 1 is impossible
+    upd = qi.SMCUpdater(qi.SimplePrecessionModel(), 64, fixed_prior(qi, x0), resample_thresh=0.0)
+    outcomes = np.array([0, 0, 1, 0, 0])
+    with pytest.raises(RuntimeError, match="All particle weights are zero"):
+        upd.batch_update(outcomes, np.array([1.0, 2.0, 3.0, 4.0, 5.0]), resample_interval=5)
+    assert upd.data_record == [0, 0, 1]                    # smc.py:409 records before the guard fires
+    np.testing.assert_allclose(upd.normalization_record, [1.0, 1.0])
+    skip = qi.SMCUpdater(qi.SimplePrecessionModel(), 64, fixed_prior(qi, x0), resample_thresh=0.0,
+                         zero_weight_policy="skip")
+    skip.batch_update(outcomes, np.array([1.0, 2.0, 3.0, 4.0, 5.0]), resample_interval=5)
+    np.testing.assert_allclose(skip.normalization_record, [1.0, 1.0, 1.0, 1.0])
+    np.testing.assert_allclose(skip.particle_weights, 1 / 64)
+
+
 # ================================================================== every-step teacher forcing
 def test_every_step_from_oracle_state(qi):
     """All 200 data of config C1, one step at a time FROM THE ORACLE'S STATE, so chaotic
@@ -738,6 +813,25 @@ def test_device_rng_end_to_end(qi):
     sd = np.sqrt(ref.est_covariance_mtx()[0, 0])
     assert abs(upd.est_mean()[0] - ref.est_mean()[0]) < 5 * sd / np.sqrt(ref.n_ess) + 0.2 * sd
     assert abs(upd.resample_count - ref.resample_count) <= 3
+
+
+def test_beyond_bucket_limits(qi, eng):
+    """N = 7e7 on one GPU: more chunks than the register scan (16384) and the LDS edge table (8192)
+    hold -> the slab scan and the direct-search resampler take over; invariants must still hold."""
+    n = 70_000_000
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        upd = qi.SMCUpdater(qi.SimplePrecessionModel(), n, qi.UniformDistribution([0.2, 0.8]), device_rng=True, seed=9)
+        upd.update(0, np.array([3.0]), check_for_resample=False)
+        cdf = eng.cumsum(upd._w, upd._norm)
+        assert float(cdf[-1].item()) == pytest.approx(1.0, abs=1e-10)
+        assert bool((cdf[1:] >= cdf[:-1]).all().item())
+        del cdf
+        m1 = upd.est_mean()
+        free = qi.LiuWestResampler(a=0.98, postselect=False, device_rng=True, seed=2)
+        new = free(upd.model, upd)
+        m2, c2 = new.est_mean(), new.est_covariance_mtx()
+    assert abs(m2[0] - m1[0]) < 6 * np.sqrt(c2[0, 0] / n)
 
 
 # ================================================================== full-size properties (1e7)
