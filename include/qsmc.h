@@ -135,6 +135,19 @@ int qsmc_update_multi(qsmc_handle_t h, const qsmc_model_t *model,
                       const qsmc_expparam_t *exps, const int64_t *outcomes, int32_t k,
                       qsmc_update_stats_t *stats_host, double *moments_host, qsmc_stream_t stream);
 
+/* Experiment design (smc.py:553-663 bayes_risk / expected_information_gain): for ONE hypothetical
+ * experiment and n_o outcomes, one pass over the cloud, nothing materialised.  With w~ = w / norm
+ * (w == NULL: all-ones) and c = shift (pass the current mean; removes one-pass cancellation):
+ *   out_host[o][0]         = sum w~ L_o                       hypothetical normalisation N[o]
+ *   out_host[o][1]         = sum w~ L_o log L_o  (0 log 0 := 0)        N KLD = [1] - [0] log [0]
+ *   out_host[o][2 + m]     = sum w~ L_o (x_m - c_m)           (d <= 4 only)
+ *   out_host[o][2 + d + m] = sum w~ L_o (x_m - c_m)^2         N var = sum_m Q_m ([2+d+m] - [2+m]^2 / [0])
+ * Row length is 2 + 2 d for d <= 4, else 2.  Synchronises. */
+int qsmc_hypothetical_sums(qsmc_handle_t h, const qsmc_model_t *model,
+                           const double *x, int64_t ldx, int64_t n, const double *w, double norm,
+                           const qsmc_expparam_t *exp, const int64_t *outcomes, int32_t n_o,
+                           const double *shift, double *out_host, qsmc_stream_t stream);
+
 /* Same update for a model without a native kernel: L[i] was produced by the user's
  * Model.likelihood on the host and uploaded (plugin slow path). */
 int qsmc_update_from_likelihood(qsmc_handle_t h, const double *L, int64_t n,

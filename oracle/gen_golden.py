@@ -367,6 +367,48 @@ def g6_guards():
     print("g6_guards", mins)
 
 
+def g7_design():
+    """bayes_risk / expected_information_gain of the reference on weighted clouds (smc.py:553-663)."""
+    out = {}
+    rs = np.random.RandomState(51)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        # precession, weighted cloud
+        m = qinfer.SimplePrecessionModel()
+        np.random.seed(1)
+        upd = qinfer.SMCUpdater(m, 3000, qinfer.UniformDistribution([0, 1]))
+        for t in (0.7, 1.9, 4.1):
+            upd.update(int(rs.randint(2)), np.array([t]))
+        ts = np.array([0.5, 2.0, 7.5, 31.0])
+        out['prec_x'], out['prec_w'], out['prec_t'] = upd.particle_locations.copy(), upd.particle_weights.copy(), ts
+        out['prec_risk'] = upd.bayes_risk(ts)
+        out['prec_eig'] = upd.expected_information_gain(ts)
+        # binomial (outcome count varies with the experiment)
+        bm = qinfer.BinomialModel(qinfer.SimplePrecessionModel())
+        np.random.seed(2)
+        upd = qinfer.SMCUpdater(bm, 2000, qinfer.UniformDistribution([0, 1]))
+        ep = np.empty((3,), dtype=bm.expparams_dtype)
+        ep['x'], ep['n_meas'] = [1.0, 3.0, 9.0], [25, 7, 12]
+        upd.update(9, ep[0:1])
+        out['bin_x'], out['bin_w'] = upd.particle_locations.copy(), upd.particle_weights.copy()
+        out['bin_t'], out['bin_n'] = ep['x'], ep['n_meas']
+        out['bin_risk'] = upd.bayes_risk(ep)
+        out['bin_eig'] = upd.expected_information_gain(ep)
+        # RB, d = 3
+        rb = qinfer.RandomizedBenchmarkingModel()
+        prior = qinfer.PostselectedDistribution(qinfer.UniformDistribution([[0.8, 1], [0, 1], [0, 1]]), rb)
+        np.random.seed(3)
+        upd = qinfer.SMCUpdater(rb, 2500, prior)
+        ep = np.empty((3,), dtype=rb.expparams_dtype)
+        ep['m'] = [3, 40, 300]
+        upd.update(0, ep[1:2])
+        out['rb_x'], out['rb_w'], out['rb_m'] = upd.particle_locations.copy(), upd.particle_weights.copy(), ep['m']
+        out['rb_risk'] = upd.bayes_risk(ep)
+        out['rb_eig'] = upd.expected_information_gain(ep)
+    np.savez_compressed(os.path.join(OUT, "g7_design.npz"), **out)
+    print("g7_design", out['prec_risk'], out['bin_eig'], out['rb_risk'])
+
+
 if __name__ == "__main__":
     g1_precession()
     g1_binomial()
@@ -377,4 +419,5 @@ if __name__ == "__main__":
     g4_liu_west()
     g5_canonicalize()
     g6_guards()
+    g7_design()
     print("total bytes:", sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT)))

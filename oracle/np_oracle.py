@@ -280,6 +280,34 @@ def sqrtm_psd(A):
     return S, np.linalg.norm(S @ S - A, 'fro')
 
 
+def _hyp_all_outcomes(w, x, lik, outcomes, expparams_list):
+    """smc.py:577-595: hypothetical weights for every outcome, the last one by complement."""
+    L = np.concatenate([lik(outcomes[:-1], x, e) for e in expparams_list], axis=2)     # (n_o-1, N, n_e)
+    w_hyp, N = hypothetical_update(w, L)
+    Lt = np.transpose(L, (0, 2, 1))
+    last = (1 - Lt.sum(axis=0)) * w[np.newaxis, :]
+    N = np.concatenate([N[:, :, 0], np.sum(last[np.newaxis, :, :], axis=2)], axis=0)
+    last = last / N[-1, :, np.newaxis]
+    return np.concatenate([w_hyp, last[np.newaxis, :, :]], axis=0), N
+
+
+def bayes_risk(w, x, lik, outcomes, expparams_list, Q=None):
+    """smc.py:553-611."""
+    Q = np.ones(x.shape[1]) if Q is None else Q
+    w_hyp, N = _hyp_all_outcomes(w, x, lik, outcomes, expparams_list)
+    mu = np.dot(w_hyp, x)
+    var = np.sum(w_hyp * np.sum(Q * (x[None, None, :, :] - mu[:, :, None, :]) ** 2, axis=3), axis=2)
+    return np.sum(N * var, axis=0)
+
+
+def expected_information_gain(w, x, lik, outcomes, expparams_list):
+    """smc.py:613-663."""
+    w_hyp, N = _hyp_all_outcomes(w, x, lik, outcomes, expparams_list)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        kld = np.sum(w_hyp * np.log(w_hyp / w), axis=2)
+    return np.sum(N * kld, axis=0)
+
+
 # ----------------------------------------------------------------------------------------------
 # Liu-West resampler (a14, a15), including quirks Q1 (mus truncation) and Q2 (unclamped search)
 # ----------------------------------------------------------------------------------------------

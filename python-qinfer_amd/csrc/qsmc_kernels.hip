@@ -54,7 +54,7 @@ struct qsmc_ctx {
         }                                                                                       \
     } while (0)
 
-constexpr int REDUCE_OUT_MAX = 64;
+constexpr int REDUCE_OUT_MAX = 192;
 
 static int ensure_partials(qsmc_ctx *h, size_t n) {
     if (h->partials_cap >= n) return QSMC_OK;
@@ -328,6 +328,68 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_update_multi(
         }
     }
     block_publish<NS>(s, mn, ro);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Experiment-design sums (bayes_risk / expected_information_gain, smc.py:553-663): for ONE
+// hypothetical experiment and up to NO outcomes, in one pass over the cloud and without
+// materialising L[n_o, N]:
+//   S0_o = sum w L_o          (= hypothetical normalisation N[o])
+//   SL_o = sum w L_o log L_o  (0 log 0 := 0)      -> N KLD = SL - S0 log S0
+//   S1_o,m = sum w L_o (x_m - c_m),  S2_o,m = sum w L_o (x_m - c_m)^2   -> N var = sum_m Q_m (S2 - S1^2/S0)
+// with w = w_raw / norm and c a shift (the current mean) that removes the cancellation of the
+// one-pass variance.  Layout of the NS sums: [o][2 + 2 D].
+// ---------------------------------------------------------------------------------------------
+template <int NO>
+struct HypArgs {
+    int n_o;
+    ExpArgs base;
+    double comb[NO], log_comb[NO];
+    int64_t outcome[NO];
+    double shift[QSMC_MAX_D];
+};
+
+template <int KIND, int NO>
+__global__ __launch_bounds__(QSMC_BLOCK) void k_hyp_sums(const double *__restrict__ x, int64_t ldx, int64_t n,
+                                                         const double *__restrict__ w, double norm,
+                                                         HypArgs<NO> ha, ReduceOut ro) {
+    constexpr int D = Model<KIND>::D <= 4 ? Model<KIND>::D : 0;    // d > 4: normalisations and SL only
+    constexpr int DD = Model<KIND>::D;
+    constexpr int PER = 2 + 2 * D;
+    constexpr int NS = NO * PER;
+    const int d = (KIND == QSMC_MODEL_TOMOGRAPHY) ? ha.base.d : DD;
+    double s[NS];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) s[q] = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * QSMC_BLOCK + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * QSMC_BLOCK) {
+        double p[DD];
+#pragma unroll
+        for (int m = 0; m < DD; ++m)
+            if (m < d) p[m] = x[m * ldx + i];
+        const double wi = (w ? w[i] : 1.0) / norm;
+        double c1[D > 0 ? D : 1];
+#pragma unroll
+        for (int m = 0; m < D; ++m) c1[m] = p[m] - ha.shift[m];
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+            if (o < ha.n_o) {
+                ExpArgs e = ha.base;
+                e.comb = ha.comb[o];
+                e.log_comb = ha.log_comb[o];
+                const double L = Model<KIND>::lik(p, e, ha.outcome[o]);
+                const double wl = wi * L;
+                s[o * PER] += wl;
+                s[o * PER + 1] += (L > 0.0) ? wl * log(L) : 0.0;
+#pragma unroll
+                for (int m = 0; m < D; ++m) {
+                    s[o * PER + 2 + m] += wl * c1[m];
+                    s[o * PER + 2 + D + m] += wl * c1[m] * c1[m];
+                }
+            }
+        }
+    }
+    block_publish<NS>(s, 0.0, ro);
 }
 
 // mode 0: w_out = (w_in / norm) * L   (generic-model slow path)
@@ -1239,7 +1301,8 @@ static int launch_reduce(qsmc_ctx *h, int ns, int grid, const ReduceOut &ro, hip
     case N:                                                                                     \
         hipLaunchKernelGGL((k_reduce_partials<N>), dim3(1), dim3(QSMC_BLOCK), 0, s, grid, ro);  \
         break;
-        LR(3) LR(5) LR(6) LR(8) LR(10) LR(12) LR(15) LR(17) LR(24) LR(26) LR(29) LR(33) LR(38)
+        LR(3) LR(4) LR(5) LR(6) LR(8) LR(10) LR(12) LR(15) LR(16) LR(17) LR(20) LR(24) LR(26) LR(29) LR(32) LR(33)
+        LR(38) LR(64) LR(80) LR(128)
 #undef LR
         default: return QSMC_ERR_INVALID;
     }
@@ -1292,6 +1355,73 @@ static int weights_pass(qsmc_ctx *h, const double *L, int64_t n, const double *w
     rc = launch_reduce(h, 3, grid, ro, s);
     if (rc) return rc;
     return collect_stats(h, 3, stats_host, nullptr, 0, s);
+}
+
+template <int KIND, int NO>
+static int hyp_launch(qsmc_ctx *h, const qsmc_model_t *model, const double *x, int64_t ldx, int64_t n,
+                      const double *w, double norm, const qsmc_expparam_t *exp, const int64_t *outcomes, int n_o,
+                      const double *shift, double *out_host, hipStream_t s) {
+    constexpr int D = Model<KIND>::D <= 4 ? Model<KIND>::D : 0;
+    constexpr int PER = 2 + 2 * D;
+    constexpr int NS = NO * PER;
+    static_assert(NS + 1 <= REDUCE_OUT_MAX - 2, "reduce buffers too small");
+    const int grid = grid_for(n, QSMC_BLOCK * 4);
+    int rc = ensure_partials(h, (size_t)grid * (NS + 1));
+    if (rc) return rc;
+    HypArgs<NO> ha;
+    memset(&ha, 0, sizeof(ha));
+    ha.n_o = n_o;
+    make_exp_args(model, exp, outcomes[0], &ha.base);
+    for (int o = 0; o < n_o; ++o) {
+        ExpArgs tmp;
+        make_exp_args(model, exp, outcomes[o], &tmp);
+        ha.comb[o] = tmp.comb;
+        ha.log_comb[o] = tmp.log_comb;
+        ha.outcome[o] = outcomes[o];
+    }
+    if (shift) for (int m = 0; m < model->d && m < QSMC_MAX_D; ++m) ha.shift[m] = shift[m];
+    const ReduceOut ro = make_reduce(h, true, nullptr);
+    hipLaunchKernelGGL((k_hyp_sums<KIND, NO>), dim3(grid), dim3(QSMC_BLOCK), 0, s, x, ldx, n, w, norm, ha, ro);
+    HIP_TRY(h, hipGetLastError());
+    rc = launch_reduce(h, NS, grid, ro, s);
+    if (rc) return rc;
+    HIP_TRY(h, hipStreamSynchronize(s));
+    memcpy(out_host, h->mapped, (size_t)n_o * PER * sizeof(double));
+    return QSMC_OK;
+}
+
+template <int KIND>
+static int hyp_dispatch(qsmc_ctx *h, const qsmc_model_t *model, const double *x, int64_t ldx, int64_t n,
+                        const double *w, double norm, const qsmc_expparam_t *exp, const int64_t *outcomes,
+                        int n_o, const double *shift, double *out_host, hipStream_t s) {
+    // outcome lists longer than 32 (binomial with n_meas > 31) are processed in groups
+    constexpr int D = Model<KIND>::D <= 4 ? Model<KIND>::D : 0;
+    constexpr int PER = 2 + 2 * D;
+    constexpr bool WIDE = PER * 32 <= 128;      // 32-outcome instantiation only where it fits in registers
+    int done = 0;
+    while (done < n_o) {
+        const int m = n_o - done;
+        int take, rc;
+        if (m <= 2) {
+            take = m;
+            rc = hyp_launch<KIND, 2>(h, model, x, ldx, n, w, norm, exp, outcomes + done, take, shift,
+                                     out_host + (size_t)done * PER, s);
+        } else if (WIDE && m > 8) {
+            take = m < 32 ? m : 32;
+            if constexpr (WIDE)
+                rc = hyp_launch<KIND, 32>(h, model, x, ldx, n, w, norm, exp, outcomes + done, take, shift,
+                                          out_host + (size_t)done * PER, s);
+            else
+                rc = QSMC_ERR_INVALID;
+        } else {
+            take = m < 8 ? m : 8;
+            rc = hyp_launch<KIND, 8>(h, model, x, ldx, n, w, norm, exp, outcomes + done, take, shift,
+                                     out_host + (size_t)done * PER, s);
+        }
+        if (rc) return rc;
+        done += take;
+    }
+    return QSMC_OK;
 }
 
 // =============================================================================================
@@ -1498,6 +1628,25 @@ int qsmc_update_multi(qsmc_handle_t h, const qsmc_model_t *model, const double *
     }
     if (moments_host) memcpy(moments_host, h->mapped + 3 * MULTI_KMAX, (size_t)n_mom * sizeof(double));
     return QSMC_OK;
+}
+
+int qsmc_hypothetical_sums(qsmc_handle_t h, const qsmc_model_t *model, const double *x, int64_t ldx, int64_t n,
+                           const double *w, double norm, const qsmc_expparam_t *exp, const int64_t *outcomes,
+                           int32_t n_o, const double *shift, double *out_host, qsmc_stream_t stream) {
+    if (!h || !x || !exp || !outcomes || !out_host || n <= 0 || n_o < 1) return QSMC_ERR_INVALID;
+    int rc = check_model(model);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    switch (model->kind) {
+#define HD(K) case K: return hyp_dispatch<K>(h, model, x, ldx, n, w, norm, exp, outcomes, n_o, shift, out_host, s);
+        HD(QSMC_MODEL_PRECESSION)
+        HD(QSMC_MODEL_BINOMIAL_PRECESSION)
+        HD(QSMC_MODEL_RB)
+        HD(QSMC_MODEL_RB_INTERLEAVED)
+        HD(QSMC_MODEL_TOMOGRAPHY)
+#undef HD
+    }
+    return QSMC_ERR_INVALID;
 }
 
 int qsmc_update_from_likelihood(qsmc_handle_t h, const double *L, int64_t n, const double *w_in,

@@ -158,6 +158,20 @@ class Engine:
             return list(st), None, None
         return list(st), mom[:d].copy(), self._unpack_upper(mom[d:], d)
 
+    def hypothetical_sums(self, desc, x, w, norm, exp, outcomes, shift):
+        """(n_o, 2 + 2d) array [N, sum wL log L, sum wL (x-c), sum wL (x-c)^2] (d <= 4; else (n_o, 2))."""
+        d = x.shape[0]
+        per = 2 + 2 * d if d <= 4 else 2
+        n_o = len(outcomes)
+        out = np.empty((n_o, per), dtype=np.float64)
+        oc = (C.c_int64 * n_o)(*[int(o) for o in outcomes])
+        shift = np.ascontiguousarray(shift, dtype=np.float64)
+        self._chk(self.lib.qsmc_hypothetical_sums(
+            self.h, C.byref(desc), self._p(x), x.stride(0), x.shape[1],
+            self._p(w) if w is not None else None, float(norm), C.byref(exp), oc, n_o,
+            _native.f64_ptr(shift), _native.f64_ptr(out), self.stream()), "qsmc_hypothetical_sums")
+        return out
+
     def update_from_likelihood(self, L, w_in, w_out, prev_norm):
         st = _native.UpdateStats()
         self._chk(self.lib.qsmc_update_from_likelihood(

@@ -20,7 +20,7 @@ __all__ = ["SimpleInversionModel", "SimplePrecessionModel", "DerivedModel", "Bin
 
 
 def _field(expparams, name):
-    return np.atleast_1d(expparams[name])
+    return np.atleast_1d(expparams[name]).ravel()
 
 
 class SimpleInversionModel(NativeModelMixin, FiniteOutcomeModel):
@@ -78,7 +78,7 @@ class SimplePrecessionModel(SimpleInversionModel):
     def _native_expparams(self, expparams):
         expparams = np.atleast_1d(expparams)
         ts = expparams['t'] if expparams.dtype.names else expparams
-        return [_native.make_expparam(t=t, w_=0.0) for t in np.atleast_1d(ts).astype(np.float64)]
+        return [_native.make_expparam(t=t, w_=0.0) for t in np.atleast_1d(ts).astype(np.float64).ravel()]
 
 
 class DerivedModel(Model):

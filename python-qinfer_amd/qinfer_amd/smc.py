@@ -411,6 +411,74 @@ class SMCUpdater(ParticleDistribution):
             self._moments_cache = (1.0, m1 / self._norm, m2 / self._norm)
         return True
 
+    # ------------------------------------------------------------------ experiment design
+    def _hyp_sums(self, expparams):
+        """Per experiment: all outcomes' hypothetical sums in one pass each (qsmc_hypothetical_sums)."""
+        eng = self._eng
+        shift = self.est_mean()
+        out = []
+        for k in range(expparams.shape[0]):
+            one = expparams[k:k + 1]
+            os_ = self.model.domain(one)[0].values
+            exp = self.model._native_expparams(one)[0]
+            out.append(eng.hypothetical_sums(self._desc, self._x, self._w, self._norm, exp, os_, shift))
+        return out
+
+    def bayes_risk(self, expparams):
+        """Bayes risk (quadratic loss, scale matrix Q) of hypothetical experiments: the expected
+        posterior variance  sum_o N[o] var[o]  for each experiment (smc.py:553-611).
+
+        Native models: one fused pass per experiment yields, for every outcome, the hypothetical
+        normalisation and the (mean-shifted) first and second moments; nothing of size
+        n_outcomes x N is materialised.  Other models go through `hypothetical_update`."""
+        expparams = np.atleast_1d(expparams).reshape(-1)
+        if self._native and self._x.shape[0] <= 4 and self._comm is None:
+            d = self._x.shape[0]
+            Q = np.asarray(self.model.Q, dtype=np.float64)
+            risk = np.empty(expparams.shape[0])
+            for k, sums in enumerate(self._hyp_sums(expparams)):
+                N, s1, s2 = sums[:, 0], sums[:, 2:2 + d], sums[:, 2 + d:2 + 2 * d]
+                with np.errstate(divide='ignore', invalid='ignore'):
+                    var = np.where(N[:, None] > 0, s2 - s1 * s1 / N[:, None], 0.0)
+                risk[k] = np.sum(var @ Q)
+            return risk
+        return self._design_generic(expparams, "risk")
+
+    def expected_information_gain(self, expparams):
+        """Expected KL divergence posterior||prior over the outcomes of each hypothetical
+        experiment,  sum_o N[o] KLD[o]  (smc.py:613-663).  `0 log 0` is taken as 0."""
+        expparams = np.atleast_1d(expparams).reshape(-1)
+        if self._native and self._comm is None:
+            eig = np.empty(expparams.shape[0])
+            for k, sums in enumerate(self._hyp_sums(expparams)):
+                N, sl = sums[:, 0], sums[:, 1]
+                with np.errstate(divide='ignore', invalid='ignore'):
+                    eig[k] = np.sum(np.where(N > 0, sl - N * np.log(N), 0.0))
+            return eig
+        return self._design_generic(expparams, "eig")
+
+    def _design_generic(self, expparams, what):
+        """Plugin path (any Model): the reference's formulas on `hypothetical_update` output."""
+        n_eps = expparams.shape[0]
+        if n_eps > 1 and not self.model.is_n_outcomes_constant:
+            return np.array([self._design_generic(expparams[i:i + 1], what)[0] for i in range(n_eps)])
+        os_ = self.model.domain(expparams[0:1])[0].values
+        w_hyp, N = self.hypothetical_update(os_, expparams, return_normalization=True)
+        N = N[:, :, 0]
+        if what == "risk":
+            locs = self.particle_locations
+            mu = np.dot(w_hyp, locs)
+            var = np.sum(w_hyp * np.sum(self.model.Q * (locs[None, None, :, :] - mu[:, :, None, :]) ** 2, axis=3),
+                         axis=2)
+            return np.sum(N * var, axis=0)
+        w = self.particle_weights
+        with np.errstate(divide='ignore', invalid='ignore'):
+            terms = np.where(w_hyp > 0, w_hyp * np.log(w_hyp / w), 0.0)
+        return np.sum(N * np.sum(terms, axis=2), axis=0)
+
+    def risk(self, x0):
+        return self.bayes_risk(np.array([(x0,)], dtype=self.model.expparams_dtype))
+
     # ------------------------------------------------------------------ resampling
     def _maybe_resample(self):
         ess = self.n_ess

@@ -742,6 +742,55 @@ def test_guards_negative_weights(qi):
     np.testing.assert_allclose(upd.n_ess, 1 / np.sum(expect ** 2), rtol=1e-12)
 
 
+# ================================================================== experiment design (G7)
+def _cloud_updater(qi, model, x, w):
+    upd = qi.SMCUpdater(model, x.shape[0], fixed_prior(qi, x))
+    upd.particle_weights = w
+    return upd
+
+
+def test_bayes_risk_and_eig_g7(qi, golden):
+    g = golden("g7_design")
+    upd = _cloud_updater(qi, qi.SimplePrecessionModel(), g["prec_x"], g["prec_w"])
+    # risk = sum_o N var: the kernel's mean-shifted one-pass sums vs the reference's two-pass form
+    np.testing.assert_allclose(upd.bayes_risk(g["prec_t"]), g["prec_risk"], rtol=1e-10)
+    np.testing.assert_allclose(upd.expected_information_gain(g["prec_t"]), g["prec_eig"], rtol=1e-10, atol=1e-14)
+    np.testing.assert_allclose(upd.risk(2.0), g["prec_risk"][1], rtol=1e-10)
+    rb = qi.RandomizedBenchmarkingModel()
+    upd = _cloud_updater(qi, rb, g["rb_x"], g["rb_w"])
+    ep = np.empty((3,), dtype=rb.expparams_dtype)
+    ep["m"] = g["rb_m"]
+    np.testing.assert_allclose(upd.bayes_risk(ep), g["rb_risk"], rtol=1e-10)
+    np.testing.assert_allclose(upd.expected_information_gain(ep), g["rb_eig"], rtol=1e-9, atol=1e-14)
+    bm = qi.BinomialModel(qi.SimplePrecessionModel())
+    upd = _cloud_updater(qi, bm, g["bin_x"], g["bin_w"])
+    ep = np.empty((3,), dtype=bm.expparams_dtype)
+    ep["x"], ep["n_meas"] = g["bin_t"], g["bin_n"]
+    np.testing.assert_allclose(upd.bayes_risk(ep), g["bin_risk"], rtol=1e-9)
+    eig = upd.expected_information_gain(ep)
+    ok = np.isfinite(g["bin_eig"])            # the reference returns NaN where some w L == 0 (0 * log 0)
+    assert ok.any() and not ok.all()
+    np.testing.assert_allclose(eig[ok], g["bin_eig"][ok], rtol=1e-9)
+    assert np.all(np.isfinite(eig)) and np.all(eig > 0)
+
+
+def test_design_generic_path_matches_native(qi, golden):
+    """A user-defined (non-native) model goes through hypothetical_update; same numbers."""
+    g = golden("g7_design")
+
+    class MyPrecession(qi.SimplePrecessionModel):
+        _native = False
+
+        def likelihood(self, outcomes, mp, ep):
+            return orc.lik_precession(outcomes, mp, np.atleast_1d(ep))
+
+        def are_models_valid(self, mp):
+            return np.ones(mp.shape[0], dtype=bool)
+    upd = _cloud_updater(qi, MyPrecession(), g["prec_x"], g["prec_w"])
+    np.testing.assert_allclose(upd.bayes_risk(g["prec_t"]), g["prec_risk"], rtol=1e-10)
+    np.testing.assert_allclose(upd.expected_information_gain(g["prec_t"]), g["prec_eig"], rtol=1e-10, atol=1e-14)
+
+
 # ================================================================== API odds and ends
 def test_hypothetical_update_matches_oracle(qi):
     rs = np.random.RandomState(8)

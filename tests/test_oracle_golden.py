@@ -242,3 +242,28 @@ def test_c1_statistical_full_run():
     assert abs(smc.est_mean()[0] - 0.3) < 1e-5
     assert smc.est_covariance_mtx()[0, 0] < 1e-9
     assert 25 <= smc.resample_count <= 60
+
+
+# ------------------------------------------------------------------ G7 experiment design
+def test_g7_design_oracle(golden):
+    g = golden("g7_design")
+    lik_p = lambda o, x, e: orc.lik_precession(o, x, e["t"])
+    eps = [{"t": g["prec_t"][k:k + 1]} for k in range(len(g["prec_t"]))]
+    risk = orc.bayes_risk(g["prec_w"], g["prec_x"], lik_p, np.array([0, 1]), eps)
+    eig = orc.expected_information_gain(g["prec_w"], g["prec_x"], lik_p, np.array([0, 1]), eps)
+    np.testing.assert_allclose(risk, g["prec_risk"], rtol=1e-12)
+    np.testing.assert_allclose(eig, g["prec_eig"], rtol=1e-11, atol=1e-15)
+    lik_rb = lambda o, x, e: orc.lik_rb(o, x, e["m"])
+    eps = [{"m": g["rb_m"][k:k + 1]} for k in range(3)]
+    np.testing.assert_allclose(orc.bayes_risk(g["rb_w"], g["rb_x"], lik_rb, np.array([0, 1]), eps),
+                               g["rb_risk"], rtol=1e-12)
+    np.testing.assert_allclose(orc.expected_information_gain(g["rb_w"], g["rb_x"], lik_rb, np.array([0, 1]), eps),
+                               g["rb_eig"], rtol=1e-10, atol=1e-15)
+    lik_b = lambda o, x, e: orc.lik_binomial_precession(o, x, e["t"], e["n_meas"])
+    for k in range(3):
+        e = [{"t": g["bin_t"][k:k + 1], "n_meas": g["bin_n"][k:k + 1]}]
+        os_ = np.arange(int(g["bin_n"][k]) + 1)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            r = orc.bayes_risk(g["bin_w"], g["bin_x"], lik_b, os_, e)
+        np.testing.assert_allclose(r[0], g["bin_risk"][k], rtol=1e-9)
