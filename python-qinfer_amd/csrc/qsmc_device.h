@@ -198,9 +198,10 @@ __host__ __device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) {
 __host__ __device__ __forceinline__ U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = mulhi32(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
-        const uint32_t hi1 = mulhi32(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
-        c = U4{hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0};
+        // one 32x32->64 multiply per word pair (v_mad_u64_u32) instead of separate mul_hi / mul_lo
+        const uint64_t p0 = (uint64_t)0xD2511F53u * (uint64_t)c.x;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * (uint64_t)c.z;
+        c = U4{(uint32_t)(p1 >> 32) ^ c.y ^ k0, (uint32_t)p1, (uint32_t)(p0 >> 32) ^ c.w ^ k1, (uint32_t)p0};
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;
     }
