@@ -208,15 +208,19 @@ int qsmc_lw_perturb(qsmc_handle_t h, const qsmc_model_t *model, int32_t postsele
                     int32_t centre_by_idx, const double *S, const double *z, int64_t ldz,
                     double *x_out, int64_t ldx_out, uint8_t *valid_out, qsmc_stream_t stream);
 
-/* Device-RNG resample in ONE launch (Philox4x32-10, counter = (particle, epoch, round)):
- * draw u -> ancestor -> centre -> Box-Muller z -> perturb -> validity; an invalid particle redraws
- * (ancestor and z) in-thread up to maxiter times.  *n_failed_host = particles still invalid
- * (synchronises); pass NULL to stay asynchronous and use qsmc_last_resample_failed.
- * For 4*4096 <= n_out and n_in <= 3.3e7 the bucketed path is used: outputs are
- * then ordered by ancestor chunk -- particles are exchangeable, the joint law is the same. */
+/* Device-RNG resample straight from the (unnormalised) weights (Philox4x32-10, deterministic per
+ * (seed, epoch, slot)): multinomial ancestors -> Liu-West centre -> Box-Muller kick -> validity; an
+ * invalid particle redraws ancestor and kick up to maxiter times.  w == NULL: all-ones weights.
+ * *n_failed_host = particles still invalid (synchronises); NULL stays asynchronous
+ * (qsmc_last_resample_failed).
+ * For 16384 <= n_out < 2^32 and n_in <= 3.3e7 the BUCKETED sampler runs: exact
+ * multinomial counts per 4096-particle chunk, then one workgroup per chunk scans ITS weights in LDS,
+ * so the CDF is never written to HBM; outputs come ordered by ancestor chunk (particles are
+ * exchangeable; same joint law).  The global CDF is materialised only if a particle needs a global
+ * redraw.  Otherwise: CDF + one binary search per particle. */
 int qsmc_lw_resample_philox(qsmc_handle_t h, const qsmc_model_t *model, int32_t postselect,
                             const double *x_in, int64_t ldx_in, int64_t n_in, int32_t d,
-                            const double *cdf, double a, const double *mean, const double *S,
+                            const double *w, double norm, double a, const double *mean, const double *S,
                             int64_t n_out, uint64_t seed, uint64_t epoch, int32_t maxiter,
                             double *x_out, int64_t ldx_out, int64_t *n_failed_host,
                             qsmc_stream_t stream);
@@ -233,11 +237,11 @@ int qsmc_last_resample_failed(qsmc_handle_t h, int64_t *n_failed_out, int32_t sy
  * dest_counts[r] (HOST, n_dest <= 16) = how many particles rank r takes from this shard (column of
  * the shared count matrix); rows_out is AoS [sum(dest_counts)][d], grouped by destination rank.
  * Inside each group the rows are an even round-robin deal of the chunk-sorted sample, so shards stay
- * exchangeable.  `cdf` is the scan of this shard's w / (its local sum).  A postselection retry
- * redraws its ancestor from this shard (exact for exchangeable shards). */
+ * exchangeable.  `norm` is this shard's own weight sum (its local CDF ends at 1).  A postselection
+ * retry redraws its ancestor from this shard (exact for exchangeable shards). */
 int qsmc_lw_resample_philox_sharded(qsmc_handle_t h, const qsmc_model_t *model, int32_t postselect,
                                     const double *x_in, int64_t ldx_in, int64_t n_in, int32_t d,
-                                    const double *cdf, double a, const double *mean, const double *S,
+                                    const double *w, double norm, double a, const double *mean, const double *S,
                                     const int64_t *dest_counts, int32_t n_dest, uint64_t seed,
                                     uint64_t epoch, int32_t maxiter, double *rows_out,
                                     int64_t *n_failed_host, qsmc_stream_t stream);

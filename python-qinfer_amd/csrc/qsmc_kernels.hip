@@ -38,6 +38,8 @@ struct qsmc_ctx {
     double *mapped_dev;    // ... and its device alias
     unsigned int *iscratch; // device integer scratch for the bucketed resampler
     size_t iscratch_cap;    // in bytes
+    double *cdf_scratch;    // device CDF, materialised only for the direct sampler / global redraws
+    size_t cdf_cap;         // in doubles
     int profiling;
     hipEvent_t ev0, ev1;
     int ev_valid;
@@ -83,6 +85,16 @@ static int ensure_iscratch(qsmc_ctx *h, size_t bytes) {
     h->iscratch_cap = 0;
     HIP_TRY(h, hipMalloc(&h->iscratch, bytes));
     h->iscratch_cap = bytes;
+    return QSMC_OK;
+}
+
+static int ensure_cdf(qsmc_ctx *h, size_t n) {
+    if (h->cdf_cap >= n) return QSMC_OK;
+    if (h->cdf_scratch) HIP_TRY(h, hipFree(h->cdf_scratch));
+    h->cdf_scratch = nullptr;
+    h->cdf_cap = 0;
+    HIP_TRY(h, hipMalloc(&h->cdf_scratch, n * sizeof(double)));
+    h->cdf_cap = n;
     return QSMC_OK;
 }
 
@@ -530,9 +542,11 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_sum_partials(const double *__res
 // =============================================================================================
 constexpr int SCAN_PER_LANE = 2;                                   // double2 per lane per tile
 constexpr int SCAN_WAVE_TILE = QSMC_WAVE * SCAN_PER_LANE;          // 128 elements
-constexpr int SCAN_TILES_PER_WAVE = 8;
-constexpr int SCAN_WAVE_CHUNK = SCAN_WAVE_TILE * SCAN_TILES_PER_WAVE;   // 1024
-constexpr int SCAN_CHUNK = SCAN_WAVE_CHUNK * QSMC_WAVES_PER_BLOCK;      // 4096 per workgroup
+constexpr int SCAN_TILES_PER_WAVE = 4;
+constexpr int SCAN_WAVE_CHUNK = SCAN_WAVE_TILE * SCAN_TILES_PER_WAVE;   // 512
+constexpr int SCAN_WAVES = 8;                                           // 512 threads scan one chunk
+constexpr int SCAN_THREADS = SCAN_WAVES * QSMC_WAVE;
+constexpr int SCAN_CHUNK = SCAN_WAVE_CHUNK * SCAN_WAVES;                // 4096 per workgroup
 
 __device__ __forceinline__ double wave_inclusive_scan(double v, int lane) {
 #pragma unroll
@@ -543,15 +557,17 @@ __device__ __forceinline__ double wave_inclusive_scan(double v, int lane) {
     return v;
 }
 
+// (the scan pipeline multiplies by 1/norm instead of dividing: fp64 division is ~25 instructions and
+// the in-sampler scan is VALU-bound; every stage uses the same expression, so they agree bit for bit)
 __global__ __launch_bounds__(QSMC_BLOCK) void k_chunk_sums(const double *__restrict__ w, int64_t n,
-                                                           double norm, double *__restrict__ sums) {
+                                                           double inv_norm, double *__restrict__ sums) {
     __shared__ double lds[QSMC_WAVES_PER_BLOCK];
     const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK;
     double v[1] = {0.0};
 #pragma unroll
     for (int u = 0; u < SCAN_CHUNK / QSMC_BLOCK; ++u) {
         const int64_t i = base + (int64_t)u * QSMC_BLOCK + threadIdx.x;
-        if (i < n) v[0] += w[i] / norm;
+        if (i < n) v[0] += (w ? w[i] : 1.0) * inv_norm;
     }
     block_sum<1>(v, lds);
     if (threadIdx.x == 0) sums[blockIdx.x] = v[0];
@@ -667,37 +683,46 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_scan_sums_big(double *__restrict
 
 // Per-chunk scan.  offsets[] has chunks + 1 monotone entries (exclusive offsets + total).
 // Every value is clamped into its wave's [lo, hi] offset window and then passed through an exact
-// prefix max, so cdf[] is non-decreasing everywhere (searchsorted on it is well defined) while
-// differing from the sequential np.cumsum only by rounding.
-__global__ __launch_bounds__(QSMC_BLOCK) void k_chunk_scan(const double *__restrict__ w, int64_t n,
-                                                           double norm, const double *__restrict__ offsets,
-                                                           double *__restrict__ cdf) {
-    __shared__ double wave_tot[QSMC_WAVES_PER_BLOCK];
+// prefix max, so the CDF is non-decreasing everywhere (searchsorted on it is well defined) while
+// differing from the sequential np.cumsum only by rounding.  The last entry of a chunk is DEFINED
+// as offsets[c + 1] (equal in exact arithmetic), so chunk edges and CDF entries are one and the
+// same numbers whether or not the CDF is ever written to HBM.
+// The first 512 threads (8 waves x 4 tiles x 128 elements) scan chunk c; every thread of the
+// workgroup must call (one barrier inside).  store(i_global, value) receives the values.
+template <class Store>
+__device__ __forceinline__ void chunk_scan_block(const double *__restrict__ w, int64_t n, double inv_norm,
+                                                 const double *__restrict__ offsets, int64_t c,
+                                                 double *wave_tot, Store store) {
+    const bool act = threadIdx.x < SCAN_THREADS;
     const int lane = threadIdx.x & (QSMC_WAVE - 1);
-    const int wave = threadIdx.x / QSMC_WAVE;
-    const int64_t wbase = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)wave * SCAN_WAVE_CHUNK;
+    const int wave = (threadIdx.x / QSMC_WAVE) & (SCAN_WAVES - 1);
+    const int64_t wbase = c * SCAN_CHUNK + (int64_t)wave * SCAN_WAVE_CHUNK;
     double r[SCAN_TILES_PER_WAVE][SCAN_PER_LANE];
     double carry = 0.0;
+    if (act) {
 #pragma unroll
-    for (int t = 0; t < SCAN_TILES_PER_WAVE; ++t) {
-        const int64_t i = wbase + (int64_t)t * SCAN_WAVE_TILE + lane * SCAN_PER_LANE;
-        const double a = i < n ? w[i] / norm : 0.0;
-        const double b = i + 1 < n ? w[i + 1] / norm : 0.0;
-        const double pair = a + b;
-        const double inc = wave_inclusive_scan(pair, lane);
-        double excl = __shfl_up(inc, 1, QSMC_WAVE);
-        if (lane == 0) excl = 0.0;
-        excl += carry;
-        r[t][0] = excl + a;
-        r[t][1] = excl + pair;
-        carry += __shfl(inc, QSMC_WAVE - 1, QSMC_WAVE);
+        for (int t = 0; t < SCAN_TILES_PER_WAVE; ++t) {
+            const int64_t i = wbase + (int64_t)t * SCAN_WAVE_TILE + lane * SCAN_PER_LANE;
+            const double a = i < n ? (w ? w[i] : 1.0) * inv_norm : 0.0;
+            const double b = i + 1 < n ? (w ? w[i + 1] : 1.0) * inv_norm : 0.0;
+            const double pair = a + b;
+            const double inc = wave_inclusive_scan(pair, lane);
+            double excl = __shfl_up(inc, 1, QSMC_WAVE);
+            if (lane == 0) excl = 0.0;
+            excl += carry;
+            r[t][0] = excl + a;
+            r[t][1] = excl + pair;
+            carry += __shfl(inc, QSMC_WAVE - 1, QSMC_WAVE);
+        }
+        if (lane == 0) wave_tot[wave] = carry;
     }
-    if (lane == 0) wave_tot[wave] = carry;
     __syncthreads();
-    const double blo = offsets[blockIdx.x], bhi = offsets[blockIdx.x + 1];
+    if (!act) return;
+    const double blo = offsets[c], bhi = offsets[c + 1];
+    const int64_t last = ((c + 1) * SCAN_CHUNK < n ? (c + 1) * SCAN_CHUNK : n) - 1;   // chunk's last particle
     double lo = blo;
     for (int wv = 0; wv < wave; ++wv) lo = fmin(lo + wave_tot[wv], bhi);
-    const double hi = (wave == QSMC_WAVES_PER_BLOCK - 1) ? bhi : fmin(lo + wave_tot[wave], bhi);
+    const double hi = (wave == SCAN_WAVES - 1) ? bhi : fmin(lo + wave_tot[wave], bhi);
     double run = lo;
 #pragma unroll
     for (int t = 0; t < SCAN_TILES_PER_WAVE; ++t) {
@@ -711,9 +736,25 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_chunk_scan(const double *__restr
         a0 = fmax(a0, prev);
         a1 = fmax(m, run);
         run = fmax(run, __shfl(m, QSMC_WAVE - 1, QSMC_WAVE));
-        if (i < n) cdf[i] = a0;
-        if (i + 1 < n) cdf[i + 1] = a1;
+        if (i < n) store(i, i == last ? bhi : a0);
+        if (i + 1 < n) store(i + 1, i + 1 == last ? bhi : a1);
     }
+}
+
+struct StoreGlobal {
+    double *cdf;
+    __device__ __forceinline__ void operator()(int64_t i, double v) const { cdf[i] = v; }
+};
+
+// Materialise the CDF.  gate != nullptr: do nothing unless *gate > 0 (the bucketed resampler only
+// needs the global CDF when some particle has to redraw a global ancestor).
+__global__ __launch_bounds__(SCAN_THREADS) void k_chunk_scan(const double *__restrict__ w, int64_t n,
+                                                             double inv_norm, const double *__restrict__ offsets,
+                                                             double *__restrict__ cdf,
+                                                             const unsigned long long *__restrict__ gate) {
+    __shared__ double wave_tot[SCAN_WAVES];
+    if (gate && *gate == 0ull) return;
+    chunk_scan_block(w, n, inv_norm, offsets, (int64_t)blockIdx.x, wave_tot, StoreGlobal{cdf});
 }
 
 // =============================================================================================
@@ -870,11 +911,10 @@ constexpr int BUCKET_MAX_CHUNKS = 8192;             // skewed edges (68 KB) + co
 constexpr int BUCKET_COUNT_BLOCKS = 256;            // one resident workgroup per CU
 constexpr int BUCKET_COUNT_THREADS = 1024;
 
-__device__ __forceinline__ double chunk_edge(const double *__restrict__ cdf, int64_t n, int64_t c) {
-    // upper CDF edge of chunk c-1 == lower edge of chunk c
-    if (c <= 0) return 0.0;
-    const int64_t idx = c * BUCKET_CHUNK - 1;
-    return cdf[idx < n ? idx : n - 1];
+// Lower CDF edge of chunk c == upper edge of chunk c-1 == offsets[c] (k_scan_sums output; the chunk
+// scan defines the last CDF entry of every chunk as exactly this number).
+__device__ __forceinline__ double chunk_edge(const double *__restrict__ offsets, int64_t c) {
+    return c <= 0 ? 0.0 : offsets[c];
 }
 
 // number of entries of a[0..m) that are <= u   (a in LDS or global)
@@ -969,7 +1009,7 @@ __device__ __forceinline__ int guided_upper_bound(const double *a, int m, const 
 //   slot 2: block (n >> 1), Box-Muller comp (n&1) n = o * d + q, q-th normal of slot o
 // retries (round r >= 1) are per output: block (o, r, 0).u0 = global ancestor, (o, r, 1 + q/2) normals.
 __global__ __launch_bounds__(BUCKET_COUNT_THREADS) void k_bucket_count(
-    const double *__restrict__ cdf, int64_t n_in, int chunks, int64_t n_out, uint32_t k0, uint32_t k1,
+    const double *__restrict__ offsets, int chunks, int64_t n_out, uint32_t k0, uint32_t k1,
     uint32_t epoch, unsigned int *__restrict__ hist /* [gridDim.x][chunks] */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double *edges = reinterpret_cast<double *>(smem);                       // skewed: upper edge of chunk c
@@ -978,7 +1018,7 @@ __global__ __launch_bounds__(BUCKET_COUNT_THREADS) void k_bucket_count(
     int *G = reinterpret_cast<int *>(cnt + chunks);
     int *wtot = G + GUIDE_BINS + 1;
     for (int c = threadIdx.x; c < chunks; c += blockDim.x) {
-        edges[lds_skew(c)] = chunk_edge(cdf, n_in, (int64_t)c + 1);
+        edges[lds_skew(c)] = chunk_edge(offsets, (int64_t)c + 1);
         cnt[c] = 0u;
     }
     __syncthreads();
@@ -1063,48 +1103,20 @@ __global__ __launch_bounds__(1024) void k_bucket_plan(const unsigned int *__rest
     }
 }
 
-constexpr int BUCKET_SAMPLE_THREADS = 1024;          // 16 waves share one 32 KB CDF chunk in LDS
+constexpr int BUCKET_RLIST_CAP = 1024;               // per-workgroup list of outputs that need a global redraw
 
-// One output particle: search the staged chunk, gather, kick, postselect (retries are rare and take
-// the global path).  z[] holds the d round-0 normals of this output.
-template <int DM, bool STAGE_X>
-__device__ __forceinline__ bool bucket_one_output(
-    int kind, int d, double min_freq, int postselect, const double *__restrict__ x_in, int64_t ldx_in,
-    int64_t n_in, const double *__restrict__ cdf, const double *lcdf, const double *lx, const int *G,
-    double gscale, int64_t base, int len, double lo_edge, double hi_edge, const LWArgs &lw, uint32_t k0, uint32_t k1, uint32_t epoch, int maxiter,
-    int64_t o, double upos, const double *z, double *__restrict__ x_out, const OutPlace &pl) {
-    double p[DM], xa[DM], zz[DM];
-    const double u = lo_edge + upos * (hi_edge - lo_edge);   // given the counts: uniform inside the chunk
-    int jl = G ? guided_upper_bound(lcdf, len, G, guide_cell(u, lo_edge, gscale), u) : upper_bound_skew(lcdf, len, u);
-    if (jl > len - 1) jl = len - 1;
-#pragma unroll
-    for (int m = 0; m < DM; ++m)
-        if (m < d) {
-            xa[m] = STAGE_X ? lx[m * BUCKET_CHUNK + jl] : x_in[m * ldx_in + base + jl];
-            zz[m] = z[m];
-        }
-    bool ok = false;
-    for (int round = 0;; ++round) {
-#pragma unroll
-        for (int m = 0; m < DM; ++m) {
-            if (m < d) {
-                double s = 0.0;
-#pragma unroll
-                for (int q = 0; q < DM; ++q)
-                    if (q < d) s += lw.S[m * d + q] * zz[q];
-                p[m] = (lw.a * xa[m] + (1.0 - lw.a) * lw.mean[m]) + s;
-            }
-        }
-        ok = !postselect || model_valid(kind, p, min_freq);
-        if (ok || round + 1 >= maxiter) break;
-        // rare: redraw a GLOBAL ancestor and a fresh kick from this output's own retry stream
-        PhiloxStream rng{(uint64_t)o, (epoch << 16) | (uint32_t)(round + 1), k0, k1};
+// Draw + kick of one redraw round (round >= 1) of output slot o from the GLOBAL CDF.
+template <int DM>
+__device__ __forceinline__ bool redraw_rounds(int kind, int d, double min_freq, const double *__restrict__ x_in,
+                                              int64_t ldx_in, int64_t n_in, const double *__restrict__ cdf,
+                                              const LWArgs &lw, uint32_t k0, uint32_t k1, uint32_t epoch,
+                                              int maxiter, int64_t o, double *p) {
+    for (int round = 1; round < maxiter; ++round) {
+        PhiloxStream rng{(uint64_t)o, (epoch << 16) | (uint32_t)round, k0, k1};
         double u0, unused;
         rng.uniforms(0, u0, unused);
         const int64_t j = search_right(cdf, n_in, u0);
-#pragma unroll
-        for (int m = 0; m < DM; ++m)
-            if (m < d) xa[m] = x_in[m * ldx_in + j];
+        double zz[DM];
 #pragma unroll
         for (int q = 0; q < DM; q += 2) {
             if (q < d) {
@@ -1114,29 +1126,50 @@ __device__ __forceinline__ bool bucket_one_output(
                 if (q + 1 < DM) zz[q + 1] = z1;
             }
         }
-    }
-    const int64_t row = place_row(pl, o);
 #pragma unroll
-    for (int m = 0; m < DM; ++m)
-        if (m < d) x_out[m * pl.ld_m + row * pl.ld_s] = p[m];
-    return ok;
+        for (int m = 0; m < DM; ++m) {
+            if (m < d) {
+                double s = 0.0;
+#pragma unroll
+                for (int q = 0; q < DM; ++q)
+                    if (q < d) s += lw.S[m * d + q] * zz[q];
+                p[m] = (lw.a * x_in[m * ldx_in + j] + (1.0 - lw.a) * lw.mean[m]) + s;
+            }
+        }
+        if (model_valid(kind, p, min_freq)) return true;
+    }
+    return false;
 }
 
-// STAGE_X: also stage the chunk's x rows in LDS (d <= 2) so the gather never leaves the CU.
-template <int D, bool STAGE_X, int BT, bool GUIDE = true>   // D = 0: runtime d; BT = threads per workgroup
+struct StoreLds {
+    double *lcdf;
+    int64_t base;
+    __device__ __forceinline__ void operator()(int64_t i, double v) const { lcdf[lds_skew((int)(i - base))] = v; }
+};
+
+// One workgroup per work item.  FROM_W: the chunk's CDF is SCANNED HERE from the weights (bit-identical
+// to k_chunk_scan), so the CDF never touches HBM; a particle that fails postselection on its first
+// try is queued for k_bucket_retry, which alone needs the (then materialised) global CDF.
+// !FROM_W: the CDF chunk is read from HBM and retries run in-thread (used when a CDF exists anyway).
+template <int D, int BT, bool FROM_W>   // D = 0: runtime d; BT = threads per workgroup
 __global__ __launch_bounds__(BT) void k_bucket_sample(
     int kind, int d_rt, double min_freq, int postselect, const double *__restrict__ x_in, int64_t ldx_in,
-    int64_t n_in, const double *__restrict__ cdf, int chunks, const long long *__restrict__ slot_off,
+    int64_t n_in, const double *__restrict__ w, double inv_norm, const double *__restrict__ offsets,
+    const double *__restrict__ cdf, int chunks, const long long *__restrict__ slot_off,
     const int *__restrict__ item_off, const int *__restrict__ item_chunk, LWArgs lw, uint32_t k0, uint32_t k1,
     uint32_t epoch, int maxiter, double *__restrict__ x_out, OutPlace pl,
-    unsigned long long *__restrict__ n_failed) {
+    unsigned long long *__restrict__ n_failed, unsigned int *__restrict__ retry_list,
+    unsigned long long *__restrict__ retry_count) {
     constexpr int DM = D > 0 ? D : QSMC_MAX_D;
-    constexpr int DX = STAGE_X ? DM : 1;
     const int d = D > 0 ? D : d_rt;
     __shared__ __attribute__((aligned(16))) double lcdf[BUCKET_CHUNK_LDS];
-    __shared__ __attribute__((aligned(16))) double lx[STAGE_X ? DX * BUCKET_CHUNK : 2];
-    __shared__ int lguide[GUIDE ? GUIDE_BINS + 1 : 1];
+    __shared__ int lguide[GUIDE_BINS + 1];
     __shared__ int lwtot[32];
+    __shared__ double wave_tot[SCAN_WAVES];
+    __shared__ int rlist[FROM_W ? BUCKET_RLIST_CAP : 1];
+    static_assert(BT >= SCAN_THREADS, "the in-sampler chunk scan needs 512 threads");
+    __shared__ int rcount;
+    __shared__ unsigned long long rbase;
     if ((int)blockIdx.x >= item_off[chunks]) return;
     const int c = item_chunk[blockIdx.x];
     const int part = (int)blockIdx.x - item_off[c];
@@ -1145,20 +1178,19 @@ __global__ __launch_bounds__(BT) void k_bucket_sample(
     const long long t1 = t0 + BUCKET_CAP < n_c ? t0 + BUCKET_CAP : n_c;
     const int64_t base = (int64_t)c * BUCKET_CHUNK;
     const int len = (int)((n_in - base) < BUCKET_CHUNK ? (n_in - base) : BUCKET_CHUNK);
-    for (int j = threadIdx.x; j < BUCKET_CHUNK; j += BT) {
-        lcdf[lds_skew(j)] = j < len ? cdf[base + j] : INFINITY;
-        if (STAGE_X) {
-#pragma unroll
-            for (int m = 0; m < DX; ++m) lx[m * BUCKET_CHUNK + j] = j < len ? x_in[m * ldx_in + base + j] : 0.0;
-        }
+    if (threadIdx.x == 0) rcount = 0;
+    if (FROM_W) {
+        for (int j = len + threadIdx.x; j < BUCKET_CHUNK; j += BT) lcdf[lds_skew(j)] = INFINITY;
+        chunk_scan_block(w, n_in, inv_norm, offsets, (int64_t)c, wave_tot, StoreLds{lcdf, base});
+    } else {
+        for (int j = threadIdx.x; j < BUCKET_CHUNK; j += BT) lcdf[lds_skew(j)] = j < len ? cdf[base + j] : INFINITY;
     }
     __syncthreads();
-    const double lo_edge = chunk_edge(cdf, n_in, c);
-    const double hi_edge = lcdf[lds_skew(len - 1)];
+    const double lo_edge = chunk_edge(offsets, c);
+    const double hi_edge = offsets[c + 1];
     const double gscale = (double)GUIDE_BINS / (hi_edge - lo_edge);
-    const bool use_guide = GUIDE && hi_edge > lo_edge && gscale < 1e300;     // workgroup-uniform
+    const bool use_guide = hi_edge > lo_edge && gscale < 1e300;     // workgroup-uniform
     if (use_guide) build_guide<BT>(lcdf, len, lo_edge, gscale, lguide, lwtot);
-    const int *G = use_guide ? lguide : nullptr;
     const int64_t o_begin = slot0 + t0, o_end = slot0 + t1;         // this item's output slots
     unsigned long long failed = 0;
     // pairs of output slots (2P, 2P+1) share their Philox blocks; a pair straddling two work items is
@@ -1180,12 +1212,70 @@ __global__ __launch_bounds__(BT) void k_bucket_sample(
         for (int e = 0; e < 2; ++e) {
             const int64_t o = 2 * P + e;
             if (o >= o_begin && o < o_end) {
-                const bool ok = bucket_one_output<DM, STAGE_X>(
-                    kind, d, min_freq, postselect, x_in, ldx_in, n_in, cdf, lcdf, lx, G, gscale, base, len, lo_edge, hi_edge,
-                    lw, k0, k1, epoch, maxiter, o, upos[e], z + e * d, x_out, pl);
+                // position inside this chunk: given the counts, uniform on [lo_edge, hi_edge)
+                const double u = lo_edge + upos[e] * (hi_edge - lo_edge);
+                int jl = use_guide ? guided_upper_bound(lcdf, len, lguide, guide_cell(u, lo_edge, gscale), u)
+                                   : upper_bound_skew(lcdf, len, u);
+                if (jl > len - 1) jl = len - 1;
+                double p[DM];
+#pragma unroll
+                for (int m = 0; m < DM; ++m) {
+                    if (m < d) {
+                        double sm = 0.0;
+#pragma unroll
+                        for (int q = 0; q < DM; ++q)
+                            if (q < d) sm += lw.S[m * d + q] * z[e * d + q];
+                        p[m] = (lw.a * x_in[m * ldx_in + base + jl] + (1.0 - lw.a) * lw.mean[m]) + sm;
+                    }
+                }
+                bool ok = !postselect || model_valid(kind, p, min_freq);
+                if (!ok && maxiter > 1) {
+                    if (FROM_W) {                   // queue for k_bucket_retry (needs the global CDF)
+                        const int idx = atomicAdd(&rcount, 1);
+                        if (idx < BUCKET_RLIST_CAP) rlist[idx] = (int)(o - o_begin);
+                        else retry_list[atomicAdd(retry_count, 1ull)] = (unsigned int)o;   // rare overflow path
+                        ok = true;                  // decided later
+                    } else {
+                        ok = redraw_rounds<DM>(kind, d, min_freq, x_in, ldx_in, n_in, cdf, lw, k0, k1, epoch, maxiter,
+                                               o, p);
+                    }
+                }
+                const int64_t row = place_row(pl, o);
+#pragma unroll
+                for (int m = 0; m < DM; ++m)
+                    if (m < d) x_out[m * pl.ld_m + row * pl.ld_s] = p[m];
                 if (!ok) ++failed;
             }
         }
+    }
+    if (failed) atomicAdd(n_failed, failed);
+    if (FROM_W) {
+        __syncthreads();
+        const int nl = rcount < BUCKET_RLIST_CAP ? rcount : BUCKET_RLIST_CAP;
+        if (nl == 0) return;
+        if (threadIdx.x == 0) rbase = atomicAdd(retry_count, (unsigned long long)nl);   // one atomic per workgroup
+        __syncthreads();
+        for (int i = threadIdx.x; i < nl; i += BT) retry_list[rbase + i] = (unsigned int)(o_begin + rlist[i]);
+    }
+}
+
+// Second chance for the queued outputs: redraw ancestor and kick from the global CDF (rounds 1..).
+__global__ __launch_bounds__(QSMC_BLOCK) void k_bucket_retry(
+    int kind, int d, double min_freq, const double *__restrict__ x_in, int64_t ldx_in, int64_t n_in,
+    const double *__restrict__ cdf, LWArgs lw, uint32_t k0, uint32_t k1, uint32_t epoch, int maxiter,
+    double *__restrict__ x_out, OutPlace pl, const unsigned int *__restrict__ retry_list,
+    const unsigned long long *__restrict__ retry_count, unsigned long long *__restrict__ n_failed) {
+    const unsigned long long cnt = *retry_count;
+    unsigned long long failed = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * QSMC_BLOCK + threadIdx.x; i < cnt;
+         i += (unsigned long long)gridDim.x * QSMC_BLOCK) {
+        const int64_t o = (int64_t)retry_list[i];
+        double p[QSMC_MAX_D];
+        const bool ok = redraw_rounds<QSMC_MAX_D>(kind, d, min_freq, x_in, ldx_in, n_in, cdf, lw, k0, k1, epoch,
+                                                  maxiter, o, p);
+        const int64_t row = place_row(pl, o);      // like the in-thread loop: the last round's value stays
+        for (int m = 0; m < d; ++m) x_out[m * pl.ld_m + row * pl.ld_s] = p[m];
+        if (!ok) ++failed;
     }
     if (failed) atomicAdd(n_failed, failed);
 }
@@ -1451,7 +1541,7 @@ int qsmc_create(qsmc_handle_t *out, int device) {
     memset(h, 0, sizeof(*h));
     h->device = device;
     hipError_t e = hipSetDevice(device);
-    if (e == hipSuccess) e = hipMalloc(&h->counter, sizeof(long long));
+    if (e == hipSuccess) e = hipMalloc(&h->counter, 2 * sizeof(long long));   // [0] failed, [1] retry count
     if (e == hipSuccess) e = hipMalloc(&h->red_out, REDUCE_OUT_MAX * sizeof(double));
     if (e == hipSuccess) e = hipHostMalloc(&h->mapped, REDUCE_OUT_MAX * sizeof(double), hipHostMallocMapped);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&h->mapped_dev, h->mapped, 0);
@@ -1472,6 +1562,7 @@ int qsmc_destroy(qsmc_handle_t h) {
     if (h->pinned) (void)hipHostFree(h->pinned);
     if (h->counter) (void)hipFree(h->counter);
     if (h->iscratch) (void)hipFree(h->iscratch);
+    if (h->cdf_scratch) (void)hipFree(h->cdf_scratch);
     if (h->red_out) (void)hipFree(h->red_out);
     if (h->mapped) (void)hipHostFree(h->mapped);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -1756,13 +1847,14 @@ int qsmc_cumsum(qsmc_handle_t h, const double *w, int64_t n, double norm, double
     const int64_t chunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
     int rc = ensure_partials(h, (size_t)chunks + 1);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_chunk_sums, dim3((unsigned)chunks), dim3(QSMC_BLOCK), 0, s, w, n, norm, h->partials);
+    const double inv_norm = 1.0 / norm;
+    hipLaunchKernelGGL(k_chunk_sums, dim3((unsigned)chunks), dim3(QSMC_BLOCK), 0, s, w, n, inv_norm, h->partials);
     if (chunks > (int64_t)SCAN_SUMS_THREADS * SCAN_SUMS_MAX_PER)
         hipLaunchKernelGGL(k_scan_sums_big, dim3(1), dim3(QSMC_BLOCK), 0, s, h->partials, chunks);
     else
         hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_SUMS_THREADS), 0, s, h->partials, chunks);
-    hipLaunchKernelGGL(k_chunk_scan, dim3((unsigned)chunks), dim3(QSMC_BLOCK), 0, s, w, n, norm, h->partials,
-                       cdf);
+    hipLaunchKernelGGL(k_chunk_scan, dim3((unsigned)chunks), dim3(SCAN_THREADS), 0, s, w, n, inv_norm, h->partials,
+                       cdf, (const unsigned long long *)nullptr);
     HIP_TRY(h, hipGetLastError());
     return QSMC_OK;
 }
@@ -1825,35 +1917,54 @@ static int read_counter(qsmc_ctx *h, int64_t *out, hipStream_t s) {
 }
 
 static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int32_t postselect,
-                                const double *x_in, int64_t ldx_in, int64_t n_in, int32_t d, const double *cdf,
-                                double a, const double *mean, const double *S, int64_t n_out, uint64_t seed,
-                                uint64_t epoch, int32_t maxiter, double *x_out, const OutPlace &pl,
+                                const double *x_in, int64_t ldx_in, int64_t n_in, int32_t d, const double *w,
+                                double norm, double a, const double *mean, const double *S, int64_t n_out,
+                                uint64_t seed, uint64_t epoch, int32_t maxiter, double *x_out, const OutPlace &pl,
                                 int64_t *n_failed_host, qsmc_stream_t stream) {
-    if (!h || !model || !x_in || !cdf || !mean || !S || !x_out || n_in <= 0 || n_out <= 0) return QSMC_ERR_INVALID;
+    if (!h || !model || !x_in || !mean || !S || !x_out || n_in <= 0 || n_out <= 0) return QSMC_ERR_INVALID;
     if (d != model->d || d < 1 || d > QSMC_MAX_D || maxiter < 1) return QSMC_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
     LWArgs lw;
     fill_lw(&lw, d, a, mean, S);
-    HIP_TRY(h, hipMemsetAsync(h->counter, 0, sizeof(long long), s));
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32) ^ (uint32_t)(epoch >> 16);
     const uint32_t ep = (uint32_t)(epoch & 0xFFFFu);
     const int64_t chunks64 = (n_in + BUCKET_CHUNK - 1) / BUCKET_CHUNK;
-    const bool bucketed = chunks64 <= BUCKET_MAX_CHUNKS && n_out >= 4 * BUCKET_CHUNK &&
+    // chunk sums -> monotone exclusive offsets (+ total) in h->partials
+    int rc = ensure_partials(h, (size_t)chunks64 + 1);
+    if (rc) return rc;
+    double *offsets = h->partials;
+    const double inv_norm = 1.0 / norm;
+    hipLaunchKernelGGL(k_chunk_sums, dim3((unsigned)chunks64), dim3(QSMC_BLOCK), 0, s, w, n_in, inv_norm, offsets);
+    if (chunks64 > (int64_t)SCAN_SUMS_THREADS * SCAN_SUMS_MAX_PER)
+        hipLaunchKernelGGL(k_scan_sums_big, dim3(1), dim3(QSMC_BLOCK), 0, s, offsets, chunks64);
+    else
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_SUMS_THREADS), 0, s, offsets, chunks64);
+    HIP_TRY(h, hipMemsetAsync(h->counter, 0, 2 * sizeof(long long), s));
+    unsigned long long *nf = reinterpret_cast<unsigned long long *>(h->counter);
+    unsigned long long *retry_count = nf + 1;
+    rc = ensure_cdf(h, (size_t)n_in);
+    if (rc) return rc;
+    const bool bucketed = chunks64 <= BUCKET_MAX_CHUNKS && n_out >= 4 * BUCKET_CHUNK && n_out < (1ll << 32) &&
                           getenv("QSMC_DIRECT_RESAMPLE") == nullptr;
     if (!bucketed) {
+        // small or very large clouds: materialise the CDF and search it directly
+        hipLaunchKernelGGL(k_chunk_scan, dim3((unsigned)chunks64), dim3(SCAN_THREADS), 0, s, w, n_in, inv_norm, offsets,
+                           h->cdf_scratch, (const unsigned long long *)nullptr);
         hipLaunchKernelGGL(k_resample_philox, dim3(grid_for(n_out, QSMC_BLOCK)), dim3(QSMC_BLOCK), 0, s,
-                           model->kind, d, model->min_freq, postselect, x_in, ldx_in, n_in, cdf, lw, n_out, k0,
-                           k1, ep, maxiter, x_out, pl, reinterpret_cast<unsigned long long *>(h->counter));
+                           model->kind, d, model->min_freq, postselect, x_in, ldx_in, n_in, h->cdf_scratch, lw, n_out,
+                           k0, k1, ep, maxiter, x_out, pl, nf);
     } else {
         const int chunks = (int)chunks64;
-        // integer scratch: hist[256][chunks] u32 | counts[chunks] u32 | slot_off[chunks+1] i64 | item_off[chunks+1] i32
+        // integer scratch: hist[256][chunks] | counts[chunks] | slot_off[chunks+1] i64 | item_off[chunks+1] |
+        //                  item_chunk[max_items] | retry_list[n_out] u32
         const size_t hist_b = (size_t)BUCKET_COUNT_BLOCKS * chunks * sizeof(unsigned int);
         const size_t counts_b = ((size_t)chunks * sizeof(unsigned int) + 15) & ~(size_t)15;
         const size_t slot_b = ((size_t)(chunks + 1) * sizeof(long long) + 15) & ~(size_t)15;
         const size_t item_b = ((size_t)(chunks + 1) * sizeof(int) + 15) & ~(size_t)15;
         const int max_items = chunks + (int)(n_out / BUCKET_CAP) + 1;
         const size_t map_b = ((size_t)max_items * sizeof(int) + 15) & ~(size_t)15;
-        int rc = ensure_iscratch(h, hist_b + counts_b + slot_b + item_b + map_b);
+        const size_t retry_b = (size_t)n_out * sizeof(unsigned int);
+        rc = ensure_iscratch(h, hist_b + counts_b + slot_b + item_b + map_b + retry_b);
         if (rc) return rc;
         unsigned char *basep = reinterpret_cast<unsigned char *>(h->iscratch);
         unsigned int *hist = reinterpret_cast<unsigned int *>(basep);
@@ -1861,35 +1972,43 @@ static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int3
         long long *slot_off = reinterpret_cast<long long *>(basep + hist_b + counts_b);
         int *item_off = reinterpret_cast<int *>(basep + hist_b + counts_b + slot_b);
         int *item_chunk = reinterpret_cast<int *>(basep + hist_b + counts_b + slot_b + item_b);
+        unsigned int *retry_list = reinterpret_cast<unsigned int *>(basep + hist_b + counts_b + slot_b + item_b + map_b);
         const size_t lds = (size_t)(chunks + (chunks >> 5) + (chunks >> 10) + 8) * sizeof(double) +
                            (size_t)chunks * sizeof(unsigned int) + (size_t)(GUIDE_BINS + 1 + 32) * sizeof(int);
         if (lds > 64 * 1024)
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(k_bucket_count),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_bucket_count, dim3(BUCKET_COUNT_BLOCKS), dim3(BUCKET_COUNT_THREADS), lds, s, cdf, n_in,
+        hipLaunchKernelGGL(k_bucket_count, dim3(BUCKET_COUNT_BLOCKS), dim3(BUCKET_COUNT_THREADS), lds, s, offsets,
                            chunks, n_out, k0, k1, ep, hist);
         hipLaunchKernelGGL(k_bucket_reduce, dim3((chunks + QSMC_BLOCK - 1) / QSMC_BLOCK), dim3(QSMC_BLOCK), 0, s,
                            hist, BUCKET_COUNT_BLOCKS, chunks, counts);
         hipLaunchKernelGGL(k_bucket_plan, dim3(1), dim3(1024), 0, s, counts, chunks, slot_off, item_off,
                            item_chunk);
-        unsigned long long *nf = reinterpret_cast<unsigned long long *>(h->counter);
-#define LAUNCH_B(DD, SX, BT)                                                                               \
-    hipLaunchKernelGGL((k_bucket_sample<DD, SX, BT>), dim3(max_items), dim3(BT), 0, s,                          \
-                       model->kind, d, model->min_freq, postselect, x_in, ldx_in, n_in, cdf, chunks, slot_off,   \
-                       item_off, item_chunk, lw, k0, k1, ep, maxiter, x_out, pl, nf)
+        // 512-thread workgroups, CDF chunk + guide in LDS (49 KB -> 3 resident workgroups per CU, so one
+        // workgroup's scan/guide-build phases overlap another's sampling loop); x is gathered from the
+        // chunk's 32 KB global window (L2-resident).
+#define LAUNCH_B(DD, BT)                                                                                       \
+    hipLaunchKernelGGL((k_bucket_sample<DD, BT, true>), dim3(max_items), dim3(BT), 0, s, model->kind, d,           \
+                       model->min_freq, postselect, x_in, ldx_in, n_in, w, inv_norm, offsets,                       \
+                       (const double *)nullptr, chunks, slot_off, item_off, item_chunk, lw, k0, k1, ep, maxiter,     \
+                       x_out, pl, nf, retry_list, retry_count)
         switch (d) {
-            // 512-thread workgroups, CDF chunk + guide in LDS (49 KB -> 3 resident workgroups per CU, so
-            // one workgroup's staging/guide-build phases overlap another's sampling loop); x is gathered
-            // from the chunk's 32 KB global window (L2-resident).  Measured at N = 1e7, d = 1: 121 us vs
-            // 155 us for 1024 threads with x staged in LDS (81 KB, one workgroup per CU).
-            case 1: LAUNCH_B(1, false, 512); break;
-            case 2: LAUNCH_B(2, false, 512); break;
-            case 3: LAUNCH_B(3, false, 512); break;
-            case 4: LAUNCH_B(4, false, 512); break;
-            case 16: LAUNCH_B(16, false, QSMC_BLOCK); break;  // 2-qubit tomography: all indices static
-            default: LAUNCH_B(0, false, QSMC_BLOCK); break;   // other d up to 16: runtime-d kernel
+            case 1: LAUNCH_B(1, 512); break;
+            case 2: LAUNCH_B(2, 512); break;
+            case 3: LAUNCH_B(3, 512); break;
+            case 4: LAUNCH_B(4, 512); break;
+            case 16: LAUNCH_B(16, 512); break;         // 2-qubit tomography: all indices static
+            default: LAUNCH_B(0, 512); break;          // other d up to 16: runtime-d kernel
         }
 #undef LAUNCH_B
+        if (postselect && maxiter > 1) {
+            // only if some particle asked for a global redraw do these two do any work
+            hipLaunchKernelGGL(k_chunk_scan, dim3((unsigned)chunks64), dim3(SCAN_THREADS), 0, s, w, n_in, inv_norm, offsets,
+                               h->cdf_scratch, (const unsigned long long *)retry_count);
+            hipLaunchKernelGGL(k_bucket_retry, dim3(grid_for(n_out / 16 + 1, QSMC_BLOCK)), dim3(QSMC_BLOCK), 0, s,
+                               model->kind, d, model->min_freq, x_in, ldx_in, n_in, h->cdf_scratch, lw, k0, k1, ep,
+                               maxiter, x_out, pl, retry_list, retry_count, nf);
+        }
     }
     HIP_TRY(h, hipGetLastError());
     if (n_failed_host) return read_counter(h, n_failed_host, s);
@@ -1901,21 +2020,21 @@ static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int3
 }
 
 int qsmc_lw_resample_philox(qsmc_handle_t h, const qsmc_model_t *model, int32_t postselect,
-                            const double *x_in, int64_t ldx_in, int64_t n_in, int32_t d, const double *cdf,
-                            double a, const double *mean, const double *S, int64_t n_out, uint64_t seed,
-                            uint64_t epoch, int32_t maxiter, double *x_out, int64_t ldx_out,
+                            const double *x_in, int64_t ldx_in, int64_t n_in, int32_t d, const double *w,
+                            double norm, double a, const double *mean, const double *S, int64_t n_out,
+                            uint64_t seed, uint64_t epoch, int32_t maxiter, double *x_out, int64_t ldx_out,
                             int64_t *n_failed_host, qsmc_stream_t stream) {
     OutPlace pl;
     memset(&pl, 0, sizeof(pl));
     pl.ld_m = ldx_out;
     pl.ld_s = 1;
-    return resample_philox_impl(h, model, postselect, x_in, ldx_in, n_in, d, cdf, a, mean, S, n_out, seed, epoch,
-                                maxiter, x_out, pl, n_failed_host, stream);
+    return resample_philox_impl(h, model, postselect, x_in, ldx_in, n_in, d, w, norm, a, mean, S, n_out, seed,
+                                epoch, maxiter, x_out, pl, n_failed_host, stream);
 }
 
 int qsmc_lw_resample_philox_sharded(qsmc_handle_t h, const qsmc_model_t *model, int32_t postselect,
                                     const double *x_in, int64_t ldx_in, int64_t n_in, int32_t d,
-                                    const double *cdf, double a, const double *mean, const double *S,
+                                    const double *w, double norm, double a, const double *mean, const double *S,
                                     const int64_t *dest_counts, int32_t n_dest, uint64_t seed, uint64_t epoch,
                                     int32_t maxiter, double *rows_out, int64_t *n_failed_host,
                                     qsmc_stream_t stream) {
@@ -1947,8 +2066,8 @@ int qsmc_lw_resample_philox_sharded(qsmc_handle_t h, const qsmc_model_t *model, 
     }
     pl.seg_start[n_dest] = start;
     if (n_out == 0) return QSMC_OK;
-    return resample_philox_impl(h, model, postselect, x_in, ldx_in, n_in, d, cdf, a, mean, S, n_out, seed, epoch,
-                                maxiter, rows_out, pl, n_failed_host, stream);
+    return resample_philox_impl(h, model, postselect, x_in, ldx_in, n_in, d, w, norm, a, mean, S, n_out, seed,
+                                epoch, maxiter, rows_out, pl, n_failed_host, stream);
 }
 
 int qsmc_last_resample_failed(qsmc_handle_t h, int64_t *n_failed_out, int32_t synchronize, qsmc_stream_t stream) {

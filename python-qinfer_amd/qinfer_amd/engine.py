@@ -254,7 +254,7 @@ class Engine:
             "qsmc_lw_perturb")
         return valid
 
-    def lw_resample_philox(self, desc, postselect, x_in, cdf, a, mean, S, n_out, seed, epoch, maxiter,
+    def lw_resample_philox(self, desc, postselect, x_in, w, norm, a, mean, S, n_out, seed, epoch, maxiter,
                            sync=True):
         """Returns (x_out, n_failed); with sync=False n_failed is None and the count is available
         from `last_resample_failed()` after the next stream synchronisation."""
@@ -265,9 +265,10 @@ class Engine:
         failed = C.c_int64()
         self._chk(self.lib.qsmc_lw_resample_philox(
             self.h, C.byref(desc), int(bool(postselect)), self._p(x_in), x_in.stride(0), x_in.shape[1], d,
-            self._p(cdf), float(a), _native.f64_ptr(mean), _native.f64_ptr(S), n_out,
-            C.c_uint64(seed & (2 ** 64 - 1)), C.c_uint64(epoch), int(maxiter), self._p(x_out),
-            x_out.stride(0), C.byref(failed) if sync else None, self.stream()), "qsmc_lw_resample_philox")
+            self._p(w) if w is not None else None, float(norm), float(a), _native.f64_ptr(mean),
+            _native.f64_ptr(S), n_out, C.c_uint64(seed & (2 ** 64 - 1)), C.c_uint64(epoch), int(maxiter),
+            self._p(x_out), x_out.stride(0), C.byref(failed) if sync else None, self.stream()),
+            "qsmc_lw_resample_philox")
         return x_out, (failed.value if sync else None)
 
     def last_resample_failed(self, synchronize=False):
@@ -276,7 +277,7 @@ class Engine:
                   "qsmc_last_resample_failed")
         return out.value
 
-    def lw_resample_philox_sharded(self, desc, postselect, x_in, cdf, a, mean, S, dest_counts, seed, epoch,
+    def lw_resample_philox_sharded(self, desc, postselect, x_in, w, norm, a, mean, S, dest_counts, seed, epoch,
                                    maxiter, sync=True):
         """Finished particles for every destination rank: AoS rows (sum(dest_counts), d), grouped by rank."""
         d = x_in.shape[0]
@@ -288,8 +289,9 @@ class Engine:
         failed = C.c_int64()
         self._chk(self.lib.qsmc_lw_resample_philox_sharded(
             self.h, C.byref(desc), int(bool(postselect)), self._p(x_in), x_in.stride(0), x_in.shape[1], d,
-            self._p(cdf), float(a), _native.f64_ptr(mean), _native.f64_ptr(S),
-            counts.ctypes.data_as(C.POINTER(C.c_int64)), len(counts), C.c_uint64(seed & (2 ** 64 - 1)),
+            self._p(w) if w is not None else None, float(norm), float(a), _native.f64_ptr(mean),
+            _native.f64_ptr(S), counts.ctypes.data_as(C.POINTER(C.c_int64)), len(counts),
+            C.c_uint64(seed & (2 ** 64 - 1)),
             C.c_uint64(epoch), int(maxiter), self._p(rows), C.byref(failed) if sync else None, self.stream()),
             "qsmc_lw_resample_philox_sharded")
         return rows, (failed.value if sync else None)

@@ -152,12 +152,12 @@ class ParticleShardGroup:
             st = eng.weight_stats(updater._weights(), 1.0)
             W = self.gather_rows(self.torch.tensor([st.sum], dtype=self.torch.float64))[:, 0]
         counts = self.plan_counts(W, n_local, epoch)
-        cdf = eng.cumsum(updater._weights(), float(W[self.rank]))    # local CDF, normalised locally
         seed_r = resampler._seed + 0x9E3779B97F4A7C15 * (self.rank + 1)
         # this shard draws, kicks and postselects the particles every destination takes from it
         defer = hasattr(resampler, "_flush_failed_warning")       # stay asynchronous; warn at the next sync
         rows, n_failed = eng.lw_resample_philox_sharded(model._native_desc(), resampler._postselect, updater._x,
-                                                        cdf, a, mean, S, counts[:, self.rank], seed_r, epoch,
+                                                        updater._w, float(W[self.rank]),   # local normaliser
+                                                        a, mean, S, counts[:, self.rank], seed_r, epoch,
                                                         resampler._maxiter, sync=not defer)
         if defer:
             resampler._pending_failed = eng

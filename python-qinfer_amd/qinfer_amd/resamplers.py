@@ -105,19 +105,20 @@ class LiuWestResampler(Resampler):
 
         native = bool(getattr(model, "_native", False))
         desc = model._native_desc() if native else None
-        x_in, w_in, norm = particle_dist._x, particle_dist._weights(), particle_dist._norm
-        cdf = eng.cumsum(w_in, norm)
+        x_in, norm = particle_dist._x, particle_dist._norm
 
         if self._device_rng and native:
+            # straight from the weights: the CDF is scanned chunk-wise inside the sampler, never in HBM
             self._epoch += 1
             defer = bool(getattr(self, "_defer_failed_check", False))
-            x_new, n_failed = eng.lw_resample_philox(desc, self._postselect, x_in, cdf, a, mean, S,
-                                                     n_particles, self._seed, self._epoch, self._maxiter,
-                                                     sync=not defer)
+            x_new, n_failed = eng.lw_resample_philox(desc, self._postselect, x_in, particle_dist._w, norm, a,
+                                                     mean, S, n_particles, self._seed, self._epoch,
+                                                     self._maxiter, sync=not defer)
             if defer:                  # stay asynchronous: the count is read at the caller's next sync
                 self._pending_failed = eng
                 n_failed = 0
         else:
+            cdf = eng.cumsum(particle_dist._weights(), norm)
             x_new, n_failed = self._legacy_draw(eng, model, desc, x_in, cdf, a, mean, S, n_particles)
         if n_failed:
             warnings.warn("Liu-West resampling failed to find valid models for {} particles within "

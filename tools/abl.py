@@ -7,11 +7,10 @@ n=10_000_000
 upd=qi.SMCUpdater(qi.SimplePrecessionModel(), n, qi.UniformDistribution([0.2,0.8]), device_rng=True, seed=1)
 upd.update(0,np.array([3.0]),check_for_resample=False)
 mean=upd.est_mean(); cov=upd.est_covariance_mtx(); S,_=eng.sqrtm_psd(cov,0.2)
-cdf=eng.cumsum(upd._w,upd._norm)
 desc=upd.model._native_desc()
 def run(tag):
-    for _ in range(3): eng.lw_resample_philox(desc,True,upd._x,cdf,0.98,mean,S,n,1,1,1000)
+    for _ in range(3): eng.lw_resample_philox(desc,True,upd._x,upd._w,upd._norm,0.98,mean,S,n,1,1,1000)
     torch.cuda.synchronize(); t=time.perf_counter()
-    for _ in range(10): eng.lw_resample_philox(desc,True,upd._x,cdf,0.98,mean,S,n,1,1,1000)
+    for _ in range(10): eng.lw_resample_philox(desc,True,upd._x,upd._w,upd._norm,0.98,mean,S,n,1,1,1000)
     torch.cuda.synchronize(); print(tag, (time.perf_counter()-t)/10*1e6,'us per resample call (count+reduce+plan+sample+readback)')
 run(os.environ.get('QSMC_ABLATE','0'))
