@@ -110,7 +110,7 @@ def lib_path():
 
 
 def check(handle, rc, what):
-    if rc != 0:
+    if rc:
         lib = load()
         msg = lib.qsmc_strerror(rc).decode()
         detail = lib.qsmc_last_hip_error(handle).decode() if handle else ""
