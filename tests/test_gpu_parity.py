@@ -372,6 +372,60 @@ def test_liu_west_philox_bucketed_vs_oracle(qi, eng, case):
     assert np.abs(freq - mass).max() < 6 * np.sqrt(mass.max() / n_out)
 
 
+def _deal_rows(dest_counts):
+    """NumPy twin of OutPlace/place_row: slot o -> row index in the destination-grouped output."""
+    counts = np.asarray(dest_counts, dtype=np.int64)
+    G = len(counts)
+    order = np.argsort(counts, kind="stable")
+    quota = counts[order]
+    base = np.concatenate([[0], np.cumsum(counts)[:-1]])
+    rows = np.empty(int(counts.sum()), dtype=np.int64)
+    o, prev = 0, 0
+    for s in range(G):
+        active = order[s:]
+        for rnd in range(prev, quota[s]):
+            for dst in active:
+                rows[o] = base[dst] + rnd
+                o += 1
+        prev = quota[s]
+    return rows
+
+
+@pytest.mark.parametrize("counts", [[30000, 50000, 10000], [25000], [0, 40000, 40000, 1], [7, 7, 7, 7, 7, 7, 7, 20000],
+                                    [29950, 30110, 29940]])
+def test_sharded_resample_placement(qi, eng, counts):
+    """qsmc_lw_resample_philox_sharded == the single-cloud sampler's particles, dealt round-robin to the
+    destination ranks with exact quotas (AoS rows grouped by destination)."""
+    rs = np.random.RandomState(5)
+    n, d = 50000, 3
+    model = qi.RandomizedBenchmarkingModel()
+    x = np.stack([rs.uniform(0.9, 1, n), rs.uniform(0.2, 0.5, n), rs.uniform(0.4, 0.6, n)], 1)
+    w = rs.random_sample(n) ** 2
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        pd = qi.ParticleDistribution(particle_locations=x, particle_weights=w)
+        mean, cov = pd.est_mean(), pd.est_covariance_mtx()
+    S, _ = eng.sqrtm_psd(cov, scale=0.3)
+    desc = model._native_desc()
+    n_out = int(np.sum(counts))
+    ref, f1 = eng.lw_resample_philox(desc, True, pd._x, pd._w, 1.0, 0.95, mean, S, n_out, 77, 3, 1000)
+    rows, f2 = eng.lw_resample_philox_sharded(desc, True, pd._x, pd._w, 1.0, 0.95, mean, S, counts, 77, 3, 1000)
+    ref = ref.cpu().numpy().T                               # (n_out, d), slot order
+    rows = rows.cpu().numpy()                                # (n_out, d), grouped by destination
+    assert rows.shape == (n_out, d) and f1 == f2 == 0
+    place = _deal_rows(counts)
+    assert sorted(place.tolist()) == list(range(n_out))      # a bijection with exact quotas
+    np.testing.assert_array_equal(rows[place], ref)
+    # with the near-equal quotas the shared multinomial plan produces (binomial spread ~ sqrt), every
+    # destination receives an even round-robin share of the whole chunk-sorted sample, not a block
+    if len(counts) > 1 and min(counts) > 0.9 * max(counts):
+        base = np.concatenate([[0], np.cumsum(counts)])
+        for r in range(len(counts)):
+            slots = np.nonzero((place >= base[r]) & (place < base[r + 1]))[0]
+            assert slots.max() - slots.min() > 0.98 * n_out
+            assert np.abs(np.diff(slots) - len(counts)).max() <= len(counts)
+
+
 def test_prior_uniform_philox(qi, eng):
     import philox as ph
     model = qi.RandomizedBenchmarkingModel()
