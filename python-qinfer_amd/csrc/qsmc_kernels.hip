@@ -596,11 +596,9 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_sum_partials(const double *__res
 // =============================================================================================
 // inclusive scan of w / norm  (three launches: chunk sums, scan of chunk sums, chunk scans)
 // =============================================================================================
-constexpr int SCAN_PER_LANE = 2;                                   // double2 per lane per tile
-constexpr int SCAN_WAVE_TILE = QSMC_WAVE * SCAN_PER_LANE;          // 128 elements
-constexpr int SCAN_TILES_PER_WAVE = 4;
-constexpr int SCAN_WAVE_CHUNK = SCAN_WAVE_TILE * SCAN_TILES_PER_WAVE;   // 512
-constexpr int SCAN_WAVES = 8;                                           // 512 threads scan one chunk
+constexpr int SCAN_PER_LANE = 8;                                   // 8 consecutive particles per lane (64 B)
+constexpr int SCAN_WAVE_CHUNK = QSMC_WAVE * SCAN_PER_LANE;         // 512 per wave
+constexpr int SCAN_WAVES = 8;                                      // 512 threads scan one chunk
 constexpr int SCAN_THREADS = SCAN_WAVES * QSMC_WAVE;
 constexpr int SCAN_CHUNK = SCAN_WAVE_CHUNK * SCAN_WAVES;                // 4096 per workgroup
 
@@ -738,13 +736,17 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_scan_sums_big(double *__restrict
 }
 
 // Per-chunk scan.  offsets[] has chunks + 1 monotone entries (exclusive offsets + total).
-// Every value is clamped into its wave's [lo, hi] offset window and then passed through an exact
-// prefix max, so the CDF is non-decreasing everywhere (searchsorted on it is well defined) while
-// differing from the sequential np.cumsum only by rounding.  The last entry of a chunk is DEFINED
-// as offsets[c + 1] (equal in exact arithmetic), so chunk edges and CDF entries are one and the
-// same numbers whether or not the CDF is ever written to HBM.
-// The first 512 threads (8 waves x 4 tiles x 128 elements) scan chunk c; every thread of the
-// workgroup must call (one barrier inside).  store(i_global, value) receives the values.
+// Lane l of wave v owns the 8 consecutive particles [512 v + 8 l, +8): a serial running sum in
+// registers (monotone by construction), one wave scan of the lane totals, 8 wave totals through LDS.
+// Every value is clamped into its wave's [lo, hi] offset window and the lanes' last values go through
+// an exact prefix max, so the CDF is non-decreasing everywhere (searchsorted on it is well defined)
+// while differing from the sequential np.cumsum only by rounding.  The last entry of a wave's
+// 512-particle segment is DEFINED as the window top hi, and the chunk's last entry as offsets[c + 1]
+// (equal in exact arithmetic), so chunk edges and CDF entries are one and the same numbers whether or
+// not the CDF is ever written to HBM, and each lane knows its predecessor's value without a barrier.
+// The first 512 threads scan chunk c; every thread of the workgroup must call (one barrier inside).
+// store(j, value, prev) receives the chunk-local index, the entry and the entry before it (the chunk's
+// lower edge for j = 0); calls are made wave-uniformly (`live` = the entry exists).
 template <class Store>
 __device__ __forceinline__ void chunk_scan_block(const double *__restrict__ w, int64_t n, double inv_norm,
                                                  const double *__restrict__ offsets, int64_t c,
@@ -752,54 +754,59 @@ __device__ __forceinline__ void chunk_scan_block(const double *__restrict__ w, i
     const bool act = threadIdx.x < SCAN_THREADS;
     const int lane = threadIdx.x & (QSMC_WAVE - 1);
     const int wave = (threadIdx.x / QSMC_WAVE) & (SCAN_WAVES - 1);
-    const int64_t wbase = c * SCAN_CHUNK + (int64_t)wave * SCAN_WAVE_CHUNK;
-    double r[SCAN_TILES_PER_WAVE][SCAN_PER_LANE];
-    double carry = 0.0;
+    const int j0 = wave * SCAN_WAVE_CHUNK + lane * SCAN_PER_LANE;          // chunk-local index of v[0]
+    const int64_t i0 = c * SCAN_CHUNK + j0;
+    double v[SCAN_PER_LANE];
+    double excl = 0.0;
     if (act) {
+        if (!w) {
 #pragma unroll
-        for (int t = 0; t < SCAN_TILES_PER_WAVE; ++t) {
-            const int64_t i = wbase + (int64_t)t * SCAN_WAVE_TILE + lane * SCAN_PER_LANE;
-            const double a = i < n ? (w ? w[i] : 1.0) * inv_norm : 0.0;
-            const double b = i + 1 < n ? (w ? w[i + 1] : 1.0) * inv_norm : 0.0;
-            const double pair = a + b;
-            const double inc = wave_inclusive_scan(pair, lane);
-            double excl = __shfl_up(inc, 1, QSMC_WAVE);
-            if (lane == 0) excl = 0.0;
-            excl += carry;
-            r[t][0] = excl + a;
-            r[t][1] = excl + pair;
-            carry += __shfl(inc, QSMC_WAVE - 1, QSMC_WAVE);
+            for (int k = 0; k < SCAN_PER_LANE; ++k) v[k] = i0 + k < n ? inv_norm : 0.0;
+        } else if (i0 + SCAN_PER_LANE <= n && ((uintptr_t)w & 31) == 0) {
+#pragma unroll
+            for (int k = 0; k < SCAN_PER_LANE; k += 4) {
+                const double4 t = *reinterpret_cast<const double4 *>(w + i0 + k);
+                v[k] = t.x * inv_norm; v[k + 1] = t.y * inv_norm; v[k + 2] = t.z * inv_norm; v[k + 3] = t.w * inv_norm;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < SCAN_PER_LANE; ++k) v[k] = i0 + k < n ? w[i0 + k] * inv_norm : 0.0;
         }
-        if (lane == 0) wave_tot[wave] = carry;
+#pragma unroll
+        for (int k = 1; k < SCAN_PER_LANE; ++k) v[k] += v[k - 1];
+        const double inc = wave_inclusive_scan(v[SCAN_PER_LANE - 1], lane);
+        excl = __shfl_up(inc, 1, QSMC_WAVE);
+        if (lane == 0) excl = 0.0;
+        if (lane == QSMC_WAVE - 1) wave_tot[wave] = inc;
     }
     __syncthreads();
     if (!act) return;
-    const double blo = offsets[c], bhi = offsets[c + 1];
-    const int64_t last = ((c + 1) * SCAN_CHUNK < n ? (c + 1) * SCAN_CHUNK : n) - 1;   // chunk's last particle
+    const double blo = c <= 0 ? 0.0 : offsets[c], bhi = offsets[c + 1];
+    const int len = (int)((n - c * SCAN_CHUNK) < SCAN_CHUNK ? (n - c * SCAN_CHUNK) : SCAN_CHUNK);
     double lo = blo;
     for (int wv = 0; wv < wave; ++wv) lo = fmin(lo + wave_tot[wv], bhi);
     const double hi = (wave == SCAN_WAVES - 1) ? bhi : fmin(lo + wave_tot[wave], bhi);
-    double run = lo;
 #pragma unroll
-    for (int t = 0; t < SCAN_TILES_PER_WAVE; ++t) {
-        const int64_t i = wbase + (int64_t)t * SCAN_WAVE_TILE + lane * SCAN_PER_LANE;
-        double a0 = fmin(fmax(lo + r[t][0], lo), hi);
-        double a1 = fmin(fmax(lo + r[t][1], lo), hi);
-        a1 = fmax(a1, a0);
-        const double m = wave_inclusive_max(a1, lane);
-        double prev = __shfl_up(m, 1, QSMC_WAVE);
-        prev = (lane == 0) ? run : fmax(prev, run);
-        a0 = fmax(a0, prev);
-        a1 = fmax(m, run);
-        run = fmax(run, __shfl(m, QSMC_WAVE - 1, QSMC_WAVE));
-        if (i < n) store(i, i == last ? bhi : a0);
-        if (i + 1 < n) store(i + 1, i + 1 == last ? bhi : a1);
+    for (int k = 0; k < SCAN_PER_LANE; ++k) v[k] = fmin(fmax(lo + (excl + v[k]), lo), hi);
+    const double m = wave_inclusive_max(v[SCAN_PER_LANE - 1], lane);
+    double prev = __shfl_up(m, 1, QSMC_WAVE);
+    if (lane == 0) prev = lo;                      // == the previous wave's (forced) last entry, or the chunk's lower edge
+#pragma unroll
+    for (int k = 0; k < SCAN_PER_LANE; ++k) {
+        const int j = j0 + k;
+        double a = fmax(v[k], prev);
+        if (j == len - 1) a = bhi;
+        else if (lane == QSMC_WAVE - 1 && k == SCAN_PER_LANE - 1) a = hi;
+        store(j, a, prev, j < len);
+        prev = a;
     }
 }
 
 struct StoreGlobal {
-    double *cdf;
-    __device__ __forceinline__ void operator()(int64_t i, double v) const { cdf[i] = v; }
+    double *cdf;                                   // + chunk base
+    __device__ __forceinline__ void operator()(int j, double v, double, bool live) const {
+        if (live) cdf[j] = v;
+    }
 };
 
 // Materialise the CDF.  gate != nullptr: do nothing unless *gate > 0 (the bucketed resampler only
@@ -810,7 +817,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_chunk_scan(const double *__res
                                                              const unsigned long long *__restrict__ gate) {
     __shared__ double wave_tot[SCAN_WAVES];
     if (gate && *gate == 0ull) return;
-    chunk_scan_block(w, n, inv_norm, offsets, (int64_t)blockIdx.x, wave_tot, StoreGlobal{cdf});
+    chunk_scan_block(w, n, inv_norm, offsets, (int64_t)blockIdx.x, wave_tot,
+                     StoreGlobal{cdf + (int64_t)blockIdx.x * SCAN_CHUNK});
 }
 
 // =============================================================================================
@@ -1007,11 +1015,13 @@ __device__ __forceinline__ int upper_bound_skew(const double *a, int m, double u
 // entries -> 1-2 probes.  Built per workgroup by an LDS histogram + scan; exactness is unaffected:
 // the final answer always comes from comparing the entries themselves with u.
 // ---------------------------------------------------------------------------------------------
-constexpr int GUIDE_BINS = 4096;
+constexpr int GUIDE_BINS = 4096;              // k_bucket_count: cells over [0, 1) for the chunk edges
+constexpr int SGUIDE_BINS = 2048;             // k_bucket_sample: cells over one chunk's 4096 CDF entries
 
+template <int BINS>
 __device__ __forceinline__ int guide_cell(double v, double lo, double scale) {
     const double t = (v - lo) * scale;
-    int k = t > 0.0 ? (t < (double)(GUIDE_BINS - 1) ? (int)t : GUIDE_BINS - 1) : 0;
+    int k = t > 0.0 ? (t < (double)(BINS - 1) ? (int)t : BINS - 1) : 0;
     return k;
 }
 
@@ -1022,7 +1032,7 @@ __device__ __forceinline__ void build_guide(const double *a, int m, double lo, d
     static_assert(GUIDE_BINS % BT == 0, "GUIDE_BINS must be a multiple of the workgroup size");
     for (int k = threadIdx.x; k <= GUIDE_BINS; k += BT) G[k] = 0;
     __syncthreads();
-    for (int j = threadIdx.x; j < m; j += BT) atomicAdd(&G[guide_cell(a[lds_skew(j)], lo, scale) + 1], 1);
+    for (int j = threadIdx.x; j < m; j += BT) atomicAdd(&G[guide_cell<GUIDE_BINS>(a[lds_skew(j)], lo, scale) + 1], 1);
     __syncthreads();
     // inclusive scan of G[1..GUIDE_BINS]: thread owns PER consecutive cells
     int loc[PER];
@@ -1049,9 +1059,12 @@ __device__ __forceinline__ void build_guide(const double *a, int m, double lo, d
 }
 
 // number of entries of the skewed table a[0..m) that are <= u, u lying in guide cell k
-__device__ __forceinline__ int guided_upper_bound(const double *a, int m, const int *G, int k, double u) {
-    int lo = G[k > 0 ? k - 1 : 0];
-    int hi = G[k + 2 < GUIDE_BINS ? k + 2 : GUIDE_BINS];
+// guide_cell is monotone and is applied identically to the entries and to u, so entries in cells
+// below k are <= u and entries in cells above k are > u: the answer lies in [G[k], G[k + 1]] exactly.
+template <class GT>
+__device__ __forceinline__ int guided_upper_bound(const double *a, int m, const GT *G, int k, double u) {
+    int lo = G[k];
+    int hi = G[k + 1];
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
         if (a[lds_skew(mid)] <= u) lo = mid + 1; else hi = mid;
@@ -1197,17 +1210,50 @@ __device__ __forceinline__ bool redraw_rounds(int kind, int d, double min_freq, 
     return false;
 }
 
-struct StoreLds {
+// chunk_scan_block sink of the sampler: the entry goes to the skewed LDS table and, in the same pass,
+// the guide table is filled -- entry j is the first one whose cell is >= k for every cell k in
+// (cell(prev), cell(v)], so G[k] = j there (G[0] = 0, G[SGUIDE_BINS] = len): no histogram, no atomics,
+// no extra barrier.  Runs longer than 8 cells (a dominant weight) are filled by the whole wave.
+struct StoreLdsGuide {
     double *lcdf;
-    int64_t base;
-    __device__ __forceinline__ void operator()(int64_t i, double v) const { lcdf[lds_skew((int)(i - base))] = v; }
+    unsigned short *G;
+    double lo_edge, gscale;
+    bool use_guide;                                // workgroup-uniform
+    int len;
+    int cp;                                        // cell of the previous entry (carried along the lane's run)
+    __device__ __forceinline__ void operator()(int j, double v, double prev, bool live) {
+        if (live) lcdf[lds_skew(j)] = v;
+        if (!use_guide) return;
+        const int lane = threadIdx.x & (QSMC_WAVE - 1);
+        if ((j & (SCAN_PER_LANE - 1)) == 0) cp = j == 0 ? -1 : guide_cell<SGUIDE_BINS>(prev, lo_edge, gscale);
+        const int cj = live ? guide_cell<SGUIDE_BINS>(v, lo_edge, gscale) : cp;
+        const unsigned short js = (unsigned short)j;
+        // straight-line for the common run lengths 0..4
+        if (cj > cp) G[cp + 1] = js;
+        if (cj > cp + 1) G[cp + 2] = js;
+        if (cj > cp + 2) G[cp + 3] = js;
+        if (cj > cp + 3) G[cp + 4] = js;
+        if (live && j == len - 1) G[SGUIDE_BINS] = (unsigned short)len;
+        unsigned long long long_runs = __ballot(cj > cp + 4);
+        while (long_runs) {                        // a dominant weight: the wave fills the run together
+            const int src = __ffsll((long long)long_runs) - 1;
+            long_runs &= long_runs - 1;
+            const int s0 = __shfl(cp + 5, src, QSMC_WAVE), e0 = __shfl(cj, src, QSMC_WAVE);
+            const int jj = __shfl(j, src, QSMC_WAVE);
+            for (int k = s0 + lane; k <= e0; k += QSMC_WAVE) G[k] = (unsigned short)jj;
+        }
+        cp = cj;
+    }
 };
 
-// One workgroup per work item.  FROM_W: the chunk's CDF is SCANNED HERE from the weights (bit-identical
+// One workgroup per work item.  The chunk's CDF is SCANNED HERE from the weights (bit-identical
 // to k_chunk_scan), so the CDF never touches HBM; a particle that fails postselection on its first
 // try is queued for k_bucket_retry, which alone needs the (then materialised) global CDF.
-// !FROM_W: the CDF chunk is read from HBM and retries run in-thread (used when a CDF exists anyway).
-template <int D, int BT, bool FROM_W>   // D = 0: runtime d; BT = threads per workgroup
+// Occupancy: 44 KB of LDS allows three workgroups per CU; the small-d instantiations are held to 80
+// VGPRs (6 waves/SIMD) so that the third one fits -- the kernel is VALU-issue bound and the extra
+// waves hide the LDS search and gather latency (121 -> 110 us at N = 1e7, d = 1).
+template <int D, int BT>   // D = 0: runtime d; BT = threads per workgroup
+__attribute__((amdgpu_waves_per_eu(D >= 1 && D <= 2 ? 6 : 1, 8)))
 __global__ __launch_bounds__(BT) void k_bucket_sample(
     int kind, int d_rt, double min_freq, int postselect, const double *__restrict__ x_in, int64_t ldx_in,
     int64_t n_in, const double *__restrict__ w, double inv_norm, const double *__restrict__ offsets,
@@ -1219,10 +1265,9 @@ __global__ __launch_bounds__(BT) void k_bucket_sample(
     constexpr int DM = D > 0 ? D : QSMC_MAX_D;
     const int d = D > 0 ? D : d_rt;
     __shared__ __attribute__((aligned(16))) double lcdf[BUCKET_CHUNK_LDS];
-    __shared__ int lguide[GUIDE_BINS + 1];
-    __shared__ int lwtot[32];
+    __shared__ unsigned short lguide[SGUIDE_BINS + 2];
     __shared__ double wave_tot[SCAN_WAVES];
-    __shared__ int rlist[FROM_W ? BUCKET_RLIST_CAP : 1];
+    __shared__ unsigned short rlist[BUCKET_RLIST_CAP];          // slot - o_begin < BUCKET_CAP
     static_assert(BT >= SCAN_THREADS, "the in-sampler chunk scan needs 512 threads");
     __shared__ int rcount;
     __shared__ unsigned long long rbase;
@@ -1235,18 +1280,13 @@ __global__ __launch_bounds__(BT) void k_bucket_sample(
     const int64_t base = (int64_t)c * BUCKET_CHUNK;
     const int len = (int)((n_in - base) < BUCKET_CHUNK ? (n_in - base) : BUCKET_CHUNK);
     if (threadIdx.x == 0) rcount = 0;
-    if (FROM_W) {
-        for (int j = len + threadIdx.x; j < BUCKET_CHUNK; j += BT) lcdf[lds_skew(j)] = INFINITY;
-        chunk_scan_block(w, n_in, inv_norm, offsets, (int64_t)c, wave_tot, StoreLds{lcdf, base});
-    } else {
-        for (int j = threadIdx.x; j < BUCKET_CHUNK; j += BT) lcdf[lds_skew(j)] = j < len ? cdf[base + j] : INFINITY;
-    }
-    __syncthreads();
     const double lo_edge = chunk_edge(offsets, c);
     const double hi_edge = offsets[c + 1];
-    const double gscale = (double)GUIDE_BINS / (hi_edge - lo_edge);
+    const double gscale = (double)SGUIDE_BINS / (hi_edge - lo_edge);
     const bool use_guide = hi_edge > lo_edge && gscale < 1e300;     // workgroup-uniform
-    if (use_guide) build_guide<BT>(lcdf, len, lo_edge, gscale, lguide, lwtot);
+    chunk_scan_block(w, n_in, inv_norm, offsets, (int64_t)c, wave_tot,
+                     StoreLdsGuide{lcdf, lguide, lo_edge, gscale, use_guide, len, -1});
+    __syncthreads();
     const int64_t o_begin = slot0 + t0, o_end = slot0 + t1;         // this item's output slots
     unsigned long long failed = 0;
     // pairs of output slots (2P, 2P+1) share their Philox blocks; a pair straddling two work items is
@@ -1270,7 +1310,7 @@ __global__ __launch_bounds__(BT) void k_bucket_sample(
             if (o >= o_begin && o < o_end) {
                 // position inside this chunk: given the counts, uniform on [lo_edge, hi_edge)
                 const double u = lo_edge + upos[e] * (hi_edge - lo_edge);
-                int jl = use_guide ? guided_upper_bound(lcdf, len, lguide, guide_cell(u, lo_edge, gscale), u)
+                int jl = use_guide ? guided_upper_bound(lcdf, len, lguide, guide_cell<SGUIDE_BINS>(u, lo_edge, gscale), u)
                                    : upper_bound_skew(lcdf, len, u);
                 if (jl > len - 1) jl = len - 1;
                 double p[DM];
@@ -1286,15 +1326,11 @@ __global__ __launch_bounds__(BT) void k_bucket_sample(
                 }
                 bool ok = !postselect || model_valid(kind, p, min_freq);
                 if (!ok && maxiter > 1) {
-                    if (FROM_W) {                   // queue for k_bucket_retry (needs the global CDF)
-                        const int idx = atomicAdd(&rcount, 1);
-                        if (idx < BUCKET_RLIST_CAP) rlist[idx] = (int)(o - o_begin);
-                        else retry_list[atomicAdd(retry_count, 1ull)] = (unsigned int)o;   // rare overflow path
-                        ok = true;                  // decided later
-                    } else {
-                        ok = redraw_rounds<DM>(kind, d, min_freq, x_in, ldx_in, n_in, cdf, lw, k0, k1, epoch, maxiter,
-                                               o, p);
-                    }
+                    // queue for k_bucket_retry (needs the global CDF)
+                    const int idx = atomicAdd(&rcount, 1);
+                    if (idx < BUCKET_RLIST_CAP) rlist[idx] = (unsigned short)(o - o_begin);
+                    else retry_list[atomicAdd(retry_count, 1ull)] = (unsigned int)o;   // rare overflow path
+                    ok = true;                      // decided later
                 }
                 const int64_t row = place_row(pl, o);
 #pragma unroll
@@ -1305,14 +1341,12 @@ __global__ __launch_bounds__(BT) void k_bucket_sample(
         }
     }
     if (failed) atomicAdd(n_failed, failed);
-    if (FROM_W) {
-        __syncthreads();
-        const int nl = rcount < BUCKET_RLIST_CAP ? rcount : BUCKET_RLIST_CAP;
-        if (nl == 0) return;
-        if (threadIdx.x == 0) rbase = atomicAdd(retry_count, (unsigned long long)nl);   // one atomic per workgroup
-        __syncthreads();
-        for (int i = threadIdx.x; i < nl; i += BT) retry_list[rbase + i] = (unsigned int)(o_begin + rlist[i]);
-    }
+    __syncthreads();
+    const int nl = rcount < BUCKET_RLIST_CAP ? rcount : BUCKET_RLIST_CAP;
+    if (nl == 0) return;
+    if (threadIdx.x == 0) rbase = atomicAdd(retry_count, (unsigned long long)nl);   // one atomic per workgroup
+    __syncthreads();
+    for (int i = threadIdx.x; i < nl; i += BT) retry_list[rbase + i] = (unsigned int)(o_begin + rlist[i]);
 }
 
 // Second chance for the queued outputs: redraw ancestor and kick from the global CDF (rounds 1..).
@@ -2040,7 +2074,7 @@ static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int3
         // workgroup's scan/guide-build phases overlap another's sampling loop); x is gathered from the
         // chunk's 32 KB global window (L2-resident).
 #define LAUNCH_B(DD, BT)                                                                                       \
-    hipLaunchKernelGGL((k_bucket_sample<DD, BT, true>), dim3(max_items), dim3(BT), 0, s, model->kind, d,           \
+    hipLaunchKernelGGL((k_bucket_sample<DD, BT>), dim3(max_items), dim3(BT), 0, s, model->kind, d,           \
                        model->min_freq, postselect, x_in, ldx_in, n_in, w, inv_norm, offsets,                       \
                        (const double *)nullptr, chunks, slot_off, item_off, item_chunk, lw, k0, k1, ep, maxiter,     \
                        x_out, pl, nf, retry_list, retry_count)
