@@ -11,6 +11,8 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -36,6 +38,9 @@ struct qsmc_ctx {
     double *red_out;       // device [REDUCE_OUT_MAX] totals of the last grid reduction
     double *mapped;        // pinned host memory the reducing workgroup writes directly ...
     double *mapped_dev;    // ... and its device alias
+    unsigned long long *flag;      // pinned host word: sequence number of the last completed reduction
+    unsigned long long *flag_dev;  // its device alias
+    unsigned long long seq;        // last sequence number handed to a reducing launch
     unsigned int *iscratch; // device integer scratch for the bucketed resampler
     size_t iscratch_cap;    // in bytes
     double *cdf_scratch;    // device CDF, materialised only for the direct sampler / global redraws
@@ -147,6 +152,8 @@ struct ReduceOut {
     double *out_dev;         // [NS + 1] device (always written)
     double *out_mapped;      // [NS + 1] device alias of pinned host memory (nullable)
     double *stats4;          // optional caller buffer in qsmc_update_stats_t order (nullable)
+    unsigned long long *flag;  // device alias of the pinned completion word (nullable)
+    unsigned long long seq;    // value to publish there once out_mapped is complete
 };
 
 template <int NS>
@@ -193,6 +200,10 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_reduce_partials(int nblocks, Red
             ro.stats4[3] = acc[2];
 #pragma unroll
             for (int k = 3; k < NS; ++k) ro.stats4[4 + (k - 3)] = acc[k];
+        }
+        if (ro.flag) {                   // the host spins on this word instead of hipStreamSynchronize
+            __threadfence_system();
+            *reinterpret_cast<volatile unsigned long long *>(ro.flag) = ro.seq;
         }
     }
 }
@@ -1472,7 +1483,30 @@ static ReduceOut make_reduce(qsmc_ctx *h, bool want_host, double *stats4) {
     ro.out_dev = h->red_out;
     ro.out_mapped = want_host ? h->mapped_dev : nullptr;
     ro.stats4 = stats4;
+    ro.flag = want_host ? h->flag_dev : nullptr;
+    ro.seq = want_host ? ++h->seq : 0ull;
     return ro;
+}
+
+// Wait for the reduction that was armed with the current h->seq.  hipStreamSynchronize costs ~12 us
+// after an (already finished) kernel on this stack; spinning on a pinned word the reducing workgroup
+// writes after a system-scope fence costs ~7 us (tools/lat/lat.hip).  Falls back to a real
+// synchronise after 20 ms so that a faulted launch reports its HIP error instead of hanging.
+static int wait_reduction(qsmc_ctx *h, hipStream_t s) {
+    const unsigned long long want = h->seq;
+    volatile unsigned long long *f = h->flag;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; ++spins) {
+        if (*f == want) {
+            std::atomic_thread_fence(std::memory_order_acquire);
+            return QSMC_OK;
+        }
+        __builtin_ia32_pause();
+        if ((spins & 0xfff) == 0xfff &&
+            std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+    }
+    HIP_TRY(h, hipStreamSynchronize(s));
+    return QSMC_OK;
 }
 
 static int launch_reduce(qsmc_ctx *h, int ns, int grid, const ReduceOut &ro, hipStream_t s) {
@@ -1495,7 +1529,8 @@ static int launch_reduce(qsmc_ctx *h, int ns, int grid, const ReduceOut &ro, hip
 static int collect_stats(qsmc_ctx *h, int ns, qsmc_update_stats_t *stats_host, double *extra_host, int n_extra,
                          hipStream_t s) {
     if (!stats_host && !extra_host) return QSMC_OK;
-    HIP_TRY(h, hipStreamSynchronize(s));
+    const int rc = wait_reduction(h, s);
+    if (rc) return rc;
     if (stats_host) {
         stats_host->sum = h->mapped[0];
         stats_host->sumsq = h->mapped[1];
@@ -1565,7 +1600,8 @@ static int hyp_launch(qsmc_ctx *h, const qsmc_model_t *model, const double *x, i
     HIP_TRY(h, hipGetLastError());
     rc = launch_reduce(h, NS, grid, ro, s);
     if (rc) return rc;
-    HIP_TRY(h, hipStreamSynchronize(s));
+    rc = wait_reduction(h, s);
+    if (rc) return rc;
     memcpy(out_host, h->mapped, (size_t)n_o * PER * sizeof(double));
     return QSMC_OK;
 }
@@ -1635,6 +1671,9 @@ int qsmc_create(qsmc_handle_t *out, int device) {
     if (e == hipSuccess) e = hipMalloc(&h->red_out, REDUCE_OUT_MAX * sizeof(double));
     if (e == hipSuccess) e = hipHostMalloc(&h->mapped, REDUCE_OUT_MAX * sizeof(double), hipHostMallocMapped);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&h->mapped_dev, h->mapped, 0);
+    if (e == hipSuccess) e = hipHostMalloc(&h->flag, 64, hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&h->flag_dev, h->flag, 0);
+    if (e == hipSuccess) *h->flag = 0ull;
     if (e == hipSuccess) e = hipEventCreate(&h->ev0);
     if (e == hipSuccess) e = hipEventCreate(&h->ev1);
     if (e != hipSuccess) {
@@ -1655,6 +1694,7 @@ int qsmc_destroy(qsmc_handle_t h) {
     if (h->cdf_scratch) (void)hipFree(h->cdf_scratch);
     if (h->red_out) (void)hipFree(h->red_out);
     if (h->mapped) (void)hipHostFree(h->mapped);
+    if (h->flag) (void)hipHostFree(h->flag);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     delete h;
@@ -1800,7 +1840,8 @@ int qsmc_update_multi(qsmc_handle_t h, const qsmc_model_t *model, const double *
     HIP_TRY(h, hipGetLastError());
     rc = launch_reduce(h, ns, grid, ro, s);
     if (rc) return rc;
-    HIP_TRY(h, hipStreamSynchronize(s));
+    rc = wait_reduction(h, s);
+    if (rc) return rc;
     for (int j = 0; j < k; ++j) {
         stats_host[j].sum = h->mapped[3 * j];
         stats_host[j].sumsq = h->mapped[3 * j + 1];
@@ -1892,7 +1933,8 @@ int qsmc_moments(qsmc_handle_t h, const double *x, int64_t ldx, int64_t n, int32
         if (out_dev)
             HIP_TRY(h, hipMemcpyAsync(out_dev, h->red_out, K * sizeof(double), hipMemcpyDeviceToDevice, s));
         if (out_host) {
-            HIP_TRY(h, hipStreamSynchronize(s));
+            rc = wait_reduction(h, s);
+            if (rc) return rc;
             memcpy(out_host, h->mapped, K * sizeof(double));
         }
         return QSMC_OK;
