@@ -225,6 +225,16 @@ int qsmc_lw_resample_philox(qsmc_handle_t h, const qsmc_model_t *model, int32_t 
                             double *x_out, int64_t ldx_out, int64_t *n_failed_host,
                             qsmc_stream_t stream);
 
+/* Queue the weight-only prefix of the NEXT qsmc_lw_resample_philox call (chunk sums, offsets, and for
+ * the bucketed sampler the multinomial chunk counts and work-item plan): none of it needs the mean or
+ * the covariance square root, so a caller can launch it the moment its n_ess test fails
+ * (smc.py:273-277) and form mean / cov / sqrtm (resamplers.py:266-300) on the host while the GPU is
+ * already busy.  The following qsmc_lw_resample_philox with the SAME (w, n_in, norm, n_out, seed,
+ * epoch, stream) then starts at the sampling kernel; any other arguments, or any call in between that
+ * changes weights, simply redo the prefix -- results are identical either way. */
+int qsmc_lw_resample_prepare(qsmc_handle_t h, const double *w, int64_t n_in, double norm, int64_t n_out,
+                             uint64_t seed, uint64_t epoch, qsmc_stream_t stream);
+
 /* qsmc_lw_resample_philox with n_failed_host == NULL does not synchronise: the failed-particle count
  * is written to pinned host memory by the stream; read it here once `stream` has been synchronised by
  * any later call (synchronize = 0), or force the wait (synchronize = 1). */

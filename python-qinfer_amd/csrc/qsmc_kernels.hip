@@ -41,6 +41,16 @@ struct qsmc_ctx {
     unsigned long long *flag;      // pinned host word: sequence number of the last completed reduction
     unsigned long long *flag_dev;  // its device alias
     unsigned long long seq;        // last sequence number handed to a reducing launch
+    double *rs_offsets;            // resampler: chunk offsets (own buffer: survives other calls' scratch use)
+    size_t rs_offsets_cap;
+    struct {                       // weight-only prefix of a resample already queued (qsmc_lw_resample_prepare)
+        int valid;
+        const double *w;
+        int64_t n_in, n_out;
+        double norm;
+        uint64_t seed, epoch;
+        hipStream_t stream;
+    } prep;
     unsigned int *iscratch; // device integer scratch for the bucketed resampler
     size_t iscratch_cap;    // in bytes
     double *cdf_scratch;    // device CDF, materialised only for the direct sampler / global redraws
@@ -80,6 +90,16 @@ static int ensure_scratch(qsmc_ctx *h, size_t n) {
     h->scratch_cap = 0;
     HIP_TRY(h, hipMalloc(&h->scratch, n * sizeof(double)));
     h->scratch_cap = n;
+    return QSMC_OK;
+}
+
+static int ensure_rs_offsets(qsmc_ctx *h, size_t n) {
+    if (h->rs_offsets_cap >= n) return QSMC_OK;
+    if (h->rs_offsets) HIP_TRY(h, hipFree(h->rs_offsets));
+    h->rs_offsets = nullptr;
+    h->rs_offsets_cap = 0;
+    HIP_TRY(h, hipMalloc(&h->rs_offsets, n * sizeof(double)));
+    h->rs_offsets_cap = n;
     return QSMC_OK;
 }
 
@@ -1687,6 +1707,7 @@ int qsmc_create(qsmc_handle_t *out, int device) {
 int qsmc_destroy(qsmc_handle_t h) {
     if (!h) return QSMC_OK;
     if (h->partials) (void)hipFree(h->partials);
+    if (h->rs_offsets) (void)hipFree(h->rs_offsets);
     if (h->scratch) (void)hipFree(h->scratch);
     if (h->pinned) (void)hipHostFree(h->pinned);
     if (h->counter) (void)hipFree(h->counter);
@@ -1763,6 +1784,7 @@ int qsmc_update_fused(qsmc_handle_t h, const qsmc_model_t *model, const double *
                       const double *w_in, double *w_out, double prev_norm, const qsmc_expparam_t *exp,
                       int64_t outcome, double *stats_dev, qsmc_update_stats_t *stats_host, double *moments_host,
                       qsmc_stream_t stream) {
+    if (h) h->prep.valid = 0;        // weights / counters are about to change: drop a queued resample prefix
     if (!h || !x || !w_out || !exp || n <= 0) return QSMC_ERR_INVALID;      // w_in == NULL: all-ones weights
     int rc = check_model(model);
     if (rc) return rc;
@@ -1803,6 +1825,7 @@ int qsmc_update_multi(qsmc_handle_t h, const qsmc_model_t *model, const double *
                       const double *w_in, double *w_out, double prev_norm, const qsmc_expparam_t *exps,
                       const int64_t *outcomes, int32_t k, qsmc_update_stats_t *stats_host, double *moments_host,
                       qsmc_stream_t stream) {
+    if (h) h->prep.valid = 0;        // weights / counters are about to change: drop a queued resample prefix
     if (!h || !x || !w_out || !exps || !outcomes || !stats_host || n <= 0 || k < 1 || k > MULTI_KMAX)
         return QSMC_ERR_INVALID;
     int rc = check_model(model);
@@ -1874,12 +1897,14 @@ int qsmc_hypothetical_sums(qsmc_handle_t h, const qsmc_model_t *model, const dou
 int qsmc_update_from_likelihood(qsmc_handle_t h, const double *L, int64_t n, const double *w_in,
                                 double *w_out, double prev_norm, double *stats_dev,
                                 qsmc_update_stats_t *stats_host, qsmc_stream_t stream) {
+    if (h) h->prep.valid = 0;        // weights / counters are about to change: drop a queued resample prefix
     if (!h || !L || !w_in || !w_out || n <= 0) return QSMC_ERR_INVALID;
     return weights_pass<0>(h, L, n, w_in, w_out, prev_norm, stats_dev, stats_host, (hipStream_t)stream);
 }
 
 int qsmc_clip_weights(qsmc_handle_t h, double *w, int64_t n, double norm, double *stats_dev,
                       qsmc_update_stats_t *stats_host, qsmc_stream_t stream) {
+    if (h) h->prep.valid = 0;        // weights / counters are about to change: drop a queued resample prefix
     if (!h || !w || n <= 0) return QSMC_ERR_INVALID;
     return weights_pass<1>(h, nullptr, n, w, w, norm, stats_dev, stats_host, (hipStream_t)stream);
 }
@@ -1892,12 +1917,14 @@ int qsmc_weight_stats(qsmc_handle_t h, const double *w, int64_t n, double norm, 
 
 int qsmc_normalize_weights(qsmc_handle_t h, const double *w_in, double *w_out, int64_t n, double norm,
                            qsmc_stream_t stream) {
+    if (h) h->prep.valid = 0;        // weights / counters are about to change: drop a queued resample prefix
     if (!h || !w_in || !w_out || n < 0) return QSMC_ERR_INVALID;
     if (n == 0) return QSMC_OK;
     return weights_pass<2>(h, nullptr, n, w_in, w_out, norm, nullptr, nullptr, (hipStream_t)stream);
 }
 
 int qsmc_fill(qsmc_handle_t h, double *w, int64_t n, double value, qsmc_stream_t stream) {
+    if (h) h->prep.valid = 0;        // weights / counters are about to change: drop a queued resample prefix
     if (!h || !w || n < 0) return QSMC_ERR_INVALID;
     if (n == 0) return QSMC_OK;
     hipLaunchKernelGGL(k_fill, dim3(grid_for(n, QSMC_BLOCK * 4)), dim3(QSMC_BLOCK), 0, (hipStream_t)stream, w,
@@ -2044,6 +2071,92 @@ static int read_counter(qsmc_ctx *h, int64_t *out, hipStream_t s) {
     return QSMC_OK;
 }
 
+// Layout of the bucketed resampler's integer scratch:
+//   hist[256][chunks] | counts[chunks] | slot_off[chunks+1] i64 | item_off[chunks+1] | item_chunk[max_items] |
+//   retry_list[n_out] u32
+struct BucketPlan {
+    bool bucketed;
+    int chunks, max_items;
+    unsigned int *hist, *counts, *retry_list;
+    long long *slot_off;
+    int *item_off, *item_chunk;
+};
+
+static bool use_buckets(int64_t chunks64, int64_t n_out) {
+    return chunks64 <= BUCKET_MAX_CHUNKS && n_out >= 4 * BUCKET_CHUNK && n_out < (1ll << 32) &&
+           getenv("QSMC_DIRECT_RESAMPLE") == nullptr;
+}
+
+static int bucket_plan_layout(qsmc_ctx *h, int64_t chunks64, int64_t n_out, BucketPlan *bp) {
+    bp->bucketed = use_buckets(chunks64, n_out);
+    if (!bp->bucketed) return QSMC_OK;
+    const int chunks = (int)chunks64;
+    const size_t hist_b = (size_t)BUCKET_COUNT_BLOCKS * chunks * sizeof(unsigned int);
+    const size_t counts_b = ((size_t)chunks * sizeof(unsigned int) + 15) & ~(size_t)15;
+    const size_t slot_b = ((size_t)(chunks + 1) * sizeof(long long) + 15) & ~(size_t)15;
+    const size_t item_b = ((size_t)(chunks + 1) * sizeof(int) + 15) & ~(size_t)15;
+    const int max_items = chunks + (int)(n_out / BUCKET_CAP) + 1;
+    const size_t map_b = ((size_t)max_items * sizeof(int) + 15) & ~(size_t)15;
+    const size_t retry_b = (size_t)n_out * sizeof(unsigned int);
+    const int rc = ensure_iscratch(h, hist_b + counts_b + slot_b + item_b + map_b + retry_b);
+    if (rc) return rc;
+    unsigned char *basep = reinterpret_cast<unsigned char *>(h->iscratch);
+    bp->chunks = chunks;
+    bp->max_items = max_items;
+    bp->hist = reinterpret_cast<unsigned int *>(basep);
+    bp->counts = reinterpret_cast<unsigned int *>(basep + hist_b);
+    bp->slot_off = reinterpret_cast<long long *>(basep + hist_b + counts_b);
+    bp->item_off = reinterpret_cast<int *>(basep + hist_b + counts_b + slot_b);
+    bp->item_chunk = reinterpret_cast<int *>(basep + hist_b + counts_b + slot_b + item_b);
+    bp->retry_list = reinterpret_cast<unsigned int *>(basep + hist_b + counts_b + slot_b + item_b + map_b);
+    return QSMC_OK;
+}
+
+static void philox_keys(uint64_t seed, uint64_t epoch, uint32_t *k0, uint32_t *k1, uint32_t *ep) {
+    *k0 = (uint32_t)seed;
+    *k1 = (uint32_t)(seed >> 32) ^ (uint32_t)(epoch >> 16);
+    *ep = (uint32_t)(epoch & 0xFFFFu);
+}
+
+// The part of a device-RNG resample that needs only the weights: chunk sums -> monotone offsets, the
+// zeroed counters and (bucketed sampler) the multinomial chunk counts and the work-item plan.  It can
+// be queued the moment the n_ess test fails, before the host has formed mean / covariance / sqrtm.
+static int resample_prefix(qsmc_ctx *h, const double *w, int64_t n_in, double norm, int64_t n_out, uint64_t seed,
+                           uint64_t epoch, hipStream_t s) {
+    uint32_t k0, k1, ep;
+    philox_keys(seed, epoch, &k0, &k1, &ep);
+    const int64_t chunks64 = (n_in + BUCKET_CHUNK - 1) / BUCKET_CHUNK;
+    int rc = ensure_rs_offsets(h, (size_t)chunks64 + 1);
+    if (rc) return rc;
+    double *offsets = h->rs_offsets;
+    const double inv_norm = 1.0 / norm;
+    hipLaunchKernelGGL(k_chunk_sums, dim3((unsigned)chunks64), dim3(QSMC_BLOCK), 0, s, w, n_in, inv_norm, offsets);
+    if (chunks64 > (int64_t)SCAN_SUMS_THREADS * SCAN_SUMS_MAX_PER)
+        hipLaunchKernelGGL(k_scan_sums_big, dim3(1), dim3(QSMC_BLOCK), 0, s, offsets, chunks64);
+    else
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_SUMS_THREADS), 0, s, offsets, chunks64);
+    HIP_TRY(h, hipMemsetAsync(h->counter, 0, 2 * sizeof(long long), s));
+    BucketPlan bp;
+    rc = bucket_plan_layout(h, chunks64, n_out, &bp);
+    if (rc) return rc;
+    if (bp.bucketed) {
+        const int chunks = bp.chunks;
+        const size_t lds = (size_t)(chunks + (chunks >> 5) + (chunks >> 10) + 8) * sizeof(double) +
+                           (size_t)chunks * sizeof(unsigned int) + (size_t)(GUIDE_BINS + 1 + 32) * sizeof(int);
+        if (lds > 64 * 1024)
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(k_bucket_count),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_bucket_count, dim3(BUCKET_COUNT_BLOCKS), dim3(BUCKET_COUNT_THREADS), lds, s, offsets,
+                           chunks, n_out, k0, k1, ep, bp.hist);
+        hipLaunchKernelGGL(k_bucket_reduce, dim3((chunks + QSMC_BLOCK - 1) / QSMC_BLOCK), dim3(QSMC_BLOCK), 0, s,
+                           bp.hist, BUCKET_COUNT_BLOCKS, chunks, bp.counts);
+        hipLaunchKernelGGL(k_bucket_plan, dim3(1), dim3(1024), 0, s, bp.counts, chunks, bp.slot_off, bp.item_off,
+                           bp.item_chunk);
+    }
+    HIP_TRY(h, hipGetLastError());
+    return QSMC_OK;
+}
+
 static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int32_t postselect,
                                 const double *x_in, int64_t ldx_in, int64_t n_in, int32_t d, const double *w,
                                 double norm, double a, const double *mean, const double *S, int64_t n_out,
@@ -2054,27 +2167,28 @@ static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int3
     hipStream_t s = (hipStream_t)stream;
     LWArgs lw;
     fill_lw(&lw, d, a, mean, S);
-    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32) ^ (uint32_t)(epoch >> 16);
-    const uint32_t ep = (uint32_t)(epoch & 0xFFFFu);
+    uint32_t k0, k1, ep;
+    philox_keys(seed, epoch, &k0, &k1, &ep);
     const int64_t chunks64 = (n_in + BUCKET_CHUNK - 1) / BUCKET_CHUNK;
-    // chunk sums -> monotone exclusive offsets (+ total) in h->partials
-    int rc = ensure_partials(h, (size_t)chunks64 + 1);
-    if (rc) return rc;
-    double *offsets = h->partials;
+    const bool prepared = h->prep.valid && h->prep.w == w && h->prep.n_in == n_in && h->prep.n_out == n_out &&
+                          h->prep.norm == norm && h->prep.seed == seed && h->prep.epoch == epoch &&
+                          h->prep.stream == s;
+    h->prep.valid = 0;
+    int rc = QSMC_OK;
+    if (!prepared) {
+        rc = resample_prefix(h, w, n_in, norm, n_out, seed, epoch, s);
+        if (rc) return rc;
+    }
+    double *offsets = h->rs_offsets;
     const double inv_norm = 1.0 / norm;
-    hipLaunchKernelGGL(k_chunk_sums, dim3((unsigned)chunks64), dim3(QSMC_BLOCK), 0, s, w, n_in, inv_norm, offsets);
-    if (chunks64 > (int64_t)SCAN_SUMS_THREADS * SCAN_SUMS_MAX_PER)
-        hipLaunchKernelGGL(k_scan_sums_big, dim3(1), dim3(QSMC_BLOCK), 0, s, offsets, chunks64);
-    else
-        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_SUMS_THREADS), 0, s, offsets, chunks64);
-    HIP_TRY(h, hipMemsetAsync(h->counter, 0, 2 * sizeof(long long), s));
     unsigned long long *nf = reinterpret_cast<unsigned long long *>(h->counter);
     unsigned long long *retry_count = nf + 1;
     rc = ensure_cdf(h, (size_t)n_in);
     if (rc) return rc;
-    const bool bucketed = chunks64 <= BUCKET_MAX_CHUNKS && n_out >= 4 * BUCKET_CHUNK && n_out < (1ll << 32) &&
-                          getenv("QSMC_DIRECT_RESAMPLE") == nullptr;
-    if (!bucketed) {
+    BucketPlan bp;
+    rc = bucket_plan_layout(h, chunks64, n_out, &bp);      // no reallocation: the prefix sized it
+    if (rc) return rc;
+    if (!bp.bucketed) {
         // small or very large clouds: materialise the CDF and search it directly
         hipLaunchKernelGGL(k_chunk_scan, dim3((unsigned)chunks64), dim3(SCAN_THREADS), 0, s, w, n_in, inv_norm, offsets,
                            h->cdf_scratch, (const unsigned long long *)nullptr);
@@ -2082,44 +2196,15 @@ static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int3
                            model->kind, d, model->min_freq, postselect, x_in, ldx_in, n_in, h->cdf_scratch, lw, n_out,
                            k0, k1, ep, maxiter, x_out, pl, nf);
     } else {
-        const int chunks = (int)chunks64;
-        // integer scratch: hist[256][chunks] | counts[chunks] | slot_off[chunks+1] i64 | item_off[chunks+1] |
-        //                  item_chunk[max_items] | retry_list[n_out] u32
-        const size_t hist_b = (size_t)BUCKET_COUNT_BLOCKS * chunks * sizeof(unsigned int);
-        const size_t counts_b = ((size_t)chunks * sizeof(unsigned int) + 15) & ~(size_t)15;
-        const size_t slot_b = ((size_t)(chunks + 1) * sizeof(long long) + 15) & ~(size_t)15;
-        const size_t item_b = ((size_t)(chunks + 1) * sizeof(int) + 15) & ~(size_t)15;
-        const int max_items = chunks + (int)(n_out / BUCKET_CAP) + 1;
-        const size_t map_b = ((size_t)max_items * sizeof(int) + 15) & ~(size_t)15;
-        const size_t retry_b = (size_t)n_out * sizeof(unsigned int);
-        rc = ensure_iscratch(h, hist_b + counts_b + slot_b + item_b + map_b + retry_b);
-        if (rc) return rc;
-        unsigned char *basep = reinterpret_cast<unsigned char *>(h->iscratch);
-        unsigned int *hist = reinterpret_cast<unsigned int *>(basep);
-        unsigned int *counts = reinterpret_cast<unsigned int *>(basep + hist_b);
-        long long *slot_off = reinterpret_cast<long long *>(basep + hist_b + counts_b);
-        int *item_off = reinterpret_cast<int *>(basep + hist_b + counts_b + slot_b);
-        int *item_chunk = reinterpret_cast<int *>(basep + hist_b + counts_b + slot_b + item_b);
-        unsigned int *retry_list = reinterpret_cast<unsigned int *>(basep + hist_b + counts_b + slot_b + item_b + map_b);
-        const size_t lds = (size_t)(chunks + (chunks >> 5) + (chunks >> 10) + 8) * sizeof(double) +
-                           (size_t)chunks * sizeof(unsigned int) + (size_t)(GUIDE_BINS + 1 + 32) * sizeof(int);
-        if (lds > 64 * 1024)
-            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(k_bucket_count),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_bucket_count, dim3(BUCKET_COUNT_BLOCKS), dim3(BUCKET_COUNT_THREADS), lds, s, offsets,
-                           chunks, n_out, k0, k1, ep, hist);
-        hipLaunchKernelGGL(k_bucket_reduce, dim3((chunks + QSMC_BLOCK - 1) / QSMC_BLOCK), dim3(QSMC_BLOCK), 0, s,
-                           hist, BUCKET_COUNT_BLOCKS, chunks, counts);
-        hipLaunchKernelGGL(k_bucket_plan, dim3(1), dim3(1024), 0, s, counts, chunks, slot_off, item_off,
-                           item_chunk);
-        // 512-thread workgroups, CDF chunk + guide in LDS (49 KB -> 3 resident workgroups per CU, so one
-        // workgroup's scan/guide-build phases overlap another's sampling loop); x is gathered from the
-        // chunk's 32 KB global window (L2-resident).
+        const int chunks = bp.chunks;
+        // 512-thread workgroups, CDF chunk + guide in LDS (40 KB -> 3 resident workgroups per CU, so one
+        // workgroup's scan phase overlaps another's sampling loop); x is gathered from the chunk's
+        // 32 KB global window (L2-resident).
 #define LAUNCH_B(DD, BT)                                                                                       \
-    hipLaunchKernelGGL((k_bucket_sample<DD, BT>), dim3(max_items), dim3(BT), 0, s, model->kind, d,           \
+    hipLaunchKernelGGL((k_bucket_sample<DD, BT>), dim3(bp.max_items), dim3(BT), 0, s, model->kind, d,           \
                        model->min_freq, postselect, x_in, ldx_in, n_in, w, inv_norm, offsets,                       \
-                       (const double *)nullptr, chunks, slot_off, item_off, item_chunk, lw, k0, k1, ep, maxiter,     \
-                       x_out, pl, nf, retry_list, retry_count)
+                       (const double *)nullptr, chunks, bp.slot_off, bp.item_off, bp.item_chunk, lw, k0, k1, ep,     \
+                       maxiter, x_out, pl, nf, bp.retry_list, retry_count)
         switch (d) {
             case 1: LAUNCH_B(1, 512); break;
             case 2: LAUNCH_B(2, 512); break;
@@ -2135,7 +2220,7 @@ static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int3
                                h->cdf_scratch, (const unsigned long long *)retry_count);
             hipLaunchKernelGGL(k_bucket_retry, dim3(grid_for(n_out / 16 + 1, QSMC_BLOCK)), dim3(QSMC_BLOCK), 0, s,
                                model->kind, d, model->min_freq, x_in, ldx_in, n_in, h->cdf_scratch, lw, k0, k1, ep,
-                               maxiter, x_out, pl, retry_list, retry_count, nf);
+                               maxiter, x_out, pl, bp.retry_list, retry_count, nf);
         }
     }
     HIP_TRY(h, hipGetLastError());
@@ -2144,6 +2229,24 @@ static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int3
     hipLaunchKernelGGL(k_publish_counter, dim3(1), dim3(64), 0, s,
                        reinterpret_cast<const unsigned long long *>(h->counter), h->mapped_dev + (REDUCE_OUT_MAX - 1));
     HIP_TRY(h, hipGetLastError());
+    return QSMC_OK;
+}
+
+int qsmc_lw_resample_prepare(qsmc_handle_t h, const double *w, int64_t n_in, double norm, int64_t n_out,
+                             uint64_t seed, uint64_t epoch, qsmc_stream_t stream) {
+    if (!h || n_in <= 0 || n_out <= 0 || !(norm > 0.0)) return QSMC_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    h->prep.valid = 0;
+    const int rc = resample_prefix(h, w, n_in, norm, n_out, seed, epoch, s);
+    if (rc) return rc;
+    h->prep.valid = 1;
+    h->prep.w = w;
+    h->prep.n_in = n_in;
+    h->prep.n_out = n_out;
+    h->prep.norm = norm;
+    h->prep.seed = seed;
+    h->prep.epoch = epoch;
+    h->prep.stream = s;
     return QSMC_OK;
 }
 
@@ -2209,6 +2312,7 @@ int qsmc_prior_uniform_philox(qsmc_handle_t h, const qsmc_model_t *model, int32_
                               const double *lo, const double *hi, int32_t d, int64_t n, uint64_t seed,
                               uint64_t epoch, int32_t maxiter, double *x_out, int64_t ldx_out,
                               int64_t *n_failed_host, qsmc_stream_t stream) {
+    if (h) h->prep.valid = 0;        // weights / counters are about to change: drop a queued resample prefix
     if (!h || !model || !lo || !hi || !x_out || n <= 0 || d < 1 || d > QSMC_MAX_D || maxiter < 1)
         return QSMC_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
@@ -2231,6 +2335,7 @@ int qsmc_prior_uniform_philox(qsmc_handle_t h, const qsmc_model_t *model, int32_
 
 int qsmc_tomo_canonicalize(qsmc_handle_t h, const double *basis, int32_t dim, double *x, int64_t ldx,
                            int64_t n, int32_t allow_subnormalized, qsmc_stream_t stream) {
+    if (h) h->prep.valid = 0;        // weights / counters are about to change: drop a queued resample prefix
     if (!h || !basis || !x || n < 0) return QSMC_ERR_INVALID;
     if (n == 0) return QSMC_OK;
     hipStream_t s = (hipStream_t)stream;

@@ -277,6 +277,12 @@ class Engine:
             "qsmc_lw_resample_philox")
         return x_out, (failed.value if sync else None)
 
+    def lw_resample_prepare(self, w, n_in, norm, n_out, seed, epoch):
+        """Queue the weight-only prefix of the next `lw_resample_philox` call with the same arguments."""
+        self._chk(self.lib.qsmc_lw_resample_prepare(
+            self.h, self._p(w) if w is not None else None, int(n_in), float(norm), int(n_out),
+            C.c_uint64(seed & (2 ** 64 - 1)), C.c_uint64(epoch), self.stream()), "qsmc_lw_resample_prepare")
+
     def last_resample_failed(self, synchronize=False):
         out = C.c_int64()
         self._chk(self.lib.qsmc_last_resample_failed(self.h, C.byref(out), int(bool(synchronize)), self.stream()),

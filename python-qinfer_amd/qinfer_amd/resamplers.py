@@ -129,6 +129,17 @@ class LiuWestResampler(Resampler):
         return ParticleDistribution._from_device(eng, x_new, None, norm=float(n_particles),
                                                  sumsq=float(n_particles))
 
+    def _prepare_device(self, model, particle_dist):
+        """Called by SMCUpdater the moment its n_ess test fails: queue the part of the resample that needs
+        only the weights (chunk sums, multinomial chunk counts, work-item plan) so that the GPU is busy
+        while `__call__` forms mean / covariance / sqrtm on the host.  Same arguments as the
+        `lw_resample_philox` call that follows, which then starts at the sampling kernel."""
+        if not (self._device_rng and getattr(model, "_native", False)):
+            return
+        n_out = (particle_dist.n_particles if self._default_n_particles is None else self._default_n_particles)
+        particle_dist._eng.lw_resample_prepare(particle_dist._w, particle_dist.n_particles, particle_dist._norm,
+                                               int(n_out), self._seed, self._epoch + 1)
+
     def _flush_failed_warning(self, synchronize=False):
         """Emit the deferred 'failed to find valid models' ResamplerWarning, if one is due."""
         eng = getattr(self, "_pending_failed", None)

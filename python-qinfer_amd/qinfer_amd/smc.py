@@ -487,6 +487,9 @@ class SMCUpdater(ParticleDistribution):
                           "Consider adding particles, or resampling more often.".format(ess),
                           ApproximationWarning)
         if ess < self.n_particles_global * self.resample_thresh:
+            prepare = getattr(self.resampler, "_prepare_device", None)
+            if prepare is not None and self._comm is None:
+                prepare(self.model, self)            # GPU starts on the weight-only prefix right away
             self.resample(_defer_warning=True)
 
     def resample(self, _defer_warning=False):

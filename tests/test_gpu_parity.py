@@ -372,6 +372,48 @@ def test_liu_west_philox_bucketed_vs_oracle(qi, eng, case):
     assert np.abs(freq - mass).max() < 6 * np.sqrt(mass.max() / n_out)
 
 
+def test_resample_prepare_is_transparent(qi, eng):
+    """qsmc_lw_resample_prepare only moves the weight-only prefix earlier: the particles are bitwise the
+    ones a plain qsmc_lw_resample_philox produces, and a stale prefix (weights changed in between, or
+    different arguments) is redone rather than used."""
+    rs = np.random.RandomState(3)
+    n, n_out = 70001, 90000
+    model = qi.SimplePrecessionModel()
+    desc = model._native_desc()
+    x = eng.locs_to_soa(np.abs(0.3 + 0.05 * rs.randn(n, 1)))
+    w = eng.to_device(rs.random_sample(n) ** 2)
+    norm = float(w.sum().item())
+    mean, S = np.array([0.3]), np.array([[0.01]])
+    args = (desc, True, x, w, norm, 0.98, mean, S, n_out, 77, 5, 1000)
+    plain, f0 = eng.lw_resample_philox(*args)
+    eng.lw_resample_prepare(w, n, norm, n_out, 77, 5)
+    prepared, f1 = eng.lw_resample_philox(*args)
+    assert f0 == f1 == 0
+    assert bool((plain == prepared).all())
+    # stale: weights rewritten in place after the prefix was queued
+    eng.lw_resample_prepare(w, n, norm, n_out, 77, 5)
+    st = eng.update_from_likelihood(eng.to_device(rs.random_sample(n)), w, w, norm)
+    norm2 = st.sum
+    fresh, _ = eng.lw_resample_philox(desc, True, x, w, norm2, 0.98, mean, S, n_out, 77, 5, 1000)
+    eng.lw_resample_prepare(w, n, norm2, n_out, 77, 6)            # other epoch queued ...
+    again, _ = eng.lw_resample_philox(desc, True, x, w, norm2, 0.98, mean, S, n_out, 77, 5, 1000)   # ... epoch 5 asked
+    assert bool((fresh == again).all())
+    assert not bool((fresh == plain).all())
+    # end to end: an updater whose n_ess test triggers the prepared path reproduces a manual resample
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        u1 = qi.SMCUpdater(model, 50000, qi.UniformDistribution([0, 1]), device_rng=True, seed=9)
+        u2 = qi.SMCUpdater(model, 50000, qi.UniformDistribution([0, 1]), device_rng=True, seed=9)
+        for k in range(12):
+            t = np.array([1.125 ** (4 * k)])
+            u1.update(k & 1, t)                                   # _maybe_resample -> prepare + resample
+            u2.update(k & 1, t, check_for_resample=False)
+            if u2.n_ess < 0.5 * u2.n_particles:
+                u2.resample()                                     # no prepare
+        assert u1.resample_count == u2.resample_count > 0
+        np.testing.assert_array_equal(u1.particle_locations, u2.particle_locations)
+
+
 def _deal_rows(dest_counts):
     """NumPy twin of OutPlace/place_row: slot o -> row index in the destination-grouped output."""
     counts = np.asarray(dest_counts, dtype=np.int64)
