@@ -213,6 +213,88 @@ __host__ __device__ __forceinline__ double u53(uint32_t a, uint32_t b) {
     return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) / 9007199254740992.0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Box-Muller arithmetic for the samplers.  The resampling kernel is VALU-issue bound and the library
+// log / sqrt / sincospi (written for all of double's range: denormals, huge arguments, NaN/inf paths)
+// were ~190 of its ~600 VALU instructions per output pair.  The arguments here live in narrow, benign
+// ranges -- ln on [2^-53, 1], sqrt on [0, 74], sin/cos(pi t) on t in [0, 2) -- so plain published
+// algorithms without the special-case plumbing do (~85 instructions), each good to ~1-2 ulp
+// (tests/test_gpu_parity.py::test_box_muller_accuracy checks them against an 80-bit reference).
+// ---------------------------------------------------------------------------------------------
+// n / d for finite d > 0: v_rcp_f64 seed, two Newton steps, one residual correction
+__device__ __forceinline__ double bm_div(double n, double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    const double q = n * r;
+    return fma(fma(-d, q, n), r, q);
+}
+
+// ln x for normal x in (0, 1]: the classic argument reduction x = 2^k m, m in [sqrt(1/2), sqrt(2)),
+// s = f / (2 + f) with f = m - 1, ln(1 + f) = f - f^2/2 + s (f^2/2 + R(s^2))   (Sun fdlibm e_log.c)
+__device__ __forceinline__ double bm_log(double x) {
+    int hx = __double2hiint(x);
+    int k = (hx >> 20) - 1023;
+    hx &= 0x000fffff;
+    const int i = (hx + 0x95f64) & 0x100000;                   // mantissa >= sqrt(2): use m / 2
+    const double m = __hiloint2double(hx | (i ^ 0x3ff00000), __double2loint(x));
+    k += i >> 20;
+    const double f = m - 1.0;
+    const double s = bm_div(f, 2.0 + f);
+    const double z = s * s;
+    const double w = z * z;
+    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+    const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01),
+                                     2.857142874366239149e-01), 6.666666666666735130e-01);
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)k;
+    return dk * 6.93147180369123816490e-01 - ((hfsq - fma(s, hfsq + R, dk * 1.90821492927058770002e-10)) - f);
+}
+
+// sqrt x for 0 <= x < 2^100: v_rsq_f64 seed + two coupled Newton (Goldschmidt) steps + one correction
+__device__ __forceinline__ double bm_sqrt(double x) {
+    const double r = __builtin_amdgcn_rsq(x);
+    double g = x * r, h = 0.5 * r;
+    double e = fma(-h, g, 0.5);
+    g = fma(g, e, g);
+    h = fma(h, e, h);
+    e = fma(-h, g, 0.5);
+    g = fma(g, e, g);
+    h = fma(h, e, h);
+    g = fma(fma(-g, g, x), h, g);
+    return x > 0.0 ? g : 0.0;
+}
+
+// sin(pi t), cos(pi t) for t in [0, 2]: t = q / 2 + y with q = rint(2 t) and |y| <= 1/4 (exact), Taylor
+// polynomials in y with the powers of pi folded into the coefficients, quadrant fix-up by q mod 4
+__device__ __forceinline__ void bm_sincospi(double t, double &sn, double &cs) {
+    const double q = rint(2.0 * t);
+    const double y = fma(-0.5, q, t);
+    const int iq = (int)q;
+    const double z = y * y;
+    double ps = fma(z, -2.1915353447830217e-05, 4.6630280576761255e-04);
+    ps = fma(z, ps, -7.3704309457143504e-03);
+    ps = fma(z, ps, 8.214588661112823e-02);
+    ps = fma(z, ps, -5.992645293207921e-01);
+    ps = fma(z, ps, 2.5501640398773455);
+    ps = fma(z, ps, -5.16771278004997);
+    ps = fma(z, ps, 3.141592653589793);
+    ps *= y;
+    double pc = fma(z, 4.303069587032947e-06, -1.046381049248457e-04);
+    pc = fma(z, pc, 1.9295743094039231e-03);
+    pc = fma(z, pc, -2.580689139001406e-02);
+    pc = fma(z, pc, 2.353306303588932e-01);
+    pc = fma(z, pc, -1.3352627688545895);
+    pc = fma(z, pc, 4.0587121264167685);
+    pc = fma(z, pc, -4.934802200544679);
+    pc = fma(z, pc, 1.0);
+    const double a = (iq & 1) ? pc : ps;                       // |sin|-like / |cos|-like by parity of q
+    const double b = (iq & 1) ? ps : pc;
+    sn = (iq & 2) ? -a : a;                                    // q mod 4: (s,c) = (ps,pc) (pc,-ps) (-ps,-pc) (-pc,ps)
+    cs = ((iq + 1) & 2) ? -b : b;
+}
+
 struct PhiloxStream {
     uint64_t particle;
     uint32_t epoch_round;     // (epoch << 16) | round  (epoch < 65536 per seed bump; host advances seed)
@@ -227,9 +309,9 @@ struct PhiloxStream {
     __device__ __forceinline__ void normals(uint32_t slot, double &z0, double &z1) const {
         double u0, u1;
         uniforms(slot, u0, u1);
-        const double r = sqrt(-2.0 * log(1.0 - u0));       // 1 - u0 in (0, 1]
+        const double r = bm_sqrt(-2.0 * bm_log(1.0 - u0));  // 1 - u0 in [2^-53, 1]
         double s, c;
-        sincospi(2.0 * u1, &s, &c);
+        bm_sincospi(2.0 * u1, s, c);
         z0 = r * c;
         z1 = r * s;
     }

@@ -1321,11 +1321,37 @@ __global__ __launch_bounds__(BT) void k_bucket_sample(
     const int64_t o_begin = slot0 + t0, o_end = slot0 + t1;         // this item's output slots
     unsigned long long failed = 0;
     // pairs of output slots (2P, 2P+1) share their Philox blocks; a pair straddling two work items is
-    // evaluated by both, each writing only its own half
-    for (int64_t P = (o_begin >> 1) + threadIdx.x; 2 * P < o_end; P += BT) {
+    // evaluated by both, each writing only its own half.
+    // Stage A (ancestors): position Philox -> guided LDS search -> gather of x (d <= 4: into registers).
+    // Stage B (kick): normals Philox + Box-Muller -> Liu-West combine -> validity -> store.
+    // A is issued first so that its LDS round trips and the L2/HBM gather are in flight during B's ~600
+    // cycles of independent arithmetic (110 -> 100 us at N = 1e7; issuing A of the NEXT pair ahead of B --
+    // a software pipeline -- was measured too and is slower, 115 us: spills).  Both halves of a pair are
+    // searched even if one belongs to the neighbouring work item: no divergence, cheap.
+    constexpr bool EARLY = DM <= 4;
+    struct Anc {
+        int jl[2];
+        double xg[2][EARLY ? DM : 1];
+    };
+    auto stage_a = [&](int64_t P, Anc &an) {
         PhiloxStream rng{(uint64_t)P, (epoch << 16), k0, k1};
         double upos[2];
         rng.uniforms(1, upos[0], upos[1]);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            // position inside this chunk: given the counts, uniform on [lo_edge, hi_edge)
+            const double u = lo_edge + upos[e] * (hi_edge - lo_edge);
+            int j = use_guide ? guided_upper_bound(lcdf, len, lguide, guide_cell<SGUIDE_BINS>(u, lo_edge, gscale), u)
+                              : upper_bound_skew(lcdf, len, u);
+            an.jl[e] = j > len - 1 ? len - 1 : j;
+            if (EARLY) {
+#pragma unroll
+                for (int m = 0; m < DM; ++m)
+                    if (m < d) an.xg[e][m] = x_in[m * ldx_in + base + an.jl[e]];
+            }
+        }
+    };
+    auto stage_b = [&](int64_t P, const Anc &an) {
         double z[2 * DM];
         PhiloxStream nrm{0, (epoch << 16), k0, k1};
 #pragma unroll
@@ -1339,11 +1365,6 @@ __global__ __launch_bounds__(BT) void k_bucket_sample(
         for (int e = 0; e < 2; ++e) {
             const int64_t o = 2 * P + e;
             if (o >= o_begin && o < o_end) {
-                // position inside this chunk: given the counts, uniform on [lo_edge, hi_edge)
-                const double u = lo_edge + upos[e] * (hi_edge - lo_edge);
-                int jl = use_guide ? guided_upper_bound(lcdf, len, lguide, guide_cell<SGUIDE_BINS>(u, lo_edge, gscale), u)
-                                   : upper_bound_skew(lcdf, len, u);
-                if (jl > len - 1) jl = len - 1;
                 double p[DM];
 #pragma unroll
                 for (int m = 0; m < DM; ++m) {
@@ -1352,7 +1373,8 @@ __global__ __launch_bounds__(BT) void k_bucket_sample(
 #pragma unroll
                         for (int q = 0; q < DM; ++q)
                             if (q < d) sm += lw.S[m * d + q] * z[e * d + q];
-                        p[m] = (lw.a * x_in[m * ldx_in + base + jl] + (1.0 - lw.a) * lw.mean[m]) + sm;
+                        const double xa = EARLY ? an.xg[e][m] : x_in[m * ldx_in + base + an.jl[e]];
+                        p[m] = (lw.a * xa + (1.0 - lw.a) * lw.mean[m]) + sm;
                     }
                 }
                 bool ok = !postselect || model_valid(kind, p, min_freq);
@@ -1370,6 +1392,11 @@ __global__ __launch_bounds__(BT) void k_bucket_sample(
                 if (!ok) ++failed;
             }
         }
+    };
+    for (int64_t P = (o_begin >> 1) + threadIdx.x; 2 * P < o_end; P += BT) {
+        Anc an;
+        stage_a(P, an);
+        stage_b(P, an);
     }
     if (failed) atomicAdd(n_failed, failed);
     __syncthreads();

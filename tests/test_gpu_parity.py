@@ -372,6 +372,46 @@ def test_liu_west_philox_bucketed_vs_oracle(qi, eng, case):
     assert np.abs(freq - mass).max() < 6 * np.sqrt(mass.max() / n_out)
 
 
+def test_box_muller_accuracy(qi, eng):
+    """The sampler's own ln / sqrt / sin-cos(pi t) (qsmc_device.h bm_*) against an 80-bit reference on the
+    very Philox uniforms the kernel consumes: with a = 0, mean = 0, S = I the resampler's output IS its
+    normal pair.  Covers the bucketed (n_out >= 16384) and the direct sampler."""
+    import philox as ph
+    model = qi.TomographyModel(qi.tomography.pauli_basis(1))
+    d = 4                                                  # tomography kind: no validity constraint
+    desc = model._native_desc()
+    assert desc.d == d
+    for n_out, bucketed in ((200000, True), (3000, False)):
+        n_in = 20000
+        x = eng.to_device(np.zeros((d, n_in)))
+        w = eng.to_device(np.ones(n_in))
+        out, failed = eng.lw_resample_philox(desc, False, x, w, float(n_in), 0.0, np.zeros(d), np.eye(d), n_out,
+                                             99, 3, 1)
+        z = out.cpu().numpy()                              # (d, n_out): z[q, o] = normal number o * d + q
+        ld = np.longdouble
+        pi = ld("3.14159265358979323846264338327950288")
+        if bucketed:
+            nidx = (np.arange(n_out)[None, :] * d + np.arange(d)[:, None]).astype(np.int64)
+            u0, u1 = ph.uniforms(nidx >> 1, 99, 3, 0, 2)
+            comp = nidx & 1
+        else:
+            ids = np.arange(n_out, dtype=np.int64)
+            u0 = np.empty((d, n_out)); u1 = np.empty((d, n_out)); comp = np.empty((d, n_out), dtype=np.int64)
+            for q in range(d):
+                a_, b_ = ph.uniforms(ids, 99, 3, 0, 1 + q // 2)
+                u0[q], u1[q], comp[q] = a_, b_, q & 1
+        r = np.sqrt(ld(-2.0) * np.log(ld(1.0) - u0.astype(ld)))
+        ang = ld(2.0) * pi * u1.astype(ld)
+        ref = np.where(comp == 1, r * np.sin(ang), r * np.cos(ang))
+        err = np.abs(z.astype(ld) - ref)
+        ulp = np.spacing(np.maximum(np.abs(ref.astype(np.float64)), 1e-300))
+        # r carries <= ~2 ulp (ln, sqrt), the trig factor <= ~1.5 ulp of 1 -> bound relative to r, not to |z|
+        bound = 4.0 * np.spacing(np.asarray(r, dtype=np.float64)) + 2.0 * ulp
+        assert np.all(err <= bound), (float((err / bound).max()), int(np.argmax(err / bound)))
+        assert abs(z.mean()) < 5 / np.sqrt(z.size) and abs(z.std() - 1) < 5 / np.sqrt(z.size)
+        assert np.abs(z).max() > 4.0                       # tails are populated
+
+
 def test_resample_prepare_is_transparent(qi, eng):
     """qsmc_lw_resample_prepare only moves the weight-only prefix earlier: the particles are bitwise the
     ones a plain qsmc_lw_resample_philox produces, and a stale prefix (weights changed in between, or

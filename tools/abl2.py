@@ -16,3 +16,17 @@ for _ in range(3): eng.lw_resample_philox(desc,True,upd._x,upd._w,upd._norm,0.98
 torch.cuda.synchronize(); t=time.perf_counter()
 for _ in range(10): eng.lw_resample_philox(desc,True,upd._x,upd._w,upd._norm,0.98,mean,S,n,1,1,1000)
 torch.cuda.synchronize(); print(os.environ.get('QSMC_ABL_LIB','default'), (time.perf_counter()-t)/10*1e6,'us per resample call')
+try:
+    import ctypes as C
+    lib = eng.lib
+    fn = lib.qsmc_dbg_phase
+    fn.argtypes = [C.POINTER(C.c_double)]; fn.restype = C.c_int
+    out = (C.c_double * 8)()
+    fn(out)                                     # reset
+    for _ in range(1): eng.lw_resample_philox(desc,True,upd._x,upd._w,upd._norm,0.98,mean,S,n,1,1,1000)
+    torch.cuda.synchronize(); fn(out)
+    nb = out[2]
+    print('scan_block: load+local scan %.2f us, barrier wait %.2f us, clamp+max+store+guide %.2f us' % (out[3]/nb/100, out[4]/nb/100, out[5]/nb/100))
+    print('phase: blocks', nb, ' setup %.2f us  pairloop %.2f us (per workgroup, thread 0, 100 MHz clock)' % (out[0] / nb / 100, out[1] / nb / 100))
+except AttributeError:
+    pass
