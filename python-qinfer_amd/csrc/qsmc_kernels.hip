@@ -56,8 +56,8 @@ struct qsmc_ctx {
     double *cdf_scratch;    // device CDF, materialised only for the direct sampler / global redraws
     size_t cdf_cap;         // in doubles
     int profiling;
-    hipEvent_t ev0, ev1;
-    int ev_valid;
+    hipEvent_t *prof_ev;   // QSMC_PROF_CAP (start, stop) pairs, created on first qsmc_set_profiling(1)
+    int prof_n;            // profiled launches since the last qsmc_profile_read / set_profiling
     char hip_err[256];
 };
 
@@ -72,6 +72,7 @@ struct qsmc_ctx {
     } while (0)
 
 constexpr int REDUCE_OUT_MAX = 192;
+constexpr int QSMC_PROF_CAP = 4096;
 
 static int ensure_partials(qsmc_ctx *h, size_t n) {
     if (h->partials_cap >= n) return QSMC_OK;
@@ -1594,7 +1595,13 @@ static void launch_update(qsmc_ctx *h, bool vec2, int grid, hipStream_t s, const
                           int64_t outcome, const ReduceOut &ro) {
     // In profiling mode the launch carries start/stop events, so the elapsed time is the kernel's
     // own execution (what rocprofv3 --kernel-trace reports), not launch latency.
-    hipEvent_t e0 = h->profiling ? h->ev0 : nullptr, e1 = h->profiling ? h->ev1 : nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->profiling && h->prof_ev) {
+        const int slot = h->prof_n % QSMC_PROF_CAP;     // a ring: beyond the capacity the oldest are overwritten
+        e0 = h->prof_ev[2 * slot];
+        e1 = h->prof_ev[2 * slot + 1];
+        ++h->prof_n;
+    }
 #define LU(V, O)                                                                                          \
     hipExtLaunchKernelGGL((k_update_fused<KIND, V, O>), dim3(grid), dim3(QSMC_BLOCK), 0, s, e0, e1, 0, x, ldx, \
                           n, w_in, w_out, prev_norm, e, outcome, ro)
@@ -1721,8 +1728,6 @@ int qsmc_create(qsmc_handle_t *out, int device) {
     if (e == hipSuccess) e = hipHostMalloc(&h->flag, 64, hipHostMallocMapped);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&h->flag_dev, h->flag, 0);
     if (e == hipSuccess) *h->flag = 0ull;
-    if (e == hipSuccess) e = hipEventCreate(&h->ev0);
-    if (e == hipSuccess) e = hipEventCreate(&h->ev1);
     if (e != hipSuccess) {
         delete h;
         return QSMC_ERR_HIP;
@@ -1743,23 +1748,47 @@ int qsmc_destroy(qsmc_handle_t h) {
     if (h->red_out) (void)hipFree(h->red_out);
     if (h->mapped) (void)hipHostFree(h->mapped);
     if (h->flag) (void)hipHostFree(h->flag);
-    if (h->ev0) (void)hipEventDestroy(h->ev0);
-    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->prof_ev) {
+        for (int i = 0; i < 2 * QSMC_PROF_CAP; ++i) (void)hipEventDestroy(h->prof_ev[i]);
+        free(h->prof_ev);
+    }
     delete h;
     return QSMC_OK;
 }
 
 int qsmc_set_profiling(qsmc_handle_t h, int enabled) {
     if (!h) return QSMC_ERR_INVALID;
+    if (enabled && !h->prof_ev) {
+        hipEvent_t *ev = static_cast<hipEvent_t *>(calloc(2 * QSMC_PROF_CAP, sizeof(hipEvent_t)));
+        if (!ev) return QSMC_ERR_ALLOC;
+        for (int i = 0; i < 2 * QSMC_PROF_CAP; ++i) HIP_TRY(h, hipEventCreate(&ev[i]));
+        h->prof_ev = ev;
+    }
     h->profiling = enabled ? 1 : 0;
-    h->ev_valid = 0;
+    h->prof_n = 0;
     return QSMC_OK;
 }
 
 int qsmc_last_update_kernel_ms(qsmc_handle_t h, float *ms_out) {
-    if (!h || !ms_out || !h->ev_valid) return QSMC_ERR_INVALID;
-    HIP_TRY(h, hipEventSynchronize(h->ev1));
-    HIP_TRY(h, hipEventElapsedTime(ms_out, h->ev0, h->ev1));
+    if (!h || !ms_out || !h->prof_ev || h->prof_n < 1) return QSMC_ERR_INVALID;
+    const int slot = (h->prof_n - 1) % QSMC_PROF_CAP;
+    HIP_TRY(h, hipEventSynchronize(h->prof_ev[2 * slot + 1]));
+    HIP_TRY(h, hipEventElapsedTime(ms_out, h->prof_ev[2 * slot], h->prof_ev[2 * slot + 1]));
+    return QSMC_OK;
+}
+
+int qsmc_profile_read(qsmc_handle_t h, float *ms_out, int32_t cap, int32_t *n_out) {
+    if (!h || !ms_out || !n_out || cap < 0) return QSMC_ERR_INVALID;
+    int n = h->prof_n < QSMC_PROF_CAP ? h->prof_n : QSMC_PROF_CAP;
+    if (n > cap) n = cap;
+    const int first = h->prof_n - n;                     // oldest launch still in the ring (or wanted)
+    for (int i = 0; i < n; ++i) {
+        const int slot = (first + i) % QSMC_PROF_CAP;
+        HIP_TRY(h, hipEventSynchronize(h->prof_ev[2 * slot + 1]));
+        HIP_TRY(h, hipEventElapsedTime(&ms_out[i], h->prof_ev[2 * slot], h->prof_ev[2 * slot + 1]));
+    }
+    *n_out = n;
+    h->prof_n = 0;
     return QSMC_OK;
 }
 
@@ -1842,7 +1871,6 @@ int qsmc_update_fused(qsmc_handle_t h, const qsmc_model_t *model, const double *
 #undef LAUNCH_U
     }
     HIP_TRY(h, hipGetLastError());
-    if (h->profiling) h->ev_valid = 1;
     rc = launch_reduce(h, ns, grid, ro, s);
     if (rc) return rc;
     return collect_stats(h, ns, stats_host, moments_host, n_mom, s);

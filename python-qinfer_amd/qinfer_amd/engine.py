@@ -99,6 +99,13 @@ class Engine:
     def set_profiling(self, enabled):
         self._chk(self.lib.qsmc_set_profiling(self.h, int(bool(enabled))), "qsmc_set_profiling")
 
+    def profile_read(self, cap=4096):
+        """Durations (ms, oldest first) of the update kernels launched since profiling was enabled / last read."""
+        buf = (C.c_float * cap)()
+        n = C.c_int32()
+        self._chk(self.lib.qsmc_profile_read(self.h, buf, cap, C.byref(n)), "qsmc_profile_read")
+        return np.array(buf[:n.value], dtype=np.float64)
+
     def last_update_kernel_ms(self):
         ms = C.c_float()
         self._chk(self.lib.qsmc_last_update_kernel_ms(self.h, C.byref(ms)), "qsmc_last_update_kernel_ms")

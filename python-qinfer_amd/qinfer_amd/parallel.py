@@ -13,35 +13,153 @@ weights and the resampler on the client.  Here every rank OWNS a contiguous bloc
                  mean/cov -> identical host sqrtm on every rank; then the only bandwidth step:
                  an all-to-all(v) of ancestor rows (8 d bytes each).
 
-Exact global multinomial resampling without a global CDF: ancestors for destination rank r come
-from source rank h with probability W_h / W, so the G x G count matrix C[r, h] ~ Multinomial(N/G;
-W/W_tot) is drawn IDENTICALLY on every rank from a shared-seed host generator; rank h then draws
-C[., h] ancestors from its LOCAL CDF (conditionally i.i.d. -- exact) with the same LDS-bucketed
-sampler the single-GPU path uses, applies the Liu-West kick and postselection there (they need only
-the ancestor and the global mean/covariance), and the finished rows travel by one
-`all_to_all_single`.  xGMI is point-to-point, so the all-to-all is a direct exchange (worst case 7/8
-of the rows leave the rank), not a ring.
+Exact global multinomial resampling without a global CDF and (normally) without moving a particle:
+the number of the N_total new particles whose ancestor lives on rank h is T ~ Multinomial(N_total;
+W_h / W), drawn IDENTICALLY on every rank from a shared-seed host generator (W_h came with the last
+update's stats, so this costs no communication); rank h then draws its T_h ancestors from its LOCAL
+CDF (conditionally i.i.d. -- exact) with the very sampler the single-GPU path uses and applies the
+Liu-West kick and postselection (they need only the ancestor and the global mean/covariance).  Every
+estimator is a sum over all particles, so WHERE a new particle lives is a layout choice, not part of
+the algorithm: the children simply stay on their ancestor's rank, and the shard sizes float
+(n_h = T_h, a +-1/sqrt(N/G) relative fluctuation) while the global count is conserved.  Only when the
+sizes have drifted by more than `rebalance_tol` does a resample also move particles: a
+minimal-movement count matrix (every rank keeps what it can, surpluses fill deficits) and one
+`all_to_all_single` of finished rows -- xGMI is point-to-point, so that is a direct exchange, not a
+ring.  `placement="mixed"` reproduces the fully mixing variant (C[r, h] ~ Multinomial(N/G; W/W_tot),
+7/8 of the rows leave the rank at G = 8).
+
+The per-datum collective is a handful of doubles per rank, i.e. pure latency.  When all ranks sit on
+one host (the one-node case this targets) it does not go through RCCL at all: each rank's sums land
+in ITS pinned host memory (the same completion-word path the single-GPU updater uses) and are
+exchanged through a POSIX shared-memory segment with sequence-numbered slots (`HostExchange`,
+~2 us) -- an RCCL all-gather of 80 bytes costs a kernel launch, a device round trip and a D2H copy
+(~60 us through torch.distributed).  RCCL carries what is bandwidth: the particle rows of a rebalance.
 
 The collectives take whatever tensors they are given (CUDA under nccl, CPU under gloo), so the
 protocol is testable on CPU with world_size 2 (tests/test_parallel_gloo.py).
 """
 import numpy as np
 
-__all__ = ["ParticleShardGroup"]
+__all__ = ["ParticleShardGroup", "HostExchange"]
+
+
+class HostExchange:
+    """All-gather of small float64 vectors between the processes of ONE host through shared memory.
+
+    Layout: two banks (parity of the call counter) x world slots; a slot is [seq (int64, own cache
+    line), payload (max_len doubles)].  Call k: write payload, then seq = k, into bank k & 1; spin until
+    every slot of that bank shows k; read.  A bank is rewritten at call k + 2, which a rank can reach
+    only after everyone has posted k + 1, i.e. after everyone has finished reading k -- so two banks
+    suffice and no barrier is needed.  x86 stores are not reordered and the interpreter does not
+    reorder them either, so payload-before-seq is what the readers observe."""
+
+    _SEQ_STRIDE = 8          # int64s per seq entry: one 64-byte line each
+
+    def __init__(self, rank, world, name=None, max_len=256, timeout=120.0):
+        from multiprocessing import shared_memory, resource_tracker
+        self.rank, self.world, self.max_len, self.timeout = rank, world, max_len, float(timeout)
+        seq_bytes = 2 * world * self._SEQ_STRIDE * 8
+        size = seq_bytes + 2 * world * max_len * 8
+        if name is None:
+            self._shm = shared_memory.SharedMemory(create=True, size=size)
+            self._owner = True
+            self._shm.buf[:size] = bytes(size)
+        else:
+            self._shm = shared_memory.SharedMemory(name=name)
+            self._owner = False
+            try:      # the creator unlinks; keep Python's tracker from unlinking (and warning) on our exit
+                resource_tracker.unregister(self._shm._name, "shared_memory")
+            except Exception:  # noqa: BLE001
+                pass
+        self.name = self._shm.name
+        self._seq = np.ndarray((2, world, self._SEQ_STRIDE), dtype=np.int64, buffer=self._shm.buf)
+        self._pay = np.ndarray((2, world, max_len), dtype=np.float64, buffer=self._shm.buf, offset=seq_bytes)
+        self._k = 0
+
+    def all_gather(self, vec):
+        """vec: 1-D float64 (len <= max_len) -> (world, len) array, rank-ordered, identical everywhere."""
+        n = len(vec)
+        if n > self.max_len:
+            raise ValueError("HostExchange payload too long")
+        self._k += 1
+        k, bank = self._k, self._k & 1
+        self._pay[bank, self.rank, :n] = vec
+        self._seq[bank, self.rank, 0] = k
+        seq = self._seq[bank, :, 0]
+        if seq.min() < k:                           # (world-1, or everyone already here: no loop at all)
+            import time
+            t0, spins = None, 0
+            while seq.min() < k:
+                spins += 1
+                if spins & 0x3ff == 0:
+                    now = time.monotonic()
+                    t0 = now if t0 is None else t0
+                    if now - t0 > self.timeout:
+                        raise RuntimeError("HostExchange: a peer did not arrive within {} s".format(self.timeout))
+        return self._pay[bank, :, :n].copy()
+
+    def close(self):
+        shm, self._shm = getattr(self, "_shm", None), None
+        if shm is None:
+            return
+        self._seq = self._pay = None
+        try:
+            shm.close()
+            if self._owner:
+                shm.unlink()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def __del__(self):
+        self.close()
 
 
 class ParticleShardGroup:
-    def __init__(self, group=None, seed=0):
+    def __init__(self, group=None, seed=0, placement="local", rebalance_tol=0.05, host_exchange=True):
         import torch
         import torch.distributed as dist
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised (launch with torch.distributed.run)")
+        if placement not in ("local", "mixed"):
+            raise ValueError("placement must be 'local' or 'mixed'")
         self.torch, self.dist, self.group = torch, dist, group
         self.rank = dist.get_rank(group)
         self.world_size = dist.get_world_size(group)
         self.backend = dist.get_backend(group)
         self.seed = int(seed)
+        self.placement = placement
+        self.rebalance_tol = float(rebalance_tol)
         self._epoch = 0
+        self.n_rebalances = 0
+        self._bitgen = np.random.Philox(key=self.seed & (2 ** 64 - 1))     # re-keyed per plan by counter
+        self._gen = np.random.Generator(self._bitgen)
+        self._host = self._open_host_exchange() if host_exchange else None
+
+    def _open_host_exchange(self):
+        """Shared-memory exchange if (and only if) every rank runs on this host; else None (RCCL/gloo)."""
+        import socket
+        try:
+            hosts = [None] * self.world_size
+            self.dist.all_gather_object(hosts, socket.gethostname(), group=self.group)
+            if len(set(hosts)) != 1:
+                return None
+            name = [None]
+            ex = None
+            if self.rank == 0:
+                ex = HostExchange(0, self.world_size)
+                name[0] = ex.name
+            self.dist.broadcast_object_list(name, src=0, group=self.group)
+            if self.rank != 0:
+                ex = HostExchange(self.rank, self.world_size, name=name[0])
+            self.dist.barrier(group=self.group)
+            return ex
+        except Exception:  # noqa: BLE001  (no /dev/shm, odd backend: fall back to the collective)
+            return None
+
+    def close(self):
+        if self._host is not None:
+            self._host.close()
+            self._host = None
 
     # ------------------------------------------------------------------ small collectives
     def _comm_tensor(self, t):
@@ -51,8 +169,15 @@ class ParticleShardGroup:
         return t.cpu() if t.is_cuda else t
 
     def gather_rows(self, vec):
-        """All-gather a 1-D float64 tensor: returns a HOST (world, len) ndarray, rank-ordered."""
+        """All-gather a 1-D float64 vector (tensor or ndarray): returns a HOST (world, len) ndarray,
+        rank-ordered.  One host: shared memory; otherwise the backend's all-gather."""
         t = self.torch
+        if self._host is not None:
+            v = vec.detach().cpu().numpy().reshape(-1) if isinstance(vec, t.Tensor) else vec
+            if len(v) <= self._host.max_len:
+                return self._host.all_gather(v)
+        if not isinstance(vec, t.Tensor):
+            vec = t.from_numpy(np.ascontiguousarray(vec, dtype=np.float64))
         v = self._comm_tensor(vec.reshape(-1).to(t.float64)).contiguous()
         out = t.empty(self.world_size * v.shape[0], dtype=t.float64, device=v.device)
         self.dist.all_gather_into_tensor(out, v, group=self.group)       # flat: accepted by nccl and gloo
@@ -64,21 +189,20 @@ class ParticleShardGroup:
         with the per-rank weight sums, in `last_extra` / `last_shard_sums`: ONE collective per datum
         serves the normaliser, n_ess, the guards, est_mean/est_covariance and the next resample plan."""
         rows = self.gather_rows(stats)
-        tot = np.zeros(rows.shape[1])
-        for r in range(self.world_size):            # fixed order: identical on every rank
-            tot += rows[r]
+        tot = rows.sum(axis=0)                      # row after row, in rank order: identical on every rank
         self.last_shard_sums = rows[:, 0].copy()
         self.last_extra = tot[4:].copy()
         return float(tot[0]), float(tot[1]), float(rows[:, 2].min()), float(tot[3])
 
     def allreduce_update_stats(self, eng, s, ss, mn, n_bad, extra=None):
-        t = self.torch
-        vec = [s, ss, mn, n_bad] + ([] if extra is None else [float(v) for v in extra])
-        return self.combine_update_stats(t.tensor(vec, dtype=t.float64))
+        vec = np.empty(4 + (0 if extra is None else len(extra)))
+        vec[0], vec[1], vec[2], vec[3] = s, ss, mn, n_bad
+        if extra is not None:
+            vec[4:] = extra
+        return self.combine_update_stats(vec)
 
     def allreduce_scalar(self, eng, value):
-        t = self.torch
-        rows = self.gather_rows(t.tensor([value], dtype=t.float64))
+        rows = self.gather_rows(np.array([value], dtype=np.float64))
         tot = 0.0
         for r in range(self.world_size):
             tot += rows[r, 0]
@@ -86,10 +210,9 @@ class ParticleShardGroup:
 
     def allreduce_moments(self, eng, s0, s1, s2):
         """Global [sum w, sum w x, sum w x x^T] from per-shard sums (already divided by the GLOBAL norm)."""
-        t = self.torch
         d = len(s1)
         packed = np.concatenate([[s0], s1, s2.reshape(-1)])
-        rows = self.gather_rows(t.from_numpy(packed))
+        rows = self.gather_rows(packed)
         tot = np.zeros_like(packed)
         for r in range(self.world_size):
             tot += rows[r]
@@ -101,12 +224,54 @@ class ParticleShardGroup:
         return v.to(tensor.device)
 
     # ------------------------------------------------------------------ resampling protocol
+    def _plan_generator(self, epoch, stream):
+        """The shared-seed host generator positioned at Philox counter (epoch, stream, 0, 0): the same
+        numbers as a fresh Generator(Philox(key=seed, counter=...)), without building one (22 -> 6 us)."""
+        st = self._bitgen.state
+        st['state']['counter'][:] = (int(epoch), int(stream), 0, 0)
+        st['buffer_pos'] = 4
+        st['has_uint32'] = 0
+        self._bitgen.state = st
+        return self._gen
+
     def plan_counts(self, shard_weights, n_out_per_rank, epoch):
         """C[r, h] = how many ancestors destination r takes from source h; identical on all ranks."""
         p = np.asarray(shard_weights, dtype=np.float64)
         p = p / p.sum()
-        gen = np.random.Generator(np.random.Philox(key=self.seed & (2 ** 64 - 1), counter=[int(epoch), 0, 0, 0]))
+        gen = self._plan_generator(epoch, 0)
         return gen.multinomial(int(n_out_per_rank), p, size=self.world_size).astype(np.int64)
+
+    def plan_totals(self, shard_weights, n_total, epoch):
+        """T[h] = how many of the n_total new particles descend from shard h ~ Multinomial(n_total; W/sum W);
+        identical on all ranks (shared-seed host Philox)."""
+        p = np.asarray(shard_weights, dtype=np.float64)
+        p = p / p.sum()
+        return self._plan_generator(epoch, 1).multinomial(int(n_total), p).astype(np.int64)
+
+    @staticmethod
+    def plan_counts_minimal(totals, n_per_rank):
+        """Count matrix C[r, h] (destination r takes C[r, h] children of source h) with column sums
+        `totals`, row sums `n_per_rank`, moving as few particles as possible: every rank keeps
+        min(T_h, n_per_rank) of its own, surpluses fill deficits in rank order.  Deterministic."""
+        T = np.asarray(totals, dtype=np.int64)
+        G = len(T)
+        q = np.broadcast_to(np.asarray(n_per_rank, dtype=np.int64), (G,)).copy()
+        if T.sum() != q.sum():
+            raise ValueError("totals and quotas must have the same sum")
+        C = np.zeros((G, G), dtype=np.int64)
+        keep = np.minimum(T, q)
+        C[np.arange(G), np.arange(G)] = keep
+        surplus, deficit = T - keep, q - keep
+        h = 0
+        for r in range(G):
+            while deficit[r] > 0:
+                while surplus[h] == 0:
+                    h += 1
+                m = min(deficit[r], surplus[h])
+                C[r, h] += m
+                deficit[r] -= m
+                surplus[h] -= m
+        return C
 
     def exchange_rows(self, send_rows, counts):
         """send_rows: (T_h, d) tensor ordered by destination rank, T_h = counts[:, rank].sum().
@@ -134,6 +299,27 @@ class ParticleShardGroup:
         epoch = self._epoch
         d = updater.n_rvs
         n_local = updater.n_particles
+        n_total = updater.n_particles_global
+        G = self.world_size
+        # shard weight totals (unnormalised sums are fine: only ratios matter); normally known from the
+        # last update's all-gather, so planning the resample needs no collective
+        W = getattr(updater, "_shard_sums", None)
+        if W is None:
+            st = eng.weight_stats(updater._weights(), 1.0)
+            W = self.gather_rows(np.array([st.sum]))[:, 0]
+        seed_r = resampler._seed + 0x9E3779B97F4A7C15 * (self.rank + 1)
+        defer = hasattr(resampler, "_flush_failed_warning")       # stay asynchronous; warn at the next sync
+        target = n_total // G                                       # balanced shard size
+        if self.placement == "local":
+            totals = self.plan_totals(W, n_total, epoch)
+            drift = np.abs(totals - target).max() / max(target, 1)
+            stay = drift <= self.rebalance_tol and totals.min() > 0
+        else:
+            totals, stay = None, False
+        if stay:
+            # children stay with their ancestor: this rank draws its T_h particles, nothing moves.  The
+            # weight-only prefix (chunk sums, multinomial chunk counts) is queued before mean / cov / sqrtm
+            eng.lw_resample_prepare(updater._w, n_local, float(W[self.rank]), int(totals[self.rank]), seed_r, epoch)
         mean = updater.est_mean()                                   # global (all-reduced) moments
         cov = updater.est_covariance_mtx()
         a, h = resampler.a, resampler.h
@@ -145,26 +331,38 @@ class ParticleShardGroup:
         if not np.isfinite(S_err):
             raise ResamplerError("Infinite error in computing the square root of the covariance "
                                  "matrix. Check that n_ess is not too small.")
-        # shard weight totals (unnormalised sums are fine: only ratios matter); normally known from the
-        # last update's all-gather, so the resample needs no collective besides the all-to-all
-        W = getattr(updater, "_shard_sums", None)
-        if W is None:
-            st = eng.weight_stats(updater._weights(), 1.0)
-            W = self.gather_rows(self.torch.tensor([st.sum], dtype=self.torch.float64))[:, 0]
-        counts = self.plan_counts(W, n_local, epoch)
-        seed_r = resampler._seed + 0x9E3779B97F4A7C15 * (self.rank + 1)
-        # this shard draws, kicks and postselects the particles every destination takes from it
-        defer = hasattr(resampler, "_flush_failed_warning")       # stay asynchronous; warn at the next sync
-        rows, n_failed = eng.lw_resample_philox_sharded(model._native_desc(), resampler._postselect, updater._x,
-                                                        updater._w, float(W[self.rank]),   # local normaliser
-                                                        a, mean, S, counts[:, self.rank], seed_r, epoch,
-                                                        resampler._maxiter, sync=not defer)
+        if stay:
+            x_new, n_failed = eng.lw_resample_philox(model._native_desc(), resampler._postselect, updater._x,
+                                                     updater._w, float(W[self.rank]), a, mean, S,
+                                                     int(totals[self.rank]), seed_r, epoch, resampler._maxiter,
+                                                     sync=not defer)
+            self.last_shard_sizes = totals
+        else:
+            # rebalance (or placement="mixed"): this shard draws, kicks and postselects the particles every
+            # destination takes from it; finished rows travel by one all-to-all
+            if self.placement == "local":
+                counts = self.plan_counts_minimal(totals, self._balanced_sizes(n_total))
+                self.n_rebalances += 1
+            else:
+                counts = self.plan_counts(W, target, epoch)
+                if n_total != target * G:
+                    raise ValueError("placement='mixed' needs equal shard sizes")
+            rows, n_failed = eng.lw_resample_philox_sharded(model._native_desc(), resampler._postselect,
+                                                            updater._x, updater._w, float(W[self.rank]),
+                                                            a, mean, S, counts[:, self.rank], seed_r, epoch,
+                                                            resampler._maxiter, sync=not defer)
+            recv = self.exchange_rows(rows, counts)                  # the only bandwidth step
+            x_new = recv.to(eng.device).t().contiguous()             # back to SoA
+            self.last_shard_sizes = counts.sum(axis=1)
         if defer:
             resampler._pending_failed = eng
-        recv = self.exchange_rows(rows, counts)                      # (n_local, d), the only bandwidth step
-        x_new = recv.to(eng.device).t().contiguous()                 # back to SoA
         if n_failed:
             warnings.warn("Liu-West resampling failed to find valid models for {} particles within {} "
                           "iterations.".format(n_failed, resampler._maxiter), ResamplerWarning)
-        n_total = n_local * self.world_size
         return ParticleDistribution._from_device(eng, x_new, None, norm=float(n_total), sumsq=float(n_total))
+
+    def _balanced_sizes(self, n_total):
+        G = self.world_size
+        q = np.full(G, n_total // G, dtype=np.int64)
+        q[: n_total - q.sum()] += 1
+        return q

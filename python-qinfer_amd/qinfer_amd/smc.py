@@ -119,8 +119,9 @@ class SMCUpdater(ParticleDistribution):
 
     @property
     def n_particles_global(self):
-        n = self.n_particles
-        return n if self._comm is None else n * self._comm.world_size
+        """Particles over all shards (== n_particles without a comm).  Constant between resets: under
+        local placement the shard sizes float, their sum does not."""
+        return self.n_particles if self._comm is None else self._n_global
 
     # ------------------------------------------------------------------ sharding hooks
     def _reduce_stats(self, st, extra=None):
@@ -156,10 +157,14 @@ class SMCUpdater(ParticleDistribution):
         if n_particles is not None and only_params is not None:
             raise ValueError("Cannot set both n_particles and only_params.")
         if n_particles is None:
-            n_particles = self.n_particles
+            # sharded: the nominal per-rank size, not the current (floating) one, so that every rank
+            # agrees on the global count
+            n_particles = self.n_particles if self._comm is None else self._n_local_nominal
+        self._n_local_nominal = n_particles
         eng = self._eng
         d = self.model.n_modelparams
         n_total = n_particles if self._comm is None else n_particles * self._comm.world_size
+        self._n_global = n_total
         if reset_weights:
             # uniform weights 1/N (smc.py:307), held implicitly: all-ones with normaliser N
             self._w = None
@@ -256,11 +261,15 @@ class SMCUpdater(ParticleDistribution):
                 raise ValueError("update() takes exactly one experiment")
             d = self._x.shape[0]
             if self._comm is not None:
-                # sharded: leave the sums on the device and all-gather them (one collective, one sync)
-                eng.update_fused(self._desc, self._x, self._w, w_out, self._norm, exps[0],
-                                 _as_int_outcome(outcome), sync=False)
+                # sharded: this shard's sums land in pinned host memory like the single-GPU path, then ONE
+                # small all-gather (shared memory on one host, else the backend's) makes them global
                 n_mom = d + d * (d + 1) // 2 if d <= 4 else 0
-                norm, sumsq, wmin, n_bad = self._comm.combine_update_stats(eng._stats[:4 + n_mom])
+                st = eng.update_fused(self._desc, self._x, self._w, w_out, self._norm, exps[0],
+                                      _as_int_outcome(outcome), moments=bool(n_mom))
+                if n_mom:
+                    st = st[0]
+                norm, sumsq, wmin, n_bad = self._comm.allreduce_update_stats(
+                    eng, st.sum, st.sumsq, st.min, st.n_bad, eng._mom[d] if n_mom else None)
                 self._shard_sums = self._comm.last_shard_sums
                 if n_mom:
                     g = self._comm.last_extra
@@ -522,8 +531,8 @@ class SMCUpdater(ParticleDistribution):
                 self.resampler._flush_failed_warning(synchronize=True)
         if isinstance(new, ParticleDistribution):
             self._x, self._w, self._norm, self._sumsq = new._x, new._w, new._norm, new._sumsq
-            if self._comm is not None:
-                self._shard_sums = np.full(self._comm.world_size, float(self.n_particles))
+            if self._comm is not None:           # uniform weights: a shard's weight total is its size
+                self._shard_sums = np.asarray(self._comm.last_shard_sizes, dtype=np.float64)
         else:                                           # foreign resampler returning host arrays
             self._set_host(new.particle_locations, new.particle_weights)
         self._w_alt = None

@@ -129,8 +129,73 @@ def _check_resample_protocol(comm, rank, world, tmpdir):
         assert abs(frac0 - W[0] / W.sum()) < 5 * np.sqrt(0.25 / g.size)
 
 
+def _check_host_exchange(comm, rank, world, tmpdir):
+    """Shared-memory all-gather: right rows, rank-ordered, over many back-to-back calls of varying length
+    (the two-bank sequence protocol must never hand out a stale or a too-new payload)."""
+    assert comm._host is not None, "all ranks are on this host: the shared-memory exchange must be active"
+    rs = np.random.RandomState(17)                       # same stream on every rank -> same lengths
+    for k in range(3000):
+        n = int(rs.randint(1, 40))
+        mine = np.arange(n, dtype=np.float64) * (rank + 1) + k
+        rows = comm._host.all_gather(mine)
+        assert rows.shape == (world, n)
+        for r in range(world):
+            np.testing.assert_array_equal(rows[r], np.arange(n, dtype=np.float64) * (r + 1) + k)
+        if k % 500 == rank:                              # desynchronise the ranks now and then
+            import time
+            time.sleep(0.01)
+    # gather_rows routes small vectors through it, large ones through the backend -- same answer
+    import torch
+    small = comm.gather_rows(np.array([rank + 0.5, 2.0]))
+    np.testing.assert_array_equal(small[:, 0], np.arange(world) + 0.5)
+    big = comm.gather_rows(torch.arange(1000, dtype=torch.float64) + rank)
+    np.testing.assert_array_equal(big[:, 0], np.arange(world, dtype=np.float64))
+    # a group built without it gives the same reductions through gloo
+    from qinfer_amd.parallel import ParticleShardGroup
+    plain = ParticleShardGroup(seed=1, host_exchange=False)
+    assert plain._host is None
+    a = comm.combine_update_stats(np.array([1.0 + rank, 2.0, -float(rank), 0.0, 5.0 * rank]))
+    b = plain.combine_update_stats(np.array([1.0 + rank, 2.0, -float(rank), 0.0, 5.0 * rank]))
+    assert a == b and np.array_equal(comm.last_extra, plain.last_extra)
+
+
+def _check_plans(comm, rank, world, tmpdir):
+    """Children-per-source totals: identical on all ranks, exact sum, right law; minimal-movement matrix."""
+    from qinfer_amd.parallel import ParticleShardGroup as P
+    W = np.array([3.0, 1.0][:world] + [1.0] * max(0, world - 2))
+    n_total = 100000 * world
+    T = comm.plan_totals(W, n_total, epoch=4)
+    rows = comm.gather_rows(T.astype(np.float64))
+    for r in range(1, world):
+        assert np.array_equal(rows[0], rows[r])
+    assert T.sum() == n_total and np.array_equal(T, comm.plan_totals(W, n_total, epoch=4))
+    assert not np.array_equal(T, comm.plan_totals(W, n_total, epoch=5))
+    p = W / W.sum()
+    assert np.all(np.abs(T - n_total * p) < 6 * np.sqrt(n_total * p * (1 - p)) + 1)
+    for totals, quota in (([120, 90, 100, 90], 100), ([0, 200], 100), ([7, 7, 7], 7), ([10, 0, 20, 10], [10, 10, 10, 10])):
+        C = P.plan_counts_minimal(totals, quota)
+        q = np.broadcast_to(np.asarray(quota), (len(totals),))
+        assert np.array_equal(C.sum(axis=0), totals) and np.array_equal(C.sum(axis=1), q) and C.min() >= 0
+        moved = C.sum() - np.trace(C)
+        assert moved == np.maximum(np.asarray(totals) - q, 0).sum()      # only the surpluses travel
+    with pytest.raises(ValueError):
+        P.plan_counts_minimal([5, 5], 6)
+
+
 def test_reductions_gloo(tmp_path):
     _run("_check_reductions", tmp_path)
+
+
+def test_host_exchange_gloo(tmp_path):
+    _run("_check_host_exchange", tmp_path)
+
+
+def test_host_exchange_three_ranks(tmp_path):
+    _run("_check_host_exchange", tmp_path, world=3)
+
+
+def test_plans_gloo(tmp_path):
+    _run("_check_plans", tmp_path)
 
 
 def test_resample_protocol_gloo(tmp_path):
@@ -141,10 +206,22 @@ def test_resample_protocol_gloo(tmp_path):
 # GPU legs: the full sharded SMCUpdater (HIP kernels + protocol).  One GPU box has one device, so
 # (i) two processes share it and talk over gloo, (ii) a world-size-1 RCCL group checks the nccl path.
 def _check_sharded_updater(comm, rank, world, tmpdir):
+    for variant in ("local", "rebalance-always", "mixed"):
+        _check_sharded_updater_variant(comm, rank, world, tmpdir, variant)
+
+
+def _check_sharded_updater_variant(comm0, rank, world, tmpdir, variant):
     import warnings
     import torch
     import qinfer_amd as qi
+    from qinfer_amd.parallel import ParticleShardGroup
     torch.cuda.set_device(0)
+    if variant == "local":
+        comm = comm0                                  # children stay with their ancestor, sizes float
+    elif variant == "rebalance-always":
+        comm = ParticleShardGroup(seed=1234, rebalance_tol=-1.0)   # every resample takes the minimal-movement exchange
+    else:
+        comm = ParticleShardGroup(seed=1234, placement="mixed")    # fully mixing count matrix
     n_local = 60000
     ts = (9 / 8) ** np.arange(50.0)
     rs = np.random.RandomState(0)
@@ -161,6 +238,16 @@ def _check_sharded_updater(comm, rank, world, tmpdir):
     rows = comm.gather_rows(torch.from_numpy(rec))
     for r in range(1, world):
         assert np.array_equal(rows[0], rows[r]), "ranks disagree on the global quantities"
+    sizes = comm.gather_rows(np.array([float(upd.n_particles)]))[:, 0]
+    assert sizes.sum() == n_local * world == upd.n_particles_global      # the global count is conserved
+    if variant == "local":
+        assert comm.n_rebalances == 0 and np.abs(sizes - n_local).max() < 0.05 * n_local
+        if world > 1:
+            assert np.abs(sizes - n_local).max() > 0                      # sizes do float
+    else:
+        assert np.all(sizes == n_local)
+        if variant == "rebalance-always":
+            assert comm.n_rebalances == upd.resample_count > 0
     np.save(os.path.join(tmpdir, "locs_%d.npy" % rank), upd.particle_locations)
     comm.dist.barrier()
     if rank == 0:
