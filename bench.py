@@ -142,8 +142,9 @@ def main():
         wall = time.perf_counter() - t0
         # every update kernel of the timed region carried start/stop events (hipExtLaunchKernelGGL, on the
         # launch stream); their durations are read here, once, not per step
-        kernel_ms = eng.profile_read()
+        all_ms, tags = eng.profile_read()
         eng.set_profiling(False)
+        kernel_ms, sampler_ms = all_ms[tags == 0], all_ms[tags == 1]
         assert len(kernel_ms) == args.steps, (len(kernel_ms), args.steps)
 
     wall_t = torch.tensor([wall], dtype=torch.float64, device="cuda")
@@ -194,6 +195,15 @@ def main():
                          "implicit_uniform_weight_variant": ones_info},
             "posterior_mean": float(upd.est_mean()[0]),
         }
+        if len(sampler_ms):
+            # the resampler's main kernel, same clock: reads w (8 B), gathers x (8d), writes x' (8d) per particle
+            samp_s = float(sampler_ms.mean()) * 1e-3
+            samp_bytes = (8 + 16 * 1) * n
+            line["resample_kernel"] = {"kernel": "k_bucket_sample<D=1,512>", "launches": int(len(sampler_ms)),
+                                       "avg_kernel_us": samp_s * 1e6, "algorithmic_bytes_per_launch": samp_bytes,
+                                       "achieved": samp_bytes / samp_s / 1e9, "unit": "GB/s",
+                                       "frac": samp_bytes / samp_s / 1e9 / HBM_PEAK_GBS,
+                                       "bound_in_practice": "VALU issue (Philox + Box-Muller + LDS search), see DESIGN.md 3.3"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(int(args.cpu_particles), args.cpu_data)
         print(json.dumps(line), flush=True)

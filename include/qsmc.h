@@ -87,12 +87,15 @@ int         qsmc_destroy(qsmc_handle_t h);
 /* Kernel timing for bench.py's roofline line: when enabled, qsmc_update_fused brackets its main
  * kernel (not the finalize/copy) with hipEvents on `stream` (hipExtLaunchKernelGGL start/stop events:
  * the kernel's own execution, what rocprofv3 --kernel-trace reports).  Up to 4096 launches are kept
- * in a ring; qsmc_profile_read hands back their durations in milliseconds, oldest first, and clears
+ * in a ring (the bucketed sampler's main kernel is timed the same way, tagged QSMC_PROF_SAMPLE);
+ * qsmc_profile_read hands back their durations in milliseconds and tags, oldest first, and clears
  * the ring -- one call after the timed region, nothing per step.  qsmc_last_update_kernel_ms waits
  * for and returns the most recent one. */
 int         qsmc_set_profiling(qsmc_handle_t h, int enabled);
 int         qsmc_last_update_kernel_ms(qsmc_handle_t h, float *ms_out);
-int         qsmc_profile_read(qsmc_handle_t h, float *ms_out, int32_t cap, int32_t *n_out);
+int         qsmc_profile_read(qsmc_handle_t h, float *ms_out, int32_t *tags_out, int32_t cap, int32_t *n_out);
+#define QSMC_PROF_UPDATE 0      /* k_update_fused */
+#define QSMC_PROF_SAMPLE 1      /* k_bucket_sample (the resampler's dominant kernel) */
 
 /* ---- likelihood, contract form (abstract_model.py:444-468 + :666-686; a6-a10) ------------ */
 /* L_out[(o * n_e + e) * n + i] = Pr(outcomes[o] | x_i ; exps[e]).  This is the

@@ -58,6 +58,7 @@ struct qsmc_ctx {
     int profiling;
     hipEvent_t *prof_ev;   // QSMC_PROF_CAP (start, stop) pairs, created on first qsmc_set_profiling(1)
     int prof_n;            // profiled launches since the last qsmc_profile_read / set_profiling
+    unsigned char *prof_tag;   // which kernel each ring entry timed (QSMC_PROF_*)
     char hip_err[256];
 };
 
@@ -1589,6 +1590,16 @@ static int collect_stats(qsmc_ctx *h, int ns, qsmc_update_stats_t *stats_host, d
     return QSMC_OK;
 }
 
+// Next (start, stop) event pair of the profiling ring, or (null, null) when profiling is off.
+static void prof_events(qsmc_ctx *h, int tag, hipEvent_t *e0, hipEvent_t *e1) {
+    if (!h->profiling || !h->prof_ev) return;
+    const int slot = h->prof_n % QSMC_PROF_CAP;         // a ring: beyond the capacity the oldest are overwritten
+    *e0 = h->prof_ev[2 * slot];
+    *e1 = h->prof_ev[2 * slot + 1];
+    h->prof_tag[slot] = (unsigned char)tag;
+    ++h->prof_n;
+}
+
 template <int KIND>
 static void launch_update(qsmc_ctx *h, bool vec2, int grid, hipStream_t s, const double *x, int64_t ldx,
                           int64_t n, const double *w_in, double *w_out, double prev_norm, const ExpArgs &e,
@@ -1596,12 +1607,7 @@ static void launch_update(qsmc_ctx *h, bool vec2, int grid, hipStream_t s, const
     // In profiling mode the launch carries start/stop events, so the elapsed time is the kernel's
     // own execution (what rocprofv3 --kernel-trace reports), not launch latency.
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (h->profiling && h->prof_ev) {
-        const int slot = h->prof_n % QSMC_PROF_CAP;     // a ring: beyond the capacity the oldest are overwritten
-        e0 = h->prof_ev[2 * slot];
-        e1 = h->prof_ev[2 * slot + 1];
-        ++h->prof_n;
-    }
+    prof_events(h, QSMC_PROF_UPDATE, &e0, &e1);
 #define LU(V, O)                                                                                          \
     hipExtLaunchKernelGGL((k_update_fused<KIND, V, O>), dim3(grid), dim3(QSMC_BLOCK), 0, s, e0, e1, 0, x, ldx, \
                           n, w_in, w_out, prev_norm, e, outcome, ro)
@@ -1751,6 +1757,7 @@ int qsmc_destroy(qsmc_handle_t h) {
     if (h->prof_ev) {
         for (int i = 0; i < 2 * QSMC_PROF_CAP; ++i) (void)hipEventDestroy(h->prof_ev[i]);
         free(h->prof_ev);
+        free(h->prof_tag);
     }
     delete h;
     return QSMC_OK;
@@ -1763,6 +1770,8 @@ int qsmc_set_profiling(qsmc_handle_t h, int enabled) {
         if (!ev) return QSMC_ERR_ALLOC;
         for (int i = 0; i < 2 * QSMC_PROF_CAP; ++i) HIP_TRY(h, hipEventCreate(&ev[i]));
         h->prof_ev = ev;
+        h->prof_tag = static_cast<unsigned char *>(calloc(QSMC_PROF_CAP, 1));
+        if (!h->prof_tag) return QSMC_ERR_ALLOC;
     }
     h->profiling = enabled ? 1 : 0;
     h->prof_n = 0;
@@ -1771,13 +1780,16 @@ int qsmc_set_profiling(qsmc_handle_t h, int enabled) {
 
 int qsmc_last_update_kernel_ms(qsmc_handle_t h, float *ms_out) {
     if (!h || !ms_out || !h->prof_ev || h->prof_n < 1) return QSMC_ERR_INVALID;
-    const int slot = (h->prof_n - 1) % QSMC_PROF_CAP;
+    int slot = -1;
+    for (int i = h->prof_n - 1; i >= 0 && i > h->prof_n - 1 - QSMC_PROF_CAP; --i)
+        if (h->prof_tag[i % QSMC_PROF_CAP] == QSMC_PROF_UPDATE) { slot = i % QSMC_PROF_CAP; break; }
+    if (slot < 0) return QSMC_ERR_INVALID;
     HIP_TRY(h, hipEventSynchronize(h->prof_ev[2 * slot + 1]));
     HIP_TRY(h, hipEventElapsedTime(ms_out, h->prof_ev[2 * slot], h->prof_ev[2 * slot + 1]));
     return QSMC_OK;
 }
 
-int qsmc_profile_read(qsmc_handle_t h, float *ms_out, int32_t cap, int32_t *n_out) {
+int qsmc_profile_read(qsmc_handle_t h, float *ms_out, int32_t *tags_out, int32_t cap, int32_t *n_out) {
     if (!h || !ms_out || !n_out || cap < 0) return QSMC_ERR_INVALID;
     int n = h->prof_n < QSMC_PROF_CAP ? h->prof_n : QSMC_PROF_CAP;
     if (n > cap) n = cap;
@@ -1786,6 +1798,7 @@ int qsmc_profile_read(qsmc_handle_t h, float *ms_out, int32_t cap, int32_t *n_ou
         const int slot = (first + i) % QSMC_PROF_CAP;
         HIP_TRY(h, hipEventSynchronize(h->prof_ev[2 * slot + 1]));
         HIP_TRY(h, hipEventElapsedTime(&ms_out[i], h->prof_ev[2 * slot], h->prof_ev[2 * slot + 1]));
+        if (tags_out) tags_out[i] = h->prof_tag[slot];
     }
     *n_out = n;
     h->prof_n = 0;
@@ -2255,8 +2268,10 @@ static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int3
         // 512-thread workgroups, CDF chunk + guide in LDS (40 KB -> 3 resident workgroups per CU, so one
         // workgroup's scan phase overlaps another's sampling loop); x is gathered from the chunk's
         // 32 KB global window (L2-resident).
+        hipEvent_t pe0 = nullptr, pe1 = nullptr;
+        prof_events(h, QSMC_PROF_SAMPLE, &pe0, &pe1);
 #define LAUNCH_B(DD, BT)                                                                                       \
-    hipLaunchKernelGGL((k_bucket_sample<DD, BT>), dim3(bp.max_items), dim3(BT), 0, s, model->kind, d,           \
+    hipExtLaunchKernelGGL((k_bucket_sample<DD, BT>), dim3(bp.max_items), dim3(BT), 0, s, pe0, pe1, 0, model->kind, d, \
                        model->min_freq, postselect, x_in, ldx_in, n_in, w, inv_norm, offsets,                       \
                        (const double *)nullptr, chunks, bp.slot_off, bp.item_off, bp.item_chunk, lw, k0, k1, ep,     \
                        maxiter, x_out, pl, nf, bp.retry_list, retry_count)

@@ -100,11 +100,13 @@ class Engine:
         self._chk(self.lib.qsmc_set_profiling(self.h, int(bool(enabled))), "qsmc_set_profiling")
 
     def profile_read(self, cap=4096):
-        """Durations (ms, oldest first) of the update kernels launched since profiling was enabled / last read."""
+        """(durations in ms, tags) of the timed kernels launched since profiling was enabled / last read,
+        oldest first.  tag 0 = update kernel, 1 = the resampler's sampling kernel."""
         buf = (C.c_float * cap)()
+        tags = (C.c_int32 * cap)()
         n = C.c_int32()
-        self._chk(self.lib.qsmc_profile_read(self.h, buf, cap, C.byref(n)), "qsmc_profile_read")
-        return np.array(buf[:n.value], dtype=np.float64)
+        self._chk(self.lib.qsmc_profile_read(self.h, buf, tags, cap, C.byref(n)), "qsmc_profile_read")
+        return np.array(buf[:n.value], dtype=np.float64), np.array(tags[:n.value], dtype=np.int64)
 
     def last_update_kernel_ms(self):
         ms = C.c_float()
