@@ -47,7 +47,9 @@ enum qsmc_model_kind {
     QSMC_MODEL_BINOMIAL_PRECESSION = 2, /* derived_models.py:222-360 BinomialModel(SimplePrecession) */
     QSMC_MODEL_RB = 3,                  /* rb.py:81-195 RandomizedBenchmarkingModel()                */
     QSMC_MODEL_RB_INTERLEAVED = 4,      /* rb.py:81-195 (interleaved=True)                           */
-    QSMC_MODEL_TOMOGRAPHY = 5           /* tomography/models.py:82-226 TomographyModel               */
+    QSMC_MODEL_TOMOGRAPHY = 5,          /* tomography/models.py:82-226 TomographyModel               */
+    QSMC_MODEL_BINOMIAL_RB = 6,         /* BinomialModel(RandomizedBenchmarkingModel()): simple_est.py:212 */
+    QSMC_MODEL_BINOMIAL_RB_INTERLEAVED = 7  /* ... (interleaved=True)                                 */
 };
 
 typedef struct qsmc_model {

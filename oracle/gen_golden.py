@@ -409,6 +409,79 @@ def g7_design():
     print("g7_design", out['prec_risk'], out['bin_eig'], out['rb_risk'])
 
 
+def g8_binomial_rb():
+    """BinomialModel(RandomizedBenchmarkingModel) (the model behind simple_est_rb, simple_est.py:184-254):
+    likelihood KATs, one SMC trajectory, and the reference's simple_est_prec / simple_est_rb front-ends on
+    fixed data tables."""
+    out = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        rb = qinfer.RandomizedBenchmarkingModel()
+        bm = qinfer.BinomialModel(rb)
+        g = np.array([0.0, 0.35, 0.9, 1.0])
+        P, A, B = np.meshgrid(np.array([0.0, 0.8, 0.95, 0.999, 1.0]), g, g, indexing='ij')
+        x = np.stack([P.ravel(), A.ravel(), B.ravel()], axis=1)
+        x = x[rb.are_models_valid(x)]                         # pmf needs 0 <= pr1 <= 1
+        ep = np.empty((4,), dtype=bm.expparams_dtype)
+        ep['m'] = [0, 1, 10, 800]
+        ep['n_meas'] = [25, 25, 7, 40]
+        out['brb_x'], out['brb_m'], out['brb_n'] = x, ep['m'], ep['n_meas']
+        out['brb_L'] = bm.likelihood(np.arange(41), x, ep)
+        rbi = qinfer.RandomizedBenchmarkingModel(interleaved=True)
+        bmi = qinfer.BinomialModel(rbi)
+        rs = np.random.RandomState(5)
+        xi = rs.uniform(0, 1.0, size=(200, 4))
+        xi = xi[rbi.are_models_valid(xi)][:48]
+        ep = np.empty((4,), dtype=bmi.expparams_dtype)
+        ep['m'] = [1, 7, 50, 400]
+        ep['reference'] = [True, False, True, False]
+        ep['n_meas'] = [10, 25, 25, 3]
+        out['brbi_x'], out['brbi_m'], out['brbi_ref'], out['brbi_n'] = xi, ep['m'], ep['reference'], ep['n_meas']
+        out['brbi_L'] = bmi.likelihood(np.arange(26), xi, ep)
+        out['brbi_dtype_names'] = np.array(list(np.dtype(bmi.expparams_dtype).names))
+        out['brb_dtype_names'] = np.array(list(np.dtype(bm.expparams_dtype).names))
+    np.savez_compressed(os.path.join(OUT, "g8_binomial_rb.npz"), **out)
+    print("g8_binomial_rb", out['brb_L'].shape, out['brbi_L'].shape)
+    # trajectory
+    prior = qinfer.PostselectedDistribution(qinfer.UniformDistribution([[0.8, 1], [0, 1], [0, 1]]), bm)
+    ep = np.empty((60,), dtype=bm.expparams_dtype)
+    ep['m'] = 1 + 5 * np.arange(60)
+    ep['n_meas'] = 25
+    sim = lambda k, e: int(np.random.binomial(25, 0.3 * 0.95 ** int(e['m'][0]) + 0.5))
+    run_trajectory("g8_binomial_rb_n1500", bm, prior, 1500, ep, sim)
+
+
+def g8_simple_est():
+    """simple_est_prec / simple_est_rb of the reference (simple_est.py:121-254) on fixed tables under
+    np.random.seed(4): a host-RNG (parity-mode) run of the build consumes the same stream."""
+    from qinfer.simple_est import simple_est_prec, simple_est_rb
+    out = {}
+    rs = np.random.RandomState(21)
+    # precession table: (counts, t, n_shots)
+    ts = np.linspace(1.0, 60.0, 40)
+    n_shots = np.full(40, 30)
+    counts = rs.binomial(n_shots, np.sin(0.31 * ts / 2) ** 2)
+    prec = np.column_stack([counts, ts, n_shots]).astype(float)
+    # RB table: (counts, m, n_shots)
+    ms = np.arange(1, 160, 4)
+    n_shots_rb = np.full(ms.shape, 40)
+    counts_rb = rs.binomial(n_shots_rb, 0.3 * 0.97 ** ms + 0.5)
+    rbt = np.column_stack([counts_rb, ms, n_shots_rb]).astype(float)
+    for name, fn, table, kw in (("prec", simple_est_prec, prec, dict(freq_min=0.0, freq_max=1.0, n_particles=3000)),
+                                ("rb", simple_est_rb, rbt, dict(p_min=0.8, p_max=1.0, n_particles=4000))):
+        np.random.seed(4)                             # legacy global RNG: prior, resampler u and randn
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            mean, cov, extra = fn(table, return_all=True, **kw)
+        upd = extra['updater']
+        out[name + "_table"] = table
+        out[name + "_mean"], out[name + "_cov"] = np.atleast_1d(mean), np.atleast_2d(cov)
+        out[name + "_resample_count"] = upd.resample_count
+        out[name + "_n_ess"] = upd.n_ess
+        print("g8_simple_est", name, mean, upd.resample_count)
+    np.savez_compressed(os.path.join(OUT, "g8_simple_est.npz"), **out)
+
+
 if __name__ == "__main__":
     g1_precession()
     g1_binomial()
@@ -420,4 +493,6 @@ if __name__ == "__main__":
     g5_canonicalize()
     g6_guards()
     g7_design()
+    g8_binomial_rb()
+    g8_simple_est()
     print("total bytes:", sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT)))

@@ -153,6 +153,15 @@ def lik_rb(outcomes, x, m, reference=None):
     return _two_outcome(outcomes, pr0)
 
 
+def lik_binomial_rb(outcomes, x, m, n_meas, reference=None):
+    """BinomialModel over rb.py:178-195 (derived_models.py:314-329): pr1 = L_RB(outcome 1) = A p^m + B
+    (computed as 1 - pr0, like the reference's chain of calls); L[k] = Binom(n_meas, pr1).pmf(k)."""
+    outcomes = np.atleast_1d(np.asarray(outcomes))
+    pr1 = lik_rb([1], x, m, reference)[0]                         # (N, n_e)
+    n_meas = np.atleast_1d(np.asarray(n_meas))
+    return np.stack([binom_pmf(n_meas[None, :], int(k), pr1) for k in outcomes], axis=0)
+
+
 def valid_rb(x):
     """rb.py:149-176."""
     x = np.asarray(x)
@@ -391,6 +400,12 @@ def binomial_precession_model(min_freq=0.0):
 def rb_model(interleaved=False):
     return OracleModel('rb', 4 if interleaved else 3,
                        lambda o, x, e: lik_rb(o, x, e['m'], e.get('reference')),
+                       valid_rb)
+
+
+def binomial_rb_model(interleaved=False):
+    return OracleModel('binomial_rb', 4 if interleaved else 3,
+                       lambda o, x, e: lik_binomial_rb(o, x, e['m'], e['n_meas'], e.get('reference')),
                        valid_rb)
 
 

@@ -55,6 +55,16 @@ def install():
             setattr(np, n, t)
     if not hasattr(np, "trapz"):
         np.trapz = np.trapezoid
+    if "issctype" not in np.__dict__:      # removed in NumPy 2.0; used by simple_est.py:86-87
+        def issctype(rep):
+            if not isinstance(rep, (type, np.dtype)):
+                return False
+            try:
+                t = np.dtype(rep).type
+            except TypeError:
+                return False
+            return t is not np.object_ and issubclass(t, np.generic)
+        np.issctype = issctype
     if REFERENCE_SRC not in sys.path:
         sys.path.insert(0, REFERENCE_SRC)
     import qinfer

@@ -59,19 +59,22 @@ template <> struct Model<QSMC_MODEL_PRECESSION> {
     }
 };
 
+// derived_models.py:317-325 + utils.py:106-111: Binom(n_meas, pr1).pmf(k), pr1 = L_underlying(outcome 1)
+__host__ __device__ __forceinline__ double binom_pmf(double pr1, const ExpArgs &e, int64_t o) {
+    const double k = (double)o;
+    if (o < 0 || k > e.n_meas) return 0.0;
+    if (isfinite(e.comb))
+        return e.comb * pow(pr1, k) * pow(1.0 - pr1, e.n_meas - k);
+    // huge n_meas: C(n,k) overflows float64 -> log space
+    const double lp = (k > 0.0 ? k * log(pr1) : 0.0) +
+                      (e.n_meas - k > 0.0 ? (e.n_meas - k) * log1p(-pr1) : 0.0);
+    return exp(e.log_comb + lp);
+}
+
 template <> struct Model<QSMC_MODEL_BINOMIAL_PRECESSION> {
     static constexpr int D = 1;
     static __host__ __device__ __forceinline__ double lik(const double *p, const ExpArgs &e, int64_t o) {
-        // derived_models.py:317-325: pr1 = L_underlying(outcome 1) = 1 - pr0;  Binom(n, pr1).pmf(k)
-        const double pr1 = 1.0 - precession_pr0(p[0], e);
-        const double k = (double)o;
-        if (o < 0 || k > e.n_meas) return 0.0;
-        if (isfinite(e.comb))
-            return e.comb * pow(pr1, k) * pow(1.0 - pr1, e.n_meas - k);
-        // huge n_meas: C(n,k) overflows float64 -> log space
-        const double lp = (k > 0.0 ? k * log(pr1) : 0.0) +
-                          (e.n_meas - k > 0.0 ? (e.n_meas - k) * log1p(-pr1) : 0.0);
-        return exp(e.log_comb + lp);
+        return binom_pmf(1.0 - precession_pr0(p[0], e), e, o);
     }
     static __host__ __device__ __forceinline__ bool valid(const double *p, double min_freq) {
         return p[0] > min_freq;
@@ -109,6 +112,31 @@ template <> struct Model<QSMC_MODEL_RB_INTERLEAVED> {
     }
 };
 
+// BinomialModel over the RB models (the model simple_est_rb builds, simple_est.py:212): n_meas sequences
+// of length m, `o` of them survived; pr1 = L_RB(outcome 1) = 1 - pr0.
+template <> struct Model<QSMC_MODEL_BINOMIAL_RB> {
+    static constexpr int D = 3;
+    static __host__ __device__ __forceinline__ double lik(const double *p, const ExpArgs &e, int64_t o) {
+        const double pr0 = 1.0 - (p[1] * pow(p[0], e.m) + p[2]);
+        return binom_pmf(1.0 - pr0, e, o);
+    }
+    static __host__ __device__ __forceinline__ bool valid(const double *p, double) {
+        return Model<QSMC_MODEL_RB>::valid(p, 0.0);
+    }
+};
+
+template <> struct Model<QSMC_MODEL_BINOMIAL_RB_INTERLEAVED> {
+    static constexpr int D = 4;
+    static __host__ __device__ __forceinline__ double lik(const double *p, const ExpArgs &e, int64_t o) {
+        const double pe = e.reference ? p[1] : p[0] * p[1];
+        const double pr0 = 1.0 - (p[2] * pow(pe, e.m) + p[3]);
+        return binom_pmf(1.0 - pr0, e, o);
+    }
+    static __host__ __device__ __forceinline__ bool valid(const double *p, double) {
+        return Model<QSMC_MODEL_RB_INTERLEAVED>::valid(p, 0.0);
+    }
+};
+
 template <> struct Model<QSMC_MODEL_TOMOGRAPHY> {
     static constexpr int D = QSMC_MAX_D;
     static __host__ __device__ __forceinline__ double lik(const double *p, const ExpArgs &e, int64_t o) {
@@ -126,8 +154,10 @@ __host__ __device__ __forceinline__ bool model_valid(int kind, const double *p, 
     switch (kind) {
         case QSMC_MODEL_PRECESSION:
         case QSMC_MODEL_BINOMIAL_PRECESSION: return p[0] > min_freq;
-        case QSMC_MODEL_RB: return Model<QSMC_MODEL_RB>::valid(p, 0.0);
-        case QSMC_MODEL_RB_INTERLEAVED: return Model<QSMC_MODEL_RB_INTERLEAVED>::valid(p, 0.0);
+        case QSMC_MODEL_RB:
+        case QSMC_MODEL_BINOMIAL_RB: return Model<QSMC_MODEL_RB>::valid(p, 0.0);
+        case QSMC_MODEL_RB_INTERLEAVED:
+        case QSMC_MODEL_BINOMIAL_RB_INTERLEAVED: return Model<QSMC_MODEL_RB_INTERLEAVED>::valid(p, 0.0);
         default: return true;
     }
 }

@@ -1495,7 +1495,8 @@ static int make_exp_args(const qsmc_model_t *model, const qsmc_expparam_t *ep, i
     for (int i = 0; i < QSMC_MAX_D; ++i) out->meas[i] = ep->meas[i];
     out->comb = 1.0;
     out->log_comb = 0.0;
-    if (model->kind == QSMC_MODEL_BINOMIAL_PRECESSION) {
+    if (model->kind == QSMC_MODEL_BINOMIAL_PRECESSION || model->kind == QSMC_MODEL_BINOMIAL_RB ||
+        model->kind == QSMC_MODEL_BINOMIAL_RB_INTERLEAVED) {
         const double n = (double)ep->n_meas, k = (double)outcome;
         if (outcome >= 0 && k <= n) {
             out->log_comb = lgamma(n + 1.0) - lgamma(k + 1.0) - lgamma(n - k + 1.0);
@@ -1519,8 +1520,10 @@ static int check_model(const qsmc_model_t *m) {
     switch (m->kind) {
         case QSMC_MODEL_PRECESSION:
         case QSMC_MODEL_BINOMIAL_PRECESSION: return m->d == 1 ? QSMC_OK : QSMC_ERR_INVALID;
-        case QSMC_MODEL_RB: return m->d == 3 ? QSMC_OK : QSMC_ERR_INVALID;
-        case QSMC_MODEL_RB_INTERLEAVED: return m->d == 4 ? QSMC_OK : QSMC_ERR_INVALID;
+        case QSMC_MODEL_RB:
+        case QSMC_MODEL_BINOMIAL_RB: return m->d == 3 ? QSMC_OK : QSMC_ERR_INVALID;
+        case QSMC_MODEL_RB_INTERLEAVED:
+        case QSMC_MODEL_BINOMIAL_RB_INTERLEAVED: return m->d == 4 ? QSMC_OK : QSMC_ERR_INVALID;
         case QSMC_MODEL_TOMOGRAPHY: return (m->d >= 1 && m->d <= QSMC_MAX_D) ? QSMC_OK : QSMC_ERR_INVALID;
         default: return QSMC_ERR_INVALID;
     }
@@ -1829,6 +1832,8 @@ int qsmc_likelihood(qsmc_handle_t h, const qsmc_model_t *model, const double *x,
                 LAUNCH_L(QSMC_MODEL_BINOMIAL_PRECESSION)
                 LAUNCH_L(QSMC_MODEL_RB)
                 LAUNCH_L(QSMC_MODEL_RB_INTERLEAVED)
+                LAUNCH_L(QSMC_MODEL_BINOMIAL_RB)
+                LAUNCH_L(QSMC_MODEL_BINOMIAL_RB_INTERLEAVED)
                 LAUNCH_L(QSMC_MODEL_TOMOGRAPHY)
 #undef LAUNCH_L
             }
@@ -1880,6 +1885,8 @@ int qsmc_update_fused(qsmc_handle_t h, const qsmc_model_t *model, const double *
         LAUNCH_U(QSMC_MODEL_BINOMIAL_PRECESSION)
         LAUNCH_U(QSMC_MODEL_RB)
         LAUNCH_U(QSMC_MODEL_RB_INTERLEAVED)
+        LAUNCH_U(QSMC_MODEL_BINOMIAL_RB)
+        LAUNCH_U(QSMC_MODEL_BINOMIAL_RB_INTERLEAVED)
         LAUNCH_U(QSMC_MODEL_TOMOGRAPHY)
 #undef LAUNCH_U
     }
@@ -1925,6 +1932,8 @@ int qsmc_update_multi(qsmc_handle_t h, const qsmc_model_t *model, const double *
         LAUNCH_MU(QSMC_MODEL_BINOMIAL_PRECESSION)
         LAUNCH_MU(QSMC_MODEL_RB)
         LAUNCH_MU(QSMC_MODEL_RB_INTERLEAVED)
+        LAUNCH_MU(QSMC_MODEL_BINOMIAL_RB)
+        LAUNCH_MU(QSMC_MODEL_BINOMIAL_RB_INTERLEAVED)
         LAUNCH_MU(QSMC_MODEL_TOMOGRAPHY)
 #undef LAUNCH_MU
     }
@@ -1956,6 +1965,8 @@ int qsmc_hypothetical_sums(qsmc_handle_t h, const qsmc_model_t *model, const dou
         HD(QSMC_MODEL_BINOMIAL_PRECESSION)
         HD(QSMC_MODEL_RB)
         HD(QSMC_MODEL_RB_INTERLEAVED)
+        HD(QSMC_MODEL_BINOMIAL_RB)
+        HD(QSMC_MODEL_BINOMIAL_RB_INTERLEAVED)
         HD(QSMC_MODEL_TOMOGRAPHY)
 #undef HD
     }

@@ -20,6 +20,7 @@ from .models import (BinomialModel, DerivedModel, RandomizedBenchmarkingModel,  
                      SimpleInversionModel, SimplePrecessionModel)
 from .resamplers import LiuWestResampler, Resampler  # noqa: F401
 from .smc import SMCUpdater  # noqa: F401
+from .simple_est import simple_est_prec, simple_est_rb  # noqa: F401
 from . import tomography, utils  # noqa: F401
 from .tomography import GinibreDistribution, TomographyModel  # noqa: F401
 

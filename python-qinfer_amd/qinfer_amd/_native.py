@@ -12,6 +12,7 @@ from ._exceptions import NativeLibraryError
 
 QSMC_MAX_D = 16
 MODEL_PRECESSION, MODEL_BINOMIAL_PRECESSION, MODEL_RB, MODEL_RB_INTERLEAVED, MODEL_TOMOGRAPHY = 1, 2, 3, 4, 5
+MODEL_BINOMIAL_RB, MODEL_BINOMIAL_RB_INTERLEAVED = 6, 7
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libqsmc_hip.so")
 

@@ -148,8 +148,9 @@ class BinomialModel(NativeModelMixin, DerivedModel):
     the underlying model's likelihood of outcome 1.  Adds the `n_meas` experiment field (and names
     a scalar underlying experiment parameter `x`).
 
-    Native (fully on the GPU) when the decorated model is a SimplePrecessionModel -- the
-    BASELINE config-3 model.  Other two-outcome models go through the plugin slow path.
+    Native (fully on the GPU) when the decorated model is a SimplePrecessionModel (the BASELINE
+    config-3 model, and what `simple_est_prec` builds) or a RandomizedBenchmarkingModel, plain or
+    interleaved (what `simple_est_rb` builds).  Other two-outcome models go through the plugin slow path.
     """
 
     def __init__(self, underlying_model):
@@ -162,7 +163,7 @@ class BinomialModel(NativeModelMixin, DerivedModel):
         else:
             self._expparams_scalar = False
             self._expparams_dtype = underlying_model.expparams_dtype + [('n_meas', 'uint')]
-        self._native = type(underlying_model) is SimplePrecessionModel
+        self._native = type(underlying_model) in (SimplePrecessionModel, RandomizedBenchmarkingModel)
 
     @property
     def decorated_model(self):
@@ -191,12 +192,20 @@ class BinomialModel(NativeModelMixin, DerivedModel):
     # native hooks
     def _native_desc(self):
         um = self.underlying_model
+        if type(um) is RandomizedBenchmarkingModel:
+            kind = _native.MODEL_BINOMIAL_RB_INTERLEAVED if um._il else _native.MODEL_BINOMIAL_RB
+            return _native.ModelDesc(kind, um.n_modelparams, 0.0, 0, 0)
         return _native.ModelDesc(_native.MODEL_BINOMIAL_PRECESSION, 1, float(um._min_freq), 0, 0)
 
     def _native_expparams(self, expparams):
         expparams = np.atleast_1d(expparams)
-        return [_native.make_expparam(t=t, w_=0.0, n_meas=n)
-                for t, n in zip(_field(expparams, 'x'), _field(expparams, 'n_meas'))]
+        um = self.underlying_model
+        ns = _field(expparams, 'n_meas')
+        if type(um) is RandomizedBenchmarkingModel:
+            ms = _field(expparams, 'm')
+            refs = _field(expparams, 'reference') if um._il else np.zeros(ms.shape, dtype=bool)
+            return [_native.make_expparam(m=m, reference=int(bool(r)), n_meas=n) for m, r, n in zip(ms, refs, ns)]
+        return [_native.make_expparam(t=t, w_=0.0, n_meas=n) for t, n in zip(_field(expparams, 'x'), ns)]
 
     def likelihood(self, outcomes, modelparams, expparams):
         Model.likelihood(self, outcomes, modelparams, expparams)

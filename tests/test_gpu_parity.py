@@ -91,6 +91,27 @@ def test_likelihood_rb_g2(qi, golden):
     np.testing.assert_array_equal(mi.are_models_valid(g["rbi_x"]), g["rbi_valid"])
 
 
+def test_likelihood_binomial_rb_g8(qi, golden):
+    """BinomialModel(RandomizedBenchmarkingModel) -- the simple_est_rb model -- on the reference's numbers."""
+    g = golden("g8_binomial_rb")
+    m = qi.BinomialModel(qi.RandomizedBenchmarkingModel())
+    assert m._native and [n for n, _ in m.expparams_dtype] == list(g["brb_dtype_names"])
+    ep = np.empty((len(g["brb_m"]),), dtype=m.expparams_dtype)
+    ep["m"], ep["n_meas"] = g["brb_m"], g["brb_n"]
+    L = m.likelihood(np.arange(41), g["brb_x"], ep)
+    assert L.shape == g["brb_L"].shape
+    # pmf error = n * |d pr1| relative; pr1 = A p^m + B carries a few ulp from pow
+    np.testing.assert_allclose(L, g["brb_L"], rtol=1e-12, atol=40 * ULP4)
+    mi = qi.BinomialModel(qi.RandomizedBenchmarkingModel(interleaved=True))
+    assert [n for n, _ in mi.expparams_dtype] == list(g["brbi_dtype_names"])
+    ep = np.empty((len(g["brbi_m"]),), dtype=mi.expparams_dtype)
+    ep["m"], ep["reference"], ep["n_meas"] = g["brbi_m"], g["brbi_ref"], g["brbi_n"]
+    Li = mi.likelihood(np.arange(26), g["brbi_x"], ep)
+    np.testing.assert_allclose(Li, g["brbi_L"], rtol=1e-12, atol=40 * ULP4)
+    assert mi.n_modelparams == 4 and m.n_modelparams == 3
+    np.testing.assert_array_equal(m.are_models_valid(g["brb_x"]), np.ones(len(g["brb_x"]), dtype=bool))
+
+
 def test_likelihood_tomography_g2(qi, golden):
     g = golden("g2_likelihoods")
     basis = qi.tomography.pauli_basis(2)
@@ -630,6 +651,56 @@ def test_traj_rb(qi, golden):
     upd, checked = _run_traj(qi, g, m, ep_of, lambda k: g["ep_m"][k])
     assert checked == len(g["outcomes"]) - 1
     np.testing.assert_allclose(upd.particle_locations, g["final_locs"], rtol=1e-9, atol=1e-12)
+
+
+def test_traj_binomial_rb(qi, golden):
+    g = golden("g8_binomial_rb_n1500")
+    m = qi.BinomialModel(qi.RandomizedBenchmarkingModel())
+
+    def ep_of(k):
+        ep = np.empty((1,), dtype=m.expparams_dtype)
+        ep["m"], ep["n_meas"] = g["ep_m"][k], g["ep_n_meas"][k]
+        return ep
+    upd, checked = _run_traj(qi, g, m, ep_of, lambda k: 25 * g["ep_m"][k])
+    assert checked == len(g["outcomes"]) - 1
+    np.testing.assert_allclose(upd.particle_locations, g["final_locs"], rtol=1e-9, atol=1e-12)
+
+
+def test_simple_est_front_ends(qi, golden):
+    """simple_est_prec / simple_est_rb (simple_est.py:121-254): same table, same seed, host-RNG parity mode
+    -> the reference's estimate; device-RNG mode -> the same posterior statistically."""
+    g = golden("g8_simple_est")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        np.random.seed(4)
+        mean, var, extra = qi.simple_est_prec(g["prec_table"], n_particles=3000, return_all=True)
+        upd = extra["updater"]
+        assert upd.resample_count == int(g["prec_resample_count"])
+        np.testing.assert_allclose(mean, g["prec_mean"][0], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(var, g["prec_cov"][0, 0], rtol=1e-6)
+        assert len(upd.data_record) == len(g["prec_table"])
+        np.random.seed(4)
+        mean_rb, cov_rb, extra = qi.simple_est_rb(g["rb_table"], p_min=0.8, p_max=1.0, n_particles=4000,
+                                                  return_all=True)
+        assert extra["updater"].resample_count == int(g["rb_resample_count"])
+        np.testing.assert_allclose(mean_rb, g["rb_mean"], rtol=0, atol=1e-8)
+        np.testing.assert_allclose(cov_rb, g["rb_cov"], rtol=1e-5, atol=1e-12)
+        # record-array input with named columns, device RNG, many more particles: same posterior
+        rec = np.rec.fromarrays(g["prec_table"].T, names="counts,t,n_shots")
+        m2, v2 = qi.simple_est_prec(rec, n_particles=400000, device_rng=True, seed=1)
+        assert abs(m2 - g["prec_mean"][0]) < 4 * np.sqrt(g["prec_cov"][0, 0] / 300) + 0.15 * np.sqrt(g["prec_cov"][0, 0])
+        m3, c3 = qi.simple_est_rb(g["rb_table"], p_min=0.8, p_max=1.0, n_particles=400000, device_rng=True, seed=2)
+        sd = np.sqrt(np.diag(g["rb_cov"]))
+        assert np.all(np.abs(m3 - g["rb_mean"]) < 0.3 * sd)      # 4000-particle reference run: MC error ~ sd/sqrt(ess)
+        # interleaved tables: 4 columns, 4 parameters
+        rs = np.random.RandomState(3)
+        ms = np.tile(np.arange(1, 80, 6), 2)
+        ref = np.repeat([1, 0], len(ms) // 2)
+        pe = np.where(ref == 1, 0.98, 0.98 * 0.99)
+        counts = rs.binomial(30, 0.3 * pe ** ms + 0.5)
+        tab = np.column_stack([counts, ms, np.full(ms.shape, 30), ref]).astype(float)
+        m4, c4 = qi.simple_est_rb(tab, interleaved=True, p_min=0.9, p_max=1.0, n_particles=100000, device_rng=True, seed=5)
+        assert m4.shape == (4,) and c4.shape == (4, 4) and 0.9 <= m4[0] <= 1 and 0.9 <= m4[1] <= 1
 
 
 def test_traj_tomography(qi, golden):

@@ -173,3 +173,29 @@ def test_pr0_to_likelihood_array_and_domain():
     np.testing.assert_allclose(L[1], 1 - pr0)
     d = qi.IntegerDomain(min=0, max=3)
     assert d.n_members == 4 and d.values.tolist() == [0, 1, 2, 3] and d.in_domain([1, 2]) and not d.in_domain([4])
+
+
+def test_simple_est_data_tables():
+    """data_to_params / load_data_or_txt (simple_est.py:69-118): positional columns of a 2-D array, named
+    columns of a record array and a CSV file give the same (outcomes, expparams)."""
+    import io
+    from qinfer_amd.simple_est import data_to_params, load_data_or_txt
+    dtype = [('x', 'float'), ('n_meas', 'uint')]
+    table = np.array([[3, 1.5, 10], [7, 2.5, 12], [0, 4.0, 9]], dtype=float)
+    cols = {'x': (1, 't'), 'n_meas': (2, 'n_shots')}
+    o1, e1 = data_to_params(table, dtype, cols_expparams=cols)
+    assert o1.dtype.kind == 'i' and o1.tolist() == [3, 7, 0]
+    assert e1['x'].tolist() == [1.5, 2.5, 4.0] and e1['n_meas'].tolist() == [10, 12, 9]
+    rec = np.array([(3, 1.5, 10), (7, 2.5, 12), (0, 4.0, 9)], dtype=[('counts', 'uint'), ('t', float), ('n_shots', 'uint')])
+    o2, e2 = data_to_params(rec, dtype, cols_expparams=cols)
+    assert np.array_equal(o1, o2) and np.array_equal(e1, e2)
+    csv = io.StringIO("3,1.5,10\n7,2.5,12\n0,4.0,9\n")
+    loaded = load_data_or_txt(csv, [('counts', 'uint'), ('t', float), ('n_shots', 'uint')])
+    o3, e3 = data_to_params(loaded, dtype, cols_expparams=cols)
+    assert np.array_equal(o1, o3) and np.array_equal(e1, e3)
+    assert load_data_or_txt(table, None) is table
+    with pytest.raises(TypeError):
+        load_data_or_txt(12345, None)
+    # scalar expparams dtype: one column
+    o4, e4 = data_to_params(table, np.float64, cols_expparams=(1, 't'))
+    assert e4.tolist() == [1.5, 2.5, 4.0]

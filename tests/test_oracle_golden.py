@@ -173,6 +173,23 @@ def test_g1_rb(golden):
     _traj(g, orc.rb_model(), lambda k: {"m": g["ep_m"][k:k + 1]}, lambda k: g["ep_m"][k])
 
 
+def test_g8_binomial_rb_likelihood(golden):
+    g = golden("g8_binomial_rb")
+    L = orc.lik_binomial_rb(np.arange(41), g["brb_x"], g["brb_m"], g["brb_n"])
+    np.testing.assert_allclose(L, g["brb_L"], rtol=1e-12, atol=1e-300)
+    Li = orc.lik_binomial_rb(np.arange(26), g["brbi_x"], g["brbi_m"], g["brbi_n"], g["brbi_ref"])
+    np.testing.assert_allclose(Li, g["brbi_L"], rtol=1e-12, atol=1e-300)
+    # every column is a pmf over k = 0..n_meas
+    np.testing.assert_allclose(L.sum(axis=0), 1.0, rtol=1e-12)
+
+
+def test_g8_binomial_rb_traj(golden):
+    g = golden("g8_binomial_rb_n1500")
+    _traj(g, orc.binomial_rb_model(),
+          lambda k: {"m": g["ep_m"][k:k + 1], "n_meas": g["ep_n_meas"][k:k + 1]},
+          lambda k: 25 * g["ep_m"][k])
+
+
 def test_g1_tomography(golden):
     g = golden("g1_tomography_n300")
     basis = orc.pauli_data(2)
