@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define QSMC_ABI_VERSION 1
+#define QSMC_ABI_VERSION 2
 #define QSMC_MAX_D 16            /* largest n_modelparams with a native kernel (2-qubit tomography) */
 
 typedef struct qsmc_ctx *qsmc_handle_t;
@@ -49,7 +49,8 @@ enum qsmc_model_kind {
     QSMC_MODEL_RB_INTERLEAVED = 4,      /* rb.py:81-195 (interleaved=True)                           */
     QSMC_MODEL_TOMOGRAPHY = 5,          /* tomography/models.py:82-226 TomographyModel               */
     QSMC_MODEL_BINOMIAL_RB = 6,         /* BinomialModel(RandomizedBenchmarkingModel()): simple_est.py:212 */
-    QSMC_MODEL_BINOMIAL_RB_INTERLEAVED = 7  /* ... (interleaved=True)                                 */
+    QSMC_MODEL_BINOMIAL_RB_INTERLEAVED = 7, /* ... (interleaved=True)                                 */
+    QSMC_MODEL_UNKNOWN_T2 = 8           /* test_models.py:222-259 UnknownT2Model (omega, 1/T2)        */
 };
 
 typedef struct qsmc_model {
@@ -58,6 +59,7 @@ typedef struct qsmc_model {
     double  min_freq;            /* precession validity: omega > min_freq (test_models.py:109-110) */
     int32_t postselect_all_valid;/* 1: are_models_valid == True everywhere (tomography :143-147) */
     int32_t reserved;
+    double  likelihood_power;    /* MLEModel(model, gamma): L ** gamma (derived_models.py:673-691); 0 = plain */
 } qsmc_model_t;
 
 /* One experiment (one row of the model's `expparams` record array). */

@@ -482,6 +482,53 @@ def g8_simple_est():
     np.savez_compressed(os.path.join(OUT, "g8_simple_est.npz"), **out)
 
 
+def g9_t2_mle():
+    """UnknownT2Model (test_models.py:222-259) and MLEModel (derived_models.py:673-691): likelihood KATs and
+    one SMC trajectory each."""
+    out = {}
+    t2 = qinfer.UnknownT2Model()
+    rs = np.random.RandomState(9)
+    x = np.column_stack([rs.uniform(0, 1, 96), rs.uniform(0, 0.2, 96)])
+    x[:4] = [[0, 0], [1, 0], [0.3, 0.05], [0.5, 1e-300]]
+    ep = np.empty((5,), dtype=t2.expparams_dtype)
+    ep['t'] = [0.0, 1.0, 17.5, (9 / 8) ** 40, (9 / 8) ** 120]
+    out['t2_x'], out['t2_t'] = x, ep['t']
+    out['t2_L'] = t2.likelihood(np.array([0, 1]), x, ep)
+    out['t2_valid_x'] = np.array([[0.1, 0.1], [-0.1, 0.1], [0.1, -1e-9], [0.0, 0.0]])
+    out['t2_valid'] = t2.are_models_valid(out['t2_valid_x'])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for tag, base, gamma in (("mle_prec", qinfer.SimplePrecessionModel(), 2.5),
+                                 ("mle_bin", qinfer.BinomialModel(qinfer.SimplePrecessionModel()), 0.5)):
+            m = qinfer.MLEModel(base, gamma)
+            omega = np.concatenate([np.linspace(0, 1, 65), [0.3, 0.29999981]])[:, None]
+            if tag == "mle_prec":
+                e = (9 / 8) ** np.array([0.0, 50, 100, 150])
+                L = m.likelihood(np.array([0, 1]), omega, e)
+                out[tag + '_t'] = e
+            else:
+                e = np.empty((3,), dtype=base.expparams_dtype)
+                e['x'] = [1.0, (9 / 8) ** 30, (9 / 8) ** 90]
+                e['n_meas'] = [25, 25, 7]
+                L = m.likelihood(np.arange(26), omega, e)
+                out[tag + '_t'], out[tag + '_n'] = e['x'], e['n_meas']
+            out[tag + '_x'], out[tag + '_gamma'], out[tag + '_L'] = omega, gamma, L
+    np.savez_compressed(os.path.join(OUT, "g9_t2_mle.npz"), **out)
+    print("g9_t2_mle", out['t2_L'].shape)
+    # trajectories
+    true = np.array([[0.3, 0.02]])
+    ep = np.empty((80,), dtype=t2.expparams_dtype)
+    ep['t'] = (9 / 8) ** (np.arange(80.0) * 0.5)
+    prior = qinfer.UniformDistribution([[0, 1], [0, 0.1]])
+    sim = lambda k, e: t2.simulate_experiment(true, e)
+    run_trajectory("g9_unknown_t2_n2000", t2, prior, 2000, ep, sim)
+    m = qinfer.MLEModel(qinfer.SimplePrecessionModel(), 3.0)
+    ts = (9 / 8) ** np.arange(70.0)
+    base = qinfer.SimplePrecessionModel()
+    sim = lambda k, e: base.simulate_experiment(np.array([[0.3]]), e)
+    run_trajectory("g9_mle_precession_n1000", m, qinfer.UniformDistribution([0, 1]), 1000, ts, sim)
+
+
 if __name__ == "__main__":
     g1_precession()
     g1_binomial()
@@ -495,4 +542,5 @@ if __name__ == "__main__":
     g7_design()
     g8_binomial_rb()
     g8_simple_est()
+    g9_t2_mle()
     print("total bytes:", sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT)))

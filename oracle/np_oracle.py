@@ -175,6 +175,21 @@ def valid_rb(x):
     return np.all(conds, axis=0)
 
 
+def lik_unknown_t2(outcomes, x, t):
+    """test_models.py:247-257: visibility = exp(-t T2_inv); pr0 = vis cos^2(w t / 2) + (1 - vis) / 2."""
+    x = np.asarray(x, dtype=np.float64)
+    w, T2_inv = x[:, 0:1], x[:, 1:2]
+    t = np.atleast_1d(np.asarray(t, dtype=np.float64))[None, :]
+    vis = np.exp(-t * T2_inv)
+    pr0 = vis * np.cos(w * t / 2) ** 2 + (1 - vis) / 2
+    return _two_outcome(outcomes, pr0)
+
+
+def valid_unknown_t2(x):
+    """test_models.py:244-245."""
+    return np.all(np.asarray(x) >= 0, axis=1)
+
+
 def lik_tomography(outcomes, x, meas):
     """tomography/models.py:211-226: pr1 = clip(meas . x, 0, 1); pr0 = 1 - pr1."""
     x = np.asarray(x, dtype=np.float64)
@@ -407,6 +422,15 @@ def binomial_rb_model(interleaved=False):
     return OracleModel('binomial_rb', 4 if interleaved else 3,
                        lambda o, x, e: lik_binomial_rb(o, x, e['m'], e['n_meas'], e.get('reference')),
                        valid_rb)
+
+
+def unknown_t2_model():
+    return OracleModel('unknown_t2', 2, lambda o, x, e: lik_unknown_t2(o, x, e['t']), valid_unknown_t2)
+
+
+def mle_model(base, power):
+    """derived_models.py:673-691: L ** power; everything else is the decorated model's."""
+    return OracleModel('mle_' + base.name, base.d, lambda o, x, e: base.lik(o, x, e) ** power, base.valid, base.canon)
 
 
 def tomography_model(basis, allow_subnormalized=False):

@@ -28,6 +28,7 @@ struct ExpArgs {
     double m;                // RB sequence length as double (NumPy: float64 ** uint64 -> pow(double))
     int32_t reference;       // RB interleaved
     int32_t d;
+    double lik_pow;          // MLEModel: likelihood ** lik_pow (0 = plain)
     double meas[QSMC_MAX_D]; // tomography
 };
 
@@ -149,6 +150,28 @@ template <> struct Model<QSMC_MODEL_TOMOGRAPHY> {
     static __host__ __device__ __forceinline__ bool valid(const double *, double) { return true; }
 };
 
+template <> struct Model<QSMC_MODEL_UNKNOWN_T2> {
+    static constexpr int D = 2;
+    static __host__ __device__ __forceinline__ double lik(const double *p, const ExpArgs &e, int64_t o) {
+        // test_models.py:247-257: visibility = exp(-t / T2); pr0 = vis cos^2(w t / 2) + (1 - vis) / 2
+        const double vis = exp(-e.t * p[1]);
+        const double c = cos(p[0] * e.t / 2.0);
+        const double pr0 = vis * (c * c) + (1.0 - vis) / 2.0;
+        return two_outcome(pr0, o);
+    }
+    static __host__ __device__ __forceinline__ bool valid(const double *p, double) {
+        return p[0] >= 0.0 && p[1] >= 0.0;       // test_models.py:244-245
+    }
+};
+
+// Likelihood as the update kernels use it: the model's, raised to the MLEModel power when one is set
+// (derived_models.py:689-691, `L ** self._pow`).  The branch is on a kernel argument (SGPR): free.
+template <int KIND>
+__host__ __device__ __forceinline__ double model_lik(const double *p, const ExpArgs &e, int64_t o) {
+    const double L = Model<KIND>::lik(p, e, o);
+    return e.lik_pow == 0.0 ? L : pow(L, e.lik_pow);
+}
+
 // Runtime-dispatched validity (used by kernels that are not templated on the model).
 __host__ __device__ __forceinline__ bool model_valid(int kind, const double *p, double min_freq) {
     switch (kind) {
@@ -158,6 +181,7 @@ __host__ __device__ __forceinline__ bool model_valid(int kind, const double *p, 
         case QSMC_MODEL_BINOMIAL_RB: return Model<QSMC_MODEL_RB>::valid(p, 0.0);
         case QSMC_MODEL_RB_INTERLEAVED:
         case QSMC_MODEL_BINOMIAL_RB_INTERLEAVED: return Model<QSMC_MODEL_RB_INTERLEAVED>::valid(p, 0.0);
+        case QSMC_MODEL_UNKNOWN_T2: return Model<QSMC_MODEL_UNKNOWN_T2>::valid(p, 0.0);
         default: return true;
     }
 }

@@ -288,8 +288,8 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_update_fused(
                         }
                     }
                     double2 wo;
-                    wo.x = (wi.x / prev_norm) * Model<KIND>::lik(p0, e, outcome);
-                    wo.y = (wi.y / prev_norm) * Model<KIND>::lik(p1, e, outcome);
+                    wo.x = (wi.x / prev_norm) * model_lik<KIND>(p0, e, outcome);
+                    wo.y = (wi.y / prev_norm) * model_lik<KIND>(p1, e, outcome);
                     *reinterpret_cast<double2 *>(w_out + i) = wo;
                     acc.add(wo.x, p0);
                     acc.add(wo.y, p1);
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_update_fused(
 #pragma unroll
                     for (int m = 0; m < D; ++m)
                         if (m < d) p0[m] = x[m * ldx + i];
-                    const double wo = ((ONES ? 1.0 : w_in[i]) / prev_norm) * Model<KIND>::lik(p0, e, outcome);
+                    const double wo = ((ONES ? 1.0 : w_in[i]) / prev_norm) * model_lik<KIND>(p0, e, outcome);
                     w_out[i] = wo;
                     acc.add(wo, p0);
                 }
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_update_fused(
 #pragma unroll
                     for (int m = 0; m < D; ++m)
                         if (m < d) p0[m] = x[m * ldx + i];
-                    const double wo = ((ONES ? 1.0 : w_in[i]) / prev_norm) * Model<KIND>::lik(p0, e, outcome);
+                    const double wo = ((ONES ? 1.0 : w_in[i]) / prev_norm) * model_lik<KIND>(p0, e, outcome);
                     w_out[i] = wo;
                     acc.add(wo, p0);
                 }
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_update_multi(
 #pragma unroll
         for (int k = 0; k < MULTI_KMAX; ++k) {
             if (k < ma.k) {
-                w = w * Model<KIND>::lik(p, ma.e[k], ma.outcome[k]);
+                w = w * model_lik<KIND>(p, ma.e[k], ma.outcome[k]);
                 s[3 * k] += w;
                 s[3 * k + 1] += w * w;
                 s[3 * k + 2] += (w >= 0.0) ? 0.0 : 1.0;
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_hyp_sums(const double *__restric
                 ExpArgs e = ha.base;
                 e.comb = ha.comb[o];
                 e.log_comb = ha.log_comb[o];
-                const double L = Model<KIND>::lik(p, e, ha.outcome[o]);
+                const double L = model_lik<KIND>(p, e, ha.outcome[o]);
                 const double wl = wi * L;
                 s[o * PER] += wl;
                 s[o * PER + 1] += (L > 0.0) ? wl * log(L) : 0.0;
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_likelihood(const double *__restr
 #pragma unroll
         for (int m = 0; m < D; ++m)
             if (m < d) p[m] = x[m * ldx + i];
-        L[i] = Model<KIND>::lik(p, e, outcome);
+        L[i] = model_lik<KIND>(p, e, outcome);
     }
 }
 
@@ -1492,6 +1492,7 @@ static int make_exp_args(const qsmc_model_t *model, const qsmc_expparam_t *ep, i
     out->m = (double)ep->m;
     out->reference = ep->reference;
     out->d = model->d;
+    out->lik_pow = (model->likelihood_power == 1.0) ? 0.0 : model->likelihood_power;
     for (int i = 0; i < QSMC_MAX_D; ++i) out->meas[i] = ep->meas[i];
     out->comb = 1.0;
     out->log_comb = 0.0;
@@ -1525,6 +1526,7 @@ static int check_model(const qsmc_model_t *m) {
         case QSMC_MODEL_RB_INTERLEAVED:
         case QSMC_MODEL_BINOMIAL_RB_INTERLEAVED: return m->d == 4 ? QSMC_OK : QSMC_ERR_INVALID;
         case QSMC_MODEL_TOMOGRAPHY: return (m->d >= 1 && m->d <= QSMC_MAX_D) ? QSMC_OK : QSMC_ERR_INVALID;
+        case QSMC_MODEL_UNKNOWN_T2: return m->d == 2 ? QSMC_OK : QSMC_ERR_INVALID;
         default: return QSMC_ERR_INVALID;
     }
 }
@@ -1834,6 +1836,7 @@ int qsmc_likelihood(qsmc_handle_t h, const qsmc_model_t *model, const double *x,
                 LAUNCH_L(QSMC_MODEL_RB_INTERLEAVED)
                 LAUNCH_L(QSMC_MODEL_BINOMIAL_RB)
                 LAUNCH_L(QSMC_MODEL_BINOMIAL_RB_INTERLEAVED)
+                LAUNCH_L(QSMC_MODEL_UNKNOWN_T2)
                 LAUNCH_L(QSMC_MODEL_TOMOGRAPHY)
 #undef LAUNCH_L
             }
@@ -1887,6 +1890,7 @@ int qsmc_update_fused(qsmc_handle_t h, const qsmc_model_t *model, const double *
         LAUNCH_U(QSMC_MODEL_RB_INTERLEAVED)
         LAUNCH_U(QSMC_MODEL_BINOMIAL_RB)
         LAUNCH_U(QSMC_MODEL_BINOMIAL_RB_INTERLEAVED)
+        LAUNCH_U(QSMC_MODEL_UNKNOWN_T2)
         LAUNCH_U(QSMC_MODEL_TOMOGRAPHY)
 #undef LAUNCH_U
     }
@@ -1934,6 +1938,7 @@ int qsmc_update_multi(qsmc_handle_t h, const qsmc_model_t *model, const double *
         LAUNCH_MU(QSMC_MODEL_RB_INTERLEAVED)
         LAUNCH_MU(QSMC_MODEL_BINOMIAL_RB)
         LAUNCH_MU(QSMC_MODEL_BINOMIAL_RB_INTERLEAVED)
+        LAUNCH_MU(QSMC_MODEL_UNKNOWN_T2)
         LAUNCH_MU(QSMC_MODEL_TOMOGRAPHY)
 #undef LAUNCH_MU
     }
@@ -1967,6 +1972,7 @@ int qsmc_hypothetical_sums(qsmc_handle_t h, const qsmc_model_t *model, const dou
         HD(QSMC_MODEL_RB_INTERLEAVED)
         HD(QSMC_MODEL_BINOMIAL_RB)
         HD(QSMC_MODEL_BINOMIAL_RB_INTERLEAVED)
+        HD(QSMC_MODEL_UNKNOWN_T2)
         HD(QSMC_MODEL_TOMOGRAPHY)
 #undef HD
     }

@@ -16,8 +16,8 @@ from .abstract_model import FiniteOutcomeModel, Model, Simulatable  # noqa: F401
 from .distributions import (Distribution, MultivariateNormalDistribution, ParticleDistribution,  # noqa: F401
                             PostselectedDistribution, ProductDistribution, UniformDistribution)
 from .domains import Domain, IntegerDomain  # noqa: F401
-from .models import (BinomialModel, DerivedModel, RandomizedBenchmarkingModel,  # noqa: F401
-                     SimpleInversionModel, SimplePrecessionModel)
+from .models import (BinomialModel, DerivedModel, MLEModel, RandomizedBenchmarkingModel,  # noqa: F401
+                     SimpleInversionModel, SimplePrecessionModel, UnknownT2Model)
 from .resamplers import LiuWestResampler, Resampler  # noqa: F401
 from .smc import SMCUpdater  # noqa: F401
 from .simple_est import simple_est_prec, simple_est_rb  # noqa: F401

@@ -12,14 +12,14 @@ from ._exceptions import NativeLibraryError
 
 QSMC_MAX_D = 16
 MODEL_PRECESSION, MODEL_BINOMIAL_PRECESSION, MODEL_RB, MODEL_RB_INTERLEAVED, MODEL_TOMOGRAPHY = 1, 2, 3, 4, 5
-MODEL_BINOMIAL_RB, MODEL_BINOMIAL_RB_INTERLEAVED = 6, 7
+MODEL_BINOMIAL_RB, MODEL_BINOMIAL_RB_INTERLEAVED, MODEL_UNKNOWN_T2 = 6, 7, 8
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libqsmc_hip.so")
 
 
 class ModelDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("d", C.c_int32), ("min_freq", C.c_double),
-                ("postselect_all_valid", C.c_int32), ("reserved", C.c_int32)]
+                ("postselect_all_valid", C.c_int32), ("reserved", C.c_int32), ("likelihood_power", C.c_double)]
 
 
 class ExpParam(C.Structure):
@@ -102,7 +102,7 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = _RESTYPE.get(name, C.c_int)
-    if lib.qsmc_abi_version() != 1:
+    if lib.qsmc_abi_version() != 2:
         raise NativeLibraryError("ABI version mismatch")
     _lib = lib
     return lib

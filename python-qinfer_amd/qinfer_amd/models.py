@@ -15,8 +15,8 @@ from . import _native
 from .abstract_model import FiniteOutcomeModel, Model, NativeModelMixin
 from .domains import IntegerDomain
 
-__all__ = ["SimpleInversionModel", "SimplePrecessionModel", "DerivedModel", "BinomialModel",
-           "RandomizedBenchmarkingModel"]
+__all__ = ["SimpleInversionModel", "SimplePrecessionModel", "UnknownT2Model", "DerivedModel", "BinomialModel",
+           "MLEModel", "RandomizedBenchmarkingModel"]
 
 
 def _field(expparams, name):
@@ -79,6 +79,45 @@ class SimplePrecessionModel(SimpleInversionModel):
         expparams = np.atleast_1d(expparams)
         ts = expparams['t'] if expparams.dtype.names else expparams
         return [_native.make_expparam(t=t, w_=0.0) for t in np.atleast_1d(ts).astype(np.float64).ravel()]
+
+
+class UnknownT2Model(NativeModelMixin, FiniteOutcomeModel):
+    r"""Qubit prepared in |+>, precessing under H = omega sigma_z / 2 with an unknown dephasing rate:
+    Pr(0 | omega, 1/T2; t) = e^{-t/T2} cos^2(omega t / 2) + (1 - e^{-t/T2}) / 2
+    (reference test_models.py:222-259).  Valid iff both parameters are >= 0."""
+
+    @property
+    def n_modelparams(self):
+        return 2
+
+    @property
+    def modelparam_names(self):
+        return [r'\omega', r'T_2^{-1}']
+
+    @property
+    def expparams_dtype(self):
+        return [('t', 'float')]
+
+    @property
+    def is_n_outcomes_constant(self):
+        return True
+
+    def n_outcomes(self, expparams):
+        return 2
+
+    def _native_desc(self):
+        return _native.ModelDesc(_native.MODEL_UNKNOWN_T2, 2, 0.0, 0, 0)
+
+    def _native_expparams(self, expparams):
+        expparams = np.atleast_1d(expparams)
+        return [_native.make_expparam(t=t) for t in _field(expparams, 't')]
+
+    def are_models_valid(self, modelparams):
+        return self._native_are_models_valid(modelparams)
+
+    def likelihood(self, outcomes, modelparams, expparams):
+        super().likelihood(outcomes, modelparams, expparams)
+        return self._native_likelihood(outcomes, modelparams, expparams)
 
 
 class DerivedModel(Model):
@@ -234,6 +273,44 @@ class BinomialModel(NativeModelMixin, DerivedModel):
 
     def update_timestep(self, modelparams, expparams):
         return self.underlying_model.update_timestep(modelparams, self._underlying_expparams(expparams))
+
+
+class MLEModel(NativeModelMixin, DerivedModel):
+    r"""Approximate maximum-likelihood estimation by amplifying the Bayes update: every likelihood
+    call of the decorated model is raised to `likelihood_power` (reference derived_models.py:673-691).
+
+    Native when the decorated model is: the power is applied inside the same kernels (`model_lik`),
+    so updating, batch updating and resampling cost what they cost for the decorated model."""
+
+    def __init__(self, underlying_model, likelihood_power):
+        super().__init__(underlying_model)
+        self._pow = likelihood_power
+        self._native = bool(getattr(underlying_model, "_native", False))
+
+    @property
+    def is_n_outcomes_constant(self):
+        return self.underlying_model.is_n_outcomes_constant
+
+    def _native_desc(self):
+        desc = self.underlying_model._native_desc()
+        prev = desc.likelihood_power if desc.likelihood_power != 0.0 else 1.0      # nested MLEModels multiply
+        return _native.ModelDesc(desc.kind, desc.d, desc.min_freq, desc.postselect_all_valid, desc.reserved,
+                                 float(prev * self._pow))
+
+    def _native_expparams(self, expparams):
+        return self.underlying_model._native_expparams(expparams)
+
+    def likelihood(self, outcomes, modelparams, expparams):
+        if self._native:
+            Model.likelihood(self, outcomes, modelparams, expparams)
+            return self._native_likelihood(outcomes, modelparams, expparams)
+        return self.underlying_model.likelihood(outcomes, modelparams, expparams) ** self._pow
+
+    def are_models_valid(self, modelparams):
+        return self.underlying_model.are_models_valid(modelparams)
+
+    def simulate_experiment(self, modelparams, expparams, repeat=1):
+        return self.underlying_model.simulate_experiment(modelparams, expparams, repeat)
 
 
 class RandomizedBenchmarkingModel(NativeModelMixin, FiniteOutcomeModel):

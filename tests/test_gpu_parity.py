@@ -112,6 +112,35 @@ def test_likelihood_binomial_rb_g8(qi, golden):
     np.testing.assert_array_equal(m.are_models_valid(g["brb_x"]), np.ones(len(g["brb_x"]), dtype=bool))
 
 
+def test_likelihood_unknown_t2_and_mle_g9(qi, golden):
+    """UnknownT2Model (test_models.py:222-259) and MLEModel (derived_models.py:673-691) on the reference's numbers."""
+    g = golden("g9_t2_mle")
+    t2 = qi.UnknownT2Model()
+    ep = np.empty((len(g["t2_t"]),), dtype=t2.expparams_dtype)
+    ep["t"] = g["t2_t"]
+    L = t2.likelihood(np.array([0, 1]), g["t2_x"], ep)
+    np.testing.assert_allclose(L, g["t2_L"], rtol=0, atol=ULP4)
+    np.testing.assert_array_equal(t2.are_models_valid(g["t2_valid_x"]), g["t2_valid"])
+    assert t2.n_modelparams == 2 and t2.n_outcomes(ep) == 2
+    m = qi.MLEModel(qi.SimplePrecessionModel(), float(g["mle_prec_gamma"]))
+    assert m._native and m.n_modelparams == 1 and m.expparams_dtype == "float"
+    L = m.likelihood(np.array([0, 1]), g["mle_prec_x"], g["mle_prec_t"])
+    # d(L^g) = g L^(g-1) dL, |dL| <= 1e-15 from cos; plus pow's own rounding
+    np.testing.assert_allclose(L, g["mle_prec_L"], rtol=1e-14, atol=3 * ULP4)
+    base = qi.BinomialModel(qi.SimplePrecessionModel())
+    mb = qi.MLEModel(base, float(g["mle_bin_gamma"]))
+    ep = np.empty((3,), dtype=mb.expparams_dtype)
+    ep["x"], ep["n_meas"] = g["mle_bin_t"], g["mle_bin_n"]
+    L = mb.likelihood(np.arange(26), g["mle_bin_x"], ep)
+    # sqrt of a pmf: relative error halves, but an absolute 3e-14 on L becomes ~1e-7 * sqrt near L = 0
+    ref = g["mle_bin_L"]
+    np.testing.assert_allclose(L ** 2, ref ** 2, rtol=1e-12, atol=30 * 1e-15)
+    # nested powers multiply
+    mm = qi.MLEModel(m, 2.0)
+    L2 = mm.likelihood(np.array([0, 1]), g["mle_prec_x"], g["mle_prec_t"])
+    np.testing.assert_allclose(L2, g["mle_prec_L"] ** 2.0, rtol=1e-13, atol=3 * ULP4)
+
+
 def test_likelihood_tomography_g2(qi, golden):
     g = golden("g2_likelihoods")
     basis = qi.tomography.pauli_basis(2)
@@ -701,6 +730,25 @@ def test_simple_est_front_ends(qi, golden):
         tab = np.column_stack([counts, ms, np.full(ms.shape, 30), ref]).astype(float)
         m4, c4 = qi.simple_est_rb(tab, interleaved=True, p_min=0.9, p_max=1.0, n_particles=100000, device_rng=True, seed=5)
         assert m4.shape == (4,) and c4.shape == (4, 4) and 0.9 <= m4[0] <= 1 and 0.9 <= m4[1] <= 1
+
+
+def test_traj_unknown_t2(qi, golden):
+    g = golden("g9_unknown_t2_n2000")
+    m = qi.UnknownT2Model()
+
+    def ep_of(k):
+        ep = np.empty((1,), dtype=m.expparams_dtype)
+        ep["t"] = g["ep_t"][k]
+        return ep
+    upd, checked = _run_traj(qi, g, m, ep_of, lambda k: g["ep_t"][k])
+    assert checked == len(g["outcomes"]) - 1
+    np.testing.assert_allclose(upd.particle_locations, g["final_locs"], rtol=1e-9, atol=1e-12)
+
+
+def test_traj_mle(qi, golden):
+    g = golden("g9_mle_precession_n1000")
+    m = qi.MLEModel(qi.SimplePrecessionModel(), 3.0)
+    _run_traj(qi, g, m, lambda k: g["ep_t"][k:k + 1], lambda k: 3.0 * g["ep_t"][k])
 
 
 def test_traj_tomography(qi, golden):

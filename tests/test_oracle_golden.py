@@ -190,6 +190,28 @@ def test_g8_binomial_rb_traj(golden):
           lambda k: 25 * g["ep_m"][k])
 
 
+def test_g9_unknown_t2_and_mle_likelihoods(golden):
+    g = golden("g9_t2_mle")
+    np.testing.assert_array_equal(orc.lik_unknown_t2([0, 1], g["t2_x"], g["t2_t"]), g["t2_L"])
+    np.testing.assert_array_equal(orc.valid_unknown_t2(g["t2_valid_x"]), g["t2_valid"])
+    mle = orc.mle_model(orc.precession_model(), float(g["mle_prec_gamma"]))
+    np.testing.assert_array_equal(mle.lik([0, 1], g["mle_prec_x"], {"t": g["mle_prec_t"]}), g["mle_prec_L"])
+    mle = orc.mle_model(orc.binomial_precession_model(), float(g["mle_bin_gamma"]))
+    L = mle.lik(np.arange(26), g["mle_bin_x"], {"t": g["mle_bin_t"], "n_meas": g["mle_bin_n"]})
+    np.testing.assert_allclose(L, g["mle_bin_L"], rtol=1e-12, atol=1e-300)
+
+
+def test_g9_unknown_t2_traj(golden):
+    g = golden("g9_unknown_t2_n2000")
+    _traj(g, orc.unknown_t2_model(), lambda k: {"t": g["ep_t"][k:k + 1]}, lambda k: g["ep_t"][k])
+
+
+def test_g9_mle_traj(golden):
+    g = golden("g9_mle_precession_n1000")
+    _traj(g, orc.mle_model(orc.precession_model(), 3.0), lambda k: {"t": g["ep_t"][k:k + 1]},
+          lambda k: 3.0 * g["ep_t"][k])
+
+
 def test_g1_tomography(golden):
     g = golden("g1_tomography_n300")
     basis = orc.pauli_data(2)
