@@ -164,10 +164,19 @@ template <> struct Model<QSMC_MODEL_UNKNOWN_T2> {
     }
 };
 
-// Likelihood as the update kernels use it: the model's, raised to the MLEModel power when one is set
-// (derived_models.py:689-691, `L ** self._pow`).  The branch is on a kernel argument (SGPR): free.
-template <int KIND>
+// Likelihood as the kernels use it: the model's, raised to the MLEModel power when one is set
+// (derived_models.py:689-691, `L ** self._pow`).  POW is a template parameter of the hot kernels -- an
+// inlined pow() behind a run-time branch cost the fused update kernel 30 VGPRs and a wave of occupancy
+// (44 -> 47 us) even when unused; the contract / design kernels take the run-time form.
+template <int KIND, bool POW>
 __host__ __device__ __forceinline__ double model_lik(const double *p, const ExpArgs &e, int64_t o) {
+    const double L = Model<KIND>::lik(p, e, o);
+    if (POW) return pow(L, e.lik_pow);
+    return L;
+}
+
+template <int KIND>
+__host__ __device__ __forceinline__ double model_lik_rt(const double *p, const ExpArgs &e, int64_t o) {
     const double L = Model<KIND>::lik(p, e, o);
     return e.lik_pow == 0.0 ? L : pow(L, e.lik_pow);
 }

@@ -260,7 +260,7 @@ struct UpdAcc {
     }
 };
 
-template <int KIND, int VEC, bool ONES>   // ONES: w_in == nullptr stands for all-ones weights
+template <int KIND, int VEC, bool ONES, bool POW>   // ONES: w_in == nullptr stands for all-ones weights; POW: MLEModel
 __global__ __launch_bounds__(QSMC_BLOCK) void k_update_fused(
     const double *__restrict__ x, int64_t ldx, int64_t n, const double *__restrict__ w_in,
     double *__restrict__ w_out, double prev_norm, ExpArgs e, int64_t outcome, ReduceOut ro) {
@@ -288,8 +288,8 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_update_fused(
                         }
                     }
                     double2 wo;
-                    wo.x = (wi.x / prev_norm) * model_lik<KIND>(p0, e, outcome);
-                    wo.y = (wi.y / prev_norm) * model_lik<KIND>(p1, e, outcome);
+                    wo.x = (wi.x / prev_norm) * model_lik<KIND, POW>(p0, e, outcome);
+                    wo.y = (wi.y / prev_norm) * model_lik<KIND, POW>(p1, e, outcome);
                     *reinterpret_cast<double2 *>(w_out + i) = wo;
                     acc.add(wo.x, p0);
                     acc.add(wo.y, p1);
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_update_fused(
 #pragma unroll
                     for (int m = 0; m < D; ++m)
                         if (m < d) p0[m] = x[m * ldx + i];
-                    const double wo = ((ONES ? 1.0 : w_in[i]) / prev_norm) * model_lik<KIND>(p0, e, outcome);
+                    const double wo = ((ONES ? 1.0 : w_in[i]) / prev_norm) * model_lik<KIND, POW>(p0, e, outcome);
                     w_out[i] = wo;
                     acc.add(wo, p0);
                 }
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_update_fused(
 #pragma unroll
                     for (int m = 0; m < D; ++m)
                         if (m < d) p0[m] = x[m * ldx + i];
-                    const double wo = ((ONES ? 1.0 : w_in[i]) / prev_norm) * model_lik<KIND>(p0, e, outcome);
+                    const double wo = ((ONES ? 1.0 : w_in[i]) / prev_norm) * model_lik<KIND, POW>(p0, e, outcome);
                     w_out[i] = wo;
                     acc.add(wo, p0);
                 }
@@ -333,7 +333,7 @@ struct MultiArgs {
     int64_t outcome[MULTI_KMAX];
 };
 
-template <int KIND>
+template <int KIND, bool POW>
 __global__ __launch_bounds__(QSMC_BLOCK) void k_update_multi(
     const double *__restrict__ x, int64_t ldx, int64_t n, const double *__restrict__ w_in,
     double *__restrict__ w_out, double prev_norm, MultiArgs ma, ReduceOut ro) {
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_update_multi(
 #pragma unroll
         for (int k = 0; k < MULTI_KMAX; ++k) {
             if (k < ma.k) {
-                w = w * model_lik<KIND>(p, ma.e[k], ma.outcome[k]);
+                w = w * model_lik<KIND, POW>(p, ma.e[k], ma.outcome[k]);
                 s[3 * k] += w;
                 s[3 * k + 1] += w * w;
                 s[3 * k + 2] += (w >= 0.0) ? 0.0 : 1.0;
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_hyp_sums(const double *__restric
                 ExpArgs e = ha.base;
                 e.comb = ha.comb[o];
                 e.log_comb = ha.log_comb[o];
-                const double L = model_lik<KIND>(p, e, ha.outcome[o]);
+                const double L = model_lik_rt<KIND>(p, e, ha.outcome[o]);
                 const double wl = wi * L;
                 s[o * PER] += wl;
                 s[o * PER + 1] += (L > 0.0) ? wl * log(L) : 0.0;
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_likelihood(const double *__restr
 #pragma unroll
         for (int m = 0; m < D; ++m)
             if (m < d) p[m] = x[m * ldx + i];
-        L[i] = model_lik<KIND>(p, e, outcome);
+        L[i] = model_lik_rt<KIND>(p, e, outcome);
     }
 }
 
@@ -1614,8 +1614,14 @@ static void launch_update(qsmc_ctx *h, bool vec2, int grid, hipStream_t s, const
     hipEvent_t e0 = nullptr, e1 = nullptr;
     prof_events(h, QSMC_PROF_UPDATE, &e0, &e1);
 #define LU(V, O)                                                                                          \
-    hipExtLaunchKernelGGL((k_update_fused<KIND, V, O>), dim3(grid), dim3(QSMC_BLOCK), 0, s, e0, e1, 0, x, ldx, \
-                          n, w_in, w_out, prev_norm, e, outcome, ro)
+    do {                                                                                                  \
+        if (e.lik_pow != 0.0)                                                                             \
+            hipExtLaunchKernelGGL((k_update_fused<KIND, V, O, true>), dim3(grid), dim3(QSMC_BLOCK), 0, s, e0, e1, 0, \
+                                  x, ldx, n, w_in, w_out, prev_norm, e, outcome, ro);                     \
+        else                                                                                              \
+            hipExtLaunchKernelGGL((k_update_fused<KIND, V, O, false>), dim3(grid), dim3(QSMC_BLOCK), 0, s, e0, e1, 0, \
+                                  x, ldx, n, w_in, w_out, prev_norm, e, outcome, ro);                     \
+    } while (0)
     if (vec2 && w_in) LU(2, false);
     else if (vec2) LU(2, true);
     else if (w_in) LU(1, false);
@@ -1929,8 +1935,12 @@ int qsmc_update_multi(qsmc_handle_t h, const qsmc_model_t *model, const double *
     switch (model->kind) {
 #define LAUNCH_MU(K)                                                                                   \
     case K:                                                                                            \
-        hipLaunchKernelGGL((k_update_multi<K>), dim3(grid), dim3(QSMC_BLOCK), 0, s, x, ldx, n, w_in, w_out, \
-                           prev_norm, ma, ro);                                                         \
+        if (ma.e[0].lik_pow != 0.0)                                                                    \
+            hipLaunchKernelGGL((k_update_multi<K, true>), dim3(grid), dim3(QSMC_BLOCK), 0, s, x, ldx, n, w_in, \
+                               w_out, prev_norm, ma, ro);                                              \
+        else                                                                                           \
+            hipLaunchKernelGGL((k_update_multi<K, false>), dim3(grid), dim3(QSMC_BLOCK), 0, s, x, ldx, n, w_in, \
+                               w_out, prev_norm, ma, ro);                                              \
         break;
         LAUNCH_MU(QSMC_MODEL_PRECESSION)
         LAUNCH_MU(QSMC_MODEL_BINOMIAL_PRECESSION)
