@@ -276,6 +276,15 @@ int qsmc_prior_uniform_philox(qsmc_handle_t h, const qsmc_model_t *model, int32_
                               qsmc_stream_t stream);
 
 /* ---- tomography canonicalize (tomography/models.py:149-209; a10) -------------------------- */
+/* Random-walk time step between data (Model.update_timestep, smc.py:447-449; RandomWalkModel /
+ * GaussianRandomWalkModel, derived_models.py:693-741, 743-963): x[m][i] += scale[m] * z in place; rows
+ * with scale[m] == 0 do not move.  z != NULL: device array, row r of the WALKING parameters (in index
+ * order) at z + r * ldz -- steps the host drew (the reference's np.random.normal stream in parity mode,
+ * or any step distribution).  z == NULL: standard normals from Philox4x32-10 keyed by (seed, epoch).
+ * `scale` is a HOST array of d doubles (std per parameter times the experiment's scale multiplier). */
+int qsmc_random_walk(qsmc_handle_t h, double *x, int64_t ldx, int64_t n, int32_t d, const double *scale,
+                     const double *z, int64_t ldz, uint64_t seed, uint64_t epoch, qsmc_stream_t stream);
+
 /* basis: DEVICE complex128 (d, dim, dim) row-major as interleaved (re, im), d = dim*dim, dim<=4.
  * In place: clamp negative eigenvalues of rho(x), then x /= x_0 sqrt(dim) unless allow_subnormalized. */
 int qsmc_tomo_canonicalize(qsmc_handle_t h, const double *basis, int32_t dim,

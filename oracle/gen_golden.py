@@ -33,6 +33,7 @@ class Recorder:
         self.enabled = True
         self._random = np.random.random
         self._randn = np.random.randn
+        self._normal = np.random.normal
 
     def random(self, size=None):
         r = self._random(size)
@@ -51,15 +52,26 @@ class Recorder:
             self.data.append(np.asarray(r, dtype=np.float64).ravel().copy())
         return r
 
+    def normal(self, loc=0.0, scale=1.0, size=None):
+        r = self._normal(loc, scale, size)
+        if self.enabled:
+            assert loc == 0.0 and scale == 1.0
+            self.kinds.append(2)
+            self.shapes.append(tuple(np.shape(r)))
+            self.data.append(np.asarray(r, dtype=np.float64).ravel().copy())
+        return r
+
     def __enter__(self):
         np.random.random = self.random
+        np.random.normal = self.normal
         return self
 
     def __exit__(self, *a):
         np.random.random = self._random
+        np.random.normal = self._normal
 
     def arrays(self):
-        shp = -np.ones((len(self.shapes), 2), dtype=np.int64)
+        shp = -np.ones((len(self.shapes), max([2] + [len(s_) for s_ in self.shapes])), dtype=np.int64)
         for i, s in enumerate(self.shapes):
             shp[i, :len(s)] = s
         data = np.concatenate(self.data) if self.data else np.zeros(0)
@@ -529,6 +541,27 @@ def g9_t2_mle():
     run_trajectory("g9_mle_precession_n1000", m, qinfer.UniformDistribution([0, 1]), 1000, ts, sim)
 
 
+def g10_random_walk():
+    """GaussianRandomWalkModel with a fixed diagonal covariance (derived_models.py:743-963): a drifting
+    precession frequency tracked through the time-step update (smc.py:447-449); every np.random.normal
+    draw of update_timestep is recorded like the resampler's."""
+    base = qinfer.SimplePrecessionModel()
+    m = qinfer.GaussianRandomWalkModel(base, fixed_covariance=np.array([2.5e-7]))
+    ts = np.tile(np.array([4.0, 9.0, 17.0, 30.0, 55.0]), 12)
+    rs = np.random.RandomState(8)
+    drift = 0.3 + np.cumsum(5e-4 * rs.randn(len(ts)))
+    sim = lambda k, e: base.simulate_experiment(np.array([[drift[k]]]), e)
+    run_trajectory("g10_grw_precession_n800", m, qinfer.UniformDistribution([0, 1]), 800, ts, sim)
+    # two parameters, only the first one walks; experiment-dependent step scale
+    t2 = qinfer.UnknownT2Model()
+    m2 = qinfer.GaussianRandomWalkModel(t2, random_walk_idxs=[0], fixed_covariance=np.array([1e-6]),
+                                        scale_mult=lambda ep: np.sqrt(ep['t']))
+    ep = np.empty((48,), dtype=t2.expparams_dtype)
+    ep['t'] = np.tile(np.array([2.0, 5.0, 11.0, 23.0]), 12)
+    sim2 = lambda k, e: t2.simulate_experiment(np.array([[0.3, 0.02]]), e)
+    run_trajectory("g10_grw_t2_n800", m2, qinfer.UniformDistribution([[0, 1], [0, 0.1]]), 800, ep, sim2)
+
+
 if __name__ == "__main__":
     g1_precession()
     g1_binomial()
@@ -543,4 +576,5 @@ if __name__ == "__main__":
     g8_binomial_rb()
     g8_simple_est()
     g9_t2_mle()
+    g10_random_walk()
     print("total bytes:", sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT)))

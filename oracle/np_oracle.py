@@ -50,9 +50,12 @@ class LegacyRNG:
     def randn(self, *shape):
         return np.random.randn(*shape)
 
+    def normal(self, shape):
+        return np.random.normal(size=shape)
+
 
 class ReplayRNG:
-    """Replays a recorded draw log: kinds (0 = uniform, 1 = normal), shapes, flat data."""
+    """Replays a recorded draw log: kinds (0 = uniform, 1 = randn, 2 = np.random.normal), shapes, flat data."""
 
     def __init__(self, kinds, shapes, data):
         self.kinds = [int(k) for k in kinds]
@@ -78,6 +81,9 @@ class ReplayRNG:
 
     def randn(self, *shape):
         return self._pop(1, shape)
+
+    def normal(self, shape):
+        return self._pop(2, shape)
 
     @property
     def exhausted(self):
@@ -396,8 +402,9 @@ def liu_west(w, x, valid_fn, rng, a=0.98, h=None, maxiter=1000, postselect=True,
 class OracleModel:
     """Bundle of callables describing one of the four hot-path models."""
 
-    def __init__(self, name, d, lik, valid, canon=None):
+    def __init__(self, name, d, lik, valid, canon=None, timestep=None):
         self.name, self.d, self.lik, self.valid, self.canon = name, d, lik, valid, canon
+        self.timestep = timestep          # (x, expparams, rng) -> x after the step, or None (static parameters)
 
 
 def precession_model(min_freq=0.0):
@@ -431,6 +438,21 @@ def unknown_t2_model():
 def mle_model(base, power):
     """derived_models.py:673-691: L ** power; everything else is the decorated model's."""
     return OracleModel('mle_' + base.name, base.d, lambda o, x, e: base.lik(o, x, e) ** power, base.valid, base.canon)
+
+
+def gaussian_random_walk_model(base, fixed_std, idxs=None, scale_mult=None):
+    """derived_models.py:743-963 with a fixed DIAGONAL covariance and no transformation: after each datum
+    x[:, idxs] += fixed_std * scale_mult(e) * normal(size=(n_eps, N, n_rw)) (update_timestep :920-963)."""
+    fixed_std = np.atleast_1d(np.asarray(fixed_std, dtype=np.float64))
+    idxs = np.arange(base.d) if idxs is None else np.atleast_1d(idxs)
+
+    def step(x, e, rng):
+        z = rng.normal((1, x.shape[0], len(idxs)))[0]
+        mult = 1.0 if scale_mult is None else float(np.ravel(scale_mult(e))[0])
+        out = x.copy()
+        out[:, idxs] += mult * (fixed_std * z)
+        return out
+    return OracleModel('grw_' + base.name, base.d, base.lik, base.valid, base.canon, timestep=step)
 
 
 def tomography_model(basis, allow_subnormalized=False):
@@ -520,6 +542,8 @@ class OracleSMC:
                 raise ValueError("Invalid zero-weight policy {} encountered.".format(self.policy))
         self.w[:] = weights[0, 0, :]                                      # :441
         self.normalization_record.append(norm[0][0])
+        if self.model.timestep is not None:                               # :447-449
+            self.x = self.model.timestep(self.x, expparams, self.rng)
         if self.n_ess <= self.min_n_ess:                                  # :452-453
             self.min_n_ess = self.n_ess
         if check_for_resample:

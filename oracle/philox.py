@@ -33,18 +33,34 @@ def keys(seed, epoch):
     return seed & 0xFFFFFFFF, ((seed >> 32) ^ (int(epoch) >> 16)) & 0xFFFFFFFF
 
 
-def uniforms(particles, seed, epoch, rnd, slot):
-    """(u0, u1) for each particle index at (epoch, round, slot)."""
+def uniforms(particles, seed, epoch, rnd, slot, key_xor=(0, 0)):
+    """(u0, u1) for each particle index at (epoch, round, slot).  key_xor: domain separation applied to
+    the two key words (qsmc_random_walk keeps its streams apart from the resampler's this way)."""
     particles = np.asarray(particles, dtype=np.uint64)
     k0, k1 = keys(seed, epoch)
+    k0, k1 = k0 ^ key_xor[0], k1 ^ key_xor[1]
     er = np.uint64(((int(epoch) & 0xFFFF) << 16) | int(rnd))
     r = philox4x32_10(particles & MASK, particles >> np.uint64(32), np.full(particles.shape, er),
                       np.full(particles.shape, np.uint64(slot)), k0, k1)
     return u53(r[0], r[1]), u53(r[2], r[3])
 
 
-def normals(particles, seed, epoch, rnd, slot):
-    u0, u1 = uniforms(particles, seed, epoch, rnd, slot)
+WALK_KEY_XOR = (0x52574B31, 0x9E3779B9)
+
+
+def random_walk_normals(n, n_rw, seed, epoch):
+    """Standard normals of qsmc_random_walk (z == NULL): (n_rw, n); particles 2P and 2P + 1 share block
+    (P, epoch, slot r) of walking parameter r -- Box-Muller component i & 1."""
+    i = np.arange(n, dtype=np.int64)
+    out = np.empty((n_rw, n))
+    for r in range(n_rw):
+        za, zb = normals(i >> 1, seed, epoch, 0, r, key_xor=WALK_KEY_XOR)
+        out[r] = np.where(i & 1, zb, za)
+    return out
+
+
+def normals(particles, seed, epoch, rnd, slot, key_xor=(0, 0)):
+    u0, u1 = uniforms(particles, seed, epoch, rnd, slot, key_xor)
     r = np.sqrt(-2.0 * np.log(1.0 - u0))
     return r * np.cos(2 * np.pi * u1), r * np.sin(2 * np.pi * u1)
 

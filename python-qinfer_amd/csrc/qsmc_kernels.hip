@@ -1461,6 +1461,44 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_prior_uniform_philox(
 }
 
 // =============================================================================================
+// time-step updates (smc.py:447-449, Model.update_timestep): the cloud takes a random-walk step between
+// data.  x[m][i] += scale[m] * z, in place; rows with scale 0 do not move and are not touched.
+//   z given (device, [row r of the walking parameters][i]): the host drew the steps (parity mode: the
+//     reference's np.random.normal call, or an arbitrary step distribution of a RandomWalkModel);
+//   z == nullptr: standard normals from Philox -- pair index P = i >> 1 shares a block across the two
+//     particles of a pair for ONE walking parameter r: block (P, epoch, slot r), Box-Muller comp i & 1.
+// HBM-bound: reads and writes the walking rows once (16 B per particle per walking parameter).
+// =============================================================================================
+struct WalkArgs {
+    double scale[QSMC_MAX_D];
+    int row[QSMC_MAX_D];        // parameter index of walking row r
+    int n_rw;
+};
+
+__global__ __launch_bounds__(QSMC_BLOCK) void k_random_walk(double *__restrict__ x, int64_t ldx, int64_t n,
+                                                            WalkArgs wa, const double *__restrict__ z, int64_t ldz,
+                                                            uint32_t k0, uint32_t k1, uint32_t epoch) {
+    const int64_t n_pairs = (n + 1) >> 1;
+    for (int64_t P = (int64_t)blockIdx.x * QSMC_BLOCK + threadIdx.x; P < n_pairs;
+         P += (int64_t)gridDim.x * QSMC_BLOCK) {
+        const int64_t i0 = 2 * P, i1 = 2 * P + 1;
+        for (int r = 0; r < wa.n_rw; ++r) {
+            double z0, z1;
+            if (z) {
+                z0 = z[r * ldz + i0];
+                z1 = i1 < n ? z[r * ldz + i1] : 0.0;
+            } else {
+                PhiloxStream rng{(uint64_t)P, (epoch << 16), k0, k1};
+                rng.normals((uint32_t)r, z0, z1);
+            }
+            double *row = x + (int64_t)wa.row[r] * ldx;
+            row[i0] += wa.scale[r] * z0;
+            if (i1 < n) row[i1] += wa.scale[r] * z1;
+        }
+    }
+}
+
+// =============================================================================================
 // tomography canonicalize: per-particle dim x dim complex Hermitian Jacobi, clamp, re-expand
 // =============================================================================================
 template <int DIM>
@@ -2427,6 +2465,30 @@ int qsmc_prior_uniform_philox(qsmc_handle_t h, const qsmc_model_t *model, int32_
                        reinterpret_cast<unsigned long long *>(h->counter));
     HIP_TRY(h, hipGetLastError());
     if (n_failed_host) return read_counter(h, n_failed_host, s);
+    return QSMC_OK;
+}
+
+int qsmc_random_walk(qsmc_handle_t h, double *x, int64_t ldx, int64_t n, int32_t d, const double *scale,
+                     const double *z, int64_t ldz, uint64_t seed, uint64_t epoch, qsmc_stream_t stream) {
+    if (!h || !x || !scale || n < 0 || d < 1 || d > QSMC_MAX_D) return QSMC_ERR_INVALID;
+    WalkArgs wa;
+    memset(&wa, 0, sizeof(wa));
+    for (int m = 0; m < d; ++m) {
+        if (!(scale[m] == scale[m])) return QSMC_ERR_INVALID;
+        if (scale[m] != 0.0) {
+            wa.scale[wa.n_rw] = scale[m];
+            wa.row[wa.n_rw] = m;
+            ++wa.n_rw;
+        }
+    }
+    if (n == 0 || wa.n_rw == 0) return QSMC_OK;
+    if (z && wa.n_rw > 1 && ldz < n) return QSMC_ERR_INVALID;      // (a single row's stride is never used)
+    // (moves particles, not weights: a queued resample prefix stays valid)
+    const uint32_t k0 = (uint32_t)seed ^ 0x52574B31u;           // "RWK1": keep the walk's streams apart from
+    const uint32_t k1 = (uint32_t)(seed >> 32) ^ (uint32_t)(epoch >> 16) ^ 0x9E3779B9u;   // the resampler's
+    hipLaunchKernelGGL(k_random_walk, dim3(grid_for((n + 1) / 2, QSMC_BLOCK)), dim3(QSMC_BLOCK), 0,
+                       (hipStream_t)stream, x, ldx, n, wa, z, ldz, k0, k1, (uint32_t)(epoch & 0xFFFFu));
+    HIP_TRY(h, hipGetLastError());
     return QSMC_OK;
 }
 

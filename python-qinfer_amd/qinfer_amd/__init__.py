@@ -16,7 +16,8 @@ from .abstract_model import FiniteOutcomeModel, Model, Simulatable  # noqa: F401
 from .distributions import (Distribution, MultivariateNormalDistribution, ParticleDistribution,  # noqa: F401
                             PostselectedDistribution, ProductDistribution, UniformDistribution)
 from .domains import Domain, IntegerDomain  # noqa: F401
-from .models import (BinomialModel, DerivedModel, MLEModel, RandomizedBenchmarkingModel,  # noqa: F401
+from .models import (BinomialModel, DerivedModel, GaussianRandomWalkModel, MLEModel,  # noqa: F401
+                     RandomWalkModel, RandomizedBenchmarkingModel,
                      SimpleInversionModel, SimplePrecessionModel, UnknownT2Model)
 from .resamplers import LiuWestResampler, Resampler  # noqa: F401
 from .smc import SMCUpdater  # noqa: F401

@@ -286,6 +286,16 @@ class Engine:
             "qsmc_lw_resample_philox")
         return x_out, (failed.value if sync else None)
 
+    def random_walk(self, x, scale, z=None, seed=0, epoch=0):
+        """x[m, :] += scale[m] * z in place (rows with scale 0 untouched); z: device (n_rw, n) steps, or None
+        for Philox standard normals."""
+        scale = np.ascontiguousarray(scale, dtype=np.float64)
+        self._chk(self.lib.qsmc_random_walk(
+            self.h, self._p(x), x.stride(0), x.shape[1], x.shape[0], _native.f64_ptr(scale),
+            self._p(z) if z is not None else None,
+            (z.stride(0) if z.shape[0] > 1 else z.shape[1]) if z is not None else 0,
+            C.c_uint64(seed & (2 ** 64 - 1)), C.c_uint64(epoch), self.stream()), "qsmc_random_walk")
+
     def lw_resample_prepare(self, w, n_in, norm, n_out, seed, epoch):
         """Queue the weight-only prefix of the next `lw_resample_philox` call with the same arguments."""
         self._chk(self.lib.qsmc_lw_resample_prepare(

@@ -16,7 +16,7 @@ from .abstract_model import FiniteOutcomeModel, Model, NativeModelMixin
 from .domains import IntegerDomain
 
 __all__ = ["SimpleInversionModel", "SimplePrecessionModel", "UnknownT2Model", "DerivedModel", "BinomialModel",
-           "MLEModel", "RandomizedBenchmarkingModel"]
+           "MLEModel", "RandomWalkModel", "GaussianRandomWalkModel", "RandomizedBenchmarkingModel"]
 
 
 def _field(expparams, name):
@@ -311,6 +311,210 @@ class MLEModel(NativeModelMixin, DerivedModel):
 
     def simulate_experiment(self, modelparams, expparams, repeat=1):
         return self.underlying_model.simulate_experiment(modelparams, expparams, repeat)
+
+
+class _WalkingModel(NativeModelMixin, DerivedModel):
+    """Shared plumbing of the random-walk decorators: likelihood, validity and simulation are the decorated
+    model's (on its first n parameters); the walk happens in `update_timestep` / `_native_timestep`."""
+
+    _walk_epoch = 0
+
+    @property
+    def is_n_outcomes_constant(self):
+        return self.underlying_model.is_n_outcomes_constant
+
+    def _native_desc(self):
+        return self.underlying_model._native_desc()
+
+    def _native_expparams(self, expparams):
+        return self.underlying_model._native_expparams(expparams)
+
+    def _walk_seed(self, updater):
+        self._walk_epoch += 1
+        rank = 0 if updater._comm is None else updater._comm.rank
+        return updater._seed + 0x9E3779B97F4A7C15 * (rank + 1), self._walk_epoch
+
+
+class RandomWalkModel(_WalkingModel):
+    r"""After every datum each particle takes a step drawn from `step_distribution`
+    (reference derived_models.py:693-741).  The steps are sampled by the distribution (host, any law) and
+    added to the device-resident cloud in place -- the locations never travel to the host."""
+
+    def __init__(self, underlying_model, step_distribution):
+        self._step_dist = step_distribution
+        super().__init__(underlying_model)
+        if self.underlying_model.n_modelparams != self._step_dist.n_rvs:
+            raise TypeError("Step distribution does not match model dimension.")
+        self._native = bool(getattr(underlying_model, "_native", False))
+
+    def likelihood(self, outcomes, modelparams, expparams):
+        Model.likelihood(self, outcomes, modelparams, expparams)
+        return self.underlying_model.likelihood(outcomes, modelparams, expparams)
+
+    def simulate_experiment(self, modelparams, expparams, repeat=1):
+        return self.underlying_model.simulate_experiment(modelparams, expparams, repeat)
+
+    def update_timestep(self, modelparams, expparams):
+        # the step is independent of the experiment; one step vector per (particle, experiment)
+        n, n_e = modelparams.shape[0], expparams.shape[0]
+        steps = self._step_dist.sample(n=n * n_e).reshape((n, n_e, self.n_modelparams)).transpose((0, 2, 1))
+        return modelparams[:, :, np.newaxis] + steps
+
+    def _native_timestep(self, updater, expparams):
+        eng = updater._eng
+        steps = np.asarray(self._step_dist.sample(n=updater.n_particles), dtype=np.float64)     # (n, d)
+        eng.random_walk(updater._x, np.ones(self.n_modelparams), z=eng.locs_to_soa(steps))
+
+
+class GaussianRandomWalkModel(_WalkingModel):
+    r"""After every datum the parameters selected by `random_walk_idxs` take a zero-mean Gaussian step
+    (reference derived_models.py:743-963).  The covariance is either fixed (`fixed_covariance`: its
+    diagonal if `diagonal`, else the full matrix) or unknown, in which case its square-root entries are
+    appended to the model parameters and each particle walks with its own belief.  `scale_mult` (a
+    function of expparams, or the name of an expparams field) scales the step of a given experiment;
+    `model_transformation = (f, f_inv)` applies the walk in transformed coordinates.
+
+    With a fixed diagonal covariance, no transformation and a decorated model that has kernels -- the case
+    SURVEY 8(f)3 names -- the whole step runs on the device (`qsmc_random_walk`): Philox normals with
+    `device_rng`, else the reference's own `np.random.normal(size=(1, N, n_rw))` draw uploaded once.
+    Every other variant keeps the reference's host arithmetic (plugin slow path)."""
+
+    def __init__(self, underlying_model, random_walk_idxs='all', fixed_covariance=None, diagonal=True,
+                 scale_mult=None, model_transformation=None):
+        n_u = underlying_model.n_modelparams
+        self._diagonal = diagonal
+        self._rw_idxs = np.s_[:n_u] if (isinstance(random_walk_idxs, str) and random_walk_idxs == 'all') \
+            else random_walk_idxs
+        explicit = np.arange(n_u)[self._rw_idxs]
+        if explicit.size == 0:
+            raise IndexError('At least one model parameter must take a random walk.')
+        self._explicit_idxs = np.atleast_1d(explicit)
+        self._rw_names = [underlying_model.modelparam_names[i] for i in self._explicit_idxs]
+        self._n_rw = len(self._explicit_idxs)
+        self._srw_names = []
+        if fixed_covariance is None:
+            self._has_fixed_covariance = False
+            if diagonal:
+                self._srw_names = [r"\sigma_{{{}}}".format(nm) for nm in self._rw_names]
+                self._srw_idxs = (n_u + np.arange(self._n_rw)).astype(int)
+            else:
+                self._srw_idxs = (n_u + np.arange(self._n_rw * (self._n_rw + 1) // 2)).astype(int)
+                self._srw_tri_idxs = np.tril_indices(self._n_rw)
+                for i1, name1 in enumerate(self._rw_names):
+                    for name2 in self._rw_names[:i1 + 1]:
+                        self._srw_names.append(r"\sigma_{{{}}}".format(name1) if name1 == name2
+                                               else r"\sigma_{{{},{}}}".format(name2, name1))
+        else:
+            fixed_covariance = np.asarray(fixed_covariance, dtype=np.float64)
+            self._has_fixed_covariance = True
+            if diagonal:
+                if fixed_covariance.ndim != 1:
+                    raise ValueError('Diagonal covariance requested, but fixed_covariance has {} dimensions.'
+                                     .format(fixed_covariance.ndim))
+                if fixed_covariance.size != self._n_rw:
+                    raise ValueError('fixed_covariance dimension, {}, inconsistent with number of parameters, {}'
+                                     .format(fixed_covariance.size, self._n_rw))
+                self._fixed_scale = np.sqrt(fixed_covariance)
+            else:
+                if fixed_covariance.ndim != 2:
+                    raise ValueError('Dense covariance requested, but fixed_covariance has {} dimensions.'
+                                     .format(fixed_covariance.ndim))
+                if fixed_covariance.shape != (self._n_rw, self._n_rw):
+                    raise ValueError('fixed_covariance expected to be square with width {}'.format(self._n_rw))
+                self._fixed_chol = np.linalg.cholesky(fixed_covariance)
+        super().__init__(underlying_model)
+        if scale_mult is None:
+            self._scale_mult_fcn = lambda expparams: 1
+        elif isinstance(scale_mult, str):
+            self._scale_mult_fcn = lambda ep: ep[scale_mult]
+        else:
+            self._scale_mult_fcn = scale_mult
+        self._has_transformation = model_transformation is not None
+        if self._has_transformation:
+            self._transform, self._inv_transform = model_transformation
+        self._native = bool(getattr(underlying_model, "_native", False) and self._has_fixed_covariance
+                            and diagonal and not self._has_transformation)
+        if not self._native:
+            self._native_timestep = None            # (instance attribute shadows the method: plugin slow path)
+
+    # ------------------------------------------------------------------ surface
+    @property
+    def modelparam_names(self):
+        return self.underlying_model.modelparam_names + self._srw_names
+
+    @property
+    def n_modelparams(self):
+        return len(self.modelparam_names)
+
+    @property
+    def is_n_outcomes_constant(self):
+        return False
+
+    def _u(self, modelparams):
+        return modelparams[..., :self.underlying_model.n_modelparams]
+
+    def are_models_valid(self, modelparams):
+        ok = self.underlying_model.are_models_valid(self._u(modelparams))
+        if self._has_fixed_covariance or not self._diagonal:
+            return ok
+        return np.logical_and(ok, np.greater_equal(modelparams[..., self._srw_idxs], 0).all(axis=-1))
+
+    def likelihood(self, outcomes, modelparams, expparams):
+        Model.likelihood(self, outcomes, modelparams, expparams)
+        return self.underlying_model.likelihood(outcomes, self._u(modelparams), expparams)
+
+    def simulate_experiment(self, modelparams, expparams, repeat=1):
+        return self.underlying_model.simulate_experiment(self._u(modelparams), expparams, repeat)
+
+    def est_update_covariance(self, modelparams):
+        """Covariance of one unit step (its particle average when it is being learned)."""
+        if self._diagonal:
+            return np.diag(self._fixed_scale ** 2 if self._has_fixed_covariance
+                           else np.mean(modelparams[:, self._srw_idxs] ** 2, axis=0))
+        if self._has_fixed_covariance:
+            return np.dot(self._fixed_chol, self._fixed_chol.T)
+        chol = np.zeros((modelparams.shape[0], self._n_rw, self._n_rw))
+        chol[(np.s_[:],) + self._srw_tri_idxs] = modelparams[:, self._srw_idxs]
+        return np.mean(np.einsum('ijk,ilk->ijl', chol, chol), axis=0)
+
+    def update_timestep(self, modelparams, expparams):
+        """Host arithmetic, every variant (legacy global RNG, draw shapes as in the reference)."""
+        n, n_e = modelparams.shape[0], expparams.shape[0]
+        if self._diagonal:
+            scale = self._fixed_scale if self._has_fixed_covariance else modelparams[:, self._srw_idxs]
+            steps = (scale * np.random.normal(size=(n_e, n, self._n_rw))).transpose((1, 2, 0))
+        elif self._has_fixed_covariance:
+            steps = np.dot(self._fixed_chol, np.random.normal(size=(self._n_rw, n * n_e))
+                           ).reshape(self._n_rw, n, n_e).transpose((1, 0, 2))
+        else:
+            chol = np.zeros((n, self._n_rw, self._n_rw))
+            chol[(np.s_[:],) + self._srw_tri_idxs] = modelparams[:, self._srw_idxs]
+            steps = np.einsum('kij,kjl->kil', chol, np.random.normal(size=(n, self._n_rw, n_e)))
+        steps = self._scale_mult_fcn(expparams) * steps
+        n_u = self.underlying_model.n_modelparams
+        if self._has_transformation:
+            new = np.repeat(modelparams[np.newaxis, :, :], n_e, axis=0).reshape((n_e * n, -1))
+            new[:, :n_u] = self._transform(new[:, :n_u])
+            new[:, self._rw_idxs] += steps.transpose((2, 0, 1)).reshape((n_e * n, -1))
+            new[:, :n_u] = self._inv_transform(new[:, :n_u])
+            return new.reshape((n_e, n, -1)).transpose((1, 2, 0))
+        new = np.repeat(modelparams[:, :, np.newaxis], n_e, axis=2)
+        new[:, self._rw_idxs, :] += steps
+        return new
+
+    def _native_timestep(self, updater, expparams):
+        """Fixed diagonal covariance: the step of one datum, in place on the device."""
+        eng = updater._eng
+        mult = float(np.ravel(self._scale_mult_fcn(np.atleast_1d(expparams)))[0])
+        scale = np.zeros(self.n_modelparams)
+        scale[self._explicit_idxs] = self._fixed_scale * mult
+        if updater._device_rng:
+            seed, epoch = self._walk_seed(updater)
+            eng.random_walk(updater._x, scale, z=None, seed=seed, epoch=epoch)
+        else:
+            # parity mode: the reference's draw, np.random.normal(size=(n_eps, n_mps, n_rw)) with n_eps = 1
+            z = np.random.normal(size=(1, updater.n_particles, self._n_rw))[0]
+            eng.random_walk(updater._x, scale, z=eng.locs_to_soa(z))
 
 
 class RandomizedBenchmarkingModel(NativeModelMixin, FiniteOutcomeModel):

@@ -333,7 +333,12 @@ class SMCUpdater(ParticleDistribution):
             self._moments_cache = (sum_w, fused_moments[0] / new_norm, fused_moments[1] / new_norm)
         self._normalization_record.append(norm)                      # smc.py:444
 
-        if not self._native and type(self.model).update_timestep is not Simulatable.update_timestep:
+        step = getattr(self.model, "_native_timestep", None)
+        if self._native and step is not None:
+            # a random-walk model with device kernels: the cloud takes its step in place (smc.py:447-449)
+            step(self, expparams)
+            self._moments_cache = None
+        elif not self._native and type(self.model).update_timestep is not Simulatable.update_timestep:
             # plugin slow path: a user model that moves particles between data (smc.py:447-449)
             locs = self.model.update_timestep(self.particle_locations, expparams)[:, :, 0]
             self._x = self._eng.locs_to_soa(locs)
@@ -363,7 +368,7 @@ class SMCUpdater(ParticleDistribution):
         if len(expparams.shape) == 1:
             expparams = expparams[:, None]
         fast = (self._native and self._comm is None and self._batch_fast_path
-                and type(self.model).update_timestep is not None)
+                and getattr(self.model, "_native_timestep", None) is None)   # moving particles: one datum at a time
         idx = 0
         kmax = self._eng.MULTI_KMAX
         while idx < n_exps:

@@ -31,12 +31,13 @@ class Replay:
         self.rng = orc.ReplayRNG(g[prefix + "draw_kinds"], g[prefix + "draw_shapes"], g[prefix + "draw_data"])
 
     def __enter__(self):
-        self._orig = np.random.random
+        self._orig, self._orig_normal = np.random.random, np.random.normal
         np.random.random = lambda size=None: self.rng.random(size if isinstance(size, tuple) else (size,))
+        np.random.normal = lambda loc=0.0, scale=1.0, size=None: self.rng.normal(size)
         return self
 
     def __exit__(self, *a):
-        np.random.random = self._orig
+        np.random.random, np.random.normal = self._orig, self._orig_normal
 
     def kernel(self, *shape):
         return self.rng.randn(*shape)
@@ -749,6 +750,89 @@ def test_traj_mle(qi, golden):
     g = golden("g9_mle_precession_n1000")
     m = qi.MLEModel(qi.SimplePrecessionModel(), 3.0)
     _run_traj(qi, g, m, lambda k: g["ep_t"][k:k + 1], lambda k: 3.0 * g["ep_t"][k])
+
+
+def test_traj_gaussian_random_walk(qi, golden):
+    """Time-step updates on the device (qsmc_random_walk), parity mode: the reference's np.random.normal draws."""
+    g = golden("g10_grw_precession_n800")
+    m = qi.GaussianRandomWalkModel(qi.SimplePrecessionModel(), fixed_covariance=np.array([2.5e-7]))
+    assert m._native and callable(m._native_timestep)
+    upd, checked = _run_traj(qi, g, m, lambda k: g["ep_t"][k:k + 1], lambda k: g["ep_t"][k])
+    assert checked == len(g["outcomes"]) - 1
+    np.testing.assert_allclose(upd.particle_locations, g["final_locs"], rtol=1e-9, atol=1e-12)
+    g = golden("g10_grw_t2_n800")
+    t2 = qi.UnknownT2Model()
+    m2 = qi.GaussianRandomWalkModel(t2, random_walk_idxs=[0], fixed_covariance=np.array([1e-6]),
+                                    scale_mult=lambda ep: np.sqrt(ep["t"]))
+
+    def ep_of(k):
+        ep = np.empty((1,), dtype=t2.expparams_dtype)
+        ep["t"] = g["ep_t"][k]
+        return ep
+    upd, checked = _run_traj(qi, g, m2, ep_of, lambda k: g["ep_t"][k])
+    assert checked == len(g["outcomes"]) - 1
+    np.testing.assert_allclose(upd.particle_locations, g["final_locs"], rtol=1e-9, atol=1e-12)
+
+
+def test_random_walk_kernel(qi, eng):
+    """qsmc_random_walk: given steps -> x + scale * z exactly, untouched rows bitwise unchanged; Philox mode ->
+    the oracle's emulated stream; RandomWalkModel (arbitrary step law, host-sampled) and the unknown-covariance
+    GaussianRandomWalkModel (plugin slow path) through SMCUpdater."""
+    import philox as ph
+    rs = np.random.RandomState(4)
+    n, d = 70001, 3
+    x0 = rs.randn(n, d)
+    z = rs.randn(n, 2)
+    x = eng.locs_to_soa(x0)
+    eng.random_walk(x, np.array([0.5, 0.0, 2.0]), z=eng.locs_to_soa(z))
+    got = x.cpu().numpy().T
+    np.testing.assert_array_equal(got[:, 1], x0[:, 1])
+    np.testing.assert_array_equal(got[:, 0], x0[:, 0] + 0.5 * z[:, 0])
+    np.testing.assert_array_equal(got[:, 2], x0[:, 2] + 2.0 * z[:, 1])
+    x = eng.locs_to_soa(x0)
+    eng.random_walk(x, np.array([0.0, 1e-3, 0.25]), z=None, seed=77, epoch=3)
+    zr = ph.random_walk_normals(n, 2, 77, 3)
+    got = x.cpu().numpy().T
+    np.testing.assert_array_equal(got[:, 0], x0[:, 0])
+    np.testing.assert_allclose(got[:, 1], x0[:, 1] + 1e-3 * zr[0], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(got[:, 2], x0[:, 2] + 0.25 * zr[1], rtol=0, atol=2e-14)
+    x2 = eng.locs_to_soa(x0)
+    eng.random_walk(x2, np.array([0.0, 1e-3, 0.25]), z=None, seed=77, epoch=4)
+    assert not bool((x2 == x).all())
+    # device-RNG walk inside an updater: a flat-likelihood datum (t = 0) leaves the weights alone, so the
+    # cloud's variance grows by exactly sigma^2 per step
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = qi.GaussianRandomWalkModel(qi.SimplePrecessionModel(), fixed_covariance=np.array([1e-4]))
+        upd = qi.SMCUpdater(m, 400000, qi.UniformDistribution([0.4, 0.6]), device_rng=True, seed=3)
+        v0 = upd.est_covariance_mtx()[0, 0]
+        for _ in range(20):
+            upd.update(0, np.array([0.0]))
+        v1 = upd.est_covariance_mtx()[0, 0]
+        assert upd.resample_count == 0
+        np.testing.assert_allclose(v1 - v0, 20 * 1e-4, rtol=0.02)
+        # batch_update must not fuse data of a walking model
+        upd.batch_update(np.zeros((6, 1), dtype=int), np.zeros(6), resample_interval=3)
+        np.testing.assert_allclose(upd.est_covariance_mtx()[0, 0] - v1, 6 * 1e-4, rtol=0.05)
+        # RandomWalkModel: any step distribution; steps sampled on the host, added on the device
+        step = qi.MultivariateNormalDistribution(np.zeros(1), np.array([[4e-4]]))
+        rw = qi.RandomWalkModel(qi.SimplePrecessionModel(), step)
+        upd = qi.SMCUpdater(rw, 200000, qi.UniformDistribution([0.4, 0.6]), device_rng=True, seed=4)
+        v0 = upd.est_covariance_mtx()[0, 0]
+        for _ in range(5):
+            upd.update(0, np.array([0.0]))
+        np.testing.assert_allclose(upd.est_covariance_mtx()[0, 0] - v0, 5 * 4e-4, rtol=0.03)
+        with pytest.raises(TypeError):
+            qi.RandomWalkModel(qi.RandomizedBenchmarkingModel(), step)
+        # unknown (learned) step size: an extra model parameter, plugin slow path
+        ml = qi.GaussianRandomWalkModel(qi.SimplePrecessionModel())
+        assert not ml._native and ml.n_modelparams == 2 and ml._native_timestep is None
+        np.random.seed(1)
+        upd = qi.SMCUpdater(ml, 2000, qi.UniformDistribution([[0.2, 0.4], [0.0, 0.01]]))
+        for k in range(10):
+            upd.update(int(k % 2), np.array([3.0 + k]))
+        assert upd.particle_locations.shape == (2000, 2) and np.isfinite(upd.est_mean()).all()
+        assert np.all(ml.are_models_valid(np.array([[0.3, 0.01], [0.3, -0.01]])) == [True, False])
 
 
 def test_traj_tomography(qi, golden):

@@ -212,6 +212,17 @@ def test_g9_mle_traj(golden):
           lambda k: 3.0 * g["ep_t"][k])
 
 
+def test_g10_random_walk_traj(golden):
+    """Time-step updates (smc.py:447-449) through GaussianRandomWalkModel with fixed diagonal covariance."""
+    g = golden("g10_grw_precession_n800")
+    model = orc.gaussian_random_walk_model(orc.precession_model(), np.sqrt(2.5e-7))
+    smc = _traj(g, model, lambda k: {"t": g["ep_t"][k:k + 1]}, lambda k: g["ep_t"][k])
+    g = golden("g10_grw_t2_n800")
+    model = orc.gaussian_random_walk_model(orc.unknown_t2_model(), np.sqrt(1e-6), idxs=[0],
+                                           scale_mult=lambda e: np.sqrt(e["t"]))
+    _traj(g, model, lambda k: {"t": g["ep_t"][k:k + 1]}, lambda k: g["ep_t"][k])
+
+
 def test_g1_tomography(golden):
     g = golden("g1_tomography_n300")
     basis = orc.pauli_data(2)

@@ -40,3 +40,20 @@ for k in range(K):
     ep=np.zeros((1,),dtype=m.expparams_dtype); p=rs.randint(1,16); ep['meas'][0,0]=1; ep['meas'][0,p]=1; eps.append(ep)
     outs.append(int(rs.random_sample() < np.clip(true[0]+true[p],0,1)))
 run("Tomography 2q (d=16)", qi.SMCUpdater(m, 1_250_000, Fixed(), device_rng=True), eps, outs)
+# (f)3 models at scale
+K=63; ts=(9/8)**(np.arange(K)*0.5)
+outs=[int(rs.random_sample() >= np.cos(0.3*t/2)**2) for t in ts]
+m=qi.GaussianRandomWalkModel(qi.SimplePrecessionModel(), fixed_covariance=np.array([1e-8]))
+run("GaussianRandomWalk(Precession)", qi.SMCUpdater(m, 10_000_000, qi.UniformDistribution([0,1]), device_rng=True), [ts[k:k+1] for k in range(K)], outs)
+m=qi.MLEModel(qi.SimplePrecessionModel(), 2.0)
+run("MLEModel(Precession, 2.0)", qi.SMCUpdater(m, 10_000_000, qi.UniformDistribution([0,1]), device_rng=True), [ts[k:k+1] for k in range(K)], outs)
+m=qi.UnknownT2Model(); eps=[]
+for k in range(K):
+    ep=np.empty((1,),dtype=m.expparams_dtype); ep['t']=ts[k]; eps.append(ep)
+run("UnknownT2 (d=2)", qi.SMCUpdater(m, 10_000_000, qi.UniformDistribution([[0,1],[0,0.1]]), device_rng=True), eps, outs)
+m=qi.BinomialModel(qi.RandomizedBenchmarkingModel()); eps=[]; outs2=[]
+prior=qi.PostselectedDistribution(qi.UniformDistribution([[0.8,1],[0,1],[0,1]]), m)
+for k in range(K):
+    ep=np.empty((1,),dtype=m.expparams_dtype); ep['m']=1+5*k; ep['n_meas']=25; eps.append(ep)
+    outs2.append(int(rs.binomial(25, 0.3*0.95**(1+5*k)+0.5)))
+run("Binomial(RB) n=25", qi.SMCUpdater(m, 12_500_000, prior, device_rng=True), eps, outs2)
