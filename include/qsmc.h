@@ -175,6 +175,11 @@ int qsmc_clip_weights(qsmc_handle_t h, double *w, int64_t n, double norm,
 int qsmc_weight_stats(qsmc_handle_t h, const double *w, int64_t n, double norm,
                       double *stats_dev, qsmc_update_stats_t *stats_host, qsmc_stream_t stream);
 
+/* est_entropy (distributions.py:457-464): -sum over the particles with w_i / norm > 0 of (w_i / norm) log(w_i / norm),
+ * one pass, result on the host.  w == NULL: implicit all-ones weights. */
+int qsmc_weight_entropy(qsmc_handle_t h, const double *w, int64_t n, double norm, double *entropy_host,
+                        qsmc_stream_t stream);
+
 /* Materialise normalised weights: w_out[i] = w_in[i] / norm (particle_weights property). */
 int qsmc_normalize_weights(qsmc_handle_t h, const double *w_in, double *w_out, int64_t n,
                            double norm, qsmc_stream_t stream);

@@ -9,6 +9,7 @@ outputs.  Nothing from the reference's sources i
 import os
 import sys
 import warnings
+from functools import partial
 
 import numpy as np
 
@@ -562,6 +563,65 @@ def g10_random_walk():
     run_trajectory("g10_grw_t2_n800", m2, qinfer.UniformDistribution([[0, 1], [0, 0.1]]), 800, ep, sim2)
 
 
+def g11_readouts():
+    """Posterior read-outs of a weighted cloud: est_entropy (distributions.py:457-464),
+    est_credible_region (:558-614), sample (:320-333, its uniforms recorded) and SMCUpdater.posterior_marginal
+    (smc.py:672-716), all computed by the reference on a fixed cloud with distinct weights."""
+    out = {}
+    rs = np.random.RandomState(31)
+    n, d = 5000, 2
+    x = np.column_stack([0.3 + 0.02 * rs.randn(n), rs.uniform(0, 0.1, n)])
+    w = rs.random_sample(n) ** 3
+    w[rs.choice(n, 40, replace=False)] = 0.0            # some exactly-zero weights (entropy skips them)
+    w /= w.sum()
+    pd = qinfer.ParticleDistribution(particle_locations=x.copy(), particle_weights=w.copy())
+    out['x'], out['w'] = x, pd.particle_weights
+    out['entropy'] = pd.est_entropy()
+    for lvl in (0.5, 0.95):
+        inside, outside = pd.est_credible_region(level=lvl, return_outside=True)
+        out['cred_%d_inside' % int(lvl * 100)] = inside
+        out['cred_%d_n_outside' % int(lvl * 100)] = outside.shape[0]
+    out['cred_95_slice0'] = pd.est_credible_region(level=0.95, modelparam_slice=slice(0, 1))
+    np.random.seed(12)
+    u = np.random.random((64,))
+    np.random.seed(12)
+    out['sample_u'], out['sample'] = u, pd.sample(n=64)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        upd = qinfer.SMCUpdater(qinfer.UnknownT2Model(), n, FixedPrior(x.copy()))
+        upd.particle_weights[:] = pd.particle_weights
+        ps, pr = upd.posterior_marginal(idx_param=0, res=60)
+        out['marg0_ps'], out['marg0_pr'] = ps, pr
+        ps, pr = upd.posterior_marginal(idx_param=1, res=40, smoothing=0.004, range_min=0.0, range_max=0.1)
+        out['marg1_ps'], out['marg1_pr'] = ps, pr
+    np.savez_compressed(os.path.join(OUT, "g11_readouts.npz"), **out)
+    print("g11_readouts", out['entropy'], out['cred_95_inside'].shape, out['cred_50_inside'].shape)
+
+
+def g12_perf_test():
+    """perf_test (perf_testing.py:182-295) of the reference under np.random.seed(6): the record array of
+    one trial with the t_k = (9/8)^k heuristic -- the loop that defines the benchmark's metric."""
+    from qinfer.perf_testing import perf_test
+    out = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        np.random.seed(6)
+        perf = perf_test(qinfer.SimplePrecessionModel(), 2000, qinfer.UniformDistribution([0, 1]), 60,
+                         qinfer.ExpSparseHeuristic)
+        for f in ('loss', 'resample_count', 'outcome', 'true', 'est', 'experiment'):
+            out['prec_' + f] = perf[f]
+        out['prec_fields'] = np.array(perf.dtype.names)
+        m = qinfer.UnknownT2Model()
+        np.random.seed(7)
+        heur = partial(qinfer.ExpSparseHeuristic, t_field='t', other_fields={})
+        perf = perf_test(m, 3000, qinfer.UniformDistribution([[0, 1], [0, 0.1]]), 40, heur)
+        for f in ('loss', 'resample_count', 'outcome', 'true', 'est', 't'):
+            out['t2_' + f] = perf[f]
+        out['t2_fields'] = np.array(perf.dtype.names)
+    np.savez_compressed(os.path.join(OUT, "g12_perf_test.npz"), **out)
+    print("g12_perf_test", out['prec_loss'][-1], out['t2_loss'][-1], out['prec_resample_count'][-1])
+
+
 if __name__ == "__main__":
     g1_precession()
     g1_binomial()
@@ -577,4 +637,6 @@ if __name__ == "__main__":
     g8_simple_est()
     g9_t2_mle()
     g10_random_walk()
+    g11_readouts()
+    g12_perf_test()
     print("total bytes:", sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT)))

@@ -397,6 +397,52 @@ def liu_west(w, x, valid_fn, rng, a=0.98, h=None, maxiter=1000, postselect=True,
 
 
 # ----------------------------------------------------------------------------------------------
+# Posterior read-outs
+# ----------------------------------------------------------------------------------------------
+def est_entropy(w):
+    """distributions.py:457-464: -sum over nonzero weights of w log w."""
+    nz = w[w > 0]
+    return -np.sum(np.log(nz) * nz)
+
+
+def est_credible_region(w, x, level=0.95, return_outside=False, modelparam_slice=None):
+    """distributions.py:558-614: highest-weight particles first until the mass reaches `level`."""
+    mps = x[:, modelparam_slice] if modelparam_slice is not None else x
+    order = np.argsort(w)[::-1]
+    cum = np.cumsum(w[order])
+    cred = cum <= level
+    cred[np.sum(cred)] = True
+    if return_outside:
+        return mps[order][cred], mps[order][np.logical_not(cred)]
+    return mps[order][cred]
+
+
+def sample_cloud(w, x, u):
+    """distributions.py:320-333 with the uniforms given: inverse-CDF draws, 'right' side, clamped."""
+    cdf = np.cumsum(w)
+    return x[np.minimum(cdf.searchsorted(u, side='right'), len(cdf) - 1)]
+
+
+def posterior_marginal(w, x, idx_param=0, res=100, smoothing=0, range_min=None, range_max=None):
+    """smc.py:672-716: derivative of the linearly interpolated marginal CDF on a res-point grid, optional
+    Gaussian smoothing (SciPy's interp1d / gaussian_filter1d, as the reference calls them)."""
+    import scipy.interpolate
+    from scipy.ndimage import gaussian_filter1d
+    s = np.argsort(x[:, idx_param])
+    locs = x[s, idx_param]
+    r_min = np.min(locs) if range_min is None else range_min
+    r_max = np.max(locs) if range_max is None else range_max
+    ps = np.linspace(r_min, r_max, res)
+    interp = scipy.interpolate.interp1d(np.append(locs, r_max + np.abs(r_max - r_min)),
+                                        np.append(np.cumsum(w[s]), 1), bounds_error=False, fill_value=0,
+                                        assume_sorted=True)
+    pr = np.gradient(interp(ps), ps[1] - ps[0])
+    if smoothing > 0:
+        gaussian_filter1d(pr, res * smoothing / (np.abs(r_max - r_min)), output=pr)
+    return ps, pr
+
+
+# ----------------------------------------------------------------------------------------------
 # Stateful driver mirroring SMCUpdater (a1, a4, a5, a16, a17)
 # ----------------------------------------------------------------------------------------------
 class OracleModel:

@@ -453,8 +453,15 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_weights_pass(const double *__res
         double w = w_in[i] / norm;
         if (MODE == 0) w = w * L[i];
         if (MODE == 1 && w == w) w = fmin(fmax(w, 0.0), 1.0);   // np.clip keeps NaN as NaN
-        if (MODE != 3) w_out[i] = w;
-        acc.add(w, nullptr);
+        if (MODE != 3 && MODE != 4) w_out[i] = w;
+        if (MODE == 4) {
+            // est_entropy (distributions.py:457-464): -sum_{w > 0} w log w, carried in the sumsq slot
+            acc.s[0] += w;
+            acc.s[1] += w > 0.0 ? -(w * log(w)) : 0.0;
+            acc.mn = fmin(acc.mn, w);
+        } else {
+            acc.add(w, nullptr);
+        }
     }
     block_publish<3>(acc.s, acc.mn, ro);
 }
@@ -2046,6 +2053,20 @@ int qsmc_weight_stats(qsmc_handle_t h, const double *w, int64_t n, double norm, 
                       qsmc_update_stats_t *stats_host, qsmc_stream_t stream) {
     if (!h || !w || n <= 0) return QSMC_ERR_INVALID;
     return weights_pass<3>(h, nullptr, n, w, nullptr, norm, stats_dev, stats_host, (hipStream_t)stream);
+}
+
+int qsmc_weight_entropy(qsmc_handle_t h, const double *w, int64_t n, double norm, double *entropy_host,
+                        qsmc_stream_t stream) {
+    if (!h || n <= 0 || !entropy_host || !(norm > 0.0)) return QSMC_ERR_INVALID;
+    if (!w) {                                    // implicit uniform weights 1 / n_total with norm = n_total
+        *entropy_host = (double)n / norm * log(norm);
+        return QSMC_OK;
+    }
+    qsmc_update_stats_t st;
+    const int rc = weights_pass<4>(h, nullptr, n, w, nullptr, norm, nullptr, &st, (hipStream_t)stream);
+    if (rc) return rc;
+    *entropy_host = st.sumsq;
+    return QSMC_OK;
 }
 
 int qsmc_normalize_weights(qsmc_handle_t h, const double *w_in, double *w_out, int64_t n, double norm,

@@ -22,6 +22,8 @@ from .models import (BinomialModel, DerivedModel, GaussianRandomWalkModel, MLEMo
 from .resamplers import LiuWestResampler, Resampler  # noqa: F401
 from .smc import SMCUpdater  # noqa: F401
 from .simple_est import simple_est_prec, simple_est_rb  # noqa: F401
+from .expdesign import EnsembleHeuristic, ExpSparseHeuristic, Heuristic, PGH  # noqa: F401
+from .perf_testing import perf_test, perf_test_multiple, timing  # noqa: F401
 from . import tomography, utils  # noqa: F401
 from .tomography import GinibreDistribution, TomographyModel  # noqa: F401
 

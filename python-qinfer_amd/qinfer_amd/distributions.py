@@ -300,11 +300,67 @@ class ParticleDistribution(Distribution):
         vals = np.asarray(fn(self.particle_locations))
         return np.einsum('i...,i...', self.particle_weights, vals)
 
+    def _single_cloud_only(self, what):
+        if getattr(self, "_comm", None) is not None:
+            raise NotImplementedError("{} looks at one cloud; a sharded updater holds only its shard".format(what))
+
     def est_entropy(self):
-        t = self._eng.torch
-        w = self._eng.normalized_weights(self._weights(), self._norm)
-        nz = w[w > 0]
-        return float(-(t.log(nz) * nz).sum().item())
+        """-sum_i w_i log w_i over the particles of nonzero weight (distributions.py:457-464); one pass."""
+        self._single_cloud_only("est_entropy")
+        return float(self._eng.weight_entropy(self._w, self.n_particles, self._norm))
+
+    # ---------------------------------------------------------------- regions / marginals (SURVEY 8(f)4)
+    def est_credible_region(self, level=0.95, return_outside=False, modelparam_slice=None):
+        """Particles of a credible set of mass >= `level`: highest weight first (distributions.py:558-614).
+
+        Sort (descending, on the device), scan, cut: returns the (n_credible, n_mps) host array of the
+        particles inside -- and with `return_outside` also the rest -- restricted to `modelparam_slice`."""
+        self._single_cloud_only("est_credible_region")
+        eng = self._eng
+        t = eng.torch
+        w = self._weights()
+        order = t.argsort(w, descending=True)
+        cdf = eng.cumsum(w[order].contiguous(), self._norm)
+        k = min(int((cdf <= level).sum().item()) + 1, self.n_particles)    # ... and the one that crosses the level
+        rows = self._x if modelparam_slice is None else self._x[modelparam_slice]
+        if rows.dim() == 1:
+            rows = rows[None, :]
+        inside = np.ascontiguousarray(rows[:, order[:k]].cpu().numpy().T)
+        if return_outside:
+            return inside, np.ascontiguousarray(rows[:, order[k:]].cpu().numpy().T)
+        return inside
+
+    def posterior_marginal(self, idx_param=0, res=100, smoothing=0, range_min=None, range_max=None):
+        """Marginal density of one parameter on a `res`-point grid: derivative of the linearly interpolated
+        weighted CDF, optionally Gaussian-smoothed (smc.py:672-716).  The cloud is sorted and scanned on
+        the device; only the 2 * res bracketing CDF entries travel to the host."""
+        from scipy.ndimage import gaussian_filter1d
+        self._single_cloud_only("posterior_marginal")
+        eng = self._eng
+        t = eng.torch
+        n = self.n_particles
+        locs, order = t.sort(self._x[idx_param])
+        cdf = eng.cumsum(self._weights()[order].contiguous(), self._norm)
+        r_min = float(locs[0].item()) if range_min is None else range_min
+        r_max = float(locs[-1].item()) if range_max is None else range_max
+        ps = np.linspace(r_min, r_max, res)
+        # piecewise-linear interpolation through (locs, cdf) plus the closing point (r_max + |r_max - r_min|, 1);
+        # zero outside [locs[0], closing point]  (interp1d(..., bounds_error=False, fill_value=0))
+        x_end = r_max + abs(r_max - r_min)
+        hi = t.searchsorted(locs, eng.to_device(ps)).clamp_(1, n)          # bracket [hi - 1, hi] in the extended table
+        lo = hi - 1
+        hi_c = hi.clamp(max=n - 1)
+        x_lo, y_lo = locs[lo].cpu().numpy(), cdf[lo].cpu().numpy()
+        last = (hi == n).cpu().numpy()
+        x_hi = np.where(last, x_end, locs[hi_c].cpu().numpy())
+        y_hi = np.where(last, 1.0, cdf[hi_c].cpu().numpy())
+        with np.errstate(divide='ignore', invalid='ignore'):
+            y = (y_hi - y_lo) / (x_hi - x_lo) * (ps - x_lo) + y_lo
+        y[(ps < float(locs[0].item())) | (ps > x_end)] = 0.0
+        pr = np.gradient(y, ps[1] - ps[0])
+        if smoothing > 0:
+            gaussian_filter1d(pr, res * smoothing / abs(r_max - r_min), output=pr)
+        return ps, pr
 
     # ---------------------------------------------------------------- sampling
     def sample(self, n=1):

@@ -214,6 +214,12 @@ class Engine:
                                                   float(norm), self.stream()), "qsmc_normalize_weights")
         return out
 
+    def weight_entropy(self, w, n, norm):
+        out = C.c_double()
+        self._chk(self.lib.qsmc_weight_entropy(self.h, self._p(w) if w is not None else None, int(n), float(norm),
+                                               C.byref(out), self.stream()), "qsmc_weight_entropy")
+        return out.value
+
     def fill(self, w, value):
         self._chk(self.lib.qsmc_fill(self.h, self._p(w), w.shape[0], float(value), self.stream()),
                   "qsmc_fill")

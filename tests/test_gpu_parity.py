@@ -835,6 +835,92 @@ def test_random_walk_kernel(qi, eng):
         assert np.all(ml.are_models_valid(np.array([[0.3, 0.01], [0.3, -0.01]])) == [True, False])
 
 
+def test_readouts_g11(qi, eng, golden):
+    """est_entropy / est_credible_region / sample / posterior_marginal on the reference's numbers."""
+    g = golden("g11_readouts")
+    w, x = g["w"], g["x"]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        pd = qi.ParticleDistribution(particle_locations=x, particle_weights=w)
+        np.testing.assert_allclose(pd.est_entropy(), g["entropy"], rtol=1e-13)
+        for lvl in (50, 95):
+            inside, outside = pd.est_credible_region(level=lvl / 100, return_outside=True)
+            ref = g["cred_%d_inside" % lvl]
+            # weights are distinct: same particles in the same (descending-weight) order; the device scan may
+            # round the running sum differently at the cut -> at most one particle of difference
+            assert abs(inside.shape[0] - ref.shape[0]) <= 1
+            k = min(inside.shape[0], ref.shape[0])
+            np.testing.assert_array_equal(inside[:k], ref[:k])
+            assert inside.shape[0] + outside.shape[0] == len(w)
+        s0 = pd.est_credible_region(level=0.95, modelparam_slice=slice(0, 1))
+        assert s0.shape[1] == 1 and abs(s0.shape[0] - g["cred_95_slice0"].shape[0]) <= 1
+        np.random.seed(12)
+        np.testing.assert_array_equal(pd.sample(n=64), g["sample"])
+        upd = qi.SMCUpdater(qi.UnknownT2Model(), len(w), fixed_prior(qi, x))
+        upd.particle_weights = w
+        ps, pr = upd.posterior_marginal(idx_param=0, res=60)
+        np.testing.assert_allclose(ps, g["marg0_ps"], rtol=1e-15)
+        # density = d(cdf)/dx on a grid of 60 cells over 5000 particles: cdf rounding 1e-13 / cell width 2e-3
+        np.testing.assert_allclose(pr, g["marg0_pr"], rtol=1e-9, atol=1e-8)
+        ps, pr = upd.posterior_marginal(idx_param=1, res=40, smoothing=0.004, range_min=0.0, range_max=0.1)
+        np.testing.assert_allclose(pr, g["marg1_pr"], rtol=1e-9, atol=1e-8)
+        # uniform (implicit) weights after a reset: entropy log N, any 30 % of the particles is a credible set
+        upd.reset()
+        np.testing.assert_allclose(upd.est_entropy(), np.log(len(w)), rtol=1e-13)
+        assert abs(upd.est_credible_region(level=0.3).shape[0] - 0.3 * len(w)) <= 2
+
+
+def test_perf_test_g12(qi, golden):
+    """perf_test / perf_test_multiple with the ExpSparse heuristic (perf_testing.py:182-384): parity mode
+    reproduces the reference's trial record; device mode runs the same loop at scale."""
+    from functools import partial
+    g = golden("g12_perf_test")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        np.random.seed(6)
+        perf = qi.perf_test(qi.SimplePrecessionModel(), 2000, qi.UniformDistribution([0, 1]), 60, qi.ExpSparseHeuristic)
+        assert list(perf.dtype.names) == list(g["prec_fields"])
+        np.testing.assert_array_equal(perf["outcome"], g["prec_outcome"])
+        np.testing.assert_array_equal(perf["resample_count"], g["prec_resample_count"])
+        np.testing.assert_allclose(perf["true"], g["prec_true"], rtol=0, atol=0)
+        np.testing.assert_allclose(perf["experiment"], g["prec_experiment"], rtol=1e-15)
+        np.testing.assert_allclose(perf["est"], g["prec_est"], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(perf["loss"], g["prec_loss"], rtol=1e-4, atol=1e-16)
+        assert np.all(perf["elapsed_time"] > 0)
+        np.random.seed(7)
+        heur = partial(qi.ExpSparseHeuristic, t_field="t", other_fields={})
+        perf = qi.perf_test(qi.UnknownT2Model(), 3000, qi.UniformDistribution([[0, 1], [0, 0.1]]), 40, heur)
+        assert list(perf.dtype.names) == list(g["t2_fields"])
+        np.testing.assert_array_equal(perf["outcome"], g["t2_outcome"])
+        np.testing.assert_array_equal(perf["resample_count"], g["t2_resample_count"])
+        np.testing.assert_allclose(perf["est"], g["t2_est"], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(perf["t"], g["t2_t"], rtol=1e-15)
+        # several trials, device RNG, more particles; one deliberately failing trial is masked out
+        many = qi.perf_test_multiple(3, qi.SimplePrecessionModel(), 200000, qi.UniformDistribution([0, 1]), 50,
+                                     qi.ExpSparseHeuristic, extra_updater_args=dict(device_rng=True, seed=3))
+        assert many.shape == (3, 50) and np.median(many["loss"][:, -1]) < 1e-4 and np.all(many["resample_count"][:, -1] > 0)
+        calls = {"n": 0}
+
+        class Flaky(qi.ExpSparseHeuristic):
+            def __call__(self):
+                calls["n"] += 1
+                if 25 <= calls["n"] < 30:
+                    raise ZeroDivisionError("synthetic failure")
+                return super().__call__()
+        masked = qi.perf_test_multiple(2, qi.SimplePrecessionModel(), 5000, qi.UniformDistribution([0, 1]), 20,
+                                       Flaky, allow_failures=True)
+        assert masked.mask["loss"][1].all() and not masked.mask["loss"][0].any()
+        # PGH on the inversion model: two posterior draws -> (x_, t)
+        inv = qi.SimpleInversionModel()
+        upd = qi.SMCUpdater(inv, 20000, qi.UniformDistribution([0, 1]), device_rng=True, seed=2)
+        pgh = qi.PGH(upd, inv_field="w_", t_field="t")
+        for _ in range(30):
+            ep = pgh()
+            assert ep.dtype.names == ("t", "w_") and ep["t"][0] > 0 and 0 <= ep["w_"][0] <= 1
+            upd.update(int(inv.simulate_experiment(np.array([[0.62]]), ep)), ep)
+        assert abs(upd.est_mean()[0] - 0.62) < 0.01
+
+
 def test_traj_tomography(qi, golden):
     g = golden("g1_tomography_n300")
     m = qi.TomographyModel(qi.tomography.pauli_basis(2))

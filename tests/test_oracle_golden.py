@@ -223,6 +223,23 @@ def test_g10_random_walk_traj(golden):
     _traj(g, model, lambda k: {"t": g["ep_t"][k:k + 1]}, lambda k: g["ep_t"][k])
 
 
+def test_g11_readouts(golden):
+    g = golden("g11_readouts")
+    w, x = g["w"], g["x"]
+    np.testing.assert_allclose(orc.est_entropy(w), g["entropy"], rtol=1e-14)
+    for lvl in (50, 95):
+        inside, outside = orc.est_credible_region(w, x, level=lvl / 100, return_outside=True)
+        np.testing.assert_array_equal(inside, g["cred_%d_inside" % lvl])
+        assert outside.shape[0] == int(g["cred_%d_n_outside" % lvl])
+    np.testing.assert_array_equal(orc.est_credible_region(w, x, 0.95, modelparam_slice=slice(0, 1)), g["cred_95_slice0"])
+    np.testing.assert_array_equal(orc.sample_cloud(w, x, g["sample_u"]), g["sample"])
+    ps, pr = orc.posterior_marginal(w, x, 0, res=60)
+    np.testing.assert_allclose(ps, g["marg0_ps"], rtol=1e-15)
+    np.testing.assert_allclose(pr, g["marg0_pr"], rtol=1e-12, atol=1e-12)
+    ps, pr = orc.posterior_marginal(w, x, 1, res=40, smoothing=0.004, range_min=0.0, range_max=0.1)
+    np.testing.assert_allclose(pr, g["marg1_pr"], rtol=1e-12, atol=1e-12)
+
+
 def test_g1_tomography(golden):
     g = golden("g1_tomography_n300")
     basis = orc.pauli_data(2)

@@ -270,6 +270,31 @@ def _check_sharded_updater_variant(comm0, rank, world, tmpdir, variant):
         assert min(s.min() for s in shards) > 0
 
 
+def _check_perf_replicas(comm, rank, world, tmpdir):
+    """perf_test_multiple(comm=...): trials are replicas -- dealt round-robin to the ranks, no data-path
+    collective, one all-gather of the records at the end; every rank returns the full table."""
+    import warnings
+    import torch
+    import qinfer_amd as qi
+    torch.cuda.set_device(0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        perf = qi.perf_test_multiple(5, qi.SimplePrecessionModel(), 20000, qi.UniformDistribution([0, 1]), 30,
+                                     qi.ExpSparseHeuristic, comm=comm,
+                                     extra_updater_args=dict(device_rng=True, seed=10 + rank))
+    assert perf.shape == (5, 30)
+    assert np.all(perf["elapsed_time"] > 0) and np.all(np.isfinite(perf["est"]))      # every row was filled by someone
+    assert np.all(perf["resample_count"][:, -1] > 0)
+    rows = comm.gather_rows(torch.from_numpy(np.ascontiguousarray(perf["loss"]).ravel()))
+    for r in range(1, world):
+        assert np.array_equal(rows[0], rows[r])
+
+
+@pytest.mark.gpu
+def test_perf_test_replicas_two_ranks_one_gpu(tmp_path):
+    _run("_check_perf_replicas", tmp_path, world=2)
+
+
 @pytest.mark.gpu
 def test_sharded_updater_two_ranks_one_gpu(tmp_path):
     _run("_check_sharded_updater", tmp_path, world=2)
