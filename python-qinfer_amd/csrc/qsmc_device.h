@@ -41,11 +41,51 @@ __host__ __device__ __forceinline__ double two_outcome(double pr0, int64_t outco
     return outcome == 0 ? pr0 : 1.0 - pr0;
 }
 
+// cos(x)^2 for the likelihoods.  The fused update kernel turned out to be VALU-bound, not HBM-bound (its
+// 240 MB working set lives in the 256 MB Infinity Cache: a bare read-read-write kernel over it takes 30 us,
+// the update took 44), and OCML's full-range fp64 cos was most of its ~140 instructions per particle.
+// Only the parity of k = rint(x * 2/pi) matters for the square: cos^2 x = cos^2 r (k even) or sin^2 r
+// (k odd), r = x - k pi/2.  Two fused steps of Cody-Waite give r: fma(-k, PIO2_HI, x) is EXACT while
+// |x| < 2^33 pi/2 (x and k PIO2_HI are both multiples of 2^-52 there and the difference is < 2), then
+// fma(-k, PIO2_LO, r) rounds once; the neglected tail is k * 2^-107 < 2^-74.  fdlibm's __kernel_sin /
+// __kernel_cos minimax polynomials on |r| <= pi/4 (+ 1e-6: k may be off by one at a boundary).
+// |error| <= ~3 ulp(1) on the square -- inside the stated 4-ulp / 1e-15 likelihood tolerance, checked
+// against the reference's own numbers up to t = (9/8)^199 (G2).  Beyond 1e10 rad: the library cos.
+// (out of line on purpose: inlined, the library cos and its Payne-Hanek tables cost the update kernel
+// 14 VGPRs and a wave of occupancy for a path no lane takes below 1e10 rad)
+__host__ __device__ __attribute__((noinline)) double cos_sq_full_range(double x) {
+    const double c = cos(x);
+    return c * c;
+}
+
+__host__ __device__ __forceinline__ double cos_sq(double x) {
+    const double ax = fabs(x);
+    if (!(ax <= 1.0e10)) return cos_sq_full_range(x);      // huge, inf or NaN
+    const double k = rint(ax * 6.36619772367581382433e-01);
+    double r = fma(-k, 1.57079632679489655800e+00, ax);
+    r = fma(-k, 6.12323399573676603587e-17, r);
+    const double z = r * r;
+    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = fma(z, ps, 2.75573137070700676789e-06);
+    ps = fma(z, ps, -1.98412698298579493134e-04);
+    ps = fma(z, ps, 8.33333333332248946124e-03);
+    ps = fma(z, ps, -1.66666666666666324348e-01);
+    const double sn = fma(r * z, ps, r);
+    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma(z, pc, -2.75573143513906633035e-07);
+    pc = fma(z, pc, 2.48015872894767294178e-05);
+    pc = fma(z, pc, -1.38888888888741095749e-03);
+    pc = fma(z, pc, 4.16666666666666019037e-02);
+    const double cs = 1.0 - (0.5 * z - (z * z) * pc);
+    const double kh = 0.5 * k;
+    const double v = (kh != floor(kh)) ? sn : cs;          // k odd: the square is sin^2 r
+    return v * v;
+}
+
 __host__ __device__ __forceinline__ double precession_pr0(double omega, const ExpArgs &e) {
     // test_models.py:134-141: cos(t * dw / 2) ** 2
     const double dw = omega - e.w_;
-    const double c = cos(e.t * dw / 2.0);
-    return c * c;
+    return cos_sq(e.t * dw / 2.0);
 }
 
 template <int KIND> struct Model;
@@ -155,8 +195,7 @@ template <> struct Model<QSMC_MODEL_UNKNOWN_T2> {
     static __host__ __device__ __forceinline__ double lik(const double *p, const ExpArgs &e, int64_t o) {
         // test_models.py:247-257: visibility = exp(-t / T2); pr0 = vis cos^2(w t / 2) + (1 - vis) / 2
         const double vis = exp(-e.t * p[1]);
-        const double c = cos(p[0] * e.t / 2.0);
-        const double pr0 = vis * (c * c) + (1.0 - vis) / 2.0;
+        const double pr0 = vis * cos_sq(p[0] * e.t / 2.0) + (1.0 - vis) / 2.0;
         return two_outcome(pr0, o);
     }
     static __host__ __device__ __forceinline__ bool valid(const double *p, double) {

@@ -270,7 +270,37 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_update_fused(
     constexpr int64_t TILE = (int64_t)QSMC_BLOCK * VEC * UPD_UNROLL;
     UpdAcc<DMOM> acc;
     acc.init();
+    // w / norm as w * (1 / norm): an fp64 division is ~25 VALU instructions per particle in a kernel whose
+    // VALU time matters (see cos_sq); the two differ by at most one rounding of the stored weight
+    const double inv_norm = 1.0 / prev_norm;
     for (int64_t base = (int64_t)blockIdx.x * TILE; base < n; base += (int64_t)gridDim.x * TILE) {
+        if (VEC == 2 && D <= 2 && base + TILE <= n) {
+            // full tile: every load of the tile is issued before the first likelihood is evaluated, so a wave
+            // has UPD_UNROLL x (1 + d) 16-byte loads in flight instead of 1 + d (the guarded path below
+            // serialises load -> compute -> store per sub-tile because of its bounds branches)
+            double2 wi[UPD_UNROLL], xv[UPD_UNROLL][D];
+#pragma unroll
+            for (int u = 0; u < UPD_UNROLL; ++u) {
+                const int64_t i = base + ((int64_t)u * QSMC_BLOCK + threadIdx.x) * 2;
+                if (ONES) { wi[u].x = 1.0; wi[u].y = 1.0; } else wi[u] = *reinterpret_cast<const double2 *>(w_in + i);
+#pragma unroll
+                for (int m = 0; m < D; ++m) xv[u][m] = *reinterpret_cast<const double2 *>(x + m * ldx + i);
+            }
+#pragma unroll
+            for (int u = 0; u < UPD_UNROLL; ++u) {
+                const int64_t i = base + ((int64_t)u * QSMC_BLOCK + threadIdx.x) * 2;
+                double p0[D], p1[D];
+#pragma unroll
+                for (int m = 0; m < D; ++m) { p0[m] = xv[u][m].x; p1[m] = xv[u][m].y; }
+                double2 wo;
+                wo.x = (wi[u].x * inv_norm) * model_lik<KIND, POW>(p0, e, outcome);
+                wo.y = (wi[u].y * inv_norm) * model_lik<KIND, POW>(p1, e, outcome);
+                *reinterpret_cast<double2 *>(w_out + i) = wo;
+                acc.add(wo.x, p0);
+                acc.add(wo.y, p1);
+            }
+            continue;
+        }
 #pragma unroll
         for (int u = 0; u < UPD_UNROLL; ++u) {
             const int64_t i = base + ((int64_t)u * QSMC_BLOCK + threadIdx.x) * VEC;
@@ -288,8 +318,8 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_update_fused(
                         }
                     }
                     double2 wo;
-                    wo.x = (wi.x / prev_norm) * model_lik<KIND, POW>(p0, e, outcome);
-                    wo.y = (wi.y / prev_norm) * model_lik<KIND, POW>(p1, e, outcome);
+                    wo.x = (wi.x * inv_norm) * model_lik<KIND, POW>(p0, e, outcome);
+                    wo.y = (wi.y * inv_norm) * model_lik<KIND, POW>(p1, e, outcome);
                     *reinterpret_cast<double2 *>(w_out + i) = wo;
                     acc.add(wo.x, p0);
                     acc.add(wo.y, p1);
@@ -298,7 +328,7 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_update_fused(
 #pragma unroll
                     for (int m = 0; m < D; ++m)
                         if (m < d) p0[m] = x[m * ldx + i];
-                    const double wo = ((ONES ? 1.0 : w_in[i]) / prev_norm) * model_lik<KIND, POW>(p0, e, outcome);
+                    const double wo = ((ONES ? 1.0 : w_in[i]) * inv_norm) * model_lik<KIND, POW>(p0, e, outcome);
                     w_out[i] = wo;
                     acc.add(wo, p0);
                 }
@@ -308,7 +338,7 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_update_fused(
 #pragma unroll
                     for (int m = 0; m < D; ++m)
                         if (m < d) p0[m] = x[m * ldx + i];
-                    const double wo = ((ONES ? 1.0 : w_in[i]) / prev_norm) * model_lik<KIND, POW>(p0, e, outcome);
+                    const double wo = ((ONES ? 1.0 : w_in[i]) * inv_norm) * model_lik<KIND, POW>(p0, e, outcome);
                     w_out[i] = wo;
                     acc.add(wo, p0);
                 }
@@ -345,13 +375,14 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_update_multi(
 #pragma unroll
     for (int q = 0; q < NS; ++q) s[q] = 0.0;
     double mn = INFINITY;
+    const double inv_norm = 1.0 / prev_norm;
     for (int64_t i = (int64_t)blockIdx.x * QSMC_BLOCK + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * QSMC_BLOCK) {
         double p[D];
 #pragma unroll
         for (int m = 0; m < D; ++m)
             if (m < d) p[m] = x[m * ldx + i];
-        double w = (w_in ? w_in[i] : 1.0) / prev_norm;
+        double w = (w_in ? w_in[i] : 1.0) * inv_norm;
 #pragma unroll
         for (int k = 0; k < MULTI_KMAX; ++k) {
             if (k < ma.k) {

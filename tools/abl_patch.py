@@ -36,10 +36,14 @@ s = rep(s, "    if (failed) atomicAdd(n_failed, failed);\n    __syncthreads();",
 s = rep(s, "    const int64_t i0 = c * SCAN_CHUNK + j0;\n    double v[SCAN_PER_LANE];", "    const int64_t i0 = c * SCAN_CHUNK + j0;\n#if QSMC_ABL == 30\n    const unsigned long long pa = wall_clock64();\n#endif\n    double v[SCAN_PER_LANE];")
 s = rep(s, "        if (lane == QSMC_WAVE - 1) wave_tot[wave] = inc;\n    }\n    __syncthreads();", "        if (lane == QSMC_WAVE - 1) wave_tot[wave] = inc;\n    }\n#if QSMC_ABL == 30\n    const unsigned long long pb = wall_clock64();\n#endif\n    __syncthreads();\n#if QSMC_ABL == 30\n    const unsigned long long pc = wall_clock64();\n#endif")
 s = rep(s, "        store(j, a, prev, j < len);\n        prev = a;\n    }\n}", "        store(j, a, prev, j < len);\n        prev = a;\n    }\n#if QSMC_ABL == 30\n    if (threadIdx.x == 0 && blockIdx.x < 8192) { const unsigned long long pd = wall_clock64(); g_phase[3 * 8192 + blockIdx.x] = pb - pa; g_phase[4 * 8192 + blockIdx.x] = pc - pb; g_phase[5 * 8192 + blockIdx.x] = pd - pc; }\n#endif\n}")
+s = rep(s, "constexpr int UPD_UNROLL = 4;", "#if QSMC_ABL == 40\nconstexpr int UPD_UNROLL = 1;\n#elif QSMC_ABL == 41\nconstexpr int UPD_UNROLL = 2;\n#else\nconstexpr int UPD_UNROLL = 4;\n#endif")
+s = rep(s, "    block_publish<UpdAcc<DMOM>::NS>(acc.s, acc.mn, ro);\n}\n\n// ---------------------------------------------------------------------------------------------\n// K data in ONE pass", "#if QSMC_ABL == 42\n    if (acc.s[0] == 1.2345e-300) block_publish<UpdAcc<DMOM>::NS>(acc.s, acc.mn, ro);\n#else\n    block_publish<UpdAcc<DMOM>::NS>(acc.s, acc.mn, ro);\n#endif\n}\n\n// ---------------------------------------------------------------------------------------------\n// K data in ONE pass")
+s = rep(s, "template <int KIND, bool POW>\n__host__ __device__ __forceinline__ double model_lik(const double *p, const ExpArgs &e, int64_t o) {\n    const double L = Model<KIND>::lik(p, e, o);", "template <int KIND, bool POW>\n__host__ __device__ __forceinline__ double model_lik(const double *p, const ExpArgs &e, int64_t o) {\n#if QSMC_ABL == 43\n    const double L = p[0] * 0.5 + 0.25;\n#else\n    const double L = Model<KIND>::lik(p, e, o);\n#endif") if False else s
 # header variant: QSMC_ABL == 20 -> library log / sqrt / sincospi in Box-Muller
 hdr = open(os.path.join(root, 'python-qinfer_amd/csrc/qsmc_device.h')).read()
 hdr = rep(hdr, "        const double r = bm_sqrt(-2.0 * bm_log(1.0 - u0));  // 1 - u0 in [2^-53, 1]\n        double s, c;\n        bm_sincospi(2.0 * u1, s, c);",
  "#if QSMC_ABL == 20\n        const double r = sqrt(-2.0 * log(1.0 - u0));\n        double s, c;\n        sincospi(2.0 * u1, &s, &c);\n#else\n        const double r = bm_sqrt(-2.0 * bm_log(1.0 - u0));\n        double s, c;\n        bm_sincospi(2.0 * u1, s, c);\n#endif")
+hdr = rep(hdr, "template <int KIND, bool POW>\n__host__ __device__ __forceinline__ double model_lik(const double *p, const ExpArgs &e, int64_t o) {\n    const double L = Model<KIND>::lik(p, e, o);", "template <int KIND, bool POW>\n__host__ __device__ __forceinline__ double model_lik(const double *p, const ExpArgs &e, int64_t o) {\n#if QSMC_ABL == 43\n    const double L = p[0] * 0.5 + 0.25;\n#else\n    const double L = Model<KIND>::lik(p, e, o);\n#endif")
 tmph = os.path.join(root, 'python-qinfer_amd/csrc/_abl_dev.h')
 open(tmph, 'w').write(hdr)
 s = rep(s, '#include "qsmc_device.h"', '#include "_abl_dev.h"')
