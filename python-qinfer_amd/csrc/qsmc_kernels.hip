@@ -180,14 +180,29 @@ struct ReduceOut {
 
 template <int NS>
 __device__ __forceinline__ void block_publish(double (&v)[NS], double mn, const ReduceOut &ro) {
-    __shared__ double lds[QSMC_WAVES_PER_BLOCK * NS];
-    block_sum<NS>(v, lds);
-    mn = block_min(mn, lds);
-    if (threadIdx.x == 0) {
-        double *p = ro.partials + (size_t)blockIdx.x * (NS + 1);
+    // one barrier: every wave reduces its NS sums and the minimum, lane 0 parks them in LDS, then thread k
+    // combines value k over the waves (in wave order, as before: bitwise the same totals) and stores it --
+    // NS + 1 parallel stores instead of one thread doing them in sequence behind three more barriers
+    __shared__ double lds[QSMC_WAVES_PER_BLOCK * (NS + 1)];
+    const int lane = threadIdx.x & (QSMC_WAVE - 1);
+    const int wave = threadIdx.x / QSMC_WAVE;
 #pragma unroll
-        for (int k = 0; k < NS; ++k) p[k] = v[k];
-        p[NS] = mn;
+    for (int k = 0; k < NS; ++k) v[k] = wave_sum(v[k]);
+    mn = wave_min(mn);
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) lds[wave * (NS + 1) + k] = v[k];
+        lds[wave * (NS + 1) + NS] = mn;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k <= NS; k += QSMC_BLOCK) {
+        double s = lds[k];
+#pragma unroll
+        for (int wv = 1; wv < QSMC_WAVES_PER_BLOCK; ++wv) {
+            const double t = lds[wv * (NS + 1) + k];
+            s = (k < NS) ? s + t : fmin(s, t);
+        }
+        ro.partials[(size_t)blockIdx.x * (NS + 1) + k] = s;
     }
 }
 
