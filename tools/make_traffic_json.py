@@ -23,11 +23,11 @@ for k in sorted(fetch):
     n, f = fetch[k]
     w = write.get(k, (0, 0.0))[1]
     allk[k] = {"calls": n, "FETCH_SIZE_KB_avg": f, "WRITE_SIZE_KB_avg": w, "hbm_bytes_corrected": (2 * f + w) * 1024}
-upd = next(v for k, v in allk.items() if "k_update_fused<1, 2, false>" in k)
-ones = next((v for k, v in allk.items() if "k_update_fused<1, 2, true>" in k), None)
+upd = next(v for k, v in allk.items() if "k_update_fused<1, 2, false" in k)
+ones = next((v for k, v in allk.items() if "k_update_fused<1, 2, true" in k), None)
 print(json.dumps({
     "update_kernel_bytes_per_launch": upd["hbm_bytes_corrected"],
-    "kernel": "k_update_fused<PRECESSION,2,false> (24 B/particle variant)",
+    "kernel": "k_update_fused<PRECESSION,2,false,false> (24 B/particle variant)",
     "n_particles": 10000000,
     "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes (+ --kernel-trace only) over "
               "`bench.py --steps 40 --warmup 5 --no-cpu-baseline` (tools/refresh_profiles.sh); per-launch averages; "
