@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-particles", type=float, default=2e6)
     ap.add_argument("--cpu-data", type=int, default=120)
+    ap.add_argument("--event-stride", type=int, default=4,
+                    help="put hipEvents on every N-th launch of each timed kernel kind (1 = all)")
     ap.add_argument("--force-comm", action="store_true",
                     help="run the sharded code path even with one rank (validation on a 1-GPU box)")
     args = ap.parse_args()
@@ -126,17 +128,15 @@ def main():
             upd.update(int(outcomes[k % N_SCHEDULE]), ts[k % N_SCHEDULE:k % N_SCHEDULE + 1])
         upd.reset()
         upd._resample_count = 0
-        eng.set_profiling(True)
-        kernel_bytes = []
+        # a launch that carries start/stop events drains the queue around itself (measured: 10.7 us per step
+        # with every launch timed), so every EVENT_STRIDE-th launch of each kernel kind is timed
+        eng.set_profiling(0 if os.environ.get("QSMC_BENCH_NO_EVENTS") else args.event_stride)
         barrier()
         t0 = time.perf_counter()
         for i in range(args.steps):
             k = i % N_SCHEDULE
             if i and k == 0:
                 upd.reset()
-            # the first update after a reset/resample consumes implicit uniform weights: no w read
-            # (this rank's shard size floats by ~1e-3 relative under local placement; n is exact at N = 1)
-            kernel_bytes.append((16 if upd._w is None else BYTES_PER_PARTICLE_UPDATE) * upd.n_particles)
             upd.update(int(outcomes[k]), ts[k:k + 1])
         barrier()
         wall = time.perf_counter() - t0
@@ -144,8 +144,9 @@ def main():
         # launch stream); their durations are read here, once, not per step
         all_ms, tags = eng.profile_read()
         eng.set_profiling(False)
-        kernel_ms, sampler_ms = all_ms[tags == 0], all_ms[tags == 1]
-        assert len(kernel_ms) == args.steps, (len(kernel_ms), args.steps)
+        # tag 0: update with explicit weights (24 B/particle), 2: first update after a reset/resample, weights
+        # implicit (16 B/particle), 1: the resampler's sampling kernel
+        full_ms, ones_ms, sampler_ms = all_ms[tags == 0], all_ms[tags == 2], all_ms[tags == 1]
 
     wall_t = torch.tensor([wall], dtype=torch.float64, device="cuda")
     if world > 1:
@@ -162,18 +163,21 @@ def main():
     os.dup2(saved, 1)
     os.close(saved)
 
+    if rank == 0 and os.environ.get("QSMC_BENCH_NO_EVENTS"):
+        # diagnostic only (not the bench line): the same loop without the per-kernel events
+        print(json.dumps({"diagnostic": "no kernel events", "ms_per_step": wall / args.steps * 1e3}), flush=True)
+        return
     if rank == 0:
         n_total = n * world
-        kb, km = np.array(kernel_bytes, dtype=np.float64), np.array(kernel_ms, dtype=np.float64)
-        full = kb > 20 * n                                   # the dominant variant: reads x and w, writes w
-        avg_kernel_s = float(km[full].mean()) * 1e-3
-        achieved = float(kb[full].mean()) / avg_kernel_s / 1e9
-        ones = ~full                                         # first update after a resample: w is implicit
+        # (under local placement a rank's shard size floats by ~1e-3 relative; n is exact at N = 1)
+        full_bytes, ones_bytes = float(BYTES_PER_PARTICLE_UPDATE * n), float(16 * n)
+        avg_kernel_s = float(full_ms.mean()) * 1e-3          # the dominant variant: reads x and w, writes w
+        achieved = full_bytes / avg_kernel_s / 1e9
         ones_info = None
-        if ones.any():
-            ones_s = float(km[ones].mean()) * 1e-3
-            ones_info = {"launches": int(ones.sum()), "algorithmic_bytes_per_launch": float(kb[ones].mean()),
-                         "avg_kernel_us": ones_s * 1e6, "achieved": float(kb[ones].mean()) / ones_s / 1e9}
+        if len(ones_ms):
+            ones_s = float(ones_ms.mean()) * 1e-3
+            ones_info = {"timed_launches": int(len(ones_ms)), "algorithmic_bytes_per_launch": ones_bytes,
+                         "avg_kernel_us": ones_s * 1e6, "achieved": ones_bytes / ones_s / 1e9}
         line = {
             "metric": "particle-updates/sec", "value": n_total * args.steps / wall,
             "unit": "particle-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -190,8 +194,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(),
                          "kernel": "k_update_fused<PRECESSION,VEC=2,ONES=false>", "avg_kernel_us": avg_kernel_s * 1e6,
-                         "launches": int(full.sum()),
-                         "algorithmic_bytes_per_launch": float(kb[full].mean()),
+                         "timed_launches": int(len(full_ms)), "event_stride": args.event_stride,
+                         "algorithmic_bytes_per_launch": full_bytes,
                          "implicit_uniform_weight_variant": ones_info},
             "posterior_mean": float(upd.est_mean()[0]),
         }
@@ -199,7 +203,7 @@ def main():
             # the resampler's main kernel, same clock: reads w (8 B), gathers x (8d), writes x' (8d) per particle
             samp_s = float(sampler_ms.mean()) * 1e-3
             samp_bytes = (8 + 16 * 1) * n
-            line["resample_kernel"] = {"kernel": "k_bucket_sample<D=1,512>", "launches": int(len(sampler_ms)),
+            line["resample_kernel"] = {"kernel": "k_bucket_sample<D=1,512>", "timed_launches": int(len(sampler_ms)),
                                        "avg_kernel_us": samp_s * 1e6, "algorithmic_bytes_per_launch": samp_bytes,
                                        "achieved": samp_bytes / samp_s / 1e9, "unit": "GB/s",
                                        "frac": samp_bytes / samp_s / 1e9 / HBM_PEAK_GBS,

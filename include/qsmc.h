@@ -94,12 +94,15 @@ int         qsmc_destroy(qsmc_handle_t h);
  * in a ring (the bucketed sampler's main kernel is timed the same way, tagged QSMC_PROF_SAMPLE);
  * qsmc_profile_read hands back their durations in milliseconds and tags, oldest first, and clears
  * the ring -- one call after the timed region, nothing per step.  qsmc_last_update_kernel_ms waits
- * for and returns the most recent one. */
+ * for and returns the most recent one.
+ * `enabled` = N > 1 times only every N-th launch of each tag: a launch that carries start/stop events
+ * drains the queue around itself (~10 us per step at N = 1 in bench.py), a sampled average does not. */
 int         qsmc_set_profiling(qsmc_handle_t h, int enabled);
 int         qsmc_last_update_kernel_ms(qsmc_handle_t h, float *ms_out);
 int         qsmc_profile_read(qsmc_handle_t h, float *ms_out, int32_t *tags_out, int32_t cap, int32_t *n_out);
-#define QSMC_PROF_UPDATE 0      /* k_update_fused */
+#define QSMC_PROF_UPDATE 0      /* k_update_fused, explicit weights (24 B/particle at d = 1) */
 #define QSMC_PROF_SAMPLE 1      /* k_bucket_sample (the resampler's dominant kernel) */
+#define QSMC_PROF_UPDATE_ONES 2 /* k_update_fused, implicit all-ones weights (16 B/particle at d = 1) */
 
 /* ---- likelihood, contract form (abstract_model.py:444-468 + :666-686; a6-a10) ------------ */
 /* L_out[(o * n_e + e) * n + i] = Pr(outcomes[o] | x_i ; exps[e]).  This is the

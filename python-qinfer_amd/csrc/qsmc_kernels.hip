@@ -59,6 +59,8 @@ struct qsmc_ctx {
     hipEvent_t *prof_ev;   // QSMC_PROF_CAP (start, stop) pairs, created on first qsmc_set_profiling(1)
     int prof_n;            // profiled launches since the last qsmc_profile_read / set_profiling
     unsigned char *prof_tag;   // which kernel each ring entry timed (QSMC_PROF_*)
+    int prof_stride;           // time every prof_stride-th launch of a tag (events cost ~10 us of queue drain each)
+    unsigned prof_seen[4];     // launches seen per tag
     char hip_err[256];
 };
 
@@ -1689,6 +1691,7 @@ static int collect_stats(qsmc_ctx *h, int ns, qsmc_update_stats_t *stats_host, d
 // Next (start, stop) event pair of the profiling ring, or (null, null) when profiling is off.
 static void prof_events(qsmc_ctx *h, int tag, hipEvent_t *e0, hipEvent_t *e1) {
     if (!h->profiling || !h->prof_ev) return;
+    if (h->prof_seen[tag & 3]++ % (unsigned)h->prof_stride != 0) return;
     const int slot = h->prof_n % QSMC_PROF_CAP;         // a ring: beyond the capacity the oldest are overwritten
     *e0 = h->prof_ev[2 * slot];
     *e1 = h->prof_ev[2 * slot + 1];
@@ -1703,7 +1706,7 @@ static void launch_update(qsmc_ctx *h, bool vec2, int grid, hipStream_t s, const
     // In profiling mode the launch carries start/stop events, so the elapsed time is the kernel's
     // own execution (what rocprofv3 --kernel-trace reports), not launch latency.
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    prof_events(h, QSMC_PROF_UPDATE, &e0, &e1);
+    prof_events(h, w_in ? QSMC_PROF_UPDATE : QSMC_PROF_UPDATE_ONES, &e0, &e1);
 #define LU(V, O)                                                                                          \
     do {                                                                                                  \
         if (e.lik_pow != 0.0)                                                                             \
@@ -1876,7 +1879,9 @@ int qsmc_set_profiling(qsmc_handle_t h, int enabled) {
         if (!h->prof_tag) return QSMC_ERR_ALLOC;
     }
     h->profiling = enabled ? 1 : 0;
+    h->prof_stride = enabled > 1 ? enabled : 1;
     h->prof_n = 0;
+    memset(h->prof_seen, 0, sizeof(h->prof_seen));
     return QSMC_OK;
 }
 
@@ -1884,7 +1889,7 @@ int qsmc_last_update_kernel_ms(qsmc_handle_t h, float *ms_out) {
     if (!h || !ms_out || !h->prof_ev || h->prof_n < 1) return QSMC_ERR_INVALID;
     int slot = -1;
     for (int i = h->prof_n - 1; i >= 0 && i > h->prof_n - 1 - QSMC_PROF_CAP; --i)
-        if (h->prof_tag[i % QSMC_PROF_CAP] == QSMC_PROF_UPDATE) { slot = i % QSMC_PROF_CAP; break; }
+        if (h->prof_tag[i % QSMC_PROF_CAP] != QSMC_PROF_SAMPLE) { slot = i % QSMC_PROF_CAP; break; }
     if (slot < 0) return QSMC_ERR_INVALID;
     HIP_TRY(h, hipEventSynchronize(h->prof_ev[2 * slot + 1]));
     HIP_TRY(h, hipEventElapsedTime(ms_out, h->prof_ev[2 * slot], h->prof_ev[2 * slot + 1]));

@@ -97,11 +97,13 @@ class Engine:
 
     # ------------------------------------------------------------------ profiling hooks (bench.py)
     def set_profiling(self, enabled):
-        self._chk(self.lib.qsmc_set_profiling(self.h, int(bool(enabled))), "qsmc_set_profiling")
+        """False/0: off; True/1: time every update / sampler launch; N > 1: every N-th launch of each kind."""
+        self._chk(self.lib.qsmc_set_profiling(self.h, int(enabled)), "qsmc_set_profiling")
 
     def profile_read(self, cap=4096):
         """(durations in ms, tags) of the timed kernels launched since profiling was enabled / last read,
-        oldest first.  tag 0 = update kernel, 1 = the resampler's sampling kernel."""
+        oldest first.  tag 0 = update kernel (explicit weights), 2 = update kernel (implicit weights),
+        1 = the resampler's sampling kernel."""
         buf = (C.c_float * cap)()
         tags = (C.c_int32 * cap)()
         n = C.c_int32()
