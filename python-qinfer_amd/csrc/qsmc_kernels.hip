@@ -1057,12 +1057,12 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_resample_philox(
 //                        Multinomial(N; W_chunk) counts, via per-workgroup LDS histograms;
 //   B  k_bucket_reduce / k_bucket_plan   column sums + exclusive scans: first output slot of each
 //                        chunk and a work list that splits heavy chunks into <= BUCKET_CAP outputs;
-//   C  k_bucket_sample   one workgroup per work item stages ITS chunk of the CDF in LDS (32 KB),
+//   C  k_bucket_sample   one workgroup per work item scans ITS chunk of the weights into LDS (32 KB of CDF),
 //                        draws the within-chunk position from an independent Philox word (given
 //                        the counts, positions are i.i.d. uniform inside the chunk -- exact),
 //                        searches in LDS, gathers x from the chunk's 32 KB window, kicks, checks
 //                        validity and writes its outputs to consecutive slots.
-// HBM traffic becomes streaming (read cdf + x once, write x' once); all scattered probes hit LDS.
+// HBM traffic becomes streaming (read w + x once, write x' once); all scattered probes hit LDS.
 // A postselection retry needs a fresh GLOBAL ancestor: that rare path falls back to the global
 // search (same semantics as k_resample_philox: redraw ancestor and kick).
 // =============================================================================================
@@ -1105,12 +1105,13 @@ __device__ __forceinline__ int upper_bound_skew(const double *a, int m, double u
 }
 
 // ---------------------------------------------------------------------------------------------
-// Guide table: a 12-probe binary search of a 4096-entry LDS table costs ~12 instructions per probe
-// (~40 % of the sample kernel's VALU work).  A uniform grid of GUIDE_BINS cells over the table's
-// value range, G[k] = #{entries whose cell < k}, brackets the answer for a query in cell k inside
-// [G[k-1], G[k+2]] (one cell of slack absorbs the rounding of the cell computation), typically 2-4
-// entries -> 1-2 probes.  Built per workgroup by an LDS histogram + scan; exactness is unaffected:
-// the final answer always comes from comparing the entries themselves with u.
+// Guide table: a 12-probe binary search of a 4096-entry LDS table costs ~12 instructions per probe.
+// A uniform grid of cells over the table's value range, G[k] = #{entries whose cell < k}, brackets the
+// answer for a query in cell k inside [G[k], G[k+1]] -- exactly, because guide_cell() is monotone and is
+// applied identically to the entries and to the query -- typically 1-2 entries -> ~1 probe.
+// k_bucket_count builds its table (cells over the chunk edges) with an LDS histogram + scan
+// (build_guide); k_bucket_sample fills its table while it stores the scanned CDF (StoreLdsGuide).
+// Exactness is unaffected either way: the answer always comes from comparing the entries with u.
 // ---------------------------------------------------------------------------------------------
 constexpr int GUIDE_BINS = 4096;              // k_bucket_count: cells over [0, 1) for the chunk edges
 constexpr int SGUIDE_BINS = 2048;             // k_bucket_sample: cells over one chunk's 4096 CDF entries
@@ -1366,7 +1367,7 @@ __attribute__((amdgpu_waves_per_eu(D >= 1 && D <= 2 ? 6 : 1, 8)))
 __global__ __launch_bounds__(BT) void k_bucket_sample(
     int kind, int d_rt, double min_freq, int postselect, const double *__restrict__ x_in, int64_t ldx_in,
     int64_t n_in, const double *__restrict__ w, double inv_norm, const double *__restrict__ offsets,
-    const double *__restrict__ cdf, int chunks, const long long *__restrict__ slot_off,
+    int chunks, const long long *__restrict__ slot_off,
     const int *__restrict__ item_off, const int *__restrict__ item_chunk, LWArgs lw, uint32_t k0, uint32_t k1,
     uint32_t epoch, int maxiter, double *__restrict__ x_out, OutPlace pl,
     unsigned long long *__restrict__ n_failed, unsigned int *__restrict__ retry_list,
@@ -2437,7 +2438,7 @@ static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int3
 #define LAUNCH_B(DD, BT)                                                                                       \
     hipExtLaunchKernelGGL((k_bucket_sample<DD, BT>), dim3(bp.max_items), dim3(BT), 0, s, pe0, pe1, 0, model->kind, d, \
                        model->min_freq, postselect, x_in, ldx_in, n_in, w, inv_norm, offsets,                       \
-                       (const double *)nullptr, chunks, bp.slot_off, bp.item_off, bp.item_chunk, lw, k0, k1, ep,     \
+                       chunks, bp.slot_off, bp.item_off, bp.item_chunk, lw, k0, k1, ep,                             \
                        maxiter, x_out, pl, nf, bp.retry_list, retry_count)
         switch (d) {
             case 1: LAUNCH_B(1, 512); break;
