@@ -104,12 +104,12 @@ template <> struct Model<QSMC_MODEL_PRECESSION> {
 __host__ __device__ __forceinline__ double binom_pmf(double pr1, const ExpArgs &e, int64_t o) {
     const double k = (double)o;
     if (o < 0 || k > e.n_meas) return 0.0;
-    if (isfinite(e.comb))
-        return e.comb * pow(pr1, k) * pow(1.0 - pr1, e.n_meas - k);
-    // huge n_meas: C(n,k) overflows float64 -> log space
-    const double lp = (k > 0.0 ? k * log(pr1) : 0.0) +
-                      (e.n_meas - k > 0.0 ? (e.n_meas - k) * log1p(-pr1) : 0.0);
-    return exp(e.log_comb + lp);
+    // C(n,k) p^k (1-p)^(n-k) as C * exp(k ln p + (n-k) ln(1-p)): two logarithms and one exponential instead of
+    // two fp64 pow() (each a log + an exp in extended precision, ~150 instructions; the binomial update kernel
+    // was 4x the precession one).  Relative error ~ (k + n - k) eps |ln| ~ 1e-14 at n_meas = 25, inside the 1e-12
+    // the closed form is held to against SciPy's pmf (G2, G8).  0 * ln 0 never forms: a zero exponent drops its term.
+    const double lp = (k > 0.0 ? k * log(pr1) : 0.0) + (e.n_meas - k > 0.0 ? (e.n_meas - k) * log1p(-pr1) : 0.0);
+    return isfinite(e.comb) ? e.comb * exp(lp) : exp(e.log_comb + lp);      // huge n_meas: C(n,k) itself in log space
 }
 
 template <> struct Model<QSMC_MODEL_BINOMIAL_PRECESSION> {
