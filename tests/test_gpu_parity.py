@@ -921,6 +921,25 @@ def test_perf_test_g12(qi, golden):
         assert abs(upd.est_mean()[0] - 0.62) < 0.01
 
 
+def test_readme_quick_start(qi):
+    """The README's snippet, at a smaller N."""
+    model = qi.SimplePrecessionModel()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        updater = qi.SMCUpdater(model, 200000, qi.UniformDistribution([0, 1]), device_rng=True, seed=0)
+        heuristic = qi.ExpSparseHeuristic(updater)
+        true = np.array([[0.3]])
+        np.random.seed(0)
+        for _ in range(60):
+            ep = heuristic()
+            updater.update(model.simulate_experiment(true, ep), ep)
+        assert abs(updater.est_mean()[0] - 0.3) < 5e-3 and updater.resample_count > 0
+        ts = np.linspace(1.0, 60.0, 40)
+        table = np.column_stack([np.random.binomial(30, np.sin(0.31 * ts / 2) ** 2), ts, np.full(40, 30)]).astype(float)
+        mean, var = qi.simple_est_prec(table, n_particles=100000, device_rng=True)
+        assert abs(mean - 0.31) < 4 * np.sqrt(var) + 1e-3
+
+
 def test_traj_tomography(qi, golden):
     g = golden("g1_tomography_n300")
     m = qi.TomographyModel(qi.tomography.pauli_basis(2))
