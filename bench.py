@@ -95,7 +95,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
+    # validation hook for a 1-GPU box: QSMC_BENCH_SHARE_GPU=1 puts every rank on device 0 and talks over gloo, so
+    # that the multi-rank control flow of this file can be exercised without N GPUs (not a measurement mode)
+    share_gpu = os.environ.get("QSMC_BENCH_SHARE_GPU") == "1"
+    device_index = 0 if share_gpu else local_rank
+    torch.cuda.set_device(device_index)
     comm = None
     if world > 1 or args.force_comm:
         import torch.distributed as dist
@@ -104,7 +108,10 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
         from qinfer_amd.parallel import ParticleShardGroup
         comm = ParticleShardGroup()
 
@@ -148,7 +155,9 @@ def main():
         # implicit (16 B/particle), 1: the resampler's sampling kernel
         full_ms, ones_ms, sampler_ms = all_ms[tags == 0], all_ms[tags == 2], all_ms[tags == 1]
 
-    wall_t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+    # collective in sharded mode (the moments are all-gathered if the last step resampled): every rank calls it
+    posterior_mean = float(upd.est_mean()[0])
+    wall_t = torch.tensor([wall], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
     if world > 1:
         torch.distributed.all_reduce(wall_t, op=torch.distributed.ReduceOp.MAX)
     wall = float(wall_t.item())
@@ -197,7 +206,7 @@ def main():
                          "timed_launches": int(len(full_ms)), "event_stride": args.event_stride,
                          "algorithmic_bytes_per_launch": full_bytes,
                          "implicit_uniform_weight_variant": ones_info},
-            "posterior_mean": float(upd.est_mean()[0]),
+            "posterior_mean": posterior_mean,
         }
         if len(sampler_ms):
             # the resampler's main kernel, same clock: reads w (8 B), gathers x (8d), writes x' (8d) per particle
