@@ -246,8 +246,12 @@ class ParticleDistribution(Distribution):
         return self._ess_from(self._sumsq)
 
     def _ess_from(self, sumsq_unnormalised):
-        with np.errstate(divide='ignore'):
-            return np.float64(self._norm) * np.float64(self._norm) / np.float64(sumsq_unnormalised)
+        # (plain floats: this sits on the per-datum path; an np.errstate block costs a microsecond)
+        s = float(sumsq_unnormalised)
+        n2 = float(self._norm) * float(self._norm)
+        if s == 0.0:
+            return np.float64(np.inf if n2 > 0 else np.nan)
+        return np.float64(n2 / s)
 
     # ---------------------------------------------------------------- moments
     def _moments(self):

@@ -76,6 +76,8 @@ class SimplePrecessionModel(SimpleInversionModel):
         return 'float'
 
     def _native_expparams(self, expparams):
+        if type(expparams) is np.ndarray and expparams.shape == (1,) and expparams.dtype.names is None:
+            return [_native.make_expparam(t=expparams[0], w_=0.0)]       # the per-datum path of update()
         expparams = np.atleast_1d(expparams)
         ts = expparams['t'] if expparams.dtype.names else expparams
         return [_native.make_expparam(t=t, w_=0.0) for t in np.atleast_1d(ts).astype(np.float64).ravel()]

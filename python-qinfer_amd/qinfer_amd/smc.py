@@ -30,6 +30,8 @@ _EPS = float(np.spacing(1))
 
 
 def _as_int_outcome(outcome):
+    if type(outcome) is int:
+        return outcome
     arr = np.asarray(outcome)
     if arr.size != 1:
         raise ValueError("update() takes a single outcome; use batch_update for several")
@@ -348,7 +350,7 @@ class SMCUpdater(ParticleDistribution):
         if ess <= self._min_n_ess:
             self._min_n_ess = ess
         if check_for_resample:
-            self._maybe_resample()
+            self._maybe_resample(ess)
 
     def batch_update(self, outcomes, expparams, resample_interval=5):
         """Update on a batch of data with the ESS test every `resample_interval` data
@@ -494,8 +496,8 @@ class SMCUpdater(ParticleDistribution):
         return self.bayes_risk(np.array([(x0,)], dtype=self.model.expparams_dtype))
 
     # ------------------------------------------------------------------ resampling
-    def _maybe_resample(self):
-        ess = self.n_ess
+    def _maybe_resample(self, ess=None):
+        ess = self.n_ess if ess is None else ess
         if ess <= 10:
             warnings.warn("Extremely small n_ess encountered ({}). Resampling is likely to fail. "
                           "Consider adding particles, or resampling more often.".format(ess),
