@@ -549,4 +549,52 @@ __host__ __device__ inline bool tomo_canon_particle(const double *__restrict__ b
     return any_neg || !allow_subnormalized;
 }
 
+// Cheap sufficient test for "rho is positive definite": the LDL^H factorisation of the Hermitian rho
+// (built from p as in tomo_canon_particle) has only positive pivots.  Used to sort a cloud into the
+// particles canonicalize leaves alone (apart from the trace renormalisation) and the ones that need the
+// eigendecomposition; anything not clearly positive definite (a zero or negative pivot) goes to the latter.
+template <int DIM>
+__host__ __device__ inline bool tomo_clearly_positive(const double *__restrict__ basis, const double *p) {
+    constexpr int D = DIM * DIM;
+    double Ar[DIM][DIM], Ai[DIM][DIM];
+#pragma unroll
+    for (int r = 0; r < DIM; ++r)
+#pragma unroll
+        for (int c = 0; c <= r; ++c) {                    // lower triangle is enough
+            double sr = 0.0, si = 0.0;
+            for (int a = 0; a < D; ++a) {
+                sr += p[a] * basis[2 * ((a * DIM + r) * DIM + c)];
+                si += p[a] * basis[2 * ((a * DIM + r) * DIM + c) + 1];
+            }
+            Ar[r][c] = sr;
+            Ai[r][c] = si;
+        }
+    // in place: A[j][j] <- d_j, A[i][j] <- l_ij (i > j)
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) {
+        double dj = Ar[j][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) dj -= (Ar[j][k] * Ar[j][k] + Ai[j][k] * Ai[j][k]) * Ar[k][k];
+        ok = ok && (dj > 0.0);
+        Ar[j][j] = dj;
+        const double inv = 1.0 / dj;                     // (garbage if !ok: the verdict is already false)
+#pragma unroll
+        for (int i = j + 1; i < DIM; ++i) {
+            double sr = Ar[i][j], si = Ai[i][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) {
+                // l_ik * conj(l_jk) * d_k
+                const double tr = Ar[i][k] * Ar[j][k] + Ai[i][k] * Ai[j][k];
+                const double ti = Ai[i][k] * Ar[j][k] - Ar[i][k] * Ai[j][k];
+                sr -= tr * Ar[k][k];
+                si -= ti * Ar[k][k];
+            }
+            Ar[i][j] = sr * inv;
+            Ai[i][j] = si * inv;
+        }
+    }
+    return ok;
+}
+
 }  // namespace qsmc

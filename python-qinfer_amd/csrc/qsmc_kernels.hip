@@ -1595,6 +1595,66 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_tomo_canon(const double *__restr
     }
 }
 
+// Two passes for dim = 4 (2 qubits): the eigendecomposition is ~6000 flops and 240 VGPRs per particle, but a
+// particle whose rho is positive definite only needs its trace renormalised -- and about two thirds of a
+// freshly resampled cloud are (36 % non-PSD measured after a Liu-West kick).  Deciding per lane inside one
+// kernel would not help (a wave is as slow as its slowest lane), so pass 1 classifies with a pivot test
+// (tomo_clearly_positive), finishes the clear cases and compacts the others into an index list
+// (one atomic per wave); pass 2 runs the Jacobi path on the list only, densely packed.
+template <int DIM>
+__global__ __launch_bounds__(QSMC_BLOCK) void k_tomo_classify(const double *__restrict__ basis,
+                                                              double *__restrict__ x, int64_t ldx, int64_t n,
+                                                              int allow_subnormalized, unsigned int *__restrict__ list,
+                                                              unsigned int *__restrict__ count) {
+    constexpr int D = DIM * DIM;
+    const int lane = threadIdx.x & (QSMC_WAVE - 1);
+    for (int64_t i0 = (int64_t)blockIdx.x * QSMC_BLOCK; i0 < n; i0 += (int64_t)gridDim.x * QSMC_BLOCK) {
+        const int64_t i = i0 + threadIdx.x;
+        bool hard = false;
+        if (i < n) {
+            double p[D];
+#pragma unroll
+            for (int a = 0; a < D; ++a) p[a] = x[a * ldx + i];
+            if (tomo_clearly_positive<DIM>(basis, p)) {
+                if (!allow_subnormalized) {                   // tomography/models.py:194-209
+                    const double nrm = p[0] * sqrt((double)DIM);
+#pragma unroll
+                    for (int a = 0; a < D; ++a) x[a * ldx + i] = p[a] / nrm;
+                }
+            } else {
+                hard = true;
+            }
+        }
+        const unsigned long long m = __ballot(hard);
+        if (m) {
+            unsigned int base = 0;
+            if (lane == 0) base = atomicAdd(count, (unsigned int)__popcll(m));
+            base = __shfl(base, 0, QSMC_WAVE);
+            if (hard) list[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned int)i;
+        }
+    }
+}
+
+template <int DIM>
+__global__ __launch_bounds__(QSMC_BLOCK) void k_tomo_canon_list(const double *__restrict__ basis,
+                                                                double *__restrict__ x, int64_t ldx,
+                                                                int allow_subnormalized,
+                                                                const unsigned int *__restrict__ list,
+                                                                const unsigned int *__restrict__ count) {
+    constexpr int D = DIM * DIM;
+    const unsigned int m = *count;
+    for (unsigned int t = blockIdx.x * QSMC_BLOCK + threadIdx.x; t < m; t += gridDim.x * QSMC_BLOCK) {
+        const int64_t i = list[t];
+        double p[D];
+#pragma unroll
+        for (int a = 0; a < D; ++a) p[a] = x[a * ldx + i];
+        if (tomo_canon_particle<DIM>(basis, p, allow_subnormalized != 0)) {
+#pragma unroll
+            for (int a = 0; a < D; ++a) x[a * ldx + i] = p[a];
+        }
+    }
+}
+
 // =============================================================================================
 // host-side helpers
 // =============================================================================================
@@ -2610,10 +2670,19 @@ int qsmc_tomo_canonicalize(qsmc_handle_t h, const double *basis, int32_t dim, do
             break;
         case 3:
             return QSMC_ERR_UNSUPPORTED;   // d = 9 fits QSMC_MAX_D but no config needs it yet
-        case 4:
-            hipLaunchKernelGGL((k_tomo_canon<4>), dim3(grid), dim3(QSMC_BLOCK), 0, s, basis, x, ldx, n,
-                               allow_subnormalized);
+        case 4: {
+            if (n >= (1ll << 32)) return QSMC_ERR_UNSUPPORTED;
+            int rc = ensure_iscratch(h, ((size_t)n + 4) * sizeof(unsigned int));
+            if (rc) return rc;
+            unsigned int *count = h->iscratch;              // [0] = list length; the list starts at [4]
+            unsigned int *list = h->iscratch + 4;
+            HIP_TRY(h, hipMemsetAsync(count, 0, sizeof(unsigned int), s));
+            hipLaunchKernelGGL((k_tomo_classify<4>), dim3(grid), dim3(QSMC_BLOCK), 0, s, basis, x, ldx, n,
+                               allow_subnormalized, list, count);
+            hipLaunchKernelGGL((k_tomo_canon_list<4>), dim3(grid), dim3(QSMC_BLOCK), 0, s, basis, x, ldx,
+                               allow_subnormalized, list, count);
             break;
+        }
         default: return QSMC_ERR_UNSUPPORTED;
     }
     HIP_TRY(h, hipGetLastError());
