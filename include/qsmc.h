@@ -244,6 +244,16 @@ int qsmc_lw_resample_philox(qsmc_handle_t h, const qsmc_model_t *model, int32_t 
                             double *x_out, int64_t ldx_out, int64_t *n_failed_host,
                             qsmc_stream_t stream);
 
+/* Every qsmc_update_fused also leaves the sum of the new weights per kernel tile (2048 particles) in the
+ * handle and bumps a generation counter (qsmc_update_token).  A caller that KNOWS the weights it is about
+ * to resample are exactly the w_out of the update with that token -- untouched since -- may say so with
+ * qsmc_lw_use_update_sums(token) right before qsmc_lw_resample_prepare / qsmc_lw_resample_philox: the
+ * resampler then forms its chunk sums from those tile sums instead of reading the weights once more
+ * (one 8 B/particle pass saved).  A stale or wrong token is ignored; any call that rewrites weights
+ * invalidates the sums.  Chunk edges then differ from the plain path by rounding only (same law). */
+int qsmc_update_token(qsmc_handle_t h, uint64_t *token_out);
+int qsmc_lw_use_update_sums(qsmc_handle_t h, uint64_t update_token);
+
 /* Queue the weight-only prefix of the NEXT qsmc_lw_resample_philox call (chunk sums, offsets, and for
  * the bucketed sampler the multinomial chunk counts and work-item plan): none of it needs the mean or
  * the covariance square root, so a caller can launch it the moment its n_ess test fails

@@ -43,6 +43,15 @@ struct qsmc_ctx {
     unsigned long long seq;        // last sequence number handed to a reducing launch
     double *rs_offsets;            // resampler: chunk offsets (own buffer: survives other calls' scratch use)
     size_t rs_offsets_cap;
+    double *tile_sums;             // sum of w' per update-kernel tile, written by the last qsmc_update_fused
+    size_t tile_sums_cap;
+    struct {
+        unsigned long long gen;    // counts qsmc_update_fused calls; the caller mirrors it as a token
+        const double *w;           // the w_out those sums describe
+        int64_t n;
+        int tile;                  // particles per tile
+        unsigned long long armed;  // token handed in by qsmc_lw_use_update_sums for the next resample (0 = none)
+    } ts;
     struct {                       // weight-only prefix of a resample already queued (qsmc_lw_resample_prepare)
         int valid;
         const double *w;
@@ -104,6 +113,16 @@ static int ensure_rs_offsets(qsmc_ctx *h, size_t n) {
     h->rs_offsets_cap = 0;
     HIP_TRY(h, hipMalloc(&h->rs_offsets, n * sizeof(double)));
     h->rs_offsets_cap = n;
+    return QSMC_OK;
+}
+
+static int ensure_tile_sums(qsmc_ctx *h, size_t n) {
+    if (h->tile_sums_cap >= n) return QSMC_OK;
+    if (h->tile_sums) HIP_TRY(h, hipFree(h->tile_sums));
+    h->tile_sums = nullptr;
+    h->tile_sums_cap = 0;
+    HIP_TRY(h, hipMalloc(&h->tile_sums, n * sizeof(double)));
+    h->tile_sums_cap = n;
     return QSMC_OK;
 }
 
@@ -180,6 +199,7 @@ struct ReduceOut {
     unsigned long long seq;    // value to publish there once out_mapped is complete
     const unsigned long long *failed_src;   // the resampler's failed-particle counter (device) ...
     double *failed_dst;                     // ... copied to its pinned slot by every host-visible reduction
+    double *tile_sums;                      // k_update_fused only: sum of w' per TILE particles (nullable)
 };
 
 template <int NS>
@@ -295,7 +315,13 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_update_fused(
     // w / norm as w * (1 / norm): an fp64 division is ~25 VALU instructions per particle in a kernel whose
     // VALU time matters (see cos_sq); the two differ by at most one rounding of the stored weight
     const double inv_norm = 1.0 / prev_norm;
+    // Sum of the new weights per tile, for the resampler: its chunk sums (k_chunk_sums, an 80 MB read) are
+    // sums of two such tiles, so a resample that follows this update starts from them instead of reading
+    // the weights once more.  One wave reduction + barrier per 2048 particles; off when ro.tile_sums is null.
+    __shared__ double ts_lds[2][QSMC_WAVES_PER_BLOCK];
+    int ts_par = 0;
     for (int64_t base = (int64_t)blockIdx.x * TILE; base < n; base += (int64_t)gridDim.x * TILE) {
+        double tsum = 0.0;
         if (VEC == 2 && D <= 2 && base + TILE <= n) {
             // full tile: every load of the tile is issued before the first likelihood is evaluated, so a wave
             // has UPD_UNROLL x (1 + d) 16-byte loads in flight instead of 1 + d (the guarded path below
@@ -320,9 +346,9 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_update_fused(
                 *reinterpret_cast<double2 *>(w_out + i) = wo;
                 acc.add(wo.x, p0);
                 acc.add(wo.y, p1);
+                tsum += wo.x + wo.y;
             }
-            continue;
-        }
+        } else {
 #pragma unroll
         for (int u = 0; u < UPD_UNROLL; ++u) {
             const int64_t i = base + ((int64_t)u * QSMC_BLOCK + threadIdx.x) * VEC;
@@ -345,6 +371,7 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_update_fused(
                     *reinterpret_cast<double2 *>(w_out + i) = wo;
                     acc.add(wo.x, p0);
                     acc.add(wo.y, p1);
+                    tsum += wo.x + wo.y;
                 } else if (i < n) {
                     double p0[D];
 #pragma unroll
@@ -353,6 +380,7 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_update_fused(
                     const double wo = ((ONES ? 1.0 : w_in[i]) * inv_norm) * model_lik<KIND, POW>(p0, e, outcome);
                     w_out[i] = wo;
                     acc.add(wo, p0);
+                    tsum += wo;
                 }
             } else {
                 if (i < n) {
@@ -363,8 +391,22 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_update_fused(
                     const double wo = ((ONES ? 1.0 : w_in[i]) * inv_norm) * model_lik<KIND, POW>(p0, e, outcome);
                     w_out[i] = wo;
                     acc.add(wo, p0);
+                    tsum += wo;
                 }
             }
+        }
+        }
+        if (ro.tile_sums) {                      // uniform
+            const double t = wave_sum(tsum);
+            if ((threadIdx.x & (QSMC_WAVE - 1)) == 0) ts_lds[ts_par][threadIdx.x / QSMC_WAVE] = t;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                double tot = ts_lds[ts_par][0];
+#pragma unroll
+                for (int wv = 1; wv < QSMC_WAVES_PER_BLOCK; ++wv) tot += ts_lds[ts_par][wv];
+                ro.tile_sums[base / TILE] = tot;
+            }
+            ts_par ^= 1;                         // the other bank next time: one barrier per tile suffices
         }
     }
     block_publish<UpdAcc<DMOM>::NS>(acc.s, acc.mn, ro);
@@ -737,8 +779,27 @@ __device__ __forceinline__ double wave_inclusive_max(double v, int lane) {
 constexpr int SCAN_SUMS_THREADS = 1024;
 constexpr int SCAN_SUMS_MAX_PER = 16;              // m <= 16384 chunks (N <= 6.7e7) in registers
 
+// tiles != nullptr: chunk c's sum is (tiles[c tpc] + ... + tiles[c tpc + tpc - 1]) * inv_norm -- the per-tile sums the
+// last update kernel left behind -- instead of sums[c] from k_chunk_sums.
+struct TileSrc {
+    const double *tiles;
+    int tpc;
+    int64_t n_tiles;
+    double inv_norm;
+};
+
+__device__ __forceinline__ double chunk_sum_in(const double *__restrict__ sums, const TileSrc &ts, int64_t c) {
+    if (!ts.tiles) return sums[c];
+    double t = 0.0;
+    for (int j = 0; j < ts.tpc; ++j) {
+        const int64_t k = c * ts.tpc + j;
+        if (k < ts.n_tiles) t += ts.tiles[k];
+    }
+    return t * ts.inv_norm;
+}
+
 __global__ __launch_bounds__(SCAN_SUMS_THREADS) void k_scan_sums(double *__restrict__ sums, int64_t m,
-                                                                 unsigned long long *__restrict__ zero2) {
+                                                                 unsigned long long *__restrict__ zero2, TileSrc ts) {
     __shared__ double wtot[SCAN_SUMS_THREADS / QSMC_WAVE];
     if (zero2 && threadIdx.x < 2) zero2[threadIdx.x] = 0ull;      // the resampler's failed / retry counters (was a memset launch)
     const int lane = threadIdx.x & (QSMC_WAVE - 1);
@@ -749,7 +810,7 @@ __global__ __launch_bounds__(SCAN_SUMS_THREADS) void k_scan_sums(double *__restr
     double run = 0.0;
 #pragma unroll
     for (int q = 0; q < SCAN_SUMS_MAX_PER; ++q) {
-        v[q] = (q < per && i0 + q < m) ? sums[i0 + q] : 0.0;
+        v[q] = (q < per && i0 + q < m) ? chunk_sum_in(sums, ts, i0 + q) : 0.0;
         run += v[q];
     }
     // exclusive offset of this thread's run
@@ -789,7 +850,7 @@ __global__ __launch_bounds__(SCAN_SUMS_THREADS) void k_scan_sums(double *__restr
 
 // Fallback for m > 16384 chunk sums (N > 6.7e7): same contract, 256-wide slabs with a carry.
 __global__ __launch_bounds__(QSMC_BLOCK) void k_scan_sums_big(double *__restrict__ sums, int64_t m,
-                                                              unsigned long long *__restrict__ zero2) {
+                                                              unsigned long long *__restrict__ zero2, TileSrc ts) {
     __shared__ double wave_tot[QSMC_WAVES_PER_BLOCK];
     if (zero2 && threadIdx.x < 2) zero2[threadIdx.x] = 0ull;
     __shared__ double carry_s;
@@ -799,7 +860,7 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_scan_sums_big(double *__restrict
     __syncthreads();
     for (int64_t base = 0; base < m; base += QSMC_BLOCK) {
         const int64_t i = base + threadIdx.x;
-        const double v = i < m ? sums[i] : 0.0;
+        const double v = i < m ? chunk_sum_in(sums, ts, i) : 0.0;
         const double inc = wave_inclusive_scan(v, lane);
         double excl = __shfl_up(inc, 1, QSMC_WAVE);
         if (lane == 0) excl = 0.0;
@@ -1716,6 +1777,7 @@ static ReduceOut make_reduce(qsmc_ctx *h, bool want_host, double *stats4) {
     ro.seq = want_host ? ++h->seq : 0ull;
     ro.failed_src = reinterpret_cast<const unsigned long long *>(h->counter);
     ro.failed_dst = want_host ? h->mapped_dev + (REDUCE_OUT_MAX - 1) : nullptr;
+    ro.tile_sums = nullptr;
     return ro;
 }
 
@@ -1936,6 +1998,7 @@ int qsmc_destroy(qsmc_handle_t h) {
     if (!h) return QSMC_OK;
     if (h->partials) (void)hipFree(h->partials);
     if (h->rs_offsets) (void)hipFree(h->rs_offsets);
+    if (h->tile_sums) (void)hipFree(h->tile_sums);
     if (h->scratch) (void)hipFree(h->scratch);
     if (h->pinned) (void)hipHostFree(h->pinned);
     if (h->counter) (void)hipFree(h->counter);
@@ -2048,7 +2111,7 @@ int qsmc_update_fused(qsmc_handle_t h, const qsmc_model_t *model, const double *
                       const double *w_in, double *w_out, double prev_norm, const qsmc_expparam_t *exp,
                       int64_t outcome, double *stats_dev, qsmc_update_stats_t *stats_host, double *moments_host,
                       qsmc_stream_t stream) {
-    if (h) h->prep.valid = 0;        // weights / counters are about to change: drop a queued resample prefix
+    if (h) { h->prep.valid = 0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
     if (!h || !x || !w_out || !exp || n <= 0) return QSMC_ERR_INVALID;      // w_in == NULL: all-ones weights
     int rc = check_model(model);
     if (rc) return rc;
@@ -2065,7 +2128,18 @@ int qsmc_update_fused(qsmc_handle_t h, const qsmc_model_t *model, const double *
     if (rc) return rc;
     ExpArgs ea;
     make_exp_args(model, exp, outcome, &ea);
-    const ReduceOut ro = make_reduce(h, stats_host || moments_host, stats_dev);
+    ReduceOut ro = make_reduce(h, stats_host || moments_host, stats_dev);
+    // per-tile sums of the new weights: a resample that follows this update takes its chunk sums from them
+    if (BUCKET_CHUNK % per_block == 0 && ensure_tile_sums(h, (size_t)((n + per_block - 1) / per_block)) == QSMC_OK) {
+        ro.tile_sums = h->tile_sums;
+        h->ts.w = w_out;
+        h->ts.n = n;
+        h->ts.tile = per_block;
+    } else {
+        h->ts.w = nullptr;
+    }
+    ++h->ts.gen;
+    h->ts.armed = 0;
     switch (model->kind) {
 #define LAUNCH_U(K)                                                                             \
     case K:                                                                                     \
@@ -2091,7 +2165,7 @@ int qsmc_update_multi(qsmc_handle_t h, const qsmc_model_t *model, const double *
                       const double *w_in, double *w_out, double prev_norm, const qsmc_expparam_t *exps,
                       const int64_t *outcomes, int32_t k, qsmc_update_stats_t *stats_host, double *moments_host,
                       qsmc_stream_t stream) {
-    if (h) h->prep.valid = 0;        // weights / counters are about to change: drop a queued resample prefix
+    if (h) { h->prep.valid = 0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
     if (!h || !x || !w_out || !exps || !outcomes || !stats_host || n <= 0 || k < 1 || k > MULTI_KMAX)
         return QSMC_ERR_INVALID;
     int rc = check_model(model);
@@ -2173,14 +2247,14 @@ int qsmc_hypothetical_sums(qsmc_handle_t h, const qsmc_model_t *model, const dou
 int qsmc_update_from_likelihood(qsmc_handle_t h, const double *L, int64_t n, const double *w_in,
                                 double *w_out, double prev_norm, double *stats_dev,
                                 qsmc_update_stats_t *stats_host, qsmc_stream_t stream) {
-    if (h) h->prep.valid = 0;        // weights / counters are about to change: drop a queued resample prefix
+    if (h) { h->prep.valid = 0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
     if (!h || !L || !w_in || !w_out || n <= 0) return QSMC_ERR_INVALID;
     return weights_pass<0>(h, L, n, w_in, w_out, prev_norm, stats_dev, stats_host, (hipStream_t)stream);
 }
 
 int qsmc_clip_weights(qsmc_handle_t h, double *w, int64_t n, double norm, double *stats_dev,
                       qsmc_update_stats_t *stats_host, qsmc_stream_t stream) {
-    if (h) h->prep.valid = 0;        // weights / counters are about to change: drop a queued resample prefix
+    if (h) { h->prep.valid = 0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
     if (!h || !w || n <= 0) return QSMC_ERR_INVALID;
     return weights_pass<1>(h, nullptr, n, w, w, norm, stats_dev, stats_host, (hipStream_t)stream);
 }
@@ -2207,14 +2281,14 @@ int qsmc_weight_entropy(qsmc_handle_t h, const double *w, int64_t n, double norm
 
 int qsmc_normalize_weights(qsmc_handle_t h, const double *w_in, double *w_out, int64_t n, double norm,
                            qsmc_stream_t stream) {
-    if (h) h->prep.valid = 0;        // weights / counters are about to change: drop a queued resample prefix
+    if (h) { h->prep.valid = 0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
     if (!h || !w_in || !w_out || n < 0) return QSMC_ERR_INVALID;
     if (n == 0) return QSMC_OK;
     return weights_pass<2>(h, nullptr, n, w_in, w_out, norm, nullptr, nullptr, (hipStream_t)stream);
 }
 
 int qsmc_fill(qsmc_handle_t h, double *w, int64_t n, double value, qsmc_stream_t stream) {
-    if (h) h->prep.valid = 0;        // weights / counters are about to change: drop a queued resample prefix
+    if (h) { h->prep.valid = 0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
     if (!h || !w || n < 0) return QSMC_ERR_INVALID;
     if (n == 0) return QSMC_OK;
     hipLaunchKernelGGL(k_fill, dim3(grid_for(n, QSMC_BLOCK * 4)), dim3(QSMC_BLOCK), 0, (hipStream_t)stream, w,
@@ -2296,10 +2370,10 @@ int qsmc_cumsum(qsmc_handle_t h, const double *w, int64_t n, double norm, double
     hipLaunchKernelGGL(k_chunk_sums, dim3((unsigned)chunks), dim3(QSMC_BLOCK), 0, s, w, n, inv_norm, h->partials);
     if (chunks > (int64_t)SCAN_SUMS_THREADS * SCAN_SUMS_MAX_PER)
         hipLaunchKernelGGL(k_scan_sums_big, dim3(1), dim3(QSMC_BLOCK), 0, s, h->partials, chunks,
-                           (unsigned long long *)nullptr);
+                           (unsigned long long *)nullptr, TileSrc{nullptr, 0, 0, 0.0});
     else
         hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_SUMS_THREADS), 0, s, h->partials, chunks,
-                           (unsigned long long *)nullptr);
+                           (unsigned long long *)nullptr, TileSrc{nullptr, 0, 0, 0.0});
     hipLaunchKernelGGL(k_chunk_scan, dim3((unsigned)chunks), dim3(SCAN_THREADS), 0, s, w, n, inv_norm, h->partials,
                        cdf, (const unsigned long long *)nullptr);
     HIP_TRY(h, hipGetLastError());
@@ -2422,13 +2496,20 @@ static int resample_prefix(qsmc_ctx *h, const double *w, int64_t n_in, double no
     if (rc) return rc;
     double *offsets = h->rs_offsets;
     const double inv_norm = 1.0 / norm;
-    hipLaunchKernelGGL(k_chunk_sums, dim3((unsigned)chunks64), dim3(QSMC_BLOCK), 0, s, w, n_in, inv_norm, offsets);
+    // chunk sums: from the tile sums of the update that produced these very weights, if the caller vouches for
+    // that (qsmc_lw_use_update_sums) and nothing has touched them since; else one pass over the weights
+    TileSrc ts{nullptr, 0, 0, 0.0};
+    if (h->ts.armed && h->ts.armed == h->ts.gen && w && h->ts.w == w && h->ts.n == n_in)
+        ts = TileSrc{h->tile_sums, BUCKET_CHUNK / h->ts.tile, (n_in + h->ts.tile - 1) / h->ts.tile, inv_norm};
+    h->ts.armed = 0;
+    if (!ts.tiles)
+        hipLaunchKernelGGL(k_chunk_sums, dim3((unsigned)chunks64), dim3(QSMC_BLOCK), 0, s, w, n_in, inv_norm, offsets);
     if (chunks64 > (int64_t)SCAN_SUMS_THREADS * SCAN_SUMS_MAX_PER)
         hipLaunchKernelGGL(k_scan_sums_big, dim3(1), dim3(QSMC_BLOCK), 0, s, offsets, chunks64,
-                           reinterpret_cast<unsigned long long *>(h->counter));
+                           reinterpret_cast<unsigned long long *>(h->counter), ts);
     else
         hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_SUMS_THREADS), 0, s, offsets, chunks64,
-                           reinterpret_cast<unsigned long long *>(h->counter));
+                           reinterpret_cast<unsigned long long *>(h->counter), ts);
     BucketPlan bp;
     rc = bucket_plan_layout(h, chunks64, n_out, &bp);
     if (rc) return rc;
@@ -2525,6 +2606,18 @@ static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int3
     return QSMC_OK;
 }
 
+int qsmc_lw_use_update_sums(qsmc_handle_t h, uint64_t update_token) {
+    if (!h) return QSMC_ERR_INVALID;
+    h->ts.armed = update_token;
+    return QSMC_OK;
+}
+
+int qsmc_update_token(qsmc_handle_t h, uint64_t *token_out) {
+    if (!h || !token_out) return QSMC_ERR_INVALID;
+    *token_out = h->ts.gen;
+    return QSMC_OK;
+}
+
 int qsmc_lw_resample_prepare(qsmc_handle_t h, const double *w, int64_t n_in, double norm, int64_t n_out,
                              uint64_t seed, uint64_t epoch, qsmc_stream_t stream) {
     if (!h || n_in <= 0 || n_out <= 0 || !(norm > 0.0)) return QSMC_ERR_INVALID;
@@ -2611,7 +2704,7 @@ int qsmc_prior_uniform_philox(qsmc_handle_t h, const qsmc_model_t *model, int32_
                               const double *lo, const double *hi, int32_t d, int64_t n, uint64_t seed,
                               uint64_t epoch, int32_t maxiter, double *x_out, int64_t ldx_out,
                               int64_t *n_failed_host, qsmc_stream_t stream) {
-    if (h) h->prep.valid = 0;        // weights / counters are about to change: drop a queued resample prefix
+    if (h) { h->prep.valid = 0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
     if (!h || !model || !lo || !hi || !x_out || n <= 0 || d < 1 || d > QSMC_MAX_D || maxiter < 1)
         return QSMC_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
@@ -2658,7 +2751,7 @@ int qsmc_random_walk(qsmc_handle_t h, double *x, int64_t ldx, int64_t n, int32_t
 
 int qsmc_tomo_canonicalize(qsmc_handle_t h, const double *basis, int32_t dim, double *x, int64_t ldx,
                            int64_t n, int32_t allow_subnormalized, qsmc_stream_t stream) {
-    if (h) h->prep.valid = 0;        // weights / counters are about to change: drop a queued resample prefix
+    if (h) { h->prep.valid = 0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
     if (!h || !basis || !x || n < 0) return QSMC_ERR_INVALID;
     if (n == 0) return QSMC_OK;
     hipStream_t s = (hipStream_t)stream;

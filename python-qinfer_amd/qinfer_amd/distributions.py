@@ -186,6 +186,7 @@ class ParticleDistribution(Distribution):
 
     def _invalidate(self):
         self._moments_cache = None
+        self._w_token = 0            # the weights are no longer (known to be) the output of a fused update
 
     def _weights(self):
         """Explicit unnormalised weights.  `_w is None` encodes an all-ones cloud (uniform weights

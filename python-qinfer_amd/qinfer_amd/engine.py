@@ -46,6 +46,7 @@ class Engine:
         h = C.c_void_p()
         _native.check(None, self.lib.qsmc_create(C.byref(h), index), "qsmc_create")
         self.h = h
+        self.update_gen = 0          # number of qsmc_update_fused calls on this handle (see use_update_sums)
         self._stats = torch.empty(4 + 4 + 10, dtype=torch.float64, device=self.device)   # stats + moments (d <= 4)
         raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
         self._raw_stream = raw if raw is not None else (
@@ -143,6 +144,7 @@ class Engine:
         sum w' x and sum w' x x^T of the new weights, produced by the same kernel).  The returned
         UpdateStats object is reused by the next call: read it before updating again."""
         d = x.shape[0]
+        self.update_gen += 1                        # mirrors the handle's generation counter (qsmc_update_token)
         self._chk(self.lib.qsmc_update_fused(
             self.h, desc, x.data_ptr(), x.stride(0), x.shape[1],
             w_in.data_ptr() if w_in is not None else None, w_out.data_ptr(),
@@ -303,6 +305,10 @@ class Engine:
             self._p(z) if z is not None else None,
             (z.stride(0) if z.shape[0] > 1 else z.shape[1]) if z is not None else 0,
             C.c_uint64(seed & (2 ** 64 - 1)), C.c_uint64(epoch), self.stream()), "qsmc_random_walk")
+
+    def use_update_sums(self, token):
+        """Vouch that the weights about to be resampled are the untouched output of update number `token`."""
+        self._chk(self.lib.qsmc_lw_use_update_sums(self.h, C.c_uint64(int(token))), "qsmc_lw_use_update_sums")
 
     def lw_resample_prepare(self, w, n_in, norm, n_out, seed, epoch):
         """Queue the weight-only prefix of the next `lw_resample_philox` call with the same arguments."""

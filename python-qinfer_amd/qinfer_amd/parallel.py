@@ -319,6 +319,7 @@ class ParticleShardGroup:
         if stay:
             # children stay with their ancestor: this rank draws its T_h particles, nothing moves.  The
             # weight-only prefix (chunk sums, multinomial chunk counts) is queued before mean / cov / sqrtm
+            resampler._arm_update_sums(updater)
             eng.lw_resample_prepare(updater._w, n_local, float(W[self.rank]), int(totals[self.rank]), seed_r, epoch)
         mean = updater.est_mean()                                   # global (all-reduced) moments
         cov = updater.est_covariance_mtx()

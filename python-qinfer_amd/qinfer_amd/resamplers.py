@@ -111,6 +111,7 @@ class LiuWestResampler(Resampler):
             # straight from the weights: the CDF is scanned chunk-wise inside the sampler, never in HBM
             self._epoch += 1
             defer = bool(getattr(self, "_defer_failed_check", False))
+            self._arm_update_sums(particle_dist)
             x_new, n_failed = eng.lw_resample_philox(desc, self._postselect, x_in, particle_dist._w, norm, a,
                                                      mean, S, n_particles, self._seed, self._epoch,
                                                      self._maxiter, sync=not defer)
@@ -129,6 +130,14 @@ class LiuWestResampler(Resampler):
         return ParticleDistribution._from_device(eng, x_new, None, norm=float(n_particles),
                                                  sumsq=float(n_particles))
 
+    @staticmethod
+    def _arm_update_sums(particle_dist):
+        """If the weights are the untouched output of the engine's latest fused update, let the resampler start
+        from that kernel's per-tile sums instead of re-reading the weights (qsmc_lw_use_update_sums)."""
+        tok = getattr(particle_dist, "_w_token", 0)
+        if tok and tok == particle_dist._eng.update_gen:
+            particle_dist._eng.use_update_sums(tok)
+
     def _prepare_device(self, model, particle_dist):
         """Called by SMCUpdater the moment its n_ess test fails: queue the part of the resample that needs
         only the weights (chunk sums, multinomial chunk counts, work-item plan) so that the GPU is busy
@@ -137,6 +146,7 @@ class LiuWestResampler(Resampler):
         if not (self._device_rng and getattr(model, "_native", False)):
             return
         n_out = (particle_dist.n_particles if self._default_n_particles is None else self._default_n_particles)
+        self._arm_update_sums(particle_dist)
         particle_dist._eng.lw_resample_prepare(particle_dist._w, particle_dist.n_particles, particle_dist._norm,
                                                int(n_out), self._seed, self._epoch + 1)
 

@@ -331,6 +331,10 @@ class SMCUpdater(ParticleDistribution):
         self._norm = float(new_norm)
         self._sumsq = float(sumsq)
         self._invalidate()
+        if self._native and n_bad == 0:
+            # these weights are exactly what update number `update_gen` of the engine wrote: a resample that
+            # follows may take its chunk sums from that kernel's tile sums (resamplers._arm_update_sums)
+            self._w_token = eng.update_gen
         if fused_moments is not None and n_bad == 0 and new_norm != 0:
             self._moments_cache = (sum_w, fused_moments[0] / new_norm, fused_moments[1] / new_norm)
         self._normalization_record.append(norm)                      # smc.py:444

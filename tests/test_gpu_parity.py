@@ -505,6 +505,44 @@ def test_resample_prepare_is_transparent(qi, eng):
         np.testing.assert_array_equal(u1.particle_locations, u2.particle_locations)
 
 
+def test_resample_from_update_tile_sums(qi, eng):
+    """A resample that follows a fused update takes its chunk sums from the update kernel's per-tile sums
+    (qsmc_lw_use_update_sums) instead of re-reading the weights: chunk edges agree to rounding, so the particles
+    are the ones the plain path produces; a stale token, rewritten weights or a foreign cloud fall back."""
+    model = qi.SimplePrecessionModel()
+    n = 300001                                        # not a multiple of the tile: exercises the ragged last tile
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        u1 = qi.SMCUpdater(model, n, qi.UniformDistribution([0, 1]), device_rng=True, seed=21, resample_thresh=0.0)
+        u2 = qi.SMCUpdater(model, n, qi.UniformDistribution([0, 1]), device_rng=True, seed=21, resample_thresh=0.0)
+        for k, t in enumerate((2.0, 5.0, 9.0)):
+            u1.update(k & 1, np.array([t]))
+            u2.update(k & 1, np.array([t]))
+        assert u1._w_token == eng.update_gen - 1 and u2._w_token == eng.update_gen    # u2 updated last
+        # the tile sums in the handle now belong to u2: the offsets it resamples from are the tile-sum ones
+        cdf_edges = eng.cumsum(u2._w, u2._norm)[4095::4096].cpu().numpy()              # plain-path chunk edges
+        u2.resample()                                 # armed: token == update_gen
+        u1.resample()                                 # stale token -> plain path (k_chunk_sums)
+        a, b = u1.particle_locations, u2.particle_locations
+        assert a.shape == b.shape == (n, 1)
+        # same seed, same weights: identical particles unless a uniform fell within rounding of a chunk edge
+        assert np.mean(a != b) < 1e-5
+        assert np.all(np.diff(cdf_edges) >= 0)
+        # weights rewritten after the update: the token is dropped
+        u2.update(1, np.array([13.0]))
+        assert u2._w_token == eng.update_gen
+        u2.particle_weights = u2.particle_weights
+        assert u2._w_token == 0
+        u2.resample()
+        # end to end: the armed path inside update() (resample_thresh = 0.5) tracks the truth
+        u3 = qi.SMCUpdater(model, n, qi.UniformDistribution([0, 1]), device_rng=True, seed=5)
+        rs = np.random.RandomState(1)
+        for k in range(60):
+            t = 1.125 ** k
+            u3.update(int(rs.random_sample() >= np.cos(0.3 * t / 2) ** 2), np.array([t]))
+        assert u3.resample_count > 5 and abs(u3.est_mean()[0] - 0.3) < 5e-3
+
+
 def _deal_rows(dest_counts):
     """NumPy twin of OutPlace/place_row: slot o -> row index in the destination-grouped output."""
     counts = np.asarray(dest_counts, dtype=np.int64)
