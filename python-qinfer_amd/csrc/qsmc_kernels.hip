@@ -317,9 +317,8 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_update_fused(
     const double inv_norm = 1.0 / prev_norm;
     // Sum of the new weights per tile, for the resampler: its chunk sums (k_chunk_sums, an 80 MB read) are
     // sums of two such tiles, so a resample that follows this update starts from them instead of reading
-    // the weights once more.  One wave reduction + barrier per 2048 particles; off when ro.tile_sums is null.
-    __shared__ double ts_lds[2][QSMC_WAVES_PER_BLOCK];
-    int ts_par = 0;
+    // the weights once more.  One wave reduction per wave and tile, no barrier: each wave stores its own part
+    // (k_scan_sums adds the parts in a fixed order); off when ro.tile_sums is null.
     for (int64_t base = (int64_t)blockIdx.x * TILE; base < n; base += (int64_t)gridDim.x * TILE) {
         double tsum = 0.0;
         if (VEC == 2 && D <= 2 && base + TILE <= n) {
@@ -398,15 +397,8 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_update_fused(
         }
         if (ro.tile_sums) {                      // uniform
             const double t = wave_sum(tsum);
-            if ((threadIdx.x & (QSMC_WAVE - 1)) == 0) ts_lds[ts_par][threadIdx.x / QSMC_WAVE] = t;
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                double tot = ts_lds[ts_par][0];
-#pragma unroll
-                for (int wv = 1; wv < QSMC_WAVES_PER_BLOCK; ++wv) tot += ts_lds[ts_par][wv];
-                ro.tile_sums[base / TILE] = tot;
-            }
-            ts_par ^= 1;                         // the other bank next time: one barrier per tile suffices
+            if ((threadIdx.x & (QSMC_WAVE - 1)) == 0)
+                ro.tile_sums[(base / TILE) * QSMC_WAVES_PER_BLOCK + threadIdx.x / QSMC_WAVE] = t;
         }
     }
     block_publish<UpdAcc<DMOM>::NS>(acc.s, acc.mn, ro);
@@ -779,8 +771,8 @@ __device__ __forceinline__ double wave_inclusive_max(double v, int lane) {
 constexpr int SCAN_SUMS_THREADS = 1024;
 constexpr int SCAN_SUMS_MAX_PER = 16;              // m <= 16384 chunks (N <= 6.7e7) in registers
 
-// tiles != nullptr: chunk c's sum is (tiles[c tpc] + ... + tiles[c tpc + tpc - 1]) * inv_norm -- the per-tile sums the
-// last update kernel left behind -- instead of sums[c] from k_chunk_sums.
+// tiles != nullptr: chunk c's sum is (tiles[c tpc] + ... + tiles[c tpc + tpc - 1]) * inv_norm -- the per-tile, per-wave
+// sums the last update kernel left behind (tpc = tiles per chunk x 4 waves) -- instead of sums[c] from k_chunk_sums.
 struct TileSrc {
     const double *tiles;
     int tpc;
@@ -2130,7 +2122,9 @@ int qsmc_update_fused(qsmc_handle_t h, const qsmc_model_t *model, const double *
     make_exp_args(model, exp, outcome, &ea);
     ReduceOut ro = make_reduce(h, stats_host || moments_host, stats_dev);
     // per-tile sums of the new weights: a resample that follows this update takes its chunk sums from them
-    if (BUCKET_CHUNK % per_block == 0 && ensure_tile_sums(h, (size_t)((n + per_block - 1) / per_block)) == QSMC_OK) {
+    static const bool tile_sums_on = getenv("QSMC_NO_TILE_SUMS") == nullptr;     // (A/B switch for measurements)
+    if (tile_sums_on && BUCKET_CHUNK % per_block == 0 &&
+        ensure_tile_sums(h, (size_t)((n + per_block - 1) / per_block) * QSMC_WAVES_PER_BLOCK) == QSMC_OK) {
         ro.tile_sums = h->tile_sums;
         h->ts.w = w_out;
         h->ts.n = n;
@@ -2500,7 +2494,8 @@ static int resample_prefix(qsmc_ctx *h, const double *w, int64_t n_in, double no
     // that (qsmc_lw_use_update_sums) and nothing has touched them since; else one pass over the weights
     TileSrc ts{nullptr, 0, 0, 0.0};
     if (h->ts.armed && h->ts.armed == h->ts.gen && w && h->ts.w == w && h->ts.n == n_in)
-        ts = TileSrc{h->tile_sums, BUCKET_CHUNK / h->ts.tile, (n_in + h->ts.tile - 1) / h->ts.tile, inv_norm};
+        ts = TileSrc{h->tile_sums, BUCKET_CHUNK / h->ts.tile * QSMC_WAVES_PER_BLOCK,
+                     (n_in + h->ts.tile - 1) / h->ts.tile * QSMC_WAVES_PER_BLOCK, inv_norm};
     h->ts.armed = 0;
     if (!ts.tiles)
         hipLaunchKernelGGL(k_chunk_sums, dim3((unsigned)chunks64), dim3(QSMC_BLOCK), 0, s, w, n_in, inv_norm, offsets);

@@ -15,6 +15,8 @@ MODEL_PRECESSION, MODEL_BINOMIAL_PRECESSION, MODEL_RB, MODEL_RB_INTERLEAVED, MOD
 MODEL_BINOMIAL_RB, MODEL_BINOMIAL_RB_INTERLEAVED, MODEL_UNKNOWN_T2 = 6, 7, 8
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libqsmc_hip.so")
+if os.environ.get("QSMC_LIB_PATH"):          # development: A/B a differently built library (tools/abl_*.sh)
+    _LIB_PATH = os.environ["QSMC_LIB_PATH"]
 
 
 class ModelDesc(C.Structure):
