@@ -1401,3 +1401,50 @@ def test_full_size_properties(qi, eng):
     assert float(upd._x.min().item()) > 0.0                  # postselection held at full size
     m3 = upd.est_mean()
     assert 0.005 < m3[0] - m1[0] < 0.02                      # the truncation shift described above
+
+
+def test_full_size_other_configs(qi, eng):
+    """BASELINE configs 3-5 at their per-GPU sizes: size-independent invariants (a pmf sums to one, postselection
+    holds for every particle, canonicalized states are physical, the global count is what was asked for)."""
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        # C3: Binomial(SimplePrecession), N = 1e7: sum_k pmf(k) = 1 => the hypothetical normalisations add to one
+        bm = qi.BinomialModel(qi.SimplePrecessionModel())
+        upd = qi.SMCUpdater(bm, 10_000_000, qi.UniformDistribution([0, 1]), device_rng=True, seed=1)
+        ep = np.empty((1,), dtype=bm.expparams_dtype)
+        ep["x"], ep["n_meas"] = 7.5, 25
+        sums = eng.hypothetical_sums(upd._desc, upd._x, upd._w, upd._norm, bm._native_expparams(ep)[0],
+                                     np.arange(26), np.zeros(1))
+        assert sums[:, 0].sum() == pytest.approx(1.0, abs=1e-12)
+        for k in (3, 11, 20):
+            upd.update(k, ep)
+        assert upd.n_ess <= upd.n_particles and np.isfinite(upd.est_mean()).all()
+        # C4 (per-GPU share): RB, N = 1.25e7: every particle valid after the prior and after a resample
+        rb = qi.RandomizedBenchmarkingModel()
+        prior = qi.PostselectedDistribution(qi.UniformDistribution([[0.8, 1], [0, 1], [0, 1]]), rb)
+        upd = qi.SMCUpdater(rb, 12_500_000, prior, device_rng=True, seed=2)
+        assert bool(eng.are_models_valid(upd._desc, upd._x).all().item())
+        ep = np.empty((1,), dtype=rb.expparams_dtype)
+        for k in range(6):
+            ep["m"] = 1 + 40 * k
+            upd.update(k & 1, ep)
+        upd.resample()
+        assert upd.n_particles == 12_500_000 and bool(eng.are_models_valid(upd._desc, upd._x).all().item())
+        assert upd.n_ess == pytest.approx(12_500_000, rel=1e-12)
+        m = upd.est_mean()
+        assert 0.8 <= m[0] <= 1 and 0 <= m[1] <= 1 and 0 <= m[2] <= 1
+        # C5 (per-GPU share): 2-qubit tomography, N = 1.25e6: after canonicalize x_0 = 1/2 exactly-ish and rho >= 0
+        basis = qi.tomography.pauli_basis(2)
+        tm = qi.TomographyModel(basis)
+        rs = np.random.RandomState(0)
+        np.random.seed(0)
+        x0 = qi.GinibreDistribution(basis).sample(5000)
+        x0 = np.tile(x0, (250, 1)) + 0.05 * rs.randn(1_250_000, 16)          # many unphysical ones
+        upd = qi.SMCUpdater(tm, 1_250_000, fixed_prior(qi, x0))               # reset() canonicalizes (smc.py:317-320)
+        x = upd._x
+        assert float((x[0] - 0.5).abs().max().item()) < 1e-12
+        idx = rs.choice(1_250_000, 3000, replace=False)
+        sub = upd.particle_locations[idx]
+        rho = np.einsum("na,aij->nij", sub, basis.data.conj())
+        ev = np.linalg.eigvalsh((rho + rho.conj().transpose(0, 2, 1)) / 2)
+        assert ev.min() > -1e-12 and np.allclose(ev.sum(axis=1), 1.0, atol=1e-12)
