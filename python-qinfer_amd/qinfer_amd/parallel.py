@@ -136,6 +136,77 @@ class ParticleShardGroup:
         self._host = self._open_host_exchange() if host_exchange else None
 
     def _open_host_exchange(self):
+        """Shared-memory exchange if (and only if) every rank runs on this host and every rank can map the
+        segment; else None (RCCL/gloo).  Collective-safe: a failure on any rank turns it off on all of them."""
+        import socket
+        dist, group = self.dist, self.group
+        try:
+            hosts = [None] * self.world_size
+            dist.all_gather_object(hosts, socket.gethostname(), group=group)
+        except Exception:  # noqa: BLE001  (a backend without object collectives)
+            return None
+        if len(set(hosts)) != 1:
+            return None
+        name, ex = [None], None
+        if self.rank == 0:
+            try:
+                ex = HostExchange(0, self.world_size)
+                name[0] = ex.name
+            except Exception:  # noqa: BLE001  (no /dev/shm, ...)
+                ex = None
+        dist.broadcast_object_list(name, src=0, group=group)
+        if name[0] is not None and self.rank != 0:
+            try:
+                ex = HostExchange(self.rank, self.world_size, name=name[0])
+            except Exception:  # noqa: BLE001
+                ex = None
+        oks = [None] * self.world_size
+        dist.all_gather_object(oks, ex is not None, group=group)
+        if not all(oks):
+            if ex is not None:
+                ex.close()
+            return None
+        dist.barrier(group=group)
+        return ex
+
+    def close(self):
+        shm, self._shm = getattr(self, "_shm", None), None
+        if shm is None:
+            return
+        self._seq = self._pay = None
+        try:
+            shm.close()
+            if self._owner:
+                shm.unlink()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def __del__(self):
+        self.close()
+
+
+class ParticleShardGroup:
+    def __init__(self, group=None, seed=0, placement="local", rebalance_tol=0.05, host_exchange=True):
+        import torch
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised (launch with torch.distributed.run)")
+        if placement not in ("local", "mixed"):
+            raise ValueError("placement must be 'local' or 'mixed'")
+        self.torch, self.dist, self.group = torch, dist, group
+        self.rank = dist.get_rank(group)
+        self.world_size = dist.get_world_size(group)
+        self.backend = dist.get_backend(group)
+        self.seed = int(seed)
+        self.placement = placement
+        self.rebalance_tol = float(rebalance_tol)
+        self._epoch = 0
+        self.n_rebalances = 0
+        self._bitgen = np.random.Philox(key=self.seed & (2 ** 64 - 1))     # re-keyed per plan by counter
+        self._gen = np.random.Generator(self._bitgen)
+        self._host = self._open_host_exchange() if host_exchange else None
+
+    def _open_host_exchange(self):
         """Shared-memory exchange if (and only if) every rank runs on this host; else None (RCCL/gloo)."""
         import socket
         try:
