@@ -83,7 +83,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-particles", type=float, default=2e6)
     ap.add_argument("--cpu-data", type=int, default=120)
-    ap.add_argument("--event-stride", type=int, default=4,
+    ap.add_argument("--event-stride", type=int, default=8,
                     help="put hipEvents on every N-th launch of each timed kernel kind (1 = all)")
     ap.add_argument("--force-comm", action="store_true",
                     help="run the sharded code path even with one rank (validation on a 1-GPU box)")
