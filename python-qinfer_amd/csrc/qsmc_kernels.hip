@@ -782,6 +782,13 @@ struct TileSrc {
 
 __device__ __forceinline__ double chunk_sum_in(const double *__restrict__ sums, const TileSrc &ts, int64_t c) {
     if (!ts.tiles) return sums[c];
+    if (ts.tpc == 8 && (c + 1) * 8 <= ts.n_tiles) {
+        // the usual case (2 tiles x 4 waves): the chunk's eight parts are one 64-byte line -> two 32-byte loads,
+        // summed in index order like the loop below
+        const double4 a = *reinterpret_cast<const double4 *>(ts.tiles + c * 8);
+        const double4 b = *reinterpret_cast<const double4 *>(ts.tiles + c * 8 + 4);
+        return (((((((a.x + a.y) + a.z) + a.w) + b.x) + b.y) + b.z) + b.w) * ts.inv_norm;
+    }
     double t = 0.0;
     for (int j = 0; j < ts.tpc; ++j) {
         const int64_t k = c * ts.tpc + j;
