@@ -178,6 +178,16 @@ int qsmc_clip_weights(qsmc_handle_t h, double *w, int64_t n, double norm,
 int qsmc_weight_stats(qsmc_handle_t h, const double *w, int64_t n, double norm,
                       double *stats_dev, qsmc_update_stats_t *stats_host, qsmc_stream_t stream);
 
+/* Sorting and searching for the posterior read-outs (est_credible_region, distributions.py:558-614;
+ * posterior_marginal, smc.py:672-716).  qsmc_argsort: stable radix sort (rocPRIM) of n < 2^31 keys, ascending or
+ * descending; keys_out and idx_out (the permutation, int64) are device arrays of n entries.
+ * qsmc_searchsorted: out[k] = #{i : a[i] < q[k]} (side 0, NumPy 'left') or #{i : a[i] <= q[k]} (side 1, 'right')
+ * for a non-decreasing device table a[0..n) and m device queries. */
+int qsmc_argsort(qsmc_handle_t h, const double *keys, int64_t n, int32_t descending, double *keys_out,
+                 int64_t *idx_out, qsmc_stream_t stream);
+int qsmc_searchsorted(qsmc_handle_t h, const double *a, int64_t n, const double *q, int64_t m, int32_t side,
+                      int64_t *out, qsmc_stream_t stream);
+
 /* est_entropy (distributions.py:457-464): -sum over the particles with w_i / norm > 0 of (w_i / norm) log(w_i / norm),
  * one pass, result on the host.  w == NULL: implicit all-ones weights. */
 int qsmc_weight_entropy(qsmc_handle_t h, const double *w, int64_t n, double norm, double *entropy_host,

@@ -19,6 +19,8 @@
 #include <cstring>
 #include <new>
 
+#include <rocprim/rocprim.hpp>      // device radix sort for the posterior read-outs (a plain library op)
+
 #include "qsmc_device.h"
 
 using namespace qsmc;
@@ -43,6 +45,8 @@ struct qsmc_ctx {
     unsigned long long seq;        // last sequence number handed to a reducing launch
     double *rs_offsets;            // resampler: chunk offsets (own buffer: survives other calls' scratch use)
     size_t rs_offsets_cap;
+    void *sort_tmp;                // rocPRIM temporary storage + key/value staging for qsmc_argsort
+    size_t sort_tmp_cap;           // in bytes
     double *tile_sums;             // sum of w' per update-kernel tile, written by the last qsmc_update_fused
     size_t tile_sums_cap;
     struct {
@@ -1998,6 +2002,7 @@ int qsmc_destroy(qsmc_handle_t h) {
     if (h->partials) (void)hipFree(h->partials);
     if (h->rs_offsets) (void)hipFree(h->rs_offsets);
     if (h->tile_sums) (void)hipFree(h->tile_sums);
+    if (h->sort_tmp) (void)hipFree(h->sort_tmp);
     if (h->scratch) (void)hipFree(h->scratch);
     if (h->pinned) (void)hipHostFree(h->pinned);
     if (h->counter) (void)hipFree(h->counter);
@@ -2780,6 +2785,66 @@ int qsmc_tomo_canonicalize(qsmc_handle_t h, const double *basis, int32_t dim, do
         }
         default: return QSMC_ERR_UNSUPPORTED;
     }
+    HIP_TRY(h, hipGetLastError());
+    return QSMC_OK;
+}
+
+// ---- posterior read-outs: sort by weight / by location, search a sorted table -------
+__global__ __launch_bounds__(QSMC_BLOCK) void k_iota(int64_t *__restrict__ v, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * QSMC_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * QSMC_BLOCK) v[i] = i;
+}
+
+// out[k] = number of entries of the non-decreasing a[0..n) that are < q[k] (side 0, 'left') or <= q[k] (side 1)
+__global__ __launch_bounds__(QSMC_BLOCK) void k_searchsorted(const double *__restrict__ a, int64_t n,
+                                                             const double *__restrict__ q, int64_t m, int side,
+                                                             int64_t *__restrict__ out) {
+    for (int64_t k = (int64_t)blockIdx.x * QSMC_BLOCK + threadIdx.x; k < m; k += (int64_t)gridDim.x * QSMC_BLOCK) {
+        const double v = q[k];
+        int64_t lo = 0, hi = n;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            const bool go_right = side ? (a[mid] <= v) : (a[mid] < v);
+            if (go_right) lo = mid + 1; else hi = mid;
+        }
+        out[k] = lo;
+    }
+}
+
+int qsmc_argsort(qsmc_handle_t h, const double *keys, int64_t n, int32_t descending, double *keys_out,
+                 int64_t *idx_out, qsmc_stream_t stream) {
+    if (!h || !keys || !keys_out || !idx_out || n <= 0 || n >= (1ll << 31)) return QSMC_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    size_t tmp_bytes = 0;
+    // (size query: null temporary storage)
+    hipError_t e = descending
+        ? rocprim::radix_sort_pairs_desc(nullptr, tmp_bytes, keys, keys_out, (const int64_t *)nullptr, idx_out, (size_t)n, 0, 64, s)
+        : rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys_out, (const int64_t *)nullptr, idx_out, (size_t)n, 0, 64, s);
+    HIP_TRY(h, e);
+    const size_t iota_bytes = (size_t)n * sizeof(int64_t);
+    const size_t need = iota_bytes + tmp_bytes + 256;
+    if (h->sort_tmp_cap < need) {
+        if (h->sort_tmp) HIP_TRY(h, hipFree(h->sort_tmp));
+        h->sort_tmp = nullptr;
+        h->sort_tmp_cap = 0;
+        HIP_TRY(h, hipMalloc(&h->sort_tmp, need));
+        h->sort_tmp_cap = need;
+    }
+    int64_t *iota = static_cast<int64_t *>(h->sort_tmp);
+    void *tmp = static_cast<char *>(h->sort_tmp) + ((iota_bytes + 255) & ~(size_t)255);
+    hipLaunchKernelGGL(k_iota, dim3(grid_for(n, QSMC_BLOCK)), dim3(QSMC_BLOCK), 0, s, iota, n);
+    e = descending
+        ? rocprim::radix_sort_pairs_desc(tmp, tmp_bytes, keys, keys_out, (const int64_t *)iota, idx_out, (size_t)n, 0, 64, s)
+        : rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys_out, (const int64_t *)iota, idx_out, (size_t)n, 0, 64, s);
+    HIP_TRY(h, e);
+    return QSMC_OK;
+}
+
+int qsmc_searchsorted(qsmc_handle_t h, const double *a, int64_t n, const double *q, int64_t m, int32_t side,
+                      int64_t *out, qsmc_stream_t stream) {
+    if (!h || !a || !q || !out || n < 0 || m < 0 || (side != 0 && side != 1)) return QSMC_ERR_INVALID;
+    if (m == 0) return QSMC_OK;
+    hipLaunchKernelGGL(k_searchsorted, dim3(grid_for(m, QSMC_BLOCK)), dim3(QSMC_BLOCK), 0, (hipStream_t)stream, a, n,
+                       q, m, side, out);
     HIP_TRY(h, hipGetLastError());
     return QSMC_OK;
 }

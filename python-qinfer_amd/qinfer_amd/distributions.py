@@ -318,21 +318,24 @@ class ParticleDistribution(Distribution):
     def est_credible_region(self, level=0.95, return_outside=False, modelparam_slice=None):
         """Particles of a credible set of mass >= `level`: highest weight first (distributions.py:558-614).
 
-        Sort (descending, on the device), scan, cut: returns the (n_credible, n_mps) host array of the
+        Sort (descending, device radix sort), scan, cut: returns the (n_credible, n_mps) host array of the
         particles inside -- and with `return_outside` also the rest -- restricted to `modelparam_slice`."""
         self._single_cloud_only("est_credible_region")
         eng = self._eng
-        t = eng.torch
-        w = self._weights()
-        order = t.argsort(w, descending=True)
-        cdf = eng.cumsum(w[order].contiguous(), self._norm)
-        k = min(int((cdf <= level).sum().item()) + 1, self.n_particles)    # ... and the one that crosses the level
+        n = self.n_particles
+        ws, order = eng.argsort(self._weights(), descending=True)
+        cdf = eng.cumsum(ws, self._norm)
+        # entries <= level, plus the one that crosses the level
+        k = min(int(eng.searchsorted(cdf, [level], side="right").cpu().numpy()[0]) + 1, n)
         rows = self._x if modelparam_slice is None else self._x[modelparam_slice]
         if rows.dim() == 1:
             rows = rows[None, :]
-        inside = np.ascontiguousarray(rows[:, order[:k]].cpu().numpy().T)
+        rows = rows.contiguous()
+        inside = np.ascontiguousarray(eng.gather_rows(rows, order[:k].contiguous()).cpu().numpy().T)
         if return_outside:
-            return inside, np.ascontiguousarray(rows[:, order[k:]].cpu().numpy().T)
+            if k == n:
+                return inside, np.empty((0, inside.shape[1]))
+            return inside, np.ascontiguousarray(eng.gather_rows(rows, order[k:].contiguous()).cpu().numpy().T)
         return inside
 
     def posterior_marginal(self, idx_param=0, res=100, smoothing=0, range_min=None, range_max=None):
@@ -342,26 +345,28 @@ class ParticleDistribution(Distribution):
         from scipy.ndimage import gaussian_filter1d
         self._single_cloud_only("posterior_marginal")
         eng = self._eng
-        t = eng.torch
         n = self.n_particles
-        locs, order = t.sort(self._x[idx_param])
-        cdf = eng.cumsum(self._weights()[order].contiguous(), self._norm)
-        r_min = float(locs[0].item()) if range_min is None else range_min
-        r_max = float(locs[-1].item()) if range_max is None else range_max
+        locs, order = eng.argsort(self._x[idx_param].contiguous())
+        cdf = eng.cumsum(eng.gather_rows(self._weights()[None, :], order)[0], self._norm)
+        ends = eng.gather_rows(locs[None, :], eng.to_device(np.array([0, n - 1], dtype=np.int64)))[0].cpu().numpy()
+        r_min = float(ends[0]) if range_min is None else range_min
+        r_max = float(ends[1]) if range_max is None else range_max
         ps = np.linspace(r_min, r_max, res)
         # piecewise-linear interpolation through (locs, cdf) plus the closing point (r_max + |r_max - r_min|, 1);
         # zero outside [locs[0], closing point]  (interp1d(..., bounds_error=False, fill_value=0))
         x_end = r_max + abs(r_max - r_min)
-        hi = t.searchsorted(locs, eng.to_device(ps)).clamp_(1, n)          # bracket [hi - 1, hi] in the extended table
+        hi = np.clip(eng.searchsorted(locs, ps, side="left").cpu().numpy(), 1, n)   # bracket [hi - 1, hi], extended table
         lo = hi - 1
-        hi_c = hi.clamp(max=n - 1)
-        x_lo, y_lo = locs[lo].cpu().numpy(), cdf[lo].cpu().numpy()
-        last = (hi == n).cpu().numpy()
-        x_hi = np.where(last, x_end, locs[hi_c].cpu().numpy())
-        y_hi = np.where(last, 1.0, cdf[hi_c].cpu().numpy())
+        last = hi == n
+        pick = eng.to_device(np.concatenate([lo, np.minimum(hi, n - 1)]).astype(np.int64))
+        xs = eng.gather_rows(locs[None, :], pick)[0].cpu().numpy()
+        ys = eng.gather_rows(cdf[None, :], pick)[0].cpu().numpy()
+        x_lo, y_lo = xs[:res], ys[:res]
+        x_hi = np.where(last, x_end, xs[res:])
+        y_hi = np.where(last, 1.0, ys[res:])
         with np.errstate(divide='ignore', invalid='ignore'):
             y = (y_hi - y_lo) / (x_hi - x_lo) * (ps - x_lo) + y_lo
-        y[(ps < float(locs[0].item())) | (ps > x_end)] = 0.0
+        y[(ps < float(ends[0])) | (ps > x_end)] = 0.0
         pr = np.gradient(y, ps[1] - ps[0])
         if smoothing > 0:
             gaussian_filter1d(pr, res * smoothing / abs(r_max - r_min), output=pr)
@@ -373,4 +378,4 @@ class ParticleDistribution(Distribution):
         cdf = self._eng.cumsum(self._weights(), self._norm)
         u = self._eng.to_device(np.random.random((n,)))
         js = self._eng.lw_ancestors(cdf, u)
-        return np.ascontiguousarray(self._x[:, js].cpu().numpy().T)
+        return np.ascontiguousarray(self._eng.gather_rows(self._x, js).cpu().numpy().T)

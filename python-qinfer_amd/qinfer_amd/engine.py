@@ -218,11 +218,39 @@ class Engine:
                                                   float(norm), self.stream()), "qsmc_normalize_weights")
         return out
 
+    def argsort(self, keys, descending=False):
+        """(sorted keys, permutation as int64) of a 1-D float64 device tensor (device radix sort)."""
+        n = keys.shape[0]
+        out = self.empty(n)
+        idx = self.empty(n, dtype=self.torch.int64)
+        self._chk(self.lib.qsmc_argsort(self.h, self._p(keys), n, int(bool(descending)), self._p(out), self._p(idx),
+                                        self.stream()), "qsmc_argsort")
+        return out, idx
+
+    def searchsorted(self, a, q, side="left"):
+        """Device table a (non-decreasing), host or device queries q -> int64 device tensor of insertion points."""
+        if not isinstance(q, self.torch.Tensor):
+            q = self.to_device(np.asarray(q, dtype=np.float64))
+        out = self.empty(q.shape[0], dtype=self.torch.int64)
+        self._chk(self.lib.qsmc_searchsorted(self.h, self._p(a), a.shape[0], self._p(q), q.shape[0],
+                                             0 if side == "left" else 1, self._p(out), self.stream()),
+                  "qsmc_searchsorted")
+        return out
+
+    def gather_rows(self, x, idx):
+        """x[:, idx] for a (d, n) device tensor and int64 device indices (the Liu-West centre kernel with a = 1)."""
+        return self.lw_centres(x, idx, 1.0, np.zeros(x.shape[0]))
+
     def weight_entropy(self, w, n, norm):
         out = C.c_double()
         self._chk(self.lib.qsmc_weight_entropy(self.h, self._p(w) if w is not None else None, int(n), float(norm),
                                                C.byref(out), self.stream()), "qsmc_weight_entropy")
         return out.value
+
+    def normalize_weights_into(self, w_in, w_out, norm):
+        """w_out = w_in / norm (may alias)."""
+        self._chk(self.lib.qsmc_normalize_weights(self.h, self._p(w_in), self._p(w_out), w_in.shape[0],
+                                                  float(norm), self.stream()), "qsmc_normalize_weights")
 
     def fill(self, w, value):
         self._chk(self.lib.qsmc_fill(self.h, self._p(w), w.shape[0], float(value), self.stream()),

@@ -227,19 +227,30 @@ class SMCUpdater(ParticleDistribution):
         n_particles) on the HOST, as in smc.py:324-386."""
         if not isinstance(outcomes, np.ndarray):
             outcomes = np.array([outcomes])
-        eng, t = self._eng, self._eng.torch
+        eng = self._eng
         L = self._device_likelihood(outcomes, expparams)               # (n_o, n_e, N) device
-        w = eng.normalized_weights(self._weights(), self._norm)
-        hyp = w * L
-        norm_scale = hyp.sum(dim=2, keepdim=True)
+        n_o, n_e, n = L.shape
+        w = self._weights()
+        hyp = eng.empty(n_o, n_e, n)
+        norm_scale = np.empty((n_o, n_e, 1))
+        # per (outcome, experiment): hyp = (w / norm) * L with its sum in the same pass (the update kernel's
+        # plugin form), then one scaling pass by the zero-fixed normaliser (smc.py:355-372)
+        for o in range(n_o):
+            for e in range(n_e):
+                st = eng.update_from_likelihood(L[o, e], w, hyp[o, e], self._norm)
+                norm_scale[o, e, 0] = st.sum
         if self._comm is not None:
-            norm_scale = self._comm.allreduce_tensor(norm_scale)
-        fixed = t.where(norm_scale.abs() < _EPS, t.ones_like(norm_scale), norm_scale)
-        out = [(hyp / fixed).cpu().numpy()]
+            norm_scale = self._comm.allreduce_tensor(eng.torch.from_numpy(norm_scale)).cpu().numpy()
+        fixed = np.where(np.abs(norm_scale) < _EPS, 1.0, norm_scale)
+        for o in range(n_o):
+            for e in range(n_e):
+                if fixed[o, e, 0] != 1.0:
+                    eng.normalize_weights_into(hyp[o, e], hyp[o, e], fixed[o, e, 0])
+        out = [hyp.cpu().numpy()]
         if return_likelihood:
             out.append(L.cpu().numpy())
         if return_normalization:
-            out.append(norm_scale.cpu().numpy())
+            out.append(norm_scale)
         return out[0] if len(out) == 1 else tuple(out)
 
     def _device_likelihood(self, outcomes, expparams):

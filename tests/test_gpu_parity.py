@@ -1448,3 +1448,36 @@ def test_full_size_other_configs(qi, eng):
         rho = np.einsum("na,aij->nij", sub, basis.data.conj())
         ev = np.linalg.eigvalsh((rho + rho.conj().transpose(0, 2, 1)) / 2)
         assert ev.min() > -1e-12 and np.allclose(ev.sum(axis=1), 1.0, atol=1e-12)
+
+
+def test_argsort_searchsorted_gather(eng):
+    """qsmc_argsort (stable device radix sort), qsmc_searchsorted and the row gather against NumPy."""
+    rs = np.random.RandomState(8)
+    n = 300007
+    keys = rs.randn(n)
+    keys[::7] = keys[3]                                   # many ties: stability decides their order
+    keys[5] = -0.0
+    keys[6] = 0.0
+    dk = eng.to_device(keys)
+    for desc in (False, True):
+        srt, idx = eng.argsort(dk, descending=desc)
+        ref = np.argsort(-keys if desc else keys, kind="stable")
+        if desc:                                          # -(-0.0) vs 0.0 compare equal for NumPy; the radix sort orders by bits
+            assert np.array_equal(np.sort(keys)[::-1], srt.cpu().numpy())
+            assert np.array_equal(keys[idx.cpu().numpy()], srt.cpu().numpy())
+        else:
+            np.testing.assert_array_equal(srt.cpu().numpy(), keys[ref])
+            same = keys[idx.cpu().numpy()] == keys[ref]
+            assert same.all()
+            ties = keys[ref] == keys[3]
+            np.testing.assert_array_equal(idx.cpu().numpy()[ties], ref[ties])     # stable among equal keys
+        assert np.array_equal(np.sort(idx.cpu().numpy()), np.arange(n))
+    table = eng.to_device(np.sort(keys))
+    q = np.concatenate([rs.randn(500), [keys[3], -10.0, 10.0]])
+    for side in ("left", "right"):
+        got = eng.searchsorted(table, q, side=side).cpu().numpy()
+        np.testing.assert_array_equal(got, np.searchsorted(np.sort(keys), q, side=side))
+    x = rs.randn(3, n)
+    pick = rs.randint(0, n, size=1000)
+    got = eng.gather_rows(eng.to_device(x), eng.to_device(pick.astype(np.int64))).cpu().numpy()
+    np.testing.assert_array_equal(got, x[:, pick])
