@@ -45,6 +45,7 @@ struct qsmc_ctx {
     unsigned long long seq;        // last sequence number handed to a reducing launch
     double *rs_offsets;            // resampler: chunk offsets (own buffer: survives other calls' scratch use)
     size_t rs_offsets_cap;
+    size_t count_lds_granted;      // dynamic LDS already opted into for k_bucket_count on this device
     void *sort_tmp;                // rocPRIM temporary storage + key/value staging for qsmc_argsort
     size_t sort_tmp_cap;           // in bytes
     double *tile_sums;             // sum of w' per update-kernel tile, written by the last qsmc_update_fused
@@ -2455,8 +2456,8 @@ struct BucketPlan {
 };
 
 static bool use_buckets(int64_t chunks64, int64_t n_out) {
-    return chunks64 <= BUCKET_MAX_CHUNKS && n_out >= 4 * BUCKET_CHUNK && n_out < (1ll << 32) &&
-           getenv("QSMC_DIRECT_RESAMPLE") == nullptr;
+    static const bool forced_direct = getenv("QSMC_DIRECT_RESAMPLE") != nullptr;     // (test / measurement switch)
+    return chunks64 <= BUCKET_MAX_CHUNKS && n_out >= 4 * BUCKET_CHUNK && n_out < (1ll << 32) && !forced_direct;
 }
 
 static int bucket_plan_layout(qsmc_ctx *h, int64_t chunks64, int64_t n_out, BucketPlan *bp) {
@@ -2524,9 +2525,13 @@ static int resample_prefix(qsmc_ctx *h, const double *w, int64_t n_in, double no
         const int chunks = bp.chunks;
         const size_t lds = (size_t)(chunks + (chunks >> 5) + (chunks >> 10) + 8) * sizeof(double) +
                            (size_t)chunks * sizeof(unsigned int) + (size_t)(GUIDE_BINS + 1 + 32) * sizeof(int);
-        if (lds > 64 * 1024)
+        size_t &lds_granted = h->count_lds_granted;        // the opt-in for > 64 KB of dynamic LDS is sticky: ask once per size
+        if (lds_granted < 64 * 1024) lds_granted = 64 * 1024;
+        if (lds > lds_granted) {
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(k_bucket_count),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            lds_granted = lds;
+        }
         hipLaunchKernelGGL(k_bucket_count, dim3(BUCKET_COUNT_BLOCKS), dim3(BUCKET_COUNT_THREADS), lds, s, offsets,
                            chunks, n_out, k0, k1, ep, bp.hist);
         hipLaunchKernelGGL(k_bucket_reduce, dim3((chunks + QSMC_WAVE - 1) / QSMC_WAVE), dim3(QSMC_BLOCK), 0, s,
