@@ -1481,3 +1481,91 @@ def test_argsort_searchsorted_gather(eng):
     pick = rs.randint(0, n, size=1000)
     got = eng.gather_rows(eng.to_device(x), eng.to_device(pick.astype(np.int64))).cpu().numpy()
     np.testing.assert_array_equal(got, x[:, pick])
+
+
+def _contract_cases(qi):
+    """(model, modelparams, expparams, outcomes) for every model class of the package, in the style of the
+    reference's tests/test_concrete_models.py."""
+    rs = np.random.RandomState(2)
+    cases = []
+    prec = qi.SimplePrecessionModel()
+    cases.append((prec, rs.uniform(0.1, 0.9, (6, 1)), np.array([0.7, 3.1, 11.0]), np.array([0, 1])))
+    inv = qi.SimpleInversionModel()
+    ep = np.empty((2,), dtype=inv.expparams_dtype)
+    ep["t"], ep["w_"] = [1.5, 4.0], [0.3, 0.6]
+    cases.append((inv, rs.uniform(0.1, 0.9, (5, 1)), ep, np.array([0, 1])))
+    t2 = qi.UnknownT2Model()
+    ep = np.empty((3,), dtype=t2.expparams_dtype)
+    ep["t"] = [0.5, 5.0, 50.0]
+    cases.append((t2, np.column_stack([rs.uniform(0, 1, 7), rs.uniform(0, 0.1, 7)]), ep, np.array([0, 1])))
+    for il in (False, True):
+        rb = qi.RandomizedBenchmarkingModel(interleaved=il)
+        ep = np.empty((3,), dtype=rb.expparams_dtype)
+        ep["m"] = [1, 10, 100]
+        if il:
+            ep["reference"] = [True, False, True]
+        mp = np.column_stack([rs.uniform(0.9, 1, 6)] * (2 if il else 1) + [rs.uniform(0.1, 0.4, 6), rs.uniform(0.3, 0.5, 6)])
+        cases.append((rb, mp, ep, np.array([0, 1])))
+        brb = qi.BinomialModel(rb)
+        ep2 = np.empty((3,), dtype=brb.expparams_dtype)
+        for f in ep.dtype.names:
+            ep2[f] = ep[f]
+        ep2["n_meas"] = 10            # one outcome count for the whole array (are_expparam_dtypes_consistent)
+        cases.append((brb, mp, ep2, np.array([0, 3, 10])))
+    bp = qi.BinomialModel(prec)
+    ep = np.empty((2,), dtype=bp.expparams_dtype)
+    ep["x"], ep["n_meas"] = [1.0, 9.0], 25
+    cases.append((bp, rs.uniform(0.1, 0.9, (4, 1)), ep, np.array([0, 12, 25])))
+    cases.append((qi.MLEModel(prec, 2.0), rs.uniform(0.1, 0.9, (5, 1)), np.array([0.7, 3.1]), np.array([0, 1])))
+    cases.append((qi.GaussianRandomWalkModel(prec, fixed_covariance=np.array([1e-6])), rs.uniform(0.2, 0.8, (5, 1)),
+                  np.array([0.7, 3.1]), np.array([0, 1])))
+    cases.append((qi.GaussianRandomWalkModel(prec), np.column_stack([rs.uniform(0.2, 0.8, 5), rs.uniform(0, 0.01, 5)]),
+                  np.array([0.7, 3.1]), np.array([0, 1])))
+    cases.append((qi.RandomWalkModel(prec, qi.MultivariateNormalDistribution(np.zeros(1), np.array([[1e-6]]))),
+                  rs.uniform(0.2, 0.8, (5, 1)), np.array([0.7, 3.1]), np.array([0, 1])))
+    basis = qi.tomography.pauli_basis(1)
+    tm = qi.TomographyModel(basis)
+    np.random.seed(3)
+    ep = np.zeros((3,), dtype=tm.expparams_dtype)
+    for k, p in enumerate((1, 2, 3)):
+        ep["meas"][k, 0] = 1 / np.sqrt(2)
+        ep["meas"][k, p] = 1 / np.sqrt(2)
+    cases.append((tm, qi.GinibreDistribution(basis).sample(6), ep, np.array([0, 1])))
+    return cases
+
+
+def test_model_contracts(qi):
+    """The reference's generic model tests (tests/base_test.py:336-435) over every model class of the package:
+    output formats of simulate_experiment / update_timestep / domain / are_models_valid / canonicalize / likelihood."""
+    from qinfer_amd.domains import Domain
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for model, mps, eps, outcomes in _contract_cases(qi):
+            name = type(model).__name__
+            n_m, n_e = mps.shape[0], eps.shape[0]
+            assert mps.shape[1] == model.n_modelparams == len(model.modelparam_names), name
+            repeat = 2
+            while repeat in (n_m, n_e):
+                repeat += 1
+            sim = model.simulate_experiment(mps, eps, repeat=repeat)
+            assert sim.shape == (repeat, n_m, n_e), name
+            for k in range(n_e):
+                dom = model.domain(eps[k:k + 1])[0]
+                assert dom.in_domain(sim[:, :, k].flatten()), name
+            step = model.update_timestep(mps, eps)
+            assert step.shape == (n_m, model.n_modelparams, n_e), name
+            moved = step.transpose((2, 0, 1)).reshape(n_m * n_e, -1)
+            assert moved.shape[1] == model.n_modelparams
+            if not isinstance(model, (qi.RandomWalkModel, qi.GaussianRandomWalkModel)):
+                assert np.all(model.are_models_valid(moved)), name          # (a walk may step out of the valid region)
+            if model.is_n_outcomes_constant:
+                assert isinstance(model.domain(None), Domain), name
+            doms = model.domain(eps)
+            assert len(doms) == n_e and all(isinstance(d_, Domain) for d_ in doms), name
+            valid = model.are_models_valid(mps)
+            assert valid.shape == (n_m,) and valid.dtype == bool, name
+            assert np.all(model.are_models_valid(model.canonicalize(mps))), name
+            L = model.likelihood(outcomes, mps, eps)
+            assert L.shape == (len(outcomes), n_m, n_e) and L.dtype == np.float64, name
+            assert np.all((L >= 0) & (L <= 1 + 1e-12)), name
+            assert model.n_outcomes(eps) is not None and model.expparams_dtype is not None
