@@ -39,6 +39,9 @@ s = rep(s, "        store(j, a, prev, j < len);\n        prev = a;\n    }\n}", "
 s = rep(s, "constexpr int UPD_UNROLL = 4;", "#if QSMC_ABL == 40\nconstexpr int UPD_UNROLL = 1;\n#elif QSMC_ABL == 41\nconstexpr int UPD_UNROLL = 2;\n#else\nconstexpr int UPD_UNROLL = 4;\n#endif")
 s = rep(s, "    block_publish<UpdAcc<DMOM>::NS>(acc.s, acc.mn, ro);\n}\n\n// ---------------------------------------------------------------------------------------------\n// K data in ONE pass", "#if QSMC_ABL == 42\n    if (acc.s[0] == 1.2345e-300) block_publish<UpdAcc<DMOM>::NS>(acc.s, acc.mn, ro);\n#else\n    block_publish<UpdAcc<DMOM>::NS>(acc.s, acc.mn, ro);\n#endif\n}\n\n// ---------------------------------------------------------------------------------------------\n// K data in ONE pass")
 s = rep(s, "template <int KIND, bool POW>\n__host__ __device__ __forceinline__ double model_lik(const double *p, const ExpArgs &e, int64_t o) {\n    const double L = Model<KIND>::lik(p, e, o);", "template <int KIND, bool POW>\n__host__ __device__ __forceinline__ double model_lik(const double *p, const ExpArgs &e, int64_t o) {\n#if QSMC_ABL == 43\n    const double L = p[0] * 0.5 + 0.25;\n#else\n    const double L = Model<KIND>::lik(p, e, o);\n#endif") if False else s
+# variant 50: sampling loop only -- the chunk CDF and guide are synthetic (linear), no weights read, no scan
+s = rep(s, "    chunk_scan_block(w, n_in, inv_norm, offsets, (int64_t)c, wave_tot,\n                     StoreLdsGuide{lcdf, lguide, lo_edge, gscale, use_guide, len, -1});",
+ "#if QSMC_ABL == 50\n    for (int j = threadIdx.x; j < len; j += BT) lcdf[lds_skew(j)] = lo_edge + (hi_edge - lo_edge) * (double)(j + 1) / (double)len;\n    for (int k = threadIdx.x; k <= SGUIDE_BINS; k += BT) { long long g = ((long long)k * len + SGUIDE_BINS - 1) / SGUIDE_BINS - 1; lguide[k] = (unsigned short)(g < 0 ? 0 : (g > len ? len : g)); }\n#else\n    chunk_scan_block(w, n_in, inv_norm, offsets, (int64_t)c, wave_tot,\n                     StoreLdsGuide{lcdf, lguide, lo_edge, gscale, use_guide, len, -1});\n#endif")
 # header variant: QSMC_ABL == 20 -> library log / sqrt / sincospi in Box-Muller
 hdr = open(os.path.join(root, 'python-qinfer_amd/csrc/qsmc_device.h')).read()
 hdr = rep(hdr, "        const double r = bm_sqrt(-2.0 * bm_log(1.0 - u0));  // 1 - u0 in [2^-53, 1]\n        double s, c;\n        bm_sincospi(2.0 * u1, s, c);",
