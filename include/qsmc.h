@@ -178,6 +178,15 @@ int qsmc_clip_weights(qsmc_handle_t h, double *w, int64_t n, double norm,
 int qsmc_weight_stats(qsmc_handle_t h, const double *w, int64_t n, double norm,
                       double *stats_dev, qsmc_update_stats_t *stats_host, qsmc_stream_t stream);
 
+/* Host-side all-gather of n <= max_len doubles between the `world` processes of one host through a shared
+ * memory segment (POSIX shm mapped by every rank; layout in qinfer_amd/parallel.py: HostExchange): call number k
+ * (1, 2, ...; the same on every rank) writes vec into this rank's slot of bank k & 1, publishes k, spins until
+ * every rank has published k, and copies the rank-ordered rows to rows_out[world][n].  No GPU involved: this
+ * is the per-datum collective of the sharded updater (a handful of sums per rank), which is pure latency.
+ * Returns QSMC_ERR_UNSUPPORTED if a peer has not arrived within timeout_s. */
+int qsmc_host_allgather(void *segment, int32_t rank, int32_t world, int32_t max_len, uint64_t k, const double *vec,
+                        int32_t n, double *rows_out, double timeout_s);
+
 /* Sorting and searching for the posterior read-outs (est_credible_region, distributions.py:558-614;
  * posterior_marginal, smc.py:672-716).  qsmc_argsort: stable radix sort (rocPRIM) of n < 2^31 keys, ascending or
  * descending; keys_out and idx_out (the permutation, int64) are device arrays of n entries.

@@ -2854,6 +2854,37 @@ int qsmc_searchsorted(qsmc_handle_t h, const double *a, int64_t n, const double 
     return QSMC_OK;
 }
 
+// ---- host: all-gather of a few doubles between the ranks of one host through shared memory -----------------
+// The per-datum collective of the sharded updater: layout and protocol of parallel.HostExchange
+// (two banks by call parity; slot = [seq: int64 on its own 64-byte line][payload: max_len doubles]); this is
+// its write / spin / read in C, no Python between the stores and the loads.
+int qsmc_host_allgather(void *segment, int32_t rank, int32_t world, int32_t max_len, uint64_t k, const double *vec,
+                        int32_t n, double *rows_out, double timeout_s) {
+    if (!segment || !vec || !rows_out || rank < 0 || rank >= world || n < 0 || n > max_len) return QSMC_ERR_INVALID;
+    constexpr int SEQ_STRIDE = 8;                              // int64s per sequence word (one cache line)
+    volatile int64_t *seq = static_cast<volatile int64_t *>(segment);
+    double *pay = reinterpret_cast<double *>(static_cast<char *>(segment) + (size_t)2 * world * SEQ_STRIDE * sizeof(int64_t));
+    const int bank = (int)(k & 1u);
+    double *mine = pay + ((size_t)bank * world + rank) * max_len;
+    memcpy(mine, vec, (size_t)n * sizeof(double));
+    std::atomic_thread_fence(std::memory_order_release);
+    seq[((size_t)bank * world + rank) * SEQ_STRIDE] = (int64_t)k;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int r = 0; r < world; ++r) {
+        volatile int64_t *s = seq + ((size_t)bank * world + r) * SEQ_STRIDE;
+        for (unsigned spins = 0; *s < (int64_t)k; ++spins) {
+            __builtin_ia32_pause();
+            if ((spins & 0xffff) == 0xffff &&
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s)
+                return QSMC_ERR_UNSUPPORTED;                   // a peer did not arrive
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    for (int r = 0; r < world; ++r)
+        memcpy(rows_out + (size_t)r * n, pay + ((size_t)bank * world + r) * max_len, (size_t)n * sizeof(double));
+    return QSMC_OK;
+}
+
 // ---- host: sqrtm_psd by cyclic Jacobi (utils.py:593-607) --------------------------------------
 int qsmc_sqrtm_psd(const double *A, int32_t d, double scale, double *S_out, double *err_out) {
     if (!A || !S_out || d < 1 || d > 64) return QSMC_ERR_INVALID;

@@ -75,6 +75,16 @@ class HostExchange:
         self._seq = np.ndarray((2, world, self._SEQ_STRIDE), dtype=np.int64, buffer=self._shm.buf)
         self._pay = np.ndarray((2, world, max_len), dtype=np.float64, buffer=self._shm.buf, offset=seq_bytes)
         self._k = 0
+        # the same protocol in C (libqsmc_hip.so, host code) when the library is loadable; pure Python otherwise
+        self._c_call, self._addr, self._anchor = None, None, None
+        try:
+            import ctypes
+            from . import _native
+            self._c_call = _native.load().qsmc_host_allgather
+            self._anchor = ctypes.c_char.from_buffer(self._shm.buf)      # keeps the mapping's address valid
+            self._addr = ctypes.addressof(self._anchor)
+        except Exception:  # noqa: BLE001  (CPU-only test environments without the built library)
+            self._c_call = None
 
     def all_gather(self, vec):
         """vec: 1-D float64 (len <= max_len) -> (world, len) array, rank-ordered, identical everywhere."""
@@ -82,6 +92,14 @@ class HostExchange:
         if n > self.max_len:
             raise ValueError("HostExchange payload too long")
         self._k += 1
+        if self._c_call is not None:                # the library's C loop: no interpreter between store and spin
+            v = np.ascontiguousarray(vec, dtype=np.float64)
+            out = np.empty((self.world, n))
+            rc = self._c_call(self._addr, self.rank, self.world, self.max_len, self._k, v.ctypes.data, n,
+                              out.ctypes.data, self.timeout)
+            if rc != 0:
+                raise RuntimeError("HostExchange: a peer did not arrive within {} s".format(self.timeout))
+            return out
         k, bank = self._k, self._k & 1
         self._pay[bank, self.rank, :n] = vec
         self._seq[bank, self.rank, 0] = k
@@ -103,6 +121,7 @@ class HostExchange:
         if shm is None:
             return
         self._seq = self._pay = None
+        self._anchor = self._c_call = None               # release the buffer export before unmapping
         try:
             shm.close()
             if self._owner:
