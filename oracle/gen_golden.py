@@ -622,6 +622,33 @@ def g12_perf_test():
     print("g12_perf_test", out['prec_loss'][-1], out['t2_loss'][-1], out['prec_resample_count'][-1])
 
 
+def g13_regions():
+    """Region estimators built on est_credible_region (distributions.py:616-754; utils.mvee :314-353): convex hull,
+    minimum-volume enclosing ellipsoid and the three in_credible_region methods, on a weighted 2-D cloud."""
+    out = {}
+    rs = np.random.RandomState(44)
+    n = 3000
+    x = rs.multivariate_normal([2.0, 3.0], [[1.0, 0.4], [0.4, 0.5]], size=n)
+    w = rs.random_sample(n) ** 2
+    w /= w.sum()
+    pd = qinfer.ParticleDistribution(particle_locations=x.copy(), particle_weights=w.copy())
+    out['x'], out['w'] = x, pd.particle_weights
+    faces, vertices = pd.region_est_hull(level=0.8)
+    out['hull_faces_shape'] = np.array(faces.shape)
+    out['hull_vertices'] = vertices
+    A, c = pd.region_est_ellipsoid(level=0.8, tol=1e-4)
+    out['mvee_A'], out['mvee_c'] = A, c
+    pts = rs.multivariate_normal([2.0, 3.0], [[2.0, 0.0], [0.0, 2.0]], size=400)
+    out['pts'] = pts
+    for method in ('pce', 'hpd-hull', 'hpd-mvee'):
+        out['in_' + method.replace('-', '_')] = pd.in_credible_region(pts, level=0.8, method=method)
+    pts3 = rs.randn(50, 3)
+    A3, c3 = qinfer.utils.mvee(pts3, 1e-5)
+    out['mvee3_pts'], out['mvee3_A'], out['mvee3_c'] = pts3, A3, c3
+    np.savez_compressed(os.path.join(OUT, "g13_regions.npz"), **out)
+    print("g13_regions", vertices.shape, [int(out[k].sum()) for k in ('in_pce', 'in_hpd_hull', 'in_hpd_mvee')])
+
+
 if __name__ == "__main__":
     g1_precession()
     g1_binomial()
@@ -639,4 +666,5 @@ if __name__ == "__main__":
     g10_random_walk()
     g11_readouts()
     g12_perf_test()
+    g13_regions()
     print("total bytes:", sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT)))

@@ -338,6 +338,45 @@ class ParticleDistribution(Distribution):
             return inside, np.ascontiguousarray(eng.gather_rows(rows, order[k:].contiguous()).cpu().numpy().T)
         return inside
 
+    def region_est_hull(self, level=0.95, modelparam_slice=None):
+        """Convex hull of the credible particle set (distributions.py:616-642): (faces, vertices) with faces of
+        shape (n_face, n_mps, n_mps) and the hull's vertices (n_vertices, n_mps).  The credible set comes from the
+        device (`est_credible_region`); the hull itself is host geometry (SciPy / Qhull, as in the reference)."""
+        from scipy.spatial import ConvexHull
+        from . import utils as u
+        points = self.est_credible_region(level=level, modelparam_slice=modelparam_slice)
+        hull = ConvexHull(points)
+        return points[hull.simplices], points[u.uniquify(hull.vertices.flatten())]
+
+    def region_est_ellipsoid(self, level=0.95, tol=0.0001, modelparam_slice=None):
+        """Minimum-volume enclosing ellipsoid of that hull (distributions.py:644-667): (A, c) with A the
+        ellipsoid's covariance-like shape matrix, x inside iff (x - c)^T A^{-1} (x - c) <= 1."""
+        from . import utils as u
+        _, vertices = self.region_est_hull(level=level, modelparam_slice=modelparam_slice)
+        return u.mvee(vertices, tol)
+
+    def in_credible_region(self, points, level=0.95, modelparam_slice=None, method='hpd-hull', tol=0.0001):
+        """Which of `points` lie in a credible region of the cloud (distributions.py:669-754): 'pce' (posterior
+        covariance ellipsoid scaled by the chi-square quantile), 'hpd-hull' (convex hull of the highest-weight
+        particles, via a Delaunay triangulation) or 'hpd-mvee' (its minimum-volume enclosing ellipsoid)."""
+        import scipy.stats as st
+        from scipy.spatial import Delaunay
+        from . import utils as u
+        points = np.asarray(points)
+        if method == 'pce':
+            s_ = np.s_[modelparam_slice] if modelparam_slice is not None else np.s_[:]
+            A = self.est_covariance_mtx()[s_, s_]
+            c = self.est_mean()[s_]
+            return u.in_ellipsoid(points, st.chi2.ppf(level, c.size) * A, c)
+        if method == 'hpd-mvee':
+            tol = 0.0001 if tol is None else tol
+            A, c = self.region_est_ellipsoid(level=level, tol=tol, modelparam_slice=modelparam_slice)
+            return u.in_ellipsoid(points, np.linalg.inv(A), c)
+        if method == 'hpd-hull':
+            hull = Delaunay(self.est_credible_region(level=level, modelparam_slice=modelparam_slice))
+            return hull.find_simplex(points) >= 0
+        raise ValueError("method must be 'pce', 'hpd-hull' or 'hpd-mvee'")
+
     def posterior_marginal(self, idx_param=0, res=100, smoothing=0, range_min=None, range_max=None):
         """Marginal density of one parameter on a `res`-point grid: derivative of the linearly interpolated
         weighted CDF, optionally Gaussian-smoothed (smc.py:672-716).  The cloud is sorted and scanned on

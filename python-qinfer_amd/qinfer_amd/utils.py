@@ -6,7 +6,7 @@ import warnings
 import numpy as np
 
 __all__ = ["sqrtm_psd", "particle_meanfn", "particle_covariance_mtx", "binomial_pdf", "outer_product",
-           "safe_shape"]
+           "safe_shape", "mvee", "in_ellipsoid", "uniquify"]
 
 
 def safe_shape(arr, idx=0, default=1):
@@ -60,3 +60,45 @@ def binomial_pdf(N, n, p):
     available through BinomialModel; this helper is the host convenience the reference exposes."""
     from scipy.stats import binom
     return binom(N, p).pmf(n)
+
+
+def mvee(points, tol=0.001):
+    """Minimum-volume enclosing ellipsoid of a point set by Khachiyan's algorithm (reference utils.py:314-353,
+    after N. Moshtagh): returns (A, c) with the ellipsoid {x : (x - c)^T A (x - c) <= 1}.
+
+    Same iteration as the reference (weights u on the lifted points Q = [x; 1]; the most outlying point gains
+    weight until the step is below `tol`), written without the N x N diagonal matrices."""
+    points = np.asarray(points, dtype=np.float64)
+    n, d = points.shape
+    Q = np.vstack([points.T, np.ones(n)])                 # (d + 1, n)
+    u = np.full(n, 1.0 / n)
+    err = 1.0
+    while err > tol:
+        X = (Q * u) @ Q.T
+        M = np.einsum('in,ij,jn->n', Q, np.linalg.inv(X), Q)
+        j = int(np.argmax(M))
+        step = (M[j] - d - 1) / ((d + 1) * (M[j] - 1))
+        new_u = (1 - step) * u
+        new_u[j] += step
+        err = np.linalg.norm(new_u - u)
+        u = new_u
+    c = points.T @ u
+    A = (1.0 / d) * np.linalg.inv((points.T * u) @ points - np.outer(c, c))
+    return A, c
+
+
+def in_ellipsoid(x, A, c):
+    """Which of the points x lie in the closed ellipsoid (c - x)^T A^{-1} (c - x) <= 1 (reference utils.py:355-374)."""
+    x = np.asarray(x)
+    Ainv = np.linalg.inv(A)
+    if x.ndim == 1:
+        y = c - x
+        return np.einsum('j,jl,l', y, Ainv, y) <= 1
+    y = c[np.newaxis, :] - x
+    return np.einsum('ij,jl,il->i', y, Ainv, y) <= 1
+
+
+def uniquify(seq):
+    """Unique elements of a sequence, first occurrences in order."""
+    seen = set()
+    return [v for v in seq if not (v in seen or seen.add(v))]

@@ -1569,3 +1569,37 @@ def test_model_contracts(qi):
             assert L.shape == (len(outcomes), n_m, n_e) and L.dtype == np.float64, name
             assert np.all((L >= 0) & (L <= 1 + 1e-12)), name
             assert model.n_outcomes(eps) is not None and model.expparams_dtype is not None
+
+
+def test_region_estimators_g13(qi, golden):
+    """region_est_hull / region_est_ellipsoid / in_credible_region (distributions.py:616-754) on the reference's
+    numbers, plus the reference's own sanity checks (tests/test_region_estimates.py:74-140) on a Gaussian cloud."""
+    g = golden("g13_regions")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        pd = qi.ParticleDistribution(particle_locations=g["x"], particle_weights=g["w"])
+        faces, vertices = pd.region_est_hull(level=0.8)
+        assert tuple(faces.shape) == tuple(g["hull_faces_shape"])
+        np.testing.assert_array_equal(np.sort(vertices, axis=0), np.sort(g["hull_vertices"], axis=0))
+        A, c = pd.region_est_ellipsoid(level=0.8, tol=1e-4)
+        np.testing.assert_allclose(A, g["mvee_A"], rtol=1e-8)
+        np.testing.assert_allclose(c, g["mvee_c"], rtol=1e-8)
+        for method in ("pce", "hpd-hull", "hpd-mvee"):
+            got = pd.in_credible_region(g["pts"], level=0.8, method=method)
+            ref = g["in_" + method.replace("-", "_")]
+            assert np.mean(got != ref) <= (0.005 if method == "pce" else 0.0), method      # pce: moments to 1e-13
+        with pytest.raises(ValueError):
+            pd.in_credible_region(g["pts"], method="nope")
+        mean = np.array([2.0, 3.0, 5.0, 7.0])
+        cov = np.array([[1, 0, 0, 0.5], [0, 1, 0.2, 0], [0, 0.2, 2, 0], [0.5, 0, 0, 1.0]])
+        np.random.seed(0)
+        upd = qi.SMCUpdater(qi.RandomizedBenchmarkingModel(interleaved=True), 10000,
+                            qi.MultivariateNormalDistribution(mean, cov), canonicalize=False)
+        p95, p90 = upd.est_credible_region(level=0.95), upd.est_credible_region(level=0.9)
+        assert p90.shape[0] < p95.shape[0] and {tuple(r) for r in p90} <= {tuple(r) for r in p95}
+        _, v95 = upd.region_est_hull(level=0.95)
+        _, v20 = upd.region_est_hull(level=0.2)
+        np.testing.assert_array_equal(np.round(v95.mean(axis=0)), np.round(mean))
+        assert np.all(v20.var(axis=0) < v95.var(axis=0))
+        A, c = upd.region_est_ellipsoid(level=0.5)
+        np.testing.assert_allclose(np.round(c), mean, atol=0.5)

@@ -199,3 +199,16 @@ def test_simple_est_data_tables():
     # scalar expparams dtype: one column
     o4, e4 = data_to_params(table, np.float64, cols_expparams=(1, 't'))
     assert e4.tolist() == [1.5, 2.5, 4.0]
+
+
+def test_mvee_and_in_ellipsoid(golden):
+    """utils.mvee / in_ellipsoid (reference utils.py:314-374) against the reference's own output (G13)."""
+    from qinfer_amd import utils as u
+    g = golden("g13_regions")
+    A, c = u.mvee(g["mvee3_pts"], 1e-5)
+    np.testing.assert_allclose(A, g["mvee3_A"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(c, g["mvee3_c"], rtol=1e-9, atol=1e-12)
+    inside = u.in_ellipsoid(g["mvee3_pts"], np.linalg.inv(A) * (1 + 1e-3), c)       # every point is enclosed
+    assert inside.all()
+    assert bool(u.in_ellipsoid(c, np.linalg.inv(A), c)) and not bool(u.in_ellipsoid(c + 100.0, np.linalg.inv(A), c))
+    assert u.uniquify([3, 1, 3, 2, 1]) == [3, 1, 2]
