@@ -308,11 +308,12 @@ class Engine:
         return valid
 
     def lw_resample_philox(self, desc, postselect, x_in, w, norm, a, mean, S, n_out, seed, epoch, maxiter,
-                           sync=True):
+                           sync=True, out=None):
         """Returns (x_out, n_failed); with sync=False n_failed is None and the count is available
-        from `last_resample_failed()` after the next stream synchronisation."""
+        from `last_resample_failed()` after the next stream synchronisation.  `out`: a (d, n_out) device
+        view to fill (row stride arbitrary) instead of a fresh tensor; x_in may be a column slice of a cloud."""
         d = x_in.shape[0]
-        x_out = self.empty(d, n_out)
+        x_out = self.empty(d, n_out) if out is None else out
         mean = np.ascontiguousarray(mean, dtype=np.float64)
         S = np.ascontiguousarray(S, dtype=np.float64)
         failed = C.c_int64()

@@ -111,6 +111,10 @@ class LiuWestResampler(Resampler):
             # straight from the weights: the CDF is scanned chunk-wise inside the sampler, never in HBM
             self._epoch += 1
             defer = bool(getattr(self, "_defer_failed_check", False))
+            if particle_dist.n_particles > self._segment_limit:
+                x_new, n_failed = self._segmented_resample(eng, desc, x_in, particle_dist._w, a, mean, S, n_particles)
+                return ParticleDistribution._from_device(eng, x_new, None, norm=float(n_particles),
+                                                         sumsq=float(n_particles))
             self._arm_update_sums(particle_dist)
             x_new, n_failed = eng.lw_resample_philox(desc, self._postselect, x_in, particle_dist._w, norm, a,
                                                      mean, S, n_particles, self._seed, self._epoch,
@@ -145,10 +149,47 @@ class LiuWestResampler(Resampler):
         `lw_resample_philox` call that follows, which then starts at the sampling kernel."""
         if not (self._device_rng and getattr(model, "_native", False)):
             return
+        if particle_dist.n_particles > self._segment_limit:
+            return                                   # segmented resample: every segment runs its own prefix
         n_out = (particle_dist.n_particles if self._default_n_particles is None else self._default_n_particles)
         self._arm_update_sums(particle_dist)
         particle_dist._eng.lw_resample_prepare(particle_dist._w, particle_dist.n_particles, particle_dist._norm,
                                                int(n_out), self._seed, self._epoch + 1)
+
+    # The LDS-bucketed sampler handles clouds of up to 8192 chunks of 4096 particles.  A larger cloud is resampled
+    # as a handful of contiguous segments, exactly like shards on several GPUs (parallel.py): the number of
+    # children per segment is one multinomial draw over the segment weights (host Philox, keyed by seed and
+    # epoch), then every segment draws its children from its own weights -- the same joint law as one global
+    # multinomial -- into its slice of the new cloud.
+    _segment_limit = 8192 * 4096
+
+    def _segmented_resample(self, eng, desc, x_in, w, a, mean, S, n_out):
+        n_in = x_in.shape[1]
+        n_seg = -(-n_in // self._segment_limit)
+        seg = -(-n_in // n_seg)
+        seg = -(-seg // 4096) * 4096                                  # whole chunks: 16-byte aligned slices
+        bounds = [(g * seg, min(n_in, (g + 1) * seg)) for g in range(n_seg) if g * seg < n_in]
+        if w is None:
+            W = np.array([b - a0 for a0, b in bounds], dtype=np.float64)
+        else:
+            W = np.array([eng.weight_stats(w[a0:b], 1.0).sum for a0, b in bounds])
+        gen = np.random.Generator(np.random.Philox(key=self._seed & (2 ** 64 - 1), counter=[int(self._epoch), 2, 0, 0]))
+        T = gen.multinomial(int(n_out), W / W.sum())
+        x_new = eng.empty(x_in.shape[0], n_out)
+        off, n_failed = 0, 0
+        for g, (a0, b) in enumerate(bounds):
+            t_g = int(T[g])
+            if t_g == 0:
+                continue
+            _, f = eng.lw_resample_philox(desc, self._postselect, x_in[:, a0:b], None if w is None else w[a0:b],
+                                          float(W[g]), a, mean, S, t_g, self._seed + 0x9E3779B97F4A7C15 * (g + 1),
+                                          self._epoch, self._maxiter, sync=True, out=x_new[:, off:off + t_g])
+            n_failed += f
+            off += t_g
+        if n_failed:
+            warnings.warn("Liu-West resampling failed to find valid models for {} particles within "
+                          "{} iterations.".format(n_failed, self._maxiter), ResamplerWarning)
+        return x_new, 0
 
     def _flush_failed_warning(self, synchronize=False):
         """Emit the deferred 'failed to find valid models' ResamplerWarning, if one is due."""

@@ -1603,3 +1603,47 @@ def test_region_estimators_g13(qi, golden):
         assert np.all(v20.var(axis=0) < v95.var(axis=0))
         A, c = upd.region_est_ellipsoid(level=0.5)
         np.testing.assert_allclose(np.round(c), mean, atol=0.5)
+
+
+def test_segmented_resample_beyond_bucket_limit(qi, eng):
+    """Clouds larger than the bucketed sampler's 8192 x 4096 limit are resampled segment by segment with a
+    multinomial split of the children (resamplers._segmented_resample); exercised here with a tiny limit."""
+    rs = np.random.RandomState(6)
+    n = 100001
+    seg_of = np.minimum(np.arange(n) // 20480, 4)                    # 5 segments at the patched limit
+    x = (seg_of + rs.uniform(0.1, 0.9, n))[:, None]                   # segment g owns the values in (g, g + 1)
+    w = rs.random_sample(n) ** 2 * (1.0 + seg_of)                     # heavier late segments
+    w /= w.sum()
+    model = qi.SimplePrecessionModel()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        pd = qi.ParticleDistribution(particle_locations=x, particle_weights=w)
+        res = qi.LiuWestResampler(a=1.0, h=1e-9, device_rng=True, seed=31)
+        res._segment_limit = 20480
+        n_out = 120000
+        new = res(model, pd, n_particles=n_out)
+        out = new.particle_locations[:, 0]
+        assert out.shape == (n_out,) and new.n_ess == pytest.approx(n_out)
+        # children per segment ~ Multinomial(n_out; W_g): a = 1, h ~ 0 keeps every child inside its ancestor's unit interval
+        counts = np.bincount(np.floor(out).astype(int), minlength=5)
+        Wg = np.bincount(seg_of, weights=pd.particle_weights, minlength=5)
+        assert counts.sum() == n_out
+        assert np.all(np.abs(counts - n_out * Wg) < 5 * np.sqrt(n_out * Wg * (1 - Wg)) + 1)
+        # inside a segment the children follow the segment's weights: compare weighted and resampled means
+        for g_ in range(5):
+            sel = seg_of == g_
+            m_ref = np.average(x[sel, 0], weights=pd.particle_weights[sel])
+            m_got = out[np.floor(out).astype(int) == g_].mean()
+            assert abs(m_got - m_ref) < 6 * x[sel, 0].std() / np.sqrt(counts[g_])
+        # same seed / epoch -> same cloud; the unsegmented path on the same cloud agrees in distribution
+        res2 = qi.LiuWestResampler(a=1.0, h=1e-9, device_rng=True, seed=31)
+        res2._segment_limit = 20480
+        np.testing.assert_array_equal(res2(model, pd, n_particles=n_out).particle_locations[:, 0], out)
+        plain = qi.LiuWestResampler(a=1.0, h=1e-9, device_rng=True, seed=31)(model, pd, n_particles=n_out)
+        assert abs(plain.est_mean()[0] - new.est_mean()[0]) < 6 * np.sqrt(new.est_covariance_mtx()[0, 0] / n_out)
+        # through an updater (the n_ess-triggered path with its deferred warning plumbing)
+        upd = qi.SMCUpdater(model, 60000, qi.UniformDistribution([0.2, 0.8]), device_rng=True, seed=2)
+        upd.resampler._segment_limit = 16384
+        for k in range(25):
+            upd.update(k & 1, np.array([1.125 ** (2 * k)]))
+        assert upd.resample_count > 2 and upd.n_particles == 60000 and float(upd._x.min().item()) > 0
