@@ -220,7 +220,7 @@ template <> struct Model<QSMC_MODEL_UNKNOWN_T2> {
 template <int KIND, bool POW>
 __host__ __device__ __forceinline__ double model_lik(const double *p, const ExpArgs &e, int64_t o) {
     const double L = Model<KIND>::lik(p, e, o);
-    if (POW) return pow(L, e.lik_pow);
+    if (POW) return L > 0.0 ? exp(e.lik_pow * log(L)) : pow(L, e.lik_pow);     // (see rb_pow: same error argument)
     return L;
 }
 
