@@ -1647,3 +1647,34 @@ def test_segmented_resample_beyond_bucket_limit(qi, eng):
         for k in range(25):
             upd.update(k & 1, np.array([1.125 ** (2 * k)]))
         assert upd.resample_count > 2 and upd.n_particles == 60000 and float(upd._x.min().item()) > 0
+
+
+def test_profiling_ring(qi, eng):
+    """qsmc_set_profiling / qsmc_profile_read (bench.py's roofline clock): every stride-th launch of each kind is
+    timed, tags tell the kernel kinds apart, reading clears the ring, durations are plausible."""
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        upd = qi.SMCUpdater(qi.SimplePrecessionModel(), 400000, qi.UniformDistribution([0, 1]), device_rng=True, seed=1)
+        upd.update(0, np.array([1.0]))
+        try:
+            eng.set_profiling(1)
+            for k in range(12):
+                upd.update(k & 1, np.array([2.0 + k]), check_for_resample=False)
+            upd.resample()
+            upd.update(0, np.array([3.0]), check_for_resample=False)        # implicit weights after the resample
+            assert eng.last_update_kernel_ms() > 0                           # the most recent update launch
+            ms, tags = eng.profile_read()
+            assert list(tags[:12]) == [0] * 12 and tags[12] == 1 and tags[13] == 2
+            assert np.all(ms > 0) and np.all(ms < 5.0)
+            ms2, _ = eng.profile_read()
+            assert len(ms2) == 0                                             # reading cleared the ring
+            eng.set_profiling(4)
+            for k in range(12):
+                upd.update(k & 1, np.array([2.0 + k]), check_for_resample=False)
+            ms, tags = eng.profile_read()
+            assert len(ms) == 3 and set(tags) == {0}                         # launches 1, 5, 9 of the kind
+        finally:
+            eng.set_profiling(0)
+        for k in range(3):
+            upd.update(k & 1, np.array([2.0 + k]), check_for_resample=False)
+        assert len(eng.profile_read()[0]) == 0
