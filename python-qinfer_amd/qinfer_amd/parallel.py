@@ -406,7 +406,8 @@ class ParticleShardGroup:
             stay = drift <= self.rebalance_tol and totals.min() > 0
         else:
             totals, stay = None, False
-        if stay:
+        big = n_local > resampler._segment_limit        # beyond the bucketed sampler's single pass: segments (resamplers.py)
+        if stay and not big:
             # children stay with their ancestor: this rank draws its T_h particles, nothing moves.  The
             # weight-only prefix (chunk sums, multinomial chunk counts) is queued before mean / cov / sqrtm
             resampler._arm_update_sums(updater)
@@ -422,7 +423,17 @@ class ParticleShardGroup:
         if not np.isfinite(S_err):
             raise ResamplerError("Infinite error in computing the square root of the covariance "
                                  "matrix. Check that n_ess is not too small.")
-        if stay:
+        if stay and big:
+            resampler._epoch = epoch                   # (the segment split is keyed by the resampler's seed and epoch)
+            seed0, resampler._seed = resampler._seed, seed_r
+            try:
+                x_new, n_failed = resampler._segmented_resample(eng, model._native_desc(), updater._x, updater._w, a,
+                                                                mean, S, int(totals[self.rank]))
+            finally:
+                resampler._seed = seed0
+            defer = False
+            self.last_shard_sizes = totals
+        elif stay:
             x_new, n_failed = eng.lw_resample_philox(model._native_desc(), resampler._postselect, updater._x,
                                                      updater._w, float(W[self.rank]), a, mean, S,
                                                      int(totals[self.rank]), seed_r, epoch, resampler._maxiter,

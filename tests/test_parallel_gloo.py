@@ -206,7 +206,7 @@ def test_resample_protocol_gloo(tmp_path):
 # GPU legs: the full sharded SMCUpdater (HIP kernels + protocol).  One GPU box has one device, so
 # (i) two processes share it and talk over gloo, (ii) a world-size-1 RCCL group checks the nccl path.
 def _check_sharded_updater(comm, rank, world, tmpdir):
-    for variant in ("local", "rebalance-always", "mixed"):
+    for variant in ("local", "local-segmented", "rebalance-always", "mixed"):
         _check_sharded_updater_variant(comm, rank, world, tmpdir, variant)
 
 
@@ -216,7 +216,7 @@ def _check_sharded_updater_variant(comm0, rank, world, tmpdir, variant):
     import qinfer_amd as qi
     from qinfer_amd.parallel import ParticleShardGroup
     torch.cuda.set_device(0)
-    if variant == "local":
+    if variant in ("local", "local-segmented"):
         comm = comm0                                  # children stay with their ancestor, sizes float
     elif variant == "rebalance-always":
         comm = ParticleShardGroup(seed=1234, rebalance_tol=-1.0)   # every resample takes the minimal-movement exchange
@@ -230,6 +230,8 @@ def _check_sharded_updater_variant(comm0, rank, world, tmpdir, variant):
         warnings.simplefilter("ignore")
         upd = qi.SMCUpdater(qi.SimplePrecessionModel(), n_local, qi.UniformDistribution([0, 1]),
                             device_rng=True, seed=5, comm=comm)
+        if variant == "local-segmented":              # shards beyond the sampler's single pass: segments inside the shard
+            upd.resampler._segment_limit = 16384
         assert upd.n_particles == n_local and upd.n_particles_global == n_local * world
         np.testing.assert_allclose(upd.n_ess, n_local * world, rtol=1e-12)
         for k in range(50):
@@ -240,7 +242,7 @@ def _check_sharded_updater_variant(comm0, rank, world, tmpdir, variant):
         assert np.array_equal(rows[0], rows[r]), "ranks disagree on the global quantities"
     sizes = comm.gather_rows(np.array([float(upd.n_particles)]))[:, 0]
     assert sizes.sum() == n_local * world == upd.n_particles_global      # the global count is conserved
-    if variant == "local":
+    if variant in ("local", "local-segmented"):
         assert comm.n_rebalances == 0 and np.abs(sizes - n_local).max() < 0.05 * n_local
         if world > 1:
             assert np.abs(sizes - n_local).max() > 0                      # sizes do float
