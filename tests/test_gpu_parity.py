@@ -1678,3 +1678,24 @@ def test_profiling_ring(qi, eng):
         for k in range(3):
             upd.update(k & 1, np.array([2.0 + k]), check_for_resample=False)
         assert len(eng.profile_read()[0]) == 0
+
+
+def test_cloud_beyond_single_pass_limit(qi, eng):
+    """N = 4e7 > 8192 x 4096: the real segmented path (two segments), no patched limit."""
+    n = 40_000_000
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        upd = qi.SMCUpdater(qi.SimplePrecessionModel(), n, qi.UniformDistribution([0, 1]), device_rng=True, seed=4)
+        for k, t in enumerate((3.0, 7.0, 12.0)):
+            upd.update(k & 1, np.array([t]), check_for_resample=False)
+        m0, c0 = upd.est_mean(), upd.est_covariance_mtx()
+        upd.resampler = qi.LiuWestResampler(a=0.98, postselect=False, device_rng=True, seed=9)
+        upd.resample()
+        assert upd.n_particles == n and upd.n_ess == pytest.approx(n, rel=1e-12)
+        m1, c1 = upd.est_mean(), upd.est_covariance_mtx()
+        assert abs(m1[0] - m0[0]) < 6 * np.sqrt(c0[0, 0] / n)          # Liu-West keeps the first two moments
+        assert abs(c1[0, 0] / c0[0, 0] - 1) < 3e-3
+        upd.update(1, np.array([15.0]))
+        assert np.isfinite(upd.est_mean()).all()
+    del upd
+    eng.torch.cuda.empty_cache()
