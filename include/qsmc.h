@@ -182,7 +182,8 @@ int qsmc_weight_stats(qsmc_handle_t h, const double *w, int64_t n, double norm,
  * memory segment (POSIX shm mapped by every rank; layout in qinfer_amd/parallel.py: HostExchange): call number k
  * (1, 2, ...; the same on every rank) writes vec into this rank's slot of bank k & 1, publishes k, spins until
  * every rank has published k, and copies the rank-ordered rows to rows_out[world][n].  No GPU involved: this
- * is the per-datum collective of the sharded updater (a handful of sums per rank), which is pure latency.
+ * is the per-datum collective of the sharded updater (a handful of sums per rank), which is pure latency;
+ * it stands where the reference gathers the whole likelihood array from its engines (parallel.py:216-224).
  * Returns QSMC_ERR_UNSUPPORTED if a peer has not arrived within timeout_s. */
 int qsmc_host_allgather(void *segment, int32_t rank, int32_t world, int32_t max_len, uint64_t k, const double *vec,
                         int32_t n, double *rows_out, double timeout_s);
@@ -263,7 +264,8 @@ int qsmc_lw_resample_philox(qsmc_handle_t h, const qsmc_model_t *model, int32_t 
                             double *x_out, int64_t ldx_out, int64_t *n_failed_host,
                             qsmc_stream_t stream);
 
-/* Every qsmc_update_fused also leaves the sum of the new weights per kernel tile (2048 particles) in the
+/* (resamplers.py:308-316, the cumsum the reference takes before searching)
+ * Every qsmc_update_fused also leaves the sum of the new weights per kernel tile (2048 particles) in the
  * handle and bumps a generation counter (qsmc_update_token).  A caller that KNOWS the weights it is about
  * to resample are exactly the w_out of the update with that token -- untouched since -- may say so with
  * qsmc_lw_use_update_sums(token) right before qsmc_lw_resample_prepare / qsmc_lw_resample_philox: the
