@@ -188,6 +188,14 @@ int qsmc_weight_stats(qsmc_handle_t h, const double *w, int64_t n, double norm,
 int qsmc_host_allgather(void *segment, int32_t rank, int32_t world, int32_t max_len, uint64_t k, const double *vec,
                         int32_t n, double *rows_out, double timeout_s);
 
+/* The same exchange with the reduction done here: tot_out[j] = sum over ranks, added in rank order (identical
+ * bits on every rank), of entry j -- except entry min_index (>= 0), which is the minimum over ranks (NaN
+ * propagates).  rows_out[world][n] still receives the rows (entry 0 of each row is that shard's weight total,
+ * the input of the next resample plan).  The sharded SMCUpdater.update makes exactly one such call per datum
+ * (smc.py:388-457: norm_scale, n_ess, the zero-weight guards; distributions.py:337-453: the moment sums). */
+int qsmc_host_allreduce(void *segment, int32_t rank, int32_t world, int32_t max_len, uint64_t k, const double *vec,
+                        int32_t n, int32_t min_index, double *rows_out, double *tot_out, double timeout_s);
+
 /* Sorting and searching for the posterior read-outs (est_credible_region, distributions.py:558-614;
  * posterior_marginal, smc.py:672-716).  qsmc_argsort: stable radix sort (rocPRIM) of n < 2^31 keys, ascending or
  * descending; keys_out and idx_out (the permutation, int64) are device arrays of n entries.

@@ -2885,6 +2885,29 @@ int qsmc_host_allgather(void *segment, int32_t rank, int32_t world, int32_t max_
     return QSMC_OK;
 }
 
+// The same exchange, reduced: tot_out[j] = rows[0][j] + rows[1][j] + ... in rank order (so every rank gets the
+// same bits), except entry min_index (if >= 0), which is the minimum over ranks.  One call per datum of the
+// sharded updater: normaliser, sum of squares, weight minimum, bad count and the fused moment sums together.
+int qsmc_host_allreduce(void *segment, int32_t rank, int32_t world, int32_t max_len, uint64_t k, const double *vec,
+                        int32_t n, int32_t min_index, double *rows_out, double *tot_out, double timeout_s) {
+    if (!tot_out) return QSMC_ERR_INVALID;
+    const int rc = qsmc_host_allgather(segment, rank, world, max_len, k, vec, n, rows_out, timeout_s);
+    if (rc != QSMC_OK) return rc;
+    for (int j = 0; j < n; ++j) {
+        double acc = rows_out[j];
+        if (j == min_index) {
+            for (int r = 1; r < world; ++r) {
+                const double v = rows_out[(size_t)r * n + j];
+                acc = (v < acc || v != v) ? v : acc;            // a NaN weight minimum must reach every rank's guard
+            }
+        } else {
+            for (int r = 1; r < world; ++r) acc += rows_out[(size_t)r * n + j];
+        }
+        tot_out[j] = acc;
+    }
+    return QSMC_OK;
+}
+
 // ---- host: sqrtm_psd by cyclic Jacobi (utils.py:593-607) --------------------------------------
 int qsmc_sqrtm_psd(const double *A, int32_t d, double scale, double *S_out, double *err_out) {
     if (!A || !S_out || d < 1 || d > 64) return QSMC_ERR_INVALID;

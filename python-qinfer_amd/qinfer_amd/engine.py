@@ -153,7 +153,7 @@ class Engine:
             "qsmc_update_fused")
         if not sync:
             return None
-        if not moments:
+        if not moments or moments == "raw":         # "raw": the packed sums stay in self._mom[d] for the caller
             return self._st
         mom = self._mom[d]
         return self._st, mom[:d].copy(), self._unpack_upper(mom[d:], d)

@@ -76,15 +76,48 @@ class HostExchange:
         self._pay = np.ndarray((2, world, max_len), dtype=np.float64, buffer=self._shm.buf, offset=seq_bytes)
         self._k = 0
         # the same protocol in C (libqsmc_hip.so, host code) when the library is loadable; pure Python otherwise
-        self._c_call, self._addr, self._anchor = None, None, None
+        self._c_call, self._c_reduce, self._addr, self._anchor = None, None, None, None
+        self._reduce_bufs = {}
         try:
             import ctypes
             from . import _native
             self._c_call = _native.load().qsmc_host_allgather
+            self._c_reduce = _native.load().qsmc_host_allreduce
             self._anchor = ctypes.c_char.from_buffer(self._shm.buf)      # keeps the mapping's address valid
             self._addr = ctypes.addressof(self._anchor)
         except Exception:  # noqa: BLE001  (CPU-only test environments without the built library)
-            self._c_call = None
+            self._c_call = self._c_reduce = None
+
+    def all_reduce(self, n, min_index=-1):
+        """Per-datum form: returns (vec, rows, tot, run) for payloads of n doubles.  Fill `vec` in place and
+        call run(): `rows` (world, n) then holds every rank's vec and `tot` their rank-ordered sum (entry
+        min_index: the minimum).  The three arrays are REUSED by the next run(): copy what must outlive it.
+        In C when the library is loadable (one foreign call per datum, no allocation), NumPy otherwise."""
+        key = (n, min_index)
+        hit = self._reduce_bufs.get(key)
+        if hit is not None:
+            return hit
+        if n > self.max_len:
+            raise ValueError("HostExchange payload too long")
+        vec, rows, tot = np.zeros(n), np.zeros((self.world, n)), np.zeros(n)
+        if self._c_reduce is not None:
+            call, addr, rank, world, max_len, timeout = (self._c_reduce, self._addr, self.rank, self.world,
+                                                         self.max_len, self.timeout)
+            pv, pr, pt = vec.ctypes.data, rows.ctypes.data, tot.ctypes.data
+
+            def run():
+                self._k += 1
+                if call(addr, rank, world, max_len, self._k, pv, n, min_index, pr, pt, timeout) != 0:
+                    raise RuntimeError("HostExchange: a peer did not arrive within {} s".format(timeout))
+        else:
+            def run():
+                rows[...] = self.all_gather(vec)
+                np.sum(rows, axis=0, out=tot)
+                if min_index >= 0:
+                    col = rows[:, min_index]
+                    tot[min_index] = np.nan if np.isnan(col).any() else col.min()
+        hit = self._reduce_bufs[key] = (vec, rows, tot, run)
+        return hit
 
     def all_gather(self, vec):
         """vec: 1-D float64 (len <= max_len) -> (world, len) array, rank-ordered, identical everywhere."""
@@ -121,7 +154,8 @@ class HostExchange:
         if shm is None:
             return
         self._seq = self._pay = None
-        self._anchor = self._c_call = None               # release the buffer export before unmapping
+        self._anchor = self._c_call = self._c_reduce = None    # release the buffer export before unmapping
+        self._reduce_bufs = {}
         try:
             shm.close()
             if self._owner:
@@ -285,7 +319,18 @@ class ParticleShardGroup:
         return float(tot[0]), float(tot[1]), float(rows[:, 2].min()), float(tot[3])
 
     def allreduce_update_stats(self, eng, s, ss, mn, n_bad, extra=None):
-        vec = np.empty(4 + (0 if extra is None else len(extra)))
+        n = 4 + (0 if extra is None else len(extra))
+        if self._host is not None and n <= self._host.max_len:
+            # the per-datum call: preallocated buffers, the gather and the rank-ordered sums in one C call
+            vec, rows, tot, run = self._host.all_reduce(n, 2)
+            vec[0], vec[1], vec[2], vec[3] = s, ss, mn, n_bad
+            if extra is not None:
+                vec[4:] = extra
+            run()
+            self.last_shard_sums = rows[:, 0].copy()
+            self.last_extra = tot[4:].copy()
+            return tot.item(0), tot.item(1), tot.item(2), tot.item(3)
+        vec = np.empty(n)
         vec[0], vec[1], vec[2], vec[3] = s, ss, mn, n_bad
         if extra is not None:
             vec[4:] = extra

@@ -278,9 +278,7 @@ class SMCUpdater(ParticleDistribution):
                 # small all-gather (shared memory on one host, else the backend's) makes them global
                 n_mom = d + d * (d + 1) // 2 if d <= 4 else 0
                 st = eng.update_fused(self._desc, self._x, self._w, w_out, self._norm, exps[0],
-                                      _as_int_outcome(outcome), moments=bool(n_mom))
-                if n_mom:
-                    st = st[0]
+                                      _as_int_outcome(outcome), moments="raw" if n_mom else False)
                 norm, sumsq, wmin, n_bad = self._comm.allreduce_update_stats(
                     eng, st.sum, st.sumsq, st.min, st.n_bad, eng._mom[d] if n_mom else None)
                 self._shard_sums = self._comm.last_shard_sums

@@ -144,6 +144,38 @@ def _check_host_exchange(comm, rank, world, tmpdir):
         if k % 500 == rank:                              # desynchronise the ranks now and then
             import time
             time.sleep(0.01)
+    # the per-datum reduced form: rank-ordered sums, the minimum in one slot, rows kept; interleaved with
+    # plain gathers (one shared call counter); the C loop and the NumPy fallback give the same bits
+    host = comm._host
+    for use_c in (True, False):
+        saved = host._c_reduce
+        if not use_c:
+            host._c_reduce, host._reduce_bufs = None, {}
+        for k in range(400):
+            n = 4 + (k % 3) * 5
+            vec, rows, tot, run = host.all_reduce(n, 2)
+            vec[:] = (np.arange(n) + 0.1 * k) * (1.0 + 0.37 * rank)
+            vec[2] = float((rank * 7 + k) % world) - 0.25 * k
+            if k == 100:
+                vec[2] = np.nan if rank == world - 1 else 1.0
+            run()
+            want = np.stack([(np.arange(n) + 0.1 * k) * (1.0 + 0.37 * r) for r in range(world)])
+            want[:, 2] = [float((r * 7 + k) % world) - 0.25 * k for r in range(world)]
+            if k == 100:
+                want[:, 2] = [1.0] * (world - 1) + [np.nan]
+            np.testing.assert_array_equal(rows, want)
+            acc = want[0].copy()
+            for r in range(1, world):
+                acc += want[r]
+            acc[2] = np.nan if k == 100 else want[:, 2].min()
+            np.testing.assert_array_equal(tot, acc)
+            if k % 50 == 0:
+                np.testing.assert_array_equal(host.all_gather(np.array([float(rank)]))[:, 0], np.arange(world))
+        host._c_reduce, host._reduce_bufs = saved, {}
+    s_, ss_, mn_, nb_ = comm.allreduce_update_stats(None, 1.0 + rank, 2.0, -float(rank), 0.0, np.array([5.0 * rank]))
+    assert (s_, ss_, mn_, nb_) == (sum(1.0 + r for r in range(world)), 2.0 * world, -float(world - 1), 0.0)
+    assert comm.last_extra[0] == 5.0 * sum(range(world))
+    np.testing.assert_array_equal(comm.last_shard_sums, 1.0 + np.arange(world))
     # gather_rows routes small vectors through it, large ones through the backend -- same answer
     import torch
     small = comm.gather_rows(np.array([rank + 0.5, 2.0]))
