@@ -112,11 +112,108 @@ def _pair_normal(n_idx, seed, epoch, slot):
     return np.where(n_idx & 1, zb, za)
 
 
+_STIRLING_SMALL = (0.08106146679532726, 0.0413406959554093, 0.02767792568499834, 0.020790672103765093,
+                   0.016644691189821193, 0.013876128823070748, 0.01189670994589177, 0.010411265261972096,
+                   0.009255462182712733, 0.00833056343336287)
+
+
+def _stirling_tail(k):
+    """ln k! - [(k + 1/2) ln(k + 1) - (k + 1) + ln(2 pi) / 2]: table for k < 10, five terms of the series beyond."""
+    if k < 10.0:
+        return _STIRLING_SMALL[int(k)]
+    rx = 1.0 / (k + 1.0)
+    r2 = rx * rx
+    return (1.0 / 12.0 - (1.0 / 360.0 - (1.0 / 1260.0 - (1.0 / 1680.0 - 1.0 / 1188.0 * r2) * r2) * r2) * r2) * rx
+
+
+def poisson_draw(mu, node, seed, epoch):
+    """X ~ Poisson(mu) exactly as poisson_draw of the device library (csrc/qsmc_kernels.hip): sequential search of
+    the cdf for mu < 10, PTRS (W. Hoermann, Insurance: Mathematics and Economics 12 (1993) 39: transformed
+    rejection with squeeze) otherwise; attempt t of chunk `node` consumes Philox block (node | t << 32, round 0,
+    slot 0) and the first accepted attempt is the draw.  Scalar floats in the device's order of operations."""
+    mu = float(mu)
+    if not (mu > 0.0):
+        return 0
+    f = float
+
+    def block(t):
+        u, v = uniforms(np.array([node | (t << 32)], dtype=np.int64), seed, epoch, 0, 0)
+        return f(u[0]), f(v[0])
+
+    def ln(x):
+        return f(np.log(x)) if x > 0.0 else -np.inf
+
+    if mu < 10.0:
+        U, _ = block(0)
+        pk = f(np.exp(-mu))
+        cdf, X = pk, 0.0
+        while U > cdf and X < 200.0:
+            X += 1.0
+            pk = pk * mu / X
+            cdf += pk
+        return int(X)
+    smu = f(np.sqrt(mu))
+    lmu = ln(mu)
+    b = 0.931 + 2.53 * smu
+    a = -0.059 + 0.02483 * b
+    linva = ln(1.1239 + 1.1328 / (b - 3.4))
+    vr = 0.9277 - 3.6224 / (b - 2.0)
+    for t in range(4096):
+        U, V = block(t)
+        u = U - 0.5
+        us = 0.5 - abs(u)
+        if us == 0.0:
+            continue                                             # (k = -inf on the device: rejected)
+        kk = f(np.floor((2.0 * a / us + b) * u + mu + 0.43))
+        if us >= 0.07 and V <= vr:
+            return int(kk)
+        if kk < 0.0 or (us < 0.013 and V > us):
+            continue
+        lhs = ln(V) + linva - ln(a / (us * us) + b)
+        lgk = (kk + 0.5) * ln(kk + 1.0) - (kk + 1.0) + 0.91893853320467274178 + _stirling_tail(kk)
+        if lhs <= -mu + kk * lmu - lgk:
+            return int(kk)
+    return 0
+
+
+def poissonised_counts(edges, n_out, seed, epoch, margin=5.0):
+    """Multinomial(n_out; chunk masses) the device's way (k_bucket_poisson + k_bucket_topup_plan): independent
+    Poisson((n_out - margin sqrt(n_out)) p_c) per chunk, then the shortfall as categorical draws against the chunk
+    edges (word j & 1 of Philox block (j >> 1, round 0, slot 3)) -- or, should the Poisson total overshoot, the
+    surplus removed item by item uniformly at random (word 0 of block (i, round 0, slot 4)).
+    edges[c] = upper CDF edge of chunk c."""
+    edges = np.asarray(edges, dtype=np.float64)
+    chunks = len(edges)
+    lam = max(float(n_out) - margin * float(np.sqrt(float(n_out))), 0.0)
+    lo = np.concatenate([[0.0], edges[:-1]])
+    mass = edges - lo
+    total = float(edges[-1])
+    counts = np.zeros(chunks, dtype=np.int64)
+    for c in range(chunks):
+        if mass[c] > 0.0 and total > 0.0:
+            counts[c] = poisson_draw(lam * float(mass[c]) / total, c, seed, epoch)
+    T = int(counts.sum())
+    if T < n_out:
+        u = _pair_word(np.arange(n_out - T), seed, epoch, 3)
+        c_of = np.minimum(np.searchsorted(edges, u, side='right'), chunks - 1)
+        counts += np.bincount(c_of, minlength=chunks)
+    else:
+        left = T
+        for i in range(T - n_out):
+            u, _ = uniforms(np.array([i], dtype=np.int64), seed, epoch, 0, 4)
+            target = min(int(float(u[0]) * float(left)), left - 1)
+            c = int(np.searchsorted(np.cumsum(counts), target, side='right'))
+            counts[c] -= 1
+            left -= 1
+    return counts
+
+
 def liu_west_philox_bucketed(w, x, valid_fn, a, h, seed, epoch, n_out, maxiter=1000, postselect=True,
-                             mean=None, cov=None, zero_cov_comp=1e-10, cdf=None):
-    """Oracle of the bucketed device-RNG resampler (k_bucket_count / _plan / _sample).  Outputs are
+                             mean=None, cov=None, zero_cov_comp=1e-10, cdf=None, margin=5.0):
+    """Oracle of the bucketed device-RNG resampler (k_bucket_poisson / _topup_plan / _sample).  Outputs are
     ordered by ancestor CHUNK.  Stream layout (round 0, two outputs per Philox block):
-      slot 0: chunk draw of output i; slot 1: within-chunk position of slot o (independent);
+      slot 0: the Poisson chunk counts, slots 3 / 4 their top-up / removal (poissonised_counts); slot 1:
+      within-chunk position of slot o (independent of the counts);
       slot 2: normal n = o * d + q.  Retries (round r >= 1) are per output and redraw a GLOBAL
       ancestor from block (o, r, 0) and normals from (o, r, 1 + q // 2)."""
     import np_oracle as orc
@@ -131,9 +228,7 @@ def liu_west_philox_bucketed(w, x, valid_fn, a, h, seed, epoch, n_out, maxiter=1
     edge_idx = np.minimum((np.arange(chunks) + 1) * BUCKET_CHUNK, N) - 1
     edges = cdf[edge_idx]
     ids = np.arange(n_out)
-    u_chunk = _pair_word(ids, seed, epoch, 0)
-    chunk_of = np.minimum(np.searchsorted(edges, u_chunk, side='right'), chunks - 1)
-    counts = np.bincount(chunk_of, minlength=chunks)
+    counts = poissonised_counts(edges, n_out, seed, epoch, margin=margin)
     c_of_slot = np.repeat(np.arange(chunks), counts)                 # chunk of every output slot
     u_pos = _pair_word(ids, seed, epoch, 1)
     lo = np.where(c_of_slot == 0, 0.0, edges[np.maximum(c_of_slot - 1, 0)])

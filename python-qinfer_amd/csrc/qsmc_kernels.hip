@@ -46,6 +46,7 @@ struct qsmc_ctx {
     double *rs_offsets;            // resampler: chunk offsets (own buffer: survives other calls' scratch use)
     size_t rs_offsets_cap;
     size_t count_lds_granted;      // dynamic LDS already opted into for k_bucket_count on this device
+    size_t topup_lds_granted;      // ... and for k_bucket_topup
     void *sort_tmp;                // rocPRIM temporary storage + key/value staging for qsmc_argsort
     size_t sort_tmp_cap;           // in bytes
     double *tile_sums;             // sum of w' per update-kernel tile, written by the last qsmc_update_fused
@@ -1117,10 +1118,12 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_resample_philox(
 // The direct kernel above does one 23-level binary search of the 80 MB CDF per output particle:
 // ~1.2e8 scattered line requests at N = 1e7 (measured 1.4 ms, 83 % of GPU time in round-1
 // profile a).  Output particles are exchangeable, so instead:
-//   A  k_bucket_count    every output draws u_i (Philox) and is binned by CDF CHUNK (4096 source
-//                        particles; the chunk edges are CDF entries, searched in LDS) -> exact
-//                        Multinomial(N; W_chunk) counts, via per-workgroup LDS histograms;
-//   B  k_bucket_reduce / k_bucket_plan   column sums + exclusive scans: first output slot of each
+//   A  chunk counts      how many outputs descend from each CDF CHUNK (4096 source particles): exact
+//                        Multinomial(N; W_chunk) counts.  k_bucket_poisson / k_bucket_topup: independent Poisson
+//                        draws per chunk plus a short categorical top-up (see "Poissonisation" below);
+//                        k_bucket_count / k_bucket_reduce (QSMC_COUNT_BY_DRAWS=1, the first implementation):
+//                        every output draws u_i and is binned against the chunk edges in LDS;
+//   B  k_bucket_plan_total / k_bucket_plan   exclusive scans: first output slot of each
 //                        chunk and a work list that splits heavy chunks into <= BUCKET_CAP outputs;
 //   C  k_bucket_sample   one workgroup per work item scans ITS chunk of the weights into LDS (32 KB of CDF),
 //                        draws the within-chunk position from an independent Philox word (given
@@ -1236,7 +1239,9 @@ __device__ __forceinline__ int guided_upper_bound(const double *a, int m, const 
 }
 
 // Philox stream layout of the bucketed resampler (round 0), two outputs per Philox block:
-//   slot 0: block (i >> 1), word (i & 1)          chunk draw of output i          (k_bucket_count)
+//   slot 0: block (c | t << 32)                   attempt t of chunk c's Poisson count (k_bucket_poisson)
+//           [QSMC_COUNT_BY_DRAWS: block (i >> 1), word (i & 1) = chunk draw of output i (k_bucket_count)]
+//   slot 3: block (j >> 1), word (j & 1)          top-up draw j;  slot 4: block (i), word 0: removal i
 //   slot 1: block (o >> 1), word (o & 1)          within-chunk position of slot o (k_bucket_sample)
 //   slot 2: block (n >> 1), Box-Muller comp (n&1) n = o * d + q, q-th normal of slot o
 // retries (round r >= 1) are per output: block (o, r, 0).u0 = global ancestor, (o, r, 1 + q/2) normals.
@@ -1276,35 +1281,114 @@ __global__ __launch_bounds__(BUCKET_COUNT_THREADS) void k_bucket_count(
     for (int c = threadIdx.x; c < chunks; c += blockDim.x) row[c] = cnt[c];
 }
 
-// counts[c] = sum_g hist[g][c].  A workgroup takes 64 chunks; its four waves each sum a quarter of the rows
-// (coalesced 256-byte row segments), LDS combines them: 4x the workgroups and a quarter of the dependent
-// loads per thread of the one-thread-per-chunk version (8.8 -> ~4 us, the launch floor).
-__global__ __launch_bounds__(QSMC_BLOCK) void k_bucket_reduce(const unsigned int *__restrict__ hist, int rows,
-                                                              int chunks, unsigned int *__restrict__ counts) {
-    __shared__ unsigned int part[QSMC_WAVES_PER_BLOCK][QSMC_WAVE];
-    const int lane = threadIdx.x & (QSMC_WAVE - 1);
-    const int wave = threadIdx.x / QSMC_WAVE;
-    const int c = blockIdx.x * QSMC_WAVE + lane;
-    unsigned int s = 0;
-    if (c < chunks) {
-#pragma unroll 16
-        for (int g = wave; g < rows; g += QSMC_WAVES_PER_BLOCK) s += hist[(size_t)g * chunks + c];
+// ---------------------------------------------------------------------------------------------
+// Chunk counts without drawing one uniform per output (k_bucket_count + k_bucket_reduce: 32 us at N = 1e7).
+// Poissonisation: if T ~ Poisson(lambda) items are dealt to the chunks with probabilities p_c, the chunk
+// counts are INDEPENDENT Poisson(lambda p_c) -- one draw per chunk, all in parallel, no tree and no depth --
+// and given T they are Multinomial(T; p).  With lambda = n_out - kappa sqrt(n_out) (kappa = 5) T falls short of
+// n_out by ~kappa sqrt(n_out) outputs, which are added as ordinary categorical draws (one uniform each,
+// searched against the chunk edges: 1.6e4 draws instead of 1e7); Multinomial(T) + Multinomial(n_out - T) =
+// Multinomial(n_out), exactly the law k_bucket_count samples.  Should T exceed n_out (probability 3e-7 per
+// resample) the surplus is taken away again by removing T - n_out of the dealt items uniformly at random,
+// which leaves an i.i.d. sample of size n_out: exact as well.
+//
+// poisson_draw: X ~ Poisson(mu), exact.  mu < 10: sequential search of the cdf from X = 0; otherwise PTRS
+// (W. Hoermann, "The transformed rejection method for generating Poisson random variables", Insurance:
+// Mathematics and Economics 12 (1993) 39): a squeeze accepts ~87 % of the proposals after one division and a
+// floor.  Attempt t of chunk c takes its uniforms from Philox block (c | t << 32, round 0, slot 0) and the
+// FIRST accepted attempt is the draw; G adjacent lanes evaluate attempts t0 .. t0 + G - 1 of one chunk at
+// once and the lowest accepted one is taken (ballot + shuffle) -- the value a sequential loop returns, which
+// is how the oracle's NumPy twin (oracle/philox.py: poisson_draw) computes it.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double stirling_tail(double k) {         // ln k! - [(k + 1/2) ln(k + 1) - (k + 1) + ln(2 pi) / 2]
+    static constexpr double small[10] = {
+        0.08106146679532726,  0.0413406959554093,   0.02767792568499834,  0.020790672103765093, 0.016644691189821193,
+        0.013876128823070748, 0.01189670994589177,  0.010411265261972096, 0.009255462182712733, 0.00833056343336287};
+    if (k < 10.0) return small[(int)k];
+    const double rx = 1.0 / (k + 1.0), r2 = rx * rx;
+    return (1.0 / 12.0 - (1.0 / 360.0 - (1.0 / 1260.0 - (1.0 / 1680.0 - 1.0 / 1188.0 * r2) * r2) * r2) * r2) * rx;
+}
+
+// Called by whole waves.  Lanes [gbase, gbase + G) of a wave form the group of one chunk (same mu, node, active);
+// G is a power of two <= 64.  Returns the draw to every lane of the group.
+__device__ unsigned int poisson_draw(bool active, double mu, uint32_t node, uint32_t epoch_round, uint32_t k0,
+                                     uint32_t k1, int G, int gbase) {
+    const bool need = active && mu > 0.0;
+    double y = 0.0;
+    const bool by_search = need && mu < 10.0;
+    if (by_search) {                                             // every lane of the group: same inputs, same value
+        PhiloxStream rng{(uint64_t)node, epoch_round, k0, k1};
+        double U, unused;
+        rng.uniforms(0, U, unused);
+        double pk = exp(-mu), cdf = pk, X = 0.0;
+        while (U > cdf && X < 200.0) {
+            X += 1.0;
+            pk = pk * mu / X;
+            cdf += pk;
+        }
+        y = X;
     }
-    part[wave][lane] = s;
-    __syncthreads();
-    if (wave == 0 && c < chunks) {
-#pragma unroll
-        for (int wv = 1; wv < QSMC_WAVES_PER_BLOCK; ++wv) s += part[wv][lane];
-        counts[c] = s;
+    bool pending = need && !by_search;
+    const double smu = sqrt(mu), lmu = log(mu);
+    const double b = 0.931 + 2.53 * smu, a = -0.059 + 0.02483 * b;
+    const double linva = log(1.1239 + 1.1328 / (b - 3.4)), vr = 0.9277 - 3.6224 / (b - 2.0);
+    const int gl = (int)(threadIdx.x & (QSMC_WAVE - 1)) - gbase;
+    const unsigned long long gmask = G >= 64 ? ~0ull : ((1ull << G) - 1ull);
+    for (uint32_t t0 = 0; t0 < 4096u; t0 += (uint32_t)G) {
+        if (__ballot(pending) == 0ull) break;                    // wave-uniform
+        bool acc = false;
+        double kk = 0.0;
+        if (pending) {
+            PhiloxStream rng{(uint64_t)node | ((uint64_t)(t0 + (uint32_t)gl) << 32), epoch_round, k0, k1};
+            double U, V;
+            rng.uniforms(0, U, V);
+            const double u = U - 0.5, us = 0.5 - fabs(u);
+            kk = floor((2.0 * a / us + b) * u + mu + 0.43);
+            if (us >= 0.07 && V <= vr) acc = true;               // the squeeze
+            else if (kk >= 0.0 && !(us < 0.013 && V > us)) {
+                const double lhs = log(V) + linva - log(a / (us * us) + b);
+                const double lgk = (kk + 0.5) * log(kk + 1.0) - (kk + 1.0) + 0.91893853320467274178 + stirling_tail(kk);
+                acc = lhs <= -mu + kk * lmu - lgk;
+            }
+        }
+        const unsigned long long grp = (__ballot(acc) >> gbase) & gmask;
+        const int src = gbase + (grp ? __builtin_ctzll(grp) : 0);
+        const double first = __shfl(kk, src, QSMC_WAVE);
+        if (pending && grp) {
+            y = first;
+            pending = false;
+        }
+    }
+    return need ? (unsigned int)y : 0u;
+}
+
+// counts[c] ~ Poisson(lambda mass_c / total), four lanes per chunk.
+constexpr int POISSON_G = 4;
+__global__ __launch_bounds__(QSMC_BLOCK) void k_bucket_poisson(const double *__restrict__ offsets, int chunks,
+                                                               double lambda, uint32_t k0, uint32_t k1,
+                                                               uint32_t epoch, unsigned int *__restrict__ counts,
+                                                               unsigned int *__restrict__ extra) {
+    const int c = (int)((blockIdx.x * QSMC_BLOCK + threadIdx.x) / POISSON_G);
+    const int lane = threadIdx.x & (QSMC_WAVE - 1);
+    const bool active = c < chunks;
+    double mu = 0.0;
+    if (active) {
+        const double mass = offsets[c + 1] - chunk_edge(offsets, c);
+        const double total = offsets[chunks];
+        mu = (mass > 0.0 && total > 0.0) ? lambda * mass / total : 0.0;
+    }
+    const unsigned int x = poisson_draw(active, mu, (uint32_t)c, (epoch << 16), k0, k1, POISSON_G, lane & ~(POISSON_G - 1));
+    if (active && (lane & (POISSON_G - 1)) == 0) {
+        counts[c] = x;
+        extra[c] = 0u;                                           // the top-up kernel adds its draws here
     }
 }
 
-// single workgroup: slot_off[c] = exclusive scan of counts; item_off[c] = exclusive scan of
-// ceil(counts / BUCKET_CAP); slot_off[chunks] = n_out, item_off[chunks] = #work items
-__global__ __launch_bounds__(1024) void k_bucket_plan(const unsigned int *__restrict__ counts, int chunks,
-                                                      long long *__restrict__ slot_off,
-                                                      int *__restrict__ item_off,
-                                                      int *__restrict__ item_chunk) {
+// single workgroup (1024 threads): slot_off[c] = exclusive scan of counts; item_off[c] = exclusive scan of
+// ceil(counts / BUCKET_CAP); slot_off[chunks] = n_out, item_off[chunks] = #work items.  counts: global or LDS.
+__device__ __forceinline__ void bucket_plan_block(const unsigned int *counts, int chunks,
+                                                  long long *__restrict__ slot_off, int *__restrict__ item_off,
+                                                  int *__restrict__ item_chunk) {
     __shared__ long long tot_s[1024];
     __shared__ int tot_i[1024];
     const int per = (chunks + 1023) / 1024;
@@ -1345,6 +1429,123 @@ __global__ __launch_bounds__(1024) void k_bucket_plan(const unsigned int *__rest
         slot_off[chunks] = tot_s[1023];
         item_off[chunks] = tot_i[1023];
     }
+}
+
+// Brings the Poisson counts to the exact total n_out.  k_bucket_topup (many workgroups: a draw costs a Philox
+// block and a 12-probe search, 1.6e4 of them on one CU were 25 us): every workgroup sums the Poisson counts to
+// T itself (2442 integers), copies the chunk edges to LDS and takes its share of the n_out - T categorical draws,
+// adding them to extra[] (zeroed by k_bucket_poisson).  Top-up draw j takes word (j & 1) of Philox block
+// (j >> 1, round 0, slot 3).  k_bucket_plan_total (one workgroup): counts += extra; should the Poisson total
+// have overshot, thread 0 removes the surplus item by item (removal i: word 0 of block (i, round 0, slot 4));
+// then the plan.
+constexpr int BUCKET_TOPUP_BLOCKS = 16, BUCKET_TOPUP_THREADS = 1024;
+__global__ __launch_bounds__(BUCKET_TOPUP_THREADS) void k_bucket_topup(const double *__restrict__ offsets, int chunks,
+                                                             int64_t n_out, uint32_t k0, uint32_t k1, uint32_t epoch,
+                                                             const unsigned int *__restrict__ counts,
+                                                             unsigned int *__restrict__ extra) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *edges = reinterpret_cast<double *>(smem);
+    unsigned int *hist = reinterpret_cast<unsigned int *>(edges + lds_skew(chunks) + 4);   // this workgroup's draws per chunk
+    __shared__ unsigned long long total_s;
+    if (threadIdx.x == 0) total_s = 0ull;
+    __syncthreads();
+    unsigned long long mine = 0ull;
+    for (int c = threadIdx.x; c < chunks; c += BUCKET_TOPUP_THREADS) {
+        edges[lds_skew(c)] = chunk_edge(offsets, (int64_t)c + 1);
+        hist[c] = 0u;
+        mine += counts[c];
+    }
+    for (int off = QSMC_WAVE / 2; off > 0; off >>= 1) mine += __shfl_down(mine, off, QSMC_WAVE);
+    if ((threadIdx.x & (QSMC_WAVE - 1)) == 0 && mine) atomicAdd(&total_s, mine);
+    __syncthreads();
+    const long long T = (long long)total_s;
+    if (T >= n_out) return;
+    const int64_t deficit = n_out - T, n_pairs = (deficit + 1) >> 1;
+    for (int64_t pr = (int64_t)blockIdx.x * BUCKET_TOPUP_THREADS + threadIdx.x; pr < n_pairs; pr += (int64_t)gridDim.x * BUCKET_TOPUP_THREADS) {
+        PhiloxStream rng{(uint64_t)pr, (epoch << 16), k0, k1};
+        double u[2];
+        rng.uniforms(3, u[0], u[1]);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            if (2 * pr + e < deficit) {
+                int c = upper_bound_skew(edges, chunks, u[e]);         // #edges <= u == chunk index
+                if (c > chunks - 1) c = chunks - 1;                    // u beyond cdf[n-1] (rounding): Q2 clamp
+                atomicAdd(&hist[c], 1u);
+            }
+        }
+    }
+    __syncthreads();                                             // (T and with it the trip counts are workgroup-uniform)
+    for (int c = threadIdx.x; c < chunks; c += BUCKET_TOPUP_THREADS)
+        if (hist[c]) atomicAdd(&extra[c], hist[c]);
+}
+
+__global__ __launch_bounds__(1024) void k_bucket_plan_total(
+    int chunks, int64_t n_out, uint32_t k0, uint32_t k1, uint32_t epoch, unsigned int *__restrict__ counts,
+    const unsigned int *__restrict__ extra, long long *__restrict__ slot_off, int *__restrict__ item_off,
+    int *__restrict__ item_chunk) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned int *cnt = reinterpret_cast<unsigned int *>(smem);
+    __shared__ unsigned long long total_s;
+    if (threadIdx.x == 0) total_s = 0ull;
+    __syncthreads();
+    unsigned long long mine = 0ull;
+    for (int c = threadIdx.x; c < chunks; c += 1024) {
+        const unsigned int x = counts[c] + extra[c];
+        cnt[c] = x;
+        mine += x;
+    }
+    for (int off = QSMC_WAVE / 2; off > 0; off >>= 1) mine += __shfl_down(mine, off, QSMC_WAVE);
+    if ((threadIdx.x & (QSMC_WAVE - 1)) == 0 && mine) atomicAdd(&total_s, mine);
+    __syncthreads();
+    const long long T = (long long)total_s;
+    if (T > n_out) {                                             // (uniform branch; ~3e-7 of the resamples)
+        if (threadIdx.x == 0) {
+            long long left = T;
+            for (long long i = 0; i < T - n_out; ++i, --left) {
+                PhiloxStream rng{(uint64_t)i, (epoch << 16), k0, k1};
+                double u, unused;
+                rng.uniforms(4, u, unused);
+                long long target = (long long)(u * (double)left);   // which of the remaining items goes
+                if (target > left - 1) target = left - 1;
+                int c = 0;
+                for (long long run = (long long)cnt[0]; run <= target; run += (long long)cnt[c]) ++c;
+                cnt[c] -= 1u;
+            }
+        }
+        __syncthreads();
+    }
+    for (int c = threadIdx.x; c < chunks; c += 1024) counts[c] = cnt[c];
+    bucket_plan_block(cnt, chunks, slot_off, item_off, item_chunk);
+}
+
+// counts[c] = sum_g hist[g][c].  A workgroup takes 64 chunks; its four waves each sum a quarter of the rows
+// (coalesced 256-byte row segments), LDS combines them: 4x the workgroups and a quarter of the dependent
+// loads per thread of the one-thread-per-chunk version (8.8 -> ~4 us, the launch floor).
+__global__ __launch_bounds__(QSMC_BLOCK) void k_bucket_reduce(const unsigned int *__restrict__ hist, int rows,
+                                                              int chunks, unsigned int *__restrict__ counts) {
+    __shared__ unsigned int part[QSMC_WAVES_PER_BLOCK][QSMC_WAVE];
+    const int lane = threadIdx.x & (QSMC_WAVE - 1);
+    const int wave = threadIdx.x / QSMC_WAVE;
+    const int c = blockIdx.x * QSMC_WAVE + lane;
+    unsigned int s = 0;
+    if (c < chunks) {
+#pragma unroll 16
+        for (int g = wave; g < rows; g += QSMC_WAVES_PER_BLOCK) s += hist[(size_t)g * chunks + c];
+    }
+    part[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && c < chunks) {
+#pragma unroll
+        for (int wv = 1; wv < QSMC_WAVES_PER_BLOCK; ++wv) s += part[wv][lane];
+        counts[c] = s;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_bucket_plan(const unsigned int *__restrict__ counts, int chunks,
+                                                      long long *__restrict__ slot_off,
+                                                      int *__restrict__ item_off,
+                                                      int *__restrict__ item_chunk) {
+    bucket_plan_block(counts, chunks, slot_off, item_off, item_chunk);
 }
 
 constexpr int BUCKET_RLIST_CAP = 1024;               // per-workgroup list of outputs that need a global redraw
@@ -2523,21 +2724,46 @@ static int resample_prefix(qsmc_ctx *h, const double *w, int64_t n_in, double no
     if (rc) return rc;
     if (bp.bucketed) {
         const int chunks = bp.chunks;
-        const size_t lds = (size_t)(chunks + (chunks >> 5) + (chunks >> 10) + 8) * sizeof(double) +
-                           (size_t)chunks * sizeof(unsigned int) + (size_t)(GUIDE_BINS + 1 + 32) * sizeof(int);
-        size_t &lds_granted = h->count_lds_granted;        // the opt-in for > 64 KB of dynamic LDS is sticky: ask once per size
-        if (lds_granted < 64 * 1024) lds_granted = 64 * 1024;
-        if (lds > lds_granted) {
-            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(k_bucket_count),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            lds_granted = lds;
+        static const bool count_by_draws = getenv("QSMC_COUNT_BY_DRAWS") != nullptr;   // (measurement switch: the
+        if (count_by_draws) {                                   //  one-uniform-per-output histogram, same law)
+            const size_t lds = (size_t)(chunks + (chunks >> 5) + (chunks >> 10) + 8) * sizeof(double) +
+                               (size_t)chunks * sizeof(unsigned int) + (size_t)(GUIDE_BINS + 1 + 32) * sizeof(int);
+            size_t &lds_granted = h->count_lds_granted;        // the opt-in for > 64 KB of dynamic LDS is sticky: ask once per size
+            if (lds_granted < 64 * 1024) lds_granted = 64 * 1024;
+            if (lds > lds_granted) {
+                HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(k_bucket_count),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                lds_granted = lds;
+            }
+            hipLaunchKernelGGL(k_bucket_count, dim3(BUCKET_COUNT_BLOCKS), dim3(BUCKET_COUNT_THREADS), lds, s, offsets,
+                               chunks, n_out, k0, k1, ep, bp.hist);
+            hipLaunchKernelGGL(k_bucket_reduce, dim3((chunks + QSMC_WAVE - 1) / QSMC_WAVE), dim3(QSMC_BLOCK), 0, s,
+                               bp.hist, BUCKET_COUNT_BLOCKS, chunks, bp.counts);
+            hipLaunchKernelGGL(k_bucket_plan, dim3(1), dim3(1024), 0, s, bp.counts, chunks, bp.slot_off, bp.item_off,
+                               bp.item_chunk);
+        } else {
+            const char *margin_env = getenv("QSMC_POISSON_MARGIN");          // (test switch: 0 makes the removal branch common)
+            const double kappa = margin_env ? atof(margin_env) : 5.0;
+            double lambda = (double)n_out - kappa * sqrt((double)n_out);
+            if (!(lambda > 0.0)) lambda = 0.0;
+            // LDS: 8192 chunks need 68 KB of edges + 32 KB of counters (top-up): the opt-in beyond 64 KB is sticky
+            const size_t lds = (size_t)(chunks + (chunks >> 5) + (chunks >> 10) + 8) * sizeof(double) +
+                               (size_t)chunks * sizeof(unsigned int);
+            size_t &lds_granted = h->topup_lds_granted;
+            if (lds_granted < 48 * 1024) lds_granted = 48 * 1024;
+            if (lds > lds_granted) {
+                HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(k_bucket_topup),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                lds_granted = lds;
+            }
+            unsigned int *extra = bp.hist;                       // (the histogram rows are not used on this path)
+            hipLaunchKernelGGL(k_bucket_poisson, dim3((chunks * POISSON_G + QSMC_BLOCK - 1) / QSMC_BLOCK), dim3(QSMC_BLOCK),
+                               0, s, offsets, chunks, lambda, k0, k1, ep, bp.counts, extra);
+            hipLaunchKernelGGL(k_bucket_topup, dim3(BUCKET_TOPUP_BLOCKS), dim3(BUCKET_TOPUP_THREADS), lds, s, offsets, chunks, n_out,
+                               k0, k1, ep, bp.counts, extra);
+            hipLaunchKernelGGL(k_bucket_plan_total, dim3(1), dim3(1024), (size_t)chunks * sizeof(unsigned int), s, chunks,
+                               n_out, k0, k1, ep, bp.counts, extra, bp.slot_off, bp.item_off, bp.item_chunk);
         }
-        hipLaunchKernelGGL(k_bucket_count, dim3(BUCKET_COUNT_BLOCKS), dim3(BUCKET_COUNT_THREADS), lds, s, offsets,
-                           chunks, n_out, k0, k1, ep, bp.hist);
-        hipLaunchKernelGGL(k_bucket_reduce, dim3((chunks + QSMC_WAVE - 1) / QSMC_WAVE), dim3(QSMC_BLOCK), 0, s,
-                           bp.hist, BUCKET_COUNT_BLOCKS, chunks, bp.counts);
-        hipLaunchKernelGGL(k_bucket_plan, dim3(1), dim3(1024), 0, s, bp.counts, chunks, bp.slot_off, bp.item_off,
-                           bp.item_chunk);
     }
     HIP_TRY(h, hipGetLastError());
     return QSMC_OK;

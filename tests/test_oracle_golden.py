@@ -334,3 +334,56 @@ def test_g7_design_oracle(golden):
             warnings.simplefilter("ignore")
             r = orc.bayes_risk(g["bin_w"], g["bin_x"], lik_b, os_, e)
         np.testing.assert_allclose(r[0], g["bin_risk"][k], rtol=1e-9)
+
+
+# ---------------------------------------------------------------------------------------------
+# The device-RNG resampler's chunk counts (oracle/philox.py twins of k_bucket_poisson / k_bucket_topup /
+# k_bucket_plan_total): the samplers' laws, checked here against scipy's exact pmfs.
+def _chi2_p(xs, cdf, n_bins_edges):
+    from scipy import stats
+    obs = np.histogram(xs, bins=n_bins_edges + 0.5)[0]
+    exp = np.diff(cdf(n_bins_edges)) * len(xs)
+    keep = exp > 5
+    chi = ((obs - exp) ** 2 / exp)[keep].sum()
+    return stats.chi2.sf(chi, keep.sum() - 1)
+
+
+@pytest.mark.parametrize("mu", [0.7, 6.5, 10.5, 77.0, 4096.0, 3.0e6])
+def test_poisson_draw_law(mu):
+    """poisson_draw (cdf search below 10, PTRS above) follows Poisson(mu): chi-square over ~30 quantile bins,
+    mean and variance, 20000 independent Philox streams."""
+    from scipy import stats
+    import philox as ph
+    M = 20000
+    xs = np.array([ph.poisson_draw(mu, node, 991 + int(mu), 2) for node in range(M)])
+    qs = np.unique(stats.poisson.ppf(np.linspace(0, 1, 31)[1:-1], mu))
+    edges = np.concatenate([[-1], qs, [1e15]])
+    assert _chi2_p(xs, lambda e: stats.poisson.cdf(e, mu), edges) > 1e-4
+    assert abs(xs.mean() - mu) < 5 * np.sqrt(mu / M)
+    assert abs(xs.var() / mu - 1) < 5 * np.sqrt(2.0 / M + 1.0 / (mu * M))
+
+
+@pytest.mark.parametrize("margin", [5.0, 0.0, -3.0])
+def test_poissonised_counts_law(margin):
+    """Poisson counts + top-up (margin 5: the production setting) or + removal (margin <= 0 overshoots about half
+    the time / nearly always) are Multinomial(n_out; p): exact total, every chunk's count Binomial(n_out, p_c)
+    across independent seeds, and the expected covariance sign between two chunks."""
+    from scipy import stats
+    import philox as ph
+    p = np.array([0.02, 0.3, 0.0, 0.08, 0.25, 0.001, 0.349])
+    edges = np.cumsum(p)
+    edges[-1] = 1.0
+    n_out, reps = 3000, 1500
+    C = np.array([ph.poissonised_counts(edges, n_out, 1000 + r, 1 + r % 7, margin=margin) for r in range(reps)])
+    assert np.all(C.sum(axis=1) == n_out) and C.min() >= 0
+    assert np.all(C[:, 2] == 0)
+    for c in (0, 1, 3, 4, 5, 6):
+        qs = np.unique(stats.binom.ppf(np.linspace(0, 1, 13)[1:-1], n_out, p[c]))
+        e = np.concatenate([[-1], qs, [n_out]])
+        assert _chi2_p(C[:, c], lambda t: stats.binom.cdf(t, n_out, p[c]), e) > 1e-4, c
+    cov = np.cov(C[:, 1], C[:, 4])[0, 1]
+    want = -n_out * p[1] * p[4]
+    assert abs(cov - want) < 6 * n_out * np.sqrt(p[1] * p[4]) / np.sqrt(reps) + 0.1 * abs(want)
+    if margin <= 0:
+        lam = n_out - margin * np.sqrt(n_out)
+        assert stats.poisson.sf(n_out, lam) > 0.4              # the removal branch really was the common one

@@ -261,7 +261,7 @@ def _check_sharded_updater_variant(comm0, rank, world, tmpdir, variant):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         upd = qi.SMCUpdater(qi.SimplePrecessionModel(), n_local, qi.UniformDistribution([0, 1]),
-                            device_rng=True, seed=5, comm=comm)
+                            device_rng=True, seed=int(os.environ.get("QSMC_TEST_SEED", "5")), comm=comm)
         if variant == "local-segmented":              # shards beyond the sampler's single pass: segments inside the shard
             upd.resampler._segment_limit = 16384
         assert upd.n_particles == n_local and upd.n_particles_global == n_local * world
@@ -297,10 +297,15 @@ def _check_sharded_updater_variant(comm0, rank, world, tmpdir, variant):
         assert abs(upd.resample_count - ref.resample_count) <= 3
         shards = [np.load(os.path.join(tmpdir, "locs_%d.npy" % r)) for r in range(world)]
         if world > 1:                               # shards are statistically exchangeable
-            # (the cloud is the proposal of the last resample: compare with ITS spread, not the posterior's)
-            spread = max(s_.std() for s_ in shards)
-            assert abs(shards[0].mean() - shards[1].mean()) < 6 * spread * np.sqrt(2.0 / n_local)
-            assert abs(shards[0].std() / shards[1].std() - 1) < 0.05
+            # (the cloud is the proposal of the last resample: compare with ITS spread, not the posterior's.  Robust
+            # statistics: a handful of particles sit in alias lobes of cos^2 up to 0.2 away -- which shard's lineage
+            # kept them is luck, and twelve of them move a raw standard deviation by 30 %.  Each shard resamples from
+            # its own ancestors, so the centres differ by the shards' own Monte Carlo error, not by 1/sqrt(n_local))
+            q = [np.percentile(s_[:, 0], [25, 50, 75]) for s_ in shards]
+            iqr = [q_[2] - q_[0] for q_ in q]
+            info = (variant, [q_.tolist() for q_ in q], upd.resample_count)
+            assert abs(q[0][1] - q[1][1]) < 0.05 * max(iqr), info
+            assert abs(iqr[0] / iqr[1] - 1) < 0.05, info
         assert min(s.min() for s in shards) > 0
 
 
