@@ -177,7 +177,7 @@ def poisson_draw(mu, node, seed, epoch):
 
 
 def poissonised_counts(edges, n_out, seed, epoch, margin=5.0):
-    """Multinomial(n_out; chunk masses) the device's way (k_bucket_poisson + k_bucket_topup_plan): independent
+    """Multinomial(n_out; chunk masses) the device's way (k_bucket_counts): independent
     Poisson((n_out - margin sqrt(n_out)) p_c) per chunk, then the shortfall as categorical draws against the chunk
     edges (word j & 1 of Philox block (j >> 1, round 0, slot 3)) -- or, should the Poisson total overshoot, the
     surplus removed item by item uniformly at random (word 0 of block (i, round 0, slot 4)).
@@ -210,7 +210,7 @@ def poissonised_counts(edges, n_out, seed, epoch, margin=5.0):
 
 def liu_west_philox_bucketed(w, x, valid_fn, a, h, seed, epoch, n_out, maxiter=1000, postselect=True,
                              mean=None, cov=None, zero_cov_comp=1e-10, cdf=None, margin=5.0):
-    """Oracle of the bucketed device-RNG resampler (k_bucket_poisson / _topup_plan / _sample).  Outputs are
+    """Oracle of the bucketed device-RNG resampler (k_bucket_counts / k_bucket_sample).  Outputs are
     ordered by ancestor CHUNK.  Stream layout (round 0, two outputs per Philox block):
       slot 0: the Poisson chunk counts, slots 3 / 4 their top-up / removal (poissonised_counts); slot 1:
       within-chunk position of slot o (independent of the counts);

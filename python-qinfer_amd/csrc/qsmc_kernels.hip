@@ -46,7 +46,9 @@ struct qsmc_ctx {
     double *rs_offsets;            // resampler: chunk offsets (own buffer: survives other calls' scratch use)
     size_t rs_offsets_cap;
     size_t count_lds_granted;      // dynamic LDS already opted into for k_bucket_count on this device
-    size_t topup_lds_granted;      // ... and for k_bucket_topup
+    size_t topup_lds_granted;      // ... and for k_bucket_counts
+    unsigned long long *gbar;      // device: [0] arrival counter of the in-kernel grid barriers (only ever grows), [1] timeouts
+    unsigned long long gbar_base;  // host shadow: arrivals handed out so far
     void *sort_tmp;                // rocPRIM temporary storage + key/value staging for qsmc_argsort
     size_t sort_tmp_cap;           // in bytes
     double *tile_sums;             // sum of w' per update-kernel tile, written by the last qsmc_update_fused
@@ -1119,11 +1121,11 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_resample_philox(
 // ~1.2e8 scattered line requests at N = 1e7 (measured 1.4 ms, 83 % of GPU time in round-1
 // profile a).  Output particles are exchangeable, so instead:
 //   A  chunk counts      how many outputs descend from each CDF CHUNK (4096 source particles): exact
-//                        Multinomial(N; W_chunk) counts.  k_bucket_poisson / k_bucket_topup: independent Poisson
+//                        Multinomial(N; W_chunk) counts.  k_bucket_counts: independent Poisson
 //                        draws per chunk plus a short categorical top-up (see "Poissonisation" below);
 //                        k_bucket_count / k_bucket_reduce (QSMC_COUNT_BY_DRAWS=1, the first implementation):
 //                        every output draws u_i and is binned against the chunk edges in LDS;
-//   B  k_bucket_plan_total / k_bucket_plan   exclusive scans: first output slot of each
+//   B  (k_bucket_counts, last step) / k_bucket_plan   exclusive scans: first output slot of each
 //                        chunk and a work list that splits heavy chunks into <= BUCKET_CAP outputs;
 //   C  k_bucket_sample   one workgroup per work item scans ITS chunk of the weights into LDS (32 KB of CDF),
 //                        draws the within-chunk position from an independent Philox word (given
@@ -1239,7 +1241,7 @@ __device__ __forceinline__ int guided_upper_bound(const double *a, int m, const 
 }
 
 // Philox stream layout of the bucketed resampler (round 0), two outputs per Philox block:
-//   slot 0: block (c | t << 32)                   attempt t of chunk c's Poisson count (k_bucket_poisson)
+//   slot 0: block (c | t << 32)                   attempt t of chunk c's Poisson count (k_bucket_counts)
 //           [QSMC_COUNT_BY_DRAWS: block (i >> 1), word (i & 1) = chunk draw of output i (k_bucket_count)]
 //   slot 3: block (j >> 1), word (j & 1)          top-up draw j;  slot 4: block (i), word 0: removal i
 //   slot 1: block (o >> 1), word (o & 1)          within-chunk position of slot o (k_bucket_sample)
@@ -1362,35 +1364,13 @@ __device__ unsigned int poisson_draw(bool active, double mu, uint32_t node, uint
     return need ? (unsigned int)y : 0u;
 }
 
-// counts[c] ~ Poisson(lambda mass_c / total), four lanes per chunk.
-constexpr int POISSON_G = 4;
-__global__ __launch_bounds__(QSMC_BLOCK) void k_bucket_poisson(const double *__restrict__ offsets, int chunks,
-                                                               double lambda, uint32_t k0, uint32_t k1,
-                                                               uint32_t epoch, unsigned int *__restrict__ counts,
-                                                               unsigned int *__restrict__ extra) {
-    const int c = (int)((blockIdx.x * QSMC_BLOCK + threadIdx.x) / POISSON_G);
-    const int lane = threadIdx.x & (QSMC_WAVE - 1);
-    const bool active = c < chunks;
-    double mu = 0.0;
-    if (active) {
-        const double mass = offsets[c + 1] - chunk_edge(offsets, c);
-        const double total = offsets[chunks];
-        mu = (mass > 0.0 && total > 0.0) ? lambda * mass / total : 0.0;
-    }
-    const unsigned int x = poisson_draw(active, mu, (uint32_t)c, (epoch << 16), k0, k1, POISSON_G, lane & ~(POISSON_G - 1));
-    if (active && (lane & (POISSON_G - 1)) == 0) {
-        counts[c] = x;
-        extra[c] = 0u;                                           // the top-up kernel adds its draws here
-    }
-}
-
 // single workgroup (1024 threads): slot_off[c] = exclusive scan of counts; item_off[c] = exclusive scan of
 // ceil(counts / BUCKET_CAP); slot_off[chunks] = n_out, item_off[chunks] = #work items.  counts: global or LDS.
 __device__ __forceinline__ void bucket_plan_block(const unsigned int *counts, int chunks,
                                                   long long *__restrict__ slot_off, int *__restrict__ item_off,
                                                   int *__restrict__ item_chunk) {
-    __shared__ long long tot_s[1024];
-    __shared__ int tot_i[1024];
+    __shared__ long long wtot_s[1024 / QSMC_WAVE];
+    __shared__ int wtot_i[1024 / QSMC_WAVE];
     const int per = (chunks + 1023) / 1024;
     const int c0 = threadIdx.x * per, c1 = min(chunks, c0 + per);
     long long s = 0;
@@ -1399,24 +1379,30 @@ __device__ __forceinline__ void bucket_plan_block(const unsigned int *counts, in
         s += counts[c];
         it += (int)((counts[c] + BUCKET_CAP - 1) / BUCKET_CAP);
     }
-    tot_s[threadIdx.x] = s;
-    tot_i[threadIdx.x] = it;
-    __syncthreads();
-    // Hillis-Steele over 1024 integer totals (exact)
-    for (int off = 1; off < 1024; off <<= 1) {
-        long long a = 0;
-        int b = 0;
-        if ((int)threadIdx.x >= off) {
-            a = tot_s[threadIdx.x - off];
-            b = tot_i[threadIdx.x - off];
+    // exclusive scan of the 1024 per-thread totals (integers: exact): shuffles inside a wave, 16 wave totals in LDS
+    const int lane = threadIdx.x & (QSMC_WAVE - 1), wave = threadIdx.x / QSMC_WAVE;
+    long long inc_s = s;
+    int inc_i = it;
+#pragma unroll
+    for (int off = 1; off < QSMC_WAVE; off <<= 1) {
+        const long long ts = __shfl_up(inc_s, off, QSMC_WAVE);
+        const int ti = __shfl_up(inc_i, off, QSMC_WAVE);
+        if (lane >= off) {
+            inc_s += ts;
+            inc_i += ti;
         }
-        __syncthreads();
-        tot_s[threadIdx.x] += a;
-        tot_i[threadIdx.x] += b;
-        __syncthreads();
     }
-    long long so = tot_s[threadIdx.x] - s;
-    int io = tot_i[threadIdx.x] - it;
+    if (lane == QSMC_WAVE - 1) {
+        wtot_s[wave] = inc_s;
+        wtot_i[wave] = inc_i;
+    }
+    __syncthreads();
+    long long so = inc_s - s;
+    int io = inc_i - it;
+    for (int wv = 0; wv < wave; ++wv) {
+        so += wtot_s[wv];
+        io += wtot_i[wv];
+    }
     for (int c = c0; c < c1; ++c) {
         slot_off[c] = so;
         item_off[c] = io;
@@ -1425,79 +1411,139 @@ __device__ __forceinline__ void bucket_plan_block(const unsigned int *counts, in
         so += counts[c];
         io += items;
     }
-    if (threadIdx.x == 1023) {
-        slot_off[chunks] = tot_s[1023];
-        item_off[chunks] = tot_i[1023];
+    if (threadIdx.x == 1023) {                                   // (after the loop: so / io have run through its chunks)
+        slot_off[chunks] = so;
+        item_off[chunks] = io;
     }
 }
 
-// Brings the Poisson counts to the exact total n_out.  k_bucket_topup (many workgroups: a draw costs a Philox
-// block and a 12-probe search, 1.6e4 of them on one CU were 25 us): every workgroup sums the Poisson counts to
-// T itself (2442 integers), copies the chunk edges to LDS and takes its share of the n_out - T categorical draws,
-// adding them to extra[] (zeroed by k_bucket_poisson).  Top-up draw j takes word (j & 1) of Philox block
-// (j >> 1, round 0, slot 3).  k_bucket_plan_total (one workgroup): counts += extra; should the Poisson total
-// have overshot, thread 0 removes the surplus item by item (removal i: word 0 of block (i, round 0, slot 4));
-// then the plan.
-constexpr int BUCKET_TOPUP_BLOCKS = 16, BUCKET_TOPUP_THREADS = 1024;
-__global__ __launch_bounds__(BUCKET_TOPUP_THREADS) void k_bucket_topup(const double *__restrict__ offsets, int chunks,
-                                                             int64_t n_out, uint32_t k0, uint32_t k1, uint32_t epoch,
-                                                             const unsigned int *__restrict__ counts,
-                                                             unsigned int *__restrict__ extra) {
+// Barrier across the workgroups of ONE launch whose grid is small enough to be resident at once (16 here).  The
+// arrival counter only ever grows: the host hands every launch the value all workgroups will have brought it to
+// at each of its barriers, so nothing is reset.  No cache maintenance: the XCDs' L2s are not coherent with each
+// other inside a launch, and a release / acquire fence pair at agent scope (L2 write-back + invalidate) measured
+// ~5 us per barrier -- instead every word that crosses workgroups is written and read with agent-scope atomics
+// (which go to the coherence point), and __syncthreads() has waited for this workgroup's own before the
+// arrival is posted.  A bounded spin (~1 s): a launch that cannot become resident aborts (the next HIP call
+// reports it) rather than hanging the queue or carrying on with half the data.
+__device__ __forceinline__ void grid_barrier(unsigned long long *bar, unsigned long long target) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(bar, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned int spins = 0;
+        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 20)) {                          // cannot happen with a resident grid: fail loudly
+                __hip_atomic_fetch_add(bar + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_trap();
+            }
+        }
+    }
+    __syncthreads();
+}
+// The same with the cache maintenance, for bulk data written with plain stores (the redraw kernel's CDF): release
+// (L2 write-back) before the arrival, acquire (invalidate) after the wait.  ~5 us, on a path most resamples skip.
+__device__ __forceinline__ void grid_barrier_fenced(unsigned long long *bar, unsigned long long target) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        __hip_atomic_fetch_add(bar, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned int spins = 0;
+        while (__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1u << 20)) {                          // cannot happen with a resident grid: fail loudly
+                __hip_atomic_fetch_add(bar + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_trap();
+            }
+        }
+    }
+    __syncthreads();
+    __threadfence();
+}
+__device__ __forceinline__ void put_shared(unsigned int *p, unsigned int v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned int get_shared(const unsigned int *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The chunk counts in one launch (each of the three steps alone is a ~5 us launch: the floor of a dependent
+// kernel on this part):
+//   1  counts[c] ~ Poisson(lambda mass_c / total), four lanes per chunk, chunks dealt to the workgroups;
+//   2  every workgroup sums the counts to T (a few thousand integers), and takes its share of the n_out - T
+//      categorical top-up draws against the chunk edges in LDS (1.6e4 draws on one CU were 25 us; spread over
+//      16 they are 2), collected in an LDS histogram and added to extra[];  top-up draw j takes word (j & 1) of
+//      Philox block (j >> 1, round 0, slot 3);
+//   3  workgroup 0: counts += extra; should the Poisson total have overshot, thread 0 removes the surplus item
+//      by item (removal i: word 0 of block (i, round 0, slot 4)); then the plan.
+constexpr int POISSON_G = 4;
+constexpr int BUCKET_COUNTS_BLOCKS = 16, BUCKET_COUNTS_THREADS = 1024;
+__global__ __launch_bounds__(BUCKET_COUNTS_THREADS) void k_bucket_counts(
+    const double *__restrict__ offsets, int chunks, int64_t n_out, double lambda, uint32_t k0, uint32_t k1,
+    uint32_t epoch, unsigned int *counts, unsigned int *extra, long long *__restrict__ slot_off,
+    int *__restrict__ item_off, int *__restrict__ item_chunk, unsigned long long *bar, unsigned long long bar_base) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double *edges = reinterpret_cast<double *>(smem);
     unsigned int *hist = reinterpret_cast<unsigned int *>(edges + lds_skew(chunks) + 4);   // this workgroup's draws per chunk
     __shared__ unsigned long long total_s;
-    if (threadIdx.x == 0) total_s = 0ull;
-    __syncthreads();
-    unsigned long long mine = 0ull;
-    for (int c = threadIdx.x; c < chunks; c += BUCKET_TOPUP_THREADS) {
-        edges[lds_skew(c)] = chunk_edge(offsets, (int64_t)c + 1);
-        hist[c] = 0u;
-        mine += counts[c];
-    }
-    for (int off = QSMC_WAVE / 2; off > 0; off >>= 1) mine += __shfl_down(mine, off, QSMC_WAVE);
-    if ((threadIdx.x & (QSMC_WAVE - 1)) == 0 && mine) atomicAdd(&total_s, mine);
-    __syncthreads();
-    const long long T = (long long)total_s;
-    if (T >= n_out) return;
-    const int64_t deficit = n_out - T, n_pairs = (deficit + 1) >> 1;
-    for (int64_t pr = (int64_t)blockIdx.x * BUCKET_TOPUP_THREADS + threadIdx.x; pr < n_pairs; pr += (int64_t)gridDim.x * BUCKET_TOPUP_THREADS) {
-        PhiloxStream rng{(uint64_t)pr, (epoch << 16), k0, k1};
-        double u[2];
-        rng.uniforms(3, u[0], u[1]);
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            if (2 * pr + e < deficit) {
-                int c = upper_bound_skew(edges, chunks, u[e]);         // #edges <= u == chunk index
-                if (c > chunks - 1) c = chunks - 1;                    // u beyond cdf[n-1] (rounding): Q2 clamp
-                atomicAdd(&hist[c], 1u);
-            }
+    const int lane = threadIdx.x & (QSMC_WAVE - 1);
+    // ---- 1: Poisson counts ----
+    const double total = offsets[chunks];
+    constexpr int PER_PASS = BUCKET_COUNTS_THREADS / POISSON_G;
+    for (int c0 = (int)blockIdx.x * PER_PASS; c0 < chunks; c0 += (int)gridDim.x * PER_PASS) {   // (uniform per workgroup)
+        const int c = c0 + (int)threadIdx.x / POISSON_G;
+        const bool active = c < chunks;
+        double mu = 0.0;
+        if (active) {
+            const double mass = offsets[c + 1] - chunk_edge(offsets, c);
+            mu = (mass > 0.0 && total > 0.0) ? lambda * mass / total : 0.0;
+        }
+        const unsigned int x = poisson_draw(active, mu, (uint32_t)c, (epoch << 16), k0, k1, POISSON_G, lane & ~(POISSON_G - 1));
+        if (active && (lane & (POISSON_G - 1)) == 0) {
+            put_shared(&counts[c], x);
+            put_shared(&extra[c], 0u);
         }
     }
-    __syncthreads();                                             // (T and with it the trip counts are workgroup-uniform)
-    for (int c = threadIdx.x; c < chunks; c += BUCKET_TOPUP_THREADS)
-        if (hist[c]) atomicAdd(&extra[c], hist[c]);
-}
-
-__global__ __launch_bounds__(1024) void k_bucket_plan_total(
-    int chunks, int64_t n_out, uint32_t k0, uint32_t k1, uint32_t epoch, unsigned int *__restrict__ counts,
-    const unsigned int *__restrict__ extra, long long *__restrict__ slot_off, int *__restrict__ item_off,
-    int *__restrict__ item_chunk) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned int *cnt = reinterpret_cast<unsigned int *>(smem);
-    __shared__ unsigned long long total_s;
-    if (threadIdx.x == 0) total_s = 0ull;
-    __syncthreads();
-    unsigned long long mine = 0ull;
-    for (int c = threadIdx.x; c < chunks; c += 1024) {
-        const unsigned int x = counts[c] + extra[c];
-        cnt[c] = x;
-        mine += x;
+    for (int c = threadIdx.x; c < chunks; c += BUCKET_COUNTS_THREADS) {
+        edges[lds_skew(c)] = chunk_edge(offsets, (int64_t)c + 1);
+        hist[c] = 0u;
     }
+    if (threadIdx.x == 0) total_s = 0ull;
+    grid_barrier(bar, bar_base + gridDim.x);
+    // ---- 2: the total, and this workgroup's share of the top-up ----
+    unsigned long long mine = 0ull;
+    for (int c = threadIdx.x; c < chunks; c += BUCKET_COUNTS_THREADS)
+        mine += get_shared(&counts[c]);
     for (int off = QSMC_WAVE / 2; off > 0; off >>= 1) mine += __shfl_down(mine, off, QSMC_WAVE);
-    if ((threadIdx.x & (QSMC_WAVE - 1)) == 0 && mine) atomicAdd(&total_s, mine);
+    if (lane == 0 && mine) atomicAdd(&total_s, mine);
     __syncthreads();
     const long long T = (long long)total_s;
+    if (T < n_out) {
+        const int64_t deficit = n_out - T, n_pairs = (deficit + 1) >> 1;
+        for (int64_t pr = (int64_t)blockIdx.x * BUCKET_COUNTS_THREADS + threadIdx.x; pr < n_pairs;
+             pr += (int64_t)gridDim.x * BUCKET_COUNTS_THREADS) {
+            PhiloxStream rng{(uint64_t)pr, (epoch << 16), k0, k1};
+            double u[2];
+            rng.uniforms(3, u[0], u[1]);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                if (2 * pr + e < deficit) {
+                    int c = upper_bound_skew(edges, chunks, u[e]);     // #edges <= u == chunk index
+                    if (c > chunks - 1) c = chunks - 1;                // u beyond cdf[n-1] (rounding): Q2 clamp
+                    atomicAdd(&hist[c], 1u);
+                }
+            }
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < chunks; c += BUCKET_COUNTS_THREADS)
+            if (hist[c]) atomicAdd(&extra[c], hist[c]);
+    }
+    grid_barrier(bar, bar_base + 2ull * gridDim.x);
+    if (blockIdx.x != 0) return;
+    // ---- 3: final counts and the plan ----
+    unsigned int *cnt = hist;
+    for (int c = threadIdx.x; c < chunks; c += BUCKET_COUNTS_THREADS)
+        cnt[c] = get_shared(&counts[c]) + get_shared(&extra[c]);
+    __syncthreads();
     if (T > n_out) {                                             // (uniform branch; ~3e-7 of the resamples)
         if (threadIdx.x == 0) {
             long long left = T;
@@ -1514,7 +1560,7 @@ __global__ __launch_bounds__(1024) void k_bucket_plan_total(
         }
         __syncthreads();
     }
-    for (int c = threadIdx.x; c < chunks; c += 1024) counts[c] = cnt[c];
+    for (int c = threadIdx.x; c < chunks; c += BUCKET_COUNTS_THREADS) counts[c] = cnt[c];
     bucket_plan_block(cnt, chunks, slot_off, item_off, item_chunk);
 }
 
@@ -1752,16 +1798,31 @@ __global__ __launch_bounds__(BT) void k_bucket_sample(
     for (int i = threadIdx.x; i < nl; i += BT) retry_list[rbase + i] = (unsigned int)(o_begin + rlist[i]);
 }
 
-// Second chance for the queued outputs: redraw ancestor and kick from the global CDF (rounds 1..).
-__global__ __launch_bounds__(QSMC_BLOCK) void k_bucket_retry(
+// Second chance for the queued outputs: redraw ancestor and kick from the global CDF (rounds 1..).  One launch,
+// resident grid: nothing queued (most resamples) -> post the barrier arrival and leave (an empty launch is ~5 us;
+// the former pair -- materialise the CDF behind a gate, then redraw -- was two of them).  Otherwise every
+// workgroup scans its share of the chunks into the global CDF, all meet at a barrier, and the queue is worked off.
+constexpr int REDRAW_BLOCKS = 128;       // (half the CUs: two processes sharing a GPU, as the tests do, both stay resident)
+__global__ __launch_bounds__(SCAN_THREADS) void k_bucket_redraw(
     int kind, int d, double min_freq, const double *__restrict__ x_in, int64_t ldx_in, int64_t n_in,
-    const double *__restrict__ cdf, LWArgs lw, uint32_t k0, uint32_t k1, uint32_t epoch, int maxiter,
-    double *__restrict__ x_out, OutPlace pl, const unsigned int *__restrict__ retry_list,
-    const unsigned long long *__restrict__ retry_count, unsigned long long *__restrict__ n_failed) {
+    const double *__restrict__ w, double inv_norm, const double *__restrict__ offsets, int64_t chunks, double *cdf,
+    LWArgs lw, uint32_t k0, uint32_t k1, uint32_t epoch, int maxiter, double *__restrict__ x_out, OutPlace pl,
+    const unsigned int *__restrict__ retry_list, const unsigned long long *__restrict__ retry_count,
+    unsigned long long *__restrict__ n_failed, unsigned long long *bar, unsigned long long bar_base) {
+    __shared__ double wave_tot[SCAN_WAVES];
     const unsigned long long cnt = *retry_count;
+    if (cnt == 0ull) {                                           // (keeps the arrival counter in step with the host's)
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(bar, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    for (int64_t c = blockIdx.x; c < chunks; c += gridDim.x) {
+        chunk_scan_block(w, n_in, inv_norm, offsets, c, wave_tot, StoreGlobal{cdf + c * SCAN_CHUNK});
+        __syncthreads();                                         // wave_tot is reused by the next chunk
+    }
+    grid_barrier_fenced(bar, bar_base + gridDim.x);
     unsigned long long failed = 0;
-    for (unsigned long long i = (unsigned long long)blockIdx.x * QSMC_BLOCK + threadIdx.x; i < cnt;
-         i += (unsigned long long)gridDim.x * QSMC_BLOCK) {
+    for (unsigned long long i = (unsigned long long)blockIdx.x * SCAN_THREADS + threadIdx.x; i < cnt;
+         i += (unsigned long long)gridDim.x * SCAN_THREADS) {
         const int64_t o = (int64_t)retry_list[i];
         double p[QSMC_MAX_D];
         const bool ok = redraw_rounds<QSMC_MAX_D>(kind, d, min_freq, x_in, ldx_in, n_in, cdf, lw, k0, k1, epoch,
@@ -2185,6 +2246,8 @@ int qsmc_create(qsmc_handle_t *out, int device) {
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipMalloc(&h->counter, 2 * sizeof(long long));   // [0] failed, [1] retry count
     if (e == hipSuccess) e = hipMemset(h->counter, 0, 2 * sizeof(long long));
+    if (e == hipSuccess) e = hipMalloc(&h->gbar, 2 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(h->gbar, 0, 2 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc(&h->red_out, REDUCE_OUT_MAX * sizeof(double));
     if (e == hipSuccess) e = hipHostMalloc(&h->mapped, REDUCE_OUT_MAX * sizeof(double), hipHostMallocMapped);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&h->mapped_dev, h->mapped, 0);
@@ -2208,6 +2271,7 @@ int qsmc_destroy(qsmc_handle_t h) {
     if (h->scratch) (void)hipFree(h->scratch);
     if (h->pinned) (void)hipHostFree(h->pinned);
     if (h->counter) (void)hipFree(h->counter);
+    if (h->gbar) (void)hipFree(h->gbar);
     if (h->iscratch) (void)hipFree(h->iscratch);
     if (h->cdf_scratch) (void)hipFree(h->cdf_scratch);
     if (h->red_out) (void)hipFree(h->red_out);
@@ -2746,23 +2810,21 @@ static int resample_prefix(qsmc_ctx *h, const double *w, int64_t n_in, double no
             const double kappa = margin_env ? atof(margin_env) : 5.0;
             double lambda = (double)n_out - kappa * sqrt((double)n_out);
             if (!(lambda > 0.0)) lambda = 0.0;
-            // LDS: 8192 chunks need 68 KB of edges + 32 KB of counters (top-up): the opt-in beyond 64 KB is sticky
+            // LDS: 8192 chunks need 68 KB of edges + 32 KB of counters: the opt-in beyond 64 KB is sticky
             const size_t lds = (size_t)(chunks + (chunks >> 5) + (chunks >> 10) + 8) * sizeof(double) +
                                (size_t)chunks * sizeof(unsigned int);
             size_t &lds_granted = h->topup_lds_granted;
             if (lds_granted < 48 * 1024) lds_granted = 48 * 1024;
             if (lds > lds_granted) {
-                HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(k_bucket_topup),
+                HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(k_bucket_counts),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 lds_granted = lds;
             }
             unsigned int *extra = bp.hist;                       // (the histogram rows are not used on this path)
-            hipLaunchKernelGGL(k_bucket_poisson, dim3((chunks * POISSON_G + QSMC_BLOCK - 1) / QSMC_BLOCK), dim3(QSMC_BLOCK),
-                               0, s, offsets, chunks, lambda, k0, k1, ep, bp.counts, extra);
-            hipLaunchKernelGGL(k_bucket_topup, dim3(BUCKET_TOPUP_BLOCKS), dim3(BUCKET_TOPUP_THREADS), lds, s, offsets, chunks, n_out,
-                               k0, k1, ep, bp.counts, extra);
-            hipLaunchKernelGGL(k_bucket_plan_total, dim3(1), dim3(1024), (size_t)chunks * sizeof(unsigned int), s, chunks,
-                               n_out, k0, k1, ep, bp.counts, extra, bp.slot_off, bp.item_off, bp.item_chunk);
+            hipLaunchKernelGGL(k_bucket_counts, dim3(BUCKET_COUNTS_BLOCKS), dim3(BUCKET_COUNTS_THREADS), lds, s, offsets,
+                               chunks, n_out, lambda, k0, k1, ep, bp.counts, extra, bp.slot_off, bp.item_off,
+                               bp.item_chunk, h->gbar, h->gbar_base);
+            h->gbar_base += 2ull * BUCKET_COUNTS_BLOCKS;
         }
     }
     HIP_TRY(h, hipGetLastError());
@@ -2830,11 +2892,10 @@ static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int3
 #undef LAUNCH_B
         if (postselect && maxiter > 1) {
             // only if some particle asked for a global redraw do these two do any work
-            hipLaunchKernelGGL(k_chunk_scan, dim3((unsigned)chunks64), dim3(SCAN_THREADS), 0, s, w, n_in, inv_norm, offsets,
-                               h->cdf_scratch, (const unsigned long long *)retry_count);
-            hipLaunchKernelGGL(k_bucket_retry, dim3(grid_for(n_out / 16 + 1, QSMC_BLOCK)), dim3(QSMC_BLOCK), 0, s,
-                               model->kind, d, model->min_freq, x_in, ldx_in, n_in, h->cdf_scratch, lw, k0, k1, ep,
-                               maxiter, x_out, pl, bp.retry_list, retry_count, nf);
+            hipLaunchKernelGGL(k_bucket_redraw, dim3(REDRAW_BLOCKS), dim3(SCAN_THREADS), 0, s, model->kind, d,
+                               model->min_freq, x_in, ldx_in, n_in, w, inv_norm, offsets, chunks64, h->cdf_scratch, lw,
+                               k0, k1, ep, maxiter, x_out, pl, bp.retry_list, retry_count, nf, h->gbar, h->gbar_base);
+            h->gbar_base += (unsigned long long)REDRAW_BLOCKS;
         }
     }
     HIP_TRY(h, hipGetLastError());

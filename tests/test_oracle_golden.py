@@ -337,8 +337,7 @@ def test_g7_design_oracle(golden):
 
 
 # ---------------------------------------------------------------------------------------------
-# The device-RNG resampler's chunk counts (oracle/philox.py twins of k_bucket_poisson / k_bucket_topup /
-# k_bucket_plan_total): the samplers' laws, checked here against scipy's exact pmfs.
+# The device-RNG resampler's chunk counts (oracle/philox.py twin of k_bucket_counts): the samplers' laws, checked here against scipy's exact pmfs.
 def _chi2_p(xs, cdf, n_bins_edges):
     from scipy import stats
     obs = np.histogram(xs, bins=n_bins_edges + 0.5)[0]
