@@ -805,10 +805,11 @@ __device__ __forceinline__ double chunk_sum_in(const double *__restrict__ sums, 
     return t * ts.inv_norm;
 }
 
-__global__ __launch_bounds__(SCAN_SUMS_THREADS) void k_scan_sums(double *__restrict__ sums, int64_t m,
-                                                                 unsigned long long *__restrict__ zero2, TileSrc ts) {
+// One workgroup of SCAN_SUMS_THREADS: exclusive, monotone prefix of the m chunk sums; sink(i, offsets[i]) for
+// i = 0 .. m (offsets[m] = total).  The sums come from `sums` or, with ts.tiles, from the update kernel's tile sums.
+template <class Sink>
+__device__ __forceinline__ void scan_sums_block(const double *sums, int64_t m, const TileSrc &ts, Sink sink) {
     __shared__ double wtot[SCAN_SUMS_THREADS / QSMC_WAVE];
-    if (zero2 && threadIdx.x < 2) zero2[threadIdx.x] = 0ull;      // the resampler's failed / retry counters (was a memset launch)
     const int lane = threadIdx.x & (QSMC_WAVE - 1);
     const int wave = threadIdx.x / QSMC_WAVE;
     const int per = (int)((m + SCAN_SUMS_THREADS - 1) / SCAN_SUMS_THREADS);
@@ -847,12 +848,18 @@ __global__ __launch_bounds__(SCAN_SUMS_THREADS) void k_scan_sums(double *__restr
     for (int wv = 0; wv < wave; ++wv) before = fmax(before, wtot[wv]);
 #pragma unroll
     for (int q = 0; q < SCAN_SUMS_MAX_PER; ++q)
-        if (q < per && i0 + q < m) sums[i0 + q] = fmax(e[q], before);
+        if (q < per && i0 + q < m) sink(i0 + q, fmax(e[q], before));
     if (threadIdx.x == SCAN_SUMS_THREADS - 1) {
         double gmax = 0.0;
         for (int wv = 0; wv < SCAN_SUMS_THREADS / QSMC_WAVE; ++wv) gmax = fmax(gmax, wtot[wv]);
-        sums[m] = fmax(total, gmax);
+        sink(m, fmax(total, gmax));
     }
+}
+
+__global__ __launch_bounds__(SCAN_SUMS_THREADS) void k_scan_sums(double *sums, int64_t m,
+                                                                 unsigned long long *__restrict__ zero2, TileSrc ts) {
+    if (zero2 && threadIdx.x < 2) zero2[threadIdx.x] = 0ull;      // the resampler's failed / retry counters (was a memset launch)
+    scan_sums_block(sums, m, ts, [&](int64_t i, double v) { sums[i] = v; });
 }
 
 // Fallback for m > 16384 chunk sums (N > 6.7e7): same contract, 256-wide slabs with a carry.
@@ -1468,6 +1475,7 @@ __device__ __forceinline__ unsigned int get_shared(const unsigned int *p) {
 
 // The chunk counts in one launch (each of the three steps alone is a ~5 us launch: the floor of a dependent
 // kernel on this part):
+//   0  (if the update kernel left tile sums) the chunk edges: see below;
 //   1  counts[c] ~ Poisson(lambda mass_c / total), four lanes per chunk, chunks dealt to the workgroups;
 //   2  every workgroup sums the counts to T (a few thousand integers), and takes its share of the n_out - T
 //      categorical top-up draws against the chunk edges in LDS (1.6e4 draws on one CU were 25 us; spread over
@@ -1478,23 +1486,42 @@ __device__ __forceinline__ unsigned int get_shared(const unsigned int *p) {
 constexpr int POISSON_G = 4;
 constexpr int BUCKET_COUNTS_BLOCKS = 16, BUCKET_COUNTS_THREADS = 1024;
 __global__ __launch_bounds__(BUCKET_COUNTS_THREADS) void k_bucket_counts(
-    const double *__restrict__ offsets, int chunks, int64_t n_out, double lambda, uint32_t k0, uint32_t k1,
-    uint32_t epoch, unsigned int *counts, unsigned int *extra, long long *__restrict__ slot_off,
-    int *__restrict__ item_off, int *__restrict__ item_chunk, unsigned long long *bar, unsigned long long bar_base) {
+    double *offsets, TileSrc ts, unsigned long long *__restrict__ zero2, int chunks, int64_t n_out, double lambda,
+    uint32_t k0, uint32_t k1, uint32_t epoch, unsigned int *counts, unsigned int *extra,
+    long long *__restrict__ slot_off, int *__restrict__ item_off, int *__restrict__ item_chunk,
+    unsigned long long *bar, unsigned long long bar_base) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double *edges = reinterpret_cast<double *>(smem);
     unsigned int *hist = reinterpret_cast<unsigned int *>(edges + lds_skew(chunks) + 4);   // this workgroup's draws per chunk
     __shared__ unsigned long long total_s;
     const int lane = threadIdx.x & (QSMC_WAVE - 1);
+    // ---- 0: the chunk edges.  Given the update kernel's tile sums (ts.tiles), EVERY workgroup forms the monotone
+    // prefix of the chunk sums itself, straight into its LDS -- the same code on the same numbers in the same
+    // order, so all agree bit for bit, and the separate one-workgroup scan launch (9 us) is gone; workgroup 0
+    // also stores offsets[] for the sampler and clears the failed / retry counters.  Otherwise offsets[] is ready.
+    static_assert(BUCKET_COUNTS_THREADS == SCAN_SUMS_THREADS, "scan_sums_block runs on this workgroup");
+    if (ts.tiles) {
+        const bool writer = blockIdx.x == 0;
+        if (writer && threadIdx.x < 2) zero2[threadIdx.x] = 0ull;
+        scan_sums_block(nullptr, (int64_t)chunks, ts, [&](int64_t i, double v) {
+            if (i > 0) edges[lds_skew((int)i - 1)] = v;             // upper edge of chunk i - 1
+            if (writer) offsets[i] = v;
+        });
+    } else {
+        for (int c = threadIdx.x; c < chunks; c += BUCKET_COUNTS_THREADS) edges[lds_skew(c)] = offsets[c + 1];
+    }
+    for (int c = threadIdx.x; c < chunks; c += BUCKET_COUNTS_THREADS) hist[c] = 0u;
+    if (threadIdx.x == 0) total_s = 0ull;
+    __syncthreads();
     // ---- 1: Poisson counts ----
-    const double total = offsets[chunks];
+    const double total = edges[lds_skew(chunks - 1)];
     constexpr int PER_PASS = BUCKET_COUNTS_THREADS / POISSON_G;
     for (int c0 = (int)blockIdx.x * PER_PASS; c0 < chunks; c0 += (int)gridDim.x * PER_PASS) {   // (uniform per workgroup)
         const int c = c0 + (int)threadIdx.x / POISSON_G;
         const bool active = c < chunks;
         double mu = 0.0;
         if (active) {
-            const double mass = offsets[c + 1] - chunk_edge(offsets, c);
+            const double mass = edges[lds_skew(c)] - (c > 0 ? edges[lds_skew(c - 1)] : 0.0);
             mu = (mass > 0.0 && total > 0.0) ? lambda * mass / total : 0.0;
         }
         const unsigned int x = poisson_draw(active, mu, (uint32_t)c, (epoch << 16), k0, k1, POISSON_G, lane & ~(POISSON_G - 1));
@@ -1503,11 +1530,6 @@ __global__ __launch_bounds__(BUCKET_COUNTS_THREADS) void k_bucket_counts(
             put_shared(&extra[c], 0u);
         }
     }
-    for (int c = threadIdx.x; c < chunks; c += BUCKET_COUNTS_THREADS) {
-        edges[lds_skew(c)] = chunk_edge(offsets, (int64_t)c + 1);
-        hist[c] = 0u;
-    }
-    if (threadIdx.x == 0) total_s = 0ull;
     grid_barrier(bar, bar_base + gridDim.x);
     // ---- 2: the total, and this workgroup's share of the top-up ----
     unsigned long long mine = 0ull;
@@ -2775,21 +2797,25 @@ static int resample_prefix(qsmc_ctx *h, const double *w, int64_t n_in, double no
         ts = TileSrc{h->tile_sums, BUCKET_CHUNK / h->ts.tile * QSMC_WAVES_PER_BLOCK,
                      (n_in + h->ts.tile - 1) / h->ts.tile * QSMC_WAVES_PER_BLOCK, inv_norm};
     h->ts.armed = 0;
+    BucketPlan bp;
+    rc = bucket_plan_layout(h, chunks64, n_out, &bp);
+    if (rc) return rc;
+    static const bool count_by_draws = getenv("QSMC_COUNT_BY_DRAWS") != nullptr;   // (measurement switch: the
+                                                                //  one-uniform-per-output histogram, same law)
+    // with tile sums the bucketed count kernel forms the offsets itself; otherwise: chunk sums, then the scan
+    const bool scan_in_counts = ts.tiles && bp.bucketed && !count_by_draws;
     if (!ts.tiles)
         hipLaunchKernelGGL(k_chunk_sums, dim3((unsigned)chunks64), dim3(QSMC_BLOCK), 0, s, w, n_in, inv_norm, offsets);
-    if (chunks64 > (int64_t)SCAN_SUMS_THREADS * SCAN_SUMS_MAX_PER)
+    if (scan_in_counts) {
+    } else if (chunks64 > (int64_t)SCAN_SUMS_THREADS * SCAN_SUMS_MAX_PER)
         hipLaunchKernelGGL(k_scan_sums_big, dim3(1), dim3(QSMC_BLOCK), 0, s, offsets, chunks64,
                            reinterpret_cast<unsigned long long *>(h->counter), ts);
     else
         hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_SUMS_THREADS), 0, s, offsets, chunks64,
                            reinterpret_cast<unsigned long long *>(h->counter), ts);
-    BucketPlan bp;
-    rc = bucket_plan_layout(h, chunks64, n_out, &bp);
-    if (rc) return rc;
     if (bp.bucketed) {
         const int chunks = bp.chunks;
-        static const bool count_by_draws = getenv("QSMC_COUNT_BY_DRAWS") != nullptr;   // (measurement switch: the
-        if (count_by_draws) {                                   //  one-uniform-per-output histogram, same law)
+        if (count_by_draws) {
             const size_t lds = (size_t)(chunks + (chunks >> 5) + (chunks >> 10) + 8) * sizeof(double) +
                                (size_t)chunks * sizeof(unsigned int) + (size_t)(GUIDE_BINS + 1 + 32) * sizeof(int);
             size_t &lds_granted = h->count_lds_granted;        // the opt-in for > 64 KB of dynamic LDS is sticky: ask once per size
@@ -2822,8 +2848,9 @@ static int resample_prefix(qsmc_ctx *h, const double *w, int64_t n_in, double no
             }
             unsigned int *extra = bp.hist;                       // (the histogram rows are not used on this path)
             hipLaunchKernelGGL(k_bucket_counts, dim3(BUCKET_COUNTS_BLOCKS), dim3(BUCKET_COUNTS_THREADS), lds, s, offsets,
-                               chunks, n_out, lambda, k0, k1, ep, bp.counts, extra, bp.slot_off, bp.item_off,
-                               bp.item_chunk, h->gbar, h->gbar_base);
+                               scan_in_counts ? ts : TileSrc{nullptr, 0, 0, 0.0},
+                               reinterpret_cast<unsigned long long *>(h->counter), chunks, n_out, lambda, k0, k1, ep,
+                               bp.counts, extra, bp.slot_off, bp.item_off, bp.item_chunk, h->gbar, h->gbar_base);
             h->gbar_base += 2ull * BUCKET_COUNTS_BLOCKS;
         }
     }
