@@ -47,7 +47,8 @@ struct qsmc_ctx {
     size_t rs_offsets_cap;
     size_t count_lds_granted;      // dynamic LDS already opted into for k_bucket_count on this device
     size_t topup_lds_granted;      // ... and for k_bucket_counts
-    unsigned long long *gbar;      // device: [0] arrival counter of the in-kernel grid barriers (only ever grows), [1] timeouts
+    unsigned long long *gbar;      // device: [0] arrival counter of the count kernel's barriers (only ever grows), [1] its
+                                   // timeouts; [2], [3] arrivals / departures of the redraw kernel's self-resetting barrier
     unsigned long long gbar_base;  // host shadow: arrivals handed out so far
     void *sort_tmp;                // rocPRIM temporary storage + key/value staging for qsmc_argsort
     size_t sort_tmp_cap;           // in bytes
@@ -1447,20 +1448,23 @@ __device__ __forceinline__ void grid_barrier(unsigned long long *bar, unsigned l
     }
     __syncthreads();
 }
-// The same with the cache maintenance, for bulk data written with plain stores (the redraw kernel's CDF): release
-// (L2 write-back) before the arrival, acquire (invalidate) after the wait.  ~5 us, on a path most resamples skip.
-__device__ __forceinline__ void grid_barrier_fenced(unsigned long long *bar, unsigned long long target) {
+// A barrier with the cache maintenance, for bulk data written with plain stores (the redraw kernel's CDF): release
+// (L2 write-back) before the arrival, acquire (invalidate) after the wait; ~5 us, on a path most resamples skip.
+// Self-resetting (bar[0] arrivals, bar[1] departures: the last workgroup to leave clears both -- nobody can still
+// be waiting then), so a launch that never reaches the barrier touches nothing.
+__device__ __forceinline__ void grid_barrier_fenced(unsigned long long *bar) {
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();
         __hip_atomic_fetch_add(bar, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         unsigned int spins = 0;
-        while (__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        while (__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned long long)gridDim.x) {
             __builtin_amdgcn_s_sleep(2);
-            if (++spins > (1u << 20)) {                          // cannot happen with a resident grid: fail loudly
-                __hip_atomic_fetch_add(bar + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __builtin_trap();
-            }
+            if (++spins > (1u << 20)) __builtin_trap();          // cannot happen with a resident grid: fail loudly
+        }
+        if (__hip_atomic_fetch_add(bar + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned long long)gridDim.x - 1ull) {
+            __hip_atomic_store(bar + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(bar, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     __syncthreads();
@@ -1821,7 +1825,7 @@ __global__ __launch_bounds__(BT) void k_bucket_sample(
 }
 
 // Second chance for the queued outputs: redraw ancestor and kick from the global CDF (rounds 1..).  One launch,
-// resident grid: nothing queued (most resamples) -> post the barrier arrival and leave (an empty launch is ~5 us;
+// resident grid: nothing queued (most resamples) -> leave at once (an empty launch is ~5 us;
 // the former pair -- materialise the CDF behind a gate, then redraw -- was two of them).  Otherwise every
 // workgroup scans its share of the chunks into the global CDF, all meet at a barrier, and the queue is worked off.
 constexpr int REDRAW_BLOCKS = 128;       // (half the CUs: two processes sharing a GPU, as the tests do, both stay resident)
@@ -1830,18 +1834,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_bucket_redraw(
     const double *__restrict__ w, double inv_norm, const double *__restrict__ offsets, int64_t chunks, double *cdf,
     LWArgs lw, uint32_t k0, uint32_t k1, uint32_t epoch, int maxiter, double *__restrict__ x_out, OutPlace pl,
     const unsigned int *__restrict__ retry_list, const unsigned long long *__restrict__ retry_count,
-    unsigned long long *__restrict__ n_failed, unsigned long long *bar, unsigned long long bar_base) {
+    unsigned long long *__restrict__ n_failed, unsigned long long *bar) {
     __shared__ double wave_tot[SCAN_WAVES];
     const unsigned long long cnt = *retry_count;
-    if (cnt == 0ull) {                                           // (keeps the arrival counter in step with the host's)
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(bar, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-    }
+    if (cnt == 0ull) return;
     for (int64_t c = blockIdx.x; c < chunks; c += gridDim.x) {
         chunk_scan_block(w, n_in, inv_norm, offsets, c, wave_tot, StoreGlobal{cdf + c * SCAN_CHUNK});
         __syncthreads();                                         // wave_tot is reused by the next chunk
     }
-    grid_barrier_fenced(bar, bar_base + gridDim.x);
+    grid_barrier_fenced(bar);
     unsigned long long failed = 0;
     for (unsigned long long i = (unsigned long long)blockIdx.x * SCAN_THREADS + threadIdx.x; i < cnt;
          i += (unsigned long long)gridDim.x * SCAN_THREADS) {
@@ -2268,8 +2269,8 @@ int qsmc_create(qsmc_handle_t *out, int device) {
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipMalloc(&h->counter, 2 * sizeof(long long));   // [0] failed, [1] retry count
     if (e == hipSuccess) e = hipMemset(h->counter, 0, 2 * sizeof(long long));
-    if (e == hipSuccess) e = hipMalloc(&h->gbar, 2 * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMemset(h->gbar, 0, 2 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc(&h->gbar, 4 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(h->gbar, 0, 4 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc(&h->red_out, REDUCE_OUT_MAX * sizeof(double));
     if (e == hipSuccess) e = hipHostMalloc(&h->mapped, REDUCE_OUT_MAX * sizeof(double), hipHostMallocMapped);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&h->mapped_dev, h->mapped, 0);
@@ -2921,8 +2922,7 @@ static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int3
             // only if some particle asked for a global redraw do these two do any work
             hipLaunchKernelGGL(k_bucket_redraw, dim3(REDRAW_BLOCKS), dim3(SCAN_THREADS), 0, s, model->kind, d,
                                model->min_freq, x_in, ldx_in, n_in, w, inv_norm, offsets, chunks64, h->cdf_scratch, lw,
-                               k0, k1, ep, maxiter, x_out, pl, bp.retry_list, retry_count, nf, h->gbar, h->gbar_base);
-            h->gbar_base += (unsigned long long)REDRAW_BLOCKS;
+                               k0, k1, ep, maxiter, x_out, pl, bp.retry_list, retry_count, nf, h->gbar + 2);
         }
     }
     HIP_TRY(h, hipGetLastError());
