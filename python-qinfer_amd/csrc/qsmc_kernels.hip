@@ -1828,7 +1828,11 @@ __global__ __launch_bounds__(BT) void k_bucket_sample(
 // resident grid: nothing queued (most resamples) -> leave at once (an empty launch is ~5 us;
 // the former pair -- materialise the CDF behind a gate, then redraw -- was two of them).  Otherwise every
 // workgroup scans its share of the chunks into the global CDF, all meet at a barrier, and the queue is worked off.
-constexpr int REDRAW_BLOCKS = 128;       // (half the CUs: two processes sharing a GPU, as the tests do, both stay resident)
+// Held to 128 VGPRs (4 waves per SIMD): two workgroups fit a CU, so 256 are resident on half the CUs and two
+// processes sharing a GPU (as the tests do) both stay resident; the scan phase takes ~10 rounds instead of 19.
+constexpr int REDRAW_BLOCKS = 256;
+template <int DM>     // particle dimension bound: 4 (registers) or QSMC_MAX_D
+__attribute__((amdgpu_waves_per_eu(4, 8)))
 __global__ __launch_bounds__(SCAN_THREADS) void k_bucket_redraw(
     int kind, int d, double min_freq, const double *__restrict__ x_in, int64_t ldx_in, int64_t n_in,
     const double *__restrict__ w, double inv_norm, const double *__restrict__ offsets, int64_t chunks, double *cdf,
@@ -1847,8 +1851,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_bucket_redraw(
     for (unsigned long long i = (unsigned long long)blockIdx.x * SCAN_THREADS + threadIdx.x; i < cnt;
          i += (unsigned long long)gridDim.x * SCAN_THREADS) {
         const int64_t o = (int64_t)retry_list[i];
-        double p[QSMC_MAX_D];
-        const bool ok = redraw_rounds<QSMC_MAX_D>(kind, d, min_freq, x_in, ldx_in, n_in, cdf, lw, k0, k1, epoch,
+        double p[DM];
+        const bool ok = redraw_rounds<DM>(kind, d, min_freq, x_in, ldx_in, n_in, cdf, lw, k0, k1, epoch,
                                                   maxiter, o, p);
         const int64_t row = place_row(pl, o);      // like the in-thread loop: the last round's value stays
         for (int m = 0; m < d; ++m) x_out[m * pl.ld_m + row * pl.ld_s] = p[m];
@@ -2920,7 +2924,8 @@ static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int3
 #undef LAUNCH_B
         if (postselect && maxiter > 1) {
             // only if some particle asked for a global redraw do these two do any work
-            hipLaunchKernelGGL(k_bucket_redraw, dim3(REDRAW_BLOCKS), dim3(SCAN_THREADS), 0, s, model->kind, d,
+            hipLaunchKernelGGL((d <= 4 ? k_bucket_redraw<4> : k_bucket_redraw<QSMC_MAX_D>), dim3(REDRAW_BLOCKS),
+                               dim3(SCAN_THREADS), 0, s, model->kind, d,
                                model->min_freq, x_in, ldx_in, n_in, w, inv_norm, offsets, chunks64, h->cdf_scratch, lw,
                                k0, k1, ep, maxiter, x_out, pl, bp.retry_list, retry_count, nf, h->gbar + 2);
         }
