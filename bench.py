@@ -98,6 +98,8 @@ def main():
     # validation hook for a 1-GPU box: QSMC_BENCH_SHARE_GPU=1 puts every rank on device 0 and talks over gloo, so
     # that the multi-rank control flow of this file can be exercised without N GPUs (not a measurement mode)
     share_gpu = os.environ.get("QSMC_BENCH_SHARE_GPU") == "1"
+    if share_gpu:       # the resampler's redraw kernel needs all its workgroups resident: split the GPU's 512 slots
+        os.environ.setdefault("QSMC_REDRAW_BLOCKS", str(max(16, 512 // max(world, 2))))
     device_index = 0 if share_gpu else local_rank
     torch.cuda.set_device(device_index)
     comm = None

@@ -2924,7 +2924,14 @@ static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int3
 #undef LAUNCH_B
         if (postselect && maxiter > 1) {
             // only if some particle asked for a global redraw do these two do any work
-            hipLaunchKernelGGL((d <= 4 ? k_bucket_redraw<4> : k_bucket_redraw<QSMC_MAX_D>), dim3(REDRAW_BLOCKS),
+            // (more than two processes on one GPU -- bench.py's control-flow check -- must shrink the grid: all of
+            //  them have to be resident together, 512 workgroup slots in total)
+            static const int redraw_blocks = [] {
+                const char *e = getenv("QSMC_REDRAW_BLOCKS");
+                const int v = e ? atoi(e) : REDRAW_BLOCKS;
+                return v < 1 ? 1 : (v > REDRAW_BLOCKS ? REDRAW_BLOCKS : v);
+            }();
+            hipLaunchKernelGGL((d <= 4 ? k_bucket_redraw<4> : k_bucket_redraw<QSMC_MAX_D>), dim3(redraw_blocks),
                                dim3(SCAN_THREADS), 0, s, model->kind, d,
                                model->min_freq, x_in, ldx_in, n_in, w, inv_norm, offsets, chunks64, h->cdf_scratch, lw,
                                k0, k1, ep, maxiter, x_out, pl, bp.retry_list, retry_count, nf, h->gbar + 2);
