@@ -1466,9 +1466,9 @@ __device__ __forceinline__ void grid_barrier_fenced(unsigned long long *bar) {
             __hip_atomic_store(bar + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(bar, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        __threadfence();                 // acquire for the whole workgroup: the CU's L1 and the XCD's L2 are shared
     }
     __syncthreads();
-    __threadfence();
 }
 __device__ __forceinline__ void put_shared(unsigned int *p, unsigned int v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
