@@ -380,13 +380,14 @@ def test_liu_west_philox_vs_oracle(qi, case):
     assert not np.array_equal(got, other)
 
 
-@pytest.mark.parametrize("case", ["prec", "rb", "tomo"])
+@pytest.mark.parametrize("case", ["prec", "rb", "tomo", "prec-large", "prec-one-chunk"])
 def test_liu_west_philox_bucketed_vs_oracle(qi, eng, case):
     """The bucketed (count -> plan -> LDS-staged sample) resampler on identical Philox numbers."""
     import philox as ph
     rs = np.random.RandomState(12)
     n = 70001
-    if case == "prec":
+    if case.startswith("prec"):
+        n = {"prec": n, "prec-large": 1500003, "prec-one-chunk": 3000}[case]
         model, valid = qi.SimplePrecessionModel(), orc.valid_precession
         x = np.abs(0.04 + 0.05 * rs.randn(n, 1))
     elif case == "rb":
@@ -399,8 +400,8 @@ def test_liu_west_philox_bucketed_vs_oracle(qi, eng, case):
         x = orc.ginibre_prior_sample(n, basis.data, rs)
     w = rs.random_sample(n) ** 2
     w[5000:9200] = 0.0                                   # an (almost) empty chunk
-    w[20000:20100] *= 400.0                              # a heavy chunk -> split into several work items
-    n_out = 90000
+    w[20000:20100] *= 400.0 if case != "prec-large" else 8000.0    # a heavy chunk -> split into several work items
+    n_out = {"prec-large": 1200000, "prec-one-chunk": 20000}.get(case, 90000)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         pd = qi.ParticleDistribution(particle_locations=x, particle_weights=w)
@@ -412,6 +413,7 @@ def test_liu_west_philox_bucketed_vs_oracle(qi, eng, case):
                                                               n_out, cdf=cdf)
     got = new.particle_locations
     assert counts.max() > 2 * 8192, "fixture must exercise the heavy-chunk split"
+    assert counts.sum() == n_out and len(counts) == (n + 4095) // 4096
     cov = orc.particle_cov(wn, x, warn=False)
     at = 1e-12 + (tol.atol_sqrtm_psd(cov) * 10 if case == "tomo" else 0)
     bad = np.abs(got - ref).max(axis=1) > at
@@ -477,7 +479,7 @@ def test_every_output_slot_is_written(qi, eng, monkeypatch):
     desc = qi.TomographyModel(qi.tomography.pauli_basis(1))._native_desc()      # d = 4, no validity constraint
     rs = np.random.RandomState(99)
     for trial in range(24):
-        n_in = int(rs.choice([4097, 20000, 65536, 100003, 300000]))
+        n_in = int(rs.choice([3000, 4097, 20000, 65536, 100003, 300000]))
         n_out = int(rs.choice([16384, 20001, 60000, 123457, 400000]))
         w = rs.random_sample(n_in) ** rs.choice([1, 4, 30])
         if trial % 3 == 0:
