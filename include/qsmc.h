@@ -261,7 +261,9 @@ int qsmc_lw_perturb(qsmc_handle_t h, const qsmc_model_t *model, int32_t postsele
  * *n_failed_host = particles still invalid (synchronises); NULL stays asynchronous
  * (qsmc_last_resample_failed).
  * For 16384 <= n_out < 2^32 and n_in <= 3.3e7 the BUCKETED sampler runs: exact
- * multinomial counts per 4096-particle chunk, then one workgroup per chunk scans ITS weights in LDS,
+ * multinomial counts per 4096-particle chunk (independent Poisson draws per chunk brought to the exact
+ * total by a short categorical top-up: the law of the reference's n_out searches of the CDF,
+ * resamplers.py:308-316, without n_out uniforms), then one workgroup per chunk scans ITS weights in LDS,
  * so the CDF is never written to HBM; outputs come ordered by ancestor chunk (particles are
  * exchangeable; same joint law).  The global CDF is materialised only if a particle needs a global
  * redraw.  Otherwise: CDF + one binary search per particle. */
