@@ -127,7 +127,7 @@ def _stirling_tail(k):
 
 
 def poisson_draw(mu, node, seed, epoch):
-    """X ~ Poisson(mu) exactly as poisson_draw of the device library (csrc/qsmc_kernels.hip): sequential search of
+    """X ~ Poisson(mu) exactly as poisson_draw of the device library (csrc/kernels/resample.hpp): sequential search of
     the cdf for mu < 10, PTRS (W. Hoermann, Insurance: Mathematics and Economics 12 (1993) 39: transformed
     rejection with squeeze) otherwise; attempt t of chunk `node` consumes Philox block (node | t << 32, round 0,
     slot 0) and the first accepted attempt is the draw.  Scalar floats in the device's order of operations."""

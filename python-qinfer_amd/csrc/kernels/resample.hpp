@@ -1,0 +1,901 @@
+// kernels/resample.hpp -- Liu-West resampling: legacy-RNG pieces, the direct device-RNG sampler and the bucketed multinomial resampler.
+// Part of the single translation unit qsmc_kernels.hip (included there, in this order; not a stand-alone header).
+#pragma once
+
+// =============================================================================================
+// Liu-West pieces
+// =============================================================================================
+// upper bound: number of entries <= u, clamped to n - 1
+__device__ __forceinline__ int64_t search_right(const double *__restrict__ cdf, int64_t n, double u) {
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
+    }
+    return lo < n - 1 ? lo : n - 1;
+}
+
+__global__ __launch_bounds__(QSMC_BLOCK) void k_ancestors(const double *__restrict__ cdf, int64_t n_in,
+                                                          const double *__restrict__ u, int64_t n_out,
+                                                          int64_t *__restrict__ js) {
+    for (int64_t i = (int64_t)blockIdx.x * QSMC_BLOCK + threadIdx.x; i < n_out;
+         i += (int64_t)gridDim.x * QSMC_BLOCK)
+        js[i] = search_right(cdf, n_in, u[i]);
+}
+
+struct LWArgs {
+    double a;
+    double mean[QSMC_MAX_D];
+    double S[QSMC_MAX_D * QSMC_MAX_D];   // row-major d x d (already times h)
+};
+
+__global__ __launch_bounds__(QSMC_BLOCK) void k_centres(const double *__restrict__ x_in, int64_t ldx_in,
+                                                        int d, const int64_t *__restrict__ js,
+                                                        int64_t n_out, double a, LWArgs lw,
+                                                        double *__restrict__ mus, int64_t ld_mus) {
+    for (int64_t i = (int64_t)blockIdx.x * QSMC_BLOCK + threadIdx.x; i < n_out;
+         i += (int64_t)gridDim.x * QSMC_BLOCK) {
+        const int64_t j = js[i];
+        for (int m = 0; m < d; ++m)
+            mus[m * ld_mus + i] = a * x_in[m * ldx_in + j] + (1.0 - a) * lw.mean[m];   // :325
+    }
+}
+
+__global__ __launch_bounds__(QSMC_BLOCK) void k_perturb(int kind, int d, double min_freq, int postselect,
+                                                        const double *__restrict__ mus, int64_t ld_mus,
+                                                        const int64_t *__restrict__ idxs, int64_t k,
+                                                        int centre_by_idx, LWArgs lw,
+                                                        const double *__restrict__ z, int64_t ldz,
+                                                        double *__restrict__ x_out, int64_t ldx_out,
+                                                        uint8_t *__restrict__ valid) {
+    for (int64_t r = (int64_t)blockIdx.x * QSMC_BLOCK + threadIdx.x; r < k;
+         r += (int64_t)gridDim.x * QSMC_BLOCK) {
+        const int64_t dst = idxs ? idxs[r] : r;
+        const int64_t c = centre_by_idx ? dst : r;
+        double p[QSMC_MAX_D];
+        for (int m = 0; m < d; ++m) {
+            double s = 0.0;                     // (S @ z)[m, r], summed in column order like np.dot
+            for (int q = 0; q < d; ++q) s += lw.S[m * d + q] * z[q * ldz + r];
+            p[m] = mus[m * ld_mus + c] + s;
+            x_out[m * ldx_out + dst] = p[m];
+        }
+        valid[r] = (!postselect || model_valid(kind, p, min_freq)) ? 1 : 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Output placement.  Single GPU: slot o -> column o of the SoA cloud.  Sharded: this
+// rank produces the finished particles for EVERY destination rank and they leave by one
+// all_to_all, so rows must be grouped by destination, AoS.  The bucketed sampler emits slots sorted
+// by ancestor chunk; dealing them to destinations round-robin (skipping a destination once its
+// quota is full -- exact quotas, closed form below) gives every destination an even, stratified
+// share of all chunks, so the shards stay statistically exchangeable.
+// ---------------------------------------------------------------------------------------------
+#define QSMC_MAX_DEST 16
+struct OutPlace {
+    int n_dest;                            // 0: identity placement
+    int64_t ld_m, ld_s;                    // element (m, row) lives at x_out[m * ld_m + row * ld_s]
+    int order[QSMC_MAX_DEST];              // destination ids by ascending quota
+    int64_t quota[QSMC_MAX_DEST];          // ascending quotas c_(0) <= ... <= c_(G-1)
+    int64_t seg_start[QSMC_MAX_DEST + 1];  // first slot of dealing segment s (rounds c_(s-1) .. c_(s)-1)
+    int64_t dest_base[QSMC_MAX_DEST];      // first row of destination r
+};
+
+__device__ __forceinline__ int64_t place_row(const OutPlace &pl, int64_t o) {
+    if (pl.n_dest == 0) return o;
+    int s = 0;
+    while (s + 1 < pl.n_dest && o >= pl.seg_start[s + 1]) ++s;
+    const int active = pl.n_dest - s;
+    const int64_t rel = o - pl.seg_start[s];
+    const int64_t round = (s ? pl.quota[s - 1] : 0) + rel / active;
+    const int dest = pl.order[s + (int)(rel % active)];
+    return pl.dest_base[dest] + round;
+}
+
+// One-launch device-RNG resample.
+__global__ __launch_bounds__(QSMC_BLOCK) void k_resample_philox(
+    int kind, int d, double min_freq, int postselect, const double *__restrict__ x_in, int64_t ldx_in,
+    int64_t n_in, const double *__restrict__ cdf, LWArgs lw, int64_t n_out, uint32_t k0, uint32_t k1,
+    uint32_t epoch, int maxiter, double *__restrict__ x_out, OutPlace pl,
+    unsigned long long *__restrict__ n_failed) {
+    unsigned long long failed = 0;
+    for (int64_t i = (int64_t)blockIdx.x * QSMC_BLOCK + threadIdx.x; i < n_out;
+         i += (int64_t)gridDim.x * QSMC_BLOCK) {
+        double p[QSMC_MAX_D];
+        bool ok = false;
+        for (int round = 0; round < maxiter && !ok; ++round) {
+            PhiloxStream rng{(uint64_t)i, (epoch << 16) | (uint32_t)round, k0, k1};
+            double u, unused;
+            rng.uniforms(0, u, unused);
+            const int64_t j = search_right(cdf, n_in, u);
+            double zz[QSMC_MAX_D];
+            for (int q = 0; q < d; q += 2) {
+                double z0, z1;
+                rng.normals(1 + (q >> 1), z0, z1);
+                zz[q] = z0;
+                if (q + 1 < d) zz[q + 1] = z1;
+            }
+            for (int m = 0; m < d; ++m) {
+                double s = 0.0;
+                for (int q = 0; q < d; ++q) s += lw.S[m * d + q] * zz[q];
+                p[m] = (lw.a * x_in[m * ldx_in + j] + (1.0 - lw.a) * lw.mean[m]) + s;
+            }
+            ok = !postselect || model_valid(kind, p, min_freq);
+        }
+        const int64_t row = place_row(pl, i);
+        for (int m = 0; m < d; ++m) x_out[m * pl.ld_m + row * pl.ld_s] = p[m];
+        if (!ok) ++failed;
+    }
+    if (failed) atomicAdd(n_failed, failed);
+}
+
+
+// =============================================================================================
+// Bucketed multinomial resampling (device RNG).
+//
+// The direct kernel above does one 23-level binary search of the 80 MB CDF per output particle:
+// ~1.2e8 scattered line requests at N = 1e7 (measured 1.4 ms, 83 % of GPU time in round-1
+// profile a).  Output particles are exchangeable, so instead:
+//   A  chunk counts      how many outputs descend from each CDF CHUNK (4096 source particles): exact
+//                        Multinomial(N; W_chunk) counts.  k_bucket_counts: independent Poisson
+//                        draws per chunk plus a short categorical top-up (see "Poissonisation" below);
+//                        k_bucket_count / k_bucket_reduce (QSMC_COUNT_BY_DRAWS=1, the first implementation):
+//                        every output draws u_i and is binned against the chunk edges in LDS;
+//   B  (k_bucket_counts, last step) / k_bucket_plan   exclusive scans: first output slot of each
+//                        chunk and a work list that splits heavy chunks into <= BUCKET_CAP outputs;
+//   C  k_bucket_sample   one workgroup per work item scans ITS chunk of the weights into LDS (32 KB of CDF),
+//                        draws the within-chunk position from an independent Philox word (given
+//                        the counts, positions are i.i.d. uniform inside the chunk -- exact),
+//                        searches in LDS, gathers x from the chunk's 32 KB window, kicks, checks
+//                        validity and writes its outputs to consecutive slots.
+// HBM traffic becomes streaming (read w + x once, write x' once); all scattered probes hit LDS.
+// A postselection retry needs a fresh GLOBAL ancestor: that rare path falls back to the global
+// search (same semantics as k_resample_philox: redraw ancestor and kick).
+// =============================================================================================
+constexpr int BUCKET_CHUNK = SCAN_CHUNK;            // 4096 source particles per bucket
+constexpr int BUCKET_CAP = 2 * BUCKET_CHUNK;        // outputs per work item
+constexpr int BUCKET_MAX_CHUNKS = 8192;             // skewed edges (68 KB) + counters (32 KB) + guide (16 KB) of LDS
+constexpr int BUCKET_COUNT_BLOCKS = 256;            // one resident workgroup per CU
+constexpr int BUCKET_COUNT_THREADS = 1024;
+
+// Lower CDF edge of chunk c == upper edge of chunk c-1 == offsets[c] (k_scan_sums output; the chunk
+// scan defines the last CDF entry of every chunk as exactly this number).
+__device__ __forceinline__ double chunk_edge(const double *__restrict__ offsets, int64_t c) {
+    return c <= 0 ? 0.0 : offsets[c];
+}
+
+// number of entries of a[0..m) that are <= u   (a in LDS or global)
+__device__ __forceinline__ int upper_bound_i32(const double *a, int m, double u) {
+    int lo = 0, hi = m;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] <= u) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// LDS index skew: binary-search midpoints of a power-of-two table are multiples of 2048, 1024, ...
+// elements, i.e. ONE bank for every lane (measured: 88 % of the sample kernel's LDS cycles were bank
+// conflicts).  j + (j >> 5) + (j >> 10) sends those strides to distinct banks.
+__device__ __forceinline__ int lds_skew(int j) { return j + (j >> 5) + (j >> 10); }
+constexpr int BUCKET_CHUNK_LDS = BUCKET_CHUNK + (BUCKET_CHUNK >> 5) + (BUCKET_CHUNK >> 10) + 4;
+
+// number of entries of the SKEWED LDS table a[skew(0..m)) that are <= u
+__device__ __forceinline__ int upper_bound_skew(const double *a, int m, double u) {
+    int lo = 0, hi = m;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[lds_skew(mid)] <= u) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Guide table: a 12-probe binary search of a 4096-entry LDS table costs ~12 instructions per probe.
+// A uniform grid of cells over the table's value range, G[k] = #{entries whose cell < k}, brackets the
+// answer for a query in cell k inside [G[k], G[k+1]] -- exactly, because guide_cell() is monotone and is
+// applied identically to the entries and to the query -- typically 1-2 entries -> ~1 probe.
+// k_bucket_count builds its table (cells over the chunk edges) with an LDS histogram + scan
+// (build_guide); k_bucket_sample fills its table while it stores the scanned CDF (StoreLdsGuide).
+// Exactness is unaffected either way: the answer always comes from comparing the entries with u.
+// ---------------------------------------------------------------------------------------------
+constexpr int GUIDE_BINS = 4096;              // k_bucket_count: cells over [0, 1) for the chunk edges
+constexpr int SGUIDE_BINS = 2048;             // k_bucket_sample: cells over one chunk's 4096 CDF entries
+
+template <int BINS>
+__device__ __forceinline__ int guide_cell(double v, double lo, double scale) {
+    const double t = (v - lo) * scale;
+    int k = t > 0.0 ? (t < (double)(BINS - 1) ? (int)t : BINS - 1) : 0;
+    return k;
+}
+
+// a: skewed LDS table of m non-decreasing values; G: int[GUIDE_BINS + 1] LDS; wtot: int[32] LDS.
+template <int BT>
+__device__ __forceinline__ void build_guide(const double *a, int m, double lo, double scale, int *G, int *wtot) {
+    constexpr int PER = GUIDE_BINS / BT;
+    static_assert(GUIDE_BINS % BT == 0, "GUIDE_BINS must be a multiple of the workgroup size");
+    for (int k = threadIdx.x; k <= GUIDE_BINS; k += BT) G[k] = 0;
+    __syncthreads();
+    for (int j = threadIdx.x; j < m; j += BT) atomicAdd(&G[guide_cell<GUIDE_BINS>(a[lds_skew(j)], lo, scale) + 1], 1);
+    __syncthreads();
+    // inclusive scan of G[1..GUIDE_BINS]: thread owns PER consecutive cells
+    int loc[PER];
+    int run = 0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        run += G[1 + threadIdx.x * PER + q];
+        loc[q] = run;
+    }
+    const int lane = threadIdx.x & (QSMC_WAVE - 1), wave = threadIdx.x / QSMC_WAVE;
+    int inc = run;
+#pragma unroll
+    for (int off = 1; off < QSMC_WAVE; off <<= 1) {
+        const int t = __shfl_up(inc, off, QSMC_WAVE);
+        if (lane >= off) inc += t;
+    }
+    if (lane == QSMC_WAVE - 1) wtot[wave] = inc;
+    __syncthreads();
+    int off0 = inc - run;
+    for (int wv = 0; wv < wave; ++wv) off0 += wtot[wv];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) G[1 + threadIdx.x * PER + q] = off0 + loc[q];
+    __syncthreads();
+}
+
+// number of entries of the skewed table a[0..m) that are <= u, u lying in guide cell k
+// guide_cell is monotone and is applied identically to the entries and to u, so entries in cells
+// below k are <= u and entries in cells above k are > u: the answer lies in [G[k], G[k + 1]] exactly.
+template <class GT>
+__device__ __forceinline__ int guided_upper_bound(const double *a, int m, const GT *G, int k, double u) {
+    int lo = G[k];
+    int hi = G[k + 1];
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[lds_skew(mid)] <= u) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// Philox stream layout of the bucketed resampler (round 0), two outputs per Philox block:
+//   slot 0: block (c | t << 32)                   attempt t of chunk c's Poisson count (k_bucket_counts)
+//           [QSMC_COUNT_BY_DRAWS: block (i >> 1), word (i & 1) = chunk draw of output i (k_bucket_count)]
+//   slot 3: block (j >> 1), word (j & 1)          top-up draw j;  slot 4: block (i), word 0: removal i
+//   slot 1: block (o >> 1), word (o & 1)          within-chunk position of slot o (k_bucket_sample)
+//   slot 2: block (n >> 1), Box-Muller comp (n&1) n = o * d + q, q-th normal of slot o
+// retries (round r >= 1) are per output: block (o, r, 0).u0 = global ancestor, (o, r, 1 + q/2) normals.
+__global__ __launch_bounds__(BUCKET_COUNT_THREADS) void k_bucket_count(
+    const double *__restrict__ offsets, int chunks, int64_t n_out, uint32_t k0, uint32_t k1,
+    uint32_t epoch, unsigned int *__restrict__ hist /* [gridDim.x][chunks] */) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *edges = reinterpret_cast<double *>(smem);                       // skewed: upper edge of chunk c
+    const int edges_len = lds_skew(chunks) + 4;
+    unsigned int *cnt = reinterpret_cast<unsigned int *>(edges + edges_len);
+    int *G = reinterpret_cast<int *>(cnt + chunks);
+    int *wtot = G + GUIDE_BINS + 1;
+    for (int c = threadIdx.x; c < chunks; c += blockDim.x) {
+        edges[lds_skew(c)] = chunk_edge(offsets, (int64_t)c + 1);
+        cnt[c] = 0u;
+    }
+    __syncthreads();
+    build_guide<BUCKET_COUNT_THREADS>(edges, chunks, 0.0, (double)GUIDE_BINS, G, wtot);
+    const int64_t n_pairs = (n_out + 1) >> 1;
+    for (int64_t pr = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pr < n_pairs;
+         pr += (int64_t)gridDim.x * blockDim.x) {
+        PhiloxStream rng{(uint64_t)pr, (epoch << 16), k0, k1};
+        double u[2];
+        rng.uniforms(0, u[0], u[1]);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            if (2 * pr + e < n_out) {
+                // #edges <= u == chunk index; u in [0, 1) so its guide cell is exactly floor(u * 4096)
+                int c = guided_upper_bound(edges, chunks, G, (int)(u[e] * (double)GUIDE_BINS), u[e]);
+                if (c > chunks - 1) c = chunks - 1;              // u beyond cdf[n-1] (rounding): Q2 clamp
+                atomicAdd(&cnt[c], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    unsigned int *row = hist + (size_t)blockIdx.x * chunks;
+    for (int c = threadIdx.x; c < chunks; c += blockDim.x) row[c] = cnt[c];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Chunk counts without drawing one uniform per output (k_bucket_count + k_bucket_reduce: 32 us at N = 1e7).
+// Poissonisation: if T ~ Poisson(lambda) items are dealt to the chunks with probabilities p_c, the chunk
+// counts are INDEPENDENT Poisson(lambda p_c) -- one draw per chunk, all in parallel, no tree and no depth --
+// and given T they are Multinomial(T; p).  With lambda = n_out - kappa sqrt(n_out) (kappa = 5) T falls short of
+// n_out by ~kappa sqrt(n_out) outputs, which are added as ordinary categorical draws (one uniform each,
+// searched against the chunk edges: 1.6e4 draws instead of 1e7); Multinomial(T) + Multinomial(n_out - T) =
+// Multinomial(n_out), exactly the law k_bucket_count samples.  Should T exceed n_out (probability 3e-7 per
+// resample) the surplus is taken away again by removing T - n_out of the dealt items uniformly at random,
+// which leaves an i.i.d. sample of size n_out: exact as well.
+//
+// poisson_draw: X ~ Poisson(mu), exact.  mu < 10: sequential search of the cdf from X = 0; otherwise PTRS
+// (W. Hoermann, "The transformed rejection method for generating Poisson random variables", Insurance:
+// Mathematics and Economics 12 (1993) 39): a squeeze accepts ~87 % of the proposals after one division and a
+// floor.  Attempt t of chunk c takes its uniforms from Philox block (c | t << 32, round 0, slot 0) and the
+// FIRST accepted attempt is the draw; G adjacent lanes evaluate attempts t0 .. t0 + G - 1 of one chunk at
+// once and the lowest accepted one is taken (ballot + shuffle) -- the value a sequential loop returns, which
+// is how the oracle's NumPy twin (oracle/philox.py: poisson_draw) computes it.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double stirling_tail(double k) {         // ln k! - [(k + 1/2) ln(k + 1) - (k + 1) + ln(2 pi) / 2]
+    static constexpr double small[10] = {
+        0.08106146679532726,  0.0413406959554093,   0.02767792568499834,  0.020790672103765093, 0.016644691189821193,
+        0.013876128823070748, 0.01189670994589177,  0.010411265261972096, 0.009255462182712733, 0.00833056343336287};
+    if (k < 10.0) return small[(int)k];
+    const double rx = 1.0 / (k + 1.0), r2 = rx * rx;
+    return (1.0 / 12.0 - (1.0 / 360.0 - (1.0 / 1260.0 - (1.0 / 1680.0 - 1.0 / 1188.0 * r2) * r2) * r2) * r2) * rx;
+}
+
+// Called by whole waves.  Lanes [gbase, gbase + G) of a wave form the group of one chunk (same mu, node, active);
+// G is a power of two <= 64.  Returns the draw to every lane of the group.
+__device__ unsigned int poisson_draw(bool active, double mu, uint32_t node, uint32_t epoch_round, uint32_t k0,
+                                     uint32_t k1, int G, int gbase) {
+    const bool need = active && mu > 0.0;
+    double y = 0.0;
+    const bool by_search = need && mu < 10.0;
+    if (by_search) {                                             // every lane of the group: same inputs, same value
+        PhiloxStream rng{(uint64_t)node, epoch_round, k0, k1};
+        double U, unused;
+        rng.uniforms(0, U, unused);
+        double pk = exp(-mu), cdf = pk, X = 0.0;
+        while (U > cdf && X < 200.0) {
+            X += 1.0;
+            pk = pk * mu / X;
+            cdf += pk;
+        }
+        y = X;
+    }
+    bool pending = need && !by_search;
+    const double smu = sqrt(mu), lmu = log(mu);
+    const double b = 0.931 + 2.53 * smu, a = -0.059 + 0.02483 * b;
+    const double linva = log(1.1239 + 1.1328 / (b - 3.4)), vr = 0.9277 - 3.6224 / (b - 2.0);
+    const int gl = (int)(threadIdx.x & (QSMC_WAVE - 1)) - gbase;
+    const unsigned long long gmask = G >= 64 ? ~0ull : ((1ull << G) - 1ull);
+    for (uint32_t t0 = 0; t0 < 4096u; t0 += (uint32_t)G) {
+        if (__ballot(pending) == 0ull) break;                    // wave-uniform
+        bool acc = false;
+        double kk = 0.0;
+        if (pending) {
+            PhiloxStream rng{(uint64_t)node | ((uint64_t)(t0 + (uint32_t)gl) << 32), epoch_round, k0, k1};
+            double U, V;
+            rng.uniforms(0, U, V);
+            const double u = U - 0.5, us = 0.5 - fabs(u);
+            kk = floor((2.0 * a / us + b) * u + mu + 0.43);
+            if (us >= 0.07 && V <= vr) acc = true;               // the squeeze
+            else if (kk >= 0.0 && !(us < 0.013 && V > us)) {
+                const double lhs = log(V) + linva - log(a / (us * us) + b);
+                const double lgk = (kk + 0.5) * log(kk + 1.0) - (kk + 1.0) + 0.91893853320467274178 + stirling_tail(kk);
+                acc = lhs <= -mu + kk * lmu - lgk;
+            }
+        }
+        const unsigned long long grp = (__ballot(acc) >> gbase) & gmask;
+        const int src = gbase + (grp ? __builtin_ctzll(grp) : 0);
+        const double first = __shfl(kk, src, QSMC_WAVE);
+        if (pending && grp) {
+            y = first;
+            pending = false;
+        }
+    }
+    return need ? (unsigned int)y : 0u;
+}
+
+// single workgroup (1024 threads): slot_off[c] = exclusive scan of counts; item_off[c] = exclusive scan of
+// ceil(counts / BUCKET_CAP); slot_off[chunks] = n_out, item_off[chunks] = #work items.  counts: global or LDS.
+__device__ __forceinline__ void bucket_plan_block(const unsigned int *counts, int chunks,
+                                                  long long *__restrict__ slot_off, int *__restrict__ item_off,
+                                                  int *__restrict__ item_chunk) {
+    __shared__ long long wtot_s[1024 / QSMC_WAVE];
+    __shared__ int wtot_i[1024 / QSMC_WAVE];
+    const int per = (chunks + 1023) / 1024;
+    const int c0 = threadIdx.x * per, c1 = min(chunks, c0 + per);
+    long long s = 0;
+    int it = 0;
+    for (int c = c0; c < c1; ++c) {
+        s += counts[c];
+        it += (int)((counts[c] + BUCKET_CAP - 1) / BUCKET_CAP);
+    }
+    // exclusive scan of the 1024 per-thread totals (integers: exact): shuffles inside a wave, 16 wave totals in LDS
+    const int lane = threadIdx.x & (QSMC_WAVE - 1), wave = threadIdx.x / QSMC_WAVE;
+    long long inc_s = s;
+    int inc_i = it;
+#pragma unroll
+    for (int off = 1; off < QSMC_WAVE; off <<= 1) {
+        const long long ts = __shfl_up(inc_s, off, QSMC_WAVE);
+        const int ti = __shfl_up(inc_i, off, QSMC_WAVE);
+        if (lane >= off) {
+            inc_s += ts;
+            inc_i += ti;
+        }
+    }
+    if (lane == QSMC_WAVE - 1) {
+        wtot_s[wave] = inc_s;
+        wtot_i[wave] = inc_i;
+    }
+    __syncthreads();
+    long long so = inc_s - s;
+    int io = inc_i - it;
+    for (int wv = 0; wv < wave; ++wv) {
+        so += wtot_s[wv];
+        io += wtot_i[wv];
+    }
+    for (int c = c0; c < c1; ++c) {
+        slot_off[c] = so;
+        item_off[c] = io;
+        const int items = (int)((counts[c] + BUCKET_CAP - 1) / BUCKET_CAP);
+        for (int k = 0; k < items; ++k) item_chunk[io + k] = c;     // work item -> chunk map
+        so += counts[c];
+        io += items;
+    }
+    if (threadIdx.x == 1023) {                                   // (after the loop: so / io have run through its chunks)
+        slot_off[chunks] = so;
+        item_off[chunks] = io;
+    }
+}
+
+// Barrier across the workgroups of ONE launch whose grid is small enough to be resident at once (16 here).  The
+// arrival counter only ever grows: the host hands every launch the value all workgroups will have brought it to
+// at each of its barriers, so nothing is reset.  No cache maintenance: the XCDs' L2s are not coherent with each
+// other inside a launch, and a release / acquire fence pair at agent scope (L2 write-back + invalidate) measured
+// ~5 us per barrier -- instead every word that crosses workgroups is written and read with agent-scope atomics
+// (which go to the coherence point), and __syncthreads() has waited for this workgroup's own before the
+// arrival is posted.  A bounded spin (~1 s): a launch that cannot become resident aborts (the next HIP call
+// reports it) rather than hanging the queue or carrying on with half the data.
+__device__ __forceinline__ void grid_barrier(unsigned long long *bar, unsigned long long target) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(bar, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned int spins = 0;
+        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 20)) {                          // cannot happen with a resident grid: fail loudly
+                __hip_atomic_fetch_add(bar + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_trap();
+            }
+        }
+    }
+    __syncthreads();
+}
+// A barrier with the cache maintenance, for bulk data written with plain stores (the redraw kernel's CDF): release
+// (L2 write-back) before the arrival, acquire (invalidate) after the wait; ~5 us, on a path most resamples skip.
+// Self-resetting (bar[0] arrivals, bar[1] departures: the last workgroup to leave clears both -- nobody can still
+// be waiting then), so a launch that never reaches the barrier touches nothing.
+__device__ __forceinline__ void grid_barrier_fenced(unsigned long long *bar) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        __hip_atomic_fetch_add(bar, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned int spins = 0;
+        while (__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned long long)gridDim.x) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1u << 20)) __builtin_trap();          // cannot happen with a resident grid: fail loudly
+        }
+        if (__hip_atomic_fetch_add(bar + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned long long)gridDim.x - 1ull) {
+            __hip_atomic_store(bar + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(bar, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __threadfence();                 // acquire for the whole workgroup: the CU's L1 and the XCD's L2 are shared
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void put_shared(unsigned int *p, unsigned int v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned int get_shared(const unsigned int *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The chunk counts in one launch (each of the three steps alone is a ~5 us launch: the floor of a dependent
+// kernel on this part):
+//   0  (if the update kernel left tile sums) the chunk edges: see below;
+//   1  counts[c] ~ Poisson(lambda mass_c / total), four lanes per chunk, chunks dealt to the workgroups;
+//   2  every workgroup sums the counts to T (a few thousand integers), and takes its share of the n_out - T
+//      categorical top-up draws against the chunk edges in LDS (1.6e4 draws on one CU were 25 us; spread over
+//      16 they are 2), collected in an LDS histogram and added to extra[];  top-up draw j takes word (j & 1) of
+//      Philox block (j >> 1, round 0, slot 3);
+//   3  workgroup 0: counts += extra; should the Poisson total have overshot, thread 0 removes the surplus item
+//      by item (removal i: word 0 of block (i, round 0, slot 4)); then the plan.
+constexpr int POISSON_G = 4;
+constexpr int BUCKET_COUNTS_BLOCKS = 16, BUCKET_COUNTS_THREADS = 1024;
+__global__ __launch_bounds__(BUCKET_COUNTS_THREADS) void k_bucket_counts(
+    double *offsets, TileSrc ts, unsigned long long *__restrict__ zero2, int chunks, int64_t n_out, double lambda,
+    uint32_t k0, uint32_t k1, uint32_t epoch, unsigned int *counts, unsigned int *extra,
+    long long *__restrict__ slot_off, int *__restrict__ item_off, int *__restrict__ item_chunk,
+    unsigned long long *bar, unsigned long long bar_base) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *edges = reinterpret_cast<double *>(smem);
+    unsigned int *hist = reinterpret_cast<unsigned int *>(edges + lds_skew(chunks) + 4);   // this workgroup's draws per chunk
+    __shared__ unsigned long long total_s;
+    const int lane = threadIdx.x & (QSMC_WAVE - 1);
+    // ---- 0: the chunk edges.  Given the update kernel's tile sums (ts.tiles), EVERY workgroup forms the monotone
+    // prefix of the chunk sums itself, straight into its LDS -- the same code on the same numbers in the same
+    // order, so all agree bit for bit, and the separate one-workgroup scan launch (9 us) is gone; workgroup 0
+    // also stores offsets[] for the sampler and clears the failed / retry counters.  Otherwise offsets[] is ready.
+    static_assert(BUCKET_COUNTS_THREADS == SCAN_SUMS_THREADS, "scan_sums_block runs on this workgroup");
+    if (ts.tiles) {
+        const bool writer = blockIdx.x == 0;
+        if (writer && threadIdx.x < 2) zero2[threadIdx.x] = 0ull;
+        scan_sums_block(nullptr, (int64_t)chunks, ts, [&](int64_t i, double v) {
+            if (i > 0) edges[lds_skew((int)i - 1)] = v;             // upper edge of chunk i - 1
+            if (writer) offsets[i] = v;
+        });
+    } else {
+        for (int c = threadIdx.x; c < chunks; c += BUCKET_COUNTS_THREADS) edges[lds_skew(c)] = offsets[c + 1];
+    }
+    for (int c = threadIdx.x; c < chunks; c += BUCKET_COUNTS_THREADS) hist[c] = 0u;
+    if (threadIdx.x == 0) total_s = 0ull;
+    __syncthreads();
+    // ---- 1: Poisson counts ----
+    const double total = edges[lds_skew(chunks - 1)];
+    constexpr int PER_PASS = BUCKET_COUNTS_THREADS / POISSON_G;
+    for (int c0 = (int)blockIdx.x * PER_PASS; c0 < chunks; c0 += (int)gridDim.x * PER_PASS) {   // (uniform per workgroup)
+        const int c = c0 + (int)threadIdx.x / POISSON_G;
+        const bool active = c < chunks;
+        double mu = 0.0;
+        if (active) {
+            const double mass = edges[lds_skew(c)] - (c > 0 ? edges[lds_skew(c - 1)] : 0.0);
+            mu = (mass > 0.0 && total > 0.0) ? lambda * mass / total : 0.0;
+        }
+        const unsigned int x = poisson_draw(active, mu, (uint32_t)c, (epoch << 16), k0, k1, POISSON_G, lane & ~(POISSON_G - 1));
+        if (active && (lane & (POISSON_G - 1)) == 0) {
+            put_shared(&counts[c], x);
+            put_shared(&extra[c], 0u);
+        }
+    }
+    grid_barrier(bar, bar_base + gridDim.x);
+    // ---- 2: the total, and this workgroup's share of the top-up ----
+    unsigned long long mine = 0ull;
+    for (int c = threadIdx.x; c < chunks; c += BUCKET_COUNTS_THREADS)
+        mine += get_shared(&counts[c]);
+    for (int off = QSMC_WAVE / 2; off > 0; off >>= 1) mine += __shfl_down(mine, off, QSMC_WAVE);
+    if (lane == 0 && mine) atomicAdd(&total_s, mine);
+    __syncthreads();
+    const long long T = (long long)total_s;
+    if (T < n_out) {
+        const int64_t deficit = n_out - T, n_pairs = (deficit + 1) >> 1;
+        for (int64_t pr = (int64_t)blockIdx.x * BUCKET_COUNTS_THREADS + threadIdx.x; pr < n_pairs;
+             pr += (int64_t)gridDim.x * BUCKET_COUNTS_THREADS) {
+            PhiloxStream rng{(uint64_t)pr, (epoch << 16), k0, k1};
+            double u[2];
+            rng.uniforms(3, u[0], u[1]);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                if (2 * pr + e < deficit) {
+                    int c = upper_bound_skew(edges, chunks, u[e]);     // #edges <= u == chunk index
+                    if (c > chunks - 1) c = chunks - 1;                // u beyond cdf[n-1] (rounding): Q2 clamp
+                    atomicAdd(&hist[c], 1u);
+                }
+            }
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < chunks; c += BUCKET_COUNTS_THREADS)
+            if (hist[c]) atomicAdd(&extra[c], hist[c]);
+    }
+    grid_barrier(bar, bar_base + 2ull * gridDim.x);
+    if (blockIdx.x != 0) return;
+    // ---- 3: final counts and the plan ----
+    unsigned int *cnt = hist;
+    for (int c = threadIdx.x; c < chunks; c += BUCKET_COUNTS_THREADS)
+        cnt[c] = get_shared(&counts[c]) + get_shared(&extra[c]);
+    __syncthreads();
+    if (T > n_out) {                                             // (uniform branch; ~3e-7 of the resamples)
+        if (threadIdx.x == 0) {
+            long long left = T;
+            for (long long i = 0; i < T - n_out; ++i, --left) {
+                PhiloxStream rng{(uint64_t)i, (epoch << 16), k0, k1};
+                double u, unused;
+                rng.uniforms(4, u, unused);
+                long long target = (long long)(u * (double)left);   // which of the remaining items goes
+                if (target > left - 1) target = left - 1;
+                int c = 0;
+                for (long long run = (long long)cnt[0]; run <= target; run += (long long)cnt[c]) ++c;
+                cnt[c] -= 1u;
+            }
+        }
+        __syncthreads();
+    }
+    for (int c = threadIdx.x; c < chunks; c += BUCKET_COUNTS_THREADS) counts[c] = cnt[c];
+    bucket_plan_block(cnt, chunks, slot_off, item_off, item_chunk);
+}
+
+// counts[c] = sum_g hist[g][c].  A workgroup takes 64 chunks; its four waves each sum a quarter of the rows
+// (coalesced 256-byte row segments), LDS combines them: 4x the workgroups and a quarter of the dependent
+// loads per thread of the one-thread-per-chunk version (8.8 -> ~4 us, the launch floor).
+__global__ __launch_bounds__(QSMC_BLOCK) void k_bucket_reduce(const unsigned int *__restrict__ hist, int rows,
+                                                              int chunks, unsigned int *__restrict__ counts) {
+    __shared__ unsigned int part[QSMC_WAVES_PER_BLOCK][QSMC_WAVE];
+    const int lane = threadIdx.x & (QSMC_WAVE - 1);
+    const int wave = threadIdx.x / QSMC_WAVE;
+    const int c = blockIdx.x * QSMC_WAVE + lane;
+    unsigned int s = 0;
+    if (c < chunks) {
+#pragma unroll 16
+        for (int g = wave; g < rows; g += QSMC_WAVES_PER_BLOCK) s += hist[(size_t)g * chunks + c];
+    }
+    part[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && c < chunks) {
+#pragma unroll
+        for (int wv = 1; wv < QSMC_WAVES_PER_BLOCK; ++wv) s += part[wv][lane];
+        counts[c] = s;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_bucket_plan(const unsigned int *__restrict__ counts, int chunks,
+                                                      long long *__restrict__ slot_off,
+                                                      int *__restrict__ item_off,
+                                                      int *__restrict__ item_chunk) {
+    bucket_plan_block(counts, chunks, slot_off, item_off, item_chunk);
+}
+
+constexpr int BUCKET_RLIST_CAP = 1024;               // per-workgroup list of outputs that need a global redraw
+
+// Draw + kick of one redraw round (round >= 1) of output slot o from the GLOBAL CDF.
+template <int DM>
+__device__ __forceinline__ bool redraw_rounds(int kind, int d, double min_freq, const double *__restrict__ x_in,
+                                              int64_t ldx_in, int64_t n_in, const double *__restrict__ cdf,
+                                              const LWArgs &lw, uint32_t k0, uint32_t k1, uint32_t epoch,
+                                              int maxiter, int64_t o, double *p) {
+    for (int round = 1; round < maxiter; ++round) {
+        PhiloxStream rng{(uint64_t)o, (epoch << 16) | (uint32_t)round, k0, k1};
+        double u0, unused;
+        rng.uniforms(0, u0, unused);
+        const int64_t j = search_right(cdf, n_in, u0);
+        double zz[DM];
+#pragma unroll
+        for (int q = 0; q < DM; q += 2) {
+            if (q < d) {
+                double z0, z1;
+                rng.normals(1 + (q >> 1), z0, z1);
+                zz[q] = z0;
+                if (q + 1 < DM) zz[q + 1] = z1;
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < DM; ++m) {
+            if (m < d) {
+                double s = 0.0;
+#pragma unroll
+                for (int q = 0; q < DM; ++q)
+                    if (q < d) s += lw.S[m * d + q] * zz[q];
+                p[m] = (lw.a * x_in[m * ldx_in + j] + (1.0 - lw.a) * lw.mean[m]) + s;
+            }
+        }
+        if (model_valid(kind, p, min_freq)) return true;
+    }
+    return false;
+}
+
+// chunk_scan_block sink of the sampler: the entry goes to the skewed LDS table and, in the same pass,
+// the guide table is filled -- entry j is the first one whose cell is >= k for every cell k in
+// (cell(prev), cell(v)], so G[k] = j there (G[0] = 0, G[SGUIDE_BINS] = len): no histogram, no atomics,
+// no extra barrier.  Runs longer than 8 cells (a dominant weight) are filled by the whole wave.
+struct StoreLdsGuide {
+    double *lcdf;
+    unsigned short *G;
+    double lo_edge, gscale;
+    bool use_guide;                                // workgroup-uniform
+    int len;
+    int cp;                                        // cell of the previous entry (carried along the lane's run)
+    __device__ __forceinline__ void operator()(int j, double v, double prev, bool live) {
+        if (live) lcdf[lds_skew(j)] = v;
+        if (!use_guide) return;
+        const int lane = threadIdx.x & (QSMC_WAVE - 1);
+        if ((j & (SCAN_PER_LANE - 1)) == 0) cp = j == 0 ? -1 : guide_cell<SGUIDE_BINS>(prev, lo_edge, gscale);
+        const int cj = live ? guide_cell<SGUIDE_BINS>(v, lo_edge, gscale) : cp;
+        const unsigned short js = (unsigned short)j;
+        // straight-line for the common run lengths 0..4
+        if (cj > cp) G[cp + 1] = js;
+        if (cj > cp + 1) G[cp + 2] = js;
+        if (cj > cp + 2) G[cp + 3] = js;
+        if (cj > cp + 3) G[cp + 4] = js;
+        if (live && j == len - 1) G[SGUIDE_BINS] = (unsigned short)len;
+        unsigned long long long_runs = __ballot(cj > cp + 4);
+        while (long_runs) {                        // a dominant weight: the wave fills the run together
+            const int src = __ffsll((long long)long_runs) - 1;
+            long_runs &= long_runs - 1;
+            const int s0 = __shfl(cp + 5, src, QSMC_WAVE), e0 = __shfl(cj, src, QSMC_WAVE);
+            const int jj = __shfl(j, src, QSMC_WAVE);
+            for (int k = s0 + lane; k <= e0; k += QSMC_WAVE) G[k] = (unsigned short)jj;
+        }
+        cp = cj;
+    }
+};
+
+// One workgroup per work item.  The chunk's CDF is SCANNED HERE from the weights (bit-identical
+// to k_chunk_scan), so the CDF never touches HBM; a particle that fails postselection on its first
+// try is queued for k_bucket_retry, which alone needs the (then materialised) global CDF.
+// Occupancy: 44 KB of LDS allows three workgroups per CU; the small-d instantiations are held to 80
+// VGPRs (6 waves/SIMD) so that the third one fits -- the kernel is VALU-issue bound and the extra
+// waves hide the LDS search and gather latency (121 -> 110 us at N = 1e7, d = 1).
+template <int D, int BT>   // D = 0: runtime d; BT = threads per workgroup
+__attribute__((amdgpu_waves_per_eu(D >= 1 && D <= 2 ? 6 : 1, 8)))
+__global__ __launch_bounds__(BT) void k_bucket_sample(
+    int kind, int d_rt, double min_freq, int postselect, const double *__restrict__ x_in, int64_t ldx_in,
+    int64_t n_in, const double *__restrict__ w, double inv_norm, const double *__restrict__ offsets,
+    int chunks, const long long *__restrict__ slot_off,
+    const int *__restrict__ item_off, const int *__restrict__ item_chunk, LWArgs lw, uint32_t k0, uint32_t k1,
+    uint32_t epoch, int maxiter, double *__restrict__ x_out, OutPlace pl,
+    unsigned long long *__restrict__ n_failed, unsigned int *__restrict__ retry_list,
+    unsigned long long *__restrict__ retry_count) {
+    constexpr int DM = D > 0 ? D : QSMC_MAX_D;
+    const int d = D > 0 ? D : d_rt;
+    __shared__ __attribute__((aligned(16))) double lcdf[BUCKET_CHUNK_LDS];
+    __shared__ unsigned short lguide[SGUIDE_BINS + 2];
+    __shared__ double wave_tot[SCAN_WAVES];
+    __shared__ unsigned short rlist[BUCKET_RLIST_CAP];          // slot - o_begin < BUCKET_CAP
+    static_assert(BT >= SCAN_THREADS, "the in-sampler chunk scan needs 512 threads");
+    __shared__ int rcount;
+    __shared__ unsigned long long rbase;
+    if ((int)blockIdx.x >= item_off[chunks]) return;
+    const int c = item_chunk[blockIdx.x];
+    const int part = (int)blockIdx.x - item_off[c];
+    const long long slot0 = slot_off[c], n_c = slot_off[c + 1] - slot0;
+    const long long t0 = (long long)part * BUCKET_CAP;
+    const long long t1 = t0 + BUCKET_CAP < n_c ? t0 + BUCKET_CAP : n_c;
+    const int64_t base = (int64_t)c * BUCKET_CHUNK;
+    const int len = (int)((n_in - base) < BUCKET_CHUNK ? (n_in - base) : BUCKET_CHUNK);
+    if (threadIdx.x == 0) rcount = 0;
+    const double lo_edge = chunk_edge(offsets, c);
+    const double hi_edge = offsets[c + 1];
+    const double gscale = (double)SGUIDE_BINS / (hi_edge - lo_edge);
+    const bool use_guide = hi_edge > lo_edge && gscale < 1e300;     // workgroup-uniform
+    chunk_scan_block(w, n_in, inv_norm, offsets, (int64_t)c, wave_tot,
+                     StoreLdsGuide{lcdf, lguide, lo_edge, gscale, use_guide, len, -1});
+    __syncthreads();
+    const int64_t o_begin = slot0 + t0, o_end = slot0 + t1;         // this item's output slots
+    unsigned long long failed = 0;
+    // pairs of output slots (2P, 2P+1) share their Philox blocks; a pair straddling two work items is
+    // evaluated by both, each writing only its own half.
+    // Stage A (ancestors): position Philox -> guided LDS search -> gather of x (d <= 4: into registers).
+    // Stage B (kick): normals Philox + Box-Muller -> Liu-West combine -> validity -> store.
+    // A is issued first so that its LDS round trips and the L2/HBM gather are in flight during B's ~600
+    // cycles of independent arithmetic (110 -> 100 us at N = 1e7; issuing A of the NEXT pair ahead of B --
+    // a software pipeline -- was measured too and is slower, 115 us: spills).  Both halves of a pair are
+    // searched even if one belongs to the neighbouring work item: no divergence, cheap.
+    constexpr bool EARLY = DM <= 4;
+    struct Anc {
+        int jl[2];
+        double xg[2][EARLY ? DM : 1];
+    };
+    auto stage_a = [&](int64_t P, Anc &an) {
+        PhiloxStream rng{(uint64_t)P, (epoch << 16), k0, k1};
+        double upos[2];
+        rng.uniforms(1, upos[0], upos[1]);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            // position inside this chunk: given the counts, uniform on [lo_edge, hi_edge)
+            const double u = lo_edge + upos[e] * (hi_edge - lo_edge);
+            int j = use_guide ? guided_upper_bound(lcdf, len, lguide, guide_cell<SGUIDE_BINS>(u, lo_edge, gscale), u)
+                              : upper_bound_skew(lcdf, len, u);
+            an.jl[e] = j > len - 1 ? len - 1 : j;
+            if (EARLY) {
+#pragma unroll
+                for (int m = 0; m < DM; ++m)
+                    if (m < d) an.xg[e][m] = x_in[m * ldx_in + base + an.jl[e]];
+            }
+        }
+    };
+    auto stage_b = [&](int64_t P, const Anc &an) {
+        double z[2 * DM];
+        PhiloxStream nrm{0, (epoch << 16), k0, k1};
+#pragma unroll
+        for (int k = 0; k < DM; ++k) {
+            if (k < d) {
+                nrm.particle = (uint64_t)P * (uint64_t)d + (uint64_t)k;
+                nrm.normals(2, z[2 * k], z[2 * k + 1]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int64_t o = 2 * P + e;
+            if (o >= o_begin && o < o_end) {
+                double p[DM];
+#pragma unroll
+                for (int m = 0; m < DM; ++m) {
+                    if (m < d) {
+                        double sm = 0.0;
+#pragma unroll
+                        for (int q = 0; q < DM; ++q)
+                            if (q < d) sm += lw.S[m * d + q] * z[e * d + q];
+                        const double xa = EARLY ? an.xg[e][m] : x_in[m * ldx_in + base + an.jl[e]];
+                        p[m] = (lw.a * xa + (1.0 - lw.a) * lw.mean[m]) + sm;
+                    }
+                }
+                bool ok = !postselect || model_valid(kind, p, min_freq);
+                if (!ok && maxiter > 1) {
+                    // queue for k_bucket_retry (needs the global CDF)
+                    const int idx = atomicAdd(&rcount, 1);
+                    if (idx < BUCKET_RLIST_CAP) rlist[idx] = (unsigned short)(o - o_begin);
+                    else retry_list[atomicAdd(retry_count, 1ull)] = (unsigned int)o;   // rare overflow path
+                    ok = true;                      // decided later
+                }
+                const int64_t row = place_row(pl, o);
+#pragma unroll
+                for (int m = 0; m < DM; ++m)
+                    if (m < d) x_out[m * pl.ld_m + row * pl.ld_s] = p[m];
+                if (!ok) ++failed;
+            }
+        }
+    };
+    for (int64_t P = (o_begin >> 1) + threadIdx.x; 2 * P < o_end; P += BT) {
+        Anc an;
+        stage_a(P, an);
+        stage_b(P, an);
+    }
+    if (failed) atomicAdd(n_failed, failed);
+    __syncthreads();
+    const int nl = rcount < BUCKET_RLIST_CAP ? rcount : BUCKET_RLIST_CAP;
+    if (nl == 0) return;
+    if (threadIdx.x == 0) rbase = atomicAdd(retry_count, (unsigned long long)nl);   // one atomic per workgroup
+    __syncthreads();
+    for (int i = threadIdx.x; i < nl; i += BT) retry_list[rbase + i] = (unsigned int)(o_begin + rlist[i]);
+}
+
+// Second chance for the queued outputs: redraw ancestor and kick from the global CDF (rounds 1..).  One launch,
+// resident grid: nothing queued (most resamples) -> leave at once (an empty launch is ~5 us;
+// the former pair -- materialise the CDF behind a gate, then redraw -- was two of them).  Otherwise every
+// workgroup scans its share of the chunks into the global CDF, all meet at a barrier, and the queue is worked off.
+// Held to 128 VGPRs (4 waves per SIMD): two workgroups fit a CU, so 256 are resident on half the CUs and two
+// processes sharing a GPU (as the tests do) both stay resident; the scan phase takes ~10 rounds instead of 19.
+constexpr int REDRAW_BLOCKS = 256;
+template <int DM>     // particle dimension bound: 4 (registers) or QSMC_MAX_D
+__attribute__((amdgpu_waves_per_eu(4, 8)))
+__global__ __launch_bounds__(SCAN_THREADS) void k_bucket_redraw(
+    int kind, int d, double min_freq, const double *__restrict__ x_in, int64_t ldx_in, int64_t n_in,
+    const double *__restrict__ w, double inv_norm, const double *__restrict__ offsets, int64_t chunks, double *cdf,
+    LWArgs lw, uint32_t k0, uint32_t k1, uint32_t epoch, int maxiter, double *__restrict__ x_out, OutPlace pl,
+    const unsigned int *__restrict__ retry_list, const unsigned long long *__restrict__ retry_count,
+    unsigned long long *__restrict__ n_failed, unsigned long long *bar) {
+    __shared__ double wave_tot[SCAN_WAVES];
+    const unsigned long long cnt = *retry_count;
+    if (cnt == 0ull) return;
+    for (int64_t c = blockIdx.x; c < chunks; c += gridDim.x) {
+        chunk_scan_block(w, n_in, inv_norm, offsets, c, wave_tot, StoreGlobal{cdf + c * SCAN_CHUNK});
+        __syncthreads();                                         // wave_tot is reused by the next chunk
+    }
+    grid_barrier_fenced(bar);
+    unsigned long long failed = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * SCAN_THREADS + threadIdx.x; i < cnt;
+         i += (unsigned long long)gridDim.x * SCAN_THREADS) {
+        const int64_t o = (int64_t)retry_list[i];
+        double p[DM];
+        const bool ok = redraw_rounds<DM>(kind, d, min_freq, x_in, ldx_in, n_in, cdf, lw, k0, k1, epoch,
+                                                  maxiter, o, p);
+        const int64_t row = place_row(pl, o);      // like the in-thread loop: the last round's value stays
+        for (int m = 0; m < d; ++m) x_out[m * pl.ld_m + row * pl.ld_s] = p[m];
+        if (!ok) ++failed;
+    }
+    if (failed) atomicAdd(n_failed, failed);
+}
+
+// copies the failed-particle counter into pinned host memory (read later, after any stream sync)
+__global__ void k_publish_counter(const unsigned long long *__restrict__ counter, double *__restrict__ mapped_slot) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *mapped_slot = (double)*counter;
+}
+
+__global__ __launch_bounds__(QSMC_BLOCK) void k_prior_uniform_philox(
+    int kind, int d, double min_freq, int postselect, LWArgs box /* mean = lo, S[0..d) = hi - lo */,
+    int64_t n, uint32_t k0, uint32_t k1, uint32_t epoch, int maxiter, double *__restrict__ x_out,
+    int64_t ldx_out, unsigned long long *__restrict__ n_failed) {
+    unsigned long long failed = 0;
+    for (int64_t i = (int64_t)blockIdx.x * QSMC_BLOCK + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * QSMC_BLOCK) {
+        double p[QSMC_MAX_D];
+        bool ok = false;
+        for (int round = 0; round < maxiter && !ok; ++round) {
+            PhiloxStream rng{(uint64_t)i, (epoch << 16) | (uint32_t)round, k0, k1};
+            for (int q = 0; q < d; q += 2) {
+                double u0, u1;
+                rng.uniforms(q >> 1, u0, u1);
+                p[q] = box.mean[q] + u0 * box.S[q];                         // lo + z * delta (:818-819)
+                if (q + 1 < d) p[q + 1] = box.mean[q + 1] + u1 * box.S[q + 1];
+            }
+            ok = !postselect || model_valid(kind, p, min_freq);
+        }
+        for (int m = 0; m < d; ++m) x_out[m * ldx_out + i] = p[m];
+        if (!ok) ++failed;
+    }
+    if (failed) atomicAdd(n_failed, failed);
+}
+

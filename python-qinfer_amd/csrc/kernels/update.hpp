@@ -1,0 +1,382 @@
+// kernels/update.hpp -- the fused Bayes update (k_update_fused, k_update_multi, hypothetical sums) and the two-level deterministic reduction they share.
+// Part of the single translation unit qsmc_kernels.hip (included there, in this order; not a stand-alone header).
+#pragma once
+
+// =============================================================================================
+// fused Bayes update
+// =============================================================================================
+constexpr int UPD_UNROLL = 4;
+
+// ---------------------------------------------------------------------------------------------
+// Two-level deterministic reduction.  Each workgroup writes NS sums + 1 min (block_publish); a
+// one-workgroup kernel (k_reduce_partials) sums the per-workgroup partials in INDEX order and writes
+// the totals to device memory AND straight into pinned host memory (no D2H copy command).
+// out layout: [sum_0 .. sum_{NS-1}, min].
+//
+// Measured alternative (round-1 profile c): doing the second level inside the same launch with an
+// agent-scope arrival ticket cost +11 us on the 44 us update kernel -- 2048 workgroups finishing
+// together saturate one atomic word (~88 arrivals/us) -- versus 4.9 us + one launch boundary here.
+// ---------------------------------------------------------------------------------------------
+struct ReduceOut {
+    double *partials;        // [grid][NS + 1]
+    double *out_dev;         // [NS + 1] device (always written)
+    double *out_mapped;      // [NS + 1] device alias of pinned host memory (nullable)
+    double *stats4;          // optional caller buffer in qsmc_update_stats_t order (nullable)
+    unsigned long long *flag;  // device alias of the pinned completion word (nullable)
+    unsigned long long seq;    // value to publish there once out_mapped is complete
+    const unsigned long long *failed_src;   // the resampler's failed-particle counter (device) ...
+    double *failed_dst;                     // ... copied to its pinned slot by every host-visible reduction
+    double *tile_sums;                      // k_update_fused only: sum of w' per TILE particles (nullable)
+};
+
+template <int NS>
+__device__ __forceinline__ void block_publish(double (&v)[NS], double mn, const ReduceOut &ro) {
+    // one barrier: every wave reduces its NS sums and the minimum, lane 0 parks them in LDS, then thread k
+    // combines value k over the waves (in wave order, as before: bitwise the same totals) and stores it --
+    // NS + 1 parallel stores instead of one thread doing them in sequence behind three more barriers
+    __shared__ double lds[QSMC_WAVES_PER_BLOCK * (NS + 1)];
+    const int lane = threadIdx.x & (QSMC_WAVE - 1);
+    const int wave = threadIdx.x / QSMC_WAVE;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) v[k] = wave_sum(v[k]);
+    mn = wave_min(mn);
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) lds[wave * (NS + 1) + k] = v[k];
+        lds[wave * (NS + 1) + NS] = mn;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k <= NS; k += QSMC_BLOCK) {
+        double s = lds[k];
+#pragma unroll
+        for (int wv = 1; wv < QSMC_WAVES_PER_BLOCK; ++wv) {
+            const double t = lds[wv * (NS + 1) + k];
+            s = (k < NS) ? s + t : fmin(s, t);
+        }
+        ro.partials[(size_t)blockIdx.x * (NS + 1) + k] = s;
+    }
+}
+
+template <int NS>
+__global__ __launch_bounds__(QSMC_BLOCK) void k_reduce_partials(int nblocks, ReduceOut ro) {
+    __shared__ double lds[QSMC_WAVES_PER_BLOCK * NS];
+    double acc[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) acc[k] = 0.0;
+    double m2 = INFINITY;
+#pragma unroll 4
+    for (int g = threadIdx.x; g < nblocks; g += QSMC_BLOCK) {
+        const double *p = ro.partials + (size_t)g * (NS + 1);
+#pragma unroll
+        for (int k = 0; k < NS; ++k) acc[k] += p[k];
+        m2 = fmin(m2, p[NS]);
+    }
+    block_sum<NS>(acc, lds);
+    m2 = block_min(m2, lds);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            ro.out_dev[k] = acc[k];
+            if (ro.out_mapped) ro.out_mapped[k] = acc[k];
+        }
+        ro.out_dev[NS] = m2;
+        if (ro.out_mapped) ro.out_mapped[NS] = m2;
+        if (ro.stats4) {                 // caller layout: qsmc_update_stats_t order, then the extra sums
+            ro.stats4[0] = acc[0];
+            ro.stats4[1] = acc[1];
+            ro.stats4[2] = m2;
+            ro.stats4[3] = acc[2];
+#pragma unroll
+            for (int k = 3; k < NS; ++k) ro.stats4[4 + (k - 3)] = acc[k];
+        }
+        // a resample queued before this reduction has finished by now (stream order): its count of particles
+        // that stayed invalid rides along (qsmc_last_resample_failed reads it after this synchronisation)
+        if (ro.failed_dst) *ro.failed_dst = (double)*ro.failed_src;
+        if (ro.flag) {                   // the host spins on this word instead of hipStreamSynchronize
+            __threadfence_system();
+            *reinterpret_cast<volatile unsigned long long *>(ro.flag) = ro.seq;
+        }
+    }
+}
+
+// Per-particle accumulation of the update: [sum w', sum w'^2, #bad, sum w' x_m (DMOM),
+// sum w' x_m x_q (m <= q)] and min w'.  DMOM > 0 folds the weighted moments of the NEW weights
+// into the same pass (x is already in registers): est_mean / est_covariance_mtx and the
+// resampler's moments then cost no extra sweep over HBM.
+template <int DMOM>
+struct UpdAcc {
+    static constexpr int NS = 3 + DMOM + DMOM * (DMOM + 1) / 2;
+    double s[NS];
+    double mn;
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) s[k] = 0.0;
+        mn = INFINITY;
+    }
+    __device__ __forceinline__ void add(double w, const double *p) {
+        s[0] += w;
+        s[1] += w * w;
+        s[2] += (w >= 0.0) ? 0.0 : 1.0;       // counts NaN too, like np.all(w >= 0)
+        mn = fmin(mn, w);                      // fmin drops NaN; s[2] records it
+        int k = 3 + DMOM;
+#pragma unroll
+        for (int m = 0; m < DMOM; ++m) {
+            const double wx = w * p[m];
+            s[3 + m] += wx;
+#pragma unroll
+            for (int q = m; q < DMOM; ++q) s[k++] += wx * p[q];
+        }
+    }
+};
+
+template <int KIND, int VEC, bool ONES, bool POW>   // ONES: w_in == nullptr stands for all-ones weights; POW: MLEModel
+__global__ __launch_bounds__(QSMC_BLOCK) void k_update_fused(
+    const double *__restrict__ x, int64_t ldx, int64_t n, const double *__restrict__ w_in,
+    double *__restrict__ w_out, double prev_norm, ExpArgs e, int64_t outcome, ReduceOut ro) {
+    constexpr int D = Model<KIND>::D;
+    constexpr int DMOM = D <= 4 ? D : 0;           // moments ride along for d <= 4
+    const int d = (KIND == QSMC_MODEL_TOMOGRAPHY) ? e.d : D;
+    constexpr int64_t TILE = (int64_t)QSMC_BLOCK * VEC * UPD_UNROLL;
+    UpdAcc<DMOM> acc;
+    acc.init();
+    // w / norm as w * (1 / norm): an fp64 division is ~25 VALU instructions per particle in a kernel whose
+    // VALU time matters (see cos_sq); the two differ by at most one rounding of the stored weight
+    const double inv_norm = 1.0 / prev_norm;
+    // Sum of the new weights per tile, for the resampler: its chunk sums (k_chunk_sums, an 80 MB read) are
+    // sums of two such tiles, so a resample that follows this update starts from them instead of reading
+    // the weights once more.  One wave reduction per wave and tile, no barrier: each wave stores its own part
+    // (k_scan_sums adds the parts in a fixed order); off when ro.tile_sums is null.
+    for (int64_t base = (int64_t)blockIdx.x * TILE; base < n; base += (int64_t)gridDim.x * TILE) {
+        double tsum = 0.0;
+        if (VEC == 2 && D <= 2 && base + TILE <= n) {
+            // full tile: every load of the tile is issued before the first likelihood is evaluated, so a wave
+            // has UPD_UNROLL x (1 + d) 16-byte loads in flight instead of 1 + d (the guarded path below
+            // serialises load -> compute -> store per sub-tile because of its bounds branches)
+            double2 wi[UPD_UNROLL], xv[UPD_UNROLL][D];
+#pragma unroll
+            for (int u = 0; u < UPD_UNROLL; ++u) {
+                const int64_t i = base + ((int64_t)u * QSMC_BLOCK + threadIdx.x) * 2;
+                if (ONES) { wi[u].x = 1.0; wi[u].y = 1.0; } else wi[u] = *reinterpret_cast<const double2 *>(w_in + i);
+#pragma unroll
+                for (int m = 0; m < D; ++m) xv[u][m] = *reinterpret_cast<const double2 *>(x + m * ldx + i);
+            }
+#pragma unroll
+            for (int u = 0; u < UPD_UNROLL; ++u) {
+                const int64_t i = base + ((int64_t)u * QSMC_BLOCK + threadIdx.x) * 2;
+                double p0[D], p1[D];
+#pragma unroll
+                for (int m = 0; m < D; ++m) { p0[m] = xv[u][m].x; p1[m] = xv[u][m].y; }
+                double2 wo;
+                wo.x = (wi[u].x * inv_norm) * model_lik<KIND, POW>(p0, e, outcome);
+                wo.y = (wi[u].y * inv_norm) * model_lik<KIND, POW>(p1, e, outcome);
+                *reinterpret_cast<double2 *>(w_out + i) = wo;
+                acc.add(wo.x, p0);
+                acc.add(wo.y, p1);
+                tsum += wo.x + wo.y;
+            }
+        } else {
+#pragma unroll
+        for (int u = 0; u < UPD_UNROLL; ++u) {
+            const int64_t i = base + ((int64_t)u * QSMC_BLOCK + threadIdx.x) * VEC;
+            if (VEC == 2) {
+                if (i + 1 < n) {
+                    double2 wi;
+                    if (ONES) { wi.x = 1.0; wi.y = 1.0; } else wi = *reinterpret_cast<const double2 *>(w_in + i);
+                    double p0[D], p1[D];
+#pragma unroll
+                    for (int m = 0; m < D; ++m) {
+                        if (m < d) {
+                            const double2 xv = *reinterpret_cast<const double2 *>(x + m * ldx + i);
+                            p0[m] = xv.x;
+                            p1[m] = xv.y;
+                        }
+                    }
+                    double2 wo;
+                    wo.x = (wi.x * inv_norm) * model_lik<KIND, POW>(p0, e, outcome);
+                    wo.y = (wi.y * inv_norm) * model_lik<KIND, POW>(p1, e, outcome);
+                    *reinterpret_cast<double2 *>(w_out + i) = wo;
+                    acc.add(wo.x, p0);
+                    acc.add(wo.y, p1);
+                    tsum += wo.x + wo.y;
+                } else if (i < n) {
+                    double p0[D];
+#pragma unroll
+                    for (int m = 0; m < D; ++m)
+                        if (m < d) p0[m] = x[m * ldx + i];
+                    const double wo = ((ONES ? 1.0 : w_in[i]) * inv_norm) * model_lik<KIND, POW>(p0, e, outcome);
+                    w_out[i] = wo;
+                    acc.add(wo, p0);
+                    tsum += wo;
+                }
+            } else {
+                if (i < n) {
+                    double p0[D];
+#pragma unroll
+                    for (int m = 0; m < D; ++m)
+                        if (m < d) p0[m] = x[m * ldx + i];
+                    const double wo = ((ONES ? 1.0 : w_in[i]) * inv_norm) * model_lik<KIND, POW>(p0, e, outcome);
+                    w_out[i] = wo;
+                    acc.add(wo, p0);
+                    tsum += wo;
+                }
+            }
+        }
+        }
+        if (ro.tile_sums) {                      // uniform
+            const double t = wave_sum(tsum);
+            if ((threadIdx.x & (QSMC_WAVE - 1)) == 0)
+                ro.tile_sums[(base / TILE) * QSMC_WAVES_PER_BLOCK + threadIdx.x / QSMC_WAVE] = t;
+        }
+    }
+    block_publish<UpdAcc<DMOM>::NS>(acc.s, acc.mn, ro);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K data in ONE pass (batch_update between two ESS checks, smc.py:459-487): the reference
+// renormalises after every datum, but the normaliser is a scalar, so
+//     w_K = w_0 * prod_k L_k / S_K,   S_k = sum_i w_0,i prod_{j<=k} L_j,i,
+// normalization_record[k] = S_k / S_{k-1} and n_ess after datum k = S_k^2 / Q_k (Q_k the sum of
+// squares).  The cloud crosses HBM once per K data instead of K times; per datum the kernel keeps
+// [S_k, Q_k, #bad_k] so the host can replay every guard / record of the reference.
+// ---------------------------------------------------------------------------------------------
+constexpr int MULTI_KMAX = 8;
+struct MultiArgs {
+    int k;
+    ExpArgs e[MULTI_KMAX];
+    int64_t outcome[MULTI_KMAX];
+};
+
+template <int KIND, bool POW>
+__global__ __launch_bounds__(QSMC_BLOCK) void k_update_multi(
+    const double *__restrict__ x, int64_t ldx, int64_t n, const double *__restrict__ w_in,
+    double *__restrict__ w_out, double prev_norm, MultiArgs ma, ReduceOut ro) {
+    constexpr int D = Model<KIND>::D;
+    constexpr int DMOM = D <= 4 ? D : 0;
+    constexpr int NS = 3 * MULTI_KMAX + DMOM + DMOM * (DMOM + 1) / 2;
+    const int d = (KIND == QSMC_MODEL_TOMOGRAPHY) ? ma.e[0].d : D;
+    double s[NS];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) s[q] = 0.0;
+    double mn = INFINITY;
+    const double inv_norm = 1.0 / prev_norm;
+    for (int64_t i = (int64_t)blockIdx.x * QSMC_BLOCK + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * QSMC_BLOCK) {
+        double p[D];
+#pragma unroll
+        for (int m = 0; m < D; ++m)
+            if (m < d) p[m] = x[m * ldx + i];
+        double w = (w_in ? w_in[i] : 1.0) * inv_norm;
+#pragma unroll
+        for (int k = 0; k < MULTI_KMAX; ++k) {
+            if (k < ma.k) {
+                w = w * model_lik<KIND, POW>(p, ma.e[k], ma.outcome[k]);
+                s[3 * k] += w;
+                s[3 * k + 1] += w * w;
+                s[3 * k + 2] += (w >= 0.0) ? 0.0 : 1.0;
+                mn = fmin(mn, w);
+            }
+        }
+        w_out[i] = w;
+        int q = 3 * MULTI_KMAX + DMOM;
+#pragma unroll
+        for (int m = 0; m < DMOM; ++m) {
+            const double wx = w * p[m];
+            s[3 * MULTI_KMAX + m] += wx;
+#pragma unroll
+            for (int m2 = m; m2 < DMOM; ++m2) s[q++] += wx * p[m2];
+        }
+    }
+    block_publish<NS>(s, mn, ro);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Experiment-design sums (bayes_risk / expected_information_gain, smc.py:553-663): for ONE
+// hypothetical experiment and up to NO outcomes, in one pass over the cloud and without
+// materialising L[n_o, N]:
+//   S0_o = sum w L_o          (= hypothetical normalisation N[o])
+//   SL_o = sum w L_o log L_o  (0 log 0 := 0)      -> N KLD = SL - S0 log S0
+//   S1_o,m = sum w L_o (x_m - c_m),  S2_o,m = sum w L_o (x_m - c_m)^2   -> N var = sum_m Q_m (S2 - S1^2/S0)
+// with w = w_raw / norm and c a shift (the current mean) that removes the cancellation of the
+// one-pass variance.  Layout of the NS sums: [o][2 + 2 D].
+// ---------------------------------------------------------------------------------------------
+template <int NO>
+struct HypArgs {
+    int n_o;
+    ExpArgs base;
+    double comb[NO], log_comb[NO];
+    int64_t outcome[NO];
+    double shift[QSMC_MAX_D];
+};
+
+template <int KIND, int NO>
+__global__ __launch_bounds__(QSMC_BLOCK) void k_hyp_sums(const double *__restrict__ x, int64_t ldx, int64_t n,
+                                                         const double *__restrict__ w, double norm,
+                                                         HypArgs<NO> ha, ReduceOut ro) {
+    constexpr int D = Model<KIND>::D <= 4 ? Model<KIND>::D : 0;    // d > 4: normalisations and SL only
+    constexpr int DD = Model<KIND>::D;
+    constexpr int PER = 2 + 2 * D;
+    constexpr int NS = NO * PER;
+    const int d = (KIND == QSMC_MODEL_TOMOGRAPHY) ? ha.base.d : DD;
+    double s[NS];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) s[q] = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * QSMC_BLOCK + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * QSMC_BLOCK) {
+        double p[DD];
+#pragma unroll
+        for (int m = 0; m < DD; ++m)
+            if (m < d) p[m] = x[m * ldx + i];
+        const double wi = (w ? w[i] : 1.0) / norm;
+        double c1[D > 0 ? D : 1];
+#pragma unroll
+        for (int m = 0; m < D; ++m) c1[m] = p[m] - ha.shift[m];
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+            if (o < ha.n_o) {
+                ExpArgs e = ha.base;
+                e.comb = ha.comb[o];
+                e.log_comb = ha.log_comb[o];
+                const double L = model_lik_rt<KIND>(p, e, ha.outcome[o]);
+                const double wl = wi * L;
+                s[o * PER] += wl;
+                s[o * PER + 1] += (L > 0.0) ? wl * log(L) : 0.0;
+#pragma unroll
+                for (int m = 0; m < D; ++m) {
+                    s[o * PER + 2 + m] += wl * c1[m];
+                    s[o * PER + 2 + D + m] += wl * c1[m] * c1[m];
+                }
+            }
+        }
+    }
+    block_publish<NS>(s, 0.0, ro);
+}
+
+// mode 0: w_out = (w_in / norm) * L   (generic-model slow path)
+// mode 1: w_out = clip(w_in / norm, 0, 1)   (negative-weight guard)
+// mode 2: w_out = w_in / norm               (materialise; stats still produced)
+// mode 3: stats of w_in / norm only (no store)
+template <int MODE>
+__global__ __launch_bounds__(QSMC_BLOCK) void k_weights_pass(const double *__restrict__ L, int64_t n,
+                                                             const double *__restrict__ w_in,
+                                                             double *__restrict__ w_out, double norm,
+                                                             ReduceOut ro) {
+    UpdAcc<0> acc;
+    acc.init();
+    for (int64_t i = (int64_t)blockIdx.x * QSMC_BLOCK + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * QSMC_BLOCK) {
+        double w = w_in[i] / norm;
+        if (MODE == 0) w = w * L[i];
+        if (MODE == 1 && w == w) w = fmin(fmax(w, 0.0), 1.0);   // np.clip keeps NaN as NaN
+        if (MODE != 3 && MODE != 4) w_out[i] = w;
+        if (MODE == 4) {
+            // est_entropy (distributions.py:457-464): -sum_{w > 0} w log w, carried in the sumsq slot
+            acc.s[0] += w;
+            acc.s[1] += w > 0.0 ? -(w * log(w)) : 0.0;
+            acc.mn = fmin(acc.mn, w);
+        } else {
+            acc.add(w, nullptr);
+        }
+    }
+    block_publish<3>(acc.s, acc.mn, ro);
+}
+

@@ -2,7 +2,11 @@
 of the kernel source.  Measurement tooling only; nothing here ships."""
 import os, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = open(os.path.join(root, 'python-qinfer_amd/csrc/qsmc_kernels.hip')).read()
+csrc = os.path.join(root, 'python-qinfer_amd/csrc')
+src = open(os.path.join(csrc, 'qsmc_kernels.hip')).read()
+for line in [l for l in src.split('\n') if l.startswith('#include "kernels/')]:     # flatten: the anchors below span files
+    part = open(os.path.join(csrc, line.split('"')[1])).read().replace('#pragma once\n', '')
+    src = src.replace(line, part, 1)
 def rep(s, old, new):
     assert old in s, old[:60]
     return s.replace(old, new, 1)
