@@ -58,6 +58,21 @@ __host__ __device__ __attribute__((noinline)) double cos_sq_full_range(double x)
     return c * c;
 }
 
+// Polynomial coefficients of cos_sq: on the device they come from constant memory, i.e. scalar loads into SGPRs.
+// As literals every Horner step compiled to a v_mov_b64 (the constant into the accumulator) + v_fmac_f64 -- 226
+// moves in k_update_fused, 15 % of its VALU instructions; as SGPR operands of v_fma_f64 they cost nothing (VALU
+// instructions -12 %, 115 -> 95 VGPRs).  The weighted kernel is HBM-bound and does not notice (40.6 us); the
+// implicit-weight variant, which streams a third less, went 33.0 -> 31.3 us.  Same values, same results.
+#ifdef __HIP_DEVICE_COMPILE__
+__constant__ double CSQ_K[12] = {
+    1.58969099521155010221e-10,  -2.50507602534068634195e-08, 2.75573137070700676789e-06,      // sin: z^5 .. z^0
+    -1.98412698298579493134e-04, 8.33333333332248946124e-03,  -1.66666666666666324348e-01,
+    -1.13596475577881948265e-11, 2.08757232129817482790e-09,  -2.75573143513906633035e-07,     // cos: z^5 .. z^0
+    2.48015872894767294178e-05,  -1.38888888888741095749e-03, 4.16666666666666019037e-02};
+#define CSQ(i, lit) CSQ_K[i]
+#else
+#define CSQ(i, lit) (lit)
+#endif
 __host__ __device__ __forceinline__ double cos_sq(double x) {
     const double ax = fabs(x);
     if (!(ax <= 1.0e10)) return cos_sq_full_range(x);      // huge, inf or NaN
@@ -65,17 +80,17 @@ __host__ __device__ __forceinline__ double cos_sq(double x) {
     double r = fma(-k, 1.57079632679489655800e+00, ax);
     r = fma(-k, 6.12323399573676603587e-17, r);
     const double z = r * r;
-    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-    ps = fma(z, ps, 2.75573137070700676789e-06);
-    ps = fma(z, ps, -1.98412698298579493134e-04);
-    ps = fma(z, ps, 8.33333333332248946124e-03);
-    ps = fma(z, ps, -1.66666666666666324348e-01);
+    double ps = fma(z, CSQ(0, 1.58969099521155010221e-10), CSQ(1, -2.50507602534068634195e-08));
+    ps = fma(z, ps, CSQ(2, 2.75573137070700676789e-06));
+    ps = fma(z, ps, CSQ(3, -1.98412698298579493134e-04));
+    ps = fma(z, ps, CSQ(4, 8.33333333332248946124e-03));
+    ps = fma(z, ps, CSQ(5, -1.66666666666666324348e-01));
     const double sn = fma(r * z, ps, r);
-    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-    pc = fma(z, pc, -2.75573143513906633035e-07);
-    pc = fma(z, pc, 2.48015872894767294178e-05);
-    pc = fma(z, pc, -1.38888888888741095749e-03);
-    pc = fma(z, pc, 4.16666666666666019037e-02);
+    double pc = fma(z, CSQ(6, -1.13596475577881948265e-11), CSQ(7, 2.08757232129817482790e-09));
+    pc = fma(z, pc, CSQ(8, -2.75573143513906633035e-07));
+    pc = fma(z, pc, CSQ(9, 2.48015872894767294178e-05));
+    pc = fma(z, pc, CSQ(10, -1.38888888888741095749e-03));
+    pc = fma(z, pc, CSQ(11, 4.16666666666666019037e-02));
     const double cs = 1.0 - (0.5 * z - (z * z) * pc);
     const double kh = 0.5 * k;
     const double v = (kh != floor(kh)) ? sn : cs;          // k odd: the square is sin^2 r
