@@ -53,6 +53,73 @@ __host__ __device__ __forceinline__ double two_outcome(double pr0, int64_t outco
 // against the reference's own numbers up to t = (9/8)^199 (G2).  Beyond 1e10 rad: the library cos.
 // (out of line on purpose: inlined, the library cos and its Payne-Hanek tables cost the update kernel
 // 14 VGPRs and a wave of occupancy for a path no lane takes below 1e10 rad)
+// ---------------------------------------------------------------------------------------------
+// ln and exp for the likelihoods that need them (binomial pmf, RB survival p^m, T2 decay, MLE power).  The
+// library's fp64 log / log1p / exp are written for every corner of double and, inlined, made the binomial
+// update kernel 7000 VALU instructions (5x the precession one, VALU-bound at twice its time).  The arguments
+// here are plain -- probabilities in [0, 1], exponents within +-700 -- so the classic fdlibm reductions do
+// (e_log.c, e_exp.c: < 1 ulp), with the coefficients in constant memory (see cos_sq) and everything unusual
+// (zero, subnormal, negative, inf, NaN, overflow) sent to the library out of line.  Host code keeps libm.
+// ---------------------------------------------------------------------------------------------
+#ifdef __HIP_DEVICE_COMPILE__
+__device__ __attribute__((noinline)) double log_full_range(double x) { return log(x); }
+__device__ __attribute__((noinline)) double exp_full_range(double x) { return exp(x); }
+__constant__ double FLOG_K[7] = {1.531383769920937332e-01, 2.222219843214978396e-01, 3.999999999940941908e-01,
+                                 1.479819860511658591e-01, 1.818357216161805012e-01, 2.857142874366239149e-01,
+                                 6.666666666666735130e-01};
+__constant__ double FEXP_K[5] = {4.13813679705723846039e-08, -1.65339022054652515390e-06, 6.61375632143793436117e-05,
+                                 -2.77777777770155933842e-03, 1.66666666666666019037e-01};
+__device__ __forceinline__ double fast_div(double n, double d) {       // finite d > 0: rcp seed, two Newton steps, one correction
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    const double q = n * r;
+    return fma(fma(-d, q, n), r, q);
+}
+__device__ __forceinline__ double fast_log(double x) {
+    if (!(x >= 2.2250738585072014e-308 && x < 1.7976931348623157e308)) return log_full_range(x);
+    int hx = __double2hiint(x);
+    int k = (hx >> 20) - 1023;
+    hx &= 0x000fffff;
+    const int i = (hx + 0x95f64) & 0x100000;                   // mantissa >= sqrt(2): use m / 2
+    const double m = __hiloint2double(hx | (i ^ 0x3ff00000), __double2loint(x));
+    k += i >> 20;
+    const double f = m - 1.0;
+    const double s = fast_div(f, 2.0 + f);
+    const double z = s * s;
+    const double w = z * z;
+    const double t1 = w * fma(w, fma(w, FLOG_K[0], FLOG_K[1]), FLOG_K[2]);
+    const double t2 = z * fma(w, fma(w, fma(w, FLOG_K[3], FLOG_K[4]), FLOG_K[5]), FLOG_K[6]);
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)k;
+    return dk * 6.93147180369123816490e-01 - ((hfsq - fma(s, hfsq + R, dk * 1.90821492927058770002e-10)) - f);
+}
+// ln(1 - p) for p in [0, 1): w = fl(1 - p) misses 1 - p by exactly d = (w - 1) + p, and ln(w - d) = ln w - d / w to
+// first order in d / w <= 2^-53 -- what log1p(-p) gives, to the last bit or two, for the price of one division.
+__device__ __forceinline__ double fast_log1m(double p) {
+    const double w = 1.0 - p;
+    if (!(w > 0.0)) return log_full_range(w);                    // p >= 1 (or NaN)
+    const double d = (w - 1.0) + p;
+    return fast_log(w) - fast_div(d, w);
+}
+__device__ __forceinline__ double fast_exp(double x) {
+    if (!(x > -708.0 && x < 709.0)) return exp_full_range(x);    // underflow / overflow range, inf, NaN
+    const double k = rint(x * 1.44269504088896338700e+00);
+    const double hi = fma(-k, 6.93147180369123816490e-01, x);   // k ln2_hi is exact: ln2_hi ends in 32 zero bits
+    const double lo = k * 1.90821492927058770002e-10;
+    const double r = hi - lo;
+    const double t = r * r;
+    const double c = r - t * fma(t, fma(t, fma(t, fma(t, FEXP_K[0], FEXP_K[1]), FEXP_K[2]), FEXP_K[3]), FEXP_K[4]);
+    const double y = 1.0 - ((lo - fast_div(r * c, 2.0 - c)) - hi);
+    return ldexp(y, (int)k);
+}
+#else
+__host__ inline double fast_log(double x) { return log(x); }
+__host__ inline double fast_log1m(double p) { return log1p(-p); }
+__host__ inline double fast_exp(double x) { return exp(x); }
+#endif
+
 __host__ __device__ __attribute__((noinline)) double cos_sq_full_range(double x) {
     const double c = cos(x);
     return c * c;
@@ -123,8 +190,8 @@ __host__ __device__ __forceinline__ double binom_pmf(double pr1, const ExpArgs &
     // two fp64 pow() (each a log + an exp in extended precision, ~150 instructions; the binomial update kernel
     // was 4x the precession one).  Relative error ~ (k + n - k) eps |ln| ~ 1e-14 at n_meas = 25, inside the 1e-12
     // the closed form is held to against SciPy's pmf (G2, G8).  0 * ln 0 never forms: a zero exponent drops its term.
-    const double lp = (k > 0.0 ? k * log(pr1) : 0.0) + (e.n_meas - k > 0.0 ? (e.n_meas - k) * log1p(-pr1) : 0.0);
-    return isfinite(e.comb) ? e.comb * exp(lp) : exp(e.log_comb + lp);      // huge n_meas: C(n,k) itself in log space
+    const double lp = (k > 0.0 ? k * fast_log(pr1) : 0.0) + (e.n_meas - k > 0.0 ? (e.n_meas - k) * fast_log1m(pr1) : 0.0);
+    return isfinite(e.comb) ? e.comb * fast_exp(lp) : fast_exp(e.log_comb + lp);      // huge n_meas: C(n,k) itself in log space
 }
 
 template <> struct Model<QSMC_MODEL_BINOMIAL_PRECESSION> {
@@ -144,7 +211,7 @@ template <> struct Model<QSMC_MODEL_BINOMIAL_PRECESSION> {
 __host__ __device__ __forceinline__ double rb_pow(double p, double m) {
     if (m == 0.0) return 1.0;                    // 0 ** 0 == 1 as well
     if (!(p > 0.0)) return p == 0.0 ? 0.0 : pow(p, m);      // 0, negative (invalid particle) or NaN: the library's answer
-    return exp(m * log(p));
+    return fast_exp(m * fast_log(p));
 }
 
 template <> struct Model<QSMC_MODEL_RB> {
@@ -219,7 +286,7 @@ template <> struct Model<QSMC_MODEL_UNKNOWN_T2> {
     static constexpr int D = 2;
     static __host__ __device__ __forceinline__ double lik(const double *p, const ExpArgs &e, int64_t o) {
         // test_models.py:247-257: visibility = exp(-t / T2); pr0 = vis cos^2(w t / 2) + (1 - vis) / 2
-        const double vis = exp(-e.t * p[1]);
+        const double vis = fast_exp(-e.t * p[1]);
         const double pr0 = vis * cos_sq(p[0] * e.t / 2.0) + (1.0 - vis) / 2.0;
         return two_outcome(pr0, o);
     }
@@ -235,7 +302,7 @@ template <> struct Model<QSMC_MODEL_UNKNOWN_T2> {
 template <int KIND, bool POW>
 __host__ __device__ __forceinline__ double model_lik(const double *p, const ExpArgs &e, int64_t o) {
     const double L = Model<KIND>::lik(p, e, o);
-    if (POW) return L > 0.0 ? exp(e.lik_pow * log(L)) : pow(L, e.lik_pow);     // (see rb_pow: same error argument)
+    if (POW) return L > 0.0 ? fast_exp(e.lik_pow * fast_log(L)) : pow(L, e.lik_pow);     // (see rb_pow: same error argument)
     return L;
 }
 
