@@ -142,6 +142,32 @@ def test_likelihood_unknown_t2_and_mle_g9(qi, golden):
     np.testing.assert_allclose(L2, g["mle_prec_L"] ** 2.0, rtol=1e-13, atol=3 * ULP4)
 
 
+def test_fast_log_exp_relative_accuracy(qi):
+    """The likelihoods' own ln / exp (qsmc_device.h: fast_log, fast_exp) in RELATIVE terms, over the whole range a
+    likelihood takes: MLEModel's L ** gamma = exp(gamma ln L) against an 80-bit power of the very L the plain model
+    returns (same cos^2, so only the power differs).  Error model: (|gamma ln L| + 2) eps, a few of them."""
+    prec = qi.SimplePrecessionModel()
+    rs = np.random.RandomState(8)
+    # omega t / 2 near odd multiples of pi/2 -> L(0) = cos^2 down to ~1e-30; elsewhere O(1)
+    t = np.array([7.0, 151.0, 4001.0])
+    k = rs.randint(0, 40, size=4000)
+    x = ((2 * k + 1) * np.pi / t[rs.randint(0, 3, size=4000)] + 10.0 ** rs.uniform(-15, -1, 4000) * rs.choice([-1, 1], 4000))
+    x = np.abs(np.concatenate([x, rs.uniform(0, 1, 4000)]))[:, None]
+    L0 = prec.likelihood(np.array([0, 1]), x, t)                     # (2, N, 3)
+    assert L0.min() < 1e-20 and L0.max() > 0.99
+    for gamma in (0.5, 2.0, 7.3):
+        m = qi.MLEModel(prec, gamma)
+        got = m.likelihood(np.array([0, 1]), x, t)
+        ref = (L0.astype(np.longdouble) ** np.longdouble(gamma)).astype(np.float64)
+        pos = L0 > 0
+        with np.errstate(divide="ignore", invalid="ignore"):
+            budget = 4 * 1.1e-16 * (np.abs(gamma * np.log(np.where(pos, L0, 1.0))) + 2.0)
+            rel = np.abs(got - ref) / np.where(ref > 0, ref, 1.0)
+        ok = np.where(ref > 1e-300, rel <= budget, np.abs(got - ref) <= 1e-300)
+        assert ok.all(), (gamma, float((rel / budget)[ref > 1e-300].max()))
+        np.testing.assert_array_equal(got[~pos], 0.0 if gamma > 0 else 1.0)
+
+
 def test_likelihood_tomography_g2(qi, golden):
     g = golden("g2_likelihoods")
     basis = qi.tomography.pauli_basis(2)
