@@ -339,7 +339,7 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_hyp_sums(const double *__restric
                 const double L = model_lik_rt<KIND>(p, e, ha.outcome[o]);
                 const double wl = wi * L;
                 s[o * PER] += wl;
-                s[o * PER + 1] += (L > 0.0) ? wl * log(L) : 0.0;
+                s[o * PER + 1] += (L > 0.0) ? wl * fast_log(L) : 0.0;
 #pragma unroll
                 for (int m = 0; m < D; ++m) {
                     s[o * PER + 2 + m] += wl * c1[m];
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_weights_pass(const double *__res
         if (MODE == 4) {
             // est_entropy (distributions.py:457-464): -sum_{w > 0} w log w, carried in the sumsq slot
             acc.s[0] += w;
-            acc.s[1] += w > 0.0 ? -(w * log(w)) : 0.0;
+            acc.s[1] += w > 0.0 ? -(w * fast_log(w)) : 0.0;
             acc.mn = fmin(acc.mn, w);
         } else {
             acc.add(w, nullptr);

@@ -115,9 +115,10 @@ __device__ __forceinline__ double fast_exp(double x) {
     return ldexp(y, (int)k);
 }
 #else
-__host__ inline double fast_log(double x) { return log(x); }
-__host__ inline double fast_log1m(double p) { return log1p(-p); }
-__host__ inline double fast_exp(double x) { return exp(x); }
+// (host compilation pass: what host code calls, and what kernels are type-checked against)
+__host__ __device__ inline double fast_log(double x) { return log(x); }
+__host__ __device__ inline double fast_log1m(double p) { return log1p(-p); }
+__host__ __device__ inline double fast_exp(double x) { return exp(x); }
 #endif
 
 __host__ __device__ __attribute__((noinline)) double cos_sq_full_range(double x) {
