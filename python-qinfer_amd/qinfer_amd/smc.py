@@ -135,6 +135,13 @@ class SMCUpdater(ParticleDistribution):
         return out
 
     def _moments(self):
+        c = self._moments_cache
+        if c is not None and len(c) == 4:
+            # left by update(): the packed sums [sum w'x, upper(sum w'xx^T)] of the fused kernel and their
+            # normaliser -- unpacked only when somebody asks (a resample, est_mean, ...), not on every datum
+            _, s0, raw, nrm = c
+            d = self._x.shape[0]
+            c = self._moments_cache = (s0, raw[:d] / nrm, self._eng._unpack_upper(raw[d:], d) / nrm)
         if self._moments_cache is None:
             if self._comm is None:
                 self._moments_cache = self._eng.moments(self._x, self._weights(), self._norm)
@@ -283,15 +290,14 @@ class SMCUpdater(ParticleDistribution):
                     eng, st.sum, st.sumsq, st.min, st.n_bad, eng._mom[d] if n_mom else None)
                 self._shard_sums = self._comm.last_shard_sums
                 if n_mom:
-                    g = self._comm.last_extra
-                    fused_moments = (g[:d].copy(), eng._unpack_upper(g[d:], d))
+                    fused_moments = self._comm.last_extra            # (a copy: packed sums, see _moments)
                 st = None
             elif d <= 4:
                 # the kernel also returns sum w'x, sum w'xx^T of the new weights (x is in registers
                 # anyway): est_mean / est_covariance_mtx / the resampler need no further pass
-                st, m1, m2 = eng.update_fused(self._desc, self._x, self._w, w_out, self._norm, exps[0],
-                                              _as_int_outcome(outcome), moments=True)
-                fused_moments = (m1, m2)
+                st = eng.update_fused(self._desc, self._x, self._w, w_out, self._norm, exps[0],
+                                      _as_int_outcome(outcome), moments="raw")
+                fused_moments = eng._mom[d].copy()                   # packed sums, unpacked lazily (_moments)
             else:
                 st = eng.update_fused(self._desc, self._x, self._w, w_out, self._norm, exps[0],
                                       _as_int_outcome(outcome))
@@ -345,7 +351,7 @@ class SMCUpdater(ParticleDistribution):
             # follows may take its chunk sums from that kernel's tile sums (resamplers._arm_update_sums)
             self._w_token = eng.update_gen
         if fused_moments is not None and n_bad == 0 and new_norm != 0:
-            self._moments_cache = (sum_w, fused_moments[0] / new_norm, fused_moments[1] / new_norm)
+            self._moments_cache = ("packed", sum_w, fused_moments, new_norm)
         self._normalization_record.append(norm)                      # smc.py:444
 
         step = getattr(self.model, "_native_timestep", None)
