@@ -753,7 +753,15 @@ __global__ __launch_bounds__(BT) void k_bucket_sample(
     // cycles of independent arithmetic (110 -> 100 us at N = 1e7; issuing A of the NEXT pair ahead of B --
     // a software pipeline -- was measured too and is slower, 115 us: spills).  Both halves of a pair are
     // searched even if one belongs to the neighbouring work item: no divergence, cheap.
-    constexpr bool EARLY = DM <= 4;
+    // d = 16 (2-qubit tomography, BIG): (i) the 32 ancestor coordinates of a pair are gathered in stage A as well,
+    // in flight during the kick's arithmetic instead of between its products; (ii) S z runs as 8 + 8 steps of a
+    // RUN-TIME loop -- draw one Box-Muller pair, add its two columns of S into the 16 sums -- so that only two
+    // columns of S (scalar loads at a run-time offset) and two normals are live: fully unrolled, all 256 entries
+    // of S sat in SGPRs spilled to VGPR lanes (2200 v_readlane / v_writelane per pair).  Same products, same order
+    // of additions: bit-identical particles.  413 -> 386 us at N = 1.25e6 -- modest, because the kernel is simply
+    // heavy: 16 Box-Muller normals and a 16 x 16 product per output, ~12k issue cycles at two waves per SIMD.
+    constexpr bool BIG = (D == 16);
+    constexpr bool EARLY = DM <= 4 || BIG;
     struct Anc {
         int jl[2];
         double xg[2][EARLY ? DM : 1];
@@ -777,13 +785,35 @@ __global__ __launch_bounds__(BT) void k_bucket_sample(
         }
     };
     auto stage_b = [&](int64_t P, const Anc &an) {
-        double z[2 * DM];
+        double z[BIG ? 2 : 2 * DM];
+        double acc[BIG ? 2 : 1][BIG ? DM : 1];
         PhiloxStream nrm{0, (epoch << 16), k0, k1};
+        if (BIG) {
 #pragma unroll
-        for (int k = 0; k < DM; ++k) {
-            if (k < d) {
-                nrm.particle = (uint64_t)P * (uint64_t)d + (uint64_t)k;
-                nrm.normals(2, z[2 * k], z[2 * k + 1]);
+            for (int e = 0; e < 2; ++e) {
+#pragma unroll
+                for (int m = 0; m < DM; ++m) acc[e][BIG ? m : 0] = 0.0;
+#pragma unroll 1
+                for (int kq = 0; kq < DM / 2; ++kq) {            // normals 2 kq, 2 kq + 1 of output e
+                    nrm.particle = (uint64_t)P * (uint64_t)DM + (uint64_t)(e * (DM / 2) + kq);
+                    nrm.normals(2, z[0], z[1]);
+                    const int q = 2 * kq;
+#pragma unroll
+                    for (int m = 0; m < DM; ++m) {
+                        double t = acc[e][BIG ? m : 0];
+                        t += lw.S[m * DM + q] * z[0];
+                        t += lw.S[m * DM + q + 1] * z[1];
+                        acc[e][BIG ? m : 0] = t;
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < DM; ++k) {
+                if (k < d) {
+                    nrm.particle = (uint64_t)P * (uint64_t)d + (uint64_t)k;
+                    nrm.normals(2, z[BIG ? 0 : 2 * k], z[BIG ? 1 : 2 * k + 1]);
+                }
             }
         }
 #pragma unroll
@@ -795,9 +825,13 @@ __global__ __launch_bounds__(BT) void k_bucket_sample(
                 for (int m = 0; m < DM; ++m) {
                     if (m < d) {
                         double sm = 0.0;
+                        if (BIG) {
+                            sm = acc[BIG ? e : 0][BIG ? m : 0];
+                        } else {
 #pragma unroll
-                        for (int q = 0; q < DM; ++q)
-                            if (q < d) sm += lw.S[m * d + q] * z[e * d + q];
+                            for (int q = 0; q < DM; ++q)
+                                if (q < d) sm += lw.S[m * d + q] * z[BIG ? 0 : e * d + q];
+                        }
                         const double xa = EARLY ? an.xg[e][m] : x_in[m * ldx_in + base + an.jl[e]];
                         p[m] = (lw.a * xa + (1.0 - lw.a) * lw.mean[m]) + sm;
                     }
