@@ -496,7 +496,7 @@ __device__ __forceinline__ unsigned int get_shared(const unsigned int *p) {
 //   3  workgroup 0: counts += extra; should the Poisson total have overshot, thread 0 removes the surplus item
 //      by item (removal i: word 0 of block (i, round 0, slot 4)); then the plan.
 constexpr int POISSON_G = 4;
-constexpr int BUCKET_COUNTS_BLOCKS = 16, BUCKET_COUNTS_THREADS = 1024;
+constexpr int BUCKET_COUNTS_BLOCKS = 16, BUCKET_COUNTS_THREADS = 1024;     // (8 workgroups: +4 us; 32: no gain)
 __global__ __launch_bounds__(BUCKET_COUNTS_THREADS) void k_bucket_counts(
     double *offsets, TileSrc ts, unsigned long long *__restrict__ zero2, int chunks, int64_t n_out, double lambda,
     uint32_t k0, uint32_t k1, uint32_t epoch, unsigned int *counts, unsigned int *extra,
