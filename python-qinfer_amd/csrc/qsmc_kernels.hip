@@ -54,6 +54,7 @@ struct qsmc_ctx {
     unsigned long long *gbar;      // device: [0] arrival counter of the count kernel's barriers (only ever grows), [1] its
                                    // timeouts; [2], [3] arrivals / departures of the redraw kernel's self-resetting barrier
     unsigned long long gbar_base;  // host shadow: arrivals handed out so far
+    int cu_count;                  // compute units of the device (bounds the resident grids of the barrier kernels)
     void *sort_tmp;                // rocPRIM temporary storage + key/value staging for qsmc_argsort
     size_t sort_tmp_cap;           // in bytes
     double *tile_sums;             // sum of w' per update-kernel tile, written by the last qsmc_update_fused
@@ -466,6 +467,11 @@ int qsmc_create(qsmc_handle_t *out, int device) {
     if (e == hipSuccess) e = hipHostMalloc(&h->flag, 64, hipHostMallocMapped);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&h->flag_dev, h->flag, 0);
     if (e == hipSuccess) *h->flag = 0ull;
+    if (e == hipSuccess) {
+        int cus = 0;
+        e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+        h->cu_count = cus > 0 ? cus : 1;
+    }
     if (e != hipSuccess) {
         delete h;
         return QSMC_ERR_HIP;
@@ -990,8 +996,10 @@ static int resample_prefix(qsmc_ctx *h, const double *w, int64_t n_in, double no
     BucketPlan bp;
     rc = bucket_plan_layout(h, chunks64, n_out, &bp);
     if (rc) return rc;
-    static const bool count_by_draws = getenv("QSMC_COUNT_BY_DRAWS") != nullptr;   // (measurement switch: the
+    static const bool count_by_draws_env = getenv("QSMC_COUNT_BY_DRAWS") != nullptr;   // (measurement switch: the
                                                                 //  one-uniform-per-output histogram, same law)
+    // (k_bucket_counts meets at grid barriers: its 16 workgroups need a CU each -- any real part has them)
+    const bool count_by_draws = count_by_draws_env || h->cu_count < BUCKET_COUNTS_BLOCKS;
     // with tile sums the bucketed count kernel forms the offsets itself; otherwise: chunk sums, then the scan
     const bool scan_in_counts = ts.tiles && bp.bucketed && !count_by_draws;
     if (!ts.tiles)
@@ -1111,11 +1119,14 @@ static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int3
             // only if some particle asked for a global redraw do these two do any work
             // (more than two processes on one GPU -- bench.py's control-flow check -- must shrink the grid: all of
             //  them have to be resident together, 512 workgroup slots in total)
-            static const int redraw_blocks = [] {
+            static const int redraw_env = [] {
                 const char *e = getenv("QSMC_REDRAW_BLOCKS");
-                const int v = e ? atoi(e) : REDRAW_BLOCKS;
-                return v < 1 ? 1 : (v > REDRAW_BLOCKS ? REDRAW_BLOCKS : v);
+                return e ? atoi(e) : REDRAW_BLOCKS;
             }();
+            // never more than one workgroup per CU of THIS device (a partitioned part has fewer CUs than 256): the
+            // grid must be resident as a whole, and half of the two-per-CU slots stay free for a second process
+            int redraw_blocks = redraw_env < h->cu_count ? redraw_env : h->cu_count;
+            redraw_blocks = redraw_blocks < 1 ? 1 : (redraw_blocks > REDRAW_BLOCKS ? REDRAW_BLOCKS : redraw_blocks);
             hipLaunchKernelGGL((d <= 4 ? k_bucket_redraw<4> : k_bucket_redraw<QSMC_MAX_D>), dim3(redraw_blocks),
                                dim3(SCAN_THREADS), 0, s, model->kind, d,
                                model->min_freq, x_in, ldx_in, n_in, w, inv_norm, offsets, chunks64, h->cdf_scratch, lw,
