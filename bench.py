@@ -5,19 +5,23 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE config 2 = SURVEY C2): SimplePrecessionModel, 1e7 particles PER GPU, fp64,
-LiuWestResampler(a=0.98), resample_thresh 0.5, prior U[0,1], true omega = 0.3, experiment
-schedule t_k = (9/8)^k (k = 0..199, wrapping with a prior reset), outcomes simulated once on the
-host from a fixed seed (they do not depend on N).  A "step" is one `SMCUpdater.update(outcome_k,
-t_k)` -- exactly what the reference's perf_test times (perf_testing.py:250-251) -- INCLUDING any
-resample it triggers.  The cloud is resident in HBM before the timed region; device RNG (Philox).
+Headline workload (BASELINE config 2 = SURVEY C2): SimplePrecessionModel, 1e7 particles PER GPU, fp64,
+LiuWestResampler(a=0.98), resample_thresh 0.5, prior U[0,1], true omega = 0.3, experiment schedule
+t_k = (9/8)^k (k = 0..199, wrapping with a prior reset), outcomes simulated once on the host from a fixed
+seed (they do not depend on N).  A "step" is one `SMCUpdater.update(outcome_k, t_k)` -- exactly what the
+reference's perf_test times (perf_testing.py:250-251) -- INCLUDING any resample it triggers.  The cloud is
+resident in HBM before the timed region; device RNG (Philox).
 
 One JSON line on rank 0 with `value` = N_total * K / wall, plus
-  roofline:     the fused update kernel's achieved algorithmic HBM bytes/s (24 B/particle: read x,
-                read w, write w; 16 B for the first update after a resample, whose uniform weights
-                are implicit) from HIP-event kernel durations measured inside the timed region;
-  cpu_baseline: the CPU oracle (NumPy restatement of the reference, oracle/np_oracle.py) timed
-                here on the host on a bounded sample of the same workload.
+  roofline            the fused update kernel's achieved algorithmic HBM bytes/s (24 B/particle) from HIP-event
+                      kernel durations measured inside the timed region (+ a census of every kernel kind taken right
+                      after it, all launches timed, so that the numbers do not hang on two launches at --steps 20);
+  roofline_beyond_l3  the same kernel at N = 1e8 (2.4 GB working set: past the 256 MB Infinity Cache);
+  other_configs       BASELINE configs 3, 4 (per-GPU share) and 5 (per-GPU share) with their SURVEY 8(d) schedules:
+                      p-u/s, and each one's kernels against their 16 + 8 d bytes / particle;
+  cpu_baseline        the C / OpenMP restatement of the reference (oracle/cpu_port.c, pinned to the reference's golden
+                      trajectories by tests/test_cpu_port.py) on this box's host cores, 1 thread and all cores, on the
+                      same cloud size and the first data of the same schedule.
 """
 import argparse
 import json
@@ -32,8 +36,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "python-qinfer_amd"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
-BYTES_PER_PARTICLE_UPDATE = 24  # 16 + 8 d, d = 1
 N_SCHEDULE = 200
+TAGS = {0: "update", 1: "sample", 2: "update_ones", 3: "canon_classify", 4: "canon_list", 5: "moments", 6: "counts"}
 
 
 def schedule():
@@ -44,36 +48,212 @@ def schedule():
     return ts, outcomes
 
 
-def cpu_baseline(n_particles, n_data):
-    """Time the oracle (kind 'port': NumPy restatement of the reference path) on this host."""
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def cpu_baseline(n_particles, n_data, gpu_same_sample):
+    """The C / OpenMP port of the reference path (oracle/cpu_port.c) on this host: same cloud size, the first
+    `n_data` data of the same schedule, Philox draws keyed by particle (so the thread count does not change the
+    algorithm), timed at 1 thread and at all cores."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import np_oracle as orc
+    import cpu_port as cp
     ts, outcomes = schedule()
-    np.random.seed(0)
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        smc = orc.OracleSMC(orc.precession_model(), n_particles, lambda n: np.random.random((n, 1)))
-        t0 = time.perf_counter()
-        for k in range(n_data):
-            smc.update(int(outcomes[k]), {"t": ts[k:k + 1]})
-        wall = time.perf_counter() - t0
-    return {"value": n_particles * n_data / wall, "unit": "particle-updates/s", "cores": 1, "kind": "port",
-            "sample": "oracle/np_oracle.py OracleSMC, SimplePrecession, N=%d, first %d data of the same "
-                      "schedule (%d resamples), %.1f s wall, single-threaded NumPy" % (
-                          n_particles, n_data, smc.resample_count, wall)}
+    x0 = np.random.RandomState(1).random_sample((n_particles, 1))
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:  # noqa: BLE001
+        pass
+    runs = {}
+    for label, th in (("all_cores", cores), ("one_thread", 1)):
+        r = cp.smc_run(cp.PRECESSION, x0, outcomes[:n_data], t=ts[:n_data], rng_mode=1, seed=0, threads=th)
+        if r["rc"] != 0:
+            return {"error": "cpu port returned %d" % r["rc"]}
+        runs[label] = {"value": n_particles * n_data / r["wall_s"], "threads": int(r["threads"]), "wall_s": r["wall_s"],
+                       "update_s": r["update_s"], "resample_s": r["resample_s"], "resamples": int(r["resample_count"]),
+                       "posterior_mean": float(r["mean"][0])}
+    allc = runs["all_cores"]
+    return {"value": allc["value"], "unit": "particle-updates/s", "cores": allc["threads"], "kind": "port",
+            "host_cpu_count": os.cpu_count(),
+            "sample": "oracle/cpu_port.c (C/OpenMP restatement of smc.py:388-457 + resamplers.py:256-392, pinned to the "
+                      "reference's golden trajectories in tests/test_cpu_port.py), SimplePrecession, N=%d, first %d data "
+                      "of the headline schedule (%d resamples), Philox draws keyed by particle; %.1f s wall on %d threads, "
+                      "%.1f s on 1 thread" % (n_particles, n_data, allc["resamples"], allc["wall_s"], allc["threads"],
+                                              runs["one_thread"]["wall_s"]),
+            "all_cores": allc, "one_thread": runs["one_thread"], "gpu_same_sample": gpu_same_sample}
 
 
 def load_traffic():
-    """HBM bytes per launch of the update kernel from a committed rocprofv3 --pmc pass, if any."""
+    """HBM bytes per launch from committed rocprofv3 --pmc passes (profiles/hbm_traffic.json), if any."""
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(path):
-        try:
-            return json.load(open(path)).get("update_kernel_bytes_per_launch")
-        except Exception:  # noqa: BLE001
-            return None
-    return None
+    try:
+        return json.load(open(path))
+    except Exception:  # noqa: BLE001
+        return {}
 
 
+def kernel_table(ms, tags):
+    out = {}
+    for t, name in TAGS.items():
+        sel = ms[tags == t]
+        if len(sel):
+            out[name] = {"launches": int(len(sel)), "avg_us": float(sel.mean()) * 1e3, "min_us": float(sel.min()) * 1e3}
+    return out
+
+
+def frac_entry(kernel, avg_us, n_bytes, launches, extra=None):
+    ach = n_bytes / (avg_us * 1e-6) / 1e9
+    e = {"kernel": kernel, "avg_kernel_us": avg_us, "timed_launches": launches, "algorithmic_bytes_per_launch": n_bytes,
+         "achieved": ach, "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": ach / HBM_PEAK_GBS}
+    if extra:
+        e.update(extra)
+    return e
+
+
+# ------------------------------------------------------------------------------------------------ other configs
+def cached_prior(qi, dist):
+    """A host-sampled prior drawn once per cloud size (the Ginibre prior of 1.25e6 states takes seconds on the
+    host; the bench resets the updater several times and prior sampling is outside every timed region)."""
+    class Cached(qi.Distribution):
+        n_rvs = dist.n_rvs
+        _memo = {}
+
+        def sample(self, n=1):
+            if n not in self._memo:
+                self._memo[n] = dist.sample(n)
+            return self._memo[n]
+    return Cached()
+
+
+def other_config_specs(qi):
+    """BASELINE configs 3, 4 (share) and 5 (share) as concrete synthetic inputs."""
+    specs = []
+    rs = np.random.RandomState(0)
+    K = 60
+    # C3: BinomialModel(SimplePrecessionModel) n_meas = 25, N = 1e7 (derived_models.py:314-329)
+    m = qi.BinomialModel(qi.SimplePrecessionModel())
+    eps, outs = [], []
+    for k in range(K):
+        ep = np.empty((1,), dtype=m.expparams_dtype)
+        ep['x'] = (9 / 8) ** k
+        ep['n_meas'] = 25
+        eps.append(ep)
+        outs.append(int(rs.binomial(25, np.sin(0.3 * (9 / 8) ** k / 2) ** 2)))
+    specs.append(dict(key="config3_binomial_precession", model=m, n=10_000_000, d=1,
+                      prior=lambda: qi.UniformDistribution([0, 1]), eps=eps, outs=outs,
+                      workload="BinomialModel(SimplePrecessionModel) n_meas=25, 1e7 particles, t_k=(9/8)^k",
+                      update_kernel="k_update_fused<BINOMIAL_PRECESSION,2,false>", sampler="k_bucket_sample<1,512>"))
+    # C4 per-GPU share: RandomizedBenchmarkingModel d = 3, N = 1.25e7 (rb.py:178-195), prior as simple_est_rb
+    m = qi.RandomizedBenchmarkingModel()
+    eps, outs = [], []
+    for k in range(K):
+        ep = np.empty((1,), dtype=m.expparams_dtype)
+        ep['m'] = 1 + 5 * k
+        eps.append(ep)
+        outs.append(int(rs.random_sample() >= 1 - (0.3 * 0.95 ** (1 + 5 * k) + 0.5)))
+    specs.append(dict(key="config4_share_rb", model=m, n=12_500_000, d=3,
+                      prior=lambda m=m: qi.PostselectedDistribution(qi.UniformDistribution([[0.8, 1], [0, 1], [0, 1]]), m),
+                      eps=eps, outs=outs,
+                      workload="RandomizedBenchmarkingModel (p, A, B), 1.25e7 particles (1e8 / 8 GPUs), m_k = 1 + 5k",
+                      update_kernel="k_update_fused<RB,1,false>", sampler="k_bucket_sample<3,512>"))
+    # C5 per-GPU share: 2-qubit TomographyModel d = 16, N = 1.25e6, Ginibre prior, random Pauli measurements
+    basis = qi.tomography.pauli_basis(2)
+    m = qi.TomographyModel(basis)
+    np.random.seed(0)
+    gin = qi.GinibreDistribution(basis)
+    true = gin.sample(1)[0]
+    eps, outs = [], []
+    for k in range(K):
+        ep = np.zeros((1,), dtype=m.expparams_dtype)
+        p = rs.randint(1, 16)
+        ep['meas'][0, 0] = 1
+        ep['meas'][0, p] = 1
+        eps.append(ep)
+        outs.append(int(rs.random_sample() < np.clip(true[0] + true[p], 0, 1)))
+    gin_cached = cached_prior(qi, gin)
+    specs.append(dict(key="config5_share_tomography", model=m, n=1_250_000, d=16, prior=lambda: gin_cached, eps=eps, outs=outs,
+                      workload="2-qubit TomographyModel (15 free params), 1.25e6 particles (1e7 / 8 GPUs), Ginibre prior, "
+                               "random Pauli measurements",
+                      update_kernel="k_update_fused<TOMOGRAPHY,1,false>", sampler="k_bucket_sample<16,512>"))
+    return specs
+
+
+def run_other_config(qi, eng, torch, spec, warmup):
+    n, d = spec["n"], spec["d"]
+    eps, outs = spec["eps"], spec["outs"]
+    upd = qi.SMCUpdater(spec["model"], n, spec["prior"](), device_rng=True, seed=0)
+    for k in range(min(warmup, len(eps))):                      # untimed: allocator growth, first-launch costs
+        upd.update(outs[k], eps[k])
+    upd.resample()
+    upd.update(outs[0], eps[0])
+    upd.reset()
+    upd._resample_count = 0
+    torch.cuda.synchronize()
+    eng.set_profiling(1)
+    t0 = time.perf_counter()
+    for k in range(len(eps)):
+        upd.update(outs[k], eps[k])
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    ms, tags = eng.profile_read()
+    eng.set_profiling(0)
+    # the same loop again without kernel events: the throughput figure (events drain the queue around each launch)
+    upd.reset()
+    rc0 = upd.resample_count
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(len(eps)):
+        upd.update(outs[k], eps[k])
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    kt = kernel_table(ms, tags)
+    K = len(eps)
+    out = {"workload": spec["workload"], "particles": n, "d": d, "steps": K, "resamples": upd.resample_count - rc0,
+           "value": n * K / wall, "unit": "particle-updates/s", "ms_per_step": wall / K * 1e3,
+           "posterior_mean_head": [float(v) for v in upd.est_mean()[:3]]}
+    if "update" in kt:
+        out["update_kernel"] = frac_entry(spec["update_kernel"], kt["update"]["avg_us"], (16 + 8 * d) * n,
+                                          kt["update"]["launches"], {"bytes_per_particle": 16 + 8 * d})
+    if "sample" in kt:
+        out["resample_kernel"] = frac_entry(spec["sampler"], kt["sample"]["avg_us"], (8 + 16 * d) * n,
+                                            kt["sample"]["launches"], {"bytes_per_particle": 8 + 16 * d})
+    if "canon_classify" in kt:
+        cus = kt["canon_classify"]["avg_us"] + kt.get("canon_list", {"avg_us": 0.0})["avg_us"]
+        out["canonicalize"] = frac_entry("k_tomo_classify<4> + k_tomo_canon_list<4>", cus, 16 * d * n,
+                                         kt["canon_classify"]["launches"],
+                                         {"bytes_per_particle": 16 * d, "classify_us": kt["canon_classify"]["avg_us"],
+                                          "canon_list_us": kt.get("canon_list", {"avg_us": 0.0})["avg_us"]})
+    if "moments" in kt:
+        out["moments_kernel"] = frac_entry("k_moments_mfma", kt["moments"]["avg_us"], (8 + 8 * d) * n,
+                                           kt["moments"]["launches"], {"bytes_per_particle": 8 + 8 * d})
+    del upd
+    torch.cuda.empty_cache()
+    return out
+
+
+def beyond_l3(qi, eng, torch, n=100_000_000, steps=12):
+    """The update kernel on a cloud past the Infinity Cache: N = 1e8, 2.4 GB streamed per launch."""
+    upd = qi.SMCUpdater(qi.SimplePrecessionModel(), n, qi.UniformDistribution([0, 1]), device_rng=True, seed=0)
+    for k in range(3):
+        upd.update(k & 1, np.array([1.5 * (k + 1)]), check_for_resample=False)
+    torch.cuda.synchronize()
+    eng.set_profiling(1)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        upd.update(k & 1, np.array([2.0 + 0.37 * k]), check_for_resample=False)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    ms, tags = eng.profile_read()
+    eng.set_profiling(0)
+    full = ms[tags == 0]
+    e = frac_entry("k_update_fused<PRECESSION,VEC=2,ONES=false>", float(full.mean()) * 1e3, 24.0 * n, int(len(full)),
+                   {"particles": n, "working_set_bytes": 24 * n, "bound": "hbm",
+                    "value_updates_only": n * steps / wall,
+                    "note": "N = 1e8: x + two weight buffers = 2.4 GB, ten times the 256 MB Infinity Cache"})
+    del upd
+    torch.cuda.empty_cache()
+    return e
+
+
+# ------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -81,10 +261,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--particles", type=float, default=1e7, help="particles PER GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-particles", type=float, default=2e6)
-    ap.add_argument("--cpu-data", type=int, default=120)
-    ap.add_argument("--event-stride", type=int, default=8,
-                    help="put hipEvents on every N-th launch of each timed kernel kind (1 = all)")
+    ap.add_argument("--no-other-configs", action="store_true", help="headline only (profiling runs)")
+    ap.add_argument("--only", default=None, help="run ONE other config by key instead of the headline (profiling runs)")
+    ap.add_argument("--cpu-data", type=int, default=20, help="data of the schedule the CPU baseline runs")
+    ap.add_argument("--event-stride", type=int, default=0,
+                    help="put hipEvents on every N-th launch of each timed kernel kind (0 = steps // 10, 1..8)")
     ap.add_argument("--force-comm", action="store_true",
                     help="run the sharded code path even with one rank (validation on a 1-GPU box)")
     args = ap.parse_args()
@@ -122,12 +303,20 @@ def main():
     eng = get_engine()
     n = int(args.particles)
     ts, outcomes = schedule()
+    stride = args.event_stride if args.event_stride > 0 else max(1, min(8, args.steps // 10))
 
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
+
+    if args.only:                      # one of the other configs alone (what the per-config rocprofv3 passes run)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            spec = next(s for s in other_config_specs(qi) if s["key"] == args.only)
+            print(json.dumps({args.only: run_other_config(qi, eng, torch, spec, args.warmup)}), flush=True)
+        return
 
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
@@ -138,8 +327,8 @@ def main():
         upd.reset()
         upd._resample_count = 0
         # a launch that carries start/stop events drains the queue around itself (measured: 10.7 us per step
-        # with every launch timed), so every EVENT_STRIDE-th launch of each kernel kind is timed
-        eng.set_profiling(0 if os.environ.get("QSMC_BENCH_NO_EVENTS") else args.event_stride)
+        # with every launch timed), so every `stride`-th launch of each kernel kind is timed
+        eng.set_profiling(0 if os.environ.get("QSMC_BENCH_NO_EVENTS") else stride)
         barrier()
         t0 = time.perf_counter()
         for i in range(args.steps):
@@ -149,13 +338,37 @@ def main():
             upd.update(int(outcomes[k]), ts[k:k + 1])
         barrier()
         wall = time.perf_counter() - t0
-        # every update kernel of the timed region carried start/stop events (hipExtLaunchKernelGGL, on the
-        # launch stream); their durations are read here, once, not per step
+        # the kernels' start/stop events (hipExtLaunchKernelGGL, on the launch stream) are read here, once
         all_ms, tags = eng.profile_read()
         eng.set_profiling(False)
+        resamples_timed = upd.resample_count
         # tag 0: update with explicit weights (24 B/particle), 2: first update after a reset/resample, weights
-        # implicit (16 B/particle), 1: the resampler's sampling kernel
+        # implicit (16 B/particle), 1: the resampler's sampling kernel, 6: its counts/plan launch
         full_ms, ones_ms, sampler_ms = all_ms[tags == 0], all_ms[tags == 2], all_ms[tags == 1]
+
+        # census (untimed for `value`): the first 64 data of the schedule once more, EVERY launch timed
+        census = None
+        gpu_same_sample = None
+        if world == 1 and comm is None:
+            upd.reset()
+            eng.set_profiling(1)
+            for k in range(64):
+                upd.update(int(outcomes[k]), ts[k:k + 1])
+            torch.cuda.synchronize()
+            c_ms, c_tags = eng.profile_read()
+            eng.set_profiling(False)
+            census = kernel_table(c_ms, c_tags)
+            # the CPU baseline's sample (first --cpu-data data) on the GPU, no events: like against like
+            upd.reset()
+            rc0 = upd.resample_count
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for k in range(args.cpu_data):
+                upd.update(int(outcomes[k]), ts[k:k + 1])
+            torch.cuda.synchronize()
+            w1 = time.perf_counter() - t1
+            gpu_same_sample = {"value": n * args.cpu_data / w1, "ms_per_step": w1 / args.cpu_data * 1e3,
+                               "resamples": upd.resample_count - rc0}
 
     # collective in sharded mode (the moments are all-gathered if the last step resampled): every rank calls it
     posterior_mean = float(upd.est_mean()[0])
@@ -163,6 +376,24 @@ def main():
     if world > 1:
         torch.distributed.all_reduce(wall_t, op=torch.distributed.ReduceOp.MAX)
     wall = float(wall_t.item())
+    del upd
+    torch.cuda.empty_cache()
+
+    extras = {}
+    if rank == 0 and world == 1 and comm is None and not args.no_other_configs:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            try:
+                extras["roofline_beyond_l3"] = beyond_l3(qi, eng, torch)
+            except Exception as e:  # noqa: BLE001
+                extras["roofline_beyond_l3"] = {"error": repr(e)}
+            oc = {}
+            for spec in other_config_specs(qi):
+                try:
+                    oc[spec["key"]] = run_other_config(qi, eng, torch, spec, min(args.warmup, 5))
+                except Exception as e:  # noqa: BLE001
+                    oc[spec["key"]] = {"error": repr(e)}
+            extras["other_configs"] = oc
 
     # RCCL prints a version banner through C stdio, which (not a tty) would be flushed at exit -- after the
     # JSON line.  Push whatever C stdio holds to stderr now so that the JSON line is the last line of stdout.
@@ -180,8 +411,11 @@ def main():
         return
     if rank == 0:
         n_total = n * world
+        traffic = load_traffic()
         # (under local placement a rank's shard size floats by ~1e-3 relative; n is exact at N = 1)
-        full_bytes, ones_bytes = float(BYTES_PER_PARTICLE_UPDATE * n), float(16 * n)
+        full_bytes, ones_bytes = float(24 * n), float(16 * n)
+        if len(full_ms) == 0 and census and "update" in census:     # (--steps too small for one sampled launch)
+            full_ms = np.array([census["update"]["avg_us"] * 1e-3])
         avg_kernel_s = float(full_ms.mean()) * 1e-3          # the dominant variant: reads x and w, writes w
         achieved = full_bytes / avg_kernel_s / 1e9
         ones_info = None
@@ -197,30 +431,48 @@ def main():
             "config": {"workload": "SimplePrecessionModel SMCUpdater.update, %.0e particles/GPU, fp64, "
                                    "Liu-West a=0.98, t_k=(9/8)^k" % n,
                        "particles_per_gpu": n, "particles_total": n_total,
-                       "resamples_in_timed_region": upd.resample_count, "rng": "philox4x32-10 (device)",
+                       "resamples_in_timed_region": resamples_timed, "rng": "philox4x32-10 (device)",
                        "parallelism": "particle-shard x%d" % world,
-                       "per_datum_collective": (None if comm is None else
-                                                ("host shared memory" if comm._host is not None else "backend all-gather")),
+                       "per_datum_collective": (None if comm is None else comm.transport_name),
                        "rebalances_in_timed_region": (None if comm is None else comm.n_rebalances)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(),
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic.get("update_kernel_bytes_per_launch"),
+                         "traffic_source": "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                           "command, committed; not collected by this run)",
                          "kernel": "k_update_fused<PRECESSION,VEC=2,ONES=false>", "avg_kernel_us": avg_kernel_s * 1e6,
-                         "timed_launches": int(len(full_ms)), "event_stride": args.event_stride,
+                         "timed_launches": int(len(full_ms)), "event_stride": stride,
                          "algorithmic_bytes_per_launch": full_bytes,
+                         "working_set_note": "240 MB at N = 1e7 fits the 256 MB Infinity Cache: see roofline_beyond_l3 for "
+                                             "the HBM-only figure",
                          "implicit_uniform_weight_variant": ones_info},
             "posterior_mean": posterior_mean,
         }
+        samp_n, samp_us = 0, None
         if len(sampler_ms):
+            samp_n, samp_us = int(len(sampler_ms)), float(sampler_ms.mean()) * 1e3
+        if census and "sample" in census and census["sample"]["launches"] > samp_n:
+            samp_n, samp_us = census["sample"]["launches"], census["sample"]["avg_us"]
+            samp_src = "census"
+        else:
+            samp_src = "timed region"
+        if samp_us:
             # the resampler's main kernel, same clock: reads w (8 B), gathers x (8d), writes x' (8d) per particle
-            samp_s = float(sampler_ms.mean()) * 1e-3
-            samp_bytes = (8 + 16 * 1) * n
-            line["resample_kernel"] = {"kernel": "k_bucket_sample<D=1,512>", "timed_launches": int(len(sampler_ms)),
-                                       "avg_kernel_us": samp_s * 1e6, "algorithmic_bytes_per_launch": samp_bytes,
-                                       "achieved": samp_bytes / samp_s / 1e9, "unit": "GB/s",
-                                       "frac": samp_bytes / samp_s / 1e9 / HBM_PEAK_GBS,
-                                       "bound_in_practice": "VALU issue (Philox + Box-Muller + LDS search), see DESIGN.md 3.3"}
+            line["resample_kernel"] = frac_entry("k_bucket_sample<D=1,512>", samp_us, float((8 + 16) * n), samp_n,
+                                                 {"source": samp_src,
+                                                  "traffic": traffic.get("sample_kernel_bytes_per_launch")})
+        if census:
+            line["kernel_census"] = {"what": "first 64 data of the schedule replayed right after the timed region, every "
+                                             "launch timed (HIP events on the launch stream)", "kernels": census}
+            if "update" in census:
+                line["roofline"]["census_avg_kernel_us"] = census["update"]["avg_us"]
+                line["roofline"]["census_launches"] = census["update"]["launches"]
+        line.update(extras)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(int(args.cpu_particles), args.cpu_data)
+            try:
+                line["cpu_baseline"] = cpu_baseline(n, args.cpu_data, gpu_same_sample)
+            except Exception as e:  # noqa: BLE001
+                line["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(line), flush=True)
     if world > 1 or args.force_comm:
         comm.close()

@@ -103,6 +103,11 @@ int         qsmc_profile_read(qsmc_handle_t h, float *ms_out, int32_t *tags_out,
 #define QSMC_PROF_UPDATE 0      /* k_update_fused, explicit weights (24 B/particle at d = 1) */
 #define QSMC_PROF_SAMPLE 1      /* k_bucket_sample (the resampler's dominant kernel) */
 #define QSMC_PROF_UPDATE_ONES 2 /* k_update_fused, implicit all-ones weights (16 B/particle at d = 1) */
+#define QSMC_PROF_CANON_CLASSIFY 3 /* tomography canonicalize, pass 1 (k_tomo_classify; or the single-pass kernel) */
+#define QSMC_PROF_CANON_LIST 4     /* tomography canonicalize, pass 2 (k_tomo_canon_list) */
+#define QSMC_PROF_MOMENTS 5        /* weighted moments, 4 < d <= 16 (k_moments_mfma) */
+#define QSMC_PROF_COUNTS 6         /* the resampler's chunk counts + plan launch (k_bucket_counts) */
+#define QSMC_PROF_NTAGS 8
 
 /* ---- likelihood, contract form (abstract_model.py:444-468 + :666-686; a6-a10) ------------ */
 /* L_out[(o * n_e + e) * n + i] = Pr(outcomes[o] | x_i ; exps[e]).  This is the

@@ -83,7 +83,7 @@ struct qsmc_ctx {
     int prof_n;            // profiled launches since the last qsmc_profile_read / set_profiling
     unsigned char *prof_tag;   // which kernel each ring entry timed (QSMC_PROF_*)
     int prof_stride;           // time every prof_stride-th launch of a tag (events cost ~10 us of queue drain each)
-    unsigned prof_seen[4];     // launches seen per tag
+    unsigned prof_seen[QSMC_PROF_NTAGS];     // launches seen per tag
     char hip_err[256];
 };
 
@@ -316,7 +316,7 @@ static int collect_stats(qsmc_ctx *h, int ns, qsmc_update_stats_t *stats_host, d
 // Next (start, stop) event pair of the profiling ring, or (null, null) when profiling is off.
 static void prof_events(qsmc_ctx *h, int tag, hipEvent_t *e0, hipEvent_t *e1) {
     if (!h->profiling || !h->prof_ev) return;
-    if (h->prof_seen[tag & 3]++ % (unsigned)h->prof_stride != 0) return;
+    if (h->prof_seen[tag & (QSMC_PROF_NTAGS - 1)]++ % (unsigned)h->prof_stride != 0) return;
     const int slot = h->prof_n % QSMC_PROF_CAP;         // a ring: beyond the capacity the oldest are overwritten
     *e0 = h->prof_ev[2 * slot];
     *e1 = h->prof_ev[2 * slot + 1];
@@ -525,7 +525,7 @@ int qsmc_last_update_kernel_ms(qsmc_handle_t h, float *ms_out) {
     if (!h || !ms_out || !h->prof_ev || h->prof_n < 1) return QSMC_ERR_INVALID;
     int slot = -1;
     for (int i = h->prof_n - 1; i >= 0 && i > h->prof_n - 1 - QSMC_PROF_CAP; --i)
-        if (h->prof_tag[i % QSMC_PROF_CAP] != QSMC_PROF_SAMPLE) { slot = i % QSMC_PROF_CAP; break; }
+        if (h->prof_tag[i % QSMC_PROF_CAP] == QSMC_PROF_UPDATE || h->prof_tag[i % QSMC_PROF_CAP] == QSMC_PROF_UPDATE_ONES) { slot = i % QSMC_PROF_CAP; break; }
     if (slot < 0) return QSMC_ERR_INVALID;
     HIP_TRY(h, hipEventSynchronize(h->prof_ev[2 * slot + 1]));
     HIP_TRY(h, hipEventElapsedTime(ms_out, h->prof_ev[2 * slot], h->prof_ev[2 * slot + 1]));
@@ -826,7 +826,9 @@ int qsmc_moments(qsmc_handle_t h, const double *x, int64_t ldx, int64_t n, int32
     if (rc) return rc;
     rc = ensure_scratch(h, 256 + MFMA_MOM_K);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_moments_mfma, dim3(gridm), dim3(QSMC_BLOCK), 0, s, x, ldx, n, d, w, norm, h->partials);
+    hipEvent_t m0 = nullptr, m1 = nullptr;
+    prof_events(h, QSMC_PROF_MOMENTS, &m0, &m1);
+    hipExtLaunchKernelGGL(k_moments_mfma, dim3(gridm), dim3(QSMC_BLOCK), 0, s, m0, m1, 0, x, ldx, n, d, w, norm, h->partials);
     double *full = h->scratch + 256;
     hipLaunchKernelGGL(k_sum_partials, dim3((MFMA_MOM_K + QSMC_WAVES_PER_BLOCK - 1) / QSMC_WAVES_PER_BLOCK), dim3(QSMC_BLOCK), 0, s,
                        h->partials, gridm, MFMA_MOM_K, full);
@@ -1045,7 +1047,9 @@ static int resample_prefix(qsmc_ctx *h, const double *w, int64_t n_in, double no
                 lds_granted = lds;
             }
             unsigned int *extra = bp.hist;                       // (the histogram rows are not used on this path)
-            hipLaunchKernelGGL(k_bucket_counts, dim3(BUCKET_COUNTS_BLOCKS), dim3(BUCKET_COUNTS_THREADS), lds, s, offsets,
+            hipEvent_t q0 = nullptr, q1 = nullptr;
+            prof_events(h, QSMC_PROF_COUNTS, &q0, &q1);
+            hipExtLaunchKernelGGL(k_bucket_counts, dim3(BUCKET_COUNTS_BLOCKS), dim3(BUCKET_COUNTS_THREADS), lds, s, q0, q1, 0, offsets,
                                scan_in_counts ? ts : TileSrc{nullptr, 0, 0, 0.0},
                                reinterpret_cast<unsigned long long *>(h->counter), chunks, n_out, lambda, k0, k1, ep,
                                bp.counts, extra, bp.slot_off, bp.item_off, bp.item_chunk, h->gbar, h->gbar_base);
@@ -1304,10 +1308,13 @@ int qsmc_tomo_canonicalize(qsmc_handle_t h, const double *basis, int32_t dim, do
             unsigned int *count = h->iscratch;              // [0] = list length; the list starts at [4]
             unsigned int *list = h->iscratch + 4;
             HIP_TRY(h, hipMemsetAsync(count, 0, sizeof(unsigned int), s));
-            hipLaunchKernelGGL((k_tomo_classify<4>), dim3(grid), dim3(QSMC_BLOCK), 0, s, basis, x, ldx, n,
-                               allow_subnormalized, list, count);
-            hipLaunchKernelGGL((k_tomo_canon_list<4>), dim3(grid), dim3(QSMC_BLOCK), 0, s, basis, x, ldx,
-                               allow_subnormalized, list, count);
+            hipEvent_t c0 = nullptr, c1 = nullptr, l0 = nullptr, l1 = nullptr;
+            prof_events(h, QSMC_PROF_CANON_CLASSIFY, &c0, &c1);
+            prof_events(h, QSMC_PROF_CANON_LIST, &l0, &l1);
+            hipExtLaunchKernelGGL((k_tomo_classify<4>), dim3(grid), dim3(QSMC_BLOCK), 0, s, c0, c1, 0, basis, x, ldx, n,
+                                  allow_subnormalized, list, count);
+            hipExtLaunchKernelGGL((k_tomo_canon_list<4>), dim3(grid), dim3(QSMC_BLOCK), 0, s, l0, l1, 0, basis, x, ldx,
+                                  allow_subnormalized, list, count);
             break;
         }
         default: return QSMC_ERR_UNSUPPORTED;

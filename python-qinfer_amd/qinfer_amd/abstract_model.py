@@ -26,7 +26,7 @@ import numpy as np
 
 from .domains import IntegerDomain
 
-__all__ = ["Simulatable", "Model", "FiniteOutcomeModel", "NativeModelMixin"]
+__all__ = ["Simulatable", "Model", "FiniteOutcomeModel", "NativeModelMixin", "native_ok"]
 
 
 def safe_shape(arr, idx=0, default=1):
@@ -217,6 +217,28 @@ class FiniteOutcomeModel(Model):
         pr1 = 1 - pr0
         outcomes = np.atleast_1d(np.asarray(outcomes))
         return np.concatenate([pr0 if outcomes[i] == 0 else pr1 for i in range(outcomes.shape[0])])
+
+
+# The methods whose arithmetic the HIP kernels of a native model stand for.  A subclass written outside this
+# package that overrides any of them means something else by the model than the kernels compute: it is served by
+# the plugin path (its own methods run on the host), like any other user `Model`.
+_KERNEL_BACKED = ("likelihood", "are_models_valid", "update_timestep", "canonicalize", "n_outcomes", "domain")
+
+
+def native_ok(model):
+    """True if `model` is served by the HIP kernels: it declares native hooks AND every kernel-backed method of
+    its class is this library's own implementation (the reference dispatches on the overriding method,
+    abstract_model.py:444-528; a user override must win here too)."""
+    if model is None or not getattr(model, "_native", False):
+        return False
+    cls = type(model)
+    pkg = __name__.rsplit(".", 1)[0] + "."
+    for name in _KERNEL_BACKED:
+        fn = getattr(cls, name, None)
+        mod = getattr(fn, "__module__", None) or ""
+        if fn is not None and not mod.startswith(pkg):
+            return False
+    return True
 
 
 class NativeModelMixin:

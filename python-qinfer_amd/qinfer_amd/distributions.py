@@ -129,7 +129,8 @@ class PostselectedDistribution(Distribution):
         return samples
 
     def sample_device(self, engine, n, seed, epoch, maxiter=None):
-        if not hasattr(self._dist, "sample_device") or not getattr(self._model, "_native", False):
+        from .abstract_model import native_ok
+        if not hasattr(self._dist, "sample_device") or not native_ok(self._model):
             raise NotImplementedError
         x, failed = self._dist.sample_device(engine, n, seed, epoch, self._model._native_desc(), True,
                                              self._maxiters if maxiter is None else maxiter)

@@ -12,7 +12,7 @@ NumPy `expparams` into the C-ABI's `qsmc_expparam_t`.
 import numpy as np
 
 from . import _native
-from .abstract_model import FiniteOutcomeModel, Model, NativeModelMixin
+from .abstract_model import FiniteOutcomeModel, Model, NativeModelMixin, native_ok
 from .domains import IntegerDomain
 
 __all__ = ["SimpleInversionModel", "SimplePrecessionModel", "UnknownT2Model", "DerivedModel", "BinomialModel",
@@ -287,7 +287,11 @@ class MLEModel(NativeModelMixin, DerivedModel):
     def __init__(self, underlying_model, likelihood_power):
         super().__init__(underlying_model)
         self._pow = likelihood_power
-        self._native = bool(getattr(underlying_model, "_native", False))
+        self._native = native_ok(underlying_model)
+        # a decorated random-walk model still walks (derived_models.py:177-178 forwards update_timestep): hand its
+        # device step through, so that update() does not have to choose between the kernel path and the walk
+        step = getattr(underlying_model, "_native_timestep", None)
+        self._native_timestep = step if (self._native and step is not None) else None
 
     @property
     def is_n_outcomes_constant(self):
@@ -347,7 +351,7 @@ class RandomWalkModel(_WalkingModel):
         super().__init__(underlying_model)
         if self.underlying_model.n_modelparams != self._step_dist.n_rvs:
             raise TypeError("Step distribution does not match model dimension.")
-        self._native = bool(getattr(underlying_model, "_native", False))
+        self._native = native_ok(underlying_model)
 
     def likelihood(self, outcomes, modelparams, expparams):
         Model.likelihood(self, outcomes, modelparams, expparams)
@@ -434,7 +438,7 @@ class GaussianRandomWalkModel(_WalkingModel):
         self._has_transformation = model_transformation is not None
         if self._has_transformation:
             self._transform, self._inv_transform = model_transformation
-        self._native = bool(getattr(underlying_model, "_native", False) and self._has_fixed_covariance
+        self._native = bool(native_ok(underlying_model) and self._has_fixed_covariance
                             and diagonal and not self._has_transformation)
         if not self._native:
             self._native_timestep = None            # (instance attribute shadows the method: plugin slow path)

@@ -223,67 +223,14 @@ class ParticleShardGroup:
         return ex
 
     def close(self):
-        shm, self._shm = getattr(self, "_shm", None), None
-        if shm is None:
-            return
-        self._seq = self._pay = None
-        try:
-            shm.close()
-            if self._owner:
-                shm.unlink()
-        except Exception:  # noqa: BLE001
-            pass
+        host, self._host = getattr(self, "_host", None), None
+        if host is not None:
+            host.close()
 
-    def __del__(self):
-        self.close()
-
-
-class ParticleShardGroup:
-    def __init__(self, group=None, seed=0, placement="local", rebalance_tol=0.05, host_exchange=True):
-        import torch
-        import torch.distributed as dist
-        if not dist.is_initialized():
-            raise RuntimeError("torch.distributed is not initialised (launch with torch.distributed.run)")
-        if placement not in ("local", "mixed"):
-            raise ValueError("placement must be 'local' or 'mixed'")
-        self.torch, self.dist, self.group = torch, dist, group
-        self.rank = dist.get_rank(group)
-        self.world_size = dist.get_world_size(group)
-        self.backend = dist.get_backend(group)
-        self.seed = int(seed)
-        self.placement = placement
-        self.rebalance_tol = float(rebalance_tol)
-        self._epoch = 0
-        self.n_rebalances = 0
-        self._bitgen = np.random.Philox(key=self.seed & (2 ** 64 - 1))     # re-keyed per plan by counter
-        self._gen = np.random.Generator(self._bitgen)
-        self._host = self._open_host_exchange() if host_exchange else None
-
-    def _open_host_exchange(self):
-        """Shared-memory exchange if (and only if) every rank runs on this host; else None (RCCL/gloo)."""
-        import socket
-        try:
-            hosts = [None] * self.world_size
-            self.dist.all_gather_object(hosts, socket.gethostname(), group=self.group)
-            if len(set(hosts)) != 1:
-                return None
-            name = [None]
-            ex = None
-            if self.rank == 0:
-                ex = HostExchange(0, self.world_size)
-                name[0] = ex.name
-            self.dist.broadcast_object_list(name, src=0, group=self.group)
-            if self.rank != 0:
-                ex = HostExchange(self.rank, self.world_size, name=name[0])
-            self.dist.barrier(group=self.group)
-            return ex
-        except Exception:  # noqa: BLE001  (no /dev/shm, odd backend: fall back to the collective)
-            return None
-
-    def close(self):
-        if self._host is not None:
-            self._host.close()
-            self._host = None
+    @property
+    def transport_name(self):
+        """What carries the per-datum reduction (bench.py reports it)."""
+        return "host shared memory" if self._host is not None else "backend all-gather (%s)" % self.backend
 
     # ------------------------------------------------------------------ small collectives
     def _comm_tensor(self, t):
@@ -428,7 +375,8 @@ class ParticleShardGroup:
         from .distributions import ParticleDistribution
         eng = updater._eng
         model = updater.model
-        if not getattr(model, "_native", False):
+        from .abstract_model import native_ok
+        if not native_ok(model):
             raise NotImplementedError("sharded resampling needs a model with native kernels")
         self._epoch += 1
         epoch = self._epoch

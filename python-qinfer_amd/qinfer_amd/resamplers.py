@@ -19,6 +19,7 @@ import warnings
 import numpy as np
 
 from ._exceptions import ResamplerError, ResamplerWarning
+from .abstract_model import native_ok
 from .distributions import ParticleDistribution
 
 __all__ = ["Resampler", "LiuWestResampler"]
@@ -103,7 +104,7 @@ class LiuWestResampler(Resampler):
             raise ResamplerError("Infinite error in computing the square root of the covariance "
                                  "matrix. Check that n_ess is not too small.")
 
-        native = bool(getattr(model, "_native", False))
+        native = native_ok(model)
         desc = model._native_desc() if native else None
         x_in, norm = particle_dist._x, particle_dist._norm
 
@@ -147,7 +148,7 @@ class LiuWestResampler(Resampler):
         only the weights (chunk sums, multinomial chunk counts, work-item plan) so that the GPU is busy
         while `__call__` forms mean / covariance / sqrtm on the host.  Same arguments as the
         `lw_resample_philox` call that follows, which then starts at the sampling kernel."""
-        if not (self._device_rng and getattr(model, "_native", False)):
+        if not (self._device_rng and native_ok(model)):
             return
         if particle_dist.n_particles > self._segment_limit:
             return                                   # segmented resample: every segment runs its own prefix

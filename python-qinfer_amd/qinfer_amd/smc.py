@@ -20,7 +20,7 @@ import numpy as np
 
 from . import _native
 from ._exceptions import ApproximationWarning, ResamplerWarning
-from .abstract_model import Simulatable
+from .abstract_model import Simulatable, native_ok
 from .distributions import ParticleDistribution
 from .resamplers import LiuWestResampler
 
@@ -86,8 +86,11 @@ class SMCUpdater(ParticleDistribution):
         self._zero_weight_policy = zero_weight_policy
         self._zero_weight_thresh = (zero_weight_thresh if zero_weight_thresh is not None
                                     else 10 * np.spacing(1))
-        self._native = bool(getattr(model, "_native", False))
+        # the HIP kernels stand for the model only if its kernel-backed methods are the library's own
+        # (a user subclass overriding likelihood / are_models_valid / update_timestep takes the plugin path)
+        self._native = native_ok(model)
         self._desc = model._native_desc() if self._native else None
+        self._timestep_identity = self._timestep_is_identity(model)
         self.reset(n_particles)
 
     # ------------------------------------------------------------------ bookkeeping properties
@@ -216,11 +219,28 @@ class SMCUpdater(ParticleDistribution):
             return False
         return True
 
+    @staticmethod
+    def _timestep_is_identity(model):
+        """True if `update_timestep` of the model (through any chain of decorators that merely forward it)
+        is the static-parameter default."""
+        from .models import BinomialModel, DerivedModel
+        m = model
+        while m is not None:
+            fn = type(m).update_timestep
+            if fn is Simulatable.update_timestep:
+                return True
+            if fn is DerivedModel.update_timestep or fn is BinomialModel.update_timestep:
+                m = m.underlying_model
+                continue
+            return False
+        return True
+
     def _canonicalize_device(self, rows=slice(None)):
         model = self.model
         if self._canonicalize_is_identity(model):
             return                                    # every hot-path model except tomography
-        if getattr(model, "_native", False) and hasattr(model, "_native_canonicalize_") and rows == slice(None):
+        whole = isinstance(rows, slice) and rows == slice(None)
+        if native_ok(model) and whole and getattr(model, "_native_canonicalize_ok", lambda: False)():
             model._native_canonicalize_(self._eng, self._x)
         else:                                         # plugin slow path
             locs = self.particle_locations
@@ -359,8 +379,9 @@ class SMCUpdater(ParticleDistribution):
             # a random-walk model with device kernels: the cloud takes its step in place (smc.py:447-449)
             step(self, expparams)
             self._moments_cache = None
-        elif not self._native and type(self.model).update_timestep is not Simulatable.update_timestep:
-            # plugin slow path: a user model that moves particles between data (smc.py:447-449)
+        elif not self._timestep_identity:
+            # plugin slow path: a model that moves particles between data and has no device step -- a user
+            # model, or a decorator over one (smc.py:447-449; DerivedModel forwards update_timestep)
             locs = self.model.update_timestep(self.particle_locations, expparams)[:, :, 0]
             self._x = self._eng.locs_to_soa(locs)
             self._invalidate()

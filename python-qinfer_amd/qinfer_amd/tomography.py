@@ -166,9 +166,14 @@ class TomographyModel(NativeModelMixin, FiniteOutcomeModel):
             self._basis_dev = eng.to_device(inter.reshape(-1))
         return self._basis_dev
 
+    def _native_canonicalize_ok(self):
+        """Device canonicalize kernels exist for 1 and 2 qubits (dim 2, 4); other dimensions (a qutrit: d = 9)
+        take `canonicalize` on the host."""
+        return self._dim in (2, 4)
+
     def _native_canonicalize_(self, eng, x):
         """In-place canonicalize of a device SoA cloud."""
-        if self._dim not in (2, 4):
+        if not self._native_canonicalize_ok():
             raise NotImplementedError("native canonicalize supports dim 2 and 4 (1 or 2 qubits)")
         eng.tomo_canonicalize(self._device_basis(eng), self._dim, x, self._allow_subnormalized)
 
@@ -182,10 +187,25 @@ class TomographyModel(NativeModelMixin, FiniteOutcomeModel):
         return self._native_likelihood(outcomes, modelparams, expparams)
 
     def canonicalize(self, modelparams):
-        eng = self._engine()
-        x = eng.locs_to_soa(np.asarray(modelparams, dtype=np.float64))
-        self._native_canonicalize_(eng, x)
-        return np.ascontiguousarray(x.cpu().numpy().T)
+        """Clamp negative eigenvalues of rho(x), re-expand, renormalise the trace (tomography/models.py:149-209)."""
+        modelparams = np.asarray(modelparams, dtype=np.float64)
+        if self._native_canonicalize_ok():
+            eng = self._engine()
+            x = eng.locs_to_soa(modelparams)
+            self._native_canonicalize_(eng, x)
+            return np.ascontiguousarray(x.cpu().numpy().T)
+        # host path for the dimensions without a kernel: batched Hermitian eigendecomposition
+        flat = self._basis.flat()                                           # (d, dim * dim)
+        rho = (modelparams @ flat).reshape(-1, self._dim, self._dim)
+        rho = 0.5 * (rho + rho.conj().transpose(0, 2, 1))
+        lam, v = np.linalg.eigh(rho)
+        neg = np.any(lam < 0, axis=1)
+        out = modelparams.copy()
+        if neg.any():
+            lam_c = np.where(lam[neg] < 0, 0.0, lam[neg])
+            fixed = (v[neg] * lam_c[:, None, :]) @ v[neg].conj().transpose(0, 2, 1)
+            out[neg] = np.real(fixed.reshape(fixed.shape[0], -1) @ flat.conj().T)
+        return out if self._allow_subnormalized else self.renormalize(out)
 
     def renormalize(self, modelparams):
         modelparams = np.asarray(modelparams, dtype=np.float64)
@@ -207,11 +227,15 @@ class GinibreDistribution(Distribution):
         return self._dim ** 2
 
     def sample(self, n=1):
+        # one legacy-RNG call for all n states, in the order a per-state loop would consume the stream
+        # (state i: real parts, then imaginary parts), in blocks so that 1e6 states do not need 1e6 x 16 x 16 temporaries
         flat = self._basis.flat()
         out = np.empty((n, self.n_rvs))
-        for i in range(n):
-            g = np.random.randn(self._dim, self._rank) + 1j * np.random.randn(self._dim, self._rank)
-            rho = g @ g.conj().T
-            rho /= np.trace(rho).real
-            out[i] = np.real(flat.conj() @ rho.flatten())
+        for i0 in range(0, n, 65536):
+            m = min(65536, n - i0)
+            z = np.random.randn(m, 2, self._dim, self._rank)
+            g = z[:, 0] + 1j * z[:, 1]
+            rho = g @ g.conj().transpose(0, 2, 1)
+            rho /= np.trace(rho, axis1=1, axis2=2).real[:, None, None]
+            out[i0:i0 + m] = np.real(rho.reshape(m, -1) @ flat.conj().T)
         return out
