@@ -183,14 +183,35 @@ template <> struct Model<QSMC_MODEL_PRECESSION> {
     }
 };
 
+// x^k for a non-negative integer k that is THE SAME FOR EVERY LANE (an outcome count or n_meas - outcome: kernel
+// arguments, i.e. SGPRs): square-and-multiply under scalar control flow, at most 2 log2(k) fp64 multiplies.  Each
+// multiply rounds once and a squaring doubles the accumulated relative error, so the result is within ~k/2 ulp.
+__host__ __device__ __forceinline__ double powi_uniform(double x, unsigned k) {
+    double r = 1.0, b = x;
+    while (k) {
+        if (k & 1u) r *= b;
+        k >>= 1;
+        if (k) b *= b;
+    }
+    return r;
+}
+
 // derived_models.py:317-325 + utils.py:106-111: Binom(n_meas, pr1).pmf(k), pr1 = L_underlying(outcome 1)
 __host__ __device__ __forceinline__ double binom_pmf(double pr1, const ExpArgs &e, int64_t o) {
     const double k = (double)o;
     if (o < 0 || k > e.n_meas) return 0.0;
-    // C(n,k) p^k (1-p)^(n-k) as C * exp(k ln p + (n-k) ln(1-p)): two logarithms and one exponential instead of
-    // two fp64 pow() (each a log + an exp in extended precision, ~150 instructions; the binomial update kernel
-    // was 4x the precession one).  Relative error ~ (k + n - k) eps |ln| ~ 1e-14 at n_meas = 25, inside the 1e-12
-    // the closed form is held to against SciPy's pmf (G2, G8).  0 * ln 0 never forms: a zero exponent drops its term.
+    if (e.n_meas <= 64.0) {
+        // C(n,k) p^k (1-p)^(n-k) literally, with the two integer powers by square-and-multiply: k and n - k come from
+        // the kernel arguments, so the loops are scalar control flow and cost <= ~20 multiplies together -- the
+        // log / log1p / exp form below is ~100 fp64 operations and made this the one update kernel that was
+        // VALU-bound at twice the precession kernel's time (75 vs 40 us at N = 1e7).  Error <= ~n/2 ulp = 4e-15 at
+        // n_meas = 25 (the closed form is held to 1e-12 against SciPy's pmf: G2, G8); the same graceful underflow.
+        if (!(pr1 >= 0.0 && pr1 <= 1.0)) return NAN;               // (an invalid particle: SciPy's pmf gives nan too)
+        return (e.comb * powi_uniform(pr1, (unsigned)o)) * powi_uniform(1.0 - pr1, (unsigned)(e.n_meas - k));
+    }
+    // many measurements: C * exp(k ln p + (n-k) ln(1-p)), two logarithms and one exponential instead of two fp64
+    // pow() (each a log + an exp in extended precision, ~150 instructions).  Relative error ~ n eps |ln|.
+    // 0 * ln 0 never forms: a zero exponent drops its term.
     const double lp = (k > 0.0 ? k * fast_log(pr1) : 0.0) + (e.n_meas - k > 0.0 ? (e.n_meas - k) * fast_log1m(pr1) : 0.0);
     return isfinite(e.comb) ? e.comb * fast_exp(lp) : fast_exp(e.log_comb + lp);      // huge n_meas: C(n,k) itself in log space
 }
