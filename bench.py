@@ -345,17 +345,15 @@ def main():
             print(json.dumps({args.only: run_other_config(qi, eng, torch, spec, args.warmup)}), flush=True)
         return
 
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        upd = qi.SMCUpdater(qi.SimplePrecessionModel(), n, qi.UniformDistribution([0, 1]),
-                            device_rng=True, seed=0, comm=comm)
-        for k in range(args.warmup):                       # untimed: first W data of a throwaway pass
+    def timed_pass(upd, events):
+        """W warm-up data of a throwaway pass, reset, then exactly --steps updates between barriers."""
+        for k in range(args.warmup):
             upd.update(int(outcomes[k % N_SCHEDULE]), ts[k % N_SCHEDULE:k % N_SCHEDULE + 1])
         upd.reset()
         upd._resample_count = 0
         # a launch that carries start/stop events drains the queue around itself (measured: 10.7 us per step
         # with every launch timed), so every `stride`-th launch of each kernel kind is timed
-        eng.set_profiling(0 if os.environ.get("QSMC_BENCH_NO_EVENTS") else stride)
+        eng.set_profiling(stride if events else 0)
         barrier()
         t0 = time.perf_counter()
         for i in range(args.steps):
@@ -364,7 +362,39 @@ def main():
                 upd.reset()
             upd.update(int(outcomes[k]), ts[k:k + 1])
         barrier()
-        wall = time.perf_counter() - t0
+        return time.perf_counter() - t0
+
+    rccl_pass = None
+    if ((world > 1 or os.environ.get("QSMC_BENCH_FORCE_RCCL_PASS")) and not share_gpu and comm is not None
+            and comm.transport != "rccl" and not os.environ.get("QSMC_BENCH_NO_RCCL_PASS")):
+        # The same workload once more with the library's own RCCL all-reduce on the launch stream carrying the
+        # per-datum reduction (north_star's transport; the headline below uses whatever ParticleShardGroup picked,
+        # host shared memory on one node).  Reported beside the headline, never as `value`.
+        try:
+            from qinfer_amd.parallel import ParticleShardGroup
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                comm_r = ParticleShardGroup(transport="rccl")
+                upd_r = qi.SMCUpdater(qi.SimplePrecessionModel(), n, qi.UniformDistribution([0, 1]),
+                                      device_rng=True, seed=0, comm=comm_r)
+                wall_r = timed_pass(upd_r, events=False)
+                wr = torch.tensor([wall_r], dtype=torch.float64, device="cuda")
+                if world > 1:
+                    torch.distributed.all_reduce(wr, op=torch.distributed.ReduceOp.MAX)
+                rccl_pass = {"per_datum_collective": comm_r.transport_name, "value": n * world * args.steps / float(wr.item()),
+                             "ms_per_step": float(wr.item()) / args.steps * 1e3, "resamples": upd_r.resample_count,
+                             "posterior_mean": float(upd_r.est_mean()[0])}
+                del upd_r
+                comm_r.close()
+                torch.cuda.empty_cache()
+        except Exception as e:  # noqa: BLE001
+            rccl_pass = {"error": repr(e)}
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        upd = qi.SMCUpdater(qi.SimplePrecessionModel(), n, qi.UniformDistribution([0, 1]),
+                            device_rng=True, seed=0, comm=comm)
+        wall = timed_pass(upd, events=not os.environ.get("QSMC_BENCH_NO_EVENTS"))
         # the kernels' start/stop events (hipExtLaunchKernelGGL, on the launch stream) are read here, once
         all_ms, tags = eng.profile_read()
         eng.set_profiling(False)
@@ -495,6 +525,8 @@ def main():
                 line["roofline"]["census_avg_kernel_us"] = census["update"]["avg_us"]
                 line["roofline"]["census_launches"] = census["update"]["launches"]
         line.update(extras)
+        if rccl_pass is not None:
+            line["rccl_transport_pass"] = rccl_pass
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(n, args.cpu_data, gpu_same_sample)

@@ -201,6 +201,25 @@ int qsmc_host_allgather(void *segment, int32_t rank, int32_t world, int32_t max_
 int qsmc_host_allreduce(void *segment, int32_t rank, int32_t world, int32_t max_len, uint64_t k, const double *vec,
                         int32_t n, int32_t min_index, double *rows_out, double *tot_out, double timeout_s);
 
+/* ---- RCCL transport of the same reduction (SURVEY 8(b2) `qsmc_comm_init` / `qsmc_allreduce_sums`, 8(e)) -------
+ * One process per GPU; the ranks of a sharded updater form an RCCL communicator inside the library.
+ * qsmc_comm_unique_id: rank 0 fills id_out[128] (ncclGetUniqueId) and hands it to the others by any side channel
+ * (the Python layer broadcasts it through torch.distributed); qsmc_comm_init: collective, every rank with the
+ * same id; qsmc_comm_destroy: also done by qsmc_destroy.  librccl is bound at run time (dlsym), preferring the copy
+ * already loaded in the process.
+ * qsmc_allreduce_sums: vec_dev = this rank's n doubles on the DEVICE (the stats_dev vector qsmc_update_fused just
+ * wrote: [sum w', sum w'^2, min w', #bad, moment sums...]); on `stream`, behind the kernel that produced it: one
+ * group of ncclAllReduce(sum) over the n entries, ncclAllReduce(min) of entry min_index (if >= 0) and an
+ * all-gather of entry 0, then a publishing kernel; returns when the result is in tot_host[n] (entry min_index =
+ * the minimum) and firsts_host[nranks] (every rank's entry 0 = its shard's weight total, nullable).  This is the
+ * collective the reference's DirectViewParallelizedModel stands in for with a gather of the whole likelihood
+ * array (parallel.py:216-224); identical bits on every rank (RCCL's guarantee for all-reduce). */
+int qsmc_comm_unique_id(void *id_out);
+int qsmc_comm_init(qsmc_handle_t h, int32_t rank, int32_t nranks, const void *unique_id);
+int qsmc_comm_destroy(qsmc_handle_t h);
+int qsmc_allreduce_sums(qsmc_handle_t h, const double *vec_dev, int32_t n, int32_t min_index, double *tot_host,
+                        double *firsts_host, qsmc_stream_t stream);
+
 /* Sorting and searching for the posterior read-outs (est_credible_region, distributions.py:558-614;
  * posterior_marginal, smc.py:672-716).  qsmc_argsort: stable radix sort (rocPRIM) of n < 2^31 keys, ascending or
  * descending; keys_out and idx_out (the permutation, int64) are device arrays of n entries.

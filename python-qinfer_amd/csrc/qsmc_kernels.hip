@@ -23,6 +23,9 @@
 #include <cstring>
 #include <new>
 
+#include <dlfcn.h>
+
+#include <rccl/rccl.h>              // types and prototypes only: the entry points are bound with dlsym (qsmc_comm_init)
 #include <rocprim/rocprim.hpp>      // device radix sort for the posterior read-outs (a plain library op)
 
 #include "qsmc_device.h"
@@ -78,6 +81,19 @@ struct qsmc_ctx {
     size_t iscratch_cap;    // in bytes
     double *cdf_scratch;    // device CDF, materialised only for the direct sampler / global redraws
     size_t cdf_cap;         // in doubles
+    struct {                       // RCCL communicator of the sharded updater (qsmc_comm_init); entry points bound at run time
+        void *lib;
+        ncclComm_t comm;
+        int rank, nranks;
+        double *buf;               // device: [sums (REDUCE_OUT_MAX) | min (8) | gathered firsts (QSMC_MAX_RANKS)]
+        decltype(&ncclCommInitRank) CommInitRank;
+        decltype(&ncclCommDestroy) CommDestroy;
+        decltype(&ncclAllReduce) AllReduce;
+        decltype(&ncclAllGather) AllGather;
+        decltype(&ncclGroupStart) GroupStart;
+        decltype(&ncclGroupEnd) GroupEnd;
+        decltype(&ncclGetErrorString) GetErrorString;
+    } cc;
     int profiling;
     hipEvent_t *prof_ev;   // QSMC_PROF_CAP (start, stop) pairs, created on first qsmc_set_profiling(1)
     int prof_n;            // profiled launches since the last qsmc_profile_read / set_profiling
@@ -482,6 +498,7 @@ int qsmc_create(qsmc_handle_t *out, int device) {
 
 int qsmc_destroy(qsmc_handle_t h) {
     if (!h) return QSMC_OK;
+    (void)qsmc_comm_destroy(h);
     if (h->partials) (void)hipFree(h->partials);
     if (h->rs_offsets) (void)hipFree(h->rs_offsets);
     if (h->tile_sums) (void)hipFree(h->tile_sums);
@@ -1380,6 +1397,128 @@ int qsmc_searchsorted(qsmc_handle_t h, const double *a, int64_t n, const double 
     hipLaunchKernelGGL(k_searchsorted, dim3(grid_for(m, QSMC_BLOCK)), dim3(QSMC_BLOCK), 0, (hipStream_t)stream, a, n,
                        q, m, side, out);
     HIP_TRY(h, hipGetLastError());
+    return QSMC_OK;
+}
+
+// ---- RCCL: the per-datum reduction of the sharded updater on the launch stream ----------
+// Replaces what the reference does with an ipyparallel gather of the likelihood array (parallel.py:216-224): here
+// only the update kernel's sums cross the links.  One group of three collectives on `stream`, right behind the
+// kernel that produced the vector -- all-reduce(sum) of the n sums, all-reduce(min) of the weight minimum, and an
+// all-gather of entry 0 (every rank's sum of weights: the next resample's shard plan) -- then a one-wave kernel
+// publishes the result in the pinned slot the completion word already guards, so the host's only wait per datum
+// is the same spin it does on one GPU.  librccl is bound with dlsym, preferring the copy already in the process
+// (torch's): two RCCLs would mean two HIP runtimes.
+constexpr int QSMC_MAX_RANKS = 64;
+
+static void *rccl_open() {
+    const char *names[] = {"librccl.so.1", "librccl.so"};
+    for (const char *n : names)
+        if (void *l = dlopen(n, RTLD_NOW | RTLD_NOLOAD)) return l;
+    for (const char *n : names)
+        if (void *l = dlopen(n, RTLD_NOW | RTLD_GLOBAL)) return l;
+    return nullptr;
+}
+
+int qsmc_comm_unique_id(void *id_out) {
+    if (!id_out) return QSMC_ERR_INVALID;
+    void *lib = rccl_open();
+    if (!lib) return QSMC_ERR_UNSUPPORTED;
+    auto get = reinterpret_cast<decltype(&ncclGetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
+    if (!get) return QSMC_ERR_UNSUPPORTED;
+    ncclUniqueId id;
+    if (get(&id) != ncclSuccess) return QSMC_ERR_HIP;
+    memcpy(id_out, &id, sizeof(id));
+    return QSMC_OK;
+}
+
+int qsmc_comm_init(qsmc_handle_t h, int32_t rank, int32_t nranks, const void *unique_id) {
+    if (!h || !unique_id || nranks < 1 || nranks > QSMC_MAX_RANKS || rank < 0 || rank >= nranks) return QSMC_ERR_INVALID;
+    if (h->cc.comm) return QSMC_ERR_INVALID;
+    void *lib = rccl_open();
+    if (!lib) {
+        snprintf(h->hip_err, sizeof(h->hip_err), "librccl not found: %s", dlerror());
+        return QSMC_ERR_UNSUPPORTED;
+    }
+    h->cc.lib = lib;
+#define BIND(NAME)                                                                         \
+    h->cc.NAME = reinterpret_cast<decltype(&nccl##NAME)>(dlsym(lib, "nccl" #NAME));         \
+    if (!h->cc.NAME) { snprintf(h->hip_err, sizeof(h->hip_err), "nccl" #NAME " missing"); return QSMC_ERR_UNSUPPORTED; }
+    BIND(CommInitRank) BIND(CommDestroy) BIND(AllReduce) BIND(AllGather) BIND(GroupStart) BIND(GroupEnd) BIND(GetErrorString)
+#undef BIND
+    HIP_TRY(h, hipSetDevice(h->device));
+    ncclUniqueId id;
+    memcpy(&id, unique_id, sizeof(id));
+    ncclComm_t comm = nullptr;
+    const ncclResult_t r = h->cc.CommInitRank(&comm, nranks, id, rank);
+    if (r != ncclSuccess) {
+        snprintf(h->hip_err, sizeof(h->hip_err), "ncclCommInitRank: %s", h->cc.GetErrorString(r));
+        return QSMC_ERR_HIP;
+    }
+    HIP_TRY(h, hipMalloc(&h->cc.buf, (REDUCE_OUT_MAX + 8 + QSMC_MAX_RANKS) * sizeof(double)));
+    h->cc.comm = comm;
+    h->cc.rank = rank;
+    h->cc.nranks = nranks;
+    return QSMC_OK;
+}
+
+int qsmc_comm_destroy(qsmc_handle_t h) {
+    if (!h) return QSMC_ERR_INVALID;
+    if (h->cc.comm) {
+        (void)h->cc.CommDestroy(h->cc.comm);
+        h->cc.comm = nullptr;
+    }
+    if (h->cc.buf) {
+        (void)hipFree(h->cc.buf);
+        h->cc.buf = nullptr;
+    }
+    return QSMC_OK;
+}
+
+__global__ void k_publish_allreduce(const double *__restrict__ sums, const double *__restrict__ mn, const double *__restrict__ firsts,
+                                    int n, int min_index, int nranks, double *__restrict__ mapped, unsigned long long *flag,
+                                    unsigned long long seq) {
+    const int t = threadIdx.x;
+    if (t < n) mapped[t] = t == min_index ? mn[0] : sums[t];
+    if (t < nranks) mapped[n + t] = firsts[t];
+    __syncthreads();
+    if (t == 0) {
+        __threadfence_system();
+        *reinterpret_cast<volatile unsigned long long *>(flag) = seq;
+    }
+}
+
+int qsmc_allreduce_sums(qsmc_handle_t h, const double *vec_dev, int32_t n, int32_t min_index, double *tot_host,
+                        double *firsts_host, qsmc_stream_t stream) {
+    if (!h || !vec_dev || !tot_host || n < 1 || n > REDUCE_OUT_MAX - QSMC_MAX_RANKS || min_index >= n) return QSMC_ERR_INVALID;
+    if (!h->cc.comm) return QSMC_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    double *sums = h->cc.buf, *mn = h->cc.buf + REDUCE_OUT_MAX, *firsts = mn + 8;
+    ncclResult_t r = h->cc.GroupStart();
+    if (r == ncclSuccess) r = h->cc.AllReduce(vec_dev, sums, (size_t)n, ncclDouble, ncclSum, h->cc.comm, s);
+    if (r == ncclSuccess && min_index >= 0) r = h->cc.AllReduce(vec_dev + min_index, mn, 1, ncclDouble, ncclMin, h->cc.comm, s);
+    if (r == ncclSuccess) r = h->cc.AllGather(vec_dev, firsts, 1, ncclDouble, h->cc.comm, s);
+    const ncclResult_t r2 = h->cc.GroupEnd();
+    if (r == ncclSuccess) r = r2;
+    if (r != ncclSuccess) {
+        snprintf(h->hip_err, sizeof(h->hip_err), "rccl: %s", h->cc.GetErrorString(r));
+        return QSMC_ERR_HIP;
+    }
+    const unsigned long long seq = ++h->seq;
+    hipLaunchKernelGGL(k_publish_allreduce, dim3(1), dim3(256), 0, s, sums, mn, firsts, (int)n, (int)min_index, h->cc.nranks,
+                       h->mapped_dev, h->flag_dev, seq);
+    HIP_TRY(h, hipGetLastError());
+    // a collective can take arbitrarily long when a peer is late: no 20 ms spin window here, wait for the stream
+    volatile unsigned long long *f = h->flag;
+    for (unsigned spins = 0; *f != seq; ++spins) {
+        __builtin_ia32_pause();
+        if ((spins & 0xfffff) == 0xfffff && hipStreamQuery(s) != hipErrorNotReady) {
+            HIP_TRY(h, hipStreamSynchronize(s));
+            break;
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    memcpy(tot_host, h->mapped, (size_t)n * sizeof(double));
+    if (firsts_host) memcpy(firsts_host, h->mapped + n, (size_t)h->cc.nranks * sizeof(double));
     return QSMC_OK;
 }
 

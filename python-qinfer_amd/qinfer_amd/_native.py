@@ -72,6 +72,10 @@ SIGNATURES = {
                                 C.POINTER(_I64), _P],
     "qsmc_host_allgather": [_P, _I32, _I32, _I32, _U64, _P, _I32, _P, _F64],
     "qsmc_host_allreduce": [_P, _I32, _I32, _I32, _U64, _P, _I32, _I32, _P, _P, _F64],
+    "qsmc_comm_unique_id": [_P],
+    "qsmc_comm_init": [_P, _I32, _I32, _P],
+    "qsmc_comm_destroy": [_P],
+    "qsmc_allreduce_sums": [_P, _P, _I32, _I32, _P, _P, _P],
     "qsmc_argsort": [_P, _P, _I64, _I32, _P, _P, _P],
     "qsmc_searchsorted": [_P, _P, _I64, _P, _I64, _I32, _P, _P],
     "qsmc_weight_entropy": [_P, _P, _I64, _F64, C.POINTER(_F64), _P],

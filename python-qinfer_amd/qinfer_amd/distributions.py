@@ -142,6 +142,62 @@ class PostselectedDistribution(Distribution):
         return self._dist.grad_log_pdf(x)
 
 
+class DeviceBackedArray(np.ndarray):
+    """What `particle_locations` / `particle_weights` return: a host snapshot of the device array that WRITES
+    THROUGH.  The reference holds these as plain NumPy attributes and mutates them in place
+    (`self.particle_weights[:] = ...`, smc.py:441; `self.particle_locations[:, :] = ...`, smc.py:529), so user code
+    written against it does the same; here every in-place write (item / slice assignment, an in-place operator or
+    a ufunc with `out=`, `fill`) -- also through a slice of the snapshot -- is followed by an upload of the whole
+    array to the device.  A snapshot taken before the cloud changed underneath it (an update, a resample, another
+    assignment) is stale: reading it gives the old numbers, writing to it raises instead of silently losing data.
+    Arithmetic on a snapshot returns plain arrays."""
+
+    def __new__(cls, arr, owner, what):
+        obj = np.asarray(arr).view(cls)
+        obj._owner, obj._what, obj._root = owner, what, obj
+        obj._version = owner._view_version
+        return obj
+
+    def __array_finalize__(self, obj):
+        root = getattr(obj, "_root", None)
+        if root is not None and self.base is not None:        # a view INTO a snapshot: shares its memory
+            self._root, self._owner, self._what = root, obj._owner, obj._what
+        else:                                                  # a fresh array (copy, result): plain behaviour
+            self._root = None
+
+    def _push(self):
+        root = getattr(self, "_root", None)
+        if root is None:
+            return
+        owner = root._owner
+        if owner._view_version != root._version:
+            raise RuntimeError("this array is a snapshot of particle_{} taken before the cloud changed (update / "
+                               "resample / assignment); take a fresh one before writing".format(root._what))
+        owner._write_back(root._what, np.asarray(root))
+        root._version = owner._view_version
+
+    def __setitem__(self, key, value):
+        super().__setitem__(key, value)
+        self._push()
+
+    def fill(self, value):
+        np.ndarray.fill(self, value)
+        self._push()
+
+    def __array_ufunc__(self, ufunc, method, *inputs, out=None, **kwargs):
+        plain = tuple(np.asarray(i) if isinstance(i, DeviceBackedArray) else i for i in inputs)
+        touched = []
+        if out is not None:
+            touched = [o for o in out if isinstance(o, DeviceBackedArray)]
+            kwargs["out"] = tuple(np.asarray(o) if isinstance(o, DeviceBackedArray) else o for o in out)
+        res = getattr(ufunc, method)(*plain, **kwargs)
+        for o in touched:
+            o._push()
+        if out is not None and len(out) == 1 and touched:
+            return out[0]
+        return res
+
+
 class ParticleDistribution(Distribution):
     """A weighted particle cloud resident on the GPU.
 
@@ -185,9 +241,19 @@ class ParticleDistribution(Distribution):
         self._sumsq = None
         self._moments_cache = None
 
+    _view_version = 0
+
     def _invalidate(self):
         self._moments_cache = None
         self._w_token = 0            # the weights are no longer (known to be) the output of a fused update
+        self._view_version += 1      # host snapshots handed out so far are stale from here on
+
+    def _write_back(self, what, arr):
+        """Upload an edited host snapshot (DeviceBackedArray._push)."""
+        if what == "weights":
+            self.particle_weights = arr
+        else:
+            self.particle_locations = arr
 
     def _weights(self):
         """Explicit unnormalised weights.  `_w is None` encodes an all-ones cloud (uniform weights
@@ -207,21 +273,23 @@ class ParticleDistribution(Distribution):
     # ---------------------------------------------------------------- reference attributes
     @property
     def particle_locations(self):
-        """(N, d) NumPy COPY of the cloud (D2H).  Assign a whole array to change it."""
-        return np.ascontiguousarray(self._x.cpu().numpy().T)
+        """(N, d) host snapshot of the cloud (D2H) that writes through: `upd.particle_locations[:, 0] = v` uploads."""
+        return DeviceBackedArray(np.ascontiguousarray(self._x.cpu().numpy().T), self, "locations")
 
     @particle_locations.setter
     def particle_locations(self, locs):
         locs = np.asarray(locs, dtype=np.float64)
         self._x = self._eng.locs_to_soa(locs)
+        self._shard_sums = None      # (sharded updater: a changed shard size invalidates the resample plan's inputs)
         self._invalidate()
 
     @property
     def particle_weights(self):
-        """(N,) NumPy COPY of the normalised weights (D2H)."""
+        """(N,) host snapshot of the normalised weights (D2H) that writes through (`upd.particle_weights[:] = w`,
+        smc.py:441, uploads)."""
         if self.n_particles == 0:
             return np.zeros((0,))
-        return self._eng.normalized_weights(self._weights(), self._norm).cpu().numpy()
+        return DeviceBackedArray(self._eng.normalized_weights(self._weights(), self._norm).cpu().numpy(), self, "weights")
 
     @particle_weights.setter
     def particle_weights(self, w):
@@ -229,6 +297,7 @@ class ParticleDistribution(Distribution):
         self._w_alt = None
         self._norm = 1.0
         self._sumsq = None
+        self._shard_sums = None      # (sharded updater: per-rank weight totals must be gathered again)
         self._invalidate()
 
     @property

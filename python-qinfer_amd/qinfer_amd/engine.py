@@ -256,6 +256,31 @@ class Engine:
         self._chk(self.lib.qsmc_fill(self.h, self._p(w), w.shape[0], float(value), self.stream()),
                   "qsmc_fill")
 
+    # ------------------------------------------------------------------ RCCL transport (sharded updater)
+    @staticmethod
+    def comm_unique_id():
+        """128-byte RCCL id (rank 0 creates it; broadcast to the other ranks by the caller)."""
+        buf = C.create_string_buffer(128)
+        _native.check(None, _native.load().qsmc_comm_unique_id(buf), "qsmc_comm_unique_id")
+        return buf.raw
+
+    def comm_init(self, rank, nranks, unique_id):
+        """Collective: every rank of the shard group, same id."""
+        self._chk(self.lib.qsmc_comm_init(self.h, int(rank), int(nranks), C.create_string_buffer(unique_id, 128)),
+                  "qsmc_comm_init")
+        self._cc_tot = np.empty(64)
+        self._cc_first = np.empty(int(nranks))
+
+    def comm_destroy(self):
+        self._chk(self.lib.qsmc_comm_destroy(self.h), "qsmc_comm_destroy")
+
+    def allreduce_sums(self, vec_dev, n, min_index=-1):
+        """RCCL all-reduce of the first n doubles of a device vector on the launch stream.  Returns (tot, firsts):
+        views of reused host arrays -- sums over ranks (entry min_index: minimum) and every rank's entry 0."""
+        self._chk(self.lib.qsmc_allreduce_sums(self.h, self._p(vec_dev), int(n), int(min_index), self._cc_tot.ctypes.data,
+                                               self._cc_first.ctypes.data, self.stream()), "qsmc_allreduce_sums")
+        return self._cc_tot[:n], self._cc_first
+
     # ------------------------------------------------------------------ moments
     def moments(self, x, w, norm):
         """Returns host (sum_w, S1[d], S2[d, d]) of the normalised weights."""

@@ -168,7 +168,18 @@ class HostExchange:
 
 
 class ParticleShardGroup:
-    def __init__(self, group=None, seed=0, placement="local", rebalance_tol=0.05, host_exchange=True):
+    """The ranks that share one sharded particle cloud.
+
+    `transport` selects what carries the per-datum reduction (a dozen doubles per rank):
+      "auto"     host shared memory when every rank runs on this host (measured ~4 us per datum), else "backend";
+      "shm"      host shared memory (HostExchange) or fail;
+      "rccl"     the library's own RCCL communicator: all-reduce on the launch stream, right behind the update kernel
+                 (`qsmc_allreduce_sums`; needs one GPU per rank);
+      "backend"  torch.distributed's all-gather (gloo on CPU, RCCL through torch on GPUs).
+    The environment variable QSMC_TRANSPORT overrides the argument."""
+
+    def __init__(self, group=None, seed=0, placement="local", rebalance_tol=0.05, host_exchange=True, transport=None):
+        import os
         import torch
         import torch.distributed as dist
         if not dist.is_initialized():
@@ -186,7 +197,16 @@ class ParticleShardGroup:
         self.n_rebalances = 0
         self._bitgen = np.random.Philox(key=self.seed & (2 ** 64 - 1))     # re-keyed per plan by counter
         self._gen = np.random.Generator(self._bitgen)
-        self._host = self._open_host_exchange() if host_exchange else None
+        transport = os.environ.get("QSMC_TRANSPORT") or transport or "auto"
+        if transport not in ("auto", "shm", "rccl", "backend"):
+            raise ValueError("transport must be 'auto', 'shm', 'rccl' or 'backend'")
+        if not host_exchange and transport == "auto":
+            transport = "backend"
+        self.transport = transport
+        self._rccl = None                 # engine whose handle holds the RCCL communicator (created at first use)
+        self._host = self._open_host_exchange() if transport in ("auto", "shm") else None
+        if transport == "shm" and self._host is None:
+            raise RuntimeError("transport='shm': the ranks do not share a host (or /dev/shm is unavailable)")
 
     def _open_host_exchange(self):
         """Shared-memory exchange if (and only if) every rank runs on this host and every rank can map the
@@ -226,11 +246,58 @@ class ParticleShardGroup:
         host, self._host = getattr(self, "_host", None), None
         if host is not None:
             host.close()
+        eng, self._rccl = getattr(self, "_rccl", None), None
+        if eng is not None:
+            eng.comm_destroy()
 
     @property
     def transport_name(self):
         """What carries the per-datum reduction (bench.py reports it)."""
+        if self.transport == "rccl":
+            return "RCCL all-reduce on the launch stream (qsmc_allreduce_sums)"
         return "host shared memory" if self._host is not None else "backend all-gather (%s)" % self.backend
+
+    @property
+    def device_transport(self):
+        """True if the per-datum reduction starts from the device vector (no host round trip before it)."""
+        return self.transport == "rccl"
+
+    def _rccl_engine(self, eng):
+        """The library's RCCL communicator over this group, created collectively at first use."""
+        if self._rccl is None:
+            uid = [eng.comm_unique_id() if self.rank == 0 else None]
+            src = 0 if self.group is None else self.dist.get_global_rank(self.group, 0)
+            self.dist.broadcast_object_list(uid, src=src, group=self.group)
+            eng.comm_init(self.rank, self.world_size, uid[0])
+            self._rccl = eng
+        return self._rccl
+
+    def allreduce_update_stats_device(self, eng, n):
+        """The per-datum reduction under transport='rccl': the update kernel left [sum, sumsq, min, #bad, moment
+        sums...] in the engine's device vector; one group of RCCL collectives on the launch stream makes them global."""
+        tot, firsts = self._rccl_engine(eng).allreduce_sums(eng._stats, n, 2)
+        self.last_shard_sums = firsts.copy()
+        self.last_extra = tot[4:].copy()
+        return tot.item(0), tot.item(1), tot.item(2), tot.item(3)
+
+    def allreduce_host_vector(self, vec, min_index=-1):
+        """Generic small reduction of a host float64 vector: (tot, rows) with tot the rank-ordered sum (entry
+        min_index: the minimum) and rows every rank's vector.  Shared memory when open, else the backend."""
+        vec = np.ascontiguousarray(vec, dtype=np.float64).reshape(-1)
+        n = len(vec)
+        if self._host is not None and n <= self._host.max_len:
+            buf, rows, tot, run = self._host.all_reduce(n, min_index)
+            buf[:] = vec
+            run()
+            return tot.copy(), rows.copy()
+        rows = self.gather_rows(vec)
+        tot = np.zeros(n)
+        for r in range(self.world_size):
+            tot += rows[r]
+        if min_index >= 0:
+            col = rows[:, min_index]
+            tot[min_index] = np.nan if np.isnan(col).any() else col.min()
+        return tot, rows
 
     # ------------------------------------------------------------------ small collectives
     def _comm_tensor(self, t):

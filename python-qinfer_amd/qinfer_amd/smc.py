@@ -304,10 +304,17 @@ class SMCUpdater(ParticleDistribution):
                 # sharded: this shard's sums land in pinned host memory like the single-GPU path, then ONE
                 # small all-gather (shared memory on one host, else the backend's) makes them global
                 n_mom = d + d * (d + 1) // 2 if d <= 4 else 0
-                st = eng.update_fused(self._desc, self._x, self._w, w_out, self._norm, exps[0],
-                                      _as_int_outcome(outcome), moments="raw" if n_mom else False)
-                norm, sumsq, wmin, n_bad = self._comm.allreduce_update_stats(
-                    eng, st.sum, st.sumsq, st.min, st.n_bad, eng._mom[d] if n_mom else None)
+                if self._comm.device_transport:
+                    # RCCL on the launch stream: the collective starts from the device vector the reducing kernel
+                    # wrote -- no host round trip between the update and the all-reduce, one wait per datum
+                    eng.update_fused(self._desc, self._x, self._w, w_out, self._norm, exps[0],
+                                     _as_int_outcome(outcome), sync=False)
+                    norm, sumsq, wmin, n_bad = self._comm.allreduce_update_stats_device(eng, 4 + n_mom)
+                else:
+                    st = eng.update_fused(self._desc, self._x, self._w, w_out, self._norm, exps[0],
+                                          _as_int_outcome(outcome), moments="raw" if n_mom else False)
+                    norm, sumsq, wmin, n_bad = self._comm.allreduce_update_stats(
+                        eng, st.sum, st.sumsq, st.min, st.n_bad, eng._mom[d] if n_mom else None)
                 self._shard_sums = self._comm.last_shard_sums
                 if n_mom:
                     fused_moments = self._comm.last_extra            # (a copy: packed sums, see _moments)
@@ -409,7 +416,7 @@ class SMCUpdater(ParticleDistribution):
             raise ValueError("The number of outcomes and experiments must match.")
         if len(expparams.shape) == 1:
             expparams = expparams[:, None]
-        fast = (self._native and self._comm is None and self._batch_fast_path
+        fast = (self._native and self._batch_fast_path
                 and getattr(self.model, "_native_timestep", None) is None)   # moving particles: one datum at a time
         idx = 0
         kmax = self._eng.MULTI_KMAX
@@ -440,6 +447,30 @@ class SMCUpdater(ParticleDistribution):
             outs.append(_as_int_outcome(outcomes[j]))
         w_out = self._scratch_weights()
         stats, m1, m2 = eng.update_multi(self._desc, self._x, self._w, w_out, self._norm, exps, outs)
+        if self._comm is not None:
+            # sharded: the window's per-datum sums (and the moment sums of its last datum) are additive over the
+            # shards -- one small reduction for the whole window instead of one per datum
+            d = self._x.shape[0]
+            vec = np.empty(3 * k + 1 + (0 if m1 is None else d + d * d))
+            for j, st in enumerate(stats):
+                vec[3 * j:3 * j + 3] = st.sum, st.sumsq, st.n_bad
+            vec[3 * k] = min(st.min for st in stats)
+            if m1 is not None:
+                vec[3 * k + 1:3 * k + 1 + d] = m1
+                vec[3 * k + 1 + d:] = m2.reshape(-1)
+            tot, rows = self._comm.allreduce_host_vector(vec, min_index=3 * k)
+
+            class _St:
+                __slots__ = ("sum", "sumsq", "n_bad", "min")
+            red = []
+            for j in range(k):
+                st = _St()
+                st.sum, st.sumsq, st.n_bad, st.min = tot[3 * j], tot[3 * j + 1], tot[3 * j + 2], tot[3 * k]
+                red.append(st)
+            stats = red
+            if m1 is not None:
+                m1, m2 = tot[3 * k + 1:3 * k + 1 + d].copy(), tot[3 * k + 1 + d:].reshape(d, d).copy()
+            shard_sums = rows[:, 3 * (k - 1)].copy()
         flush = getattr(self.resampler, "_flush_failed_warning", None)
         if flush is not None:
             flush()
@@ -463,6 +494,8 @@ class SMCUpdater(ParticleDistribution):
         self._norm = float(stats[-1].sum)
         self._sumsq = float(stats[-1].sumsq)
         self._invalidate()
+        if self._comm is not None:
+            self._shard_sums = shard_sums
         if m1 is not None:
             self._moments_cache = (1.0, m1 / self._norm, m2 / self._norm)
         return True
@@ -477,7 +510,12 @@ class SMCUpdater(ParticleDistribution):
             one = expparams[k:k + 1]
             os_ = self.model.domain(one)[0].values
             exp = self.model._native_expparams(one)[0]
-            out.append(eng.hypothetical_sums(self._desc, self._x, self._w, self._norm, exp, os_, shift))
+            sums = eng.hypothetical_sums(self._desc, self._x, self._w, self._norm, exp, os_, shift)
+            if self._comm is not None:
+                # every entry is a sum over particles with the GLOBAL normaliser and a shift all ranks agree on
+                # (the global mean): additive over the shards
+                sums = self._comm.allreduce_host_vector(sums.reshape(-1))[0].reshape(sums.shape)
+            out.append(sums)
         return out
 
     def bayes_risk(self, expparams):
@@ -488,7 +526,7 @@ class SMCUpdater(ParticleDistribution):
         normalisation and the (mean-shifted) first and second moments; nothing of size
         n_outcomes x N is materialised.  Other models go through `hypothetical_update`."""
         expparams = np.atleast_1d(expparams).reshape(-1)
-        if self._native and self._x.shape[0] <= 4 and self._comm is None:
+        if self._native and self._x.shape[0] <= 4:
             d = self._x.shape[0]
             Q = np.asarray(self.model.Q, dtype=np.float64)
             risk = np.empty(expparams.shape[0])
@@ -504,7 +542,7 @@ class SMCUpdater(ParticleDistribution):
         """Expected KL divergence posterior||prior over the outcomes of each hypothetical
         experiment,  sum_o N[o] KLD[o]  (smc.py:613-663).  `0 log 0` is taken as 0."""
         expparams = np.atleast_1d(expparams).reshape(-1)
-        if self._native and self._comm is None:
+        if self._native:
             eig = np.empty(expparams.shape[0])
             for k, sums in enumerate(self._hyp_sums(expparams)):
                 N, sl = sums[:, 0], sums[:, 1]
@@ -515,6 +553,7 @@ class SMCUpdater(ParticleDistribution):
 
     def _design_generic(self, expparams, what):
         """Plugin path (any Model): the reference's formulas on `hypothetical_update` output."""
+        self._single_cloud_only("bayes_risk / expected_information_gain of a model without native kernels")
         n_eps = expparams.shape[0]
         if n_eps > 1 and not self.model.is_n_outcomes_constant:
             return np.array([self._design_generic(expparams[i:i + 1], what)[0] for i in range(n_eps)])

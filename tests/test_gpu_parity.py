@@ -1420,6 +1420,99 @@ def test_reset_and_setters(qi):
                       resampler=qi.LiuWestResampler())
 
 
+def test_write_through_views(qi):
+    """Drop-in mutability (SURVEY 8(b1): `particle_locations` / `particle_weights` are public mutable attributes;
+    the reference itself writes `self.particle_weights[:] = ...`, smc.py:441, and
+    `self.particle_locations[:, :] = ...`, smc.py:529): in-place writes to what the properties return reach the device."""
+    rs = np.random.RandomState(0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        upd = qi.SMCUpdater(qi.SimplePrecessionModel(), 1000, qi.UniformDistribution([0, 1]))
+        w = rs.random_sample(1000) ** 2
+        w /= w.sum()
+        upd.particle_weights[:] = w                                    # smc.py:441
+        np.testing.assert_allclose(np.asarray(upd.particle_weights), w, rtol=1e-15)
+        np.testing.assert_allclose(upd.n_ess, 1 / np.sum(w ** 2), rtol=1e-12)
+        x = rs.random_sample((1000, 1))
+        upd.particle_locations[:, :] = x                               # smc.py:529
+        np.testing.assert_allclose(upd.est_mean(), w @ x, rtol=1e-13)
+        upd.particle_locations[:, 0] = 0.25
+        np.testing.assert_allclose(upd.est_mean(), [0.25], rtol=1e-14)
+        part = upd.particle_locations[10:20]                           # a slice of the snapshot writes through as well
+        part[:] = 0.5
+        assert np.all(np.asarray(upd.particle_locations)[10:20] == 0.5) and upd.particle_locations[9, 0] == 0.25
+        pw = upd.particle_weights
+        pw *= 2.0                                                      # in-place operator
+        np.testing.assert_allclose(np.asarray(upd.particle_weights), 2 * w, rtol=1e-15)
+        np.multiply(pw, 0.5, out=pw)                                   # ufunc with out=
+        np.testing.assert_allclose(np.asarray(upd.particle_weights), w, rtol=1e-15)
+        doubled = upd.particle_weights * 2                             # arithmetic gives a plain array ...
+        doubled[0] = 123.0                                             # ... whose edits go nowhere
+        assert upd.particle_weights[0] != 123.0
+        cp = upd.particle_weights.copy()
+        cp[:] = 0.0
+        assert upd.particle_weights.sum() > 0.5
+        # a snapshot taken before the cloud changed must not be written back over the new state
+        stale = upd.particle_weights
+        upd.update(0, np.array([1.0]))
+        with pytest.raises(RuntimeError, match="snapshot"):
+            stale[0] = 1.0
+        fresh = upd.particle_weights
+        fresh[0] = 0.0                                                 # a fresh one works, repeatedly
+        fresh[1] = 0.0
+        assert upd.particle_weights[0] == 0.0 and upd.particle_weights[1] == 0.0
+
+
+def test_user_override_of_a_native_model_wins(qi):
+    """A user subclass that overrides a kernel-backed method of a native model is served by the plugin path: its
+    likelihood / validity / time step are what the updater runs (abstract_model.py:444-528), not the base kernel."""
+    class Flat(qi.SimplePrecessionModel):                              # a likelihood the kernel does not compute
+        def likelihood(self, outcomes, modelparams, expparams):
+            qi.Model.likelihood(self, outcomes, modelparams, expparams)
+            pr0 = np.full((modelparams.shape[0], expparams.shape[0]), 0.25)
+            return qi.FiniteOutcomeModel.pr0_to_likelihood_array(outcomes, pr0)
+
+    class Drift(qi.SimplePrecessionModel):                             # static likelihood, moving particles
+        def update_timestep(self, modelparams, expparams):
+            return np.repeat((modelparams + 0.01)[:, :, np.newaxis], expparams.shape[0], axis=2)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        upd = qi.SMCUpdater(Flat(), 500, qi.UniformDistribution([0, 1]))
+        assert not upd._native
+        upd.update(0, np.array([3.0]))
+        np.testing.assert_allclose(np.ravel(upd.normalization_record), [0.25], rtol=1e-14)
+        upd = qi.SMCUpdater(Drift(), 500, qi.UniformDistribution([0, 1]))
+        m0 = upd.est_mean()[0]
+        upd.update(0, np.array([0.0]), check_for_resample=False)       # t = 0: likelihood 1 for everyone
+        np.testing.assert_allclose(upd.est_mean()[0], m0 + 0.01, rtol=1e-12)
+        # the same through a decorator: MLEModel over a random-walk model still walks
+        base = qi.GaussianRandomWalkModel(qi.SimplePrecessionModel(), fixed_covariance=np.array([1e-4]))
+        upd = qi.SMCUpdater(qi.MLEModel(base, 2.0), 4000, qi.UniformDistribution([0.4, 0.6]), device_rng=True, seed=3)
+        assert upd._native
+        v0 = upd.est_covariance_mtx()[0, 0]
+        for _ in range(5):
+            upd.update(0, np.array([0.0]), check_for_resample=False)
+        assert upd.est_covariance_mtx()[0, 0] > v0 + 4e-4                # five steps of variance 1e-4 were taken
+    # a qutrit model constructs and canonicalizes (host path: no kernel for dim 3)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        b3 = qi.tomography.gell_mann_basis(3)
+        m3 = qi.TomographyModel(b3)
+        rs = np.random.RandomState(1)
+        x = rs.randn(300, 9) * 0.3
+        x[:, 0] = 1 / np.sqrt(3)
+        y = m3.canonicalize(x)
+        np.testing.assert_allclose(y, orc.tomo_canonicalize(x, b3.data), rtol=0, atol=1e-13)
+
+        class Pr(qi.Distribution):
+            n_rvs = 9
+
+            def sample(self, n=1):
+                return x[:n].copy()
+        upd = qi.SMCUpdater(m3, 300, Pr())                             # reset() -> canonicalize: used to raise
+        np.testing.assert_allclose(np.asarray(upd.particle_locations), y, rtol=0, atol=1e-13)
+
+
 def test_smc_fitting_statistical(qi):
     """tests/test_precession_model.py:86-110: N = 10 000, 100 times in linspace(1, 10)."""
     np.random.seed(0)

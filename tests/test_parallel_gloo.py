@@ -234,6 +234,41 @@ def test_resample_protocol_gloo(tmp_path):
     _run("_check_resample_protocol", tmp_path)
 
 
+def _check_host_exchange_failure_is_collective(comm0, rank, world, tmpdir):
+    """If ONE rank cannot map the shared-memory segment, every rank must fall back together (no rank may spin on
+    shared memory while another talks to the backend): the segment is dropped everywhere and the reductions go
+    through the backend's all-gather, with the same results."""
+    import qinfer_amd.parallel as par
+    real = par.HostExchange
+
+    class Flaky(real):
+        def __init__(self, r, w, name=None, **kw):
+            if r == 1:
+                raise OSError("no /dev/shm on this rank")
+            super().__init__(r, w, name=name, **kw)
+    par.HostExchange = Flaky
+    try:
+        comm = par.ParticleShardGroup(seed=7)
+    finally:
+        par.HostExchange = real
+    assert comm._host is None and comm.transport_name.startswith("backend")
+    tot, rows = comm.allreduce_host_vector(np.array([1.0 + rank, 10.0 * (rank + 1), -float(rank)]), min_index=2)
+    assert rows.shape == (world, 3)
+    np.testing.assert_array_equal(tot, [sum(1.0 + r for r in range(world)), sum(10.0 * (r + 1) for r in range(world)),
+                                        -float(world - 1)])
+    out = comm.allreduce_update_stats(None, 1.0 + rank, 2.0, 0.5 - rank, 0.0, np.array([3.0, 4.0]))
+    assert out == (sum(1.0 + r for r in range(world)), 2.0 * world, 0.5 - (world - 1), 0.0)
+    np.testing.assert_array_equal(comm.last_extra, [3.0 * world, 4.0 * world])
+    comm.close()
+    # and with the segment: the same numbers
+    tot2, _ = comm0.allreduce_host_vector(np.array([1.0 + rank, 10.0 * (rank + 1), -float(rank)]), min_index=2)
+    np.testing.assert_array_equal(tot, tot2)
+
+
+def test_host_exchange_failure_is_collective(tmp_path):
+    _run("_check_host_exchange_failure_is_collective", tmp_path)
+
+
 # ---------------------------------------------------------------------------------------------
 # GPU legs: the full sharded SMCUpdater (HIP kernels + protocol).  One GPU box has one device, so
 # (i) two processes share it and talk over gloo, (ii) a world-size-1 RCCL group checks the nccl path.
@@ -309,6 +344,61 @@ def _check_sharded_updater_variant(comm0, rank, world, tmpdir, variant):
         assert min(s.min() for s in shards) > 0
 
 
+def _check_sharded_fast_paths(comm, rank, world, tmpdir):
+    """What a sharded updater must not lose (round-1 verdict): the fused batch_update windows, and bayes_risk /
+    expected_information_gain from the native one-pass sums -- compared with ONE updater holding the union cloud."""
+    import warnings
+    import torch
+    import qinfer_amd as qi
+    torch.cuda.set_device(0)
+    n_local = 40000
+    rs = np.random.RandomState(3)
+    x_all = 0.2 + 0.2 * rs.random_sample((n_local * world, 1))
+
+    class Slice(qi.Distribution):
+        n_rvs = 1
+
+        def __init__(self, lo, hi):
+            self.lo, self.hi = lo, hi
+
+        def sample(self, n=1):
+            assert n == self.hi - self.lo
+            return x_all[self.lo:self.hi].copy()
+    ts = (9 / 8) ** np.arange(24.0)
+    outcomes = (rs.random_sample(24) >= np.cos(0.3 * ts / 2) ** 2).astype(int)
+    model = qi.SimplePrecessionModel()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        shard = qi.SMCUpdater(model, n_local, Slice(rank * n_local, (rank + 1) * n_local), device_rng=True, seed=5,
+                              comm=comm, resample_thresh=0.0)
+        whole = qi.SMCUpdater(model, n_local * world, Slice(0, n_local * world), device_rng=True, seed=5,
+                              resample_thresh=0.0)
+        # (a) fused windows: 24 data, windows of 5 (kernel passes of <= 8 data); no resampling (threshold 0), so the
+        # sharded and the single cloud must agree to rounding in every record
+        calls = []
+        real = shard._fused_window
+        shard._fused_window = lambda o, e: calls.append(len(o)) or real(o, e)
+        shard.batch_update(outcomes, ts, resample_interval=5)
+        whole.batch_update(outcomes, ts, resample_interval=5)
+        assert sum(calls) >= 20, calls                               # the windows really went through the fused kernel
+        np.testing.assert_allclose(np.ravel(shard.normalization_record), np.ravel(whole.normalization_record), rtol=1e-12)
+        np.testing.assert_allclose(shard.n_ess, whole.n_ess, rtol=1e-11)
+        np.testing.assert_allclose(shard.est_mean(), whole.est_mean(), rtol=0, atol=1e-13)
+        np.testing.assert_allclose(shard.est_covariance_mtx(), whole.est_covariance_mtx(), rtol=1e-7, atol=1e-18)
+        # (b) experiment design on the sharded cloud
+        eps = np.array([3.0, 11.0, 40.0])
+        np.testing.assert_allclose(shard.bayes_risk(eps), whole.bayes_risk(eps), rtol=1e-9)
+        np.testing.assert_allclose(shard.expected_information_gain(eps), whole.expected_information_gain(eps), rtol=1e-9)
+    rows = comm.gather_rows(torch.from_numpy(np.concatenate([shard.bayes_risk(eps), shard.est_mean()])))
+    for r in range(1, world):
+        assert np.array_equal(rows[0], rows[r])
+
+
+@pytest.mark.gpu
+def test_sharded_fast_paths_two_ranks_one_gpu(tmp_path):
+    _run("_check_sharded_fast_paths", tmp_path, world=2)
+
+
 def _check_perf_replicas(comm, rank, world, tmpdir):
     """perf_test_multiple(comm=...): trials are replicas -- dealt round-robin to the ranks, no data-path
     collective, one all-gather of the records at the end; every rank returns the full table."""
@@ -359,3 +449,68 @@ def _nccl_world1(rank, port, tmpdir):
 def test_sharded_updater_rccl_world1(tmp_path):
     import torch.multiprocessing as mp
     mp.spawn(_nccl_world1, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+
+
+def _rccl_transport_world1(rank, port, tmpdir):
+    """transport='rccl': the library's own communicator (qsmc_comm_init) and the all-reduce on the launch stream
+    (qsmc_allreduce_sums) -- same records, bit for bit, as the host-exchange transport on the same seeds."""
+    for p in (os.path.join(ROOT, "python-qinfer_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import warnings
+    import torch
+    import torch.distributed as dist
+    import qinfer_amd as qi
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from qinfer_amd.parallel import ParticleShardGroup
+    from qinfer_amd.engine import get_engine
+    eng = get_engine()
+    # the raw entry point on a known vector
+    comm = ParticleShardGroup(seed=1234, transport="rccl")
+    assert comm.device_transport and "RCCL" in comm.transport_name
+    vec = eng.to_device(np.array([1.5, 2.5, -0.25, 0.0, 7.0, 8.0]))
+    tot, firsts = comm._rccl_engine(eng).allreduce_sums(vec, 6, 2)
+    np.testing.assert_array_equal(tot, [1.5, 2.5, -0.25, 0.0, 7.0, 8.0])
+    np.testing.assert_array_equal(firsts, [1.5])
+    ts = (9 / 8) ** np.arange(50.0)
+    rs = np.random.RandomState(0)
+    outcomes = (rs.random_sample(50) >= np.cos(0.3 * ts / 2) ** 2).astype(int)
+    recs = []
+    for c in (comm, ParticleShardGroup(seed=1234, transport="auto")):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            upd = qi.SMCUpdater(qi.SimplePrecessionModel(), 60000, qi.UniformDistribution([0, 1]), device_rng=True,
+                                seed=5, comm=c)
+            for k in range(50):
+                upd.update(int(outcomes[k]), ts[k:k + 1])
+        recs.append(np.array([upd.resample_count, upd.n_ess, upd.min_n_ess] + list(np.ravel(upd.normalization_record))
+                             + list(upd.est_mean())))
+        assert upd.resample_count > 5
+    np.testing.assert_array_equal(recs[0], recs[1])
+    # RB (d = 3: the moment sums ride along in the same all-reduce)
+    m = qi.RandomizedBenchmarkingModel()
+    prior = qi.PostselectedDistribution(qi.UniformDistribution([[0.8, 1], [0, 1], [0, 1]]), m)
+    recs = []
+    comm._epoch = 0                        # (the resample epoch keys the Philox streams: start both groups level)
+    for c in (comm, ParticleShardGroup(seed=1234, transport="auto")):
+        rs2 = np.random.RandomState(1)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            upd = qi.SMCUpdater(m, 50000, prior, device_rng=True, seed=9, comm=c)
+            for k in range(40):
+                ep = np.empty((1,), dtype=m.expparams_dtype)
+                ep['m'] = 1 + 5 * k
+                upd.update(int(rs2.random_sample() >= 1 - (0.3 * 0.95 ** (1 + 5 * k) + 0.5)), ep)
+        recs.append(np.concatenate([[upd.resample_count, upd.n_ess], np.ravel(upd.normalization_record), upd.est_mean(),
+                                    upd.est_covariance_mtx().ravel()]))
+    np.testing.assert_array_equal(recs[0], recs[1])
+    comm.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_rccl_transport_world1(tmp_path):
+    import torch.multiprocessing as mp
+    mp.spawn(_rccl_transport_world1, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
