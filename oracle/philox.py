@@ -208,8 +208,16 @@ def poissonised_counts(edges, n_out, seed, epoch, margin=5.0):
     return counts
 
 
+def bucket_cap(n_out):
+    """Outputs per work item (qsmc_kernels.hip: bucket_cap): largest power of two <= 8192 leaving >= 1024 items."""
+    cap = 2 * BUCKET_CHUNK
+    while cap > 512 and n_out // cap < 1024:
+        cap >>= 1
+    return cap
+
+
 def liu_west_philox_bucketed(w, x, valid_fn, a, h, seed, epoch, n_out, maxiter=1000, postselect=True,
-                             mean=None, cov=None, zero_cov_comp=1e-10, cdf=None, margin=5.0):
+                             mean=None, cov=None, zero_cov_comp=1e-10, cdf=None, margin=5.0, sort_items=None):
     """Oracle of the bucketed device-RNG resampler (k_bucket_counts / k_bucket_sample).  Outputs are
     ordered by ancestor CHUNK.  Stream layout (round 0, two outputs per Philox block):
       slot 0: the Poisson chunk counts, slots 3 / 4 their top-up / removal (poissonised_counts); slot 1:
@@ -237,6 +245,17 @@ def liu_west_philox_bucketed(w, x, valid_fn, a, h, seed, epoch, n_out, maxiter=1
     base = c_of_slot * BUCKET_CHUNK
     end = np.minimum(base + BUCKET_CHUNK, N)
     js = np.minimum(np.maximum(np.searchsorted(cdf, u, side='right'), base), end - 1)
+    if sort_items is None:
+        sort_items = d == 16
+    if sort_items:
+        # the d = 16 sampler (k_bucket_sample16) kicks the ancestors of a work item in ascending order: slot
+        # o_begin + k takes the k-th smallest ancestor of the item and the normals of that slot
+        cap = bucket_cap(n_out)
+        slot0 = np.concatenate([[0], np.cumsum(counts)])
+        for c in range(chunks):
+            for b in range(int(slot0[c]), int(slot0[c + 1]), cap):
+                e = min(b + cap, int(slot0[c + 1]))
+                js[b:e] = np.sort(js[b:e], kind='stable')
     z = np.stack([_pair_normal(ids * d + q, seed, epoch, 2) for q in range(d)])      # (d, n_out)
     out = (a * x[js] + (1 - a) * mean) + (S @ z).T
     ok = valid_fn(out) if postselect else np.ones(n_out, dtype=bool)

@@ -153,7 +153,7 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_resample_philox(
 // search (same semantics as k_resample_philox: redraw ancestor and kick).
 // =============================================================================================
 constexpr int BUCKET_CHUNK = SCAN_CHUNK;            // 4096 source particles per bucket
-constexpr int BUCKET_CAP = 2 * BUCKET_CHUNK;        // outputs per work item
+constexpr int BUCKET_CAP = 2 * BUCKET_CHUNK;        // outputs per work item, at most (the host picks `cap` <= this: bucket_cap())
 constexpr int BUCKET_MAX_CHUNKS = 8192;             // skewed edges (68 KB) + counters (32 KB) + guide (16 KB) of LDS
 constexpr int BUCKET_COUNT_BLOCKS = 256;            // one resident workgroup per CU
 constexpr int BUCKET_COUNT_THREADS = 1024;
@@ -382,7 +382,7 @@ __device__ unsigned int poisson_draw(bool active, double mu, uint32_t node, uint
 
 // single workgroup (1024 threads): slot_off[c] = exclusive scan of counts; item_off[c] = exclusive scan of
 // ceil(counts / BUCKET_CAP); slot_off[chunks] = n_out, item_off[chunks] = #work items.  counts: global or LDS.
-__device__ __forceinline__ void bucket_plan_block(const unsigned int *counts, int chunks,
+__device__ __forceinline__ void bucket_plan_block(const unsigned int *counts, int chunks, int cap,
                                                   long long *__restrict__ slot_off, int *__restrict__ item_off,
                                                   int *__restrict__ item_chunk) {
     __shared__ long long wtot_s[1024 / QSMC_WAVE];
@@ -393,7 +393,7 @@ __device__ __forceinline__ void bucket_plan_block(const unsigned int *counts, in
     int it = 0;
     for (int c = c0; c < c1; ++c) {
         s += counts[c];
-        it += (int)((counts[c] + BUCKET_CAP - 1) / BUCKET_CAP);
+        it += (int)((counts[c] + (unsigned)cap - 1u) / (unsigned)cap);
     }
     // exclusive scan of the 1024 per-thread totals (integers: exact): shuffles inside a wave, 16 wave totals in LDS
     const int lane = threadIdx.x & (QSMC_WAVE - 1), wave = threadIdx.x / QSMC_WAVE;
@@ -422,7 +422,7 @@ __device__ __forceinline__ void bucket_plan_block(const unsigned int *counts, in
     for (int c = c0; c < c1; ++c) {
         slot_off[c] = so;
         item_off[c] = io;
-        const int items = (int)((counts[c] + BUCKET_CAP - 1) / BUCKET_CAP);
+        const int items = (int)((counts[c] + (unsigned)cap - 1u) / (unsigned)cap);
         for (int k = 0; k < items; ++k) item_chunk[io + k] = c;     // work item -> chunk map
         so += counts[c];
         io += items;
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(BUCKET_COUNTS_THREADS) void k_bucket_counts(
     double *offsets, TileSrc ts, unsigned long long *__restrict__ zero2, int chunks, int64_t n_out, double lambda,
     uint32_t k0, uint32_t k1, uint32_t epoch, unsigned int *counts, unsigned int *extra,
     long long *__restrict__ slot_off, int *__restrict__ item_off, int *__restrict__ item_chunk,
-    unsigned long long *bar, unsigned long long bar_base) {
+    unsigned long long *bar, unsigned long long bar_base, int cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double *edges = reinterpret_cast<double *>(smem);
     unsigned int *hist = reinterpret_cast<unsigned int *>(edges + lds_skew(chunks) + 4);   // this workgroup's draws per chunk
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(BUCKET_COUNTS_THREADS) void k_bucket_counts(
         __syncthreads();
     }
     for (int c = threadIdx.x; c < chunks; c += BUCKET_COUNTS_THREADS) counts[c] = cnt[c];
-    bucket_plan_block(cnt, chunks, slot_off, item_off, item_chunk);
+    bucket_plan_block(cnt, chunks, cap, slot_off, item_off, item_chunk);
 }
 
 // counts[c] = sum_g hist[g][c].  A workgroup takes 64 chunks; its four waves each sum a quarter of the rows
@@ -621,11 +621,11 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_bucket_reduce(const unsigned int
     }
 }
 
-__global__ __launch_bounds__(1024) void k_bucket_plan(const unsigned int *__restrict__ counts, int chunks,
+__global__ __launch_bounds__(1024) void k_bucket_plan(const unsigned int *__restrict__ counts, int chunks, int cap,
                                                       long long *__restrict__ slot_off,
                                                       int *__restrict__ item_off,
                                                       int *__restrict__ item_chunk) {
-    bucket_plan_block(counts, chunks, slot_off, item_off, item_chunk);
+    bucket_plan_block(counts, chunks, cap, slot_off, item_off, item_chunk);
 }
 
 constexpr int BUCKET_RLIST_CAP = 1024;               // per-workgroup list of outputs that need a global redraw
@@ -717,7 +717,7 @@ __global__ __launch_bounds__(BT) void k_bucket_sample(
     const int *__restrict__ item_off, const int *__restrict__ item_chunk, LWArgs lw, uint32_t k0, uint32_t k1,
     uint32_t epoch, int maxiter, double *__restrict__ x_out, OutPlace pl,
     unsigned long long *__restrict__ n_failed, unsigned int *__restrict__ retry_list,
-    unsigned long long *__restrict__ retry_count) {
+    unsigned long long *__restrict__ retry_count, int cap) {
     constexpr int DM = D > 0 ? D : QSMC_MAX_D;
     const int d = D > 0 ? D : d_rt;
     __shared__ __attribute__((aligned(16))) double lcdf[BUCKET_CHUNK_LDS];
@@ -731,8 +731,8 @@ __global__ __launch_bounds__(BT) void k_bucket_sample(
     const int c = item_chunk[blockIdx.x];
     const int part = (int)blockIdx.x - item_off[c];
     const long long slot0 = slot_off[c], n_c = slot_off[c + 1] - slot0;
-    const long long t0 = (long long)part * BUCKET_CAP;
-    const long long t1 = t0 + BUCKET_CAP < n_c ? t0 + BUCKET_CAP : n_c;
+    const long long t0 = (long long)part * cap;
+    const long long t1 = t0 + cap < n_c ? t0 + cap : n_c;
     const int64_t base = (int64_t)c * BUCKET_CHUNK;
     const int len = (int)((n_in - base) < BUCKET_CHUNK ? (n_in - base) : BUCKET_CHUNK);
     if (threadIdx.x == 0) rcount = 0;
@@ -864,6 +864,162 @@ __global__ __launch_bounds__(BT) void k_bucket_sample(
     if (threadIdx.x == 0) rbase = atomicAdd(retry_count, (unsigned long long)nl);   // one atomic per workgroup
     __syncthreads();
     for (int i = threadIdx.x; i < nl; i += BT) retry_list[rbase + i] = (unsigned int)(o_begin + rlist[i]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// d = 16 (2-qubit tomography) sampler on the matrix cores.  The generic kernel's d = 16 instantiation gave every lane
+// one output PAIR: 16 Box-Muller pairs and a 2 x 16 x 16 product per lane, 256 VGPRs, two waves per SIMD, 383 us at
+// N = 1.25e6 (0.11 of the HBM roofline).  Here a wave owns 16 outputs per trip and the 16 x 16 tile of their kicks
+// K = S Z is one v_mfma_f64_16x16x4 chain:
+//   lane l = (g = l >> 4, n = l & 15):  B operand of step s = Z[4 g + s][n], the (4 g + s)-th normal of output n --
+//     so lane (g, n) draws exactly the two Box-Muller pairs 2 g, 2 g + 1 of output n (blocks o * 8 + 2 g, + 1 of the
+//     same Philox stream as before: the normals are the very same numbers);
+//   A operand of step s = S[l & 15][4 g + s] (four values per lane, loaded once);
+//   D: value r of lane l = K[g + 4 r][n]: each lane ends up with 4 of the 16 coordinates of output n, adds the
+//     Liu-West centre of those coordinates (4 gathers) and stores them.
+// Position draw and LDS search are done by every lane for its output n (the four lanes of a column agree).
+// Only the order in which S z is summed differs from the generic kernel (k = 4 g + s: g inside an MFMA, s across).
+// Tomography has no validity constraint (tomography/models.py:143-147), so there is no retry queue here.
+// ---------------------------------------------------------------------------------------------
+// Gathers: an output needs all 16 coordinates of its ancestor, and in the SoA cloud those sit in 16 rows 8 N bytes
+// apart -- 16 cache lines per output, 256 per wave trip when the ancestors of neighbouring outputs are unrelated
+// (2.6 GB of line traffic for 160 MB of payload at N = 1.25e6: that, not arithmetic, is what held both d = 16
+// kernels at ~370 us).  Outputs are exchangeable, so a work item first HISTOGRAMS its ancestors (one LDS atomic per
+// output, after the same position draw and search as before), scans the 4096 counts and expands them into the
+// ancestor list in ascending order; trip t then kicks list entries 16 t .. 16 t + 15, whose ancestors are neighbours
+// (about one line per row and trip).  Slot o_begin + k takes the k-th smallest ancestor and the normals of slot
+// o_begin + k: the same law (the normals are independent of the ancestors), and what oracle/philox.py does too.
+typedef double v4d_s __attribute__((ext_vector_type(4)));
+constexpr int S16_HEAVY = 24, S16_HEAVY_CAP = BUCKET_CAP / S16_HEAVY + 8;
+template <int BT>
+__global__ __launch_bounds__(BT) void k_bucket_sample16(
+    const double *__restrict__ x_in, int64_t ldx_in, int64_t n_in, const double *__restrict__ w, double inv_norm,
+    const double *__restrict__ offsets, int chunks, const long long *__restrict__ slot_off,
+    const int *__restrict__ item_off, const int *__restrict__ item_chunk, LWArgs lw, uint32_t k0, uint32_t k1,
+    uint32_t epoch, double *__restrict__ x_out, OutPlace pl, int cap) {
+    constexpr int DM = 16;
+    __shared__ __attribute__((aligned(16))) double lcdf[BUCKET_CHUNK_LDS];
+    __shared__ unsigned short lguide[SGUIDE_BINS + 2];
+    __shared__ double wave_tot[SCAN_WAVES];
+    __shared__ int iwave_tot[SCAN_WAVES];
+    __shared__ double sS[DM * DM + DM];                             // S (row-major) and the mean
+    __shared__ unsigned int cnt[BUCKET_CHUNK];                      // children per source particle
+    __shared__ unsigned short sorted[BUCKET_CAP];                   // ancestors of the item's outputs, ascending
+    __shared__ unsigned int heavy[2 * S16_HEAVY_CAP];
+    __shared__ int hcount;
+    static_assert(BT == SCAN_THREADS, "one lane owns 8 consecutive source particles");
+    if ((int)blockIdx.x >= item_off[chunks]) return;
+    const int c = item_chunk[blockIdx.x];
+    const int part = (int)blockIdx.x - item_off[c];
+    const long long slot0 = slot_off[c], n_c = slot_off[c + 1] - slot0;
+    const long long t0 = (long long)part * cap;
+    const long long t1 = t0 + cap < n_c ? t0 + cap : n_c;
+    const int64_t base = (int64_t)c * BUCKET_CHUNK;
+    const int len = (int)((n_in - base) < BUCKET_CHUNK ? (n_in - base) : BUCKET_CHUNK);
+    const double lo_edge = chunk_edge(offsets, c);
+    const double hi_edge = offsets[c + 1];
+    const double gscale = (double)SGUIDE_BINS / (hi_edge - lo_edge);
+    const bool use_guide = hi_edge > lo_edge && gscale < 1e300;     // workgroup-uniform
+    for (int k = threadIdx.x; k < DM * DM; k += BT) sS[k] = lw.S[k];
+    if (threadIdx.x < DM) sS[DM * DM + threadIdx.x] = lw.mean[threadIdx.x];
+    for (int k = threadIdx.x; k < BUCKET_CHUNK; k += BT) cnt[k] = 0u;
+    if (threadIdx.x == 0) hcount = 0;
+    chunk_scan_block(w, n_in, inv_norm, offsets, (int64_t)c, wave_tot,
+                     StoreLdsGuide{lcdf, lguide, lo_edge, gscale, use_guide, len, -1});
+    __syncthreads();
+    const int64_t o_begin = slot0 + t0, o_end = slot0 + t1;
+    const int q = (int)(o_end - o_begin);
+    const int lane = threadIdx.x & (QSMC_WAVE - 1), wave = threadIdx.x / QSMC_WAVE;
+    // ---- 1: ancestors of all q outputs, histogrammed.  Position of slot o: word o & 1 of block (o >> 1, slot 1); a
+    // lane takes the pair (2 P, 2 P + 1) so the block is computed once (pairs straddling two items: each its half)
+    for (int64_t P = (o_begin >> 1) + threadIdx.x; 2 * P < o_end; P += BT) {
+        PhiloxStream rng{(uint64_t)P, (epoch << 16), k0, k1};
+        double upos[2];
+        rng.uniforms(1, upos[0], upos[1]);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int64_t o = 2 * P + e;
+            const double u = lo_edge + upos[e] * (hi_edge - lo_edge);
+            int j = use_guide ? guided_upper_bound(lcdf, len, lguide, guide_cell<SGUIDE_BINS>(u, lo_edge, gscale), u)
+                              : upper_bound_skew(lcdf, len, u);
+            j = j > len - 1 ? len - 1 : j;
+            if (o >= o_begin && o < o_end) atomicAdd(&cnt[j], 1u);
+        }
+    }
+    __syncthreads();
+    // ---- 2: exclusive scan of the counts (lane l owns particles 8 l .. 8 l + 7), ancestors expanded in ascending order
+    {
+        const int j0 = (int)threadIdx.x * 8;
+        unsigned int nj[8];
+        int lt = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            nj[k] = cnt[j0 + k];
+            lt += (int)nj[k];
+        }
+        int inc = lt;
+#pragma unroll
+        for (int off = 1; off < QSMC_WAVE; off <<= 1) {
+            const int t = __shfl_up(inc, off, QSMC_WAVE);
+            if (lane >= off) inc += t;
+        }
+        if (lane == QSMC_WAVE - 1) iwave_tot[wave] = inc;
+        __syncthreads();
+        int off0 = inc - lt;
+        for (int wv = 0; wv < wave; ++wv) off0 += iwave_tot[wv];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int nk = (int)nj[k];
+            if (nk > S16_HEAVY) {                                    // a dominant particle: the whole workgroup fills its run
+                const int h = atomicAdd(&hcount, 1);
+                heavy[2 * h] = (unsigned int)off0 | ((unsigned int)(j0 + k) << 16);
+                heavy[2 * h + 1] = (unsigned int)nk;
+            } else {
+                for (int r = 0; r < nk; ++r) sorted[off0 + r] = (unsigned short)(j0 + k);
+            }
+            off0 += nk;
+        }
+        __syncthreads();
+        const int nh = hcount;
+        for (int h = 0; h < nh; ++h) {
+            const unsigned int st = heavy[2 * h] & 0xffffu, jj = heavy[2 * h] >> 16, cn = heavy[2 * h + 1];
+            for (unsigned int r = threadIdx.x; r < cn; r += BT) sorted[st + r] = (unsigned short)jj;
+        }
+        __syncthreads();
+    }
+    // ---- 3: the kicks, 16 consecutive list entries per wave trip
+    const int n = lane & 15, g = lane >> 4;
+    double aS[4], mu4[4];
+#pragma unroll
+    for (int sidx = 0; sidx < 4; ++sidx) aS[sidx] = sS[(lane & 15) * DM + 4 * g + sidx];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mu4[r] = (1.0 - lw.a) * sS[DM * DM + g + 4 * r];
+    constexpr int PER_TRIP = (BT / QSMC_WAVE) * 16;                  // outputs per workgroup trip
+    for (int kb = wave * 16; kb < q; kb += PER_TRIP) {
+        const int k = kb + n;
+        const bool live = k < q;
+        const int kc = live ? k : q - 1;                            // (idle columns shadow the last one: no divergence)
+        const int64_t oc = o_begin + kc;
+        const int j = (int)sorted[kc];
+        double xa[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xa[r] = x_in[(int64_t)(g + 4 * r) * ldx_in + base + j];
+        // the four normals 4 g .. 4 g + 3 of slot oc: pairs 2 g and 2 g + 1 (blocks oc * 8 + 2 g, + 1; slot 2)
+        double z[4];
+        PhiloxStream nrm{(uint64_t)oc * 8u + (uint64_t)(2 * g), (epoch << 16), k0, k1};
+        nrm.normals(2, z[0], z[1]);
+        nrm.particle += 1;
+        nrm.normals(2, z[2], z[3]);
+        v4d_s acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aS[sidx], z[sidx], acc, 0, 0, 0);
+        if (live) {
+            const int64_t row = place_row(pl, oc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                x_out[(int64_t)(g + 4 * r) * pl.ld_m + row * pl.ld_s] = (lw.a * xa[r] + mu4[r]) + acc[r];
+        }
+    }
 }
 
 // Second chance for the queued outputs: redraw ancestor and kick from the global CDF (rounds 1..).  One launch,

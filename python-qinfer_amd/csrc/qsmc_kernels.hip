@@ -951,11 +951,21 @@ static int read_counter(qsmc_ctx *h, int64_t *out, hipStream_t s) {
 //   retry_list[n_out] u32
 struct BucketPlan {
     bool bucketed;
-    int chunks, max_items;
+    int chunks, max_items, cap;
     unsigned int *hist, *counts, *retry_list;
     long long *slot_off;
     int *item_off, *item_chunk;
 };
+
+// Outputs per work item.  A work item re-scans its chunk's weights, so big items amortise that -- but the grid must fill
+// the chip: 768 workgroups are resident at once (256 CUs x 3), and a cloud of 1.25e6 particles (the per-GPU share of
+// config 5) has only 306 chunks, i.e. 1.2 workgroups per CU at 8192 outputs each: the d = 16 sampler ran at a third
+// of a wave's worth of latency hiding (383 us).  Largest power of two <= 8192 that still leaves >= 1024 items.
+static int bucket_cap(int64_t n_out) {
+    int cap = BUCKET_CAP;
+    while (cap > 512 && n_out / cap < 1024) cap >>= 1;
+    return cap;
+}
 
 static bool use_buckets(int64_t chunks64, int64_t n_out) {
     static const bool forced_direct = getenv("QSMC_DIRECT_RESAMPLE") != nullptr;     // (test / measurement switch)
@@ -970,7 +980,8 @@ static int bucket_plan_layout(qsmc_ctx *h, int64_t chunks64, int64_t n_out, Buck
     const size_t counts_b = ((size_t)chunks * sizeof(unsigned int) + 15) & ~(size_t)15;
     const size_t slot_b = ((size_t)(chunks + 1) * sizeof(long long) + 15) & ~(size_t)15;
     const size_t item_b = ((size_t)(chunks + 1) * sizeof(int) + 15) & ~(size_t)15;
-    const int max_items = chunks + (int)(n_out / BUCKET_CAP) + 1;
+    const int cap = bucket_cap(n_out);
+    const int max_items = chunks + (int)(n_out / cap) + 1;
     const size_t map_b = ((size_t)max_items * sizeof(int) + 15) & ~(size_t)15;
     const size_t retry_b = (size_t)n_out * sizeof(unsigned int);
     const int rc = ensure_iscratch(h, hist_b + counts_b + slot_b + item_b + map_b + retry_b);
@@ -978,6 +989,7 @@ static int bucket_plan_layout(qsmc_ctx *h, int64_t chunks64, int64_t n_out, Buck
     unsigned char *basep = reinterpret_cast<unsigned char *>(h->iscratch);
     bp->chunks = chunks;
     bp->max_items = max_items;
+    bp->cap = cap;
     bp->hist = reinterpret_cast<unsigned int *>(basep);
     bp->counts = reinterpret_cast<unsigned int *>(basep + hist_b);
     bp->slot_off = reinterpret_cast<long long *>(basep + hist_b + counts_b);
@@ -1046,7 +1058,7 @@ static int resample_prefix(qsmc_ctx *h, const double *w, int64_t n_in, double no
                                chunks, n_out, k0, k1, ep, bp.hist);
             hipLaunchKernelGGL(k_bucket_reduce, dim3((chunks + QSMC_WAVE - 1) / QSMC_WAVE), dim3(QSMC_BLOCK), 0, s,
                                bp.hist, BUCKET_COUNT_BLOCKS, chunks, bp.counts);
-            hipLaunchKernelGGL(k_bucket_plan, dim3(1), dim3(1024), 0, s, bp.counts, chunks, bp.slot_off, bp.item_off,
+            hipLaunchKernelGGL(k_bucket_plan, dim3(1), dim3(1024), 0, s, bp.counts, chunks, bp.cap, bp.slot_off, bp.item_off,
                                bp.item_chunk);
         } else {
             const char *margin_env = getenv("QSMC_POISSON_MARGIN");          // (test switch: 0 makes the removal branch common)
@@ -1069,7 +1081,7 @@ static int resample_prefix(qsmc_ctx *h, const double *w, int64_t n_in, double no
             hipExtLaunchKernelGGL(k_bucket_counts, dim3(BUCKET_COUNTS_BLOCKS), dim3(BUCKET_COUNTS_THREADS), lds, s, q0, q1, 0, offsets,
                                scan_in_counts ? ts : TileSrc{nullptr, 0, 0, 0.0},
                                reinterpret_cast<unsigned long long *>(h->counter), chunks, n_out, lambda, k0, k1, ep,
-                               bp.counts, extra, bp.slot_off, bp.item_off, bp.item_chunk, h->gbar, h->gbar_base);
+                               bp.counts, extra, bp.slot_off, bp.item_off, bp.item_chunk, h->gbar, h->gbar_base, bp.cap);
             h->gbar_base += 2ull * BUCKET_COUNTS_BLOCKS;
         }
     }
@@ -1126,7 +1138,14 @@ static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int3
     hipExtLaunchKernelGGL((k_bucket_sample<DD, BT>), dim3(bp.max_items), dim3(BT), 0, s, pe0, pe1, 0, model->kind, d, \
                        model->min_freq, postselect, x_in, ldx_in, n_in, w, inv_norm, offsets,                       \
                        chunks, bp.slot_off, bp.item_off, bp.item_chunk, lw, k0, k1, ep,                             \
-                       maxiter, x_out, pl, nf, bp.retry_list, retry_count)
+                       maxiter, x_out, pl, nf, bp.retry_list, retry_count, bp.cap)
+        static const bool no_mfma16 = getenv("QSMC_NO_MFMA_SAMPLER") != nullptr;       // (A/B switch for measurements)
+        if (d == 16 && model->kind == QSMC_MODEL_TOMOGRAPHY && !no_mfma16) {
+            // 2-qubit tomography: the kick matrix product on the f64 matrix cores, 16 outputs per wave trip
+            hipExtLaunchKernelGGL((k_bucket_sample16<512>), dim3(bp.max_items), dim3(512), 0, s, pe0, pe1, 0, x_in, ldx_in,
+                                  n_in, w, inv_norm, offsets, chunks, bp.slot_off, bp.item_off, bp.item_chunk, lw, k0, k1,
+                                  ep, x_out, pl, bp.cap);
+        } else
         switch (d) {
             case 1: LAUNCH_B(1, 512); break;
             case 2: LAUNCH_B(2, 512); break;
