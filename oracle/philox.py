@@ -246,10 +246,11 @@ def liu_west_philox_bucketed(w, x, valid_fn, a, h, seed, epoch, n_out, maxiter=1
     end = np.minimum(base + BUCKET_CHUNK, N)
     js = np.minimum(np.maximum(np.searchsorted(cdf, u, side='right'), base), end - 1)
     if sort_items is None:
-        sort_items = d == 16
+        sort_items = d >= 3
     if sort_items:
-        # the d = 16 sampler (k_bucket_sample16) kicks the ancestors of a work item in ascending order: slot
-        # o_begin + k takes the k-th smallest ancestor of the item and the normals of that slot
+        # from d = 3 on the samplers (k_bucket_sample_ordered, k_bucket_sample16) kick the ancestors of a work item in
+        # ascending order (neighbouring lanes then gather neighbouring particles): slot o_begin + k takes the k-th
+        # smallest ancestor of the item and the normals of that slot -- the same law, the cloud being exchangeable
         cap = bucket_cap(n_out)
         slot0 = np.concatenate([[0], np.cumsum(counts)])
         for c in range(chunks):

@@ -702,9 +702,12 @@ struct StoreLdsGuide {
     }
 };
 
-// One workgroup per work item.  The chunk's CDF is SCANNED HERE from the weights (bit-identical
-// to k_chunk_scan), so the CDF never touches HBM; a particle that fails postselection on its first
-// try is queued for k_bucket_retry, which alone needs the (then materialised) global CDF.
+// The single-pass sampler (d <= 2).  One workgroup per work item.  The chunk's CDF is SCANNED HERE from the weights
+// (bit-identical to k_chunk_scan), so the CDF never touches HBM; every output pair draws its positions, searches, gathers
+// and is kicked in one loop iteration; a particle that fails postselection on its first try is queued for
+// k_bucket_redraw, which alone needs the (then materialised) global CDF.  With one or two coordinates per particle the
+// gather is cheap and the search's LDS round trips hide under the kick's arithmetic of the same iteration; from d = 3 on
+// the ordered kernel below wins (measured at N = 1e7, d = 1: 89 us here, 104 us ordered; d = 3, N = 1.25e7: 315 vs 259).
 // Occupancy: 44 KB of LDS allows three workgroups per CU; the small-d instantiations are held to 80
 // VGPRs (6 waves/SIMD) so that the third one fits -- the kernel is VALU-issue bound and the extra
 // waves hide the LDS search and gather latency (121 -> 110 us at N = 1e7, d = 1).
@@ -856,6 +859,191 @@ __global__ __launch_bounds__(BT) void k_bucket_sample(
         Anc an;
         stage_a(P, an);
         stage_b(P, an);
+    }
+    if (failed) atomicAdd(n_failed, failed);
+    __syncthreads();
+    const int nl = rcount < BUCKET_RLIST_CAP ? rcount : BUCKET_RLIST_CAP;
+    if (nl == 0) return;
+    if (threadIdx.x == 0) rbase = atomicAdd(retry_count, (unsigned long long)nl);   // one atomic per workgroup
+    __syncthreads();
+    for (int i = threadIdx.x; i < nl; i += BT) retry_list[rbase + i] = (unsigned int)(o_begin + rlist[i]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The ordered sampler (d >= 3).  One workgroup per work item = (chunk c, <= cap of its output slots), three phases:
+//   1  ANCESTORS.  The chunk's CDF is scanned here from the weights into LDS (bit-identical to k_chunk_scan, so the CDF
+//      never touches HBM) together with its guide table; every output slot draws its position inside the chunk (given
+//      the counts, positions are i.i.d. uniform on the chunk's mass: exact), finds its ancestor by the guided LDS
+//      search and adds one to that particle's counter (two 16-bit counters per LDS word).
+//   2  ORDER.  An integer scan of the 4096 counters; each particle writes its index as many times as it was drawn:
+//      the item's ancestors in ASCENDING order (the list overlays the CDF, which is no longer needed).  Outputs are
+//      exchangeable, so slot o_begin + k may take the k-th smallest ancestor -- and then neighbouring lanes gather
+//      neighbouring particles: the gather of x was 64 distinct cache lines per wave instruction per coordinate when
+//      the ancestors came in drawing order, now it is a handful.
+//   3  KICK.  Slots in pairs (2 P, 2 P + 1) sharing the Box-Muller pairs of Philox blocks P d + m (slot 2), Liu-West
+//      combine, validity, store; a particle that fails postselection is queued for k_bucket_redraw, which alone needs
+//      the (then materialised) global CDF.  The loop has no search and no dependent LDS chain in it any more.
+// A pair straddling two work items is evaluated by both, each writing only its own half.
+// Occupancy: ~50 KB of LDS, 80 - 90 VGPRs at d = 3, 4: two to three workgroups per CU.
+// ---------------------------------------------------------------------------------------------
+constexpr int SMP_HEAVY = 24, SMP_HEAVY_CAP = BUCKET_CAP / SMP_HEAVY + 8;
+
+template <int D, int BT>   // D = 0: runtime d; BT = threads per workgroup.  (Held to 80 VGPRs for a third workgroup per
+                           // CU, d = 3 spills 14 registers and is slower: 277 vs 259 us.)
+__global__ __launch_bounds__(BT) void k_bucket_sample_ordered(
+    int kind, int d_rt, double min_freq, int postselect, const double *__restrict__ x_in, int64_t ldx_in,
+    int64_t n_in, const double *__restrict__ w, double inv_norm, const double *__restrict__ offsets,
+    int chunks, const long long *__restrict__ slot_off,
+    const int *__restrict__ item_off, const int *__restrict__ item_chunk, LWArgs lw, uint32_t k0, uint32_t k1,
+    uint32_t epoch, int maxiter, double *__restrict__ x_out, OutPlace pl,
+    unsigned long long *__restrict__ n_failed, unsigned int *__restrict__ retry_list,
+    unsigned long long *__restrict__ retry_count, int cap) {
+    constexpr int DM = D > 0 ? D : QSMC_MAX_D;
+    const int d = D > 0 ? D : d_rt;
+    __shared__ __attribute__((aligned(16))) double lcdf[BUCKET_CHUNK_LDS];
+    __shared__ unsigned short lguide[SGUIDE_BINS + 2];
+    __shared__ unsigned int cnt2[BUCKET_CHUNK / 2];             // children per source particle, two counters a word
+    __shared__ double wave_tot[SCAN_WAVES];
+    __shared__ int iwave_tot[SCAN_WAVES];
+    __shared__ unsigned int heavy[2 * SMP_HEAVY_CAP];
+    __shared__ unsigned short rlist[BUCKET_RLIST_CAP];          // slot - o_begin < cap
+    static_assert(BT == SCAN_THREADS, "one lane owns 8 consecutive source particles: 512 threads per chunk");
+    static_assert(BUCKET_CAP * 2 <= BUCKET_CHUNK_LDS * 8, "the ancestor list overlays the CDF");
+    __shared__ int rcount, hcount;
+    __shared__ unsigned long long rbase;
+    if ((int)blockIdx.x >= item_off[chunks]) return;
+    const int c = item_chunk[blockIdx.x];
+    const int part = (int)blockIdx.x - item_off[c];
+    const long long slot0 = slot_off[c], n_c = slot_off[c + 1] - slot0;
+    const long long t0 = (long long)part * cap;
+    const long long t1 = t0 + cap < n_c ? t0 + cap : n_c;
+    const int64_t base = (int64_t)c * BUCKET_CHUNK;
+    const int len = (int)((n_in - base) < BUCKET_CHUNK ? (n_in - base) : BUCKET_CHUNK);
+    if (threadIdx.x == 0) { rcount = 0; hcount = 0; }
+    for (int k = threadIdx.x; k < BUCKET_CHUNK / 2; k += BT) cnt2[k] = 0u;
+    const double lo_edge = chunk_edge(offsets, c);
+    const double hi_edge = offsets[c + 1];
+    const double gscale = (double)SGUIDE_BINS / (hi_edge - lo_edge);
+    const bool use_guide = hi_edge > lo_edge && gscale < 1e300;     // workgroup-uniform
+    chunk_scan_block(w, n_in, inv_norm, offsets, (int64_t)c, wave_tot,
+                     StoreLdsGuide{lcdf, lguide, lo_edge, gscale, use_guide, len, -1});
+    __syncthreads();
+    const int64_t o_begin = slot0 + t0, o_end = slot0 + t1;         // this item's output slots
+    const int lane = threadIdx.x & (QSMC_WAVE - 1), wave = threadIdx.x / QSMC_WAVE;
+    // ---- 1: ancestors, histogrammed.  Position of slot o: word o & 1 of Philox block (o >> 1, round 0, slot 1)
+    for (int64_t P = (o_begin >> 1) + threadIdx.x; 2 * P < o_end; P += BT) {
+        PhiloxStream rng{(uint64_t)P, (epoch << 16), k0, k1};
+        double upos[2];
+        rng.uniforms(1, upos[0], upos[1]);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int64_t o = 2 * P + e;
+            const double u = lo_edge + upos[e] * (hi_edge - lo_edge);
+            int j = use_guide ? guided_upper_bound(lcdf, len, lguide, guide_cell<SGUIDE_BINS>(u, lo_edge, gscale), u)
+                              : upper_bound_skew(lcdf, len, u);
+            j = j > len - 1 ? len - 1 : j;
+            if (o >= o_begin && o < o_end) atomicAdd(&cnt2[j >> 1], 1u << (16 * (j & 1)));
+        }
+    }
+    __syncthreads();
+    // ---- 2: the ancestors in ascending order (lane l owns particles 8 l .. 8 l + 7; the list overlays the CDF)
+    unsigned short *sorted = reinterpret_cast<unsigned short *>(lcdf);
+    {
+        const int j0 = (int)threadIdx.x * 8;
+        int nj[8], lt = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k += 2) {
+            const unsigned int two = cnt2[(j0 + k) >> 1];
+            nj[k] = (int)(two & 0xffffu);
+            nj[k + 1] = (int)(two >> 16);
+            lt += nj[k] + nj[k + 1];
+        }
+        int inc = lt;
+#pragma unroll
+        for (int off = 1; off < QSMC_WAVE; off <<= 1) {
+            const int t = __shfl_up(inc, off, QSMC_WAVE);
+            if (lane >= off) inc += t;
+        }
+        if (lane == QSMC_WAVE - 1) iwave_tot[wave] = inc;
+        __syncthreads();                                            // (also: every CDF read of phase 1 is done)
+        int off0 = inc - lt;
+        for (int wv = 0; wv < wave; ++wv) off0 += iwave_tot[wv];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int nk = nj[k];
+            if (nk > SMP_HEAVY) {                                    // a dominant particle: the whole workgroup fills its run
+                const int h = atomicAdd(&hcount, 1);
+                heavy[2 * h] = (unsigned int)off0 | ((unsigned int)(j0 + k) << 16);
+                heavy[2 * h + 1] = (unsigned int)nk;
+            } else {
+                for (int r = 0; r < nk; ++r) sorted[off0 + r] = (unsigned short)(j0 + k);
+            }
+            off0 += nk;
+        }
+        __syncthreads();
+        const int nh = hcount;
+        for (int h = 0; h < nh; ++h) {
+            const unsigned int st = heavy[2 * h] & 0xffffu, jj = heavy[2 * h] >> 16, cn = heavy[2 * h + 1];
+            for (unsigned int r = threadIdx.x; r < cn; r += BT) sorted[st + r] = (unsigned short)jj;
+        }
+        __syncthreads();
+    }
+    // ---- 3: the kicks
+    unsigned long long failed = 0;
+    constexpr bool EARLY = DM <= 4;
+    for (int64_t P = (o_begin >> 1) + threadIdx.x; 2 * P < o_end; P += BT) {
+        int jl[2];
+        double xg[2][EARLY ? DM : 1];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int64_t o = 2 * P + e;
+            jl[e] = (o >= o_begin && o < o_end) ? (int)sorted[o - o_begin] : 0;
+            if (EARLY) {                                            // (in flight during the normals' arithmetic)
+#pragma unroll
+                for (int m = 0; m < DM; ++m)
+                    if (m < d) xg[e][m] = x_in[m * ldx_in + base + jl[e]];
+            }
+        }
+        double z[2 * DM];
+        PhiloxStream nrm{0, (epoch << 16), k0, k1};
+#pragma unroll
+        for (int k = 0; k < DM; ++k) {
+            if (k < d) {
+                nrm.particle = (uint64_t)P * (uint64_t)d + (uint64_t)k;
+                nrm.normals(2, z[2 * k], z[2 * k + 1]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int64_t o = 2 * P + e;
+            if (o >= o_begin && o < o_end) {
+                double p[DM];
+#pragma unroll
+                for (int m = 0; m < DM; ++m) {
+                    if (m < d) {
+                        double sm = 0.0;
+#pragma unroll
+                        for (int q = 0; q < DM; ++q)
+                            if (q < d) sm += lw.S[m * d + q] * z[e * d + q];
+                        const double xa = EARLY ? xg[e][m] : x_in[m * ldx_in + base + jl[e]];
+                        p[m] = (lw.a * xa + (1.0 - lw.a) * lw.mean[m]) + sm;
+                    }
+                }
+                bool ok = !postselect || model_valid(kind, p, min_freq);
+                if (!ok && maxiter > 1) {
+                    // queue for k_bucket_redraw (needs the global CDF)
+                    const int idx = atomicAdd(&rcount, 1);
+                    if (idx < BUCKET_RLIST_CAP) rlist[idx] = (unsigned short)(o - o_begin);
+                    else retry_list[atomicAdd(retry_count, 1ull)] = (unsigned int)o;   // rare overflow path
+                    ok = true;                      // decided later
+                }
+                const int64_t row = place_row(pl, o);
+#pragma unroll
+                for (int m = 0; m < DM; ++m)
+                    if (m < d) x_out[m * pl.ld_m + row * pl.ld_s] = p[m];
+                if (!ok) ++failed;
+            }
+        }
     }
     if (failed) atomicAdd(n_failed, failed);
     __syncthreads();

@@ -1134,8 +1134,8 @@ static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int3
         // 32 KB global window (L2-resident).
         hipEvent_t pe0 = nullptr, pe1 = nullptr;
         prof_events(h, QSMC_PROF_SAMPLE, &pe0, &pe1);
-#define LAUNCH_B(DD, BT)                                                                                       \
-    hipExtLaunchKernelGGL((k_bucket_sample<DD, BT>), dim3(bp.max_items), dim3(BT), 0, s, pe0, pe1, 0, model->kind, d, \
+#define LAUNCH_B(KERNEL, DD, BT)                                                                               \
+    hipExtLaunchKernelGGL((KERNEL<DD, BT>), dim3(bp.max_items), dim3(BT), 0, s, pe0, pe1, 0, model->kind, d, \
                        model->min_freq, postselect, x_in, ldx_in, n_in, w, inv_norm, offsets,                       \
                        chunks, bp.slot_off, bp.item_off, bp.item_chunk, lw, k0, k1, ep,                             \
                        maxiter, x_out, pl, nf, bp.retry_list, retry_count, bp.cap)
@@ -1147,12 +1147,12 @@ static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int3
                                   ep, x_out, pl, bp.cap);
         } else
         switch (d) {
-            case 1: LAUNCH_B(1, 512); break;
-            case 2: LAUNCH_B(2, 512); break;
-            case 3: LAUNCH_B(3, 512); break;
-            case 4: LAUNCH_B(4, 512); break;
-            case 16: LAUNCH_B(16, 512); break;         // 2-qubit tomography: all indices static
-            default: LAUNCH_B(0, 512); break;          // other d up to 16: runtime-d kernel
+            // d <= 2: the single-pass kernel; d >= 3: ancestors first, kicked in ascending order (coalesced gathers)
+            case 1: LAUNCH_B(k_bucket_sample, 1, 512); break;
+            case 2: LAUNCH_B(k_bucket_sample, 2, 512); break;
+            case 3: LAUNCH_B(k_bucket_sample_ordered, 3, 512); break;
+            case 4: LAUNCH_B(k_bucket_sample_ordered, 4, 512); break;
+            default: LAUNCH_B(k_bucket_sample_ordered, 0, 512); break;          // other d up to 16: runtime-d kernel
         }
 #undef LAUNCH_B
         if (postselect && maxiter > 1) {
