@@ -363,6 +363,15 @@ int qsmc_random_walk(qsmc_handle_t h, double *x, int64_t ldx, int64_t n, int32_t
 int qsmc_tomo_canonicalize(qsmc_handle_t h, const double *basis, int32_t dim,
                            double *x, int64_t ldx, int64_t n, int32_t allow_subnormalized,
                            qsmc_stream_t stream);
+/* The same with the basis NAMED: basis_kind = QSMC_BASIS_PAULI says `basis` is the reference's n-qubit Pauli basis
+ * (pauli_basis(nq), tomography/bases.py:137-154: tensor products of (I, X, Y, Z) / sqrt 2, first qubit slowest);
+ * for dim = 4 the library then contracts with the basis' four non-zero entries per element instead of the dense
+ * (16, 4, 4) tensor (`basis` may be NULL).  QSMC_BASIS_DENSE: any orthonormal Hermitian basis, as above. */
+#define QSMC_BASIS_DENSE 0
+#define QSMC_BASIS_PAULI 1
+int qsmc_tomo_canonicalize2(qsmc_handle_t h, const double *basis, int32_t dim, int32_t basis_kind,
+                            double *x, int64_t ldx, int64_t n, int32_t allow_subnormalized,
+                            qsmc_stream_t stream);
 
 #ifdef __cplusplus
 }

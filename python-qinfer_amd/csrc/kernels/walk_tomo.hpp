@@ -43,9 +43,8 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_random_walk(double *__restrict__
 // =============================================================================================
 // tomography canonicalize: per-particle dim x dim complex Hermitian Jacobi, clamp, re-expand
 // =============================================================================================
-template <int DIM>
-__global__ __launch_bounds__(QSMC_BLOCK) void k_tomo_canon(const double *__restrict__ basis,
-                                                           double *__restrict__ x, int64_t ldx, int64_t n,
+template <int DIM, class Basis>
+__global__ __launch_bounds__(QSMC_BLOCK) void k_tomo_canon(Basis B, double *__restrict__ x, int64_t ldx, int64_t n,
                                                            int allow_subnormalized) {
     constexpr int D = DIM * DIM;
     for (int64_t i = (int64_t)blockIdx.x * QSMC_BLOCK + threadIdx.x; i < n;
@@ -53,7 +52,7 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_tomo_canon(const double *__restr
         double p[D];
 #pragma unroll
         for (int a = 0; a < D; ++a) p[a] = x[a * ldx + i];
-        if (tomo_canon_particle<DIM>(basis, p, allow_subnormalized != 0)) {
+        if (tomo_canon_particle<DIM>(B, p, allow_subnormalized != 0)) {
 #pragma unroll
             for (int a = 0; a < D; ++a) x[a * ldx + i] = p[a];
         }
@@ -66,13 +65,29 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_tomo_canon(const double *__restr
 // kernel would not help (a wave is as slow as its slowest lane), so pass 1 classifies with a pivot test
 // (tomo_clearly_positive), finishes the clear cases and compacts the others into an index list
 // (one atomic per wave); pass 2 runs the Jacobi path on the list only, densely packed.
-template <int DIM>
-__global__ __launch_bounds__(QSMC_BLOCK) void k_tomo_classify(const double *__restrict__ basis,
-                                                              double *__restrict__ x, int64_t ldx, int64_t n,
+// The hard particles' indices are collected in LDS (one LDS atomic per wave) and appended to the global list in
+// batches, one global atomic per flush: a returning atomic on ONE global word serialises at ~88 per microsecond on this
+// part, and one per wave (19531 of them at N = 1.25e6) was 220 of this kernel's 250 us.
+constexpr int CLASSIFY_BUF = 2048;
+template <int DIM, class Basis>
+__global__ __launch_bounds__(QSMC_BLOCK) void k_tomo_classify(Basis B, double *__restrict__ x, int64_t ldx, int64_t n,
                                                               int allow_subnormalized, unsigned int *__restrict__ list,
                                                               unsigned int *__restrict__ count) {
     constexpr int D = DIM * DIM;
+    __shared__ unsigned int buf[CLASSIFY_BUF + QSMC_BLOCK];
+    __shared__ unsigned int bcount, gbase;
     const int lane = threadIdx.x & (QSMC_WAVE - 1);
+    if (threadIdx.x == 0) bcount = 0u;
+    __syncthreads();
+    auto flush = [&]() {                                           // workgroup-uniform call
+        const unsigned int m = bcount;
+        if (threadIdx.x == 0) gbase = atomicAdd(count, m);
+        __syncthreads();
+        for (unsigned int t = threadIdx.x; t < m; t += QSMC_BLOCK) list[gbase + t] = buf[t];
+        __syncthreads();
+        if (threadIdx.x == 0) bcount = 0u;
+        __syncthreads();
+    };
     for (int64_t i0 = (int64_t)blockIdx.x * QSMC_BLOCK; i0 < n; i0 += (int64_t)gridDim.x * QSMC_BLOCK) {
         const int64_t i = i0 + threadIdx.x;
         bool hard = false;
@@ -80,11 +95,11 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_tomo_classify(const double *__re
             double p[D];
 #pragma unroll
             for (int a = 0; a < D; ++a) p[a] = x[a * ldx + i];
-            if (tomo_clearly_positive<DIM>(basis, p)) {
+            if (tomo_clearly_positive<DIM>(B, p)) {
                 if (!allow_subnormalized) {                   // tomography/models.py:194-209
-                    const double nrm = p[0] * sqrt((double)DIM);
+                    const double inv = 1.0 / (p[0] * sqrt((double)DIM));
 #pragma unroll
-                    for (int a = 0; a < D; ++a) x[a * ldx + i] = p[a] / nrm;
+                    for (int a = 0; a < D; ++a) x[a * ldx + i] = p[a] * inv;
                 }
             } else {
                 hard = true;
@@ -93,16 +108,18 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_tomo_classify(const double *__re
         const unsigned long long m = __ballot(hard);
         if (m) {
             unsigned int base = 0;
-            if (lane == 0) base = atomicAdd(count, (unsigned int)__popcll(m));
+            if (lane == 0) base = atomicAdd(&bcount, (unsigned int)__popcll(m));
             base = __shfl(base, 0, QSMC_WAVE);
-            if (hard) list[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned int)i;
+            if (hard) buf[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned int)i;
         }
+        __syncthreads();
+        if (bcount >= CLASSIFY_BUF) flush();                      // (uniform: bcount is read after the barrier)
     }
+    if (bcount) flush();
 }
 
-template <int DIM>
-__global__ __launch_bounds__(QSMC_BLOCK) void k_tomo_canon_list(const double *__restrict__ basis,
-                                                                double *__restrict__ x, int64_t ldx,
+template <int DIM, class Basis>
+__global__ __launch_bounds__(QSMC_BLOCK) void k_tomo_canon_list(Basis B, double *__restrict__ x, int64_t ldx,
                                                                 int allow_subnormalized,
                                                                 const unsigned int *__restrict__ list,
                                                                 const unsigned int *__restrict__ count) {
@@ -113,10 +130,9 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_tomo_canon_list(const double *__
         double p[D];
 #pragma unroll
         for (int a = 0; a < D; ++a) p[a] = x[a * ldx + i];
-        if (tomo_canon_particle<DIM>(basis, p, allow_subnormalized != 0)) {
+        if (tomo_canon_particle<DIM>(B, p, allow_subnormalized != 0)) {
 #pragma unroll
             for (int a = 0; a < D; ++a) x[a * ldx + i] = p[a];
         }
     }
 }
-

@@ -545,27 +545,39 @@ struct PhiloxStream {
 // ---------------------------------------------------------------------------------------------
 // Tomography canonicalize for ONE particle (tomography/models.py:149-209): rho = sum_a p_a B_a,
 // complex-Hermitian cyclic Jacobi, clamp negative eigenvalues, re-expand, renormalise trace.
-// Returns true if p[] was modified.  basis: (D, DIM, DIM) complex128 interleaved (re, im).
+// Three pieces, so that the basis-dependent contractions can be swapped for sparse ones:
+//   TomoDense<DIM>    rho <-> p through the dense (D, DIM, DIM) complex128 basis (interleaved re, im): any basis;
+//   TomoPauli2        the reference's 2-qubit Pauli basis (pauli_basis(2), bases.py:137-154: tensor products of
+//                     (I, X, Y, Z) / sqrt 2, first qubit slowest): every element has four non-zero entries, so rho and
+//                     the re-expansion are ~50 additions each instead of 2 x 512 multiply-adds and 1024 basis loads;
+//   jacobi_clamp      the eigendecomposition and the clamped reconstruction, basis-free.
+// The rotation's scalars (one |h|, three divisions and two square roots per pivot in the textbook form) use the
+// hardware reciprocal / reciprocal-square-root seeds with two Newton steps: a rotation that is off by an ulp is still
+// unitary to an ulp, and Jacobi corrects itself in the next sweep.
 // ---------------------------------------------------------------------------------------------
+#ifdef __HIP_DEVICE_COMPILE__
+__device__ __forceinline__ double j_rsqrt(double x) {             // x > 0, normal range
+    double r = __builtin_amdgcn_rsq(x);
+    const double h = 0.5 * x;
+    r = r * fma(-h * r, r, 1.5);
+    r = r * fma(-h * r, r, 1.5);
+    return r;
+}
+__device__ __forceinline__ double j_rcp(double x) {               // x != 0, normal range
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+#else
+__host__ __device__ inline double j_rsqrt(double x) { return 1.0 / sqrt(x); }
+__host__ __device__ inline double j_rcp(double x) { return 1.0 / x; }
+#endif
+
+// In: Hermitian A (full storage).  Out: any eigenvalue negative?  If so R = V max(lambda, 0) V^H (tomography/models.py:185-192).
 template <int DIM>
-__host__ __device__ inline bool tomo_canon_particle(const double *__restrict__ basis, double *p,
-                                                    bool allow_subnormalized) {
-    constexpr int D = DIM * DIM;
-    // rho = sum_a x_a B_a (Hermitian)
-    double Ar[DIM][DIM], Ai[DIM][DIM];
-#pragma unroll
-    for (int r = 0; r < DIM; ++r)
-#pragma unroll
-        for (int c = 0; c < DIM; ++c) {
-            double sr = 0.0, si = 0.0;
-            for (int a = 0; a < D; ++a) {
-                sr += p[a] * basis[2 * ((a * DIM + r) * DIM + c)];
-                si += p[a] * basis[2 * ((a * DIM + r) * DIM + c) + 1];
-            }
-            Ar[r][c] = sr;
-            Ai[r][c] = si;
-        }
-    // keep the original for reconstruction scale; V = I
+__host__ __device__ inline bool jacobi_clamp(double (&Ar)[DIM][DIM], double (&Ai)[DIM][DIM], double (&Rr)[DIM][DIM],
+                                             double (&Ri)[DIM][DIM]) {
     double Vr[DIM][DIM], Vi[DIM][DIM];
 #pragma unroll
     for (int r = 0; r < DIM; ++r)
@@ -589,18 +601,18 @@ __host__ __device__ inline bool tomo_canon_particle(const double *__restrict__ b
 #pragma unroll
             for (int q = pI + 1; q < DIM; ++q) {
                 const double hr = Ar[pI][q], hi = Ai[pI][q];
-                const double mag = sqrt(hr * hr + hi * hi);
-                if (mag < 1e-300) continue;
+                const double mag2 = hr * hr + hi * hi;
+                if (mag2 < 1e-290) continue;
                 // phase e^{i phi} = h / |h|
-                const double er = hr / mag, ei = hi / mag;
-                const double app = Ar[pI][pI], aqq = Ar[q][q];
-                const double tau = (aqq - app) / (2.0 * mag);
-                const double tt = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-                const double cs = 1.0 / sqrt(1.0 + tt * tt);
+                const double imag = j_rsqrt(mag2);
+                const double er = hr * imag, ei = hi * imag;
+                const double tau = (Ar[q][q] - Ar[pI][pI]) * (0.5 * imag);
+                const double t2 = 1.0 + tau * tau;
+                const double rt = t2 * j_rsqrt(t2);                 // sqrt(1 + tau^2)
+                const double tt = (tau >= 0.0 ? 1.0 : -1.0) * j_rcp(fabs(tau) + rt);
+                const double cs = j_rsqrt(1.0 + tt * tt);
                 const double sn = tt * cs;
-                // Rotation: columns p,q of A and V:  col_p' = c col_p - s e^{-i phi} col_q ... applied as
-                // A <- J^H A J with J = [[c, s e^{i phi}], [-s e^{-i phi}, c]] on (p, q)
-                // update columns
+                // A <- J^H A J with J = [[c, s e^{i phi}], [-s e^{-i phi}, c]] on (p, q): columns, then rows
 #pragma unroll
                 for (int r = 0; r < DIM; ++r) {
                     const double apr = Ar[r][pI], api = Ai[r][pI], aqr = Ar[r][q], aqi = Ai[r][q];
@@ -615,7 +627,7 @@ __host__ __device__ inline bool tomo_canon_particle(const double *__restrict__ b
                     Vr[r][q] = sn * (er * vpr - ei * vpi) + cs * vqr;
                     Vi[r][q] = sn * (er * vpi + ei * vpr) + cs * vqi;
                 }
-                // update rows: row_p' = c*row_p - s*e*row_q ; row_q' = s*conj(e)*row_p + c*row_q
+                // row_p' = c*row_p - s*e*row_q ; row_q' = s*conj(e)*row_p + c*row_q
 #pragma unroll
                 for (int c2 = 0; c2 < DIM; ++c2) {
                     const double apr = Ar[pI][c2], api = Ai[pI][c2], aqr = Ar[q][c2], aqi = Ai[q][c2];
@@ -633,11 +645,9 @@ __host__ __device__ inline bool tomo_canon_particle(const double *__restrict__ b
         lam[r] = Ar[r][r];
         any_neg |= !(lam[r] >= 0.0);
     }
-    if (any_neg) {                                        // tomography/models.py:185-192
+    if (any_neg) {
 #pragma unroll
         for (int r = 0; r < DIM; ++r) lam[r] = lam[r] < 0.0 ? 0.0 : lam[r];
-        // rho+ = V diag(lam) V^H ;  x_a = Re tr(B_a^H rho+) = Re sum_{rc} conj(B_a[r][c]) rho+[r][c]
-        double Rr[DIM][DIM], Ri[DIM][DIM];
 #pragma unroll
         for (int r = 0; r < DIM; ++r)
 #pragma unroll
@@ -652,21 +662,105 @@ __host__ __device__ inline bool tomo_canon_particle(const double *__restrict__ b
                 Rr[r][c] = sr;
                 Ri[r][c] = si;
             }
+    }
+    return any_neg;
+}
+
+template <int DIM>
+struct TomoDense {
+    const double *__restrict__ basis;
+    // rho = sum_a x_a B_a; `lower_only`: the classification needs one triangle
+    __host__ __device__ inline void build(const double *p, double (&Ar)[DIM][DIM], double (&Ai)[DIM][DIM], bool lower_only) const {
+        constexpr int D = DIM * DIM;
+#pragma unroll
+        for (int r = 0; r < DIM; ++r)
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) {
+                if (lower_only && c > r) continue;
+                double sr = 0.0, si = 0.0;
+                for (int a = 0; a < D; ++a) {
+                    sr += p[a] * basis[2 * ((a * DIM + r) * DIM + c)];
+                    si += p[a] * basis[2 * ((a * DIM + r) * DIM + c) + 1];
+                }
+                Ar[r][c] = sr;
+                Ai[r][c] = si;
+            }
+    }
+    // x_a = Re tr(B_a^H R) = Re sum_{rc} conj(B_a[r][c]) R[r][c]
+    __host__ __device__ inline void expand(const double (&Rr)[DIM][DIM], const double (&Ri)[DIM][DIM], double *p) const {
+        constexpr int D = DIM * DIM;
         for (int a = 0; a < D; ++a) {
             double s = 0.0;
 #pragma unroll
             for (int r = 0; r < DIM; ++r)
 #pragma unroll
                 for (int c = 0; c < DIM; ++c)
-                    s += basis[2 * ((a * DIM + r) * DIM + c)] * Rr[r][c] +
-                         basis[2 * ((a * DIM + r) * DIM + c) + 1] * Ri[r][c];
+                    s += basis[2 * ((a * DIM + r) * DIM + c)] * Rr[r][c] + basis[2 * ((a * DIM + r) * DIM + c) + 1] * Ri[r][c];
             p[a] = s;
         }
     }
-    if (!allow_subnormalized) {                           // :194-209
-        const double nrm = p[0] * sqrt((double)DIM);
+};
+
+// B_{4 i + j} = sigma_i (x) sigma_j / 2.  With M_i = sum_j x_{4 i + j} sigma_j = [[a_i, b_i - i c_i], [b_i + i c_i, d_i]]
+// (a_i = x_{i0} + x_{i3}, d_i = x_{i0} - x_{i3}, b_i = x_{i1}, c_i = x_{i2}) the 2 x 2 blocks of rho are
+//   R00 = (M_0 + M_3) / 2,  R11 = (M_0 - M_3) / 2,  R10 = (M_1 + i M_2) / 2,  R01 = R10^H,
+// and back: with t_0(G) = g00 + g11, t_3 = g00 - g11, t_1 = g01 + g10, t_2 = i (g01 - g10) for a block G,
+//   x_{0j} = Re[t_j(R00) + t_j(R11)] / 2,  x_{3j} = Re[t_j(R00) - t_j(R11)] / 2,  x_{1j} = Re t_j(R10),  x_{2j} = Im t_j(R10).
+struct TomoPauli2 {
+    __host__ __device__ inline void build(const double *x, double (&Ar)[4][4], double (&Ai)[4][4], bool) const {
+        double a[4], dd[4];
 #pragma unroll
-        for (int a = 0; a < D; ++a) p[a] = p[a] / nrm;
+        for (int i = 0; i < 4; ++i) {
+            a[i] = x[4 * i] + x[4 * i + 3];
+            dd[i] = x[4 * i] - x[4 * i + 3];
+        }
+        const double *b0 = x, *b1 = x + 4, *b2 = x + 8, *b3 = x + 12;      // b_i = x[4 i + 1], c_i = x[4 i + 2]
+        Ar[0][0] = 0.5 * (a[0] + a[3]);            Ai[0][0] = 0.0;
+        Ar[1][1] = 0.5 * (dd[0] + dd[3]);          Ai[1][1] = 0.0;
+        Ar[2][2] = 0.5 * (a[0] - a[3]);            Ai[2][2] = 0.0;
+        Ar[3][3] = 0.5 * (dd[0] - dd[3]);          Ai[3][3] = 0.0;
+        Ar[1][0] = 0.5 * (b0[1] + b3[1]);          Ai[1][0] = 0.5 * (b0[2] + b3[2]);
+        Ar[3][2] = 0.5 * (b0[1] - b3[1]);          Ai[3][2] = 0.5 * (b0[2] - b3[2]);
+        Ar[2][0] = 0.5 * a[1];                     Ai[2][0] = 0.5 * a[2];
+        Ar[2][1] = 0.5 * (b1[1] + b2[2]);          Ai[2][1] = 0.5 * (b2[1] - b1[2]);
+        Ar[3][0] = 0.5 * (b1[1] - b2[2]);          Ai[3][0] = 0.5 * (b1[2] + b2[1]);
+        Ar[3][1] = 0.5 * dd[1];                    Ai[3][1] = 0.5 * dd[2];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = r + 1; c < 4; ++c) {
+                Ar[r][c] = Ar[c][r];
+                Ai[r][c] = -Ai[c][r];
+            }
+    }
+    __host__ __device__ inline void expand(const double (&Rr)[4][4], const double (&Ri)[4][4], double *x) const {
+        // diagonal blocks (Hermitian): t_0 = g00 + g11, t_3 = g00 - g11, t_1 = 2 Re g10, t_2 = 2 Im g10
+        const double u0 = Rr[0][0] + Rr[1][1], u3 = Rr[0][0] - Rr[1][1], u1 = 2.0 * Rr[1][0], u2 = 2.0 * Ri[1][0];
+        const double v0 = Rr[2][2] + Rr[3][3], v3 = Rr[2][2] - Rr[3][3], v1 = 2.0 * Rr[3][2], v2 = 2.0 * Ri[3][2];
+        x[0] = 0.5 * (u0 + v0);  x[1] = 0.5 * (u1 + v1);  x[2] = 0.5 * (u2 + v2);  x[3] = 0.5 * (u3 + v3);
+        x[12] = 0.5 * (u0 - v0); x[13] = 0.5 * (u1 - v1); x[14] = 0.5 * (u2 - v2); x[15] = 0.5 * (u3 - v3);
+        // off-diagonal block G = R10 = [[rho20, rho21], [rho30, rho31]]
+        const double g00r = Rr[2][0], g00i = Ri[2][0], g01r = Rr[2][1], g01i = Ri[2][1];
+        const double g10r = Rr[3][0], g10i = Ri[3][0], g11r = Rr[3][1], g11i = Ri[3][1];
+        x[4] = g00r + g11r;          x[8] = g00i + g11i;             // t_0
+        x[7] = g00r - g11r;          x[11] = g00i - g11i;            // t_3
+        x[5] = g01r + g10r;          x[9] = g01i + g10i;             // t_1
+        x[6] = -(g01i - g10i);       x[10] = g01r - g10r;            // t_2 = i (g01 - g10): Re = -(Im g01 - Im g10), Im = Re g01 - Re g10
+    }
+};
+
+// Returns true if p[] was modified.
+template <int DIM, class Basis>
+__host__ __device__ inline bool tomo_canon_particle(const Basis &B, double *p, bool allow_subnormalized) {
+    constexpr int D = DIM * DIM;
+    double Ar[DIM][DIM], Ai[DIM][DIM], Rr[DIM][DIM], Ri[DIM][DIM];
+    B.build(p, Ar, Ai, false);
+    const bool any_neg = jacobi_clamp<DIM>(Ar, Ai, Rr, Ri);
+    if (any_neg) B.expand(Rr, Ri, p);
+    if (!allow_subnormalized) {                           // :194-209 (x / (x_0 sqrt(dim)): one reciprocal, D products)
+        const double inv = 1.0 / (p[0] * sqrt((double)DIM));
+#pragma unroll
+        for (int a = 0; a < D; ++a) p[a] = p[a] * inv;
     }
     return any_neg || !allow_subnormalized;
 }
@@ -675,22 +769,10 @@ __host__ __device__ inline bool tomo_canon_particle(const double *__restrict__ b
 // (built from p as in tomo_canon_particle) has only positive pivots.  Used to sort a cloud into the
 // particles canonicalize leaves alone (apart from the trace renormalisation) and the ones that need the
 // eigendecomposition; anything not clearly positive definite (a zero or negative pivot) goes to the latter.
-template <int DIM>
-__host__ __device__ inline bool tomo_clearly_positive(const double *__restrict__ basis, const double *p) {
-    constexpr int D = DIM * DIM;
+template <int DIM, class Basis>
+__host__ __device__ inline bool tomo_clearly_positive(const Basis &B, const double *p) {
     double Ar[DIM][DIM], Ai[DIM][DIM];
-#pragma unroll
-    for (int r = 0; r < DIM; ++r)
-#pragma unroll
-        for (int c = 0; c <= r; ++c) {                    // lower triangle is enough
-            double sr = 0.0, si = 0.0;
-            for (int a = 0; a < D; ++a) {
-                sr += p[a] * basis[2 * ((a * DIM + r) * DIM + c)];
-                si += p[a] * basis[2 * ((a * DIM + r) * DIM + c) + 1];
-            }
-            Ar[r][c] = sr;
-            Ai[r][c] = si;
-        }
+    B.build(p, Ar, Ai, true);                             // lower triangle is enough
     // in place: A[j][j] <- d_j, A[i][j] <- l_ij (i > j)
     bool ok = true;
 #pragma unroll

@@ -446,6 +446,27 @@ static int hyp_dispatch(qsmc_ctx *h, const qsmc_model_t *model, const double *x,
     return QSMC_OK;
 }
 
+template <class Basis>
+static int canon_dim4(qsmc_ctx *h, Basis B, double *x, int64_t ldx, int64_t n, int32_t allow_subnormalized, hipStream_t s) {
+    if (n >= (1ll << 32)) return QSMC_ERR_UNSUPPORTED;
+    const int grid = grid_for(n, QSMC_BLOCK);
+    int rc = ensure_iscratch(h, ((size_t)n + 4) * sizeof(unsigned int));
+    if (rc) return rc;
+    unsigned int *count = h->iscratch;              // [0] = list length; the list starts at [4]
+    unsigned int *list = h->iscratch + 4;
+    HIP_TRY(h, hipMemsetAsync(count, 0, sizeof(unsigned int), s));
+    hipEvent_t c0 = nullptr, c1 = nullptr, l0 = nullptr, l1 = nullptr;
+    prof_events(h, QSMC_PROF_CANON_CLASSIFY, &c0, &c1);
+    prof_events(h, QSMC_PROF_CANON_LIST, &l0, &l1);
+    const int cgrid = grid < 1024 ? grid : 1024;       // (few flushes per workgroup: see k_tomo_classify)
+    hipExtLaunchKernelGGL((k_tomo_classify<4, Basis>), dim3(cgrid), dim3(QSMC_BLOCK), 0, s, c0, c1, 0, B, x, ldx, n,
+                          allow_subnormalized, list, count);
+    hipExtLaunchKernelGGL((k_tomo_canon_list<4, Basis>), dim3(grid), dim3(QSMC_BLOCK), 0, s, l0, l1, 0, B, x, ldx,
+                          allow_subnormalized, list, count);
+    HIP_TRY(h, hipGetLastError());
+    return QSMC_OK;
+}
+
 // =============================================================================================
 // C ABI
 // =============================================================================================
@@ -1323,40 +1344,35 @@ int qsmc_random_walk(qsmc_handle_t h, double *x, int64_t ldx, int64_t n, int32_t
     return QSMC_OK;
 }
 
-int qsmc_tomo_canonicalize(qsmc_handle_t h, const double *basis, int32_t dim, double *x, int64_t ldx,
-                           int64_t n, int32_t allow_subnormalized, qsmc_stream_t stream) {
+int qsmc_tomo_canonicalize2(qsmc_handle_t h, const double *basis, int32_t dim, int32_t basis_kind, double *x, int64_t ldx,
+                            int64_t n, int32_t allow_subnormalized, qsmc_stream_t stream) {
     if (h) { h->prep.valid = 0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
-    if (!h || !basis || !x || n < 0) return QSMC_ERR_INVALID;
+    if (!h || !x || n < 0) return QSMC_ERR_INVALID;
+    if (basis_kind != QSMC_BASIS_DENSE && basis_kind != QSMC_BASIS_PAULI) return QSMC_ERR_INVALID;
+    if (basis_kind == QSMC_BASIS_DENSE && !basis) return QSMC_ERR_INVALID;
     if (n == 0) return QSMC_OK;
     hipStream_t s = (hipStream_t)stream;
     const int grid = grid_for(n, QSMC_BLOCK);
     switch (dim) {
         case 2:
-            hipLaunchKernelGGL((k_tomo_canon<2>), dim3(grid), dim3(QSMC_BLOCK), 0, s, basis, x, ldx, n,
-                               allow_subnormalized);
+            if (!basis) return QSMC_ERR_INVALID;        // (one qubit: the dense contraction is 4 x 4 already)
+            hipLaunchKernelGGL((k_tomo_canon<2, TomoDense<2>>), dim3(grid), dim3(QSMC_BLOCK), 0, s, TomoDense<2>{basis}, x, ldx,
+                               n, allow_subnormalized);
             break;
         case 3:
-            return QSMC_ERR_UNSUPPORTED;   // d = 9 fits QSMC_MAX_D but no config needs it yet
-        case 4: {
-            if (n >= (1ll << 32)) return QSMC_ERR_UNSUPPORTED;
-            int rc = ensure_iscratch(h, ((size_t)n + 4) * sizeof(unsigned int));
-            if (rc) return rc;
-            unsigned int *count = h->iscratch;              // [0] = list length; the list starts at [4]
-            unsigned int *list = h->iscratch + 4;
-            HIP_TRY(h, hipMemsetAsync(count, 0, sizeof(unsigned int), s));
-            hipEvent_t c0 = nullptr, c1 = nullptr, l0 = nullptr, l1 = nullptr;
-            prof_events(h, QSMC_PROF_CANON_CLASSIFY, &c0, &c1);
-            prof_events(h, QSMC_PROF_CANON_LIST, &l0, &l1);
-            hipExtLaunchKernelGGL((k_tomo_classify<4>), dim3(grid), dim3(QSMC_BLOCK), 0, s, c0, c1, 0, basis, x, ldx, n,
-                                  allow_subnormalized, list, count);
-            hipExtLaunchKernelGGL((k_tomo_canon_list<4>), dim3(grid), dim3(QSMC_BLOCK), 0, s, l0, l1, 0, basis, x, ldx,
-                                  allow_subnormalized, list, count);
-            break;
-        }
+            return QSMC_ERR_UNSUPPORTED;   // d = 9 fits QSMC_MAX_D but has no kernel: TomographyModel.canonicalize runs on the host
+        case 4:
+            if (basis_kind == QSMC_BASIS_PAULI) return canon_dim4(h, TomoPauli2{}, x, ldx, n, allow_subnormalized, s);
+            return canon_dim4(h, TomoDense<4>{basis}, x, ldx, n, allow_subnormalized, s);
         default: return QSMC_ERR_UNSUPPORTED;
     }
     HIP_TRY(h, hipGetLastError());
     return QSMC_OK;
+}
+
+int qsmc_tomo_canonicalize(qsmc_handle_t h, const double *basis, int32_t dim, double *x, int64_t ldx,
+                           int64_t n, int32_t allow_subnormalized, qsmc_stream_t stream) {
+    return qsmc_tomo_canonicalize2(h, basis, dim, QSMC_BASIS_DENSE, x, ldx, n, allow_subnormalized, stream);
 }
 
 // ---- posterior read-outs: sort by weight / by location, search a sorted table -------

@@ -90,6 +90,7 @@ SIGNATURES = {
     "qsmc_prior_uniform_philox": [_P, C.POINTER(ModelDesc), _I32, C.POINTER(_F64), C.POINTER(_F64), _I32,
                                   _I64, _U64, _U64, _I32, _P, _I64, C.POINTER(_I64), _P],
     "qsmc_tomo_canonicalize": [_P, _P, _I32, _P, _I64, _I64, _I32, _P],
+    "qsmc_tomo_canonicalize2": [_P, _P, _I32, _I32, _P, _I64, _I64, _I32, _P],
 }
 _RESTYPE = {"qsmc_strerror": C.c_char_p, "qsmc_last_hip_error": C.c_char_p}
 

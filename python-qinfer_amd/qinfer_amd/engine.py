@@ -407,7 +407,8 @@ class Engine:
             x_out.stride(0), C.byref(failed), self.stream()), "qsmc_prior_uniform_philox")
         return x_out, failed.value
 
-    def tomo_canonicalize(self, basis_dev, dim, x, allow_subnormalized):
-        self._chk(self.lib.qsmc_tomo_canonicalize(self.h, self._p(basis_dev), dim, self._p(x), x.stride(0),
-                                                  x.shape[1], int(bool(allow_subnormalized)), self.stream()),
-                  "qsmc_tomo_canonicalize")
+    def tomo_canonicalize(self, basis_dev, dim, x, allow_subnormalized, pauli=False):
+        """`pauli`: the basis is the reference's n-qubit Pauli basis (sparse contraction for 2 qubits)."""
+        self._chk(self.lib.qsmc_tomo_canonicalize2(self.h, self._p(basis_dev), dim, 1 if pauli else 0, self._p(x),
+                                                   x.stride(0), x.shape[1], int(bool(allow_subnormalized)), self.stream()),
+                  "qsmc_tomo_canonicalize2")

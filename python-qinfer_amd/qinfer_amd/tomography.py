@@ -121,6 +121,7 @@ class TomographyModel(NativeModelMixin, FiniteOutcomeModel):
         self._basis = basis
         self._allow_subnormalized = bool(allow_subnormalized)
         self._basis_dev = None
+        self._is_pauli = None
         super().__init__()
         self._native = self.n_modelparams <= _native.QSMC_MAX_D
 
@@ -175,7 +176,10 @@ class TomographyModel(NativeModelMixin, FiniteOutcomeModel):
         """In-place canonicalize of a device SoA cloud."""
         if not self._native_canonicalize_ok():
             raise NotImplementedError("native canonicalize supports dim 2 and 4 (1 or 2 qubits)")
-        eng.tomo_canonicalize(self._device_basis(eng), self._dim, x, self._allow_subnormalized)
+        if self._is_pauli is None:               # is this the reference's Pauli basis, element for element?
+            nq = int(round(np.log2(self._dim)))
+            self._is_pauli = bool(2 ** nq == self._dim and np.array_equal(self._basis.data, pauli_basis(nq).data))
+        eng.tomo_canonicalize(self._device_basis(eng), self._dim, x, self._allow_subnormalized, pauli=self._is_pauli)
 
     # NumPy contract
     def are_models_valid(self, modelparams):

@@ -751,6 +751,17 @@ def test_tomo_canonicalize_g5(qi, golden):
     rho = np.tensordot(y, basis.data, 1)
     np.testing.assert_allclose(np.trace(rho, axis1=1, axis2=2).real, 1.0, atol=1e-12)
     assert np.linalg.eigvalsh(rho).min() > -1e-12
+    # a dim-4 basis that is NOT the Pauli basis takes the dense contraction (the Pauli one above the sparse one)
+    gm = qi.tomography.gell_mann_basis(4)
+    rs = np.random.RandomState(5)
+    xg = 0.25 * rs.randn(400, 16)
+    xg[:, 0] = 0.5
+    yg = qi.TomographyModel(gm).canonicalize(xg)
+    np.testing.assert_allclose(yg, orc.tomo_canonicalize(xg, gm.data), rtol=0, atol=1e-12)
+    assert qi.TomographyModel(gm)._is_pauli is None
+    tm = qi.TomographyModel(basis)
+    tm.canonicalize(g["x"][:4])
+    assert tm._is_pauli is True
     # single-qubit kernel instantiation
     b1 = qi.tomography.pauli_basis(1)
     x1 = np.array([[0.70710678, 0.9, 0.1, 0.2], [0.70710678, 0.1, 0.1, 0.1]])
