@@ -225,7 +225,10 @@ static double exact_comb(uint64_t n, uint64_t k) {                 /* math.comb(
     if (k > n) return 0.0;
     if (k > n - k) k = n - k;
     long double c = 1.0L;
-    for (uint64_t j = 1; j <= k; ++j) c = c * (long double)(n - k + j) / (long double)j;
+    for (uint64_t j = 1; j <= k; ++j) {
+        c = c * (long double)(n - k + j) / (long double)j;
+        if (c > 1.0e305L) return INFINITY;
+    }
     return (double)c;
 }
 
@@ -234,7 +237,11 @@ static inline double two_outcome(double pr0, int64_t o) { return o == 0 ? pr0 : 
 static inline double binom_pmf(const exp_t *e, double p) {         /* np_oracle.binom_pmf: c * p**k * (1-p)**(n-k) */
     const double k = (double)e->outcome;
     if (e->outcome < 0 || k > e->n_meas) return 0.0;
-    return e->comb * pow(p, k) * pow(1.0 - p, e->n_meas - k);
+    if (e->n_meas <= 64.0) return e->comb * pow(p, k) * pow(1.0 - p, e->n_meas - k);
+    /* many measurements: the powers underflow (and the coefficient overflows) long before the product: log space */
+    const double lc = lgamma(e->n_meas + 1.0) - lgamma(k + 1.0) - lgamma(e->n_meas - k + 1.0);
+    const double lp = (k > 0.0 ? k * log(p) : 0.0) + (e->n_meas - k > 0.0 ? (e->n_meas - k) * log1p(-p) : 0.0);
+    return exp(lc + lp);
 }
 
 static inline double lik_one(const exp_t *e, const double *p) {

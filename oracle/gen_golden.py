@@ -246,6 +246,72 @@ def g2_likelihoods():
     print("g2_likelihoods")
 
 
+def g2_edges():
+    """Likelihood corners the main G2 grid does not reach: arguments of cos beyond 1e10 rad (the device code leaves
+    its in-range argument reduction there), non-finite parameters, and binomial pmfs with many measurements (beyond
+    the small-n closed form; beyond the largest finite binomial coefficient)."""
+    out = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = qinfer.SimplePrecessionModel()
+        omega = np.concatenate([np.linspace(0.01, 1, 64), [0.3, 0.29999981, 1e-300, 0.0, np.inf, np.nan, -0.4]])[:, None]
+        ts = np.array([2.5e10, 1e11, 3.7e11, 1e12, 7.7e15, 1e300])
+        out['prec_x'], out['prec_t'] = omega, ts
+        out['prec_L'] = m.likelihood(np.array([0, 1]), omega, ts)
+        bm = qinfer.BinomialModel(m)
+        om2 = np.linspace(0.02, 1, 48)[:, None]
+        ns = [65, 100, 1000, 1100, 5000]
+        ep = np.empty((len(ns),), dtype=bm.expparams_dtype)
+        ep['x'] = [1.0, 7.3, 2.1, 3.3, 0.9]
+        ep['n_meas'] = ns
+        out['bin_x'], out['bin_t'], out['bin_n'] = om2, ep['x'], ep['n_meas']
+        ks = np.array([0, 1, 2, 17, 32, 50, 64, 65, 99, 100, 333, 550, 999, 1000, 1099, 1100, 2500, 4999, 5000])
+        out['bin_k'] = ks
+        # (one experiment at a time: the outcome domain depends on n_meas)
+        L = np.zeros((len(ks), om2.shape[0], len(ns)))
+        for e in range(len(ns)):
+            ok = ks <= ns[e]
+            L[ok, :, e] = bm.likelihood(ks[ok], om2, ep[e:e + 1])[:, :, 0]
+        out['bin_L'] = L
+    np.savez_compressed(os.path.join(OUT, "g2_edges.npz"), **out)
+    print("g2_edges")
+
+
+def g1_clouds():
+    """Config 1 once more (same seed, same data as g1_precession_n1000) with the cloud the reference holds after
+    EVERY resample: lets a test force the device updater onto the reference's trajectory at each resample and then
+    hold it to the reference's final state (the free-running comparison stops at the conditioning horizon)."""
+    prior = qinfer.UniformDistribution([0, 1])
+    m = qinfer.SimplePrecessionModel()
+    true = np.array([[0.3]])
+    np.random.seed(0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        upd = qinfer.SMCUpdater(m, 1000, prior)
+        x0 = upd.particle_locations.copy()
+        clouds, at, outcomes, ts, rcs, means, norms, ess = [], [], [], [], [], [], [], []
+        for k in range(200):
+            t = np.array([(9 / 8) ** k])
+            d = m.simulate_experiment(true, t)
+            before = upd.resample_count
+            upd.update(d, t)
+            if upd.resample_count != before:
+                clouds.append(upd.particle_locations.copy())
+                at.append(k)
+            outcomes.append(int(d))
+            ts.append(t[0])
+            rcs.append(upd.resample_count)
+            means.append(upd.est_mean().copy())
+            norms.append(float(np.ravel(upd.normalization_record[-1])[0]))
+            ess.append(float(upd.n_ess))
+    np.savez_compressed(os.path.join(OUT, "g1_precession_n1000_clouds.npz"), x0=x0, outcomes=np.array(outcomes),
+                        ep_t=np.array(ts), resample_count=np.array(rcs), resample_at=np.array(at),
+                        clouds=np.array(clouds), means=np.array(means), norms=np.array(norms), n_ess=np.array(ess),
+                        final_locs=upd.particle_locations.copy(), final_weights=upd.particle_weights.copy(),
+                        final_mean=upd.est_mean(), final_cov=upd.est_covariance_mtx())
+    print("g1_precession_n1000_clouds", len(at), "resamples, final mean", upd.est_mean())
+
+
 def g3_moments():
     out = {}
     rs = np.random.RandomState(21)
@@ -667,4 +733,6 @@ if __name__ == "__main__":
     g11_readouts()
     g12_perf_test()
     g13_regions()
+    g2_edges()
+    g1_clouds()
     print("total bytes:", sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT)))

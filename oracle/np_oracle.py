@@ -131,9 +131,16 @@ def binom_pmf(n, k, p):
         sel = nb == nv
         if k < 0 or k > nv_i:
             continue
-        c = float(math.comb(nv_i, k))
         pp = pb[sel]
-        out[sel] = c * pp ** k * (1 - pp) ** (nv_i - k)
+        if nv_i <= 64:
+            out[sel] = float(math.comb(nv_i, k)) * pp ** k * (1 - pp) ** (nv_i - k)
+        else:
+            # many measurements: the powers underflow (and eventually the coefficient overflows) long before their
+            # product does -- log space, what SciPy's pmf does internally for every n
+            lc = math.lgamma(nv_i + 1.0) - math.lgamma(k + 1.0) - math.lgamma(nv_i - k + 1.0)
+            with np.errstate(divide='ignore', invalid='ignore'):
+                lp = (k * np.log(pp) if k > 0 else 0.0) + ((nv_i - k) * np.log1p(-pp) if nv_i - k > 0 else 0.0)
+            out[sel] = np.exp(lc + lp)
     return out
 
 

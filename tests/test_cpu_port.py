@@ -46,6 +46,21 @@ def test_g2_likelihoods(golden):
             np.testing.assert_allclose(L, g["tomo_L"][o, :, e], rtol=0, atol=4e-16)
 
 
+def test_g2_edges(golden):
+    g = golden("g2_edges")
+    x, ts = g["prec_x"], g["prec_t"]
+    for o in (0, 1):
+        for e, t in enumerate(ts):
+            L = cp.likelihood(cp.PRECESSION, x, o, t=t)
+            np.testing.assert_allclose(L, g["prec_L"][o, :, e], rtol=0, atol=1e-15)     # NaN matches NaN
+    ks, ns = g["bin_k"], g["bin_n"]
+    for e in range(len(ns)):
+        for i, k in enumerate(ks):
+            if k <= ns[e]:
+                L = cp.likelihood(cp.BINOMIAL_PRECESSION, g["bin_x"], int(k), t=g["bin_t"][e], n_meas=int(ns[e]))
+                np.testing.assert_allclose(L, g["bin_L"][i, :, e], rtol=1e-9, atol=1e-300)
+
+
 def test_g8_binomial_rb_likelihood(golden):
     g = golden("g8_binomial_rb")
     x, ms, ns = g["brb_x"], g["brb_m"], g["brb_n"]

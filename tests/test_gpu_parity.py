@@ -76,6 +76,28 @@ def test_likelihood_binomial_g2(qi, golden):
     np.testing.assert_allclose(L, ref, rtol=1e-12, atol=30 * 1e-15)
 
 
+def test_likelihood_edges_g2(qi, golden):
+    """Corners of the likelihood kernels, against the reference (fixture g2_edges): cos^2 arguments beyond 1e10 rad
+    (where cos_sq leaves its in-range reduction for the library routine), non-finite / negative parameters, and
+    binomial pmfs with many measurements (log-space branch; coefficient beyond the largest finite double)."""
+    g = golden("g2_edges")
+    m = qi.SimplePrecessionModel()
+    with np.errstate(invalid="ignore"):
+        L = m.likelihood(np.array([0, 1]), g["prec_x"], g["prec_t"])
+    assert np.array_equal(np.isnan(L), np.isnan(g["prec_L"]))
+    np.testing.assert_allclose(L, g["prec_L"], rtol=0, atol=1e-15)        # <= 4 ulp(1); NaN matches NaN
+    assert float(np.nanmax(np.abs(0.5 * g["prec_t"][None, :] * g["prec_x"]))) > 1e10
+    bm = qi.BinomialModel(qi.SimplePrecessionModel())
+    ks, ns = g["bin_k"], g["bin_n"]
+    for e in range(len(ns)):
+        ep = np.empty((1,), dtype=bm.expparams_dtype)
+        ep['x'], ep['n_meas'] = g["bin_t"][e], ns[e]
+        ok = ks <= ns[e]
+        L = bm.likelihood(ks[ok], g["bin_x"], ep)[:, :, 0]
+        np.testing.assert_allclose(L, g["bin_L"][ok, :, e], rtol=1e-9, atol=1e-300, err_msg="n_meas %d" % ns[e])
+        assert np.count_nonzero(g["bin_L"][ok, :, e] > 1e-200) > 20       # (the comparison is not about zeros)
+
+
 def test_likelihood_rb_g2(qi, golden):
     g = golden("g2_likelihoods")
     m = qi.RandomizedBenchmarkingModel()
@@ -1207,6 +1229,39 @@ def test_batch_update_fused_guard_replay(qi):
 
 
 # ================================================================== every-step teacher forcing
+def test_c1_forced_at_resamples_reaches_reference_final_state(qi, golden):
+    """Config 1 (N = 1000, 200 data) on the HIP path all the way to the reference's FINAL state.  Free-running
+    trajectories of two IEEE-correct implementations decorrelate past the conditioning horizon (parity_tols), because
+    every resample amplifies an ulp; here the device updater is put back on the reference's cloud after each resample
+    (fixture g1_precession_n1000_clouds, recorded from the reference), so nothing compounds: every datum's
+    normalisation, n_ess and mean, every resample DECISION, and the final mean / covariance / count are held to the
+    reference's numbers."""
+    g = golden("g1_precession_n1000_clouds")
+    ts, outcomes = g["ep_t"], g["outcomes"]
+    at = list(g["resample_at"])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        np.random.seed(123)                                # (the device resampler's own draws are overwritten below)
+        upd = qi.SMCUpdater(qi.SimplePrecessionModel(), 1000, fixed_prior(qi, g["x0"]))
+        for k in range(200):
+            upd.update(int(outcomes[k]), ts[k:k + 1])
+            assert upd.resample_count == g["resample_count"][k], "datum %d: resample decision differs" % k
+            np.testing.assert_allclose(np.ravel(upd.normalization_record[-1])[0], g["norms"][k], rtol=1e-11,
+                                       err_msg="datum %d" % k)
+            if k in at:
+                upd.particle_locations = g["clouds"][at.index(k)]          # the reference's cloud after this resample
+                assert upd.just_resampled
+            np.testing.assert_allclose(upd.n_ess, g["n_ess"][k], rtol=1e-10, err_msg="datum %d" % k)
+            np.testing.assert_allclose(upd.est_mean(), g["means"][k], rtol=0, atol=1e-13, err_msg="datum %d" % k)
+    assert upd.resample_count == 38 == len(at)
+    np.testing.assert_allclose(upd.est_mean(), g["final_mean"], rtol=0, atol=1e-13)
+    assert abs(upd.est_mean()[0] - 0.29999981) < 5e-9                       # SURVEY 8(d), C1
+    w = np.asarray(upd.particle_weights)
+    np.testing.assert_allclose(w, g["final_weights"], rtol=1e-9, atol=1e-18)
+    np.testing.assert_allclose(upd.est_covariance_mtx(), g["final_cov"], rtol=0,
+                               atol=tol.atol_cov(g["final_mean"], np.sum(g["final_mean"] ** 2), 1000))
+
+
 def test_every_step_from_oracle_state(qi):
     """All 200 data of config C1, one step at a time FROM THE ORACLE'S STATE, so chaotic
     amplification (parity_tols docstring) cannot hide a per-step discrepancy at large t."""

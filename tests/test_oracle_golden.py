@@ -45,6 +45,19 @@ def test_g2_tomography_and_bases(golden):
     np.testing.assert_allclose(L, g["tomo_L"], rtol=0, atol=4e-16)
 
 
+def test_g2_edges(golden):
+    """Corners: cos arguments beyond 1e10 rad, non-finite parameters, binomial pmfs with many measurements."""
+    g = golden("g2_edges")
+    with np.errstate(invalid="ignore"):
+        L = orc.lik_precession([0, 1], g["prec_x"], g["prec_t"])
+    np.testing.assert_array_equal(L, g["prec_L"])              # (NaN == NaN under assert_array_equal)
+    ks, ns = g["bin_k"], g["bin_n"]
+    for e in range(len(ns)):
+        ok = ks <= ns[e]
+        L = orc.lik_binomial_precession(ks[ok], g["bin_x"], g["bin_t"][e:e + 1], ns[e:e + 1])[:, :, 0]
+        np.testing.assert_allclose(L, g["bin_L"][ok, :, e], rtol=1e-9, atol=1e-300, err_msg="n_meas %d" % ns[e])
+
+
 # ------------------------------------------------------------------ G3
 def test_g3_moments(golden):
     g = golden("g3_moments")
