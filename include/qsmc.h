@@ -87,6 +87,10 @@ const char *qsmc_strerror(int status);
 const char *qsmc_last_hip_error(qsmc_handle_t h);
 int         qsmc_create(qsmc_handle_t *out, int device);
 int         qsmc_destroy(qsmc_handle_t h);
+/* Compute units this process can actually run on (a census taken by qsmc_create: under HSA_CU_MASK or a partitioned
+ * part fewer than the device attribute reports) and the reported number.  The resampler's grid-barrier kernels
+ * (k_bucket_counts, k_bucket_redraw) size their resident grids by the first. */
+int         qsmc_device_cus(qsmc_handle_t h, int32_t *usable_out, int32_t *reported_out);
 
 /* Kernel timing for bench.py's roofline line: when enabled, qsmc_update_fused brackets its main
  * kernel (not the finalize/copy) with hipEvents on `stream` (hipExtLaunchKernelGGL start/stop events:

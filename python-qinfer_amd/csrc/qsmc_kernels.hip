@@ -57,7 +57,8 @@ struct qsmc_ctx {
     unsigned long long *gbar;      // device: [0] arrival counter of the count kernel's barriers (only ever grows), [1] its
                                    // timeouts; [2], [3] arrivals / departures of the redraw kernel's self-resetting barrier
     unsigned long long gbar_base;  // host shadow: arrivals handed out so far
-    int cu_count;                  // compute units of the device (bounds the resident grids of the barrier kernels)
+    int cu_count;                  // compute units this process can run on (bounds the resident grids of the barrier kernels)
+    int cu_reported;               // what the device attribute says
     void *sort_tmp;                // rocPRIM temporary storage + key/value staging for qsmc_argsort
     size_t sort_tmp_cap;           // in bytes
     double *tile_sums;             // sum of w' per update-kernel tile, written by the last qsmc_update_fused
@@ -115,6 +116,39 @@ struct qsmc_ctx {
 
 constexpr int REDUCE_OUT_MAX = 192;
 constexpr int QSMC_PROF_CAP = 4096;
+
+// Census of the compute units this process can actually run on.  hipDeviceAttributeMultiprocessorCount reports the
+// device's CUs; under a CU mask (HSA_CU_MASK / ROC_GLOBAL_CU_MASK) or other restrictions fewer are usable, and the
+// resampler's barrier kernels size their grids by residency: a grid that cannot be resident as a whole would never
+// pass its barrier (it aborts after a bounded spin, but aborts).  Every workgroup of a short saturating launch records
+// (XCC, SE, SH, CU) of where it ran in a bitmap; the host counts the bits.
+__global__ void k_cu_census(unsigned int *__restrict__ bitmap) {
+    if (threadIdx.x == 0) {
+        const unsigned int hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);      // HW_REG_HW_ID, all 32 bits
+        const unsigned int xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);     // HW_REG_XCC_ID[3:0]
+        const unsigned int key = ((xcc & 0xfu) << 8) | ((hw >> 8) & 0xffu);                // CU_ID 11:8, SH_ID 12, SE_ID 15:13
+        atomicOr(&bitmap[key >> 5], 1u << (key & 31u));
+    }
+    for (int i = 0; i < 64; ++i) __builtin_amdgcn_s_sleep(127);        // stay a few microseconds: later blocks go elsewhere
+}
+
+static int cu_census(int reported) {
+    unsigned int *bm = nullptr;
+    constexpr int WORDS = 4096 / 32;
+    if (hipMalloc(&bm, WORDS * sizeof(unsigned int)) != hipSuccess) return reported;
+    int usable = reported;
+    unsigned int host[WORDS];
+    if (hipMemset(bm, 0, sizeof(host)) == hipSuccess) {
+        hipLaunchKernelGGL(k_cu_census, dim3(reported * 16), dim3(256), 0, 0, bm);
+        if (hipMemcpy(host, bm, sizeof(host), hipMemcpyDeviceToHost) == hipSuccess) {
+            int n = 0;
+            for (int w = 0; w < WORDS; ++w) n += __builtin_popcount(host[w]);
+            if (n >= 1 && n <= reported) usable = n;
+        }
+    }
+    (void)hipFree(bm);
+    return usable;
+}
 
 static int ensure_partials(qsmc_ctx *h, size_t n) {
     if (h->partials_cap >= n) return QSMC_OK;
@@ -507,7 +541,8 @@ int qsmc_create(qsmc_handle_t *out, int device) {
     if (e == hipSuccess) {
         int cus = 0;
         e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
-        h->cu_count = cus > 0 ? cus : 1;
+        h->cu_reported = cus > 0 ? cus : 1;
+        h->cu_count = e == hipSuccess ? cu_census(h->cu_reported) : h->cu_reported;
     }
     if (e != hipSuccess) {
         delete h;
@@ -539,6 +574,13 @@ int qsmc_destroy(qsmc_handle_t h) {
         free(h->prof_tag);
     }
     delete h;
+    return QSMC_OK;
+}
+
+int qsmc_device_cus(qsmc_handle_t h, int32_t *usable_out, int32_t *reported_out) {
+    if (!h) return QSMC_ERR_INVALID;
+    if (usable_out) *usable_out = h->cu_count;
+    if (reported_out) *reported_out = h->cu_reported;
     return QSMC_OK;
 }
 

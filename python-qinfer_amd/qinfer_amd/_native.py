@@ -43,6 +43,7 @@ SIGNATURES = {
     "qsmc_last_hip_error": [_P],
     "qsmc_create": [C.POINTER(_P), C.c_int],
     "qsmc_destroy": [_P],
+    "qsmc_device_cus": [_P, C.POINTER(_I32), C.POINTER(_I32)],
     "qsmc_set_profiling": [_P, C.c_int],
     "qsmc_profile_read": [_P, C.POINTER(C.c_float), C.POINTER(_I32), _I32, C.POINTER(_I32)],
     "qsmc_last_update_kernel_ms": [_P, C.POINTER(C.c_float)],

@@ -96,6 +96,12 @@ class Engine:
     def _chk(self, rc, what):
         _native.check(self.h, rc, what)
 
+    def device_cus(self):
+        """(usable, reported) compute units: the census the library sizes its grid-barrier kernels by."""
+        a, b = C.c_int32(), C.c_int32()
+        self._chk(self.lib.qsmc_device_cus(self.h, C.byref(a), C.byref(b)), "qsmc_device_cus")
+        return a.value, b.value
+
     # ------------------------------------------------------------------ profiling hooks (bench.py)
     def set_profiling(self, enabled):
         """False/0: off; True/1: time every update / sampler launch; N > 1: every N-th launch of each kind."""

@@ -1,6 +1,7 @@
 """GPU parity tests: every HIP kernel, called through the product API (ctypes -> C ABI), against
 the CPU oracle and the committed golden vectors.  Tolerances are the stated fp64 ones
 (tests/parity_tols.py).  Run with `pytest -m gpu` on an MI355X."""
+import os
 import warnings
 
 import numpy as np
@@ -1918,6 +1919,60 @@ def test_segmented_resample_beyond_bucket_limit(qi, eng):
         for k in range(25):
             upd.update(k & 1, np.array([1.125 ** (2 * k)]))
         assert upd.resample_count > 2 and upd.n_particles == 60000 and float(upd._x.min().item()) > 0
+
+
+_CU_MASK_SCRIPT = r"""
+import os, sys, warnings
+import numpy as np
+sys.path.insert(0, os.path.join(sys.argv[1], "python-qinfer_amd"))
+import qinfer_amd as qi
+from qinfer_amd.engine import get_engine
+warnings.simplefilter("ignore")
+eng = get_engine()
+usable, reported = eng.device_cus()
+rs = np.random.RandomState(8)
+n = 300000
+x = np.abs(0.002 * rs.randn(n, 1))                    # a cloud hugging omega = 0: the kick throws ~ half of it out
+w = rs.random_sample(n) ** 2
+pd = qi.ParticleDistribution(particle_locations=x, particle_weights=w)
+res = qi.LiuWestResampler(a=0.9, device_rng=True, seed=77)
+new = res(qi.SimplePrecessionModel(), pd, n_particles=n)
+np.save(sys.argv[2], np.asarray(new.particle_locations))
+print("CUS", usable, reported)
+"""
+
+
+def test_barrier_kernels_under_cu_mask(qi, eng, tmp_path):
+    """The resampler's grid-barrier kernels (k_bucket_counts, k_bucket_redraw) need all their workgroups resident at
+    once; the library sizes them by a census of the CUs the process can really use.  Run a resample that triggers the
+    global redraw path in a child process confined to a few CUs (HSA_CU_MASK): it must complete and give bit for bit
+    the particles of the unmasked run."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "masked.py"
+    script.write_text(_CU_MASK_SCRIPT)
+    usable0, reported0 = eng.device_cus()
+    assert 1 <= usable0 <= reported0
+    outs = {}
+    for tag, mask in (("full", None), ("masked", "0:0-23")):
+        env = dict(os.environ)
+        env.pop("HSA_CU_MASK", None)
+        if mask:
+            env["HSA_CU_MASK"] = mask
+        out = tmp_path / (tag + ".npy")
+        r = subprocess.run([sys.executable, str(script), root, str(out)], env=env, capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        cus = [ln for ln in r.stdout.splitlines() if ln.startswith("CUS")][-1].split()
+        outs[tag] = (np.load(out), int(cus[1]), int(cus[2]))
+    full, masked = outs["full"], outs["masked"]
+    assert full[1] == usable0
+    if masked[1] >= full[1]:
+        pytest.skip("HSA_CU_MASK is not honoured on this stack (census sees %d CUs either way)" % masked[1])
+    assert masked[1] <= 24 < masked[2] == reported0              # the census saw the mask; the attribute does not
+    np.testing.assert_array_equal(masked[0], full[0])
+    assert np.all(full[0] > 0)
 
 
 def test_profiling_ring(qi, eng):

@@ -399,6 +399,82 @@ def test_sharded_fast_paths_two_ranks_one_gpu(tmp_path):
     _run("_check_sharded_fast_paths", tmp_path, world=2)
 
 
+def _check_sharded_resample_vs_twin(comm, rank, world, tmpdir):
+    """The sharded Liu-West step of configs 4 and 5 (RB, 2-qubit tomography) on two ranks, particle for particle
+    against the oracle on IDENTICAL Philox streams: the shard totals are the shared-seed host multinomial, and each
+    shard's children are what oracle/philox.py draws from that shard's weights with that rank's seed, the global mean
+    and covariance -- not just invariants of the result."""
+    import warnings
+    import torch
+    import qinfer_amd as qi
+    import np_oracle as orc
+    import philox as ph
+    import parity_tols as tol
+    torch.cuda.set_device(0)
+    n_local = 40000
+    for case in ("rb", "tomo"):
+        rs = np.random.RandomState(17)
+        if case == "rb":
+            model, valid = qi.RandomizedBenchmarkingModel(), orc.valid_rb
+            x_all = np.stack([rs.uniform(0.9, 1, 2 * n_local), rs.uniform(0.2, 0.5, 2 * n_local),
+                              rs.uniform(0.4, 0.6, 2 * n_local)], 1)
+            eps = []
+            for mm in (3, 20, 60):
+                ep = np.empty((1,), dtype=model.expparams_dtype)
+                ep['m'] = mm
+                eps.append(ep)
+            canon = None
+        else:
+            basis = qi.tomography.pauli_basis(2)
+            model, valid = qi.TomographyModel(basis), (lambda z: np.ones(z.shape[0], dtype=bool))
+            x_all = orc.ginibre_prior_sample(2 * n_local, basis.data, rs)
+            eps = []
+            for pp in (3, 7, 12):
+                ep = np.zeros((1,), dtype=model.expparams_dtype)
+                ep['meas'][0, 0] = 1
+                ep['meas'][0, pp] = 1
+                eps.append(ep)
+            canon = basis.data
+        d = x_all.shape[1]
+
+        class Slice(qi.Distribution):
+            n_rvs = d
+
+            def sample(self, n=1):
+                return x_all[rank * n_local:(rank + 1) * n_local].copy()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            upd = qi.SMCUpdater(model, n_local, Slice(), device_rng=True, seed=11, comm=comm, resample_thresh=0.0)
+            for k, ep in enumerate(eps):
+                upd.update(k & 1, ep)
+            x_before = np.asarray(upd.particle_locations)
+            w_dev, W = upd._w, np.array(upd._shard_sums)
+            mean, cov = upd.est_mean(), upd.est_covariance_mtx()
+            cdf = upd._eng.cumsum(w_dev, float(W[rank])).cpu().numpy()
+            n_total = upd.n_particles_global
+            upd.resample()
+            got = np.asarray(upd.particle_locations)
+            epoch = comm._epoch
+            totals = comm.plan_totals(W, n_total, epoch)
+            assert got.shape[0] == totals[rank] and totals.sum() == n_total
+            res = upd.resampler
+            seed_r = res._seed + 0x9E3779B97F4A7C15 * (rank + 1)
+            ref, failed, js, counts = ph.liu_west_philox_bucketed(
+                np.ones(n_local) / n_local, x_before, valid, res.a, res.h, seed_r, epoch, int(totals[rank]),
+                mean=mean, cov=cov, cdf=cdf)
+            if canon is not None:
+                ref = orc.tomo_canonicalize(ref, canon)
+        at = 1e-12 + (tol.atol_sqrtm_psd(cov) * 10 if case == "tomo" else 0)
+        bad = np.abs(got - ref).max(axis=1) > at
+        assert bad.sum() <= tol.max_js_flips(got.shape[0]), (case, int(bad.sum()))
+        assert np.all(valid(got)) and failed == 0
+
+
+@pytest.mark.gpu
+def test_sharded_resample_vs_twin_two_ranks_one_gpu(tmp_path):
+    _run("_check_sharded_resample_vs_twin", tmp_path, world=2)
+
+
 def _check_perf_replicas(comm, rank, world, tmpdir):
     """perf_test_multiple(comm=...): trials are replicas -- dealt round-robin to the ranks, no data-path
     collective, one all-gather of the records at the end; every rank returns the full table."""
