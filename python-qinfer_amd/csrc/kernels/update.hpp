@@ -91,7 +91,10 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_reduce_partials(int nblocks, Red
         }
         // a resample queued before this reduction has finished by now (stream order): its count of particles
         // that stayed invalid rides along (qsmc_last_resample_failed reads it after this synchronisation)
-        if (ro.failed_dst) *ro.failed_dst = (double)*ro.failed_src;
+        if (ro.failed_dst) {
+            ro.failed_dst[0] = (double)ro.failed_src[0];
+            ro.failed_dst[-1] = (double)ro.failed_src[1];       // how many outputs of that resample needed a global redraw
+        }
         if (ro.flag) {                   // the host spins on this word instead of hipStreamSynchronize
             __threadfence_system();
             *reinterpret_cast<volatile unsigned long long *>(ro.flag) = ro.seq;

@@ -129,7 +129,7 @@ __global__ void k_cu_census(unsigned int *__restrict__ bitmap) {
         const unsigned int key = ((xcc & 0xfu) << 8) | ((hw >> 8) & 0xffu);                // CU_ID 11:8, SH_ID 12, SE_ID 15:13
         atomicOr(&bitmap[key >> 5], 1u << (key & 31u));
     }
-    for (int i = 0; i < 64; ++i) __builtin_amdgcn_s_sleep(127);        // stay a few microseconds: later blocks go elsewhere
+    for (int i = 0; i < 12; ++i) __builtin_amdgcn_s_sleep(127);        // stay a few microseconds: later blocks go elsewhere
 }
 
 static int cu_census(int reported) {
@@ -1230,10 +1230,23 @@ static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int3
             // grid must be resident as a whole, and half of the two-per-CU slots stay free for a second process
             int redraw_blocks = redraw_env < h->cu_count ? redraw_env : h->cu_count;
             redraw_blocks = redraw_blocks < 1 ? 1 : (redraw_blocks > REDRAW_BLOCKS ? REDRAW_BLOCKS : redraw_blocks);
-            hipLaunchKernelGGL((d <= 4 ? k_bucket_redraw<4> : k_bucket_redraw<QSMC_MAX_D>), dim3(redraw_blocks),
-                               dim3(SCAN_THREADS), 0, s, model->kind, d,
+            // Which form?  Nothing queued (most resamples of most models): ONE resident-grid launch that leaves at once.
+            // Models whose postselection bites at every resample (RB: the cloud leans on A + B <= 1) spent ~300 us in
+            // that kernel's scan phase -- 256 workgroups walking 3000 chunks in a dozen rounds behind a grid barrier --
+            // so if the PREVIOUS resample on this handle queued redraws (its count came back with the last
+            // host-visible reduction), the CDF is materialised by a full-grid gated k_chunk_scan first (40 us when
+            // the gate is open, ~5 us when it is not) and the redraw kernel skips its scan and its barrier.  Same CDF,
+            // same particles either way.
+            static const bool never_split = getenv("QSMC_REDRAW_ONE_LAUNCH") != nullptr;      // (A/B switch)
+            const bool expect_redraws = !never_split && h->mapped[REDUCE_OUT_MAX - 2] > 0.0;
+            if (expect_redraws)
+                hipLaunchKernelGGL(k_chunk_scan, dim3((unsigned)chunks64), dim3(SCAN_THREADS), 0, s, w, n_in, inv_norm,
+                                   offsets, h->cdf_scratch, (const unsigned long long *)retry_count);
+            hipLaunchKernelGGL((d <= 4 ? k_bucket_redraw<4> : k_bucket_redraw<QSMC_MAX_D>),
+                               dim3(expect_redraws ? 1024 : redraw_blocks), dim3(SCAN_THREADS), 0, s, model->kind, d,
                                model->min_freq, x_in, ldx_in, n_in, w, inv_norm, offsets, chunks64, h->cdf_scratch, lw,
-                               k0, k1, ep, maxiter, x_out, pl, bp.retry_list, retry_count, nf, h->gbar + 2);
+                               k0, k1, ep, maxiter, x_out, pl, bp.retry_list, retry_count, nf, h->gbar + 2,
+                               expect_redraws ? 1 : 0);
         }
     }
     HIP_TRY(h, hipGetLastError());

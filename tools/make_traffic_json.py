@@ -1,9 +1,14 @@
-"""Per-kernel HBM bytes per launch from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs).
-Counters are in KB; on gfx950 FETCH_SIZE reports half of a coalesced streaming read (MI355X_MICROARCH.md,
-HBM section), hence bytes = (2 * FETCH + WRITE) * 1024."""
+"""Per-kernel HBM bytes per launch from the rocprofv3 --pmc passes tools/profile_configs.sh leaves behind
+(<dir>/<tag>_{c2,c3,c4,c5}_pmc_{fetch,write}.csv: FETCH_SIZE and WRITE_SIZE in SEPARATE runs, kernel-trace only).
+Counters are in KB; on gfx950 FETCH_SIZE reports half of a coalesced streaming read (MI355X_MICROARCH.md, HBM
+section), hence bytes = (2 * FETCH + WRITE) * 1024 -- checked here on kernels whose reads are known.
+
+    python tools/make_traffic_json.py <dir> <tag> > profiles/hbm_traffic.json
+"""
 import collections
 import csv
 import json
+import os
 import re
 import sys
 
@@ -12,29 +17,50 @@ def per_kernel(path, counter):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == counter:
-            acc[re.sub(r"\(.*", "", r["Kernel_Name"])].append(float(r["Counter_Value"]))
+            acc[re.sub(r"\(.*", "", r["Kernel_Name"]).strip()].append(float(r["Counter_Value"]))
     return {k: (len(v), sum(v) / len(v)) for k, v in acc.items()}
 
 
-fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
-write = per_kernel(sys.argv[2], "WRITE_SIZE")
-allk = {}
-for k in sorted(fetch):
-    n, f = fetch[k]
-    w = write.get(k, (0, 0.0))[1]
-    allk[k] = {"calls": n, "FETCH_SIZE_KB_avg": f, "WRITE_SIZE_KB_avg": w, "hbm_bytes_corrected": (2 * f + w) * 1024}
-upd = next(v for k, v in allk.items() if "k_update_fused<1, 2, false" in k)
-ones = next((v for k, v in allk.items() if "k_update_fused<1, 2, true" in k), None)
-print(json.dumps({
-    "update_kernel_bytes_per_launch": upd["hbm_bytes_corrected"],
+def config_table(d, tag, cfg):
+    f = os.path.join(d, "%s_%s_pmc_fetch.csv" % (tag, cfg))
+    w = os.path.join(d, "%s_%s_pmc_write.csv" % (tag, cfg))
+    if not (os.path.exists(f) and os.path.exists(w)):
+        return None
+    fetch, write = per_kernel(f, "FETCH_SIZE"), per_kernel(w, "WRITE_SIZE")
+    out = {}
+    for k in sorted(fetch):
+        n, fv = fetch[k]
+        wv = write.get(k, (0, 0.0))[1]
+        out[k] = {"calls": n, "FETCH_SIZE_KB_avg": fv, "WRITE_SIZE_KB_avg": wv, "hbm_bytes_corrected": (2 * fv + wv) * 1024}
+    return out
+
+
+def pick(table, needle):
+    for k, v in table.items():
+        if needle in k:
+            return v
+    return None
+
+
+d, tag = sys.argv[1], sys.argv[2]
+tables = {c: config_table(d, tag, c) for c in ("c2", "c3", "c4", "c5")}
+c2 = tables["c2"] or {}
+upd = pick(c2, "k_update_fused<1, 2, false")
+ones = pick(c2, "k_update_fused<1, 2, true")
+samp = pick(c2, "k_bucket_sample<1")
+res = {
+    "update_kernel_bytes_per_launch": upd and upd["hbm_bytes_corrected"],
+    "sample_kernel_bytes_per_launch": samp and samp["hbm_bytes_corrected"],
     "kernel": "k_update_fused<PRECESSION,2,false,false> (24 B/particle variant)",
     "n_particles": 10000000,
-    "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes (+ --kernel-trace only) over "
-              "`bench.py --steps 40 --warmup 5 --no-cpu-baseline` (tools/refresh_profiles.sh); per-launch averages; "
-              "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: counters are in KB and on gfx950 FETCH_SIZE reports exactly "
-              "half of a coalesced streaming read (MI355X_MICROARCH.md, HBM section) -- confirmed here by k_chunk_sums "
-              "whose read is known (80 MB)",
-    "FETCH_SIZE_KB_avg": upd["FETCH_SIZE_KB_avg"], "WRITE_SIZE_KB_avg": upd["WRITE_SIZE_KB_avg"],
     "algorithmic_bytes_per_launch": 240000000,
-    "ones_variant_bytes_per_launch": None if ones is None else ones["hbm_bytes_corrected"],
-    "all_kernels": allk}, indent=1))
+    "ones_variant_bytes_per_launch": ones and ones["hbm_bytes_corrected"],
+    "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes (+ --kernel-trace only) over the bench "
+              "commands of tools/profile_configs.sh (headline: `bench.py --steps 200 --warmup 20 --no-cpu-baseline "
+              "--no-other-configs`; configs 3-5: `bench.py --only <config>`); per-launch averages; bytes = (2*FETCH_SIZE "
+              "+ WRITE_SIZE)*1024: counters are in KB and on gfx950 FETCH_SIZE reports exactly half of a coalesced "
+              "streaming read (MI355X_MICROARCH.md, HBM section)",
+    "tag": tag,
+    "configs": {c: t for c, t in tables.items() if t},
+}
+print(json.dumps(res, indent=1))
