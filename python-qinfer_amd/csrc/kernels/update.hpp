@@ -135,7 +135,7 @@ struct UpdAcc {
 template <int KIND, int VEC, bool ONES, bool POW>   // ONES: w_in == nullptr stands for all-ones weights; POW: MLEModel
 __global__ __launch_bounds__(QSMC_BLOCK) void k_update_fused(
     const double *__restrict__ x, int64_t ldx, int64_t n, const double *__restrict__ w_in,
-    double *__restrict__ w_out, double prev_norm, ExpArgs e, int64_t outcome, ReduceOut ro) {
+    double *__restrict__ w_out, double prev_norm, ExpArgs e, int64_t outcome, ReduceOut ro, int nt) {
     constexpr int D = Model<KIND>::D;
     constexpr int DMOM = D <= 4 ? D : 0;           // moments ride along for d <= 4
     const int d = (KIND == QSMC_MODEL_TOMOGRAPHY) ? e.d : D;
@@ -159,9 +159,16 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_update_fused(
 #pragma unroll
             for (int u = 0; u < UPD_UNROLL; ++u) {
                 const int64_t i = base + ((int64_t)u * QSMC_BLOCK + threadIdx.x) * 2;
-                if (ONES) { wi[u].x = 1.0; wi[u].y = 1.0; } else wi[u] = *reinterpret_cast<const double2 *>(w_in + i);
+                typedef double nt2 __attribute__((ext_vector_type(2)));
+                if (nt) {               // (uniform) a cloud beyond the Infinity Cache: streaming hints on loads and stores
+                    if (ONES) { wi[u].x = 1.0; wi[u].y = 1.0; } else { const nt2 t = __builtin_nontemporal_load(reinterpret_cast<const nt2 *>(w_in + i)); wi[u].x = t.x; wi[u].y = t.y; }
 #pragma unroll
-                for (int m = 0; m < D; ++m) xv[u][m] = *reinterpret_cast<const double2 *>(x + m * ldx + i);
+                    for (int m = 0; m < D; ++m) { const nt2 t = __builtin_nontemporal_load(reinterpret_cast<const nt2 *>(x + m * ldx + i)); xv[u][m].x = t.x; xv[u][m].y = t.y; }
+                } else {
+                    if (ONES) { wi[u].x = 1.0; wi[u].y = 1.0; } else wi[u] = *reinterpret_cast<const double2 *>(w_in + i);
+#pragma unroll
+                    for (int m = 0; m < D; ++m) xv[u][m] = *reinterpret_cast<const double2 *>(x + m * ldx + i);
+                }
             }
 #pragma unroll
             for (int u = 0; u < UPD_UNROLL; ++u) {
@@ -172,7 +179,15 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_update_fused(
                 double2 wo;
                 wo.x = (wi[u].x * inv_norm) * model_lik<KIND, POW>(p0, e, outcome);
                 wo.y = (wi[u].y * inv_norm) * model_lik<KIND, POW>(p1, e, outcome);
-                *reinterpret_cast<double2 *>(w_out + i) = wo;
+                if (nt) {
+                    typedef double nt2 __attribute__((ext_vector_type(2)));
+                    nt2 t;
+                    t.x = wo.x;
+                    t.y = wo.y;
+                    __builtin_nontemporal_store(t, reinterpret_cast<nt2 *>(w_out + i));
+                } else {
+                    *reinterpret_cast<double2 *>(w_out + i) = wo;
+                }
                 acc.add(wo.x, p0);
                 acc.add(wo.y, p1);
                 tsum += wo.x + wo.y;

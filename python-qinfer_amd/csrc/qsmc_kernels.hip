@@ -382,14 +382,17 @@ static void launch_update(qsmc_ctx *h, bool vec2, int grid, hipStream_t s, const
     // own execution (what rocprofv3 --kernel-trace reports), not launch latency.
     hipEvent_t e0 = nullptr, e1 = nullptr;
     prof_events(h, w_in ? QSMC_PROF_UPDATE : QSMC_PROF_UPDATE_ONES, &e0, &e1);
+    // streaming (non-temporal) hints once the pass no longer fits the 256 MB Infinity Cache: measured at N = 3e7 / 1e8
+    // (d = 1) 128 -> 121 us / 455 -> 420 us; inside the cache they cost ~4 % (41.0 -> 42.5 us at N = 1e7), so not there
+    const int nt = (double)n * (double)(16 + 8 * e.d) > 3.0e8 ? 1 : 0;
 #define LU(V, O)                                                                                          \
     do {                                                                                                  \
         if (e.lik_pow != 0.0)                                                                             \
             hipExtLaunchKernelGGL((k_update_fused<KIND, V, O, true>), dim3(grid), dim3(QSMC_BLOCK), 0, s, e0, e1, 0, \
-                                  x, ldx, n, w_in, w_out, prev_norm, e, outcome, ro);                     \
+                                  x, ldx, n, w_in, w_out, prev_norm, e, outcome, ro, nt);                 \
         else                                                                                              \
             hipExtLaunchKernelGGL((k_update_fused<KIND, V, O, false>), dim3(grid), dim3(QSMC_BLOCK), 0, s, e0, e1, 0, \
-                                  x, ldx, n, w_in, w_out, prev_norm, e, outcome, ro);                     \
+                                  x, ldx, n, w_in, w_out, prev_norm, e, outcome, ro, nt);                 \
     } while (0)
     if (vec2 && w_in) LU(2, false);
     else if (vec2) LU(2, true);
