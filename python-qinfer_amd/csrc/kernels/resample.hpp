@@ -702,6 +702,80 @@ struct StoreLdsGuide {
     }
 };
 
+// ---------------------------------------------------------------------------------------------
+// The chunk's CDF as the samplers hold it in LDS (round 2).  Round 1 kept the 4096 entries in one skewed table with a
+// 2048-cell guide over ALL entries, filled while the entries were stored: ~40 instructions per entry, two thirds of the
+// set-up's 614 instructions per lane (24 us of the d = 1 kernel's 89 at N = 1e7).  The scan already groups the entries by
+// lane -- lane l owns entries 8 l .. 8 l + 7 -- so now:
+//   cdf8[4096]   the entries, unskewed: a lane's eight are 64 contiguous bytes;
+//   tops[512]    entry 8 l + 7 of every lane (skewed index), i.e. the CDF at block granularity;
+//   G[1025]      guide over the TOPS only (1024 cells over the chunk's mass: one guide entry per lane, not eight).
+// A query finds its block among the tops (guide bracket, usually zero or one probe) and then counts the entries of
+// that block that are <= u (four 16-byte LDS reads issued together, eight compares): the same index as an upper bound
+// over all 4096 entries -- tops[s - 1] <= u < tops[s] puts every earlier block below u and every later one above.
+// Entries past the end of a short last chunk read as +inf.
+// ---------------------------------------------------------------------------------------------
+constexpr int TGUIDE_BINS = 1024;
+constexpr int TOPS_N = BUCKET_CHUNK / SCAN_PER_LANE;                 // 512
+constexpr int TOPS_LDS = TOPS_N + (TOPS_N >> 5) + 4;
+__device__ __forceinline__ int tops_skew(int l) { return l + (l >> 5); }
+
+struct StoreLdsTops {
+    double *cdf8, *tops;
+    unsigned short *G;
+    double lo_edge, hi_edge, gscale;
+    bool use_guide;                                // workgroup-uniform
+    int len;
+    int cp;                                        // guide cell of the previous block's top
+    __device__ __forceinline__ void operator()(int j, double v, double prev, bool live) {
+        cdf8[j] = live ? v : INFINITY;
+        const int k = j & (SCAN_PER_LANE - 1), l = j >> 3;
+        if (k == 0) cp = (j == 0 || !use_guide) ? -1 : guide_cell<TGUIDE_BINS>(prev, lo_edge, gscale);
+        if (k != SCAN_PER_LANE - 1) return;
+        const bool has = (j - (SCAN_PER_LANE - 1)) < len;          // the block holds at least one entry of the chunk
+        const double top = live ? v : (has ? hi_edge : INFINITY);  // (a short block ends with the chunk's last entry = hi_edge)
+        tops[tops_skew(l)] = top;
+        if (!use_guide) return;
+        const int lane = threadIdx.x & (QSMC_WAVE - 1);
+        const int cj = has ? guide_cell<TGUIDE_BINS>(top, lo_edge, gscale) : cp;
+        const unsigned short ls = (unsigned short)l;
+        // block l is the first whose top's cell is >= c for every cell c in (cp, cj]: G[c] = l there
+        if (cj > cp) G[cp + 1] = ls;
+        if (cj > cp + 1) G[cp + 2] = ls;
+        if (cj > cp + 2) G[cp + 3] = ls;
+        if (cj > cp + 3) G[cp + 4] = ls;
+        if (has && j + 1 >= len) G[TGUIDE_BINS] = (unsigned short)(l + 1);       // the chunk's last block: #blocks
+        unsigned long long long_runs = __ballot(cj > cp + 4);
+        while (long_runs) {                        // a dominant weight: the wave fills the run together
+            const int src = __ffsll((long long)long_runs) - 1;
+            long_runs &= long_runs - 1;
+            const int s0 = __shfl(cp + 5, src, QSMC_WAVE), e0 = __shfl(cj, src, QSMC_WAVE);
+            const int ll = __shfl(l, src, QSMC_WAVE);
+            for (int c = s0 + lane; c <= e0; c += QSMC_WAVE) G[c] = (unsigned short)ll;
+        }
+    }
+};
+
+// number of entries of the chunk's CDF that are <= u (the caller clamps to len - 1)
+__device__ __forceinline__ int table_upper_bound(const double *cdf8, const double *tops, const unsigned short *G,
+                                                 int n_blocks, bool use_guide, double lo_edge, double gscale, double u) {
+    int lo = 0, hi = n_blocks;
+    if (use_guide) {
+        const int c = guide_cell<TGUIDE_BINS>(u, lo_edge, gscale);
+        lo = G[c];
+        hi = G[c + 1];
+    }
+    while (lo < hi) {                              // # tops <= u
+        const int mid = (lo + hi) >> 1;
+        if (tops[tops_skew(mid)] <= u) lo = mid + 1; else hi = mid;
+    }
+    const int sb = lo < n_blocks ? lo : n_blocks - 1;
+    const double4 a = *reinterpret_cast<const double4 *>(cdf8 + 8 * sb);
+    const double4 b = *reinterpret_cast<const double4 *>(cdf8 + 8 * sb + 4);
+    const int cnt = (a.x <= u) + (a.y <= u) + (a.z <= u) + (a.w <= u) + (b.x <= u) + (b.y <= u) + (b.z <= u) + (b.w <= u);
+    return 8 * sb + cnt;
+}
+
 // The single-pass sampler (d <= 2).  One workgroup per work item.  The chunk's CDF is SCANNED HERE from the weights
 // (bit-identical to k_chunk_scan), so the CDF never touches HBM; every output pair draws its positions, searches, gathers
 // and is kicked in one loop iteration; a particle that fails postselection on its first try is queued for
@@ -723,8 +797,9 @@ __global__ __launch_bounds__(BT) void k_bucket_sample(
     unsigned long long *__restrict__ retry_count, int cap) {
     constexpr int DM = D > 0 ? D : QSMC_MAX_D;
     const int d = D > 0 ? D : d_rt;
-    __shared__ __attribute__((aligned(16))) double lcdf[BUCKET_CHUNK_LDS];
-    __shared__ unsigned short lguide[SGUIDE_BINS + 2];
+    __shared__ __attribute__((aligned(32))) double lcdf[BUCKET_CHUNK];
+    __shared__ double ltops[TOPS_LDS];
+    __shared__ unsigned short lguide[TGUIDE_BINS + 2];
     __shared__ double wave_tot[SCAN_WAVES];
     __shared__ unsigned short rlist[BUCKET_RLIST_CAP];          // slot - o_begin < BUCKET_CAP
     static_assert(BT >= SCAN_THREADS, "the in-sampler chunk scan needs 512 threads");
@@ -741,10 +816,10 @@ __global__ __launch_bounds__(BT) void k_bucket_sample(
     if (threadIdx.x == 0) rcount = 0;
     const double lo_edge = chunk_edge(offsets, c);
     const double hi_edge = offsets[c + 1];
-    const double gscale = (double)SGUIDE_BINS / (hi_edge - lo_edge);
+    const double gscale = (double)TGUIDE_BINS / (hi_edge - lo_edge);
     const bool use_guide = hi_edge > lo_edge && gscale < 1e300;     // workgroup-uniform
     chunk_scan_block(w, n_in, inv_norm, offsets, (int64_t)c, wave_tot,
-                     StoreLdsGuide{lcdf, lguide, lo_edge, gscale, use_guide, len, -1});
+                     StoreLdsTops{lcdf, ltops, lguide, lo_edge, hi_edge, gscale, use_guide, len, -1});
     __syncthreads();
     const int64_t o_begin = slot0 + t0, o_end = slot0 + t1;         // this item's output slots
     unsigned long long failed = 0;
@@ -777,8 +852,7 @@ __global__ __launch_bounds__(BT) void k_bucket_sample(
         for (int e = 0; e < 2; ++e) {
             // position inside this chunk: given the counts, uniform on [lo_edge, hi_edge)
             const double u = lo_edge + upos[e] * (hi_edge - lo_edge);
-            int j = use_guide ? guided_upper_bound(lcdf, len, lguide, guide_cell<SGUIDE_BINS>(u, lo_edge, gscale), u)
-                              : upper_bound_skew(lcdf, len, u);
+            int j = table_upper_bound(lcdf, ltops, lguide, (len + 7) >> 3, use_guide, lo_edge, gscale, u);
             an.jl[e] = j > len - 1 ? len - 1 : j;
             if (EARLY) {
 #pragma unroll
@@ -900,15 +974,16 @@ __global__ __launch_bounds__(BT) void k_bucket_sample_ordered(
     unsigned long long *__restrict__ retry_count, int cap) {
     constexpr int DM = D > 0 ? D : QSMC_MAX_D;
     const int d = D > 0 ? D : d_rt;
-    __shared__ __attribute__((aligned(16))) double lcdf[BUCKET_CHUNK_LDS];
-    __shared__ unsigned short lguide[SGUIDE_BINS + 2];
+    __shared__ __attribute__((aligned(32))) double lcdf[BUCKET_CHUNK];
+    __shared__ double ltops[TOPS_LDS];
+    __shared__ unsigned short lguide[TGUIDE_BINS + 2];
     __shared__ unsigned int cnt2[BUCKET_CHUNK / 2];             // children per source particle, two counters a word
     __shared__ double wave_tot[SCAN_WAVES];
     __shared__ int iwave_tot[SCAN_WAVES];
     __shared__ unsigned int heavy[2 * SMP_HEAVY_CAP];
     __shared__ unsigned short rlist[BUCKET_RLIST_CAP];          // slot - o_begin < cap
     static_assert(BT == SCAN_THREADS, "one lane owns 8 consecutive source particles: 512 threads per chunk");
-    static_assert(BUCKET_CAP * 2 <= BUCKET_CHUNK_LDS * 8, "the ancestor list overlays the CDF");
+    static_assert(BUCKET_CAP * 2 <= BUCKET_CHUNK * 8, "the ancestor list overlays the CDF");
     __shared__ int rcount, hcount;
     __shared__ unsigned long long rbase;
     if ((int)blockIdx.x >= item_off[chunks]) return;
@@ -923,10 +998,10 @@ __global__ __launch_bounds__(BT) void k_bucket_sample_ordered(
     for (int k = threadIdx.x; k < BUCKET_CHUNK / 2; k += BT) cnt2[k] = 0u;
     const double lo_edge = chunk_edge(offsets, c);
     const double hi_edge = offsets[c + 1];
-    const double gscale = (double)SGUIDE_BINS / (hi_edge - lo_edge);
+    const double gscale = (double)TGUIDE_BINS / (hi_edge - lo_edge);
     const bool use_guide = hi_edge > lo_edge && gscale < 1e300;     // workgroup-uniform
     chunk_scan_block(w, n_in, inv_norm, offsets, (int64_t)c, wave_tot,
-                     StoreLdsGuide{lcdf, lguide, lo_edge, gscale, use_guide, len, -1});
+                     StoreLdsTops{lcdf, ltops, lguide, lo_edge, hi_edge, gscale, use_guide, len, -1});
     __syncthreads();
     const int64_t o_begin = slot0 + t0, o_end = slot0 + t1;         // this item's output slots
     const int lane = threadIdx.x & (QSMC_WAVE - 1), wave = threadIdx.x / QSMC_WAVE;
@@ -939,8 +1014,7 @@ __global__ __launch_bounds__(BT) void k_bucket_sample_ordered(
         for (int e = 0; e < 2; ++e) {
             const int64_t o = 2 * P + e;
             const double u = lo_edge + upos[e] * (hi_edge - lo_edge);
-            int j = use_guide ? guided_upper_bound(lcdf, len, lguide, guide_cell<SGUIDE_BINS>(u, lo_edge, gscale), u)
-                              : upper_bound_skew(lcdf, len, u);
+            int j = table_upper_bound(lcdf, ltops, lguide, (len + 7) >> 3, use_guide, lo_edge, gscale, u);
             j = j > len - 1 ? len - 1 : j;
             if (o >= o_begin && o < o_end) atomicAdd(&cnt2[j >> 1], 1u << (16 * (j & 1)));
         }
@@ -1086,8 +1160,9 @@ __global__ __launch_bounds__(BT) void k_bucket_sample16(
     const int *__restrict__ item_off, const int *__restrict__ item_chunk, LWArgs lw, uint32_t k0, uint32_t k1,
     uint32_t epoch, double *__restrict__ x_out, OutPlace pl, int cap) {
     constexpr int DM = 16;
-    __shared__ __attribute__((aligned(16))) double lcdf[BUCKET_CHUNK_LDS];
-    __shared__ unsigned short lguide[SGUIDE_BINS + 2];
+    __shared__ __attribute__((aligned(32))) double lcdf[BUCKET_CHUNK];
+    __shared__ double ltops[TOPS_LDS];
+    __shared__ unsigned short lguide[TGUIDE_BINS + 2];
     __shared__ double wave_tot[SCAN_WAVES];
     __shared__ int iwave_tot[SCAN_WAVES];
     __shared__ double sS[DM * DM + DM];                             // S (row-major) and the mean
@@ -1112,14 +1187,14 @@ __global__ __launch_bounds__(BT) void k_bucket_sample16(
     const int len = (int)((n_in - base) < BUCKET_CHUNK ? (n_in - base) : BUCKET_CHUNK);
     const double lo_edge = chunk_edge(offsets, c);
     const double hi_edge = offsets[c + 1];
-    const double gscale = (double)SGUIDE_BINS / (hi_edge - lo_edge);
+    const double gscale = (double)TGUIDE_BINS / (hi_edge - lo_edge);
     const bool use_guide = hi_edge > lo_edge && gscale < 1e300;     // workgroup-uniform
     for (int k = threadIdx.x; k < DM * DM; k += BT) sS[k] = lw.S[k];
     if (threadIdx.x < DM) sS[DM * DM + threadIdx.x] = lw.mean[threadIdx.x];
     for (int k = threadIdx.x; k < BUCKET_CHUNK; k += BT) cnt[k] = 0u;
     if (threadIdx.x == 0) hcount = 0;
     chunk_scan_block(w, n_in, inv_norm, offsets, (int64_t)c, wave_tot,
-                     StoreLdsGuide{lcdf, lguide, lo_edge, gscale, use_guide, len, -1});
+                     StoreLdsTops{lcdf, ltops, lguide, lo_edge, hi_edge, gscale, use_guide, len, -1});
     __syncthreads();
     const int64_t o_begin = slot0 + t0, o_end = slot0 + t1;
     const int q = (int)(o_end - o_begin);
@@ -1134,8 +1209,7 @@ __global__ __launch_bounds__(BT) void k_bucket_sample16(
         for (int e = 0; e < 2; ++e) {
             const int64_t o = 2 * P + e;
             const double u = lo_edge + upos[e] * (hi_edge - lo_edge);
-            int j = use_guide ? guided_upper_bound(lcdf, len, lguide, guide_cell<SGUIDE_BINS>(u, lo_edge, gscale), u)
-                              : upper_bound_skew(lcdf, len, u);
+            int j = table_upper_bound(lcdf, ltops, lguide, (len + 7) >> 3, use_guide, lo_edge, gscale, u);
             j = j > len - 1 ? len - 1 : j;
             if (o >= o_begin && o < o_end) atomicAdd(&cnt[j], 1u);
         }
