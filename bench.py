@@ -200,6 +200,19 @@ def other_config_specs(qi):
                       workload="2-qubit TomographyModel (15 free params), 1.25e6 particles (1e7 / 8 GPUs), Ginibre prior, "
                                "random Pauli measurements",
                       update_kernel="k_update_fused<TOMOGRAPHY,1,false>", sampler="k_bucket_sample<16,512>"))
+    # (not a BASELINE config, not in the default run: `--only extra_binomial_rb` -- the model simple_est_rb builds)
+    m = qi.BinomialModel(qi.RandomizedBenchmarkingModel())
+    eps, outs = [], []
+    for k in range(K):
+        ep = np.empty((1,), dtype=m.expparams_dtype)
+        ep['m'] = 1 + 5 * k
+        ep['n_meas'] = 25
+        eps.append(ep)
+        outs.append(int(rs.binomial(25, 0.3 * 0.95 ** (1 + 5 * k) + 0.5)))
+    specs.append(dict(key="extra_binomial_rb", model=m, n=12_500_000, d=3, extra=True,
+                      prior=lambda m=m: qi.PostselectedDistribution(qi.UniformDistribution([[0.8, 1], [0, 1], [0, 1]]), m),
+                      eps=eps, outs=outs, workload="BinomialModel(RandomizedBenchmarkingModel) n_meas=25, 1.25e7 particles",
+                      update_kernel="k_update_fused<BINOMIAL_RB,1,false>", sampler="k_bucket_sample_ordered<3,512>"))
     return specs
 
 
@@ -446,6 +459,8 @@ def main():
                 extras["roofline_beyond_l3"] = {"error": repr(e)}
             oc = {}
             for spec in other_config_specs(qi):
+                if spec.get("extra"):
+                    continue
                 try:
                     oc[spec["key"]] = run_other_config(qi, eng, torch, spec, min(args.warmup, 5))
                 except Exception as e:  # noqa: BLE001

@@ -198,21 +198,37 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_update_fused(
             const int64_t i = base + ((int64_t)u * QSMC_BLOCK + threadIdx.x) * VEC;
             if (VEC == 2) {
                 if (i + 1 < n) {
+                    typedef double nt2g __attribute__((ext_vector_type(2)));
                     double2 wi;
-                    if (ONES) { wi.x = 1.0; wi.y = 1.0; } else wi = *reinterpret_cast<const double2 *>(w_in + i);
+                    if (ONES) { wi.x = 1.0; wi.y = 1.0; }
+                    else if (nt) { const nt2g t = __builtin_nontemporal_load(reinterpret_cast<const nt2g *>(w_in + i)); wi.x = t.x; wi.y = t.y; }
+                    else wi = *reinterpret_cast<const double2 *>(w_in + i);
                     double p0[D], p1[D];
 #pragma unroll
                     for (int m = 0; m < D; ++m) {
                         if (m < d) {
-                            const double2 xv = *reinterpret_cast<const double2 *>(x + m * ldx + i);
-                            p0[m] = xv.x;
-                            p1[m] = xv.y;
+                            if (nt) {
+                                const nt2g t = __builtin_nontemporal_load(reinterpret_cast<const nt2g *>(x + m * ldx + i));
+                                p0[m] = t.x;
+                                p1[m] = t.y;
+                            } else {
+                                const double2 xv = *reinterpret_cast<const double2 *>(x + m * ldx + i);
+                                p0[m] = xv.x;
+                                p1[m] = xv.y;
+                            }
                         }
                     }
                     double2 wo;
                     wo.x = (wi.x * inv_norm) * model_lik<KIND, POW>(p0, e, outcome);
                     wo.y = (wi.y * inv_norm) * model_lik<KIND, POW>(p1, e, outcome);
-                    *reinterpret_cast<double2 *>(w_out + i) = wo;
+                    if (nt) {
+                        nt2g t;
+                        t.x = wo.x;
+                        t.y = wo.y;
+                        __builtin_nontemporal_store(t, reinterpret_cast<nt2g *>(w_out + i));
+                    } else {
+                        *reinterpret_cast<double2 *>(w_out + i) = wo;
+                    }
                     acc.add(wo.x, p0);
                     acc.add(wo.y, p1);
                     tsum += wo.x + wo.y;

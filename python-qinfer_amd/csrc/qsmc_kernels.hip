@@ -384,7 +384,8 @@ static void launch_update(qsmc_ctx *h, bool vec2, int grid, hipStream_t s, const
     prof_events(h, w_in ? QSMC_PROF_UPDATE : QSMC_PROF_UPDATE_ONES, &e0, &e1);
     // streaming (non-temporal) hints once the pass no longer fits the 256 MB Infinity Cache: measured at N = 3e7 / 1e8
     // (d = 1) 128 -> 121 us / 455 -> 420 us; inside the cache they cost ~4 % (41.0 -> 42.5 us at N = 1e7), so not there
-    const int nt = (double)n * (double)(16 + 8 * e.d) > 3.0e8 ? 1 : 0;
+    static const bool no_nt = getenv("QSMC_NO_NT") != nullptr;                    // (A/B switch)
+    const int nt = (!no_nt && (double)n * (double)(16 + 8 * e.d) > 3.0e8) ? 1 : 0;
 #define LU(V, O)                                                                                          \
     do {                                                                                                  \
         if (e.lik_pow != 0.0)                                                                             \
