@@ -377,12 +377,13 @@ def main():
         barrier()
         return time.perf_counter() - t0
 
-    rccl_pass = None
-    if ((world > 1 or os.environ.get("QSMC_BENCH_FORCE_RCCL_PASS")) and not share_gpu and comm is not None
-            and comm.transport != "rccl" and not os.environ.get("QSMC_BENCH_NO_RCCL_PASS")):
-        # The same workload once more with the library's own RCCL all-reduce on the launch stream carrying the
-        # per-datum reduction (north_star's transport; the headline below uses whatever ParticleShardGroup picked,
-        # host shared memory on one node).  Reported beside the headline, never as `value`.
+    def rccl_transport_pass():
+        """The same workload once more with the library's own RCCL all-reduce on the launch stream carrying the
+        per-datum reduction (north_star's transport; the headline uses whatever ParticleShardGroup picked -- host shared
+        memory on one node).  Runs AFTER the JSON line is printed and reports on stderr, so the bench line never waits on
+        it; a watchdog ends the process should a collective hang."""
+        import threading
+        threading.Timer(float(os.environ.get("QSMC_BENCH_RCCL_DEADLINE", "120")), lambda: os._exit(0)).start()
         try:
             from qinfer_amd.parallel import ParticleShardGroup
             with warnings.catch_warnings():
@@ -394,14 +395,15 @@ def main():
                 wr = torch.tensor([wall_r], dtype=torch.float64, device="cuda")
                 if world > 1:
                     torch.distributed.all_reduce(wr, op=torch.distributed.ReduceOp.MAX)
-                rccl_pass = {"per_datum_collective": comm_r.transport_name, "value": n * world * args.steps / float(wr.item()),
-                             "ms_per_step": float(wr.item()) / args.steps * 1e3, "resamples": upd_r.resample_count,
-                             "posterior_mean": float(upd_r.est_mean()[0])}
-                del upd_r
+                res = {"per_datum_collective": comm_r.transport_name, "n_gpus": world,
+                       "value": n * world * args.steps / float(wr.item()),
+                       "ms_per_step": float(wr.item()) / args.steps * 1e3, "resamples": upd_r.resample_count,
+                       "posterior_mean": float(upd_r.est_mean()[0])}
                 comm_r.close()
-                torch.cuda.empty_cache()
         except Exception as e:  # noqa: BLE001
-            rccl_pass = {"error": repr(e)}
+            res = {"error": repr(e)}
+        if rank == 0:
+            print("RCCL_TRANSPORT_PASS " + json.dumps(res), file=sys.stderr, flush=True)
 
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
@@ -540,17 +542,20 @@ def main():
                 line["roofline"]["census_avg_kernel_us"] = census["update"]["avg_us"]
                 line["roofline"]["census_launches"] = census["update"]["launches"]
         line.update(extras)
-        if rccl_pass is not None:
-            line["rccl_transport_pass"] = rccl_pass
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(n, args.cpu_data, gpu_same_sample)
             except Exception as e:  # noqa: BLE001
                 line["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(line), flush=True)
+    if ((world > 1 or os.environ.get("QSMC_BENCH_FORCE_RCCL_PASS")) and not share_gpu and comm is not None
+            and comm.transport != "rccl" and not os.environ.get("QSMC_BENCH_NO_RCCL_PASS")):
+        rccl_transport_pass()
     if world > 1 or args.force_comm:
         comm.close()
         torch.distributed.destroy_process_group()
+    if ((world > 1 or os.environ.get("QSMC_BENCH_FORCE_RCCL_PASS")) and not share_gpu and comm is not None):
+        os._exit(0)                                   # (the watchdog timer thread must not keep the process alive)
 
 
 if __name__ == "__main__":
