@@ -1570,10 +1570,15 @@ int qsmc_comm_destroy(qsmc_handle_t h) {
 
 __global__ void k_publish_allreduce(const double *__restrict__ sums, const double *__restrict__ mn, const double *__restrict__ firsts,
                                     int n, int min_index, int nranks, double *__restrict__ mapped, unsigned long long *flag,
-                                    unsigned long long seq) {
+                                    unsigned long long seq, const unsigned long long *__restrict__ counters,
+                                    double *__restrict__ failed_dst) {
     const int t = threadIdx.x;
     if (t < n) mapped[t] = t == min_index ? mn[0] : sums[t];
     if (t < nranks) mapped[n + t] = firsts[t];
+    if (t == 0) {                    // like every host-visible reduction: the last resample's failed / redraw counts ride along
+        failed_dst[0] = (double)counters[0];
+        failed_dst[-1] = (double)counters[1];
+    }
     __syncthreads();
     if (t == 0) {
         __threadfence_system();
@@ -1599,7 +1604,8 @@ int qsmc_allreduce_sums(qsmc_handle_t h, const double *vec_dev, int32_t n, int32
     }
     const unsigned long long seq = ++h->seq;
     hipLaunchKernelGGL(k_publish_allreduce, dim3(1), dim3(256), 0, s, sums, mn, firsts, (int)n, (int)min_index, h->cc.nranks,
-                       h->mapped_dev, h->flag_dev, seq);
+                       h->mapped_dev, h->flag_dev, seq, reinterpret_cast<const unsigned long long *>(h->counter),
+                       h->mapped_dev + (REDUCE_OUT_MAX - 1));
     HIP_TRY(h, hipGetLastError());
     // a collective can take arbitrarily long when a peer is late: no 20 ms spin window here, wait for the stream
     volatile unsigned long long *f = h->flag;
