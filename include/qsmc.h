@@ -111,6 +111,7 @@ int         qsmc_profile_read(qsmc_handle_t h, float *ms_out, int32_t *tags_out,
 #define QSMC_PROF_CANON_LIST 4     /* tomography canonicalize, pass 2 (k_tomo_canon_list) */
 #define QSMC_PROF_MOMENTS 5        /* weighted moments, 4 < d <= 16 (k_moments_mfma) */
 #define QSMC_PROF_COUNTS 6         /* the resampler's chunk counts + plan launch (k_bucket_counts) */
+#define QSMC_PROF_COUNTS_SKIPPED 7 /* a speculative k_bucket_counts that left at its gate (qsmc_lw_arm_prefix) */
 #define QSMC_PROF_NTAGS 8
 
 /* ---- likelihood, contract form (abstract_model.py:444-468 + :666-686; a6-a10) ------------ */
@@ -322,6 +323,21 @@ int qsmc_lw_use_update_sums(qsmc_handle_t h, uint64_t update_token);
  * changes weights, simply redo the prefix -- results are identical either way. */
 int qsmc_lw_resample_prepare(qsmc_handle_t h, const double *w, int64_t n_in, double norm, int64_t n_out,
                              uint64_t seed, uint64_t epoch, qsmc_stream_t stream);
+
+/* (smc.py:263-277: the n_ess test that decides on a resample, taken on the device)
+ * enabled != 0: every later qsmc_update_fused with host-visible statistics queues that same weight-only prefix for
+ * (n_out, seed, epoch) right behind its reducing kernel, gated ON THE DEVICE by the test the host is about to make
+ * -- (sum w')^2 / sum w'^2 < ess_below, no negative weight, |sum w'| not below machine epsilon -- with the same IEEE
+ * operations on the same sums.  A closed gate costs a ~3 us launch that leaves at once, inside the host's round
+ * trip; an open one has the counts and the plan under way while the host still waits for the update's statistics.
+ * qsmc_lw_resample_prepare / qsmc_lw_resample_philox with matching arguments (and the caller's qsmc_lw_use_update_sums
+ * vouching for the weights) then find the prefix done; with anything different they redo it as before -- the device's
+ * decision never replaces the caller's, it only starts early the work the caller is about to ask for.  Same counts,
+ * same particles either way.  Re-arm after every resample (the epoch moves on); enabled = 0 stops it. */
+int qsmc_lw_arm_prefix(qsmc_handle_t h, int32_t enabled, double ess_below, int64_t n_out, uint64_t seed,
+                       uint64_t epoch);
+/* how many prefixes were queued that way on this handle, and how many resamples found theirs done */
+int qsmc_lw_prefix_stats(qsmc_handle_t h, int64_t *n_queued, int64_t *n_adopted);
 
 /* qsmc_lw_resample_philox with n_failed_host == NULL does not synchronise: the failed-particle count
  * is written to pinned host memory by the stream; read it here once `stream` has been synchronised by

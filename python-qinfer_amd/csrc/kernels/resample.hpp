@@ -501,8 +501,18 @@ __global__ __launch_bounds__(BUCKET_COUNTS_THREADS) void k_bucket_counts(
     double *offsets, TileSrc ts, unsigned long long *__restrict__ zero2, int chunks, int64_t n_out, double lambda,
     uint32_t k0, uint32_t k1, uint32_t epoch, unsigned int *counts, unsigned int *extra,
     long long *__restrict__ slot_off, int *__restrict__ item_off, int *__restrict__ item_chunk,
-    unsigned long long *bar, unsigned long long bar_base, int cap) {
+    unsigned long long *bar, unsigned long long bar_base, int cap, const int *__restrict__ gate,
+    const double *__restrict__ norm_dev) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (gate) {
+        // queued speculatively behind an update (qsmc_lw_arm_prefix): the reducing kernel decided whether a resample
+        // is due.  Not due: leave at once, having made this launch's two barrier arrivals (the counter only grows).
+        if (*gate == 0) {
+            if (threadIdx.x == 0) __hip_atomic_fetch_add(bar, 2ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        ts.inv_norm = 1.0 / *norm_dev;             // sum w' of that update, as the host will pass it to the sampler
+    }
     double *edges = reinterpret_cast<double *>(smem);
     unsigned int *hist = reinterpret_cast<unsigned int *>(edges + lds_skew(chunks) + 4);   // this workgroup's draws per chunk
     __shared__ unsigned long long total_s;

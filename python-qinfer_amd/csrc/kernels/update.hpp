@@ -27,7 +27,12 @@ struct ReduceOut {
     const unsigned long long *failed_src;   // the resampler's failed-particle counter (device) ...
     double *failed_dst;                     // ... copied to its pinned slot by every host-visible reduction
     double *tile_sums;                      // k_update_fused only: sum of w' per TILE particles (nullable)
+    int *prefix_gate;                       // k_update_fused only: device word for the resample-prefix gate (nullable) ...
+    double prefix_thresh;                   // ... opened when (sum w')^2 / sum w'^2 < prefix_thresh and no guard is due
 };
+
+// |sum w'| below this and the host renormalises by 1 instead (smc.py:369-370): no speculative prefix then
+constexpr double PREFIX_NORM_EPS = 2.220446049250313e-16;
 
 template <int NS>
 __device__ __forceinline__ void block_publish(double (&v)[NS], double mn, const ReduceOut &ro) {
@@ -94,6 +99,20 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_reduce_partials(int nblocks, Red
         if (ro.failed_dst) {
             ro.failed_dst[0] = (double)ro.failed_src[0];
             ro.failed_dst[-1] = (double)ro.failed_src[1];       // how many outputs of that resample needed a global redraw
+        }
+        if (ro.prefix_gate) {
+            // The host's resample test (smc.py:263-277 via n_ess = 1 / sum w^2 of the normalised weights), taken here
+            // with the same three IEEE operations on the same two sums, so that the weight-only prefix of the
+            // resampler (k_bucket_counts, queued right behind this kernel) starts NOW instead of a host round trip
+            // later.  The gate and the normaliser it used are published: the host takes the prefix as done only if
+            // both agree with its own decision and numbers, else it queues the prefix itself as before.
+            const double ess = acc[0] * acc[0] / acc[1];
+            const int open = (acc[2] == 0.0 && fabs(acc[0]) >= PREFIX_NORM_EPS && ess < ro.prefix_thresh) ? 1 : 0;
+            *ro.prefix_gate = open;
+            if (ro.failed_dst) {
+                ro.failed_dst[-2] = (double)open;
+                ro.failed_dst[-3] = acc[0];
+            }
         }
         if (ro.flag) {                   // the host spins on this word instead of hipStreamSynchronize
             __threadfence_system();

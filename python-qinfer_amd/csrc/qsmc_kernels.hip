@@ -78,6 +78,19 @@ struct qsmc_ctx {
         uint64_t seed, epoch;
         hipStream_t stream;
     } prep;
+    struct {                       // the prefix queued speculatively behind every update (qsmc_lw_arm_prefix)
+        int enabled;
+        double thresh;             // resample when (sum w')^2 / sum w'^2 < thresh
+        int64_t n_out;
+        uint64_t seed, epoch;
+        int *gate;                 // device word the reducing kernel sets, the count kernel reads
+        int launched;              // a speculative prefix followed update number `gen` ...
+        unsigned long long gen;
+        const double *w;           // ... of these weights
+        int64_t n_in;
+        int prof_slot;             // profiling-ring entry of that launch (-1: not timed)
+        long long n_queued, n_adopted;   // speculative launches so far / resamples that found theirs done
+    } spec;
     unsigned int *iscratch; // device integer scratch for the bucketed resampler
     size_t iscratch_cap;    // in bytes
     double *cdf_scratch;    // device CDF, materialised only for the direct sampler / global redraws
@@ -307,6 +320,8 @@ static ReduceOut make_reduce(qsmc_ctx *h, bool want_host, double *stats4) {
     ro.failed_src = reinterpret_cast<const unsigned long long *>(h->counter);
     ro.failed_dst = want_host ? h->mapped_dev + (REDUCE_OUT_MAX - 1) : nullptr;
     ro.tile_sums = nullptr;
+    ro.prefix_gate = nullptr;
+    ro.prefix_thresh = 0.0;
     return ro;
 }
 
@@ -353,6 +368,10 @@ static int collect_stats(qsmc_ctx *h, int ns, qsmc_update_stats_t *stats_host, d
     if (!stats_host && !extra_host) return QSMC_OK;
     const int rc = wait_reduction(h, s);
     if (rc) return rc;
+    if (h->spec.prof_slot >= 0) {          // the timed count launch behind this update left at its gate: not a count
+        if (h->spec.launched && h->mapped[REDUCE_OUT_MAX - 3] != 1.0) h->prof_tag[h->spec.prof_slot] = QSMC_PROF_COUNTS_SKIPPED;
+        h->spec.prof_slot = -1;
+    }
     if (stats_host) {
         stats_host->sum = h->mapped[0];
         stats_host->sumsq = h->mapped[1];
@@ -423,7 +442,7 @@ static int hyp_launch(qsmc_ctx *h, const qsmc_model_t *model, const double *x, i
     constexpr int D = Model<KIND>::D <= 4 ? Model<KIND>::D : 0;
     constexpr int PER = 2 + 2 * D;
     constexpr int NS = NO * PER;
-    static_assert(NS + 1 <= REDUCE_OUT_MAX - 2, "reduce buffers too small");
+    static_assert(NS + 1 <= REDUCE_OUT_MAX - 4, "reduce buffers too small");
     const int grid = grid_for(n, QSMC_BLOCK * 4);
     int rc = ensure_partials(h, (size_t)grid * (NS + 1));
     if (rc) return rc;
@@ -536,6 +555,9 @@ int qsmc_create(qsmc_handle_t *out, int device) {
     if (e == hipSuccess) e = hipMemset(h->counter, 0, 2 * sizeof(long long));
     if (e == hipSuccess) e = hipMalloc(&h->gbar, 4 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(h->gbar, 0, 4 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc(&h->spec.gate, sizeof(int));
+    if (e == hipSuccess) e = hipMemset(h->spec.gate, 0, sizeof(int));
+    h->spec.prof_slot = -1;
     if (e == hipSuccess) e = hipMalloc(&h->red_out, REDUCE_OUT_MAX * sizeof(double));
     if (e == hipSuccess) e = hipHostMalloc(&h->mapped, REDUCE_OUT_MAX * sizeof(double), hipHostMallocMapped);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&h->mapped_dev, h->mapped, 0);
@@ -567,6 +589,7 @@ int qsmc_destroy(qsmc_handle_t h) {
     if (h->pinned) (void)hipHostFree(h->pinned);
     if (h->counter) (void)hipFree(h->counter);
     if (h->gbar) (void)hipFree(h->gbar);
+    if (h->spec.gate) (void)hipFree(h->spec.gate);
     if (h->iscratch) (void)hipFree(h->iscratch);
     if (h->cdf_scratch) (void)hipFree(h->cdf_scratch);
     if (h->red_out) (void)hipFree(h->red_out);
@@ -679,6 +702,9 @@ int qsmc_are_models_valid(qsmc_handle_t h, const qsmc_model_t *model, const doub
     return QSMC_OK;
 }
 
+static int resample_prefix(qsmc_ctx *h, const double *w, int64_t n_in, double norm, int64_t n_out, uint64_t seed,
+                           uint64_t epoch, hipStream_t s, bool speculative);
+
 int qsmc_update_fused(qsmc_handle_t h, const qsmc_model_t *model, const double *x, int64_t ldx, int64_t n,
                       const double *w_in, double *w_out, double prev_norm, const qsmc_expparam_t *exp,
                       int64_t outcome, double *stats_dev, qsmc_update_stats_t *stats_host, double *moments_host,
@@ -714,6 +740,12 @@ int qsmc_update_fused(qsmc_handle_t h, const qsmc_model_t *model, const double *
     }
     ++h->ts.gen;
     h->ts.armed = 0;
+    h->spec.launched = 0;
+    if (h->spec.enabled && ro.tile_sums && ro.failed_dst) {
+        // the resampler's weight-only prefix goes out right behind the reduction, gated on the device-side ESS test
+        ro.prefix_gate = h->spec.gate;
+        ro.prefix_thresh = h->spec.thresh;
+    }
     switch (model->kind) {
 #define LAUNCH_U(K)                                                                             \
     case K:                                                                                     \
@@ -732,7 +764,29 @@ int qsmc_update_fused(qsmc_handle_t h, const qsmc_model_t *model, const double *
     HIP_TRY(h, hipGetLastError());
     rc = launch_reduce(h, ns, grid, ro, s);
     if (rc) return rc;
+    if (ro.prefix_gate) {
+        rc = resample_prefix(h, w_out, n, 0.0, h->spec.n_out, h->spec.seed, h->spec.epoch, s, true);
+        if (rc) return rc;
+    }
     return collect_stats(h, ns, stats_host, moments_host, n_mom, s);
+}
+
+int qsmc_lw_arm_prefix(qsmc_handle_t h, int32_t enabled, double ess_below, int64_t n_out, uint64_t seed, uint64_t epoch) {
+    if (!h || (enabled && (n_out <= 0 || !(ess_below == ess_below)))) return QSMC_ERR_INVALID;
+    static const bool never = getenv("QSMC_NO_SPECULATIVE_PREFIX") != nullptr;     // (A/B switch)
+    h->spec.enabled = enabled && !never;
+    h->spec.thresh = ess_below;
+    h->spec.n_out = n_out;
+    h->spec.seed = seed;
+    h->spec.epoch = epoch;
+    return QSMC_OK;
+}
+
+int qsmc_lw_prefix_stats(qsmc_handle_t h, int64_t *n_queued, int64_t *n_adopted) {
+    if (!h || !n_queued || !n_adopted) return QSMC_ERR_INVALID;
+    *n_queued = h->spec.n_queued;
+    *n_adopted = h->spec.n_adopted;
+    return QSMC_OK;
 }
 
 int qsmc_update_multi(qsmc_handle_t h, const qsmc_model_t *model, const double *x, int64_t ldx, int64_t n,
@@ -1075,22 +1129,38 @@ static void philox_keys(uint64_t seed, uint64_t epoch, uint32_t *k0, uint32_t *k
 // The part of a device-RNG resample that needs only the weights: chunk sums -> monotone offsets, the
 // zeroed counters and (bucketed sampler) the multinomial chunk counts and the work-item plan.  It can
 // be queued the moment the n_ess test fails, before the host has formed mean / covariance / sqrtm.
+// speculative = true: called by qsmc_update_fused itself right behind the reducing kernel (qsmc_lw_arm_prefix): the
+// count kernel is gated on the device-side resample test and takes the normaliser from device memory; only the
+// one-launch form (tile sums -> edges -> counts -> plan) is ever queued this way.
 static int resample_prefix(qsmc_ctx *h, const double *w, int64_t n_in, double norm, int64_t n_out, uint64_t seed,
-                           uint64_t epoch, hipStream_t s) {
+                           uint64_t epoch, hipStream_t s, bool speculative) {
+    if (!speculative && h->spec.launched) {
+        // the update that wrote these weights queued this very prefix behind itself and its gate opened: done already
+        // (everything the host would pass now is compared with what the device used; any difference -> redo it here)
+        h->spec.launched = 0;
+        if (h->spec.gen == h->ts.gen && h->ts.armed == h->ts.gen && w && w == h->spec.w && h->ts.w == w &&
+            n_in == h->spec.n_in &&
+            n_out == h->spec.n_out && seed == h->spec.seed && epoch == h->spec.epoch &&
+            h->mapped[REDUCE_OUT_MAX - 3] == 1.0 && h->mapped[REDUCE_OUT_MAX - 4] == norm) {
+            h->ts.armed = 0;
+            ++h->spec.n_adopted;
+            return QSMC_OK;
+        }
+    }
     uint32_t k0, k1, ep;
     philox_keys(seed, epoch, &k0, &k1, &ep);
     const int64_t chunks64 = (n_in + BUCKET_CHUNK - 1) / BUCKET_CHUNK;
     int rc = ensure_rs_offsets(h, (size_t)chunks64 + 1);
     if (rc) return rc;
     double *offsets = h->rs_offsets;
-    const double inv_norm = 1.0 / norm;
+    const double inv_norm = speculative ? 0.0 : 1.0 / norm;
     // chunk sums: from the tile sums of the update that produced these very weights, if the caller vouches for
     // that (qsmc_lw_use_update_sums) and nothing has touched them since; else one pass over the weights
     TileSrc ts{nullptr, 0, 0, 0.0};
-    if (h->ts.armed && h->ts.armed == h->ts.gen && w && h->ts.w == w && h->ts.n == n_in)
+    if ((speculative || (h->ts.armed && h->ts.armed == h->ts.gen)) && w && h->ts.w == w && h->ts.n == n_in)
         ts = TileSrc{h->tile_sums, BUCKET_CHUNK / h->ts.tile * QSMC_WAVES_PER_BLOCK,
                      (n_in + h->ts.tile - 1) / h->ts.tile * QSMC_WAVES_PER_BLOCK, inv_norm};
-    h->ts.armed = 0;
+    if (!speculative) h->ts.armed = 0;
     BucketPlan bp;
     rc = bucket_plan_layout(h, chunks64, n_out, &bp);
     if (rc) return rc;
@@ -1100,6 +1170,7 @@ static int resample_prefix(qsmc_ctx *h, const double *w, int64_t n_in, double no
     const bool count_by_draws = count_by_draws_env || h->cu_count < BUCKET_COUNTS_BLOCKS;
     // with tile sums the bucketed count kernel forms the offsets itself; otherwise: chunk sums, then the scan
     const bool scan_in_counts = ts.tiles && bp.bucketed && !count_by_draws;
+    if (speculative && !scan_in_counts) return QSMC_OK;         // nothing queued (h->spec.launched stays 0)
     if (!ts.tiles)
         hipLaunchKernelGGL(k_chunk_sums, dim3((unsigned)chunks64), dim3(QSMC_BLOCK), 0, s, w, n_in, inv_norm, offsets);
     if (scan_in_counts) {
@@ -1144,12 +1215,23 @@ static int resample_prefix(qsmc_ctx *h, const double *w, int64_t n_in, double no
             }
             unsigned int *extra = bp.hist;                       // (the histogram rows are not used on this path)
             hipEvent_t q0 = nullptr, q1 = nullptr;
+            const int ring_before = h->prof_n;
             prof_events(h, QSMC_PROF_COUNTS, &q0, &q1);
             hipExtLaunchKernelGGL(k_bucket_counts, dim3(BUCKET_COUNTS_BLOCKS), dim3(BUCKET_COUNTS_THREADS), lds, s, q0, q1, 0, offsets,
                                scan_in_counts ? ts : TileSrc{nullptr, 0, 0, 0.0},
                                reinterpret_cast<unsigned long long *>(h->counter), chunks, n_out, lambda, k0, k1, ep,
-                               bp.counts, extra, bp.slot_off, bp.item_off, bp.item_chunk, h->gbar, h->gbar_base, bp.cap);
+                               bp.counts, extra, bp.slot_off, bp.item_off, bp.item_chunk, h->gbar, h->gbar_base, bp.cap,
+                               speculative ? h->spec.gate : (const int *)nullptr,
+                               speculative ? h->red_out : (const double *)nullptr);
             h->gbar_base += 2ull * BUCKET_COUNTS_BLOCKS;
+            if (speculative) {
+                h->spec.launched = 1;
+                ++h->spec.n_queued;
+                h->spec.gen = h->ts.gen;
+                h->spec.w = w;
+                h->spec.n_in = n_in;
+                h->spec.prof_slot = (q0 && h->prof_n != ring_before) ? ring_before % QSMC_PROF_CAP : -1;
+            }
         }
     }
     HIP_TRY(h, hipGetLastError());
@@ -1175,7 +1257,7 @@ static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int3
     h->prep.valid = 0;
     int rc = QSMC_OK;
     if (!prepared) {
-        rc = resample_prefix(h, w, n_in, norm, n_out, seed, epoch, s);
+        rc = resample_prefix(h, w, n_in, norm, n_out, seed, epoch, s, false);
         if (rc) return rc;
     }
     double *offsets = h->rs_offsets;
@@ -1277,7 +1359,7 @@ int qsmc_lw_resample_prepare(qsmc_handle_t h, const double *w, int64_t n_in, dou
     if (!h || n_in <= 0 || n_out <= 0 || !(norm > 0.0)) return QSMC_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
     h->prep.valid = 0;
-    const int rc = resample_prefix(h, w, n_in, norm, n_out, seed, epoch, s);
+    const int rc = resample_prefix(h, w, n_in, norm, n_out, seed, epoch, s, false);
     if (rc) return rc;
     h->prep.valid = 1;
     h->prep.w = w;

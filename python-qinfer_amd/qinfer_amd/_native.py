@@ -84,6 +84,8 @@ SIGNATURES = {
     "qsmc_update_token": [_P, C.POINTER(_U64)],
     "qsmc_lw_use_update_sums": [_P, _U64],
     "qsmc_lw_resample_prepare": [_P, _P, _I64, _F64, _I64, _U64, _U64, _P],
+    "qsmc_lw_arm_prefix": [_P, _I32, _F64, _I64, _U64, _U64],
+    "qsmc_lw_prefix_stats": [_P, C.POINTER(_I64), C.POINTER(_I64)],
     "qsmc_last_resample_failed": [_P, C.POINTER(_I64), _I32, _P],
     "qsmc_lw_resample_philox_sharded": [_P, C.POINTER(ModelDesc), _I32, _P, _I64, _I64, _I32, _P, _F64, _F64,
                                         C.POINTER(_F64), C.POINTER(_F64), C.POINTER(_I64), _I32, _U64, _U64,
@@ -136,9 +138,19 @@ def check(handle, rc, what):
         raise RuntimeError("{} failed: {} {}".format(what, msg, detail))
 
 
+_F64_ARRAYS = {}
+
+
 def f64_ptr(a):
     """Pointer to a C-contiguous float64 NumPy array (kept alive by the caller)."""
     assert a.dtype == np.float64 and a.flags.c_contiguous
+    if a.flags.writeable and a.size:
+        # a ctypes array over the same buffer converts to POINTER(c_double) at the call: 0.4 us against the 2.1 us of
+        # ndarray.ctypes.data_as -- these sit on the resample path, four to a call
+        t = _F64_ARRAYS.get(a.size)
+        if t is None:
+            t = _F64_ARRAYS[a.size] = _F64 * a.size
+        return t.from_buffer(a)
     return a.ctypes.data_as(C.POINTER(_F64))
 
 

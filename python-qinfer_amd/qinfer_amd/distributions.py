@@ -12,6 +12,7 @@ Its `particle_locations` / `particle_weights` properties materialise NumPy copie
 reference's layout ((N, d) C-order, normalised weights) only when somebody asks.
 """
 import abc
+import math
 import warnings
 
 import numpy as np
@@ -351,6 +352,14 @@ class ParticleDistribution(Distribution):
 
     @staticmethod
     def _cov_from_sums(s1, s2):
+        if s2.shape == (1, 1):
+            # one parameter: the same subtraction on plain floats (this is on the resample path of every d = 1 model)
+            c = float(s2[0, 0]) - float(s1[0]) * float(s1[0])
+            assert math.isfinite(c)
+            if not c >= 0:
+                warnings.warn('Numerical error in covariance estimation causing positive semidefinite '
+                              'violation.', ApproximationWarning)
+            return np.array([[c]])
         cov = s2 - np.outer(s1, s1)                       # E[x x^T] - mu mu^T (distributions.py:386-390)
         assert np.all(np.isfinite(cov))
         psd = (cov[0, 0] >= 0) if cov.shape == (1, 1) else np.all(np.linalg.eigvals(cov) >= 0)

@@ -5,6 +5,7 @@ Layout contract: particle locations are SoA `x[d, N]` float64 co
 weights `w[N]` float64, kept unnormalised with a host-side normaliser.
 """
 import ctypes as C
+import os
 import threading
 
 import numpy as np
@@ -36,6 +37,9 @@ def get_engine(device=None):
         return _engines[idx]
 
 
+_NO_SPECULATIVE_PREFIX = bool(os.environ.get("QSMC_NO_SPECULATIVE_PREFIX"))     # (A/B switch, read by the library too)
+
+
 class Engine:
     def __init__(self, index):
         import torch
@@ -55,6 +59,7 @@ class Engine:
         self._mom = {d: np.empty(d + d * (d + 1) // 2, dtype=np.float64) for d in range(1, 5)}
         self._mom_ptr = {d: _native.f64_ptr(a) for d, a in self._mom.items()}
         self._st_ref = C.byref(self._st)
+        self._armed_prefix = None    # what qsmc_lw_arm_prefix was last told (arm_resample_prefix)
 
     # ------------------------------------------------------------------ memory / streams
     def stream(self):
@@ -375,6 +380,28 @@ class Engine:
         self._chk(self.lib.qsmc_lw_resample_prepare(
             self.h, self._p(w) if w is not None else None, int(n_in), float(norm), int(n_out),
             C.c_uint64(seed & (2 ** 64 - 1)), C.c_uint64(epoch), self.stream()), "qsmc_lw_resample_prepare")
+
+    def arm_resample_prefix(self, key):
+        """key = (ess_below, n_out, seed, epoch) or None: from now on every host-visible `update_fused` queues the
+        resampler's weight-only prefix for that resample behind itself, gated on the device-side ESS test
+        (qsmc_lw_arm_prefix).  Called only when the key changes -- once per resample."""
+        if key is not None and _NO_SPECULATIVE_PREFIX:
+            key = None
+        if key == self._armed_prefix:
+            return
+        self._armed_prefix = key
+        if key is None:
+            self._chk(self.lib.qsmc_lw_arm_prefix(self.h, 0, 0.0, 1, C.c_uint64(0), C.c_uint64(0)), "qsmc_lw_arm_prefix")
+        else:
+            self._chk(self.lib.qsmc_lw_arm_prefix(self.h, 1, float(key[0]), int(key[1]),
+                                                  C.c_uint64(key[2] & (2 ** 64 - 1)), C.c_uint64(key[3])),
+                      "qsmc_lw_arm_prefix")
+
+    def prefix_stats(self):
+        """(speculative prefixes queued, resamples that found theirs done) on this handle."""
+        q, a = C.c_int64(), C.c_int64()
+        self._chk(self.lib.qsmc_lw_prefix_stats(self.h, C.byref(q), C.byref(a)), "qsmc_lw_prefix_stats")
+        return q.value, a.value
 
     def last_resample_failed(self, synchronize=False):
         out = C.c_int64()

@@ -14,6 +14,7 @@ Two RNG modes:
   redraws its ancestor and kick in-thread.  Statistically equivalent, not stream-identical.
 """
 import abc
+import math
 import warnings
 
 import numpy as np
@@ -94,18 +95,23 @@ class LiuWestResampler(Resampler):
         n_particles = int(n_particles)
         d = particle_dist.n_rvs
         a, h = self._a, self._h
-        if not cov.any():                                  # la.norm(cov, 'fro') == 0  (resamplers.py:283)
+        # (this call sits between the update that failed the n_ess test and the launch of the sampling kernel, with the
+        #  GPU waiting: scalar tests on plain floats where d = 1, cached model facts where the updater has them)
+        if not (cov[0, 0] != 0.0 if cov.shape == (1, 1) else cov.any()):   # la.norm(cov, 'fro') == 0  (resamplers.py:283)
             warnings.warn("Covariance has zero norm; adding in small covariance in resampler. "
                           "Consider increasing n_particles to improve covariance estimates.",
                           ResamplerWarning)
             cov = self._zero_cov_comp * np.eye(d)
         S, S_err = eng.sqrtm_psd(cov, scale=h)
-        if not np.isfinite(S_err):
+        if not math.isfinite(S_err):
             raise ResamplerError("Infinite error in computing the square root of the covariance "
                                  "matrix. Check that n_ess is not too small.")
 
-        native = native_ok(model)
-        desc = model._native_desc() if native else None
+        if getattr(particle_dist, "model", None) is model and hasattr(particle_dist, "_desc"):
+            native, desc = particle_dist._native, particle_dist._desc      # an SMCUpdater and its own model
+        else:
+            native = native_ok(model)
+            desc = model._native_desc() if native else None
         x_in, norm = particle_dist._x, particle_dist._norm
 
         if self._device_rng and native:

@@ -320,12 +320,14 @@ class SMCUpdater(ParticleDistribution):
                     fused_moments = self._comm.last_extra            # (a copy: packed sums, see _moments)
                 st = None
             elif d <= 4:
+                eng.arm_resample_prefix(self._prefix_key() if check_for_resample else None)
                 # the kernel also returns sum w'x, sum w'xx^T of the new weights (x is in registers
                 # anyway): est_mean / est_covariance_mtx / the resampler need no further pass
                 st = eng.update_fused(self._desc, self._x, self._w, w_out, self._norm, exps[0],
                                       _as_int_outcome(outcome), moments="raw")
                 fused_moments = eng._mom[d].copy()                   # packed sums, unpacked lazily (_moments)
             else:
+                eng.arm_resample_prefix(self._prefix_key() if check_for_resample else None)
                 st = eng.update_fused(self._desc, self._x, self._w, w_out, self._norm, exps[0],
                                       _as_int_outcome(outcome))
         else:
@@ -575,6 +577,21 @@ class SMCUpdater(ParticleDistribution):
         return self.bayes_risk(np.array([(x0,)], dtype=self.model.expparams_dtype))
 
     # ------------------------------------------------------------------ resampling
+    def _prefix_key(self):
+        """What the resample after THIS update would ask the device for first (resamplers._prepare_device), so the
+        update can queue it behind itself, gated on the device-side copy of the test in `_maybe_resample`
+        (qsmc_lw_arm_prefix); None when that resample would not take the device-RNG path.  (On the per-datum path:
+        attribute reads only.)"""
+        r = self.resampler
+        if not self._native or not getattr(r, "_device_rng", False):
+            return None
+        n = self._x.shape[1]
+        if n > r._segment_limit:
+            return None
+        n_out = r._default_n_particles
+        return (self.n_particles_global * self.resample_thresh, n if n_out is None else int(n_out), r._seed,
+                r._epoch + 1)
+
     def _maybe_resample(self, ess=None):
         ess = self.n_ess if ess is None else ess
         if ess <= 10:
@@ -583,7 +600,9 @@ class SMCUpdater(ParticleDistribution):
                           ApproximationWarning)
         if ess < self.n_particles_global * self.resample_thresh:
             prepare = getattr(self.resampler, "_prepare_device", None)
-            if prepare is not None and self._comm is None:
+            if prepare is not None and self._comm is None and self._eng._armed_prefix is None:
+                # (with the prefix armed the update queued it behind itself on the device's own ESS test: the
+                #  resampler's call finds it done, or redoes it should the device have decided otherwise)
                 prepare(self.model, self)            # GPU starts on the weight-only prefix right away
             self.resample(_defer_warning=True)
 

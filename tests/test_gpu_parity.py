@@ -1487,6 +1487,55 @@ def test_reset_and_setters(qi):
                       resampler=qi.LiuWestResampler())
 
 
+def test_speculative_prefix_same_particles(qi, monkeypatch):
+    """The resampler's weight-only prefix queued behind every update, gated on the device-side ESS test
+    (qsmc_lw_arm_prefix), changes no number: same clouds, same records as with the host queueing it after its own test,
+    over models whose resamples differ (d = 1 single-pass sampler; RB with redraws; user changes in between)."""
+    from qinfer_amd import smc as smc_mod
+    rng = np.random.default_rng(5)
+
+    def run(model, prior, n, data, speculative, tamper_at=None):
+        if not speculative:
+            monkeypatch.setattr(smc_mod.SMCUpdater, "_prefix_key", lambda self: None)
+        else:
+            monkeypatch.undo()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            upd = qi.SMCUpdater(model, n, prior, device_rng=True, seed=11)
+            q0, a0 = upd._eng.prefix_stats()
+            for k, (o, ep) in enumerate(data):
+                if k == tamper_at:                       # user writes the weights: the host must not vouch for the sums
+                    w = upd.particle_weights
+                    w[:] = w[::-1].copy()
+                upd.update(o, ep)
+            q1, a1 = upd._eng.prefix_stats()
+        return upd, q1 - q0, a1 - a0
+
+    ts = (9 / 8) ** np.arange(60)
+    prec = [(int(rng.random() < np.sin(0.3 * t / 2) ** 2), np.array([t])) for t in ts]
+    rb_model = qi.RandomizedBenchmarkingModel()
+    rb = [(int(rng.random() < 0.5), np.array([(1 + 5 * k,)], dtype=rb_model.expparams_dtype)) for k in range(40)]
+    cases = [
+        (lambda: qi.SimplePrecessionModel(), lambda m: qi.UniformDistribution([0, 1]), 300_000, prec, None),
+        (lambda: qi.SimplePrecessionModel(), lambda m: qi.UniformDistribution([0, 1]), 300_000, prec, 7),
+        (lambda: rb_model, lambda m: qi.PostselectedDistribution(
+            qi.UniformDistribution([[0.8, 1], [0, 1], [0, 1]]), m), 200_000, rb, None),
+    ]
+    for make_model, make_prior, n, data, tamper in cases:
+        m = make_model()
+        a, q_a, ad_a = run(m, make_prior(m), n, data, True, tamper)
+        m = make_model()
+        b, q_b, ad_b = run(m, make_prior(m), n, data, False, tamper)
+        assert a.resample_count == b.resample_count and a.resample_count > 0
+        assert q_a == len(data) and q_b == 0                       # queued behind every update / never
+        assert ad_b == 0 and 0 < ad_a <= a.resample_count
+        if tamper is None:
+            assert ad_a == a.resample_count                        # every resample found its prefix done
+        np.testing.assert_array_equal(a.particle_locations, b.particle_locations)
+        np.testing.assert_array_equal(a.particle_weights, b.particle_weights)
+        np.testing.assert_array_equal(np.asarray(a.normalization_record), np.asarray(b.normalization_record))
+
+
 def test_write_through_views(qi):
     """Drop-in mutability (SURVEY 8(b1): `particle_locations` / `particle_weights` are public mutable attributes;
     the reference itself writes `self.particle_weights[:] = ...`, smc.py:441, and
