@@ -18,7 +18,7 @@ constexpr int UPD_UNROLL = 4;
 // together saturate one atomic word (~88 arrivals/us) -- versus 4.9 us + one launch boundary here.
 // ---------------------------------------------------------------------------------------------
 struct ReduceOut {
-    double *partials;        // [grid][NS + 1]
+    double *partials;        // [NS + 1][grid]
     double *out_dev;         // [NS + 1] device (always written)
     double *out_mapped;      // [NS + 1] device alias of pinned host memory (nullable)
     double *stats4;          // optional caller buffer in qsmc_update_stats_t order (nullable)
@@ -58,26 +58,80 @@ __device__ __forceinline__ void block_publish(double (&v)[NS], double mn, const 
             const double t = lds[wv * (NS + 1) + k];
             s = (k < NS) ? s + t : fmin(s, t);
         }
-        ro.partials[(size_t)blockIdx.x * (NS + 1) + k] = s;
+        ro.partials[(size_t)k * gridDim.x + blockIdx.x] = s;          // column k of [NS + 1][grid]: the reducer reads it coalesced
     }
 }
 
+// One workgroup on the critical path of every datum: 4.8 us at N = 1e7 (2442 partial rows of 6).  Split with
+// wall_clock64(): the sweep 1.8-2.1 us WHATEVER the unrolling (4 or 10 rows in flight), the thread count (128 ... 1024;
+// 1024 was slower overall, 6.6 us) or the layout (row-major at a 48-byte stride, or column-major and coalesced as now) --
+// one cold first touch of lines other XCDs wrote, not bandwidth and not rounds of latency; wave/LDS reduction and the
+// stores 1.1 us (1.4 before the resampler's two counters were fetched ahead of the sweep); the system-scope fence before
+// the completion word 0.9 us (a bare s_waitcnt costs the same: it is the wait for the pinned-memory stores, not a cache
+// write-back); the rest is launch.  Doing this level inside the update kernel behind arrival tickets was measured in
+// round 1 (+11 us) and re-costed in round 2: every dependent global round trip is 1-2 us and that chain has more of them.
 template <int NS>
 __global__ __launch_bounds__(QSMC_BLOCK) void k_reduce_partials(int nblocks, ReduceOut ro) {
-    __shared__ double lds[QSMC_WAVES_PER_BLOCK * NS];
+    constexpr int THREADS = QSMC_BLOCK, WAVES = THREADS / QSMC_WAVE, UNROLL = NS <= 17 ? 4 : (NS <= 38 ? 2 : 1);
+    __shared__ double lds[WAVES * (NS + 1)];
+    __shared__ double tot[NS + 1];
+    unsigned long long failed0 = 0ull, failed1 = 0ull;
+    if (threadIdx.x == 0 && ro.failed_dst) {
+        failed0 = ro.failed_src[0];
+        failed1 = ro.failed_src[1];
+    }
     double acc[NS];
 #pragma unroll
     for (int k = 0; k < NS; ++k) acc[k] = 0.0;
     double m2 = INFINITY;
-#pragma unroll 4
-    for (int g = threadIdx.x; g < nblocks; g += QSMC_BLOCK) {
-        const double *p = ro.partials + (size_t)g * (NS + 1);
+    // UNROLL rows per thread and trip, every load of a trip issued before the first add (rows past the end are
+    // clamped to the last row and their values dropped: a guarded loop with a run-time trip count ends in a
+    // remainder loop that takes the rows one latency at a time)
+    for (int g0 = threadIdx.x; g0 < nblocks; g0 += THREADS * UNROLL) {
+        double v[UNROLL][NS + 1];
 #pragma unroll
-        for (int k = 0; k < NS; ++k) acc[k] += p[k];
-        m2 = fmin(m2, p[NS]);
+        for (int u = 0; u < UNROLL; ++u) {
+            const int g = g0 + u * THREADS;
+            const double *p = ro.partials + (g < nblocks ? g : nblocks - 1);
+#pragma unroll
+            for (int k = 0; k <= NS; ++k) v[u][k] = p[(size_t)k * nblocks];
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const bool in = g0 + u * THREADS < nblocks;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) acc[k] += in ? v[u][k] : 0.0;
+            m2 = fmin(m2, in ? v[u][NS] : INFINITY);
+        }
     }
-    block_sum<NS>(acc, lds);
-    m2 = block_min(m2, lds);
+    {   // waves, then thread k combines value k over the waves in wave order, then thread 0 publishes
+        const int lane = threadIdx.x & (QSMC_WAVE - 1), wave = threadIdx.x / QSMC_WAVE;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) acc[k] = wave_sum(acc[k]);
+        m2 = wave_min(m2);
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < NS; ++k) lds[wave * (NS + 1) + k] = acc[k];
+            lds[wave * (NS + 1) + NS] = m2;
+        }
+        __syncthreads();
+        if (threadIdx.x <= NS) {
+            const int k = threadIdx.x;
+            double t = lds[k];
+#pragma unroll
+            for (int wv = 1; wv < WAVES; ++wv) {
+                const double u = lds[wv * (NS + 1) + k];
+                t = (k < NS) ? t + u : fmin(t, u);
+            }
+            tot[k] = t;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int k = 0; k < NS; ++k) acc[k] = tot[k];
+            m2 = tot[NS];
+        }
+    }
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
@@ -97,8 +151,8 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_reduce_partials(int nblocks, Red
         // a resample queued before this reduction has finished by now (stream order): its count of particles
         // that stayed invalid rides along (qsmc_last_resample_failed reads it after this synchronisation)
         if (ro.failed_dst) {
-            ro.failed_dst[0] = (double)ro.failed_src[0];
-            ro.failed_dst[-1] = (double)ro.failed_src[1];       // how many outputs of that resample needed a global redraw
+            ro.failed_dst[0] = (double)failed0;
+            ro.failed_dst[-1] = (double)failed1;                // how many outputs of that resample needed a global redraw
         }
         if (ro.prefix_gate) {
             // The host's resample test (smc.py:263-277 via n_ess = 1 / sum w^2 of the normalised weights), taken here
