@@ -240,6 +240,15 @@ int qsmc_searchsorted(qsmc_handle_t h, const double *a, int64_t n, const double 
 int qsmc_weight_entropy(qsmc_handle_t h, const double *w, int64_t n, double norm, double *entropy_host,
                         qsmc_stream_t stream);
 
+/* The kernel-density cross term of est_kl_divergence / SMCUpdater's resampling divergences (distributions.py:466-487,
+ * smc.py:506-542; distances metrics.py:72-106):
+ *     *out_host = sum_i (w_i / norm_p) log( sum_j (v_j / norm_q) phi(|| scale o (x_i - y_j) ||_2) ),
+ * phi the standard normal pdf, scale[q] = sqrt(Q_q) / delta on the host (d doubles); w or v NULL: all-ones weights.
+ * The divergence is -est_entropy(p) - *out_host / delta.  O(n m d) work, nothing of size n x m is stored. */
+int qsmc_kde_cross_entropy(qsmc_handle_t h, const double *x, int64_t ldx, int64_t n, const double *w, double norm_p,
+                           const double *y, int64_t ldy, int64_t m, const double *v, double norm_q, int32_t d,
+                           const double *scale_host, double *out_host, qsmc_stream_t stream);
+
 /* Materialise normalised weights: w_out[i] = w_in[i] / norm (particle_weights property). */
 int qsmc_normalize_weights(qsmc_handle_t h, const double *w_in, double *w_out, int64_t n,
                            double norm, qsmc_stream_t stream);

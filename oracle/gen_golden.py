@@ -715,6 +715,65 @@ def g13_regions():
     print("g13_regions", vertices.shape, [int(out[k].sum()) for k in ('in_pce', 'in_hpd_hull', 'in_hpd_mvee')])
 
 
+def g14_kl_divergence():
+    """Kernel-density KL divergence between particle clouds (distributions.py:466-500, metrics.py:72-106) and the
+    per-resample divergences an updater records with track_resampling_divergence=True (smc.py:506-542):
+    computed by the reference on fixed clouds, and along a seeded precession / RB run (every RNG draw of the resampler
+    is the legacy stream, so a replaying updater reaches the same clouds)."""
+    out = {}
+    rs = np.random.RandomState(77)
+    for tag, n, m, d in (("d1", 400, 300, 1), ("d3", 250, 350, 3)):
+        x = 0.3 + 0.01 * rs.randn(n, d)
+        y = 0.3 + 0.012 * rs.randn(m, d) + 0.002
+        w = rs.random_sample(n) ** 2
+        w[rs.choice(n, 10, replace=False)] = 0.0               # est_entropy skips zero weights, the KDE term keeps them
+        w /= w.sum()
+        v = rs.random_sample(m)
+        v /= v.sum()
+        p = qinfer.ParticleDistribution(particle_locations=x.copy(), particle_weights=w.copy())
+        q = qinfer.ParticleDistribution(particle_locations=y.copy(), particle_weights=v.copy())
+        out[tag + '_x'], out[tag + '_w'], out[tag + '_y'], out[tag + '_v'] = x, p.particle_weights, y, q.particle_weights
+        out[tag + '_kl'] = p.est_kl_divergence(q)
+        out[tag + '_kl_delta'] = p.est_kl_divergence(q, delta=0.05)
+    # an updater's own divergences: every call of _kl_divergence from SMCUpdater.resample is recorded with the clouds it
+    # compared (the model's scale matrix Q enters through rescaled_distance_mtx; the reference's models all have
+    # Q = 1, so one with a non-trivial Q is made here by instance attribute)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for tag, model, n, n_exp, true in (
+                ("prec", qinfer.SimplePrecessionModel(), 300, 40, np.array([[0.3]])),
+                ("rb", qinfer.RandomizedBenchmarkingModel(), 400, 30, np.array([[0.95, 0.3, 0.5]]))):
+            if tag == "rb":
+                model._Q = np.array([4.0, 1.0, 0.25])
+                prior = qinfer.PostselectedDistribution(qinfer.UniformDistribution([[0.8, 1], [0, 1], [0, 1]]), model)
+                eps = [np.array([(1 + 5 * k,)], dtype=model.expparams_dtype) for k in range(n_exp)]
+            else:
+                prior = qinfer.UniformDistribution([0, 1])
+                eps = [np.array([(9 / 8) ** k]) for k in range(n_exp)]
+            np.random.seed(21)
+            upd = qinfer.SMCUpdater(model, n, prior, track_resampling_divergence=True)
+            recs = []
+            orig = upd._kl_divergence
+
+            def rec_kl(old_locs, old_w, *a, **k):
+                val = orig(old_locs, old_w, *a, **k)
+                recs.append((old_locs.copy(), old_w.copy(), upd.particle_locations.copy(),
+                             upd.particle_weights.copy(), val))
+                return val
+            upd._kl_divergence = rec_kl
+            for ep in eps:
+                upd.update(int(np.ravel(model.simulate_experiment(true, ep))[0]), ep)
+            out[tag + '_divergences'] = np.array(upd.resampling_divergences)
+            out[tag + '_Q'] = np.asarray(model.Q, dtype=np.float64)
+            out[tag + '_n_recorded'] = min(3, len(recs))
+            for i, (xo, wo, xn, wn, val) in enumerate(recs[:3]):
+                out['%s_r%d_old_x' % (tag, i)], out['%s_r%d_old_w' % (tag, i)] = xo, wo
+                out['%s_r%d_new_x' % (tag, i)], out['%s_r%d_new_w' % (tag, i)] = xn, wn
+                out['%s_r%d_kl' % (tag, i)] = val
+    np.savez_compressed(os.path.join(OUT, "g14_kl_divergence.npz"), **out)
+    print("g14_kl_divergence", out['d1_kl'], out['d3_kl'], out['prec_divergences'][:3], out['rb_divergences'][:3])
+
+
 if __name__ == "__main__":
     g1_precession()
     g1_binomial()
@@ -735,4 +794,5 @@ if __name__ == "__main__":
     g13_regions()
     g2_edges()
     g1_clouds()
+    g14_kl_divergence()
     print("total bytes:", sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT)))

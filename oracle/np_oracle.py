@@ -412,6 +412,19 @@ def est_entropy(w):
     return -np.sum(np.log(nz) * nz)
 
 
+def kl_divergence(x, w, other_x, other_w, Q=1.0, delta=1e-2):
+    """Kernel-density estimate of KL(p || q) between two weighted clouds (distributions.py:466-487 with the default
+    standard-normal kernel; distances from metrics.py:72-106: ||sqrt(Q) (x_i - y_j)||_2):
+        -H(w) - (1 / delta) sum_i w_i log( sum_j v_j phi(d_ij / delta) )."""
+    x, other_x = np.asarray(x, dtype=np.float64), np.asarray(other_x, dtype=np.float64)
+    diff = np.sqrt(Q) * (x[:, None, :] - other_x[None, :, :])
+    dist = np.sqrt(np.sum(diff ** 2, axis=-1)) / delta
+    K = np.exp(-0.5 * dist ** 2) / np.sqrt(2.0 * np.pi)
+    with np.errstate(divide="ignore"):
+        inner = np.log(np.sum(np.asarray(other_w) * K, axis=1))
+    return -est_entropy(w) - (1.0 / delta) * np.sum(np.asarray(w) * inner, axis=0)
+
+
 def est_credible_region(w, x, level=0.95, return_outside=False, modelparam_slice=None):
     """distributions.py:558-614: highest-weight particles first until the mass reaches `level`."""
     mps = x[:, modelparam_slice] if modelparam_slice is not None else x

@@ -169,3 +169,55 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_sum_partials(const double *__res
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Kernel-density cross term of est_kl_divergence (distributions.py:466-487; distances metrics.py:72-106):
+//     sum_i p_i log( sum_j q_j phi(|| sqrt(Q) (x_i - y_j) ||_2 / delta) ),   phi = standard normal pdf,
+// p = w / norm_p over the n particles x, q = v / norm_q over the m particles y (null weights: all ones).
+// O(n m d): the reference forms the n x m distance matrix on the host; here a thread owns one x_i and the y_j go
+// past in LDS tiles of 256 (every lane reads the same y_j: an LDS broadcast), nothing of size n m exists.
+// `scale` = sqrt(Q) / delta per parameter, applied to both clouds before the subtraction.
+// ---------------------------------------------------------------------------------------------
+constexpr int KDE_TILE = QSMC_BLOCK;
+struct KdeScale { double s[QSMC_MAX_D]; };
+
+__global__ __launch_bounds__(QSMC_BLOCK) void k_kde_cross(const double *__restrict__ x, int64_t ldx, int64_t n,
+                                                          const double *__restrict__ w, double inv_norm_p,
+                                                          const double *__restrict__ y, int64_t ldy, int64_t m,
+                                                          const double *__restrict__ v, double inv_norm_q, int d,
+                                                          KdeScale sc, ReduceOut ro) {
+    __shared__ double ys[QSMC_MAX_D][KDE_TILE];
+    __shared__ double vs[KDE_TILE];
+    double total[3] = {0.0, 0.0, 0.0};
+    for (int64_t base = (int64_t)blockIdx.x * QSMC_BLOCK; base < n; base += (int64_t)gridDim.x * QSMC_BLOCK) {
+        const int64_t i = base + threadIdx.x;
+        const bool live = i < n;
+        double xi[QSMC_MAX_D];
+#pragma unroll
+        for (int q = 0; q < QSMC_MAX_D; ++q) xi[q] = (q < d && live) ? x[q * ldx + i] * sc.s[q] : 0.0;
+        double acc = 0.0;
+        for (int64_t j0 = 0; j0 < m; j0 += KDE_TILE) {
+            __syncthreads();
+            const int64_t j = j0 + threadIdx.x;
+            for (int q = 0; q < d; ++q) ys[q][threadIdx.x] = j < m ? y[q * ldy + j] * sc.s[q] : 0.0;
+            vs[threadIdx.x] = j < m ? (v ? v[j] : 1.0) * inv_norm_q : 0.0;
+            __syncthreads();
+            const int len = (int)((m - j0) < KDE_TILE ? (m - j0) : KDE_TILE);
+            for (int jj = 0; jj < len; ++jj) {
+                double z2 = 0.0;
+#pragma unroll
+                for (int q = 0; q < QSMC_MAX_D; ++q)
+                    if (q < d) {
+                        const double t = xi[q] - ys[q][jj];
+                        z2 += t * t;
+                    }
+                acc += vs[jj] * exp(-0.5 * z2);
+            }
+        }
+        if (live) {
+            const double dens = acc * 0.3989422804014327;                       // 1 / sqrt(2 pi)
+            total[0] += ((w ? w[i] : 1.0) * inv_norm_p) * log(dens);            // log 0 = -inf like the reference
+        }
+    }
+    block_publish<3>(total, INFINITY, ro);
+}
+

@@ -907,6 +907,31 @@ int qsmc_weight_entropy(qsmc_handle_t h, const double *w, int64_t n, double norm
     return QSMC_OK;
 }
 
+int qsmc_kde_cross_entropy(qsmc_handle_t h, const double *x, int64_t ldx, int64_t n, const double *w, double norm_p,
+                           const double *y, int64_t ldy, int64_t m, const double *v, double norm_q, int32_t d,
+                           const double *scale_host, double *out_host, qsmc_stream_t stream) {
+    if (!h || !x || !y || !scale_host || !out_host || n <= 0 || m <= 0 || d < 1 || d > QSMC_MAX_D ||
+        !(norm_p > 0.0) || !(norm_q > 0.0))
+        return QSMC_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = grid_for(n, QSMC_BLOCK);
+    int rc = ensure_partials(h, (size_t)grid * 4);
+    if (rc) return rc;
+    KdeScale sc;
+    for (int q = 0; q < QSMC_MAX_D; ++q) sc.s[q] = q < d ? scale_host[q] : 0.0;
+    const ReduceOut ro = make_reduce(h, true, nullptr);
+    hipLaunchKernelGGL(k_kde_cross, dim3(grid), dim3(QSMC_BLOCK), 0, s, x, ldx, n, w, 1.0 / norm_p, y, ldy, m, v,
+                       1.0 / norm_q, (int)d, sc, ro);
+    HIP_TRY(h, hipGetLastError());
+    rc = launch_reduce(h, 3, grid, ro, s);
+    if (rc) return rc;
+    qsmc_update_stats_t st;
+    rc = collect_stats(h, 3, &st, nullptr, 0, s);
+    if (rc) return rc;
+    *out_host = st.sum;
+    return QSMC_OK;
+}
+
 int qsmc_normalize_weights(qsmc_handle_t h, const double *w_in, double *w_out, int64_t n, double norm,
                            qsmc_stream_t stream) {
     if (h) { h->prep.valid = 0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state

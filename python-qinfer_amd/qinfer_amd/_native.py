@@ -84,6 +84,8 @@ SIGNATURES = {
     "qsmc_update_token": [_P, C.POINTER(_U64)],
     "qsmc_lw_use_update_sums": [_P, _U64],
     "qsmc_lw_resample_prepare": [_P, _P, _I64, _F64, _I64, _U64, _U64, _P],
+    "qsmc_kde_cross_entropy": [_P, _P, _I64, _I64, _P, _F64, _P, _I64, _I64, _P, _F64, _I32, C.POINTER(_F64),
+                               C.POINTER(_F64), _P],
     "qsmc_lw_arm_prefix": [_P, _I32, _F64, _I64, _U64, _U64],
     "qsmc_lw_prefix_stats": [_P, C.POINTER(_I64), C.POINTER(_I64)],
     "qsmc_last_resample_failed": [_P, C.POINTER(_I64), _I32, _P],

@@ -393,6 +393,45 @@ class ParticleDistribution(Distribution):
         self._single_cloud_only("est_entropy")
         return float(self._eng.weight_entropy(self._w, self.n_particles, self._norm))
 
+    def _kl_scale(self):
+        """sqrt(Q) of metrics.rescaled_distance_mtx: the model's scale matrix for an updater, 1 for a bare cloud
+        (metrics.py:97)."""
+        model = getattr(self, "model", None)
+        return 1.0 if model is None else np.sqrt(np.asarray(model.Q, dtype=np.float64))
+
+    def _kl_from_device(self, other_x, other_w, other_norm, kernel=None, delta=1e-2):
+        """KL(self || other) with `other` a device cloud: SoA locations (d, m), unnormalised weights (None = all
+        ones) and their normaliser."""
+        self._single_cloud_only("est_kl_divergence")
+        if kernel is not None:
+            # a user kernel is a host callable: the reference's own O(n m) evaluation on host copies
+            y = np.ascontiguousarray(other_x.cpu().numpy().T)
+            v = (np.full(y.shape[0], 1.0 / other_norm) if other_w is None
+                 else other_w.cpu().numpy() / other_norm)
+            x = self.particle_locations
+            diff = self._kl_scale() * (x[:, None, :] - y[None, :, :])
+            K = kernel(np.sqrt(np.sum(diff ** 2, axis=-1)) / delta)
+            with np.errstate(divide="ignore"):
+                inner = np.log(np.sum(v * K, axis=1))
+            return -self.est_entropy() - (1 / delta) * np.sum(self.particle_weights * inner, axis=0)
+        cross = self._eng.kde_cross_entropy(self._x, self._w, self._norm, other_x, other_w, other_norm,
+                                            self._kl_scale() / delta)
+        return -self.est_entropy() - (1 / delta) * cross
+
+    def _kl_divergence(self, other_locs, other_weights, kernel=None, delta=1e-2):
+        """KL divergence of this distribution from another cloud, smoothing the other cloud's particles with a
+        kernel density estimator (distributions.py:466-487): host arrays (m, d) and (m,) in, evaluated on the GPU."""
+        eng = self._eng
+        y = eng.locs_to_soa(np.asarray(other_locs, dtype=np.float64))
+        v = eng.to_device(np.ascontiguousarray(other_weights, dtype=np.float64))
+        return self._kl_from_device(y, v, 1.0, kernel, delta)
+
+    def est_kl_divergence(self, other, kernel=None, delta=1e-2):
+        """KL divergence between this and another particle distribution (distributions.py:489-500)."""
+        if isinstance(other, ParticleDistribution) and other._eng is self._eng:
+            return self._kl_from_device(other._x, other._w, other._norm, kernel, delta)
+        return self._kl_divergence(other.particle_locations, other.particle_weights, kernel, delta)
+
     # ---------------------------------------------------------------- regions / marginals (SURVEY 8(f)4)
     def est_credible_region(self, level=0.95, return_outside=False, modelparam_slice=None):
         """Particles of a credible set of mass >= `level`: highest weight first (distributions.py:558-614).

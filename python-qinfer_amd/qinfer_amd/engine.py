@@ -258,6 +258,18 @@ class Engine:
                                                C.byref(out), self.stream()), "qsmc_weight_entropy")
         return out.value
 
+    def kde_cross_entropy(self, x, w, norm_p, y, v, norm_q, scale):
+        """sum_i p_i log sum_j q_j phi(||scale o (x_i - y_j)||): x (d, n), y (d, m) device SoA clouds, w / v their
+        unnormalised weights (None = all ones) with normalisers norm_p / norm_q, scale = sqrt(Q) / delta (host, d)."""
+        d = x.shape[0]
+        scale = np.ascontiguousarray(np.broadcast_to(np.asarray(scale, dtype=np.float64), (d,)))
+        out = C.c_double()
+        self._chk(self.lib.qsmc_kde_cross_entropy(
+            self.h, self._p(x), x.stride(0), x.shape[1], self._p(w) if w is not None else None, float(norm_p),
+            self._p(y), y.stride(0), y.shape[1], self._p(v) if v is not None else None, float(norm_q), d,
+            _native.f64_ptr(scale), C.byref(out), self.stream()), "qsmc_kde_cross_entropy")
+        return out.value
+
     def normalize_weights_into(self, w_in, w_out, norm):
         """w_out = w_in / norm (may alias)."""
         self._chk(self.lib.qsmc_normalize_weights(self.h, self._p(w_in), self._p(w_out), w_in.shape[0],

@@ -79,10 +79,11 @@ class SMCUpdater(ParticleDistribution):
         self._data_record = []
         self._normalization_record = []
         self._resampling_divergences = [] if track_resampling_divergence else None
-        if track_resampling_divergence:
-            warnings.warn("track_resampling_divergence needs an O(N^2) kernel-density estimate and "
-                          "is not supported on the GPU path; divergences will not be recorded.",
+        if track_resampling_divergence and comm is not None:
+            warnings.warn("track_resampling_divergence compares whole clouds (an O(N^2) kernel-density estimate); "
+                          "a sharded updater holds only its shard: divergences will not be recorded.",
                           ApproximationWarning)
+            self._resampling_divergences = None
         self._zero_weight_policy = zero_weight_policy
         self._zero_weight_thresh = (zero_weight_thresh if zero_weight_thresh is not None
                                     else 10 * np.spacing(1))
@@ -620,6 +621,10 @@ class SMCUpdater(ParticleDistribution):
         self._resample_count += 1
         if self._debug_resampling:
             old_mean, old_cov = self.est_mean(), self.est_covariance_mtx()
+        if self._resampling_divergences is not None:
+            # (smc.py:506-510 copies the cloud; here the old device buffers simply stay referenced: the resampler
+            #  writes a fresh cloud and the weight buffers are not reused before the next update)
+            old_cloud = (self._x, self._w, self._norm)
 
         if self._comm is not None:
             new = self._comm.resample(self, self.resampler)
@@ -648,6 +653,8 @@ class SMCUpdater(ParticleDistribution):
             self.model.clear_cache()
         except Exception as e:  # noqa: BLE001  (reference demotes these to warnings, smc.py:533-536)
             warnings.warn("Exception raised when clearing model cache: {}. Ignoring.".format(e))
+        if self._resampling_divergences is not None:                  # smc.py:538-542
+            self._resampling_divergences.append(self._kl_from_device(*old_cloud))
         if self._debug_resampling:
             import logging
             new_mean, new_cov = self.est_mean(), self.est_covariance_mtx()

@@ -1536,6 +1536,55 @@ def test_speculative_prefix_same_particles(qi, monkeypatch):
         np.testing.assert_array_equal(np.asarray(a.normalization_record), np.asarray(b.normalization_record))
 
 
+def test_kl_divergence_g14(qi, golden):
+    """est_kl_divergence / SMCUpdater's resampling divergences (distributions.py:466-500, smc.py:506-542) on the device
+    against the reference's values (fixture g14) and the oracle."""
+    g = golden("g14_kl_divergence")
+    for tag in ("d1", "d3"):
+        p = qi.ParticleDistribution(particle_locations=g[tag + "_x"], particle_weights=g[tag + "_w"])
+        q = qi.ParticleDistribution(particle_locations=g[tag + "_y"], particle_weights=g[tag + "_v"])
+        np.testing.assert_allclose(p.est_kl_divergence(q), g[tag + "_kl"], rtol=1e-10)
+        np.testing.assert_allclose(p.est_kl_divergence(q, delta=0.05), g[tag + "_kl_delta"], rtol=1e-10)
+        np.testing.assert_allclose(p._kl_divergence(g[tag + "_y"], g[tag + "_v"]), g[tag + "_kl"], rtol=1e-10)
+        # a user kernel takes the host path: the normal pdf handed in explicitly gives the same number
+        from scipy import stats as st
+        np.testing.assert_allclose(p.est_kl_divergence(q, kernel=st.norm(0, 1).pdf), g[tag + "_kl"], rtol=1e-10)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for tag, model, prior in (("prec", qi.SimplePrecessionModel(), qi.UniformDistribution([0, 1])),
+                                  ("rb", qi.RandomizedBenchmarkingModel(),
+                                   qi.UniformDistribution([[0.8, 1], [0, 1], [0, 1]]))):
+            model._Q = np.asarray(g[tag + "_Q"], dtype=np.float64)
+            for i in range(int(g[tag + "_n_recorded"])):
+                new_x, new_w = g["%s_r%d_new_x" % (tag, i)], g["%s_r%d_new_w" % (tag, i)]
+                upd = qi.SMCUpdater(model, new_x.shape[0], prior)
+                upd.particle_locations[:] = new_x
+                upd.particle_weights[:] = new_w
+                val = upd._kl_divergence(g["%s_r%d_old_x" % (tag, i)], g["%s_r%d_old_w" % (tag, i)])
+                np.testing.assert_allclose(val, g["%s_r%d_kl" % (tag, i)], rtol=1e-10)
+        # the updater records one divergence per resample, each the KDE divergence of the new cloud from the old
+        rng = np.random.default_rng(3)
+        upd = qi.SMCUpdater(qi.SimplePrecessionModel(), 3000, qi.UniformDistribution([0, 1]), device_rng=True,
+                            seed=4, track_resampling_divergence=True)
+        clouds = []
+        inner = upd._kl_from_device
+
+        def spy(ox, ow, on, *a, **k):
+            clouds.append((ox.cpu().numpy().T.copy(), None if ow is None else ow.cpu().numpy() / on))
+            return inner(ox, ow, on, *a, **k)
+        upd._kl_from_device = spy
+        for k in range(40):
+            t = (9 / 8) ** k
+            upd.update(int(rng.random() < np.sin(0.3 * t / 2) ** 2), np.array([t]))
+            if len(clouds) > len(getattr(upd, "_seen", [])):
+                upd._seen = list(clouds)
+                ox, ow = clouds[-1]
+                want = orc.kl_divergence(upd.particle_locations, upd.particle_weights, ox,
+                                         np.full(ox.shape[0], 1.0 / ox.shape[0]) if ow is None else ow)
+                np.testing.assert_allclose(upd.resampling_divergences[-1], want, rtol=1e-9)
+        assert upd.resample_count > 3 and len(upd.resampling_divergences) == upd.resample_count
+
+
 def test_write_through_views(qi):
     """Drop-in mutability (SURVEY 8(b1): `particle_locations` / `particle_weights` are public mutable attributes;
     the reference itself writes `self.particle_weights[:] = ...`, smc.py:441, and

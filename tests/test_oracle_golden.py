@@ -399,3 +399,19 @@ def test_poissonised_counts_law(margin):
     if margin <= 0:
         lam = n_out - margin * np.sqrt(n_out)
         assert stats.poisson.sf(n_out, lam) > 0.4              # the removal branch really was the common one
+
+
+def test_g14_kl_divergence(golden):
+    """oracle.kl_divergence against the reference's est_kl_divergence and the divergences its updater recorded."""
+    g = golden("g14_kl_divergence")
+    for tag in ("d1", "d3"):
+        x, w, y, v = g[tag + "_x"], g[tag + "_w"], g[tag + "_y"], g[tag + "_v"]
+        np.testing.assert_allclose(orc.kl_divergence(x, w, y, v), g[tag + "_kl"], rtol=1e-12)
+        np.testing.assert_allclose(orc.kl_divergence(x, w, y, v, delta=0.05), g[tag + "_kl_delta"], rtol=1e-12)
+    for tag in ("prec", "rb"):
+        assert int(g[tag + "_n_recorded"]) >= 1
+        for i in range(int(g[tag + "_n_recorded"])):
+            val = orc.kl_divergence(g["%s_r%d_new_x" % (tag, i)], g["%s_r%d_new_w" % (tag, i)],
+                                    g["%s_r%d_old_x" % (tag, i)], g["%s_r%d_old_w" % (tag, i)], Q=g[tag + "_Q"])
+            np.testing.assert_allclose(val, g["%s_r%d_kl" % (tag, i)], rtol=1e-12)
+            np.testing.assert_allclose(val, g[tag + "_divergences"][i], rtol=1e-12)
