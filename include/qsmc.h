@@ -353,6 +353,9 @@ int qsmc_lw_prefix_stats(qsmc_handle_t h, int64_t *n_queued, int64_t *n_adopted)
  * any later call (synchronize = 0), or force the wait (synchronize = 1). */
 int qsmc_last_resample_failed(qsmc_handle_t h, int64_t *n_failed_out, int32_t synchronize,
                               qsmc_stream_t stream);
+/* How many outputs of the latest resample asked for a global redraw (their first ancestor's kick failed postselection,
+ * resamplers.py:341-372), as published with the latest host-visible reduction after it: a diagnostic. */
+int qsmc_last_resample_redraws(qsmc_handle_t h, int64_t *n_redraws_out);
 
 /* Sharded resampling: THIS rank produces the finished Liu-West particles for every
  * destination rank -- the kick needs only the ancestor and the (already all-reduced) global mean /

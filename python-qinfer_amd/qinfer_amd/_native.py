@@ -86,6 +86,7 @@ SIGNATURES = {
     "qsmc_lw_resample_prepare": [_P, _P, _I64, _F64, _I64, _U64, _U64, _P],
     "qsmc_kde_cross_entropy": [_P, _P, _I64, _I64, _P, _F64, _P, _I64, _I64, _P, _F64, _I32, C.POINTER(_F64),
                                C.POINTER(_F64), _P],
+    "qsmc_last_resample_redraws": [_P, C.POINTER(_I64)],
     "qsmc_lw_arm_prefix": [_P, _I32, _F64, _I64, _U64, _U64],
     "qsmc_lw_prefix_stats": [_P, C.POINTER(_I64), C.POINTER(_I64)],
     "qsmc_last_resample_failed": [_P, C.POINTER(_I64), _I32, _P],

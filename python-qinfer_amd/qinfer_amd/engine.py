@@ -409,6 +409,12 @@ class Engine:
                                                   C.c_uint64(key[2] & (2 ** 64 - 1)), C.c_uint64(key[3])),
                       "qsmc_lw_arm_prefix")
 
+    def last_resample_redraws(self):
+        """Outputs of the latest resample that needed a global redraw (known after the next synchronising call)."""
+        out = C.c_int64()
+        self._chk(self.lib.qsmc_last_resample_redraws(self.h, C.byref(out)), "qsmc_last_resample_redraws")
+        return out.value
+
     def prefix_stats(self):
         """(speculative prefixes queued, resamples that found theirs done) on this handle."""
         q, a = C.c_int64(), C.c_int64()
