@@ -645,12 +645,29 @@ template <int DM>
 __device__ __forceinline__ bool redraw_rounds(int kind, int d, double min_freq, const double *__restrict__ x_in,
                                               int64_t ldx_in, int64_t n_in, const double *__restrict__ cdf,
                                               const LWArgs &lw, uint32_t k0, uint32_t k1, uint32_t epoch,
-                                              int maxiter, int64_t o, double *p) {
+                                              int maxiter, int64_t o, double *p, const double *edges, int chunks) {
     for (int round = 1; round < maxiter; ++round) {
         PhiloxStream rng{(uint64_t)o, (epoch << 16) | (uint32_t)round, k0, k1};
         double u0, unused;
         rng.uniforms(0, u0, unused);
-        const int64_t j = search_right(cdf, n_in, u0);
+        int64_t j;
+        if (edges) {
+            // two levels: the chunk among the edges in LDS (the chunk's last CDF entry IS its upper edge, so
+            // #edges <= u is the chunk of the upper bound), then 12 probes of that chunk's 32 KB of the CDF instead of
+            // 24 scattered over all of it -- the same index as search_right over the whole table
+            int c = upper_bound_skew(edges, chunks, u0);
+            if (c > chunks - 1) c = chunks - 1;
+            const int64_t base = (int64_t)c * SCAN_CHUNK;
+            const int64_t len = n_in - base < SCAN_CHUNK ? n_in - base : SCAN_CHUNK;
+            int64_t lo = 0, hi = len;
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (cdf[base + mid] <= u0) lo = mid + 1; else hi = mid;
+            }
+            j = base + lo < n_in - 1 ? base + lo : n_in - 1;
+        } else {
+            j = search_right(cdf, n_in, u0);
+        }
         double zz[DM];
 #pragma unroll
         for (int q = 0; q < DM; q += 2) {
@@ -1314,10 +1331,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_bucket_redraw(
     const double *__restrict__ w, double inv_norm, const double *__restrict__ offsets, int64_t chunks, double *cdf,
     LWArgs lw, uint32_t k0, uint32_t k1, uint32_t epoch, int maxiter, double *__restrict__ x_out, OutPlace pl,
     const unsigned int *__restrict__ retry_list, const unsigned long long *__restrict__ retry_count,
-    unsigned long long *__restrict__ n_failed, unsigned long long *bar, int cdf_ready) {
+    unsigned long long *__restrict__ n_failed, unsigned long long *bar, int cdf_ready, int edges_in_lds) {
     __shared__ double wave_tot[SCAN_WAVES];
+    extern __shared__ __attribute__((aligned(16))) unsigned char redraw_smem[];
     const unsigned long long cnt = *retry_count;
     if (cnt == 0ull) return;
+    double *edges = edges_in_lds ? reinterpret_cast<double *>(redraw_smem) : nullptr;
+    if (edges) {                                         // upper edge of every chunk (offsets[c + 1]); read after the
+        for (int c = threadIdx.x; c < (int)chunks; c += SCAN_THREADS) edges[lds_skew(c)] = offsets[c + 1];   // scans' barriers
+    }
     if (!cdf_ready) {                                                // (cdf_ready: a full-grid k_chunk_scan ran before this launch)
         for (int64_t c = blockIdx.x; c < chunks; c += gridDim.x) {
             chunk_scan_block(w, n_in, inv_norm, offsets, c, wave_tot, StoreGlobal{cdf + c * SCAN_CHUNK});
@@ -1325,13 +1347,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_bucket_redraw(
         }
         grid_barrier_fenced(bar);
     }
+    __syncthreads();
     unsigned long long failed = 0;
     for (unsigned long long i = (unsigned long long)blockIdx.x * SCAN_THREADS + threadIdx.x; i < cnt;
          i += (unsigned long long)gridDim.x * SCAN_THREADS) {
         const int64_t o = (int64_t)retry_list[i];
         double p[DM];
         const bool ok = redraw_rounds<DM>(kind, d, min_freq, x_in, ldx_in, n_in, cdf, lw, k0, k1, epoch,
-                                                  maxiter, o, p);
+                                                  maxiter, o, p, edges, (int)chunks);
         const int64_t row = place_row(pl, o);      // like the in-thread loop: the last round's value stays
         for (int m = 0; m < d; ++m) x_out[m * pl.ld_m + row * pl.ld_s] = p[m];
         if (!ok) ++failed;

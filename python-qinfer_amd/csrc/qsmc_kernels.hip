@@ -1355,11 +1355,15 @@ static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int3
             if (expect_redraws)
                 hipLaunchKernelGGL(k_chunk_scan, dim3((unsigned)chunks64), dim3(SCAN_THREADS), 0, s, w, n_in, inv_norm,
                                    offsets, h->cdf_scratch, (const unsigned long long *)retry_count);
+            // the chunk edges ride in LDS (first level of the redraw's ancestor search) while they fit 48 KB
+            const size_t edges_lds = (size_t)(chunks64 + (chunks64 >> 5) + (chunks64 >> 10) + 4) * sizeof(double);      // (lds_skew)
+            const int edges_in_lds = edges_lds <= 48 * 1024 ? 1 : 0;
             hipLaunchKernelGGL((d <= 4 ? k_bucket_redraw<4> : k_bucket_redraw<QSMC_MAX_D>),
-                               dim3(expect_redraws ? 1024 : redraw_blocks), dim3(SCAN_THREADS), 0, s, model->kind, d,
+                               dim3(expect_redraws ? 1024 : redraw_blocks), dim3(SCAN_THREADS),
+                               edges_in_lds ? edges_lds : 0, s, model->kind, d,
                                model->min_freq, x_in, ldx_in, n_in, w, inv_norm, offsets, chunks64, h->cdf_scratch, lw,
                                k0, k1, ep, maxiter, x_out, pl, bp.retry_list, retry_count, nf, h->gbar + 2,
-                               expect_redraws ? 1 : 0);
+                               expect_redraws ? 1 : 0, edges_in_lds);
         }
     }
     HIP_TRY(h, hipGetLastError());
