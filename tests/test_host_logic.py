@@ -212,3 +212,52 @@ def test_mvee_and_in_ellipsoid(golden):
     assert inside.all()
     assert bool(u.in_ellipsoid(c, np.linalg.inv(A), c)) and not bool(u.in_ellipsoid(c + 100.0, np.linalg.inv(A), c))
     assert u.uniquify([3, 1, 3, 2, 1]) == [3, 1, 2]
+
+
+def test_f64_ptr_paths():
+    """_native.f64_ptr: the from_buffer fast path and the data_as fall-back address the same memory."""
+    import ctypes as C
+    a = np.arange(6, dtype=np.float64)
+    p = _native.f64_ptr(a)                                   # writeable: a ctypes array over the buffer
+    assert C.addressof(p) == a.ctypes.data and list(p) == a.tolist()
+    p[2] = -1.0
+    assert a[2] == -1.0
+    ro = np.arange(4, dtype=np.float64)
+    ro.setflags(write=False)
+    q = _native.f64_ptr(ro)                                  # read-only: ndarray.ctypes.data_as
+    assert C.cast(q, C.c_void_p).value == ro.ctypes.data and q[3] == 3.0
+    with pytest.raises(AssertionError):
+        _native.f64_ptr(np.zeros(3, dtype=np.float32))
+    with pytest.raises(AssertionError):
+        _native.f64_ptr(np.zeros((4, 4))[:, ::2])
+
+
+def test_cov_from_sums_scalar_path_equals_matrix_path():
+    """ParticleDistribution._cov_from_sums: the one-parameter scalar path gives the matrix path's number bit for bit
+    and the same warning / assertion behaviour (distributions.py:386-399)."""
+    import warnings
+    rs = np.random.RandomState(2)
+    f = qi.ParticleDistribution._cov_from_sums
+    for _ in range(200):
+        m = rs.uniform(-3, 3)
+        s1, s2 = np.array([m]), np.array([[m * m + rs.uniform(0, 1e-3) * rs.choice([1, 1e-9])]])
+        want = s2 - np.outer(s1, s1)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            got = f(s1, s2)
+        assert got.shape == (1, 1) and got[0, 0] == want[0, 0]
+    with pytest.warns(qi.ApproximationWarning):
+        f(np.array([1.0]), np.array([[1.0 - 1e-12]]))        # negative variance from cancellation: warned, returned
+    with pytest.raises(AssertionError):
+        f(np.array([np.nan]), np.array([[1.0]]))
+    with pytest.warns(qi.ApproximationWarning):               # d = 2: the eigenvalue test of the matrix path
+        f(np.array([0.0, 0.0]), np.array([[1.0, 2.0], [2.0, 1.0]]))
+
+
+def test_make_expparam_measurement_vector():
+    v = np.linspace(0.0, 1.5, 16)
+    e = _native.make_expparam(meas=v)
+    assert list(e.meas) == v.tolist()
+    e = _native.make_expparam(meas=v[:5])
+    assert list(e.meas)[:5] == v[:5].tolist() and all(x == 0.0 for x in list(e.meas)[5:])
+
