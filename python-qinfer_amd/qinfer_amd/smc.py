@@ -305,6 +305,7 @@ class SMCUpdater(ParticleDistribution):
                 # sharded: this shard's sums land in pinned host memory like the single-GPU path, then ONE
                 # small all-gather (shared memory on one host, else the backend's) makes them global
                 n_mom = d + d * (d + 1) // 2 if d <= 4 else 0
+                eng.arm_resample_prefix(None)        # (the n_ess test of a sharded cloud needs every shard's sums)
                 if self._comm.device_transport:
                     # RCCL on the launch stream: the collective starts from the device vector the reducing kernel
                     # wrote -- no host round trip between the update and the all-reduce, one wait per datum
