@@ -383,7 +383,7 @@ def main():
         memory on one node).  Runs AFTER the JSON line is printed and reports on stderr, so the bench line never waits on
         it; a watchdog ends the process should a collective hang."""
         import threading
-        threading.Timer(float(os.environ.get("QSMC_BENCH_RCCL_DEADLINE", "120")), lambda: os._exit(0)).start()
+        threading.Timer(float(os.environ.get("QSMC_BENCH_RCCL_DEADLINE", "60")), lambda: os._exit(0)).start()
         try:
             from qinfer_amd.parallel import ParticleShardGroup
             with warnings.catch_warnings():
