@@ -239,8 +239,11 @@ class BinomialModel(NativeModelMixin, DerivedModel):
         return _native.ModelDesc(_native.MODEL_BINOMIAL_PRECESSION, 1, float(um._min_freq), 0, 0)
 
     def _native_expparams(self, expparams):
-        expparams = np.atleast_1d(expparams)
         um = self.underlying_model
+        if type(expparams) is np.ndarray and expparams.shape == (1,) and type(um) is not RandomizedBenchmarkingModel:
+            e = expparams[0]                                           # the per-datum path of update()
+            return [_native.make_expparam(t=e['x'], w_=0.0, n_meas=e['n_meas'])]
+        expparams = np.atleast_1d(expparams)
         ns = _field(expparams, 'n_meas')
         if type(um) is RandomizedBenchmarkingModel:
             ms = _field(expparams, 'm')
@@ -559,6 +562,8 @@ class RandomizedBenchmarkingModel(NativeModelMixin, FiniteOutcomeModel):
         return _native.ModelDesc(kind, self.n_modelparams, 0.0, 0, 0)
 
     def _native_expparams(self, expparams):
+        if type(expparams) is np.ndarray and expparams.shape == (1,) and not self._il:
+            return [_native.make_expparam(m=expparams[0]['m'], reference=0)]     # the per-datum path of update()
         expparams = np.atleast_1d(expparams)
         ms = _field(expparams, 'm')
         refs = _field(expparams, 'reference') if self._il else np.zeros(ms.shape, dtype=bool)
