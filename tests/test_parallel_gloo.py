@@ -400,7 +400,7 @@ def test_sharded_fast_paths_two_ranks_one_gpu(tmp_path):
 
 
 def _check_sharded_resample_vs_twin(comm, rank, world, tmpdir):
-    """The sharded Liu-West step of configs 4 and 5 (RB, 2-qubit tomography) on two ranks, particle for particle
+    """The sharded Liu-West step of configs 4 and 5 (RB, 2-qubit tomography) on `world` ranks, particle for particle
     against the oracle on IDENTICAL Philox streams: the shard totals are the shared-seed host multinomial, and each
     shard's children are what oracle/philox.py draws from that shard's weights with that rank's seed, the global mean
     and covariance -- not just invariants of the result."""
@@ -416,8 +416,8 @@ def _check_sharded_resample_vs_twin(comm, rank, world, tmpdir):
         rs = np.random.RandomState(17)
         if case == "rb":
             model, valid = qi.RandomizedBenchmarkingModel(), orc.valid_rb
-            x_all = np.stack([rs.uniform(0.9, 1, 2 * n_local), rs.uniform(0.2, 0.5, 2 * n_local),
-                              rs.uniform(0.4, 0.6, 2 * n_local)], 1)
+            x_all = np.stack([rs.uniform(0.9, 1, world * n_local), rs.uniform(0.2, 0.5, world * n_local),
+                              rs.uniform(0.4, 0.6, world * n_local)], 1)
             eps = []
             for mm in (3, 20, 60):
                 ep = np.empty((1,), dtype=model.expparams_dtype)
@@ -427,7 +427,7 @@ def _check_sharded_resample_vs_twin(comm, rank, world, tmpdir):
         else:
             basis = qi.tomography.pauli_basis(2)
             model, valid = qi.TomographyModel(basis), (lambda z: np.ones(z.shape[0], dtype=bool))
-            x_all = orc.ginibre_prior_sample(2 * n_local, basis.data, rs)
+            x_all = orc.ginibre_prior_sample(world * n_local, basis.data, rs)
             eps = []
             for pp in (3, 7, 12):
                 ep = np.zeros((1,), dtype=model.expparams_dtype)
@@ -473,6 +473,12 @@ def _check_sharded_resample_vs_twin(comm, rank, world, tmpdir):
 @pytest.mark.gpu
 def test_sharded_resample_vs_twin_two_ranks_one_gpu(tmp_path):
     _run("_check_sharded_resample_vs_twin", tmp_path, world=2)
+
+
+@pytest.mark.gpu
+def test_sharded_resample_vs_twin_four_ranks_one_gpu(tmp_path):
+    """The same with four shards (the shard plan, the per-rank seeds and the host exchange beyond a pair)."""
+    _run("_check_sharded_resample_vs_twin", tmp_path, world=4)
 
 
 def _check_perf_replicas(comm, rank, world, tmpdir):
