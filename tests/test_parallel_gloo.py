@@ -310,8 +310,12 @@ def _check_sharded_updater_variant(comm0, rank, world, tmpdir, variant):
     sizes = comm.gather_rows(np.array([float(upd.n_particles)]))[:, 0]
     assert sizes.sum() == n_local * world == upd.n_particles_global      # the global count is conserved
     if variant in ("local", "local-segmented"):
-        assert comm.n_rebalances == 0 and np.abs(sizes - n_local).max() < 0.05 * n_local
-        if world > 1:
+        # sizes float inside the tolerance; beyond it a resample rebalances (with two shards the drift of this
+        # schedule never gets there, with four it may)
+        assert np.abs(sizes - n_local).max() <= 0.05 * n_local
+        if world == 2:
+            assert comm.n_rebalances == 0
+        if world > 1 and comm.n_rebalances == 0:
             assert np.abs(sizes - n_local).max() > 0                      # sizes do float
     else:
         assert np.all(sizes == n_local)
@@ -509,6 +513,12 @@ def test_perf_test_replicas_two_ranks_one_gpu(tmp_path):
 @pytest.mark.gpu
 def test_sharded_updater_two_ranks_one_gpu(tmp_path):
     _run("_check_sharded_updater", tmp_path, world=2)
+
+
+@pytest.mark.gpu
+def test_sharded_updater_four_ranks_one_gpu(tmp_path):
+    """Four shards: the minimal-movement rebalance and the fully mixing exchange move rows between more than a pair."""
+    _run("_check_sharded_updater", tmp_path, world=4)
 
 
 def _nccl_world1(rank, port, tmpdir):
