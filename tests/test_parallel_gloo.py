@@ -516,6 +516,13 @@ def test_sharded_updater_two_ranks_one_gpu(tmp_path):
 
 
 @pytest.mark.gpu
+def test_sharded_resample_vs_twin_eight_ranks_one_gpu(tmp_path):
+    """Configs 4 and 5 are specified on eight shards: that form (reduced N, the eight processes sharing the one GPU of
+    the test box, collectives over gloo) particle for particle against the twin."""
+    _run("_check_sharded_resample_vs_twin", tmp_path, world=8)
+
+
+@pytest.mark.gpu
 def test_sharded_updater_four_ranks_one_gpu(tmp_path):
     """Four shards: the minimal-movement rebalance and the fully mixing exchange move rows between more than a pair."""
     _run("_check_sharded_updater", tmp_path, world=4)
