@@ -2,6 +2,7 @@
 """bench.py -- particle-updates/sec of the SMC hot path on MI355X (BASELINE.json metric).
 
     python bench.py --gpus 1 --steps 200 --warmup 20
+    python bench.py --gpus N --steps K --warmup W          (no launcher: spawns its own N ranks, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -21,7 +22,11 @@ One JSON line on rank 0 with `value` = N_total * K / wall, plus
                       p-u/s, and each one's kernels against their 16 + 8 d bytes / particle;
   cpu_baseline        the C / OpenMP restatement of the reference (oracle/cpu_port.c, pinned to the reference's golden
                       trajectories by tests/test_cpu_port.py) on this box's host cores, 1 thread and all cores, on the
-                      same cloud size and the first data of the same schedule.
+                      same cloud size and the first data of the same schedule;
+  transports          (sharded runs: --gpus N > 1, or --force-comm) the same K steps under each transport of the
+                      per-datum reduction: "shm" (host shared memory, the default on one node: `value` is this pass)
+                      and "rccl" (the library's own RCCL all-gather on the launch stream) with `ranks_in_comm` read
+                      back from the communicator (ncclCommCount).
 """
 import argparse
 import json
@@ -293,6 +298,24 @@ def beyond_l3(qi, eng, torch, n=100_000_000, steps=12):
     return e
 
 
+# ------------------------------------------------------------------------------------------------ launcher
+def self_launch(n_ranks):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU, rendezvous
+    on 127.0.0.1 and a free port.  Rank 0's JSON line passes through on stdout (the children inherit it)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    env["QSMC_BENCH_LAUNCHER"] = "self"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 # ------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
@@ -310,12 +333,22 @@ def main():
                     help="run the sharded code path even with one rank (validation on a 1-GPU box)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher: this process becomes one (the ranks are its children under torch.distributed.run)
+        if os.environ.get("QSMC_BENCH_SHARE_GPU") != "1":
+            import torch
+            have = torch.cuda.device_count()
+            if have < args.gpus:
+                raise SystemExit("--gpus %d but %d GPU(s) visible (QSMC_BENCH_SHARE_GPU=1 puts every rank on device 0: "
+                                 "a control-flow check, not a measurement)" % (args.gpus, have))
+        raise SystemExit(self_launch(args.gpus))
+
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     # validation hook for a 1-GPU box: QSMC_BENCH_SHARE_GPU=1 puts every rank on device 0 and talks over gloo, so
     # that the multi-rank control flow of this file can be exercised without N GPUs (not a measurement mode)
     share_gpu = os.environ.get("QSMC_BENCH_SHARE_GPU") == "1"
@@ -378,12 +411,10 @@ def main():
         return time.perf_counter() - t0
 
     def rccl_transport_pass():
-        """The same workload once more with the library's own RCCL all-reduce on the launch stream carrying the
-        per-datum reduction (north_star's transport; the headline uses whatever ParticleShardGroup picked -- host shared
-        memory on one node).  Runs AFTER the JSON line is printed and reports on stderr, so the bench line never waits on
-        it; a watchdog ends the process should a collective hang."""
-        import threading
-        threading.Timer(float(os.environ.get("QSMC_BENCH_RCCL_DEADLINE", "60")), lambda: os._exit(0)).start()
+        """The same K steps once more with the library's own RCCL collective on the launch stream carrying the
+        per-datum reduction (north_star's transport; `value` is the pass with whatever ParticleShardGroup picked -- host
+        shared memory on one node).  Returns the `transports["rccl"]` entry; `ranks_in_comm` is what the communicator
+        itself reports (ncclCommCount)."""
         try:
             from qinfer_amd.parallel import ParticleShardGroup
             with warnings.catch_warnings():
@@ -392,18 +423,18 @@ def main():
                 upd_r = qi.SMCUpdater(qi.SimplePrecessionModel(), n, qi.UniformDistribution([0, 1]),
                                       device_rng=True, seed=0, comm=comm_r)
                 wall_r = timed_pass(upd_r, events=False)
+                ranks_in_comm, rank_in_comm = comm_r.ranks_in_comm(eng)
                 wr = torch.tensor([wall_r], dtype=torch.float64, device="cuda")
                 if world > 1:
                     torch.distributed.all_reduce(wr, op=torch.distributed.ReduceOp.MAX)
-                res = {"per_datum_collective": comm_r.transport_name, "n_gpus": world,
+                res = {"per_datum_collective": comm_r.transport_name, "ranks_in_comm": ranks_in_comm,
                        "value": n * world * args.steps / float(wr.item()),
                        "ms_per_step": float(wr.item()) / args.steps * 1e3, "resamples": upd_r.resample_count,
                        "posterior_mean": float(upd_r.est_mean()[0])}
                 comm_r.close()
         except Exception as e:  # noqa: BLE001
             res = {"error": repr(e)}
-        if rank == 0:
-            print("RCCL_TRANSPORT_PASS " + json.dumps(res), file=sys.stderr, flush=True)
+        return res
 
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
@@ -469,15 +500,17 @@ def main():
                     oc[spec["key"]] = {"error": repr(e)}
             extras["other_configs"] = oc
 
-    # RCCL prints a version banner through C stdio, which (not a tty) would be flushed at exit -- after the
-    # JSON line.  Push whatever C stdio holds to stderr now so that the JSON line is the last line of stdout.
-    import ctypes
-    sys.stdout.flush()
-    saved = os.dup(1)
-    os.dup2(2, 1)
-    ctypes.CDLL(None).fflush(None)
-    os.dup2(saved, 1)
-    os.close(saved)
+    def drain_c_stdio():
+        # RCCL prints a version banner through C stdio, which (not a tty) would be flushed at exit -- after the
+        # JSON line.  Push whatever C stdio holds to stderr so that the JSON line is the last line of stdout.
+        import ctypes
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        ctypes.CDLL(None).fflush(None)
+        os.dup2(saved, 1)
+        os.close(saved)
+    drain_c_stdio()
 
     if rank == 0 and os.environ.get("QSMC_BENCH_NO_EVENTS"):
         # diagnostic only (not the bench line): the same loop without the per-kernel events
@@ -547,15 +580,60 @@ def main():
                 line["cpu_baseline"] = cpu_baseline(n, args.cpu_data, gpu_same_sample)
             except Exception as e:  # noqa: BLE001
                 line["cpu_baseline"] = {"error": repr(e)}
-        print(json.dumps(line), flush=True)
-    if ((world > 1 or os.environ.get("QSMC_BENCH_FORCE_RCCL_PASS")) and not share_gpu and comm is not None
-            and comm.transport != "rccl" and not os.environ.get("QSMC_BENCH_NO_RCCL_PASS")):
-        rccl_transport_pass()
+        line["config"]["launcher"] = os.environ.get("QSMC_BENCH_LAUNCHER", "torchrun" if "TORCHELASTIC_RUN_ID" in os.environ
+                                                    else "none")
+    else:
+        line = None
+
+    # ---- the transports of the per-datum reduction, both inside the line (sharded runs only)
+    done = {"printed": False}
+
+    def emit():
+        if rank == 0 and not done["printed"]:
+            done["printed"] = True
+            drain_c_stdio()
+            print(json.dumps(line), flush=True)
+
+    watchdog = None
+    if comm is not None:
+        key = "rccl" if comm.transport == "rccl" else ("shm" if comm.transport_name == "host shared memory" else "backend")
+        if rank == 0:
+            line["transports"] = {key: {"per_datum_collective": comm.transport_name, "value": line["value"],
+                                        "ms_per_step": line["ms_per_step"], "resamples": resamples_timed,
+                                        "posterior_mean": posterior_mean, "headline": True}}
+        want_rccl = ((world > 1 or os.environ.get("QSMC_BENCH_FORCE_RCCL_PASS")) and comm.transport != "rccl"
+                     and not os.environ.get("QSMC_BENCH_NO_RCCL_PASS"))
+        if want_rccl and share_gpu:
+            if rank == 0:
+                line["transports"]["rccl"] = {"skipped": "QSMC_BENCH_SHARE_GPU=1: every rank sits on device 0 (control-flow "
+                                                         "check); an RCCL communicator needs one GPU per rank"}
+        elif want_rccl:
+            # a collective that hangs must not take the line with it: past the deadline rank 0 prints the line with
+            # the time-out recorded and every rank leaves
+            import threading
+            deadline = float(os.environ.get("QSMC_BENCH_RCCL_DEADLINE", "60"))
+
+            def give_up():
+                if rank == 0:
+                    line["transports"]["rccl"] = {"error": "no result within %.0f s (watchdog)" % deadline}
+                emit()
+                os._exit(0)
+            watchdog = threading.Timer(deadline, give_up)
+            watchdog.daemon = True
+            watchdog.start()
+            res = rccl_transport_pass()
+            watchdog.cancel()
+            if rank == 0:
+                line["transports"]["rccl"] = res
+    emit()
     if world > 1 or args.force_comm:
-        comm.close()
-        torch.distributed.destroy_process_group()
-    if ((world > 1 or os.environ.get("QSMC_BENCH_FORCE_RCCL_PASS")) and not share_gpu and comm is not None):
-        os._exit(0)                                   # (the watchdog timer thread must not keep the process alive)
+        sys.stdout.flush()
+        try:
+            comm.close()
+            torch.distributed.destroy_process_group()
+        finally:
+            if watchdog is not None:
+                os._exit(0)                               # (RCCL's own threads must not keep the process alive)
 
 
 if __name__ == "__main__":

@@ -213,15 +213,20 @@ int qsmc_host_allreduce(void *segment, int32_t rank, int32_t world, int32_t max_
  * same id; qsmc_comm_destroy: also done by qsmc_destroy.  librccl is bound at run time (dlsym), preferring the copy
  * already loaded in the process.
  * qsmc_allreduce_sums: vec_dev = this rank's n doubles on the DEVICE (the stats_dev vector qsmc_update_fused just
- * wrote: [sum w', sum w'^2, min w', #bad, moment sums...]); on `stream`, behind the kernel that produced it: one
- * group of ncclAllReduce(sum) over the n entries, ncclAllReduce(min) of entry min_index (if >= 0) and an
- * all-gather of entry 0, then a publishing kernel; returns when the result is in tot_host[n] (entry min_index =
- * the minimum) and firsts_host[nranks] (every rank's entry 0 = its shard's weight total, nullable).  This is the
- * collective the reference's DirectViewParallelizedModel stands in for with a gather of the whole likelihood
- * array (parallel.py:216-224); identical bits on every rank (RCCL's guarantee for all-reduce). */
+ * wrote: [sum w', sum w'^2, min w', #bad, moment sums...]); on `stream`, behind the kernel that produced it: ONE
+ * ncclAllGather of the n entries of every rank, then a one-workgroup kernel that adds the rows IN RANK ORDER (entry
+ * min_index, if >= 0: the minimum, NaN propagating) and publishes the totals; returns when they are in tot_host[n]
+ * and firsts_host[nranks] (every rank's entry 0 = its shard's weight total, nullable).  n + nranks <= 188.  This is
+ * the collective the reference's DirectViewParallelizedModel stands in for with a gather of the whole likelihood
+ * array (parallel.py:216-224).  A gather moves bits without arithmetic and the summation order is fixed, so every
+ * rank holds identical totals (and therefore takes the same n_ess / resample decision, smc.py:263-277), identical
+ * also to qsmc_host_allreduce's on the same rows.
+ * qsmc_comm_count: ranks in the communicator and this rank's index as RCCL itself reports them (ncclCommCount /
+ * ncclCommUserRank) -- what bench.py records as `ranks_in_comm`. */
 int qsmc_comm_unique_id(void *id_out);
 int qsmc_comm_init(qsmc_handle_t h, int32_t rank, int32_t nranks, const void *unique_id);
 int qsmc_comm_destroy(qsmc_handle_t h);
+int qsmc_comm_count(qsmc_handle_t h, int32_t *nranks_out, int32_t *rank_out);
 int qsmc_allreduce_sums(qsmc_handle_t h, const double *vec_dev, int32_t n, int32_t min_index, double *tot_host,
                         double *firsts_host, qsmc_stream_t stream);
 

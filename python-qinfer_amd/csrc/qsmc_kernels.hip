@@ -99,13 +99,12 @@ struct qsmc_ctx {
         void *lib;
         ncclComm_t comm;
         int rank, nranks;
-        double *buf;               // device: [sums (REDUCE_OUT_MAX) | min (8) | gathered firsts (QSMC_MAX_RANKS)]
+        double *buf;               // device: every rank's vector, [QSMC_MAX_RANKS][REDUCE_OUT_MAX]
         decltype(&ncclCommInitRank) CommInitRank;
         decltype(&ncclCommDestroy) CommDestroy;
-        decltype(&ncclAllReduce) AllReduce;
+        decltype(&ncclCommCount) CommCount;
+        decltype(&ncclCommUserRank) CommUserRank;
         decltype(&ncclAllGather) AllGather;
-        decltype(&ncclGroupStart) GroupStart;
-        decltype(&ncclGroupEnd) GroupEnd;
         decltype(&ncclGetErrorString) GetErrorString;
     } cc;
     int profiling;
@@ -1615,11 +1614,13 @@ int qsmc_searchsorted(qsmc_handle_t h, const double *a, int64_t n, const double 
 
 // ---- RCCL: the per-datum reduction of the sharded updater on the launch stream ----------
 // Replaces what the reference does with an ipyparallel gather of the likelihood array (parallel.py:216-224): here
-// only the update kernel's sums cross the links.  One group of three collectives on `stream`, right behind the
-// kernel that produced the vector -- all-reduce(sum) of the n sums, all-reduce(min) of the weight minimum, and an
-// all-gather of entry 0 (every rank's sum of weights: the next resample's shard plan) -- then a one-wave kernel
-// publishes the result in the pinned slot the completion word already guards, so the host's only wait per datum
-// is the same spin it does on one GPU.  librccl is bound with dlsym, preferring the copy already in the process
+// only the update kernel's sums cross the links.  ONE collective on `stream`, right behind the kernel that produced
+// the vector: an all-gather of every rank's n doubles (18 at d = 3: bytes, not bandwidth); a one-workgroup kernel then
+// sums the rows in rank order (the weight minimum: min; entry 0 of every row doubles as that shard's weight total, the
+// next resample's shard plan) and publishes the result in the pinned slot the completion word already guards, so the
+// host's only wait per datum is the same spin it does on one GPU.  Round 2 used all-reduce(sum) + all-reduce(min) +
+// all-gather in a group: three collectives, and the sums' association order was RCCL's; a gather moves bits only, so
+// every rank -- and the shared-memory transport -- forms the same totals and takes the same resample decision.  librccl is bound with dlsym, preferring the copy already in the process
 // (torch's): two RCCLs would mean two HIP runtimes.
 constexpr int QSMC_MAX_RANKS = 64;
 
@@ -1656,7 +1657,7 @@ int qsmc_comm_init(qsmc_handle_t h, int32_t rank, int32_t nranks, const void *un
 #define BIND(NAME)                                                                         \
     h->cc.NAME = reinterpret_cast<decltype(&nccl##NAME)>(dlsym(lib, "nccl" #NAME));         \
     if (!h->cc.NAME) { snprintf(h->hip_err, sizeof(h->hip_err), "nccl" #NAME " missing"); return QSMC_ERR_UNSUPPORTED; }
-    BIND(CommInitRank) BIND(CommDestroy) BIND(AllReduce) BIND(AllGather) BIND(GroupStart) BIND(GroupEnd) BIND(GetErrorString)
+    BIND(CommInitRank) BIND(CommDestroy) BIND(CommCount) BIND(CommUserRank) BIND(AllGather) BIND(GetErrorString)
 #undef BIND
     HIP_TRY(h, hipSetDevice(h->device));
     ncclUniqueId id;
@@ -1667,7 +1668,7 @@ int qsmc_comm_init(qsmc_handle_t h, int32_t rank, int32_t nranks, const void *un
         snprintf(h->hip_err, sizeof(h->hip_err), "ncclCommInitRank: %s", h->cc.GetErrorString(r));
         return QSMC_ERR_HIP;
     }
-    HIP_TRY(h, hipMalloc(&h->cc.buf, (REDUCE_OUT_MAX + 8 + QSMC_MAX_RANKS) * sizeof(double)));
+    HIP_TRY(h, hipMalloc(&h->cc.buf, (size_t)QSMC_MAX_RANKS * REDUCE_OUT_MAX * sizeof(double)));
     h->cc.comm = comm;
     h->cc.rank = rank;
     h->cc.nranks = nranks;
@@ -1687,13 +1688,26 @@ int qsmc_comm_destroy(qsmc_handle_t h) {
     return QSMC_OK;
 }
 
-__global__ void k_publish_allreduce(const double *__restrict__ sums, const double *__restrict__ mn, const double *__restrict__ firsts,
-                                    int n, int min_index, int nranks, double *__restrict__ mapped, unsigned long long *flag,
-                                    unsigned long long seq, const unsigned long long *__restrict__ counters,
-                                    double *__restrict__ failed_dst) {
+// rows[r][0..n): rank r's vector as the all-gather delivered it.  Thread t sums entry t over the ranks IN RANK ORDER
+// (entry min_index: the minimum, NaN propagating) -- the very loop qsmc_host_allreduce runs on the host, so the two
+// transports agree bit for bit and, an all-gather moving bits without arithmetic, so do all ranks.
+__global__ void k_publish_allgather(const double *__restrict__ rows, int n, int min_index, int nranks,
+                                    double *__restrict__ mapped, unsigned long long *flag, unsigned long long seq,
+                                    const unsigned long long *__restrict__ counters, double *__restrict__ failed_dst) {
     const int t = threadIdx.x;
-    if (t < n) mapped[t] = t == min_index ? mn[0] : sums[t];
-    if (t < nranks) mapped[n + t] = firsts[t];
+    if (t < n) {
+        double acc = rows[t];
+        if (t == min_index) {
+            for (int r = 1; r < nranks; ++r) {
+                const double v = rows[(size_t)r * n + t];
+                acc = (v < acc || v != v) ? v : acc;
+            }
+        } else {
+            for (int r = 1; r < nranks; ++r) acc += rows[(size_t)r * n + t];
+        }
+        mapped[t] = acc;
+    }
+    if (t < nranks) mapped[n + t] = rows[(size_t)t * n];
     if (t == 0) {                    // like every host-visible reduction: the last resample's failed / redraw counts ride along
         failed_dst[0] = (double)counters[0];
         failed_dst[-1] = (double)counters[1];
@@ -1705,24 +1719,36 @@ __global__ void k_publish_allreduce(const double *__restrict__ sums, const doubl
     }
 }
 
+int qsmc_comm_count(qsmc_handle_t h, int32_t *nranks_out, int32_t *rank_out) {
+    if (!h || !nranks_out) return QSMC_ERR_INVALID;
+    if (!h->cc.comm) return QSMC_ERR_INVALID;
+    int count = -1, rank = -1;
+    ncclResult_t r = h->cc.CommCount(h->cc.comm, &count);
+    if (r == ncclSuccess) r = h->cc.CommUserRank(h->cc.comm, &rank);
+    if (r != ncclSuccess) {
+        snprintf(h->hip_err, sizeof(h->hip_err), "rccl: %s", h->cc.GetErrorString(r));
+        return QSMC_ERR_HIP;
+    }
+    *nranks_out = count;
+    if (rank_out) *rank_out = rank;
+    return QSMC_OK;
+}
+
 int qsmc_allreduce_sums(qsmc_handle_t h, const double *vec_dev, int32_t n, int32_t min_index, double *tot_host,
                         double *firsts_host, qsmc_stream_t stream) {
-    if (!h || !vec_dev || !tot_host || n < 1 || n > REDUCE_OUT_MAX - QSMC_MAX_RANKS || min_index >= n) return QSMC_ERR_INVALID;
+    if (!h || !vec_dev || !tot_host || n < 1 || min_index >= n) return QSMC_ERR_INVALID;
     if (!h->cc.comm) return QSMC_ERR_INVALID;
+    // the result and every rank's entry 0 share the pinned block with the four reserved tail slots (failed count,
+    // redraw count, prefix gate and its normaliser)
+    if (n + h->cc.nranks > REDUCE_OUT_MAX - 4) return QSMC_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
-    double *sums = h->cc.buf, *mn = h->cc.buf + REDUCE_OUT_MAX, *firsts = mn + 8;
-    ncclResult_t r = h->cc.GroupStart();
-    if (r == ncclSuccess) r = h->cc.AllReduce(vec_dev, sums, (size_t)n, ncclDouble, ncclSum, h->cc.comm, s);
-    if (r == ncclSuccess && min_index >= 0) r = h->cc.AllReduce(vec_dev + min_index, mn, 1, ncclDouble, ncclMin, h->cc.comm, s);
-    if (r == ncclSuccess) r = h->cc.AllGather(vec_dev, firsts, 1, ncclDouble, h->cc.comm, s);
-    const ncclResult_t r2 = h->cc.GroupEnd();
-    if (r == ncclSuccess) r = r2;
+    const ncclResult_t r = h->cc.AllGather(vec_dev, h->cc.buf, (size_t)n, ncclDouble, h->cc.comm, s);
     if (r != ncclSuccess) {
         snprintf(h->hip_err, sizeof(h->hip_err), "rccl: %s", h->cc.GetErrorString(r));
         return QSMC_ERR_HIP;
     }
     const unsigned long long seq = ++h->seq;
-    hipLaunchKernelGGL(k_publish_allreduce, dim3(1), dim3(256), 0, s, sums, mn, firsts, (int)n, (int)min_index, h->cc.nranks,
+    hipLaunchKernelGGL(k_publish_allgather, dim3(1), dim3(256), 0, s, h->cc.buf, (int)n, (int)min_index, h->cc.nranks,
                        h->mapped_dev, h->flag_dev, seq, reinterpret_cast<const unsigned long long *>(h->counter),
                        h->mapped_dev + (REDUCE_OUT_MAX - 1));
     HIP_TRY(h, hipGetLastError());

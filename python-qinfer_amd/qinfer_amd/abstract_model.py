@@ -225,20 +225,33 @@ class FiniteOutcomeModel(Model):
 _KERNEL_BACKED = ("likelihood", "are_models_valid", "update_timestep", "canonicalize", "n_outcomes", "domain")
 
 
+_OWN_MODULES = frozenset(__name__.rsplit(".", 1)[0] + "." + m for m in ("abstract_model", "models", "tomography"))
+_CLASS_OK = {}
+
+
+def _class_is_native(cls):
+    """Every kernel-backed method of `cls` is DEFINED by a class of this library (looked up along the MRO, so
+    properties, partials and builtins -- which carry no __module__ of their own -- are judged by the class that
+    holds them).  Cached per class."""
+    ok = _CLASS_OK.get(cls)
+    if ok is None:
+        ok = True
+        for name in _KERNEL_BACKED:
+            owner = next((k for k in cls.__mro__ if name in vars(k)), None)
+            if owner is not None and owner.__module__ not in _OWN_MODULES:
+                ok = False
+                break
+        _CLASS_OK[cls] = ok
+    return ok
+
+
 def native_ok(model):
     """True if `model` is served by the HIP kernels: it declares native hooks AND every kernel-backed method of
     its class is this library's own implementation (the reference dispatches on the overriding method,
     abstract_model.py:444-528; a user override must win here too)."""
     if model is None or not getattr(model, "_native", False):
         return False
-    cls = type(model)
-    pkg = __name__.rsplit(".", 1)[0] + "."
-    for name in _KERNEL_BACKED:
-        fn = getattr(cls, name, None)
-        mod = getattr(fn, "__module__", None) or ""
-        if fn is not None and not mod.startswith(pkg):
-            return False
-    return True
+    return _class_is_native(type(model))
 
 
 class NativeModelMixin:

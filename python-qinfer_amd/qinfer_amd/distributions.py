@@ -147,11 +147,16 @@ class DeviceBackedArray(np.ndarray):
     """What `particle_locations` / `particle_weights` return: a host snapshot of the device array that WRITES
     THROUGH.  The reference holds these as plain NumPy attributes and mutates them in place
     (`self.particle_weights[:] = ...`, smc.py:441; `self.particle_locations[:, :] = ...`, smc.py:529), so user code
-    written against it does the same; here every in-place write (item / slice assignment, an in-place operator or
-    a ufunc with `out=`, `fill`) -- also through a slice of the snapshot -- is followed by an upload of the whole
-    array to the device.  A snapshot taken before the cloud changed underneath it (an update, a resample, another
-    assignment) is stale: reading it gives the old numbers, writing to it raises instead of silently losing data.
-    Arithmetic on a snapshot returns plain arrays."""
+    written against it does the same; here every in-place write -- item / slice assignment, an in-place operator, a
+    ufunc with `out=` or `.at`, `fill`, `sort`, `put`, `itemset`-style method calls, `np.copyto` / `np.put` /
+    `np.place` / `np.putmask` with the snapshot as destination -- also through a VIEW of the snapshot (a basic slice,
+    a transpose) -- is followed by an upload of the whole array to the device.  A snapshot taken before the cloud
+    changed underneath it (an update, a resample, another assignment) is stale: reading it gives the old numbers,
+    writing to it raises instead of silently losing data.
+    Arithmetic on a snapshot, `.copy()`, and fancy / boolean-mask indexing (`snap[mask]`, `snap[[1, 2]]`) return
+    arrays that own their memory: editing those touches nothing else, exactly as with the reference's plain arrays.
+    One path cannot be seen from here and does NOT write through: writing via `np.asarray(snap)` / a memoryview of the
+    snapshot (the base-class view drops the subclass); assign the result back (`upd.particle_weights = w`)."""
 
     def __new__(cls, arr, owner, what):
         obj = np.asarray(arr).view(cls)
@@ -161,9 +166,12 @@ class DeviceBackedArray(np.ndarray):
 
     def __array_finalize__(self, obj):
         root = getattr(obj, "_root", None)
-        if root is not None and self.base is not None:        # a view INTO a snapshot: shares its memory
+        # a view INTO a snapshot shares its memory and writes through; anything else derived from one (NumPy wraps the
+        # results of fancy / mask indexing and of `take` in the subclass too, with `.base` set to a private buffer) is
+        # a copy and behaves like a plain array
+        if root is not None and self.base is not None and np.may_share_memory(self, root):
             self._root, self._owner, self._what = root, obj._owner, obj._what
-        else:                                                  # a fresh array (copy, result): plain behaviour
+        else:
             self._root = None
 
     def _push(self):
@@ -185,17 +193,44 @@ class DeviceBackedArray(np.ndarray):
         np.ndarray.fill(self, value)
         self._push()
 
+    def sort(self, *args, **kwargs):
+        np.ndarray.sort(self, *args, **kwargs)
+        self._push()
+
+    def put(self, *args, **kwargs):
+        np.ndarray.put(self, *args, **kwargs)
+        self._push()
+
+    def partition(self, *args, **kwargs):
+        np.ndarray.partition(self, *args, **kwargs)
+        self._push()
+
     def __array_ufunc__(self, ufunc, method, *inputs, out=None, **kwargs):
         plain = tuple(np.asarray(i) if isinstance(i, DeviceBackedArray) else i for i in inputs)
         touched = []
         if out is not None:
             touched = [o for o in out if isinstance(o, DeviceBackedArray)]
             kwargs["out"] = tuple(np.asarray(o) if isinstance(o, DeviceBackedArray) else o for o in out)
+        if method == "at" and inputs and isinstance(inputs[0], DeviceBackedArray):
+            touched.append(inputs[0])                   # ufunc.at(a, idx[, b]) edits its first operand in place
         res = getattr(ufunc, method)(*plain, **kwargs)
         for o in touched:
             o._push()
         if out is not None and len(out) == 1 and touched:
             return out[0]
+        return res
+
+    _INPLACE_FUNCS = {np.copyto: "dst", np.put: "a", np.place: "arr", np.putmask: "a"}
+
+    def __array_function__(self, func, types, args, kwargs):
+        dst_name = self._INPLACE_FUNCS.get(func)
+        if dst_name is None:
+            return super().__array_function__(func, types, args, kwargs)
+        dst = args[0] if args else kwargs.get(dst_name)
+        strip = lambda a: np.asarray(a) if isinstance(a, DeviceBackedArray) else a     # noqa: E731
+        res = func(*[strip(a) for a in args], **{k: strip(v) for k, v in kwargs.items()})
+        if isinstance(dst, DeviceBackedArray):
+            dst._push()
         return res
 
 

@@ -291,15 +291,27 @@ class Engine:
         """Collective: every rank of the shard group, same id."""
         self._chk(self.lib.qsmc_comm_init(self.h, int(rank), int(nranks), C.create_string_buffer(unique_id, 128)),
                   "qsmc_comm_init")
-        self._cc_tot = np.empty(64)
+        self._cc_tot = np.empty(self.REDUCE_MAX)          # the C side's bound on n (+ nranks) -- see allreduce_sums
         self._cc_first = np.empty(int(nranks))
+        self._cc_nranks = int(nranks)
+
+    REDUCE_MAX = 188              # REDUCE_OUT_MAX - 4 reserved tail slots of the pinned block (qsmc_kernels.hip)
+
+    def comm_count(self):
+        """(ranks in the communicator, this rank's index) as RCCL reports them (ncclCommCount / ncclCommUserRank)."""
+        n, r = C.c_int32(), C.c_int32()
+        self._chk(self.lib.qsmc_comm_count(self.h, C.byref(n), C.byref(r)), "qsmc_comm_count")
+        return n.value, r.value
 
     def comm_destroy(self):
         self._chk(self.lib.qsmc_comm_destroy(self.h), "qsmc_comm_destroy")
 
     def allreduce_sums(self, vec_dev, n, min_index=-1):
-        """RCCL all-reduce of the first n doubles of a device vector on the launch stream.  Returns (tot, firsts):
-        views of reused host arrays -- sums over ranks (entry min_index: minimum) and every rank's entry 0."""
+        """RCCL all-gather + rank-ordered sum of the first n doubles of a device vector on the launch stream.  Returns
+        (tot, firsts): views of reused host arrays -- sums over ranks (entry min_index: minimum) and every rank's
+        entry 0."""
+        if n + self._cc_nranks > self.REDUCE_MAX:
+            raise ValueError("allreduce_sums: n + nranks = {} exceeds {}".format(n + self._cc_nranks, self.REDUCE_MAX))
         self._chk(self.lib.qsmc_allreduce_sums(self.h, self._p(vec_dev), int(n), int(min_index), self._cc_tot.ctypes.data,
                                                self._cc_first.ctypes.data, self.stream()), "qsmc_allreduce_sums")
         return self._cc_tot[:n], self._cc_first

@@ -204,7 +204,11 @@ class BinomialModel(NativeModelMixin, DerivedModel):
         else:
             self._expparams_scalar = False
             self._expparams_dtype = underlying_model.expparams_dtype + [('n_meas', 'uint')]
-        self._native = type(underlying_model) in (SimplePrecessionModel, RandomizedBenchmarkingModel)
+        # kernels exist for Binomial(SimplePrecession) and Binomial(RB[interleaved]); the same rule as every other
+        # decorator decides whether the underlying model is the library's own (abstract_model.native_ok)
+        self._native = (native_ok(underlying_model)
+                        and isinstance(underlying_model, (SimplePrecessionModel, RandomizedBenchmarkingModel)))
+        self._um_is_rb = isinstance(underlying_model, RandomizedBenchmarkingModel)
 
     @property
     def decorated_model(self):
@@ -233,19 +237,19 @@ class BinomialModel(NativeModelMixin, DerivedModel):
     # native hooks
     def _native_desc(self):
         um = self.underlying_model
-        if type(um) is RandomizedBenchmarkingModel:
+        if self._um_is_rb:
             kind = _native.MODEL_BINOMIAL_RB_INTERLEAVED if um._il else _native.MODEL_BINOMIAL_RB
             return _native.ModelDesc(kind, um.n_modelparams, 0.0, 0, 0)
         return _native.ModelDesc(_native.MODEL_BINOMIAL_PRECESSION, 1, float(um._min_freq), 0, 0)
 
     def _native_expparams(self, expparams):
         um = self.underlying_model
-        if type(expparams) is np.ndarray and expparams.shape == (1,) and type(um) is not RandomizedBenchmarkingModel:
+        if type(expparams) is np.ndarray and expparams.shape == (1,) and not self._um_is_rb:
             e = expparams[0]                                           # the per-datum path of update()
             return [_native.make_expparam(t=e['x'], w_=0.0, n_meas=e['n_meas'])]
         expparams = np.atleast_1d(expparams)
         ns = _field(expparams, 'n_meas')
-        if type(um) is RandomizedBenchmarkingModel:
+        if self._um_is_rb:
             ms = _field(expparams, 'm')
             refs = _field(expparams, 'reference') if um._il else np.zeros(ms.shape, dtype=bool)
             return [_native.make_expparam(m=m, reference=int(bool(r)), n_meas=n) for m, r, n in zip(ms, refs, ns)]

@@ -173,8 +173,8 @@ class ParticleShardGroup:
     `transport` selects what carries the per-datum reduction (a dozen doubles per rank):
       "auto"     host shared memory when every rank runs on this host (measured ~4 us per datum), else "backend";
       "shm"      host shared memory (HostExchange) or fail;
-      "rccl"     the library's own RCCL communicator: all-reduce on the launch stream, right behind the update kernel
-                 (`qsmc_allreduce_sums`; needs one GPU per rank);
+      "rccl"     the library's own RCCL communicator: all-gather on the launch stream, right behind the update kernel,
+                 and a rank-ordered sum on the device (`qsmc_allreduce_sums`; needs one GPU per rank);
       "backend"  torch.distributed's all-gather (gloo on CPU, RCCL through torch on GPUs).
     The environment variable QSMC_TRANSPORT overrides the argument."""
 
@@ -254,7 +254,7 @@ class ParticleShardGroup:
     def transport_name(self):
         """What carries the per-datum reduction (bench.py reports it)."""
         if self.transport == "rccl":
-            return "RCCL all-reduce on the launch stream (qsmc_allreduce_sums)"
+            return "RCCL all-gather on the launch stream + rank-ordered device sum (qsmc_allreduce_sums)"
         return "host shared memory" if self._host is not None else "backend all-gather (%s)" % self.backend
 
     @property
@@ -272,9 +272,15 @@ class ParticleShardGroup:
             self._rccl = eng
         return self._rccl
 
+    def ranks_in_comm(self, eng):
+        """(ranks, this rank's index) read back from the library's RCCL communicator (ncclCommCount /
+        ncclCommUserRank): the record that RCCL itself saw every rank of the group."""
+        return self._rccl_engine(eng).comm_count()
+
     def allreduce_update_stats_device(self, eng, n):
         """The per-datum reduction under transport='rccl': the update kernel left [sum, sumsq, min, #bad, moment
-        sums...] in the engine's device vector; one group of RCCL collectives on the launch stream makes them global."""
+        sums...] in the engine's device vector; one RCCL all-gather on the launch stream and a rank-ordered sum on the
+        device make them global -- the same bits on every rank, and the same as the shared-memory transport forms."""
         tot, firsts = self._rccl_engine(eng).allreduce_sums(eng._stats, n, 2)
         self.last_shard_sums = firsts.copy()
         self.last_extra = tot[4:].copy()

@@ -243,11 +243,17 @@ class SMCUpdater(ParticleDistribution):
         whole = isinstance(rows, slice) and rows == slice(None)
         if native_ok(model) and whole and getattr(model, "_native_canonicalize_ok", lambda: False)():
             model._native_canonicalize_(self._eng, self._x)
-        else:                                         # plugin slow path
-            locs = self.particle_locations
+        else:                                         # plugin slow path (plain host arrays: no write-through uploads)
+            locs = self._host_locations()
             locs[:, rows] = model.canonicalize(locs[:, rows])
             self._x = self._eng.locs_to_soa(locs)
         self._invalidate()
+
+    def _host_locations(self):
+        """(N, d) bare ndarray copy of the cloud for the library's own host paths and for user model callbacks
+        (`likelihood`, `canonicalize`, `update_timestep`): an in-place operation inside a plugin must not trigger a
+        whole-cloud upload per statement, as it would on the write-through snapshot `particle_locations` returns."""
+        return np.ascontiguousarray(self._x.cpu().numpy().T)
 
     # ------------------------------------------------------------------ updates
     def hypothetical_update(self, outcomes, expparams, return_likelihood=False, return_normalization=False):
@@ -286,7 +292,7 @@ class SMCUpdater(ParticleDistribution):
         if self._native:
             return self._eng.likelihood(self._desc, self._x, self.model._native_expparams(expparams),
                                         outcomes.astype(np.int64))
-        L = np.asarray(self.model.likelihood(outcomes, self.particle_locations, expparams), dtype=np.float64)
+        L = np.asarray(self.model.likelihood(outcomes, self._host_locations(), expparams), dtype=np.float64)
         return self._eng.to_device(np.ascontiguousarray(L.transpose(0, 2, 1)))
 
     def update(self, outcome, expparams, check_for_resample=True):
@@ -393,7 +399,7 @@ class SMCUpdater(ParticleDistribution):
         elif not self._timestep_identity:
             # plugin slow path: a model that moves particles between data and has no device step -- a user
             # model, or a decorator over one (smc.py:447-449; DerivedModel forwards update_timestep)
-            locs = self.model.update_timestep(self.particle_locations, expparams)[:, :, 0]
+            locs = self.model.update_timestep(self._host_locations(), expparams)[:, :, 0]
             self._x = self._eng.locs_to_soa(locs)
             self._invalidate()
 

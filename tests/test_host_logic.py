@@ -261,3 +261,81 @@ def test_make_expparam_measurement_vector():
     e = _native.make_expparam(meas=v[:5])
     assert list(e.meas)[:5] == v[:5].tolist() and all(x == 0.0 for x in list(e.meas)[5:])
 
+
+
+def test_device_backed_array_copies_do_not_write_through():
+    """A write-through snapshot (distributions.DeviceBackedArray) uploads on in-place writes to itself and to VIEWS of
+    itself -- and only those: what fancy / boolean-mask indexing returns owns its memory (as with the reference's
+    plain arrays) and must neither upload nor raise 'stale snapshot' when edited after the cloud changed."""
+    from qinfer_amd.distributions import DeviceBackedArray
+
+    class Owner:
+        _view_version = 0
+
+        def __init__(self):
+            self.uploads = []
+
+        def _write_back(self, what, arr):
+            self.uploads.append((what, np.array(arr)))
+            self._view_version += 1
+
+    own = Owner()
+    snap = DeviceBackedArray(np.arange(10.0), own, "weights")
+    mask = np.arange(10) % 2 == 0
+    sel, fancy, taken = snap[mask], snap[[1, 2, 3]], snap.take([4, 5])
+    view = snap[2:5]
+    assert not np.shares_memory(sel, snap) and np.shares_memory(view, snap)
+    own._view_version += 1                                # an update / resample happened: `snap` is stale now
+    sel[0] = -1.0                                         # private copies: no upload, no raise
+    fancy += 1.0
+    taken.fill(0.0)
+    sel.sort()
+    assert own.uploads == [] and snap[0] == 0.0
+    with pytest.raises(RuntimeError, match="snapshot"):
+        view[0] = 7.0                                     # a view of the stale snapshot is stale too
+    # a fresh snapshot: every in-place path uploads, through views as well
+    own = Owner()
+    snap = DeviceBackedArray(np.arange(10.0), own, "locations")
+    snap[3] = 30.0
+    snap[2:5][0] = 20.0
+    snap.T[9] = 90.0
+    np.copyto(snap, snap[::-1].copy())
+    np.put(snap, [0], [5.0])
+    np.add.at(snap, [1, 1], 1.0)
+    np.place(snap, snap > 80, [1.0])
+    np.putmask(snap, np.asarray(snap) == 1.0, 2.0)
+    snap.sort()
+    snap.put([0], [-3.0])
+    assert len(own.uploads) == 10
+    assert own.uploads[-1][1][0] == -3.0 and own.uploads[0][1][3] == 30.0
+    out = snap * 2                                        # arithmetic: a plain result
+    out[0] = 1e9
+    assert len(own.uploads) == 10
+
+
+def test_native_ok_judges_by_defining_class():
+    """abstract_model.native_ok: the library's kernels stand for a model only if every kernel-backed method is DEFINED
+    by a class of the library -- judged along the MRO (a property, a functools.partial or a builtin has no __module__ of
+    its own), cached per class, and a user module whose name merely starts with 'qinfer_amd.' does not pass."""
+    import functools
+    import qinfer_amd as qi
+    from qinfer_amd import abstract_model as am
+
+    class Plain(qi.SimplePrecessionModel):                # adds nothing kernel-backed: still native
+        def extra(self):
+            return 1
+
+    class WithPartial(qi.SimplePrecessionModel):          # an override without a __module__ of its own: plugin path
+        likelihood = functools.partial(lambda self, *a, **k: None)
+    assert getattr(WithPartial.likelihood, "__module__", None) in (None, "functools")
+
+    class Spoof(qi.SimplePrecessionModel):
+        def are_models_valid(self, modelparams):
+            return np.ones(modelparams.shape[0], dtype=bool)
+    Spoof.__module__ = "qinfer_amd.userstuff"
+    assert am.native_ok(qi.SimplePrecessionModel()) and am.native_ok(Plain())
+    assert not am.native_ok(WithPartial()) and not am.native_ok(Spoof())
+    assert am._CLASS_OK[Plain] is True and am._CLASS_OK[Spoof] is False
+    # BinomialModel follows the same rule for its underlying model
+    assert qi.BinomialModel(Plain())._native and not qi.BinomialModel(Spoof())._native
+    assert qi.BinomialModel(qi.RandomizedBenchmarkingModel())._native

@@ -269,6 +269,65 @@ def test_host_exchange_failure_is_collective(tmp_path):
     _run("_check_host_exchange_failure_is_collective", tmp_path)
 
 
+def _check_same_decision_under_order_sensitive_sums(comm0, rank, world, tmpdir):
+    """The resample decision must be the same on every rank whatever the backend's reduction does with association
+    order (an all-reduce may add in a rank-dependent order; RCCL promises no order).  The per-datum reduction
+    therefore never asks the backend to REDUCE: it gathers (bits only) and adds the rows in rank order itself --
+    shared memory, the backend path and (on the device, qsmc_allreduce_sums) RCCL alike.  Here: the backend's
+    all_reduce is replaced by one that adds starting from the caller's own rank (non-associative on these data), and
+    the sums are chosen so that the order flips the n_ess test."""
+    import torch
+    import torch.distributed as dist
+    import qinfer_amd.parallel as par
+    calls = {"all_reduce": 0}
+    real_all_reduce = dist.all_reduce
+
+    def rank_rotated_all_reduce(t, op=dist.ReduceOp.SUM, group=None, async_op=False):
+        calls["all_reduce"] += 1
+        rows = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(rows, t.contiguous(), group=group)
+        acc = rows[rank].clone()
+        for k in range(1, world):
+            acc += rows[(rank + k) % world]
+        t.copy_(acc)
+    # sum w' over three shards: 1e16, 1, -1e16 -> rank order gives 0, any rotation gives 1 or 0 depending on the start
+    mine = [1e16, 1.0, -1e16][rank]
+    sq = [0.25, 0.25, 0.25][rank]
+    want_sum = (1e16 + 1.0) + -1e16                      # rank order: 0.0
+    dist.all_reduce = rank_rotated_all_reduce
+    try:
+        seen = []
+        for c in (comm0, par.ParticleShardGroup(seed=3, host_exchange=False)):        # shared memory; backend all-gather
+            for use_c in ((True, False) if c._host is not None else (None,)):
+                if use_c is False:
+                    saved, c._host._c_reduce, c._host._reduce_bufs = c._host._c_reduce, None, {}
+                s_, ss_, mn_, nb_ = c.allreduce_update_stats(None, mine, sq, 0.0, 0.0, np.array([mine * 0.5]))
+                tot, rows = c.allreduce_host_vector(np.array([mine, sq, mine * 0.5]))
+                if use_c is False:
+                    c._host._c_reduce, c._host._reduce_bufs = saved, {}
+                assert s_ == want_sum and tot[0] == want_sum and ss_ == 0.75
+                assert c.last_extra[0] == (0.5e16 + 0.5) + -0.5e16
+                # the decision an updater would take from these numbers (smc.py:263-277 on n_ess = sum^2 / sumsq)
+                ess = s_ * s_ / ss_
+                seen.append((s_, ss_, ess < 1.0))
+        assert calls["all_reduce"] == 0, "the per-datum reduction must not hand the association order to the backend"
+        # every rank saw the same bits
+        rows = comm0.gather_rows(np.array([v[0] for v in seen] + [float(v[2]) for v in seen]))
+        for r in range(1, world):
+            np.testing.assert_array_equal(rows[0], rows[r])
+        # whereas the mocked all-reduce itself does differ between ranks on these data (the hazard is real)
+        t = torch.tensor([mine], dtype=torch.float64)
+        rank_rotated_all_reduce(t)
+        got = comm0.gather_rows(np.array([float(t[0])]))[:, 0]
+        assert len(set(got.tolist())) > 1, got
+    finally:
+        dist.all_reduce = real_all_reduce
+
+
+def test_same_decision_under_order_sensitive_sums(tmp_path):
+    _run("_check_same_decision_under_order_sensitive_sums", tmp_path, world=3)
+
+
 # ---------------------------------------------------------------------------------------------
 # GPU legs: the full sharded SMCUpdater (HIP kernels + protocol).  One GPU box has one device, so
 # (i) two processes share it and talk over gloo, (ii) a world-size-1 RCCL group checks the nccl path.
@@ -573,6 +632,9 @@ def _rccl_transport_world1(rank, port, tmpdir):
     tot, firsts = comm._rccl_engine(eng).allreduce_sums(vec, 6, 2)
     np.testing.assert_array_equal(tot, [1.5, 2.5, -0.25, 0.0, 7.0, 8.0])
     np.testing.assert_array_equal(firsts, [1.5])
+    assert comm.ranks_in_comm(eng) == (1, 0)            # ncclCommCount / ncclCommUserRank of the library's communicator
+    with pytest.raises(ValueError):
+        comm._rccl_engine(eng).allreduce_sums(eng.empty(256), 188, 2)       # n + nranks beyond the pinned block
     ts = (9 / 8) ** np.arange(50.0)
     rs = np.random.RandomState(0)
     outcomes = (rs.random_sample(50) >= np.cos(0.3 * ts / 2) ** 2).astype(int)
