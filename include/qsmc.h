@@ -146,6 +146,65 @@ int qsmc_update_fused(qsmc_handle_t h, const qsmc_model_t *model,
                       double *stats_dev, qsmc_update_stats_t *stats_host, double *moments_host,
                       qsmc_stream_t stream);
 
+/* ---- one datum in ONE call (SMCUpdater.update, smc.py:388-457, with its resample test smc.py:263-277) -------
+ * qsmc_update_fused + the part of `update` that follows it when no guard fires, in C, so that between two data the
+ * host runs a handful of Python statements instead of a page of them (round 2: 13 us of Python per datum, the GPU
+ * idle a quarter of the run):
+ *   fused update of w_alt <- (w / norm) * L(x; exp, outcome) with its sums (and the moment sums, d <= 4);
+ *   norm_scale = sum w' with the |.| < eps -> 1 fix (smc.py:357-370); negative / NaN weights (smc.py:416-418) or
+ *   all-zero weights (smc.py:423-436) -> QSMC_STEP_GUARD: NOTHING is committed, the raw sums are in the struct and the
+ *   caller runs its guard / policy code exactly as after qsmc_update_fused (w_alt holds the new weights);
+ *   otherwise commit: w <-> w_alt swapped IN THE STRUCT, norm, sumsq, n_ess = norm^2 / sumsq (distributions.py:299-307),
+ *   min_n_ess (smc.py:452-453); then, if check_for_resample: n_ess <= 10 -> QSMC_STEP_SMALL_ESS (the caller warns,
+ *   smc.py:265-270); n_ess < ess_below -> QSMC_STEP_RESAMPLE_DUE.
+ * A due resample is also QUEUED here when the caller allows it (lw.enabled, device-RNG Liu-West, d <= 4, whose
+ * moments came with the update): mean = S1 / norm, cov = S2 / norm - mean mean^T (distributions.py:337-399), the
+ * zero-covariance substitute (resamplers.py:283-290), S = h sqrtm_psd(cov) (utils.py:593-607), and
+ * qsmc_lw_resample_philox into lw.x_out -- the very call the caller is about to make, a host round trip earlier
+ * (QSMC_STEP_RESAMPLE_QUEUED).  The caller still forms mean / covariance / square root itself, with its warnings and
+ * errors (resamplers.py:283-299), and calls qsmc_lw_resample_philox as always: called with bit-identical arguments
+ * (and x_out = lw.x_out) it finds its work done and returns at once; with anything different the resample is simply
+ * run again into the caller's buffer.  The queued resample never replaces the caller's decision, it only starts it
+ * early.
+ * The speculative weight-only prefix of qsmc_lw_arm_prefix is armed from lw.* by every call with lw.prefix != 0.
+ * w == NULL: implicit all-ones weights (then w_alt becomes NULL on commit: supply a buffer before the next call). */
+#define QSMC_STEP_GUARD           1
+#define QSMC_STEP_SMALL_ESS       2
+#define QSMC_STEP_RESAMPLE_DUE    4
+#define QSMC_STEP_RESAMPLE_QUEUED 8
+typedef struct qsmc_step_lw {
+    int32_t  enabled;            /* queue the resample when it is due (needs x_out)                         */
+    int32_t  prefix;             /* arm the gated weight-only prefix behind every update (qsmc_lw_arm_prefix) */
+    int32_t  postselect, maxiter;
+    double   a, h, zero_cov_comp;
+    uint64_t seed, epoch;        /* of the resample that would follow                                       */
+    int64_t  n_out;
+    double  *x_out;              /* device, SoA d x n_out, row stride ldx_out                               */
+    int64_t  ldx_out;
+} qsmc_step_lw_t;
+typedef struct qsmc_step {
+    /* the cloud -- kept current by the caller; w / w_alt / norm / sumsq / min_n_ess advance here on commit */
+    const double *x; int64_t ldx; int64_t n;
+    const double *w;             /* unnormalised weights, true weight w / norm; NULL: all ones              */
+    double       *w_alt;         /* where the new weights go                                                */
+    double        norm, sumsq, min_n_ess;
+    /* tests */
+    double        zero_weight_thresh, ess_below;
+    int32_t       check_for_resample, reserved0;
+    qsmc_step_lw_t lw;
+    /* results of the latest call */
+    int32_t       status, reserved1;
+    uint64_t      update_token;  /* qsmc_update_token after this update                                     */
+    qsmc_update_stats_t stats;   /* raw sums of the new weights                                             */
+    double        n_ess;
+    double        moments[14];   /* d <= 4: [sum w' x_m, upper(sum w' x_m x_n)] of the new weights           */
+    double        mean[QSMC_MAX_D], cov[QSMC_MAX_D * QSMC_MAX_D], S[QSMC_MAX_D * QSMC_MAX_D], S_err;   /* of a queued resample */
+} qsmc_step_t;
+int qsmc_step(qsmc_handle_t h, qsmc_step_t *st, const qsmc_model_t *model, const qsmc_expparam_t *exp,
+              int64_t outcome, qsmc_stream_t stream);
+/* how many resamples qsmc_step queued on this handle, and how many of them the caller's own call adopted */
+int qsmc_step_stats(qsmc_handle_t h, int64_t *n_queued, int64_t *n_adopted);
+
 /* batch_update fast path (smc.py:459-487): k <= 8 data applied in ONE pass over the cloud,
  * w_out[i] = (w_in[i] / prev_norm) * prod_j Pr(outcomes[j] | x_i ; exps[j]).
  * stats_host[j] holds the cumulative sums after datum j: sum = S_j, sumsq = Q_j, n_bad = #{!(w >= 0)}

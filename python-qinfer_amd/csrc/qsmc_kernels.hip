@@ -91,6 +91,19 @@ struct qsmc_ctx {
         int prof_slot;             // profiling-ring entry of that launch (-1: not timed)
         long long n_queued, n_adopted;   // speculative launches so far / resamples that found theirs done
     } spec;
+    struct {                       // the resample qsmc_step queued itself (adopted by a matching qsmc_lw_resample_philox)
+        int valid;
+        qsmc_model_t model;
+        int32_t postselect, d, maxiter;
+        const double *x_in, *w;
+        int64_t ldx_in, n_in, n_out, ldx_out;
+        double norm, a;
+        double mean[QSMC_MAX_D], S[QSMC_MAX_D * QSMC_MAX_D];
+        uint64_t seed, epoch;
+        double *x_out;
+        hipStream_t stream;
+        long long n_queued, n_adopted;
+    } rsq;
     unsigned int *iscratch; // device integer scratch for the bucketed resampler
     size_t iscratch_cap;    // in bytes
     double *cdf_scratch;    // device CDF, materialised only for the direct sampler / global redraws
@@ -708,7 +721,7 @@ int qsmc_update_fused(qsmc_handle_t h, const qsmc_model_t *model, const double *
                       const double *w_in, double *w_out, double prev_norm, const qsmc_expparam_t *exp,
                       int64_t outcome, double *stats_dev, qsmc_update_stats_t *stats_host, double *moments_host,
                       qsmc_stream_t stream) {
-    if (h) { h->prep.valid = 0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
+    if (h) { h->prep.valid = 0; h->rsq.valid = 0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
     if (!h || !x || !w_out || !exp || n <= 0) return QSMC_ERR_INVALID;      // w_in == NULL: all-ones weights
     int rc = check_model(model);
     if (rc) return rc;
@@ -794,7 +807,7 @@ int qsmc_update_multi(qsmc_handle_t h, const qsmc_model_t *model, const double *
                       const double *w_in, double *w_out, double prev_norm, const qsmc_expparam_t *exps,
                       const int64_t *outcomes, int32_t k, qsmc_update_stats_t *stats_host, double *moments_host,
                       qsmc_stream_t stream) {
-    if (h) { h->prep.valid = 0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
+    if (h) { h->prep.valid = 0; h->rsq.valid = 0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
     if (!h || !x || !w_out || !exps || !outcomes || !stats_host || n <= 0 || k < 1 || k > MULTI_KMAX)
         return QSMC_ERR_INVALID;
     int rc = check_model(model);
@@ -876,14 +889,14 @@ int qsmc_hypothetical_sums(qsmc_handle_t h, const qsmc_model_t *model, const dou
 int qsmc_update_from_likelihood(qsmc_handle_t h, const double *L, int64_t n, const double *w_in,
                                 double *w_out, double prev_norm, double *stats_dev,
                                 qsmc_update_stats_t *stats_host, qsmc_stream_t stream) {
-    if (h) { h->prep.valid = 0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
+    if (h) { h->prep.valid = 0; h->rsq.valid = 0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
     if (!h || !L || !w_in || !w_out || n <= 0) return QSMC_ERR_INVALID;
     return weights_pass<0>(h, L, n, w_in, w_out, prev_norm, stats_dev, stats_host, (hipStream_t)stream);
 }
 
 int qsmc_clip_weights(qsmc_handle_t h, double *w, int64_t n, double norm, double *stats_dev,
                       qsmc_update_stats_t *stats_host, qsmc_stream_t stream) {
-    if (h) { h->prep.valid = 0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
+    if (h) { h->prep.valid = 0; h->rsq.valid = 0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
     if (!h || !w || n <= 0) return QSMC_ERR_INVALID;
     return weights_pass<1>(h, nullptr, n, w, w, norm, stats_dev, stats_host, (hipStream_t)stream);
 }
@@ -935,14 +948,14 @@ int qsmc_kde_cross_entropy(qsmc_handle_t h, const double *x, int64_t ldx, int64_
 
 int qsmc_normalize_weights(qsmc_handle_t h, const double *w_in, double *w_out, int64_t n, double norm,
                            qsmc_stream_t stream) {
-    if (h) { h->prep.valid = 0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
+    if (h) { h->prep.valid = 0; h->rsq.valid = 0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
     if (!h || !w_in || !w_out || n < 0) return QSMC_ERR_INVALID;
     if (n == 0) return QSMC_OK;
     return weights_pass<2>(h, nullptr, n, w_in, w_out, norm, nullptr, nullptr, (hipStream_t)stream);
 }
 
 int qsmc_fill(qsmc_handle_t h, double *w, int64_t n, double value, qsmc_stream_t stream) {
-    if (h) { h->prep.valid = 0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
+    if (h) { h->prep.valid = 0; h->rsq.valid = 0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
     if (!h || !w || n < 0) return QSMC_ERR_INVALID;
     if (n == 0) return QSMC_OK;
     hipLaunchKernelGGL(k_fill, dim3(grid_for(n, QSMC_BLOCK * 4)), dim3(QSMC_BLOCK), 0, (hipStream_t)stream, w,
@@ -1272,6 +1285,24 @@ static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int3
     if (!h || !model || !x_in || !mean || !S || !x_out || n_in <= 0 || n_out <= 0) return QSMC_ERR_INVALID;
     if (d != model->d || d < 1 || d > QSMC_MAX_D || maxiter < 1) return QSMC_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
+    if (h->rsq.valid) {
+        // qsmc_step queued a resample when its n_ess test failed: if this is that very call -- every argument equal,
+        // mean and S bit for bit -- the work is done (or under way on `stream`); anything else runs as if nothing had
+        // been queued (the queued one wrote its own buffer and is overwritten or ignored)
+        const auto &q = h->rsq;
+        const bool same = q.model.kind == model->kind && q.model.d == model->d && q.model.min_freq == model->min_freq &&
+                          q.postselect == postselect && q.d == d && q.maxiter == maxiter && q.x_in == x_in && q.w == w &&
+                          q.ldx_in == ldx_in && q.n_in == n_in && q.n_out == n_out && q.norm == norm && q.a == a &&
+                          q.seed == seed && q.epoch == epoch && q.x_out == x_out && q.stream == s && pl.n_dest == 0 &&
+                          pl.ld_m == q.ldx_out && memcmp(q.mean, mean, sizeof(double) * d) == 0 &&
+                          memcmp(q.S, S, sizeof(double) * d * d) == 0;
+        h->rsq.valid = 0;
+        if (same) {
+            ++h->rsq.n_adopted;
+            if (n_failed_host) return read_counter(h, n_failed_host, s);
+            return QSMC_OK;
+        }
+    }
     LWArgs lw;
     fill_lw(&lw, d, a, mean, S);
     uint32_t k0, k1, ep;
@@ -1415,6 +1446,111 @@ int qsmc_lw_resample_philox(qsmc_handle_t h, const qsmc_model_t *model, int32_t 
                                 epoch, maxiter, x_out, pl, n_failed_host, stream);
 }
 
+int qsmc_step_stats(qsmc_handle_t h, int64_t *n_queued, int64_t *n_adopted) {
+    if (!h || !n_queued || !n_adopted) return QSMC_ERR_INVALID;
+    *n_queued = h->rsq.n_queued;
+    *n_adopted = h->rsq.n_adopted;
+    return QSMC_OK;
+}
+
+// mean = S1 / norm, cov = S2 / norm - mean mean^T from the packed sums of the fused update: the operations
+// ParticleDistribution._moments / _cov_from_sums perform (one division, one product, one subtraction per entry; this
+// file is compiled with -ffp-contract=off), so the caller's own numbers come out bit for bit
+static void moments_to_mean_cov(const double *packed, int d, double norm, double *mean, double *cov) {
+    for (int m = 0; m < d; ++m) mean[m] = packed[m] / norm;
+    int k = d;
+    for (int m = 0; m < d; ++m)
+        for (int q = m; q < d; ++q) {
+            const double e2 = packed[k++] / norm;
+            cov[m * d + q] = e2 - mean[m] * mean[q];
+            cov[q * d + m] = e2 - mean[q] * mean[m];
+        }
+}
+
+int qsmc_step(qsmc_handle_t h, qsmc_step_t *st, const qsmc_model_t *model, const qsmc_expparam_t *exp, int64_t outcome,
+              qsmc_stream_t stream) {
+    if (!h || !st || !model || !exp || !st->x || !st->w_alt || st->n <= 0) return QSMC_ERR_INVALID;
+    st->status = 0;
+    const int d = model->d;
+    const bool small_d = d >= 1 && d <= 4;
+    if (st->lw.prefix && st->check_for_resample) {           // (qsmc_lw_arm_prefix, from the struct)
+        static const bool never = getenv("QSMC_NO_SPECULATIVE_PREFIX") != nullptr;
+        h->spec.enabled = !never && st->lw.n_out > 0;
+        h->spec.thresh = st->ess_below;
+        h->spec.n_out = st->lw.n_out;
+        h->spec.seed = st->lw.seed;
+        h->spec.epoch = st->lw.epoch;
+    } else {
+        h->spec.enabled = 0;
+    }
+    int rc = qsmc_update_fused(h, model, st->x, st->ldx, st->n, st->w, st->w_alt, st->norm, exp, outcome, nullptr,
+                               &st->stats, small_d ? st->moments : nullptr, stream);
+    if (rc) return rc;
+    st->update_token = h->ts.gen;
+    const double norm = st->stats.sum;
+    const double fixed = fabs(norm) < PREFIX_NORM_EPS ? 1.0 : norm;                       // smc.py:369-370
+    if (st->stats.n_bad > 0.0) { st->status = QSMC_STEP_GUARD; return QSMC_OK; }       // smc.py:416-418
+    const double sum_w = norm / fixed;
+    if (sum_w <= st->zero_weight_thresh || !(sum_w == sum_w)) { st->status = QSMC_STEP_GUARD; return QSMC_OK; }   // :423-436
+    // commit (smc.py:441): the new weights become the cloud's, the old buffer the next scratch
+    const double *old_w = st->w;
+    st->w = st->w_alt;
+    st->w_alt = const_cast<double *>(old_w);
+    st->norm = fixed;
+    st->sumsq = st->stats.sumsq;
+    const double n2 = fixed * fixed;
+    const double ess = st->stats.sumsq == 0.0 ? (n2 > 0.0 ? INFINITY : NAN) : n2 / st->stats.sumsq;
+    st->n_ess = ess;
+    if (ess <= st->min_n_ess) st->min_n_ess = ess;
+    if (!st->check_for_resample) return QSMC_OK;
+    if (ess <= 10.0) st->status |= QSMC_STEP_SMALL_ESS;
+    if (!(ess < st->ess_below)) return QSMC_OK;
+    st->status |= QSMC_STEP_RESAMPLE_DUE;
+    static const bool no_queue = getenv("QSMC_NO_STEP_RESAMPLE") != nullptr;              // (A/B switch)
+    if (!st->lw.enabled || !small_d || !st->lw.x_out || st->lw.n_out <= 0 || no_queue) return QSMC_OK;
+    // the caller's resample (resamplers.py:266-300), started from here
+    moments_to_mean_cov(st->moments, d, fixed, st->mean, st->cov);
+    bool finite = true, any = false;
+    for (int k = 0; k < d * d; ++k) {
+        finite = finite && std::isfinite(st->cov[k]);
+        any = any || st->cov[k] != 0.0;
+    }
+    if (!finite) return QSMC_OK;                               // (the caller's own assertion fires)
+    double cov_used[16];
+    for (int k = 0; k < d * d; ++k) cov_used[k] = any ? st->cov[k] : ((k / d == k % d) ? st->lw.zero_cov_comp : 0.0);
+    rc = qsmc_sqrtm_psd(cov_used, d, st->lw.h, st->S, &st->S_err);
+    if (rc) return rc;
+    if (!std::isfinite(st->S_err)) return QSMC_OK;             // (ResamplerError is the caller's to raise)
+    h->ts.armed = h->ts.gen;                                   // these weights ARE update number ts.gen's output
+    rc = qsmc_lw_resample_philox(h, model, st->lw.postselect, st->x, st->ldx, st->n, d, st->w, fixed, st->lw.a, st->mean,
+                                 st->S, st->lw.n_out, st->lw.seed, st->lw.epoch, st->lw.maxiter, st->lw.x_out,
+                                 st->lw.ldx_out, nullptr, stream);
+    if (rc) return rc;
+    auto &q = h->rsq;
+    q.valid = 1;
+    q.model = *model;
+    q.postselect = st->lw.postselect;
+    q.d = d;
+    q.maxiter = st->lw.maxiter;
+    q.x_in = st->x;
+    q.w = st->w;
+    q.ldx_in = st->ldx;
+    q.n_in = st->n;
+    q.n_out = st->lw.n_out;
+    q.ldx_out = st->lw.ldx_out;
+    q.norm = fixed;
+    q.a = st->lw.a;
+    memcpy(q.mean, st->mean, sizeof(double) * d);
+    memcpy(q.S, st->S, sizeof(double) * d * d);
+    q.seed = st->lw.seed;
+    q.epoch = st->lw.epoch;
+    q.x_out = st->lw.x_out;
+    q.stream = (hipStream_t)stream;
+    ++q.n_queued;
+    st->status |= QSMC_STEP_RESAMPLE_QUEUED;
+    return QSMC_OK;
+}
+
 int qsmc_lw_resample_philox_sharded(qsmc_handle_t h, const qsmc_model_t *model, int32_t postselect,
                                     const double *x_in, int64_t ldx_in, int64_t n_in, int32_t d,
                                     const double *w, double norm, double a, const double *mean, const double *S,
@@ -1476,7 +1612,7 @@ int qsmc_prior_uniform_philox(qsmc_handle_t h, const qsmc_model_t *model, int32_
                               const double *lo, const double *hi, int32_t d, int64_t n, uint64_t seed,
                               uint64_t epoch, int32_t maxiter, double *x_out, int64_t ldx_out,
                               int64_t *n_failed_host, qsmc_stream_t stream) {
-    if (h) { h->prep.valid = 0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
+    if (h) { h->prep.valid = 0; h->rsq.valid = 0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
     if (!h || !model || !lo || !hi || !x_out || n <= 0 || d < 1 || d > QSMC_MAX_D || maxiter < 1)
         return QSMC_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
@@ -1523,7 +1659,7 @@ int qsmc_random_walk(qsmc_handle_t h, double *x, int64_t ldx, int64_t n, int32_t
 
 int qsmc_tomo_canonicalize2(qsmc_handle_t h, const double *basis, int32_t dim, int32_t basis_kind, double *x, int64_t ldx,
                             int64_t n, int32_t allow_subnormalized, qsmc_stream_t stream) {
-    if (h) { h->prep.valid = 0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
+    if (h) { h->prep.valid = 0; h->rsq.valid = 0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
     if (!h || !x || n < 0) return QSMC_ERR_INVALID;
     if (basis_kind != QSMC_BASIS_DENSE && basis_kind != QSMC_BASIS_PAULI) return QSMC_ERR_INVALID;
     if (basis_kind == QSMC_BASIS_DENSE && !basis) return QSMC_ERR_INVALID;

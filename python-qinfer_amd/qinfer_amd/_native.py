@@ -33,6 +33,32 @@ class UpdateStats(C.Structure):
     _fields_ = [("sum", C.c_double), ("sumsq", C.c_double), ("min", C.c_double), ("n_bad", C.c_double)]
 
 
+class StepLW(C.Structure):
+    _fields_ = [("enabled", C.c_int32), ("prefix", C.c_int32), ("postselect", C.c_int32), ("maxiter", C.c_int32),
+                ("a", C.c_double), ("h", C.c_double), ("zero_cov_comp", C.c_double),
+                ("seed", C.c_uint64), ("epoch", C.c_uint64), ("n_out", C.c_int64),
+                ("x_out", C.c_void_p), ("ldx_out", C.c_int64)]
+
+
+class Step(C.Structure):
+    """qsmc_step_t (include/qsmc.h): the cloud's pointers / scalars and the results of the latest qsmc_step."""
+    _fields_ = [("x", C.c_void_p), ("ldx", C.c_int64), ("n", C.c_int64),
+                ("w", C.c_void_p), ("w_alt", C.c_void_p),
+                ("norm", C.c_double), ("sumsq", C.c_double), ("min_n_ess", C.c_double),
+                ("zero_weight_thresh", C.c_double), ("ess_below", C.c_double),
+                ("check_for_resample", C.c_int32), ("reserved0", C.c_int32),
+                ("lw", StepLW),
+                ("status", C.c_int32), ("reserved1", C.c_int32),
+                ("update_token", C.c_uint64),
+                ("stats", UpdateStats),
+                ("n_ess", C.c_double),
+                ("moments", C.c_double * 14),
+                ("mean", C.c_double * QSMC_MAX_D), ("cov", C.c_double * (QSMC_MAX_D * QSMC_MAX_D)),
+                ("S", C.c_double * (QSMC_MAX_D * QSMC_MAX_D)), ("S_err", C.c_double)]
+
+
+STEP_GUARD, STEP_SMALL_ESS, STEP_RESAMPLE_DUE, STEP_RESAMPLE_QUEUED = 1, 2, 4, 8
+
 _P = C.c_void_p          # device pointers and streams travel as integers
 _I64, _I32, _F64, _U64 = C.c_int64, C.c_int32, C.c_double, C.c_uint64
 
@@ -52,6 +78,8 @@ SIGNATURES = {
     "qsmc_are_models_valid": [_P, C.POINTER(ModelDesc), _P, _I64, _I64, _P, _P],
     "qsmc_update_fused": [_P, C.POINTER(ModelDesc), _P, _I64, _I64, _P, _P, _F64, C.POINTER(ExpParam),
                           _I64, _P, C.POINTER(UpdateStats), C.POINTER(_F64), _P],
+    "qsmc_step": [_P, C.POINTER(Step), C.POINTER(ModelDesc), C.POINTER(ExpParam), _I64, _P],
+    "qsmc_step_stats": [_P, C.POINTER(_I64), C.POINTER(_I64)],
     "qsmc_update_multi": [_P, C.POINTER(ModelDesc), _P, _I64, _I64, _P, _P, _F64, C.POINTER(ExpParam),
                           C.POINTER(_I64), _I32, C.POINTER(UpdateStats), C.POINTER(_F64), _P],
     "qsmc_hypothetical_sums": [_P, C.POINTER(ModelDesc), _P, _I64, _I64, _P, _F64, C.POINTER(ExpParam),

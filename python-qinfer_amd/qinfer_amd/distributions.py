@@ -283,6 +283,7 @@ class ParticleDistribution(Distribution):
         self._moments_cache = None
         self._w_token = 0            # the weights are no longer (known to be) the output of a fused update
         self._view_version += 1      # host snapshots handed out so far are stale from here on
+        self._step_synced = False    # (SMCUpdater: the qsmc_step_t mirror of the cloud must be refilled)
 
     def _write_back(self, what, arr):
         """Upload an edited host snapshot (DeviceBackedArray._push)."""
@@ -301,9 +302,14 @@ class ParticleDistribution(Distribution):
         return self._w
 
     def _scratch_weights(self):
+        """Where the next update writes its weights: the one of two pooled buffers that is not `_w` (kept across
+        resamples, which leave the weights implicit, so that no allocation sits on the per-datum path)."""
         n = self.n_particles
         if self._w_alt is None or self._w_alt.shape[0] != n:
-            self._w_alt = self._eng.empty(n)
+            pool = getattr(self, "_w_pool", None)
+            if pool is None or pool[0].shape[0] != n:
+                pool = self._w_pool = (self._eng.empty(n), self._eng.empty(n))
+            self._w_alt = pool[1] if pool[0] is self._w else pool[0]
         return self._w_alt
 
     # ---------------------------------------------------------------- reference attributes

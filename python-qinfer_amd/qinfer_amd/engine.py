@@ -60,6 +60,8 @@ class Engine:
         self._mom_ptr = {d: _native.f64_ptr(a) for d, a in self._mom.items()}
         self._st_ref = C.byref(self._st)
         self._armed_prefix = None    # what qsmc_lw_arm_prefix was last told (arm_resample_prefix)
+        self._qsmc_step = self.lib.qsmc_step
+        self._h_int = h.value        # (the handle as a plain int: marshalled fastest on the per-datum call)
 
     # ------------------------------------------------------------------ memory / streams
     def stream(self):
@@ -168,6 +170,22 @@ class Engine:
             return self._st
         mom = self._mom[d]
         return self._st, mom[:d].copy(), self._unpack_upper(mom[d:], d)
+
+    STEP_ARMED = "armed by qsmc_step"      # value of _armed_prefix while the per-datum C path arms the prefix itself
+
+    def step(self, st_ref, desc_ref, ep_ref, outcome):
+        """One datum through qsmc_step (see include/qsmc.h): fused update + the no-guard tail of SMCUpdater.update
+        + (when allowed and due) the Liu-West resample queued in C.  Results are in the qsmc_step_t behind st_ref."""
+        rc = self._qsmc_step(self._h_int, st_ref, desc_ref, ep_ref, outcome, self._raw_stream(self.index))
+        if rc:
+            self._chk(rc, "qsmc_step")
+        self._armed_prefix = self.STEP_ARMED
+
+    def step_stats(self):
+        """(resamples queued by qsmc_step, resamples whose caller-side call adopted the queued one)."""
+        q, a = C.c_int64(), C.c_int64()
+        self._chk(self.lib.qsmc_step_stats(self.h, C.byref(q), C.byref(a)), "qsmc_step_stats")
+        return q.value, a.value
 
     MULTI_KMAX = 8
 

@@ -75,6 +75,14 @@ class SimplePrecessionModel(SimpleInversionModel):
     def expparams_dtype(self):
         return 'float'
 
+    def _native_fill_expparam(self, ep, expparams):
+        """Per-datum path of SMCUpdater.update: write the one experiment into the updater's own qsmc_expparam_t
+        (no allocation).  False: not the plain shape -- take `_native_expparams`."""
+        if type(expparams) is np.ndarray and expparams.shape == (1,) and expparams.dtype.names is None:
+            ep.t = expparams[0]
+            return True
+        return False
+
     def _native_expparams(self, expparams):
         if type(expparams) is np.ndarray and expparams.shape == (1,) and expparams.dtype.names is None:
             return [_native.make_expparam(t=expparams[0], w_=0.0)]       # the per-datum path of update()
@@ -241,6 +249,13 @@ class BinomialModel(NativeModelMixin, DerivedModel):
             kind = _native.MODEL_BINOMIAL_RB_INTERLEAVED if um._il else _native.MODEL_BINOMIAL_RB
             return _native.ModelDesc(kind, um.n_modelparams, 0.0, 0, 0)
         return _native.ModelDesc(_native.MODEL_BINOMIAL_PRECESSION, 1, float(um._min_freq), 0, 0)
+
+    def _native_fill_expparam(self, ep, expparams):
+        if type(expparams) is np.ndarray and expparams.shape == (1,) and not self._um_is_rb:
+            e = expparams[0]
+            ep.t, ep.n_meas = e['x'], int(e['n_meas'])
+            return True
+        return False
 
     def _native_expparams(self, expparams):
         um = self.underlying_model
@@ -564,6 +579,12 @@ class RandomizedBenchmarkingModel(NativeModelMixin, FiniteOutcomeModel):
     def _native_desc(self):
         kind = _native.MODEL_RB_INTERLEAVED if self._il else _native.MODEL_RB
         return _native.ModelDesc(kind, self.n_modelparams, 0.0, 0, 0)
+
+    def _native_fill_expparam(self, ep, expparams):
+        if type(expparams) is np.ndarray and expparams.shape == (1,) and not self._il:
+            ep.m = int(expparams[0]['m'])
+            return True
+        return False
 
     def _native_expparams(self, expparams):
         if type(expparams) is np.ndarray and expparams.shape == (1,) and not self._il:

@@ -123,9 +123,14 @@ class LiuWestResampler(Resampler):
                 return ParticleDistribution._from_device(eng, x_new, None, norm=float(n_particles),
                                                          sumsq=float(n_particles))
             self._arm_update_sums(particle_dist)
+            # an updater keeps a spare cloud of its own size: the new particles go there (and qsmc_step may have
+            # queued this very call already -- same arguments, same buffer: the library then has nothing left to do)
+            spare = getattr(particle_dist, "_x_spare", None)
+            if spare is not None and (tuple(spare.shape) != (d, n_particles) or spare is x_in):
+                spare = None
             x_new, n_failed = eng.lw_resample_philox(desc, self._postselect, x_in, particle_dist._w, norm, a,
                                                      mean, S, n_particles, self._seed, self._epoch,
-                                                     self._maxiter, sync=not defer)
+                                                     self._maxiter, sync=not defer, out=spare)
             if defer:                  # stay asynchronous: the count is read at the caller's next sync
                 self._pending_failed = eng
                 n_failed = 0

@@ -27,6 +27,8 @@ from .resamplers import LiuWestResampler
 __all__ = ["SMCUpdater"]
 
 _EPS = float(np.spacing(1))
+_NO_STEP = bool(__import__("os").environ.get("QSMC_NO_STEP"))      # (A/B switch: the round-2 per-datum path in Python)
+_U64 = 2 ** 64 - 1
 
 
 def _as_int_outcome(outcome):
@@ -36,6 +38,9 @@ def _as_int_outcome(outcome):
     if arr.size != 1:
         raise ValueError("update() takes a single outcome; use batch_update for several")
     return int(arr.reshape(-1)[0])
+
+
+_FROM_STEP = ("moments in the qsmc_step_t",)
 
 
 class SMCUpdater(ParticleDistribution):
@@ -92,6 +97,17 @@ class SMCUpdater(ParticleDistribution):
         self._native = native_ok(model)
         self._desc = model._native_desc() if self._native else None
         self._timestep_identity = self._timestep_is_identity(model)
+        # the per-datum C path (qsmc_step): native model, one cloud
+        self._st = _native.Step() if (self._native and comm is None and not _NO_STEP) else None
+        if self._st is not None:
+            import ctypes
+            self._st_ref = ctypes.byref(self._st)
+            self._desc_ref = ctypes.byref(self._desc)
+            self._ep = _native.ExpParam()
+            self._ep_ref = ctypes.byref(self._ep)
+            self._ep_fill = getattr(model, "_native_fill_expparam", None)
+        self._step_synced = False
+        self._x_spare = None
         self.reset(n_particles)
 
     # ------------------------------------------------------------------ bookkeeping properties
@@ -140,6 +156,12 @@ class SMCUpdater(ParticleDistribution):
 
     def _moments(self):
         c = self._moments_cache
+        if c is _FROM_STEP:
+            # left by the C per-datum path: the packed sums are still in the qsmc_step_t (the next update replaces
+            # both them and this marker)
+            d = self._x.shape[0]
+            raw = np.array(self._st.moments[:d + d * (d + 1) // 2])
+            c = self._moments_cache = ("packed", 1.0, raw, self._norm)
         if c is not None and len(c) == 4:
             # left by update(): the packed sums [sum w'x, upper(sum w'xx^T)] of the fused kernel and their
             # normaliser -- unpacked only when somebody asks (a resample, est_mean, ...), not on every datum
@@ -295,8 +317,94 @@ class SMCUpdater(ParticleDistribution):
         L = np.asarray(self.model.likelihood(outcomes, self._host_locations(), expparams), dtype=np.float64)
         return self._eng.to_device(np.ascontiguousarray(L.transpose(0, 2, 1)))
 
+    # ------------------------------------------------------------------ per-datum C path
+    def _step_sync(self):
+        """Refill the qsmc_step_t from the Python-side state (after a reset, a resample, a user write, a changed
+        resampler or threshold -- anything that went through `_invalidate`); nothing here runs per datum."""
+        st, x, r = self._st, self._x, self.resampler
+        d, n = x.shape
+        st.x, st.ldx, st.n = x.data_ptr(), x.stride(0), n
+        st.w = self._w.data_ptr() if self._w is not None else None
+        st.w_alt = self._scratch_weights().data_ptr()
+        st.norm = self._norm
+        st.min_n_ess = float(self._min_n_ess)
+        st.zero_weight_thresh = float(self._zero_weight_thresh)
+        st.ess_below = self.n_particles_global * self.resample_thresh
+        lw = st.lw
+        key = self._prefix_key()
+        lw.prefix = int(key is not None)
+        lw.enabled = 0
+        if key is not None:
+            lw.n_out, lw.seed, lw.epoch = key[1], key[2] & _U64, key[3]
+            # the resample itself is queued from C only when nothing sits between this update and it: the stock
+            # resampler class, a cloud that does not move between data, moments that came with the update (d <= 4),
+            # same-size output (the spare buffer ping-pongs with the cloud), no divergence tracking
+            if (type(r) is LiuWestResampler and self._timestep_identity and key[1] == n
+                    and getattr(self.model, "_native_timestep", None) is None and d <= 4
+                    and self._resampling_divergences is None):
+                if self._x_spare is None or self._x_spare.shape != x.shape:
+                    self._x_spare = self._eng.empty(d, n)
+                lw.enabled = 1
+                lw.postselect, lw.maxiter = int(bool(r._postselect)), int(r._maxiter)
+                lw.a, lw.h, lw.zero_cov_comp = float(r._a), float(r._h), float(r._zero_cov_comp)
+                lw.x_out, lw.ldx_out = self._x_spare.data_ptr(), self._x_spare.stride(0)
+        self._step_key = (r, self.resample_thresh)
+        self._step_synced = True
+
+    def _update_step(self, outcome, expparams, check_for_resample):
+        """`update` for a native model on one cloud: qsmc_step does the fused update, the guards' tests, the commit,
+        n_ess / min_n_ess and the resample test in C (and queues a due Liu-West resample itself); what is left here is
+        the bookkeeping the reference keeps in Python objects (smc.py:388-457)."""
+        self._data_record.append(outcome)
+        self._just_resampled = False
+        st = self._st
+        if not self._step_synced or self._step_key[0] is not self.resampler or self._step_key[1] != self.resample_thresh:
+            self._step_sync()
+        elif self._w_alt is None:                     # (the update after a reset / resample committed into implicit weights)
+            st.w_alt = self._scratch_weights().data_ptr()
+        fill = self._ep_fill
+        if fill is not None and fill(self._ep, expparams):
+            ep_ref = self._ep_ref
+        else:
+            exps = self.model._native_expparams(expparams)
+            if len(exps) != 1:
+                raise ValueError("update() takes exactly one experiment")
+            ep_ref = exps[0]
+        st.check_for_resample = check_for_resample
+        eng = self._eng
+        eng.step(self._st_ref, self._desc_ref, ep_ref, outcome if type(outcome) is int else _as_int_outcome(outcome))
+        eng.update_gen = st.update_token
+        if not check_for_resample:
+            eng._armed_prefix = None                  # (the call disarmed the gated prefix)
+        status = st.status
+        w_out = self._w_alt
+        if status & _native.STEP_GUARD:
+            # a guard is due: nothing was committed; the reference's own sequence, from the sums
+            us = st.stats
+            d = self._x.shape[0]
+            mom = np.array(st.moments[:d + d * (d + 1) // 2]) if d <= 4 else None
+            self._step_synced = False
+            return self._finish_update(us.sum, us.sumsq, us.min, us.n_bad, w_out, mom, expparams, check_for_resample)
+        flush = getattr(self.resampler, "_flush_failed_warning", None)
+        if flush is not None:
+            flush()                       # the stream was just synchronised: deferred resampler warning
+        # mirror the commit C made in the struct
+        self._w, self._w_alt = w_out, self._w
+        self._norm, self._sumsq = st.norm, st.sumsq
+        self._moments_cache = _FROM_STEP if self._x.shape[0] <= 4 else None
+        self._w_token = st.update_token
+        self._view_version += 1
+        self._normalization_record.append(st.stats.sum)
+        self._min_n_ess = st.min_n_ess
+        if not self._timestep_identity or getattr(self.model, "_native_timestep", None) is not None:
+            self._timestep(expparams)
+        if status & (_native.STEP_SMALL_ESS | _native.STEP_RESAMPLE_DUE):
+            self._maybe_resample(np.float64(st.n_ess), bool(status & _native.STEP_RESAMPLE_QUEUED))
+
     def update(self, outcome, expparams, check_for_resample=True):
         """One Bayes step (smc.py:388-457)."""
+        if self._st is not None:
+            return self._update_step(outcome, expparams, check_for_resample)
         self._data_record.append(outcome)
         self._just_resampled = False
         eng = self._eng
@@ -339,12 +447,19 @@ class SMCUpdater(ParticleDistribution):
                 st = eng.update_fused(self._desc, self._x, self._w, w_out, self._norm, exps[0],
                                       _as_int_outcome(outcome))
         else:
+            eng.arm_resample_prefix(None)             # (no fused update on this path: nothing may stay armed on the handle)
             L = self._device_likelihood(outcome, expparams)
             if L.shape[0] != 1 or L.shape[1] != 1:
                 raise ValueError("update() takes exactly one outcome and one experiment")
             st = eng.update_from_likelihood(L.reshape(-1), self._weights(), w_out, self._norm)
         if st is not None:
             norm, sumsq, wmin, n_bad = self._reduce_stats(st)
+        return self._finish_update(norm, sumsq, wmin, n_bad, w_out, fused_moments, expparams, check_for_resample)
+
+    def _finish_update(self, norm, sumsq, wmin, n_bad, w_out, fused_moments, expparams, check_for_resample):
+        """Everything of `update` after the sums are known (smc.py:369-457): guards, policies, commit, records,
+        time step, n_ess, resample test."""
+        eng = self._eng
         flush = getattr(self.resampler, "_flush_failed_warning", None)
         if flush is not None:
             flush()                       # the stream was just synchronised: deferred resampler warning
@@ -390,24 +505,27 @@ class SMCUpdater(ParticleDistribution):
         if fused_moments is not None and n_bad == 0 and new_norm != 0:
             self._moments_cache = ("packed", sum_w, fused_moments, new_norm)
         self._normalization_record.append(norm)                      # smc.py:444
-
-        step = getattr(self.model, "_native_timestep", None)
-        if self._native and step is not None:
-            # a random-walk model with device kernels: the cloud takes its step in place (smc.py:447-449)
-            step(self, expparams)
-            self._moments_cache = None
-        elif not self._timestep_identity:
-            # plugin slow path: a model that moves particles between data and has no device step -- a user
-            # model, or a decorator over one (smc.py:447-449; DerivedModel forwards update_timestep)
-            locs = self.model.update_timestep(self._host_locations(), expparams)[:, :, 0]
-            self._x = self._eng.locs_to_soa(locs)
-            self._invalidate()
+        self._timestep(expparams)
 
         ess = self.n_ess                                             # smc.py:452-453
         if ess <= self._min_n_ess:
             self._min_n_ess = ess
         if check_for_resample:
             self._maybe_resample(ess)
+
+    def _timestep(self, expparams):
+        """Model.update_timestep between data (smc.py:447-449)."""
+        step = getattr(self.model, "_native_timestep", None)
+        if self._native and step is not None:
+            # a random-walk model with device kernels: the cloud takes its step in place
+            step(self, expparams)
+            self._moments_cache = None
+        elif not self._timestep_identity:
+            # plugin slow path: a model that moves particles between data and has no device step -- a user
+            # model, or a decorator over one (DerivedModel forwards update_timestep)
+            locs = self.model.update_timestep(self._host_locations(), expparams)[:, :, 0]
+            self._x = self._eng.locs_to_soa(locs)
+            self._invalidate()
 
     def batch_update(self, outcomes, expparams, resample_interval=5):
         """Update on a batch of data with the ESS test every `resample_interval` data
@@ -600,7 +718,7 @@ class SMCUpdater(ParticleDistribution):
         return (self.n_particles_global * self.resample_thresh, n if n_out is None else int(n_out), r._seed,
                 r._epoch + 1)
 
-    def _maybe_resample(self, ess=None):
+    def _maybe_resample(self, ess=None, queued=False):
         ess = self.n_ess if ess is None else ess
         if ess <= 10:
             warnings.warn("Extremely small n_ess encountered ({}). Resampling is likely to fail. "
@@ -608,9 +726,13 @@ class SMCUpdater(ParticleDistribution):
                           ApproximationWarning)
         if ess < self.n_particles_global * self.resample_thresh:
             prepare = getattr(self.resampler, "_prepare_device", None)
-            if prepare is not None and self._comm is None and self._eng._armed_prefix is None:
-                # (with the prefix armed the update queued it behind itself on the device's own ESS test: the
-                #  resampler's call finds it done, or redoes it should the device have decided otherwise)
+            armed = self._eng._armed_prefix
+            if (prepare is not None and self._comm is None and not queued
+                    and not (armed is not None and self._w_token == self._eng.update_gen
+                             and (armed is self._eng.STEP_ARMED or armed == self._prefix_key()))):
+                # (with the prefix armed FOR THIS UPDATER'S latest fused update, the update queued it behind itself on
+                #  the device's own ESS test: the resampler's call finds it done, or redoes it should the device have
+                #  decided otherwise; a resample qsmc_step queued itself is further along still)
                 prepare(self.model, self)            # GPU starts on the weight-only prefix right away
             self.resample(_defer_warning=True)
 
@@ -647,6 +769,8 @@ class SMCUpdater(ParticleDistribution):
             if not _defer_warning and hasattr(self.resampler, "_flush_failed_warning"):
                 self.resampler._flush_failed_warning(synchronize=True)
         if isinstance(new, ParticleDistribution):
+            if new._x is self._x_spare:               # the resampler filled the spare cloud: the old one is the next spare
+                self._x_spare = self._x if self._x.shape == new._x.shape else None
             self._x, self._w, self._norm, self._sumsq = new._x, new._w, new._norm, new._sumsq
             if self._comm is not None:           # uniform weights: a shard's weight total is its size
                 self._shard_sums = np.asarray(self._comm.last_shard_sizes, dtype=np.float64)

@@ -156,6 +156,13 @@ class TomographyModel(NativeModelMixin, FiniteOutcomeModel):
     def _native_desc(self):
         return _native.ModelDesc(_native.MODEL_TOMOGRAPHY, self.n_modelparams, 0.0, 1, 0)
 
+    def _native_fill_expparam(self, ep, expparams):
+        d = self.n_modelparams
+        if type(expparams) is np.ndarray and expparams.shape == (1,) and d <= _native.QSMC_MAX_D:
+            ep.meas[:d] = expparams['meas'].reshape(-1).tolist()
+            return True
+        return False
+
     def _native_expparams(self, expparams):
         expparams = np.atleast_1d(expparams)
         meas = np.asarray(expparams['meas'], dtype=np.float64).reshape(-1, self.n_modelparams)

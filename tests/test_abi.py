@@ -48,13 +48,16 @@ def test_ctypes_table_matches_header(lib):
 def test_struct_layouts(lib):
     """ctypes mirrors of the header structs have the sizes the C compiler gives them."""
     from qinfer_amd import _native
-    src = '#include "qsmc.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu\\n", sizeof(qsmc_model_t),' \
-          ' sizeof(qsmc_expparam_t), sizeof(qsmc_update_stats_t));return 0;}'
+    src = '#include "qsmc.h"\n#include <stdio.h>\n#include <stddef.h>\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu\\n", ' \
+          'sizeof(qsmc_model_t), sizeof(qsmc_expparam_t), sizeof(qsmc_update_stats_t), sizeof(qsmc_step_t), ' \
+          'offsetof(qsmc_step_t, lw), offsetof(qsmc_step_t, status), offsetof(qsmc_step_t, moments));return 0;}'
     exe = "/tmp/qsmc_sizeof"
     subprocess.run(["gcc", "-x", "c", "-", "-I", os.path.join(ROOT, "include"), "-o", exe],
                    input=src, text=True, check=True)
     sizes = [int(v) for v in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()]
-    assert sizes == [C.sizeof(_native.ModelDesc), C.sizeof(_native.ExpParam), C.sizeof(_native.UpdateStats)]
+    assert sizes == [C.sizeof(_native.ModelDesc), C.sizeof(_native.ExpParam), C.sizeof(_native.UpdateStats),
+                     C.sizeof(_native.Step), _native.Step.lw.offset, _native.Step.status.offset,
+                     _native.Step.moments.offset]
 
 
 def test_invalid_arguments_return_status(lib):

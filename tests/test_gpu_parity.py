@@ -1536,6 +1536,112 @@ def test_speculative_prefix_same_particles(qi, monkeypatch):
         np.testing.assert_array_equal(np.asarray(a.normalization_record), np.asarray(b.normalization_record))
 
 
+def test_step_path_same_particles(qi, monkeypatch):
+    """qsmc_step -- the fused update, the no-guard tail of `update` and (d <= 4, static cloud) the Liu-West resample
+    queued from C the moment the n_ess test fails -- changes no number: bit-identical clouds, weights and records to the
+    round-2 path (QSMC_NO_STEP: everything after the sums in Python, the resample launched by the resampler's own
+    call), for every native model family; every resample the C side queued is adopted by the resampler's call."""
+    from qinfer_amd import smc as smc_mod
+    rng = np.random.default_rng(8)
+    ts = (9 / 8) ** np.arange(70)
+    prec = [(int(rng.random() < np.sin(0.3 * t / 2) ** 2), np.array([t])) for t in ts]
+    bm = qi.BinomialModel(qi.SimplePrecessionModel())
+    binom = []
+    for t in ts[:40]:
+        ep = np.empty((1,), dtype=bm.expparams_dtype)
+        ep['x'], ep['n_meas'] = t, 25
+        binom.append((int(rng.binomial(25, np.sin(0.3 * t / 2) ** 2)), ep))
+    rbm = qi.RandomizedBenchmarkingModel()
+    rb = [(int(rng.random() < 0.5), np.array([(1 + 5 * k,)], dtype=rbm.expparams_dtype)) for k in range(40)]
+    basis = qi.tomography.pauli_basis(2)
+    tm = qi.TomographyModel(basis)
+    tomo = []
+    for k in range(40):
+        ep = np.zeros((1,), dtype=tm.expparams_dtype)
+        ep['meas'][0, 0] = 1
+        ep['meas'][0, int(rng.integers(1, 16))] = 1
+        tomo.append((int(rng.random() < 0.5), ep))
+    np.random.seed(3)
+    gin = qi.GinibreDistribution(basis).sample(60_000)
+    grw = qi.GaussianRandomWalkModel(qi.SimplePrecessionModel(), fixed_covariance=np.array([1e-6]))
+    cases = [
+        ("precession", lambda: qi.SimplePrecessionModel(), lambda m: qi.UniformDistribution([0, 1]), 300_000, prec, True),
+        ("binomial", lambda: qi.BinomialModel(qi.SimplePrecessionModel()), lambda m: qi.UniformDistribution([0, 1]),
+         200_000, binom, True),
+        ("rb", lambda: qi.RandomizedBenchmarkingModel(), lambda m: qi.PostselectedDistribution(
+            qi.UniformDistribution([[0.8, 1], [0, 1], [0, 1]]), m), 200_000, rb, True),
+        ("tomography", lambda: qi.TomographyModel(basis), lambda m: fixed_prior(qi, gin), 60_000, tomo, None),
+        ("random walk", lambda: qi.GaussianRandomWalkModel(qi.SimplePrecessionModel(), fixed_covariance=np.array([1e-6])),
+         lambda m: qi.UniformDistribution([0, 1]), 200_000, prec[:40], False),
+    ]
+    assert grw is not None
+
+    def run(make_model, make_prior, n, data, step):
+        monkeypatch.setattr(smc_mod, "_NO_STEP", not step)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m = make_model()
+            upd = qi.SMCUpdater(m, n, make_prior(m), device_rng=True, seed=21)
+            assert (upd._st is not None) == step
+            q0, a0 = upd._eng.step_stats()
+            ess = []
+            for o, ep in data:
+                upd.update(o, ep)
+                ess.append(float(upd.n_ess))
+            q1, a1 = upd._eng.step_stats()
+        return upd, np.array(ess), q1 - q0, a1 - a0
+
+    for name, make_model, make_prior, n, data, queued in cases:
+        a, ess_a, q_a, ad_a = run(make_model, make_prior, n, data, True)
+        b, ess_b, q_b, ad_b = run(make_model, make_prior, n, data, False)
+        assert a.resample_count == b.resample_count and a.resample_count > 0, name
+        np.testing.assert_array_equal(a.particle_locations, b.particle_locations, err_msg=name)
+        np.testing.assert_array_equal(a.particle_weights, b.particle_weights, err_msg=name)
+        np.testing.assert_array_equal(np.ravel(a.normalization_record), np.ravel(b.normalization_record), err_msg=name)
+        np.testing.assert_array_equal(ess_a, ess_b, err_msg=name)
+        assert float(a.min_n_ess) == float(b.min_n_ess), name
+        np.testing.assert_array_equal(a.est_mean(), b.est_mean(), err_msg=name)
+        np.testing.assert_array_equal(a.est_covariance_mtx(), b.est_covariance_mtx(), err_msg=name)
+        assert q_b == 0 and ad_b == 0
+        if queued:                                   # every resample was queued from C and adopted by the resampler's call
+            assert q_a == a.resample_count and ad_a == a.resample_count, (name, q_a, ad_a, a.resample_count)
+        elif queued is False:
+            assert q_a == 0
+    # the guards still fire from the step path, with the reference's messages (fixture G6 mirrors them for the old path)
+    monkeypatch.setattr(smc_mod, "_NO_STEP", False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        upd = qi.SMCUpdater(qi.SimplePrecessionModel(), 5000, qi.UniformDistribution([0, 1]))
+        upd.particle_weights = np.zeros(5000)
+    with pytest.raises(RuntimeError, match="All particle weights are zero"):
+        upd.update(0, np.array([1.0]))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        upd = qi.SMCUpdater(qi.SimplePrecessionModel(), 5000, qi.UniformDistribution([0, 1]), zero_weight_policy='skip')
+        w = np.full(5000, 1 / 5000)
+        w[0] = -0.5
+        upd.particle_weights = w
+    with pytest.warns(qi.ApproximationWarning, match="Negative weights"):
+        upd.update(0, np.array([0.0]))
+    assert np.all(np.asarray(upd.particle_weights) >= 0)
+    # a user swaps the resampler / the threshold between data: the struct follows
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        upd = qi.SMCUpdater(qi.SimplePrecessionModel(), 100_000, qi.UniformDistribution([0, 1]), device_rng=True, seed=2)
+        for o, ep in prec[:10]:
+            upd.update(o, ep)
+        rc = upd.resample_count
+        upd.resample_thresh = 0.0                    # never again
+        for o, ep in prec[10:30]:
+            upd.update(o, ep)
+        assert upd.resample_count == rc
+        upd.resample_thresh = 0.99                   # at every datum now
+        upd.resampler = qi.LiuWestResampler(a=0.9, device_rng=True, seed=5)
+        for o, ep in prec[30:34]:
+            upd.update(o, ep)
+        assert upd.resample_count == rc + 4
+
+
 def test_kl_divergence_g14(qi, golden):
     """est_kl_divergence / SMCUpdater's resampling divergences (distributions.py:466-500, smc.py:506-542) on the device
     against the reference's values (fixture g14) and the oracle."""
