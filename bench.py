@@ -42,7 +42,8 @@ sys.path.insert(0, os.path.join(ROOT, "python-qinfer_amd"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 N_SCHEDULE = 200
-TAGS = {0: "update", 1: "sample", 2: "update_ones", 3: "canon_classify", 4: "canon_list", 5: "moments", 6: "counts"}
+TAGS = {0: "update", 1: "sample", 2: "update_ones", 3: "canon_classify", 4: "canon_list", 5: "moments", 6: "counts",
+        8: "ancestors"}
 
 
 def schedule():
@@ -258,14 +259,28 @@ def run_other_config(qi, eng, torch, spec, warmup):
         out["update_kernel"] = frac_entry(spec["update_kernel"], kt["update"]["avg_us"], (16 + 8 * d) * n,
                                           kt["update"]["launches"], {"bytes_per_particle": 16 + 8 * d})
     if "sample" in kt:
-        out["resample_kernel"] = frac_entry(spec["sampler"], kt["sample"]["avg_us"], (8 + 16 * d) * n,
-                                            kt["sample"]["launches"], {"bytes_per_particle": 8 + 16 * d})
+        if "ancestors" in kt:
+            # d = 16: the sampler is two kernels (ancestors, then the kicks with canonicalize's classify pass folded in)
+            us = kt["sample"]["avg_us"] + kt["ancestors"]["avg_us"]
+            out["resample_kernel"] = frac_entry("k_bucket_anc16<512> + k_bucket_kick16 (classify fused)", us, (8 + 16 * d) * n,
+                                                kt["sample"]["launches"],
+                                                {"bytes_per_particle": 8 + 16 * d, "ancestors_us": kt["ancestors"]["avg_us"],
+                                                 "kick_us": kt["sample"]["avg_us"]})
+        else:
+            out["resample_kernel"] = frac_entry(spec["sampler"], kt["sample"]["avg_us"], (8 + 16 * d) * n,
+                                                kt["sample"]["launches"], {"bytes_per_particle": 8 + 16 * d})
     if "canon_classify" in kt:
         cus = kt["canon_classify"]["avg_us"] + kt.get("canon_list", {"avg_us": 0.0})["avg_us"]
         out["canonicalize"] = frac_entry("k_tomo_classify<4> + k_tomo_canon_list<4>", cus, 16 * d * n,
                                          kt["canon_classify"]["launches"],
                                          {"bytes_per_particle": 16 * d, "classify_us": kt["canon_classify"]["avg_us"],
                                           "canon_list_us": kt.get("canon_list", {"avg_us": 0.0})["avg_us"]})
+    elif "canon_list" in kt:
+        # classify rides in the kick kernel (no pass of its own): what is left of canonicalize is the list pass over the
+        # particles whose rho is not positive definite (about a third: read + write 16 rows of those)
+        out["canonicalize"] = {"kernel": "k_tomo_canon_list<4> (classify fused into k_bucket_kick16)",
+                               "avg_kernel_us": kt["canon_list"]["avg_us"], "timed_launches": kt["canon_list"]["launches"],
+                               "classify_us": 0.0, "canon_list_us": kt["canon_list"]["avg_us"]}
     if "moments" in kt:
         out["moments_kernel"] = frac_entry("k_moments_mfma", kt["moments"]["avg_us"], (8 + 8 * d) * n,
                                            kt["moments"]["launches"], {"bytes_per_particle": 8 + 8 * d})

@@ -112,7 +112,8 @@ int         qsmc_profile_read(qsmc_handle_t h, float *ms_out, int32_t *tags_out,
 #define QSMC_PROF_MOMENTS 5        /* weighted moments, 4 < d <= 16 (k_moments_mfma) */
 #define QSMC_PROF_COUNTS 6         /* the resampler's chunk counts + plan launch (k_bucket_counts) */
 #define QSMC_PROF_COUNTS_SKIPPED 7 /* a speculative k_bucket_counts that left at its gate (qsmc_lw_arm_prefix) */
-#define QSMC_PROF_NTAGS 8
+#define QSMC_PROF_ANCESTORS 8      /* d = 16 sampler, first half: ancestors of every slot (k_bucket_anc16); tag 1 is its kick kernel */
+#define QSMC_PROF_NTAGS 16
 
 /* ---- likelihood, contract form (abstract_model.py:444-468 + :666-686; a6-a10) ------------ */
 /* L_out[(o * n_e + e) * n + i] = Pr(outcomes[o] | x_i ; exps[e]).  This is the
@@ -166,6 +167,11 @@ int qsmc_update_fused(qsmc_handle_t h, const qsmc_model_t *model,
  * (and x_out = lw.x_out) it finds its work done and returns at once; with anything different the resample is simply
  * run again into the caller's buffer.  The queued resample never replaces the caller's decision, it only starts it
  * early.
+ * d = 16 (2-qubit tomography; moments are a pass of their own, k_moments_mfma): the call queues the moments and the
+ * first half of the split sampler (k_bucket_anc16: ancestors, needs weights only), waits for the moments, forms mean /
+ * covariance / S on the host while that kernel runs, and queues the second half (k_bucket_kick16) behind it; the moments
+ * come back in moments_big (qsmc_moments' out_host layout) so the caller need not compute them again.  In round 2 the
+ * GPU idled ~120 us per d = 16 resample while Python did this between two launches.
  * The speculative weight-only prefix of qsmc_lw_arm_prefix is armed from lw.* by every call with lw.prefix != 0.
  * w == NULL: implicit all-ones weights (then w_alt becomes NULL on commit: supply a buffer before the next call). */
 #define QSMC_STEP_GUARD           1
@@ -181,6 +187,9 @@ typedef struct qsmc_step_lw {
     int64_t  n_out;
     double  *x_out;              /* device, SoA d x n_out, row stride ldx_out                               */
     int64_t  ldx_out;
+    int32_t  canon_kind;         /* d = 16 tomography, canonicalize folded into the resample (qsmc_lw_fuse_canonicalize): */
+    int32_t  canon_allow_sub;    /*   0 = no, 1 = the 2-qubit Pauli basis, 2 = a dense basis; allow_subnormalized         */
+    const double *canon_basis;   /*   device basis tensor (dense) or NULL (Pauli)                                         */
 } qsmc_step_lw_t;
 typedef struct qsmc_step {
     /* the cloud -- kept current by the caller; w / w_alt / norm / sumsq / min_n_ess advance here on commit */
@@ -199,6 +208,7 @@ typedef struct qsmc_step {
     double        n_ess;
     double        moments[14];   /* d <= 4: [sum w' x_m, upper(sum w' x_m x_n)] of the new weights           */
     double        mean[QSMC_MAX_D], cov[QSMC_MAX_D * QSMC_MAX_D], S[QSMC_MAX_D * QSMC_MAX_D], S_err;   /* of a queued resample */
+    double        moments_big[1 + QSMC_MAX_D + QSMC_MAX_D * (QSMC_MAX_D + 1) / 2];   /* d > 4, a queued resample: qsmc_moments' out_host */
 } qsmc_step_t;
 int qsmc_step(qsmc_handle_t h, qsmc_step_t *st, const qsmc_model_t *model, const qsmc_expparam_t *exp,
               int64_t outcome, qsmc_stream_t stream);
@@ -411,6 +421,16 @@ int qsmc_lw_arm_prefix(qsmc_handle_t h, int32_t enabled, double ess_below, int64
                        uint64_t epoch);
 /* how many prefixes were queued that way on this handle, and how many resamples found theirs done */
 int qsmc_lw_prefix_stats(qsmc_handle_t h, int64_t *n_queued, int64_t *n_adopted);
+
+/* TomographyModel.canonicalize folded into the resample (smc.py:529 runs it on the fresh cloud; tomography/models.py:149-209):
+ * the NEXT qsmc_lw_resample_philox on this handle -- a d = 16 TOMOGRAPHY model on the bucketed path -- classifies every
+ * new particle while it still holds it in registers (LDL^H pivot test: a positive-definite rho only needs x / (x_0 sqrt dim),
+ * done in the same store), lists the others and runs the eigenvalue-clamping pass (k_tomo_canon_list) on the list:
+ * the result is what qsmc_tomo_canonicalize2(basis, 4, basis_kind, x_out, ...) would leave, bit for bit, without the
+ * pass that re-read and re-wrote the whole cloud.  One-shot: consumed (or dropped, if it does not apply: status
+ * QSMC_ERR_UNSUPPORTED from the resample) by that call; any call that changes weights clears it. */
+int qsmc_lw_fuse_canonicalize(qsmc_handle_t h, const double *basis, int32_t dim, int32_t basis_kind,
+                              int32_t allow_subnormalized);
 
 /* qsmc_lw_resample_philox with n_failed_host == NULL does not synchronise: the failed-particle count
  * is written to pinned host memory by the stream; read it here once `stream` has been synchronised by

@@ -1156,7 +1156,7 @@ __global__ __launch_bounds__(BT) void k_bucket_sample_ordered(
 }
 
 // ---------------------------------------------------------------------------------------------
-// d = 16 (2-qubit tomography) sampler on the matrix cores.  The generic kernel's d = 16 instantiation gave every lane
+// d = 16 (2-qubit tomography) sampler on the matrix cores (k_bucket_anc16 + k_bucket_kick16 below).  The generic kernel's d = 16 instantiation gave every lane
 // one output PAIR: 16 Box-Muller pairs and a 2 x 16 x 16 product per lane, 256 VGPRs, two waves per SIMD, 383 us at
 // N = 1.25e6 (0.11 of the HBM roofline).  Here a wave owns 16 outputs per trip and the 16 x 16 tile of their kicks
 // K = S Z is one v_mfma_f64_16x16x4 chain:
@@ -1180,31 +1180,33 @@ __global__ __launch_bounds__(BT) void k_bucket_sample_ordered(
 // o_begin + k: the same law (the normals are independent of the ancestors), and what oracle/philox.py does too.
 typedef double v4d_s __attribute__((ext_vector_type(4)));
 constexpr int S16_HEAVY = 24, S16_HEAVY_CAP = BUCKET_CAP / S16_HEAVY + 8;
+
+// Round 3: the d = 16 sampler is TWO kernels.  Phases 1-2 above need only the weights and the plan; the kick needs the
+// mean and S = h sqrtm(cov), and at d = 16 the moments behind those are a pass of their own (k_moments_mfma) whose
+// result the host turns into S (a 16 x 16 Jacobi, ~20 us).  With one kernel the GPU sat idle through all of that
+// (~120 us per resample in round 2).  Split, k_bucket_anc16 is launched the moment the resample is due and runs while
+// the host forms S; k_bucket_kick16 is queued behind it as soon as S exists -- before the first has finished.  The
+// ancestors travel through HBM as 4-byte indices (5 MB at N = 1.25e6 against 330 MB of particles).  The kick kernel
+// no longer carries the chunk tables (70 KB of LDS, two workgroups per CU): 35 KB, five workgroups of four waves.
+//
+// k_bucket_anc16: anc[o] = source particle (global index) of output slot o; within a work item ascending.
 template <int BT>
-__global__ __launch_bounds__(BT) void k_bucket_sample16(
-    const double *__restrict__ x_in, int64_t ldx_in, int64_t n_in, const double *__restrict__ w, double inv_norm,
-    const double *__restrict__ offsets, int chunks, const long long *__restrict__ slot_off,
-    const int *__restrict__ item_off, const int *__restrict__ item_chunk, LWArgs lw, uint32_t k0, uint32_t k1,
-    uint32_t epoch, double *__restrict__ x_out, OutPlace pl, int cap) {
-    constexpr int DM = 16;
+__global__ __launch_bounds__(BT) void k_bucket_anc16(
+    int64_t n_in, const double *__restrict__ w, double inv_norm, const double *__restrict__ offsets, int chunks,
+    const long long *__restrict__ slot_off, const int *__restrict__ item_off, const int *__restrict__ item_chunk,
+    uint32_t k0, uint32_t k1, uint32_t epoch, unsigned int *__restrict__ anc, int cap) {
     __shared__ __attribute__((aligned(32))) double lcdf[BUCKET_CHUNK];
     __shared__ double ltops[TOPS_LDS];
     __shared__ unsigned short lguide[TGUIDE_BINS + 2];
     __shared__ double wave_tot[SCAN_WAVES];
     __shared__ int iwave_tot[SCAN_WAVES];
-    __shared__ double sS[DM * DM + DM];                             // S (row-major) and the mean
     __shared__ unsigned int cnt[BUCKET_CHUNK];                      // children per source particle
     __shared__ unsigned short sorted[BUCKET_CAP];                   // ancestors of the item's outputs, ascending
     __shared__ unsigned int heavy[2 * S16_HEAVY_CAP];
     __shared__ int hcount;
     static_assert(BT == SCAN_THREADS, "one lane owns 8 consecutive source particles");
-    // XCD-aware work list: workgroup b runs on XCD b % 8 and each XCD has its own L2.  The items of one chunk gather
-    // from the same 16 x 32 KB window of the cloud, so they are dealt to ONE XCD, back to back (item = xcd * per + b / 8)
-    // -- dealt round-robin, every XCD fetched every chunk's window: 876 MB of traffic for 330 MB of payload.
-    const int n_items = item_off[chunks];
-    const int per = (n_items + 7) >> 3;
-    const int bid = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
-    if (((int)blockIdx.x >> 3) >= per || bid >= n_items) return;
+    const int bid = (int)blockIdx.x;
+    if (bid >= item_off[chunks]) return;
     const int c = item_chunk[bid];
     const int part = bid - item_off[c];
     const long long slot0 = slot_off[c], n_c = slot_off[c + 1] - slot0;
@@ -1216,8 +1218,6 @@ __global__ __launch_bounds__(BT) void k_bucket_sample16(
     const double hi_edge = offsets[c + 1];
     const double gscale = (double)TGUIDE_BINS / (hi_edge - lo_edge);
     const bool use_guide = hi_edge > lo_edge && gscale < 1e300;     // workgroup-uniform
-    for (int k = threadIdx.x; k < DM * DM; k += BT) sS[k] = lw.S[k];
-    if (threadIdx.x < DM) sS[DM * DM + threadIdx.x] = lw.mean[threadIdx.x];
     for (int k = threadIdx.x; k < BUCKET_CHUNK; k += BT) cnt[k] = 0u;
     if (threadIdx.x == 0) hcount = 0;
     chunk_scan_block(w, n_in, inv_norm, offsets, (int64_t)c, wave_tot,
@@ -1282,37 +1282,119 @@ __global__ __launch_bounds__(BT) void k_bucket_sample16(
         }
         __syncthreads();
     }
-    // ---- 3: the kicks, 16 consecutive list entries per wave trip
+    for (int k = threadIdx.x; k < q; k += BT) anc[o_begin + k] = (unsigned int)(base + (int64_t)sorted[k]);
+}
+
+// k_bucket_kick16: the kicks of all output slots, 64 per wave trip, and -- CANON != 0 -- the first pass of
+// TomographyModel.canonicalize on the way out (smc.py:529, tomography/models.py:149-209).
+// Per sub-trip t = 0..3 a wave does what one trip of the round-2 kernel did for 16 slots: lane (g, n) gathers 4
+// coordinates of the ancestor of slot k0 + 16 t + n, draws its two Box-Muller pairs and the 16 x 16 tile of kicks
+// K = S Z is one v_mfma_f64_16x16x4 chain (operand layout as described above); the results go to an LDS tile
+// [slot][coordinate] (row stride 17: the transposed read below is conflict-free up to 2 ways).  After four
+// sub-trips lane L owns ALL 16 coordinates of slot k0 + L:
+//   * CANON: the LDL^H pivot test (tomo_clearly_positive); a positive-definite rho (two thirds of a fresh cloud) is
+//     finished here (x / (x_0 sqrt dim)), the others are listed for k_tomo_canon_list -- round 2 ran this test as a
+//     separate pass (k_tomo_classify) that read the cloud back and wrote it again: 320 MB and 61 us per resample;
+//   * the particle is written once, row by row: 64 consecutive slots of one coordinate per store instruction (512 B),
+//     where the MFMA layout's own stores were 16 slots x 4 coordinates (128 B segments; 1.27x the algorithmic bytes).
+// Same arithmetic per particle as before the split: (a x_a + (1 - a) mu) + (S z), then p * inv -- bit-identical clouds.
+// Workgroup b takes slots [r per_block, (r + 1) per_block), r = (b & 7) per + (b >> 3): ranges adjacent in slot order
+// (whose ancestors are neighbours) go to ONE XCD (b % 8) back to back, so each 16 x 32 KB source window is fetched by
+// one L2 instead of eight.
+constexpr int KICK16_BT = 256, KICK16_WAVES = KICK16_BT / QSMC_WAVE, KICK16_ROW = 17, KICK16_PER_BLOCK = 1024;
+template <int CANON>       // 0: no canonicalize; 1: the 2-qubit Pauli basis (sparse contraction); 2: dense basis
+__global__ __launch_bounds__(KICK16_BT) void k_bucket_kick16(
+    const double *__restrict__ x_in, int64_t ldx_in, const unsigned int *__restrict__ anc, int64_t n_out, LWArgs lw,
+    uint32_t k0, uint32_t k1, uint32_t epoch, double *__restrict__ x_out, OutPlace pl,
+    const double *__restrict__ basis, int allow_subnormalized, unsigned int *__restrict__ list,
+    unsigned int *__restrict__ count) {
+    constexpr int DM = 16;
+    __shared__ double tile[KICK16_WAVES][QSMC_WAVE * KICK16_ROW];
+    __shared__ double sS[DM * DM + DM];                             // S (row-major) and the mean
+    __shared__ unsigned int hard_buf[KICK16_PER_BLOCK];
+    __shared__ unsigned int bcount, gbase;
+    const int64_t n_ranges = (n_out + KICK16_PER_BLOCK - 1) / KICK16_PER_BLOCK;
+    const int per = ((int)gridDim.x + 7) >> 3;
+    const int64_t rb = (int64_t)((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+    if (((int)blockIdx.x >> 3) >= per || rb >= n_ranges) return;
+    const int64_t r0 = rb * KICK16_PER_BLOCK;
+    const int64_t r1 = r0 + KICK16_PER_BLOCK < n_out ? r0 + KICK16_PER_BLOCK : n_out;
+    for (int k = threadIdx.x; k < DM * DM; k += KICK16_BT) sS[k] = lw.S[k];
+    if (threadIdx.x < DM) sS[DM * DM + threadIdx.x] = lw.mean[threadIdx.x];
+    if (threadIdx.x == 0) bcount = 0u;
+    __syncthreads();
+    const int lane = threadIdx.x & (QSMC_WAVE - 1), wave = threadIdx.x / QSMC_WAVE;
     const int n = lane & 15, g = lane >> 4;
     double aS[4], mu4[4];
 #pragma unroll
     for (int sidx = 0; sidx < 4; ++sidx) aS[sidx] = sS[(lane & 15) * DM + 4 * g + sidx];
 #pragma unroll
     for (int r = 0; r < 4; ++r) mu4[r] = (1.0 - lw.a) * sS[DM * DM + g + 4 * r];
-    constexpr int PER_TRIP = (BT / QSMC_WAVE) * 16;                  // outputs per workgroup trip
-    for (int kb = wave * 16; kb < q; kb += PER_TRIP) {
-        const int k = kb + n;
-        const bool live = k < q;
-        const int kc = live ? k : q - 1;                            // (idle columns shadow the last one: no divergence)
-        const int64_t oc = o_begin + kc;
-        const int j = (int)sorted[kc];
-        double xa[4];
+    double *mine = tile[wave];
+    for (int64_t kb = r0; kb < r1; kb += KICK16_BT) {               // (uniform over the workgroup)
+        const int64_t k64 = kb + (int64_t)wave * QSMC_WAVE;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) xa[r] = x_in[(int64_t)(g + 4 * r) * ldx_in + base + j];
-        // the four normals 4 g .. 4 g + 3 of slot oc: pairs 2 g and 2 g + 1 (blocks oc * 8 + 2 g, + 1; slot 2)
-        double z[4];
-        PhiloxStream nrm{(uint64_t)oc * 8u + (uint64_t)(2 * g), (epoch << 16), k0, k1};
-        nrm.normals(2, z[0], z[1]);
-        nrm.particle += 1;
-        nrm.normals(2, z[2], z[3]);
-        v4d_s acc = {0.0, 0.0, 0.0, 0.0};
+        for (int t = 0; t < 4; ++t) {
+            const int64_t k = k64 + 16 * t + n;
+            const int64_t oc = k < r1 ? k : r1 - 1;                 // (idle columns shadow the last slot: no divergence)
+            const int64_t j = (int64_t)anc[oc];
+            double xa[4];
 #pragma unroll
-        for (int sidx = 0; sidx < 4; ++sidx) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aS[sidx], z[sidx], acc, 0, 0, 0);
-        if (live) {
-            const int64_t row = place_row(pl, oc);
+            for (int r = 0; r < 4; ++r) xa[r] = x_in[(int64_t)(g + 4 * r) * ldx_in + j];
+            // the four normals 4 g .. 4 g + 3 of slot oc: pairs 2 g and 2 g + 1 (blocks oc * 8 + 2 g, + 1; slot 2)
+            double z[4];
+            PhiloxStream nrm{(uint64_t)oc * 8u + (uint64_t)(2 * g), (epoch << 16), k0, k1};
+            nrm.normals(2, z[0], z[1]);
+            nrm.particle += 1;
+            nrm.normals(2, z[2], z[3]);
+            v4d_s acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                x_out[(int64_t)(g + 4 * r) * pl.ld_m + row * pl.ld_s] = (lw.a * xa[r] + mu4[r]) + acc[r];
+            for (int sidx = 0; sidx < 4; ++sidx) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aS[sidx], z[sidx], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mine[(16 * t + n) * KICK16_ROW + g + 4 * r] = (lw.a * xa[r] + mu4[r]) + acc[r];
+        }
+        __syncthreads();
+        const int64_t o = k64 + lane;
+        bool hard = false;
+        if (o < r1) {
+            double p[DM];
+#pragma unroll
+            for (int m = 0; m < DM; ++m) p[m] = mine[lane * KICK16_ROW + m];
+            if (CANON) {
+                bool pos;
+                if (CANON == 1) pos = tomo_clearly_positive<4>(TomoPauli2{}, p);
+                else pos = tomo_clearly_positive<4>(TomoDense<4>{basis}, p);
+                if (pos) {
+                    if (!allow_subnormalized) {                     // tomography/models.py:194-209
+                        const double inv = 1.0 / (p[0] * sqrt(4.0));
+#pragma unroll
+                        for (int m = 0; m < DM; ++m) p[m] = p[m] * inv;
+                    }
+                } else {
+                    hard = true;
+                }
+            }
+            const int64_t row = place_row(pl, o);
+#pragma unroll
+            for (int m = 0; m < DM; ++m) x_out[(int64_t)m * pl.ld_m + row * pl.ld_s] = p[m];
+        }
+        if (CANON) {
+            const unsigned long long mk = __ballot(hard);
+            if (mk) {
+                unsigned int hb = 0;
+                if (lane == 0) hb = atomicAdd(&bcount, (unsigned int)__popcll(mk));
+                hb = __shfl(hb, 0, QSMC_WAVE);
+                if (hard) hard_buf[hb + __popcll(mk & ((1ull << lane) - 1ull))] = (unsigned int)o;
+            }
+        }
+        __syncthreads();                                            // the tile is rewritten by the next trip
+    }
+    if (CANON) {
+        const unsigned int m = bcount;                              // (read after the loop's last barrier)
+        if (m) {
+            if (threadIdx.x == 0) gbase = atomicAdd(count, m);
+            __syncthreads();
+            for (unsigned int t = threadIdx.x; t < m; t += KICK16_BT) list[gbase + t] = hard_buf[t];
         }
     }
 }

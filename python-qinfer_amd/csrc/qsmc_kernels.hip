@@ -47,6 +47,8 @@ struct qsmc_ctx {
     double *red_out;       // device [REDUCE_OUT_MAX] totals of the last grid reduction
     double *mapped;        // pinned host memory the reducing workgroup writes directly ...
     double *mapped_dev;    // ... and its device alias
+    double *mapped_big;            // pinned host block for the d > 4 moments of a queued resample (MFMA_MOM_K doubles) ...
+    double *mapped_big_dev;        // ... and its device alias
     unsigned long long *flag;      // pinned host word: sequence number of the last completed reduction
     unsigned long long *flag_dev;  // its device alias
     unsigned long long seq;        // last sequence number handed to a reducing launch
@@ -91,8 +93,15 @@ struct qsmc_ctx {
         int prof_slot;             // profiling-ring entry of that launch (-1: not timed)
         long long n_queued, n_adopted;   // speculative launches so far / resamples that found theirs done
     } spec;
+    struct {                       // qsmc_lw_fuse_canonicalize: consumed by the next qsmc_lw_resample_philox
+        int kind;                  // 0: none, 1: 2-qubit Pauli basis, 2: dense basis
+        int allow_sub;
+        const double *basis;
+    } canon_next;
     struct {                       // the resample qsmc_step queued itself (adopted by a matching qsmc_lw_resample_philox)
         int valid;
+        int canon_kind, canon_allow_sub;
+        const double *canon_basis;
         qsmc_model_t model;
         int32_t postselect, d, maxiter;
         const double *x_in, *w;
@@ -104,6 +113,8 @@ struct qsmc_ctx {
         hipStream_t stream;
         long long n_queued, n_adopted;
     } rsq;
+    unsigned int *anc16;    // device: ancestors + canonicalize list of the split d = 16 sampler
+    size_t anc16_cap;       // in bytes
     unsigned int *iscratch; // device integer scratch for the bucketed resampler
     size_t iscratch_cap;    // in bytes
     double *cdf_scratch;    // device CDF, materialised only for the direct sampler / global redraws
@@ -573,6 +584,8 @@ int qsmc_create(qsmc_handle_t *out, int device) {
     if (e == hipSuccess) e = hipMalloc(&h->red_out, REDUCE_OUT_MAX * sizeof(double));
     if (e == hipSuccess) e = hipHostMalloc(&h->mapped, REDUCE_OUT_MAX * sizeof(double), hipHostMallocMapped);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&h->mapped_dev, h->mapped, 0);
+    if (e == hipSuccess) e = hipHostMalloc(&h->mapped_big, 512 * sizeof(double), hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&h->mapped_big_dev, h->mapped_big, 0);
     if (e == hipSuccess) e = hipHostMalloc(&h->flag, 64, hipHostMallocMapped);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&h->flag_dev, h->flag, 0);
     if (e == hipSuccess) *h->flag = 0ull;
@@ -603,10 +616,12 @@ int qsmc_destroy(qsmc_handle_t h) {
     if (h->gbar) (void)hipFree(h->gbar);
     if (h->spec.gate) (void)hipFree(h->spec.gate);
     if (h->iscratch) (void)hipFree(h->iscratch);
+    if (h->anc16) (void)hipFree(h->anc16);
     if (h->cdf_scratch) (void)hipFree(h->cdf_scratch);
     if (h->red_out) (void)hipFree(h->red_out);
     if (h->mapped) (void)hipHostFree(h->mapped);
     if (h->flag) (void)hipHostFree(h->flag);
+    if (h->mapped_big) (void)hipHostFree(h->mapped_big);
     if (h->prof_ev) {
         for (int i = 0; i < 2 * QSMC_PROF_CAP; ++i) (void)hipEventDestroy(h->prof_ev[i]);
         free(h->prof_ev);
@@ -721,7 +736,7 @@ int qsmc_update_fused(qsmc_handle_t h, const qsmc_model_t *model, const double *
                       const double *w_in, double *w_out, double prev_norm, const qsmc_expparam_t *exp,
                       int64_t outcome, double *stats_dev, qsmc_update_stats_t *stats_host, double *moments_host,
                       qsmc_stream_t stream) {
-    if (h) { h->prep.valid = 0; h->rsq.valid = 0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
+    if (h) { h->prep.valid = 0; h->rsq.valid = 0; h->canon_next.kind = 0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
     if (!h || !x || !w_out || !exp || n <= 0) return QSMC_ERR_INVALID;      // w_in == NULL: all-ones weights
     int rc = check_model(model);
     if (rc) return rc;
@@ -807,7 +822,7 @@ int qsmc_update_multi(qsmc_handle_t h, const qsmc_model_t *model, const double *
                       const double *w_in, double *w_out, double prev_norm, const qsmc_expparam_t *exps,
                       const int64_t *outcomes, int32_t k, qsmc_update_stats_t *stats_host, double *moments_host,
                       qsmc_stream_t stream) {
-    if (h) { h->prep.valid = 0; h->rsq.valid = 0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
+    if (h) { h->prep.valid = 0; h->rsq.valid = 0; h->canon_next.kind = 0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
     if (!h || !x || !w_out || !exps || !outcomes || !stats_host || n <= 0 || k < 1 || k > MULTI_KMAX)
         return QSMC_ERR_INVALID;
     int rc = check_model(model);
@@ -889,14 +904,14 @@ int qsmc_hypothetical_sums(qsmc_handle_t h, const qsmc_model_t *model, const dou
 int qsmc_update_from_likelihood(qsmc_handle_t h, const double *L, int64_t n, const double *w_in,
                                 double *w_out, double prev_norm, double *stats_dev,
                                 qsmc_update_stats_t *stats_host, qsmc_stream_t stream) {
-    if (h) { h->prep.valid = 0; h->rsq.valid = 0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
+    if (h) { h->prep.valid = 0; h->rsq.valid = 0; h->canon_next.kind = 0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
     if (!h || !L || !w_in || !w_out || n <= 0) return QSMC_ERR_INVALID;
     return weights_pass<0>(h, L, n, w_in, w_out, prev_norm, stats_dev, stats_host, (hipStream_t)stream);
 }
 
 int qsmc_clip_weights(qsmc_handle_t h, double *w, int64_t n, double norm, double *stats_dev,
                       qsmc_update_stats_t *stats_host, qsmc_stream_t stream) {
-    if (h) { h->prep.valid = 0; h->rsq.valid = 0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
+    if (h) { h->prep.valid = 0; h->rsq.valid = 0; h->canon_next.kind = 0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
     if (!h || !w || n <= 0) return QSMC_ERR_INVALID;
     return weights_pass<1>(h, nullptr, n, w, w, norm, stats_dev, stats_host, (hipStream_t)stream);
 }
@@ -948,14 +963,14 @@ int qsmc_kde_cross_entropy(qsmc_handle_t h, const double *x, int64_t ldx, int64_
 
 int qsmc_normalize_weights(qsmc_handle_t h, const double *w_in, double *w_out, int64_t n, double norm,
                            qsmc_stream_t stream) {
-    if (h) { h->prep.valid = 0; h->rsq.valid = 0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
+    if (h) { h->prep.valid = 0; h->rsq.valid = 0; h->canon_next.kind = 0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
     if (!h || !w_in || !w_out || n < 0) return QSMC_ERR_INVALID;
     if (n == 0) return QSMC_OK;
     return weights_pass<2>(h, nullptr, n, w_in, w_out, norm, nullptr, nullptr, (hipStream_t)stream);
 }
 
 int qsmc_fill(qsmc_handle_t h, double *w, int64_t n, double value, qsmc_stream_t stream) {
-    if (h) { h->prep.valid = 0; h->rsq.valid = 0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
+    if (h) { h->prep.valid = 0; h->rsq.valid = 0; h->canon_next.kind = 0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
     if (!h || !w || n < 0) return QSMC_ERR_INVALID;
     if (n == 0) return QSMC_OK;
     hipLaunchKernelGGL(k_fill, dim3(grid_for(n, QSMC_BLOCK * 4)), dim3(QSMC_BLOCK), 0, (hipStream_t)stream, w,
@@ -1109,10 +1124,12 @@ static int read_counter(qsmc_ctx *h, int64_t *out, hipStream_t s) {
 // Layout of the bucketed resampler's integer scratch:
 //   hist[256][chunks] | counts[chunks] | slot_off[chunks+1] i64 | item_off[chunks+1] | item_chunk[max_items] |
 //   retry_list[n_out] u32
+// (d = 16 only, in a buffer of their own -- the prefix is queued before d is known and must not be reallocated under the
+//  kernels that use it: anc[n_out] u32 | canon count[4] + list[n_out] u32)
 struct BucketPlan {
     bool bucketed;
     int chunks, max_items, cap;
-    unsigned int *hist, *counts, *retry_list;
+    unsigned int *hist, *counts, *retry_list, *anc, *clist;
     long long *slot_off;
     int *item_off, *item_chunk;
 };
@@ -1132,8 +1149,19 @@ static bool use_buckets(int64_t chunks64, int64_t n_out) {
     return chunks64 <= BUCKET_MAX_CHUNKS && n_out >= 4 * BUCKET_CHUNK && n_out < (1ll << 32) && !forced_direct;
 }
 
-static int bucket_plan_layout(qsmc_ctx *h, int64_t chunks64, int64_t n_out, BucketPlan *bp) {
+static int ensure_anc16(qsmc_ctx *h, size_t bytes) {
+    if (h->anc16_cap >= bytes) return QSMC_OK;
+    if (h->anc16) HIP_TRY(h, hipFree(h->anc16));
+    h->anc16 = nullptr;
+    h->anc16_cap = 0;
+    HIP_TRY(h, hipMalloc(&h->anc16, bytes));
+    h->anc16_cap = bytes;
+    return QSMC_OK;
+}
+
+static int bucket_plan_layout(qsmc_ctx *h, int64_t chunks64, int64_t n_out, BucketPlan *bp, bool split16 = false) {
     bp->bucketed = use_buckets(chunks64, n_out);
+    bp->anc = bp->clist = nullptr;
     if (!bp->bucketed) return QSMC_OK;
     const int chunks = (int)chunks64;
     const size_t hist_b = (size_t)BUCKET_COUNT_BLOCKS * chunks * sizeof(unsigned int);
@@ -1143,8 +1171,10 @@ static int bucket_plan_layout(qsmc_ctx *h, int64_t chunks64, int64_t n_out, Buck
     const int cap = bucket_cap(n_out);
     const int max_items = chunks + (int)(n_out / cap) + 1;
     const size_t map_b = ((size_t)max_items * sizeof(int) + 15) & ~(size_t)15;
-    const size_t retry_b = (size_t)n_out * sizeof(unsigned int);
-    const int rc = ensure_iscratch(h, hist_b + counts_b + slot_b + item_b + map_b + retry_b);
+    const size_t retry_b = ((size_t)n_out * sizeof(unsigned int) + 15) & ~(size_t)15;
+    int rc = ensure_iscratch(h, hist_b + counts_b + slot_b + item_b + map_b + retry_b);
+    if (rc) return rc;
+    if (split16) rc = ensure_anc16(h, 2 * retry_b + 16);
     if (rc) return rc;
     unsigned char *basep = reinterpret_cast<unsigned char *>(h->iscratch);
     bp->chunks = chunks;
@@ -1156,6 +1186,10 @@ static int bucket_plan_layout(qsmc_ctx *h, int64_t chunks64, int64_t n_out, Buck
     bp->item_off = reinterpret_cast<int *>(basep + hist_b + counts_b + slot_b);
     bp->item_chunk = reinterpret_cast<int *>(basep + hist_b + counts_b + slot_b + item_b);
     bp->retry_list = reinterpret_cast<unsigned int *>(basep + hist_b + counts_b + slot_b + item_b + map_b);
+    if (split16) {
+        bp->anc = h->anc16;
+        bp->clist = reinterpret_cast<unsigned int *>(reinterpret_cast<unsigned char *>(h->anc16) + retry_b);
+    }
     return QSMC_OK;
 }
 
@@ -1277,15 +1311,25 @@ static int resample_prefix(qsmc_ctx *h, const double *w, int64_t n_in, double no
     return QSMC_OK;
 }
 
+// TomographyModel.canonicalize (smc.py:529) folded into a d = 16 resample: kind 0 = not asked for
+struct CanonSpec {
+    int kind, allow_sub;
+    const double *basis;
+};
+constexpr int RS_STAGE_ANCESTORS = 1, RS_STAGE_KICK = 2, RS_STAGE_ALL = 3;
+
+// stages: the split d = 16 sampler may be queued in two halves (qsmc_step: ancestors while the host forms S, kicks after);
+// every other caller passes RS_STAGE_ALL.
 static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int32_t postselect,
                                 const double *x_in, int64_t ldx_in, int64_t n_in, int32_t d, const double *w,
                                 double norm, double a, const double *mean, const double *S, int64_t n_out,
                                 uint64_t seed, uint64_t epoch, int32_t maxiter, double *x_out, const OutPlace &pl,
-                                int64_t *n_failed_host, qsmc_stream_t stream) {
+                                int64_t *n_failed_host, qsmc_stream_t stream, CanonSpec canon = CanonSpec{0, 0, nullptr},
+                                int stages = RS_STAGE_ALL) {
     if (!h || !model || !x_in || !mean || !S || !x_out || n_in <= 0 || n_out <= 0) return QSMC_ERR_INVALID;
     if (d != model->d || d < 1 || d > QSMC_MAX_D || maxiter < 1) return QSMC_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
-    if (h->rsq.valid) {
+    if (h->rsq.valid && stages == RS_STAGE_ALL) {
         // qsmc_step queued a resample when its n_ess test failed: if this is that very call -- every argument equal,
         // mean and S bit for bit -- the work is done (or under way on `stream`); anything else runs as if nothing had
         // been queued (the queued one wrote its own buffer and is overwritten or ignored)
@@ -1295,7 +1339,8 @@ static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int3
                           q.ldx_in == ldx_in && q.n_in == n_in && q.n_out == n_out && q.norm == norm && q.a == a &&
                           q.seed == seed && q.epoch == epoch && q.x_out == x_out && q.stream == s && pl.n_dest == 0 &&
                           pl.ld_m == q.ldx_out && memcmp(q.mean, mean, sizeof(double) * d) == 0 &&
-                          memcmp(q.S, S, sizeof(double) * d * d) == 0;
+                          memcmp(q.S, S, sizeof(double) * d * d) == 0 && q.canon_kind == canon.kind &&
+                          (canon.kind == 0 || (q.canon_allow_sub == canon.allow_sub && q.canon_basis == canon.basis));
         h->rsq.valid = 0;
         if (same) {
             ++h->rsq.n_adopted;
@@ -1308,12 +1353,16 @@ static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int3
     uint32_t k0, k1, ep;
     philox_keys(seed, epoch, &k0, &k1, &ep);
     const int64_t chunks64 = (n_in + BUCKET_CHUNK - 1) / BUCKET_CHUNK;
+    static const bool no_mfma16 = getenv("QSMC_NO_MFMA_SAMPLER") != nullptr;       // (A/B switch for measurements)
+    const bool split16 = d == 16 && model->kind == QSMC_MODEL_TOMOGRAPHY && !no_mfma16 && use_buckets(chunks64, n_out);
+    if (!split16 && (stages != RS_STAGE_ALL || canon.kind != 0)) return QSMC_ERR_UNSUPPORTED;
+    if (canon.kind != 0 && pl.n_dest != 0) return QSMC_ERR_UNSUPPORTED;
     const bool prepared = h->prep.valid && h->prep.w == w && h->prep.n_in == n_in && h->prep.n_out == n_out &&
                           h->prep.norm == norm && h->prep.seed == seed && h->prep.epoch == epoch &&
                           h->prep.stream == s;
     h->prep.valid = 0;
     int rc = QSMC_OK;
-    if (!prepared) {
+    if (!prepared && (stages & RS_STAGE_ANCESTORS)) {
         rc = resample_prefix(h, w, n_in, norm, n_out, seed, epoch, s, false);
         if (rc) return rc;
     }
@@ -1321,10 +1370,12 @@ static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int3
     const double inv_norm = 1.0 / norm;
     unsigned long long *nf = reinterpret_cast<unsigned long long *>(h->counter);
     unsigned long long *retry_count = nf + 1;
-    rc = ensure_cdf(h, (size_t)n_in);
-    if (rc) return rc;
+    if (!split16) {
+        rc = ensure_cdf(h, (size_t)n_in);
+        if (rc) return rc;
+    }
     BucketPlan bp;
-    rc = bucket_plan_layout(h, chunks64, n_out, &bp);      // no reallocation: the prefix sized it
+    rc = bucket_plan_layout(h, chunks64, n_out, &bp, split16);      // no reallocation: the prefix sized it
     if (rc) return rc;
     if (!bp.bucketed) {
         // small or very large clouds: materialise the CDF and search it directly
@@ -1333,6 +1384,42 @@ static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int3
         hipLaunchKernelGGL(k_resample_philox, dim3(grid_for(n_out, QSMC_BLOCK)), dim3(QSMC_BLOCK), 0, s,
                            model->kind, d, model->min_freq, postselect, x_in, ldx_in, n_in, h->cdf_scratch, lw, n_out,
                            k0, k1, ep, maxiter, x_out, pl, nf);
+    } else if (split16) {
+        // 2-qubit tomography: ancestors (needs the weights and the plan only), then the kicks on the f64 matrix cores
+        // with the first pass of canonicalize on the way out; tomography has no validity constraint: no redraws
+        const int chunks = bp.chunks;
+        if (stages & RS_STAGE_ANCESTORS) {
+            hipEvent_t a0 = nullptr, a1 = nullptr;
+            prof_events(h, QSMC_PROF_ANCESTORS, &a0, &a1);
+            hipExtLaunchKernelGGL((k_bucket_anc16<512>), dim3(bp.max_items), dim3(512), 0, s, a0, a1, 0, n_in, w, inv_norm,
+                                  offsets, chunks, bp.slot_off, bp.item_off, bp.item_chunk, k0, k1, ep, bp.anc, bp.cap);
+        }
+        if (stages & RS_STAGE_KICK) {
+            hipEvent_t pe0 = nullptr, pe1 = nullptr;
+            prof_events(h, QSMC_PROF_SAMPLE, &pe0, &pe1);
+            const int64_t n_ranges = (n_out + KICK16_PER_BLOCK - 1) / KICK16_PER_BLOCK;
+            const unsigned kgrid = (unsigned)(((n_ranges + 7) / 8) * 8);
+            unsigned int *ccount = bp.clist, *clist = bp.clist + 4;
+            if (canon.kind) HIP_TRY(h, hipMemsetAsync(ccount, 0, sizeof(unsigned int), s));
+#define LAUNCH_K16(C)                                                                                                 \
+    hipExtLaunchKernelGGL((k_bucket_kick16<C>), dim3(kgrid), dim3(KICK16_BT), 0, s, pe0, pe1, 0, x_in, ldx_in, bp.anc,  \
+                          n_out, lw, k0, k1, ep, x_out, pl, canon.basis, canon.allow_sub, clist, ccount)
+            if (canon.kind == 1) LAUNCH_K16(1);
+            else if (canon.kind == 2) LAUNCH_K16(2);
+            else LAUNCH_K16(0);
+#undef LAUNCH_K16
+            if (canon.kind) {
+                hipEvent_t l0 = nullptr, l1 = nullptr;
+                prof_events(h, QSMC_PROF_CANON_LIST, &l0, &l1);
+                const int lgrid = grid_for(n_out, QSMC_BLOCK);
+                if (canon.kind == 1)
+                    hipExtLaunchKernelGGL((k_tomo_canon_list<4, TomoPauli2>), dim3(lgrid), dim3(QSMC_BLOCK), 0, s, l0, l1, 0,
+                                          TomoPauli2{}, x_out, pl.ld_m, canon.allow_sub, clist, ccount);
+                else
+                    hipExtLaunchKernelGGL((k_tomo_canon_list<4, TomoDense<4>>), dim3(lgrid), dim3(QSMC_BLOCK), 0, s, l0, l1, 0,
+                                          TomoDense<4>{canon.basis}, x_out, pl.ld_m, canon.allow_sub, clist, ccount);
+            }
+        }
     } else {
         const int chunks = bp.chunks;
         // 512-thread workgroups, CDF chunk + guide in LDS (40 KB -> 3 resident workgroups per CU, so one
@@ -1345,13 +1432,6 @@ static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int3
                        model->min_freq, postselect, x_in, ldx_in, n_in, w, inv_norm, offsets,                       \
                        chunks, bp.slot_off, bp.item_off, bp.item_chunk, lw, k0, k1, ep,                             \
                        maxiter, x_out, pl, nf, bp.retry_list, retry_count, bp.cap)
-        static const bool no_mfma16 = getenv("QSMC_NO_MFMA_SAMPLER") != nullptr;       // (A/B switch for measurements)
-        if (d == 16 && model->kind == QSMC_MODEL_TOMOGRAPHY && !no_mfma16) {
-            // 2-qubit tomography: the kick matrix product on the f64 matrix cores, 16 outputs per wave trip
-            hipExtLaunchKernelGGL((k_bucket_sample16<512>), dim3(bp.max_items), dim3(512), 0, s, pe0, pe1, 0, x_in, ldx_in,
-                                  n_in, w, inv_norm, offsets, chunks, bp.slot_off, bp.item_off, bp.item_chunk, lw, k0, k1,
-                                  ep, x_out, pl, bp.cap);
-        } else
         switch (d) {
             // d <= 2: the single-pass kernel; d >= 3: ancestors first, kicked in ascending order (coalesced gathers)
             case 1: LAUNCH_B(k_bucket_sample, 1, 512); break;
@@ -1433,6 +1513,19 @@ int qsmc_lw_resample_prepare(qsmc_handle_t h, const double *w, int64_t n_in, dou
     return QSMC_OK;
 }
 
+int qsmc_lw_fuse_canonicalize(qsmc_handle_t h, const double *basis, int32_t dim, int32_t basis_kind,
+                              int32_t allow_subnormalized) {
+    if (!h) return QSMC_ERR_INVALID;
+    h->canon_next.kind = 0;
+    if (dim != 4) return QSMC_ERR_UNSUPPORTED;                       // (the fused pass exists for 2 qubits, d = 16)
+    if (basis_kind != QSMC_BASIS_DENSE && basis_kind != QSMC_BASIS_PAULI) return QSMC_ERR_INVALID;
+    if (basis_kind == QSMC_BASIS_DENSE && !basis) return QSMC_ERR_INVALID;
+    h->canon_next.kind = basis_kind == QSMC_BASIS_PAULI ? 1 : 2;
+    h->canon_next.allow_sub = allow_subnormalized ? 1 : 0;
+    h->canon_next.basis = basis_kind == QSMC_BASIS_PAULI ? nullptr : basis;
+    return QSMC_OK;
+}
+
 int qsmc_lw_resample_philox(qsmc_handle_t h, const qsmc_model_t *model, int32_t postselect,
                             const double *x_in, int64_t ldx_in, int64_t n_in, int32_t d, const double *w,
                             double norm, double a, const double *mean, const double *S, int64_t n_out,
@@ -1442,8 +1535,24 @@ int qsmc_lw_resample_philox(qsmc_handle_t h, const qsmc_model_t *model, int32_t 
     memset(&pl, 0, sizeof(pl));
     pl.ld_m = ldx_out;
     pl.ld_s = 1;
+    CanonSpec canon{0, 0, nullptr};
+    if (h && h->canon_next.kind) {                                  // one-shot (qsmc_lw_fuse_canonicalize)
+        canon = CanonSpec{h->canon_next.kind, h->canon_next.allow_sub, h->canon_next.basis};
+        h->canon_next.kind = 0;
+    }
     return resample_philox_impl(h, model, postselect, x_in, ldx_in, n_in, d, w, norm, a, mean, S, n_out, seed,
-                                epoch, maxiter, x_out, pl, n_failed_host, stream);
+                                epoch, maxiter, x_out, pl, n_failed_host, stream, canon);
+}
+
+// out[0..K) (device) -> pinned host block, then the completion word: the d > 4 moments of a resample queued by qsmc_step
+__global__ void k_publish_big(const double *__restrict__ src, int K, double *__restrict__ mapped, unsigned long long *flag,
+                              unsigned long long seq) {
+    for (int k = threadIdx.x; k < K; k += blockDim.x) mapped[k] = src[k];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence_system();
+        *reinterpret_cast<volatile unsigned long long *>(flag) = seq;
+    }
 }
 
 int qsmc_step_stats(qsmc_handle_t h, int64_t *n_queued, int64_t *n_adopted) {
@@ -1507,27 +1616,84 @@ int qsmc_step(qsmc_handle_t h, qsmc_step_t *st, const qsmc_model_t *model, const
     if (!(ess < st->ess_below)) return QSMC_OK;
     st->status |= QSMC_STEP_RESAMPLE_DUE;
     static const bool no_queue = getenv("QSMC_NO_STEP_RESAMPLE") != nullptr;              // (A/B switch)
-    if (!st->lw.enabled || !small_d || !st->lw.x_out || st->lw.n_out <= 0 || no_queue) return QSMC_OK;
-    // the caller's resample (resamplers.py:266-300), started from here
-    moments_to_mean_cov(st->moments, d, fixed, st->mean, st->cov);
+    if (!st->lw.enabled || !st->lw.x_out || st->lw.n_out <= 0 || no_queue) return QSMC_OK;
+    const CanonSpec canon{st->lw.canon_kind, st->lw.canon_allow_sub, st->lw.canon_basis};
+    hipStream_t s = (hipStream_t)stream;
+    OutPlace pl;
+    memset(&pl, 0, sizeof(pl));
+    pl.ld_m = st->lw.ldx_out;
+    pl.ld_s = 1;
+    if (small_d) {
+        if (canon.kind) return QSMC_OK;
+        // the caller's resample (resamplers.py:266-300), started from here
+        moments_to_mean_cov(st->moments, d, fixed, st->mean, st->cov);
+    } else {
+        // d = 16 tomography on the split sampler: moments (their own pass) and the ancestors are queued now; the host
+        // forms S while the ancestor kernel runs and queues the kicks behind it
+        static const bool no_mfma16 = getenv("QSMC_NO_MFMA_SAMPLER") != nullptr;
+        const int64_t chunks64 = (st->n + BUCKET_CHUNK - 1) / BUCKET_CHUNK;
+        if (d != 16 || model->kind != QSMC_MODEL_TOMOGRAPHY || no_mfma16 || !use_buckets(chunks64, st->lw.n_out))
+            return QSMC_OK;
+        const int gridm = grid_for(st->n, QSMC_BLOCK) < 1024 ? grid_for(st->n, QSMC_BLOCK) : 1024;
+        rc = ensure_partials(h, (size_t)gridm * MFMA_MOM_K);
+        if (rc) return rc;
+        rc = ensure_scratch(h, 256 + MFMA_MOM_K);
+        if (rc) return rc;
+        hipEvent_t m0 = nullptr, m1 = nullptr;
+        prof_events(h, QSMC_PROF_MOMENTS, &m0, &m1);
+        hipExtLaunchKernelGGL(k_moments_mfma, dim3(gridm), dim3(QSMC_BLOCK), 0, s, m0, m1, 0, st->x, st->ldx, st->n, d,
+                              st->w, fixed, h->partials);
+        double *full = h->scratch + 256;
+        hipLaunchKernelGGL(k_sum_partials, dim3((MFMA_MOM_K + QSMC_WAVES_PER_BLOCK - 1) / QSMC_WAVES_PER_BLOCK),
+                           dim3(QSMC_BLOCK), 0, s, h->partials, gridm, MFMA_MOM_K, full);
+        const unsigned long long seq = ++h->seq;
+        hipLaunchKernelGGL(k_publish_big, dim3(1), dim3(QSMC_BLOCK), 0, s, full, MFMA_MOM_K, h->mapped_big_dev, h->flag_dev, seq);
+        HIP_TRY(h, hipGetLastError());
+        h->ts.armed = h->ts.gen;                               // these weights ARE update number ts.gen's output
+        rc = resample_philox_impl(h, model, st->lw.postselect, st->x, st->ldx, st->n, d, st->w, fixed, st->lw.a, st->mean,
+                                  st->S, st->lw.n_out, st->lw.seed, st->lw.epoch, st->lw.maxiter, st->lw.x_out, pl,
+                                  nullptr, stream, canon, RS_STAGE_ANCESTORS);
+        if (rc) return rc;
+        rc = wait_reduction(h, s);
+        if (rc) return rc;
+        // qsmc_moments' packing of the same block: [sum w, sum w x (d), upper(sum w x x^T)], weights already / norm
+        const double *hf = h->mapped_big;
+        st->moments_big[0] = hf[272];
+        int k = 1 + d;
+        for (int m = 0; m < d; ++m) {
+            st->moments_big[1 + m] = hf[256 + m];
+            for (int q = m; q < d; ++q) st->moments_big[k++] = hf[m * 16 + q];
+        }
+        for (int m = 0; m < d; ++m) st->mean[m] = st->moments_big[1 + m];
+        k = 1 + d;
+        for (int m = 0; m < d; ++m)
+            for (int q = m; q < d; ++q) {
+                const double e2 = st->moments_big[k++];
+                st->cov[m * d + q] = e2 - st->mean[m] * st->mean[q];
+                st->cov[q * d + m] = e2 - st->mean[q] * st->mean[m];
+            }
+    }
     bool finite = true, any = false;
     for (int k = 0; k < d * d; ++k) {
         finite = finite && std::isfinite(st->cov[k]);
         any = any || st->cov[k] != 0.0;
     }
     if (!finite) return QSMC_OK;                               // (the caller's own assertion fires)
-    double cov_used[16];
+    double cov_used[QSMC_MAX_D * QSMC_MAX_D];
     for (int k = 0; k < d * d; ++k) cov_used[k] = any ? st->cov[k] : ((k / d == k % d) ? st->lw.zero_cov_comp : 0.0);
     rc = qsmc_sqrtm_psd(cov_used, d, st->lw.h, st->S, &st->S_err);
     if (rc) return rc;
     if (!std::isfinite(st->S_err)) return QSMC_OK;             // (ResamplerError is the caller's to raise)
-    h->ts.armed = h->ts.gen;                                   // these weights ARE update number ts.gen's output
-    rc = qsmc_lw_resample_philox(h, model, st->lw.postselect, st->x, st->ldx, st->n, d, st->w, fixed, st->lw.a, st->mean,
-                                 st->S, st->lw.n_out, st->lw.seed, st->lw.epoch, st->lw.maxiter, st->lw.x_out,
-                                 st->lw.ldx_out, nullptr, stream);
+    if (small_d) h->ts.armed = h->ts.gen;                      // these weights ARE update number ts.gen's output
+    rc = resample_philox_impl(h, model, st->lw.postselect, st->x, st->ldx, st->n, d, st->w, fixed, st->lw.a, st->mean,
+                              st->S, st->lw.n_out, st->lw.seed, st->lw.epoch, st->lw.maxiter, st->lw.x_out, pl, nullptr,
+                              stream, canon, small_d ? RS_STAGE_ALL : RS_STAGE_KICK);
     if (rc) return rc;
     auto &q = h->rsq;
     q.valid = 1;
+    q.canon_kind = canon.kind;
+    q.canon_allow_sub = canon.allow_sub;
+    q.canon_basis = canon.basis;
     q.model = *model;
     q.postselect = st->lw.postselect;
     q.d = d;
@@ -1545,7 +1711,7 @@ int qsmc_step(qsmc_handle_t h, qsmc_step_t *st, const qsmc_model_t *model, const
     q.seed = st->lw.seed;
     q.epoch = st->lw.epoch;
     q.x_out = st->lw.x_out;
-    q.stream = (hipStream_t)stream;
+    q.stream = s;
     ++q.n_queued;
     st->status |= QSMC_STEP_RESAMPLE_QUEUED;
     return QSMC_OK;
@@ -1612,7 +1778,7 @@ int qsmc_prior_uniform_philox(qsmc_handle_t h, const qsmc_model_t *model, int32_
                               const double *lo, const double *hi, int32_t d, int64_t n, uint64_t seed,
                               uint64_t epoch, int32_t maxiter, double *x_out, int64_t ldx_out,
                               int64_t *n_failed_host, qsmc_stream_t stream) {
-    if (h) { h->prep.valid = 0; h->rsq.valid = 0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
+    if (h) { h->prep.valid = 0; h->rsq.valid = 0; h->canon_next.kind = 0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
     if (!h || !model || !lo || !hi || !x_out || n <= 0 || d < 1 || d > QSMC_MAX_D || maxiter < 1)
         return QSMC_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
@@ -1659,7 +1825,7 @@ int qsmc_random_walk(qsmc_handle_t h, double *x, int64_t ldx, int64_t n, int32_t
 
 int qsmc_tomo_canonicalize2(qsmc_handle_t h, const double *basis, int32_t dim, int32_t basis_kind, double *x, int64_t ldx,
                             int64_t n, int32_t allow_subnormalized, qsmc_stream_t stream) {
-    if (h) { h->prep.valid = 0; h->rsq.valid = 0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
+    if (h) { h->prep.valid = 0; h->rsq.valid = 0; h->canon_next.kind = 0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
     if (!h || !x || n < 0) return QSMC_ERR_INVALID;
     if (basis_kind != QSMC_BASIS_DENSE && basis_kind != QSMC_BASIS_PAULI) return QSMC_ERR_INVALID;
     if (basis_kind == QSMC_BASIS_DENSE && !basis) return QSMC_ERR_INVALID;

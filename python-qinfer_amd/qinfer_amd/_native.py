@@ -37,7 +37,8 @@ class StepLW(C.Structure):
     _fields_ = [("enabled", C.c_int32), ("prefix", C.c_int32), ("postselect", C.c_int32), ("maxiter", C.c_int32),
                 ("a", C.c_double), ("h", C.c_double), ("zero_cov_comp", C.c_double),
                 ("seed", C.c_uint64), ("epoch", C.c_uint64), ("n_out", C.c_int64),
-                ("x_out", C.c_void_p), ("ldx_out", C.c_int64)]
+                ("x_out", C.c_void_p), ("ldx_out", C.c_int64),
+                ("canon_kind", C.c_int32), ("canon_allow_sub", C.c_int32), ("canon_basis", C.c_void_p)]
 
 
 class Step(C.Structure):
@@ -54,7 +55,8 @@ class Step(C.Structure):
                 ("n_ess", C.c_double),
                 ("moments", C.c_double * 14),
                 ("mean", C.c_double * QSMC_MAX_D), ("cov", C.c_double * (QSMC_MAX_D * QSMC_MAX_D)),
-                ("S", C.c_double * (QSMC_MAX_D * QSMC_MAX_D)), ("S_err", C.c_double)]
+                ("S", C.c_double * (QSMC_MAX_D * QSMC_MAX_D)), ("S_err", C.c_double),
+                ("moments_big", C.c_double * (1 + QSMC_MAX_D + QSMC_MAX_D * (QSMC_MAX_D + 1) // 2))]
 
 
 STEP_GUARD, STEP_SMALL_ESS, STEP_RESAMPLE_DUE, STEP_RESAMPLE_QUEUED = 1, 2, 4, 8
@@ -80,6 +82,7 @@ SIGNATURES = {
                           _I64, _P, C.POINTER(UpdateStats), C.POINTER(_F64), _P],
     "qsmc_step": [_P, C.POINTER(Step), C.POINTER(ModelDesc), C.POINTER(ExpParam), _I64, _P],
     "qsmc_step_stats": [_P, C.POINTER(_I64), C.POINTER(_I64)],
+    "qsmc_lw_fuse_canonicalize": [_P, _P, _I32, _I32, _I32],
     "qsmc_update_multi": [_P, C.POINTER(ModelDesc), _P, _I64, _I64, _P, _P, _F64, C.POINTER(ExpParam),
                           C.POINTER(_I64), _I32, C.POINTER(UpdateStats), C.POINTER(_F64), _P],
     "qsmc_hypothetical_sums": [_P, C.POINTER(ModelDesc), _P, _I64, _I64, _P, _F64, C.POINTER(ExpParam),

@@ -386,11 +386,18 @@ class Engine:
         return valid
 
     def lw_resample_philox(self, desc, postselect, x_in, w, norm, a, mean, S, n_out, seed, epoch, maxiter,
-                           sync=True, out=None):
+                           sync=True, out=None, canon=None):
         """Returns (x_out, n_failed); with sync=False n_failed is None and the count is available
         from `last_resample_failed()` after the next stream synchronisation.  `out`: a (d, n_out) device
-        view to fill (row stride arbitrary) instead of a fresh tensor; x_in may be a column slice of a cloud."""
+        view to fill (row stride arbitrary) instead of a fresh tensor; x_in may be a column slice of a cloud.
+        `canon` = (kind, basis_dev, allow_subnormalized) from TomographyModel._native_canonicalize_fused: the new cloud
+        comes out canonicalized (qsmc_lw_fuse_canonicalize)."""
         d = x_in.shape[0]
+        if canon is not None:
+            kind, basis_dev, allow_sub = canon
+            self._chk(self.lib.qsmc_lw_fuse_canonicalize(self.h, self._p(basis_dev) if basis_dev is not None else None, 4,
+                                                         1 if kind == 1 else 0, int(bool(allow_sub))),
+                      "qsmc_lw_fuse_canonicalize")
         x_out = self.empty(d, n_out) if out is None else out
         mean = np.ascontiguousarray(mean, dtype=np.float64)
         S = np.ascontiguousarray(S, dtype=np.float64)
@@ -402,6 +409,16 @@ class Engine:
             self._p(x_out), x_out.stride(0), C.byref(failed) if sync else None, self.stream()),
             "qsmc_lw_resample_philox")
         return x_out, (failed.value if sync else None)
+
+    @staticmethod
+    def fused_canon_applies(d, n_in, n_out):
+        """Does a resample of this shape take the split d = 16 sampler (the one that can fold canonicalize in)?  The
+        library's own rule (use_buckets in qsmc_kernels.hip): the bucketed path, i.e. at most 8192 chunks of 4096
+        source particles and at least 4 chunks' worth of outputs."""
+        import os
+        chunks = -(-n_in // 4096)
+        return (d == 16 and chunks <= 8192 and 4 * 4096 <= n_out < 2 ** 32 and not os.environ.get("QSMC_DIRECT_RESAMPLE")
+                and not os.environ.get("QSMC_NO_MFMA_SAMPLER"))
 
     def random_walk(self, x, scale, z=None, seed=0, epoch=0):
         """x[m, :] += scale[m] * z in place (rows with scale 0 untouched); z: device (n_rw, n) steps, or None

@@ -114,6 +114,7 @@ class LiuWestResampler(Resampler):
             desc = model._native_desc() if native else None
         x_in, norm = particle_dist._x, particle_dist._norm
 
+        canon = None
         if self._device_rng and native:
             # straight from the weights: the CDF is scanned chunk-wise inside the sampler, never in HBM
             self._epoch += 1
@@ -128,9 +129,14 @@ class LiuWestResampler(Resampler):
             spare = getattr(particle_dist, "_x_spare", None)
             if spare is not None and (tuple(spare.shape) != (d, n_particles) or spare is x_in):
                 spare = None
+            # an updater that canonicalizes its cloud after every resample (smc.py:529) may have it done by the
+            # resample's own kernels (2-qubit tomography): the returned cloud is marked so that it is not done twice
+            canon = getattr(particle_dist, "_fused_canon", None)
+            if canon is not None and not eng.fused_canon_applies(d, particle_dist.n_particles, n_particles):
+                canon = None
             x_new, n_failed = eng.lw_resample_philox(desc, self._postselect, x_in, particle_dist._w, norm, a,
                                                      mean, S, n_particles, self._seed, self._epoch,
-                                                     self._maxiter, sync=not defer, out=spare)
+                                                     self._maxiter, sync=not defer, out=spare, canon=canon)
             if defer:                  # stay asynchronous: the count is read at the caller's next sync
                 self._pending_failed = eng
                 n_failed = 0
@@ -143,8 +149,9 @@ class LiuWestResampler(Resampler):
 
         # uniform weights np.ones(n) / n (resamplers.py:390), held implicitly: w = None means all-ones
         # with normaliser n, so no fill pass is spent and the next update reads 8 B/particle less
-        return ParticleDistribution._from_device(eng, x_new, None, norm=float(n_particles),
-                                                 sumsq=float(n_particles))
+        new = ParticleDistribution._from_device(eng, x_new, None, norm=float(n_particles), sumsq=float(n_particles))
+        new._canonicalized = bool(self._device_rng and native and canon is not None)
+        return new
 
     @staticmethod
     def _arm_update_sums(particle_dist):

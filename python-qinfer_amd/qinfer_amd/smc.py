@@ -28,6 +28,7 @@ __all__ = ["SMCUpdater"]
 
 _EPS = float(np.spacing(1))
 _NO_STEP = bool(__import__("os").environ.get("QSMC_NO_STEP"))      # (A/B switch: the round-2 per-datum path in Python)
+_NO_FUSED_CANON = bool(__import__("os").environ.get("QSMC_NO_FUSED_CANON"))      # (A/B switch)
 _U64 = 2 ** 64 - 1
 
 
@@ -108,6 +109,10 @@ class SMCUpdater(ParticleDistribution):
             self._ep_fill = getattr(model, "_native_fill_expparam", None)
         self._step_synced = False
         self._x_spare = None
+        # canonicalize after a resample (smc.py:529) done by the resample's own kernels where the library can
+        fc = getattr(model, "_native_canonicalize_fused", None)
+        self._fused_canon = (fc(self._eng) if (fc is not None and self._native and self._canonicalize and comm is None
+                                               and not _NO_FUSED_CANON) else None)
         self.reset(n_particles)
 
     # ------------------------------------------------------------------ bookkeeping properties
@@ -339,8 +344,12 @@ class SMCUpdater(ParticleDistribution):
             # the resample itself is queued from C only when nothing sits between this update and it: the stock
             # resampler class, a cloud that does not move between data, moments that came with the update (d <= 4),
             # same-size output (the spare buffer ping-pongs with the cloud), no divergence tracking
+            fc = self._fused_canon
+            if fc is not None and not self._eng.fused_canon_applies(d, n, key[1]):
+                fc = None
+            big_ok = d == 16 and self._eng.fused_canon_applies(d, n, key[1])       # (the split d = 16 sampler)
             if (type(r) is LiuWestResampler and self._timestep_identity and key[1] == n
-                    and getattr(self.model, "_native_timestep", None) is None and d <= 4
+                    and getattr(self.model, "_native_timestep", None) is None and (d <= 4 or big_ok)
                     and self._resampling_divergences is None):
                 if self._x_spare is None or self._x_spare.shape != x.shape:
                     self._x_spare = self._eng.empty(d, n)
@@ -348,6 +357,10 @@ class SMCUpdater(ParticleDistribution):
                 lw.postselect, lw.maxiter = int(bool(r._postselect)), int(r._maxiter)
                 lw.a, lw.h, lw.zero_cov_comp = float(r._a), float(r._h), float(r._zero_cov_comp)
                 lw.x_out, lw.ldx_out = self._x_spare.data_ptr(), self._x_spare.stride(0)
+                lw.canon_kind = 0
+                if fc is not None and d == 16:
+                    lw.canon_kind, lw.canon_allow_sub = fc[0], int(bool(fc[2]))
+                    lw.canon_basis = fc[1].data_ptr() if fc[1] is not None else None
         self._step_key = (r, self.resample_thresh)
         self._step_synced = True
 
@@ -399,7 +412,13 @@ class SMCUpdater(ParticleDistribution):
         if not self._timestep_identity or getattr(self.model, "_native_timestep", None) is not None:
             self._timestep(expparams)
         if status & (_native.STEP_SMALL_ESS | _native.STEP_RESAMPLE_DUE):
-            self._maybe_resample(np.float64(st.n_ess), bool(status & _native.STEP_RESAMPLE_QUEUED))
+            queued = bool(status & _native.STEP_RESAMPLE_QUEUED)
+            if queued and self._x.shape[0] > 4:
+                # the moments pass ran inside the call (its result drove the queued resample): what eng.moments returns
+                d = self._x.shape[0]
+                mb = np.array(st.moments_big[:1 + d + d * (d + 1) // 2])
+                self._moments_cache = (float(mb[0]), mb[1:1 + d].copy(), eng._unpack_upper(mb[1 + d:], d))
+            self._maybe_resample(np.float64(st.n_ess), queued)
 
     def update(self, outcome, expparams, check_for_resample=True):
         """One Bayes step (smc.py:388-457)."""
@@ -778,7 +797,7 @@ class SMCUpdater(ParticleDistribution):
             self._set_host(new.particle_locations, new.particle_weights)
         self._w_alt = None
         self._invalidate()
-        if self._canonicalize:
+        if self._canonicalize and not getattr(new, "_canonicalized", False):
             self._canonicalize_device()
         try:
             self.model.clear_cache()

@@ -179,14 +179,27 @@ class TomographyModel(NativeModelMixin, FiniteOutcomeModel):
         take `canonicalize` on the host."""
         return self._dim in (2, 4)
 
+    def _pauli(self):
+        if self._is_pauli is None:               # is this the reference's Pauli basis, element for element?
+            nq = int(round(np.log2(self._dim)))
+            self._is_pauli = bool(2 ** nq == self._dim and np.array_equal(self._basis.data, pauli_basis(nq).data))
+        return self._is_pauli
+
     def _native_canonicalize_(self, eng, x):
         """In-place canonicalize of a device SoA cloud."""
         if not self._native_canonicalize_ok():
             raise NotImplementedError("native canonicalize supports dim 2 and 4 (1 or 2 qubits)")
-        if self._is_pauli is None:               # is this the reference's Pauli basis, element for element?
-            nq = int(round(np.log2(self._dim)))
-            self._is_pauli = bool(2 ** nq == self._dim and np.array_equal(self._basis.data, pauli_basis(nq).data))
-        eng.tomo_canonicalize(self._device_basis(eng), self._dim, x, self._allow_subnormalized, pauli=self._is_pauli)
+        eng.tomo_canonicalize(self._device_basis(eng), self._dim, x, self._allow_subnormalized, pauli=self._pauli())
+
+    def _native_canonicalize_fused(self, eng):
+        """(kind, basis device tensor or None, allow_subnormalized) if the device-RNG Liu-West resample can fold
+        `canonicalize` of its output into its own kernels (qsmc_lw_fuse_canonicalize: 2 qubits), else None.
+        kind 1: the reference's Pauli basis (sparse contraction), 2: a dense basis."""
+        if self._dim != 4:
+            return None
+        if self._pauli():
+            return (1, None, self._allow_subnormalized)
+        return (2, self._device_basis(eng), self._allow_subnormalized)
 
     # NumPy contract
     def are_models_valid(self, modelparams):

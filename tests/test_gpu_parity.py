@@ -1564,13 +1564,19 @@ def test_step_path_same_particles(qi, monkeypatch):
     np.random.seed(3)
     gin = qi.GinibreDistribution(basis).sample(60_000)
     grw = qi.GaussianRandomWalkModel(qi.SimplePrecessionModel(), fixed_covariance=np.array([1e-6]))
+    # the same states in the Gell-Mann basis (a dense-basis model: the generic contraction in the fused classify)
+    gm = qi.tomography.gell_mann_basis(4)
+    rho = np.einsum('na,aij->nij', gin, basis.data)
+    gin_gm = np.real(np.einsum('nij,aji->na', rho, gm.data))
     cases = [
         ("precession", lambda: qi.SimplePrecessionModel(), lambda m: qi.UniformDistribution([0, 1]), 300_000, prec, True),
         ("binomial", lambda: qi.BinomialModel(qi.SimplePrecessionModel()), lambda m: qi.UniformDistribution([0, 1]),
          200_000, binom, True),
         ("rb", lambda: qi.RandomizedBenchmarkingModel(), lambda m: qi.PostselectedDistribution(
             qi.UniformDistribution([[0.8, 1], [0, 1], [0, 1]]), m), 200_000, rb, True),
-        ("tomography", lambda: qi.TomographyModel(basis), lambda m: fixed_prior(qi, gin), 60_000, tomo, None),
+        ("tomography", lambda: qi.TomographyModel(basis), lambda m: fixed_prior(qi, gin), 60_000, tomo, True),
+        ("tomography, dense basis", lambda: qi.TomographyModel(qi.tomography.gell_mann_basis(4)),
+         lambda m: fixed_prior(qi, gin_gm), 60_000, tomo, True),
         ("random walk", lambda: qi.GaussianRandomWalkModel(qi.SimplePrecessionModel(), fixed_covariance=np.array([1e-6])),
          lambda m: qi.UniformDistribution([0, 1]), 200_000, prec[:40], False),
     ]
@@ -1578,6 +1584,7 @@ def test_step_path_same_particles(qi, monkeypatch):
 
     def run(make_model, make_prior, n, data, step):
         monkeypatch.setattr(smc_mod, "_NO_STEP", not step)
+        monkeypatch.setattr(smc_mod, "_NO_FUSED_CANON", not step)       # (round-2 path: canonicalize as its own two passes)
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             m = make_model()
