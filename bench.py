@@ -20,6 +20,8 @@ One JSON line on rank 0 with `value` = N_total * K / wall, plus
   roofline_beyond_l3  the same kernel at N = 1e8 (2.4 GB working set: past the 256 MB Infinity Cache);
   other_configs       BASELINE configs 3, 4 (per-GPU share) and 5 (per-GPU share) with their SURVEY 8(d) schedules:
                       p-u/s, and each one's kernels against their 16 + 8 d bytes / particle;
+  other_paths         SURVEY 8(f): `batch_update` at resample_interval 5 and 8 and one `bayes_risk` call over 26 outcomes,
+                      each with its kernel (k_update_multi, k_hyp_sums) against its algorithmic bytes;
   cpu_baseline        the C / OpenMP restatement of the reference (oracle/cpu_port.c, pinned to the reference's golden
                       trajectories by tests/test_cpu_port.py) on this box's host cores, 1 thread and all cores, on the
                       same cloud size and the first data of the same schedule;
@@ -43,7 +45,7 @@ sys.path.insert(0, os.path.join(ROOT, "python-qinfer_amd"))
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 N_SCHEDULE = 200
 TAGS = {0: "update", 1: "sample", 2: "update_ones", 3: "canon_classify", 4: "canon_list", 5: "moments", 6: "counts",
-        8: "ancestors"}
+        8: "ancestors", 10: "update_multi", 11: "hyp_sums"}
 
 
 def schedule():
@@ -289,6 +291,76 @@ def run_other_config(qi, eng, torch, spec, warmup):
     return out
 
 
+def other_paths(qi, eng, torch, n=10_000_000):
+    """SURVEY 8(f) rows 1-2 on the headline cloud size: `batch_update` (smc.py:459-487; data between two n_ess tests
+    applied in ONE pass over the cloud, k_update_multi) at resample_interval 5 and 8, and one `bayes_risk` call
+    (smc.py:553-611) over the 26 outcomes of a Binomial(n_meas = 25) experiment (k_hyp_sums: every outcome's
+    hypothetical normalisation and moments in one pass, nothing n_outcomes x N stored).  Kernel times from HIP events."""
+    out = {}
+    ts, outcomes = schedule()
+    for interval in (5, 8):
+        upd = qi.SMCUpdater(qi.SimplePrecessionModel(), n, qi.UniformDistribution([0, 1]), device_rng=True, seed=0)
+        upd.batch_update(outcomes[:40], ts[:40], resample_interval=interval)      # untimed: allocator, first launches
+        upd.reset()
+        upd._resample_count = 0
+        torch.cuda.synchronize()
+        eng.set_profiling(1)
+        upd.batch_update(outcomes, ts, resample_interval=interval)
+        torch.cuda.synchronize()
+        ms, tags = eng.profile_read()
+        eng.set_profiling(0)
+        upd.reset()
+        rc0 = upd.resample_count
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        upd.batch_update(outcomes, ts, resample_interval=interval)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        kt = kernel_table(ms, tags)
+        e = {"workload": "SimplePrecessionModel batch_update, %.0e particles, the %d data of the headline schedule, "
+                         "resample_interval=%d" % (n, N_SCHEDULE, interval),
+             "value": n * N_SCHEDULE / wall, "unit": "particle-updates/s", "ms_per_datum": wall / N_SCHEDULE * 1e3,
+             "resamples": upd.resample_count - rc0, "posterior_mean": float(upd.est_mean()[0])}
+        if "update_multi" in kt:
+            # one window = one pass: read x (8 d) and w (8), write w (8), whatever the number of data in it
+            e["window_kernel"] = frac_entry("k_update_multi<PRECESSION>", kt["update_multi"]["avg_us"], 24.0 * n,
+                                            kt["update_multi"]["launches"],
+                                            {"bytes_per_particle_per_window": 24, "data_per_window": interval if interval <= 8 else 8,
+                                             "note": "VALU-bound: up to 8 likelihoods per particle per pass"})
+        out["batch_update_interval_%d" % interval] = e
+        del upd
+        torch.cuda.empty_cache()
+    m = qi.BinomialModel(qi.SimplePrecessionModel())
+    upd = qi.SMCUpdater(m, n, qi.UniformDistribution([0, 1]), device_rng=True, seed=0)
+    ep = np.empty((1,), dtype=m.expparams_dtype)
+    ep['x'], ep['n_meas'] = 7.0, 25
+    upd.update(11, ep)                                       # a non-trivial posterior to design against
+    design = np.empty((4,), dtype=m.expparams_dtype)
+    design['x'], design['n_meas'] = [3.0, 9.0, 14.0, 21.0], 25
+    upd.bayes_risk(design[:1])
+    torch.cuda.synchronize()
+    eng.set_profiling(1)
+    t0 = time.perf_counter()
+    risk = upd.bayes_risk(design)
+    wall = time.perf_counter() - t0
+    ms, tags = eng.profile_read()
+    eng.set_profiling(0)
+    kt = kernel_table(ms, tags)
+    e = {"workload": "bayes_risk of 4 hypothetical Binomial(SimplePrecession, n_meas=25) experiments (26 outcomes each), "
+                     "%.0e particles" % n,
+         "ms_per_experiment": wall / 4 * 1e3, "hypothetical_likelihoods_per_s": 26 * 4 * n / wall,
+         "risk": [float(v) for v in risk]}
+    if "hyp_sums" in kt:
+        e["kernel"] = frac_entry("k_hyp_sums<BINOMIAL_PRECESSION,32>", kt["hyp_sums"]["avg_us"], 16.0 * n,
+                                 kt["hyp_sums"]["launches"],
+                                 {"bytes_per_particle": 16, "outcomes_per_pass": 26,
+                                  "note": "VALU-bound: 26 pmf evaluations and 26 x 4 running sums per particle per pass"})
+    out["bayes_risk_26_outcomes"] = e
+    del upd
+    torch.cuda.empty_cache()
+    return out
+
+
 def beyond_l3(qi, eng, torch, n=100_000_000, steps=12):
     """The update kernel on a cloud past the Infinity Cache: N = 1e8, 2.4 GB streamed per launch."""
     upd = qi.SMCUpdater(qi.SimplePrecessionModel(), n, qi.UniformDistribution([0, 1]), device_rng=True, seed=0)
@@ -399,6 +471,11 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    if args.only == "other_paths":     # (SURVEY 8(f) rows alone: profiling runs)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            print(json.dumps({"other_paths": other_paths(qi, eng, torch)}), flush=True)
+        return
     if args.only:                      # one of the other configs alone (what the per-config rocprofv3 passes run)
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
@@ -514,6 +591,10 @@ def main():
                 except Exception as e:  # noqa: BLE001
                     oc[spec["key"]] = {"error": repr(e)}
             extras["other_configs"] = oc
+            try:
+                extras["other_paths"] = other_paths(qi, eng, torch)
+            except Exception as e:  # noqa: BLE001
+                extras["other_paths"] = {"error": repr(e)}
 
     def drain_c_stdio():
         # RCCL prints a version banner through C stdio, which (not a tty) would be flushed at exit -- after the

@@ -113,6 +113,8 @@ int         qsmc_profile_read(qsmc_handle_t h, float *ms_out, int32_t *tags_out,
 #define QSMC_PROF_COUNTS 6         /* the resampler's chunk counts + plan launch (k_bucket_counts) */
 #define QSMC_PROF_COUNTS_SKIPPED 7 /* a speculative k_bucket_counts that left at its gate (qsmc_lw_arm_prefix) */
 #define QSMC_PROF_ANCESTORS 8      /* d = 16 sampler, first half: ancestors of every slot (k_bucket_anc16); tag 1 is its kick kernel */
+#define QSMC_PROF_UPDATE_MULTI 10   /* k_update_multi: up to 8 data in one pass (batch_update's fused windows) */
+#define QSMC_PROF_HYP_SUMS 11       /* k_hyp_sums: one hypothetical experiment, all outcomes (bayes_risk / expected_information_gain) */
 #define QSMC_PROF_NTAGS 16
 
 /* ---- likelihood, contract form (abstract_model.py:444-468 + :666-686; a6-a10) ------------ */

@@ -437,16 +437,19 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_hyp_sums(const double *__restric
         double c1[D > 0 ? D : 1];
 #pragma unroll
         for (int m = 0; m < D; ++m) c1[m] = p[m] - ha.shift[m];
+        HypPre<KIND> pre;                              // what all outcomes of this experiment share (binomial: pr1, its logs)
+        pre.prepare(p, ha.base);
 #pragma unroll
         for (int o = 0; o < NO; ++o) {
             if (o < ha.n_o) {
                 ExpArgs e = ha.base;
                 e.comb = ha.comb[o];
                 e.log_comb = ha.log_comb[o];
-                const double L = model_lik_rt<KIND>(p, e, ha.outcome[o]);
+                double L, logL;
+                pre.eval(p, e, ha.outcome[o], L, logL);
                 const double wl = wi * L;
                 s[o * PER] += wl;
-                s[o * PER + 1] += (L > 0.0) ? wl * fast_log(L) : 0.0;
+                s[o * PER + 1] += (L > 0.0) ? wl * logL : 0.0;
 #pragma unroll
                 for (int m = 0; m < D; ++m) {
                     s[o * PER + 2 + m] += wl * c1[m];

@@ -336,6 +336,51 @@ __host__ __device__ __forceinline__ double model_lik_rt(const double *p, const E
     return e.lik_pow == 0.0 ? L : pow(L, e.lik_pow);
 }
 
+// The experiment-design pass (k_hyp_sums) evaluates MANY outcomes of ONE experiment per particle.  For the binomial
+// models everything but the outcome is shared: pr1 (a cos^2 or an RB survival law), and ln pr1 / ln(1 - pr1), from
+// which ln pmf = ln C + k ln p + (n - k) ln(1 - p) follows with two multiply-adds per outcome.  Round 2 evaluated the
+// full likelihood and a logarithm per outcome: 26 cos^2 and 26 logarithms per particle for a Binomial(25) experiment.
+template <int KIND>
+struct HypPre {                                           // generic: nothing shared
+    __host__ __device__ __forceinline__ void prepare(const double *, const ExpArgs &) {}
+    __host__ __device__ __forceinline__ void eval(const double *p, const ExpArgs &e, int64_t o, double &L, double &logL) const {
+        L = model_lik_rt<KIND>(p, e, o);
+        logL = L > 0.0 ? fast_log(L) : 0.0;
+    }
+};
+struct HypPreBinomial {
+    double pr1, lp, lq;
+    __host__ __device__ __forceinline__ void set(double pr1_) {
+        pr1 = pr1_;
+        lp = pr1_ > 0.0 ? fast_log(pr1_) : 0.0;
+        lq = pr1_ < 1.0 ? fast_log1m(pr1_) : 0.0;
+    }
+    __host__ __device__ __forceinline__ void eval(const double *, const ExpArgs &e, int64_t o, double &L, double &logL) const {
+        const double pmf = binom_pmf(pr1, e, o);
+        L = e.lik_pow == 0.0 ? pmf : pow(pmf, e.lik_pow);
+        const double k = (double)o;
+        // (0 * ln 0 never forms: a zero exponent drops its term, as in binom_pmf's log-space branch)
+        const double lpm = e.log_comb + (k > 0.0 ? k * lp : 0.0) + (e.n_meas - k > 0.0 ? (e.n_meas - k) * lq : 0.0);
+        logL = e.lik_pow == 0.0 ? lpm : e.lik_pow * lpm;
+    }
+};
+template <> struct HypPre<QSMC_MODEL_BINOMIAL_PRECESSION> : HypPreBinomial {
+    __host__ __device__ __forceinline__ void prepare(const double *p, const ExpArgs &e) { set(1.0 - precession_pr0(p[0], e)); }
+};
+template <> struct HypPre<QSMC_MODEL_BINOMIAL_RB> : HypPreBinomial {
+    __host__ __device__ __forceinline__ void prepare(const double *p, const ExpArgs &e) {
+        const double pr0 = 1.0 - (p[1] * rb_pow(p[0], e.m) + p[2]);
+        set(1.0 - pr0);
+    }
+};
+template <> struct HypPre<QSMC_MODEL_BINOMIAL_RB_INTERLEAVED> : HypPreBinomial {
+    __host__ __device__ __forceinline__ void prepare(const double *p, const ExpArgs &e) {
+        const double pe = e.reference ? p[1] : p[0] * p[1];
+        const double pr0 = 1.0 - (p[2] * rb_pow(pe, e.m) + p[3]);
+        set(1.0 - pr0);
+    }
+};
+
 // Runtime-dispatched validity (used by kernels that are not templated on the model).
 __host__ __device__ __forceinline__ bool model_valid(int kind, const double *p, double min_freq) {
     switch (kind) {

@@ -482,7 +482,9 @@ static int hyp_launch(qsmc_ctx *h, const qsmc_model_t *model, const double *x, i
     }
     if (shift) for (int m = 0; m < model->d && m < QSMC_MAX_D; ++m) ha.shift[m] = shift[m];
     const ReduceOut ro = make_reduce(h, true, nullptr);
-    hipLaunchKernelGGL((k_hyp_sums<KIND, NO>), dim3(grid), dim3(QSMC_BLOCK), 0, s, x, ldx, n, w, norm, ha, ro);
+    hipEvent_t he0 = nullptr, he1 = nullptr;
+    prof_events(h, QSMC_PROF_HYP_SUMS, &he0, &he1);
+    hipExtLaunchKernelGGL((k_hyp_sums<KIND, NO>), dim3(grid), dim3(QSMC_BLOCK), 0, s, he0, he1, 0, x, ldx, n, w, norm, ha, ro);
     HIP_TRY(h, hipGetLastError());
     rc = launch_reduce(h, NS, grid, ro, s);
     if (rc) return rc;
@@ -500,6 +502,13 @@ static int hyp_dispatch(qsmc_ctx *h, const qsmc_model_t *model, const double *x,
     constexpr int D = Model<KIND>::D <= 4 ? Model<KIND>::D : 0;
     constexpr int PER = 2 + 2 * D;
     constexpr bool WIDE = PER * 32 <= 128;      // 32-outcome instantiation only where it fits in registers
+    // how many outcomes per pass?  A pass re-reads x and w (16 + 8 d bytes per particle: ~30 us at N = 1e7) and repeats
+    // what the outcomes share; the running sums (PER per outcome) live in registers: 32 outcomes x 4 sums = 256 VGPRs,
+    // one wave per SIMD.  QSMC_HYP_OUTCOMES_PER_PASS = 8 | 32 (measurement switch; default below)
+    static const int per_pass = [] {
+        const char *e = getenv("QSMC_HYP_OUTCOMES_PER_PASS");
+        return e ? atoi(e) : 8;
+    }();
     int done = 0;
     while (done < n_o) {
         const int m = n_o - done;
@@ -508,7 +517,7 @@ static int hyp_dispatch(qsmc_ctx *h, const qsmc_model_t *model, const double *x,
             take = m;
             rc = hyp_launch<KIND, 2>(h, model, x, ldx, n, w, norm, exp, outcomes + done, take, shift,
                                      out_host + (size_t)done * PER, s);
-        } else if (WIDE && m > 8) {
+        } else if (WIDE && m > 8 && per_pass >= 32) {
             take = m < 32 ? m : 32;
             if constexpr (WIDE)
                 rc = hyp_launch<KIND, 32>(h, model, x, ldx, n, w, norm, exp, outcomes + done, take, shift,
@@ -844,15 +853,17 @@ int qsmc_update_multi(qsmc_handle_t h, const qsmc_model_t *model, const double *
         ma.outcome[j] = outcomes[j];
     }
     const ReduceOut ro = make_reduce(h, true, nullptr);
+    hipEvent_t me0 = nullptr, me1 = nullptr;
+    prof_events(h, QSMC_PROF_UPDATE_MULTI, &me0, &me1);
     switch (model->kind) {
 #define LAUNCH_MU(K)                                                                                   \
     case K:                                                                                            \
         if (ma.e[0].lik_pow != 0.0)                                                                    \
-            hipLaunchKernelGGL((k_update_multi<K, true>), dim3(grid), dim3(QSMC_BLOCK), 0, s, x, ldx, n, w_in, \
-                               w_out, prev_norm, ma, ro);                                              \
+            hipExtLaunchKernelGGL((k_update_multi<K, true>), dim3(grid), dim3(QSMC_BLOCK), 0, s, me0, me1, 0, x, ldx, n, \
+                                  w_in, w_out, prev_norm, ma, ro);                                     \
         else                                                                                           \
-            hipLaunchKernelGGL((k_update_multi<K, false>), dim3(grid), dim3(QSMC_BLOCK), 0, s, x, ldx, n, w_in, \
-                               w_out, prev_norm, ma, ro);                                              \
+            hipExtLaunchKernelGGL((k_update_multi<K, false>), dim3(grid), dim3(QSMC_BLOCK), 0, s, me0, me1, 0, x, ldx, n, \
+                                  w_in, w_out, prev_norm, ma, ro);                                     \
         break;
         LAUNCH_MU(QSMC_MODEL_PRECESSION)
         LAUNCH_MU(QSMC_MODEL_BINOMIAL_PRECESSION)

@@ -77,39 +77,64 @@ def _shorten_right(*args):
     return tuple(a[..., -m:] for a in arrs)
 
 
-def perf_test(model, n_particles, prior, n_exp, heuristic_class, true_model=None, true_prior=None, true_mps=None,
-              extra_updater_args=None):
-    """One trial; returns a record array of length n_exp (see module docstring)."""
-    true_model = model if true_model is None else true_model
-    true_prior = prior if true_prior is None else true_prior
-    true_mps = true_prior.sample() if true_mps is None else true_mps
-    extra_updater_args = {} if extra_updater_args is None else extra_updater_args
-    n_min = min(model.n_modelparams, true_model.n_modelparams)
-    dtype, is_scalar_exp = actual_dtype(model, true_model)
-    performance = np.zeros((n_exp,), dtype=dtype)
-    updater = SMCUpdater(model, n_particles, prior, **extra_updater_args)
-    heuristic = heuristic_class(updater)
-    for idx in range(n_exp):
-        performance[idx]['true'] = true_mps          # inside the loop: the true model may itself drift
+class _TrialColumns:
+    """Per-datum results of one trial, column by column in plain arrays; the record array of the reference's layout
+    (perf_testing.py:182-218 dtype) is assembled from them once, at the end of the trial."""
+
+    def __init__(self, model, true_model, n_exp):
+        self.dtype, self.scalar_experiment = actual_dtype(model, true_model)
+        self.experiment_fields = [] if self.scalar_experiment else [f[0] for f in model.expparams_dtype]
+        self.elapsed = np.zeros(n_exp)
+        self.loss = np.zeros(n_exp)
+        self.resample_count = np.zeros(n_exp, dtype=int)
+        self.outcome = np.zeros(n_exp, dtype=int)
+        self.true = np.zeros((n_exp, true_model.n_modelparams))
+        self.est = np.zeros((n_exp, model.n_modelparams))
+        self.experiments = [None] * n_exp
+
+    def record(self):
+        rec = np.zeros((len(self.elapsed),), dtype=self.dtype)
+        rec['elapsed_time'], rec['loss'] = self.elapsed, self.loss
+        rec['resample_count'], rec['outcome'] = self.resample_count, self.outcome
+        rec['true'], rec['est'] = self.true, self.est
+        if self.scalar_experiment:
+            rec['experiment'] = np.concatenate([np.ravel(e) for e in self.experiments])
+        else:
+            for name in self.experiment_fields:
+                rec[name] = np.concatenate([np.atleast_1d(e[name]) for e in self.experiments]).reshape(rec[name].shape)
+        return rec
+
+
+def _data_stream(updater, heuristic, true_model, true_mps, n_exp):
+    """The experiment loop of a trial as a generator: design -> simulated datum -> TIMED update -> the true model's own
+    time step.  Yields (experiment, datum, seconds in `update`, true parameters before / after the datum)."""
+    for _ in range(n_exp):
         expparams = heuristic()
         datum = true_model.simulate_experiment(true_mps, expparams)
         with timing() as t:
             updater.update(datum, expparams)
+        before = true_mps
         true_mps = true_model.update_timestep(_promote_dims_left(true_mps, 2), expparams)[:, :, 0]
-        est_mean = updater.est_mean()
-        a, b = _shorten_right(est_mean, true_mps)
-        delta = np.subtract(a, b)
-        performance[idx]['elapsed_time'] = t.delta_t
-        performance[idx]['loss'] = np.dot(delta ** 2, model.Q[-n_min:])
-        performance[idx]['resample_count'] = updater.resample_count
-        performance[idx]['outcome'] = datum
-        performance[idx]['est'] = est_mean
-        if is_scalar_exp:
-            performance[idx]['experiment'] = expparams
-        else:
-            for name in [f[0] for f in model.expparams_dtype]:
-                performance[idx][name] = expparams[name]
-    return performance
+        yield expparams, datum, t.delta_t, before, true_mps
+
+
+def perf_test(model, n_particles, prior, n_exp, heuristic_class, true_model=None, true_prior=None, true_mps=None,
+              extra_updater_args=None):
+    """One trial; returns a record array of length n_exp (see module docstring)."""
+    true_model = model if true_model is None else true_model
+    true_mps = (prior if true_prior is None else true_prior).sample() if true_mps is None else true_mps
+    updater = SMCUpdater(model, n_particles, prior, **({} if extra_updater_args is None else extra_updater_args))
+    cols = _TrialColumns(model, true_model, n_exp)
+    q_tail = model.Q[-min(model.n_modelparams, true_model.n_modelparams):]
+    stream = _data_stream(updater, heuristic_class(updater), true_model, true_mps, n_exp)
+    for k, (expparams, datum, seconds, true_before, true_after) in enumerate(stream):
+        cols.true[k] = true_before                   # (per datum: the true model may itself drift)
+        cols.experiments[k], cols.outcome[k], cols.elapsed[k] = expparams, datum, seconds
+        cols.est[k] = updater.est_mean()
+        est, tru = _shorten_right(cols.est[k], true_after)
+        cols.loss[k] = np.dot(np.subtract(est, tru) ** 2, q_tail)
+        cols.resample_count[k] = updater.resample_count
+    return cols.record()
 
 
 class apply_serial:
@@ -125,6 +150,17 @@ class apply_serial:
         return self._value
 
 
+def _finished_trials(indices, apply, trial_fn):
+    """Dispatch every trial through `apply` first (a parallel engine starts them all), then hand back
+    (trial index, record or the exception it raised) as they are collected, in dispatch order."""
+    handles = [(idx, apply(trial_fn)) for idx in indices]
+    for idx, handle in handles:
+        try:
+            yield idx, handle.get()
+        except Exception as exc:  # noqa: BLE001
+            yield idx, exc
+
+
 def perf_test_multiple(n_trials, model, n_particles, prior, n_exp, heuristic_class, true_model=None,
                        true_prior=None, true_mps=None, apply=apply_serial, allow_failures=False,
                        extra_updater_args=None, progressbar=None, comm=None):
@@ -137,22 +173,20 @@ def perf_test_multiple(n_trials, model, n_particles, prior, n_exp, heuristic_cla
     performance = (ma.zeros if allow_failures else np.zeros)((n_trials, n_exp), dtype=dtype)
     rank, world = (0, 1) if comm is None else (comm.rank, comm.world_size)
     mine = list(range(rank, n_trials, world))
-    prog = None
+    prog = progressbar() if progressbar is not None else None
     try:
-        if progressbar is not None:
-            prog = progressbar()
+        if prog is not None:
             prog.start(len(mine))
         with numpy_err_policy(divide='raise'):
-            results = [(idx, apply(trial_fn)) for idx in mine]
-            for done, (idx, result) in enumerate(results):
-                try:
-                    performance[idx, :] = result.get()
-                    if prog is not None:
-                        prog.update(done)
-                except Exception:  # noqa: BLE001
+            for done, (idx, outcome) in enumerate(_finished_trials(mine, apply, trial_fn)):
+                if isinstance(outcome, Exception):
                     if not allow_failures:
-                        raise
+                        raise outcome
                     performance.mask[idx, :] = True
+                    continue
+                performance[idx, :] = outcome
+                if prog is not None:
+                    prog.update(done)
     finally:
         if prog is not None:
             prog.finished()

@@ -456,10 +456,11 @@ def test_liu_west_philox_bucketed_vs_oracle(qi, eng, case):
         pd = qi.ParticleDistribution(particle_locations=x, particle_weights=w)
         res = qi.LiuWestResampler(a=0.9, device_rng=True, seed=4321)
         new = res(model, pd, n_particles=n_out)
-        wn = pd.particle_weights
-        cdf = eng.cumsum(pd._w, 1.0).cpu().numpy()       # the device CDF: same chunk edges as the kernel
-        ref, failed, js, counts = ph.liu_west_philox_bucketed(wn, x, valid, 0.9, np.sqrt(1 - 0.81), 4321, 1,
-                                                              n_out, cdf=cdf)
+        wn = np.asarray(pd.particle_weights)
+        # the twin works on ITS OWN CDF (np.cumsum of the weights, as the reference forms it, resamplers.py:308): chunk
+        # edges and entries differ from the device scan by rounding only, which can move an ancestor across a CDF
+        # boundary (max_js_flips) but not change a count -- the device scan has its own check against np.cumsum
+        ref, failed, js, counts = ph.liu_west_philox_bucketed(wn, x, valid, 0.9, np.sqrt(1 - 0.81), 4321, 1, n_out)
     got = new.particle_locations
     assert counts.max() > 2 * 8192, "fixture must exercise the heavy-chunk split"
     assert counts.sum() == n_out and len(counts) == (n + 4095) // 4096
@@ -494,10 +495,10 @@ def test_bucketed_counts_removal_branch(qi, eng, margin, monkeypatch):
             pd = qi.ParticleDistribution(particle_locations=x, particle_weights=w)
             res = qi.LiuWestResampler(a=0.9, device_rng=True, seed=seed)
             new = res(model, pd, n_particles=n_out)
-            wn = pd.particle_weights
-            cdf = eng.cumsum(pd._w, 1.0).cpu().numpy()
+            wn = np.asarray(pd.particle_weights)
+            cdf = np.cumsum(wn)
             ref, failed, js, counts = ph.liu_west_philox_bucketed(wn, x, orc.valid_precession, 0.9, np.sqrt(1 - 0.81),
-                                                                  seed, 1, n_out, cdf=cdf, margin=float(margin))
+                                                                  seed, 1, n_out, margin=float(margin))
         got = new.particle_locations
         assert got.shape == (n_out, 1) and counts.sum() == n_out
         bad = np.abs(got - ref).max(axis=1) > 1e-12
@@ -1647,6 +1648,68 @@ def test_step_path_same_particles(qi, monkeypatch):
         for o, ep in prec[30:34]:
             upd.update(o, ep)
         assert upd.resample_count == rc + 4
+
+
+# Fixed seeds and a stated level for the statistical pins below: with the resampler right, each p-value is uniform, so
+# a run of ~30 tests at ALPHA = 1e-4 fails by chance 0.3 % of the time -- and, the seeds being fixed, never or always.
+STAT_SEEDS = list(range(101, 133))                         # 32 device seeds; the oracle takes 1000 + s
+STAT_ALPHA = 1e-4
+
+
+def _two_sample_checks(dev, ref, label):
+    """dev / ref: (n_seeds, n, d) clouds.  Per coordinate: two-sample KS over the pooled particles; Welch z-tests on the
+    per-seed means and on the per-seed (co)variances."""
+    from scipy import stats
+    d = dev.shape[2]
+    for q in range(d):
+        ks = stats.ks_2samp(dev[:, :, q].ravel(), ref[:, :, q].ravel())
+        assert ks.pvalue > STAT_ALPHA, (label, "KS", q, ks)
+        for what, fn in (("mean", lambda c: c[:, :, q].mean(axis=1)), ("var", lambda c: c[:, :, q].var(axis=1))):
+            t = stats.ttest_ind(fn(dev), fn(ref), equal_var=False)
+            assert t.pvalue > STAT_ALPHA, (label, what, q, t)
+    for q in range(d):
+        for r in range(q + 1, d):
+            cv = lambda c: np.array([np.cov(c[k, :, q], c[k, :, r])[0, 1] for k in range(c.shape[0])])   # noqa: E731
+            t = stats.ttest_ind(cv(dev), cv(ref), equal_var=False)
+            assert t.pvalue > STAT_ALPHA, (label, "cov", q, r, t)
+
+
+@pytest.mark.parametrize("case", ["d1", "d1-postselect", "d3"])
+def test_device_resampler_vs_pinned_oracle_statistics(qi, case):
+    """The device-RNG resampler (Philox, bucketed counts, Poissonisation, ordered sampler, redraws) is pinned particle
+    for particle only to a twin written to mirror it.  This ties it to the REFERENCE: 32 seeds of the device resampler
+    against 32 seeds of `np_oracle.liu_west` -- the restatement of resamplers.py:256-392 that the golden vectors pin
+    (G4) -- on the same weighted cloud: same law of the new cloud, coordinate by coordinate (KS), same moments."""
+    rs = np.random.RandomState(77)
+    n = 20000                                               # >= 4 chunks' worth of outputs: the bucketed path
+    if case.startswith("d1"):
+        model, valid = qi.SimplePrecessionModel(), orc.valid_precession
+        centre = 0.3 if case == "d1" else 0.012              # the second cloud leans on omega > 0: ~15 % of the kicks fail
+        x = np.abs(centre + 0.02 * rs.randn(n, 1))
+        a = 0.9
+    else:
+        model, valid = qi.RandomizedBenchmarkingModel(), orc.valid_rb
+        x = np.stack([rs.uniform(0.93, 1, n), rs.uniform(0.2, 0.5, n), rs.uniform(0.4, 0.62, n)], 1)
+        x = x[orc.valid_rb(x)]
+        x = np.concatenate([x, x[: n - x.shape[0]]])
+        a = 0.9
+    w = rs.random_sample(n) ** 2
+    w /= w.sum()
+    dev, ref = [], []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        pd = qi.ParticleDistribution(particle_locations=x, particle_weights=w)
+        for s_ in STAT_SEEDS:
+            res = qi.LiuWestResampler(a=a, device_rng=True, seed=s_)
+            dev.append(np.asarray(res(model, pd).particle_locations))
+            np.random.seed(1000 + s_)
+            ref.append(orc.liu_west(w, x, valid, orc.LegacyRNG(), a=a)[0])
+    dev, ref = np.stack(dev), np.stack(ref)
+    assert np.all(valid(dev.reshape(-1, x.shape[1])))
+    if case == "d1-postselect":                             # the fixture must make postselection bite
+        kick = np.sqrt(1 - a ** 2) * np.sqrt(orc.particle_cov(w, x, warn=False)[0, 0])
+        assert np.mean(x[:, 0] < 2 * kick) > 0.2
+    _two_sample_checks(dev, ref, case)
 
 
 def test_kl_divergence_g14(qi, golden):

@@ -513,7 +513,8 @@ def _check_sharded_resample_vs_twin(comm, rank, world, tmpdir):
             x_before = np.asarray(upd.particle_locations)
             w_dev, W = upd._w, np.array(upd._shard_sums)
             mean, cov = upd.est_mean(), upd.est_covariance_mtx()
-            cdf = upd._eng.cumsum(w_dev, float(W[rank])).cpu().numpy()
+            # the twin's own CDF (np.cumsum of this shard's normalised weights), not the device's scan
+            w_host = w_dev.cpu().numpy() / float(W[rank])
             n_total = upd.n_particles_global
             upd.resample()
             got = np.asarray(upd.particle_locations)
@@ -523,14 +524,80 @@ def _check_sharded_resample_vs_twin(comm, rank, world, tmpdir):
             res = upd.resampler
             seed_r = res._seed + 0x9E3779B97F4A7C15 * (rank + 1)
             ref, failed, js, counts = ph.liu_west_philox_bucketed(
-                np.ones(n_local) / n_local, x_before, valid, res.a, res.h, seed_r, epoch, int(totals[rank]),
-                mean=mean, cov=cov, cdf=cdf)
+                w_host, x_before, valid, res.a, res.h, seed_r, epoch, int(totals[rank]), mean=mean, cov=cov)
             if canon is not None:
                 ref = orc.tomo_canonicalize(ref, canon)
         at = 1e-12 + (tol.atol_sqrtm_psd(cov) * 10 if case == "tomo" else 0)
         bad = np.abs(got - ref).max(axis=1) > at
         assert bad.sum() <= tol.max_js_flips(got.shape[0]), (case, int(bad.sum()))
         assert np.all(valid(got)) and failed == 0
+
+
+def _check_sharded_resample_statistics(comm, rank, world, tmpdir):
+    """The sharded resample (shared-seed shard totals, per-rank bucketed samplers, global moments) against the
+    single-cloud REFERENCE resample (`np_oracle.liu_west`, the restatement the golden vectors pin) on the union cloud:
+    32 seeds each, KS per coordinate over the pooled particles and Welch tests on the per-seed moments, at the level
+    and with the seed list of tests/test_gpu_parity.py."""
+    import warnings
+    import torch
+    import qinfer_amd as qi
+    import np_oracle as orc
+    from test_gpu_parity import STAT_SEEDS, _two_sample_checks
+    torch.cuda.set_device(0)
+    n_local = 17000                                        # (>= 4 chunks' worth of outputs per shard: the bucketed sampler)
+    rs = np.random.RandomState(5)
+    model = qi.RandomizedBenchmarkingModel()
+    x_all = np.stack([rs.uniform(0.93, 1, world * n_local), rs.uniform(0.2, 0.5, world * n_local),
+                      rs.uniform(0.4, 0.6, world * n_local)], 1)
+    eps = []
+    for mm in (3, 20, 60):
+        ep = np.empty((1,), dtype=model.expparams_dtype)
+        ep['m'] = mm
+        eps.append(ep)
+    outs = [0, 1, 0]
+
+    class Slice(qi.Distribution):
+        n_rvs = 3
+
+        def sample(self, n=1):
+            return x_all[rank * n_local:(rank + 1) * n_local].copy()
+    # the union cloud's weights after the three data, on the host (oracle likelihood)
+    w_all = np.ones(world * n_local)
+    for o, ep in zip(outs, eps):
+        w_all = w_all * orc.lik_rb(np.array([o]), x_all, np.array([float(ep['m'][0])]))[0, :, 0]
+    w_all /= w_all.sum()
+    dev, ref = [], []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for s_ in STAT_SEEDS:
+            upd = qi.SMCUpdater(model, n_local, Slice(), device_rng=True, seed=s_, comm=comm, resample_thresh=0.0)
+            for o, ep in zip(outs, eps):
+                upd.update(o, ep)
+            upd.resample()
+            mine = np.asarray(upd.particle_locations)
+            # gather the union of the new cloud (shard sizes float): pad to a common length through the backend
+            sizes = comm.gather_rows(np.array([float(mine.shape[0])]))[:, 0].astype(int)
+            pad = np.full((int(sizes.max()), 3), np.nan)
+            pad[:mine.shape[0]] = mine
+            rows = comm.gather_rows(torch.from_numpy(pad.reshape(-1)))
+            union = np.concatenate([rows[r].reshape(-1, 3)[:sizes[r]] for r in range(world)])
+            assert union.shape[0] == world * n_local and np.all(orc.valid_rb(union))
+            dev.append(union)
+            np.random.seed(1000 + s_)
+            ref.append(orc.liu_west(w_all, x_all, orc.valid_rb, orc.LegacyRNG(), a=0.98)[0])
+    if rank == 0:
+        _two_sample_checks(np.stack(dev), np.stack(ref), "sharded x%d" % world)
+
+
+@pytest.mark.gpu
+def test_sharded_resample_statistics_two_ranks_one_gpu(tmp_path):
+    _run("_check_sharded_resample_statistics", tmp_path, world=2)
+
+
+@pytest.mark.gpu
+def test_sharded_resample_statistics_eight_ranks_one_gpu(tmp_path, monkeypatch):
+    monkeypatch.setenv("QSMC_REDRAW_BLOCKS", "64")             # (eight processes share the device's resident-grid slots)
+    _run("_check_sharded_resample_statistics", tmp_path, world=8)
 
 
 @pytest.mark.gpu
