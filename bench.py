@@ -235,7 +235,7 @@ def run_other_config(qi, eng, torch, spec, warmup):
     upd.reset()
     upd._resample_count = 0
     torch.cuda.synchronize()
-    eng.set_profiling(1)
+    eng.set_profiling(0 if os.environ.get("QSMC_BENCH_NO_EVENTS") else 1)      # (no events: for kernel-trace gap profiles)
     t0 = time.perf_counter()
     for k in range(len(eps)):
         upd.update(outs[k], eps[k])

@@ -659,30 +659,34 @@ __host__ __device__ inline bool jacobi_clamp(double (&Ar)[DIM][DIM], double (&Ai
                 const double tt = (tau >= 0.0 ? 1.0 : -1.0) * j_rcp(fabs(tau) + rt);
                 const double cs = j_rsqrt(1.0 + tt * tt);
                 const double sn = tt * cs;
-                // A <- J^H A J with J = [[c, s e^{i phi}], [-s e^{-i phi}, c]] on (p, q): columns, then rows
+                // A <- J^H A J with J = [[c, s e^{i phi}], [-s e^{-i phi}, c]] on (p, q), using that A stays Hermitian:
+                // only the entries (k, p), (k, q) of the OTHER rows are rotated (col_p' = c col_p - s conj(e) col_q,
+                // col_q' = s e col_p + c col_q) and mirrored; the 2 x 2 pivot block has the closed form
+                // a_pp' = a_pp - t |h|, a_qq' = a_qq + t |h|, a_pq' = 0 (t = tan of the rotation angle).  Round 2 rotated all
+                // four rows' columns and then all four columns' rows -- 224 multiply-adds per pivot for what is 56 here;
+                // with the eigenvector update (unchanged) a pivot costs ~230 instead of ~400 flops, and this kernel runs
+                // at the fp64 VALU's rate.
+                const double th = tt * (mag2 * imag);               // t |h|
 #pragma unroll
                 for (int r = 0; r < DIM; ++r) {
-                    const double apr = Ar[r][pI], api = Ai[r][pI], aqr = Ar[r][q], aqi = Ai[r][q];
-                    // col_p' = c*col_p - s*conj(e)*col_q ; col_q' = s*e*col_p + c*col_q
-                    Ar[r][pI] = cs * apr - sn * (er * aqr + ei * aqi);
-                    Ai[r][pI] = cs * api - sn * (er * aqi - ei * aqr);
-                    Ar[r][q] = sn * (er * apr - ei * api) + cs * aqr;
-                    Ai[r][q] = sn * (er * api + ei * apr) + cs * aqi;
+                    if (r != pI && r != q) {
+                        const double apr = Ar[r][pI], api = Ai[r][pI], aqr = Ar[r][q], aqi = Ai[r][q];
+                        const double npr = cs * apr - sn * (er * aqr + ei * aqi);
+                        const double npi = cs * api - sn * (er * aqi - ei * aqr);
+                        const double nqr = sn * (er * apr - ei * api) + cs * aqr;
+                        const double nqi = sn * (er * api + ei * apr) + cs * aqi;
+                        Ar[r][pI] = npr; Ai[r][pI] = npi; Ar[pI][r] = npr; Ai[pI][r] = -npi;
+                        Ar[r][q] = nqr; Ai[r][q] = nqi; Ar[q][r] = nqr; Ai[q][r] = -nqi;
+                    }
                     const double vpr = Vr[r][pI], vpi = Vi[r][pI], vqr = Vr[r][q], vqi = Vi[r][q];
                     Vr[r][pI] = cs * vpr - sn * (er * vqr + ei * vqi);
                     Vi[r][pI] = cs * vpi - sn * (er * vqi - ei * vqr);
                     Vr[r][q] = sn * (er * vpr - ei * vpi) + cs * vqr;
                     Vi[r][q] = sn * (er * vpi + ei * vpr) + cs * vqi;
                 }
-                // row_p' = c*row_p - s*e*row_q ; row_q' = s*conj(e)*row_p + c*row_q
-#pragma unroll
-                for (int c2 = 0; c2 < DIM; ++c2) {
-                    const double apr = Ar[pI][c2], api = Ai[pI][c2], aqr = Ar[q][c2], aqi = Ai[q][c2];
-                    Ar[pI][c2] = cs * apr - sn * (er * aqr - ei * aqi);
-                    Ai[pI][c2] = cs * api - sn * (er * aqi + ei * aqr);
-                    Ar[q][c2] = sn * (er * apr + ei * api) + cs * aqr;
-                    Ai[q][c2] = sn * (er * api - ei * apr) + cs * aqi;
-                }
+                Ar[pI][pI] -= th;
+                Ar[q][q] += th;
+                Ar[pI][q] = 0.0; Ai[pI][q] = 0.0; Ar[q][pI] = 0.0; Ai[q][pI] = 0.0;
             }
     }
     bool any_neg = false;

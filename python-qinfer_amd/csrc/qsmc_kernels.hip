@@ -1403,15 +1403,15 @@ static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int3
             hipEvent_t a0 = nullptr, a1 = nullptr;
             prof_events(h, QSMC_PROF_ANCESTORS, &a0, &a1);
             hipExtLaunchKernelGGL((k_bucket_anc16<512>), dim3(bp.max_items), dim3(512), 0, s, a0, a1, 0, n_in, w, inv_norm,
-                                  offsets, chunks, bp.slot_off, bp.item_off, bp.item_chunk, k0, k1, ep, bp.anc, bp.cap);
+                                  offsets, chunks, bp.slot_off, bp.item_off, bp.item_chunk, k0, k1, ep, bp.anc, bp.cap,
+                                  bp.clist /* [0]: the canonicalize list's length */);
         }
         if (stages & RS_STAGE_KICK) {
             hipEvent_t pe0 = nullptr, pe1 = nullptr;
             prof_events(h, QSMC_PROF_SAMPLE, &pe0, &pe1);
             const int64_t n_ranges = (n_out + KICK16_PER_BLOCK - 1) / KICK16_PER_BLOCK;
             const unsigned kgrid = (unsigned)(((n_ranges + 7) / 8) * 8);
-            unsigned int *ccount = bp.clist, *clist = bp.clist + 4;
-            if (canon.kind) HIP_TRY(h, hipMemsetAsync(ccount, 0, sizeof(unsigned int), s));
+            unsigned int *ccount = bp.clist, *clist = bp.clist + 4;      // (ccount was cleared by k_bucket_anc16)
 #define LAUNCH_K16(C)                                                                                                 \
     hipExtLaunchKernelGGL((k_bucket_kick16<C>), dim3(kgrid), dim3(KICK16_BT), 0, s, pe0, pe1, 0, x_in, ldx_in, bp.anc,  \
                           n_out, lw, k0, k1, ep, x_out, pl, canon.basis, canon.allow_sub, clist, ccount)
