@@ -39,7 +39,19 @@ def _worker(rank, world, port, fn_name, tmpdir):
 
 def _run(fn_name, tmp_path, world=2):
     import torch.multiprocessing as mp
-    mp.spawn(_worker, args=(world, _free_port(), fn_name, str(tmp_path)), nprocs=world, join=True)
+    # The GPU legs put `world` processes on ONE device.  The resampler's redraw kernel meets at a grid barrier and
+    # sizes its grid for a device of its own (one workgroup per CU); several such grids from different processes
+    # can each become half resident and starve one another, so the test boxes' shared device is split explicitly
+    # (as bench.py does under QSMC_BENCH_SHARE_GPU): 512 resident workgroup slots / world.
+    saved = os.environ.get("QSMC_REDRAW_BLOCKS")
+    os.environ["QSMC_REDRAW_BLOCKS"] = str(max(16, 512 // max(world, 2)))
+    try:
+        mp.spawn(_worker, args=(world, _free_port(), fn_name, str(tmp_path)), nprocs=world, join=True)
+    finally:
+        if saved is None:
+            os.environ.pop("QSMC_REDRAW_BLOCKS", None)
+        else:
+            os.environ["QSMC_REDRAW_BLOCKS"] = saved
 
 
 # ---------------------------------------------------------------------------------------------
@@ -595,8 +607,7 @@ def test_sharded_resample_statistics_two_ranks_one_gpu(tmp_path):
 
 
 @pytest.mark.gpu
-def test_sharded_resample_statistics_eight_ranks_one_gpu(tmp_path, monkeypatch):
-    monkeypatch.setenv("QSMC_REDRAW_BLOCKS", "64")             # (eight processes share the device's resident-grid slots)
+def test_sharded_resample_statistics_eight_ranks_one_gpu(tmp_path):
     _run("_check_sharded_resample_statistics", tmp_path, world=8)
 
 
