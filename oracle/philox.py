@@ -216,36 +216,6 @@ def bucket_cap(n_out):
     return cap
 
 
-REDRAW_TRIES = 64
-
-
-def _redraw_ancestors(slots, w, wmax, edges, N, seed, epoch, rnd):
-    """Global ancestor of every slot in redraw round `rnd`, as redraw_rounds (kernels/resample.hpp) draws it: the
-    chunk from the chunk edges with the first uniform of block (slot, rnd, 0); inside the chunk by rejection on the
-    weights -- try t takes both uniforms of block (slot, rnd, 16 + t): index floor(u len), accepted if u' max_c < w_j
-    -- and after REDRAW_TRIES rejections one walk along the chunk's weights with block (slot, rnd, 15)."""
-    chunks = len(edges)
-    ur, _ = uniforms(slots, seed, epoch, rnd, 0)
-    c = np.minimum(np.searchsorted(edges, ur, side='right'), chunks - 1)
-    base = c * BUCKET_CHUNK
-    ln = np.minimum(base + BUCKET_CHUNK, N) - base
-    jl = np.full(slots.shape, -1, dtype=np.int64)
-    for t in range(REDRAW_TRIES):
-        pend = np.flatnonzero(jl < 0)
-        if not pend.size:
-            break
-        ui, ua = uniforms(slots[pend], seed, epoch, rnd, 16 + t)
-        jj = np.minimum((ui * ln[pend]).astype(np.int64), ln[pend] - 1)
-        acc = ua * wmax[c[pend]] < w[base[pend] + jj]
-        jl[pend[acc]] = jj[acc]
-    for k in np.flatnonzero(jl < 0):                                    # a chunk dominated by very few weights
-        us, _ = uniforms(slots[k:k + 1], seed, epoch, rnd, 15)
-        run = np.cumsum(w[base[k]:base[k] + ln[k]])
-        hit = np.flatnonzero(run > us[0] * run[-1])
-        jl[k] = hit[0] if hit.size else ln[k] - 1
-    return base + jl
-
-
 def liu_west_philox_bucketed(w, x, valid_fn, a, h, seed, epoch, n_out, maxiter=1000, postselect=True,
                              mean=None, cov=None, zero_cov_comp=1e-10, cdf=None, margin=5.0, sort_items=None):
     """Oracle of the bucketed device-RNG resampler (k_bucket_counts / k_bucket_sample).  Outputs are
@@ -253,8 +223,7 @@ def liu_west_philox_bucketed(w, x, valid_fn, a, h, seed, epoch, n_out, maxiter=1
       slot 0: the Poisson chunk counts, slots 3 / 4 their top-up / removal (poissonised_counts); slot 1:
       within-chunk position of slot o (independent of the counts);
       slot 2: normal n = o * d + q.  Retries (round r >= 1) are per output and redraw a GLOBAL
-      ancestor (_redraw_ancestors: chunk from block (o, r, 0), rejection inside it from blocks (o, r, 16 + t)) and
-      normals from (o, r, 1 + q // 2)."""
+      ancestor from block (o, r, 0) and normals from (o, r, 1 + q // 2)."""
     import np_oracle as orc
     N, d = x.shape
     mean = orc.particle_mean(w, x) if mean is None else mean
@@ -292,11 +261,11 @@ def liu_west_philox_bucketed(w, x, valid_fn, a, h, seed, epoch, n_out, maxiter=1
     out = (a * x[js] + (1 - a) * mean) + (S @ z).T
     ok = valid_fn(out) if postselect else np.ones(n_out, dtype=bool)
     todo = ids[~ok]
-    wmax = np.maximum.reduceat(w, np.arange(0, N, BUCKET_CHUNK))           # largest weight of every chunk
     for rnd in range(1, maxiter):
         if not todo.size:
             break
-        jr = _redraw_ancestors(todo, w, wmax, edges, N, seed, epoch, rnd)
+        ur, _ = uniforms(todo, seed, epoch, rnd, 0)
+        jr = np.minimum(cdf.searchsorted(ur, side='right'), N - 1)
         zr = np.empty((d, todo.size))
         for q in range(0, d, 2):
             z0, z1 = normals(todo, seed, epoch, rnd, 1 + q // 2)

@@ -262,8 +262,7 @@ __device__ __forceinline__ int guided_upper_bound(const double *a, int m, const 
 //   slot 3: block (j >> 1), word (j & 1)          top-up draw j;  slot 4: block (i), word 0: removal i
 //   slot 1: block (o >> 1), word (o & 1)          within-chunk position of slot o (k_bucket_sample)
 //   slot 2: block (n >> 1), Box-Muller comp (n&1) n = o * d + q, q-th normal of slot o
-// retries (round r >= 1) are per output: block (o, r, 0).u0 = the ancestor's chunk, blocks (o, r, 16 + t) the rejection
-// tries inside it (redraw_rounds), (o, r, 1 + q/2) normals.
+// retries (round r >= 1) are per output: block (o, r, 0).u0 = global ancestor, (o, r, 1 + q/2) normals.
 __global__ __launch_bounds__(BUCKET_COUNT_THREADS) void k_bucket_count(
     const double *__restrict__ offsets, int chunks, int64_t n_out, uint32_t k0, uint32_t k1,
     uint32_t epoch, unsigned int *__restrict__ hist /* [gridDim.x][chunks] */) {
@@ -641,72 +640,62 @@ __global__ __launch_bounds__(1024) void k_bucket_plan(const unsigned int *__rest
 
 constexpr int BUCKET_RLIST_CAP = 1024;               // per-workgroup list of outputs that need a global redraw
 
-// Draw + kick of the redraw rounds (round >= 1) of output slot o: a fresh GLOBAL ancestor j ~ w, then the kick, until
-// the particle is valid.  Round 2 searched a materialised global CDF: a 100 MB scan + write per resample whenever
-// redraws were expected (k_chunk_scan, 75 us) and 12 scattered cache lines per redraw (717 MB per million).  Round 3
-// draws the ancestor in two exact steps that need neither:
-//   chunk   c = #{chunk edges <= u0}: the edges (the resample plan's offsets[], the scan of the chunk sums) sit in LDS;
-//   inside  rejection on the weights themselves: j uniform in the chunk, accepted with probability w_j / max_c, max_c
-//           the chunk's largest weight (k_chunk_max: one read of the weights, no write) -- on average max_c / mean_c
-//           tries of ONE 8-byte read each (2-3 for the likelihood-sized weight spreads an n_ess-triggered resample sees).
-// P(j) = (mass_c / total) (w_j / sum_c w): the multinomial law, as before.  Try t of round r takes both uniforms of
-// Philox block (o, r, 16 + t); after REDRAW_TRIES rejections (a chunk dominated by one weight) the lane walks the
-// chunk's weights once with a fresh uniform (block (o, r, 15)): still exact, just slow.  Implicit uniform weights
-// (w == NULL): the second uniform of the chunk draw picks the index directly.
-// oracle/philox.py mirrors this draw for draw.
-constexpr int REDRAW_TRIES = 64;
+// Draw + kick of one redraw round (round >= 1) of output slot o from the GLOBAL CDF.
 template <int DM>
 __device__ __forceinline__ bool redraw_rounds(int kind, int d, double min_freq, const double *__restrict__ x_in,
-                                              int64_t ldx_in, int64_t n_in, const double *__restrict__ w,
-                                              const double *__restrict__ chunk_max, const double *__restrict__ offsets,
+                                              int64_t ldx_in, int64_t n_in, const double *__restrict__ cdf,
                                               const LWArgs &lw, uint32_t k0, uint32_t k1, uint32_t epoch,
                                               int maxiter, int64_t o, double *p, const double *edges, int chunks) {
     for (int round = 1; round < maxiter; ++round) {
         PhiloxStream rng{(uint64_t)o, (epoch << 16) | (uint32_t)round, k0, k1};
-        double u0, u1;
-        rng.uniforms(0, u0, u1);
-        int c;
+        double u0, unused;
+        rng.uniforms(0, u0, unused);
+        int64_t j;
         if (edges) {
-            c = upper_bound_skew(edges, chunks, u0);
-        } else {                                      // (more chunks than the LDS table holds: the plan's offsets in global memory)
-            int lo = 0, hi = chunks;
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (offsets[mid + 1] <= u0) lo = mid + 1; else hi = mid;
-            }
-            c = lo;
-        }
-        if (c > chunks - 1) c = chunks - 1;           // u beyond the last edge (rounding): Q2 clamp
-        const int64_t base = (int64_t)c * SCAN_CHUNK;
-        const int len = (int)(n_in - base < SCAN_CHUNK ? n_in - base : SCAN_CHUNK);
-        int jl = -1;
-        if (!w) {
-            jl = (int)(u1 * (double)len);
-            jl = jl > len - 1 ? len - 1 : jl;
-        } else {
-            const double wm = chunk_max[c];
-            for (int t = 0; t < REDRAW_TRIES && jl < 0; ++t) {
-                double ui, ua;
-                rng.uniforms(16u + (uint32_t)t, ui, ua);
-                int jj = (int)(ui * (double)len);
-                jj = jj > len - 1 ? len - 1 : jj;
-                if (ua * wm < w[base + jj]) jl = jj;
-            }
-            if (jl < 0) {                             // a chunk dominated by very few weights: one exact walk
-                double us, unused;
-                rng.uniforms(15u, us, unused);
-                double tot = 0.0;
-                for (int k = 0; k < len; ++k) tot += w[base + k];
-                const double target = us * tot;
-                double run = 0.0;
-                jl = len - 1;
-                for (int k = 0; k < len; ++k) {
-                    run += w[base + k];
-                    if (run > target) { jl = k; break; }
+            // two levels: the chunk among the edges in LDS (the chunk's last CDF entry IS its upper edge, so
+            // #edges <= u is the chunk of the upper bound), then 12 probes of that chunk's 32 KB of the CDF instead of
+            // 24 scattered over all of it -- the same index as search_right over the whole table
+            int c = upper_bound_skew(edges, chunks, u0);
+            if (c > chunks - 1) c = chunks - 1;
+            const int64_t base = (int64_t)c * SCAN_CHUNK;
+            const int len = (int)(n_in - base < SCAN_CHUNK ? n_in - base : SCAN_CHUNK);
+            // Upper bound inside the chunk's 4096 CDF entries (32 KB of global memory).  A plain binary search is 12
+            // dependent loads from 12 different cache lines (717 MB of line traffic per million redraws, round 2).  The CDF
+            // of a chunk is a sum of thousands of weights, i.e. close to a straight line between its two edges: start at
+            // the interpolated position, bracket the answer by doubling steps (8, 16, ... entries), then bisect inside the
+            // bracket -- the same index (everything below `lo` is <= u, everything from `hi` on is > u, at every step),
+            // from 3-4 neighbouring lines instead of 12 scattered ones.
+            const double c_lo = c > 0 ? edges[lds_skew(c - 1)] : 0.0, c_hi = edges[lds_skew(c)];
+            int lo = 0, hi = len;
+            if (c_hi > c_lo) {
+                const double f = (u0 - c_lo) / (c_hi - c_lo) * (double)len;
+                int g = f > 0.0 ? (f < (double)(len - 1) ? (int)f : len - 1) : 0;
+                const double* row = cdf + base;
+                if (row[g] <= u0) {
+                    lo = g + 1;
+                    int step = 8;
+                    while (lo < len) {
+                        const int probe = lo + step - 1 < len - 1 ? lo + step - 1 : len - 1;
+                        if (row[probe] <= u0) { lo = probe + 1; step <<= 1; } else { hi = probe; break; }
+                    }
+                    if (lo >= len) hi = len;
+                } else {
+                    hi = g;
+                    int step = 8;
+                    while (hi > 0) {
+                        const int probe = hi - step > 0 ? hi - step : 0;
+                        if (row[probe] <= u0) { lo = probe + 1; break; } else { hi = probe; step <<= 1; }
+                    }
                 }
             }
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (cdf[base + mid] <= u0) lo = mid + 1; else hi = mid;
+            }
+            j = base + lo < n_in - 1 ? base + lo : n_in - 1;
+        } else {
+            j = search_right(cdf, n_in, u0);
         }
-        const int64_t j = base + jl;
         double zz[DM];
 #pragma unroll
         for (int q = 0; q < DM; q += 2) {
@@ -730,39 +719,6 @@ __device__ __forceinline__ bool redraw_rounds(int kind, int d, double min_freq, 
         if (model_valid(kind, p, min_freq)) return true;
     }
     return false;
-}
-
-// max of the (raw) weights of chunk c, by one workgroup (the first 512 threads own 8 consecutive weights each)
-__device__ __forceinline__ void chunk_max_block(const double *__restrict__ w, int64_t n, int64_t c, double *wave_tot,
-                                                double *__restrict__ out) {
-    const int lane = threadIdx.x & (QSMC_WAVE - 1), wave = threadIdx.x / QSMC_WAVE;
-    double m = 0.0;
-    if (threadIdx.x < SCAN_THREADS) {
-        const int64_t i0 = c * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_PER_LANE;
-#pragma unroll
-        for (int k = 0; k < SCAN_PER_LANE; ++k)
-            if (i0 + k < n) m = fmax(m, w[i0 + k]);
-    }
-#pragma unroll
-    for (int off = QSMC_WAVE / 2; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off, QSMC_WAVE));
-    if (lane == 0 && wave < SCAN_WAVES) wave_tot[wave] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = wave_tot[0];
-#pragma unroll
-        for (int wv = 1; wv < SCAN_WAVES; ++wv) t = fmax(t, wave_tot[wv]);
-        out[c] = t;
-    }
-    __syncthreads();
-}
-
-// gate != nullptr: do nothing unless *gate > 0 (only a resample with queued redraws needs the maxima)
-__global__ __launch_bounds__(SCAN_THREADS) void k_chunk_max(const double *__restrict__ w, int64_t n,
-                                                            double *__restrict__ out,
-                                                            const unsigned long long *__restrict__ gate) {
-    __shared__ double wave_tot[SCAN_WAVES];
-    if (gate && *gate == 0ull) return;
-    chunk_max_block(w, n, (int64_t)blockIdx.x, wave_tot, out);
 }
 
 // chunk_scan_block sink of the sampler: the entry goes to the skewed LDS table and, in the same pass,
@@ -1486,20 +1442,23 @@ template <int DM>     // particle dimension bound: 4 (registers) or QSMC_MAX_D
 __attribute__((amdgpu_waves_per_eu(4, 8)))
 __global__ __launch_bounds__(SCAN_THREADS) void k_bucket_redraw(
     int kind, int d, double min_freq, const double *__restrict__ x_in, int64_t ldx_in, int64_t n_in,
-    const double *__restrict__ w, const double *__restrict__ offsets, int64_t chunks, double *chunk_max,
+    const double *__restrict__ w, double inv_norm, const double *__restrict__ offsets, int64_t chunks, double *cdf,
     LWArgs lw, uint32_t k0, uint32_t k1, uint32_t epoch, int maxiter, double *__restrict__ x_out, OutPlace pl,
     const unsigned int *__restrict__ retry_list, const unsigned long long *__restrict__ retry_count,
-    unsigned long long *__restrict__ n_failed, unsigned long long *bar, int max_ready, int edges_in_lds) {
+    unsigned long long *__restrict__ n_failed, unsigned long long *bar, int cdf_ready, int edges_in_lds) {
     __shared__ double wave_tot[SCAN_WAVES];
     extern __shared__ __attribute__((aligned(16))) unsigned char redraw_smem[];
     const unsigned long long cnt = *retry_count;
     if (cnt == 0ull) return;
     double *edges = edges_in_lds ? reinterpret_cast<double *>(redraw_smem) : nullptr;
-    if (edges) {                                         // upper edge of every chunk (offsets[c + 1])
-        for (int c = threadIdx.x; c < (int)chunks; c += SCAN_THREADS) edges[lds_skew(c)] = offsets[c + 1];
+    if (edges) {                                         // upper edge of every chunk (offsets[c + 1]); read after the
+        for (int c = threadIdx.x; c < (int)chunks; c += SCAN_THREADS) edges[lds_skew(c)] = offsets[c + 1];   // scans' barriers
     }
-    if (!max_ready && w) {                                           // (max_ready: a full-grid k_chunk_max ran before this launch)
-        for (int64_t c = blockIdx.x; c < chunks; c += gridDim.x) chunk_max_block(w, n_in, c, wave_tot, chunk_max);
+    if (!cdf_ready) {                                                // (cdf_ready: a full-grid k_chunk_scan ran before this launch)
+        for (int64_t c = blockIdx.x; c < chunks; c += gridDim.x) {
+            chunk_scan_block(w, n_in, inv_norm, offsets, c, wave_tot, StoreGlobal{cdf + c * SCAN_CHUNK});
+            __syncthreads();                                         // wave_tot is reused by the next chunk
+        }
         grid_barrier_fenced(bar);
     }
     __syncthreads();
@@ -1508,8 +1467,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_bucket_redraw(
          i += (unsigned long long)gridDim.x * SCAN_THREADS) {
         const int64_t o = (int64_t)retry_list[i];
         double p[DM];
-        const bool ok = redraw_rounds<DM>(kind, d, min_freq, x_in, ldx_in, n_in, w, chunk_max, offsets, lw, k0, k1, epoch,
-                                          maxiter, o, p, edges, (int)chunks);
+        const bool ok = redraw_rounds<DM>(kind, d, min_freq, x_in, ldx_in, n_in, cdf, lw, k0, k1, epoch,
+                                                  maxiter, o, p, edges, (int)chunks);
         const int64_t row = place_row(pl, o);      // like the in-thread loop: the last round's value stays
         for (int m = 0; m < d; ++m) x_out[m * pl.ld_m + row * pl.ld_s] = p[m];
         if (!ok) ++failed;

@@ -1381,12 +1381,14 @@ static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int3
     const double inv_norm = 1.0 / norm;
     unsigned long long *nf = reinterpret_cast<unsigned long long *>(h->counter);
     unsigned long long *retry_count = nf + 1;
+    if (!split16) {
+        rc = ensure_cdf(h, (size_t)n_in);
+        if (rc) return rc;
+    }
     BucketPlan bp;
     rc = bucket_plan_layout(h, chunks64, n_out, &bp, split16);      // no reallocation: the prefix sized it
     if (rc) return rc;
     if (!bp.bucketed) {
-        rc = ensure_cdf(h, (size_t)n_in);                            // (the direct sampler searches a materialised CDF)
-        if (rc) return rc;
         // small or very large clouds: materialise the CDF and search it directly
         hipLaunchKernelGGL(k_chunk_scan, dim3((unsigned)chunks64), dim3(SCAN_THREADS), 0, s, w, n_in, inv_norm, offsets,
                            h->cdf_scratch, (const unsigned long long *)nullptr);
@@ -1466,26 +1468,21 @@ static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int3
             // Models whose postselection bites at every resample (RB: the cloud leans on A + B <= 1) spent ~300 us in
             // that kernel's scan phase -- 256 workgroups walking 3000 chunks in a dozen rounds behind a grid barrier --
             // so if the PREVIOUS resample on this handle queued redraws (its count came back with the last
-            // host-visible reduction), what the redraws need beside the plan -- round 2: the whole CDF (k_chunk_scan,
-            // 75 us, 100 MB written); round 3: each chunk's largest weight (k_chunk_max, one read of the weights) -- is
-            // produced by a full-grid gated launch first and the redraw kernel skips that phase and its barrier.  Same
-            // particles either way.
+            // host-visible reduction), the CDF is materialised by a full-grid gated k_chunk_scan first (40 us when
+            // the gate is open, ~5 us when it is not) and the redraw kernel skips its scan and its barrier.  Same CDF,
+            // same particles either way.
             static const bool never_split = getenv("QSMC_REDRAW_ONE_LAUNCH") != nullptr;      // (A/B switch)
-            const bool expect_redraws = !never_split && w && h->mapped[REDUCE_OUT_MAX - 2] > 0.0;
-            // the redraws reject against each chunk's largest weight (redraw_rounds): chunks doubles of scratch
-            rc = ensure_cdf(h, (size_t)chunks64 + 8);
-            if (rc) return rc;
-            double *chunk_max = h->cdf_scratch;
+            const bool expect_redraws = !never_split && h->mapped[REDUCE_OUT_MAX - 2] > 0.0;
             if (expect_redraws)
-                hipLaunchKernelGGL(k_chunk_max, dim3((unsigned)chunks64), dim3(SCAN_THREADS), 0, s, w, n_in, chunk_max,
-                                   (const unsigned long long *)retry_count);
+                hipLaunchKernelGGL(k_chunk_scan, dim3((unsigned)chunks64), dim3(SCAN_THREADS), 0, s, w, n_in, inv_norm,
+                                   offsets, h->cdf_scratch, (const unsigned long long *)retry_count);
             // the chunk edges ride in LDS (first level of the redraw's ancestor search) while they fit 48 KB
             const size_t edges_lds = (size_t)(chunks64 + (chunks64 >> 5) + (chunks64 >> 10) + 4) * sizeof(double);      // (lds_skew)
             const int edges_in_lds = edges_lds <= 48 * 1024 ? 1 : 0;
             hipLaunchKernelGGL((d <= 4 ? k_bucket_redraw<4> : k_bucket_redraw<QSMC_MAX_D>),
                                dim3(expect_redraws ? 1024 : redraw_blocks), dim3(SCAN_THREADS),
                                edges_in_lds ? edges_lds : 0, s, model->kind, d,
-                               model->min_freq, x_in, ldx_in, n_in, w, offsets, chunks64, chunk_max, lw,
+                               model->min_freq, x_in, ldx_in, n_in, w, inv_norm, offsets, chunks64, h->cdf_scratch, lw,
                                k0, k1, ep, maxiter, x_out, pl, bp.retry_list, retry_count, nf, h->gbar + 2,
                                expect_redraws ? 1 : 0, edges_in_lds);
         }
