@@ -658,38 +658,14 @@ __device__ __forceinline__ bool redraw_rounds(int kind, int d, double min_freq, 
             int c = upper_bound_skew(edges, chunks, u0);
             if (c > chunks - 1) c = chunks - 1;
             const int64_t base = (int64_t)c * SCAN_CHUNK;
-            const int len = (int)(n_in - base < SCAN_CHUNK ? n_in - base : SCAN_CHUNK);
-            // Upper bound inside the chunk's 4096 CDF entries (32 KB of global memory).  A plain binary search is 12
-            // dependent loads from 12 different cache lines (717 MB of line traffic per million redraws, round 2).  The CDF
-            // of a chunk is a sum of thousands of weights, i.e. close to a straight line between its two edges: start at
-            // the interpolated position, bracket the answer by doubling steps (8, 16, ... entries), then bisect inside the
-            // bracket -- the same index (everything below `lo` is <= u, everything from `hi` on is > u, at every step),
-            // from 3-4 neighbouring lines instead of 12 scattered ones.
-            const double c_lo = c > 0 ? edges[lds_skew(c - 1)] : 0.0, c_hi = edges[lds_skew(c)];
-            int lo = 0, hi = len;
-            if (c_hi > c_lo) {
-                const double f = (u0 - c_lo) / (c_hi - c_lo) * (double)len;
-                int g = f > 0.0 ? (f < (double)(len - 1) ? (int)f : len - 1) : 0;
-                const double* row = cdf + base;
-                if (row[g] <= u0) {
-                    lo = g + 1;
-                    int step = 8;
-                    while (lo < len) {
-                        const int probe = lo + step - 1 < len - 1 ? lo + step - 1 : len - 1;
-                        if (row[probe] <= u0) { lo = probe + 1; step <<= 1; } else { hi = probe; break; }
-                    }
-                    if (lo >= len) hi = len;
-                } else {
-                    hi = g;
-                    int step = 8;
-                    while (hi > 0) {
-                        const int probe = hi - step > 0 ? hi - step : 0;
-                        if (row[probe] <= u0) { lo = probe + 1; break; } else { hi = probe; step <<= 1; }
-                    }
-                }
-            }
+            const int64_t len = n_in - base < SCAN_CHUNK ? n_in - base : SCAN_CHUNK;
+            // (round 3 tried an interpolated starting point + galloping bracket here -- 3-4 neighbouring cache lines instead
+            //  of 12 scattered ones, same index: no change, 145 vs 140 us per launch at a million redraws -- and a CDF-free
+            //  rejection draw against each chunk's largest weight, which weights that are products of a dozen likelihoods
+            //  make five times slower; tools/experiments/r3_redraw_by_rejection.patch)
+            int64_t lo = 0, hi = len;
             while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
+                const int64_t mid = (lo + hi) >> 1;
                 if (cdf[base + mid] <= u0) lo = mid + 1; else hi = mid;
             }
             j = base + lo < n_in - 1 ? base + lo : n_in - 1;
