@@ -192,6 +192,10 @@ typedef struct qsmc_step_lw {
     int32_t  canon_kind;         /* d = 16 tomography, canonicalize folded into the resample (qsmc_lw_fuse_canonicalize): */
     int32_t  canon_allow_sub;    /*   0 = no, 1 = the 2-qubit Pauli basis, 2 = a dense basis; allow_subnormalized         */
     const double *canon_basis;   /*   device basis tensor (dense) or NULL (Pauli)                                         */
+    int64_t  redraws_seen;       /* first tries of this cloud's LAST resample that failed postselection (maintained by    */
+    int32_t  redraw_pending;     /*   qsmc_step: read back with the next update's sums while redraw_pending != 0; the      */
+    int32_t  reserved2;          /*   caller sets redraw_pending after a resample of its own, 0 / 0 after a reset): what  */
+                                 /*   the next resample is told to expect (qsmc_lw_expect_redraws)                         */
 } qsmc_step_lw_t;
 typedef struct qsmc_step {
     /* the cloud -- kept current by the caller; w / w_alt / norm / sumsq / min_n_ess advance here on commit */
@@ -433,6 +437,15 @@ int qsmc_lw_prefix_stats(qsmc_handle_t h, int64_t *n_queued, int64_t *n_adopted)
  * QSMC_ERR_UNSUPPORTED from the resample) by that call; any call that changes weights clears it. */
 int qsmc_lw_fuse_canonicalize(qsmc_handle_t h, const double *basis, int32_t dim, int32_t basis_kind,
                               int32_t allow_subnormalized);
+
+/* Postselection without global redraws (resamplers.py:341-372) for models whose constraint bites at every resample (RB):
+ * n_expected = how many first tries of THIS cloud's previous resample failed postselection (qsmc_last_resample_redraws
+ * after the update that followed it).  One-shot, consumed by the next qsmc_lw_resample_philox: with n_expected > 0 and
+ * d = 3 or 4 the ordered sampler also produces ~1.25 n_expected spare proposals (ancestor ~ w, kick: exactly what a
+ * redraw draws) while each chunk's CDF is in LDS anyway, and a failed slot is served spares -- in an order that does not
+ * depend on their values -- until one is valid; only slots the bank could not serve go to the global-CDF redraw kernel.
+ * Same law; different particles than with n_expected = 0 (the redraws consume other Philox blocks); deterministic. */
+int qsmc_lw_expect_redraws(qsmc_handle_t h, int64_t n_expected);
 
 /* qsmc_lw_resample_philox with n_failed_host == NULL does not synchronise: the failed-particle count
  * is written to pinned host memory by the stream; read it here once `stream` has been synchronised by

@@ -98,17 +98,17 @@ def liu_west_philox(w, x, valid_fn, a, h, seed, epoch, n_out, maxiter=1000, post
 BUCKET_CHUNK = 4096
 
 
-def _pair_word(ids, seed, epoch, slot):
-    """word (id & 1) of Philox block (id >> 1, round 0, slot): two outputs share one block."""
+def _pair_word(ids, seed, epoch, slot, rnd=0):
+    """word (id & 1) of Philox block (id >> 1, round `rnd`, slot): two outputs share one block."""
     ids = np.asarray(ids, dtype=np.int64)
-    ua, ub = uniforms(ids >> 1, seed, epoch, 0, slot)
+    ua, ub = uniforms(ids >> 1, seed, epoch, rnd, slot)
     return np.where(ids & 1, ub, ua)
 
 
-def _pair_normal(n_idx, seed, epoch, slot):
-    """Box-Muller component (n & 1) of block (n >> 1, round 0, slot)."""
+def _pair_normal(n_idx, seed, epoch, slot, rnd=0):
+    """Box-Muller component (n & 1) of block (n >> 1, round `rnd`, slot)."""
     n_idx = np.asarray(n_idx, dtype=np.int64)
-    za, zb = normals(n_idx >> 1, seed, epoch, 0, slot)
+    za, zb = normals(n_idx >> 1, seed, epoch, rnd, slot)
     return np.where(n_idx & 1, zb, za)
 
 
@@ -126,7 +126,7 @@ def _stirling_tail(k):
     return (1.0 / 12.0 - (1.0 / 360.0 - (1.0 / 1260.0 - (1.0 / 1680.0 - 1.0 / 1188.0 * r2) * r2) * r2) * r2) * rx
 
 
-def poisson_draw(mu, node, seed, epoch):
+def poisson_draw(mu, node, seed, epoch, rnd=0):
     """X ~ Poisson(mu) exactly as poisson_draw of the device library (csrc/kernels/resample.hpp): sequential search of
     the cdf for mu < 10, PTRS (W. Hoermann, Insurance: Mathematics and Economics 12 (1993) 39: transformed
     rejection with squeeze) otherwise; attempt t of chunk `node` consumes Philox block (node | t << 32, round 0,
@@ -137,7 +137,7 @@ def poisson_draw(mu, node, seed, epoch):
     f = float
 
     def block(t):
-        u, v = uniforms(np.array([node | (t << 32)], dtype=np.int64), seed, epoch, 0, 0)
+        u, v = uniforms(np.array([node | (t << 32)], dtype=np.int64), seed, epoch, rnd, 0)
         return f(u[0]), f(v[0])
 
     def ln(x):
@@ -216,8 +216,109 @@ def bucket_cap(n_out):
     return cap
 
 
+BANK_ROUNDS, BANK_MAX_PER_ITEM = 7, 4096
+_M64 = (1 << 64) - 1
+
+
+def bank_keys(seed, epoch):
+    """The four keys of the bank's bijection (qsmc_kernels.hip: bank_layout): splitmix64 from seed and epoch."""
+    x = (int(seed) ^ ((int(epoch) * 0xD1342543DE82EF95) & _M64) ^ 0x62616E6B) & _M64
+    keys = []
+    for _ in range(4):
+        x = (x + 0x9E3779B97F4A7C15) & _M64
+        z = x
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+        keys.append(z ^ (z >> 31))
+    return keys
+
+
+def bank_perm(g, n, key):
+    """kernels/resample.hpp: bank_perm -- a keyed bijection of [0, n), cycle-walked on ceil(log2 n) bits."""
+    if n < 2:
+        return 0
+    b = 1
+    while (1 << b) < n:
+        b += 1
+    mask = (1 << b) - 1
+    s1, s2 = max(b // 2, 1), max((b + 2) // 3, 1)
+    x = int(g)
+    while True:
+        x = (x * 0x9E3779B97F4A7C15 + key[0]) & mask
+        x ^= x >> s1
+        x = (x * 0xBF58476D1CE4E5B9 + key[1]) & mask
+        x ^= x >> s2
+        x = (x * 0x94D049BB133111EB + key[2]) & mask
+        x ^= x >> s1
+        x = (x * 0xD6E8FEB86659FD93 + key[3]) & mask
+        x ^= x >> s2
+        if x < n:
+            return x
+
+
+def bank_spares(x, cdf, edges, counts, cap, lam, a, mean, S, valid_fn, seed, epoch):
+    """The proposal bank as k_bucket_sample_ordered fills it: per work item (chunk, part) e_i ~ Poisson(lam mass / total /
+    parts) spares (block (item, attempt), round tag 0xFFFE); spare k of item i: position from word k & 1 of block
+    ((i << 12) | k >> 1, round tag 0xFFFF, slot 1), normals from the same pair id (slot 2), ancestor NOT sorted.
+    Returns (values (E, d), valid (E,)) in the bank's logical order: items ascending, spares in order."""
+    N, d = x.shape
+    chunks = len(edges)
+    total = float(edges[-1])
+    vals, oks = [], []
+    item = 0
+    for c in range(chunks):
+        parts = -(-int(counts[c]) // cap)
+        lo = 0.0 if c == 0 else float(edges[c - 1])
+        hi = float(edges[c])
+        for _ in range(parts):
+            mu = lam * ((hi - lo) / total) / float(parts) if (total > 0.0 and hi > lo) else 0.0
+            e_i = min(poisson_draw(mu, item, seed, epoch, rnd=0xFFFE), BANK_MAX_PER_ITEM)
+            if e_i:
+                ids = 2 * ((item << 12) + (np.arange(e_i) >> 1)) + (np.arange(e_i) & 1)
+                u = lo + _pair_word(ids, seed, epoch, 1, rnd=0xFFFF) * (hi - lo)
+                base, end = c * BUCKET_CHUNK, min((c + 1) * BUCKET_CHUNK, N)
+                js = np.minimum(np.maximum(np.searchsorted(cdf, u, side='right'), base), end - 1)
+                z = np.stack([_pair_normal(ids * d + q, seed, epoch, 2, rnd=0xFFFF) for q in range(d)])
+                v = (a * x[js] + (1 - a) * mean) + (S @ z).T
+                vals.append(v)
+                oks.append(valid_fn(v))
+            item += 1
+    if not vals:
+        return np.zeros((0, d)), np.zeros((0,), dtype=bool)
+    return np.concatenate(vals), np.concatenate(oks)
+
+
+def bank_serve(failed_slots, bank_vals, bank_ok, out, seed, epoch):
+    """k_bank_round: round t hands the j-th slot still failed (ascending slot order, order kept from round to round)
+    spare perm(B_t + j).  Returns the slots left for the global-CDF redraw."""
+    E = bank_vals.shape[0]
+    key = bank_keys(seed, epoch)
+    todo = np.sort(np.asarray(failed_slots, dtype=np.int64))
+    leftover = []
+    B = 0
+    for _ in range(BANK_ROUNDS):
+        nxt = []
+        for j, slot in enumerate(todo):
+            g = B + j
+            if g >= E:
+                leftover.append(int(slot))
+                continue
+            pg = bank_perm(g, E, key)
+            if bank_ok[pg]:
+                out[slot] = bank_vals[pg]
+            else:
+                nxt.append(int(slot))
+        B += len(todo)
+        todo = np.asarray(nxt, dtype=np.int64)
+        if not todo.size:
+            break
+    leftover.extend(int(v) for v in todo)
+    return np.asarray(leftover, dtype=np.int64)
+
+
 def liu_west_philox_bucketed(w, x, valid_fn, a, h, seed, epoch, n_out, maxiter=1000, postselect=True,
-                             mean=None, cov=None, zero_cov_comp=1e-10, cdf=None, margin=5.0, sort_items=None):
+                             mean=None, cov=None, zero_cov_comp=1e-10, cdf=None, margin=5.0, sort_items=None,
+                             expect_redraws=0):
     """Oracle of the bucketed device-RNG resampler (k_bucket_counts / k_bucket_sample).  Outputs are
     ordered by ancestor CHUNK.  Stream layout (round 0, two outputs per Philox block):
       slot 0: the Poisson chunk counts, slots 3 / 4 their top-up / removal (poissonised_counts); slot 1:
@@ -261,6 +362,12 @@ def liu_west_philox_bucketed(w, x, valid_fn, a, h, seed, epoch, n_out, maxiter=1
     out = (a * x[js] + (1 - a) * mean) + (S @ z).T
     ok = valid_fn(out) if postselect else np.ones(n_out, dtype=bool)
     todo = ids[~ok]
+    if expect_redraws > 0 and postselect and maxiter > 1 and d in (3, 4):
+        # the proposal bank (qsmc_lw_expect_redraws): spares made by the sampler serve the failed first tries
+        m = 1.25 * float(expect_redraws)
+        lam = m + 6.0 * float(np.sqrt(m)) + 64.0
+        bank_vals, bank_ok = bank_spares(x, cdf, edges, counts, bucket_cap(n_out), lam, a, mean, S, valid_fn, seed, epoch)
+        todo = bank_serve(todo, bank_vals, bank_ok, out, seed, epoch)
     for rnd in range(1, maxiter):
         if not todo.size:
             break

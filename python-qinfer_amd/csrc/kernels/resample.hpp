@@ -991,6 +991,42 @@ __global__ __launch_bounds__(BT) void k_bucket_sample(
 // A pair straddling two work items is evaluated by both, each writing only its own half.
 // Occupancy: ~50 KB of LDS, 80 - 90 VGPRs at d = 3, 4: two to three workgroups per CU.
 // ---------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------
+// Proposal bank (round 3): postselection without global redraws, for models whose constraint bites at EVERY resample
+// (RB: A + B <= 1 runs through the cloud; 8 % of the first-try children fail at N = 1.25e7, a million of them).
+// Round 2 sent each of them back to the global CDF: a 100 MB scan + write (k_chunk_scan, 75 us) and a redraw kernel of
+// scattered searches and gathers (k_bucket_redraw, 145-170 us, 717 MB of line traffic) per resample.
+// A redraw is nothing but a FRESH proposal -- ancestor ~ w, kick -- so the sampler now also produces a bank of spare
+// proposals while every chunk's CDF is in LDS anyway, and a failed slot takes bank entries until one is valid:
+//   * how many spares each work item makes is Poisson(lambda mass_item / total), independently per item: given their
+//     total E the spares' ancestors are then i.i.d. ~ w (Poissonisation again), whatever E turns out to be;
+//   * a spare = position in the chunk (Philox round tag 0xFFFF, block (item, pair), slot 1) -> LDS search -> gather ->
+//     kick (normals: round tag 0xFFFF, blocks ((item << 12 | pair) d + q, slot 2)) -> validity flag, written to the
+//     item's reservation in the bank (one atomic per item; WHERE the reservation lands is timing, WHAT it holds is not);
+//   * the failed first tries of an item are listed in ascending slot order (a bit mask in LDS, not an atomic append),
+//     so "the j-th failed slot" and "the g-th spare" (items in order, spares in pair order) mean the same on every run;
+//   * k_bank_round t = 1, 2, ...: the j-th slot still failed takes spare perm(B_t + j), perm a keyed bijection of
+//     [0, E) (a fixed one would hand the early chunks' spares to the early chunks' failures; which spares are consumed
+//     must not depend on where they came from), B_t = spares handed out before round t.  Valid: the slot is done.
+//     Invalid: it is listed again (block-local compaction + k_bank_scan's prefix of the block counts) for round t + 1.
+//     Each spare is looked at once, each failed slot gets independent proposals: the law of the redraw loop
+//     (resamplers.py:341-372), without its search.  BANK_ROUNDS rounds are queued (8 % -> 0.6 % -> ... a million
+//     failures are through in six); slots left after that, or past the end of the bank, go to k_bucket_redraw.
+// Deterministic for given Philox keys; oracle/philox.py (bank_*) mirrors it entry for entry.
+// ---------------------------------------------------------------------------------------------
+constexpr int BANK_STRIDE = 8;                       // doubles per bank entry: x[0..d), d <= 4, then ..., [7] = valid flag
+constexpr int BANK_MAX_PER_ITEM = 4096;              // spares per work item (8 per thread, kept in registers between phases)
+constexpr int BANK_ROUNDS = 7;
+constexpr int BANK_VB = 512;                         // entries per (virtual) block of a round
+struct BankOut {
+    double lambda;                                   // expected spares over the whole launch; 0: no bank
+    double *entries;                                 // [capacity][BANK_STRIDE]
+    unsigned long long *top;                         // spares reserved so far
+    long long capacity;
+    int *e_cnt, *f_cnt;                              // per work item: spares made / first tries failed
+    long long *e_base, *f_base;                      // per work item: where its spares / its failed slots (retry_list) start
+};
+
 constexpr int SMP_HEAVY = 24, SMP_HEAVY_CAP = BUCKET_CAP / SMP_HEAVY + 8;
 
 template <int D, int BT>   // D = 0: runtime d; BT = threads per workgroup.  (Held to 80 VGPRs for a third workgroup per
@@ -1002,7 +1038,7 @@ __global__ __launch_bounds__(BT) void k_bucket_sample_ordered(
     const int *__restrict__ item_off, const int *__restrict__ item_chunk, LWArgs lw, uint32_t k0, uint32_t k1,
     uint32_t epoch, int maxiter, double *__restrict__ x_out, OutPlace pl,
     unsigned long long *__restrict__ n_failed, unsigned int *__restrict__ retry_list,
-    unsigned long long *__restrict__ retry_count, int cap) {
+    unsigned long long *__restrict__ retry_count, int cap, BankOut bank) {
     constexpr int DM = D > 0 ? D : QSMC_MAX_D;
     const int d = D > 0 ? D : d_rt;
     __shared__ __attribute__((aligned(32))) double lcdf[BUCKET_CHUNK];
@@ -1012,12 +1048,17 @@ __global__ __launch_bounds__(BT) void k_bucket_sample_ordered(
     __shared__ double wave_tot[SCAN_WAVES];
     __shared__ int iwave_tot[SCAN_WAVES];
     __shared__ unsigned int heavy[2 * SMP_HEAVY_CAP];
-    __shared__ unsigned short rlist[BUCKET_RLIST_CAP];          // slot - o_begin < cap
+    __shared__ unsigned int failmask[BUCKET_CAP / 32];          // bit (slot - o_begin): the first try failed postselection
     static_assert(BT == SCAN_THREADS, "one lane owns 8 consecutive source particles: 512 threads per chunk");
     static_assert(BUCKET_CAP * 2 <= BUCKET_CHUNK * 8, "the ancestor list overlays the CDF");
-    __shared__ int rcount, hcount;
-    __shared__ unsigned long long rbase;
-    if ((int)blockIdx.x >= item_off[chunks]) return;
+    static_assert(BUCKET_CAP / 32 <= BT, "one thread per word of the failure mask");
+    __shared__ int hcount;
+    __shared__ long long rbase, ebase_s;
+    const bool banked = bank.lambda > 0.0;                      // (uniform)
+    if ((int)blockIdx.x >= item_off[chunks]) {
+        if (banked && threadIdx.x == 0) { bank.e_cnt[blockIdx.x] = 0; bank.f_cnt[blockIdx.x] = 0; }
+        return;
+    }
     const int c = item_chunk[blockIdx.x];
     const int part = (int)blockIdx.x - item_off[c];
     const long long slot0 = slot_off[c], n_c = slot_off[c + 1] - slot0;
@@ -1025,7 +1066,8 @@ __global__ __launch_bounds__(BT) void k_bucket_sample_ordered(
     const long long t1 = t0 + cap < n_c ? t0 + cap : n_c;
     const int64_t base = (int64_t)c * BUCKET_CHUNK;
     const int len = (int)((n_in - base) < BUCKET_CHUNK ? (n_in - base) : BUCKET_CHUNK);
-    if (threadIdx.x == 0) { rcount = 0; hcount = 0; }
+    if (threadIdx.x == 0) hcount = 0;
+    if (threadIdx.x < BUCKET_CAP / 32) failmask[threadIdx.x] = 0u;
     for (int k = threadIdx.x; k < BUCKET_CHUNK / 2; k += BT) cnt2[k] = 0u;
     const double lo_edge = chunk_edge(offsets, c);
     const double hi_edge = offsets[c + 1];
@@ -1050,7 +1092,43 @@ __global__ __launch_bounds__(BT) void k_bucket_sample_ordered(
             if (o >= o_begin && o < o_end) atomicAdd(&cnt2[j >> 1], 1u << (16 * (j & 1)));
         }
     }
+    // ---- 1x: the spares of the proposal bank.  e_i ~ Poisson(lambda mass / total / parts): the parts of a split chunk
+    // share its mass evenly (independent Poissons add up to the chunk's).  Their ancestors are found now, while the CDF
+    // is still in LDS, and wait in registers (two 16-bit indices a word) until the primaries have been kicked.
+    int e_i = 0;
+    unsigned int jx[BANK_MAX_PER_ITEM / (2 * BT)];
+    if (banked) {
+        const int parts = item_off[c + 1] - item_off[c];
+        const double total = offsets[chunks];
+        const double mu = (total > 0.0 && hi_edge > lo_edge) ? bank.lambda * ((hi_edge - lo_edge) / total) / (double)parts : 0.0;
+        e_i = (int)poisson_draw(true, mu, (uint32_t)blockIdx.x, (epoch << 16) | 0xFFFEu, k0, k1, POISSON_G,
+                                lane & ~(POISSON_G - 1));
+        e_i = e_i < BANK_MAX_PER_ITEM ? e_i : BANK_MAX_PER_ITEM;
+        if (threadIdx.x == 0) {
+            long long eb = e_i ? (long long)atomicAdd(bank.top, (unsigned long long)e_i) : 0ll;
+            if (eb + e_i > bank.capacity) eb = -1;             // (cannot happen with the host's sizing; the item then banks nothing)
+            ebase_s = eb;
+        }
+#pragma unroll
+        for (int k = 0; k < BANK_MAX_PER_ITEM / (2 * BT); ++k) {
+            const int P = (int)threadIdx.x + k * BT;            // spare pair P: spares 2 P, 2 P + 1 of this item
+            jx[k] = 0u;
+            if (2 * P < e_i) {
+                PhiloxStream rng{((uint64_t)blockIdx.x << 12) | (uint64_t)P, (epoch << 16) | 0xFFFFu, k0, k1};
+                double upos[2];
+                rng.uniforms(1, upos[0], upos[1]);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const double u = lo_edge + upos[e] * (hi_edge - lo_edge);
+                    int j = table_upper_bound(lcdf, ltops, lguide, (len + 7) >> 3, use_guide, lo_edge, gscale, u);
+                    j = j > len - 1 ? len - 1 : j;
+                    jx[k] |= (unsigned int)j << (16 * e);
+                }
+            }
+        }
+    }
     __syncthreads();
+    if (banked && ebase_s < 0) e_i = 0;
     // ---- 2: the ancestors in ascending order (lane l owns particles 8 l .. 8 l + 7; the list overlays the CDF)
     unsigned short *sorted = reinterpret_cast<unsigned short *>(lcdf);
     {
@@ -1136,10 +1214,8 @@ __global__ __launch_bounds__(BT) void k_bucket_sample_ordered(
                 }
                 bool ok = !postselect || model_valid(kind, p, min_freq);
                 if (!ok && maxiter > 1) {
-                    // queue for k_bucket_redraw (needs the global CDF)
-                    const int idx = atomicAdd(&rcount, 1);
-                    if (idx < BUCKET_RLIST_CAP) rlist[idx] = (unsigned short)(o - o_begin);
-                    else retry_list[atomicAdd(retry_count, 1ull)] = (unsigned int)o;   // rare overflow path
+                    // listed for the proposal bank / k_bucket_redraw: a bit per slot, so that the list comes out in slot order
+                    atomicOr(&failmask[(unsigned int)(o - o_begin) >> 5], 1u << ((unsigned int)(o - o_begin) & 31u));
                     ok = true;                      // decided later
                 }
                 const int64_t row = place_row(pl, o);
@@ -1150,13 +1226,250 @@ __global__ __launch_bounds__(BT) void k_bucket_sample_ordered(
             }
         }
     }
+    // ---- 3x: the spares are kicked like any slot (their own normals) and banked with their validity
+    if (banked && e_i > 0) {
+        const long long eb = ebase_s;
+#pragma unroll
+        for (int k = 0; k < BANK_MAX_PER_ITEM / (2 * BT); ++k) {
+            const int P = (int)threadIdx.x + k * BT;
+            if (2 * P < e_i) {
+                double z[2 * DM];
+                PhiloxStream nrm{0, (epoch << 16) | 0xFFFFu, k0, k1};
+#pragma unroll
+                for (int q = 0; q < DM; ++q) {
+                    if (q < d) {
+                        nrm.particle = (((uint64_t)blockIdx.x << 12) | (uint64_t)P) * (uint64_t)d + (uint64_t)q;
+                        nrm.normals(2, z[2 * q], z[2 * q + 1]);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    if (2 * P + e < e_i) {
+                        const int jl = (int)((jx[k] >> (16 * e)) & 0xffffu);
+                        double *ent = bank.entries + (eb + 2 * P + e) * BANK_STRIDE;
+                        double p[DM];
+#pragma unroll
+                        for (int m = 0; m < DM; ++m) {
+                            if (m < d) {
+                                double sm = 0.0;
+#pragma unroll
+                                for (int q = 0; q < DM; ++q)
+                                    if (q < d) sm += lw.S[m * d + q] * z[e * d + q];
+                                p[m] = (lw.a * x_in[m * ldx_in + base + jl] + (1.0 - lw.a) * lw.mean[m]) + sm;
+                                if (m < BANK_STRIDE - 1) ent[m] = p[m];
+                            }
+                        }
+                        ent[BANK_STRIDE - 1] = model_valid(kind, p, min_freq) ? 1.0 : 0.0;
+                    }
+                }
+            }
+        }
+    }
     if (failed) atomicAdd(n_failed, failed);
     __syncthreads();
-    const int nl = rcount < BUCKET_RLIST_CAP ? rcount : BUCKET_RLIST_CAP;
-    if (nl == 0) return;
-    if (threadIdx.x == 0) rbase = atomicAdd(retry_count, (unsigned long long)nl);   // one atomic per workgroup
+    // the failed first tries, in ascending slot order: word t of the mask belongs to thread t
+    {
+        const unsigned int word = threadIdx.x < BUCKET_CAP / 32 ? failmask[threadIdx.x] : 0u;
+        const int pc = __popc(word);
+        int inc = pc;
+#pragma unroll
+        for (int off = 1; off < QSMC_WAVE; off <<= 1) {
+            const int t = __shfl_up(inc, off, QSMC_WAVE);
+            if (lane >= off) inc += t;
+        }
+        if (lane == QSMC_WAVE - 1) iwave_tot[wave] = inc;
+        __syncthreads();
+        int off0 = inc - pc, nl = 0;
+        for (int wv = 0; wv < SCAN_WAVES; ++wv) {
+            if (wv < wave) off0 += iwave_tot[wv];
+            nl += iwave_tot[wv];
+        }
+        if (threadIdx.x == 0) {
+            rbase = nl ? (long long)atomicAdd(retry_count, (unsigned long long)nl) : 0ll;      // one atomic per workgroup
+            if (banked) {
+                bank.e_cnt[blockIdx.x] = e_i;
+                bank.e_base[blockIdx.x] = ebase_s;
+                bank.f_cnt[blockIdx.x] = nl;
+                bank.f_base[blockIdx.x] = rbase;
+            }
+        }
+        __syncthreads();
+        unsigned int bits = word;
+        long long at = rbase + off0;
+        while (bits) {
+            const int bpos = __ffs((int)bits) - 1;
+            bits &= bits - 1u;
+            retry_list[at++] = (unsigned int)(o_begin + 32 * (int)threadIdx.x + bpos);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The bank's consumer: see the "Proposal bank" block above k_bucket_sample_ordered.
+// ctr layout (long long): [0] E, [1] F (failed first tries), [2] leftover count (unsigned, bumped atomically),
+//                         [8 + t] F_t, [24 + t] B_t for round t = 1 ..
+// ---------------------------------------------------------------------------------------------
+struct BankIn {
+    const double *entries;
+    const int *e_cnt, *f_cnt;
+    const long long *e_base, *f_base;
+    long long *e_off, *f_off;                         // [max_items + 1] exclusive prefixes over the work items
+    long long *ctr;
+    unsigned int *tmp[2];                             // failed slots of a round, virtual block by virtual block
+    int *bcount[2];                                   // ... how many in each virtual block
+    long long *boff[2];                               // ... and their exclusive prefix
+    unsigned int *leftover;                           // slots for k_bucket_redraw
+    unsigned long long key[4];                        // of the bijection
+};
+
+// a keyed bijection of [0, n): four rounds of (odd multiply, add key, xor-shift) on ceil(log2 n) bits, cycle-walked
+__host__ __device__ __forceinline__ unsigned long long bank_perm(unsigned long long g, unsigned long long n,
+                                                                 const unsigned long long *key) {
+    if (n < 2ull) return 0ull;
+    int b = 1;
+    while ((1ull << b) < n) ++b;
+    const unsigned long long mask = (1ull << b) - 1ull;
+    const int s1 = b / 2 > 0 ? b / 2 : 1, s2 = (b + 2) / 3 > 0 ? (b + 2) / 3 : 1;
+    unsigned long long x = g;
+    do {
+        x = (x * 0x9E3779B97F4A7C15ull + key[0]) & mask;
+        x ^= x >> s1;
+        x = (x * 0xBF58476D1CE4E5B9ull + key[1]) & mask;
+        x ^= x >> s2;
+        x = (x * 0x94D049BB133111EBull + key[2]) & mask;
+        x ^= x >> s1;
+        x = (x * 0xD6E8FEB86659FD93ull + key[3]) & mask;
+        x ^= x >> s2;
+    } while (x >= n);
+    return x;
+}
+
+// number of entries of the non-decreasing a[0..m) that are <= v
+__device__ __forceinline__ int upper_bound_ll(const long long *__restrict__ a, int m, long long v) {
+    int lo = 0, hi = m;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] <= v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// one workgroup: exclusive prefix of src[0..m) (int) into dst[0..m], total returned to every thread
+__device__ __forceinline__ long long block_exclusive_scan_i(const int *__restrict__ src, int m, long long *__restrict__ dst) {
+    __shared__ long long wtot[1024 / QSMC_WAVE];
+    __shared__ long long carry;
+    const int lane = threadIdx.x & (QSMC_WAVE - 1), wave = threadIdx.x / QSMC_WAVE, nw = blockDim.x / QSMC_WAVE;
+    if (threadIdx.x == 0) carry = 0ll;
     __syncthreads();
-    for (int i = threadIdx.x; i < nl; i += BT) retry_list[rbase + i] = (unsigned int)(o_begin + rlist[i]);
+    for (int base = 0; base < m; base += (int)blockDim.x) {
+        const int i = base + (int)threadIdx.x;
+        const long long v = i < m ? (long long)src[i] : 0ll;
+        long long inc = v;
+#pragma unroll
+        for (int off = 1; off < QSMC_WAVE; off <<= 1) {
+            const long long t = __shfl_up(inc, off, QSMC_WAVE);
+            if (lane >= off) inc += t;
+        }
+        if (lane == QSMC_WAVE - 1) wtot[wave] = inc;
+        __syncthreads();
+        long long off0 = carry + inc - v;
+        for (int wv = 0; wv < wave; ++wv) off0 += wtot[wv];
+        if (i < m) dst[i] = off0;
+        __syncthreads();
+        if (threadIdx.x == blockDim.x - 1) {
+            long long tot = 0ll;
+            for (int wv = 0; wv < nw; ++wv) tot += wtot[wv];
+            carry += tot;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) dst[m] = carry;
+    __syncthreads();
+    return carry;
+}
+
+// round 0: prefixes of the per-item counts; round t >= 1: prefix of round t's per-block failure counts
+__global__ __launch_bounds__(1024) void k_bank_scan(BankIn bk, const int *__restrict__ item_off, int chunks, int t) {
+    if (t == 0) {
+        const int n_items = item_off[chunks];
+        const long long E = block_exclusive_scan_i(bk.e_cnt, n_items, bk.e_off);
+        const long long F = block_exclusive_scan_i(bk.f_cnt, n_items, bk.f_off);
+        if (threadIdx.x == 0) {
+            bk.ctr[0] = E;
+            bk.ctr[1] = F;
+            bk.ctr[2] = 0ll;
+            bk.ctr[8 + 1] = F;
+            bk.ctr[24 + 1] = 0ll;
+        }
+        return;
+    }
+    const long long Ft = bk.ctr[8 + t];
+    const int nvb = (int)((Ft + BANK_VB - 1) / BANK_VB);
+    const long long next = block_exclusive_scan_i(bk.bcount[t & 1], nvb, bk.boff[t & 1]);
+    if (threadIdx.x == 0) {
+        bk.ctr[8 + t + 1] = next;
+        bk.ctr[24 + t + 1] = bk.ctr[24 + t] + Ft;
+    }
+}
+
+// round t: the j-th slot still failed (j < F_t) looks at spare perm(B_t + j)
+template <int DM>
+__global__ __launch_bounds__(BANK_VB) void k_bank_round(BankIn bk, const int *__restrict__ item_off, int chunks, int t, int d,
+                                                        const unsigned int *__restrict__ retry_list,
+                                                        double *__restrict__ x_out, OutPlace pl) {
+    __shared__ int wcount[BANK_VB / QSMC_WAVE];
+    const long long Ft = bk.ctr[8 + t];
+    if (Ft == 0ll) return;
+    const long long Bt = bk.ctr[24 + t], E = bk.ctr[0];
+    const int n_items = item_off[chunks];
+    const int lane = threadIdx.x & (QSMC_WAVE - 1), wave = threadIdx.x / QSMC_WAVE;
+    const int prev = (t - 1) & 1, cur = t & 1;
+    const int nvb_prev = t > 1 ? (int)((bk.ctr[8 + t - 1] + BANK_VB - 1) / BANK_VB) : 0;
+    for (long long vb = blockIdx.x; vb * BANK_VB < Ft; vb += gridDim.x) {
+        const long long j = vb * BANK_VB + threadIdx.x;
+        const bool live = j < Ft;
+        unsigned int slot = 0u;
+        bool fail = false;
+        if (live) {
+            if (t == 1) {
+                const int it = upper_bound_ll(bk.f_off, n_items + 1, j) - 1;
+                slot = retry_list[bk.f_base[it] + (j - bk.f_off[it])];
+            } else {
+                const int pb = upper_bound_ll(bk.boff[prev], nvb_prev + 1, j) - 1;
+                slot = bk.tmp[prev][(long long)pb * BANK_VB + (j - bk.boff[prev][pb])];
+            }
+            const long long g = Bt + j;
+            if (g >= E || t > BANK_ROUNDS) {
+                // the bank is exhausted (or the queued rounds are): the old way
+                const unsigned long long at = atomicAdd(reinterpret_cast<unsigned long long *>(bk.ctr + 2), 1ull);
+                bk.leftover[at] = slot;
+            } else {
+                const long long pg = (long long)bank_perm((unsigned long long)g, (unsigned long long)E, bk.key);
+                const int bi = upper_bound_ll(bk.e_off, n_items + 1, pg) - 1;
+                const double *ent = bk.entries + (bk.e_base[bi] + (pg - bk.e_off[bi])) * BANK_STRIDE;
+                if (ent[BANK_STRIDE - 1] != 0.0) {
+                    const int64_t row = place_row(pl, (int64_t)slot);
+#pragma unroll
+                    for (int m = 0; m < DM; ++m)
+                        if (m < d) x_out[m * pl.ld_m + row * pl.ld_s] = ent[m];
+                } else {
+                    fail = true;
+                }
+            }
+        }
+        // the still-failed of this virtual block, in order
+        const unsigned long long mk = __ballot(fail);
+        if (lane == 0) wcount[wave] = __popcll(mk);
+        __syncthreads();
+        int off0 = 0, tot = 0;
+        for (int wv = 0; wv < BANK_VB / QSMC_WAVE; ++wv) {
+            if (wv < wave) off0 += wcount[wv];
+            tot += wcount[wv];
+        }
+        if (fail) bk.tmp[cur][vb * BANK_VB + off0 + __popcll(mk & ((1ull << lane) - 1ull))] = slot;
+        if (threadIdx.x == 0) bk.bcount[cur][vb] = tot;
+        __syncthreads();
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -102,6 +102,7 @@ struct qsmc_ctx {
         int valid;
         int canon_kind, canon_allow_sub;
         const double *canon_basis;
+        double expect;
         qsmc_model_t model;
         int32_t postselect, d, maxiter;
         const double *x_in, *w;
@@ -113,6 +114,14 @@ struct qsmc_ctx {
         hipStream_t stream;
         long long n_queued, n_adopted;
     } rsq;
+    struct {                // proposal bank of the ordered sampler (kernels/resample.hpp): device buffers, grown on demand
+        double *entries;
+        long long capacity;           // in entries
+        unsigned char *aux;           // per-item arrays, prefixes, counters, round lists
+        size_t aux_cap;               // in bytes
+        long long n_banked, n_rounds_leftover;   // resamples that used the bank (diagnostic)
+    } bank;
+    double expect_next;     // qsmc_lw_expect_redraws: consumed by the next qsmc_lw_resample_philox
     unsigned int *anc16;    // device: ancestors + canonicalize list of the split d = 16 sampler
     size_t anc16_cap;       // in bytes
     unsigned int *iscratch; // device integer scratch for the bucketed resampler
@@ -626,6 +635,8 @@ int qsmc_destroy(qsmc_handle_t h) {
     if (h->spec.gate) (void)hipFree(h->spec.gate);
     if (h->iscratch) (void)hipFree(h->iscratch);
     if (h->anc16) (void)hipFree(h->anc16);
+    if (h->bank.entries) (void)hipFree(h->bank.entries);
+    if (h->bank.aux) (void)hipFree(h->bank.aux);
     if (h->cdf_scratch) (void)hipFree(h->cdf_scratch);
     if (h->red_out) (void)hipFree(h->red_out);
     if (h->mapped) (void)hipHostFree(h->mapped);
@@ -745,7 +756,7 @@ int qsmc_update_fused(qsmc_handle_t h, const qsmc_model_t *model, const double *
                       const double *w_in, double *w_out, double prev_norm, const qsmc_expparam_t *exp,
                       int64_t outcome, double *stats_dev, qsmc_update_stats_t *stats_host, double *moments_host,
                       qsmc_stream_t stream) {
-    if (h) { h->prep.valid = 0; h->rsq.valid = 0; h->canon_next.kind = 0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
+    if (h) { h->prep.valid = 0; h->rsq.valid = 0; h->canon_next.kind = 0; h->expect_next = 0.0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
     if (!h || !x || !w_out || !exp || n <= 0) return QSMC_ERR_INVALID;      // w_in == NULL: all-ones weights
     int rc = check_model(model);
     if (rc) return rc;
@@ -831,7 +842,7 @@ int qsmc_update_multi(qsmc_handle_t h, const qsmc_model_t *model, const double *
                       const double *w_in, double *w_out, double prev_norm, const qsmc_expparam_t *exps,
                       const int64_t *outcomes, int32_t k, qsmc_update_stats_t *stats_host, double *moments_host,
                       qsmc_stream_t stream) {
-    if (h) { h->prep.valid = 0; h->rsq.valid = 0; h->canon_next.kind = 0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
+    if (h) { h->prep.valid = 0; h->rsq.valid = 0; h->canon_next.kind = 0; h->expect_next = 0.0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
     if (!h || !x || !w_out || !exps || !outcomes || !stats_host || n <= 0 || k < 1 || k > MULTI_KMAX)
         return QSMC_ERR_INVALID;
     int rc = check_model(model);
@@ -915,14 +926,14 @@ int qsmc_hypothetical_sums(qsmc_handle_t h, const qsmc_model_t *model, const dou
 int qsmc_update_from_likelihood(qsmc_handle_t h, const double *L, int64_t n, const double *w_in,
                                 double *w_out, double prev_norm, double *stats_dev,
                                 qsmc_update_stats_t *stats_host, qsmc_stream_t stream) {
-    if (h) { h->prep.valid = 0; h->rsq.valid = 0; h->canon_next.kind = 0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
+    if (h) { h->prep.valid = 0; h->rsq.valid = 0; h->canon_next.kind = 0; h->expect_next = 0.0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
     if (!h || !L || !w_in || !w_out || n <= 0) return QSMC_ERR_INVALID;
     return weights_pass<0>(h, L, n, w_in, w_out, prev_norm, stats_dev, stats_host, (hipStream_t)stream);
 }
 
 int qsmc_clip_weights(qsmc_handle_t h, double *w, int64_t n, double norm, double *stats_dev,
                       qsmc_update_stats_t *stats_host, qsmc_stream_t stream) {
-    if (h) { h->prep.valid = 0; h->rsq.valid = 0; h->canon_next.kind = 0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
+    if (h) { h->prep.valid = 0; h->rsq.valid = 0; h->canon_next.kind = 0; h->expect_next = 0.0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
     if (!h || !w || n <= 0) return QSMC_ERR_INVALID;
     return weights_pass<1>(h, nullptr, n, w, w, norm, stats_dev, stats_host, (hipStream_t)stream);
 }
@@ -974,14 +985,14 @@ int qsmc_kde_cross_entropy(qsmc_handle_t h, const double *x, int64_t ldx, int64_
 
 int qsmc_normalize_weights(qsmc_handle_t h, const double *w_in, double *w_out, int64_t n, double norm,
                            qsmc_stream_t stream) {
-    if (h) { h->prep.valid = 0; h->rsq.valid = 0; h->canon_next.kind = 0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
+    if (h) { h->prep.valid = 0; h->rsq.valid = 0; h->canon_next.kind = 0; h->expect_next = 0.0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
     if (!h || !w_in || !w_out || n < 0) return QSMC_ERR_INVALID;
     if (n == 0) return QSMC_OK;
     return weights_pass<2>(h, nullptr, n, w_in, w_out, norm, nullptr, nullptr, (hipStream_t)stream);
 }
 
 int qsmc_fill(qsmc_handle_t h, double *w, int64_t n, double value, qsmc_stream_t stream) {
-    if (h) { h->prep.valid = 0; h->rsq.valid = 0; h->canon_next.kind = 0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
+    if (h) { h->prep.valid = 0; h->rsq.valid = 0; h->canon_next.kind = 0; h->expect_next = 0.0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
     if (!h || !w || n < 0) return QSMC_ERR_INVALID;
     if (n == 0) return QSMC_OK;
     hipLaunchKernelGGL(k_fill, dim3(grid_for(n, QSMC_BLOCK * 4)), dim3(QSMC_BLOCK), 0, (hipStream_t)stream, w,
@@ -1322,6 +1333,66 @@ static int resample_prefix(qsmc_ctx *h, const double *w, int64_t n_in, double no
     return QSMC_OK;
 }
 
+static unsigned long long splitmix64(unsigned long long &x) {
+    unsigned long long z = (x += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// Device buffers of the proposal bank for a resample of n_out particles over max_items work items, expecting `lambda`
+// spares: entries (2 lambda + 65536 of them: the Poisson total does not get there), the per-item arrays and prefixes,
+// the counters, two round lists with their block counts / prefixes, the leftover list.
+static int bank_layout(qsmc_ctx *h, double lambda, int max_items, int64_t n_out, uint64_t seed, uint64_t epoch, BankOut *bo,
+                       BankIn *bi) {
+    const long long capacity = (long long)(2.0 * lambda) + 65536;
+    if (h->bank.capacity < capacity) {
+        if (h->bank.entries) HIP_TRY(h, hipFree(h->bank.entries));
+        h->bank.entries = nullptr;
+        h->bank.capacity = 0;
+        HIP_TRY(h, hipMalloc(&h->bank.entries, (size_t)capacity * BANK_STRIDE * sizeof(double)));
+        h->bank.capacity = capacity;
+    }
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t items_i = up((size_t)max_items * sizeof(int)), items_l = up(((size_t)max_items + 1) * sizeof(long long));
+    const size_t nvb = (size_t)(n_out / BANK_VB) + 2;
+    const size_t list_b = up((size_t)n_out * sizeof(unsigned int));
+    const size_t need = 256 /* top */ + up(64 * sizeof(long long)) + 2 * items_i + 4 * items_l + 2 * list_b +
+                        2 * up(nvb * sizeof(int)) + 2 * up((nvb + 1) * sizeof(long long)) + list_b;
+    if (h->bank.aux_cap < need) {
+        if (h->bank.aux) HIP_TRY(h, hipFree(h->bank.aux));
+        h->bank.aux = nullptr;
+        h->bank.aux_cap = 0;
+        HIP_TRY(h, hipMalloc(&h->bank.aux, need));
+        h->bank.aux_cap = need;
+    }
+    unsigned char *p = h->bank.aux;
+    auto take = [&](size_t b) { unsigned char *r = p; p += b; return r; };
+    bo->lambda = lambda;
+    bo->entries = h->bank.entries;
+    bo->capacity = h->bank.capacity;
+    bo->top = reinterpret_cast<unsigned long long *>(take(256));
+    bi->ctr = reinterpret_cast<long long *>(take(up(64 * sizeof(long long))));
+    bo->e_cnt = reinterpret_cast<int *>(take(items_i));
+    bo->f_cnt = reinterpret_cast<int *>(take(items_i));
+    bo->e_base = reinterpret_cast<long long *>(take(items_l));
+    bo->f_base = reinterpret_cast<long long *>(take(items_l));
+    bi->e_off = reinterpret_cast<long long *>(take(items_l));
+    bi->f_off = reinterpret_cast<long long *>(take(items_l));
+    for (int k = 0; k < 2; ++k) bi->tmp[k] = reinterpret_cast<unsigned int *>(take(list_b));
+    for (int k = 0; k < 2; ++k) bi->bcount[k] = reinterpret_cast<int *>(take(up(nvb * sizeof(int))));
+    for (int k = 0; k < 2; ++k) bi->boff[k] = reinterpret_cast<long long *>(take(up((nvb + 1) * sizeof(long long))));
+    bi->leftover = reinterpret_cast<unsigned int *>(take(list_b));
+    bi->entries = bo->entries;
+    bi->e_cnt = bo->e_cnt;
+    bi->f_cnt = bo->f_cnt;
+    bi->e_base = bo->e_base;
+    bi->f_base = bo->f_base;
+    unsigned long long sm = seed ^ (epoch * 0xD1342543DE82EF95ull) ^ 0x62616E6Bull;       // "bank"
+    for (int k = 0; k < 4; ++k) bi->key[k] = splitmix64(sm);
+    return QSMC_OK;
+}
+
 // TomographyModel.canonicalize (smc.py:529) folded into a d = 16 resample: kind 0 = not asked for
 struct CanonSpec {
     int kind, allow_sub;
@@ -1336,7 +1407,7 @@ static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int3
                                 double norm, double a, const double *mean, const double *S, int64_t n_out,
                                 uint64_t seed, uint64_t epoch, int32_t maxiter, double *x_out, const OutPlace &pl,
                                 int64_t *n_failed_host, qsmc_stream_t stream, CanonSpec canon = CanonSpec{0, 0, nullptr},
-                                int stages = RS_STAGE_ALL) {
+                                int stages = RS_STAGE_ALL, double expect_redraws = 0.0) {
     if (!h || !model || !x_in || !mean || !S || !x_out || n_in <= 0 || n_out <= 0) return QSMC_ERR_INVALID;
     if (d != model->d || d < 1 || d > QSMC_MAX_D || maxiter < 1) return QSMC_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
@@ -1350,7 +1421,8 @@ static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int3
                           q.ldx_in == ldx_in && q.n_in == n_in && q.n_out == n_out && q.norm == norm && q.a == a &&
                           q.seed == seed && q.epoch == epoch && q.x_out == x_out && q.stream == s && pl.n_dest == 0 &&
                           pl.ld_m == q.ldx_out && memcmp(q.mean, mean, sizeof(double) * d) == 0 &&
-                          memcmp(q.S, S, sizeof(double) * d * d) == 0 && q.canon_kind == canon.kind &&
+                          memcmp(q.S, S, sizeof(double) * d * d) == 0 && q.expect == expect_redraws &&
+                          q.canon_kind == canon.kind &&
                           (canon.kind == 0 || (q.canon_allow_sub == canon.allow_sub && q.canon_basis == canon.basis));
         h->rsq.valid = 0;
         if (same) {
@@ -1443,15 +1515,55 @@ static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int3
                        model->min_freq, postselect, x_in, ldx_in, n_in, w, inv_norm, offsets,                       \
                        chunks, bp.slot_off, bp.item_off, bp.item_chunk, lw, k0, k1, ep,                             \
                        maxiter, x_out, pl, nf, bp.retry_list, retry_count, bp.cap)
+#define LAUNCH_O(DD)                                                                                           \
+    hipExtLaunchKernelGGL((k_bucket_sample_ordered<DD, 512>), dim3(bp.max_items), dim3(512), 0, s, pe0, pe1, 0, model->kind, d, \
+                       model->min_freq, postselect, x_in, ldx_in, n_in, w, inv_norm, offsets,                       \
+                       chunks, bp.slot_off, bp.item_off, bp.item_chunk, lw, k0, k1, ep,                             \
+                       maxiter, x_out, pl, nf, bp.retry_list, retry_count, bp.cap, bo)
+        // The proposal bank (kernels/resample.hpp): when the caller expects redraws (the count of this cloud's previous
+        // resample), the ordered sampler also produces ~1.25 x that many spare proposals and the failed first tries are
+        // served from them; the global-CDF redraw kernel stays behind it for whatever is left.
+        static const bool no_bank = getenv("QSMC_NO_BANK") != nullptr;                   // (A/B switch)
+        BankOut bo;
+        memset(&bo, 0, sizeof(bo));
+        BankIn bi;
+        memset(&bi, 0, sizeof(bi));
+        bool banked = false;
+        if (!no_bank && expect_redraws > 0.0 && postselect && maxiter > 1 && (d == 3 || d == 4)) {
+            const double m = 1.25 * expect_redraws;
+            const double lambda = m + 6.0 * sqrt(m) + 64.0;
+            rc = bank_layout(h, lambda, bp.max_items, n_out, seed, epoch, &bo, &bi);
+            if (rc) return rc;
+            HIP_TRY(h, hipMemsetAsync(bo.top, 0, sizeof(unsigned long long), s));
+            banked = true;
+            ++h->bank.n_banked;
+        }
         switch (d) {
             // d <= 2: the single-pass kernel; d >= 3: ancestors first, kicked in ascending order (coalesced gathers)
             case 1: LAUNCH_B(k_bucket_sample, 1, 512); break;
             case 2: LAUNCH_B(k_bucket_sample, 2, 512); break;
-            case 3: LAUNCH_B(k_bucket_sample_ordered, 3, 512); break;
-            case 4: LAUNCH_B(k_bucket_sample_ordered, 4, 512); break;
-            default: LAUNCH_B(k_bucket_sample_ordered, 0, 512); break;          // other d up to 16: runtime-d kernel
+            case 3: LAUNCH_O(3); break;
+            case 4: LAUNCH_O(4); break;
+            default: LAUNCH_O(0); break;          // other d up to 16: runtime-d kernel
         }
 #undef LAUNCH_B
+#undef LAUNCH_O
+        const unsigned int *redraw_list = bp.retry_list;
+        const unsigned long long *redraw_count = retry_count;
+        if (banked) {
+            hipLaunchKernelGGL(k_bank_scan, dim3(1), dim3(1024), 0, s, bi, bp.item_off, chunks, 0);
+            double est = expect_redraws * 2.0 + 4096.0;
+            for (int t = 1; t <= BANK_ROUNDS + 1; ++t) {
+                long long g = (long long)(est / BANK_VB) + 8;
+                g = g > 8192 ? 8192 : g;
+                hipLaunchKernelGGL((k_bank_round<4>), dim3((unsigned)g), dim3(BANK_VB), 0, s, bi, bp.item_off, chunks, t, d,
+                                   bp.retry_list, x_out, pl);
+                hipLaunchKernelGGL(k_bank_scan, dim3(1), dim3(1024), 0, s, bi, bp.item_off, chunks, t);
+                est *= 0.25;
+            }
+            redraw_list = bi.leftover;
+            redraw_count = reinterpret_cast<const unsigned long long *>(bi.ctr + 2);
+        }
         if (postselect && maxiter > 1) {
             // only if some particle asked for a global redraw do these two do any work
             // (more than two processes on one GPU -- bench.py's control-flow check -- must shrink the grid: all of
@@ -1472,19 +1584,19 @@ static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int3
             // the gate is open, ~5 us when it is not) and the redraw kernel skips its scan and its barrier.  Same CDF,
             // same particles either way.
             static const bool never_split = getenv("QSMC_REDRAW_ONE_LAUNCH") != nullptr;      // (A/B switch)
-            const bool expect_redraws = !never_split && h->mapped[REDUCE_OUT_MAX - 2] > 0.0;
-            if (expect_redraws)
+            const bool expect_cdf = !never_split && !banked && h->mapped[REDUCE_OUT_MAX - 2] > 0.0;
+            if (expect_cdf)
                 hipLaunchKernelGGL(k_chunk_scan, dim3((unsigned)chunks64), dim3(SCAN_THREADS), 0, s, w, n_in, inv_norm,
                                    offsets, h->cdf_scratch, (const unsigned long long *)retry_count);
             // the chunk edges ride in LDS (first level of the redraw's ancestor search) while they fit 48 KB
             const size_t edges_lds = (size_t)(chunks64 + (chunks64 >> 5) + (chunks64 >> 10) + 4) * sizeof(double);      // (lds_skew)
             const int edges_in_lds = edges_lds <= 48 * 1024 ? 1 : 0;
             hipLaunchKernelGGL((d <= 4 ? k_bucket_redraw<4> : k_bucket_redraw<QSMC_MAX_D>),
-                               dim3(expect_redraws ? 1024 : redraw_blocks), dim3(SCAN_THREADS),
+                               dim3(expect_cdf ? 1024 : redraw_blocks), dim3(SCAN_THREADS),
                                edges_in_lds ? edges_lds : 0, s, model->kind, d,
                                model->min_freq, x_in, ldx_in, n_in, w, inv_norm, offsets, chunks64, h->cdf_scratch, lw,
-                               k0, k1, ep, maxiter, x_out, pl, bp.retry_list, retry_count, nf, h->gbar + 2,
-                               expect_redraws ? 1 : 0, edges_in_lds);
+                               k0, k1, ep, maxiter, x_out, pl, redraw_list, redraw_count, nf, h->gbar + 2,
+                               expect_cdf ? 1 : 0, edges_in_lds);
         }
     }
     HIP_TRY(h, hipGetLastError());
@@ -1547,12 +1659,23 @@ int qsmc_lw_resample_philox(qsmc_handle_t h, const qsmc_model_t *model, int32_t 
     pl.ld_m = ldx_out;
     pl.ld_s = 1;
     CanonSpec canon{0, 0, nullptr};
+    double expect = 0.0;
     if (h && h->canon_next.kind) {                                  // one-shot (qsmc_lw_fuse_canonicalize)
         canon = CanonSpec{h->canon_next.kind, h->canon_next.allow_sub, h->canon_next.basis};
         h->canon_next.kind = 0;
     }
+    if (h) {                                                        // one-shot (qsmc_lw_expect_redraws)
+        expect = h->expect_next;
+        h->expect_next = 0.0;
+    }
     return resample_philox_impl(h, model, postselect, x_in, ldx_in, n_in, d, w, norm, a, mean, S, n_out, seed,
-                                epoch, maxiter, x_out, pl, n_failed_host, stream, canon);
+                                epoch, maxiter, x_out, pl, n_failed_host, stream, canon, RS_STAGE_ALL, expect);
+}
+
+int qsmc_lw_expect_redraws(qsmc_handle_t h, int64_t n_expected) {
+    if (!h || n_expected < 0) return QSMC_ERR_INVALID;
+    h->expect_next = (double)n_expected;
+    return QSMC_OK;
 }
 
 // out[0..K) (device) -> pinned host block, then the completion word: the d > 4 moments of a resample queued by qsmc_step
@@ -1607,6 +1730,10 @@ int qsmc_step(qsmc_handle_t h, qsmc_step_t *st, const qsmc_model_t *model, const
                                &st->stats, small_d ? st->moments : nullptr, stream);
     if (rc) return rc;
     st->update_token = h->ts.gen;
+    if (st->lw.redraw_pending) {                               // this update's reduction published the last resample's count
+        st->lw.redraws_seen = (int64_t)h->mapped[REDUCE_OUT_MAX - 2];
+        st->lw.redraw_pending = 0;
+    }
     const double norm = st->stats.sum;
     const double fixed = fabs(norm) < PREFIX_NORM_EPS ? 1.0 : norm;                       // smc.py:369-370
     if (st->stats.n_bad > 0.0) { st->status = QSMC_STEP_GUARD; return QSMC_OK; }       // smc.py:416-418
@@ -1696,12 +1823,15 @@ int qsmc_step(qsmc_handle_t h, qsmc_step_t *st, const qsmc_model_t *model, const
     if (rc) return rc;
     if (!std::isfinite(st->S_err)) return QSMC_OK;             // (ResamplerError is the caller's to raise)
     if (small_d) h->ts.armed = h->ts.gen;                      // these weights ARE update number ts.gen's output
+    const double expect = small_d ? (double)st->lw.redraws_seen : 0.0;
     rc = resample_philox_impl(h, model, st->lw.postselect, st->x, st->ldx, st->n, d, st->w, fixed, st->lw.a, st->mean,
                               st->S, st->lw.n_out, st->lw.seed, st->lw.epoch, st->lw.maxiter, st->lw.x_out, pl, nullptr,
-                              stream, canon, small_d ? RS_STAGE_ALL : RS_STAGE_KICK);
+                              stream, canon, small_d ? RS_STAGE_ALL : RS_STAGE_KICK, expect);
     if (rc) return rc;
+    st->lw.redraw_pending = 1;
     auto &q = h->rsq;
     q.valid = 1;
+    q.expect = expect;
     q.canon_kind = canon.kind;
     q.canon_allow_sub = canon.allow_sub;
     q.canon_basis = canon.basis;
@@ -1761,6 +1891,7 @@ int qsmc_lw_resample_philox_sharded(qsmc_handle_t h, const qsmc_model_t *model, 
         prev = pl.quota[sidx];
     }
     pl.seg_start[n_dest] = start;
+    if (h) h->expect_next = 0.0;                       // (the proposal bank is not used by the sharded form)
     if (n_out == 0) return QSMC_OK;
     return resample_philox_impl(h, model, postselect, x_in, ldx_in, n_in, d, w, norm, a, mean, S, n_out, seed,
                                 epoch, maxiter, rows_out, pl, n_failed_host, stream);
@@ -1789,7 +1920,7 @@ int qsmc_prior_uniform_philox(qsmc_handle_t h, const qsmc_model_t *model, int32_
                               const double *lo, const double *hi, int32_t d, int64_t n, uint64_t seed,
                               uint64_t epoch, int32_t maxiter, double *x_out, int64_t ldx_out,
                               int64_t *n_failed_host, qsmc_stream_t stream) {
-    if (h) { h->prep.valid = 0; h->rsq.valid = 0; h->canon_next.kind = 0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
+    if (h) { h->prep.valid = 0; h->rsq.valid = 0; h->canon_next.kind = 0; h->expect_next = 0.0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
     if (!h || !model || !lo || !hi || !x_out || n <= 0 || d < 1 || d > QSMC_MAX_D || maxiter < 1)
         return QSMC_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
@@ -1836,7 +1967,7 @@ int qsmc_random_walk(qsmc_handle_t h, double *x, int64_t ldx, int64_t n, int32_t
 
 int qsmc_tomo_canonicalize2(qsmc_handle_t h, const double *basis, int32_t dim, int32_t basis_kind, double *x, int64_t ldx,
                             int64_t n, int32_t allow_subnormalized, qsmc_stream_t stream) {
-    if (h) { h->prep.valid = 0; h->rsq.valid = 0; h->canon_next.kind = 0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
+    if (h) { h->prep.valid = 0; h->rsq.valid = 0; h->canon_next.kind = 0; h->expect_next = 0.0; h->ts.w = nullptr; }   // weights / counters are about to change: drop queued resample state
     if (!h || !x || n < 0) return QSMC_ERR_INVALID;
     if (basis_kind != QSMC_BASIS_DENSE && basis_kind != QSMC_BASIS_PAULI) return QSMC_ERR_INVALID;
     if (basis_kind == QSMC_BASIS_DENSE && !basis) return QSMC_ERR_INVALID;

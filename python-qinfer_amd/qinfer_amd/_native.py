@@ -38,7 +38,8 @@ class StepLW(C.Structure):
                 ("a", C.c_double), ("h", C.c_double), ("zero_cov_comp", C.c_double),
                 ("seed", C.c_uint64), ("epoch", C.c_uint64), ("n_out", C.c_int64),
                 ("x_out", C.c_void_p), ("ldx_out", C.c_int64),
-                ("canon_kind", C.c_int32), ("canon_allow_sub", C.c_int32), ("canon_basis", C.c_void_p)]
+                ("canon_kind", C.c_int32), ("canon_allow_sub", C.c_int32), ("canon_basis", C.c_void_p),
+                ("redraws_seen", C.c_int64), ("redraw_pending", C.c_int32), ("reserved2", C.c_int32)]
 
 
 class Step(C.Structure):
@@ -83,6 +84,7 @@ SIGNATURES = {
     "qsmc_step": [_P, C.POINTER(Step), C.POINTER(ModelDesc), C.POINTER(ExpParam), _I64, _P],
     "qsmc_step_stats": [_P, C.POINTER(_I64), C.POINTER(_I64)],
     "qsmc_lw_fuse_canonicalize": [_P, _P, _I32, _I32, _I32],
+    "qsmc_lw_expect_redraws": [_P, _I64],
     "qsmc_update_multi": [_P, C.POINTER(ModelDesc), _P, _I64, _I64, _P, _P, _F64, C.POINTER(ExpParam),
                           C.POINTER(_I64), _I32, C.POINTER(UpdateStats), C.POINTER(_F64), _P],
     "qsmc_hypothetical_sums": [_P, C.POINTER(ModelDesc), _P, _I64, _I64, _P, _F64, C.POINTER(ExpParam),

@@ -386,13 +386,17 @@ class Engine:
         return valid
 
     def lw_resample_philox(self, desc, postselect, x_in, w, norm, a, mean, S, n_out, seed, epoch, maxiter,
-                           sync=True, out=None, canon=None):
+                           sync=True, out=None, canon=None, expect_redraws=0):
         """Returns (x_out, n_failed); with sync=False n_failed is None and the count is available
         from `last_resample_failed()` after the next stream synchronisation.  `out`: a (d, n_out) device
         view to fill (row stride arbitrary) instead of a fresh tensor; x_in may be a column slice of a cloud.
         `canon` = (kind, basis_dev, allow_subnormalized) from TomographyModel._native_canonicalize_fused: the new cloud
         comes out canonicalized (qsmc_lw_fuse_canonicalize)."""
         d = x_in.shape[0]
+        if expect_redraws:
+            # (how many first tries of this cloud's previous resample failed postselection: the library then banks
+            #  spare proposals for that many redraws -- qsmc_lw_expect_redraws)
+            self._chk(self.lib.qsmc_lw_expect_redraws(self.h, int(expect_redraws)), "qsmc_lw_expect_redraws")
         if canon is not None:
             kind, basis_dev, allow_sub = canon
             self._chk(self.lib.qsmc_lw_fuse_canonicalize(self.h, self._p(basis_dev) if basis_dev is not None else None, 4,

@@ -136,7 +136,8 @@ class LiuWestResampler(Resampler):
                 canon = None
             x_new, n_failed = eng.lw_resample_philox(desc, self._postselect, x_in, particle_dist._w, norm, a,
                                                      mean, S, n_particles, self._seed, self._epoch,
-                                                     self._maxiter, sync=not defer, out=spare, canon=canon)
+                                                     self._maxiter, sync=not defer, out=spare, canon=canon,
+                                                     expect_redraws=self._expected_redraws(particle_dist, eng))
             if defer:                  # stay asynchronous: the count is read at the caller's next sync
                 self._pending_failed = eng
                 n_failed = 0
@@ -152,6 +153,19 @@ class LiuWestResampler(Resampler):
         new = ParticleDistribution._from_device(eng, x_new, None, norm=float(n_particles), sumsq=float(n_particles))
         new._canonicalized = bool(self._device_rng and native and canon is not None)
         return new
+
+    def _expected_redraws(self, particle_dist, eng):
+        """How many first tries of the previous resample of THIS cloud failed postselection: what the library is told to
+        bank spare proposals for (qsmc_lw_expect_redraws).  An updater on the per-datum C path keeps the number in its
+        qsmc_step_t; otherwise this resampler reads it back when it is next called (it is published with the sums of
+        the update that followed the resample)."""
+        st = getattr(particle_dist, "_st", None)
+        if st is not None:
+            return int(st.lw.redraws_seen)
+        if getattr(self, "_redraw_pending", False):
+            self._redraws_seen = int(eng.last_resample_redraws())
+        self._redraw_pending = True
+        return int(getattr(self, "_redraws_seen", 0))
 
     @staticmethod
     def _arm_update_sums(particle_dist):

@@ -230,6 +230,8 @@ class SMCUpdater(ParticleDistribution):
             rows = only_params
             self._x[rows, :] = x_new[rows, :]
         self._invalidate()
+        if getattr(self, "_st", None) is not None:
+            self._st.lw.redraws_seen, self._st.lw.redraw_pending = 0, 0
         if self._canonicalize:
             self._canonicalize_device(rows)
 
@@ -797,6 +799,8 @@ class SMCUpdater(ParticleDistribution):
             self._set_host(new.particle_locations, new.particle_weights)
         self._w_alt = None
         self._invalidate()
+        if self._st is not None:
+            self._st.lw.redraw_pending = 1            # (its failed-first-try count comes back with the next update's sums)
         if self._canonicalize and not getattr(new, "_canonicalized", False):
             self._canonicalize_device()
         try:

@@ -429,12 +429,17 @@ def test_liu_west_philox_vs_oracle(qi, case):
     assert not np.array_equal(got, other)
 
 
-@pytest.mark.parametrize("case", ["prec", "rb", "tomo", "prec-large", "prec-one-chunk"])
+@pytest.mark.parametrize("case", ["prec", "rb", "rb-bank", "rb-bank-short", "tomo", "prec-large", "prec-one-chunk"])
 def test_liu_west_philox_bucketed_vs_oracle(qi, eng, case):
-    """The bucketed (count -> plan -> LDS-staged sample) resampler on identical Philox numbers."""
+    """The bucketed (count -> plan -> LDS-staged sample) resampler on identical Philox numbers.  rb-bank: the failed
+    first tries are served from the proposal bank (qsmc_lw_expect_redraws); rb-bank-short: a bank far too small, so
+    that most of them fall through to the global-CDF redraw kernel behind it."""
     import philox as ph
     rs = np.random.RandomState(12)
     n = 70001
+    expect = {"rb-bank": 9000, "rb-bank-short": 700}.get(case, 0)
+    if case.startswith("rb"):
+        case = "rb"
     if case.startswith("prec"):
         n = {"prec": n, "prec-large": 1500003, "prec-one-chunk": 3000}[case]
         model, valid = qi.SimplePrecessionModel(), orc.valid_precession
@@ -455,13 +460,17 @@ def test_liu_west_philox_bucketed_vs_oracle(qi, eng, case):
         warnings.simplefilter("ignore")
         pd = qi.ParticleDistribution(particle_locations=x, particle_weights=w)
         res = qi.LiuWestResampler(a=0.9, device_rng=True, seed=4321)
+        res._redraws_seen, res._redraw_pending = expect, False     # (what a previous resample of this cloud would have left)
         new = res(model, pd, n_particles=n_out)
         wn = np.asarray(pd.particle_weights)
         # the twin works on ITS OWN CDF (np.cumsum of the weights, as the reference forms it, resamplers.py:308): chunk
         # edges and entries differ from the device scan by rounding only, which can move an ancestor across a CDF
         # boundary (max_js_flips) but not change a count -- the device scan has its own check against np.cumsum
-        ref, failed, js, counts = ph.liu_west_philox_bucketed(wn, x, valid, 0.9, np.sqrt(1 - 0.81), 4321, 1, n_out)
+        ref, failed, js, counts = ph.liu_west_philox_bucketed(wn, x, valid, 0.9, np.sqrt(1 - 0.81), 4321, 1, n_out,
+                                                              expect_redraws=expect)
     got = new.particle_locations
+    if expect:                                           # (the bank changes which Philox blocks a redraw consumes)
+        assert not np.array_equal(got, ph.liu_west_philox_bucketed(wn, x, valid, 0.9, np.sqrt(1 - 0.81), 4321, 1, n_out)[0])
     assert counts.max() > 2 * 8192, "fixture must exercise the heavy-chunk split"
     assert counts.sum() == n_out and len(counts) == (n + 4095) // 4096
     cov = orc.particle_cov(wn, x, warn=False)
@@ -1674,7 +1683,7 @@ def _two_sample_checks(dev, ref, label):
             assert t.pvalue > STAT_ALPHA, (label, "cov", q, r, t)
 
 
-@pytest.mark.parametrize("case", ["d1", "d1-postselect", "d3"])
+@pytest.mark.parametrize("case", ["d1", "d1-postselect", "d3", "d3-bank"])
 def test_device_resampler_vs_pinned_oracle_statistics(qi, case):
     """The device-RNG resampler (Philox, bucketed counts, Poissonisation, ordered sampler, redraws) is pinned particle
     for particle only to a twin written to mirror it.  This ties it to the REFERENCE: 32 seeds of the device resampler
@@ -1701,11 +1710,16 @@ def test_device_resampler_vs_pinned_oracle_statistics(qi, case):
         pd = qi.ParticleDistribution(particle_locations=x, particle_weights=w)
         for s_ in STAT_SEEDS:
             res = qi.LiuWestResampler(a=a, device_rng=True, seed=s_)
+            if case == "d3-bank":               # the proposal bank serves the failed first tries (their number: measured below)
+                res._redraws_seen, res._redraw_pending = 2500, False
             dev.append(np.asarray(res(model, pd).particle_locations))
             np.random.seed(1000 + s_)
             ref.append(orc.liu_west(w, x, valid, orc.LegacyRNG(), a=a)[0])
     dev, ref = np.stack(dev), np.stack(ref)
     assert np.all(valid(dev.reshape(-1, x.shape[1])))
+    if case.startswith("d3"):                                # the fixture must make postselection bite: ~10 % of first tries
+        kicked = orc.liu_west(w, x, lambda z: np.ones(z.shape[0], dtype=bool), orc.LegacyRNG(), a=a, postselect=False)[0]
+        assert 0.03 < np.mean(~orc.valid_rb(kicked)) < 0.3
     if case == "d1-postselect":                             # the fixture must make postselection bite
         kick = np.sqrt(1 - a ** 2) * np.sqrt(orc.particle_cov(w, x, warn=False)[0, 0])
         assert np.mean(x[:, 0] < 2 * kick) > 0.2
