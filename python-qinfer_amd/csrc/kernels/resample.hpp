@@ -1014,17 +1014,18 @@ __global__ __launch_bounds__(BT) void k_bucket_sample(
 //     failures are through in six); slots left after that, or past the end of the bank, go to k_bucket_redraw.
 // Deterministic for given Philox keys; oracle/philox.py (bank_*) mirrors it entry for entry.
 // ---------------------------------------------------------------------------------------------
-constexpr int BANK_STRIDE = 8;                       // doubles per bank entry: x[0..d), d <= 4, then ..., [7] = valid flag
+// doubles per bank entry: x[0..d) and, last, the validity flag: 4 for d <= 3, 8 for d = 4 (entries stay 32 / 64-byte aligned)
+__host__ __device__ __forceinline__ int bank_stride(int d) { return d <= 3 ? 4 : 8; }
 constexpr int BANK_MAX_PER_ITEM = 4096;              // spares per work item (8 per thread, kept in registers between phases)
 constexpr int BANK_ROUNDS = 7;
 constexpr int BANK_VB = 512;                         // entries per (virtual) block of a round
 struct BankOut {
     double lambda;                                   // expected spares over the whole launch; 0: no bank
+    int stride, reserved;                            // bank_stride(d)
     double *entries;                                 // [capacity][BANK_STRIDE]
-    unsigned long long *top;                         // spares reserved so far
     long long capacity;
-    int *e_cnt, *f_cnt;                              // per work item: spares made / first tries failed
-    long long *e_base, *f_base;                      // per work item: where its spares / its failed slots (retry_list) start
+    int *e_cnt, *f_cnt;                              // per work item: spares to make (k_bank_counts) / first tries that failed
+    long long *e_base, *f_base;                      // per work item: where its spares (prefix of e_cnt) / its failed slots start
 };
 
 constexpr int SMP_HEAVY = 24, SMP_HEAVY_CAP = BUCKET_CAP / SMP_HEAVY + 8;
@@ -1056,7 +1057,7 @@ __global__ __launch_bounds__(BT) void k_bucket_sample_ordered(
     __shared__ long long rbase, ebase_s;
     const bool banked = bank.lambda > 0.0;                      // (uniform)
     if ((int)blockIdx.x >= item_off[chunks]) {
-        if (banked && threadIdx.x == 0) { bank.e_cnt[blockIdx.x] = 0; bank.f_cnt[blockIdx.x] = 0; }
+        if (banked && threadIdx.x == 0) bank.f_cnt[blockIdx.x] = 0;
         return;
     }
     const int c = item_chunk[blockIdx.x];
@@ -1092,20 +1093,17 @@ __global__ __launch_bounds__(BT) void k_bucket_sample_ordered(
             if (o >= o_begin && o < o_end) atomicAdd(&cnt2[j >> 1], 1u << (16 * (j & 1)));
         }
     }
-    // ---- 1x: the spares of the proposal bank.  e_i ~ Poisson(lambda mass / total / parts): the parts of a split chunk
-    // share its mass evenly (independent Poissons add up to the chunk's).  Their ancestors are found now, while the CDF
+    // ---- 1x: the spares of the proposal bank (e_i of them: k_bank_counts).  Their ancestors are found now, while the CDF
     // is still in LDS, and wait in registers (two 16-bit indices a word) until the primaries have been kicked.
     int e_i = 0;
     unsigned int jx[BANK_MAX_PER_ITEM / (2 * BT)];
     if (banked) {
-        const int parts = item_off[c + 1] - item_off[c];
-        const double total = offsets[chunks];
-        const double mu = (total > 0.0 && hi_edge > lo_edge) ? bank.lambda * ((hi_edge - lo_edge) / total) / (double)parts : 0.0;
-        e_i = (int)poisson_draw(true, mu, (uint32_t)blockIdx.x, (epoch << 16) | 0xFFFEu, k0, k1, POISSON_G,
-                                lane & ~(POISSON_G - 1));
-        e_i = e_i < BANK_MAX_PER_ITEM ? e_i : BANK_MAX_PER_ITEM;
+        e_i = bank.e_cnt[blockIdx.x];                        // (k_bank_counts drew it: the Poisson sampler inlined here cost
+                                                              //  27 VGPRs and a wave of occupancy)
         if (threadIdx.x == 0) {
-            long long eb = e_i ? (long long)atomicAdd(bank.top, (unsigned long long)e_i) : 0ll;
+            // where this item's spares go: the prefix of the counts (k_bank_counts) -- a reservation by a returning atomic
+            // on one word, 4600 of them, was a visible part of the kernel's time
+            long long eb = bank.e_base[blockIdx.x];
             if (eb + e_i > bank.capacity) eb = -1;             // (cannot happen with the host's sizing; the item then banks nothing)
             ebase_s = eb;
         }
@@ -1128,10 +1126,10 @@ __global__ __launch_bounds__(BT) void k_bucket_sample_ordered(
         }
     }
     __syncthreads();
-    if (banked && ebase_s < 0) e_i = 0;
+    if (banked && ebase_s < 0) e_i = 0;                      // (E is clamped to the capacity by k_bank_counts: never addressed)
     // ---- 2: the ancestors in ascending order (lane l owns particles 8 l .. 8 l + 7; the list overlays the CDF)
     unsigned short *sorted = reinterpret_cast<unsigned short *>(lcdf);
-    {
+    auto expand_sorted = [&]() {              // cnt2 (children per particle) -> sorted[0 .. total): workgroup-wide, ends on a barrier
         const int j0 = (int)threadIdx.x * 8;
         int nj[8], lt = 0;
 #pragma unroll
@@ -1170,7 +1168,8 @@ __global__ __launch_bounds__(BT) void k_bucket_sample_ordered(
             for (unsigned int r = threadIdx.x; r < cn; r += BT) sorted[st + r] = (unsigned short)jj;
         }
         __syncthreads();
-    }
+    };
+    expand_sorted();
     // ---- 3: the kicks
     unsigned long long failed = 0;
     constexpr bool EARLY = DM <= 4;
@@ -1226,7 +1225,27 @@ __global__ __launch_bounds__(BT) void k_bucket_sample_ordered(
             }
         }
     }
-    // ---- 3x: the spares are kicked like any slot (their own normals) and banked with their validity
+    // ---- 3x: the spares are kicked like any slot (their own normals) and banked with their validity.  Their ancestors
+    // go through the same histogram -> ascending list as the primaries' did (the counters and the list are free again):
+    // spare k takes the k-th smallest of them, so neighbouring lanes gather neighbouring particles here too.
+    if (banked) {                                             // (uniform)
+        __syncthreads();                                      // every primary has read its entry of the list
+        for (int k = threadIdx.x; k < BUCKET_CHUNK / 2; k += BT) cnt2[k] = 0u;
+        if (threadIdx.x == 0) hcount = 0;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < BANK_MAX_PER_ITEM / (2 * BT); ++k) {
+            const int P = (int)threadIdx.x + k * BT;
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                if (2 * P + e < e_i) {
+                    const unsigned int j = (jx[k] >> (16 * e)) & 0xffffu;
+                    atomicAdd(&cnt2[j >> 1], 1u << (16 * (j & 1u)));
+                }
+        }
+        __syncthreads();
+        expand_sorted();
+    }
     if (banked && e_i > 0) {
         const long long eb = ebase_s;
 #pragma unroll
@@ -1245,8 +1264,8 @@ __global__ __launch_bounds__(BT) void k_bucket_sample_ordered(
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     if (2 * P + e < e_i) {
-                        const int jl = (int)((jx[k] >> (16 * e)) & 0xffffu);
-                        double *ent = bank.entries + (eb + 2 * P + e) * BANK_STRIDE;
+                        const int jl = (int)sorted[2 * P + e];
+                        double *ent = bank.entries + (eb + 2 * P + e) * bank.stride;
                         double p[DM];
 #pragma unroll
                         for (int m = 0; m < DM; ++m) {
@@ -1256,10 +1275,10 @@ __global__ __launch_bounds__(BT) void k_bucket_sample_ordered(
                                 for (int q = 0; q < DM; ++q)
                                     if (q < d) sm += lw.S[m * d + q] * z[e * d + q];
                                 p[m] = (lw.a * x_in[m * ldx_in + base + jl] + (1.0 - lw.a) * lw.mean[m]) + sm;
-                                if (m < BANK_STRIDE - 1) ent[m] = p[m];
+                                if (m < bank.stride - 1) ent[m] = p[m];
                             }
                         }
-                        ent[BANK_STRIDE - 1] = model_valid(kind, p, min_freq) ? 1.0 : 0.0;
+                        ent[bank.stride - 1] = model_valid(kind, p, min_freq) ? 1.0 : 0.0;
                     }
                 }
             }
@@ -1287,8 +1306,6 @@ __global__ __launch_bounds__(BT) void k_bucket_sample_ordered(
         if (threadIdx.x == 0) {
             rbase = nl ? (long long)atomicAdd(retry_count, (unsigned long long)nl) : 0ll;      // one atomic per workgroup
             if (banked) {
-                bank.e_cnt[blockIdx.x] = e_i;
-                bank.e_base[blockIdx.x] = ebase_s;
                 bank.f_cnt[blockIdx.x] = nl;
                 bank.f_base[blockIdx.x] = rbase;
             }
@@ -1307,14 +1324,58 @@ __global__ __launch_bounds__(BT) void k_bucket_sample_ordered(
 // ---------------------------------------------------------------------------------------------
 // The bank's consumer: see the "Proposal bank" block above k_bucket_sample_ordered.
 // ctr layout (long long): [0] E, [1] F (failed first tries), [2] leftover count (unsigned, bumped atomically),
-//                         [8 + t] F_t, [24 + t] B_t for round t = 1 ..
+//                         [8 + t] F_t, [24 + t] B_t for round t = 1 .., [40 + t] workgroups of round t that are done
 // ---------------------------------------------------------------------------------------------
+template <bool ATOMIC>
+__device__ __forceinline__ long long block_exclusive_scan_i(const int *src, int m, long long *__restrict__ dst);
+
+// How many spares each work item makes: e_i ~ Poisson(lambda mass_c / total / parts_c), independently per item -- the
+// parts of a split chunk share its mass evenly (independent Poissons add up to the chunk's).  Four lanes per item
+// (poisson_draw's group), block (item, attempt) of round tag 0xFFFE.  Launched between the plan and the sampler.
+__global__ __launch_bounds__(QSMC_BLOCK) void k_bank_counts(const double *__restrict__ offsets, int chunks,
+                                                            const int *__restrict__ item_off, const int *__restrict__ item_chunk,
+                                                            int max_items, double lambda, uint32_t k0, uint32_t k1, uint32_t epoch,
+                                                            int *e_cnt, long long *__restrict__ e_off, long long *ctr,
+                                                            long long capacity) {
+    __shared__ int is_last;
+    const int lane = threadIdx.x & (QSMC_WAVE - 1);
+    const int n_items = item_off[chunks];
+    const double total = offsets[chunks];
+    for (int i0 = (int)blockIdx.x * (QSMC_BLOCK / POISSON_G); i0 < max_items; i0 += (int)gridDim.x * (QSMC_BLOCK / POISSON_G)) {
+        const int it = i0 + (int)threadIdx.x / POISSON_G;
+        const bool active = it < n_items;
+        double mu = 0.0;
+        if (active) {
+            const int c = item_chunk[it];
+            const int parts = item_off[c + 1] - item_off[c];
+            const double lo_edge = chunk_edge(offsets, c), hi_edge = offsets[c + 1];
+            mu = (total > 0.0 && hi_edge > lo_edge) ? lambda * ((hi_edge - lo_edge) / total) / (double)parts : 0.0;
+        }
+        unsigned int e = poisson_draw(active, mu, (uint32_t)it, (epoch << 16) | 0xFFFEu, k0, k1, POISSON_G, lane & ~(POISSON_G - 1));
+        e = e < (unsigned)BANK_MAX_PER_ITEM ? e : (unsigned)BANK_MAX_PER_ITEM;
+        if (it < max_items && (lane & (POISSON_G - 1)) == 0)
+            __hip_atomic_store(&e_cnt[it], active ? (int)e : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // the last workgroup to finish forms the prefix: every item's place in the bank is known before the sampler starts
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long done = __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(ctr + 40), 1ull,
+                                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = done == (unsigned long long)gridDim.x - 1ull;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    const long long E = block_exclusive_scan_i<true>(e_cnt, n_items, e_off);
+    if (threadIdx.x == 0) ctr[0] = E < capacity ? E : capacity;
+}
+
 struct BankIn {
     const double *entries;
+    int stride, reserved;
     const int *e_cnt, *f_cnt;
     const long long *e_base, *f_base;
     long long *e_off, *f_off;                         // [max_items + 1] exclusive prefixes over the work items
-    long long *ctr;
+    long long *ctr;                                   // [0] E, [1] F, [2] leftover count, [8 + t] F_t, [24 + t] B_t, [40 + t] blocks done
     unsigned int *tmp[2];                             // failed slots of a round, virtual block by virtual block
     int *bcount[2];                                   // ... how many in each virtual block
     long long *boff[2];                               // ... and their exclusive prefix
@@ -1354,16 +1415,20 @@ __device__ __forceinline__ int upper_bound_ll(const long long *__restrict__ a, i
     return lo;
 }
 
-// one workgroup: exclusive prefix of src[0..m) (int) into dst[0..m], total returned to every thread
-__device__ __forceinline__ long long block_exclusive_scan_i(const int *__restrict__ src, int m, long long *__restrict__ dst) {
+// one workgroup: exclusive prefix of src[0..m) into dst[0..m], total returned to every thread.  ATOMIC: src was written
+// by other workgroups of THIS launch with agent-scope atomic stores (the XCDs' L2s are not coherent inside a launch).
+template <bool ATOMIC>
+__device__ __forceinline__ long long block_exclusive_scan_i(const int *src, int m, long long *__restrict__ dst) {
     __shared__ long long wtot[1024 / QSMC_WAVE];
     __shared__ long long carry;
     const int lane = threadIdx.x & (QSMC_WAVE - 1), wave = threadIdx.x / QSMC_WAVE, nw = blockDim.x / QSMC_WAVE;
+    __syncthreads();
     if (threadIdx.x == 0) carry = 0ll;
     __syncthreads();
     for (int base = 0; base < m; base += (int)blockDim.x) {
         const int i = base + (int)threadIdx.x;
-        const long long v = i < m ? (long long)src[i] : 0ll;
+        long long v = 0ll;
+        if (i < m) v = ATOMIC ? (long long)__hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (long long)src[i];
         long long inc = v;
 #pragma unroll
         for (int off = 1; off < QSMC_WAVE; off <<= 1) {
@@ -1376,48 +1441,63 @@ __device__ __forceinline__ long long block_exclusive_scan_i(const int *__restric
         for (int wv = 0; wv < wave; ++wv) off0 += wtot[wv];
         if (i < m) dst[i] = off0;
         __syncthreads();
-        if (threadIdx.x == blockDim.x - 1) {
+        if (threadIdx.x == 0) {
             long long tot = 0ll;
             for (int wv = 0; wv < nw; ++wv) tot += wtot[wv];
             carry += tot;
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) dst[m] = carry;
+    const long long total = carry;
+    if (threadIdx.x == 0) dst[m] = total;
     __syncthreads();
-    return carry;
+    return total;
 }
 
-// round 0: prefixes of the per-item counts; round t >= 1: prefix of round t's per-block failure counts
-__global__ __launch_bounds__(1024) void k_bank_scan(BankIn bk, const int *__restrict__ item_off, int chunks, int t) {
-    if (t == 0) {
-        const int n_items = item_off[chunks];
-        const long long E = block_exclusive_scan_i(bk.e_cnt, n_items, bk.e_off);
-        const long long F = block_exclusive_scan_i(bk.f_cnt, n_items, bk.f_off);
-        if (threadIdx.x == 0) {
-            bk.ctr[0] = E;
-            bk.ctr[1] = F;
-            bk.ctr[2] = 0ll;
-            bk.ctr[8 + 1] = F;
-            bk.ctr[24 + 1] = 0ll;
-        }
-        return;
-    }
-    const long long Ft = bk.ctr[8 + t];
-    const int nvb = (int)((Ft + BANK_VB - 1) / BANK_VB);
-    const long long next = block_exclusive_scan_i(bk.bcount[t & 1], nvb, bk.boff[t & 1]);
+// before round 1: prefix of the per-item failure counts, the counters
+__global__ __launch_bounds__(1024) void k_bank_scan(BankIn bk, const int *__restrict__ item_off, int chunks) {
+    const int n_items = item_off[chunks];
+    const long long F = block_exclusive_scan_i<false>(bk.f_cnt, n_items, bk.f_off);
+    if (threadIdx.x >= 1 && threadIdx.x < 64) bk.ctr[threadIdx.x] = 0ll;      // ([0] = E: k_bank_counts)
+    __syncthreads();
     if (threadIdx.x == 0) {
-        bk.ctr[8 + t + 1] = next;
-        bk.ctr[24 + t + 1] = bk.ctr[24 + t] + Ft;
+        bk.ctr[1] = F;
+        bk.ctr[8 + 1] = F;
     }
 }
 
-// round t: the j-th slot still failed (j < F_t) looks at spare perm(B_t + j)
+// one failed slot, one spare: true if the spare was invalid too (or the slot was sent to the leftover list)
+template <int DM>
+__device__ __forceinline__ bool bank_try(const BankIn &bk, long long g, long long E, int n_items, unsigned int slot, int d,
+                                         double *__restrict__ x_out, const OutPlace &pl, bool &left) {
+    left = false;
+    if (g >= E) {                                     // the bank is exhausted: the old way
+        const unsigned long long at = atomicAdd(reinterpret_cast<unsigned long long *>(bk.ctr + 2), 1ull);
+        bk.leftover[at] = slot;
+        left = true;
+        return false;
+    }
+    const long long pg = (long long)bank_perm((unsigned long long)g, (unsigned long long)E, bk.key);
+    const int bi = upper_bound_ll(bk.e_off, n_items + 1, pg) - 1;
+    const double *ent = bk.entries + (bk.e_base[bi] + (pg - bk.e_off[bi])) * bk.stride;
+    if (ent[bk.stride - 1] == 0.0) return true;
+    const int64_t row = place_row(pl, (int64_t)slot);
+#pragma unroll
+    for (int m = 0; m < DM; ++m)
+        if (m < d) x_out[m * pl.ld_m + row * pl.ld_s] = ent[m];
+    return false;
+}
+
+// rounds 1 and 2, over the whole device: the j-th slot still failed (j < F_t) looks at spare perm(B_t + j); the slots
+// that fail again are listed per virtual block of 512 (order kept), and the LAST workgroup to finish forms the prefix of
+// the block counts for the next round (the counts travel as agent-scope atomics; the slot lists are read by the next
+// launch only).
 template <int DM>
 __global__ __launch_bounds__(BANK_VB) void k_bank_round(BankIn bk, const int *__restrict__ item_off, int chunks, int t, int d,
                                                         const unsigned int *__restrict__ retry_list,
                                                         double *__restrict__ x_out, OutPlace pl) {
     __shared__ int wcount[BANK_VB / QSMC_WAVE];
+    __shared__ int is_last;
     const long long Ft = bk.ctr[8 + t];
     if (Ft == 0ll) return;
     const long long Bt = bk.ctr[24 + t], E = bk.ctr[0];
@@ -1425,12 +1505,12 @@ __global__ __launch_bounds__(BANK_VB) void k_bank_round(BankIn bk, const int *__
     const int lane = threadIdx.x & (QSMC_WAVE - 1), wave = threadIdx.x / QSMC_WAVE;
     const int prev = (t - 1) & 1, cur = t & 1;
     const int nvb_prev = t > 1 ? (int)((bk.ctr[8 + t - 1] + BANK_VB - 1) / BANK_VB) : 0;
-    for (long long vb = blockIdx.x; vb * BANK_VB < Ft; vb += gridDim.x) {
+    const int nvb = (int)((Ft + BANK_VB - 1) / BANK_VB);
+    for (long long vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
         const long long j = vb * BANK_VB + threadIdx.x;
-        const bool live = j < Ft;
         unsigned int slot = 0u;
         bool fail = false;
-        if (live) {
+        if (j < Ft) {
             if (t == 1) {
                 const int it = upper_bound_ll(bk.f_off, n_items + 1, j) - 1;
                 slot = retry_list[bk.f_base[it] + (j - bk.f_off[it])];
@@ -1438,26 +1518,9 @@ __global__ __launch_bounds__(BANK_VB) void k_bank_round(BankIn bk, const int *__
                 const int pb = upper_bound_ll(bk.boff[prev], nvb_prev + 1, j) - 1;
                 slot = bk.tmp[prev][(long long)pb * BANK_VB + (j - bk.boff[prev][pb])];
             }
-            const long long g = Bt + j;
-            if (g >= E || t > BANK_ROUNDS) {
-                // the bank is exhausted (or the queued rounds are): the old way
-                const unsigned long long at = atomicAdd(reinterpret_cast<unsigned long long *>(bk.ctr + 2), 1ull);
-                bk.leftover[at] = slot;
-            } else {
-                const long long pg = (long long)bank_perm((unsigned long long)g, (unsigned long long)E, bk.key);
-                const int bi = upper_bound_ll(bk.e_off, n_items + 1, pg) - 1;
-                const double *ent = bk.entries + (bk.e_base[bi] + (pg - bk.e_off[bi])) * BANK_STRIDE;
-                if (ent[BANK_STRIDE - 1] != 0.0) {
-                    const int64_t row = place_row(pl, (int64_t)slot);
-#pragma unroll
-                    for (int m = 0; m < DM; ++m)
-                        if (m < d) x_out[m * pl.ld_m + row * pl.ld_s] = ent[m];
-                } else {
-                    fail = true;
-                }
-            }
+            bool left;
+            fail = bank_try<DM>(bk, Bt + j, E, n_items, slot, d, x_out, pl, left);
         }
-        // the still-failed of this virtual block, in order
         const unsigned long long mk = __ballot(fail);
         if (lane == 0) wcount[wave] = __popcll(mk);
         __syncthreads();
@@ -1467,8 +1530,83 @@ __global__ __launch_bounds__(BANK_VB) void k_bank_round(BankIn bk, const int *__
             tot += wcount[wv];
         }
         if (fail) bk.tmp[cur][vb * BANK_VB + off0 + __popcll(mk & ((1ull << lane) - 1ull))] = slot;
-        if (threadIdx.x == 0) bk.bcount[cur][vb] = tot;
+        if (threadIdx.x == 0) __hip_atomic_store(&bk.bcount[cur][vb], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
+    }
+    __syncthreads();                                  // (this workgroup's atomic stores have been issued and waited for)
+    if (threadIdx.x == 0) {
+        const unsigned long long done = __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(bk.ctr + 40 + t), 1ull,
+                                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = done == (unsigned long long)gridDim.x - 1ull;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    const long long next = block_exclusive_scan_i<true>(bk.bcount[cur], nvb, bk.boff[cur]);
+    if (threadIdx.x == 0) {
+        bk.ctr[8 + t + 1] = next;
+        bk.ctr[24 + t + 1] = Bt + Ft;
+    }
+}
+
+// rounds t0 .. BANK_ROUNDS in ONE workgroup (after two rounds a million failures are down to a few thousand: a launch
+// per round would be launch latency and nothing else), then whatever is left goes to the leftover list.
+template <int DM>
+__global__ __launch_bounds__(1024) void k_bank_tail(BankIn bk, const int *__restrict__ item_off, int chunks, int t0, int d,
+                                                    double *__restrict__ x_out, OutPlace pl) {
+    __shared__ int wcount[1024 / QSMC_WAVE];
+    __shared__ long long s_out;
+    long long Ft = bk.ctr[8 + t0];
+    if (Ft == 0ll) return;
+    long long Bt = bk.ctr[24 + t0];
+    const long long E = bk.ctr[0];
+    const int n_items = item_off[chunks];
+    const int lane = threadIdx.x & (QSMC_WAVE - 1), wave = threadIdx.x / QSMC_WAVE;
+    const int prev = (t0 - 1) & 1, cur = t0 & 1;
+    const int nvb_prev = (int)((bk.ctr[8 + t0 - 1] + BANK_VB - 1) / BANK_VB);
+    // this round's slots, densely: out of the previous round's per-block lists
+    unsigned int *in = bk.tmp[cur], *out = bk.tmp[cur] + ((Ft + 1023) & ~1023ll);
+    for (long long j = threadIdx.x; j < Ft; j += 1024) {
+        const int pb = upper_bound_ll(bk.boff[prev], nvb_prev + 1, j) - 1;
+        in[j] = bk.tmp[prev][(long long)pb * BANK_VB + (j - bk.boff[prev][pb])];
+    }
+    __syncthreads();
+    for (int t = t0; t <= BANK_ROUNDS && Ft > 0ll; ++t) {
+        if (threadIdx.x == 0) s_out = 0ll;
+        __syncthreads();
+        for (long long base = 0; base < Ft; base += 1024) {
+            const long long j = base + threadIdx.x;
+            unsigned int slot = 0u;
+            bool fail = false;
+            if (j < Ft) {
+                slot = in[j];
+                bool left;
+                fail = bank_try<DM>(bk, Bt + j, E, n_items, slot, d, x_out, pl, left);
+            }
+            const unsigned long long mk = __ballot(fail);
+            if (lane == 0) wcount[wave] = __popcll(mk);
+            __syncthreads();
+            long long off0 = s_out;
+            int tot = 0;
+            for (int wv = 0; wv < 1024 / QSMC_WAVE; ++wv) {
+                if (wv < wave) off0 += wcount[wv];
+                tot += wcount[wv];
+            }
+            if (fail) out[off0 + __popcll(mk & ((1ull << lane) - 1ull))] = slot;
+            __syncthreads();
+            if (threadIdx.x == 0) s_out += tot;
+            __syncthreads();
+        }
+        Bt += Ft;
+        Ft = s_out;
+        unsigned int *sw = in;
+        in = out;
+        out = sw;
+        __syncthreads();
+    }
+    // not served within the queued rounds
+    for (long long j = threadIdx.x; j < Ft; j += 1024) {
+        const unsigned long long at = atomicAdd(reinterpret_cast<unsigned long long *>(bk.ctr + 2), 1ull);
+        bk.leftover[at] = in[j];
     }
 }
 

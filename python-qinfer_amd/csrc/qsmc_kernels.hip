@@ -1343,6 +1343,7 @@ static unsigned long long splitmix64(unsigned long long &x) {
 // Device buffers of the proposal bank for a resample of n_out particles over max_items work items, expecting `lambda`
 // spares: entries (2 lambda + 65536 of them: the Poisson total does not get there), the per-item arrays and prefixes,
 // the counters, two round lists with their block counts / prefixes, the leftover list.
+constexpr int BANK_STRIDE_MAX = 8;
 static int bank_layout(qsmc_ctx *h, double lambda, int max_items, int64_t n_out, uint64_t seed, uint64_t epoch, BankOut *bo,
                        BankIn *bi) {
     const long long capacity = (long long)(2.0 * lambda) + 65536;
@@ -1350,13 +1351,13 @@ static int bank_layout(qsmc_ctx *h, double lambda, int max_items, int64_t n_out,
         if (h->bank.entries) HIP_TRY(h, hipFree(h->bank.entries));
         h->bank.entries = nullptr;
         h->bank.capacity = 0;
-        HIP_TRY(h, hipMalloc(&h->bank.entries, (size_t)capacity * BANK_STRIDE * sizeof(double)));
+        HIP_TRY(h, hipMalloc(&h->bank.entries, (size_t)capacity * BANK_STRIDE_MAX * sizeof(double)));
         h->bank.capacity = capacity;
     }
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t items_i = up((size_t)max_items * sizeof(int)), items_l = up(((size_t)max_items + 1) * sizeof(long long));
     const size_t nvb = (size_t)(n_out / BANK_VB) + 2;
-    const size_t list_b = up((size_t)n_out * sizeof(unsigned int));
+    const size_t list_b = up((2 * (size_t)n_out + 8192) * sizeof(unsigned int));   // (k_bank_tail splits a list buffer in two)
     const size_t need = 256 /* top */ + up(64 * sizeof(long long)) + 2 * items_i + 4 * items_l + 2 * list_b +
                         2 * up(nvb * sizeof(int)) + 2 * up((nvb + 1) * sizeof(long long)) + list_b;
     if (h->bank.aux_cap < need) {
@@ -1369,9 +1370,10 @@ static int bank_layout(qsmc_ctx *h, double lambda, int max_items, int64_t n_out,
     unsigned char *p = h->bank.aux;
     auto take = [&](size_t b) { unsigned char *r = p; p += b; return r; };
     bo->lambda = lambda;
+    bo->stride = bi->stride = BANK_STRIDE_MAX;
     bo->entries = h->bank.entries;
     bo->capacity = h->bank.capacity;
-    bo->top = reinterpret_cast<unsigned long long *>(take(256));
+    (void)take(256);
     bi->ctr = reinterpret_cast<long long *>(take(up(64 * sizeof(long long))));
     bo->e_cnt = reinterpret_cast<int *>(take(items_i));
     bo->f_cnt = reinterpret_cast<int *>(take(items_i));
@@ -1386,7 +1388,8 @@ static int bank_layout(qsmc_ctx *h, double lambda, int max_items, int64_t n_out,
     bi->entries = bo->entries;
     bi->e_cnt = bo->e_cnt;
     bi->f_cnt = bo->f_cnt;
-    bi->e_base = bo->e_base;
+    bo->e_base = bi->e_off;                          // (an item's spares start at the prefix of the counts)
+    bi->e_base = bi->e_off;
     bi->f_base = bo->f_base;
     unsigned long long sm = seed ^ (epoch * 0xD1342543DE82EF95ull) ^ 0x62616E6Bull;       // "bank"
     for (int k = 0; k < 4; ++k) bi->key[k] = splitmix64(sm);
@@ -1534,7 +1537,11 @@ static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int3
             const double lambda = m + 6.0 * sqrt(m) + 64.0;
             rc = bank_layout(h, lambda, bp.max_items, n_out, seed, epoch, &bo, &bi);
             if (rc) return rc;
-            HIP_TRY(h, hipMemsetAsync(bo.top, 0, sizeof(unsigned long long), s));
+            bo.stride = bi.stride = bank_stride(d);
+            HIP_TRY(h, hipMemsetAsync(bi.ctr, 0, 64 * sizeof(long long), s));
+            hipLaunchKernelGGL(k_bank_counts, dim3((bp.max_items + QSMC_BLOCK / POISSON_G - 1) / (QSMC_BLOCK / POISSON_G)),
+                               dim3(QSMC_BLOCK), 0, s, offsets, chunks, bp.item_off, bp.item_chunk, bp.max_items, lambda, k0, k1,
+                               ep, bo.e_cnt, bi.e_off, bi.ctr, bo.capacity);
             banked = true;
             ++h->bank.n_banked;
         }
@@ -1551,16 +1558,19 @@ static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int3
         const unsigned int *redraw_list = bp.retry_list;
         const unsigned long long *redraw_count = retry_count;
         if (banked) {
-            hipLaunchKernelGGL(k_bank_scan, dim3(1), dim3(1024), 0, s, bi, bp.item_off, chunks, 0);
-            double est = expect_redraws * 2.0 + 4096.0;
-            for (int t = 1; t <= BANK_ROUNDS + 1; ++t) {
+            // four launches: prefixes, two device-wide rounds (each ends with its own prefix), the remaining rounds in one
+            // workgroup.  (First cut: a launch per round and per prefix, 17 of them at ~5 us each -- as slow as the
+            // global-CDF redraws they replace.)
+            hipLaunchKernelGGL(k_bank_scan, dim3(1), dim3(1024), 0, s, bi, bp.item_off, chunks);
+            double est = expect_redraws * 1.5 + 4096.0;
+            for (int t = 1; t <= 2; ++t) {
                 long long g = (long long)(est / BANK_VB) + 8;
                 g = g > 8192 ? 8192 : g;
                 hipLaunchKernelGGL((k_bank_round<4>), dim3((unsigned)g), dim3(BANK_VB), 0, s, bi, bp.item_off, chunks, t, d,
                                    bp.retry_list, x_out, pl);
-                hipLaunchKernelGGL(k_bank_scan, dim3(1), dim3(1024), 0, s, bi, bp.item_off, chunks, t);
-                est *= 0.25;
+                est *= 0.2;
             }
+            hipLaunchKernelGGL((k_bank_tail<4>), dim3(1), dim3(1024), 0, s, bi, bp.item_off, chunks, 3, d, x_out, pl);
             redraw_list = bi.leftover;
             redraw_count = reinterpret_cast<const unsigned long long *>(bi.ctr + 2);
         }
