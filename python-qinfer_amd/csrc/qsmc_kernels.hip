@@ -503,6 +503,43 @@ static int hyp_launch(qsmc_ctx *h, const qsmc_model_t *model, const double *x, i
     return QSMC_OK;
 }
 
+// binomial models, many outcomes: one lane per outcome (k_hyp_sums_lanes), up to 32 outcomes a pass
+template <int KIND>
+static int hyp_launch_lanes(qsmc_ctx *h, const qsmc_model_t *model, const double *x, int64_t ldx, int64_t n,
+                            const double *w, double norm, const qsmc_expparam_t *exp, const int64_t *outcomes, int n_o,
+                            const double *shift, double *out_host, hipStream_t s) {
+    constexpr int D = Model<KIND>::D <= 4 ? Model<KIND>::D : 0;
+    constexpr int PER = 2 + 2 * D;
+    constexpr int NS = 32 * PER;
+    static_assert(NS + 1 <= REDUCE_OUT_MAX - 4, "reduce buffers too small");
+    const int grid = grid_for(n, QSMC_BLOCK * 4);
+    int rc = ensure_partials(h, (size_t)grid * (NS + 1));
+    if (rc) return rc;
+    HypArgs<32> ha;
+    memset(&ha, 0, sizeof(ha));
+    ha.n_o = n_o;
+    make_exp_args(model, exp, outcomes[0], &ha.base);
+    for (int o = 0; o < n_o; ++o) {
+        ExpArgs tmp;
+        make_exp_args(model, exp, outcomes[o], &tmp);
+        ha.comb[o] = tmp.comb;
+        ha.log_comb[o] = tmp.log_comb;
+        ha.outcome[o] = outcomes[o];
+    }
+    if (shift) for (int m = 0; m < model->d && m < QSMC_MAX_D; ++m) ha.shift[m] = shift[m];
+    const ReduceOut ro = make_reduce(h, true, nullptr);
+    hipEvent_t he0 = nullptr, he1 = nullptr;
+    prof_events(h, QSMC_PROF_HYP_SUMS, &he0, &he1);
+    hipExtLaunchKernelGGL((k_hyp_sums_lanes<KIND>), dim3(grid), dim3(QSMC_BLOCK), 0, s, he0, he1, 0, x, ldx, n, w, norm, ha, ro);
+    HIP_TRY(h, hipGetLastError());
+    rc = launch_reduce(h, NS, grid, ro, s);
+    if (rc) return rc;
+    rc = wait_reduction(h, s);
+    if (rc) return rc;
+    memcpy(out_host, h->mapped, (size_t)n_o * PER * sizeof(double));
+    return QSMC_OK;
+}
+
 template <int KIND>
 static int hyp_dispatch(qsmc_ctx *h, const qsmc_model_t *model, const double *x, int64_t ldx, int64_t n,
                         const double *w, double norm, const qsmc_expparam_t *exp, const int64_t *outcomes,
@@ -519,10 +556,20 @@ static int hyp_dispatch(qsmc_ctx *h, const qsmc_model_t *model, const double *x,
         return e ? atoi(e) : 8;
     }();
     int done = 0;
+    static const bool no_lanes = getenv("QSMC_HYP_NO_LANES") != nullptr;            // (A/B switch)
+    constexpr bool BINOMIAL = KIND == QSMC_MODEL_BINOMIAL_PRECESSION || KIND == QSMC_MODEL_BINOMIAL_RB ||
+                              KIND == QSMC_MODEL_BINOMIAL_RB_INTERLEAVED;
     while (done < n_o) {
         const int m = n_o - done;
         int take, rc;
-        if (m <= 2) {
+        if (BINOMIAL && WIDE && m > 8 && !no_lanes && model->likelihood_power == 0.0) {
+            take = m < 32 ? m : 32;
+            if constexpr (BINOMIAL && WIDE)
+                rc = hyp_launch_lanes<KIND>(h, model, x, ldx, n, w, norm, exp, outcomes + done, take, shift,
+                                            out_host + (size_t)done * PER, s);
+            else
+                rc = QSMC_ERR_INVALID;
+        } else if (m <= 2) {
             take = m;
             rc = hyp_launch<KIND, 2>(h, model, x, ldx, n, w, norm, exp, outcomes + done, take, shift,
                                      out_host + (size_t)done * PER, s);
