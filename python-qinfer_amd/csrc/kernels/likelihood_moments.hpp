@@ -169,6 +169,21 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_sum_partials(const double *__res
     }
 }
 
+// out[k] = sum_g partials[k * nblocks + g] (column-major rows of block_publish): a wave per column, lanes stride over the
+// rows (coalesced), fixed shuffle tree -> deterministic.  For the wide reductions (129 columns x 2048 rows) that one
+// workgroup (k_reduce_partials) took 269 us over.
+__global__ __launch_bounds__(QSMC_BLOCK) void k_sum_columns(const double *__restrict__ partials, int nblocks, int K,
+                                                            double *__restrict__ out) {
+    const int lane = threadIdx.x & (QSMC_WAVE - 1);
+    const int wave = threadIdx.x / QSMC_WAVE;
+    for (int k = blockIdx.x * QSMC_WAVES_PER_BLOCK + wave; k < K; k += gridDim.x * QSMC_WAVES_PER_BLOCK) {
+        double s = 0.0;
+        for (int g = lane; g < nblocks; g += QSMC_WAVE) s += partials[(size_t)k * nblocks + g];
+        s = wave_sum(s);
+        if (lane == 0) out[k] = s;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Kernel-density cross term of est_kl_divergence (distributions.py:466-487; distances metrics.py:72-106):
 //     sum_i p_i log( sum_j q_j phi(|| sqrt(Q) (x_i - y_j) ||_2 / delta) ),   phi = standard normal pdf,

@@ -290,6 +290,17 @@ static inline bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; 
 #include "kernels/resample.hpp"
 #include "kernels/walk_tomo.hpp"
 
+// out[0..K) (device) -> pinned host block, then the completion word: the d > 4 moments of a resample queued by qsmc_step
+__global__ void k_publish_big(const double *__restrict__ src, int K, double *__restrict__ mapped, unsigned long long *flag,
+                              unsigned long long seq) {
+    for (int k = threadIdx.x; k < K; k += blockDim.x) mapped[k] = src[k];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence_system();
+        *reinterpret_cast<volatile unsigned long long *>(flag) = seq;
+    }
+}
+
 // =============================================================================================
 // host-side helpers
 // =============================================================================================
@@ -511,9 +522,11 @@ static int hyp_launch_lanes(qsmc_ctx *h, const qsmc_model_t *model, const double
     constexpr int D = Model<KIND>::D <= 4 ? Model<KIND>::D : 0;
     constexpr int PER = 2 + 2 * D;
     constexpr int NS = 32 * PER;
-    static_assert(NS + 1 <= REDUCE_OUT_MAX - 4, "reduce buffers too small");
+    static_assert(NS <= 512, "the pinned block of the wide sums holds 512 doubles");
     const int grid = grid_for(n, QSMC_BLOCK * 4);
     int rc = ensure_partials(h, (size_t)grid * (NS + 1));
+    if (rc) return rc;
+    rc = ensure_scratch(h, 256 + 512);
     if (rc) return rc;
     HypArgs<32> ha;
     memset(&ha, 0, sizeof(ha));
@@ -527,16 +540,23 @@ static int hyp_launch_lanes(qsmc_ctx *h, const qsmc_model_t *model, const double
         ha.outcome[o] = outcomes[o];
     }
     if (shift) for (int m = 0; m < model->d && m < QSMC_MAX_D; ++m) ha.shift[m] = shift[m];
-    const ReduceOut ro = make_reduce(h, true, nullptr);
+    ReduceOut ro;
+    memset(&ro, 0, sizeof(ro));
+    ro.partials = h->partials;
     hipEvent_t he0 = nullptr, he1 = nullptr;
     prof_events(h, QSMC_PROF_HYP_SUMS, &he0, &he1);
     hipExtLaunchKernelGGL((k_hyp_sums_lanes<KIND>), dim3(grid), dim3(QSMC_BLOCK), 0, s, he0, he1, 0, x, ldx, n, w, norm, ha, ro);
+    // 129 columns x 2048 rows of partials: a wave per column (k_sum_columns), then one workgroup publishes the totals
+    // behind the completion word -- the one-workgroup reduction of the narrow sums (k_reduce_partials) took 269 us here
+    double *full = h->scratch + 256;
+    hipLaunchKernelGGL(k_sum_columns, dim3((NS + QSMC_WAVES_PER_BLOCK - 1) / QSMC_WAVES_PER_BLOCK), dim3(QSMC_BLOCK), 0, s,
+                       h->partials, grid, NS, full);
+    const unsigned long long seq = ++h->seq;
+    hipLaunchKernelGGL(k_publish_big, dim3(1), dim3(QSMC_BLOCK), 0, s, full, NS, h->mapped_big_dev, h->flag_dev, seq);
     HIP_TRY(h, hipGetLastError());
-    rc = launch_reduce(h, NS, grid, ro, s);
-    if (rc) return rc;
     rc = wait_reduction(h, s);
     if (rc) return rc;
-    memcpy(out_host, h->mapped, (size_t)n_o * PER * sizeof(double));
+    memcpy(out_host, h->mapped_big, (size_t)n_o * PER * sizeof(double));
     return QSMC_OK;
 }
 
@@ -1733,17 +1753,6 @@ int qsmc_lw_expect_redraws(qsmc_handle_t h, int64_t n_expected) {
     if (!h || n_expected < 0) return QSMC_ERR_INVALID;
     h->expect_next = (double)n_expected;
     return QSMC_OK;
-}
-
-// out[0..K) (device) -> pinned host block, then the completion word: the d > 4 moments of a resample queued by qsmc_step
-__global__ void k_publish_big(const double *__restrict__ src, int K, double *__restrict__ mapped, unsigned long long *flag,
-                              unsigned long long seq) {
-    for (int k = threadIdx.x; k < K; k += blockDim.x) mapped[k] = src[k];
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence_system();
-        *reinterpret_cast<volatile unsigned long long *>(flag) = seq;
-    }
 }
 
 int qsmc_step_stats(qsmc_handle_t h, int64_t *n_queued, int64_t *n_adopted) {

@@ -102,7 +102,11 @@ class LiuWestResampler(Resampler):
                           "Consider increasing n_particles to improve covariance estimates.",
                           ResamplerWarning)
             cov = self._zero_cov_comp * np.eye(d)
-        S, S_err = eng.sqrtm_psd(cov, scale=h)
+        hint = particle_dist.__dict__.pop("_queued_sqrt", None)      # (SMCUpdater: qsmc_step has formed it already)
+        if hint is not None and hint[1] == float(h) and hint[0] == np.ascontiguousarray(cov, dtype=np.float64).tobytes():
+            S, S_err = hint[2], hint[3]
+        else:
+            S, S_err = eng.sqrtm_psd(cov, scale=h)
         if not math.isfinite(S_err):
             raise ResamplerError("Infinite error in computing the square root of the covariance "
                                  "matrix. Check that n_ess is not too small.")

@@ -415,6 +415,15 @@ class SMCUpdater(ParticleDistribution):
             self._timestep(expparams)
         if status & (_native.STEP_SMALL_ESS | _native.STEP_RESAMPLE_DUE):
             queued = bool(status & _native.STEP_RESAMPLE_QUEUED)
+            if queued:
+                # the square root the library formed for the resample it queued: sqrtm_psd of exactly this matrix, by the
+                # routine the resampler is about to call -- handed over so that the host does not repeat it (40 us at
+                # d = 16) while the GPU is already sampling; the resampler takes it only for a bit-identical covariance
+                d = self._x.shape[0]
+                cov_c = np.array(st.cov[:d * d]).reshape(d, d)
+                if not cov_c.any():
+                    cov_c = st.lw.zero_cov_comp * np.eye(d)
+                self._queued_sqrt = (cov_c.tobytes(), st.lw.h, np.array(st.S[:d * d]).reshape(d, d), st.S_err)
             if queued and self._x.shape[0] > 4:
                 # the moments pass ran inside the call (its result drove the queued resample): what eng.moments returns
                 d = self._x.shape[0]
