@@ -7,6 +7,10 @@ rows = rows[skip:]
 busy = sum(int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in rows)
 wall = int(rows[-1]['End_Timestamp']) - int(rows[0]['Start_Timestamp'])
 print('kernels', len(rows), 'busy us', busy / 1e3, 'wall us', wall / 1e3, 'idle frac', 1 - busy / wall)
+# the update loop alone: gaps above 200 us are the host between loops (prior sampling, resets, allocation, start-up)
+loop_gaps = [int(b['Start_Timestamp']) - int(a['End_Timestamp']) for a, b in zip(rows, rows[1:])]
+small = sum(g for g in loop_gaps if 0 < g <= 200_000)
+print('inside the loops (gaps <= 200 us only): idle us', small / 1e3, 'idle frac', small / (busy + small))
 gap = collections.defaultdict(list)
 for a, b in zip(rows, rows[1:]):
     gap[(a['Kernel_Name'][:28], b['Kernel_Name'][:28])].append(int(b['Start_Timestamp']) - int(a['End_Timestamp']))
