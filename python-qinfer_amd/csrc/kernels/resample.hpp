@@ -1458,7 +1458,9 @@ __device__ __forceinline__ long long block_exclusive_scan_i(const int *src, int 
 __global__ __launch_bounds__(1024) void k_bank_scan(BankIn bk, const int *__restrict__ item_off, int chunks) {
     const int n_items = item_off[chunks];
     const long long F = block_exclusive_scan_i<false>(bk.f_cnt, n_items, bk.f_off);
-    if (threadIdx.x >= 1 && threadIdx.x < 64) bk.ctr[threadIdx.x] = 0ll;      // ([0] = E: k_bank_counts)
+    // ([0] = E: k_bank_counts.  Everything else starts from zero -- including the workgroup counters of the NEXT resample's
+    //  k_bank_counts and rounds, which is why no memset is queued per resample)
+    if (threadIdx.x >= 1 && threadIdx.x < 64) bk.ctr[threadIdx.x] = 0ll;
     __syncthreads();
     if (threadIdx.x == 0) {
         bk.ctr[1] = F;

@@ -1432,6 +1432,7 @@ static int bank_layout(qsmc_ctx *h, double lambda, int max_items, int64_t n_out,
         h->bank.aux = nullptr;
         h->bank.aux_cap = 0;
         HIP_TRY(h, hipMalloc(&h->bank.aux, need));
+        HIP_TRY(h, hipMemset(h->bank.aux, 0, need));          // (the counters start at zero; the kernels leave them so)
         h->bank.aux_cap = need;
     }
     unsigned char *p = h->bank.aux;
@@ -1605,7 +1606,8 @@ static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int3
             rc = bank_layout(h, lambda, bp.max_items, n_out, seed, epoch, &bo, &bi);
             if (rc) return rc;
             bo.stride = bi.stride = bank_stride(d);
-            HIP_TRY(h, hipMemsetAsync(bi.ctr, 0, 64 * sizeof(long long), s));
+            // (no memset command here: k_bank_scan clears the counters for the next resample -- a fill command between the
+            //  plan and the sampler showed up as a 26 us bubble in the kernel trace)
             hipLaunchKernelGGL(k_bank_counts, dim3((bp.max_items + QSMC_BLOCK / POISSON_G - 1) / (QSMC_BLOCK / POISSON_G)),
                                dim3(QSMC_BLOCK), 0, s, offsets, chunks, bp.item_off, bp.item_chunk, bp.max_items, lambda, k0, k1,
                                ep, bo.e_cnt, bi.e_off, bi.ctr, bo.capacity);
