@@ -498,7 +498,7 @@ __device__ __forceinline__ unsigned int get_shared(const unsigned int *p) {
 constexpr int POISSON_G = 4;
 constexpr int BUCKET_COUNTS_BLOCKS = 16, BUCKET_COUNTS_THREADS = 1024;     // (8 workgroups: +4 us; 32: no gain)
 __global__ __launch_bounds__(BUCKET_COUNTS_THREADS) void k_bucket_counts(
-    double *offsets, TileSrc ts, unsigned long long *__restrict__ zero2, int chunks, int64_t n_out, double lambda,
+    double *offsets, TileSrc ts, const double *__restrict__ tile_prefix, unsigned long long *__restrict__ zero2, int chunks, int64_t n_out, double lambda,
     uint32_t k0, uint32_t k1, uint32_t epoch, unsigned int *counts, unsigned int *extra,
     long long *__restrict__ slot_off, int *__restrict__ item_off, int *__restrict__ item_chunk,
     unsigned long long *bar, unsigned long long bar_base, int cap, const int *__restrict__ gate,
@@ -522,7 +522,18 @@ __global__ __launch_bounds__(BUCKET_COUNTS_THREADS) void k_bucket_counts(
     // order, so all agree bit for bit, and the separate one-workgroup scan launch (9 us) is gone; workgroup 0
     // also stores offsets[] for the sampler and clears the failed / retry counters.  Otherwise offsets[] is ready.
     static_assert(BUCKET_COUNTS_THREADS == SCAN_SUMS_THREADS, "scan_sums_block runs on this workgroup");
-    if (ts.tiles) {
+    if (ts.tiles && tile_prefix) {
+        // (round 3) the prefix of the unnormalised chunk sums is ready -- the update's reducing launch formed it beside
+        // the reduction (k_reduce_partials_scan): one multiply per edge; scaling by a positive number keeps it monotone
+        const bool writer = blockIdx.x == 0;
+        if (writer && threadIdx.x < 2) zero2[threadIdx.x] = 0ull;
+        for (int c = threadIdx.x; c < chunks; c += BUCKET_COUNTS_THREADS) {
+            const double v = tile_prefix[c + 1] * ts.inv_norm;
+            edges[lds_skew(c)] = v;
+            if (writer) offsets[c + 1] = v;
+        }
+        if (writer && threadIdx.x == 0) offsets[0] = 0.0;
+    } else if (ts.tiles) {
         const bool writer = blockIdx.x == 0;
         if (writer && threadIdx.x < 2) zero2[threadIdx.x] = 0ull;
         scan_sums_block(nullptr, (int64_t)chunks, ts, [&](int64_t i, double v) {

@@ -81,19 +81,51 @@ __device__ __forceinline__ double chunk_sum_in(const double *__restrict__ sums, 
 
 // One workgroup of SCAN_SUMS_THREADS: exclusive, monotone prefix of the m chunk sums; sink(i, offsets[i]) for
 // i = 0 .. m (offsets[m] = total).  The sums come from `sums` or, with ts.tiles, from the update kernel's tile sums.
-template <class Sink>
+template <int THREADS = SCAN_SUMS_THREADS, class Sink>
 __device__ __forceinline__ void scan_sums_block(const double *sums, int64_t m, const TileSrc &ts, Sink sink) {
-    __shared__ double wtot[SCAN_SUMS_THREADS / QSMC_WAVE];
+    __shared__ double wtot[THREADS / QSMC_WAVE];
     const int lane = threadIdx.x & (QSMC_WAVE - 1);
     const int wave = threadIdx.x / QSMC_WAVE;
-    const int per = (int)((m + SCAN_SUMS_THREADS - 1) / SCAN_SUMS_THREADS);
+    const int per = (int)((m + THREADS - 1) / THREADS);
     const int64_t i0 = (int64_t)threadIdx.x * per;
     double v[SCAN_SUMS_MAX_PER];
     double run = 0.0;
+    if (THREADS <= 256 && ts.tiles && ts.tpc == 8) {
+        // (uniform; the reducing launch's prefix workgroup) 2 tiles x 4 waves per chunk: a chunk's eight parts are one
+        // 64-byte line.  Thread t's RUN is `per` consecutive chunks, so loading it directly makes every wave instruction
+        // touch 64 different lines, one memory latency after the other (7.8 us for 2442 chunks, against 4.3 us for the
+        // reduction beside it).  Instead the chunk sums are formed lane-consecutive (chunk q THREADS + t: whole lines,
+        // coalesced, every load of the thread in flight together), parked in LDS, and the runs are read from there:
+        // the same sums added in the same order.  The update kernel zero-filled the last chunk's missing tiles.
+        __shared__ double csum[THREADS <= 256 ? THREADS * SCAN_SUMS_MAX_PER : 1];
+        double4 a[SCAN_SUMS_MAX_PER], b[SCAN_SUMS_MAX_PER];
 #pragma unroll
-    for (int q = 0; q < SCAN_SUMS_MAX_PER; ++q) {
-        v[q] = (q < per && i0 + q < m) ? chunk_sum_in(sums, ts, i0 + q) : 0.0;
-        run += v[q];
+        for (int q = 0; q < SCAN_SUMS_MAX_PER; ++q) {
+            if (q < per) {                                          // (uniform)
+                const int64_t c = (int64_t)q * THREADS + threadIdx.x;
+                const int64_t cc = c < m ? c : m - 1;
+                a[q] = *reinterpret_cast<const double4 *>(ts.tiles + cc * 8);
+                b[q] = *reinterpret_cast<const double4 *>(ts.tiles + cc * 8 + 4);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < SCAN_SUMS_MAX_PER; ++q) {
+            if (q < per)
+                csum[q * THREADS + threadIdx.x] =
+                    (((((((a[q].x + a[q].y) + a[q].z) + a[q].w) + b[q].x) + b[q].y) + b[q].z) + b[q].w) * ts.inv_norm;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < SCAN_SUMS_MAX_PER; ++q) {
+            v[q] = (q < per && i0 + q < m) ? csum[i0 + q] : 0.0;
+            run += v[q];
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < SCAN_SUMS_MAX_PER; ++q) {
+            v[q] = (q < per && i0 + q < m) ? chunk_sum_in(sums, ts, i0 + q) : 0.0;
+            run += v[q];
+        }
     }
     // exclusive offset of this thread's run
     double inc = wave_inclusive_scan(run, lane);
@@ -102,7 +134,7 @@ __device__ __forceinline__ void scan_sums_block(const double *sums, int64_t m, c
     double off = inc - run;
     for (int wv = 0; wv < wave; ++wv) off += wtot[wv];
     double total = 0.0;
-    for (int wv = 0; wv < SCAN_SUMS_THREADS / QSMC_WAVE; ++wv) total += wtot[wv];
+    for (int wv = 0; wv < THREADS / QSMC_WAVE; ++wv) total += wtot[wv];
     __syncthreads();
     // exclusive values of my entries, then make everything monotone with an exact prefix max
     double e[SCAN_SUMS_MAX_PER];
@@ -123,9 +155,9 @@ __device__ __forceinline__ void scan_sums_block(const double *sums, int64_t m, c
 #pragma unroll
     for (int q = 0; q < SCAN_SUMS_MAX_PER; ++q)
         if (q < per && i0 + q < m) sink(i0 + q, fmax(e[q], before));
-    if (threadIdx.x == SCAN_SUMS_THREADS - 1) {
+    if (threadIdx.x == THREADS - 1) {
         double gmax = 0.0;
-        for (int wv = 0; wv < SCAN_SUMS_THREADS / QSMC_WAVE; ++wv) gmax = fmax(gmax, wtot[wv]);
+        for (int wv = 0; wv < THREADS / QSMC_WAVE; ++wv) gmax = fmax(gmax, wtot[wv]);
         sink(m, fmax(total, gmax));
     }
 }
@@ -134,6 +166,23 @@ __global__ __launch_bounds__(SCAN_SUMS_THREADS) void k_scan_sums(double *sums, i
                                                                  unsigned long long *__restrict__ zero2, TileSrc ts) {
     if (zero2 && threadIdx.x < 2) zero2[threadIdx.x] = 0ull;      // the resampler's failed / retry counters (was a memset launch)
     scan_sums_block(sums, m, ts, [&](int64_t i, double v) { sums[i] = v; });
+}
+
+// The reducing launch of an update that left tile sums, with a second workgroup: while workgroup 0 reduces the
+// partials (and decides the resample gate), workgroup 1 forms the monotone prefix of the chunk sums from the tile
+// sums -- UNNORMALISED: the normaliser is what workgroup 0 is computing -- so that k_bucket_counts, should a resample
+// be due, starts from 20 KB of ready offsets (one multiply each) instead of scanning 156 KB of tile sums itself
+// (10 of its 28 us at N = 1e7, in every one of its 16 workgroups).  On the other steps the prefix costs nothing on
+// the critical path: it runs beside the reduction, inside the host's round trip.
+constexpr int TILE_PREFIX_MAX_CHUNKS = QSMC_BLOCK * SCAN_SUMS_MAX_PER;        // 4096 chunks: N <= 1.67e7
+template <int NS>
+__global__ __launch_bounds__(QSMC_BLOCK) void k_reduce_partials_scan(int nblocks, ReduceOut ro) {
+    if (blockIdx.x == 0) {
+        reduce_partials_body<NS>(nblocks, ro);
+        return;
+    }
+    const TileSrc ts{ro.tile_sums, ro.tp_tpc, (int64_t)ro.tp_ntiles, 1.0};
+    scan_sums_block<QSMC_BLOCK>(nullptr, (int64_t)ro.tp_chunks, ts, [&](int64_t i, double v) { ro.tile_prefix[i] = v; });
 }
 
 // Fallback for m > 16384 chunk sums (N > 6.7e7): same contract, 256-wide slabs with a carry.

@@ -29,6 +29,9 @@ struct ReduceOut {
     double *tile_sums;                      // k_update_fused only: sum of w' per TILE particles (nullable)
     int *prefix_gate;                       // k_update_fused only: device word for the resample-prefix gate (nullable) ...
     double prefix_thresh;                   // ... opened when (sum w')^2 / sum w'^2 < prefix_thresh and no guard is due
+    double *tile_prefix;                    // k_update_fused only (nullable): [tp_chunks + 1] monotone prefix of the UNNORMALISED
+    int tp_chunks, tp_tpc;                  //   chunk sums, formed from tile_sums by a second workgroup of the reducing launch
+    long long tp_ntiles;                    //   (k_reduce_partials_scan) while the first one reduces
 };
 
 // |sum w'| below this and the host renormalises by 1 instead (smc.py:369-370): no speculative prefix then
@@ -71,7 +74,7 @@ __device__ __forceinline__ void block_publish(double (&v)[NS], double mn, const 
 // write-back); the rest is launch.  Doing this level inside the update kernel behind arrival tickets was measured in
 // round 1 (+11 us) and re-costed in round 2: every dependent global round trip is 1-2 us and that chain has more of them.
 template <int NS>
-__global__ __launch_bounds__(QSMC_BLOCK) void k_reduce_partials(int nblocks, ReduceOut ro) {
+__device__ __forceinline__ void reduce_partials_body(int nblocks, const ReduceOut &ro) {
     constexpr int THREADS = QSMC_BLOCK, WAVES = THREADS / QSMC_WAVE, UNROLL = NS <= 17 ? 4 : (NS <= 38 ? 2 : 1);
     __shared__ double lds[WAVES * (NS + 1)];
     __shared__ double tot[NS + 1];
@@ -175,6 +178,11 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_reduce_partials(int nblocks, Red
     }
 }
 
+template <int NS>
+__global__ __launch_bounds__(QSMC_BLOCK) void k_reduce_partials(int nblocks, ReduceOut ro) {
+    reduce_partials_body<NS>(nblocks, ro);
+}
+
 // Per-particle accumulation of the update: [sum w', sum w'^2, #bad, sum w' x_m (DMOM),
 // sum w' x_m x_q (m <= q)] and min w'.  DMOM > 0 folds the weighted moments of the NEW weights
 // into the same pass (x is already in registers): est_mean / est_covariance_mtx and the
@@ -224,6 +232,8 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_update_fused(
     // (k_scan_sums adds the parts in a fixed order); off when ro.tile_sums is null.
     for (int64_t base = (int64_t)blockIdx.x * TILE; base < n; base += (int64_t)gridDim.x * TILE) {
         double tsum = 0.0;
+        // (D <= 2 only.  Round 3 tried the same form for RB, d = 3 / 4: 16 loads in flight per wave but 174 / 204 VGPRs,
+        //  two waves per SIMD instead of four -- 94 -> 98 us at N = 1.25e7, Binomial(RB) 125 -> 143 us.)
         if (VEC == 2 && D <= 2 && base + TILE <= n) {
             // full tile: every load of the tile is issued before the first likelihood is evaluated, so a wave
             // has UPD_UNROLL x (1 + d) 16-byte loads in flight instead of 1 + d (the guarded path below
@@ -333,6 +343,20 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_update_fused(
             const double t = wave_sum(tsum);
             if ((threadIdx.x & (QSMC_WAVE - 1)) == 0)
                 ro.tile_sums[(base / TILE) * QSMC_WAVES_PER_BLOCK + threadIdx.x / QSMC_WAVE] = t;
+        }
+    }
+    if (ro.tile_sums) {                          // uniform
+        // the workgroup that took the last tile zeroes the entries up to the end of that tile's 4096-particle chunk, so that
+        // the chunk-sum scan reads whole chunks without a bounds test per load (the buffer is sized in whole chunks).
+        // (Outside the loop: inside it, one more live value took the d = 16 kernel from 168 to 169 VGPRs -- two waves
+        //  per SIMD instead of three, 35 -> 55 us.)
+        static_assert(4096 % TILE == 0, "tiles per chunk");
+        constexpr int64_t PER_CHUNK = 4096 / TILE * QSMC_WAVES_PER_BLOCK;
+        const int64_t last = (n - 1) / TILE;
+        if ((int64_t)blockIdx.x == last % (int64_t)gridDim.x) {
+            const int64_t first = (last + 1) * QSMC_WAVES_PER_BLOCK;
+            const int64_t end = (first + PER_CHUNK - 1) / PER_CHUNK * PER_CHUNK;
+            for (int64_t k = first + threadIdx.x; k < end; k += QSMC_BLOCK) ro.tile_sums[k] = 0.0;
         }
     }
     block_publish<UpdAcc<DMOM>::NS>(acc.s, acc.mn, ro);

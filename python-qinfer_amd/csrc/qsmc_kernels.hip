@@ -65,6 +65,9 @@ struct qsmc_ctx {
     size_t sort_tmp_cap;           // in bytes
     double *tile_sums;             // sum of w' per update-kernel tile, written by the last qsmc_update_fused
     size_t tile_sums_cap;
+    double *tile_prefix;           // monotone prefix of the unnormalised chunk sums (k_reduce_partials_scan) ...
+    size_t tile_prefix_cap;
+    unsigned long long tile_prefix_gen;   // ... of update number ts.gen (0: none)
     struct {
         unsigned long long gen;    // counts qsmc_update_fused calls; the caller mirrors it as a token
         const double *w;           // the w_out those sums describe
@@ -363,6 +366,9 @@ static ReduceOut make_reduce(qsmc_ctx *h, bool want_host, double *stats4) {
     ro.failed_src = reinterpret_cast<const unsigned long long *>(h->counter);
     ro.failed_dst = want_host ? h->mapped_dev + (REDUCE_OUT_MAX - 1) : nullptr;
     ro.tile_sums = nullptr;
+    ro.tile_prefix = nullptr;
+    ro.tp_chunks = ro.tp_tpc = 0;
+    ro.tp_ntiles = 0;
     ro.prefix_gate = nullptr;
     ro.prefix_thresh = 0.0;
     return ro;
@@ -390,6 +396,19 @@ static int wait_reduction(qsmc_ctx *h, hipStream_t s) {
 }
 
 static int launch_reduce(qsmc_ctx *h, int ns, int grid, const ReduceOut &ro, hipStream_t s) {
+    if (ro.tile_prefix) {                  // an update's reduction with the chunk-sum prefix beside it (ns = 3 + d + d (d + 1) / 2, d <= 4)
+        switch (ns) {
+#define LRS(N)                                                                                        \
+    case N:                                                                                           \
+        hipLaunchKernelGGL((k_reduce_partials_scan<N>), dim3(2), dim3(QSMC_BLOCK), 0, s, grid, ro);   \
+        break;
+            LRS(3) LRS(5) LRS(8) LRS(12) LRS(17)
+#undef LRS
+            default: return QSMC_ERR_INVALID;
+        }
+        HIP_TRY(h, hipGetLastError());
+        return QSMC_OK;
+    }
     switch (ns) {
 #define LR(N)                                                                                   \
     case N:                                                                                     \
@@ -694,6 +713,7 @@ int qsmc_destroy(qsmc_handle_t h) {
     if (h->partials) (void)hipFree(h->partials);
     if (h->rs_offsets) (void)hipFree(h->rs_offsets);
     if (h->tile_sums) (void)hipFree(h->tile_sums);
+    if (h->tile_prefix) (void)hipFree(h->tile_prefix);
     if (h->sort_tmp) (void)hipFree(h->sort_tmp);
     if (h->scratch) (void)hipFree(h->scratch);
     if (h->pinned) (void)hipHostFree(h->pinned);
@@ -846,7 +866,7 @@ int qsmc_update_fused(qsmc_handle_t h, const qsmc_model_t *model, const double *
     // per-tile sums of the new weights: a resample that follows this update takes its chunk sums from them
     static const bool tile_sums_on = getenv("QSMC_NO_TILE_SUMS") == nullptr;     // (A/B switch for measurements)
     if (tile_sums_on && BUCKET_CHUNK % per_block == 0 &&
-        ensure_tile_sums(h, (size_t)((n + per_block - 1) / per_block) * QSMC_WAVES_PER_BLOCK) == QSMC_OK) {
+        ensure_tile_sums(h, (size_t)((n + BUCKET_CHUNK - 1) / BUCKET_CHUNK) * (BUCKET_CHUNK / per_block) * QSMC_WAVES_PER_BLOCK) == QSMC_OK) {   // (whole chunks: the update kernel zero-fills the last one)
         ro.tile_sums = h->tile_sums;
         h->ts.w = w_out;
         h->ts.n = n;
@@ -857,6 +877,22 @@ int qsmc_update_fused(qsmc_handle_t h, const qsmc_model_t *model, const double *
     ++h->ts.gen;
     h->ts.armed = 0;
     h->spec.launched = 0;
+    static const bool tile_prefix_on = getenv("QSMC_NO_TILE_PREFIX") == nullptr;     // (A/B switch)
+    const int64_t tp_chunks = (n + BUCKET_CHUNK - 1) / BUCKET_CHUNK;
+    if (tile_prefix_on && ro.tile_sums && tp_chunks <= TILE_PREFIX_MAX_CHUNKS && (ns == 3 || ns == 5 || ns == 8 || ns == 12 || ns == 17)) {
+        if (h->tile_prefix_cap < (size_t)tp_chunks + 1) {
+            if (h->tile_prefix) HIP_TRY(h, hipFree(h->tile_prefix));
+            h->tile_prefix = nullptr;
+            h->tile_prefix_cap = 0;
+            HIP_TRY(h, hipMalloc(&h->tile_prefix, (size_t)(TILE_PREFIX_MAX_CHUNKS + 1) * sizeof(double)));
+            h->tile_prefix_cap = TILE_PREFIX_MAX_CHUNKS + 1;
+        }
+        ro.tile_prefix = h->tile_prefix;
+        ro.tp_chunks = (int)tp_chunks;
+        ro.tp_tpc = BUCKET_CHUNK / per_block * QSMC_WAVES_PER_BLOCK;
+        ro.tp_ntiles = (long long)((n + per_block - 1) / per_block) * QSMC_WAVES_PER_BLOCK;
+        h->tile_prefix_gen = h->ts.gen;
+    }
     if (h->spec.enabled && ro.tile_sums && ro.failed_dst) {
         // the resampler's weight-only prefix goes out right behind the reduction, gated on the device-side ESS test
         ro.prefix_gate = h->spec.gate;
@@ -1381,6 +1417,7 @@ static int resample_prefix(qsmc_ctx *h, const double *w, int64_t n_in, double no
             prof_events(h, QSMC_PROF_COUNTS, &q0, &q1);
             hipExtLaunchKernelGGL(k_bucket_counts, dim3(BUCKET_COUNTS_BLOCKS), dim3(BUCKET_COUNTS_THREADS), lds, s, q0, q1, 0, offsets,
                                scan_in_counts ? ts : TileSrc{nullptr, 0, 0, 0.0},
+                               (scan_in_counts && h->tile_prefix_gen == h->ts.gen) ? h->tile_prefix : (const double *)nullptr,
                                reinterpret_cast<unsigned long long *>(h->counter), chunks, n_out, lambda, k0, k1, ep,
                                bp.counts, extra, bp.slot_off, bp.item_off, bp.item_chunk, h->gbar, h->gbar_base, bp.cap,
                                speculative ? h->spec.gate : (const int *)nullptr,
