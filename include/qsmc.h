@@ -489,7 +489,7 @@ int qsmc_prior_uniform_philox(qsmc_handle_t h, const qsmc_model_t *model, int32_
 int qsmc_random_walk(qsmc_handle_t h, double *x, int64_t ldx, int64_t n, int32_t d, const double *scale,
                      const double *z, int64_t ldz, uint64_t seed, uint64_t epoch, qsmc_stream_t stream);
 
-/* basis: DEVICE complex128 (d, dim, dim) row-major as interleaved (re, im), d = dim*dim, dim<=4.
+/* basis: DEVICE complex128 (d, dim, dim) row-major as interleaved (re, im), d = dim*dim, dim = 2, 3 or 4.
  * In place: clamp negative eigenvalues of rho(x), then x /= x_0 sqrt(dim) unless allow_subnormalized. */
 int qsmc_tomo_canonicalize(qsmc_handle_t h, const double *basis, int32_t dim,
                            double *x, int64_t ldx, int64_t n, int32_t allow_subnormalized,

@@ -18,7 +18,7 @@ sys.path.insert(0, HERE)
 import ref_shim  # noqa: E402
 
 qinfer = ref_shim.install()
-from qinfer.tomography import TomographyModel, pauli_basis  # noqa: E402
+from qinfer.tomography import TomographyModel, pauli_basis, gell_mann_basis  # noqa: E402
 import np_oracle as orc  # noqa: E402  (only for the restated Ginibre prior; qutip is absent)
 
 OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
@@ -407,6 +407,25 @@ def g5_canonicalize():
     print("g5_canonicalize")
 
 
+def g5_canonicalize_qutrit():
+    """tomography/models.py:149-209 on a qutrit (gell_mann_basis(3), d = 9): the dimension between the two BASELINE uses."""
+    basis = gell_mann_basis(3)
+    tm = TomographyModel(basis)
+    rs = np.random.RandomState(43)
+    x = orc.ginibre_prior_sample(256, basis.data, rs)
+    x[:, 1:] += 0.2 * rs.randn(256, 8)            # many become non-PSD
+    x[:, 0] = 1 / np.sqrt(3) + 0.01 * rs.randn(256)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        y = tm.canonicalize(x.copy())
+        tm2 = TomographyModel(basis, allow_subnormalized=True)
+        y2 = tm2.canonicalize(x.copy())
+    rho = np.tensordot(x, basis.data, 1)
+    n_bad = int((np.linalg.eigvalsh(rho).min(axis=1) < 0).sum())
+    np.savez_compressed(os.path.join(OUT, "g5_canonicalize_qutrit.npz"), x=x, y=y, y_subnorm=y2, basis=basis.data)
+    print("g5_canonicalize_qutrit", n_bad, "of 256 not PSD")
+
+
 def g6_guards():
     """Mirrors tests/test_smc.py:98-137 on a DecimationModel-style likelihood (0.5 / 0 step)."""
     out = {}
@@ -783,6 +802,7 @@ if __name__ == "__main__":
     g3_moments()
     g4_liu_west()
     g5_canonicalize()
+    g5_canonicalize_qutrit()
     g6_guards()
     g7_design()
     g8_binomial_rb()

@@ -2085,8 +2085,11 @@ int qsmc_tomo_canonicalize2(qsmc_handle_t h, const double *basis, int32_t dim, i
             hipLaunchKernelGGL((k_tomo_canon<2, TomoDense<2>>), dim3(grid), dim3(QSMC_BLOCK), 0, s, TomoDense<2>{basis}, x, ldx,
                                n, allow_subnormalized);
             break;
-        case 3:
-            return QSMC_ERR_UNSUPPORTED;   // d = 9 fits QSMC_MAX_D but has no kernel: TomographyModel.canonicalize runs on the host
+        case 3:                                         // a qutrit (d = 9): one pass, dense contraction, 3 x 3 Jacobi per lane
+            if (!basis) return QSMC_ERR_INVALID;
+            hipLaunchKernelGGL((k_tomo_canon<3, TomoDense<3>>), dim3(grid), dim3(QSMC_BLOCK), 0, s, TomoDense<3>{basis}, x, ldx,
+                               n, allow_subnormalized);
+            break;
         case 4:
             if (basis_kind == QSMC_BASIS_PAULI) return canon_dim4(h, TomoPauli2{}, x, ldx, n, allow_subnormalized, s);
             return canon_dim4(h, TomoDense<4>{basis}, x, ldx, n, allow_subnormalized, s);

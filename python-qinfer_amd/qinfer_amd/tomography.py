@@ -175,9 +175,9 @@ class TomographyModel(NativeModelMixin, FiniteOutcomeModel):
         return self._basis_dev
 
     def _native_canonicalize_ok(self):
-        """Device canonicalize kernels exist for 1 and 2 qubits (dim 2, 4); other dimensions (a qutrit: d = 9)
-        take `canonicalize` on the host."""
-        return self._dim in (2, 4)
+        """Device canonicalize kernels exist for dim 2, 3, 4 (one qubit, a qutrit, two qubits: every dimension whose
+        d = dim^2 fits QSMC_MAX_D = 16); larger systems take `canonicalize` on the host."""
+        return self._dim in (2, 3, 4)
 
     def _pauli(self):
         if self._is_pauli is None:               # is this the reference's Pauli basis, element for element?
@@ -188,7 +188,7 @@ class TomographyModel(NativeModelMixin, FiniteOutcomeModel):
     def _native_canonicalize_(self, eng, x):
         """In-place canonicalize of a device SoA cloud."""
         if not self._native_canonicalize_ok():
-            raise NotImplementedError("native canonicalize supports dim 2 and 4 (1 or 2 qubits)")
+            raise NotImplementedError("native canonicalize supports dim 2, 3 and 4")
         eng.tomo_canonicalize(self._device_basis(eng), self._dim, x, self._allow_subnormalized, pauli=self._pauli())
 
     def _native_canonicalize_fused(self, eng):

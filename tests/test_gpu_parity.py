@@ -773,6 +773,58 @@ def test_deferred_failed_warning(qi):
 
 
 # ================================================================== canonicalize (G5)
+def test_tomo_qutrit(qi, golden):
+    """dim 3 (d = 9): canonicalize on the device against the REFERENCE's outputs (fixture g5_canonicalize_qutrit), and a
+    qutrit updater end to end -- fused update (runtime d), MFMA moments, the generic-d device-RNG Liu-West sampler and
+    the device canonicalize behind it -- against the oracle's own run on the same data."""
+    g = golden("g5_canonicalize_qutrit")
+    b3 = qi.tomography.gell_mann_basis(3)
+    np.testing.assert_array_equal(b3.data, g["basis"])
+    m3 = qi.TomographyModel(b3)
+    assert m3._native_canonicalize_ok()
+    np.testing.assert_allclose(m3.canonicalize(g["x"]), g["y"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(qi.TomographyModel(b3, allow_subnormalized=True).canonicalize(g["x"]), g["y_subnorm"],
+                               rtol=0, atol=1e-12)
+    rho = np.tensordot(m3.canonicalize(g["x"]), b3.data, 1)
+    np.testing.assert_allclose(np.trace(rho, axis1=1, axis2=2).real, 1.0, atol=1e-12)
+    assert np.linalg.eigvalsh(rho).min() > -1e-12
+    # end to end
+    rs = np.random.RandomState(3)
+    true = orc.ginibre_prior_sample(1, b3.data, rs)[0]
+    K = 120
+    eps, outs = [], []
+    for k in range(K):
+        v = rs.randn(3) + 1j * rs.randn(3)
+        v /= np.linalg.norm(v)
+        proj = np.outer(v, v.conj())
+        meas = np.real(np.einsum('aij,ji->a', b3.data.conj(), proj))          # <<B_a | proj>>
+        ep = np.zeros((1,), dtype=m3.expparams_dtype)
+        ep['meas'][0] = meas
+        eps.append(ep)
+        outs.append(int(rs.random_sample() < np.clip(meas @ true, 0, 1)))
+    n = 40000
+    np.random.seed(11)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        upd = qi.SMCUpdater(m3, n, qi.GinibreDistribution(b3), device_rng=True, seed=4)
+        assert upd._native
+        for k in range(K):
+            upd.update(outs[k], eps[k])
+        np.random.seed(12)
+        ref = orc.OracleSMC(orc.tomography_model(b3.data), 8000, lambda m: orc.ginibre_prior_sample(m, b3.data, np.random))
+        for k in range(K):
+            ref.update(outs[k], {"meas": eps[k]['meas']})
+    assert upd.resample_count >= 2 and abs(upd.resample_count - ref.resample_count) <= 3
+    x = np.asarray(upd.particle_locations)
+    rho = np.tensordot(x, b3.data, 1)
+    np.testing.assert_allclose(np.trace(rho, axis1=1, axis2=2).real, 1.0, atol=1e-10)
+    assert np.linalg.eigvalsh(rho).min() > -1e-10                       # every particle is a state
+    sd = np.sqrt(np.diag(ref.est_covariance_mtx())[1:])
+    gap = np.abs(upd.est_mean()[1:] - ref.est_mean()[1:])
+    assert np.all(gap < 5 * sd / np.sqrt(ref.n_ess) + 0.35 * sd), (gap / sd)
+    assert np.linalg.norm(upd.est_mean() - true) < np.linalg.norm(ref.est_mean() - true) + 0.1
+
+
 def test_tomo_canonicalize_g5(qi, golden):
     g = golden("g5_canonicalize")
     basis = qi.tomography.pauli_basis(2)
@@ -1848,7 +1900,7 @@ def test_user_override_of_a_native_model_wins(qi):
         for _ in range(5):
             upd.update(0, np.array([0.0]), check_for_resample=False)
         assert upd.est_covariance_mtx()[0, 0] > v0 + 4e-4                # five steps of variance 1e-4 were taken
-    # a qutrit model constructs and canonicalizes (host path: no kernel for dim 3)
+    # a qutrit model constructs and canonicalizes (device kernel for dim 3 since round 3; see test_tomo_qutrit)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         b3 = qi.tomography.gell_mann_basis(3)

@@ -121,6 +121,15 @@ def test_g5_canonicalize(golden):
     np.testing.assert_allclose(y2, g["y_subnorm"], rtol=0, atol=1e-13)
 
 
+def test_g5_canonicalize_qutrit(golden):
+    """The same restatement on a qutrit (gell_mann_basis(3), d = 9), against the reference's outputs."""
+    g = golden("g5_canonicalize_qutrit")
+    assert g["x"].shape == (256, 9) and g["basis"].shape == (9, 3, 3)
+    np.testing.assert_allclose(orc.tomo_canonicalize(g["x"], g["basis"]), g["y"], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(orc.tomo_canonicalize(g["x"], g["basis"], allow_subnormalized=True), g["y_subnorm"],
+                               rtol=0, atol=1e-13)
+
+
 # ------------------------------------------------------------------ G1 trajectories
 def _traj(g, model, ep_of, cond, batch=None):
     rng = _replay(g)
