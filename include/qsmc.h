@@ -180,6 +180,7 @@ int qsmc_update_fused(qsmc_handle_t h, const qsmc_model_t *model,
 #define QSMC_STEP_SMALL_ESS       2
 #define QSMC_STEP_RESAMPLE_DUE    4
 #define QSMC_STEP_RESAMPLE_QUEUED 8
+#define QSMC_STEP_MAX_RANKS 64
 typedef struct qsmc_step_lw {
     int32_t  enabled;            /* queue the resample when it is due (needs x_out)                         */
     int32_t  prefix;             /* arm the gated weight-only prefix behind every update (qsmc_lw_arm_prefix) */
@@ -215,6 +216,19 @@ typedef struct qsmc_step {
     double        moments[14];   /* d <= 4: [sum w' x_m, upper(sum w' x_m x_n)] of the new weights           */
     double        mean[QSMC_MAX_D], cov[QSMC_MAX_D * QSMC_MAX_D], S[QSMC_MAX_D * QSMC_MAX_D], S_err;   /* of a queued resample */
     double        moments_big[1 + QSMC_MAX_D + QSMC_MAX_D * (QSMC_MAX_D + 1) / 2];   /* d > 4, a queued resample: qsmc_moments' out_host */
+    /* A SHARD of a cloud held by `ex_world` processes of one host (one per GPU): with ex_segment != NULL the step makes
+     * the sharded updater's one per-datum collective itself -- qsmc_host_allreduce (below) of [sum w', sum w'^2, min,
+     * #bad, moment sums] right after this shard's sums arrive -- and everything after it (guards, commit, n_ess, the
+     * resample test: smc.py:369-457) runs on the GLOBAL sums, which is what `stats`, `moments`, `norm`, `sumsq`, `n_ess`
+     * then hold; `n` stays this shard's size, `ess_below` / `min_n_ess` are the caller's global figures.  *ex_k is the
+     * exchange's call counter (shared with the caller's other qsmc_host_* calls on the segment; advanced here).
+     * shard_sums[r] = shard r's sum w' (the next resample plan's input).  lw.enabled / lw.prefix must be 0: a sharded
+     * resample needs the shard plan, which is the caller's. */
+    void         *ex_segment;
+    int32_t       ex_rank, ex_world, ex_max_len, ex_reserved;
+    uint64_t     *ex_k;
+    double        ex_timeout_s;
+    double        shard_sums[QSMC_STEP_MAX_RANKS];
 } qsmc_step_t;
 int qsmc_step(qsmc_handle_t h, qsmc_step_t *st, const qsmc_model_t *model, const qsmc_expparam_t *exp,
               int64_t outcome, qsmc_stream_t stream);

@@ -1835,6 +1835,27 @@ int qsmc_step(qsmc_handle_t h, qsmc_step_t *st, const qsmc_model_t *model, const
                                &st->stats, small_d ? st->moments : nullptr, stream);
     if (rc) return rc;
     st->update_token = h->ts.gen;
+    if (st->ex_segment) {
+        // a shard: the one per-datum collective of the sharded updater, here instead of a trip through the caller
+        if (st->ex_world < 1 || st->ex_world > QSMC_STEP_MAX_RANKS || !st->ex_k || st->lw.enabled || st->lw.prefix)
+            return QSMC_ERR_INVALID;
+        const int n_mom = small_d ? d + d * (d + 1) / 2 : 0, nv = 4 + n_mom;
+        double vec[4 + 14], tot[4 + 14], rows[QSMC_STEP_MAX_RANKS * (4 + 14)];
+        vec[0] = st->stats.sum;
+        vec[1] = st->stats.sumsq;
+        vec[2] = st->stats.min;
+        vec[3] = st->stats.n_bad;
+        for (int k = 0; k < n_mom; ++k) vec[4 + k] = st->moments[k];
+        rc = qsmc_host_allreduce(st->ex_segment, st->ex_rank, st->ex_world, st->ex_max_len, ++*st->ex_k, vec, nv, 2, rows, tot,
+                                 st->ex_timeout_s);
+        if (rc) return rc;
+        st->stats.sum = tot[0];
+        st->stats.sumsq = tot[1];
+        st->stats.min = tot[2];
+        st->stats.n_bad = tot[3];
+        for (int k = 0; k < n_mom; ++k) st->moments[k] = tot[4 + k];
+        for (int r = 0; r < st->ex_world; ++r) st->shard_sums[r] = rows[(size_t)r * nv];
+    }
     if (st->lw.redraw_pending) {                               // this update's reduction published the last resample's count
         st->lw.redraws_seen = (int64_t)h->mapped[REDUCE_OUT_MAX - 2];
         st->lw.redraw_pending = 0;

@@ -42,6 +42,9 @@ class StepLW(C.Structure):
                 ("redraws_seen", C.c_int64), ("redraw_pending", C.c_int32), ("reserved2", C.c_int32)]
 
 
+STEP_MAX_RANKS = 64
+
+
 class Step(C.Structure):
     """qsmc_step_t (include/qsmc.h): the cloud's pointers / scalars and the results of the latest qsmc_step."""
     _fields_ = [("x", C.c_void_p), ("ldx", C.c_int64), ("n", C.c_int64),
@@ -57,7 +60,11 @@ class Step(C.Structure):
                 ("moments", C.c_double * 14),
                 ("mean", C.c_double * QSMC_MAX_D), ("cov", C.c_double * (QSMC_MAX_D * QSMC_MAX_D)),
                 ("S", C.c_double * (QSMC_MAX_D * QSMC_MAX_D)), ("S_err", C.c_double),
-                ("moments_big", C.c_double * (1 + QSMC_MAX_D + QSMC_MAX_D * (QSMC_MAX_D + 1) // 2))]
+                ("moments_big", C.c_double * (1 + QSMC_MAX_D + QSMC_MAX_D * (QSMC_MAX_D + 1) // 2)),
+                ("ex_segment", C.c_void_p),
+                ("ex_rank", C.c_int32), ("ex_world", C.c_int32), ("ex_max_len", C.c_int32), ("ex_reserved", C.c_int32),
+                ("ex_k", C.POINTER(C.c_uint64)), ("ex_timeout_s", C.c_double),
+                ("shard_sums", C.c_double * STEP_MAX_RANKS)]
 
 
 STEP_GUARD, STEP_SMALL_ESS, STEP_RESAMPLE_DUE, STEP_RESAMPLE_QUEUED = 1, 2, 4, 8

@@ -74,7 +74,8 @@ class HostExchange:
         self.name = self._shm.name
         self._seq = np.ndarray((2, world, self._SEQ_STRIDE), dtype=np.int64, buffer=self._shm.buf)
         self._pay = np.ndarray((2, world, max_len), dtype=np.float64, buffer=self._shm.buf, offset=seq_bytes)
-        self._k = 0
+        import ctypes as _ct
+        self._kc = _ct.c_uint64(0)        # the call counter, in memory qsmc_step can advance too (`_k` below)
         # the same protocol in C (libqsmc_hip.so, host code) when the library is loadable; pure Python otherwise
         self._c_call, self._c_reduce, self._addr, self._anchor = None, None, None, None
         self._reduce_bufs = {}
@@ -87,6 +88,14 @@ class HostExchange:
             self._addr = ctypes.addressof(self._anchor)
         except Exception:  # noqa: BLE001  (CPU-only test environments without the built library)
             self._c_call = self._c_reduce = None
+
+    @property
+    def _k(self):
+        return self._kc.value
+
+    @_k.setter
+    def _k(self, v):
+        self._kc.value = v
 
     def all_reduce(self, n, min_index=-1):
         """Per-datum form: returns (vec, rows, tot, run) for payloads of n doubles.  Fill `vec` in place and
@@ -256,6 +265,15 @@ class ParticleShardGroup:
         if self.transport == "rccl":
             return "RCCL all-gather on the launch stream + rank-ordered device sum (qsmc_allreduce_sums)"
         return "host shared memory" if self._host is not None else "backend all-gather (%s)" % self.backend
+
+    def step_exchange(self):
+        """The HostExchange qsmc_step can run the per-datum reduction on itself (shared memory transport, the C
+        protocol loaded, at most 64 ranks), else None: the updater then makes the collective from Python."""
+        host = self._host
+        if (self.transport == "rccl" or host is None or host._c_reduce is None or host._addr is None
+                or host.world > 64 or host.max_len < 18):
+            return None
+        return host
 
     @property
     def device_transport(self):

@@ -41,6 +41,7 @@ def _as_int_outcome(outcome):
     return int(arr.reshape(-1)[0])
 
 
+_NO_SHARDED_STEP = bool(__import__("os").environ.get("QSMC_NO_SHARDED_STEP"))    # (A/B switch: a shard's update through the Python path)
 _FROM_STEP = ("moments in the qsmc_step_t",)
 
 
@@ -98,8 +99,11 @@ class SMCUpdater(ParticleDistribution):
         self._native = native_ok(model)
         self._desc = model._native_desc() if self._native else None
         self._timestep_identity = self._timestep_is_identity(model)
-        # the per-datum C path (qsmc_step): native model, one cloud
-        self._st = _native.Step() if (self._native and comm is None and not _NO_STEP) else None
+        # the per-datum C path (qsmc_step): native model; one cloud, or a shard whose per-datum reduction goes through
+        # shared memory (the C call then makes that collective too)
+        self._st_exchange = None if (comm is None or _NO_SHARDED_STEP) else comm.step_exchange()
+        self._st = _native.Step() if (self._native and not _NO_STEP
+                                      and (comm is None or self._st_exchange is not None)) else None
         if self._st is not None:
             import ctypes
             self._st_ref = ctypes.byref(self._st)
@@ -339,6 +343,15 @@ class SMCUpdater(ParticleDistribution):
         st.ess_below = self.n_particles_global * self.resample_thresh
         lw = st.lw
         key = self._prefix_key()
+        ex = self._st_exchange
+        if ex is not None:
+            # a shard: qsmc_step makes the per-datum reduction over the shards itself; the n_ess test needs every shard's
+            # sums and the resample the shard plan, so nothing is armed or queued from C (parallel.py: resample)
+            key = None
+            if st.ex_segment is None:
+                st.ex_segment, st.ex_rank, st.ex_world, st.ex_max_len = ex._addr, ex.rank, ex.world, ex.max_len
+                st.ex_k, st.ex_timeout_s = __import__("ctypes").pointer(ex._kc), ex.timeout
+                self._shard_view = np.ctypeslib.as_array(st.shard_sums)[:ex.world]
         lw.prefix = int(key is not None)
         lw.enabled = 0
         if key is not None:
@@ -387,7 +400,17 @@ class SMCUpdater(ParticleDistribution):
             ep_ref = exps[0]
         st.check_for_resample = check_for_resample
         eng = self._eng
-        eng.step(self._st_ref, self._desc_ref, ep_ref, outcome if type(outcome) is int else _as_int_outcome(outcome))
+        if self._st_exchange is None:
+            eng.step(self._st_ref, self._desc_ref, ep_ref, outcome if type(outcome) is int else _as_int_outcome(outcome))
+        else:
+            try:
+                eng.step(self._st_ref, self._desc_ref, ep_ref, _as_int_outcome(outcome))
+            except RuntimeError as e:
+                if "unsupported" in str(e):           # (qsmc_host_allreduce's time-out status)
+                    raise RuntimeError("HostExchange: a peer did not arrive within {} s".format(
+                        self._st_exchange.timeout)) from None
+                raise
+            self._shard_sums = self._shard_view.copy()       # every shard's sum w' (the next resample plan's input)
         eng.update_gen = st.update_token
         if not check_for_resample:
             eng._armed_prefix = None                  # (the call disarmed the gated prefix)

@@ -361,6 +361,7 @@ def _check_sharded_updater_variant(comm0, rank, world, tmpdir, variant):
     else:
         comm = ParticleShardGroup(seed=1234, placement="mixed")    # fully mixing count matrix
     n_local = 60000
+    epoch_start = comm._epoch
     ts = (9 / 8) ** np.arange(50.0)
     rs = np.random.RandomState(0)
     outcomes = (rs.random_sample(50) >= np.cos(0.3 * ts / 2) ** 2).astype(int)
@@ -378,6 +379,26 @@ def _check_sharded_updater_variant(comm0, rank, world, tmpdir, variant):
     rows = comm.gather_rows(torch.from_numpy(rec))
     for r in range(1, world):
         assert np.array_equal(rows[0], rows[r]), "ranks disagree on the global quantities"
+    if variant == "local":
+        # the shard's update went through qsmc_step with the per-datum reduction inside the C call (shared-memory
+        # transport); the same run with the collective made from Python (the round-2 sharded path) is the same run
+        assert upd._st is not None and upd._st_exchange is comm._host
+        epoch0 = comm._epoch
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            comm._epoch = epoch_start
+            upd2 = qi.SMCUpdater(qi.SimplePrecessionModel(), n_local, qi.UniformDistribution([0, 1]),
+                                 device_rng=True, seed=int(os.environ.get("QSMC_TEST_SEED", "5")), comm=comm)
+            upd2._st = upd2._st_exchange = None
+            for k in range(50):
+                upd2.update(int(outcomes[k]), ts[k:k + 1])
+            comm._epoch = max(epoch0, comm._epoch)
+        assert upd2.resample_count == upd.resample_count
+        np.testing.assert_array_equal(np.array(upd2.normalization_record), np.array(upd.normalization_record))
+        np.testing.assert_array_equal(upd2.particle_locations, upd.particle_locations)
+        np.testing.assert_array_equal(upd2.particle_weights, upd.particle_weights)
+        assert upd2.n_ess == upd.n_ess and upd2.min_n_ess == upd.min_n_ess
+        del upd2
     sizes = comm.gather_rows(np.array([float(upd.n_particles)]))[:, 0]
     assert sizes.sum() == n_local * world == upd.n_particles_global      # the global count is conserved
     if variant in ("local", "local-segmented"):
