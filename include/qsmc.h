@@ -180,6 +180,8 @@ int qsmc_update_fused(qsmc_handle_t h, const qsmc_model_t *model,
 #define QSMC_STEP_SMALL_ESS       2
 #define QSMC_STEP_RESAMPLE_DUE    4
 #define QSMC_STEP_RESAMPLE_QUEUED 8
+#define QSMC_STEP_PLAN_READY      16
+#define QSMC_STEP_PREFIX_QUEUED   32
 #define QSMC_STEP_MAX_RANKS 64
 typedef struct qsmc_step_lw {
     int32_t  enabled;            /* queue the resample when it is due (needs x_out)                         */
@@ -229,6 +231,17 @@ typedef struct qsmc_step {
     uint64_t     *ex_k;
     double        ex_timeout_s;
     double        shard_sums[QSMC_STEP_MAX_RANKS];
+    /* ... and, with plan_enabled, the first moves of a due resample: the shard plan (qsmc_shard_plan_totals with
+     * plan_seed / plan_epoch over shard_sums[] and plan_n_total; status gets QSMC_STEP_PLAN_READY, plan_totals[] the plan)
+     * and, when every shard's share is within plan_tol of the balanced size n_total / world and none is empty
+     * (plan_stay = 1: children stay with their ancestors, parallel.py), the resampler's weight-only prefix for THIS shard
+     * -- qsmc_lw_resample_prepare(w, n, shard_sums[rank], plan_totals[rank], plan_prefix_seed, plan_epoch) from this
+     * update's tile sums -- queued at once (QSMC_STEP_PREFIX_QUEUED); the caller's resample finds both done. */
+    int32_t       plan_enabled, plan_stay;
+    uint64_t      plan_seed, plan_epoch, plan_prefix_seed;
+    int64_t       plan_n_total;
+    double        plan_tol;
+    int64_t       plan_totals[QSMC_STEP_MAX_RANKS];
 } qsmc_step_t;
 int qsmc_step(qsmc_handle_t h, qsmc_step_t *st, const qsmc_model_t *model, const qsmc_expparam_t *exp,
               int64_t outcome, qsmc_stream_t stream);
@@ -276,6 +289,15 @@ int qsmc_clip_weights(qsmc_handle_t h, double *w, int64_t n, double norm,
  * distributions.py:299-307). */
 int qsmc_weight_stats(qsmc_handle_t h, const double *w, int64_t n, double norm,
                       double *stats_dev, qsmc_update_stats_t *stats_host, qsmc_stream_t stream);
+
+/* The shard plan of a sharded resample (host only; no handle, no GPU): totals_out[h] = how many of the n_total new
+ * particles descend from shard h, T ~ Multinomial(n_total; W_h / sum W), exact (conditional binomials: inversion /
+ * BTPE on a Philox4x32-10 stream keyed by (seed, epoch)).  Every rank calls it with the same arguments -- the W_h
+ * arrive with the update's sums (qsmc_host_allreduce rows / qsmc_step_t.shard_sums) -- and holds the same plan
+ * without a collective.  Then shard h draws ITS totals_out[h] children from its local weights: given T the ancestors
+ * are i.i.d. within a shard, which is resamplers.py:308-311's multinomial over the whole cloud, factorised. */
+int qsmc_shard_plan_totals(uint64_t seed, uint64_t epoch, const double *shard_weights, int32_t n_shards,
+                           int64_t n_total, int64_t *totals_out);
 
 /* Host-side all-gather of n <= max_len doubles between the `world` processes of one host through a shared
  * memory segment (POSIX shm mapped by every rank; layout in qinfer_amd/parallel.py: HostExchange): call number k

@@ -1880,6 +1880,31 @@ int qsmc_step(qsmc_handle_t h, qsmc_step_t *st, const qsmc_model_t *model, const
     if (!(ess < st->ess_below)) return QSMC_OK;
     st->status |= QSMC_STEP_RESAMPLE_DUE;
     static const bool no_queue = getenv("QSMC_NO_STEP_RESAMPLE") != nullptr;              // (A/B switch)
+    if (st->ex_segment && st->plan_enabled && !no_queue) {
+        // a shard: plan the resample (every rank draws the same plan from the shard sums it has just received) and start
+        // this shard's weight-only prefix; mean / covariance / square root and the sampler are the caller's, behind it
+        const int G = st->ex_world;
+        rc = qsmc_shard_plan_totals(st->plan_seed, st->plan_epoch, st->shard_sums, G, st->plan_n_total, st->plan_totals);
+        if (rc) return QSMC_OK;                                // (odd shard sums: the caller's own plan raises)
+        st->status |= QSMC_STEP_PLAN_READY;
+        const int64_t target = st->plan_n_total / G;
+        int64_t dev = 0, tmin = st->plan_totals[0];
+        for (int r = 0; r < G; ++r) {
+            const int64_t e = st->plan_totals[r] > target ? st->plan_totals[r] - target : target - st->plan_totals[r];
+            dev = e > dev ? e : dev;
+            tmin = st->plan_totals[r] < tmin ? st->plan_totals[r] : tmin;
+        }
+        const double drift = (double)dev / (double)(target > 1 ? target : 1);
+        st->plan_stay = (drift <= st->plan_tol && tmin > 0) ? 1 : 0;
+        if (st->plan_stay && st->shard_sums[st->ex_rank] > 0.0) {
+            h->ts.armed = h->ts.gen;                           // these weights ARE update number ts.gen's output
+            rc = qsmc_lw_resample_prepare(h, st->w, st->n, st->shard_sums[st->ex_rank], st->plan_totals[st->ex_rank],
+                                          st->plan_prefix_seed, st->plan_epoch, stream);
+            if (rc) return rc;
+            st->status |= QSMC_STEP_PREFIX_QUEUED;
+        }
+        return QSMC_OK;
+    }
     if (!st->lw.enabled || !st->lw.x_out || st->lw.n_out <= 0 || no_queue) return QSMC_OK;
     const CanonSpec canon{st->lw.canon_kind, st->lw.canon_allow_sub, st->lw.canon_basis};
     hipStream_t s = (hipStream_t)stream;
@@ -2337,6 +2362,143 @@ int qsmc_allreduce_sums(qsmc_handle_t h, const double *vec_dev, int32_t n, int32
     std::atomic_thread_fence(std::memory_order_acquire);
     memcpy(tot_host, h->mapped, (size_t)n * sizeof(double));
     if (firsts_host) memcpy(firsts_host, h->mapped + n, (size_t)h->cc.nranks * sizeof(double));
+    return QSMC_OK;
+}
+
+// ---- host: the shard plan of a sharded resample ------------------------------------------------------------
+// T ~ Multinomial(n_total; W_h / sum W): how many of the n_total children descend from shard h.  Every rank draws it
+// from the same (seed, epoch) and gets the same answer, so planning a resample needs no communication (the W_h came
+// with the update's sums).  G - 1 conditional binomials, T_h | T_<h ~ Binomial(n_left, W_h / W_>=h); the binomial is
+// exact: sequential inversion while n min(p, 1 - p) < 30, else the BTPE rejection algorithm (Kachitvichyanukul &
+// Schmeiser, "Binomial random variate generation", CACM 31 (1988) 216-222, steps 0-6: triangle / parallelogram /
+// two exponential tails as the majorising function, squeeze, explicit recursion near the mode, Stirling bound far
+// from it).  Uniforms: Philox4x32-10, key = seed, counter (draw index, epoch, stream 0x504C414E "PLAN"): two per block.
+struct PlanRng {
+    uint32_t k0, k1, epoch_lo, epoch_hi;
+    uint64_t block;
+    int have;
+    double spare;
+    double next() {
+        if (have) { have = 0; return spare; }
+        const U4 r = philox4x32_10(U4{(uint32_t)block, (uint32_t)(block >> 32) ^ epoch_hi, epoch_lo, 0x504C414Eu}, k0, k1);
+        ++block;
+        spare = u53(r.z, r.w);
+        have = 1;
+        return u53(r.x, r.y);
+    }
+};
+
+static int64_t binomial_inversion(PlanRng &g, int64_t n, double p) {     // n p < 30, p <= 1/2
+    const double q = 1.0 - p, s = p / q, a = (double)(n + 1) * s;
+    const double r0 = exp((double)n * log(q));                            // Pr(0); n p < 30 keeps it above e^-60
+    for (;;) {
+        double r = r0, u = g.next();
+        int64_t x = 0;
+        bool ok = true;
+        while (u > r) {
+            u -= r;
+            ++x;
+            if (x > n || x > 4096) { ok = false; break; }                 // (rounding at the far tail: draw again)
+            r *= a / (double)x - s;
+        }
+        if (ok) return x;
+    }
+}
+
+static double btpe_stirling(double t2) {                                  // the correction series of step 5.3
+    return (13860.0 - (462.0 - (132.0 - (99.0 - 140.0 / t2) / t2) / t2) / t2) / 166320.0;
+}
+
+static int64_t binomial_btpe(PlanRng &g, int64_t n, double p) {           // n p >= 30, p <= 1/2
+    const double r = p, q = 1.0 - r, nd = (double)n, nrq = nd * r * q;
+    const double fm = nd * r + r;
+    const int64_t M = (int64_t)floor(fm);
+    const double p1 = floor(2.195 * sqrt(nrq) - 4.6 * q) + 0.5;
+    const double xm = (double)M + 0.5, xl = xm - p1, xr = xm + p1;
+    const double c = 0.134 + 20.5 / (15.3 + (double)M);
+    double al = (fm - xl) / (fm - xl * r);
+    const double laml = al * (1.0 + 0.5 * al);
+    al = (xr - fm) / (xr * q);
+    const double lamr = al * (1.0 + 0.5 * al);
+    const double p2 = p1 * (1.0 + 2.0 * c), p3 = p2 + c / laml, p4 = p3 + c / lamr;
+    for (;;) {
+        const double u = g.next() * p4;
+        double v = g.next();
+        int64_t y;
+        if (u <= p1) {                                                    // 1: the triangle -- accept at once
+            return (int64_t)floor(xm - p1 * v + u);
+        } else if (u <= p2) {                                             // 2: the parallelograms
+            const double x = xl + (u - p1) / c;
+            v = v * c + 1.0 - fabs((double)M - x + 0.5) / p1;
+            if (v > 1.0 || v <= 0.0) continue;
+            y = (int64_t)floor(x);
+        } else if (u <= p3) {                                             // 3: left exponential tail
+            if (v <= 0.0) continue;
+            y = (int64_t)floor(xl + log(v) / laml);
+            if (y < 0) continue;
+            v = v * (u - p2) * laml;
+        } else {                                                          // 4: right exponential tail
+            if (v <= 0.0) continue;
+            y = (int64_t)floor(xr - log(v) / lamr);
+            if (y > n) continue;
+            v = v * (u - p3) * lamr;
+        }
+        // 5: accept y with probability f(y) / (majorising function), f(y) = Pr(y) / Pr(M)
+        const int64_t k = y > M ? y - M : M - y;
+        if (k <= 20 || (double)k >= 0.5 * nrq - 1.0) {                    // 5.1: f(y) by the recursion from the mode
+            const double s = r / q, a = s * (nd + 1.0);
+            double F = 1.0;
+            if (M < y) for (int64_t i = M + 1; i <= y; ++i) F *= a / (double)i - s;
+            else if (M > y) for (int64_t i = y + 1; i <= M; ++i) F /= a / (double)i - s;
+            if (v > F) continue;
+            return y;
+        }
+        const double kd = (double)k;                                      // 5.2: squeeze on ln f(y)
+        const double rho = (kd / nrq) * ((kd * (kd / 3.0 + 0.625) + 0.1666666666666) / nrq + 0.5);
+        const double t = -kd * kd / (2.0 * nrq), A = log(v);
+        if (A < t - rho) return y;
+        if (A > t + rho) continue;
+        const double x1 = (double)(y + 1), f1 = (double)(M + 1), z = nd + 1.0 - (double)M, w = nd - (double)y + 1.0;   // 5.3
+        const double bound = xm * log(f1 / x1) + (nd - (double)M + 0.5) * log(z / w) + (double)(y - M) * log(w * r / (x1 * q)) +
+                             btpe_stirling(f1 * f1) / f1 + btpe_stirling(z * z) / z + btpe_stirling(x1 * x1) / x1 +
+                             btpe_stirling(w * w) / w;
+        if (A > bound) continue;
+        return y;
+    }
+}
+
+static int64_t binomial_exact(PlanRng &g, int64_t n, double p) {
+    if (n <= 0 || !(p > 0.0)) return 0;
+    if (p >= 1.0) return n;
+    const bool flip = p > 0.5;
+    const double r = flip ? 1.0 - p : p;
+    const int64_t y = (double)n * r < 30.0 ? binomial_inversion(g, n, r) : binomial_btpe(g, n, r);
+    return flip ? n - y : y;
+}
+
+int qsmc_shard_plan_totals(uint64_t seed, uint64_t epoch, const double *shard_weights, int32_t n_shards, int64_t n_total,
+                           int64_t *totals_out) {
+    if (!shard_weights || !totals_out || n_shards < 1 || n_total < 0) return QSMC_ERR_INVALID;
+    double rest = 0.0;
+    for (int h = 0; h < n_shards; ++h) {
+        if (!(shard_weights[h] >= 0.0) || !std::isfinite(shard_weights[h])) return QSMC_ERR_INVALID;
+        rest += shard_weights[h];
+    }
+    if (!(rest > 0.0)) return QSMC_ERR_INVALID;
+    PlanRng g{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)epoch, (uint32_t)(epoch >> 32), 0ull, 0, 0.0};
+    int64_t left = n_total;
+    for (int h = 0; h < n_shards; ++h) {
+        // tail mass summed from the back would be more accurate; with <= 64 non-negative terms the running difference is
+        // good to a few ulp, and the last shard with weight takes what is left so that the total is exact
+        double tail = 0.0;
+        for (int j = h + 1; j < n_shards; ++j) tail += shard_weights[j];
+        int64_t t;
+        if (left == 0 || shard_weights[h] == 0.0) t = 0;
+        else if (tail == 0.0) t = left;
+        else t = binomial_exact(g, left, shard_weights[h] / (shard_weights[h] + tail));
+        totals_out[h] = t;
+        left -= t;
+    }
     return QSMC_OK;
 }
 

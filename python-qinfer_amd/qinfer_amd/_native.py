@@ -64,10 +64,14 @@ class Step(C.Structure):
                 ("ex_segment", C.c_void_p),
                 ("ex_rank", C.c_int32), ("ex_world", C.c_int32), ("ex_max_len", C.c_int32), ("ex_reserved", C.c_int32),
                 ("ex_k", C.POINTER(C.c_uint64)), ("ex_timeout_s", C.c_double),
-                ("shard_sums", C.c_double * STEP_MAX_RANKS)]
+                ("shard_sums", C.c_double * STEP_MAX_RANKS),
+                ("plan_enabled", C.c_int32), ("plan_stay", C.c_int32),
+                ("plan_seed", C.c_uint64), ("plan_epoch", C.c_uint64), ("plan_prefix_seed", C.c_uint64),
+                ("plan_n_total", C.c_int64), ("plan_tol", C.c_double),
+                ("plan_totals", C.c_int64 * STEP_MAX_RANKS)]
 
 
-STEP_GUARD, STEP_SMALL_ESS, STEP_RESAMPLE_DUE, STEP_RESAMPLE_QUEUED = 1, 2, 4, 8
+STEP_GUARD, STEP_SMALL_ESS, STEP_RESAMPLE_DUE, STEP_RESAMPLE_QUEUED, STEP_PLAN_READY, STEP_PREFIX_QUEUED = 1, 2, 4, 8, 16, 32
 
 _P = C.c_void_p          # device pointers and streams travel as integers
 _I64, _I32, _F64, _U64 = C.c_int64, C.c_int32, C.c_double, C.c_uint64
@@ -111,6 +115,7 @@ SIGNATURES = {
     "qsmc_lw_resample_philox": [_P, C.POINTER(ModelDesc), _I32, _P, _I64, _I64, _I32, _P, _F64, _F64,
                                 C.POINTER(_F64), C.POINTER(_F64), _I64, _U64, _U64, _I32, _P, _I64,
                                 C.POINTER(_I64), _P],
+    "qsmc_shard_plan_totals": [_U64, _U64, C.POINTER(_F64), _I32, _I64, C.POINTER(_I64)],
     "qsmc_host_allgather": [_P, _I32, _I32, _I32, _U64, _P, _I32, _P, _F64],
     "qsmc_host_allreduce": [_P, _I32, _I32, _I32, _U64, _P, _I32, _I32, _P, _P, _F64],
     "qsmc_comm_unique_id": [_P],

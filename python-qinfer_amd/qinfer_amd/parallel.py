@@ -416,10 +416,19 @@ class ParticleShardGroup:
 
     def plan_totals(self, shard_weights, n_total, epoch):
         """T[h] = how many of the n_total new particles descend from shard h ~ Multinomial(n_total; W/sum W);
-        identical on all ranks (shared-seed host Philox)."""
-        p = np.asarray(shard_weights, dtype=np.float64)
-        p = p / p.sum()
-        return self._plan_generator(epoch, 1).multinomial(int(n_total), p).astype(np.int64)
+        identical on all ranks: the library's host-side plan on a Philox stream keyed by (group seed, epoch)
+        (qsmc_shard_plan_totals -- the same call qsmc_step makes when it plans a shard's resample itself)."""
+        import ctypes
+        from . import _native
+        w = np.ascontiguousarray(shard_weights, dtype=np.float64)
+        out = np.empty(len(w), dtype=np.int64)
+        rc = _native.load().qsmc_shard_plan_totals(
+            ctypes.c_uint64(self.seed & (2 ** 64 - 1)), ctypes.c_uint64(int(epoch)),
+            w.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), len(w), int(n_total),
+            out.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)))
+        if rc:
+            raise ValueError("shard plan: invalid shard weights {}".format(w))
+        return out
 
     @staticmethod
     def plan_counts_minimal(totals, n_per_rank):
@@ -484,14 +493,20 @@ class ParticleShardGroup:
         seed_r = resampler._seed + 0x9E3779B97F4A7C15 * (self.rank + 1)
         defer = hasattr(resampler, "_flush_failed_warning")       # stay asynchronous; warn at the next sync
         target = n_total // G                                       # balanced shard size
+        prefix_done = False
         if self.placement == "local":
-            totals = self.plan_totals(W, n_total, epoch)
+            # (qsmc_step may have drawn this very plan -- same seed, epoch and shard sums -- and queued the prefix already)
+            pre, updater._step_plan = getattr(updater, "_step_plan", None), None
+            if pre is not None and pre[0] == epoch and pre[3] == getattr(updater, "_w_token", None):
+                totals, prefix_done = pre[1], pre[2]
+            else:
+                totals = self.plan_totals(W, n_total, epoch)
             drift = np.abs(totals - target).max() / max(target, 1)
             stay = drift <= self.rebalance_tol and totals.min() > 0
         else:
             totals, stay = None, False
         big = n_local > resampler._segment_limit        # beyond the bucketed sampler's single pass: segments (resamplers.py)
-        if stay and not big:
+        if stay and not big and not prefix_done:
             # children stay with their ancestor: this rank draws its T_h particles, nothing moves.  The
             # weight-only prefix (chunk sums, multinomial chunk counts) is queued before mean / cov / sqrtm
             resampler._arm_update_sums(updater)

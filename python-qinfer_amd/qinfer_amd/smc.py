@@ -41,6 +41,7 @@ def _as_int_outcome(outcome):
     return int(arr.reshape(-1)[0])
 
 
+_NO_SHARDED_PLAN = bool(__import__("os").environ.get("QSMC_NO_SHARDED_PLAN"))    # (A/B switch: the shard plan and prefix from Python)
 _NO_SHARDED_STEP = bool(__import__("os").environ.get("QSMC_NO_SHARDED_STEP"))    # (A/B switch: a shard's update through the Python path)
 _FROM_STEP = ("moments in the qsmc_step_t",)
 
@@ -352,6 +353,16 @@ class SMCUpdater(ParticleDistribution):
                 st.ex_segment, st.ex_rank, st.ex_world, st.ex_max_len = ex._addr, ex.rank, ex.world, ex.max_len
                 st.ex_k, st.ex_timeout_s = __import__("ctypes").pointer(ex._kc), ex.timeout
                 self._shard_view = np.ctypeslib.as_array(st.shard_sums)[:ex.world]
+                self._plan_view = np.ctypeslib.as_array(st.plan_totals)[:ex.world]
+            # the first moves of a due resample from C as well: the shard plan and, when the children stay with their
+            # ancestors, this shard's weight-only prefix (ParticleShardGroup.resample finds both done)
+            comm = self._comm
+            st.plan_enabled = int(comm.placement == "local" and type(r) is LiuWestResampler
+                                  and getattr(r, "_device_rng", False) and n <= r._segment_limit and not _NO_SHARDED_PLAN)
+            if st.plan_enabled:
+                st.plan_seed, st.plan_epoch = comm.seed & _U64, comm._epoch + 1
+                st.plan_prefix_seed = (r._seed + 0x9E3779B97F4A7C15 * (comm.rank + 1)) & _U64
+                st.plan_n_total, st.plan_tol = self.n_particles_global, float(comm.rebalance_tol)
         lw.prefix = int(key is not None)
         lw.enabled = 0
         if key is not None:
@@ -411,6 +422,9 @@ class SMCUpdater(ParticleDistribution):
                         self._st_exchange.timeout)) from None
                 raise
             self._shard_sums = self._shard_view.copy()       # every shard's sum w' (the next resample plan's input)
+            if st.status & _native.STEP_PLAN_READY:
+                self._step_plan = (st.plan_epoch, self._plan_view.copy(), bool(st.status & _native.STEP_PREFIX_QUEUED),
+                                   st.update_token)
         eng.update_gen = st.update_token
         if not check_for_resample:
             eng._armed_prefix = None                  # (the call disarmed the gated prefix)

@@ -103,3 +103,55 @@ def test_compute_without_gpu_fails_loudly():
         qi.SMCUpdater(qi.SimplePrecessionModel(), 10, qi.UniformDistribution([0, 1]))
     with pytest.raises(qi.NativeLibraryError):
         qi.SimplePrecessionModel().likelihood(np.array([0]), np.array([[0.5]]), np.array([1.0]))
+
+
+def _plan(lib, seed, epoch, w, n_total):
+    w = np.ascontiguousarray(w, dtype=np.float64)
+    out = np.empty(len(w), dtype=np.int64)
+    rc = lib.qsmc_shard_plan_totals(C.c_uint64(seed), C.c_uint64(epoch), w.ctypes.data_as(C.POINTER(C.c_double)), len(w),
+                                    int(n_total), out.ctypes.data_as(C.POINTER(C.c_int64)))
+    assert rc == 0
+    return out
+
+
+@pytest.mark.parametrize("n,p", [(40, 0.3), (25, 0.97), (400, 0.02), (400, 0.2), (3000, 0.5), (100000, 0.07),
+                                 (80000000, 0.125), (80000000, 0.5), (12345678, 0.999)])
+def test_shard_plan_binomial_law(lib, n, p):
+    """qsmc_shard_plan_totals with two shards IS a binomial draw: its law against the exact pmf (scipy), through both
+    samplers (inversion below n min(p, 1-p) = 30, BTPE above) -- a chi-square over the bins that hold the mass, plus the
+    first two moments; and the obvious invariants (sum, determinism, epoch and seed dependence)."""
+    from scipy import stats
+    draws = 40000
+    x = np.array([_plan(lib, 7, e, [p, 1 - p], n)[0] for e in range(draws)])
+    assert x.min() >= 0 and x.max() <= n
+    mu, var = n * p, n * p * (1 - p)
+    assert abs(x.mean() - mu) < 5 * np.sqrt(var / draws)
+    assert abs(x.var() / var - 1) < 5 * np.sqrt(2.0 / draws) + 3.0 / max(var, 1.0) ** 0.5 / np.sqrt(draws)
+    # bins of (about) equal probability from the exact quantiles
+    qs = np.unique(stats.binom.ppf(np.linspace(0, 1, 41)[1:-1], n, p)).astype(np.int64)
+    edges = np.concatenate([[-1], qs, [n]])
+    probs = np.diff(stats.binom.cdf(edges, n, p))
+    keep = probs > 0
+    obs = np.histogram(x, bins=edges.astype(np.float64) + 0.5)[0]
+    chi2 = (((obs - draws * probs) ** 2)[keep] / (draws * probs[keep])).sum()
+    assert stats.chi2.sf(chi2, keep.sum() - 1) > 1e-5, (chi2, keep.sum())
+
+
+def test_shard_plan_multinomial(lib):
+    w = np.array([3.0, 0.0, 1.0, 2.0, 2.0])
+    n = 1000003
+    t = _plan(lib, 11, 5, w, n)
+    assert t.sum() == n and t[1] == 0 and np.array_equal(t, _plan(lib, 11, 5, w, n))
+    assert not np.array_equal(t, _plan(lib, 11, 6, w, n)) and not np.array_equal(t, _plan(lib, 12, 5, w, n))
+    ts = np.array([_plan(lib, 3, e, w, 5000) for e in range(4000)])
+    p = w / w.sum()
+    assert np.all(ts.sum(axis=1) == 5000)
+    np.testing.assert_allclose(ts.mean(axis=0), 5000 * p, atol=5 * np.sqrt(5000 * 0.25 / 4000))
+    cov = np.cov(ts.T)
+    want = 5000 * (np.diag(p) - np.outer(p, p))
+    np.testing.assert_allclose(cov, want, atol=0.12 * 5000 * 0.25)
+    assert np.array_equal(_plan(lib, 1, 1, [0.0, 2.5], 77), [0, 77])
+    bad = np.array([1.0, -1.0])
+    out = np.empty(2, dtype=np.int64)
+    assert lib.qsmc_shard_plan_totals(C.c_uint64(1), C.c_uint64(1), bad.ctypes.data_as(C.POINTER(C.c_double)), 2, 10,
+                                      out.ctypes.data_as(C.POINTER(C.c_int64))) != 0
