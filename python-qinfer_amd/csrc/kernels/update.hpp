@@ -377,6 +377,7 @@ struct MultiArgs {
     int64_t outcome[MULTI_KMAX];
 };
 
+constexpr int MULTI_PER_THREAD = 8;
 template <int KIND, bool POW>
 __global__ __launch_bounds__(QSMC_BLOCK) void k_update_multi(
     const double *__restrict__ x, int64_t ldx, int64_t n, const double *__restrict__ w_in,
@@ -390,31 +391,57 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_update_multi(
     for (int q = 0; q < NS; ++q) s[q] = 0.0;
     double mn = INFINITY;
     const double inv_norm = 1.0 / prev_norm;
-    for (int64_t i = (int64_t)blockIdx.x * QSMC_BLOCK + threadIdx.x; i < n;
-         i += (int64_t)gridDim.x * QSMC_BLOCK) {
-        double p[D];
+    // tiles of 2048 consecutive particles (eight per thread), as in k_update_fused with 16-byte loads: the sum of the final
+    // weights per tile and wave goes to ro.tile_sums, so that a resample after the window starts from them (and from the
+    // chunk-sum prefix the reducing launch forms beside the reduction) instead of reading the weights once more
+    constexpr int64_t TILE = (int64_t)QSMC_BLOCK * MULTI_PER_THREAD;
+    for (int64_t base = (int64_t)blockIdx.x * TILE; base < n; base += (int64_t)gridDim.x * TILE) {
+        double tsum = 0.0;
+#pragma unroll 1
+        for (int u = 0; u < MULTI_PER_THREAD; ++u) {
+            const int64_t i = base + (int64_t)u * QSMC_BLOCK + threadIdx.x;
+            if (i < n) {
+                double p[D];
 #pragma unroll
-        for (int m = 0; m < D; ++m)
-            if (m < d) p[m] = x[m * ldx + i];
-        double w = (w_in ? w_in[i] : 1.0) * inv_norm;
+                for (int m = 0; m < D; ++m)
+                    if (m < d) p[m] = x[m * ldx + i];
+                double w = (w_in ? w_in[i] : 1.0) * inv_norm;
 #pragma unroll
-        for (int k = 0; k < MULTI_KMAX; ++k) {
-            if (k < ma.k) {
-                w = w * model_lik<KIND, POW>(p, ma.e[k], ma.outcome[k]);
-                s[3 * k] += w;
-                s[3 * k + 1] += w * w;
-                s[3 * k + 2] += (w >= 0.0) ? 0.0 : 1.0;
-                mn = fmin(mn, w);
+                for (int k = 0; k < MULTI_KMAX; ++k) {
+                    if (k < ma.k) {
+                        w = w * model_lik<KIND, POW>(p, ma.e[k], ma.outcome[k]);
+                        s[3 * k] += w;
+                        s[3 * k + 1] += w * w;
+                        s[3 * k + 2] += (w >= 0.0) ? 0.0 : 1.0;
+                        mn = fmin(mn, w);
+                    }
+                }
+                w_out[i] = w;
+                tsum += w;
+                int q = 3 * MULTI_KMAX + DMOM;
+#pragma unroll
+                for (int m = 0; m < DMOM; ++m) {
+                    const double wx = w * p[m];
+                    s[3 * MULTI_KMAX + m] += wx;
+#pragma unroll
+                    for (int m2 = m; m2 < DMOM; ++m2) s[q++] += wx * p[m2];
+                }
             }
         }
-        w_out[i] = w;
-        int q = 3 * MULTI_KMAX + DMOM;
-#pragma unroll
-        for (int m = 0; m < DMOM; ++m) {
-            const double wx = w * p[m];
-            s[3 * MULTI_KMAX + m] += wx;
-#pragma unroll
-            for (int m2 = m; m2 < DMOM; ++m2) s[q++] += wx * p[m2];
+        if (ro.tile_sums) {                      // uniform
+            const double t = wave_sum(tsum);
+            if ((threadIdx.x & (QSMC_WAVE - 1)) == 0)
+                ro.tile_sums[(base / TILE) * QSMC_WAVES_PER_BLOCK + threadIdx.x / QSMC_WAVE] = t;
+        }
+    }
+    if (ro.tile_sums) {                          // (as in k_update_fused: zero the last chunk's missing tiles)
+        static_assert(4096 % TILE == 0, "tiles per chunk");
+        constexpr int64_t PER_CHUNK = 4096 / TILE * QSMC_WAVES_PER_BLOCK;
+        const int64_t last = (n - 1) / TILE;
+        if ((int64_t)blockIdx.x == last % (int64_t)gridDim.x) {
+            const int64_t first = (last + 1) * QSMC_WAVES_PER_BLOCK;
+            const int64_t end = (first + PER_CHUNK - 1) / PER_CHUNK * PER_CHUNK;
+            for (int64_t k = first + threadIdx.x; k < end; k += QSMC_BLOCK) ro.tile_sums[k] = 0.0;
         }
     }
     block_publish<NS>(s, mn, ro);

@@ -402,7 +402,7 @@ static int launch_reduce(qsmc_ctx *h, int ns, int grid, const ReduceOut &ro, hip
     case N:                                                                                           \
         hipLaunchKernelGGL((k_reduce_partials_scan<N>), dim3(2), dim3(QSMC_BLOCK), 0, s, grid, ro);   \
         break;
-            LRS(3) LRS(5) LRS(8) LRS(12) LRS(17)
+            LRS(3) LRS(5) LRS(8) LRS(12) LRS(17) LRS(24) LRS(26) LRS(29) LRS(33) LRS(38)
 #undef LRS
             default: return QSMC_ERR_INVALID;
         }
@@ -839,6 +839,29 @@ int qsmc_are_models_valid(qsmc_handle_t h, const qsmc_model_t *model, const doub
 static int resample_prefix(qsmc_ctx *h, const double *w, int64_t n_in, double norm, int64_t n_out, uint64_t seed,
                            uint64_t epoch, hipStream_t s, bool speculative);
 
+// the chunk-sum prefix beside the reduction (k_reduce_partials_scan), for the update kernels that leave tile sums
+static bool reduce_scan_has(int ns) {
+    return ns == 3 || ns == 5 || ns == 8 || ns == 12 || ns == 17 || ns == 24 || ns == 26 || ns == 29 || ns == 33 || ns == 38;
+}
+static int setup_tile_prefix(qsmc_ctx *h, ReduceOut &ro, int64_t n, int per_block, int ns) {
+    static const bool tile_prefix_on = getenv("QSMC_NO_TILE_PREFIX") == nullptr;     // (A/B switch)
+    const int64_t tp_chunks = (n + BUCKET_CHUNK - 1) / BUCKET_CHUNK;
+    if (!(tile_prefix_on && ro.tile_sums && tp_chunks <= TILE_PREFIX_MAX_CHUNKS && reduce_scan_has(ns))) return QSMC_OK;
+    if (h->tile_prefix_cap < (size_t)tp_chunks + 1) {
+        if (h->tile_prefix) HIP_TRY(h, hipFree(h->tile_prefix));
+        h->tile_prefix = nullptr;
+        h->tile_prefix_cap = 0;
+        HIP_TRY(h, hipMalloc(&h->tile_prefix, (size_t)(TILE_PREFIX_MAX_CHUNKS + 1) * sizeof(double)));
+        h->tile_prefix_cap = TILE_PREFIX_MAX_CHUNKS + 1;
+    }
+    ro.tile_prefix = h->tile_prefix;
+    ro.tp_chunks = (int)tp_chunks;
+    ro.tp_tpc = BUCKET_CHUNK / per_block * QSMC_WAVES_PER_BLOCK;
+    ro.tp_ntiles = (long long)((n + per_block - 1) / per_block) * QSMC_WAVES_PER_BLOCK;
+    h->tile_prefix_gen = h->ts.gen;
+    return QSMC_OK;
+}
+
 int qsmc_update_fused(qsmc_handle_t h, const qsmc_model_t *model, const double *x, int64_t ldx, int64_t n,
                       const double *w_in, double *w_out, double prev_norm, const qsmc_expparam_t *exp,
                       int64_t outcome, double *stats_dev, qsmc_update_stats_t *stats_host, double *moments_host,
@@ -877,22 +900,8 @@ int qsmc_update_fused(qsmc_handle_t h, const qsmc_model_t *model, const double *
     ++h->ts.gen;
     h->ts.armed = 0;
     h->spec.launched = 0;
-    static const bool tile_prefix_on = getenv("QSMC_NO_TILE_PREFIX") == nullptr;     // (A/B switch)
-    const int64_t tp_chunks = (n + BUCKET_CHUNK - 1) / BUCKET_CHUNK;
-    if (tile_prefix_on && ro.tile_sums && tp_chunks <= TILE_PREFIX_MAX_CHUNKS && (ns == 3 || ns == 5 || ns == 8 || ns == 12 || ns == 17)) {
-        if (h->tile_prefix_cap < (size_t)tp_chunks + 1) {
-            if (h->tile_prefix) HIP_TRY(h, hipFree(h->tile_prefix));
-            h->tile_prefix = nullptr;
-            h->tile_prefix_cap = 0;
-            HIP_TRY(h, hipMalloc(&h->tile_prefix, (size_t)(TILE_PREFIX_MAX_CHUNKS + 1) * sizeof(double)));
-            h->tile_prefix_cap = TILE_PREFIX_MAX_CHUNKS + 1;
-        }
-        ro.tile_prefix = h->tile_prefix;
-        ro.tp_chunks = (int)tp_chunks;
-        ro.tp_tpc = BUCKET_CHUNK / per_block * QSMC_WAVES_PER_BLOCK;
-        ro.tp_ntiles = (long long)((n + per_block - 1) / per_block) * QSMC_WAVES_PER_BLOCK;
-        h->tile_prefix_gen = h->ts.gen;
-    }
+    rc = setup_tile_prefix(h, ro, n, per_block, ns);
+    if (rc) return rc;
     if (h->spec.enabled && ro.tile_sums && ro.failed_dst) {
         // the resampler's weight-only prefix goes out right behind the reduction, gated on the device-side ESS test
         ro.prefix_gate = h->spec.gate;
@@ -956,7 +965,8 @@ int qsmc_update_multi(qsmc_handle_t h, const qsmc_model_t *model, const double *
     const int n_mom = dmom + dmom * (dmom + 1) / 2;
     const int ns = 3 * MULTI_KMAX + n_mom;
     hipStream_t s = (hipStream_t)stream;
-    const int grid = grid_for(n, QSMC_BLOCK * 4);
+    const int per_block = QSMC_BLOCK * MULTI_PER_THREAD;
+    const int grid = grid_for(n, per_block);
     rc = ensure_partials(h, (size_t)grid * (ns + 1));
     if (rc) return rc;
     MultiArgs ma;
@@ -966,7 +976,22 @@ int qsmc_update_multi(qsmc_handle_t h, const qsmc_model_t *model, const double *
         make_exp_args(model, &exps[j], outcomes[j], &ma.e[j]);
         ma.outcome[j] = outcomes[j];
     }
-    const ReduceOut ro = make_reduce(h, true, nullptr);
+    ReduceOut ro = make_reduce(h, true, nullptr);
+    // per-tile sums of the window's final weights + their chunk prefix, as qsmc_update_fused leaves them: a resample
+    // after the window (qsmc_lw_use_update_sums with this call's token) does not read the weights again
+    static const bool tile_sums_on = getenv("QSMC_NO_TILE_SUMS") == nullptr;
+    if (tile_sums_on && ensure_tile_sums(h, (size_t)((n + BUCKET_CHUNK - 1) / BUCKET_CHUNK) * (BUCKET_CHUNK / per_block) *
+                                                QSMC_WAVES_PER_BLOCK) == QSMC_OK) {
+        ro.tile_sums = h->tile_sums;
+        h->ts.w = w_out;
+        h->ts.n = n;
+        h->ts.tile = per_block;
+    }
+    ++h->ts.gen;
+    h->ts.armed = 0;
+    h->spec.launched = 0;
+    rc = setup_tile_prefix(h, ro, n, per_block, ns);
+    if (rc) return rc;
     hipEvent_t me0 = nullptr, me1 = nullptr;
     prof_events(h, QSMC_PROF_UPDATE_MULTI, &me0, &me1);
     switch (model->kind) {

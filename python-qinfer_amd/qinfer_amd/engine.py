@@ -202,6 +202,7 @@ class Engine:
             self.h, C.byref(desc), self._p(x), x.stride(0), x.shape[1],
             self._p(w_in) if w_in is not None else None, self._p(w_out), float(prev_norm), ep, oc, k, st,
             _native.f64_ptr(mom) if mom is not None else None, self.stream()), "qsmc_update_multi")
+        self.update_gen += 1                        # (the window left tile sums like a fused update: qsmc_update_token)
         if mom is None:
             return list(st), None, None
         return list(st), mom[:d].copy(), self._unpack_upper(mom[d:], d)

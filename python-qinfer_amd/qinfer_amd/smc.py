@@ -689,6 +689,9 @@ class SMCUpdater(ParticleDistribution):
         self._norm = float(stats[-1].sum)
         self._sumsq = float(stats[-1].sumsq)
         self._invalidate()
+        # (these weights are what update number `update_gen` -- the window's pass -- wrote: a resample that follows takes its
+        #  chunk sums from that kernel's tile sums, resamplers._arm_update_sums)
+        self._w_token = eng.update_gen
         if self._comm is not None:
             self._shard_sums = shard_sums
         if m1 is not None:
