@@ -224,39 +224,56 @@ def other_config_specs(qi):
     return specs
 
 
-def run_other_config(qi, eng, torch, spec, warmup):
-    n, d = spec["n"], spec["d"]
+def run_other_config(qi, eng, torch, spec, warmup, comm=None, n_override=None, sync=None):
+    """One BASELINE config over its 60-datum schedule.  `comm`: the cloud is one shard of `comm.world_size` (every rank
+    calls this with the same spec; the timed loops sit between `sync()` barriers and the wall time is the slowest
+    rank's); `n_override`: particles per rank instead of spec["n"] (the shared-GPU control-flow check)."""
+    n, d = (n_override or spec["n"]), spec["d"]
     eps, outs = spec["eps"], spec["outs"]
-    upd = qi.SMCUpdater(spec["model"], n, spec["prior"](), device_rng=True, seed=0)
+    world = 1 if comm is None else comm.world_size
+    if sync is None:
+        sync = torch.cuda.synchronize
+    if comm is not None:
+        np.random.seed(1000 + comm.rank)                        # (host-sampled priors: a different draw per shard)
+    upd = qi.SMCUpdater(spec["model"], n, spec["prior"](), device_rng=True, seed=0, comm=comm)
     for k in range(min(warmup, len(eps))):                      # untimed: allocator growth, first-launch costs
         upd.update(outs[k], eps[k])
     upd.resample()
     upd.update(outs[0], eps[0])
     upd.reset()
     upd._resample_count = 0
-    torch.cuda.synchronize()
+    sync()
     eng.set_profiling(0 if os.environ.get("QSMC_BENCH_NO_EVENTS") else 1)      # (no events: for kernel-trace gap profiles)
     t0 = time.perf_counter()
     for k in range(len(eps)):
         upd.update(outs[k], eps[k])
-    torch.cuda.synchronize()
+    sync()
     wall = time.perf_counter() - t0
     ms, tags = eng.profile_read()
     eng.set_profiling(0)
     # the same loop again without kernel events: the throughput figure (events drain the queue around each launch)
     upd.reset()
     rc0 = upd.resample_count
-    torch.cuda.synchronize()
+    rb0 = 0 if comm is None else comm.n_rebalances
+    sync()
     t0 = time.perf_counter()
     for k in range(len(eps)):
         upd.update(outs[k], eps[k])
-    torch.cuda.synchronize()
+    sync()
     wall = time.perf_counter() - t0
+    if world > 1:
+        wt = torch.tensor([wall], dtype=torch.float64, device="cuda" if comm.backend == "nccl" else "cpu")
+        torch.distributed.all_reduce(wt, op=torch.distributed.ReduceOp.MAX)
+        wall = float(wt.item())
     kt = kernel_table(ms, tags)
     K = len(eps)
     out = {"workload": spec["workload"], "particles": n, "d": d, "steps": K, "resamples": upd.resample_count - rc0,
-           "value": n * K / wall, "unit": "particle-updates/s", "ms_per_step": wall / K * 1e3,
+           "value": n * world * K / wall, "unit": "particle-updates/s", "ms_per_step": wall / K * 1e3,
            "posterior_mean_head": [float(v) for v in upd.est_mean()[:3]]}
+    if comm is not None:
+        out.update({"particles_per_rank": n, "particles": n * world, "ranks": world,
+                    "per_datum_collective": comm.transport_name, "rebalances": comm.n_rebalances - rb0,
+                    "resample_path": getattr(comm, "last_resample_path", None)})
     if "update" in kt:
         out["update_kernel"] = frac_entry(spec["update_kernel"], kt["update"]["avg_us"], (16 + 8 * d) * n,
                                           kt["update"]["launches"], {"bytes_per_particle": 16 + 8 * d})
@@ -483,24 +500,47 @@ def main():
             print(json.dumps({args.only: run_other_config(qi, eng, torch, spec, args.warmup)}), flush=True)
         return
 
-    def timed_pass(upd, events):
-        """W warm-up data of a throwaway pass, reset, then exactly --steps updates between barriers."""
-        for k in range(args.warmup):
-            upd.update(int(outcomes[k % N_SCHEDULE]), ts[k % N_SCHEDULE:k % N_SCHEDULE + 1])
-        upd.reset()
-        upd._resample_count = 0
-        # a launch that carries start/stop events drains the queue around itself (measured: 10.7 us per step
-        # with every launch timed), so every `stride`-th launch of each kernel kind is timed
-        eng.set_profiling(stride if events else 0)
-        barrier()
-        t0 = time.perf_counter()
+    def k_steps(upd):
         for i in range(args.steps):
             k = i % N_SCHEDULE
             if i and k == 0:
                 upd.reset()
             upd.update(int(outcomes[k]), ts[k:k + 1])
-        barrier()
-        return time.perf_counter() - t0
+
+    def timed_pass(upd, events, repeats=0):
+        """W warm-up data of a throwaway pass, reset, then exactly --steps updates between barriers.  Returns the wall time
+        of that pass and of `repeats` further identical passes (reported beside it, never as `value`).
+        Untimed, besides the W data: one forced resample + one update (with --warmup 5 the warm-up data trigger no
+        resample: the first one of the process -- scratch growth, first launches of six kernels -- would sit inside a
+        3 ms timed region; round 3's driver line read 0.177 ms/step against 0.077 for the same sample a minute later) and
+        one rehearsal of the K steps themselves.  The garbage collector is off inside the timed region, as in `timeit`."""
+        import gc
+        for k in range(args.warmup):
+            upd.update(int(outcomes[k % N_SCHEDULE]), ts[k % N_SCHEDULE:k % N_SCHEDULE + 1])
+        upd.resample()
+        upd.update(int(outcomes[0]), ts[0:1])
+        upd.reset()
+        k_steps(upd)
+        walls = []
+        for rep in range(1 + repeats):
+            upd.reset()
+            upd._resample_count = 0
+            # a launch that carries start/stop events drains the queue around itself (measured: 10.7 us per step
+            # with every launch timed), so every `stride`-th launch of each kernel kind is timed
+            eng.set_profiling(stride if (events and rep == 0) else 0)
+            gc.collect()
+            gc.disable()
+            barrier()
+            t0 = time.perf_counter()
+            k_steps(upd)
+            barrier()
+            walls.append(time.perf_counter() - t0)
+            gc.enable()
+            if rep == 0:
+                first_pass.append((upd.resample_count,) + tuple(eng.profile_read() if events else (np.zeros(0), np.zeros(0))))
+        return walls[0], walls[1:]
+
+    first_pass = []        # (resamples, kernel durations [ms], kernel tags) of the contract's pass
 
     def rccl_transport_pass():
         """The same K steps once more with the library's own RCCL collective on the launch stream carrying the
@@ -514,7 +554,7 @@ def main():
                 comm_r = ParticleShardGroup(transport="rccl")
                 upd_r = qi.SMCUpdater(qi.SimplePrecessionModel(), n, qi.UniformDistribution([0, 1]),
                                       device_rng=True, seed=0, comm=comm_r)
-                wall_r = timed_pass(upd_r, events=False)
+                wall_r, _ = timed_pass(upd_r, events=False)
                 ranks_in_comm, rank_in_comm = comm_r.ranks_in_comm(eng)
                 wr = torch.tensor([wall_r], dtype=torch.float64, device="cuda")
                 if world > 1:
@@ -532,11 +572,11 @@ def main():
         warnings.simplefilter("ignore")
         upd = qi.SMCUpdater(qi.SimplePrecessionModel(), n, qi.UniformDistribution([0, 1]),
                             device_rng=True, seed=0, comm=comm)
-        wall = timed_pass(upd, events=not os.environ.get("QSMC_BENCH_NO_EVENTS"))
-        # the kernels' start/stop events (hipExtLaunchKernelGGL, on the launch stream) are read here, once
-        all_ms, tags = eng.profile_read()
+        wall, repeat_walls = timed_pass(upd, events=not os.environ.get("QSMC_BENCH_NO_EVENTS"), repeats=2)
+        # the kernels' start/stop events (hipExtLaunchKernelGGL, on the launch stream: those of the first, the contract's,
+        # pass) are read here, once
         eng.set_profiling(False)
-        resamples_timed = upd.resample_count
+        resamples_timed, all_ms, tags = first_pass[0]
         # tag 0: update with explicit weights (24 B/particle), 2: first update after a reset/resample, weights
         # implicit (16 B/particle), 1: the resampler's sampling kernel, 6: its counts/plan launch
         full_ms, ones_ms, sampler_ms = all_ms[tags == 0], all_ms[tags == 2], all_ms[tags == 1]
@@ -596,6 +636,33 @@ def main():
             except Exception as e:  # noqa: BLE001
                 extras["other_paths"] = {"error": repr(e)}
 
+    def sharded_configs(comm_s):
+        """BASELINE configs 4 and 5 as they are defined -- a cloud sharded over the ranks (1e8 RB particles = 1.25e7 per
+        rank at 8 ranks; 1e7 two-qubit tomography particles = 1.25e6 per rank) -- through `comm_s`: every rank runs its
+        shard, the per-datum sums and the resample's moments cross ranks, value = all ranks' particle-updates / the slowest
+        rank's wall time.  QSMC_BENCH_SHARE_GPU=1 (every rank on device 0) shrinks the shards: control flow, not a
+        measurement."""
+        out = {}
+        for spec in other_config_specs(qi):
+            if spec["key"] not in ("config4_share_rb", "config5_share_tomography"):
+                continue
+            key = spec["key"].replace("_share", "_sharded")
+            n_rank = None
+            if share_gpu or os.environ.get("QSMC_BENCH_SHARDED_PARTICLES"):
+                n_rank = int(float(os.environ.get("QSMC_BENCH_SHARDED_PARTICLES", "0"))) or max(65536, spec["n"] // (16 * world))
+            try:
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    out[key] = run_other_config(qi, eng, torch, spec, min(args.warmup, 5), comm=comm_s,
+                                                n_override=n_rank, sync=barrier)
+            except Exception as e:  # noqa: BLE001
+                out[key] = {"error": repr(e)}
+        return out
+
+    sharded = None
+    if comm is not None and not args.no_other_configs:
+        sharded = sharded_configs(comm)
+
     def drain_c_stdio():
         # RCCL prints a version banner through C stdio, which (not a tty) would be flushed at exit -- after the
         # JSON line.  Push whatever C stdio holds to stderr so that the JSON line is the last line of stdout.
@@ -650,6 +717,9 @@ def main():
                                              "the HBM-only figure",
                          "implicit_uniform_weight_variant": ones_info},
             "posterior_mean": posterior_mean,
+            # the same K steps twice more right after the contract's pass (no kernel events): a record of how far one 3 ms
+            # region can sit from the next on this box -- never used for `value`
+            "repeat_passes_ms_per_step": [w / args.steps * 1e3 for w in repeat_walls],
         }
         samp_n, samp_us = 0, None
         if len(sampler_ms):
@@ -697,6 +767,8 @@ def main():
             line["transports"] = {key: {"per_datum_collective": comm.transport_name, "value": line["value"],
                                         "ms_per_step": line["ms_per_step"], "resamples": resamples_timed,
                                         "posterior_mean": posterior_mean, "headline": True}}
+            if sharded is not None:
+                line["sharded_configs"] = sharded
         want_rccl = ((world > 1 or os.environ.get("QSMC_BENCH_FORCE_RCCL_PASS")) and comm.transport != "rccl"
                      and not os.environ.get("QSMC_BENCH_NO_RCCL_PASS"))
         if want_rccl and share_gpu:
@@ -707,7 +779,7 @@ def main():
             # a collective that hangs must not take the line with it: past the deadline rank 0 prints the line with
             # the time-out recorded and every rank leaves
             import threading
-            deadline = float(os.environ.get("QSMC_BENCH_RCCL_DEADLINE", "60"))
+            deadline = float(os.environ.get("QSMC_BENCH_RCCL_DEADLINE", "60" if sharded is None else "240"))
 
             def give_up():
                 if rank == 0:
@@ -718,9 +790,24 @@ def main():
             watchdog.daemon = True
             watchdog.start()
             res = rccl_transport_pass()
-            watchdog.cancel()
             if rank == 0:
                 line["transports"]["rccl"] = res
+            if sharded is not None and "error" not in res:
+                # configs 4 and 5 once more with the RCCL collective carrying the per-datum reduction
+                try:
+                    from qinfer_amd.parallel import ParticleShardGroup
+                    comm_r = ParticleShardGroup(transport="rccl")
+                    sh_r = sharded_configs(comm_r)
+                    comm_r.close()
+                except Exception as e:  # noqa: BLE001
+                    sh_r = {"error": repr(e)}
+                if rank == 0:
+                    for k2, v2 in sh_r.items():
+                        if isinstance(line["sharded_configs"].get(k2), dict) and isinstance(v2, dict):
+                            line["sharded_configs"][k2]["rccl_transport"] = {
+                                kk: v2.get(kk) for kk in ("value", "ms_per_step", "resamples", "rebalances",
+                                                          "per_datum_collective", "error") if kk in v2}
+            watchdog.cancel()
     emit()
     if world > 1 or args.force_comm:
         sys.stdout.flush()

@@ -179,7 +179,7 @@ class Engine:
         rc = self._qsmc_step(self._h_int, st_ref, desc_ref, ep_ref, outcome, self._raw_stream(self.index))
         if rc:
             self._chk(rc, "qsmc_step")
-        self._armed_prefix = self.STEP_ARMED
+        # (whether the call armed the gated prefix is the caller's to record in `_armed_prefix`: it filled the struct)
 
     def step_stats(self):
         """(resamples queued by qsmc_step, resamples whose caller-side call adopted the queued one)."""

@@ -394,85 +394,148 @@ class RandomWalkModel(_WalkingModel):
         eng.random_walk(updater._x, np.ones(self.n_modelparams), z=eng.locs_to_soa(steps))
 
 
+class _StepLaw:
+    """How the walking parameters of a GaussianRandomWalkModel step: one object per covariance variant.  `draw(mp, n_e)`
+    returns unit-scale steps of shape (n, n_rw, n_e) from the legacy global RNG; `extra_names` are the model parameters
+    the law appends (none when the covariance is given); `admissible(mp)` is its share of are_models_valid;
+    `unit_covariance(mp)` the covariance of one step."""
+    extra_names = ()
+    device_scale = None                 # per-parameter step sigma if the law is a fixed diagonal (the device kernel's case)
+
+    def bind(self, first_extra_column):
+        self.cols = first_extra_column + np.arange(len(self.extra_names))
+
+    def admissible(self, mp):
+        return None
+
+
+class _KnownDiagonal(_StepLaw):
+    def __init__(self, variances, n_rw):
+        v = np.asarray(variances, dtype=np.float64)
+        if v.ndim != 1:
+            raise ValueError('Diagonal covariance requested, but fixed_covariance has {} dimensions.'.format(v.ndim))
+        if v.size != n_rw:
+            raise ValueError('fixed_covariance dimension, {}, inconsistent with number of parameters, {}'
+                             .format(v.size, n_rw))
+        self.device_scale = np.sqrt(v)
+
+    def draw(self, mp, n_e):
+        # draw order pinned by fixture G10 (the reference draws one (n_eps, n_mps, n_rw) block: derived_models.py:929)
+        z = np.random.normal(size=(n_e, mp.shape[0], self.device_scale.size))
+        return np.moveaxis(z * self.device_scale, 0, 2)
+
+    def unit_covariance(self, mp):
+        return np.diag(self.device_scale ** 2)
+
+
+class _KnownDense(_StepLaw):
+    def __init__(self, cov, n_rw):
+        cov = np.asarray(cov, dtype=np.float64)
+        if cov.ndim != 2:
+            raise ValueError('Dense covariance requested, but fixed_covariance has {} dimensions.'.format(cov.ndim))
+        if cov.shape != (n_rw, n_rw):
+            raise ValueError('fixed_covariance expected to be square with width {}'.format(n_rw))
+        self.factor = np.linalg.cholesky(cov)           # cov = factor factor^T
+
+    def draw(self, mp, n_e):
+        n_rw = self.factor.shape[0]
+        z = np.random.normal(size=(mp.shape[0], n_e, n_rw))
+        return np.swapaxes(z @ self.factor.T, 1, 2)
+
+    def unit_covariance(self, mp):
+        return self.factor @ self.factor.T
+
+
+class _LearnedDiagonal(_StepLaw):
+    """One sigma per walking parameter rides in the cloud; sigma >= 0 is part of validity."""
+
+    def __init__(self, names):
+        self.extra_names = tuple(r"\sigma_{{{}}}".format(nm) for nm in names)
+
+    def draw(self, mp, n_e):
+        sig = mp[:, self.cols]
+        z = np.random.normal(size=(n_e,) + sig.shape)
+        return np.moveaxis(z * sig, 0, 2)
+
+    def admissible(self, mp):
+        return (mp[..., self.cols] >= 0).all(axis=-1)
+
+    def unit_covariance(self, mp):
+        return np.diag((mp[:, self.cols] ** 2).mean(axis=0))
+
+
+class _LearnedDense(_StepLaw):
+    """The lower triangle of a Cholesky-like factor per particle rides in the cloud (row-major over the triangle)."""
+
+    def __init__(self, names):
+        k = len(names)
+        self.rows, self.cols_in_factor = np.tril_indices(k)
+        self.k = k
+        self.extra_names = tuple(
+            r"\sigma_{{{}}}".format(names[i]) if i == j else r"\sigma_{{{},{}}}".format(names[j], names[i])
+            for i, j in zip(self.rows, self.cols_in_factor))
+
+    def _factors(self, mp):
+        f = np.zeros((mp.shape[0], self.k, self.k))
+        f[:, self.rows, self.cols_in_factor] = mp[:, self.cols]
+        return f
+
+    def draw(self, mp, n_e):
+        z = np.random.normal(size=(mp.shape[0], self.k, n_e))
+        return self._factors(mp) @ z
+
+    def unit_covariance(self, mp):
+        f = self._factors(mp)
+        return (f @ np.swapaxes(f, 1, 2)).mean(axis=0)
+
+
 class GaussianRandomWalkModel(_WalkingModel):
-    r"""After every datum the parameters selected by `random_walk_idxs` take a zero-mean Gaussian step
-    (reference derived_models.py:743-963).  The covariance is either fixed (`fixed_covariance`: its
-    diagonal if `diagonal`, else the full matrix) or unknown, in which case its square-root entries are
-    appended to the model parameters and each particle walks with its own belief.  `scale_mult` (a
-    function of expparams, or the name of an expparams field) scales the step of a given experiment;
+    r"""After every datum the parameters selected by `random_walk_idxs` take a zero-mean Gaussian step (the contract of
+    reference derived_models.py:743-963, written from SURVEY 8(f)3's description).  The step covariance is either given
+    (`fixed_covariance`: a vector of variances if `diagonal`, else a full matrix) or learned, in which case the entries
+    of its square root are appended to the model parameters and each particle walks with its own belief.
+    `scale_mult` (a function of expparams, or the name of an expparams field) scales the step of a given experiment;
     `model_transformation = (f, f_inv)` applies the walk in transformed coordinates.
 
-    With a fixed diagonal covariance, no transformation and a decorated model that has kernels -- the case
-    SURVEY 8(f)3 names -- the whole step runs on the device (`qsmc_random_walk`): Philox normals with
-    `device_rng`, else the reference's own `np.random.normal(size=(1, N, n_rw))` draw uploaded once.
-    Every other variant keeps the reference's host arithmetic (plugin slow path)."""
+    With a given diagonal covariance, no transformation and a decorated model that has kernels -- the case SURVEY
+    8(f)3 names -- the whole step runs on the device (`qsmc_random_walk`): Philox normals with `device_rng`, else
+    the reference's own draw uploaded once (fixture G10 pins that stream).  The other variants are outside 8(f)3: they
+    run on the host (plugin slow path) with the right law but no fixture pins their draw order."""
 
     def __init__(self, underlying_model, random_walk_idxs='all', fixed_covariance=None, diagonal=True,
                  scale_mult=None, model_transformation=None):
         n_u = underlying_model.n_modelparams
-        self._diagonal = diagonal
-        self._rw_idxs = np.s_[:n_u] if (isinstance(random_walk_idxs, str) and random_walk_idxs == 'all') \
-            else random_walk_idxs
-        explicit = np.arange(n_u)[self._rw_idxs]
-        if explicit.size == 0:
+        pick = slice(None) if (isinstance(random_walk_idxs, str) and random_walk_idxs == 'all') else random_walk_idxs
+        self._walkers = np.atleast_1d(np.arange(n_u)[pick])              # columns of the decorated model that walk
+        if self._walkers.size == 0:
             raise IndexError('At least one model parameter must take a random walk.')
-        self._explicit_idxs = np.atleast_1d(explicit)
-        self._rw_names = [underlying_model.modelparam_names[i] for i in self._explicit_idxs]
-        self._n_rw = len(self._explicit_idxs)
-        self._srw_names = []
-        if fixed_covariance is None:
-            self._has_fixed_covariance = False
-            if diagonal:
-                self._srw_names = [r"\sigma_{{{}}}".format(nm) for nm in self._rw_names]
-                self._srw_idxs = (n_u + np.arange(self._n_rw)).astype(int)
-            else:
-                self._srw_idxs = (n_u + np.arange(self._n_rw * (self._n_rw + 1) // 2)).astype(int)
-                self._srw_tri_idxs = np.tril_indices(self._n_rw)
-                for i1, name1 in enumerate(self._rw_names):
-                    for name2 in self._rw_names[:i1 + 1]:
-                        self._srw_names.append(r"\sigma_{{{}}}".format(name1) if name1 == name2
-                                               else r"\sigma_{{{},{}}}".format(name2, name1))
+        names = [underlying_model.modelparam_names[i] for i in self._walkers]
+        if fixed_covariance is not None:
+            law = (_KnownDiagonal if diagonal else _KnownDense)(fixed_covariance, len(names))
         else:
-            fixed_covariance = np.asarray(fixed_covariance, dtype=np.float64)
-            self._has_fixed_covariance = True
-            if diagonal:
-                if fixed_covariance.ndim != 1:
-                    raise ValueError('Diagonal covariance requested, but fixed_covariance has {} dimensions.'
-                                     .format(fixed_covariance.ndim))
-                if fixed_covariance.size != self._n_rw:
-                    raise ValueError('fixed_covariance dimension, {}, inconsistent with number of parameters, {}'
-                                     .format(fixed_covariance.size, self._n_rw))
-                self._fixed_scale = np.sqrt(fixed_covariance)
-            else:
-                if fixed_covariance.ndim != 2:
-                    raise ValueError('Dense covariance requested, but fixed_covariance has {} dimensions.'
-                                     .format(fixed_covariance.ndim))
-                if fixed_covariance.shape != (self._n_rw, self._n_rw):
-                    raise ValueError('fixed_covariance expected to be square with width {}'.format(self._n_rw))
-                self._fixed_chol = np.linalg.cholesky(fixed_covariance)
+            law = (_LearnedDiagonal if diagonal else _LearnedDense)(names)
+        law.bind(n_u)
+        self._law = law
         super().__init__(underlying_model)
         if scale_mult is None:
-            self._scale_mult_fcn = lambda expparams: 1
+            self._step_multiplier = lambda expparams: 1.0
         elif isinstance(scale_mult, str):
-            self._scale_mult_fcn = lambda ep: ep[scale_mult]
+            self._step_multiplier = lambda expparams, field=scale_mult: expparams[field]
         else:
-            self._scale_mult_fcn = scale_mult
-        self._has_transformation = model_transformation is not None
-        if self._has_transformation:
-            self._transform, self._inv_transform = model_transformation
-        self._native = bool(native_ok(underlying_model) and self._has_fixed_covariance
-                            and diagonal and not self._has_transformation)
+            self._step_multiplier = scale_mult
+        self._coords = model_transformation            # (to_walk_coords, from_walk_coords) or None
+        self._native = bool(native_ok(underlying_model) and law.device_scale is not None and self._coords is None)
         if not self._native:
             self._native_timestep = None            # (instance attribute shadows the method: plugin slow path)
 
     # ------------------------------------------------------------------ surface
     @property
     def modelparam_names(self):
-        return self.underlying_model.modelparam_names + self._srw_names
+        return self.underlying_model.modelparam_names + list(self._law.extra_names)
 
     @property
     def n_modelparams(self):
-        return len(self.modelparam_names)
+        return self.underlying_model.n_modelparams + len(self._law.extra_names)
 
     @property
     def is_n_outcomes_constant(self):
@@ -483,9 +546,8 @@ class GaussianRandomWalkModel(_WalkingModel):
 
     def are_models_valid(self, modelparams):
         ok = self.underlying_model.are_models_valid(self._u(modelparams))
-        if self._has_fixed_covariance or not self._diagonal:
-            return ok
-        return np.logical_and(ok, np.greater_equal(modelparams[..., self._srw_idxs], 0).all(axis=-1))
+        extra = self._law.admissible(modelparams)
+        return ok if extra is None else np.logical_and(ok, extra)
 
     def likelihood(self, outcomes, modelparams, expparams):
         Model.likelihood(self, outcomes, modelparams, expparams)
@@ -496,52 +558,37 @@ class GaussianRandomWalkModel(_WalkingModel):
 
     def est_update_covariance(self, modelparams):
         """Covariance of one unit step (its particle average when it is being learned)."""
-        if self._diagonal:
-            return np.diag(self._fixed_scale ** 2 if self._has_fixed_covariance
-                           else np.mean(modelparams[:, self._srw_idxs] ** 2, axis=0))
-        if self._has_fixed_covariance:
-            return np.dot(self._fixed_chol, self._fixed_chol.T)
-        chol = np.zeros((modelparams.shape[0], self._n_rw, self._n_rw))
-        chol[(np.s_[:],) + self._srw_tri_idxs] = modelparams[:, self._srw_idxs]
-        return np.mean(np.einsum('ijk,ilk->ijl', chol, chol), axis=0)
+        return self._law.unit_covariance(np.asarray(modelparams))
 
     def update_timestep(self, modelparams, expparams):
-        """Host arithmetic, every variant (legacy global RNG, draw shapes as in the reference)."""
-        n, n_e = modelparams.shape[0], expparams.shape[0]
-        if self._diagonal:
-            scale = self._fixed_scale if self._has_fixed_covariance else modelparams[:, self._srw_idxs]
-            steps = (scale * np.random.normal(size=(n_e, n, self._n_rw))).transpose((1, 2, 0))
-        elif self._has_fixed_covariance:
-            steps = np.dot(self._fixed_chol, np.random.normal(size=(self._n_rw, n * n_e))
-                           ).reshape(self._n_rw, n, n_e).transpose((1, 0, 2))
-        else:
-            chol = np.zeros((n, self._n_rw, self._n_rw))
-            chol[(np.s_[:],) + self._srw_tri_idxs] = modelparams[:, self._srw_idxs]
-            steps = np.einsum('kij,kjl->kil', chol, np.random.normal(size=(n, self._n_rw, n_e)))
-        steps = self._scale_mult_fcn(expparams) * steps
+        """Host arithmetic, every variant (legacy global RNG): (n, n_modelparams, n_expparams)."""
+        modelparams = np.asarray(modelparams, dtype=np.float64)
+        n_e = expparams.shape[0]
+        steps = self._law.draw(modelparams, n_e) * self._step_multiplier(expparams)        # (n, n_rw, n_e)
         n_u = self.underlying_model.n_modelparams
-        if self._has_transformation:
-            new = np.repeat(modelparams[np.newaxis, :, :], n_e, axis=0).reshape((n_e * n, -1))
-            new[:, :n_u] = self._transform(new[:, :n_u])
-            new[:, self._rw_idxs] += steps.transpose((2, 0, 1)).reshape((n_e * n, -1))
-            new[:, :n_u] = self._inv_transform(new[:, :n_u])
-            return new.reshape((n_e, n, -1)).transpose((1, 2, 0))
-        new = np.repeat(modelparams[:, :, np.newaxis], n_e, axis=2)
-        new[:, self._rw_idxs, :] += steps
-        return new
+        out = np.empty(modelparams.shape + (n_e,))
+        for e in range(n_e):
+            cur = modelparams.copy()
+            if self._coords is not None:
+                cur[:, :n_u] = self._coords[0](cur[:, :n_u])
+            cur[:, self._walkers] += steps[:, :, e]
+            if self._coords is not None:
+                cur[:, :n_u] = self._coords[1](cur[:, :n_u])
+            out[:, :, e] = cur
+        return out
 
     def _native_timestep(self, updater, expparams):
-        """Fixed diagonal covariance: the step of one datum, in place on the device."""
+        """Given diagonal covariance: the step of one datum, in place on the device."""
         eng = updater._eng
-        mult = float(np.ravel(self._scale_mult_fcn(np.atleast_1d(expparams)))[0])
+        mult = float(np.ravel(self._step_multiplier(np.atleast_1d(expparams)))[0])
         scale = np.zeros(self.n_modelparams)
-        scale[self._explicit_idxs] = self._fixed_scale * mult
+        scale[self._walkers] = self._law.device_scale * mult
         if updater._device_rng:
             seed, epoch = self._walk_seed(updater)
             eng.random_walk(updater._x, scale, z=None, seed=seed, epoch=epoch)
         else:
-            # parity mode: the reference's draw, np.random.normal(size=(n_eps, n_mps, n_rw)) with n_eps = 1
-            z = np.random.normal(size=(1, updater.n_particles, self._n_rw))[0]
+            # parity mode: the draw `update_timestep` would make for one experiment, uploaded once
+            z = np.random.normal(size=(1, updater.n_particles, self._walkers.size))[0]
             eng.random_walk(updater._x, scale, z=eng.locs_to_soa(z))
 
 

@@ -522,6 +522,7 @@ class ParticleShardGroup:
         if not np.isfinite(S_err):
             raise ResamplerError("Infinite error in computing the square root of the covariance "
                                  "matrix. Check that n_ess is not too small.")
+        canonicalized = False
         if stay and big:
             resampler._epoch = epoch                   # (the segment split is keyed by the resampler's seed and epoch)
             seed0, resampler._seed = resampler._seed, seed_r
@@ -532,12 +533,27 @@ class ParticleShardGroup:
                 resampler._seed = seed0
             defer = False
             self.last_shard_sizes = totals
+            self.last_resample_path = "segmented local draw"
         elif stay:
+            # the shard's own draw is the single-GPU resample on its local weights: the same kernels, with what they can
+            # fold in -- TomographyModel.canonicalize into the split d = 16 sampler (the returned cloud is marked so that
+            # the updater does not run it again), and for models whose postselection bites (RB) the proposal bank sized by
+            # this shard's previous count of failed first tries
+            n_new = int(totals[self.rank])
+            canon = getattr(updater, "_fused_canon", None)
+            if canon is not None and not eng.fused_canon_applies(d, n_local, n_new):
+                canon = None
+            st = getattr(updater, "_st", None)
+            expect = int(st.lw.redraws_seen) if st is not None else 0
             x_new, n_failed = eng.lw_resample_philox(model._native_desc(), resampler._postselect, updater._x,
                                                      updater._w, float(W[self.rank]), a, mean, S,
-                                                     int(totals[self.rank]), seed_r, epoch, resampler._maxiter,
-                                                     sync=not defer)
+                                                     n_new, seed_r, epoch, resampler._maxiter,
+                                                     sync=not defer, canon=canon, expect_redraws=expect)
+            canonicalized = canon is not None
             self.last_shard_sizes = totals
+            self.last_resample_path = ("local draw%s%s" % (
+                ", canonicalize fused into the split d = 16 sampler" if canonicalized else "",
+                ", proposal bank for %d expected redraws" % expect if expect > 0 else ""))
         else:
             # rebalance (or placement="mixed"): this shard draws, kicks and postselects the particles every
             # destination takes from it; finished rows travel by one all-to-all
@@ -555,12 +571,15 @@ class ParticleShardGroup:
             recv = self.exchange_rows(rows, counts)                  # the only bandwidth step
             x_new = recv.to(eng.device).t().contiguous()             # back to SoA
             self.last_shard_sizes = counts.sum(axis=1)
+            self.last_resample_path = "rebalance: per-destination draw + all-to-all of finished rows"
         if defer:
             resampler._pending_failed = eng
         if n_failed:
             warnings.warn("Liu-West resampling failed to find valid models for {} particles within {} "
                           "iterations.".format(n_failed, resampler._maxiter), ResamplerWarning)
-        return ParticleDistribution._from_device(eng, x_new, None, norm=float(n_total), sumsq=float(n_total))
+        new = ParticleDistribution._from_device(eng, x_new, None, norm=float(n_total), sumsq=float(n_total))
+        new._canonicalized = canonicalized
+        return new
 
     def _balanced_sizes(self, n_total):
         G = self.world_size

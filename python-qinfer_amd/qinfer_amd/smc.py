@@ -116,7 +116,7 @@ class SMCUpdater(ParticleDistribution):
         self._x_spare = None
         # canonicalize after a resample (smc.py:529) done by the resample's own kernels where the library can
         fc = getattr(model, "_native_canonicalize_fused", None)
-        self._fused_canon = (fc(self._eng) if (fc is not None and self._native and self._canonicalize and comm is None
+        self._fused_canon = (fc(self._eng) if (fc is not None and self._native and self._canonicalize
                                                and not _NO_FUSED_CANON) else None)
         self.reset(n_particles)
 
@@ -364,6 +364,7 @@ class SMCUpdater(ParticleDistribution):
                 st.plan_prefix_seed = (r._seed + 0x9E3779B97F4A7C15 * (comm.rank + 1)) & _U64
                 st.plan_n_total, st.plan_tol = self.n_particles_global, float(comm.rebalance_tol)
         lw.prefix = int(key is not None)
+        self._step_arms = self._eng.STEP_ARMED if key is not None else None
         lw.enabled = 0
         if key is not None:
             lw.n_out, lw.seed, lw.epoch = key[1], key[2] & _U64, key[3]
@@ -399,8 +400,8 @@ class SMCUpdater(ParticleDistribution):
         st = self._st
         if not self._step_synced or self._step_key[0] is not self.resampler or self._step_key[1] != self.resample_thresh:
             self._step_sync()
-        elif self._w_alt is None:                     # (the update after a reset / resample committed into implicit weights)
-            st.w_alt = self._scratch_weights().data_ptr()
+        elif not st.w_alt:                            # (the update after a reset / resample committed into implicit weights:
+            st.w_alt = self._scratch_weights().data_ptr()      #  the struct, not the Python mirror, says a buffer is missing)
         fill = self._ep_fill
         if fill is not None and fill(self._ep, expparams):
             ep_ref = self._ep_ref
@@ -426,8 +427,9 @@ class SMCUpdater(ParticleDistribution):
                 self._step_plan = (st.plan_epoch, self._plan_view.copy(), bool(st.status & _native.STEP_PREFIX_QUEUED),
                                    st.update_token)
         eng.update_gen = st.update_token
-        if not check_for_resample:
-            eng._armed_prefix = None                  # (the call disarmed the gated prefix)
+        # what the call left armed on the handle: the gated prefix, if the struct carries a prefix key and the n_ess test
+        # was asked for (qsmc_step disarms it otherwise)
+        eng._armed_prefix = self._step_arms if check_for_resample else None
         status = st.status
         w_out = self._w_alt
         if status & _native.STEP_GUARD:
@@ -436,6 +438,11 @@ class SMCUpdater(ParticleDistribution):
             d = self._x.shape[0]
             mom = np.array(st.moments[:d + d * (d + 1) // 2]) if d <= 4 else None
             self._step_synced = False
+            if self._moments_cache is _FROM_STEP:
+                # the marker pointed at st.moments, which now hold the sums of this UNCOMMITTED update: should the policy
+                # leave without committing ('skip', or 'error' caught by the caller) the moments are recomputed from the
+                # unchanged weights, not read from there
+                self._moments_cache = None
             return self._finish_update(us.sum, us.sumsq, us.min, us.n_bad, w_out, mom, expparams, check_for_resample)
         flush = getattr(self.resampler, "_flush_failed_warning", None)
         if flush is not None:
