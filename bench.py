@@ -537,10 +537,12 @@ def main():
             walls.append(time.perf_counter() - t0)
             gc.enable()
             if rep == 0:
-                first_pass.append((upd.resample_count,) + tuple(eng.profile_read() if events else (np.zeros(0), np.zeros(0))))
+                # (est_mean is a collective on a sharded cloud: every rank is here)
+                first_pass.append((upd.resample_count,) + tuple(eng.profile_read() if events else (np.zeros(0), np.zeros(0)))
+                                  + (float(upd.est_mean()[0]),))
         return walls[0], walls[1:]
 
-    first_pass = []        # (resamples, kernel durations [ms], kernel tags) of the contract's pass
+    first_pass = []        # (resamples, kernel durations [ms], kernel tags, posterior mean) of each call's contract pass
 
     def rccl_transport_pass():
         """The same K steps once more with the library's own RCCL collective on the launch stream carrying the
@@ -555,14 +557,15 @@ def main():
                 upd_r = qi.SMCUpdater(qi.SimplePrecessionModel(), n, qi.UniformDistribution([0, 1]),
                                       device_rng=True, seed=0, comm=comm_r)
                 wall_r, _ = timed_pass(upd_r, events=False)
+                resamples_r, _, _, mean_r = first_pass[-1]
                 ranks_in_comm, rank_in_comm = comm_r.ranks_in_comm(eng)
                 wr = torch.tensor([wall_r], dtype=torch.float64, device="cuda")
                 if world > 1:
                     torch.distributed.all_reduce(wr, op=torch.distributed.ReduceOp.MAX)
                 res = {"per_datum_collective": comm_r.transport_name, "ranks_in_comm": ranks_in_comm,
                        "value": n * world * args.steps / float(wr.item()),
-                       "ms_per_step": float(wr.item()) / args.steps * 1e3, "resamples": upd_r.resample_count,
-                       "posterior_mean": float(upd_r.est_mean()[0])}
+                       "ms_per_step": float(wr.item()) / args.steps * 1e3, "resamples": resamples_r,
+                       "posterior_mean": mean_r}
                 comm_r.close()
         except Exception as e:  # noqa: BLE001
             res = {"error": repr(e)}
@@ -576,7 +579,7 @@ def main():
         # the kernels' start/stop events (hipExtLaunchKernelGGL, on the launch stream: those of the first, the contract's,
         # pass) are read here, once
         eng.set_profiling(False)
-        resamples_timed, all_ms, tags = first_pass[0]
+        resamples_timed, all_ms, tags, posterior_mean = first_pass[0]
         # tag 0: update with explicit weights (24 B/particle), 2: first update after a reset/resample, weights
         # implicit (16 B/particle), 1: the resampler's sampling kernel, 6: its counts/plan launch
         full_ms, ones_ms, sampler_ms = all_ms[tags == 0], all_ms[tags == 2], all_ms[tags == 1]
@@ -605,8 +608,6 @@ def main():
             gpu_same_sample = {"value": n * args.cpu_data / w1, "ms_per_step": w1 / args.cpu_data * 1e3,
                                "resamples": upd.resample_count - rc0}
 
-    # collective in sharded mode (the moments are all-gathered if the last step resampled): every rank calls it
-    posterior_mean = float(upd.est_mean()[0])
     wall_t = torch.tensor([wall], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
     if world > 1:
         torch.distributed.all_reduce(wall_t, op=torch.distributed.ReduceOp.MAX)

@@ -473,6 +473,22 @@ int qsmc_lw_prefix_stats(qsmc_handle_t h, int64_t *n_queued, int64_t *n_adopted)
  * QSMC_ERR_UNSUPPORTED from the resample) by that call; any call that changes weights clears it. */
 int qsmc_lw_fuse_canonicalize(qsmc_handle_t h, const double *basis, int32_t dim, int32_t basis_kind,
                               int32_t allow_subnormalized);
+/* Does a d = 16 resample of this shape take the split sampler that can fold canonicalize in (the rule the library itself
+ * applies: the bucketed path -- at most 8192 chunks of 4096 source particles, at least 4 chunks' worth of outputs)?
+ * 1 / 0.  A caller asks this instead of restating the rule. */
+int qsmc_lw_can_fuse_canonicalize(int32_t d, int64_t n_in, int64_t n_out);
+
+/* Grow every scratch buffer that updates of a cloud of n_in particles (d parameters) and its Liu-West resample into n_out
+ * particles would otherwise grow at first use (chunk tables, plan, CDF, partial sums ...): called once when a cloud is
+ * set up, so that the first resample of a process costs what the hundredth does.  (Round 3: a driver run whose 5
+ * warm-up data triggered no resample timed 3.5 ms for 20 steps that take 1.6 ms.)  Idempotent; allocates, never frees
+ * below what is in use. */
+int qsmc_reserve(qsmc_handle_t h, int64_t n_in, int64_t n_out, int32_t d);
+
+/* d = 16 resamples queued by qsmc_step whose covariance square root was formed on the device (kernels/sqrtm.hpp), and how
+ * many of those the host's own square root confirmed bit for bit (only those are adopted). */
+int qsmc_step_sqrt_stats(qsmc_handle_t h, int64_t *n_device, int64_t *n_agreed);
+
 
 /* Postselection without global redraws (resamplers.py:341-372) for models whose constraint bites at every resample (RB):
  * n_expected = how many first tries of THIS cloud's previous resample failed postselection (qsmc_last_resample_redraws

@@ -1663,7 +1663,7 @@ __global__ __launch_bounds__(BT) void k_bucket_anc16(
     int64_t n_in, const double *__restrict__ w, double inv_norm, const double *__restrict__ offsets, int chunks,
     const long long *__restrict__ slot_off, const int *__restrict__ item_off, const int *__restrict__ item_chunk,
     uint32_t k0, uint32_t k1, uint32_t epoch, unsigned int *__restrict__ anc, int cap,
-    unsigned int *__restrict__ canon_count) {
+    unsigned int *__restrict__ canon_count, SqrtJob sq) {
     __shared__ __attribute__((aligned(32))) double lcdf[BUCKET_CHUNK];
     __shared__ double ltops[TOPS_LDS];
     __shared__ unsigned short lguide[TGUIDE_BINS + 2];
@@ -1674,7 +1674,17 @@ __global__ __launch_bounds__(BT) void k_bucket_anc16(
     __shared__ unsigned int heavy[2 * S16_HEAVY_CAP];
     __shared__ int hcount;
     static_assert(BT == SCAN_THREADS, "one lane owns 8 consecutive source particles");
-    const int bid = (int)blockIdx.x;
+    int bid = (int)blockIdx.x;
+    if (sq.full) {
+        // round 4: workgroup 0 (scheduled first) carries ONE wavefront that turns the summed moments into the Liu-West
+        // arguments of the kick kernel (kernels/sqrtm.hpp) while every other workgroup draws ancestors -- the host did this
+        // between the two kernels before (~26 us of idle GPU per d = 16 resample)
+        if (bid == 0) {
+            if (threadIdx.x < QSMC_WAVE) lw_sqrt16_wave(sq, lcdf);
+            return;
+        }
+        bid -= 1;
+    }
     // (the kick kernel's list of particles for canonicalize's second pass starts empty: cleared here, a launch earlier,
     //  instead of by a memset command between the two kernels -- that was a 10 us bubble)
     if (bid == 0 && threadIdx.x == 0 && canon_count) *canon_count = 0u;
@@ -1779,8 +1789,12 @@ __global__ __launch_bounds__(KICK16_BT) void k_bucket_kick16(
     const double *__restrict__ x_in, int64_t ldx_in, const unsigned int *__restrict__ anc, int64_t n_out, LWArgs lw,
     uint32_t k0, uint32_t k1, uint32_t epoch, double *__restrict__ x_out, OutPlace pl,
     const double *__restrict__ basis, int allow_subnormalized, unsigned int *__restrict__ list,
-    unsigned int *__restrict__ count) {
+    unsigned int *__restrict__ count, const LWDev *__restrict__ lwd) {
     constexpr int DM = 16;
+    // lwd != nullptr: a, mean and S come from device memory (written by lw_sqrt16_wave in the kernel before this one);
+    // a block marked invalid (covariance or square-root error not finite) means the host will not adopt this resample
+    if (lwd && lwd->valid != 1.0) return;
+    const double lw_a = lwd ? lwd->a : lw.a;
     __shared__ double tile[KICK16_WAVES][QSMC_WAVE * KICK16_ROW];
     __shared__ double sS[DM * DM + DM];                             // S (row-major) and the mean
     __shared__ unsigned int hard_buf[KICK16_PER_BLOCK];
@@ -1791,8 +1805,8 @@ __global__ __launch_bounds__(KICK16_BT) void k_bucket_kick16(
     if (((int)blockIdx.x >> 3) >= per || rb >= n_ranges) return;
     const int64_t r0 = rb * KICK16_PER_BLOCK;
     const int64_t r1 = r0 + KICK16_PER_BLOCK < n_out ? r0 + KICK16_PER_BLOCK : n_out;
-    for (int k = threadIdx.x; k < DM * DM; k += KICK16_BT) sS[k] = lw.S[k];
-    if (threadIdx.x < DM) sS[DM * DM + threadIdx.x] = lw.mean[threadIdx.x];
+    for (int k = threadIdx.x; k < DM * DM; k += KICK16_BT) sS[k] = lwd ? lwd->S[k] : lw.S[k];
+    if (threadIdx.x < DM) sS[DM * DM + threadIdx.x] = lwd ? lwd->mean[threadIdx.x] : lw.mean[threadIdx.x];
     if (threadIdx.x == 0) bcount = 0u;
     __syncthreads();
     const int lane = threadIdx.x & (QSMC_WAVE - 1), wave = threadIdx.x / QSMC_WAVE;
@@ -1801,7 +1815,7 @@ __global__ __launch_bounds__(KICK16_BT) void k_bucket_kick16(
 #pragma unroll
     for (int sidx = 0; sidx < 4; ++sidx) aS[sidx] = sS[(lane & 15) * DM + 4 * g + sidx];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) mu4[r] = (1.0 - lw.a) * sS[DM * DM + g + 4 * r];
+    for (int r = 0; r < 4; ++r) mu4[r] = (1.0 - lw_a) * sS[DM * DM + g + 4 * r];
     double *mine = tile[wave];
     for (int64_t kb = r0; kb < r1; kb += KICK16_BT) {               // (uniform over the workgroup)
         const int64_t k64 = kb + (int64_t)wave * QSMC_WAVE;
@@ -1823,7 +1837,7 @@ __global__ __launch_bounds__(KICK16_BT) void k_bucket_kick16(
 #pragma unroll
             for (int sidx = 0; sidx < 4; ++sidx) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aS[sidx], z[sidx], acc, 0, 0, 0);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) mine[(16 * t + n) * KICK16_ROW + g + 4 * r] = (lw.a * xa[r] + mu4[r]) + acc[r];
+            for (int r = 0; r < 4; ++r) mine[(16 * t + n) * KICK16_ROW + g + 4 * r] = (lw_a * xa[r] + mu4[r]) + acc[r];
         }
         __syncthreads();
         const int64_t o = k64 + lane;

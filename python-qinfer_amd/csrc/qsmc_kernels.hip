@@ -35,6 +35,7 @@ using namespace qsmc;
 // =============================================================================================
 // context
 // =============================================================================================
+struct LWDev;             // kernels/sqrtm.hpp
 struct qsmc_ctx {
     int device;
     double *partials;      // device scratch for per-workgroup partial sums
@@ -125,6 +126,8 @@ struct qsmc_ctx {
         long long n_banked, n_rounds_leftover;   // resamples that used the bank (diagnostic)
     } bank;
     double expect_next;     // qsmc_lw_expect_redraws: consumed by the next qsmc_lw_resample_philox
+    LWDev *lw_dev;          // device: Liu-West arguments of a d = 16 resample formed on the device (kernels/sqrtm.hpp)
+    long long n_sqrt_dev, n_sqrt_agreed;   // square roots formed on the device by qsmc_step / of those, adopted after the host's check
     unsigned int *anc16;    // device: ancestors + canonicalize list of the split d = 16 sampler
     size_t anc16_cap;       // in bytes
     unsigned int *iscratch; // device integer scratch for the bucketed resampler
@@ -289,6 +292,7 @@ static inline bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; 
 
 #include "kernels/update.hpp"
 #include "kernels/likelihood_moments.hpp"
+#include "kernels/sqrtm.hpp"
 #include "kernels/scan.hpp"
 #include "kernels/resample.hpp"
 #include "kernels/walk_tomo.hpp"
@@ -688,7 +692,9 @@ int qsmc_create(qsmc_handle_t *out, int device) {
     if (e == hipSuccess) e = hipMalloc(&h->red_out, REDUCE_OUT_MAX * sizeof(double));
     if (e == hipSuccess) e = hipHostMalloc(&h->mapped, REDUCE_OUT_MAX * sizeof(double), hipHostMallocMapped);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&h->mapped_dev, h->mapped, 0);
-    if (e == hipSuccess) e = hipHostMalloc(&h->mapped_big, 512 * sizeof(double), hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostMalloc(&h->mapped_big, SQRT_MAPPED_DOUBLES * sizeof(double), hipHostMallocMapped);
+    if (e == hipSuccess) e = hipMalloc(&h->lw_dev, sizeof(LWDev));
+    if (e == hipSuccess) e = hipMemset(h->lw_dev, 0, sizeof(LWDev));
     if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&h->mapped_big_dev, h->mapped_big, 0);
     if (e == hipSuccess) e = hipHostMalloc(&h->flag, 64, hipHostMallocMapped);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&h->flag_dev, h->flag, 0);
@@ -722,6 +728,7 @@ int qsmc_destroy(qsmc_handle_t h) {
     if (h->spec.gate) (void)hipFree(h->spec.gate);
     if (h->iscratch) (void)hipFree(h->iscratch);
     if (h->anc16) (void)hipFree(h->anc16);
+    if (h->lw_dev) (void)hipFree(h->lw_dev);
     if (h->bank.entries) (void)hipFree(h->bank.entries);
     if (h->bank.aux) (void)hipFree(h->bank.aux);
     if (h->cdf_scratch) (void)hipFree(h->cdf_scratch);
@@ -1540,7 +1547,8 @@ static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int3
                                 double norm, double a, const double *mean, const double *S, int64_t n_out,
                                 uint64_t seed, uint64_t epoch, int32_t maxiter, double *x_out, const OutPlace &pl,
                                 int64_t *n_failed_host, qsmc_stream_t stream, CanonSpec canon = CanonSpec{0, 0, nullptr},
-                                int stages = RS_STAGE_ALL, double expect_redraws = 0.0) {
+                                int stages = RS_STAGE_ALL, double expect_redraws = 0.0,
+                                const SqrtJob *sqrt_job = nullptr, const LWDev *lw_dev = nullptr) {
     if (!h || !model || !x_in || !mean || !S || !x_out || n_in <= 0 || n_out <= 0) return QSMC_ERR_INVALID;
     if (d != model->d || d < 1 || d > QSMC_MAX_D || maxiter < 1) return QSMC_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
@@ -1607,9 +1615,12 @@ static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int3
         if (stages & RS_STAGE_ANCESTORS) {
             hipEvent_t a0 = nullptr, a1 = nullptr;
             prof_events(h, QSMC_PROF_ANCESTORS, &a0, &a1);
-            hipExtLaunchKernelGGL((k_bucket_anc16<512>), dim3(bp.max_items), dim3(512), 0, s, a0, a1, 0, n_in, w, inv_norm,
-                                  offsets, chunks, bp.slot_off, bp.item_off, bp.item_chunk, k0, k1, ep, bp.anc, bp.cap,
-                                  bp.clist /* [0]: the canonicalize list's length */);
+            SqrtJob sj;
+            memset(&sj, 0, sizeof(sj));
+            if (sqrt_job) sj = *sqrt_job;
+            hipExtLaunchKernelGGL((k_bucket_anc16<512>), dim3(bp.max_items + (sj.full ? 1 : 0)), dim3(512), 0, s, a0, a1, 0, n_in,
+                                  w, inv_norm, offsets, chunks, bp.slot_off, bp.item_off, bp.item_chunk, k0, k1, ep, bp.anc,
+                                  bp.cap, bp.clist /* [0]: the canonicalize list's length */, sj);
         }
         if (stages & RS_STAGE_KICK) {
             hipEvent_t pe0 = nullptr, pe1 = nullptr;
@@ -1619,7 +1630,7 @@ static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int3
             unsigned int *ccount = bp.clist, *clist = bp.clist + 4;      // (ccount was cleared by k_bucket_anc16)
 #define LAUNCH_K16(C)                                                                                                 \
     hipExtLaunchKernelGGL((k_bucket_kick16<C>), dim3(kgrid), dim3(KICK16_BT), 0, s, pe0, pe1, 0, x_in, ldx_in, bp.anc,  \
-                          n_out, lw, k0, k1, ep, x_out, pl, canon.basis, canon.allow_sub, clist, ccount)
+                          n_out, lw, k0, k1, ep, x_out, pl, canon.basis, canon.allow_sub, clist, ccount, lw_dev)
             if (canon.kind == 1) LAUNCH_K16(1);
             else if (canon.kind == 2) LAUNCH_K16(2);
             else LAUNCH_K16(0);
@@ -1826,6 +1837,56 @@ int qsmc_step_stats(qsmc_handle_t h, int64_t *n_queued, int64_t *n_adopted) {
     return QSMC_OK;
 }
 
+int qsmc_step_sqrt_stats(qsmc_handle_t h, int64_t *n_device, int64_t *n_agreed) {
+    if (!h || !n_device || !n_agreed) return QSMC_ERR_INVALID;
+    *n_device = h->n_sqrt_dev;
+    *n_agreed = h->n_sqrt_agreed;
+    return QSMC_OK;
+}
+
+int qsmc_lw_can_fuse_canonicalize(int32_t d, int64_t n_in, int64_t n_out) {
+    if (d != 16 || n_in <= 0 || n_out <= 0) return 0;
+    static const bool no_mfma16 = getenv("QSMC_NO_MFMA_SAMPLER") != nullptr;
+    return (!no_mfma16 && use_buckets((n_in + BUCKET_CHUNK - 1) / BUCKET_CHUNK, n_out)) ? 1 : 0;
+}
+
+int qsmc_reserve(qsmc_handle_t h, int64_t n_in, int64_t n_out, int32_t d) {
+    if (!h || n_in <= 0 || n_out <= 0 || d < 1 || d > QSMC_MAX_D) return QSMC_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    // every buffer the update and a resample of this shape grow on first use, grown now
+    const int per_block = QSMC_BLOCK * 2 * UPD_UNROLL;
+    const int dmom = d <= 4 ? d : 0;
+    int rc = ensure_partials(h, (size_t)QSMC_GRID_CAP * (3 + dmom + dmom * (dmom + 1) / 2 + 1));
+    if (rc) return rc;
+    const int64_t chunks64 = (n_in + BUCKET_CHUNK - 1) / BUCKET_CHUNK;
+    rc = ensure_tile_sums(h, (size_t)chunks64 * (BUCKET_CHUNK / (per_block / 2)) * QSMC_WAVES_PER_BLOCK);
+    if (rc) return rc;
+    if (chunks64 <= TILE_PREFIX_MAX_CHUNKS && h->tile_prefix_cap < (size_t)TILE_PREFIX_MAX_CHUNKS + 1) {
+        if (h->tile_prefix) HIP_TRY(h, hipFree(h->tile_prefix));
+        h->tile_prefix = nullptr;
+        h->tile_prefix_cap = 0;
+        HIP_TRY(h, hipMalloc(&h->tile_prefix, (size_t)(TILE_PREFIX_MAX_CHUNKS + 1) * sizeof(double)));
+        h->tile_prefix_cap = TILE_PREFIX_MAX_CHUNKS + 1;
+    }
+    rc = ensure_rs_offsets(h, (size_t)chunks64 + 1);
+    if (rc) return rc;
+    const bool split16 = qsmc_lw_can_fuse_canonicalize(d, n_in, n_out) != 0;
+    BucketPlan bp;
+    rc = bucket_plan_layout(h, chunks64, n_out, &bp, split16);
+    if (rc) return rc;
+    if (!split16) {
+        rc = ensure_cdf(h, (size_t)n_in);
+        if (rc) return rc;
+    } else {
+        const int gridm = grid_for(n_in, QSMC_BLOCK) < 1024 ? grid_for(n_in, QSMC_BLOCK) : 1024;
+        rc = ensure_partials(h, (size_t)gridm * MFMA_MOM_K);
+        if (rc) return rc;
+        rc = ensure_scratch(h, 256 + MFMA_MOM_K);
+        if (rc) return rc;
+    }
+    return ensure_pinned(h, 64);
+}
+
 // mean = S1 / norm, cov = S2 / norm - mean mean^T from the packed sums of the fused update: the operations
 // ParticleDistribution._moments / _cov_from_sums perform (one division, one product, one subtraction per entry; this
 // file is compiled with -ffp-contract=off), so the caller's own numbers come out bit for bit
@@ -1937,6 +1998,7 @@ int qsmc_step(qsmc_handle_t h, qsmc_step_t *st, const qsmc_model_t *model, const
     memset(&pl, 0, sizeof(pl));
     pl.ld_m = st->lw.ldx_out;
     pl.ld_s = 1;
+    bool device_sqrt = false;
     if (small_d) {
         if (canon.kind) return QSMC_OK;
         // the caller's resample (resamplers.py:266-300), started from here
@@ -1961,13 +2023,38 @@ int qsmc_step(qsmc_handle_t h, qsmc_step_t *st, const qsmc_model_t *model, const
         hipLaunchKernelGGL(k_sum_partials, dim3((MFMA_MOM_K + QSMC_WAVES_PER_BLOCK - 1) / QSMC_WAVES_PER_BLOCK),
                            dim3(QSMC_BLOCK), 0, s, h->partials, gridm, MFMA_MOM_K, full);
         const unsigned long long seq = ++h->seq;
-        hipLaunchKernelGGL(k_publish_big, dim3(1), dim3(QSMC_BLOCK), 0, s, full, MFMA_MOM_K, h->mapped_big_dev, h->flag_dev, seq);
-        HIP_TRY(h, hipGetLastError());
+        static const bool host_sqrt = getenv("QSMC_HOST_SQRT") != nullptr;               // (A/B switch: round 3's form)
+        device_sqrt = !host_sqrt;
         h->ts.armed = h->ts.gen;                               // these weights ARE update number ts.gen's output
-        rc = resample_philox_impl(h, model, st->lw.postselect, st->x, st->ldx, st->n, d, st->w, fixed, st->lw.a, st->mean,
-                                  st->S, st->lw.n_out, st->lw.seed, st->lw.epoch, st->lw.maxiter, st->lw.x_out, pl,
-                                  nullptr, stream, canon, RS_STAGE_ANCESTORS);
-        if (rc) return rc;
+        if (device_sqrt) {
+            // round 4: nothing of the resample waits for the host any more.  One wavefront riding in the ancestor kernel
+            // (kernels/sqrtm.hpp) turns the summed moments into mean / covariance / S = h sqrtm_psd(cov) in device memory,
+            // the kick kernel reads them from there, canonicalize's list pass follows: all queued here, now.  The host then
+            // receives moments, S and its error, repeats the square root with the same routine and adopts the queued
+            // resample only if every bit agrees (else the caller's own call runs it again with the host's numbers).
+            SqrtJob sj;
+            sj.full = full;
+            sj.out = h->lw_dev;
+            sj.mapped = h->mapped_big_dev;
+            sj.flag = h->flag_dev;
+            sj.seq = seq;
+            sj.a = st->lw.a;
+            sj.h = st->lw.h;
+            sj.zero_cov_comp = st->lw.zero_cov_comp;
+            HIP_TRY(h, hipGetLastError());
+            rc = resample_philox_impl(h, model, st->lw.postselect, st->x, st->ldx, st->n, d, st->w, fixed, st->lw.a, st->mean,
+                                      st->S, st->lw.n_out, st->lw.seed, st->lw.epoch, st->lw.maxiter, st->lw.x_out, pl,
+                                      nullptr, stream, canon, RS_STAGE_ALL, 0.0, &sj, h->lw_dev);
+            if (rc) return rc;
+            ++h->n_sqrt_dev;
+        } else {
+            hipLaunchKernelGGL(k_publish_big, dim3(1), dim3(QSMC_BLOCK), 0, s, full, MFMA_MOM_K, h->mapped_big_dev, h->flag_dev, seq);
+            HIP_TRY(h, hipGetLastError());
+            rc = resample_philox_impl(h, model, st->lw.postselect, st->x, st->ldx, st->n, d, st->w, fixed, st->lw.a, st->mean,
+                                      st->S, st->lw.n_out, st->lw.seed, st->lw.epoch, st->lw.maxiter, st->lw.x_out, pl,
+                                      nullptr, stream, canon, RS_STAGE_ANCESTORS);
+            if (rc) return rc;
+        }
         rc = wait_reduction(h, s);
         if (rc) return rc;
         // qsmc_moments' packing of the same block: [sum w, sum w x (d), upper(sum w x x^T)], weights already / norm
@@ -2000,10 +2087,19 @@ int qsmc_step(qsmc_handle_t h, qsmc_step_t *st, const qsmc_model_t *model, const
     if (!std::isfinite(st->S_err)) return QSMC_OK;             // (ResamplerError is the caller's to raise)
     if (small_d) h->ts.armed = h->ts.gen;                      // these weights ARE update number ts.gen's output
     const double expect = small_d ? (double)st->lw.redraws_seen : 0.0;
-    rc = resample_philox_impl(h, model, st->lw.postselect, st->x, st->ldx, st->n, d, st->w, fixed, st->lw.a, st->mean,
-                              st->S, st->lw.n_out, st->lw.seed, st->lw.epoch, st->lw.maxiter, st->lw.x_out, pl, nullptr,
-                              stream, canon, small_d ? RS_STAGE_ALL : RS_STAGE_KICK, expect);
-    if (rc) return rc;
+    if (device_sqrt) {
+        // the device's square root against the host's: same routine, same input -- the same bits, or no adoption
+        const double *dv = h->mapped_big;
+        if (dv[SQRT_MAPPED_VALID] != 1.0 || memcmp(&dv[SQRT_MAPPED_ERR], &st->S_err, sizeof(double)) != 0 ||
+            memcmp(dv + SQRT_MAPPED_S, st->S, sizeof(double) * d * d) != 0)
+            return QSMC_OK;                                    // (the caller's own call repeats the resample with its S)
+        ++h->n_sqrt_agreed;
+    } else {
+        rc = resample_philox_impl(h, model, st->lw.postselect, st->x, st->ldx, st->n, d, st->w, fixed, st->lw.a, st->mean,
+                                  st->S, st->lw.n_out, st->lw.seed, st->lw.epoch, st->lw.maxiter, st->lw.x_out, pl, nullptr,
+                                  stream, canon, small_d ? RS_STAGE_ALL : RS_STAGE_KICK, expect);
+        if (rc) return rc;
+    }
     st->lw.redraw_pending = 1;
     auto &q = h->rsq;
     q.valid = 1;
@@ -2584,70 +2680,7 @@ int qsmc_host_allreduce(void *segment, int32_t rank, int32_t world, int32_t max_
 // ---- host: sqrtm_psd by cyclic Jacobi (utils.py:593-607) --------------------------------------
 int qsmc_sqrtm_psd(const double *A, int32_t d, double scale, double *S_out, double *err_out) {
     if (!A || !S_out || d < 1 || d > 64) return QSMC_ERR_INVALID;
-    const int n = d;
-    double *a = (double *)malloc(sizeof(double) * n * n * 3);
-    if (!a) return QSMC_ERR_ALLOC;
-    double *v = a + n * n, *sq = v + n * n;
-    for (int i = 0; i < n; ++i)
-        for (int j = 0; j < n; ++j) {
-            a[i * n + j] = 0.5 * (A[i * n + j] + A[j * n + i]);   // eigh reads one triangle; symmetrise
-            v[i * n + j] = (i == j) ? 1.0 : 0.0;
-        }
-    for (int sweep = 0; sweep < 64; ++sweep) {
-        double off = 0.0, diag = 0.0;
-        for (int i = 0; i < n; ++i) {
-            diag += a[i * n + i] * a[i * n + i];
-            for (int j = i + 1; j < n; ++j) off += a[i * n + j] * a[i * n + j];
-        }
-        if (off == 0.0 || off <= 1e-34 * diag) break;
-        for (int p = 0; p < n; ++p)
-            for (int q = p + 1; q < n; ++q) {
-                const double apq = a[p * n + q];
-                if (apq == 0.0) continue;
-                const double tau = (a[q * n + q] - a[p * n + p]) / (2.0 * apq);
-                const double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-                const double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
-                for (int k = 0; k < n; ++k) {
-                    const double akp = a[k * n + p], akq = a[k * n + q];
-                    a[k * n + p] = c * akp - s * akq;
-                    a[k * n + q] = s * akp + c * akq;
-                }
-                for (int k = 0; k < n; ++k) {
-                    const double apk = a[p * n + k], aqk = a[q * n + k];
-                    a[p * n + k] = c * apk - s * aqk;
-                    a[q * n + k] = s * apk + c * aqk;
-                }
-                for (int k = 0; k < n; ++k) {
-                    const double vkp = v[k * n + p], vkq = v[k * n + q];
-                    v[k * n + p] = c * vkp - s * vkq;
-                    v[k * n + q] = s * vkp + c * vkq;
-                }
-            }
-    }
-    // S = V sqrt(max(lambda, 0)) V^T
-    for (int i = 0; i < n; ++i)
-        for (int j = 0; j < n; ++j) {
-            double s = 0.0;
-            for (int k = 0; k < n; ++k) {
-                const double lam = a[k * n + k];
-                const double r = lam <= 0.0 ? 0.0 : sqrt(lam);
-                s += v[i * n + k] * r * v[j * n + k];
-            }
-            sq[i * n + j] = s;
-        }
-    if (err_out) {
-        double e2 = 0.0;
-        for (int i = 0; i < n; ++i)
-            for (int j = 0; j < n; ++j) {
-                double s = 0.0;
-                for (int k = 0; k < n; ++k) s += sq[i * n + k] * sq[k * n + j];
-                const double dlt = s - A[i * n + j];
-                e2 += dlt * dlt;
-            }
-        *err_out = sqrt(e2);
-    }
-    for (int k = 0; k < n * n; ++k) S_out[k] = scale * sq[k];
-    free(a);
+    sqrtm_psd_host(A, d, scale, S_out, err_out);          // kernels/sqrtm.hpp: the routine the device wavefront mirrors
     return QSMC_OK;
 }
 

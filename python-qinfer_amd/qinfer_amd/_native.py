@@ -96,6 +96,9 @@ SIGNATURES = {
     "qsmc_step_stats": [_P, C.POINTER(_I64), C.POINTER(_I64)],
     "qsmc_lw_fuse_canonicalize": [_P, _P, _I32, _I32, _I32],
     "qsmc_lw_expect_redraws": [_P, _I64],
+    "qsmc_lw_can_fuse_canonicalize": [_I32, _I64, _I64],
+    "qsmc_reserve": [_P, _I64, _I64, _I32],
+    "qsmc_step_sqrt_stats": [_P, C.POINTER(_I64), C.POINTER(_I64)],
     "qsmc_update_multi": [_P, C.POINTER(ModelDesc), _P, _I64, _I64, _P, _P, _F64, C.POINTER(ExpParam),
                           C.POINTER(_I64), _I32, C.POINTER(UpdateStats), C.POINTER(_F64), _P],
     "qsmc_hypothetical_sums": [_P, C.POINTER(ModelDesc), _P, _I64, _I64, _P, _F64, C.POINTER(ExpParam),

@@ -415,15 +415,20 @@ class Engine:
             "qsmc_lw_resample_philox")
         return x_out, (failed.value if sync else None)
 
-    @staticmethod
-    def fused_canon_applies(d, n_in, n_out):
+    def fused_canon_applies(self, d, n_in, n_out):
         """Does a resample of this shape take the split d = 16 sampler (the one that can fold canonicalize in)?  The
-        library's own rule (use_buckets in qsmc_kernels.hip): the bucketed path, i.e. at most 8192 chunks of 4096
-        source particles and at least 4 chunks' worth of outputs."""
-        import os
-        chunks = -(-n_in // 4096)
-        return (d == 16 and chunks <= 8192 and 4 * 4096 <= n_out < 2 ** 32 and not os.environ.get("QSMC_DIRECT_RESAMPLE")
-                and not os.environ.get("QSMC_NO_MFMA_SAMPLER"))
+        library's own rule, asked of the library (qsmc_lw_can_fuse_canonicalize)."""
+        return bool(self.lib.qsmc_lw_can_fuse_canonicalize(int(d), int(n_in), int(n_out)))
+
+    def reserve(self, n_in, n_out, d):
+        """Grow the handle's update / resample scratch for a cloud of this shape now, not inside the first resample."""
+        self._chk(self.lib.qsmc_reserve(self.h, int(n_in), int(n_out), int(d)), "qsmc_reserve")
+
+    def step_sqrt_stats(self):
+        """(d = 16 square roots formed on the device by qsmc_step, of those confirmed bit for bit by the host)."""
+        q, a = C.c_int64(), C.c_int64()
+        self._chk(self.lib.qsmc_step_sqrt_stats(self.h, C.byref(q), C.byref(a)), "qsmc_step_sqrt_stats")
+        return q.value, a.value
 
     def random_walk(self, x, scale, z=None, seed=0, epoch=0):
         """x[m, :] += scale[m] * z in place (rows with scale 0 untouched); z: device (n_rw, n) steps, or None

@@ -239,6 +239,11 @@ class SMCUpdater(ParticleDistribution):
             self._st.lw.redraws_seen, self._st.lw.redraw_pending = 0, 0
         if self._canonicalize:
             self._canonicalize_device(rows)
+        r = self.resampler
+        if self._native and getattr(r, "_device_rng", False) and n_particles <= getattr(r, "_segment_limit", 0):
+            # the scratch a resample of this cloud will want, grown now rather than inside the first resample
+            n_out = getattr(r, "_default_n_particles", None)
+            eng.reserve(n_particles, n_particles if n_out is None else int(n_out), d)
 
     @staticmethod
     def _canonicalize_is_identity(model):

@@ -1653,11 +1653,14 @@ def test_step_path_same_particles(qi, monkeypatch):
             upd = qi.SMCUpdater(m, n, make_prior(m), device_rng=True, seed=21)
             assert (upd._st is not None) == step
             q0, a0 = upd._eng.step_stats()
+            sq0 = upd._eng.step_sqrt_stats()
             ess = []
             for o, ep in data:
                 upd.update(o, ep)
                 ess.append(float(upd.n_ess))
             q1, a1 = upd._eng.step_stats()
+            sq1 = upd._eng.step_sqrt_stats()
+        upd._sqrt_stats = (sq1[0] - sq0[0], sq1[1] - sq0[1])
         return upd, np.array(ess), q1 - q0, a1 - a0
 
     for name, make_model, make_prior, n, data, queued in cases:
@@ -1674,6 +1677,12 @@ def test_step_path_same_particles(qi, monkeypatch):
         assert q_b == 0 and ad_b == 0
         if queued:                                   # every resample was queued from C and adopted by the resampler's call
             assert q_a == a.resample_count and ad_a == a.resample_count, (name, q_a, ad_a, a.resample_count)
+        if name.startswith("tomography"):
+            # d = 16: mean / covariance / S = h sqrtm_psd(cov) were formed by a wavefront on the device (kernels/sqrtm.hpp)
+            # and every one of them was confirmed bit for bit by the host's run of the same routine -- and the clouds above
+            # equal the ones of the path on which the host's routine is the only one (utils.py:593-607)
+            assert a._sqrt_stats == (a.resample_count, a.resample_count), (name, a._sqrt_stats, a.resample_count)
+            assert b._sqrt_stats == (0, 0)
         elif queued is False:
             assert q_a == 0
     # the guards still fire from the step path, with the reference's messages (fixture G6 mirrors them for the old path)
@@ -1693,6 +1702,34 @@ def test_step_path_same_particles(qi, monkeypatch):
     with pytest.warns(qi.ApproximationWarning, match="Negative weights"):
         upd.update(0, np.array([0.0]))
     assert np.all(np.asarray(upd.particle_weights) >= 0)
+    # an update the zero-weight policy skips leaves the estimates of the committed state (the struct's moment slots hold
+    # the discarded update's sums by then: they must not be read)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        upd = qi.SMCUpdater(qi.SimplePrecessionModel(), 50_000, qi.UniformDistribution([0.2, 0.4]), device_rng=True, seed=5,
+                            zero_weight_policy='skip')
+        upd.update(1, np.array([1.0]), check_for_resample=False)
+        upd.update(0, np.array([2.0]), check_for_resample=False)
+        w_before = np.asarray(upd.particle_weights).copy()
+        ref_mean = w_before @ np.asarray(upd.particle_locations)
+        upd.update(0, np.array([2.5]), check_for_resample=False)        # (leaves the lazy moment marker: nothing read yet)
+        w_before = np.asarray(upd.particle_weights).copy()
+        ref_mean = w_before @ np.asarray(upd.particle_locations)
+        # (the zero-weight test is `sum of the normalised new weights <= thresh`: a threshold above 1 makes any datum
+        #  "impossible"; set in the struct too, so that the moment marker of the last committed update stays in place)
+        upd._zero_weight_thresh = 10.0
+        upd._st.zero_weight_thresh = 10.0
+        from qinfer_amd.smc import _FROM_STEP
+        assert upd._moments_cache is _FROM_STEP or upd._moments_cache is not None
+        n_rec = len(upd.normalization_record)
+        upd.update(1, np.array([3.0]), check_for_resample=False)        # skipped: sum w' <= thresh
+        assert len(upd.normalization_record) == n_rec
+        np.testing.assert_array_equal(np.asarray(upd.particle_weights), w_before)
+        np.testing.assert_allclose(upd.est_mean(), ref_mean, rtol=1e-11)
+        upd._zero_weight_thresh = 10 * np.spacing(1)
+        upd._invalidate()
+        upd.update(1, np.array([3.0]), check_for_resample=False)        # and the path goes on
+        assert len(upd.normalization_record) == n_rec + 1
     # a user swaps the resampler / the threshold between data: the struct follows
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
