@@ -1932,7 +1932,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_bucket_redraw(
 
 // copies the failed-particle counter into pinned host memory (read later, after any stream sync)
 __global__ void k_publish_counter(const unsigned long long *__restrict__ counter, double *__restrict__ mapped_slot) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) *mapped_slot = (double)*counter;
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        mapped_slot[0] = (double)counter[0];
+        mapped_slot[-1] = (double)counter[1];          // how many outputs of that resample needed a global redraw
+    }
 }
 
 __global__ __launch_bounds__(QSMC_BLOCK) void k_prior_uniform_philox(

@@ -149,7 +149,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 
 // One wavefront (64 lanes; the caller guarantees threadIdx.x < 64 and that no other wave touches `lds`): n = 16.
 // lds: at least 16 * 17 * 3 + 64 doubles.
-__device__ __noinline__ void lw_sqrt16_wave(const SqrtJob job, double *lds) {
+__device__ __forceinline__ void lw_sqrt16_wave(const SqrtJob job, double *lds) {
     constexpr int N = 16, LD = 17;
     double *A = lds, *V = lds + N * LD, *A0 = lds + 2 * N * LD, *tmp = lds + 3 * N * LD;   // tmp[64]
     const int lane = threadIdx.x & 63;

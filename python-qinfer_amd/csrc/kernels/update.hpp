@@ -612,6 +612,113 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_hyp_sums_lanes(const double *__r
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Round 4: binomial experiments, consecutive outcomes k_first, k_first + 1, ... -- the sums above with ONE exponential
+// per particle and pass instead of one per (particle, outcome).  k_hyp_sums_lanes is VALU-bound on fast_exp (SQ counters:
+// profiles/r4_*_paths_sq_counters.json): 32 outcome slots x ~46 fp64 instructions per particle.  The pmfs of consecutive
+// outcomes obey
+//     pmf(k + 1) = pmf(k) [(n - k) / (k + 1)] [p / (1 - p)],
+// two multiplications -- but along the OUTCOME axis, which the lane-per-outcome layout spreads over lanes.  Here a lane
+// owns a particle (as in k_hyp_sums) and walks the outcomes of one pass, NO = 52 / (2 + 2 D) of them (13 at D = 1): the
+// NO x (2 + 2 D) running sums are 104 VGPRs (k_hyp_sums at 32 outcomes needed 256 and spilled), and per (particle,
+// outcome) the work is 2 multiplications for the pmf, 2 multiply-adds for ln pmf and 2 + 2 D for the sums.  A 26-outcome
+// experiment is two passes of 13.  The matrix cores do not come into it: on gfx950 the fp64 MFMA rate equals the fp64
+// vector rate and a 16 x 16 x 4 tile would carry 5 useful columns of 16; what MFMA accumulators would buy is registers,
+// which the two-pass split buys cheaper.  (Also built this round, and slower -- tools/experiments/r4_hyp_sums_recurrence
+// _via_lds.patch: the recurrence in the particle's lane, pmfs handed to outcome lanes through LDS.)
+// The walk starts at the pass's first outcome.  Relative error of the walk <= ~3 ulp per step: 4e-15 over 12 steps
+// (fixture G7 allows 1e-10).
+// ---------------------------------------------------------------------------------------------
+constexpr int CHAIN_SUMS = 52;      // running sums per lane: 13 outcomes x (2 + 2 D) at D = 1 -- a 26-outcome experiment is two passes
+struct ChainArgs {
+    int n_o;                       // outcomes in this pass (<= NO), consecutive from k_first
+    ExpArgs base;
+    int j_full;                    // the j with k_first + j == n_meas (-1: not in this pass)
+    double k_first;
+    double lc[16];                 // ln C(n, k_first + j)
+    double ratio[16];              // (n - k) / (k + 1) at k = k_first + j: pmf(k + 1) / pmf(k) without the odds
+    double shift[QSMC_MAX_D];
+};
+
+template <int KIND>
+__attribute__((amdgpu_waves_per_eu(3, 4)))
+__global__ __launch_bounds__(QSMC_BLOCK) void k_hyp_sums_chain(const double *__restrict__ x, int64_t ldx, int64_t n,
+                                                               const double *__restrict__ w, double norm,
+                                                               ChainArgs ca, ReduceOut ro) {
+    constexpr int D = Model<KIND>::D <= 4 ? Model<KIND>::D : 0;
+    constexpr int DD = Model<KIND>::D;
+    constexpr int PER = 2 + 2 * D;
+    constexpr int NO = CHAIN_SUMS / PER;
+    constexpr int NS = NO * PER;
+    double s[NS];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) s[q] = 0.0;
+    const double n_meas = ca.base.n_meas;
+    const double inv_norm = 1.0 / norm;
+    const int64_t stride = (int64_t)gridDim.x * QSMC_BLOCK;
+    int64_t i = (int64_t)blockIdx.x * QSMC_BLOCK + threadIdx.x;
+    // the next particle's loads are issued before this one's ~300 instructions: at two or three waves per SIMD (the
+    // running sums take 104 VGPRs) nothing else hides the load latency -- 271 us per pass without, measured
+    double pn[DD], wn = 1.0;
+    if (i < n) {
+#pragma unroll
+        for (int m = 0; m < DD; ++m) pn[m] = x[m * ldx + i];
+        if (w) wn = w[i];
+    }
+    for (; i < n; i += stride) {
+        double p[DD];
+#pragma unroll
+        for (int m = 0; m < DD; ++m) p[m] = pn[m];
+        const double wi = wn * inv_norm;
+        if (i + stride < n) {
+#pragma unroll
+            for (int m = 0; m < DD; ++m) pn[m] = x[m * ldx + i + stride];
+            if (w) wn = w[i + stride];
+        }
+        HypPre<KIND> pre;
+        pre.prepare(p, ca.base);
+        double c1[D > 0 ? D : 1], c2[D > 0 ? D : 1];
+#pragma unroll
+        for (int m = 0; m < D; ++m) {
+            c1[m] = p[m] - ca.shift[m];
+            c2[m] = c1[m] * c1[m];
+        }
+        const double pr1 = pre.pr1, lp = pre.lp, lq = pre.lq;
+        // ln pmf(k_first + j) = lc[j] + t_j, t_j = n ln(1 - p) + (k_first + j) (ln p - ln(1 - p)): a running sum (what is
+        // uniform over the lanes stays in scalar registers: lc[j] and ratio[j] are the only per-outcome operands -- with
+        // k_j and n - k_j as operands the compiler kept 2 x 13 loop-invariant doubles in VGPRs and spilled 80)
+        const double dl = lp - lq;
+        double t = n_meas * lq + ca.k_first * dl;
+        const double logL0 = ca.lc[0] + t;
+        // The walk needs no second path.  pr1 == 0: the pmf is [k == 0] -- start there, multiply by 0.  pr1 == 1: [k == n],
+        // selected per outcome.  pr1 outside [0, 1] (an invalid particle): NaN throughout, like SciPy's pmf (weight 0: 0).
+        // A first pmf that underflows makes the pass 0 for this particle: with <= 13 outcomes a pass and 1 - pr1 >= 1.1e-16
+        // the later ones are then below 1e-150 of a sum that is O(1) (ln pmf is finite in every case: HypPreBinomial sets
+        // the logarithm of a vanishing probability to 0, so w pmf ln pmf needs no guard).
+        const bool inside = pr1 > 0.0 && pr1 < 1.0, one = pr1 == 1.0;
+        const double step = inside ? pr1 / (1.0 - pr1) : 0.0;
+        double cur = inside ? wi * fast_exp(logL0)
+                            : (pr1 == 0.0 ? (ca.k_first == 0.0 ? wi : 0.0) : (one || wi == 0.0 ? 0.0 : NAN));
+#pragma unroll
+        for (int j = 0; j < NO; ++j) {
+            if (j < ca.n_o) {                                   // (uniform)
+                const double logL = ca.lc[j] + t;
+                const double wl = one ? (j == ca.j_full ? wi : 0.0) : cur;     // w pmf(k_first + j)
+                t += dl;
+                s[j * PER] += wl;
+                s[j * PER + 1] += wl * logL;
+#pragma unroll
+                for (int m = 0; m < D; ++m) {
+                    s[j * PER + 2 + m] += wl * c1[m];
+                    s[j * PER + 2 + D + m] += wl * c2[m];
+                }
+                cur = cur * (ca.ratio[j] * step);
+            }
+        }
+    }
+    block_publish<NS>(s, 0.0, ro);
+}
+
 // mode 0: w_out = (w_in / norm) * L   (generic-model slow path)
 // mode 1: w_out = clip(w_in / norm, 0, 1)   (negative-weight guard)
 // mode 2: w_out = w_in / norm               (materialise; stats still produced)

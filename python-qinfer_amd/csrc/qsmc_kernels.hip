@@ -583,6 +583,55 @@ static int hyp_launch_lanes(qsmc_ctx *h, const qsmc_model_t *model, const double
     return QSMC_OK;
 }
 
+// binomial models, consecutive outcomes: a lane per particle walks the outcomes of a pass (k_hyp_sums_chain)
+template <int KIND>
+static int hyp_launch_chain(qsmc_ctx *h, const qsmc_model_t *model, const double *x, int64_t ldx, int64_t n,
+                            const double *w, double norm, const qsmc_expparam_t *exp, const int64_t *outcomes, int n_o,
+                            const double *shift, double *out_host, hipStream_t s) {
+    constexpr int D = Model<KIND>::D <= 4 ? Model<KIND>::D : 0;
+    constexpr int PER = 2 + 2 * D;
+    constexpr int NO = CHAIN_SUMS / PER;
+    constexpr int NS = NO * PER;
+    if (n_o < 1 || n_o > NO) return QSMC_ERR_INVALID;
+    const int grid = grid_for(n, QSMC_BLOCK * 4);
+    int rc = ensure_partials(h, (size_t)grid * (NS + 1));
+    if (rc) return rc;
+    rc = ensure_scratch(h, 256 + 512);
+    if (rc) return rc;
+    ChainArgs ca;
+    memset(&ca, 0, sizeof(ca));
+    ca.n_o = n_o;
+    make_exp_args(model, exp, outcomes[0], &ca.base);
+    ca.k_first = (double)outcomes[0];
+    const double nm = (double)exp->n_meas;
+    ca.j_full = -1;
+    for (int j = 0; j < n_o; ++j) {
+        if ((uint64_t)outcomes[j] == exp->n_meas) ca.j_full = j;
+        ExpArgs tmp;
+        make_exp_args(model, exp, outcomes[j], &tmp);
+        ca.lc[j] = tmp.log_comb;
+        const double k = ca.k_first + (double)j;
+        ca.ratio[j] = (nm - k) / (k + 1.0);
+    }
+    if (shift) for (int m = 0; m < model->d && m < QSMC_MAX_D; ++m) ca.shift[m] = shift[m];
+    ReduceOut ro;
+    memset(&ro, 0, sizeof(ro));
+    ro.partials = h->partials;
+    hipEvent_t he0 = nullptr, he1 = nullptr;
+    prof_events(h, QSMC_PROF_HYP_SUMS, &he0, &he1);
+    hipExtLaunchKernelGGL((k_hyp_sums_chain<KIND>), dim3(grid), dim3(QSMC_BLOCK), 0, s, he0, he1, 0, x, ldx, n, w, norm, ca, ro);
+    double *full = h->scratch + 256;
+    hipLaunchKernelGGL(k_sum_columns, dim3((NS + QSMC_WAVES_PER_BLOCK - 1) / QSMC_WAVES_PER_BLOCK), dim3(QSMC_BLOCK), 0, s,
+                       h->partials, grid, NS, full);
+    const unsigned long long seq = ++h->seq;
+    hipLaunchKernelGGL(k_publish_big, dim3(1), dim3(QSMC_BLOCK), 0, s, full, NS, h->mapped_big_dev, h->flag_dev, seq);
+    HIP_TRY(h, hipGetLastError());
+    rc = wait_reduction(h, s);
+    if (rc) return rc;
+    memcpy(out_host, h->mapped_big, (size_t)n_o * PER * sizeof(double));
+    return QSMC_OK;
+}
+
 template <int KIND>
 static int hyp_dispatch(qsmc_ctx *h, const qsmc_model_t *model, const double *x, int64_t ldx, int64_t n,
                         const double *w, double norm, const qsmc_expparam_t *exp, const int64_t *outcomes,
@@ -602,10 +651,25 @@ static int hyp_dispatch(qsmc_ctx *h, const qsmc_model_t *model, const double *x,
     static const bool no_lanes = getenv("QSMC_HYP_NO_LANES") != nullptr;            // (A/B switch)
     constexpr bool BINOMIAL = KIND == QSMC_MODEL_BINOMIAL_PRECESSION || KIND == QSMC_MODEL_BINOMIAL_RB ||
                               KIND == QSMC_MODEL_BINOMIAL_RB_INTERLEAVED;
+    static const bool no_chain = getenv("QSMC_HYP_NO_CHAIN") != nullptr;             // (A/B switch)
+    // consecutive outcomes inside [0, n_meas] (the domain of a binomial experiment, in order): passes of equal size
+    bool consecutive = BINOMIAL && !no_chain && n_o > 2 && model->likelihood_power == 0.0 && outcomes[0] >= 0 &&
+                       (uint64_t)outcomes[n_o - 1] <= exp->n_meas;
+    for (int o = 1; o < n_o && consecutive; ++o) consecutive = outcomes[o] == outcomes[0] + o;
+    constexpr int CHAIN_NO = CHAIN_SUMS / PER;
+    const int chain_passes = (n_o + CHAIN_NO - 1) / CHAIN_NO;
+    const int chain_take = (n_o + chain_passes - 1) / chain_passes;
     while (done < n_o) {
         const int m = n_o - done;
         int take, rc;
-        if (BINOMIAL && WIDE && m > 8 && !no_lanes && model->likelihood_power == 0.0) {
+        if (consecutive) {
+            take = m < chain_take ? m : chain_take;
+            if constexpr (BINOMIAL)
+                rc = hyp_launch_chain<KIND>(h, model, x, ldx, n, w, norm, exp, outcomes + done, take, shift,
+                                            out_host + (size_t)done * PER, s);
+            else
+                rc = QSMC_ERR_INVALID;
+        } else if (BINOMIAL && WIDE && m > 8 && !no_lanes && model->likelihood_power == 0.0) {
             take = m < 32 ? m : 32;
             if constexpr (BINOMIAL && WIDE)
                 rc = hyp_launch_lanes<KIND>(h, model, x, ldx, n, w, norm, exp, outcomes + done, take, shift,

@@ -506,6 +506,18 @@ class ParticleShardGroup:
         else:
             totals, stay = None, False
         big = n_local > resampler._segment_limit        # beyond the bucketed sampler's single pass: segments (resamplers.py)
+        # how many first tries of this shard's previous resample failed postselection (what the proposal bank is sized by):
+        # an updater on the per-datum C path has it in its qsmc_step_t (it came back with the sums of the update after that
+        # resample); under the RCCL transport no reduction is host-visible, so it is fetched here -- before this resample's
+        # prefix clears the counters
+        st = getattr(updater, "_st", None)
+        if st is not None:
+            expect = int(st.lw.redraws_seen)
+        elif getattr(updater, "_shard_resampled", False):
+            eng.last_resample_failed(synchronize=True)
+            expect = int(eng.last_resample_redraws())
+        else:
+            expect = 0
         if stay and not big and not prefix_done:
             # children stay with their ancestor: this rank draws its T_h particles, nothing moves.  The
             # weight-only prefix (chunk sums, multinomial chunk counts) is queued before mean / cov / sqrtm
@@ -543,8 +555,6 @@ class ParticleShardGroup:
             canon = getattr(updater, "_fused_canon", None)
             if canon is not None and not eng.fused_canon_applies(d, n_local, n_new):
                 canon = None
-            st = getattr(updater, "_st", None)
-            expect = int(st.lw.redraws_seen) if st is not None else 0
             x_new, n_failed = eng.lw_resample_philox(model._native_desc(), resampler._postselect, updater._x,
                                                      updater._w, float(W[self.rank]), a, mean, S,
                                                      n_new, seed_r, epoch, resampler._maxiter,
@@ -577,6 +587,7 @@ class ParticleShardGroup:
         if n_failed:
             warnings.warn("Liu-West resampling failed to find valid models for {} particles within {} "
                           "iterations.".format(n_failed, resampler._maxiter), ResamplerWarning)
+        updater._shard_resampled = True
         new = ParticleDistribution._from_device(eng, x_new, None, norm=float(n_total), sumsq=float(n_total))
         new._canonicalized = canonicalized
         return new

@@ -237,6 +237,7 @@ class SMCUpdater(ParticleDistribution):
         self._invalidate()
         if getattr(self, "_st", None) is not None:
             self._st.lw.redraws_seen, self._st.lw.redraw_pending = 0, 0
+        self._shard_resampled = False
         if self._canonicalize:
             self._canonicalize_device(rows)
         r = self.resampler
