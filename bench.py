@@ -188,7 +188,7 @@ def other_config_specs(qi):
                       prior=lambda m=m: qi.PostselectedDistribution(qi.UniformDistribution([[0.8, 1], [0, 1], [0, 1]]), m),
                       eps=eps, outs=outs,
                       workload="RandomizedBenchmarkingModel (p, A, B), 1.25e7 particles (1e8 / 8 GPUs), m_k = 1 + 5k",
-                      update_kernel="k_update_fused<RB,1,false>", sampler="k_bucket_sample<3,512>"))
+                      update_kernel="k_update_fused<RB,1,false>", sampler="k_bucket_sample_ordered<3,512>"))
     # C5 per-GPU share: 2-qubit TomographyModel d = 16, N = 1.25e6, Ginibre prior, random Pauli measurements
     basis = qi.tomography.pauli_basis(2)
     m = qi.TomographyModel(basis)
@@ -207,7 +207,7 @@ def other_config_specs(qi):
     specs.append(dict(key="config5_share_tomography", model=m, n=1_250_000, d=16, prior=lambda: gin_cached, eps=eps, outs=outs,
                       workload="2-qubit TomographyModel (15 free params), 1.25e6 particles (1e7 / 8 GPUs), Ginibre prior, "
                                "random Pauli measurements",
-                      update_kernel="k_update_fused<TOMOGRAPHY,1,false>", sampler="k_bucket_sample<16,512>"))
+                      update_kernel="k_update_fused<TOMOGRAPHY,1,false>", sampler="k_bucket_anc16<512> + k_bucket_kick16"))
     # (not a BASELINE config, not in the default run: `--only extra_binomial_rb` -- the model simple_est_rb builds)
     m = qi.BinomialModel(qi.RandomizedBenchmarkingModel())
     eps, outs = [], []
@@ -368,10 +368,13 @@ def other_paths(qi, eng, torch, n=10_000_000):
          "ms_per_experiment": wall / 4 * 1e3, "hypothetical_likelihoods_per_s": 26 * 4 * n / wall,
          "risk": [float(v) for v in risk]}
     if "hyp_sums" in kt:
-        e["kernel"] = frac_entry("k_hyp_sums<BINOMIAL_PRECESSION,32>", kt["hyp_sums"]["avg_us"], 16.0 * n,
+        passes = kt["hyp_sums"]["launches"] // 4          # (launches per experiment: 26 outcomes = two passes of 13)
+        e["kernel"] = frac_entry("k_hyp_sums_chain<BINOMIAL_PRECESSION>", kt["hyp_sums"]["avg_us"], 16.0 * n,
                                  kt["hyp_sums"]["launches"],
-                                 {"bytes_per_particle": 16, "outcomes_per_pass": 26,
-                                  "note": "VALU-bound: 26 pmf evaluations and 26 x 4 running sums per particle per pass"})
+                                 {"bytes_per_particle": 16, "outcomes_per_pass": 13, "passes_per_experiment": passes,
+                                  "kernel_us_per_experiment": kt["hyp_sums"]["avg_us"] * passes,
+                                  "note": "VALU-bound (80 % VALU-busy, profiles/r4_a_paths_sq_counters.json): one pmf by "
+                                          "exponential + 12 by recurrence and 13 x 4 running sums per particle per pass"})
     out["bayes_risk_26_outcomes"] = e
     del upd
     torch.cuda.empty_cache()

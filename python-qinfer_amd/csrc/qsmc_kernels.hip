@@ -593,7 +593,11 @@ static int hyp_launch_chain(qsmc_ctx *h, const qsmc_model_t *model, const double
     constexpr int NO = CHAIN_SUMS / PER;
     constexpr int NS = NO * PER;
     if (n_o < 1 || n_o > NO) return QSMC_ERR_INVALID;
-    const int grid = grid_for(n, QSMC_BLOCK * 4);
+    // one resident round (three 256-thread workgroups per CU at 168 VGPRs): the 52 wave reductions at the end of a
+    // workgroup cost ~1000 instructions per thread -- as much as three particles -- and 2048 workgroups on 768 slots end in
+    // a ragged third round
+    int grid = grid_for(n, QSMC_BLOCK * 4);
+    if (grid > 3 * h->cu_count) grid = 3 * h->cu_count;
     int rc = ensure_partials(h, (size_t)grid * (NS + 1));
     if (rc) return rc;
     rc = ensure_scratch(h, 256 + 512);
