@@ -435,7 +435,7 @@ def main():
     ap.add_argument("--only", default=None, help="run ONE other config by key instead of the headline (profiling runs)")
     ap.add_argument("--cpu-data", type=int, default=20, help="data of the schedule the CPU baseline runs")
     ap.add_argument("--event-stride", type=int, default=0,
-                    help="put hipEvents on every N-th launch of each timed kernel kind (0 = steps // 10, 1..8)")
+                    help="put hipEvents on every N-th launch of each timed kernel kind (0 = steps // 5, 1..8)")
     ap.add_argument("--force-comm", action="store_true",
                     help="run the sharded code path even with one rank (validation on a 1-GPU box)")
     args = ap.parse_args()
@@ -483,7 +483,7 @@ def main():
     eng = get_engine()
     n = int(args.particles)
     ts, outcomes = schedule()
-    stride = args.event_stride if args.event_stride > 0 else max(1, min(8, args.steps // 10))
+    stride = args.event_stride if args.event_stride > 0 else max(1, min(8, args.steps // 5))
 
     def barrier():
         torch.cuda.synchronize()
@@ -518,6 +518,11 @@ def main():
         3 ms timed region; round 3's driver line read 0.177 ms/step against 0.077 for the same sample a minute later) and
         one rehearsal of the K steps themselves.  The garbage collector is off inside the timed region, as in `timeit`."""
         import gc
+        # (collected once, up front, then off until the last pass is done: a full collection right before the timed region
+        #  is tens of milliseconds of idle GPU -- measured: the passes behind it ran 0.085-0.096 ms/step, clocks ramping
+        #  back up, against 0.077 for the same 20 data in a busy process)
+        gc.collect()
+        gc.disable()
         for k in range(args.warmup):
             upd.update(int(outcomes[k % N_SCHEDULE]), ts[k % N_SCHEDULE:k % N_SCHEDULE + 1])
         upd.resample()
@@ -531,18 +536,16 @@ def main():
             # a launch that carries start/stop events drains the queue around itself (measured: 10.7 us per step
             # with every launch timed), so every `stride`-th launch of each kernel kind is timed
             eng.set_profiling(stride if (events and rep == 0) else 0)
-            gc.collect()
-            gc.disable()
             barrier()
             t0 = time.perf_counter()
             k_steps(upd)
             barrier()
             walls.append(time.perf_counter() - t0)
-            gc.enable()
             if rep == 0:
                 # (est_mean is a collective on a sharded cloud: every rank is here)
                 first_pass.append((upd.resample_count,) + tuple(eng.profile_read() if events else (np.zeros(0), np.zeros(0)))
                                   + (float(upd.est_mean()[0]),))
+        gc.enable()
         return walls[0], walls[1:]
 
     first_pass = []        # (resamples, kernel durations [ms], kernel tags, posterior mean) of each call's contract pass

@@ -64,6 +64,7 @@ struct qsmc_ctx {
     int cu_reported;               // what the device attribute says
     void *sort_tmp;                // rocPRIM temporary storage + key/value staging for qsmc_argsort
     size_t sort_tmp_cap;           // in bytes
+    unsigned int *tickets;         // device: arrival words of the reduction folded into the update kernel (QSMC_FOLD_REDUCE)
     double *tile_sums;             // sum of w' per update-kernel tile, written by the last qsmc_update_fused
     size_t tile_sums_cap;
     double *tile_prefix;           // monotone prefix of the unnormalised chunk sums (k_reduce_partials_scan) ...
@@ -375,6 +376,7 @@ static ReduceOut make_reduce(qsmc_ctx *h, bool want_host, double *stats4) {
     ro.tp_ntiles = 0;
     ro.prefix_gate = nullptr;
     ro.prefix_thresh = 0.0;
+    ro.tickets = nullptr;
     return ro;
 }
 
@@ -754,6 +756,8 @@ int qsmc_create(qsmc_handle_t *out, int device) {
     if (e == hipSuccess) e = hipMemset(h->counter, 0, 2 * sizeof(long long));
     if (e == hipSuccess) e = hipMalloc(&h->gbar, 4 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(h->gbar, 0, 4 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc(&h->tickets, 128 * sizeof(unsigned int));
+    if (e == hipSuccess) e = hipMemset(h->tickets, 0, 128 * sizeof(unsigned int));
     if (e == hipSuccess) e = hipMalloc(&h->spec.gate, sizeof(int));
     if (e == hipSuccess) e = hipMemset(h->spec.gate, 0, sizeof(int));
     h->spec.prof_slot = -1;
@@ -794,6 +798,7 @@ int qsmc_destroy(qsmc_handle_t h) {
     if (h->counter) (void)hipFree(h->counter);
     if (h->gbar) (void)hipFree(h->gbar);
     if (h->spec.gate) (void)hipFree(h->spec.gate);
+    if (h->tickets) (void)hipFree(h->tickets);
     if (h->iscratch) (void)hipFree(h->iscratch);
     if (h->anc16) (void)hipFree(h->anc16);
     if (h->lw_dev) (void)hipFree(h->lw_dev);
@@ -975,8 +980,16 @@ int qsmc_update_fused(qsmc_handle_t h, const qsmc_model_t *model, const double *
     ++h->ts.gen;
     h->ts.armed = 0;
     h->spec.launched = 0;
-    rc = setup_tile_prefix(h, ro, n, per_block, ns);
-    if (rc) return rc;
+    // the second level of the reduction inside the update kernel (its last workgroup), no reducing launch: the chunk-sum
+    // prefix that launch formed beside the reduction is then left to k_bucket_counts (which scans the tile sums itself
+    // when a resample is due: +6 us per resample against ~5 us per datum)
+    static const bool fold_env = getenv("QSMC_FOLD_REDUCE") != nullptr;                 // (A/B switch; off until measured)
+    const bool fold = fold_env && ns <= 17 && grid <= 2048 && (stats_host || moments_host);
+    if (fold) ro.tickets = h->tickets;
+    else {
+        rc = setup_tile_prefix(h, ro, n, per_block, ns);
+        if (rc) return rc;
+    }
     if (h->spec.enabled && ro.tile_sums && ro.failed_dst) {
         // the resampler's weight-only prefix goes out right behind the reduction, gated on the device-side ESS test
         ro.prefix_gate = h->spec.gate;
@@ -998,8 +1011,10 @@ int qsmc_update_fused(qsmc_handle_t h, const qsmc_model_t *model, const double *
 #undef LAUNCH_U
     }
     HIP_TRY(h, hipGetLastError());
-    rc = launch_reduce(h, ns, grid, ro, s);
-    if (rc) return rc;
+    if (!fold) {
+        rc = launch_reduce(h, ns, grid, ro, s);
+        if (rc) return rc;
+    }
     if (ro.prefix_gate) {
         rc = resample_prefix(h, w_out, n, 0.0, h->spec.n_out, h->spec.seed, h->spec.epoch, s, true);
         if (rc) return rc;
@@ -2091,8 +2106,13 @@ int qsmc_step(qsmc_handle_t h, qsmc_step_t *st, const qsmc_model_t *model, const
         hipLaunchKernelGGL(k_sum_partials, dim3((MFMA_MOM_K + QSMC_WAVES_PER_BLOCK - 1) / QSMC_WAVES_PER_BLOCK),
                            dim3(QSMC_BLOCK), 0, s, h->partials, gridm, MFMA_MOM_K, full);
         const unsigned long long seq = ++h->seq;
-        static const bool host_sqrt = getenv("QSMC_HOST_SQRT") != nullptr;               // (A/B switch: round 3's form)
-        device_sqrt = !host_sqrt;
+        // (round 4 built the device form -- kernels/sqrtm.hpp -- and measured it: the gap between the two sampler kernels
+        //  closes, but the one wavefront that forms S is latency-bound, ~90 rounds of three dependent LDS / fp64-division
+        //  steps sharing a SIMD with the ancestor kernel's own waves: k_bucket_anc16 36 -> 96 us, a d = 16 resample
+        //  +40 us, config-5 share 0.0727 -> 0.0742 ms/step.  The host's Jacobi (~25 us) runs WHILE the ancestor kernel
+        //  does and leaves a 10-25 us gap: it stays the default; QSMC_DEVICE_SQRT=1 selects the device form.)
+        static const bool dev_sqrt_env = getenv("QSMC_DEVICE_SQRT") != nullptr;
+        device_sqrt = dev_sqrt_env;
         h->ts.armed = h->ts.gen;                               // these weights ARE update number ts.gen's output
         if (device_sqrt) {
             // round 4: nothing of the resample waits for the host any more.  One wavefront riding in the ancestor kernel

@@ -1598,6 +1598,20 @@ def test_speculative_prefix_same_particles(qi, monkeypatch):
         np.testing.assert_array_equal(np.asarray(a.normalization_record), np.asarray(b.normalization_record))
 
 
+def test_device_sqrt_agrees_with_host():
+    """The d = 16 resample with its covariance square root formed on the device (QSMC_DEVICE_SQRT=1: one wavefront in the
+    ancestor kernel, kernels/sqrtm.hpp; the library reads the switch once per process, hence the subprocess): every square
+    root is confirmed bit for bit by the host's run of the same round-robin Jacobi, every queued resample adopted, and the
+    clouds equal those of the Python-side path (test_step_path_same_particles, run under the switch)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, QSMC_DEVICE_SQRT="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k",
+                        "test_step_path_same_particles"], capture_output=True, text=True, env=env, timeout=900,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "1 passed" in r.stdout, (r.stdout[-3000:], r.stderr[-2000:])
+
+
 def test_step_path_same_particles(qi, monkeypatch):
     """qsmc_step -- the fused update, the no-guard tail of `update` and (d <= 4, static cloud) the Liu-West resample
     queued from C the moment the n_ess test fails -- changes no number: bit-identical clouds, weights and records to the
@@ -1677,12 +1691,15 @@ def test_step_path_same_particles(qi, monkeypatch):
         assert q_b == 0 and ad_b == 0
         if queued:                                   # every resample was queued from C and adopted by the resampler's call
             assert q_a == a.resample_count and ad_a == a.resample_count, (name, q_a, ad_a, a.resample_count)
-        if name.startswith("tomography"):
-            # d = 16: mean / covariance / S = h sqrtm_psd(cov) were formed by a wavefront on the device (kernels/sqrtm.hpp)
-            # and every one of them was confirmed bit for bit by the host's run of the same routine -- and the clouds above
-            # equal the ones of the path on which the host's routine is the only one (utils.py:593-607)
+        if name.startswith("tomography") and os.environ.get("QSMC_DEVICE_SQRT"):
+            # d = 16 with QSMC_DEVICE_SQRT=1: mean / covariance / S = h sqrtm_psd(cov) were formed by a wavefront on the
+            # device (kernels/sqrtm.hpp) and every one of them was confirmed bit for bit by the host's run of the same
+            # routine -- and the clouds above equal the ones of the path on which the host's routine is the only one
+            # (utils.py:593-607).  test_device_sqrt_agrees_with_host runs this test that way.
             assert a._sqrt_stats == (a.resample_count, a.resample_count), (name, a._sqrt_stats, a.resample_count)
             assert b._sqrt_stats == (0, 0)
+        elif name.startswith("tomography"):
+            assert a._sqrt_stats == (0, 0) and b._sqrt_stats == (0, 0)
         elif queued is False:
             assert q_a == 0
     # the guards still fire from the step path, with the reference's messages (fixture G6 mirrors them for the old path)
