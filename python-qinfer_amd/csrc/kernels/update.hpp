@@ -32,8 +32,6 @@ struct ReduceOut {
     double *tile_prefix;                    // k_update_fused only (nullable): [tp_chunks + 1] monotone prefix of the UNNORMALISED
     int tp_chunks, tp_tpc;                  //   chunk sums, formed from tile_sums by a second workgroup of the reducing launch
     long long tp_ntiles;                    //   (k_reduce_partials_scan) while the first one reduces
-    unsigned int *tickets;                  // k_update_fused only (nullable): [0] groups that have arrived, [1 + g] workgroups of
-                                            //   group g (32 each) -- non-null folds the second level into the update kernel
 };
 
 // |sum w'| below this and the host renormalises by 1 instead (smc.py:369-370): no speculative prefix then
@@ -74,11 +72,14 @@ __device__ __forceinline__ void block_publish(double (&v)[NS], double mn, const 
 // stores 1.1 us (1.4 before the resampler's two counters were fetched ahead of the sweep); the system-scope fence before
 // the completion word 0.9 us (a bare s_waitcnt costs the same: it is the wait for the pinned-memory stores, not a cache
 // write-back); the rest is launch.  Doing this level inside the update kernel behind arrival tickets was measured in
-// round 1 (+11 us) and re-costed in round 2: every dependent global round trip is 1-2 us and that chain has more of them.
-template <int NS, int UNROLL_ = 0>
+// round 1 (+11 us), re-costed in round 2 (every dependent global round trip is 1-2 us and that chain has more of them) and
+// built again in round 4 with two-level tickets (tools/experiments/r4_reduction_folded_into_update.patch): with agent-scope
+// release fences every workgroup writes back its XCD's L2 (update kernel 39 -> 120 us); with the partials stored through the
+// caches and order-only fences the kernel grows by 5.4 us (ticket chain, a cold sweep of the rows, the publish -- serial at
+// its end) against 7-8 us of launch saved, and with the chunk prefix back in k_bucket_counts the step comes out 2-3 % slower.
+template <int NS>
 __device__ __forceinline__ void reduce_partials_body(int nblocks, const ReduceOut &ro) {
-    constexpr int THREADS = QSMC_BLOCK, WAVES = THREADS / QSMC_WAVE,
-                  UNROLL = UNROLL_ > 0 ? UNROLL_ : (NS <= 17 ? 4 : (NS <= 38 ? 2 : 1));
+    constexpr int THREADS = QSMC_BLOCK, WAVES = THREADS / QSMC_WAVE, UNROLL = NS <= 17 ? 4 : (NS <= 38 ? 2 : 1);
     __shared__ double lds[WAVES * (NS + 1)];
     __shared__ double tot[NS + 1];
     unsigned long long failed0 = 0ull, failed1 = 0ull;
@@ -363,36 +364,6 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_update_fused(
         }
     }
     block_publish<UpdAcc<DMOM>::NS>(acc.s, acc.mn, ro);
-    if (ro.tickets) {                            // uniform
-        // Round 4: the second level of the reduction by the LAST workgroup to finish, instead of a launch of its own
-        // (k_reduce_partials: 1.6 us of launch boundary + 5-6.6 us on the critical path of every datum).  Round 1 measured
-        // this form at +11 us with one arrival word for ~20 000 workgroups; here at most 2048 workgroups arrive in groups
-        // of 32 (one word per group, then one word for the groups: <= 32 + 64 arrivals on any one address).  The ticket is
-        // an agent-scope acq_rel read-modify-write: every partial written before it is visible to whoever draws the last
-        // ticket, which then sums the rows in index order exactly as the separate kernel does -- the same bits.
-        __shared__ int fold_last;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const unsigned int g = blockIdx.x >> 5, n_groups = (gridDim.x + 31u) >> 5;
-            const unsigned int in_group = (g + 1u < n_groups) ? 32u : gridDim.x - (g << 5);
-            int last = 0;
-            const unsigned int t = __hip_atomic_fetch_add(&ro.tickets[1 + g], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-            if (t == in_group - 1u) {
-                __hip_atomic_store(&ro.tickets[1 + g], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned int t2 = __hip_atomic_fetch_add(&ro.tickets[0], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-                if (t2 == n_groups - 1u) {
-                    __hip_atomic_store(&ro.tickets[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    last = 1;
-                }
-            }
-            fold_last = last;
-        }
-        __syncthreads();
-        if (fold_last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            reduce_partials_body<UpdAcc<DMOM>::NS, 2>((int)gridDim.x, ro);
-        }
-    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -64,7 +64,6 @@ struct qsmc_ctx {
     int cu_reported;               // what the device attribute says
     void *sort_tmp;                // rocPRIM temporary storage + key/value staging for qsmc_argsort
     size_t sort_tmp_cap;           // in bytes
-    unsigned int *tickets;         // device: arrival words of the reduction folded into the update kernel (QSMC_FOLD_REDUCE)
     double *tile_sums;             // sum of w' per update-kernel tile, written by the last qsmc_update_fused
     size_t tile_sums_cap;
     double *tile_prefix;           // monotone prefix of the unnormalised chunk sums (k_reduce_partials_scan) ...
@@ -376,7 +375,6 @@ static ReduceOut make_reduce(qsmc_ctx *h, bool want_host, double *stats4) {
     ro.tp_ntiles = 0;
     ro.prefix_gate = nullptr;
     ro.prefix_thresh = 0.0;
-    ro.tickets = nullptr;
     return ro;
 }
 
@@ -756,8 +754,6 @@ int qsmc_create(qsmc_handle_t *out, int device) {
     if (e == hipSuccess) e = hipMemset(h->counter, 0, 2 * sizeof(long long));
     if (e == hipSuccess) e = hipMalloc(&h->gbar, 4 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(h->gbar, 0, 4 * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMalloc(&h->tickets, 128 * sizeof(unsigned int));
-    if (e == hipSuccess) e = hipMemset(h->tickets, 0, 128 * sizeof(unsigned int));
     if (e == hipSuccess) e = hipMalloc(&h->spec.gate, sizeof(int));
     if (e == hipSuccess) e = hipMemset(h->spec.gate, 0, sizeof(int));
     h->spec.prof_slot = -1;
@@ -798,7 +794,6 @@ int qsmc_destroy(qsmc_handle_t h) {
     if (h->counter) (void)hipFree(h->counter);
     if (h->gbar) (void)hipFree(h->gbar);
     if (h->spec.gate) (void)hipFree(h->spec.gate);
-    if (h->tickets) (void)hipFree(h->tickets);
     if (h->iscratch) (void)hipFree(h->iscratch);
     if (h->anc16) (void)hipFree(h->anc16);
     if (h->lw_dev) (void)hipFree(h->lw_dev);
@@ -980,16 +975,8 @@ int qsmc_update_fused(qsmc_handle_t h, const qsmc_model_t *model, const double *
     ++h->ts.gen;
     h->ts.armed = 0;
     h->spec.launched = 0;
-    // the second level of the reduction inside the update kernel (its last workgroup), no reducing launch: the chunk-sum
-    // prefix that launch formed beside the reduction is then left to k_bucket_counts (which scans the tile sums itself
-    // when a resample is due: +6 us per resample against ~5 us per datum)
-    static const bool fold_env = getenv("QSMC_FOLD_REDUCE") != nullptr;                 // (A/B switch; off until measured)
-    const bool fold = fold_env && ns <= 17 && grid <= 2048 && (stats_host || moments_host);
-    if (fold) ro.tickets = h->tickets;
-    else {
-        rc = setup_tile_prefix(h, ro, n, per_block, ns);
-        if (rc) return rc;
-    }
+    rc = setup_tile_prefix(h, ro, n, per_block, ns);
+    if (rc) return rc;
     if (h->spec.enabled && ro.tile_sums && ro.failed_dst) {
         // the resampler's weight-only prefix goes out right behind the reduction, gated on the device-side ESS test
         ro.prefix_gate = h->spec.gate;
@@ -1011,10 +998,8 @@ int qsmc_update_fused(qsmc_handle_t h, const qsmc_model_t *model, const double *
 #undef LAUNCH_U
     }
     HIP_TRY(h, hipGetLastError());
-    if (!fold) {
-        rc = launch_reduce(h, ns, grid, ro, s);
-        if (rc) return rc;
-    }
+    rc = launch_reduce(h, ns, grid, ro, s);
+    if (rc) return rc;
     if (ro.prefix_gate) {
         rc = resample_prefix(h, w_out, n, 0.0, h->spec.n_out, h->spec.seed, h->spec.epoch, s, true);
         if (rc) return rc;
