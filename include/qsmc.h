@@ -197,8 +197,11 @@ typedef struct qsmc_step_lw {
     const double *canon_basis;   /*   device basis tensor (dense) or NULL (Pauli)                                         */
     int64_t  redraws_seen;       /* first tries of this cloud's LAST resample that failed postselection (maintained by    */
     int32_t  redraw_pending;     /*   qsmc_step: read back with the next update's sums while redraw_pending != 0; the      */
-    int32_t  reserved2;          /*   caller sets redraw_pending after a resample of its own, 0 / 0 after a reset): what  */
+                                 /*   caller sets redraw_pending after a resample of its own, 0 / 0 after a reset): what  */
                                  /*   the next resample is told to expect (qsmc_lw_expect_redraws)                         */
+    int32_t  adopt;              /* != 0: a resample queued by this call IS the caller's (it will not repeat the call to  */
+                                 /*   qsmc_lw_resample_philox; the flags it needs for the reference's warnings are in the */
+                                 /*   struct: cov, cov_lambda_min, S_err): counted as adopted at once                      */
 } qsmc_step_lw_t;
 typedef struct qsmc_step {
     /* the cloud -- kept current by the caller; w / w_alt / norm / sumsq / min_n_ess advance here on commit */
@@ -242,6 +245,10 @@ typedef struct qsmc_step {
     int64_t       plan_n_total;
     double        plan_tol;
     int64_t       plan_totals[QSMC_STEP_MAX_RANKS];
+    /* of a queued resample: the smallest eigenvalue of the covariance the square root was formed from (the Jacobi's own
+     * diagonal) -- the caller's positive-semidefiniteness check (distributions.py:392-399: la.eig(cov) >= 0) without a
+     * second eigendecomposition on the host while the GPU waits */
+    double        cov_lambda_min;
 } qsmc_step_t;
 int qsmc_step(qsmc_handle_t h, qsmc_step_t *st, const qsmc_model_t *model, const qsmc_expparam_t *exp,
               int64_t outcome, qsmc_stream_t stream);

@@ -36,7 +36,8 @@ constexpr int SQRTM_MAX_SWEEPS = 64;
 constexpr double SQRTM_OFF_TOL = 1e-34;
 
 // Host execution, n <= 64.  A row-major n x n; S_out = scale * sqrt(A); *err_out = || sqrt(A) sqrt(A) - A ||_F.
-static void sqrtm_psd_host(const double *A, int n, double scale, double *S_out, double *err_out) {
+static void sqrtm_psd_host(const double *A, int n, double scale, double *S_out, double *err_out,
+                           double *lambda_min_out = nullptr) {
     double a[64 * 64], v[64 * 64], sq[64 * 64];
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < n; ++j) {
@@ -88,6 +89,11 @@ static void sqrtm_psd_host(const double *A, int n, double scale, double *S_out, 
                 }
             }
         }
+    }
+    if (lambda_min_out) {
+        double mn = a[0];
+        for (int k = 1; k < n; ++k) mn = a[k * n + k] < mn ? a[k * n + k] : mn;
+        *lambda_min_out = mn;
     }
     // S = V sqrt(max(lambda, 0)) V^T
     for (int i = 0; i < n; ++i)

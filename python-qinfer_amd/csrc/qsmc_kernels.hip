@@ -2155,8 +2155,7 @@ int qsmc_step(qsmc_handle_t h, qsmc_step_t *st, const qsmc_model_t *model, const
     if (!finite) return QSMC_OK;                               // (the caller's own assertion fires)
     double cov_used[QSMC_MAX_D * QSMC_MAX_D];
     for (int k = 0; k < d * d; ++k) cov_used[k] = any ? st->cov[k] : ((k / d == k % d) ? st->lw.zero_cov_comp : 0.0);
-    rc = qsmc_sqrtm_psd(cov_used, d, st->lw.h, st->S, &st->S_err);
-    if (rc) return rc;
+    sqrtm_psd_host(cov_used, d, st->lw.h, st->S, &st->S_err, &st->cov_lambda_min);
     if (!std::isfinite(st->S_err)) return QSMC_OK;             // (ResamplerError is the caller's to raise)
     if (small_d) h->ts.armed = h->ts.gen;                      // these weights ARE update number ts.gen's output
     const double expect = small_d ? (double)st->lw.redraws_seen : 0.0;
@@ -2199,6 +2198,10 @@ int qsmc_step(qsmc_handle_t h, qsmc_step_t *st, const qsmc_model_t *model, const
     q.x_out = st->lw.x_out;
     q.stream = s;
     ++q.n_queued;
+    if (st->lw.adopt) {                                    // the caller takes the queued resample as its own, without a second call
+        ++q.n_adopted;
+        q.valid = 0;
+    }
     st->status |= QSMC_STEP_RESAMPLE_QUEUED;
     return QSMC_OK;
 }

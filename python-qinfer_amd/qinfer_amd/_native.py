@@ -39,7 +39,7 @@ class StepLW(C.Structure):
                 ("seed", C.c_uint64), ("epoch", C.c_uint64), ("n_out", C.c_int64),
                 ("x_out", C.c_void_p), ("ldx_out", C.c_int64),
                 ("canon_kind", C.c_int32), ("canon_allow_sub", C.c_int32), ("canon_basis", C.c_void_p),
-                ("redraws_seen", C.c_int64), ("redraw_pending", C.c_int32), ("reserved2", C.c_int32)]
+                ("redraws_seen", C.c_int64), ("redraw_pending", C.c_int32), ("adopt", C.c_int32)]
 
 
 STEP_MAX_RANKS = 64
@@ -68,7 +68,8 @@ class Step(C.Structure):
                 ("plan_enabled", C.c_int32), ("plan_stay", C.c_int32),
                 ("plan_seed", C.c_uint64), ("plan_epoch", C.c_uint64), ("plan_prefix_seed", C.c_uint64),
                 ("plan_n_total", C.c_int64), ("plan_tol", C.c_double),
-                ("plan_totals", C.c_int64 * STEP_MAX_RANKS)]
+                ("plan_totals", C.c_int64 * STEP_MAX_RANKS),
+                ("cov_lambda_min", C.c_double)]
 
 
 STEP_GUARD, STEP_SMALL_ESS, STEP_RESAMPLE_DUE, STEP_RESAMPLE_QUEUED, STEP_PLAN_READY, STEP_PREFIX_QUEUED = 1, 2, 4, 8, 16, 32

@@ -392,7 +392,7 @@ class ParticleDistribution(Distribution):
         return cls._cov_from_sums(s1, s2)
 
     @staticmethod
-    def _cov_from_sums(s1, s2):
+    def _cov_from_sums(s1, s2, psd_hint=None):
         if s2.shape == (1, 1):
             # one parameter: the same subtraction on plain floats (this is on the resample path of every d = 1 model)
             c = float(s2[0, 0]) - float(s1[0]) * float(s1[0])
@@ -405,7 +405,13 @@ class ParticleDistribution(Distribution):
         assert np.all(np.isfinite(cov))
         # (the reference asks the general solver, `la.eig(cov)[0] >= 0`; cov is exactly symmetric here, so the symmetric
         #  one answers the same question at a third of the time -- 15 us instead of 36-74 at d = 16, on every resample)
-        psd = (cov[0, 0] >= 0) if cov.shape == (1, 1) else np.linalg.eigvalsh(cov)[0] >= 0
+        if psd_hint is not None and psd_hint[0] == cov.tobytes():
+            # this very matrix went through the library's Jacobi a moment ago (a resample queued by qsmc_step): its smallest
+            # eigenvalue is known -- the eigendecomposition here (15 us warm, 100+ us on the cold caches of a resample
+            # step) would keep the GPU waiting for the next datum
+            psd = psd_hint[1] >= 0
+        else:
+            psd = (cov[0, 0] >= 0) if cov.shape == (1, 1) else np.linalg.eigvalsh(cov)[0] >= 0
         if not psd:
             warnings.warn('Numerical error in covariance estimation causing positive semidefinite '
                           'violation.', ApproximationWarning)
@@ -416,7 +422,8 @@ class ParticleDistribution(Distribution):
 
     def est_covariance_mtx(self, corr=False):
         _, s1, s2 = self._moments()
-        cov = self._cov_from_sums(s1, s2)
+        hint = self.__dict__.pop("_queued_psd", None)     # (SMCUpdater: qsmc_step's Jacobi already has the eigenvalues)
+        cov = self._cov_from_sums(s1, s2, hint)
         if corr:
             dstd = np.sqrt(np.diag(cov))
             cov = cov / np.outer(dstd, dstd)

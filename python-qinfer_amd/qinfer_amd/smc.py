@@ -29,6 +29,7 @@ __all__ = ["SMCUpdater"]
 _EPS = float(np.spacing(1))
 _NO_STEP = bool(__import__("os").environ.get("QSMC_NO_STEP"))      # (A/B switch: the round-2 per-datum path in Python)
 _NO_FUSED_CANON = bool(__import__("os").environ.get("QSMC_NO_FUSED_CANON"))      # (A/B switch)
+_NO_ADOPT = bool(__import__("os").environ.get("QSMC_NO_ADOPT"))      # (A/B switch: the resampler's own call re-derives a queued resample)
 _U64 = 2 ** 64 - 1
 
 
@@ -112,6 +113,11 @@ class SMCUpdater(ParticleDistribution):
             self._ep = _native.ExpParam()
             self._ep_ref = ctypes.byref(self._ep)
             self._ep_fill = getattr(model, "_native_fill_expparam", None)
+            # NumPy views of the struct's result arrays (no copy; a ctypes slice builds a Python list first: 256 floats
+            # per matrix, on the resample path of every d = 16 step while the GPU waits)
+            as_arr = np.ctypeslib.as_array
+            self._st_cov, self._st_S = as_arr(self._st.cov), as_arr(self._st.S)
+            self._st_mom, self._st_mom_big = as_arr(self._st.moments), as_arr(self._st.moments_big)
         self._step_synced = False
         self._x_spare = None
         # canonicalize after a resample (smc.py:529) done by the resample's own kernels where the library can
@@ -170,7 +176,7 @@ class SMCUpdater(ParticleDistribution):
             # left by the C per-datum path: the packed sums are still in the qsmc_step_t (the next update replaces
             # both them and this marker)
             d = self._x.shape[0]
-            raw = np.array(self._st.moments[:d + d * (d + 1) // 2])
+            raw = self._st_mom[:d + d * (d + 1) // 2].copy()
             c = self._moments_cache = ("packed", 1.0, raw, self._norm)
         if c is not None and len(c) == 4:
             # left by update(): the packed sums [sum w'x, upper(sum w'xx^T)] of the fused kernel and their
@@ -369,6 +375,7 @@ class SMCUpdater(ParticleDistribution):
                 st.plan_seed, st.plan_epoch = comm.seed & _U64, comm._epoch + 1
                 st.plan_prefix_seed = (r._seed + 0x9E3779B97F4A7C15 * (comm.rank + 1)) & _U64
                 st.plan_n_total, st.plan_tol = self.n_particles_global, float(comm.rebalance_tol)
+        lw.adopt = 0
         lw.prefix = int(key is not None)
         self._step_arms = self._eng.STEP_ARMED if key is not None else None
         lw.enabled = 0
@@ -387,6 +394,9 @@ class SMCUpdater(ParticleDistribution):
                 if self._x_spare is None or self._x_spare.shape != x.shape:
                     self._x_spare = self._eng.empty(d, n)
                 lw.enabled = 1
+                # ... and is taken as done without re-deriving it in Python (`_adopt_queued`): nothing but the stock
+                # resampler's own arithmetic stands between the n_ess test and the new cloud, and C has done exactly that
+                lw.adopt = int(not self._debug_resampling and not _NO_ADOPT)
                 lw.postselect, lw.maxiter = int(bool(r._postselect)), int(r._maxiter)
                 lw.a, lw.h, lw.zero_cov_comp = float(r._a), float(r._h), float(r._zero_cov_comp)
                 lw.x_out, lw.ldx_out = self._x_spare.data_ptr(), self._x_spare.stride(0)
@@ -442,7 +452,7 @@ class SMCUpdater(ParticleDistribution):
             # a guard is due: nothing was committed; the reference's own sequence, from the sums
             us = st.stats
             d = self._x.shape[0]
-            mom = np.array(st.moments[:d + d * (d + 1) // 2]) if d <= 4 else None
+            mom = self._st_mom[:d + d * (d + 1) // 2].copy() if d <= 4 else None
             self._step_synced = False
             if self._moments_cache is _FROM_STEP:
                 # the marker pointed at st.moments, which now hold the sums of this UNCOMMITTED update: should the policy
@@ -465,21 +475,65 @@ class SMCUpdater(ParticleDistribution):
             self._timestep(expparams)
         if status & (_native.STEP_SMALL_ESS | _native.STEP_RESAMPLE_DUE):
             queued = bool(status & _native.STEP_RESAMPLE_QUEUED)
+            if queued and st.lw.adopt:
+                return self._adopt_queued(status)
             if queued:
                 # the square root the library formed for the resample it queued: sqrtm_psd of exactly this matrix, by the
                 # routine the resampler is about to call -- handed over so that the host does not repeat it (40 us at
                 # d = 16) while the GPU is already sampling; the resampler takes it only for a bit-identical covariance
                 d = self._x.shape[0]
-                cov_c = np.array(st.cov[:d * d]).reshape(d, d)
+                cov_c = self._st_cov[:d * d].reshape(d, d)
+                cov_bytes = cov_c.tobytes()                   # (before any substitute: what est_covariance_mtx will form)
                 if not cov_c.any():
                     cov_c = st.lw.zero_cov_comp * np.eye(d)
-                self._queued_sqrt = (cov_c.tobytes(), st.lw.h, np.array(st.S[:d * d]).reshape(d, d), st.S_err)
+                self._queued_sqrt = (cov_c.tobytes(), st.lw.h, self._st_S[:d * d].reshape(d, d).copy(), st.S_err)
+                # the covariance's smallest eigenvalue came out of the same Jacobi: est_covariance_mtx's PSD check for
+                # exactly this matrix needs no second eigendecomposition (distributions._cov_from_sums)
+                self._queued_psd = (cov_bytes, st.cov_lambda_min)
             if queued and self._x.shape[0] > 4:
                 # the moments pass ran inside the call (its result drove the queued resample): what eng.moments returns
                 d = self._x.shape[0]
-                mb = np.array(st.moments_big[:1 + d + d * (d + 1) // 2])
+                mb = self._st_mom_big[:1 + d + d * (d + 1) // 2]
                 self._moments_cache = (float(mb[0]), mb[1:1 + d].copy(), eng._unpack_upper(mb[1 + d:], d))
             self._maybe_resample(np.float64(st.n_ess), queued)
+
+    def _adopt_queued(self, status):
+        """The resample qsmc_step queued IS this update's resample (smc.py:263-277 -> 491-551 with
+        resamplers.py:256-392 inside): mean, covariance, its zero-norm substitute, S = h sqrtm_psd(cov) and the sampler
+        call were made in C with the resampler's own parameters, into the spare cloud.  What is left here is what the
+        reference does around that arithmetic: its warnings (from the flags C left: n_ess, the covariance, its smallest
+        eigenvalue), the counters, the swap, canonicalize if the kernels did not fold it in, clear_cache.  Round 4: the
+        Python re-derivation this replaces (moments -> covariance -> eigvalsh -> the same call again, 120 us warm and
+        ~400 us on the cold caches of the first resample after a reset) kept the GPU idle after a d = 16 resample's
+        last kernel -- the "136 us after k_tomo_canon_list" of the round-3 traces."""
+        st, r = self._st, self.resampler
+        d, n = self._x.shape
+        if status & _native.STEP_SMALL_ESS:                          # smc.py:267-271
+            warnings.warn("Extremely small n_ess encountered ({}). Resampling is likely to fail. "
+                          "Consider adding particles, or resampling more often.".format(np.float64(st.n_ess)),
+                          ApproximationWarning)
+        self._just_resampled = True                                  # (update() cleared it: no 'without additional data')
+        self._resample_count += 1
+        if st.cov_lambda_min < 0:                                    # distributions.py:392-399, via est_covariance_mtx
+            warnings.warn('Numerical error in covariance estimation causing positive semidefinite '
+                          'violation.', ApproximationWarning)
+        if not self._st_cov[:d * d].any():                           # resamplers.py:283-290
+            warnings.warn("Covariance has zero norm; adding in small covariance in resampler. "
+                          "Consider increasing n_particles to improve covariance estimates.", ResamplerWarning)
+        # the resampler's own state moves on as if it had been called (its Philox epoch keys the draw C made)
+        r._epoch += 1
+        assert r._epoch == st.lw.epoch
+        r._pending_failed = self._eng                                # "failed to find valid models": at the next sync
+        self._x, self._x_spare = self._x_spare, self._x              # the new cloud; the old one is the next spare
+        self._w = self._w_alt = None                                 # uniform weights 1 / N, held implicitly
+        self._norm = self._sumsq = float(n)
+        self._invalidate()
+        if self._canonicalize and not st.lw.canon_kind:              # smc.py:529 (the d = 16 kernels fold it in)
+            self._canonicalize_device()
+        try:
+            self.model.clear_cache()
+        except Exception as e:  # noqa: BLE001  (reference demotes these to warnings, smc.py:533-536)
+            warnings.warn("Exception raised when clearing model cache: {}. Ignoring.".format(e))
 
     def update(self, outcome, expparams, check_for_resample=True):
         """One Bayes step (smc.py:388-457)."""
