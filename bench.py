@@ -207,7 +207,11 @@ def other_config_specs(qi):
     specs.append(dict(key="config5_share_tomography", model=m, n=1_250_000, d=16, prior=lambda: gin_cached, eps=eps, outs=outs,
                       workload="2-qubit TomographyModel (15 free params), 1.25e6 particles (1e7 / 8 GPUs), Ginibre prior, "
                                "random Pauli measurements",
-                      update_kernel="k_update_fused<TOMOGRAPHY,1,false>", sampler="k_bucket_anc16<512> + k_bucket_kick16"))
+                      update_kernel="k_update_tomo<NNZ=2,false>", sampler="k_bucket_anc16<512> + k_bucket_kick16",
+                      # a Pauli measurement (I + P) / 2 = e_0 + e_P has two nonzero entries: the likelihood reads w and those
+                      # two of the 16 rows, writes w' (the dense form, 16 + 8 d = 144 B, multiplies 14 rows by zero)
+                      update_bpp=32, update_note="sparse measurement vector: 16 + 8 nnz = 32 B per particle "
+                                                 "(dense form: 144 B; QSMC_TOMO_DENSE_UPDATE=1)"))
     # (not a BASELINE config, not in the default run: `--only extra_binomial_rb` -- the model simple_est_rb builds)
     m = qi.BinomialModel(qi.RandomizedBenchmarkingModel())
     eps, outs = [], []
@@ -282,8 +286,12 @@ def run_other_config(qi, eng, torch, spec, warmup, comm=None, n_override=None, s
                     "per_datum_collective": comm.transport_name, "rebalances": comm.n_rebalances - rb0,
                     "resample_path": getattr(comm, "last_resample_path", None)})
     if "update" in kt:
-        out["update_kernel"] = frac_entry(spec["update_kernel"], kt["update"]["avg_us"], (16 + 8 * d) * n,
-                                          kt["update"]["launches"], {"bytes_per_particle": 16 + 8 * d})
+        bpp = spec.get("update_bpp", 16 + 8 * d)
+        extra = {"bytes_per_particle": bpp}
+        if "update_note" in spec:
+            extra["note"] = spec["update_note"]
+        out["update_kernel"] = frac_entry(spec["update_kernel"], kt["update"]["avg_us"], bpp * n,
+                                          kt["update"]["launches"], extra)
     if "sample" in kt:
         if "ancestors" in kt:
             # d = 16: the sampler is two kernels (ancestors, then the kicks with canonicalize's classify pass folded in)

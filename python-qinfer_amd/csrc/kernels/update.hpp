@@ -367,6 +367,103 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_update_fused(
 }
 
 // ---------------------------------------------------------------------------------------------
+// Round 4: the tomography update reads the rows it needs.  TomographyModel.likelihood (tomography/models.py:211-226) is
+// pr1 = clip(sum_i meas_i x_i, 0, 1): a measurement vector with NNZ nonzero entries touches NNZ of the d = 16 rows --
+// and the measurements of a tomography experiment are sparse by construction: a Pauli measurement (I + P) / 2 is
+// e_0 + e_P in the Pauli basis (RandomPauliHeuristic, tomography/expdesign.py:134-160; SURVEY config 5): NNZ = 2.
+// k_update_fused<TOMOGRAPHY> loads all 16 rows (144 B per particle: 35 us at N = 1.25e6, 0.63 of the roofline) to
+// multiply 14 of them by zero; this kernel loads w and the NNZ rows (16 + 8 NNZ = 32 B per particle).  The skipped terms
+// are +-0 and x + (+-0) = x in IEEE arithmetic, so for finite particles the sum -- added in ascending i as before --
+// has the same bits (a NaN in a coordinate the measurement does not look at no longer poisons the weight; the
+// reference's 0 * NaN would).  The weighted moments of d > 4 are a pass of their own (k_moments_mfma), so nothing
+// else in the update wants the other rows.  Same tiles, tile sums and partials as k_update_fused: everything behind
+// it (reduction, chunk prefix, speculative counts, resample) is unchanged.  Full tiles issue all their loads first.
+// ---------------------------------------------------------------------------------------------
+template <int NNZ, bool ONES>
+__global__ __launch_bounds__(QSMC_BLOCK) void k_update_tomo(
+    const double *__restrict__ x, int64_t ldx, int64_t n, const double *__restrict__ w_in,
+    double *__restrict__ w_out, double prev_norm, ExpArgs e, int64_t outcome, ReduceOut ro) {
+    constexpr int64_t TILE = (int64_t)QSMC_BLOCK * 2 * UPD_UNROLL;
+    UpdAcc<0> acc;
+    acc.init();
+    const double inv_norm = 1.0 / prev_norm;
+    const double *row[NNZ];
+    double mv[NNZ];
+#pragma unroll
+    for (int j = 0; j < NNZ; ++j) {
+        row[j] = x + (int64_t)e.nz_idx[j] * ldx;
+        mv[j] = e.meas[e.nz_idx[j]];
+    }
+    auto lik = [&](const double *xs) -> double {
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < NNZ; ++j) s += mv[j] * xs[j];
+        const double pr1 = fmin(fmax(s, 0.0), 1.0);
+        return two_outcome(1.0 - pr1, outcome);
+    };
+    for (int64_t base = (int64_t)blockIdx.x * TILE; base < n; base += (int64_t)gridDim.x * TILE) {
+        double tsum = 0.0;
+        if (base + TILE <= n) {
+            double2 wi[UPD_UNROLL], xv[UPD_UNROLL][NNZ];
+#pragma unroll
+            for (int u = 0; u < UPD_UNROLL; ++u) {
+                const int64_t i = base + ((int64_t)u * QSMC_BLOCK + threadIdx.x) * 2;
+                if (ONES) { wi[u].x = 1.0; wi[u].y = 1.0; } else wi[u] = *reinterpret_cast<const double2 *>(w_in + i);
+#pragma unroll
+                for (int j = 0; j < NNZ; ++j) xv[u][j] = *reinterpret_cast<const double2 *>(row[j] + i);
+            }
+#pragma unroll
+            for (int u = 0; u < UPD_UNROLL; ++u) {
+                const int64_t i = base + ((int64_t)u * QSMC_BLOCK + threadIdx.x) * 2;
+                double a0[NNZ], a1[NNZ];
+#pragma unroll
+                for (int j = 0; j < NNZ; ++j) { a0[j] = xv[u][j].x; a1[j] = xv[u][j].y; }
+                double2 wo;
+                wo.x = (wi[u].x * inv_norm) * lik(a0);
+                wo.y = (wi[u].y * inv_norm) * lik(a1);
+                *reinterpret_cast<double2 *>(w_out + i) = wo;
+                acc.add(wo.x, nullptr);
+                acc.add(wo.y, nullptr);
+                tsum += wo.x + wo.y;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < UPD_UNROLL; ++u) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int64_t i = base + ((int64_t)u * QSMC_BLOCK + threadIdx.x) * 2 + h;
+                    if (i < n) {
+                        double a[NNZ];
+#pragma unroll
+                        for (int j = 0; j < NNZ; ++j) a[j] = row[j][i];
+                        const double wo = ((ONES ? 1.0 : w_in[i]) * inv_norm) * lik(a);
+                        w_out[i] = wo;
+                        acc.add(wo, nullptr);
+                        tsum += wo;
+                    }
+                }
+            }
+        }
+        if (ro.tile_sums) {                      // uniform
+            const double t = wave_sum(tsum);
+            if ((threadIdx.x & (QSMC_WAVE - 1)) == 0)
+                ro.tile_sums[(base / TILE) * QSMC_WAVES_PER_BLOCK + threadIdx.x / QSMC_WAVE] = t;
+        }
+    }
+    if (ro.tile_sums) {                          // (as in k_update_fused: zero the last chunk's missing tiles)
+        static_assert(4096 % TILE == 0, "tiles per chunk");
+        constexpr int64_t PER_CHUNK = 4096 / TILE * QSMC_WAVES_PER_BLOCK;
+        const int64_t last = (n - 1) / TILE;
+        if ((int64_t)blockIdx.x == last % (int64_t)gridDim.x) {
+            const int64_t first = (last + 1) * QSMC_WAVES_PER_BLOCK;
+            const int64_t end = (first + PER_CHUNK - 1) / PER_CHUNK * PER_CHUNK;
+            for (int64_t k = first + threadIdx.x; k < end; k += QSMC_BLOCK) ro.tile_sums[k] = 0.0;
+        }
+    }
+    block_publish<3>(acc.s, acc.mn, ro);
+}
+
+// ---------------------------------------------------------------------------------------------
 // K data in ONE pass (batch_update between two ESS checks, smc.py:459-487): the reference
 // renormalises after every datum, but the normaliser is a scalar, so
 //     w_K = w_0 * prod_k L_k / S_K,   S_k = sum_i w_0,i prod_{j<=k} L_j,i,

@@ -30,6 +30,8 @@ struct ExpArgs {
     int32_t d;
     double lik_pow;          // MLEModel: likelihood ** lik_pow (0 = plain)
     double meas[QSMC_MAX_D]; // tomography
+    int32_t nnz;             // tomography: how many entries of meas[0 .. d) are not zero, and which (ascending)
+    int32_t nz_idx[QSMC_MAX_D];
 };
 
 // ---------------------------------------------------------------------------------------------

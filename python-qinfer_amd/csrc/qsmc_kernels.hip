@@ -322,6 +322,9 @@ static int make_exp_args(const qsmc_model_t *model, const qsmc_expparam_t *ep, i
     out->d = model->d;
     out->lik_pow = (model->likelihood_power == 1.0) ? 0.0 : model->likelihood_power;
     for (int i = 0; i < QSMC_MAX_D; ++i) out->meas[i] = ep->meas[i];
+    if (model->kind == QSMC_MODEL_TOMOGRAPHY)
+        for (int i = 0; i < model->d && i < QSMC_MAX_D; ++i)
+            if (!(ep->meas[i] == 0.0)) out->nz_idx[out->nnz++] = i;          // (a NaN entry counts as present)
     out->comb = 1.0;
     out->log_comb = 0.0;
     if (model->kind == QSMC_MODEL_BINOMIAL_PRECESSION || model->kind == QSMC_MODEL_BINOMIAL_RB ||
@@ -994,7 +997,28 @@ int qsmc_update_fused(qsmc_handle_t h, const qsmc_model_t *model, const double *
         LAUNCH_U(QSMC_MODEL_BINOMIAL_RB)
         LAUNCH_U(QSMC_MODEL_BINOMIAL_RB_INTERLEAVED)
         LAUNCH_U(QSMC_MODEL_UNKNOWN_T2)
-        LAUNCH_U(QSMC_MODEL_TOMOGRAPHY)
+        case QSMC_MODEL_TOMOGRAPHY: {
+            // a measurement vector with at most four nonzero entries (a Pauli measurement has two): read those rows only
+            static const bool dense_env = getenv("QSMC_TOMO_DENSE_UPDATE") != nullptr;     // (A/B switch)
+            if (!dense_env && vec2 && ea.lik_pow == 0.0 && ea.nnz >= 1 && ea.nnz <= 4) {
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                prof_events(h, w_in ? QSMC_PROF_UPDATE : QSMC_PROF_UPDATE_ONES, &e0, &e1);
+#define LT(NZ)                                                                                                          \
+    case NZ:                                                                                                            \
+        if (w_in)                                                                                                       \
+            hipExtLaunchKernelGGL((k_update_tomo<NZ, false>), dim3(grid), dim3(QSMC_BLOCK), 0, s, e0, e1, 0, x, ldx, n, w_in, \
+                                  w_out, prev_norm, ea, outcome, ro);                                                   \
+        else                                                                                                            \
+            hipExtLaunchKernelGGL((k_update_tomo<NZ, true>), dim3(grid), dim3(QSMC_BLOCK), 0, s, e0, e1, 0, x, ldx, n, w_in,  \
+                                  w_out, prev_norm, ea, outcome, ro);                                                   \
+        break;
+                switch (ea.nnz) { LT(1) LT(2) LT(3) LT(4) }
+#undef LT
+            } else {
+                launch_update<QSMC_MODEL_TOMOGRAPHY>(h, vec2, grid, s, x, ldx, n, w_in, w_out, prev_norm, ea, outcome, ro);
+            }
+            break;
+        }
 #undef LAUNCH_U
     }
     HIP_TRY(h, hipGetLastError());
