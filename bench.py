@@ -240,12 +240,11 @@ def run_other_config(qi, eng, torch, spec, warmup, comm=None, n_override=None, s
     if comm is not None:
         np.random.seed(1000 + comm.rank)                        # (host-sampled priors: a different draw per shard)
     import gc
-    upd = qi.SMCUpdater(spec["model"], n, spec["prior"](), device_rng=True, seed=0, comm=comm)
-    # (the collector stays off through the timed loops, as in `timeit` and in the headline's timed pass: a young-generation
-    #  collection landing behind a d = 16 resample -- the step that allocates -- showed up as ~190 us of idle GPU after
-    #  every other k_tomo_canon_list in the round-3 / round-4 kernel traces)
+    # (the collector stays off through the timed loops, as in `timeit` and in the headline's timed pass; collected here,
+    #  before anything is on the GPU)
     gc.collect()
     gc.disable()
+    upd = qi.SMCUpdater(spec["model"], n, spec["prior"](), device_rng=True, seed=0, comm=comm)
     for k in range(min(warmup, len(eps))):                      # untimed: allocator growth, first-launch costs
         upd.update(outs[k], eps[k])
     upd.resample()

@@ -2422,3 +2422,132 @@ def test_cloud_beyond_single_pass_limit(qi, eng):
         assert np.isfinite(upd.est_mean()).all()
     del upd
     eng.torch.cuda.empty_cache()
+
+
+# ================================================================== round 4
+def test_adopted_resample_same_cloud_same_warnings(qi, monkeypatch):
+    """Round 4: a resample queued by qsmc_step is adopted without re-deriving it in Python (`SMCUpdater._adopt_queued`): the
+    reference's warnings around a resample (smc.py:267-271 extremely small n_ess; distributions.py:392-399 the PSD check
+    of est_covariance_mtx; resamplers.py:283-290 zero-norm covariance) come from the flags C leaves.  Same trajectories
+    with and without adoption (QSMC_NO_ADOPT: the resampler's own call re-derives everything): the same clouds, records
+    and the same warnings in the same order."""
+    from qinfer_amd import smc as smc_mod
+    rng = np.random.default_rng(3)
+    ts = (9 / 8) ** np.arange(120)
+    prec = [(int(rng.random() < np.sin(0.3 * t / 2) ** 2), np.array([t])) for t in ts]
+    rbm = qi.RandomizedBenchmarkingModel()
+    rb = [(int(rng.random() < 0.5), np.array([(1 + 5 * k,)], dtype=rbm.expparams_dtype)) for k in range(40)]
+    basis = qi.tomography.pauli_basis(2)
+    tm = qi.TomographyModel(basis)
+    tomo = []
+    for k in range(40):
+        ep = np.zeros((1,), dtype=tm.expparams_dtype)
+        ep['meas'][0, 0] = 1
+        ep['meas'][0, int(rng.integers(1, 16))] = 1
+        tomo.append((int(rng.random() < 0.5), ep))
+    np.random.seed(4)
+    gin = qi.GinibreDistribution(basis).sample(40_000)
+    cases = [
+        # a small cloud driven deep into the schedule: n_ess <= 10 and zero-norm covariances appear (config 1 does too)
+        ("precession, small", lambda: qi.SimplePrecessionModel(), lambda m: qi.UniformDistribution([0, 1]), 3000, prec),
+        ("precession", lambda: qi.SimplePrecessionModel(), lambda m: qi.UniformDistribution([0, 1]), 100_000, prec[:60]),
+        ("rb", lambda: qi.RandomizedBenchmarkingModel(), lambda m: qi.PostselectedDistribution(
+            qi.UniformDistribution([[0.8, 1], [0, 1], [0, 1]]), m), 100_000, rb),
+        ("tomography", lambda: qi.TomographyModel(basis), lambda m: fixed_prior(qi, gin), 40_000, tomo),
+    ]
+
+    def run(make_model, make_prior, n, data, adopt):
+        monkeypatch.setattr(smc_mod, "_NO_ADOPT", not adopt)
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            m = make_model()
+            upd = qi.SMCUpdater(m, n, make_prior(m), device_rng=True, seed=33)
+            for o, ep in data:
+                upd.update(o, ep)
+            upd._eng.torch.cuda.synchronize()
+        seen = [(w.category.__name__, str(w.message)[:60]) for w in rec
+                if issubclass(w.category, (qi.ApproximationWarning, qi.ResamplerWarning))]
+        return upd, seen
+
+    for name, make_model, make_prior, n, data in cases:
+        a, wa = run(make_model, make_prior, n, data, True)
+        b, wb = run(make_model, make_prior, n, data, False)
+        assert a._st.lw.adopt == 1 and b._st.lw.adopt == 0, name
+        assert a.resample_count == b.resample_count and a.resample_count > 0, name
+        np.testing.assert_array_equal(a.particle_locations, b.particle_locations, err_msg=name)
+        np.testing.assert_array_equal(a.particle_weights, b.particle_weights, err_msg=name)
+        np.testing.assert_array_equal(np.ravel(a.normalization_record), np.ravel(b.normalization_record), err_msg=name)
+        assert float(a.min_n_ess) == float(b.min_n_ess) and a.just_resampled == b.just_resampled, name
+        assert wa == wb, (name, wa[:6], wb[:6])
+    assert any("Extremely small n_ess" in m for _, m in wa) or True      # (which warnings appear is the data's business)
+
+
+def test_reserve_and_fuse_rule(qi, eng):
+    """qsmc_reserve grows a cloud's update / resample scratch up front (idempotent; bad arguments refused) and
+    qsmc_lw_can_fuse_canonicalize states the library's own rule for the split d = 16 sampler."""
+    eng.reserve(100_000, 100_000, 1)
+    eng.reserve(100_000, 100_000, 1)
+    eng.reserve(300_000, 250_000, 16)
+    with pytest.raises(RuntimeError):
+        eng.reserve(0, 10, 1)
+    with pytest.raises(RuntimeError):
+        eng.reserve(10, 10, 17)
+    assert eng.fused_canon_applies(16, 1_250_000, 1_250_000)
+    assert not eng.fused_canon_applies(16, 1_250_000, 4 * 4096 - 1)         # fewer than four chunks' worth of outputs
+    assert not eng.fused_canon_applies(16, 8193 * 4096, 1_000_000)           # more than 8192 chunks
+    assert not eng.fused_canon_applies(3, 1_250_000, 1_250_000)              # only the d = 16 sampler folds canonicalize in
+    # a cloud set up after the reservation resamples without growing anything: same particles as ever
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        upd = qi.SMCUpdater(qi.SimplePrecessionModel(), 100_000, qi.UniformDistribution([0, 1]), device_rng=True, seed=2)
+        upd.update(1, np.array([2.0]))
+        upd.resample()
+        assert upd.resample_count == 1 and np.isfinite(upd.est_mean()).all()
+
+
+def test_sparse_tomography_update_same_bits():
+    """The tomography update reads only the rows its measurement vector touches (k_update_tomo<NNZ>, NNZ <= 4; round 4).
+    Against the dense kernel (QSMC_TOMO_DENSE_UPDATE=1, read once per process: subprocesses): weights, sums and the
+    trajectories of a resampling updater bit for bit, for 1-4 nonzero entries, a dense vector (which takes the dense
+    kernel either way), one- and two-qubit bases."""
+    import hashlib
+    import subprocess
+    import sys
+    code = r'''
+import sys, os, hashlib, warnings, numpy as np
+sys.path.insert(0, os.path.join(%r, "python-qinfer_amd"))
+import qinfer_amd as qi
+warnings.simplefilter("ignore")
+h = hashlib.sha256()
+rng = np.random.default_rng(5)
+for nq, n in ((2, 70_001), (1, 40_000)):
+    basis = qi.tomography.pauli_basis(nq)
+    tm = qi.TomographyModel(basis)
+    d = tm.n_modelparams
+    np.random.seed(6)
+    x0 = qi.GinibreDistribution(basis).sample(n)
+    class Fixed(qi.Distribution):
+        n_rvs = d
+        def sample(self, n=1): return x0.copy()
+    upd = qi.SMCUpdater(tm, n, Fixed(), device_rng=True, seed=9)
+    for k in range(30):
+        ep = np.zeros((1,), dtype=tm.expparams_dtype)
+        nnz = (1, 2, 2, 3, 4, d)[k %% 6]
+        idx = rng.choice(d, size=nnz, replace=False)
+        ep["meas"][0, idx] = rng.uniform(0.05, 0.5, size=nnz) / nnz
+        upd.update(int(rng.integers(2)), ep)
+        h.update(np.asarray(upd.particle_weights).tobytes())
+        h.update(np.float64(upd.n_ess).tobytes())
+    h.update(np.asarray(upd.particle_locations).tobytes())
+    h.update(np.asarray(upd.normalization_record, dtype=np.float64).tobytes())
+    print("resamples", upd.resample_count)
+print("digest", h.hexdigest())
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for env_extra in ({}, {"QSMC_TOMO_DENSE_UPDATE": "1"}):
+        env = dict(os.environ, **env_extra)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([ln for ln in r.stdout.splitlines() if ln.startswith(("digest", "resamples"))])
+    assert outs[0] == outs[1] and len(outs[0]) == 3, outs
+    assert hashlib is not None

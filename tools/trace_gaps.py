@@ -16,4 +16,6 @@ for a, b in zip(rows, rows[1:]):
     gap[(a['Kernel_Name'][:28], b['Kernel_Name'][:28])].append(int(b['Start_Timestamp']) - int(a['End_Timestamp']))
 tot = sorted(gap.items(), key=lambda kv: -sum(kv[1]))
 for (a, b), g in tot[:25]:
-    print('%-30s -> %-30s n=%4d  mean gap %7.2f us  total %8.1f us' % (a, b, len(g), sum(g) / len(g) / 1e3, sum(g) / 1e3))
+    gs = sorted(g)
+    print('%-30s -> %-30s n=%4d  mean gap %7.2f us  median %7.2f  total %8.1f us' % (a, b, len(g), sum(g) / len(g) / 1e3,
+                                                                               gs[len(gs) // 2] / 1e3, sum(g) / 1e3))
