@@ -550,6 +550,9 @@ def main():
             # a launch that carries start/stop events drains the queue around itself (measured: 10.7 us per step
             # with every launch timed), so every `stride`-th launch of each kernel kind is timed
             eng.set_profiling(stride if (events and rep == 0) else 0)
+            # (in the timed region only the dominant kernel carries events -- the update, tags 0 and 2: what `roofline`
+            #  is made of; the sampler / counts figures come from the census right after, every launch timed)
+            eng.set_profiling_tags((0, 2) if (events and rep == 0 and world == 1 and comm is None) else None)
             barrier()
             t0 = time.perf_counter()
             k_steps(upd)
@@ -560,6 +563,7 @@ def main():
                 first_pass.append((upd.resample_count,) + tuple(eng.profile_read() if events else (np.zeros(0), np.zeros(0)))
                                   + (float(upd.est_mean()[0]),))
         gc.enable()
+        eng.set_profiling_tags(None)
         return walls[0], walls[1:]
 
     first_pass = []        # (resamples, kernel durations [ms], kernel tags, posterior mean) of each call's contract pass

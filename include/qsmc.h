@@ -102,6 +102,10 @@ int         qsmc_device_cus(qsmc_handle_t h, int32_t *usable_out, int32_t *repor
  * `enabled` = N > 1 times only every N-th launch of each tag: a launch that carries start/stop events
  * drains the queue around itself (~10 us per step at N = 1 in bench.py), a sampled average does not. */
 int         qsmc_set_profiling(qsmc_handle_t h, int enabled);
+/* Which tags (bit t = QSMC_PROF_* tag t) are timed while profiling is on; default: all.  bench.py's timed pass times the
+ * dominant kernel only (the update: tags 0 and 2) -- every other event pair there is queue drain that the roofline
+ * object does not need; the other kernels' durations come from the census pass right after it. */
+int         qsmc_set_profiling_tags(qsmc_handle_t h, uint32_t tag_mask);
 int         qsmc_last_update_kernel_ms(qsmc_handle_t h, float *ms_out);
 int         qsmc_profile_read(qsmc_handle_t h, float *ms_out, int32_t *tags_out, int32_t cap, int32_t *n_out);
 #define QSMC_PROF_UPDATE 0      /* k_update_fused, explicit weights (24 B/particle at d = 1) */

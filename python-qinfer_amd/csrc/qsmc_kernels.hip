@@ -151,6 +151,7 @@ struct qsmc_ctx {
     int prof_n;            // profiled launches since the last qsmc_profile_read / set_profiling
     unsigned char *prof_tag;   // which kernel each ring entry timed (QSMC_PROF_*)
     int prof_stride;           // time every prof_stride-th launch of a tag (events cost ~10 us of queue drain each)
+    unsigned prof_mask;        // tags that are timed at all (qsmc_set_profiling_tags; 0 = all)
     unsigned prof_seen[QSMC_PROF_NTAGS];     // launches seen per tag
     char hip_err[256];
 };
@@ -454,6 +455,7 @@ static int collect_stats(qsmc_ctx *h, int ns, qsmc_update_stats_t *stats_host, d
 // Next (start, stop) event pair of the profiling ring, or (null, null) when profiling is off.
 static void prof_events(qsmc_ctx *h, int tag, hipEvent_t *e0, hipEvent_t *e1) {
     if (!h->profiling || !h->prof_ev) return;
+    if (h->prof_mask && !(h->prof_mask & (1u << (tag & (QSMC_PROF_NTAGS - 1))))) return;
     if (h->prof_seen[tag & (QSMC_PROF_NTAGS - 1)]++ % (unsigned)h->prof_stride != 0) return;
     const int slot = h->prof_n % QSMC_PROF_CAP;         // a ring: beyond the capacity the oldest are overwritten
     *e0 = h->prof_ev[2 * slot];
@@ -837,6 +839,12 @@ int qsmc_set_profiling(qsmc_handle_t h, int enabled) {
     h->prof_stride = enabled > 1 ? enabled : 1;
     h->prof_n = 0;
     memset(h->prof_seen, 0, sizeof(h->prof_seen));
+    return QSMC_OK;
+}
+
+int qsmc_set_profiling_tags(qsmc_handle_t h, uint32_t tag_mask) {
+    if (!h) return QSMC_ERR_INVALID;
+    h->prof_mask = tag_mask;
     return QSMC_OK;
 }
 

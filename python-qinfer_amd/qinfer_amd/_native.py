@@ -86,6 +86,7 @@ SIGNATURES = {
     "qsmc_destroy": [_P],
     "qsmc_device_cus": [_P, C.POINTER(_I32), C.POINTER(_I32)],
     "qsmc_set_profiling": [_P, C.c_int],
+    "qsmc_set_profiling_tags": [_P, C.c_uint32],
     "qsmc_profile_read": [_P, C.POINTER(C.c_float), C.POINTER(_I32), _I32, C.POINTER(_I32)],
     "qsmc_last_update_kernel_ms": [_P, C.POINTER(C.c_float)],
     "qsmc_likelihood": [_P, C.POINTER(ModelDesc), _P, _I64, _I64, C.POINTER(ExpParam), _I32,

@@ -114,6 +114,11 @@ class Engine:
         """False/0: off; True/1: time every update / sampler launch; N > 1: every N-th launch of each kind."""
         self._chk(self.lib.qsmc_set_profiling(self.h, int(enabled)), "qsmc_set_profiling")
 
+    def set_profiling_tags(self, tags=None):
+        """Which kernel kinds carry events while profiling is on: an iterable of tag numbers, or None for all."""
+        mask = 0 if tags is None else sum(1 << int(t) for t in tags)
+        self._chk(self.lib.qsmc_set_profiling_tags(self.h, mask), "qsmc_set_profiling_tags")
+
     def profile_read(self, cap=4096):
         """(durations in ms, tags) of the timed kernels launched since profiling was enabled / last read,
         oldest first.  tag 0 = update kernel (explicit weights), 2 = update kernel (implicit weights),

@@ -2551,3 +2551,57 @@ print("digest", h.hexdigest())
         outs.append([ln for ln in r.stdout.splitlines() if ln.startswith(("digest", "resamples"))])
     assert outs[0] == outs[1] and len(outs[0]) == 3, outs
     assert hashlib is not None
+
+
+def test_design_chain_kernel_vs_lanes_kernel_edges():
+    """bayes_risk / expected_information_gain of binomial experiments through k_hyp_sums_chain (one exponential per
+    particle and pass, pmfs by recurrence; round 4) against k_hyp_sums_lanes (one exponential per particle and outcome;
+    QSMC_HYP_NO_CHAIN=1, read once per process: subprocesses), on clouds with the cases the walk folds into its start
+    value: pr1 exactly 0 (omega = 0), weights that are exactly 0, very small and very large pr1, and for n_meas from 1 to
+    100 (one to eight passes; the outcome n_meas alone in a pass).  Every entry of the per-outcome sums agrees to 1e-11 of
+    the experiment's largest entry (the walk's error is ~3 ulp per step; what a pass's first pmf loses to underflow is
+    below 1e-150 of the sums)."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, os, warnings, numpy as np
+sys.path.insert(0, os.path.join(%r, "python-qinfer_amd"))
+import qinfer_amd as qi
+warnings.simplefilter("ignore")
+rs = np.random.RandomState(11)
+n = 50_000
+x = rs.random_sample((n, 1))
+x[:50] = 0.0                        # cos^2(0) = 1: pr1 == 0 exactly
+x[50:100] = 1e-9                    # pr1 ~ 1e-17
+x[100:150] = np.pi / 3.0            # with t = 3: cos^2(pi / 2) ~ 4e-33, pr1 rounds to 1
+w = rs.random_sample(n)
+w[200:260] = 0.0
+w /= w.sum()
+class Fixed(qi.Distribution):
+    n_rvs = 1
+    def sample(self, n=1): return x.copy()
+m = qi.BinomialModel(qi.SimplePrecessionModel())
+upd = qi.SMCUpdater(m, n, Fixed())
+upd.particle_weights = w
+out = []
+for n_meas in (1, 2, 12, 13, 14, 25, 26, 40, 100):
+    ep = np.empty((3,), dtype=m.expparams_dtype)
+    ep["x"], ep["n_meas"] = [3.0, 0.7, 41.0], n_meas
+    for sums in upd._hyp_sums(ep):
+        out.append(np.asarray(sums).ravel())
+    out.append(np.asarray(upd.bayes_risk(ep)))
+    out.append(np.asarray(upd.expected_information_gain(ep)))
+np.save(sys.argv[1], np.concatenate(out))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import tempfile
+    res = []
+    with tempfile.TemporaryDirectory() as td:
+        for tag, env_extra in (("chain", {}), ("lanes", {"QSMC_HYP_NO_CHAIN": "1"})):
+            path = os.path.join(td, tag + ".npy")
+            r = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True,
+                               env=dict(os.environ, **env_extra), timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            res.append(np.load(path))
+    a, b = res
+    assert a.shape == b.shape and np.isfinite(b).all() and np.isfinite(a).all()
+    np.testing.assert_allclose(a, b, rtol=1e-10, atol=1e-11 * np.abs(b).max())
