@@ -1892,6 +1892,7 @@ __global__ __launch_bounds__(KICK16_BT) void k_bucket_kick16(
 // Held to 128 VGPRs (4 waves per SIMD): two workgroups fit a CU, so 256 are resident on half the CUs and two
 // processes sharing a GPU (as the tests do) both stay resident; the scan phase takes ~10 rounds instead of 19.
 constexpr int REDRAW_BLOCKS = 256;
+constexpr int REDRAW_SMALL_MAX = 8192;      // queued outputs up to which the redraw works chunk by chunk in LDS (no global CDF)
 template <int DM>     // particle dimension bound: 4 (registers) or QSMC_MAX_D
 __attribute__((amdgpu_waves_per_eu(4, 8)))
 __global__ __launch_bounds__(SCAN_THREADS) void k_bucket_redraw(
@@ -1899,11 +1900,81 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_bucket_redraw(
     const double *__restrict__ w, double inv_norm, const double *__restrict__ offsets, int64_t chunks, double *cdf,
     LWArgs lw, uint32_t k0, uint32_t k1, uint32_t epoch, int maxiter, double *__restrict__ x_out, OutPlace pl,
     const unsigned int *__restrict__ retry_list, const unsigned long long *__restrict__ retry_count,
-    unsigned long long *__restrict__ n_failed, unsigned long long *bar, int cdf_ready, int edges_in_lds) {
+    unsigned long long *__restrict__ n_failed, unsigned long long *bar, int cdf_ready, int edges_in_lds, int small_lds) {
     __shared__ double wave_tot[SCAN_WAVES];
     extern __shared__ __attribute__((aligned(16))) unsigned char redraw_smem[];
     const unsigned long long cnt = *retry_count;
     if (cnt == 0ull) return;
+    if (!cdf_ready && cnt <= (unsigned long long)REDRAW_SMALL_MAX && small_lds) {
+        // Round 4: a handful of queued outputs (precession's omega > 0 bites at a few early resamples: 2-3 % of config 2's,
+        // one in six of config 3's) used to cost the whole one-launch form -- every workgroup scanning its share of ALL
+        // chunks into the global CDF, 160 MB of traffic and a grid barrier, ~150 us, for a few hundred particles.  Here a
+        // workgroup takes one queued output at a time: the chunk its draw falls into (binary search of the offsets) is
+        // scanned into LDS by the same routine that fills the global CDF (chunk_scan_block: the same numbers), searched,
+        // kicked, tested; next round if invalid.  Same Philox blocks, same CDF entries, same particles as the global form.
+        double *lcdf = reinterpret_cast<double *>(redraw_smem);
+        __shared__ int s_j, s_ok;
+        unsigned long long failed_small = 0;
+        for (unsigned long long i = blockIdx.x; i < cnt; i += gridDim.x) {
+            const int64_t o = (int64_t)retry_list[i];
+            double p[DM];
+            bool ok = false;
+            for (int round = 1; round < maxiter && !ok; ++round) {          // (uniform over the workgroup)
+                PhiloxStream rng{(uint64_t)o, (epoch << 16) | (uint32_t)round, k0, k1};
+                double u0, unused;
+                rng.uniforms(0, u0, unused);
+                int64_t lo = 0, hi = chunks;                                 // #upper edges <= u0 = the chunk of the upper bound
+                while (lo < hi) {
+                    const int64_t mid = (lo + hi) >> 1;
+                    if (offsets[mid + 1] <= u0) lo = mid + 1; else hi = mid;
+                }
+                const int64_t c = lo > chunks - 1 ? chunks - 1 : lo;
+                __syncthreads();                                             // (lcdf / s_ok of the previous round are done with)
+                chunk_scan_block(w, n_in, inv_norm, offsets, c, wave_tot, StoreGlobal{lcdf});
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    const int64_t base = c * SCAN_CHUNK;
+                    const int64_t len = n_in - base < SCAN_CHUNK ? n_in - base : SCAN_CHUNK;
+                    int64_t l2 = 0, h2 = len;
+                    while (l2 < h2) {
+                        const int64_t mid = (l2 + h2) >> 1;
+                        if (lcdf[mid] <= u0) l2 = mid + 1; else h2 = mid;
+                    }
+                    const int64_t j = base + l2 < n_in - 1 ? base + l2 : n_in - 1;
+                    double zz[DM];
+#pragma unroll
+                    for (int q = 0; q < DM; q += 2) {
+                        if (q < d) {
+                            double z0, z1;
+                            rng.normals(1 + (q >> 1), z0, z1);
+                            zz[q] = z0;
+                            if (q + 1 < DM) zz[q + 1] = z1;
+                        }
+                    }
+#pragma unroll
+                    for (int m = 0; m < DM; ++m) {
+                        if (m < d) {
+                            double sm = 0.0;
+#pragma unroll
+                            for (int q = 0; q < DM; ++q)
+                                if (q < d) sm += lw.S[m * d + q] * zz[q];
+                            p[m] = (lw.a * x_in[m * ldx_in + j] + (1.0 - lw.a) * lw.mean[m]) + sm;
+                        }
+                    }
+                    s_ok = model_valid(kind, p, min_freq) ? 1 : 0;
+                }
+                __syncthreads();
+                ok = s_ok != 0;
+            }
+            if (threadIdx.x == 0) {
+                const int64_t row = place_row(pl, o);      // like the global form: the last round's value stays
+                for (int m = 0; m < d; ++m) x_out[m * pl.ld_m + row * pl.ld_s] = p[m];
+                if (!ok) ++failed_small;
+            }
+        }
+        if (threadIdx.x == 0 && failed_small) atomicAdd(n_failed, failed_small);
+        return;
+    }
     double *edges = edges_in_lds ? reinterpret_cast<double *>(redraw_smem) : nullptr;
     if (edges) {                                         // upper edge of every chunk (offsets[c + 1]); read after the
         for (int c = threadIdx.x; c < (int)chunks; c += SCAN_THREADS) edges[lds_skew(c)] = offsets[c + 1];   // scans' barriers

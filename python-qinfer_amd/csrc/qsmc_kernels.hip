@@ -1843,12 +1843,19 @@ static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int3
             // the chunk edges ride in LDS (first level of the redraw's ancestor search) while they fit 48 KB
             const size_t edges_lds = (size_t)(chunks64 + (chunks64 >> 5) + (chunks64 >> 10) + 4) * sizeof(double);      // (lds_skew)
             const int edges_in_lds = edges_lds <= 48 * 1024 ? 1 : 0;
+            // (few queued outputs: chunk by chunk in LDS, no global CDF -- needs room for one chunk's CDF in the dynamic
+            //  segment; QSMC_REDRAW_NO_SMALL keeps the global form for A/B)
+            static const bool no_small = getenv("QSMC_REDRAW_NO_SMALL") != nullptr;
+            const size_t small_bytes = (size_t)SCAN_CHUNK * sizeof(double);
+            size_t dyn = edges_in_lds ? edges_lds : 0;
+            const int small_lds = (!no_small && !expect_cdf) ? 1 : 0;
+            if (small_lds && dyn < small_bytes) dyn = small_bytes;
             hipLaunchKernelGGL((d <= 4 ? k_bucket_redraw<4> : k_bucket_redraw<QSMC_MAX_D>),
                                dim3(expect_cdf ? 1024 : redraw_blocks), dim3(SCAN_THREADS),
-                               edges_in_lds ? edges_lds : 0, s, model->kind, d,
+                               dyn, s, model->kind, d,
                                model->min_freq, x_in, ldx_in, n_in, w, inv_norm, offsets, chunks64, h->cdf_scratch, lw,
                                k0, k1, ep, maxiter, x_out, pl, redraw_list, redraw_count, nf, h->gbar + 2,
-                               expect_cdf ? 1 : 0, edges_in_lds);
+                               expect_cdf ? 1 : 0, edges_in_lds, small_lds);
         }
     }
     HIP_TRY(h, hipGetLastError());

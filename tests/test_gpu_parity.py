@@ -2605,3 +2605,52 @@ np.save(sys.argv[1], np.concatenate(out))
     a, b = res
     assert a.shape == b.shape and np.isfinite(b).all() and np.isfinite(a).all()
     np.testing.assert_allclose(a, b, rtol=1e-10, atol=1e-11 * np.abs(b).max())
+
+
+def test_small_redraw_queue_same_particles():
+    """A resample whose postselection queue holds only a few outputs (precession: omega > 0 bites at the early resamples)
+    redraws them chunk by chunk in LDS instead of materialising the global CDF (k_bucket_redraw's small form, round 4).
+    Same Philox blocks, same CDF entries: the clouds of whole trajectories are bit-identical to the global form
+    (QSMC_REDRAW_NO_SMALL=1, read once per process: subprocesses), for d = 1, the binomial model and RB without a bank."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, os, hashlib, warnings, numpy as np
+sys.path.insert(0, os.path.join(%r, "python-qinfer_amd"))
+import qinfer_amd as qi
+warnings.simplefilter("ignore")
+h = hashlib.sha256()
+rng = np.random.default_rng(12)
+redraws = 0
+# a wide prior against the omega > 0 wall and a generous kernel (a = 0.9): first tries fail at the early resamples
+for n, a in ((300_000, 0.9), (70_000, 0.98)):
+    upd = qi.SMCUpdater(qi.SimplePrecessionModel(), n, qi.UniformDistribution([0, 0.3]), device_rng=True, seed=4,
+                        resampler=qi.LiuWestResampler(a=a, device_rng=True, seed=4))
+    for k in range(40):
+        t = 1.3 ** k
+        upd.update(int(rng.random() < np.sin(0.02 * t / 2) ** 2), np.array([t]))
+        if upd.just_resampled:
+            upd._eng.torch.cuda.synchronize()
+            upd._eng.last_resample_failed(synchronize=True)
+            redraws += upd._eng.last_resample_redraws()
+    h.update(np.asarray(upd.particle_locations).tobytes()); h.update(np.asarray(upd.particle_weights).tobytes())
+    print("resamples", upd.resample_count)
+m = qi.RandomizedBenchmarkingModel()
+upd = qi.SMCUpdater(m, 60_000, qi.PostselectedDistribution(qi.UniformDistribution([[0.8, 1], [0, 1], [0, 1]]), m),
+                    device_rng=True, seed=2)
+upd._st.lw.enabled = 0
+for k in range(6):
+    upd.update(int(rng.random() < 0.5), np.array([(1 + 5 * k,)], dtype=m.expparams_dtype))
+h.update(np.asarray(upd.particle_locations).tobytes())
+print("redraws", redraws)
+print("digest", h.hexdigest())
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for env_extra in ({}, {"QSMC_REDRAW_NO_SMALL": "1"}):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **env_extra),
+                           timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([ln for ln in r.stdout.splitlines() if ln.startswith(("digest", "resamples", "redraws"))])
+    assert outs[0] == outs[1] and len(outs[0]) == 4, outs
+    n_redraws = int(outs[0][2].split()[1])
+    assert n_redraws > 0, outs[0]                       # (the queue was in use: the test saw the path it is about)
