@@ -476,7 +476,14 @@ class SMCUpdater(ParticleDistribution):
         if status & (_native.STEP_SMALL_ESS | _native.STEP_RESAMPLE_DUE):
             queued = bool(status & _native.STEP_RESAMPLE_QUEUED)
             if queued and st.lw.adopt:
-                return self._adopt_queued(status)
+                r, lw = self.resampler, st.lw
+                # (the struct was filled at the last _step_sync: a resampler whose parameters were edited in place since --
+                #  `upd.resampler.a = 0.9` -- must get ITS resample, so the queued one is taken only if it used them)
+                if (r._a == lw.a and r._h == lw.h and r._zero_cov_comp == lw.zero_cov_comp and r._epoch + 1 == lw.epoch
+                        and (r._seed & _U64) == lw.seed and int(bool(r._postselect)) == lw.postselect
+                        and int(r._maxiter) == lw.maxiter and r._default_n_particles in (None, lw.n_out)):
+                    return self._adopt_queued(status)
+                queued = False                        # the resampler's own call runs it again, with its parameters
             if queued:
                 # the square root the library formed for the resample it queued: sqrtm_psd of exactly this matrix, by the
                 # routine the resampler is about to call -- handed over so that the host does not repeat it (40 us at
