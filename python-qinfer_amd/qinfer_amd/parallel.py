@@ -76,7 +76,11 @@ class HostExchange:
         self._pay = np.ndarray((2, world, max_len), dtype=np.float64, buffer=self._shm.buf, offset=seq_bytes)
         import ctypes as _ct
         self._kc = _ct.c_uint64(0)        # the call counter, in memory qsmc_step can advance too (`_k` below)
-        # the same protocol in C (libqsmc_hip.so, host code) when the library is loadable; pure Python otherwise
+        # the same protocol in C (libqsmc_hip.so, host code) when the library is loadable.  The pure-Python form below is kept
+        # for the EXCHANGE only (it is what the protocol is specified by, and the CPU tests compare the two); a sharded
+        # updater as a whole needs the library regardless -- the resample plan is `qsmc_shard_plan_totals` (host code, no
+        # GPU needed), there is no NumPy mirror of it (round 3 moved the plan's stream into the library: totals for a given
+        # seed and epoch differ from round 2's `Generator(Philox).multinomial`)
         self._c_call, self._c_reduce, self._addr, self._anchor = None, None, None, None
         self._reduce_bufs = {}
         try:
