@@ -258,6 +258,30 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_update_fused(
                     for (int m = 0; m < D; ++m) xv[u][m] = *reinterpret_cast<const double2 *>(x + m * ldx + i);
                 }
             }
+            // Binomial(SimplePrecession), n_meas <= 64 (round 4): the two integer powers of the pmf for the tile's eight
+            // particles in ONE square-and-multiply loop -- eight independent chains inside each bit step instead of sixteen
+            // dependent loops one after the other (binom_pmf per particle: the update kernel of config 3 sat at 0.53 of the
+            // roofline with its VALUs a third busy).  Same multiplications per particle in the same order: same bits.
+            double Lb[2 * UPD_UNROLL];
+            bool batched = false;
+            if constexpr (KIND == QSMC_MODEL_BINOMIAL_PRECESSION && !POW) {
+                if (e.n_meas <= 64.0 && outcome >= 0 && (double)outcome <= e.n_meas) {       // (uniform)
+                    double pr[2 * UPD_UNROLL], qr[2 * UPD_UNROLL], pk[2 * UPD_UNROLL], qk[2 * UPD_UNROLL];
+#pragma unroll
+                    for (int u = 0; u < UPD_UNROLL; ++u) {
+                        pr[2 * u] = 1.0 - precession_pr0(xv[u][0].x, e);
+                        pr[2 * u + 1] = 1.0 - precession_pr0(xv[u][0].y, e);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 2 * UPD_UNROLL; ++q) qr[q] = 1.0 - pr[q];
+                    powi_uniform_n<2 * UPD_UNROLL>(pr, (unsigned)outcome, pk);
+                    powi_uniform_n<2 * UPD_UNROLL>(qr, (unsigned)(e.n_meas - (double)outcome), qk);
+#pragma unroll
+                    for (int q = 0; q < 2 * UPD_UNROLL; ++q)
+                        Lb[q] = (pr[q] >= 0.0 && pr[q] <= 1.0) ? (e.comb * pk[q]) * qk[q] : NAN;
+                    batched = true;
+                }
+            }
 #pragma unroll
             for (int u = 0; u < UPD_UNROLL; ++u) {
                 const int64_t i = base + ((int64_t)u * QSMC_BLOCK + threadIdx.x) * 2;
@@ -265,8 +289,8 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_update_fused(
 #pragma unroll
                 for (int m = 0; m < D; ++m) { p0[m] = xv[u][m].x; p1[m] = xv[u][m].y; }
                 double2 wo;
-                wo.x = (wi[u].x * inv_norm) * model_lik<KIND, POW>(p0, e, outcome);
-                wo.y = (wi[u].y * inv_norm) * model_lik<KIND, POW>(p1, e, outcome);
+                wo.x = (wi[u].x * inv_norm) * (batched ? Lb[2 * u] : model_lik<KIND, POW>(p0, e, outcome));
+                wo.y = (wi[u].y * inv_norm) * (batched ? Lb[2 * u + 1] : model_lik<KIND, POW>(p1, e, outcome));
                 if (nt) {
                     typedef double nt2 __attribute__((ext_vector_type(2)));
                     nt2 t;

@@ -195,6 +195,27 @@ __host__ __device__ __forceinline__ double powi_uniform(double x, unsigned k) {
     return r;
 }
 
+// The same for N values at once (one bit loop, N independent multiply chains inside it): per value the very multiplications
+// of powi_uniform in the same order -- the same bits -- but the N chains overlap instead of running one after the other
+// (a lane of the update kernel holds 8 particles of a tile; round 4).
+template <int N>
+__host__ __device__ __forceinline__ void powi_uniform_n(const double (&x)[N], unsigned k, double (&r)[N]) {
+    double b[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { r[i] = 1.0; b[i] = x[i]; }
+    while (k) {
+        if (k & 1u) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) r[i] *= b[i];
+        }
+        k >>= 1;
+        if (k) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) b[i] *= b[i];
+        }
+    }
+}
+
 // derived_models.py:317-325 + utils.py:106-111: Binom(n_meas, pr1).pmf(k), pr1 = L_underlying(outcome 1)
 __host__ __device__ __forceinline__ double binom_pmf(double pr1, const ExpArgs &e, int64_t o) {
     const double k = (double)o;
