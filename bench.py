@@ -684,10 +684,6 @@ def main():
                 out[key] = {"error": repr(e)}
         return out
 
-    sharded = None
-    if comm is not None and not args.no_other_configs:
-        sharded = sharded_configs(comm)
-
     def drain_c_stdio():
         # RCCL prints a version banner through C stdio, which (not a tty) would be flushed at exit -- after the
         # JSON line.  Push whatever C stdio holds to stderr so that the JSON line is the last line of stdout.
@@ -700,9 +696,10 @@ def main():
         os.close(saved)
     drain_c_stdio()
 
-    if rank == 0 and os.environ.get("QSMC_BENCH_NO_EVENTS"):
+    if os.environ.get("QSMC_BENCH_NO_EVENTS"):
         # diagnostic only (not the bench line): the same loop without the per-kernel events
-        print(json.dumps({"diagnostic": "no kernel events", "ms_per_step": wall / args.steps * 1e3}), flush=True)
+        if rank == 0:
+            print(json.dumps({"diagnostic": "no kernel events", "ms_per_step": wall / args.steps * 1e3}), flush=True)
         return
     if rank == 0:
         n_total = n * world
@@ -792,33 +789,49 @@ def main():
             line["transports"] = {key: {"per_datum_collective": comm.transport_name, "value": line["value"],
                                         "ms_per_step": line["ms_per_step"], "resamples": resamples_timed,
                                         "posterior_mean": posterior_mean, "headline": True}}
-            if sharded is not None:
-                line["sharded_configs"] = sharded
+        want_sharded = not args.no_other_configs
         want_rccl = ((world > 1 or os.environ.get("QSMC_BENCH_FORCE_RCCL_PASS")) and comm.transport != "rccl"
                      and not os.environ.get("QSMC_BENCH_NO_RCCL_PASS"))
+        # everything after the headline (the sharded configs 4 and 5, the RCCL pass) runs under a watchdog: a rank
+        # that hangs or a collective that never returns must not take the line with it.  Past the deadline rank 0
+        # prints the line with the time-out recorded against the stage that was running, and every rank leaves.
+        import threading
+        deadline = float(os.environ.get("QSMC_BENCH_DEADLINE", os.environ.get(
+            "QSMC_BENCH_RCCL_DEADLINE", "420" if want_sharded else "60")))
+        stage = {"name": "sharded_configs" if want_sharded else "rccl"}
+
+        def give_up():
+            if rank == 0:
+                msg = {"error": "no result within %.0f s of the headline (watchdog), stage: %s" % (deadline, stage["name"])}
+                if stage["name"] == "sharded_configs":
+                    line["sharded_configs"] = msg
+                elif stage["name"] == "sharded_configs_rccl":
+                    line["sharded_configs"]["rccl_transport"] = msg
+                else:
+                    line["transports"]["rccl"] = msg
+            emit()
+            os._exit(0)
+        if want_sharded or (want_rccl and not share_gpu):
+            watchdog = threading.Timer(deadline, give_up)
+            watchdog.daemon = True
+            watchdog.start()
+        sharded = None
+        if want_sharded:
+            sharded = sharded_configs(comm)
+            if rank == 0:
+                line["sharded_configs"] = sharded
+        stage["name"] = "rccl"
         if want_rccl and share_gpu:
             if rank == 0:
                 line["transports"]["rccl"] = {"skipped": "QSMC_BENCH_SHARE_GPU=1: every rank sits on device 0 (control-flow "
                                                          "check); an RCCL communicator needs one GPU per rank"}
         elif want_rccl:
-            # a collective that hangs must not take the line with it: past the deadline rank 0 prints the line with
-            # the time-out recorded and every rank leaves
-            import threading
-            deadline = float(os.environ.get("QSMC_BENCH_RCCL_DEADLINE", "60" if sharded is None else "240"))
-
-            def give_up():
-                if rank == 0:
-                    line["transports"]["rccl"] = {"error": "no result within %.0f s (watchdog)" % deadline}
-                emit()
-                os._exit(0)
-            watchdog = threading.Timer(deadline, give_up)
-            watchdog.daemon = True
-            watchdog.start()
             res = rccl_transport_pass()
             if rank == 0:
                 line["transports"]["rccl"] = res
             if sharded is not None and "error" not in res:
                 # configs 4 and 5 once more with the RCCL collective carrying the per-datum reduction
+                stage["name"] = "sharded_configs_rccl"
                 try:
                     from qinfer_amd.parallel import ParticleShardGroup
                     comm_r = ParticleShardGroup(transport="rccl")
@@ -832,6 +845,7 @@ def main():
                             line["sharded_configs"][k2]["rccl_transport"] = {
                                 kk: v2.get(kk) for kk in ("value", "ms_per_step", "resamples", "rebalances",
                                                           "per_datum_collective", "error") if kk in v2}
+        if watchdog is not None:
             watchdog.cancel()
     emit()
     if world > 1 or args.force_comm:

@@ -68,6 +68,18 @@ def test_launcherless_shared_gpu(n_ranks):
 
 
 @pytest.mark.gpu
+def test_headline_survives_a_stage_that_overruns():
+    """Whatever runs after the headline's timed region (sharded configs 4/5, the RCCL pass) sits under a watchdog: with
+    a deadline no sharded config can meet, the line still goes out -- headline intact, the overrun recorded -- and
+    every rank exits 0."""
+    r = _run_bench(["--gpus", "2"] + SHARDED, {"QSMC_BENCH_SHARE_GPU": "1", "QSMC_BENCH_DEADLINE": "0.2"})
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    line = _one_json_line(r.stdout)
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["transports"]["shm"]["headline"]
+    assert "watchdog" in line["sharded_configs"]["error"] and "sharded_configs" in line["sharded_configs"]["error"]
+
+
+@pytest.mark.gpu
 def test_driver_command_headline_is_steady_state():
     """The driver's own command, in a fresh process: `python bench.py --gpus 1 --steps 20 --warmup 5` (what the reference's
     harness times is this loop: perf_testing.py:250-251).  The 20 timed steps (3 resamples) must cost what the same 20
