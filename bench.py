@@ -815,6 +815,31 @@ def main():
             watchdog = threading.Timer(deadline, give_up)
             watchdog.daemon = True
             watchdog.start()
+        if world > 1:
+            # a rank that DIES in one of these stages makes the launcher SIGTERM the others: rank 0 still prints the
+            # line (headline intact, the stage marked) before it goes.  The C-level handler writes to a pipe whichever
+            # thread takes the signal; the watcher thread runs even while the main thread sits in a C call.
+            import signal
+            rfd, wfd = os.pipe()
+            os.set_blocking(wfd, False)
+            signal.signal(signal.SIGTERM, lambda *a: None)
+            signal.set_wakeup_fd(wfd, warn_on_full_buffer=False)
+
+            def on_sigterm():
+                os.read(rfd, 1)
+                if rank == 0 and not done["printed"]:
+                    msg = {"error": "terminated by the launcher (another rank failed), stage: %s" % stage["name"]}
+                    if stage["name"] == "sharded_configs":
+                        line["sharded_configs"] = msg
+                    elif stage["name"] == "sharded_configs_rccl":
+                        line["sharded_configs"]["rccl_transport"] = msg
+                    else:
+                        line["transports"]["rccl"] = msg
+                    emit()
+                os._exit(1)
+            threading.Thread(target=on_sigterm, daemon=True).start()
+            if os.environ.get("QSMC_BENCH_TEST_DIE_RANK") == str(rank):      # (tests/test_bench_launch.py only)
+                os.kill(os.getpid(), signal.SIGKILL)
         sharded = None
         if want_sharded:
             sharded = sharded_configs(comm)

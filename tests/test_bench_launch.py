@@ -80,6 +80,17 @@ def test_headline_survives_a_stage_that_overruns():
 
 
 @pytest.mark.gpu
+def test_headline_survives_a_rank_that_dies():
+    """A rank killed after the headline's timed region (here: rank 1, by the test hook) makes the launcher terminate the
+    others; rank 0 prints the line on its way out -- headline intact, the stage the job was in marked."""
+    r = _run_bench(["--gpus", "2"] + SHARDED, {"QSMC_BENCH_SHARE_GPU": "1", "QSMC_BENCH_TEST_DIE_RANK": "1"})
+    assert r.returncode != 0
+    line = _one_json_line(r.stdout)
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["transports"]["shm"]["headline"]
+    assert "another rank failed" in line["sharded_configs"]["error"]
+
+
+@pytest.mark.gpu
 def test_driver_command_headline_is_steady_state():
     """The driver's own command, in a fresh process: `python bench.py --gpus 1 --steps 20 --warmup 5` (what the reference's
     harness times is this loop: perf_testing.py:250-251).  The 20 timed steps (3 resamples) must cost what the same 20
