@@ -382,13 +382,16 @@ def other_paths(qi, eng, torch, n=10_000_000):
          "ms_per_experiment": wall / 4 * 1e3, "hypothetical_likelihoods_per_s": 26 * 4 * n / wall,
          "risk": [float(v) for v in risk]}
     if "hyp_sums" in kt:
-        passes = kt["hyp_sums"]["launches"] // 4          # (launches per experiment: 26 outcomes = two passes of 13)
-        e["kernel"] = frac_entry("k_hyp_sums_chain<BINOMIAL_PRECESSION>", kt["hyp_sums"]["avg_us"], 16.0 * n,
+        passes = kt["hyp_sums"]["launches"] // 4          # (launches per experiment: 26 outcomes = one two-ended pass of 13 + 13)
+        e["kernel"] = frac_entry("k_hyp_sums_chain2<BINOMIAL_PRECESSION,MOMENTS,13>", kt["hyp_sums"]["avg_us"], 16.0 * n,
                                  kt["hyp_sums"]["launches"],
-                                 {"bytes_per_particle": 16, "outcomes_per_pass": 13, "passes_per_experiment": passes,
+                                 {"bytes_per_particle": 16, "outcomes_per_pass": 26 // max(passes, 1), "passes_per_experiment": passes,
                                   "kernel_us_per_experiment": kt["hyp_sums"]["avg_us"] * passes,
-                                  "note": "VALU-bound (80 % VALU-busy, profiles/r4_a_paths_sq_counters.json): one pmf by "
-                                          "exponential + 12 by recurrence and 13 x 4 running sums per particle per pass"})
+                                  "note": "VALU-bound (~260 instructions per particle and pass, two waves per SIMD: "
+                                          "profiles/r4_c_paths_sq_counters.json): cos^2, two integer powers and one reciprocal per "
+                                          "particle, then a geometric walk from both ends of the outcome range -- 1 multiply + 1 add "
+                                          "+ 2 multiply-adds per (particle, outcome), 78 running sums; binomial coefficients applied "
+                                          "on the host; the four experiments' passes queue back to back behind one wait"})
     out["bayes_risk_26_outcomes"] = e
     del upd
     torch.cuda.empty_cache()

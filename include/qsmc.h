@@ -285,6 +285,21 @@ int qsmc_hypothetical_sums(qsmc_handle_t h, const qsmc_model_t *model,
                            const qsmc_expparam_t *exp, const int64_t *outcomes, int32_t n_o,
                            const double *shift, double *out_host, qsmc_stream_t stream);
 
+/* The same for n_e experiments in one call, with the caller saying which columns it will read -- bayes_risk
+ * (smc.py:553-611) uses [0] and the moment columns, expected_information_gain (smc.py:613-663) [0] and [1]: `what` =
+ * QSMC_HYP_LOG | QSMC_HYP_MOMENTS bits; column [0] is always formed.  Experiment e has n_o[e] outcomes; `outcomes` holds
+ * them one experiment after the other and out_host the rows in the same order (sum n_o rows of 2 + 2 d, or 2).  For
+ * binomial experiments over consecutive outcomes the columns not asked for are not computed (no logarithm per particle
+ * for the moments; no moments for the logarithm) and come back as NaN, and the experiments' passes are queued back to
+ * back with ONE wait at the end; other models form every column whatever `what` says, an experiment at a time.
+ * qsmc_hypothetical_sums is this call with n_e = 1 and both bits set.  Synchronises. */
+#define QSMC_HYP_LOG 1
+#define QSMC_HYP_MOMENTS 2
+int qsmc_hypothetical_sums_multi(qsmc_handle_t h, const qsmc_model_t *model,
+                                 const double *x, int64_t ldx, int64_t n, const double *w, double norm,
+                                 const qsmc_expparam_t *exps, int32_t n_e, const int64_t *outcomes, const int32_t *n_o,
+                                 const double *shift, int32_t what, double *out_host, qsmc_stream_t stream);
+
 /* Same update for a model without a native kernel: L[i] was produced by the user's
  * Model.likelihood on the host and uploaded (plugin slow path). */
 int qsmc_update_from_likelihood(qsmc_handle_t h, const double *L, int64_t n,

@@ -845,6 +845,182 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_hyp_sums_chain(const double *__r
     block_publish<NS>(s, 0.0, ro);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Round 4b: the walk from BOTH ends of a pass, with the binomial coefficients taken out of the kernel.
+// ISA of k_hyp_sums_chain (tools/isa_count.sh): ~20 VALU instructions per (particle, outcome) in the walk -- every
+// `s += wl * c` is a multiply and an add (the library is built without contraction: the update path must match NumPy
+// operation for operation; these sums are held to rtol 1e-10, not to bits), the pr1 == 1 select is four v_cndmask per
+// outcome, the per-outcome uniforms (ln C, the ratios) and the uniform `j < n_o` guards spill SGPRs to VGPR lanes --
+// and ~200 per particle and pass for two logarithms and an exponential that bayes_risk never uses.  Here:
+//   * every sum is linear in the pmf, and pmf(k) = C(n, k) p^k q^(n - k): the kernel walks the GEOMETRIC sequence
+//     v_j = pmf(k_ref) (p / q)^j -- one multiplication per step, no per-outcome operand -- and the host multiplies
+//     the finished sums of slot j by C(n, k_ref + j) / C(n, k_ref) (Chain2Plan::scale);  ln pmf = ln C + t_j with
+//     t_j = n ln q + k_j (ln p - ln q) a running sum, so sum w pmf ln pmf = scale * sum v t + ln C * sum w pmf: the
+//     ln C term is added on the host as well;
+//   * a pass takes its outcomes from both ends: slots 0 .. n_up - 1 upwards from k_first with p / q, the others
+//     downwards from k_last with q / p.  pr1 == 0 (all mass at k = 0) and pr1 == 1 (all at k = n) are then ordinary
+//     starts -- the odds are set to 0 where they would be infinite -- and nothing is selected inside the walk; an
+//     invalid particle (pr1 outside [0, 1] or NaN) starts from NaN and stays there (weight 0: from 0), like SciPy's pmf;
+//   * WHAT says which sums the caller uses: bayes_risk the moments (no logarithm at all; the start values are integer
+//     powers for n_meas <= 64, as in binom_pmf), expected_information_gain sum w L ln L (no moments), the C ABI's
+//     qsmc_hypothetical_sums both;  2 NH slots x PER sums each are the registers a lane holds;
+//   * explicit fma for the sums; slots past the pass's outcomes cost their instructions but no branch (their sums are
+//     dropped on the host).
+// Per (particle, outcome): 1 multiplication + 1 addition + 2 D multiply-adds (moments) / + 1 addition + 1 multiply-add
+// (logarithm).  A half pass is <= 13 steps, so what an underflowing start value loses is < 1e-140 of sums that are O(1).
+// ---------------------------------------------------------------------------------------------
+constexpr int HYP_WHAT_LOG = 1, HYP_WHAT_MOM = 2;
+#ifndef CHAIN2_UNROLL
+#define CHAIN2_UNROLL 1
+#endif
+struct Chain2Args {
+    ExpArgs base;
+    int n_up, n_dn;                // slots walked upwards from k_first / downwards from k_last (>= 1 / >= 0)
+    int use_powi;                  // start values by integer powers (n_meas <= 64), else exp(ln pmf)
+    unsigned k_first, k_last;
+    double comb_first, comb_last;  // C(n, k_first), C(n, k_last)       (use_powi)
+    double lc_first, lc_last;      // their logarithms                  (!use_powi)
+    double shift[QSMC_MAX_D];
+};
+
+template <int KIND, int WHAT, int NH>
+constexpr int chain2_sums() {              // running sums per lane
+    return 2 * NH * (1 + ((WHAT & HYP_WHAT_LOG) ? 1 : 0) + (((WHAT & HYP_WHAT_MOM) && Model<KIND>::D <= 4) ? 2 * Model<KIND>::D : 0));
+}
+
+// (registers: two per running sum + ~50: three waves per SIMD = 168 VGPRs up to 58 sums, else two.  Measured and not kept:
+//  a particle on a lane PAIR, each lane with one of the two walks -- 39 sums a lane and four waves per SIMD for the
+//  26-outcome moments pass, VALU-busy 50 -> 65 %, but everything before the walk is then computed twice and that is more
+//  than half of a particle's ~260 instructions: 140 -> 174 us;  two or three particles per lane and trip: 139 -> 141 / 144 us)
+template <int KIND, int WHAT, int NH>
+__attribute__((amdgpu_waves_per_eu(chain2_sums<KIND, WHAT, NH>() <= 58 ? 3 : 2, 4)))
+__global__ __launch_bounds__(QSMC_BLOCK) void k_hyp_sums_chain2(const double *__restrict__ x, int64_t ldx, int64_t n,
+                                                                const double *__restrict__ w, double norm,
+                                                                Chain2Args ca, ReduceOut ro) {
+    constexpr bool LOG = (WHAT & HYP_WHAT_LOG) != 0, MOM = (WHAT & HYP_WHAT_MOM) != 0;
+    constexpr int D = (MOM && Model<KIND>::D <= 4) ? Model<KIND>::D : 0;
+    constexpr int DD = Model<KIND>::D;
+    constexpr int PER = 1 + (LOG ? 1 : 0) + 2 * D;           // [S0, (St), S1[D], S2[D]]
+    constexpr int NS = 2 * NH * PER;
+    double s[NS];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) s[q] = 0.0;
+    const double n_meas = ca.base.n_meas;
+    const double inv_norm = 1.0 / norm;
+    const double kf = (double)ca.k_first, kl = (double)ca.k_last;
+    // U particles per lane and trip (i, i + stride, ...): at two or three waves per SIMD the serial parts of a particle --
+    // the range reduction and polynomial of cos^2, the square-and-multiply powers, a division -- leave the SIMD idle
+    // between dependent instructions, and one 16-byte prefetch per lane is ~2 MB in flight over the chip, a third of what
+    // the memory system needs; the U particles' chains interleave and their prefetches double up (138 -> see DESIGN 3.7)
+    constexpr int U = CHAIN2_UNROLL;
+    const int64_t stride = (int64_t)gridDim.x * QSMC_BLOCK;
+    int64_t i = (int64_t)blockIdx.x * QSMC_BLOCK + threadIdx.x;
+    double pn[U][DD], wn[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t iu = i + u * stride;
+        wn[u] = 0.0;
+#pragma unroll
+        for (int m = 0; m < DD; ++m) pn[u][m] = 0.5;
+        if (iu < n) {
+#pragma unroll
+            for (int m = 0; m < DD; ++m) pn[u][m] = x[m * ldx + iu];
+            wn[u] = w ? w[iu] : 1.0;
+        }
+    }
+    for (; i < n; i += U * stride) {
+        double p[U][DD], wi[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int m = 0; m < DD; ++m) p[u][m] = pn[u][m];
+            wi[u] = wn[u] * inv_norm;
+            const int64_t iu = i + (U + u) * stride;
+            if (iu < n) {
+#pragma unroll
+                for (int m = 0; m < DD; ++m) pn[u][m] = x[m * ldx + iu];
+                wn[u] = w ? w[iu] : 1.0;
+            } else {
+                wn[u] = 0.0;                                  // (a slot past the end: weight 0 on the last valid coordinates)
+            }
+        }
+        double c1[U][D > 0 ? D : 1], c2[U][D > 0 ? D : 1];
+        double cu[U], cd[U], step[U], istep[U], tu[U], td[U], dl[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int m = 0; m < D; ++m) {
+                c1[u][m] = p[u][m] - ca.shift[m];
+                c2[u][m] = c1[u][m] * c1[u][m];
+            }
+            const double pr1 = hyp_pr1<KIND>(p[u], ca.base);
+            const double qr1 = 1.0 - pr1;
+            const bool valid = pr1 >= 0.0 && pr1 <= 1.0;
+            // odds p / q and q / p for the two walks from ONE reciprocal, 1 / (p q) (seed + two Newton steps, ~2 ulp: a walk
+            // of 12 steps stays inside 1e-14; two IEEE divisions were 28 of a particle's ~260 instructions); 0 where a walk
+            // starts on all of the mass or on none and must stay at 0 -- p or q exactly 0, and p below 1e-290, where every
+            // pmf but pmf(0) is below 1e-290 itself (q is >= 1.1e-16 or 0)
+            const double pq = pr1 * qr1;
+            const bool odds = valid && pq > 1.0e-290;
+            double rc = __builtin_amdgcn_rcp(odds ? pq : 1.0);
+            rc = fma(fma(-pq, rc, 1.0), rc, rc);
+            rc = fma(fma(-pq, rc, 1.0), rc, rc);
+            step[u] = odds ? pr1 * (pr1 * rc) : 0.0;
+            istep[u] = odds ? qr1 * (qr1 * rc) : 0.0;
+            double lp = 0.0, lq = 0.0;
+            if (LOG || !ca.use_powi) {                        // (the second condition is uniform)
+                lp = (valid && pr1 > 0.0) ? fast_log(pr1) : 0.0;
+                lq = (valid && pr1 < 1.0) ? fast_log1m(pr1) : 0.0;
+            }
+            dl[u] = lp - lq;
+            tu[u] = n_meas * lq + kf * dl[u];                 // ln pmf - ln C at the two starts
+            td[u] = n_meas * lq + kl * dl[u];
+            double su0, sd0;
+            if (ca.use_powi) {
+                su0 = (ca.comb_first * powi_uniform(pr1, ca.k_first)) * powi_uniform(qr1, (unsigned)n_meas - ca.k_first);
+                sd0 = (ca.comb_last * powi_uniform(pr1, ca.k_last)) * powi_uniform(qr1, (unsigned)n_meas - ca.k_last);
+            } else {
+                const bool inside = pr1 > 0.0 && pr1 < 1.0;
+                const double edge_u = pr1 == 0.0 ? (kf == 0.0 ? 1.0 : 0.0) : (kf == n_meas ? 1.0 : 0.0);
+                const double edge_d = pr1 == 0.0 ? (kl == 0.0 ? 1.0 : 0.0) : (kl == n_meas ? 1.0 : 0.0);
+                su0 = inside ? fast_exp(ca.lc_first + tu[u]) : edge_u;
+                sd0 = inside ? fast_exp(ca.lc_last + td[u]) : edge_d;
+            }
+            const double bad = wi[u] == 0.0 ? 0.0 : NAN;
+            cu[u] = valid ? wi[u] * su0 : bad;
+            cd[u] = valid ? wi[u] * sd0 : bad;
+        }
+        constexpr int B1 = 1 + (LOG ? 1 : 0);
+        {
+#pragma unroll
+            for (int j = 0; j < NH; ++j) {
+                double *a = s + j * PER, *b = s + (NH + j) * PER;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    a[0] += cu[u];
+                    b[0] += cd[u];
+                    if (LOG) {
+                        a[1] = fma(cu[u], tu[u], a[1]);
+                        b[1] = fma(cd[u], td[u], b[1]);
+                        tu[u] += dl[u];
+                        td[u] -= dl[u];
+                    }
+#pragma unroll
+                    for (int m = 0; m < D; ++m) {
+                        a[B1 + m] = fma(cu[u], c1[u][m], a[B1 + m]);
+                        a[B1 + D + m] = fma(cu[u], c2[u][m], a[B1 + D + m]);
+                        b[B1 + m] = fma(cd[u], c1[u][m], b[B1 + m]);
+                        b[B1 + D + m] = fma(cd[u], c2[u][m], b[B1 + D + m]);
+                    }
+                    cu[u] *= step[u];
+                    cd[u] *= istep[u];
+                }
+            }
+        }
+    }
+    block_publish<NS>(s, 0.0, ro);
+}
+
 // mode 0: w_out = (w_in / norm) * L   (generic-model slow path)
 // mode 1: w_out = clip(w_in / norm, 0, 1)   (negative-weight guard)
 // mode 2: w_out = w_in / norm               (materialise; stats still produced)

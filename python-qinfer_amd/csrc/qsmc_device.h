@@ -401,6 +401,21 @@ template <> struct HypPre<QSMC_MODEL_BINOMIAL_RB_INTERLEAVED> : HypPreBinomial {
     }
 };
 
+// pr1 alone (the same expressions as HypPre<KIND>::prepare), for the design kernel that needs no logarithm of it
+template <int KIND> __host__ __device__ __forceinline__ double hyp_pr1(const double *p, const ExpArgs &e);
+template <> __host__ __device__ __forceinline__ double hyp_pr1<QSMC_MODEL_BINOMIAL_PRECESSION>(const double *p, const ExpArgs &e) {
+    return 1.0 - precession_pr0(p[0], e);
+}
+template <> __host__ __device__ __forceinline__ double hyp_pr1<QSMC_MODEL_BINOMIAL_RB>(const double *p, const ExpArgs &e) {
+    const double pr0 = 1.0 - (p[1] * rb_pow(p[0], e.m) + p[2]);
+    return 1.0 - pr0;
+}
+template <> __host__ __device__ __forceinline__ double hyp_pr1<QSMC_MODEL_BINOMIAL_RB_INTERLEAVED>(const double *p, const ExpArgs &e) {
+    const double pe = e.reference ? p[1] : p[0] * p[1];
+    const double pr0 = 1.0 - (p[2] * rb_pow(pe, e.m) + p[3]);
+    return 1.0 - pr0;
+}
+
 // Runtime-dispatched validity (used by kernels that are not templated on the model).
 __host__ __device__ __forceinline__ bool model_valid(int kind, const double *p, double min_freq) {
     switch (kind) {

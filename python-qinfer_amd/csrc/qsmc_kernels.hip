@@ -641,10 +641,150 @@ static int hyp_launch_chain(qsmc_ctx *h, const qsmc_model_t *model, const double
     return QSMC_OK;
 }
 
+// binomial models, consecutive outcomes, round 4b: the geometric walk from both ends of the pass (k_hyp_sums_chain2);
+// the binomial coefficients and the ln C term of sum w L ln L are applied on the host, to the finished sums.
+// Two halves, so that the passes of SEVERAL experiments queue back to back and the host waits once (bayes_risk over a
+// design: per experiment ~15 us of launch + publish + completion-word round trip and the caller's own per-call work
+// otherwise sit between the kernels): chain2_enqueue launches a pass and publishes its sums to a slot of the pinned
+// block; chain2_collect, after the wait, turns a slot into the caller's rows.
+constexpr int CHAIN2_MAX_SLOTS = 2 * 13;
+constexpr int CHAIN2_PENDING_MAX = 12;             // passes in flight: 12 x 78 doubles <= the pinned block's 1024
+struct Chain2Pending {
+    int off;                       // first double of the pass's sums in h->mapped_big
+    int n_o, n_up, nh, per, what, d_out;
+    double nm;
+    int64_t outcomes[CHAIN2_MAX_SLOTS];
+    double lc[CHAIN2_MAX_SLOTS];
+    double *out;                   // the pass's rows of the caller's array
+};
+
+template <int KIND, int WHAT, int NH>
+static int chain2_enqueue(qsmc_ctx *h, const qsmc_model_t *model, const double *x, int64_t ldx, int64_t n,
+                          const double *w, double norm, const qsmc_expparam_t *exp, const int64_t *outcomes, int n_o,
+                          const double *shift, double *out_host, int off, Chain2Pending *pend, hipStream_t s) {
+    constexpr bool LOG = (WHAT & HYP_WHAT_LOG) != 0, MOM = (WHAT & HYP_WHAT_MOM) != 0;
+    constexpr int DO = Model<KIND>::D <= 4 ? Model<KIND>::D : 0;       // the caller's row: [N, SL, S1[DO], S2[DO]]
+    constexpr int D = MOM ? DO : 0;
+    constexpr int PER = 1 + (LOG ? 1 : 0) + 2 * D;
+    constexpr int NS = 2 * NH * PER;
+    static_assert(NS <= 512 && 2 * NH <= CHAIN2_MAX_SLOTS, "the pinned block of the wide sums holds 512 doubles a pass");
+    if (n_o < 1 || n_o > 2 * NH || off < 0 || off + NS > SQRT_MAPPED_DOUBLES) return QSMC_ERR_INVALID;
+    // one resident round, as for k_hyp_sums_chain: the NS wave reductions at a workgroup's end are worth a few particles
+    static const int per_cu = [] {
+        int b = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_hyp_sums_chain2<KIND, WHAT, NH>, QSMC_BLOCK, 0) != hipSuccess || b < 1) b = 2;
+        return b > 8 ? 8 : b;
+    }();
+    int grid = grid_for(n, QSMC_BLOCK * 4);
+    if (grid > per_cu * h->cu_count) grid = per_cu * h->cu_count;
+    int rc = ensure_partials(h, (size_t)grid * (NS + 1));
+    if (rc) return rc;
+    rc = ensure_scratch(h, 256 + 512);
+    if (rc) return rc;
+    Chain2Args ca;
+    memset(&ca, 0, sizeof(ca));
+    make_exp_args(model, exp, outcomes[0], &ca.base);
+    ca.n_up = (n_o + 1) / 2;
+    ca.n_dn = n_o - ca.n_up;
+    ca.use_powi = exp->n_meas <= 64 ? 1 : 0;
+    ca.k_first = (unsigned)outcomes[0];
+    ca.k_last = (unsigned)outcomes[n_o - 1];
+    pend->off = off;
+    pend->n_o = n_o;
+    pend->n_up = ca.n_up;
+    pend->nh = NH;
+    pend->per = PER;
+    pend->what = WHAT;
+    pend->d_out = DO;
+    pend->nm = (double)exp->n_meas;
+    pend->out = out_host;
+    for (int j = 0; j < n_o; ++j) {
+        ExpArgs tmp;
+        make_exp_args(model, exp, outcomes[j], &tmp);
+        pend->outcomes[j] = outcomes[j];
+        pend->lc[j] = tmp.log_comb;
+        if (j == 0) { ca.comb_first = tmp.comb; ca.lc_first = tmp.log_comb; }
+        if (j == n_o - 1) { ca.comb_last = tmp.comb; ca.lc_last = tmp.log_comb; }
+    }
+    if (shift) for (int m = 0; m < model->d && m < QSMC_MAX_D; ++m) ca.shift[m] = shift[m];
+    ReduceOut ro;
+    memset(&ro, 0, sizeof(ro));
+    ro.partials = h->partials;
+    hipEvent_t he0 = nullptr, he1 = nullptr;
+    prof_events(h, QSMC_PROF_HYP_SUMS, &he0, &he1);
+    hipExtLaunchKernelGGL((k_hyp_sums_chain2<KIND, WHAT, NH>), dim3(grid), dim3(QSMC_BLOCK), 0, s, he0, he1, 0, x, ldx, n, w, norm, ca, ro);
+    double *full = h->scratch + 256;
+    hipLaunchKernelGGL(k_sum_columns, dim3((NS + QSMC_WAVES_PER_BLOCK - 1) / QSMC_WAVES_PER_BLOCK), dim3(QSMC_BLOCK), 0, s,
+                       h->partials, grid, NS, full);
+    const unsigned long long seq = ++h->seq;           // (the completion word steps through the passes; the host waits for the last)
+    hipLaunchKernelGGL(k_publish_big, dim3(1), dim3(QSMC_BLOCK), 0, s, full, NS, h->mapped_big_dev + off, h->flag_dev, seq);
+    HIP_TRY(h, hipGetLastError());
+    return QSMC_OK;
+}
+
+// slot -> outcome, C(n, k) / C(n, k_start) by the ratios of neighbouring coefficients, ln C for the entropy term
+static void chain2_collect(const qsmc_ctx *h, const Chain2Pending &pd) {
+    const bool LOG = (pd.what & HYP_WHAT_LOG) != 0, MOM = (pd.what & HYP_WHAT_MOM) != 0;
+    const int DO = pd.d_out, D = MOM ? DO : 0, PER_OUT = 2 + 2 * DO, B1 = 1 + (LOG ? 1 : 0);
+    const double *sums = h->mapped_big + pd.off;
+    double scale = 1.0;
+    for (int j = 0; j < pd.n_o; ++j) {
+        const bool up = j < pd.n_up;
+        const int o = up ? j : pd.n_o - 1 - (j - pd.n_up);               // index into this pass's outcomes
+        const int slot = up ? j : pd.nh + (j - pd.n_up);
+        if (j == 0 || j == pd.n_up) scale = 1.0;
+        const double *v = sums + (size_t)slot * pd.per;
+        double *row = pd.out + (size_t)o * PER_OUT;
+        for (int q = 0; q < PER_OUT; ++q) row[q] = NAN;                  // what the caller did not ask for
+        row[0] = scale * v[0];
+        if (LOG) row[1] = scale * v[1] + pd.lc[o] * row[0];
+        for (int m = 0; m < D; ++m) {
+            row[2 + m] = scale * v[B1 + m];
+            row[2 + DO + m] = scale * v[B1 + D + m];
+        }
+        const double k = (double)pd.outcomes[o];
+        scale *= up ? (pd.nm - k) / (k + 1.0) : k / (pd.nm - k + 1.0);   // to the next slot of this walk
+    }
+}
+
+struct Chain2Queue {
+    Chain2Pending pend[CHAIN2_PENDING_MAX];
+    int count = 0, off = 0;
+};
+
+static int chain2_flush(qsmc_ctx *h, Chain2Queue &q, hipStream_t s) {
+    if (q.count == 0) return QSMC_OK;
+    const int rc = wait_reduction(h, s);               // (the last pass queued holds h->seq)
+    if (rc) return rc;
+    for (int i = 0; i < q.count; ++i) chain2_collect(h, q.pend[i]);
+    q.count = 0;
+    q.off = 0;
+    return QSMC_OK;
+}
+
+template <int KIND, int WHAT, int NH>
+static int chain2_go(qsmc_ctx *h, Chain2Queue &q, const qsmc_model_t *model, const double *x, int64_t ldx, int64_t n,
+                     const double *w, double norm, const qsmc_expparam_t *exp, const int64_t *outcomes, int n_o,
+                     const double *shift, double *out_host, hipStream_t s) {
+    constexpr int NS = chain2_sums<KIND, WHAT, NH>();
+    if (q.count == CHAIN2_PENDING_MAX || q.off + NS > SQRT_MAPPED_DOUBLES) {
+        const int rc = chain2_flush(h, q, s);
+        if (rc) return rc;
+    }
+    const int rc = chain2_enqueue<KIND, WHAT, NH>(h, model, x, ldx, n, w, norm, exp, outcomes, n_o, shift, out_host, q.off,
+                                                  &q.pend[q.count], s);
+    if (rc) return rc;
+    q.count += 1;
+    q.off += NS;
+    return QSMC_OK;
+}
+
+// One experiment.  Passes of the two-ended walk are left in `q` (the caller flushes it); every other path flushes `q`
+// first and returns with its rows filled.
 template <int KIND>
-static int hyp_dispatch(qsmc_ctx *h, const qsmc_model_t *model, const double *x, int64_t ldx, int64_t n,
+static int hyp_dispatch(qsmc_ctx *h, Chain2Queue &q, const qsmc_model_t *model, const double *x, int64_t ldx, int64_t n,
                         const double *w, double norm, const qsmc_expparam_t *exp, const int64_t *outcomes,
-                        int n_o, const double *shift, double *out_host, hipStream_t s) {
+                        int n_o, const double *shift, double *out_host, hipStream_t s, int what) {
     // outcome lists longer than 32 (binomial with n_meas > 31) are processed in groups
     constexpr int D = Model<KIND>::D <= 4 ? Model<KIND>::D : 0;
     constexpr int PER = 2 + 2 * D;
@@ -666,18 +806,38 @@ static int hyp_dispatch(qsmc_ctx *h, const qsmc_model_t *model, const double *x,
                        (uint64_t)outcomes[n_o - 1] <= exp->n_meas;
     for (int o = 1; o < n_o && consecutive; ++o) consecutive = outcomes[o] == outcomes[0] + o;
     constexpr int CHAIN_NO = CHAIN_SUMS / PER;
-    const int chain_passes = (n_o + CHAIN_NO - 1) / CHAIN_NO;
+    static const bool chain1 = getenv("QSMC_HYP_CHAIN1") != nullptr;                 // (A/B switch: round 4's one-ended walk)
+    what &= HYP_WHAT_LOG | HYP_WHAT_MOM;
+    if (what == 0 || D == 0) what |= HYP_WHAT_LOG;
+    // slots per pass of the two-ended walk: 2 NH, NH from the registers the sums take (2 NH x PER doubles: ~56 for three
+    // waves per SIMD; the moments at D = 1 take 78 -- a 26-outcome experiment in ONE pass at two waves per SIMD, 138 us,
+    // against two passes of 13 at three waves, 216 us)
+    constexpr int NH_LOG = 13, NH_MOM = D <= 1 ? 13 : (D <= 3 ? 4 : 3), NH_ALL = D <= 1 ? 7 : (D <= 3 ? 4 : 3);
+    const int chain_slots = chain1 ? CHAIN_NO : 2 * (what == HYP_WHAT_LOG ? NH_LOG : (what == HYP_WHAT_MOM ? NH_MOM : NH_ALL));
+    const int chain_passes = (n_o + chain_slots - 1) / chain_slots;
     const int chain_take = (n_o + chain_passes - 1) / chain_passes;
     while (done < n_o) {
         const int m = n_o - done;
         int take, rc;
         if (consecutive) {
             take = m < chain_take ? m : chain_take;
-            if constexpr (BINOMIAL)
-                rc = hyp_launch_chain<KIND>(h, model, x, ldx, n, w, norm, exp, outcomes + done, take, shift,
-                                            out_host + (size_t)done * PER, s);
-            else
+            if constexpr (BINOMIAL) {
+                const int64_t *oc = outcomes + done;
+                double *oh = out_host + (size_t)done * PER;
+                if (chain1) {
+                    rc = chain2_flush(h, q, s);
+                    if (!rc) rc = hyp_launch_chain<KIND>(h, model, x, ldx, n, w, norm, exp, oc, take, shift, oh, s);
+                }
+                else if (what == HYP_WHAT_LOG)
+                    rc = chain2_go<KIND, HYP_WHAT_LOG, NH_LOG>(h, q, model, x, ldx, n, w, norm, exp, oc, take, shift, oh, s);
+                else if (what == HYP_WHAT_MOM)
+                    rc = chain2_go<KIND, HYP_WHAT_MOM, NH_MOM>(h, q, model, x, ldx, n, w, norm, exp, oc, take, shift, oh, s);
+                else
+                    rc = chain2_go<KIND, HYP_WHAT_LOG | HYP_WHAT_MOM, NH_ALL>(h, q, model, x, ldx, n, w, norm, exp, oc, take, shift, oh, s);
+            } else
                 rc = QSMC_ERR_INVALID;
+        } else if ((rc = chain2_flush(h, q, s)) != QSMC_OK) {
+            return rc;
         } else if (BINOMIAL && WIDE && m > 8 && !no_lanes && model->likelihood_power == 0.0) {
             take = m < 32 ? m : 32;
             if constexpr (BINOMIAL && WIDE)
@@ -1139,23 +1299,47 @@ int qsmc_update_multi(qsmc_handle_t h, const qsmc_model_t *model, const double *
 int qsmc_hypothetical_sums(qsmc_handle_t h, const qsmc_model_t *model, const double *x, int64_t ldx, int64_t n,
                            const double *w, double norm, const qsmc_expparam_t *exp, const int64_t *outcomes,
                            int32_t n_o, const double *shift, double *out_host, qsmc_stream_t stream) {
-    if (!h || !x || !exp || !outcomes || !out_host || n <= 0 || n_o < 1) return QSMC_ERR_INVALID;
+    return qsmc_hypothetical_sums_multi(h, model, x, ldx, n, w, norm, exp, 1, outcomes, &n_o, shift,
+                                        QSMC_HYP_LOG | QSMC_HYP_MOMENTS, out_host, stream);
+}
+
+int qsmc_hypothetical_sums_multi(qsmc_handle_t h, const qsmc_model_t *model, const double *x, int64_t ldx, int64_t n,
+                                 const double *w, double norm, const qsmc_expparam_t *exps, int32_t n_e,
+                                 const int64_t *outcomes, const int32_t *n_o, const double *shift, int32_t what,
+                                 double *out_host, qsmc_stream_t stream) {
+    if (!h || !x || !exps || !outcomes || !n_o || !out_host || n <= 0 || n_e < 1) return QSMC_ERR_INVALID;
+    if (what & ~(QSMC_HYP_LOG | QSMC_HYP_MOMENTS)) return QSMC_ERR_INVALID;
+    static_assert(QSMC_HYP_LOG == HYP_WHAT_LOG && QSMC_HYP_MOMENTS == HYP_WHAT_MOM, "the header's bits are the kernels'");
+    for (int e = 0; e < n_e; ++e) if (n_o[e] < 1) return QSMC_ERR_INVALID;
     int rc = check_model(model);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
-    switch (model->kind) {
-#define HD(K) case K: return hyp_dispatch<K>(h, model, x, ldx, n, w, norm, exp, outcomes, n_o, shift, out_host, s);
-        HD(QSMC_MODEL_PRECESSION)
-        HD(QSMC_MODEL_BINOMIAL_PRECESSION)
-        HD(QSMC_MODEL_RB)
-        HD(QSMC_MODEL_RB_INTERLEAVED)
-        HD(QSMC_MODEL_BINOMIAL_RB)
-        HD(QSMC_MODEL_BINOMIAL_RB_INTERLEAVED)
-        HD(QSMC_MODEL_UNKNOWN_T2)
-        HD(QSMC_MODEL_TOMOGRAPHY)
+    const int per = 2 + 2 * (model->d <= 4 ? model->d : 0);
+    Chain2Queue q;
+    size_t done = 0;
+    for (int e = 0; e < n_e && rc == QSMC_OK; ++e) {
+        const int64_t *oc = outcomes + done;
+        double *oh = out_host + done * per;
+        switch (model->kind) {
+#define HD(K) case K: rc = hyp_dispatch<K>(h, q, model, x, ldx, n, w, norm, exps + e, oc, n_o[e], shift, oh, s, what); break;
+            HD(QSMC_MODEL_PRECESSION)
+            HD(QSMC_MODEL_BINOMIAL_PRECESSION)
+            HD(QSMC_MODEL_RB)
+            HD(QSMC_MODEL_RB_INTERLEAVED)
+            HD(QSMC_MODEL_BINOMIAL_RB)
+            HD(QSMC_MODEL_BINOMIAL_RB_INTERLEAVED)
+            HD(QSMC_MODEL_UNKNOWN_T2)
+            HD(QSMC_MODEL_TOMOGRAPHY)
 #undef HD
+            default: rc = QSMC_ERR_INVALID;
+        }
+        done += (size_t)n_o[e];
     }
-    return QSMC_ERR_INVALID;
+    if (rc) {                                  // leave nothing in flight that writes the pinned block behind the caller's back
+        (void)hipStreamSynchronize(s);
+        return rc;
+    }
+    return chain2_flush(h, q, s);
 }
 
 int qsmc_update_from_likelihood(qsmc_handle_t h, const double *L, int64_t n, const double *w_in,

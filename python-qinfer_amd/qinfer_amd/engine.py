@@ -212,19 +212,36 @@ class Engine:
             return list(st), None, None
         return list(st), mom[:d].copy(), self._unpack_upper(mom[d:], d)
 
-    def hypothetical_sums(self, desc, x, w, norm, exp, outcomes, shift):
-        """(n_o, 2 + 2d) array [N, sum wL log L, sum wL (x-c), sum wL (x-c)^2] (d <= 4; else (n_o, 2))."""
+    HYP_LOG, HYP_MOMENTS = 1, 2                     # qsmc.h: QSMC_HYP_LOG / QSMC_HYP_MOMENTS
+
+    def hypothetical_sums(self, desc, x, w, norm, exp, outcomes, shift, what=3):
+        """(n_o, 2 + 2d) array [N, sum wL log L, sum wL (x-c), sum wL (x-c)^2] (d <= 4; else (n_o, 2)) of one experiment.
+        `what`: the columns the caller reads (HYP_LOG: [1], HYP_MOMENTS: [2:]); binomial experiments leave the others NaN."""
+        return self.hypothetical_sums_multi(desc, x, w, norm, [exp], [outcomes], shift, what)[0]
+
+    def hypothetical_sums_multi(self, desc, x, w, norm, exps, outcomes, shift, what=3):
+        """The same for several experiments in one call (qsmc_hypothetical_sums_multi: binomial experiments' passes queue
+        back to back, one wait): `exps` ExpParam records, `outcomes` one outcome list per experiment; a list of arrays."""
         d = x.shape[0]
         per = 2 + 2 * d if d <= 4 else 2
-        n_o = len(outcomes)
-        out = np.empty((n_o, per), dtype=np.float64)
-        oc = (C.c_int64 * n_o)(*[int(o) for o in outcomes])
+        n_e = len(exps)
+        counts = [len(o) for o in outcomes]
+        total = sum(counts)
+        out = np.empty((total, per), dtype=np.float64)
+        oc = np.ascontiguousarray(np.concatenate([np.asarray(o).ravel() for o in outcomes]), dtype=np.int64)
+        no = np.asarray(counts, dtype=np.int32)
+        ep = (_native.ExpParam * n_e)(*exps)
         shift = np.ascontiguousarray(shift, dtype=np.float64)
-        self._chk(self.lib.qsmc_hypothetical_sums(
+        self._chk(self.lib.qsmc_hypothetical_sums_multi(
             self.h, C.byref(desc), self._p(x), x.stride(0), x.shape[1],
-            self._p(w) if w is not None else None, float(norm), C.byref(exp), oc, n_o,
-            _native.f64_ptr(shift), _native.f64_ptr(out), self.stream()), "qsmc_hypothetical_sums")
-        return out
+            self._p(w) if w is not None else None, float(norm), ep, n_e,
+            oc.ctypes.data_as(C.POINTER(C.c_int64)), no.ctypes.data_as(C.POINTER(C.c_int32)),
+            _native.f64_ptr(shift), int(what), _native.f64_ptr(out), self.stream()), "qsmc_hypothetical_sums_multi")
+        res, at = [], 0
+        for c in counts:
+            res.append(out[at:at + c])
+            at += c
+        return res
 
     def update_from_likelihood(self, L, w_in, w_out, prev_norm):
         st = _native.UpdateStats()

@@ -773,22 +773,25 @@ class SMCUpdater(ParticleDistribution):
         return True
 
     # ------------------------------------------------------------------ experiment design
-    def _hyp_sums(self, expparams):
-        """Per experiment: all outcomes' hypothetical sums in one pass each (qsmc_hypothetical_sums)."""
+    def _hyp_sums(self, expparams, what=3):
+        """Per experiment: all outcomes' hypothetical sums (qsmc_hypothetical_sums_multi: one call for the whole design;
+        `what`: the columns the caller reads, Engine.HYP_LOG | Engine.HYP_MOMENTS)."""
         eng = self._eng
         shift = self.est_mean()
-        out = []
-        for k in range(expparams.shape[0]):
-            one = expparams[k:k + 1]
-            os_ = self.model.domain(one)[0].values
-            exp = self.model._native_expparams(one)[0]
-            sums = eng.hypothetical_sums(self._desc, self._x, self._w, self._norm, exp, os_, shift)
-            if self._comm is not None:
-                # every entry is a sum over particles with the GLOBAL normaliser and a shift all ranks agree on
-                # (the global mean): additive over the shards
-                sums = self._comm.allreduce_host_vector(sums.reshape(-1))[0].reshape(sums.shape)
-            out.append(sums)
-        return out
+        exps = self.model._native_expparams(expparams)
+        outs = [dom.values for dom in self.model.domain(expparams)]
+        sums = eng.hypothetical_sums_multi(self._desc, self._x, self._w, self._norm, exps, outs, shift, what)
+        if self._comm is not None:
+            # every entry is a sum over particles with the GLOBAL normaliser and a shift all ranks agree on (the global
+            # mean): additive over the shards (columns nobody asked for are NaN on every shard); one reduction per design
+            flat = np.concatenate([a.reshape(-1) for a in sums])
+            tot = self._comm.allreduce_host_vector(flat)[0]
+            out, at = [], 0
+            for a in sums:
+                out.append(tot[at:at + a.size].reshape(a.shape))
+                at += a.size
+            sums = out
+        return sums
 
     def bayes_risk(self, expparams):
         """Bayes risk (quadratic loss, scale matrix Q) of hypothetical experiments: the expected
@@ -802,11 +805,17 @@ class SMCUpdater(ParticleDistribution):
             d = self._x.shape[0]
             Q = np.asarray(self.model.Q, dtype=np.float64)
             risk = np.empty(expparams.shape[0])
-            for k, sums in enumerate(self._hyp_sums(expparams)):
-                N, s1, s2 = sums[:, 0], sums[:, 2:2 + d], sums[:, 2 + d:2 + 2 * d]
+            sums = self._hyp_sums(expparams, self._eng.HYP_MOMENTS)
+            if len({a.shape for a in sums}) == 1:
+                sums = [np.stack(sums)]                      # equal outcome counts: the whole design in one set of array operations
+            at = 0
+            for a in sums:
+                a = a.reshape((-1,) + a.shape[-2:])
+                N, s1, s2 = a[..., 0:1], a[..., 2:2 + d], a[..., 2 + d:2 + 2 * d]
                 with np.errstate(divide='ignore', invalid='ignore'):
-                    var = np.where(N[:, None] > 0, s2 - s1 * s1 / N[:, None], 0.0)
-                risk[k] = np.sum(var @ Q)
+                    var = np.where(N > 0, s2 - s1 * s1 / N, 0.0)
+                risk[at:at + a.shape[0]] = np.sum(var @ Q, axis=-1)
+                at += a.shape[0]
             return risk
         return self._design_generic(expparams, "risk")
 
@@ -816,10 +825,16 @@ class SMCUpdater(ParticleDistribution):
         expparams = np.atleast_1d(expparams).reshape(-1)
         if self._native:
             eig = np.empty(expparams.shape[0])
-            for k, sums in enumerate(self._hyp_sums(expparams)):
-                N, sl = sums[:, 0], sums[:, 1]
+            sums = self._hyp_sums(expparams, self._eng.HYP_LOG)
+            if len({a.shape for a in sums}) == 1:
+                sums = [np.stack(sums)]
+            at = 0
+            for a in sums:
+                a = a.reshape((-1,) + a.shape[-2:])
+                N, sl = a[..., 0], a[..., 1]
                 with np.errstate(divide='ignore', invalid='ignore'):
-                    eig[k] = np.sum(np.where(N > 0, sl - N * np.log(N), 0.0))
+                    eig[at:at + a.shape[0]] = np.sum(np.where(N > 0, sl - N * np.log(N), 0.0), axis=-1)
+                at += a.shape[0]
             return eig
         return self._design_generic(expparams, "eig")
 

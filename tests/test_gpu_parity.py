@@ -2568,11 +2568,13 @@ print("digest", h.hexdigest())
 
 
 def test_design_chain_kernel_vs_lanes_kernel_edges():
-    """bayes_risk / expected_information_gain of binomial experiments through k_hyp_sums_chain (one exponential per
-    particle and pass, pmfs by recurrence; round 4) against k_hyp_sums_lanes (one exponential per particle and outcome;
-    QSMC_HYP_NO_CHAIN=1, read once per process: subprocesses), on clouds with the cases the walk folds into its start
-    value: pr1 exactly 0 (omega = 0), weights that are exactly 0, very small and very large pr1, and for n_meas from 1 to
-    100 (one to eight passes; the outcome n_meas alone in a pass).  Every entry of the per-outcome sums agrees to 1e-11 of
+    """bayes_risk / expected_information_gain of binomial experiments through k_hyp_sums_chain2 (the geometric walk from
+    both ends of a pass, binomial coefficients applied on the host, only the columns the caller reads; round 4) and
+    through k_hyp_sums_chain (QSMC_HYP_CHAIN1=1: the one-ended walk) against k_hyp_sums_lanes (one exponential per particle
+    and outcome; QSMC_HYP_NO_CHAIN=1; switches are read once per process: subprocesses), on clouds with the cases the walk
+    folds into its start value: pr1 exactly 0 (omega = 0), weights that are exactly 0, very small and very large pr1, for
+    n_meas from 1 to 200 (integer-power and exponential start values; one to eight passes, queued over the experiments of
+    a call and collected after one wait) and designs that mix n_meas.  Every entry of the per-outcome sums agrees to 1e-11 of
     the experiment's largest entry (the walk's error is ~3 ulp per step; what a pass's first pmf loses to underflow is
     below 1e-150 of the sums)."""
     import subprocess
@@ -2598,27 +2600,35 @@ m = qi.BinomialModel(qi.SimplePrecessionModel())
 upd = qi.SMCUpdater(m, n, Fixed())
 upd.particle_weights = w
 out = []
-for n_meas in (1, 2, 12, 13, 14, 25, 26, 40, 100):
+for n_meas in (1, 2, 12, 13, 14, 25, 26, 40, 64, 65, 100, (5, 25, 70), (200, 3, 64)):
     ep = np.empty((3,), dtype=m.expparams_dtype)
     ep["x"], ep["n_meas"] = [3.0, 0.7, 41.0], n_meas
     for sums in upd._hyp_sums(ep):
         out.append(np.asarray(sums).ravel())
     out.append(np.asarray(upd.bayes_risk(ep)))
     out.append(np.asarray(upd.expected_information_gain(ep)))
+    # the columns a caller asks for are the ones of the full rows; the others come back NaN (walk kernels) or filled
+    for what, cols in ((1, (0, 1)), (2, (0, 2, 3))):
+        for full, part in zip(upd._hyp_sums(ep), upd._hyp_sums(ep, what)):
+            full, part = np.asarray(full), np.asarray(part)
+            assert part.shape == full.shape
+            scale = np.abs(full).max()
+            assert np.allclose(part[:, cols], full[:, cols], rtol=1e-10, atol=1e-12 * scale), (n_meas, what)
 np.save(sys.argv[1], np.concatenate(out))
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     import tempfile
     res = []
     with tempfile.TemporaryDirectory() as td:
-        for tag, env_extra in (("chain", {}), ("lanes", {"QSMC_HYP_NO_CHAIN": "1"})):
+        for tag, env_extra in (("chain2", {}), ("chain", {"QSMC_HYP_CHAIN1": "1"}), ("lanes", {"QSMC_HYP_NO_CHAIN": "1"})):
             path = os.path.join(td, tag + ".npy")
             r = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True,
                                env=dict(os.environ, **env_extra), timeout=600)
             assert r.returncode == 0, r.stderr[-2000:]
             res.append(np.load(path))
-    a, b = res
-    assert a.shape == b.shape and np.isfinite(b).all() and np.isfinite(a).all()
-    np.testing.assert_allclose(a, b, rtol=1e-10, atol=1e-11 * np.abs(b).max())
+    b = res[2]
+    for a in res[:2]:
+        assert a.shape == b.shape and np.isfinite(b).all() and np.isfinite(a).all()
+        np.testing.assert_allclose(a, b, rtol=1e-10, atol=1e-11 * np.abs(b).max())
 
 
 def test_small_redraw_queue_same_particles():
