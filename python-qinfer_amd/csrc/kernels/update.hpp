@@ -739,122 +739,24 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_hyp_sums_lanes(const double *__r
 }
 
 // ---------------------------------------------------------------------------------------------
-// Round 4: binomial experiments, consecutive outcomes k_first, k_first + 1, ... -- the sums above with ONE exponential
-// per particle and pass instead of one per (particle, outcome).  k_hyp_sums_lanes is VALU-bound on fast_exp (SQ counters:
+// Round 4: binomial experiments, consecutive outcomes k_first, k_first + 1, ... -- the sums above with the pmfs of a pass
+// WALKED instead of one exponential per (particle, outcome).  k_hyp_sums_lanes is VALU-bound on fast_exp (SQ counters:
 // profiles/r4_*_paths_sq_counters.json): 32 outcome slots x ~46 fp64 instructions per particle.  The pmfs of consecutive
-// outcomes obey
-//     pmf(k + 1) = pmf(k) [(n - k) / (k + 1)] [p / (1 - p)],
-// two multiplications -- but along the OUTCOME axis, which the lane-per-outcome layout spreads over lanes.  Here a lane
-// owns a particle (as in k_hyp_sums) and walks the outcomes of one pass, NO = 52 / (2 + 2 D) of them (13 at D = 1): the
-// NO x (2 + 2 D) running sums are 104 VGPRs (k_hyp_sums at 32 outcomes needed 256 and spilled), and per (particle,
-// outcome) the work is 2 multiplications for the pmf, 2 multiply-adds for ln pmf and 2 + 2 D for the sums.  A 26-outcome
-// experiment is two passes of 13.  The matrix cores do not come into it: on gfx950 the fp64 MFMA rate equals the fp64
-// vector rate and a 16 x 16 x 4 tile would carry 5 useful columns of 16; what MFMA accumulators would buy is registers,
-// which the two-pass split buys cheaper.  (Also built this round, and slower -- tools/experiments/r4_hyp_sums_recurrence
-// _via_lds.patch: the recurrence in the particle's lane, pmfs handed to outcome lanes through LDS.)
-// The walk starts at the pass's first outcome.  Relative error of the walk <= ~3 ulp per step: 4e-15 over 12 steps
-// (fixture G7 allows 1e-10).
-// ---------------------------------------------------------------------------------------------
-constexpr int CHAIN_SUMS = 52;      // running sums per lane: 13 outcomes x (2 + 2 D) at D = 1 -- a 26-outcome experiment is two passes
-struct ChainArgs {
-    int n_o;                       // outcomes in this pass (<= NO), consecutive from k_first
-    ExpArgs base;
-    int j_full;                    // the j with k_first + j == n_meas (-1: not in this pass)
-    double k_first;
-    double lc[16];                 // ln C(n, k_first + j)
-    double ratio[16];              // (n - k) / (k + 1) at k = k_first + j: pmf(k + 1) / pmf(k) without the odds
-    double shift[QSMC_MAX_D];
-};
-
-template <int KIND>
-__attribute__((amdgpu_waves_per_eu(3, 4)))
-__global__ __launch_bounds__(QSMC_BLOCK) void k_hyp_sums_chain(const double *__restrict__ x, int64_t ldx, int64_t n,
-                                                               const double *__restrict__ w, double norm,
-                                                               ChainArgs ca, ReduceOut ro) {
-    constexpr int D = Model<KIND>::D <= 4 ? Model<KIND>::D : 0;
-    constexpr int DD = Model<KIND>::D;
-    constexpr int PER = 2 + 2 * D;
-    constexpr int NO = CHAIN_SUMS / PER;
-    constexpr int NS = NO * PER;
-    double s[NS];
-#pragma unroll
-    for (int q = 0; q < NS; ++q) s[q] = 0.0;
-    const double n_meas = ca.base.n_meas;
-    const double inv_norm = 1.0 / norm;
-    const int64_t stride = (int64_t)gridDim.x * QSMC_BLOCK;
-    int64_t i = (int64_t)blockIdx.x * QSMC_BLOCK + threadIdx.x;
-    // the next particle's loads are issued before this one's ~300 instructions: at two or three waves per SIMD (the
-    // running sums take 104 VGPRs) nothing else hides the load latency -- 271 us per pass without, measured
-    double pn[DD], wn = 1.0;
-    if (i < n) {
-#pragma unroll
-        for (int m = 0; m < DD; ++m) pn[m] = x[m * ldx + i];
-        if (w) wn = w[i];
-    }
-    for (; i < n; i += stride) {
-        double p[DD];
-#pragma unroll
-        for (int m = 0; m < DD; ++m) p[m] = pn[m];
-        const double wi = wn * inv_norm;
-        if (i + stride < n) {
-#pragma unroll
-            for (int m = 0; m < DD; ++m) pn[m] = x[m * ldx + i + stride];
-            if (w) wn = w[i + stride];
-        }
-        HypPre<KIND> pre;
-        pre.prepare(p, ca.base);
-        double c1[D > 0 ? D : 1], c2[D > 0 ? D : 1];
-#pragma unroll
-        for (int m = 0; m < D; ++m) {
-            c1[m] = p[m] - ca.shift[m];
-            c2[m] = c1[m] * c1[m];
-        }
-        const double pr1 = pre.pr1, lp = pre.lp, lq = pre.lq;
-        // ln pmf(k_first + j) = lc[j] + t_j, t_j = n ln(1 - p) + (k_first + j) (ln p - ln(1 - p)): a running sum (what is
-        // uniform over the lanes stays in scalar registers: lc[j] and ratio[j] are the only per-outcome operands -- with
-        // k_j and n - k_j as operands the compiler kept 2 x 13 loop-invariant doubles in VGPRs and spilled 80)
-        const double dl = lp - lq;
-        double t = n_meas * lq + ca.k_first * dl;
-        const double logL0 = ca.lc[0] + t;
-        // The walk needs no second path.  pr1 == 0: the pmf is [k == 0] -- start there, multiply by 0.  pr1 == 1: [k == n],
-        // selected per outcome.  pr1 outside [0, 1] (an invalid particle): NaN throughout, like SciPy's pmf (weight 0: 0).
-        // A first pmf that underflows makes the pass 0 for this particle: with <= 13 outcomes a pass and 1 - pr1 >= 1.1e-16
-        // the later ones are then below 1e-150 of a sum that is O(1) (ln pmf is finite in every case: HypPreBinomial sets
-        // the logarithm of a vanishing probability to 0, so w pmf ln pmf needs no guard).
-        const bool inside = pr1 > 0.0 && pr1 < 1.0, one = pr1 == 1.0;
-        const double step = inside ? pr1 / (1.0 - pr1) : 0.0;
-        double cur = inside ? wi * fast_exp(logL0)
-                            : (pr1 == 0.0 ? (ca.k_first == 0.0 ? wi : 0.0) : (one || wi == 0.0 ? 0.0 : NAN));
-#pragma unroll
-        for (int j = 0; j < NO; ++j) {
-            if (j < ca.n_o) {                                   // (uniform)
-                const double logL = ca.lc[j] + t;
-                const double wl = one ? (j == ca.j_full ? wi : 0.0) : cur;     // w pmf(k_first + j)
-                t += dl;
-                s[j * PER] += wl;
-                s[j * PER + 1] += wl * logL;
-#pragma unroll
-                for (int m = 0; m < D; ++m) {
-                    s[j * PER + 2 + m] += wl * c1[m];
-                    s[j * PER + 2 + D + m] += wl * c2[m];
-                }
-                cur = cur * (ca.ratio[j] * step);
-            }
-        }
-    }
-    block_publish<NS>(s, 0.0, ro);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Round 4b: the walk from BOTH ends of a pass, with the binomial coefficients taken out of the kernel.
-// ISA of k_hyp_sums_chain (tools/isa_count.sh): ~20 VALU instructions per (particle, outcome) in the walk -- every
-// `s += wl * c` is a multiply and an add (the library is built without contraction: the update path must match NumPy
-// operation for operation; these sums are held to rtol 1e-10, not to bits), the pr1 == 1 select is four v_cndmask per
-// outcome, the per-outcome uniforms (ln C, the ratios) and the uniform `j < n_o` guards spill SGPRs to VGPR lanes --
-// and ~200 per particle and pass for two logarithms and an exponential that bayes_risk never uses.  Here:
+// outcomes obey  pmf(k + 1) = pmf(k) [(n - k) / (k + 1)] [p / (1 - p)]  -- along the OUTCOME axis, which the lane-per-
+// outcome layout spreads over lanes; here a lane owns a particle (as in k_hyp_sums) and walks the outcomes of a pass.
+// The first form (k_hyp_sums_chain, mid-round: one walk upwards from k_first with ln C and the ratios as per-outcome
+// uniforms, all four sums, 13 outcomes a pass; 589 -> 2 x 176 us per 26-outcome experiment at N = 1e7) showed in its ISA
+// ~20 VALU instructions per (particle, outcome) in the walk -- every `s += wl * c` is a multiply and an add (the library
+// is built without contraction: the update path must match NumPy operation for operation; these sums are held to rtol
+// 1e-10, not to bits), the pr1 == 1 select was four v_cndmask per outcome, the per-outcome uniforms and the uniform
+// `j < n_o` guards spilled SGPRs to VGPR lanes -- and ~200 per particle and pass for two logarithms and an exponential
+// that bayes_risk never uses.  The matrix cores do not come into it: on gfx950 the fp64 MFMA rate equals the fp64 vector
+// rate and a 16 x 16 x 4 tile would carry 5 useful columns of 16.  (Also built and slower: tools/experiments/
+// r4_hyp_sums_recurrence_via_lds.patch, the walk in the particle's lane with the pmfs handed to outcome lanes through LDS.)
+// The form below:
 //   * every sum is linear in the pmf, and pmf(k) = C(n, k) p^k q^(n - k): the kernel walks the GEOMETRIC sequence
 //     v_j = pmf(k_ref) (p / q)^j -- one multiplication per step, no per-outcome operand -- and the host multiplies
-//     the finished sums of slot j by C(n, k_ref + j) / C(n, k_ref) (Chain2Plan::scale);  ln pmf = ln C + t_j with
+//     the finished sums of slot j by C(n, k_ref + j) / C(n, k_ref) (chain2_collect);  ln pmf = ln C + t_j with
 //     t_j = n ln q + k_j (ln p - ln q) a running sum, so sum w pmf ln pmf = scale * sum v t + ln C * sum w pmf: the
 //     ln C term is added on the host as well;
 //   * a pass takes its outcomes from both ends: slots 0 .. n_up - 1 upwards from k_first with p / q, the others
@@ -908,10 +810,9 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_hyp_sums_chain2(const double *__
     const double n_meas = ca.base.n_meas;
     const double inv_norm = 1.0 / norm;
     const double kf = (double)ca.k_first, kl = (double)ca.k_last;
-    // U particles per lane and trip (i, i + stride, ...): at two or three waves per SIMD the serial parts of a particle --
-    // the range reduction and polynomial of cos^2, the square-and-multiply powers, a division -- leave the SIMD idle
-    // between dependent instructions, and one 16-byte prefetch per lane is ~2 MB in flight over the chip, a third of what
-    // the memory system needs; the U particles' chains interleave and their prefetches double up (138 -> see DESIGN 3.7)
+    // U particles per lane and trip (i, i + stride, ...), the next trip's loads issued ahead of this one's arithmetic.
+    // U = 1: two or three particles interleaved per lane -- their serial parts (cos^2, the powers, the reciprocal) side
+    // by side, two or three prefetches in flight -- were measured at 141 / 144 us against 139 (-DCHAIN2_UNROLL=2 / 3)
     constexpr int U = CHAIN2_UNROLL;
     const int64_t stride = (int64_t)gridDim.x * QSMC_BLOCK;
     int64_t i = (int64_t)blockIdx.x * QSMC_BLOCK + threadIdx.x;

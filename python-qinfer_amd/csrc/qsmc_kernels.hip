@@ -588,60 +588,7 @@ static int hyp_launch_lanes(qsmc_ctx *h, const qsmc_model_t *model, const double
     return QSMC_OK;
 }
 
-// binomial models, consecutive outcomes: a lane per particle walks the outcomes of a pass (k_hyp_sums_chain)
-template <int KIND>
-static int hyp_launch_chain(qsmc_ctx *h, const qsmc_model_t *model, const double *x, int64_t ldx, int64_t n,
-                            const double *w, double norm, const qsmc_expparam_t *exp, const int64_t *outcomes, int n_o,
-                            const double *shift, double *out_host, hipStream_t s) {
-    constexpr int D = Model<KIND>::D <= 4 ? Model<KIND>::D : 0;
-    constexpr int PER = 2 + 2 * D;
-    constexpr int NO = CHAIN_SUMS / PER;
-    constexpr int NS = NO * PER;
-    if (n_o < 1 || n_o > NO) return QSMC_ERR_INVALID;
-    // one resident round (three 256-thread workgroups per CU at 168 VGPRs): the 52 wave reductions at the end of a
-    // workgroup cost ~1000 instructions per thread -- as much as three particles -- and 2048 workgroups on 768 slots end in
-    // a ragged third round
-    int grid = grid_for(n, QSMC_BLOCK * 4);
-    if (grid > 3 * h->cu_count) grid = 3 * h->cu_count;
-    int rc = ensure_partials(h, (size_t)grid * (NS + 1));
-    if (rc) return rc;
-    rc = ensure_scratch(h, 256 + 512);
-    if (rc) return rc;
-    ChainArgs ca;
-    memset(&ca, 0, sizeof(ca));
-    ca.n_o = n_o;
-    make_exp_args(model, exp, outcomes[0], &ca.base);
-    ca.k_first = (double)outcomes[0];
-    const double nm = (double)exp->n_meas;
-    ca.j_full = -1;
-    for (int j = 0; j < n_o; ++j) {
-        if ((uint64_t)outcomes[j] == exp->n_meas) ca.j_full = j;
-        ExpArgs tmp;
-        make_exp_args(model, exp, outcomes[j], &tmp);
-        ca.lc[j] = tmp.log_comb;
-        const double k = ca.k_first + (double)j;
-        ca.ratio[j] = (nm - k) / (k + 1.0);
-    }
-    if (shift) for (int m = 0; m < model->d && m < QSMC_MAX_D; ++m) ca.shift[m] = shift[m];
-    ReduceOut ro;
-    memset(&ro, 0, sizeof(ro));
-    ro.partials = h->partials;
-    hipEvent_t he0 = nullptr, he1 = nullptr;
-    prof_events(h, QSMC_PROF_HYP_SUMS, &he0, &he1);
-    hipExtLaunchKernelGGL((k_hyp_sums_chain<KIND>), dim3(grid), dim3(QSMC_BLOCK), 0, s, he0, he1, 0, x, ldx, n, w, norm, ca, ro);
-    double *full = h->scratch + 256;
-    hipLaunchKernelGGL(k_sum_columns, dim3((NS + QSMC_WAVES_PER_BLOCK - 1) / QSMC_WAVES_PER_BLOCK), dim3(QSMC_BLOCK), 0, s,
-                       h->partials, grid, NS, full);
-    const unsigned long long seq = ++h->seq;
-    hipLaunchKernelGGL(k_publish_big, dim3(1), dim3(QSMC_BLOCK), 0, s, full, NS, h->mapped_big_dev, h->flag_dev, seq);
-    HIP_TRY(h, hipGetLastError());
-    rc = wait_reduction(h, s);
-    if (rc) return rc;
-    memcpy(out_host, h->mapped_big, (size_t)n_o * PER * sizeof(double));
-    return QSMC_OK;
-}
-
-// binomial models, consecutive outcomes, round 4b: the geometric walk from both ends of the pass (k_hyp_sums_chain2);
+// binomial models, consecutive outcomes: a lane per particle walks the outcomes of a pass from both ends (k_hyp_sums_chain2);
 // the binomial coefficients and the ln C term of sum w L ln L are applied on the host, to the finished sums.
 // Two halves, so that the passes of SEVERAL experiments queue back to back and the host waits once (bayes_risk over a
 // design: per experiment ~15 us of launch + publish + completion-word round trip and the caller's own per-call work
@@ -669,7 +616,8 @@ static int chain2_enqueue(qsmc_ctx *h, const qsmc_model_t *model, const double *
     constexpr int NS = 2 * NH * PER;
     static_assert(NS <= 512 && 2 * NH <= CHAIN2_MAX_SLOTS, "the pinned block of the wide sums holds 512 doubles a pass");
     if (n_o < 1 || n_o > 2 * NH || off < 0 || off + NS > SQRT_MAPPED_DOUBLES) return QSMC_ERR_INVALID;
-    // one resident round, as for k_hyp_sums_chain: the NS wave reductions at a workgroup's end are worth a few particles
+    // one resident round: the NS wave reductions at a workgroup's end are worth a few particles each, and a grid of
+    // 2048 workgroups on 512 - 768 resident slots ends in a ragged last round
     static const int per_cu = [] {
         int b = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_hyp_sums_chain2<KIND, WHAT, NH>, QSMC_BLOCK, 0) != hipSuccess || b < 1) b = 2;
@@ -805,15 +753,13 @@ static int hyp_dispatch(qsmc_ctx *h, Chain2Queue &q, const qsmc_model_t *model, 
     bool consecutive = BINOMIAL && !no_chain && n_o > 2 && model->likelihood_power == 0.0 && outcomes[0] >= 0 &&
                        (uint64_t)outcomes[n_o - 1] <= exp->n_meas;
     for (int o = 1; o < n_o && consecutive; ++o) consecutive = outcomes[o] == outcomes[0] + o;
-    constexpr int CHAIN_NO = CHAIN_SUMS / PER;
-    static const bool chain1 = getenv("QSMC_HYP_CHAIN1") != nullptr;                 // (A/B switch: round 4's one-ended walk)
     what &= HYP_WHAT_LOG | HYP_WHAT_MOM;
     if (what == 0 || D == 0) what |= HYP_WHAT_LOG;
     // slots per pass of the two-ended walk: 2 NH, NH from the registers the sums take (2 NH x PER doubles: ~56 for three
     // waves per SIMD; the moments at D = 1 take 78 -- a 26-outcome experiment in ONE pass at two waves per SIMD, 138 us,
     // against two passes of 13 at three waves, 216 us)
     constexpr int NH_LOG = 13, NH_MOM = D <= 1 ? 13 : (D <= 3 ? 4 : 3), NH_ALL = D <= 1 ? 7 : (D <= 3 ? 4 : 3);
-    const int chain_slots = chain1 ? CHAIN_NO : 2 * (what == HYP_WHAT_LOG ? NH_LOG : (what == HYP_WHAT_MOM ? NH_MOM : NH_ALL));
+    const int chain_slots = 2 * (what == HYP_WHAT_LOG ? NH_LOG : (what == HYP_WHAT_MOM ? NH_MOM : NH_ALL));
     const int chain_passes = (n_o + chain_slots - 1) / chain_slots;
     const int chain_take = (n_o + chain_passes - 1) / chain_passes;
     while (done < n_o) {
@@ -824,11 +770,7 @@ static int hyp_dispatch(qsmc_ctx *h, Chain2Queue &q, const qsmc_model_t *model, 
             if constexpr (BINOMIAL) {
                 const int64_t *oc = outcomes + done;
                 double *oh = out_host + (size_t)done * PER;
-                if (chain1) {
-                    rc = chain2_flush(h, q, s);
-                    if (!rc) rc = hyp_launch_chain<KIND>(h, model, x, ldx, n, w, norm, exp, oc, take, shift, oh, s);
-                }
-                else if (what == HYP_WHAT_LOG)
+                if (what == HYP_WHAT_LOG)
                     rc = chain2_go<KIND, HYP_WHAT_LOG, NH_LOG>(h, q, model, x, ldx, n, w, norm, exp, oc, take, shift, oh, s);
                 else if (what == HYP_WHAT_MOM)
                     rc = chain2_go<KIND, HYP_WHAT_MOM, NH_MOM>(h, q, model, x, ldx, n, w, norm, exp, oc, take, shift, oh, s);

@@ -2569,9 +2569,9 @@ print("digest", h.hexdigest())
 
 def test_design_chain_kernel_vs_lanes_kernel_edges():
     """bayes_risk / expected_information_gain of binomial experiments through k_hyp_sums_chain2 (the geometric walk from
-    both ends of a pass, binomial coefficients applied on the host, only the columns the caller reads; round 4) and
-    through k_hyp_sums_chain (QSMC_HYP_CHAIN1=1: the one-ended walk) against k_hyp_sums_lanes (one exponential per particle
-    and outcome; QSMC_HYP_NO_CHAIN=1; switches are read once per process: subprocesses), on clouds with the cases the walk
+    both ends of a pass, binomial coefficients applied on the host, only the columns the caller reads; round 4) against
+    k_hyp_sums_lanes (one exponential per particle and outcome; QSMC_HYP_NO_CHAIN=1, read once per process:
+    subprocesses), on clouds with the cases the walk
     folds into its start value: pr1 exactly 0 (omega = 0), weights that are exactly 0, very small and very large pr1, for
     n_meas from 1 to 200 (integer-power and exponential start values; one to eight passes, queued over the experiments of
     a call and collected after one wait) and designs that mix n_meas.  Every entry of the per-outcome sums agrees to 1e-11 of
@@ -2619,16 +2619,15 @@ np.save(sys.argv[1], np.concatenate(out))
     import tempfile
     res = []
     with tempfile.TemporaryDirectory() as td:
-        for tag, env_extra in (("chain2", {}), ("chain", {"QSMC_HYP_CHAIN1": "1"}), ("lanes", {"QSMC_HYP_NO_CHAIN": "1"})):
+        for tag, env_extra in (("chain2", {}), ("lanes", {"QSMC_HYP_NO_CHAIN": "1"})):
             path = os.path.join(td, tag + ".npy")
             r = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True,
                                env=dict(os.environ, **env_extra), timeout=600)
             assert r.returncode == 0, r.stderr[-2000:]
             res.append(np.load(path))
-    b = res[2]
-    for a in res[:2]:
-        assert a.shape == b.shape and np.isfinite(b).all() and np.isfinite(a).all()
-        np.testing.assert_allclose(a, b, rtol=1e-10, atol=1e-11 * np.abs(b).max())
+    a, b = res
+    assert a.shape == b.shape and np.isfinite(b).all() and np.isfinite(a).all()
+    np.testing.assert_allclose(a, b, rtol=1e-10, atol=1e-11 * np.abs(b).max())
 
 
 def test_small_redraw_queue_same_particles():
