@@ -660,6 +660,11 @@ __host__ __device__ inline double j_rcp(double x) { return 1.0 / x; }
 template <int DIM>
 __host__ __device__ inline bool jacobi_clamp(double (&Ar)[DIM][DIM], double (&Ai)[DIM][DIM], double (&Rr)[DIM][DIM],
                                              double (&Ri)[DIM][DIM]) {
+    // (contraction ON in here, against the library's -ffp-contract=off: the rotations are complex multiply-adds, 986
+    //  v_mul_f64 + 516 v_add_f64 per particle of k_tomo_canon_list uncontracted; nothing outside this function reproduces
+    //  its intermediate bits -- the reference's eigh does not either, G5 holds the RESULT to 1e-12 -- and `on` contracts
+    //  inside source expressions only, so every kernel that inlines this function gets the same fmas)
+#pragma clang fp contract(on)
     double Vr[DIM][DIM], Vi[DIM][DIM];
 #pragma unroll
     for (int r = 0; r < DIM; ++r)
@@ -857,6 +862,7 @@ __host__ __device__ inline bool tomo_canon_particle(const Basis &B, double *p, b
 // eigendecomposition; anything not clearly positive definite (a zero or negative pivot) goes to the latter.
 template <int DIM, class Basis>
 __host__ __device__ inline bool tomo_clearly_positive(const Basis &B, const double *p) {
+#pragma clang fp contract(on)                             // (as in jacobi_clamp: a verdict, not a reproduced value)
     double Ar[DIM][DIM], Ai[DIM][DIM];
     B.build(p, Ar, Ai, true);                             // lower triangle is enough
     // in place: A[j][j] <- d_j, A[i][j] <- l_ij (i > j)
