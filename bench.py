@@ -387,11 +387,12 @@ def other_paths(qi, eng, torch, n=10_000_000):
                                  kt["hyp_sums"]["launches"],
                                  {"bytes_per_particle": 16, "outcomes_per_pass": 26 // max(passes, 1), "passes_per_experiment": passes,
                                   "kernel_us_per_experiment": kt["hyp_sums"]["avg_us"] * passes,
-                                  "note": "VALU-bound (~260 instructions per particle and pass, two waves per SIMD: "
-                                          "profiles/r4_c_paths_sq_counters.json): cos^2, two integer powers and one reciprocal per "
-                                          "particle, then a geometric walk from both ends of the outcome range -- 1 multiply + 1 add "
-                                          "+ 2 multiply-adds per (particle, outcome), 78 running sums; binomial coefficients applied "
-                                          "on the host; the four experiments' passes queue back to back behind one wait"})
+                                  "note": "VALU-bound (~260 instructions per particle and pass, 59-69 % VALU-busy at four waves per "
+                                          "SIMD): cos^2, two integer powers and one reciprocal per particle, then a geometric walk from "
+                                          "both ends of the outcome range -- 1 multiply + 1 add + 2 multiply-adds per (particle, "
+                                          "outcome) -- the two directions on partner waves (start values handed over through LDS), 39 "
+                                          "running sums a lane; binomial coefficients applied on the host; the four experiments' "
+                                          "passes queue back to back behind one wait"})
     out["bayes_risk_26_outcomes"] = e
     del upd
     torch.cuda.empty_cache()

@@ -765,16 +765,13 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_hyp_sums_lanes(const double *__r
 //     invalid particle (pr1 outside [0, 1] or NaN) starts from NaN and stays there (weight 0: from 0), like SciPy's pmf;
 //   * WHAT says which sums the caller uses: bayes_risk the moments (no logarithm at all; the start values are integer
 //     powers for n_meas <= 64, as in binom_pmf), expected_information_gain sum w L ln L (no moments), the C ABI's
-//     qsmc_hypothetical_sums both;  2 NH slots x PER sums each are the registers a lane holds;
+//     qsmc_hypothetical_sums both;
 //   * explicit fma for the sums; slots past the pass's outcomes cost their instructions but no branch (their sums are
 //     dropped on the host).
 // Per (particle, outcome): 1 multiplication + 1 addition + 2 D multiply-adds (moments) / + 1 addition + 1 multiply-add
 // (logarithm).  A half pass is <= 13 steps, so what an underflowing start value loses is < 1e-140 of sums that are O(1).
 // ---------------------------------------------------------------------------------------------
 constexpr int HYP_WHAT_LOG = 1, HYP_WHAT_MOM = 2;
-#ifndef CHAIN2_UNROLL
-#define CHAIN2_UNROLL 1
-#endif
 struct Chain2Args {
     ExpArgs base;
     int n_up, n_dn;                // slots walked upwards from k_first / downwards from k_last (>= 1 / >= 0)
@@ -785,17 +782,27 @@ struct Chain2Args {
     double shift[QSMC_MAX_D];
 };
 
+// ---------------------------------------------------------------------------------------------
+// The two directions sit on two WAVES.  The first form of this kernel kept both walks' sums in one lane: 78 doubles for
+// the 26-outcome moments pass = 256 VGPRs, two waves per SIMD, VALUs 49 % busy between dependent instructions and the
+// prefetch (profiles/r4_c_paths_sq_counters.json), 120-133 us; two passes of 13 outcomes at three waves: 216 us; two or
+// three particles per lane and trip: 141 / 144 us; a particle on a lane PAIR, one walk each: four waves, 65 % busy, but
+// everything before the walk -- more than half of a particle's ~260 instructions -- computed twice: 174 us.  Here waves
+// 2 m and 2 m + 1 of a workgroup are partners: each prepares ITS OWN 64 particles (cos^2, powers, odds: once per
+// particle), keeps what its direction needs of them -- wave 2 m walks upwards, wave 2 m + 1 downwards -- and hands the
+// other direction's start value, odds (and ln-pmf offset) and the shifted coordinates to the partner through LDS; after
+// one barrier each wave walks ITS direction for both its own and the partner's particles.  Same instructions per
+// particle (+ 2 x PAY LDS accesses per lane), half the running sums per lane: 39 for that pass = four waves per SIMD:
+// 117 us, VALUs 59-69 % busy (the clock sags to ~2.0 GHz under this load).  Double-buffered exchange: one barrier per
+// trip.  Columns of the partial sums: [up slots][down slots], NH x PER each.
+// ---------------------------------------------------------------------------------------------
 template <int KIND, int WHAT, int NH>
-constexpr int chain2_sums() {              // running sums per lane
-    return 2 * NH * (1 + ((WHAT & HYP_WHAT_LOG) ? 1 : 0) + (((WHAT & HYP_WHAT_MOM) && Model<KIND>::D <= 4) ? 2 * Model<KIND>::D : 0));
+constexpr int chain2_lane_sums() {
+    return NH * (1 + ((WHAT & HYP_WHAT_LOG) ? 1 : 0) + (((WHAT & HYP_WHAT_MOM) && Model<KIND>::D <= 4) ? 2 * Model<KIND>::D : 0));
 }
 
-// (registers: two per running sum + ~50: three waves per SIMD = 168 VGPRs up to 58 sums, else two.  Measured and not kept:
-//  a particle on a lane PAIR, each lane with one of the two walks -- 39 sums a lane and four waves per SIMD for the
-//  26-outcome moments pass, VALU-busy 50 -> 65 %, but everything before the walk is then computed twice and that is more
-//  than half of a particle's ~260 instructions: 140 -> 174 us;  two or three particles per lane and trip: 139 -> 141 / 144 us)
 template <int KIND, int WHAT, int NH>
-__attribute__((amdgpu_waves_per_eu(chain2_sums<KIND, WHAT, NH>() <= 58 ? 3 : 2, 4)))
+__attribute__((amdgpu_waves_per_eu(chain2_lane_sums<KIND, WHAT, NH>() <= 39 ? 4 : (chain2_lane_sums<KIND, WHAT, NH>() <= 58 ? 3 : 2), 4)))
 __global__ __launch_bounds__(QSMC_BLOCK) void k_hyp_sums_chain2(const double *__restrict__ x, int64_t ldx, int64_t n,
                                                                 const double *__restrict__ w, double norm,
                                                                 Chain2Args ca, ReduceOut ro) {
@@ -803,123 +810,153 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_hyp_sums_chain2(const double *__
     constexpr int D = (MOM && Model<KIND>::D <= 4) ? Model<KIND>::D : 0;
     constexpr int DD = Model<KIND>::D;
     constexpr int PER = 1 + (LOG ? 1 : 0) + 2 * D;           // [S0, (St), S1[D], S2[D]]
-    constexpr int NS = 2 * NH * PER;
-    double s[NS];
+    constexpr int NSH = NH * PER;                            // this lane's running sums: ONE direction
+    constexpr int PAY = 2 + (LOG ? 2 : 0) + 2 * D;           // handed to the partner: start value, odds, (t, dl), c1[D], c2[D]
+    constexpr int B1 = 1 + (LOG ? 1 : 0);
+    static_assert(QSMC_WAVES_PER_BLOCK == 4, "two wave pairs per workgroup");
+    __shared__ double xch[2][PAY][QSMC_BLOCK];
+    __shared__ double red[QSMC_WAVES_PER_BLOCK][NSH];
+    double s[NSH];
 #pragma unroll
-    for (int q = 0; q < NS; ++q) s[q] = 0.0;
+    for (int q = 0; q < NSH; ++q) s[q] = 0.0;
     const double n_meas = ca.base.n_meas;
     const double inv_norm = 1.0 / norm;
     const double kf = (double)ca.k_first, kl = (double)ca.k_last;
-    // U particles per lane and trip (i, i + stride, ...), the next trip's loads issued ahead of this one's arithmetic.
-    // U = 1: two or three particles interleaved per lane -- their serial parts (cos^2, the powers, the reciprocal) side
-    // by side, two or three prefetches in flight -- were measured at 141 / 144 us against 139 (-DCHAIN2_UNROLL=2 / 3)
-    constexpr int U = CHAIN2_UNROLL;
+    const int wave = threadIdx.x / QSMC_WAVE;
+    const bool down = (wave & 1) != 0;                       // (wave-uniform)
+    const int ptid = threadIdx.x ^ QSMC_WAVE;                // the partner wave's lane with my lane number
     const int64_t stride = (int64_t)gridDim.x * QSMC_BLOCK;
-    int64_t i = (int64_t)blockIdx.x * QSMC_BLOCK + threadIdx.x;
-    double pn[U][DD], wn[U];
+    double pn[DD], wn = 0.0;
+    {
+        const int64_t i0 = (int64_t)blockIdx.x * QSMC_BLOCK + threadIdx.x;
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int64_t iu = i + u * stride;
-        wn[u] = 0.0;
+        for (int m = 0; m < DD; ++m) pn[m] = 0.5;
+        if (i0 < n) {
 #pragma unroll
-        for (int m = 0; m < DD; ++m) pn[u][m] = 0.5;
-        if (iu < n) {
-#pragma unroll
-            for (int m = 0; m < DD; ++m) pn[u][m] = x[m * ldx + iu];
-            wn[u] = w ? w[iu] : 1.0;
+            for (int m = 0; m < DD; ++m) pn[m] = x[m * ldx + i0];
+            wn = w ? w[i0] : 1.0;
         }
     }
-    for (; i < n; i += U * stride) {
-        double p[U][DD], wi[U];
+    int buf = 0;
+    // (the trip count is the workgroup's: every wave reaches every barrier; lanes past the end carry weight 0)
+    for (int64_t base = (int64_t)blockIdx.x * QSMC_BLOCK; base < n; base += stride, buf ^= 1) {
+        double p[DD];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-#pragma unroll
-            for (int m = 0; m < DD; ++m) p[u][m] = pn[u][m];
-            wi[u] = wn[u] * inv_norm;
-            const int64_t iu = i + (U + u) * stride;
-            if (iu < n) {
-#pragma unroll
-                for (int m = 0; m < DD; ++m) pn[u][m] = x[m * ldx + iu];
-                wn[u] = w ? w[iu] : 1.0;
-            } else {
-                wn[u] = 0.0;                                  // (a slot past the end: weight 0 on the last valid coordinates)
-            }
-        }
-        double c1[U][D > 0 ? D : 1], c2[U][D > 0 ? D : 1];
-        double cu[U], cd[U], step[U], istep[U], tu[U], td[U], dl[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-#pragma unroll
-            for (int m = 0; m < D; ++m) {
-                c1[u][m] = p[u][m] - ca.shift[m];
-                c2[u][m] = c1[u][m] * c1[u][m];
-            }
-            const double pr1 = hyp_pr1<KIND>(p[u], ca.base);
-            const double qr1 = 1.0 - pr1;
-            const bool valid = pr1 >= 0.0 && pr1 <= 1.0;
-            // odds p / q and q / p for the two walks from ONE reciprocal, 1 / (p q) (seed + two Newton steps, ~2 ulp: a walk
-            // of 12 steps stays inside 1e-14; two IEEE divisions were 28 of a particle's ~260 instructions); 0 where a walk
-            // starts on all of the mass or on none and must stay at 0 -- p or q exactly 0, and p below 1e-290, where every
-            // pmf but pmf(0) is below 1e-290 itself (q is >= 1.1e-16 or 0)
-            const double pq = pr1 * qr1;
-            const bool odds = valid && pq > 1.0e-290;
-            double rc = __builtin_amdgcn_rcp(odds ? pq : 1.0);
-            rc = fma(fma(-pq, rc, 1.0), rc, rc);
-            rc = fma(fma(-pq, rc, 1.0), rc, rc);
-            step[u] = odds ? pr1 * (pr1 * rc) : 0.0;
-            istep[u] = odds ? qr1 * (qr1 * rc) : 0.0;
-            double lp = 0.0, lq = 0.0;
-            if (LOG || !ca.use_powi) {                        // (the second condition is uniform)
-                lp = (valid && pr1 > 0.0) ? fast_log(pr1) : 0.0;
-                lq = (valid && pr1 < 1.0) ? fast_log1m(pr1) : 0.0;
-            }
-            dl[u] = lp - lq;
-            tu[u] = n_meas * lq + kf * dl[u];                 // ln pmf - ln C at the two starts
-            td[u] = n_meas * lq + kl * dl[u];
-            double su0, sd0;
-            if (ca.use_powi) {
-                su0 = (ca.comb_first * powi_uniform(pr1, ca.k_first)) * powi_uniform(qr1, (unsigned)n_meas - ca.k_first);
-                sd0 = (ca.comb_last * powi_uniform(pr1, ca.k_last)) * powi_uniform(qr1, (unsigned)n_meas - ca.k_last);
-            } else {
-                const bool inside = pr1 > 0.0 && pr1 < 1.0;
-                const double edge_u = pr1 == 0.0 ? (kf == 0.0 ? 1.0 : 0.0) : (kf == n_meas ? 1.0 : 0.0);
-                const double edge_d = pr1 == 0.0 ? (kl == 0.0 ? 1.0 : 0.0) : (kl == n_meas ? 1.0 : 0.0);
-                su0 = inside ? fast_exp(ca.lc_first + tu[u]) : edge_u;
-                sd0 = inside ? fast_exp(ca.lc_last + td[u]) : edge_d;
-            }
-            const double bad = wi[u] == 0.0 ? 0.0 : NAN;
-            cu[u] = valid ? wi[u] * su0 : bad;
-            cd[u] = valid ? wi[u] * sd0 : bad;
-        }
-        constexpr int B1 = 1 + (LOG ? 1 : 0);
+        for (int m = 0; m < DD; ++m) p[m] = pn[m];
+        const double wi = wn * inv_norm;
         {
+            const int64_t inx = base + stride + threadIdx.x;
+            if (inx < n) {
 #pragma unroll
-            for (int j = 0; j < NH; ++j) {
-                double *a = s + j * PER, *b = s + (NH + j) * PER;
+                for (int m = 0; m < DD; ++m) pn[m] = x[m * ldx + inx];
+                wn = w ? w[inx] : 1.0;
+            } else {
+                wn = 0.0;
+            }
+        }
+        double c1[D > 0 ? D : 1], c2[D > 0 ? D : 1];
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    a[0] += cu[u];
-                    b[0] += cd[u];
-                    if (LOG) {
-                        a[1] = fma(cu[u], tu[u], a[1]);
-                        b[1] = fma(cd[u], td[u], b[1]);
-                        tu[u] += dl[u];
-                        td[u] -= dl[u];
-                    }
+        for (int m = 0; m < D; ++m) {
+            c1[m] = p[m] - ca.shift[m];
+            c2[m] = c1[m] * c1[m];
+        }
+        const double pr1 = hyp_pr1<KIND>(p, ca.base);
+        const double qr1 = 1.0 - pr1;
+        const bool valid = pr1 >= 0.0 && pr1 <= 1.0;
+        const double pq = pr1 * qr1;                          // (odds p / q and q / p from ONE reciprocal, 1 / (p q): seed + two Newton steps, ~2 ulp -- a walk of 12 steps stays
+        // inside 1e-14; two IEEE divisions were 28 of a particle's ~260 instructions.  0 where a walk starts on all of the mass
+        // or on none and must stay at 0: p or q exactly 0, and p below 1e-290, where every pmf but pmf(0) is below 1e-290)
+        const bool odds = valid && pq > 1.0e-290;
+        double rc = __builtin_amdgcn_rcp(odds ? pq : 1.0);
+        rc = fma(fma(-pq, rc, 1.0), rc, rc);
+        rc = fma(fma(-pq, rc, 1.0), rc, rc);
+        const double step = odds ? pr1 * (pr1 * rc) : 0.0;
+        const double istep = odds ? qr1 * (qr1 * rc) : 0.0;
+        double lp = 0.0, lq = 0.0;
+        if (LOG || !ca.use_powi) {                            // (the second condition is uniform)
+            lp = (valid && pr1 > 0.0) ? fast_log(pr1) : 0.0;
+            lq = (valid && pr1 < 1.0) ? fast_log1m(pr1) : 0.0;
+        }
+        const double dl = lp - lq;
+        const double tu = n_meas * lq + kf * dl, td = n_meas * lq + kl * dl;
+        double su0, sd0;
+        if (ca.use_powi) {
+            su0 = (ca.comb_first * powi_uniform(pr1, ca.k_first)) * powi_uniform(qr1, (unsigned)n_meas - ca.k_first);
+            sd0 = (ca.comb_last * powi_uniform(pr1, ca.k_last)) * powi_uniform(qr1, (unsigned)n_meas - ca.k_last);
+        } else {
+            const bool inside = pr1 > 0.0 && pr1 < 1.0;
+            const double edge_u = pr1 == 0.0 ? (kf == 0.0 ? 1.0 : 0.0) : (kf == n_meas ? 1.0 : 0.0);
+            const double edge_d = pr1 == 0.0 ? (kl == 0.0 ? 1.0 : 0.0) : (kl == n_meas ? 1.0 : 0.0);
+            su0 = inside ? fast_exp(ca.lc_first + tu) : edge_u;
+            sd0 = inside ? fast_exp(ca.lc_last + td) : edge_d;
+        }
+        const double bad = wi == 0.0 ? 0.0 : NAN;
+        const double cu = valid ? wi * su0 : bad, cd = valid ? wi * sd0 : bad;
+        // mine: this wave's direction of my particle; theirs: the other direction, for the partner
+        double cur[2], stp[2], t[2], dls[2], a1[2][D > 0 ? D : 1], a2[2][D > 0 ? D : 1];
+        cur[0] = down ? cd : cu;
+        stp[0] = down ? istep : step;
+        t[0] = down ? td : tu;
+        dls[0] = down ? -dl : dl;
 #pragma unroll
-                    for (int m = 0; m < D; ++m) {
-                        a[B1 + m] = fma(cu[u], c1[u][m], a[B1 + m]);
-                        a[B1 + D + m] = fma(cu[u], c2[u][m], a[B1 + D + m]);
-                        b[B1 + m] = fma(cd[u], c1[u][m], b[B1 + m]);
-                        b[B1 + D + m] = fma(cd[u], c2[u][m], b[B1 + D + m]);
-                    }
-                    cu[u] *= step[u];
-                    cd[u] *= istep[u];
+        for (int m = 0; m < D; ++m) { a1[0][m] = c1[m]; a2[0][m] = c2[m]; }
+        xch[buf][0][threadIdx.x] = down ? cu : cd;
+        xch[buf][1][threadIdx.x] = down ? step : istep;
+        if (LOG) {
+            xch[buf][2][threadIdx.x] = down ? tu : td;
+            xch[buf][3][threadIdx.x] = down ? dl : -dl;
+        }
+#pragma unroll
+        for (int m = 0; m < D; ++m) {
+            xch[buf][2 + (LOG ? 2 : 0) + m][threadIdx.x] = c1[m];
+            xch[buf][2 + (LOG ? 2 : 0) + D + m][threadIdx.x] = c2[m];
+        }
+        __syncthreads();
+        cur[1] = xch[buf][0][ptid];
+        stp[1] = xch[buf][1][ptid];
+        t[1] = LOG ? xch[buf][LOG ? 2 : 0][ptid] : 0.0;
+        dls[1] = LOG ? xch[buf][LOG ? 3 : 0][ptid] : 0.0;
+#pragma unroll
+        for (int m = 0; m < D; ++m) {
+            a1[1][m] = xch[buf][2 + (LOG ? 2 : 0) + m][ptid];
+            a2[1][m] = xch[buf][2 + (LOG ? 2 : 0) + D + m][ptid];
+        }
+#pragma unroll
+        for (int j = 0; j < NH; ++j) {
+            double *a = s + j * PER;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                a[0] += cur[u];
+                if (LOG) {
+                    a[1] = fma(cur[u], t[u], a[1]);
+                    t[u] += dls[u];
                 }
+#pragma unroll
+                for (int m = 0; m < D; ++m) {
+                    a[B1 + m] = fma(cur[u], a1[u][m], a[B1 + m]);
+                    a[B1 + D + m] = fma(cur[u], a2[u][m], a[B1 + D + m]);
+                }
+                cur[u] *= stp[u];
             }
         }
     }
-    block_publish<NS>(s, 0.0, ro);
+    // partial sums of the workgroup: waves 0, 2 hold the upward slots, 1, 3 the downward ones
+    const int lane = threadIdx.x & (QSMC_WAVE - 1);
+#pragma unroll
+    for (int k = 0; k < NSH; ++k) s[k] = wave_sum(s[k]);
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < NSH; ++k) red[wave][k] = s[k];
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k <= 2 * NSH; k += QSMC_BLOCK) {
+        double tsum = 0.0;
+        if (k < 2 * NSH) {
+            const int dir = k / NSH, kk = k - dir * NSH;
+            tsum = red[dir][kk] + red[dir + 2][kk];
+        }
+        ro.partials[(size_t)k * gridDim.x + blockIdx.x] = tsum;       // (entry 2 NSH: the unused minimum slot)
+    }
 }
 
 // mode 0: w_out = (w_in / norm) * L   (generic-model slow path)

@@ -620,7 +620,8 @@ static int chain2_enqueue(qsmc_ctx *h, const qsmc_model_t *model, const double *
     // 2048 workgroups on 512 - 768 resident slots ends in a ragged last round
     static const int per_cu = [] {
         int b = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_hyp_sums_chain2<KIND, WHAT, NH>, QSMC_BLOCK, 0) != hipSuccess || b < 1) b = 2;
+        const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_hyp_sums_chain2<KIND, WHAT, NH>, QSMC_BLOCK, 0);
+        if (e != hipSuccess || b < 1) b = 2;
         return b > 8 ? 8 : b;
     }();
     int grid = grid_for(n, QSMC_BLOCK * 4);
@@ -714,7 +715,7 @@ template <int KIND, int WHAT, int NH>
 static int chain2_go(qsmc_ctx *h, Chain2Queue &q, const qsmc_model_t *model, const double *x, int64_t ldx, int64_t n,
                      const double *w, double norm, const qsmc_expparam_t *exp, const int64_t *outcomes, int n_o,
                      const double *shift, double *out_host, hipStream_t s) {
-    constexpr int NS = chain2_sums<KIND, WHAT, NH>();
+    constexpr int NS = 2 * chain2_lane_sums<KIND, WHAT, NH>();
     if (q.count == CHAIN2_PENDING_MAX || q.off + NS > SQRT_MAPPED_DOUBLES) {
         const int rc = chain2_flush(h, q, s);
         if (rc) return rc;
@@ -758,7 +759,9 @@ static int hyp_dispatch(qsmc_ctx *h, Chain2Queue &q, const qsmc_model_t *model, 
     // slots per pass of the two-ended walk: 2 NH, NH from the registers the sums take (2 NH x PER doubles: ~56 for three
     // waves per SIMD; the moments at D = 1 take 78 -- a 26-outcome experiment in ONE pass at two waves per SIMD, 138 us,
     // against two passes of 13 at three waves, 216 us)
-    constexpr int NH_LOG = 13, NH_MOM = D <= 1 ? 13 : (D <= 3 ? 4 : 3), NH_ALL = D <= 1 ? 7 : (D <= 3 ? 4 : 3);
+    // slots per pass of the two-ended walk: 2 NH, NH from the registers the sums of ONE direction take in a lane (NH x PER
+    // doubles: <= 39 for four waves per SIMD, <= 58 for three)
+    constexpr int NH_LOG = 13, NH_MOM = D <= 1 ? 13 : (D <= 3 ? 8 : 6), NH_ALL = D <= 1 ? 13 : (D <= 3 ? 7 : 5);
     const int chain_slots = 2 * (what == HYP_WHAT_LOG ? NH_LOG : (what == HYP_WHAT_MOM ? NH_MOM : NH_ALL));
     const int chain_passes = (n_o + chain_slots - 1) / chain_slots;
     const int chain_take = (n_o + chain_passes - 1) / chain_passes;
@@ -770,12 +773,11 @@ static int hyp_dispatch(qsmc_ctx *h, Chain2Queue &q, const qsmc_model_t *model, 
             if constexpr (BINOMIAL) {
                 const int64_t *oc = outcomes + done;
                 double *oh = out_host + (size_t)done * PER;
-                if (what == HYP_WHAT_LOG)
-                    rc = chain2_go<KIND, HYP_WHAT_LOG, NH_LOG>(h, q, model, x, ldx, n, w, norm, exp, oc, take, shift, oh, s);
-                else if (what == HYP_WHAT_MOM)
-                    rc = chain2_go<KIND, HYP_WHAT_MOM, NH_MOM>(h, q, model, x, ldx, n, w, norm, exp, oc, take, shift, oh, s);
-                else
-                    rc = chain2_go<KIND, HYP_WHAT_LOG | HYP_WHAT_MOM, NH_ALL>(h, q, model, x, ldx, n, w, norm, exp, oc, take, shift, oh, s);
+#define CG(W, N_) chain2_go<KIND, W, N_>(h, q, model, x, ldx, n, w, norm, exp, oc, take, shift, oh, s)
+                if (what == HYP_WHAT_LOG) rc = CG(HYP_WHAT_LOG, NH_LOG);
+                else if (what == HYP_WHAT_MOM) rc = CG(HYP_WHAT_MOM, NH_MOM);
+                else rc = CG(HYP_WHAT_LOG | HYP_WHAT_MOM, NH_ALL);
+#undef CG
             } else
                 rc = QSMC_ERR_INVALID;
         } else if ((rc = chain2_flush(h, q, s)) != QSMC_OK) {
