@@ -130,7 +130,11 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_tomo_canon_list(Basis B, double 
         double p[D];
 #pragma unroll
         for (int a = 0; a < D; ++a) p[a] = x[a * ldx + i];
-        if (tomo_canon_particle<DIM>(B, p, allow_subnormalized != 0)) {
+        auto reload = [&](double *pp) {                      // (a listed particle without a negative eigenvalue: rare)
+#pragma unroll
+            for (int a = 0; a < D; ++a) pp[a] = x[a * ldx + i];
+        };
+        if (tomo_canon_particle<DIM>(B, p, allow_subnormalized != 0, reload)) {
 #pragma unroll
             for (int a = 0; a < D; ++a) x[a * ldx + i] = p[a];
         }

@@ -656,7 +656,9 @@ __host__ __device__ inline double j_rsqrt(double x) { return 1.0 / sqrt(x); }
 __host__ __device__ inline double j_rcp(double x) { return 1.0 / x; }
 #endif
 
-// In: Hermitian A (full storage).  Out: any eigenvalue negative?  If so R = V max(lambda, 0) V^H (tomography/models.py:185-192).
+// In: Hermitian A, LOWER triangle (Ar[r][c], Ai[r][c] for r >= c; the upper entries are never touched: a full iterate kept
+// both mirror images live across the sweep loop -- 12 more doubles in a kernel at 200 VGPRs).  Out: any eigenvalue
+// negative?  If so R = V max(lambda, 0) V^H (tomography/models.py:185-192).
 template <int DIM>
 __host__ __device__ inline bool jacobi_clamp(double (&Ar)[DIM][DIM], double (&Ai)[DIM][DIM], double (&Rr)[DIM][DIM],
                                              double (&Ri)[DIM][DIM]) {
@@ -665,6 +667,13 @@ __host__ __device__ inline bool jacobi_clamp(double (&Ar)[DIM][DIM], double (&Ai
     //  its intermediate bits -- the reference's eigh does not either, G5 holds the RESULT to 1e-12 -- and `on` contracts
     //  inside source expressions only, so every kernel that inlines this function gets the same fmas)
 #pragma clang fp contract(on)
+    // a_rc for any (r, c) from the stored triangle (indices are compile-time constants after unrolling: the branches fold)
+    auto GR = [&](int r, int c) -> double { return r >= c ? Ar[r][c] : Ar[c][r]; };
+    auto GI = [&](int r, int c) -> double { return r > c ? Ai[r][c] : (r == c ? 0.0 : -Ai[c][r]); };
+    auto SET = [&](int r, int c, double re, double im) {
+        if (r >= c) { Ar[r][c] = re; Ai[r][c] = im; }
+        else { Ar[c][r] = re; Ai[c][r] = -im; }
+    };
     double Vr[DIM][DIM], Vi[DIM][DIM];
 #pragma unroll
     for (int r = 0; r < DIM; ++r)
@@ -681,15 +690,20 @@ __host__ __device__ inline bool jacobi_clamp(double (&Ar)[DIM][DIM], double (&Ai
 #pragma unroll
         for (int r = 0; r < DIM; ++r)
 #pragma unroll
-            for (int c = r + 1; c < DIM; ++c) off += Ar[r][c] * Ar[r][c] + Ai[r][c] * Ai[r][c];
-        if (off <= 1e-34 * diag2) break;
+            for (int c = r + 1; c < DIM; ++c) off += Ar[c][r] * Ar[c][r] + Ai[c][r] * Ai[c][r];
+        // converged: every off-diagonal entry at machine epsilon of the diagonal's norm (sum of squares <= 1e-30 diag2, i.e.
+        // |a_rc| <= 1e-15 ||diag||: what eigh delivers; the iteration squares `off` per sweep, and the former 1e-34 bought a
+        // whole further sweep whenever a sweep landed between the two).  Pivots already below their share of that bound
+        // are not rotated.
+        if (off <= 1e-30 * diag2) break;
+        const double skip2 = (1e-30 / (DIM * (DIM - 1) / 2)) * diag2;
 #pragma unroll
         for (int pI = 0; pI < DIM; ++pI)
 #pragma unroll
             for (int q = pI + 1; q < DIM; ++q) {
-                const double hr = Ar[pI][q], hi = Ai[pI][q];
+                const double hr = GR(pI, q), hi = GI(pI, q);
                 const double mag2 = hr * hr + hi * hi;
-                if (mag2 < 1e-290) continue;
+                if (mag2 < 1e-290 || mag2 <= skip2) continue;
                 // phase e^{i phi} = h / |h|
                 const double imag = j_rsqrt(mag2);
                 const double er = hr * imag, ei = hi * imag;
@@ -701,7 +715,7 @@ __host__ __device__ inline bool jacobi_clamp(double (&Ar)[DIM][DIM], double (&Ai
                 const double sn = tt * cs;
                 // A <- J^H A J with J = [[c, s e^{i phi}], [-s e^{-i phi}, c]] on (p, q), using that A stays Hermitian:
                 // only the entries (k, p), (k, q) of the OTHER rows are rotated (col_p' = c col_p - s conj(e) col_q,
-                // col_q' = s e col_p + c col_q) and mirrored; the 2 x 2 pivot block has the closed form
+                // col_q' = s e col_p + c col_q); the 2 x 2 pivot block has the closed form
                 // a_pp' = a_pp - t |h|, a_qq' = a_qq + t |h|, a_pq' = 0 (t = tan of the rotation angle).  Round 2 rotated all
                 // four rows' columns and then all four columns' rows -- 224 multiply-adds per pivot for what is 56 here;
                 // with the eigenvector update (unchanged) a pivot costs ~230 instead of ~400 flops, and this kernel runs
@@ -710,13 +724,13 @@ __host__ __device__ inline bool jacobi_clamp(double (&Ar)[DIM][DIM], double (&Ai
 #pragma unroll
                 for (int r = 0; r < DIM; ++r) {
                     if (r != pI && r != q) {
-                        const double apr = Ar[r][pI], api = Ai[r][pI], aqr = Ar[r][q], aqi = Ai[r][q];
+                        const double apr = GR(r, pI), api = GI(r, pI), aqr = GR(r, q), aqi = GI(r, q);
                         const double npr = cs * apr - sn * (er * aqr + ei * aqi);
                         const double npi = cs * api - sn * (er * aqi - ei * aqr);
                         const double nqr = sn * (er * apr - ei * api) + cs * aqr;
                         const double nqi = sn * (er * api + ei * apr) + cs * aqi;
-                        Ar[r][pI] = npr; Ai[r][pI] = npi; Ar[pI][r] = npr; Ai[pI][r] = -npi;
-                        Ar[r][q] = nqr; Ai[r][q] = nqi; Ar[q][r] = nqr; Ai[q][r] = -nqi;
+                        SET(r, pI, npr, npi);
+                        SET(r, q, nqr, nqi);
                     }
                     const double vpr = Vr[r][pI], vpi = Vi[r][pI], vqr = Vr[r][q], vqi = Vi[r][q];
                     Vr[r][pI] = cs * vpr - sn * (er * vqr + ei * vqi);
@@ -726,7 +740,8 @@ __host__ __device__ inline bool jacobi_clamp(double (&Ar)[DIM][DIM], double (&Ai
                 }
                 Ar[pI][pI] -= th;
                 Ar[q][q] += th;
-                Ar[pI][q] = 0.0; Ai[pI][q] = 0.0; Ar[q][pI] = 0.0; Ai[q][pI] = 0.0;
+                Ar[q][pI] = 0.0;
+                Ai[q][pI] = 0.0;
             }
     }
     bool any_neg = false;
@@ -840,14 +855,18 @@ struct TomoPauli2 {
     }
 };
 
-// Returns true if p[] was modified.
-template <int DIM, class Basis>
-__host__ __device__ inline bool tomo_canon_particle(const Basis &B, double *p, bool allow_subnormalized) {
+// Returns true if p[] was modified.  `reload(p)` fetches p again where it is still needed after the eigendecomposition
+// (no negative eigenvalue: only the trace renormalisation is left) -- the D coordinates do not stay live across the
+// Jacobi sweeps then (32 VGPRs at D = 16); a no-op functor keeps them.
+struct TomoKeepP { __host__ __device__ inline void operator()(double *) const {} };
+template <int DIM, class Basis, class Reload = TomoKeepP>
+__host__ __device__ inline bool tomo_canon_particle(const Basis &B, double *p, bool allow_subnormalized, Reload reload = Reload{}) {
     constexpr int D = DIM * DIM;
     double Ar[DIM][DIM], Ai[DIM][DIM], Rr[DIM][DIM], Ri[DIM][DIM];
-    B.build(p, Ar, Ai, false);
+    B.build(p, Ar, Ai, true);                             // (jacobi_clamp works on the lower triangle)
     const bool any_neg = jacobi_clamp<DIM>(Ar, Ai, Rr, Ri);
     if (any_neg) B.expand(Rr, Ri, p);
+    else reload(p);
     if (!allow_subnormalized) {                           // :194-209 (x / (x_0 sqrt(dim)): one reciprocal, D products)
         const double inv = 1.0 / (p[0] * sqrt((double)DIM));
 #pragma unroll
