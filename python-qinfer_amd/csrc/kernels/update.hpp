@@ -238,7 +238,8 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_update_fused(
         double tsum = 0.0;
         // (D <= 2 only.  Round 3 tried the same form for RB, d = 3 / 4: 16 loads in flight per wave but 174 / 204 VGPRs,
         //  two waves per SIMD instead of four -- 94 -> 98 us at N = 1.25e7, Binomial(RB) 125 -> 143 us.  Round 4: HALF a
-        //  tile's loads at a time -- still 173 / 203 VGPRs: 96-98 -> 98 us, Binomial(RB) 125 -> 137 us.)
+        //  tile's loads at a time -- still 173 / 203 VGPRs: 96-98 -> 98 us, Binomial(RB) 125 -> 137 us.  And one sub-tile
+        //  AHEAD of the arithmetic, held to 168 VGPRs for three waves per SIMD (12 spills): 95.8 -> 94.9 us -- not kept.)
         if (VEC == 2 && D <= 2 && base + TILE <= n) {
             // full tile: every load of the tile is issued before the first likelihood is evaluated, so a wave
             // has UPD_UNROLL x (1 + d) 16-byte loads in flight instead of 1 + d (the guarded path below
