@@ -2574,7 +2574,8 @@ def test_design_chain_kernel_vs_lanes_kernel_edges():
     subprocesses), on clouds with the cases the walk
     folds into its start value: pr1 exactly 0 (omega = 0), weights that are exactly 0, very small and very large pr1, for
     n_meas from 1 to 200 (integer-power and exponential start values; one to eight passes, queued over the experiments of
-    a call and collected after one wait) and designs that mix n_meas.  Every entry of the per-outcome sums agrees to 1e-11 of
+    a call and collected after one wait) and designs that mix n_meas; and for Binomial(RB), d = 3 (eight slots a
+    direction, 7 sums a slot), against the thread-per-particle kernel k_hyp_sums (the lanes kernel is d = 1 only).  Every entry of the per-outcome sums agrees to 1e-11 of
     the experiment's largest entry (the walk's error is ~3 ulp per step; what a pass's first pmf loses to underflow is
     below 1e-150 of the sums)."""
     import subprocess
@@ -2614,6 +2615,22 @@ for n_meas in (1, 2, 12, 13, 14, 25, 26, 40, 64, 65, 100, (5, 25, 70), (200, 3, 
             assert part.shape == full.shape
             scale = np.abs(full).max()
             assert np.allclose(part[:, cols], full[:, cols], rtol=1e-10, atol=1e-12 * scale), (n_meas, what)
+# d = 3: Binomial(RB) -- the walk against the thread-per-particle kernel (k_hyp_sums; the lanes kernel is d = 1 only)
+xr = np.column_stack([0.8 + 0.2 * rs.random_sample(20_000), 0.5 * rs.random_sample(20_000), 0.5 * rs.random_sample(20_000)])
+xr[:40, 0] = 1.0
+xr[40:80, 1] = 0.0
+class FixedRB(qi.Distribution):
+    n_rvs = 3
+    def sample(self, n=1): return xr.copy()
+mr = qi.BinomialModel(qi.RandomizedBenchmarkingModel())
+ur = qi.SMCUpdater(mr, 20_000, FixedRB())
+for n_meas in (1, 7, 25, 40, (3, 64, 90)):
+    ep = np.empty((3,), dtype=mr.expparams_dtype)
+    ep["m"], ep["n_meas"] = [1, 12, 150], n_meas
+    for sums in ur._hyp_sums(ep):
+        out.append(np.asarray(sums).ravel())
+    out.append(np.asarray(ur.bayes_risk(ep)))
+    out.append(np.asarray(ur.expected_information_gain(ep)))
 np.save(sys.argv[1], np.concatenate(out))
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     import tempfile
