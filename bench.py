@@ -244,33 +244,35 @@ def run_other_config(qi, eng, torch, spec, warmup, comm=None, n_override=None, s
     #  before anything is on the GPU)
     gc.collect()
     gc.disable()
-    upd = qi.SMCUpdater(spec["model"], n, spec["prior"](), device_rng=True, seed=0, comm=comm)
-    for k in range(min(warmup, len(eps))):                      # untimed: allocator growth, first-launch costs
-        upd.update(outs[k], eps[k])
-    upd.resample()
-    upd.update(outs[0], eps[0])
-    upd.reset()
-    upd._resample_count = 0
-    sync()
-    eng.set_profiling(0 if os.environ.get("QSMC_BENCH_NO_EVENTS") else 1)      # (no events: for kernel-trace gap profiles)
-    t0 = time.perf_counter()
-    for k in range(len(eps)):
-        upd.update(outs[k], eps[k])
-    sync()
-    wall = time.perf_counter() - t0
-    ms, tags = eng.profile_read()
-    eng.set_profiling(0)
-    # the same loop again without kernel events: the throughput figure (events drain the queue around each launch)
-    upd.reset()
-    rc0 = upd.resample_count
-    rb0 = 0 if comm is None else comm.n_rebalances
-    sync()
-    t0 = time.perf_counter()
-    for k in range(len(eps)):
-        upd.update(outs[k], eps[k])
-    sync()
-    wall = time.perf_counter() - t0
-    gc.enable()
+    try:                                                        # (a failure in here must not leave the collector off)
+        upd = qi.SMCUpdater(spec["model"], n, spec["prior"](), device_rng=True, seed=0, comm=comm)
+        for k in range(min(warmup, len(eps))):                  # untimed: allocator growth, first-launch costs
+            upd.update(outs[k], eps[k])
+        upd.resample()
+        upd.update(outs[0], eps[0])
+        upd.reset()
+        upd._resample_count = 0
+        sync()
+        eng.set_profiling(0 if os.environ.get("QSMC_BENCH_NO_EVENTS") else 1)  # (no events: for kernel-trace gap profiles)
+        t0 = time.perf_counter()
+        for k in range(len(eps)):
+            upd.update(outs[k], eps[k])
+        sync()
+        wall = time.perf_counter() - t0
+        ms, tags = eng.profile_read()
+        eng.set_profiling(0)
+        # the same loop again without kernel events: the throughput figure (events drain the queue around each launch)
+        upd.reset()
+        rc0 = upd.resample_count
+        rb0 = 0 if comm is None else comm.n_rebalances
+        sync()
+        t0 = time.perf_counter()
+        for k in range(len(eps)):
+            upd.update(outs[k], eps[k])
+        sync()
+        wall = time.perf_counter() - t0
+    finally:
+        gc.enable()
     if world > 1:
         wt = torch.tensor([wall], dtype=torch.float64, device="cuda" if comm.backend == "nccl" else "cpu")
         torch.distributed.all_reduce(wt, op=torch.distributed.ReduceOp.MAX)
@@ -454,6 +456,8 @@ def main():
     ap.add_argument("--cpu-data", type=int, default=20, help="data of the schedule the CPU baseline runs")
     ap.add_argument("--event-stride", type=int, default=0,
                     help="put hipEvents on every N-th launch of each timed kernel kind (0 = steps // 5, 1..8)")
+    ap.add_argument("--strong-particles", type=float, default=1e7,
+                    help="particles IN TOTAL of the strong-scaling leg of a sharded run (BASELINE.json: 1e7 at 1/2/4/8 GPU)")
     ap.add_argument("--force-comm", action="store_true",
                     help="run the sharded code path even with one rank (validation on a 1-GPU box)")
     args = ap.parse_args()
@@ -541,33 +545,35 @@ def main():
         #  back up, against 0.077 for the same 20 data in a busy process)
         gc.collect()
         gc.disable()
-        for k in range(args.warmup):
-            upd.update(int(outcomes[k % N_SCHEDULE]), ts[k % N_SCHEDULE:k % N_SCHEDULE + 1])
-        upd.resample()
-        upd.update(int(outcomes[0]), ts[0:1])
-        upd.reset()
-        k_steps(upd)
-        walls = []
-        for rep in range(1 + repeats):
+        try:                                                    # (a failure in here must not leave the collector off)
+            for k in range(args.warmup):
+                upd.update(int(outcomes[k % N_SCHEDULE]), ts[k % N_SCHEDULE:k % N_SCHEDULE + 1])
+            upd.resample()
+            upd.update(int(outcomes[0]), ts[0:1])
             upd.reset()
-            upd._resample_count = 0
-            # a launch that carries start/stop events drains the queue around itself (measured: 10.7 us per step
-            # with every launch timed), so every `stride`-th launch of each kernel kind is timed
-            eng.set_profiling(stride if (events and rep == 0) else 0)
-            # (in the timed region only the dominant kernel carries events -- the update, tags 0 and 2: what `roofline`
-            #  is made of; the sampler / counts figures come from the census right after, every launch timed)
-            eng.set_profiling_tags((0, 2) if (events and rep == 0 and world == 1 and comm is None) else None)
-            barrier()
-            t0 = time.perf_counter()
             k_steps(upd)
-            barrier()
-            walls.append(time.perf_counter() - t0)
-            if rep == 0:
-                # (est_mean is a collective on a sharded cloud: every rank is here)
-                first_pass.append((upd.resample_count,) + tuple(eng.profile_read() if events else (np.zeros(0), np.zeros(0)))
-                                  + (float(upd.est_mean()[0]),))
-        gc.enable()
-        eng.set_profiling_tags(None)
+            walls = []
+            for rep in range(1 + repeats):
+                upd.reset()
+                upd._resample_count = 0
+                # a launch that carries start/stop events drains the queue around itself (measured: 10.7 us per step
+                # with every launch timed), so every `stride`-th launch of each kernel kind is timed
+                eng.set_profiling(stride if (events and rep == 0) else 0)
+                # (in the timed region only the dominant kernel carries events -- the update, tags 0 and 2: what `roofline`
+                #  is made of; the sampler / counts figures come from the census right after, every launch timed)
+                eng.set_profiling_tags((0, 2) if (events and rep == 0 and world == 1 and comm is None) else None)
+                barrier()
+                t0 = time.perf_counter()
+                k_steps(upd)
+                barrier()
+                walls.append(time.perf_counter() - t0)
+                if rep == 0:
+                    # (est_mean is a collective on a sharded cloud: every rank is here)
+                    first_pass.append((upd.resample_count,) + tuple(eng.profile_read() if events else (np.zeros(0), np.zeros(0)))
+                                      + (float(upd.est_mean()[0]),))
+        finally:
+            gc.enable()
+            eng.set_profiling_tags(None)
         return walls[0], walls[1:]
 
     first_pass = []        # (resamples, kernel durations [ms], kernel tags, posterior mean) of each call's contract pass
@@ -643,6 +649,36 @@ def main():
     del upd
     torch.cuda.empty_cache()
 
+    def shard_preview(n_shard):
+        """The headline workload on ONE rank's share of a strong-scaling run (1e7 particles over 8 GPUs = 1.25e6 each):
+        what a GPU of the 8-GPU point does between two collectives, measured where it can be -- on one GPU, no
+        communication.  At this size a datum is launch / round-trip bound, not bandwidth bound."""
+        upd_p = qi.SMCUpdater(qi.SimplePrecessionModel(), n_shard, qi.UniformDistribution([0, 1]), device_rng=True, seed=0)
+        wall_p, _ = timed_pass(upd_p, events=False)
+        res_p, _, _, mean_p = first_pass[-1]
+        upd_p.reset()
+        eng.set_profiling(1)
+        for k in range(min(64, N_SCHEDULE)):
+            upd_p.update(int(outcomes[k]), ts[k:k + 1])
+        torch.cuda.synchronize()
+        p_ms, p_tags = eng.profile_read()
+        eng.set_profiling(False)
+        kt = kernel_table(p_ms, p_tags)
+        out = {"workload": "SimplePrecessionModel SMCUpdater.update, %.3g particles (one rank's share of 1e7 over 8 GPUs), "
+                           "same schedule and resampler as the headline, one GPU, no collective" % n_shard,
+               "particles": n_shard, "steps": args.steps, "value": n_shard * args.steps / wall_p,
+               "ms_per_step": wall_p / args.steps * 1e3, "resamples": res_p, "posterior_mean": mean_p,
+               "eight_of_these_without_a_collective": 8 * n_shard * args.steps / wall_p}
+        if "update" in kt:
+            out["update_kernel"] = frac_entry("k_update_fused<PRECESSION,VEC=2,ONES=false>", kt["update"]["avg_us"],
+                                              24.0 * n_shard, kt["update"]["launches"], {"bytes_per_particle": 24})
+        if "sample" in kt:
+            out["resample_kernel"] = frac_entry("k_bucket_sample<D=1,512>", kt["sample"]["avg_us"], 24.0 * n_shard,
+                                                kt["sample"]["launches"], {"bytes_per_particle": 24})
+        del upd_p
+        torch.cuda.empty_cache()
+        return out
+
     extras = {}
     if rank == 0 and world == 1 and comm is None and not args.no_other_configs:
         with warnings.catch_warnings():
@@ -651,6 +687,10 @@ def main():
                 extras["roofline_beyond_l3"] = beyond_l3(qi, eng, torch)
             except Exception as e:  # noqa: BLE001
                 extras["roofline_beyond_l3"] = {"error": repr(e)}
+            try:
+                extras["strong_scaling_shard_preview"] = shard_preview(max(4096, int(args.strong_particles) // 8))
+            except Exception as e:  # noqa: BLE001
+                extras["strong_scaling_shard_preview"] = {"error": repr(e)}
             oc = {}
             for spec in other_config_specs(qi):
                 if spec.get("extra"):
@@ -778,44 +818,75 @@ def main():
         line = None
 
     # ---- the transports of the per-datum reduction, both inside the line (sharded runs only)
+    import threading
     done = {"printed": False}
+    line_lock = threading.RLock()      # the main thread, the watchdog timer and the SIGTERM watcher all touch `line`
 
     def emit():
-        if rank == 0 and not done["printed"]:
-            done["printed"] = True
-            drain_c_stdio()
-            print(json.dumps(line), flush=True)
+        # `printed` turns true only AFTER the line has been flushed, and the whole thing sits under the lock: a side
+        # thread (watchdog / SIGTERM watcher) that calls os._exit right after its own emit() either finds the line already
+        # out, or prints it itself -- never exits between a set flag and an unflushed line, never dumps a half-edited dict
+        with line_lock:
+            if rank == 0 and not done["printed"]:
+                drain_c_stdio()
+                print(json.dumps(line), flush=True)
+                done["printed"] = True
+
+    def set_line(path, value):
+        """line[path[0]][path[1]]... = value, under the lock (rank 0 only holds a line)."""
+        if rank != 0:
+            return
+        with line_lock:
+            if done["printed"]:
+                return
+            node = line
+            for k_ in path[:-1]:
+                node = node[k_]
+            node[path[-1]] = value
 
     watchdog = None
     if comm is not None:
         key = "rccl" if comm.transport == "rccl" else ("shm" if comm.transport_name == "host shared memory" else "backend")
-        if rank == 0:
-            line["transports"] = {key: {"per_datum_collective": comm.transport_name, "value": line["value"],
-                                        "ms_per_step": line["ms_per_step"], "resamples": resamples_timed,
-                                        "posterior_mean": posterior_mean, "headline": True}}
+        set_line(("transports",), {key: {"per_datum_collective": comm.transport_name, "value": None if line is None else line["value"],
+                                         "ms_per_step": None if line is None else line["ms_per_step"],
+                                         "resamples": resamples_timed, "posterior_mean": posterior_mean, "headline": True}})
+        set_line(("config", "headline_transport"), key)       # which transport `value` was measured under
         want_sharded = not args.no_other_configs
+        want_strong = (world > 1 or args.force_comm) and not os.environ.get("QSMC_BENCH_NO_STRONG")
         want_rccl = ((world > 1 or os.environ.get("QSMC_BENCH_FORCE_RCCL_PASS")) and comm.transport != "rccl"
                      and not os.environ.get("QSMC_BENCH_NO_RCCL_PASS"))
-        # everything after the headline (the sharded configs 4 and 5, the RCCL pass) runs under a watchdog: a rank
-        # that hangs or a collective that never returns must not take the line with it.  Past the deadline rank 0
-        # prints the line with the time-out recorded against the stage that was running, and every rank leaves.
-        import threading
+        # everything after the headline (the strong-scaling leg, the sharded configs 4 and 5, the RCCL pass) runs under a
+        # watchdog: a rank that hangs or a collective that never returns must not take the line with it.  Past the
+        # deadline rank 0 prints the line with the time-out recorded against the stage that was running, and every rank
+        # leaves.
         deadline = float(os.environ.get("QSMC_BENCH_DEADLINE", os.environ.get(
-            "QSMC_BENCH_RCCL_DEADLINE", "420" if want_sharded else "60")))
-        stage = {"name": "sharded_configs" if want_sharded else "rccl"}
+            "QSMC_BENCH_RCCL_DEADLINE", "420" if want_sharded else "90")))
+        stage = {"name": "strong_scaling" if want_strong else ("sharded_configs" if want_sharded else "rccl")}
 
-        def give_up():
-            if rank == 0:
-                msg = {"error": "no result within %.0f s of the headline (watchdog), stage: %s" % (deadline, stage["name"])}
-                if stage["name"] == "sharded_configs":
+        def mark_stage(msg):
+            """Record `msg` against the stage that was running (rank 0, under the line's lock)."""
+            if rank != 0:
+                return
+            with line_lock:
+                if done["printed"]:
+                    return
+                name = stage["name"]
+                if name == "strong_scaling":
+                    line["strong_scaling"] = msg
+                elif name == "strong_scaling_rccl":
+                    line["strong_scaling"].setdefault("transports", {})["rccl"] = msg
+                elif name == "sharded_configs":
                     line["sharded_configs"] = msg
-                elif stage["name"] == "sharded_configs_rccl":
+                elif name == "sharded_configs_rccl":
                     line["sharded_configs"]["rccl_transport"] = msg
                 else:
                     line["transports"]["rccl"] = msg
+
+        def give_up():
+            mark_stage({"error": "no result within %.0f s of the headline (watchdog), stage: %s" % (deadline, stage["name"])})
             emit()
             os._exit(0)
-        if want_sharded or (want_rccl and not share_gpu):
+        if want_sharded or want_strong or (want_rccl and not share_gpu):
             watchdog = threading.Timer(deadline, give_up)
             watchdog.daemon = True
             watchdog.start()
@@ -831,33 +902,79 @@ def main():
 
             def on_sigterm():
                 os.read(rfd, 1)
-                if rank == 0 and not done["printed"]:
-                    msg = {"error": "terminated by the launcher (another rank failed), stage: %s" % stage["name"]}
-                    if stage["name"] == "sharded_configs":
-                        line["sharded_configs"] = msg
-                    elif stage["name"] == "sharded_configs_rccl":
-                        line["sharded_configs"]["rccl_transport"] = msg
-                    else:
-                        line["transports"]["rccl"] = msg
-                    emit()
+                mark_stage({"error": "terminated by the launcher (another rank failed), stage: %s" % stage["name"]})
+                emit()
                 os._exit(1)
             threading.Thread(target=on_sigterm, daemon=True).start()
             if os.environ.get("QSMC_BENCH_TEST_DIE_RANK") == str(rank):      # (tests/test_bench_launch.py only)
                 os.kill(os.getpid(), signal.SIGKILL)
+
+        # ---- strong scaling: BASELINE.json quotes its metric on "1e7 particles ... at 1/2/4/8 GPU" -- 1e7 in TOTAL.  The
+        # headline above is the weak-scaling reading (1e7 per GPU); this leg holds the total fixed: every rank gets
+        # 1e7 / world particles, same model, schedule and resampler, the per-datum reduction under each transport.
+        strong_total = int(float(os.environ.get("QSMC_BENCH_STRONG_PARTICLES", "0")) or args.strong_particles)
+        if share_gpu and not os.environ.get("QSMC_BENCH_STRONG_PARTICLES"):
+            strong_total = max(65536 * world, strong_total // 16)          # (control flow on one shared device)
+        n_strong = max(1, strong_total // world)
+
+        def strong_leg(transport):
+            """SimplePrecession, n_strong particles per rank (strong_total over all ranks), the headline's K steps."""
+            from qinfer_amd.parallel import ParticleShardGroup
+            try:
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    grp = ParticleShardGroup(transport=transport)
+                    upd_s = qi.SMCUpdater(qi.SimplePrecessionModel(), n_strong, qi.UniformDistribution([0, 1]),
+                                          device_rng=True, seed=0, comm=grp)
+                    rb0 = grp.n_rebalances
+                    wall_s, _ = timed_pass(upd_s, events=False)
+                    resamples_s, _, _, mean_s = first_pass[-1]
+                    ws = torch.tensor([wall_s], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
+                    if world > 1:
+                        torch.distributed.all_reduce(ws, op=torch.distributed.ReduceOp.MAX)
+                    wall_s = float(ws.item())
+                    res = {"per_datum_collective": grp.transport_name, "value": n_strong * world * args.steps / wall_s,
+                           "ms_per_step": wall_s / args.steps * 1e3, "resamples": resamples_s,
+                           "rebalances": grp.n_rebalances - rb0, "posterior_mean": mean_s}
+                    if transport == "rccl":
+                        res["ranks_in_comm"] = grp.ranks_in_comm(eng)[0]
+                    del upd_s
+                    grp.close()
+            except Exception as e:  # noqa: BLE001
+                res = {"error": repr(e)}
+            return res
+
+        if want_strong:
+            leg = strong_leg(None)
+            set_line(("strong_scaling",), {
+                "scaling": "strong", "metric": "particle-updates/sec",
+                "workload": "SimplePrecessionModel SMCUpdater.update, %.3g particles IN TOTAL over %d rank(s) (%.3g per "
+                            "rank), fp64, Liu-West a=0.98, t_k=(9/8)^k: BASELINE.json's '1e7 particles at 1/2/4/8 GPU' "
+                            "read as a fixed total" % (n_strong * world, world, n_strong),
+                "particles_total": n_strong * world, "particles_per_rank": n_strong, "ranks": world, "steps": args.steps,
+                "warmup": args.warmup, "value": leg.get("value"), "ms_per_step": leg.get("ms_per_step"),
+                "value_transport": key,
+                "transports": {key: leg}})
         sharded = None
         if want_sharded:
+            stage["name"] = "sharded_configs"
             sharded = sharded_configs(comm)
-            if rank == 0:
-                line["sharded_configs"] = sharded
+            set_line(("sharded_configs",), sharded)
         stage["name"] = "rccl"
         if want_rccl and share_gpu:
-            if rank == 0:
-                line["transports"]["rccl"] = {"skipped": "QSMC_BENCH_SHARE_GPU=1: every rank sits on device 0 (control-flow "
-                                                         "check); an RCCL communicator needs one GPU per rank"}
+            skipped = {"skipped": "QSMC_BENCH_SHARE_GPU=1: every rank sits on device 0 (control-flow check); an RCCL "
+                                  "communicator needs one GPU per rank"}
+            set_line(("transports", "rccl"), skipped)
+            if want_strong and rank == 0 and isinstance(line.get("strong_scaling"), dict) and "transports" in line["strong_scaling"]:
+                set_line(("strong_scaling", "transports", "rccl"), skipped)
         elif want_rccl:
             res = rccl_transport_pass()
-            if rank == 0:
-                line["transports"]["rccl"] = res
+            set_line(("transports", "rccl"), res)
+            if want_strong and "error" not in res:
+                stage["name"] = "strong_scaling_rccl"
+                leg_r = strong_leg("rccl")
+                if rank == 0 and isinstance(line.get("strong_scaling"), dict) and "transports" in line["strong_scaling"]:
+                    set_line(("strong_scaling", "transports", "rccl"), leg_r)
             if sharded is not None and "error" not in res:
                 # configs 4 and 5 once more with the RCCL collective carrying the per-datum reduction
                 stage["name"] = "sharded_configs_rccl"
@@ -869,11 +986,12 @@ def main():
                 except Exception as e:  # noqa: BLE001
                     sh_r = {"error": repr(e)}
                 if rank == 0:
-                    for k2, v2 in sh_r.items():
-                        if isinstance(line["sharded_configs"].get(k2), dict) and isinstance(v2, dict):
-                            line["sharded_configs"][k2]["rccl_transport"] = {
-                                kk: v2.get(kk) for kk in ("value", "ms_per_step", "resamples", "rebalances",
-                                                          "per_datum_collective", "error") if kk in v2}
+                    with line_lock:
+                        for k2, v2 in sh_r.items():
+                            if isinstance(line["sharded_configs"].get(k2), dict) and isinstance(v2, dict):
+                                line["sharded_configs"][k2]["rccl_transport"] = {
+                                    kk: v2.get(kk) for kk in ("value", "ms_per_step", "resamples", "rebalances",
+                                                              "per_datum_collective", "error") if kk in v2}
         if watchdog is not None:
             watchdog.cancel()
     emit()

@@ -205,7 +205,7 @@ typedef struct qsmc_step_lw {
                                  /*   the next resample is told to expect (qsmc_lw_expect_redraws)                         */
     int32_t  adopt;              /* != 0: a resample queued by this call IS the caller's (it will not repeat the call to  */
                                  /*   qsmc_lw_resample_philox; the flags it needs for the reference's warnings are in the */
-                                 /*   struct: cov, cov_lambda_min, S_err): counted as adopted at once                      */
+                                 /*   struct: cov, cov_lambda_min, S_err): counted when the caller says qsmc_step_adopted  */
 } qsmc_step_lw_t;
 typedef struct qsmc_step {
     /* the cloud -- kept current by the caller; w / w_alt / norm / sumsq / min_n_ess advance here on commit */
@@ -258,6 +258,10 @@ int qsmc_step(qsmc_handle_t h, qsmc_step_t *st, const qsmc_model_t *model, const
               int64_t outcome, qsmc_stream_t stream);
 /* how many resamples qsmc_step queued on this handle, and how many of them the caller's own call adopted */
 int qsmc_step_stats(qsmc_handle_t h, int64_t *n_queued, int64_t *n_adopted);
+/* lw.adopt callers: "the resample the latest qsmc_step queued is mine" (SMCUpdater._adopt_queued) -- counted as adopted
+ * HERE, by the party that decides; a caller that declines (its resampler's a / h / seed / epoch were edited in place
+ * after the struct was filled) simply runs its own resample and the queued one shows up as queued, not adopted. */
+int qsmc_step_adopted(qsmc_handle_t h);
 
 /* batch_update fast path (smc.py:459-487): k <= 8 data applied in ONE pass over the cloud,
  * w_out[i] = (w_in[i] / prev_norm) * prod_j Pr(outcomes[j] | x_i ; exps[j]).

@@ -648,6 +648,37 @@ def g10_random_walk():
     run_trajectory("g10_grw_t2_n800", m2, qinfer.UniformDistribution([[0, 1], [0, 0.1]]), 800, ep, sim2)
 
 
+def g10_walk_steps():
+    """One seeded `GaussianRandomWalkModel.update_timestep` call of the reference for each covariance variant
+    (derived_models.py:920-963: given diagonal, given dense, learned diagonal, learned dense): the cloud in, the global
+    seed, the stepped cloud out -- pins the draw SHAPE and ORDER of every variant (the trajectories above pin the diagonal
+    one only)."""
+    out = {}
+    rs = np.random.RandomState(19)
+    t2 = qinfer.UnknownT2Model()
+    ep = np.empty((3,), dtype=t2.expparams_dtype)
+    ep['t'] = [2.0, 5.0, 11.0]
+    n = 7
+    base = np.column_stack([rs.uniform(0.2, 0.8, n), rs.uniform(0.01, 0.09, n)])
+    cov = np.array([[4e-4, 1e-4], [1e-4, 9e-4]])
+    variants = {
+        "known_diag": (dict(fixed_covariance=np.array([4e-4, 9e-4])), base),
+        "known_dense": (dict(fixed_covariance=cov, diagonal=False), base),
+        "learned_diag": (dict(), np.column_stack([base, rs.uniform(0.0, 0.03, (n, 2))])),
+        "learned_dense": (dict(diagonal=False), np.column_stack([base, rs.uniform(0.0, 0.03, (n, 3))])),
+    }
+    out["expparam_t"] = ep['t'].astype(np.float64)
+    out["cov_dense"] = cov
+    out["tags"] = np.array(sorted(variants))
+    for tag, (kw, mp) in variants.items():
+        m = qinfer.GaussianRandomWalkModel(t2, scale_mult=lambda e: np.sqrt(e['t']), **kw)
+        assert m.n_modelparams == mp.shape[1], (tag, m.n_modelparams)
+        np.random.seed(4242)
+        out[tag + "_in"] = mp
+        out[tag + "_out"] = np.asarray(m.update_timestep(mp.copy(), ep), dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "g10_grw_steps.npz"), **out)
+
+
 def g11_readouts():
     """Posterior read-outs of a weighted cloud: est_entropy (distributions.py:457-464),
     est_credible_region (:558-614), sample (:320-333, its uniforms recorded) and SMCUpdater.posterior_marginal
@@ -809,6 +840,7 @@ if __name__ == "__main__":
     g8_simple_est()
     g9_t2_mle()
     g10_random_walk()
+    g10_walk_steps()
     g11_readouts()
     g12_perf_test()
     g13_regions()

@@ -36,9 +36,11 @@ constexpr int SQRTM_MAX_SWEEPS = 64;
 constexpr double SQRTM_OFF_TOL = 1e-34;
 
 // Host execution, n <= 64.  A row-major n x n; S_out = scale * sqrt(A); *err_out = || sqrt(A) sqrt(A) - A ||_F.
-static void sqrtm_psd_host(const double *A, int n, double scale, double *S_out, double *err_out,
-                           double *lambda_min_out = nullptr) {
-    double a[64 * 64], v[64 * 64], sq[64 * 64];
+// `a`, `v`, `sq`: caller-provided work arrays of n * n doubles each (sqrtm_psd_host below sizes them by n: the step
+// path's d <= 16 on the stack -- 6 KB -- anything larger from the heap; a fixed 3 x 64 x 64 = 96 KB of stack was
+// within reach of a small-stack worker thread calling the C ABI).
+static void sqrtm_psd_host_work(const double *A, int n, double scale, double *S_out, double *err_out,
+                                double *lambda_min_out, double *a, double *v, double *sq) {
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < n; ++j) {
             a[i * n + j] = 0.5 * (A[i * n + j] + A[j * n + i]);   // eigh reads one triangle; symmetrise
@@ -121,6 +123,22 @@ static void sqrtm_psd_host(const double *A, int n, double scale, double *S_out, 
         *err_out = sqrt(e2);
     }
     for (int k = 0; k < n * n; ++k) S_out[k] = scale * sq[k];
+}
+
+// Returns false when the work arrays of an n > 16 matrix could not be allocated (the caller reports QSMC_ERR_ALLOC).
+static bool sqrtm_psd_host(const double *A, int n, double scale, double *S_out, double *err_out,
+                           double *lambda_min_out = nullptr) {
+    constexpr int SMALL = QSMC_MAX_D;
+    if (n <= SMALL) {
+        double a[SMALL * SMALL], v[SMALL * SMALL], sq[SMALL * SMALL];
+        sqrtm_psd_host_work(A, n, scale, S_out, err_out, lambda_min_out, a, v, sq);
+        return true;
+    }
+    double *work = static_cast<double *>(malloc(sizeof(double) * 3 * (size_t)n * (size_t)n));
+    if (!work) return false;
+    sqrtm_psd_host_work(A, n, scale, S_out, err_out, lambda_min_out, work, work + (size_t)n * n, work + 2 * (size_t)n * n);
+    free(work);
+    return true;
 }
 
 // ---------------------------------------------------------------------------------------------

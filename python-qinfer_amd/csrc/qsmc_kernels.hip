@@ -60,6 +60,7 @@ struct qsmc_ctx {
     unsigned long long *gbar;      // device: [0] arrival counter of the count kernel's barriers (only ever grows), [1] its
                                    // timeouts; [2], [3] arrivals / departures of the redraw kernel's self-resetting barrier
     unsigned long long gbar_base;  // host shadow: arrivals handed out so far
+    unsigned int *tickets;         // device: arrival words of the small-grid update (kernels/update.hpp: fold_tail), self-resetting
     int cu_count;                  // compute units this process can run on (bounds the resident grids of the barrier kernels)
     int cu_reported;               // what the device attribute says
     void *sort_tmp;                // rocPRIM temporary storage + key/value staging for qsmc_argsort
@@ -167,6 +168,7 @@ struct qsmc_ctx {
     } while (0)
 
 constexpr int REDUCE_OUT_MAX = 192;
+constexpr int FOLD_TICKET_WORDS = 1 + 64 + 63;      // [0] + one word per group of 32 workgroups (grid <= QSMC_GRID_CAP = 2048), padded
 constexpr int QSMC_PROF_CAP = 4096;
 
 // Census of the compute units this process can actually run on.  hipDeviceAttributeMultiprocessorCount reports the
@@ -379,7 +381,19 @@ static ReduceOut make_reduce(qsmc_ctx *h, bool want_host, double *stats4) {
     ro.tp_ntiles = 0;
     ro.prefix_gate = nullptr;
     ro.prefix_thresh = 0.0;
+    ro.tickets = nullptr;
     return ro;
+}
+
+// The small-grid form of an update (kernels/update.hpp: fold_tail): the update kernel's last workgroup reduces and publishes,
+// no reducing launch, no speculative count launch.  For grids of at most QSMC_FOLD_MAX_GRID workgroups (default below;
+// 0 switches it off) whose sums the host waits for.  Read per call (a getenv is ~0.1 us): the tests A/B it in one process.
+constexpr int FOLD_MAX_GRID_DEFAULT = 1024;
+static bool fold_applies(int grid, bool want_host) {
+    if (!want_host) return false;
+    const char *e = getenv("QSMC_FOLD_MAX_GRID");
+    const int cap = e ? atoi(e) : FOLD_MAX_GRID_DEFAULT;
+    return grid <= cap && grid <= 32 * 64;
 }
 
 // Wait for the reduction that was armed with the current h->seq.  hipStreamSynchronize costs ~12 us
@@ -485,7 +499,15 @@ static void launch_update(qsmc_ctx *h, bool vec2, int grid, hipStream_t s, const
             hipExtLaunchKernelGGL((k_update_fused<KIND, V, O, false>), dim3(grid), dim3(QSMC_BLOCK), 0, s, e0, e1, 0, \
                                   x, ldx, n, w_in, w_out, prev_norm, e, outcome, ro, nt);                 \
     } while (0)
-    if (vec2 && w_in) LU(2, false);
+    if (ro.tickets) {            // the small-grid form (16-byte lanes, plain likelihood: update_can_fold)
+        if (w_in)
+            hipExtLaunchKernelGGL((k_update_fused<KIND, 2, false, false, true>), dim3(grid), dim3(QSMC_BLOCK), 0, s, e0, e1, 0,
+                                  x, ldx, n, w_in, w_out, prev_norm, e, outcome, ro, nt);
+        else
+            hipExtLaunchKernelGGL((k_update_fused<KIND, 2, true, false, true>), dim3(grid), dim3(QSMC_BLOCK), 0, s, e0, e1, 0,
+                                  x, ldx, n, w_in, w_out, prev_norm, e, outcome, ro, nt);
+    }
+    else if (vec2 && w_in) LU(2, false);
     else if (vec2) LU(2, true);
     else if (w_in) LU(1, false);
     else LU(1, true);
@@ -863,6 +885,8 @@ int qsmc_create(qsmc_handle_t *out, int device) {
     if (e == hipSuccess) e = hipMemset(h->counter, 0, 2 * sizeof(long long));
     if (e == hipSuccess) e = hipMalloc(&h->gbar, 4 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(h->gbar, 0, 4 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc(&h->tickets, FOLD_TICKET_WORDS * sizeof(unsigned int));
+    if (e == hipSuccess) e = hipMemset(h->tickets, 0, FOLD_TICKET_WORDS * sizeof(unsigned int));
     if (e == hipSuccess) e = hipMalloc(&h->spec.gate, sizeof(int));
     if (e == hipSuccess) e = hipMemset(h->spec.gate, 0, sizeof(int));
     h->spec.prof_slot = -1;
@@ -902,6 +926,7 @@ int qsmc_destroy(qsmc_handle_t h) {
     if (h->pinned) (void)hipHostFree(h->pinned);
     if (h->counter) (void)hipFree(h->counter);
     if (h->gbar) (void)hipFree(h->gbar);
+    if (h->tickets) (void)hipFree(h->tickets);
     if (h->spec.gate) (void)hipFree(h->spec.gate);
     if (h->iscratch) (void)hipFree(h->iscratch);
     if (h->anc16) (void)hipFree(h->anc16);
@@ -1090,12 +1115,17 @@ int qsmc_update_fused(qsmc_handle_t h, const qsmc_model_t *model, const double *
     ++h->ts.gen;
     h->ts.armed = 0;
     h->spec.launched = 0;
-    rc = setup_tile_prefix(h, ro, n, per_block, ns);
-    if (rc) return rc;
-    if (h->spec.enabled && ro.tile_sums && ro.failed_dst) {
-        // the resampler's weight-only prefix goes out right behind the reduction, gated on the device-side ESS test
-        ro.prefix_gate = h->spec.gate;
-        ro.prefix_thresh = h->spec.thresh;
+    const bool fold = vec2 && ea.lik_pow == 0.0 && fold_applies(grid, stats_host || moments_host);
+    if (fold) {
+        ro.tickets = h->tickets;           // one launch: no chunk prefix beside a reduction, no gated count launch behind it
+    } else {
+        rc = setup_tile_prefix(h, ro, n, per_block, ns);
+        if (rc) return rc;
+        if (h->spec.enabled && ro.tile_sums && ro.failed_dst) {
+            // the resampler's weight-only prefix goes out right behind the reduction, gated on the device-side ESS test
+            ro.prefix_gate = h->spec.gate;
+            ro.prefix_thresh = h->spec.thresh;
+        }
     }
     switch (model->kind) {
 #define LAUNCH_U(K)                                                                             \
@@ -1117,7 +1147,13 @@ int qsmc_update_fused(qsmc_handle_t h, const qsmc_model_t *model, const double *
                 prof_events(h, w_in ? QSMC_PROF_UPDATE : QSMC_PROF_UPDATE_ONES, &e0, &e1);
 #define LT(NZ)                                                                                                          \
     case NZ:                                                                                                            \
-        if (w_in)                                                                                                       \
+        if (w_in && fold)                                                                                               \
+            hipExtLaunchKernelGGL((k_update_tomo<NZ, false, true>), dim3(grid), dim3(QSMC_BLOCK), 0, s, e0, e1, 0, x, ldx, n, \
+                                  w_in, w_out, prev_norm, ea, outcome, ro);                                             \
+        else if (fold)                                                                                                  \
+            hipExtLaunchKernelGGL((k_update_tomo<NZ, true, true>), dim3(grid), dim3(QSMC_BLOCK), 0, s, e0, e1, 0, x, ldx, n,  \
+                                  w_in, w_out, prev_norm, ea, outcome, ro);                                             \
+        else if (w_in)                                                                                                  \
             hipExtLaunchKernelGGL((k_update_tomo<NZ, false>), dim3(grid), dim3(QSMC_BLOCK), 0, s, e0, e1, 0, x, ldx, n, w_in, \
                                   w_out, prev_norm, ea, outcome, ro);                                                   \
         else                                                                                                            \
@@ -1134,8 +1170,10 @@ int qsmc_update_fused(qsmc_handle_t h, const qsmc_model_t *model, const double *
 #undef LAUNCH_U
     }
     HIP_TRY(h, hipGetLastError());
-    rc = launch_reduce(h, ns, grid, ro, s);
-    if (rc) return rc;
+    if (!fold) {
+        rc = launch_reduce(h, ns, grid, ro, s);
+        if (rc) return rc;
+    }
     if (ro.prefix_gate) {
         rc = resample_prefix(h, w_out, n, 0.0, h->spec.n_out, h->spec.seed, h->spec.epoch, s, true);
         if (rc) return rc;
@@ -1205,6 +1243,42 @@ int qsmc_update_multi(qsmc_handle_t h, const qsmc_model_t *model, const double *
     if (rc) return rc;
     hipEvent_t me0 = nullptr, me1 = nullptr;
     prof_events(h, QSMC_PROF_UPDATE_MULTI, &me0, &me1);
+    // tomography with sparse measurement vectors (every datum of the window touches at most four rows -- a Pauli
+    // measurement two): the window reads those rows only (k_update_multi_tomo)
+    bool sparse_tomo = false;
+    if (model->kind == QSMC_MODEL_TOMOGRAPHY && k >= 2) {
+        static const bool dense_env = getenv("QSMC_TOMO_DENSE_UPDATE") != nullptr;     // (A/B switch, as for the single datum)
+        sparse_tomo = !dense_env && aligned16(x) && (!w_in || aligned16(w_in)) && aligned16(w_out) && (ldx % 2 == 0) &&
+                      ma.e[0].lik_pow == 0.0;
+        int nz_max = 0;
+        for (int j = 0; j < k && sparse_tomo; ++j) {
+            if (ma.e[j].nnz < 1 || ma.e[j].nnz > MULTI_TOMO_NZ) sparse_tomo = false;
+            nz_max = ma.e[j].nnz > nz_max ? ma.e[j].nnz : nz_max;
+        }
+        if (sparse_tomo) {
+            MultiTomoArgs mt;
+            memset(&mt, 0, sizeof(mt));
+            for (int j = 0; j < k; ++j) {
+                for (int q = 0; q < ma.e[j].nnz; ++q) {
+                    mt.idx[j][q] = ma.e[j].nz_idx[q];
+                    mt.mv[j][q] = ma.e[j].meas[ma.e[j].nz_idx[q]];
+                }
+                mt.outcome[j] = outcomes[j];                    // (padding: row 0, coefficient +0 -- the memset)
+            }
+#define LMT(KK)                                                                                                       \
+    case KK:                                                                                                          \
+        if (nz_max <= 2)                                                                                              \
+            hipExtLaunchKernelGGL((k_update_multi_tomo<KK, 2>), dim3(grid), dim3(QSMC_BLOCK), 0, s, me0, me1, 0, x, ldx, n, \
+                                  w_in, w_out, prev_norm, mt, ro);                                                    \
+        else                                                                                                          \
+            hipExtLaunchKernelGGL((k_update_multi_tomo<KK, MULTI_TOMO_NZ>), dim3(grid), dim3(QSMC_BLOCK), 0, s, me0, me1, 0, \
+                                  x, ldx, n, w_in, w_out, prev_norm, mt, ro);                                         \
+        break;
+            switch (k) { LMT(2) LMT(3) LMT(4) LMT(5) LMT(6) LMT(7) LMT(8) }
+#undef LMT
+        }
+    }
+    if (!sparse_tomo)
     switch (model->kind) {
 #define LAUNCH_MU(K)                                                                                   \
     case K:                                                                                            \
@@ -2072,6 +2146,12 @@ int qsmc_step_stats(qsmc_handle_t h, int64_t *n_queued, int64_t *n_adopted) {
     return QSMC_OK;
 }
 
+int qsmc_step_adopted(qsmc_handle_t h) {
+    if (!h) return QSMC_ERR_INVALID;
+    ++h->rsq.n_adopted;
+    return QSMC_OK;
+}
+
 int qsmc_step_sqrt_stats(qsmc_handle_t h, int64_t *n_device, int64_t *n_agreed) {
     if (!h || !n_device || !n_agreed) return QSMC_ERR_INVALID;
     *n_device = h->n_sqrt_dev;
@@ -2255,15 +2335,19 @@ int qsmc_step(qsmc_handle_t h, qsmc_step_t *st, const qsmc_model_t *model, const
         hipExtLaunchKernelGGL(k_moments_mfma, dim3(gridm), dim3(QSMC_BLOCK), 0, s, m0, m1, 0, st->x, st->ldx, st->n, d,
                               st->w, fixed, h->partials);
         double *full = h->scratch + 256;
-        hipLaunchKernelGGL(k_sum_partials, dim3((MFMA_MOM_K + QSMC_WAVES_PER_BLOCK - 1) / QSMC_WAVES_PER_BLOCK),
-                           dim3(QSMC_BLOCK), 0, s, h->partials, gridm, MFMA_MOM_K, full);
         const unsigned long long seq = ++h->seq;
+        static const bool dev_sqrt_env = getenv("QSMC_DEVICE_SQRT") != nullptr;
+        constexpr int SUM_GRID = (MFMA_MOM_K + QSMC_WAVES_PER_BLOCK - 1) / QSMC_WAVES_PER_BLOCK;
+        if (dev_sqrt_env)         // (the device square root publishes for itself, from the ancestor kernel)
+            hipLaunchKernelGGL(k_sum_partials, dim3(SUM_GRID), dim3(QSMC_BLOCK), 0, s, h->partials, gridm, MFMA_MOM_K, full);
+        else                      // sums and their publish to the host in one launch (round 5; two before)
+            hipLaunchKernelGGL(k_sum_partials_publish, dim3(SUM_GRID), dim3(QSMC_BLOCK), 0, s, h->partials, gridm, MFMA_MOM_K,
+                               full, h->mapped_big_dev, h->flag_dev, seq, h->tickets + FOLD_TICKET_WORDS - 1);
         // (round 4 built the device form -- kernels/sqrtm.hpp -- and measured it: the gap between the two sampler kernels
         //  closes, but the one wavefront that forms S is latency-bound, ~90 rounds of three dependent LDS / fp64-division
         //  steps sharing a SIMD with the ancestor kernel's own waves: k_bucket_anc16 36 -> 96 us, a d = 16 resample
         //  +40 us, config-5 share 0.0727 -> 0.0742 ms/step.  The host's Jacobi (~25 us) runs WHILE the ancestor kernel
         //  does and leaves a 10-25 us gap: it stays the default; QSMC_DEVICE_SQRT=1 selects the device form.)
-        static const bool dev_sqrt_env = getenv("QSMC_DEVICE_SQRT") != nullptr;
         device_sqrt = dev_sqrt_env;
         h->ts.armed = h->ts.gen;                               // these weights ARE update number ts.gen's output
         if (device_sqrt) {
@@ -2288,7 +2372,6 @@ int qsmc_step(qsmc_handle_t h, qsmc_step_t *st, const qsmc_model_t *model, const
             if (rc) return rc;
             ++h->n_sqrt_dev;
         } else {
-            hipLaunchKernelGGL(k_publish_big, dim3(1), dim3(QSMC_BLOCK), 0, s, full, MFMA_MOM_K, h->mapped_big_dev, h->flag_dev, seq);
             HIP_TRY(h, hipGetLastError());
             rc = resample_philox_impl(h, model, st->lw.postselect, st->x, st->ldx, st->n, d, st->w, fixed, st->lw.a, st->mean,
                                       st->S, st->lw.n_out, st->lw.seed, st->lw.epoch, st->lw.maxiter, st->lw.x_out, pl,
@@ -2365,8 +2448,10 @@ int qsmc_step(qsmc_handle_t h, qsmc_step_t *st, const qsmc_model_t *model, const
     q.x_out = st->lw.x_out;
     q.stream = s;
     ++q.n_queued;
-    if (st->lw.adopt) {                                    // the caller takes the queued resample as its own, without a second call
-        ++q.n_adopted;
+    if (st->lw.adopt) {
+        // the caller MAY take the queued resample as its own, without a second call to qsmc_lw_resample_philox: it says so
+        // with qsmc_step_adopted (counted there, not here -- a caller whose resampler was edited in place since the struct
+        // was filled runs its own resample and must not show up as an adoption); the record is closed either way
         q.valid = 0;
     }
     st->status |= QSMC_STEP_RESAMPLE_QUEUED;
@@ -2923,8 +3008,8 @@ int qsmc_host_allreduce(void *segment, int32_t rank, int32_t world, int32_t max_
 // ---- host: sqrtm_psd by cyclic Jacobi (utils.py:593-607) --------------------------------------
 int qsmc_sqrtm_psd(const double *A, int32_t d, double scale, double *S_out, double *err_out) {
     if (!A || !S_out || d < 1 || d > 64) return QSMC_ERR_INVALID;
-    sqrtm_psd_host(A, d, scale, S_out, err_out);          // kernels/sqrtm.hpp: the routine the device wavefront mirrors
-    return QSMC_OK;
+    // kernels/sqrtm.hpp: the routine the device wavefront mirrors (work arrays on the stack for d <= 16, heap above)
+    return sqrtm_psd_host(A, d, scale, S_out, err_out) ? QSMC_OK : QSMC_ERR_ALLOC;
 }
 
 }  // extern "C"

@@ -96,6 +96,7 @@ SIGNATURES = {
                           _I64, _P, C.POINTER(UpdateStats), C.POINTER(_F64), _P],
     "qsmc_step": [_P, C.POINTER(Step), C.POINTER(ModelDesc), C.POINTER(ExpParam), _I64, _P],
     "qsmc_step_stats": [_P, C.POINTER(_I64), C.POINTER(_I64)],
+    "qsmc_step_adopted": [_P],
     "qsmc_lw_fuse_canonicalize": [_P, _P, _I32, _I32, _I32],
     "qsmc_lw_expect_redraws": [_P, _I64],
     "qsmc_lw_can_fuse_canonicalize": [_I32, _I64, _I64],

@@ -186,6 +186,10 @@ class Engine:
             self._chk(rc, "qsmc_step")
         # (whether the call armed the gated prefix is the caller's to record in `_armed_prefix`: it filled the struct)
 
+    def step_adopted(self):
+        """The caller has taken the resample queued by the latest `step` as its own (counted by qsmc_step_stats)."""
+        self.lib.qsmc_step_adopted(self.h)
+
     def step_stats(self):
         """(resamples queued by qsmc_step, resamples whose caller-side call adopted the queued one)."""
         q, a = C.c_int64(), C.c_int64()

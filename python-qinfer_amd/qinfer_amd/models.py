@@ -438,9 +438,13 @@ class _KnownDense(_StepLaw):
         self.factor = np.linalg.cholesky(cov)           # cov = factor factor^T
 
     def draw(self, mp, n_e):
-        n_rw = self.factor.shape[0]
-        z = np.random.normal(size=(mp.shape[0], n_e, n_rw))
-        return np.swapaxes(z @ self.factor.T, 1, 2)
+        # stream order of the reference's dense-fixed branch (derived_models.py:932-935): ONE block of unit normals with a
+        # row per walking parameter and a column per (particle, experiment) pair, particle-major -- coloured from the left
+        # by the factor -- so that a seeded legacy-RNG run consumes np.random exactly as QInfer does (fixture g10 dense case)
+        n, n_rw = mp.shape[0], self.factor.shape[0]
+        white = np.random.normal(size=(n_rw, n * n_e))
+        coloured = self.factor @ white                                   # (n_rw, n * n_e)
+        return np.moveaxis(coloured.reshape(n_rw, n, n_e), 0, 1)       # (n, n_rw, n_e)
 
     def unit_covariance(self, mp):
         return self.factor @ self.factor.T

@@ -519,9 +519,15 @@ class SMCUpdater(ParticleDistribution):
             warnings.warn("Extremely small n_ess encountered ({}). Resampling is likely to fail. "
                           "Consider adding particles, or resampling more often.".format(np.float64(st.n_ess)),
                           ApproximationWarning)
+        self._eng.step_adopted()                                     # (counted by the party that decides: qsmc_step_stats)
         self._just_resampled = True                                  # (update() cleared it: no 'without additional data')
         self._resample_count += 1
-        if st.cov_lambda_min < 0:                                    # distributions.py:392-399, via est_covariance_mtx
+        # distributions.py:392-399 (via est_covariance_mtx): `not np.all(la.eig(cov)[0] >= 0)`.  The sign test is taken on
+        # the smallest diagonal entry the Jacobi sweeps converged to; for an eigenvalue that is rounding noise around zero
+        # (|lambda| <~ eps ||cov||: a singular covariance, e.g. tomography's x_0 = 1/2 row) LAPACK's `eig` and a Jacobi
+        # iteration may land on different sides of zero, as two LAPACK builds may -- the warning is then a coin toss in the
+        # reference too; no tolerance is applied, so that a genuinely indefinite covariance warns exactly as before.
+        if st.cov_lambda_min < 0:
             warnings.warn('Numerical error in covariance estimation causing positive semidefinite '
                           'violation.', ApproximationWarning)
         if not self._st_cov[:d * d].any():                           # resamplers.py:283-290
@@ -814,7 +820,9 @@ class SMCUpdater(ParticleDistribution):
                 N, s1, s2 = a[..., 0:1], a[..., 2:2 + d], a[..., 2 + d:2 + 2 * d]
                 with np.errstate(divide='ignore', invalid='ignore'):
                     var = np.where(N > 0, s2 - s1 * s1 / N, 0.0)
-                risk[at:at + a.shape[0]] = np.sum(var @ Q, axis=-1)
+                # (Q is the vector of smc.py:598's `Q * (x - mu) ** 2`; a square Q, which the per-experiment form of this
+                #  method also took, contracts to one more axis: everything after the experiment axis is summed)
+                risk[at:at + a.shape[0]] = (var @ Q).reshape(a.shape[0], -1).sum(axis=-1)
                 at += a.shape[0]
             return risk
         return self._design_generic(expparams, "risk")

@@ -42,7 +42,7 @@ def test_launcherless_without_gpus_fails_loudly():
 @pytest.mark.gpu
 @pytest.mark.parametrize("n_ranks", [2, 8])
 def test_launcherless_shared_gpu(n_ranks):
-    r = _run_bench(["--gpus", str(n_ranks)] + SHARDED, {"QSMC_BENCH_SHARE_GPU": "1"})
+    r = _run_bench(["--gpus", str(n_ranks)] + SHARDED, {"QSMC_BENCH_SHARE_GPU": "1", "QSMC_BENCH_STRONG_PARTICLES": "160000"})
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     line = _one_json_line(r.stdout)
     assert line["n_gpus"] == n_ranks and line["steps"] == 12 and line["warmup"] == 3
@@ -65,6 +65,18 @@ def test_launcherless_shared_gpu(n_ranks):
         assert c["value"] == pytest.approx(c["particles"] * 60 / (c["ms_per_step"] * 1e-3 * 60), rel=1e-9)
     assert "canonicalize fused" in c5["resample_path"]          # the shard's draw runs on the split d = 16 sampler
     assert abs(c4["posterior_mean_head"][0] - 0.95) < 0.15 and c5["posterior_mean_head"][0] == pytest.approx(0.5, abs=1e-9)
+    # the strong-scaling leg: BASELINE.json's "1e7 particles at 1/2/4/8 GPU" as a FIXED total over the ranks, beside the
+    # weak-scaling headline; each object says which scaling it is and which transport its `value` was measured under
+    ss = line["strong_scaling"]
+    assert "error" not in ss, ss
+    assert ss["scaling"] == "strong" and ss["ranks"] == n_ranks and ss["steps"] == 12
+    assert ss["particles_total"] == 160000 - 160000 % n_ranks and ss["particles_per_rank"] == 160000 // n_ranks
+    assert ss["value_transport"] == "shm" and line["config"]["headline_transport"] == "shm"
+    leg = ss["transports"]["shm"]
+    assert leg["per_datum_collective"] == "host shared memory" and leg["value"] == ss["value"] > 0
+    assert leg["value"] == pytest.approx(ss["particles_total"] * 12 / (leg["ms_per_step"] * 1e-3 * 12), rel=1e-9)
+    assert leg["resamples"] >= 1 and leg["rebalances"] >= 0 and abs(leg["posterior_mean"] - 0.3) < 0.2
+    assert "skipped" in ss["transports"]["rccl"]
 
 
 @pytest.mark.gpu
@@ -76,6 +88,13 @@ def test_headline_survives_a_stage_that_overruns():
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     line = _one_json_line(r.stdout)
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["transports"]["shm"]["headline"]
+    # (the first stage behind the headline is the strong-scaling leg: the overrun is recorded against it)
+    assert "watchdog" in line["strong_scaling"]["error"] and "strong_scaling" in line["strong_scaling"]["error"]
+    r = _run_bench(["--gpus", "2"] + SHARDED, {"QSMC_BENCH_SHARE_GPU": "1", "QSMC_BENCH_DEADLINE": "0.2",
+                                               "QSMC_BENCH_NO_STRONG": "1"})
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    line = _one_json_line(r.stdout)
+    assert line["n_gpus"] == 2 and line["value"] > 0 and "strong_scaling" not in line
     assert "watchdog" in line["sharded_configs"]["error"] and "sharded_configs" in line["sharded_configs"]["error"]
 
 
@@ -87,7 +106,7 @@ def test_headline_survives_a_rank_that_dies():
     assert r.returncode != 0
     line = _one_json_line(r.stdout)
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["transports"]["shm"]["headline"]
-    assert "another rank failed" in line["sharded_configs"]["error"]
+    assert "another rank failed" in line["strong_scaling"]["error"]
 
 
 @pytest.mark.gpu
@@ -117,7 +136,8 @@ def test_driver_command_headline_is_steady_state():
 def test_rccl_pass_inside_the_line_world1():
     """One rank through the full sharded path, the RCCL-transport pass forced: its result sits INSIDE the JSON line,
     with the rank count read back from the communicator."""
-    r = _run_bench(["--gpus", "1", "--force-comm"] + SMALL, {"QSMC_BENCH_FORCE_RCCL_PASS": "1", "MASTER_PORT": "29643"})
+    r = _run_bench(["--gpus", "1", "--force-comm", "--strong-particles", "150000"] + SMALL,
+                   {"QSMC_BENCH_FORCE_RCCL_PASS": "1", "MASTER_PORT": "29643"})
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     line = _one_json_line(r.stdout)
     tr = line["transports"]
@@ -127,3 +147,9 @@ def test_rccl_pass_inside_the_line_world1():
     assert rc["ranks_in_comm"] == 1 and rc["value"] > 0 and "RCCL" in rc["per_datum_collective"]
     assert rc["resamples"] == tr["shm"]["resamples"]
     assert rc["posterior_mean"] == tr["shm"]["posterior_mean"]       # both transports sum in rank order: same bits
+    # the strong-scaling leg carries both transports too (one rank: the "total" is this rank's cloud)
+    ss = line["strong_scaling"]
+    assert ss["scaling"] == "strong" and ss["particles_total"] == 150000 and ss["ranks"] == 1
+    a, b = ss["transports"]["shm"], ss["transports"]["rccl"]
+    assert "error" not in a and "error" not in b, (a, b)
+    assert b["ranks_in_comm"] == 1 and a["resamples"] == b["resamples"] and a["posterior_mean"] == b["posterior_mean"]

@@ -1563,6 +1563,10 @@ def test_speculative_prefix_same_particles(qi, monkeypatch):
             monkeypatch.setattr(smc_mod.SMCUpdater, "_prefix_key", lambda self: None)
         else:
             monkeypatch.undo()
+        # (clouds this small would take the one-launch form of round 5, which queues nothing behind an update: the
+        #  mechanism under test is the large-cloud one, so that form is switched off here -- the library reads the
+        #  variable per call)
+        monkeypatch.setenv("QSMC_FOLD_MAX_GRID", "0")
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             upd = qi.SMCUpdater(model, n, prior, device_rng=True, seed=11)
@@ -1598,6 +1602,87 @@ def test_speculative_prefix_same_particles(qi, monkeypatch):
         np.testing.assert_array_equal(a.particle_locations, b.particle_locations)
         np.testing.assert_array_equal(a.particle_weights, b.particle_weights)
         np.testing.assert_array_equal(np.asarray(a.normalization_record), np.asarray(b.normalization_record))
+
+
+def test_small_grid_one_launch_same_numbers(qi, monkeypatch):
+    """Round 5: a small cloud's datum is ONE launch -- the update kernel's last workgroup sums the partials, publishes and
+    sets the completion word (kernels/update.hpp: fold_tail); no reducing launch, no gated count launch behind it, the
+    host queues k_bucket_counts when its own n_ess test fails.  The rows are summed in the same index order by the same
+    code, so nothing may change: bit-identical clouds, weights, records, n_ess and resample decisions against the
+    two-launch form (QSMC_FOLD_MAX_GRID=0), for every update kernel that has the form (d = 1, binomial, RB, T2, sparse
+    and dense tomography), with ragged last tiles and with implicit weights; and the count of speculative prefix
+    launches says which form ran."""
+    rng = np.random.default_rng(12)
+    ts = (9 / 8) ** np.arange(70)
+    prec = [(int(rng.random() < np.sin(0.3 * t / 2) ** 2), np.array([t])) for t in ts]
+    bm = qi.BinomialModel(qi.SimplePrecessionModel())
+    binom = []
+    for k in range(30):
+        ep = np.empty((1,), dtype=bm.expparams_dtype)
+        ep["x"], ep["n_meas"] = (9 / 8) ** k, 25
+        binom.append((int(rng.binomial(25, np.sin(0.3 * (9 / 8) ** k / 2) ** 2)), ep))
+    rbm = qi.RandomizedBenchmarkingModel()
+    rb = [(int(rng.random() < 0.5), np.array([(1 + 5 * k,)], dtype=rbm.expparams_dtype)) for k in range(40)]
+    t2 = qi.UnknownT2Model()
+    t2d = []
+    for k in range(40):
+        ep = np.empty((1,), dtype=t2.expparams_dtype)
+        ep["t"] = 1.0 + 2.0 * k
+        t2d.append((int(rng.random() < 0.5), ep))
+    basis = qi.tomography.pauli_basis(2)
+    tm = qi.TomographyModel(basis)
+    tomo, tomo_dense = [], []
+    for k in range(40):
+        ep = np.zeros((1,), dtype=tm.expparams_dtype)
+        ep["meas"][0, 0], ep["meas"][0, int(rng.integers(1, 16))] = 1, 1
+        tomo.append((int(rng.random() < 0.5), ep))
+        ep = np.zeros((1,), dtype=tm.expparams_dtype)
+        ep["meas"][0, :] = rng.normal(size=16) * 0.1
+        ep["meas"][0, 0] = 1
+        tomo_dense.append((int(rng.random() < 0.5), ep))
+    np.random.seed(9)
+    gin = qi.GinibreDistribution(basis).sample(30_011)
+    cases = [
+        ("precession", lambda: qi.SimplePrecessionModel(), lambda m: qi.UniformDistribution([0, 1]), 1_250_000, prec),
+        ("precession ragged", lambda: qi.SimplePrecessionModel(), lambda m: qi.UniformDistribution([0, 1]), 70_001, prec),
+        ("precession tiny", lambda: qi.SimplePrecessionModel(), lambda m: qi.UniformDistribution([0, 1]), 900, prec[:40]),
+        ("binomial", lambda: qi.BinomialModel(qi.SimplePrecessionModel()), lambda m: qi.UniformDistribution([0, 1]), 200_003, binom),
+        ("rb", lambda: qi.RandomizedBenchmarkingModel(), lambda m: qi.PostselectedDistribution(
+            qi.UniformDistribution([[0.8, 1], [0, 1], [0, 1]]), m), 150_000, rb),
+        ("t2", lambda: qi.UnknownT2Model(), lambda m: qi.UniformDistribution([[0, 1], [0, 0.1]]), 120_000, t2d),
+        ("tomography", lambda: qi.TomographyModel(basis), lambda m: fixed_prior(qi, gin), 30_011, tomo),
+        ("tomography dense", lambda: qi.TomographyModel(basis), lambda m: fixed_prior(qi, gin), 30_011, tomo_dense),
+    ]
+
+    def run(make_model, make_prior, n, data, fold):
+        monkeypatch.setenv("QSMC_FOLD_MAX_GRID", "1024" if fold else "0")
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m = make_model()
+            upd = qi.SMCUpdater(m, n, make_prior(m), device_rng=True, seed=21)
+            q0, _ = upd._eng.prefix_stats()
+            ess = []
+            for o, ep in data:
+                upd.update(o, ep)
+                ess.append(float(upd.n_ess))
+            q1, _ = upd._eng.prefix_stats()
+            upd._eng.torch.cuda.synchronize()
+        return upd, np.array(ess), q1 - q0
+
+    for name, make_model, make_prior, n, data in cases:
+        a, ess_a, q_a = run(make_model, make_prior, n, data, True)
+        b, ess_b, q_b = run(make_model, make_prior, n, data, False)
+        assert q_a == 0, (name, q_a)                              # one launch per datum: nothing queued behind an update
+        if a._x.shape[0] <= 4:
+            assert q_b == len(data), (name, q_b)                  # the two-launch form queues its gated prefix every time
+        assert a.resample_count == b.resample_count and a.resample_count > 0, (name, a.resample_count, b.resample_count)
+        np.testing.assert_array_equal(ess_a, ess_b, err_msg=name)
+        np.testing.assert_array_equal(np.ravel(a.normalization_record), np.ravel(b.normalization_record), err_msg=name)
+        np.testing.assert_array_equal(a.particle_locations, b.particle_locations, err_msg=name)
+        np.testing.assert_array_equal(a.particle_weights, b.particle_weights, err_msg=name)
+        np.testing.assert_array_equal(a.est_mean(), b.est_mean(), err_msg=name)
+        np.testing.assert_array_equal(a.est_covariance_mtx(), b.est_covariance_mtx(), err_msg=name)
+        assert float(a.min_n_ess) == float(b.min_n_ess), name
 
 
 def test_device_sqrt_agrees_with_host():
@@ -1832,6 +1917,52 @@ def test_device_resampler_vs_pinned_oracle_statistics(qi, case):
         kick = np.sqrt(1 - a ** 2) * np.sqrt(orc.particle_cov(w, x, warn=False)[0, 0])
         assert np.mean(x[:, 0] < 2 * kick) > 0.2
     _two_sample_checks(dev, ref, case)
+
+
+def test_device_resampler_vs_pinned_oracle_statistics_d16(qi, eng):
+    """The d = 16 perf path -- k_bucket_anc16 + k_bucket_kick16 (MFMA kicks, canonicalize's classify pass fused) +
+    k_tomo_canon_list, i.e. what config 5 runs -- tied to the REFERENCE's restatement: 32 seeds of the device resample of
+    one weighted Ginibre cloud (an SMCUpdater over a 2-qubit TomographyModel, canonicalize on: resamplers.py:256-392
+    followed by smc.py:529 / tomography/models.py:149-209) against 32 seeds of `np_oracle.liu_west` (G4-pinned) followed
+    by `np_oracle.tomo_canonicalize` (G5-pinned) on the same cloud.  Per free coordinate: KS over the pooled particles,
+    Welch tests on the per-seed means and variances, every off-diagonal covariance; and every device output is a
+    physical state (x_0 = 1/2, rho >= 0, tr rho = 1).  Round 4 had this tie for d = 1 and d = 3 only."""
+    rs = np.random.RandomState(5)
+    n, a = 17000, 0.9                                       # > 4 chunks' worth of outputs: the split bucketed sampler
+    basis = qi.tomography.pauli_basis(2)
+    tm = qi.TomographyModel(basis)
+    x = orc.ginibre_prior_sample(n, basis.data, rs)
+    w = rs.random_sample(n) ** 2
+    w /= w.sum()
+    always = lambda z: np.ones(z.shape[0], dtype=bool)      # noqa: E731  (tomography/models.py:143-147)
+    dev, ref = [], []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        upd = qi.SMCUpdater(tm, n, fixed_prior(qi, x), device_rng=True, seed=0)
+        upd.particle_weights = w
+        assert upd._fused_canon is not None and eng.fused_canon_applies(16, n, n)
+        for s_ in STAT_SEEDS:
+            res = qi.LiuWestResampler(a=a, device_rng=True, seed=s_)
+            new = res(tm, upd)
+            assert new._canonicalized                       # the resample's own kernels folded canonicalize in
+            dev.append(np.asarray(new.particle_locations))
+            np.random.seed(1000 + s_)
+            kicked = orc.liu_west(w, x, always, orc.LegacyRNG(), a=a)[0]
+            ref.append(orc.tomo_canonicalize(kicked, basis.data))
+    dev, ref = np.stack(dev), np.stack(ref)
+    # the fixture must make canonicalize bite: a good share of the kicked particles leave the state space
+    rho_k = np.einsum("na,aij->nij", kicked, basis.data.conj())
+    frac_unphysical = np.mean(np.linalg.eigvalsh((rho_k + rho_k.conj().transpose(0, 2, 1)) / 2).min(axis=1) < 0)
+    assert 0.1 < frac_unphysical < 0.9, frac_unphysical
+    # physicality of EVERY device output (32 x 17000 states)
+    flat = dev.reshape(-1, 16)
+    assert np.abs(flat[:, 0] - 0.5).max() < 1e-12
+    rho = np.einsum("na,aij->nij", flat, basis.data.conj())
+    ev = np.linalg.eigvalsh((rho + rho.conj().transpose(0, 2, 1)) / 2)
+    assert ev.min() > -1e-12 and np.abs(ev.sum(axis=1) - 1.0).max() < 1e-12
+    assert np.abs(ref.reshape(-1, 16)[:, 0] - 0.5).max() < 1e-12
+    # same law, coordinate by coordinate, on the 15 free coordinates (x_0 is the constant 1/2 on both sides)
+    _two_sample_checks(dev[:, :, 1:], ref[:, :, 1:], "d16")
 
 
 def test_kl_divergence_g14(qi, golden):
@@ -2108,14 +2239,38 @@ def test_full_size_other_configs(qi, eng):
         np.random.seed(0)
         x0 = qi.GinibreDistribution(basis).sample(5000)
         x0 = np.tile(x0, (250, 1)) + 0.05 * rs.randn(1_250_000, 16)          # many unphysical ones
-        upd = qi.SMCUpdater(tm, 1_250_000, fixed_prior(qi, x0))               # reset() canonicalizes (smc.py:317-320)
-        x = upd._x
-        assert float((x[0] - 0.5).abs().max().item()) < 1e-12
-        idx = rs.choice(1_250_000, 3000, replace=False)
-        sub = upd.particle_locations[idx]
-        rho = np.einsum("na,aij->nij", sub, basis.data.conj())
-        ev = np.linalg.eigvalsh((rho + rho.conj().transpose(0, 2, 1)) / 2)
-        assert ev.min() > -1e-12 and np.allclose(ev.sum(axis=1), 1.0, atol=1e-12)
+        upd = qi.SMCUpdater(tm, 1_250_000, fixed_prior(qi, x0), device_rng=True, seed=5)   # reset() canonicalizes (smc.py:317-320)
+
+        def physical(u):
+            x = u._x
+            assert tuple(x.shape) == (16, 1_250_000)
+            assert float((x[0] - 0.5).abs().max().item()) < 1e-12
+            idx = rs.choice(1_250_000, 3000, replace=False)
+            sub = u.particle_locations[idx]
+            rho = np.einsum("na,aij->nij", sub, basis.data.conj())
+            ev = np.linalg.eigvalsh((rho + rho.conj().transpose(0, 2, 1)) / 2)
+            assert ev.min() > -1e-12 and np.allclose(ev.sum(axis=1), 1.0, atol=1e-12)
+        physical(upd)
+        # ... then the config's own loop at full size: six sparse-Pauli updates (k_update_tomo<2>: e_0 + e_P) and a
+        # device-RNG resample on the split d = 16 sampler with canonicalize's classify pass fused into the kicks
+        # (k_bucket_anc16 + k_bucket_kick16 + k_tomo_canon_list) -- the same physicality checks on the new cloud
+        mean0 = upd.est_mean()
+        for k, pauli in enumerate((3, 7, 12, 5, 9, 14)):
+            ep = np.zeros((1,), dtype=tm.expparams_dtype)
+            ep["meas"][0, 0], ep["meas"][0, pauli] = 1, 1
+            upd.update(k & 1, ep, check_for_resample=False)
+            assert 0 < upd.normalization_record[-1] < 1
+        assert upd.n_ess < upd.n_particles and np.isfinite(upd.est_mean()).all()
+        m_before, c_before = upd.est_mean(), upd.est_covariance_mtx()
+        rc0 = upd.resample_count
+        upd.resample()
+        assert upd.resample_count == rc0 + 1 and upd.n_particles == 1_250_000
+        assert upd.n_ess == pytest.approx(1_250_000, rel=1e-12)
+        physical(upd)
+        # Liu-West keeps the posterior mean (up to Monte-Carlo error and the pull of canonicalize towards the state space)
+        m_after = upd.est_mean()
+        assert abs(m_after[0] - 0.5) < 1e-12 and np.abs(m_after - m_before).max() < 0.02
+        assert np.abs(mean0 - m_before).max() > 1e-4          # (the six data did move the posterior)
 
 
 def test_argsort_searchsorted_gather(eng):
@@ -2491,9 +2646,16 @@ def test_adopted_resample_same_cloud_same_warnings(qi, monkeypatch):
                     upd.resampler.a = 0.9
                 upd.update(o, ep)
         return upd
-    a, b = run_edit(True), run_edit(False)
+    from qinfer_amd.engine import get_engine
+    q0, a0 = get_engine().step_stats()
+    a = run_edit(True)
+    q1, a1 = get_engine().step_stats()
+    b = run_edit(False)
     assert a.resample_count == b.resample_count > 2
     np.testing.assert_array_equal(a.particle_locations, b.particle_locations)
+    # ... and is not COUNTED as adopted either (qsmc_step_adopted is the caller's word; round 4 counted in qsmc_step, before
+    # the caller had decided): every resample was queued, all but the one that followed the edit were adopted
+    assert q1 - q0 == a.resample_count and a1 - a0 == a.resample_count - 1, (q1 - q0, a1 - a0, a.resample_count)
 
 
 def test_reserve_and_fuse_rule(qi, eng):

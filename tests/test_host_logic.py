@@ -339,3 +339,25 @@ def test_native_ok_judges_by_defining_class():
     # BinomialModel follows the same rule for its underlying model
     assert qi.BinomialModel(Plain())._native and not qi.BinomialModel(Spoof())._native
     assert qi.BinomialModel(qi.RandomizedBenchmarkingModel())._native
+
+
+def test_gaussian_random_walk_step_laws_seed_for_seed(golden):
+    """GaussianRandomWalkModel.update_timestep, all four covariance variants (given diagonal / given dense / learned
+    diagonal / learned dense), against ONE seeded call of the reference each (fixture g10_grw_steps, generated by
+    oracle/gen_golden.py from derived_models.py:920-963): the same draw shapes in the same order from the legacy
+    global stream, so a seeded host-RNG run consumes np.random as QInfer does."""
+    g = golden("g10_grw_steps")
+    t2 = qi.UnknownT2Model()
+    ep = np.empty((3,), dtype=t2.expparams_dtype)
+    ep['t'] = g["expparam_t"]
+    kws = {"known_diag": dict(fixed_covariance=np.array([4e-4, 9e-4])),
+           "known_dense": dict(fixed_covariance=g["cov_dense"], diagonal=False),
+           "learned_diag": dict(), "learned_dense": dict(diagonal=False)}
+    assert sorted(kws) == sorted(str(t) for t in g["tags"])
+    for tag, kw in kws.items():
+        m = qi.GaussianRandomWalkModel(t2, scale_mult=lambda e: np.sqrt(e['t']), **kw)
+        mp = g[tag + "_in"]
+        assert m.n_modelparams == mp.shape[1], tag
+        np.random.seed(4242)
+        out = m.update_timestep(mp.copy(), ep)
+        np.testing.assert_allclose(out, g[tag + "_out"], rtol=0, atol=1e-15, err_msg=tag)
