@@ -1687,7 +1687,7 @@ __global__ __launch_bounds__(BT) void k_bucket_anc16(
     }
     // (the kick kernel's list of particles for canonicalize's second pass starts empty: cleared here, a launch earlier,
     //  instead of by a memset command between the two kernels -- that was a 10 us bubble)
-    if (bid == 0 && threadIdx.x == 0 && canon_count) *canon_count = 0u;
+    if (bid == 0 && threadIdx.x < 2 && canon_count) canon_count[threadIdx.x] = 0u;      // ([1]: the list pass's second list)
     if (bid >= item_off[chunks]) return;
     const int c = item_chunk[bid];
     const int part = bid - item_off[c];

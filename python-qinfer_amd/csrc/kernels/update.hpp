@@ -32,29 +32,12 @@ struct ReduceOut {
     double *tile_prefix;                    // k_update_fused only (nullable): [tp_chunks + 1] monotone prefix of the UNNORMALISED
     int tp_chunks, tp_tpc;                  //   chunk sums, formed from tile_sums by a second workgroup of the reducing launch
     long long tp_ntiles;                    //   (k_reduce_partials_scan) while the first one reduces
-    unsigned int *tickets;                  // non-null: the SMALL-GRID form -- no reducing launch; the last workgroup of the update
-                                            //   kernel itself (two-level arrival tickets: [0] the groups' word, [1 + g] group g's)
-                                            //   sums the partials, publishes and takes the resample test (fold_tail)
 };
 
 // |sum w'| below this and the host renormalises by 1 instead (smc.py:369-370): no speculative prefix then
 constexpr double PREFIX_NORM_EPS = 2.220446049250313e-16;
 
-// Ordering without a cache flush (the pattern of rocPRIM's decoupled look-back scan state on this hardware): a value written
-// with an agent-scope atomic store goes THROUGH the caches; waiting for the store to complete (s_waitcnt vmcnt(0)) before
-// the agent-scope read-modify-write that announces it orders the two at the memory side.  A full agent-scope release fence
-// instead writes back the whole L2 of the XCD -- the w' stores of this very kernel: measured 39 -> 120 us per update at
-// N = 1e7 (round 4; round 1 saw the same as "+11 us").  The reader uses agent-scope atomic loads (past its own L2).
-__device__ __forceinline__ void fence_order_only_release() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_waitcnt(/*vmcnt*/ 0 | (/*expcnt*/ 0x7 << 4) | (/*lgkmcnt*/ 0xf << 8));
-}
-__device__ __forceinline__ void fence_order_only_acquire() {
-    __builtin_amdgcn_s_waitcnt(/*vmcnt*/ 0 | (/*expcnt*/ 0x7 << 4) | (/*lgkmcnt*/ 0xf << 8));
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
-template <int NS, bool FOLD = false>
+template <int NS>
 __device__ __forceinline__ void block_publish(double (&v)[NS], double mn, const ReduceOut &ro) {
     // one barrier: every wave reduces its NS sums and the minimum, lane 0 parks them in LDS, then thread k
     // combines value k over the waves (in wave order, as before: bitwise the same totals) and stores it --
@@ -78,15 +61,7 @@ __device__ __forceinline__ void block_publish(double (&v)[NS], double mn, const 
             const double t = lds[wv * (NS + 1) + k];
             s = (k < NS) ? s + t : fmin(s, t);
         }
-        double *dst = &ro.partials[(size_t)k * gridDim.x + blockIdx.x];    // column k of [NS + 1][grid]: the reducer reads it coalesced
-        if (FOLD) {
-            // small-grid form: the reader is a workgroup of THIS launch, possibly behind another XCD's L2 -- the store goes
-            // through the caches (agent-scope atomic store) and is waited for before this workgroup draws its ticket
-            __hip_atomic_store(dst, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            fence_order_only_release();
-        } else {
-            *dst = s;
-        }
+        ro.partials[(size_t)k * gridDim.x + blockIdx.x] = s;          // column k of [NS + 1][grid]: the reducer reads it coalesced
     }
 }
 
@@ -102,13 +77,9 @@ __device__ __forceinline__ void block_publish(double (&v)[NS], double mn, const 
 // release fences every workgroup writes back its XCD's L2 (update kernel 39 -> 120 us); with the partials stored through the
 // caches and order-only fences the kernel grows by 5.4 us (ticket chain, a cold sweep of the rows, the publish -- serial at
 // its end) against 7-8 us of launch saved, and with the chunk prefix back in k_bucket_counts the step comes out 2-3 % slower.
-template <int NS, bool COHERENT = false>      // COHERENT: the partials were written by this very launch (fold_tail)
+template <int NS>
 __device__ __forceinline__ void reduce_partials_body(int nblocks, const ReduceOut &ro) {
-    // (rows in flight per thread and trip; a thread adds its rows in ascending order whatever the unrolling, so the sums do
-    //  not depend on it.  Inside an update kernel -- COHERENT -- the registers of this tail count against the kernel's
-    //  occupancy: at most ~40 doubles)
-    constexpr int THREADS = QSMC_BLOCK, WAVES = THREADS / QSMC_WAVE,
-                  UNROLL = COHERENT ? (NS <= 5 ? 4 : (NS <= 12 ? 2 : 1)) : (NS <= 17 ? 4 : (NS <= 38 ? 2 : 1));
+    constexpr int THREADS = QSMC_BLOCK, WAVES = THREADS / QSMC_WAVE, UNROLL = NS <= 17 ? 4 : (NS <= 38 ? 2 : 1);
     __shared__ double lds[WAVES * (NS + 1)];
     __shared__ double tot[NS + 1];
     unsigned long long failed0 = 0ull, failed1 = 0ull;
@@ -130,9 +101,7 @@ __device__ __forceinline__ void reduce_partials_body(int nblocks, const ReduceOu
             const int g = g0 + u * THREADS;
             const double *p = ro.partials + (g < nblocks ? g : nblocks - 1);
 #pragma unroll
-            for (int k = 0; k <= NS; ++k)
-                v[u][k] = COHERENT ? __hip_atomic_load(p + (size_t)k * nblocks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                   : p[(size_t)k * nblocks];
+            for (int k = 0; k <= NS; ++k) v[u][k] = p[(size_t)k * nblocks];
         }
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
@@ -218,47 +187,6 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_reduce_partials(int nblocks, Red
     reduce_partials_body<NS>(nblocks, ro);
 }
 
-// ---------------------------------------------------------------------------------------------
-// Round 5: ONE launch per datum for a SMALL cloud.  A shard of 1.25e6 particles (config 5's share of an 8-GPU node; the
-// headline under strong scaling) is 611 tiles: its update kernel runs 10 us, and the reducing launch behind it (5.2 us
-// of kernel that is launch ramp, one cold sweep and a fence) plus the gated count launch behind that were two thirds of
-// what the GPU did per datum (profiles/r4_c_c5_trace_gaps.txt).  Here the LAST workgroup of the update kernel to finish
-// does the second level itself -- the same rows summed in the same index order by the same code (reduce_partials_body),
-// so the totals, and everything derived from them, have the same bits as with the separate launch -- publishes to pinned
-// memory and sets the completion word.  No reducing launch; no speculative count launch either: the host launches
-// k_bucket_counts when its own n_ess test says a resample is due (one host decision, not two launches per datum).
-// Round 4 built this for EVERY grid and measured it at N = 1e7 (2048 workgroups: -2..3 %, a cold sweep of 2048 rows
-// serial at the end of a 40 us kernel, the chunk prefix back inside the count kernel: tools/experiments/
-// r4_reduction_folded_into_update.patch); the host picks it for grids up to QSMC_FOLD_MAX_GRID workgroups only.
-// Arrival: groups of 32 workgroups share a word, the groups' last arrivals share one more (<= 32 + 64 read-modify-writes
-// on any address; 2048 arrivals on ONE word serialise at ~88 per us).  Nothing is flushed: partials went through the
-// caches with agent-scope stores that were waited for (block_publish), tickets are relaxed agent-scope atomics, the last
-// workgroup reads the rows with agent-scope loads.  The words reset themselves for the next launch.
-// ---------------------------------------------------------------------------------------------
-template <int NS>
-__device__ __forceinline__ void fold_tail(const ReduceOut &ro) {
-    __shared__ int fold_last;
-    __syncthreads();                                         // every partial of this workgroup has completed (block_publish)
-    if (threadIdx.x == 0) {
-        const unsigned int g = blockIdx.x >> 5, n_groups = (gridDim.x + 31u) >> 5;
-        const unsigned int in_group = (g + 1u < n_groups) ? 32u : gridDim.x - (g << 5);
-        int last = 0;
-        const unsigned int t = __hip_atomic_fetch_add(&ro.tickets[1 + g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (t == in_group - 1u) {
-            __hip_atomic_store(&ro.tickets[1 + g], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned int t2 = __hip_atomic_fetch_add(&ro.tickets[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (t2 == n_groups - 1u) {
-                __hip_atomic_store(&ro.tickets[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                last = 1;
-            }
-        }
-        fence_order_only_acquire();
-        fold_last = last;
-    }
-    __syncthreads();
-    if (fold_last) reduce_partials_body<NS, true>((int)gridDim.x, ro);
-}
-
 // Per-particle accumulation of the update: [sum w', sum w'^2, #bad, sum w' x_m (DMOM),
 // sum w' x_m x_q (m <= q)] and min w'.  DMOM > 0 folds the weighted moments of the NEW weights
 // into the same pass (x is already in registers): est_mean / est_covariance_mtx and the
@@ -289,10 +217,7 @@ struct UpdAcc {
     }
 };
 
-// FOLD: the small-grid form (fold_tail below block_publish): its own instantiation, because the reducing tail's registers
-// count against the kernel's occupancy (d = 1: 92 -> 102 VGPRs, five waves per SIMD -> four) -- nothing a 611-workgroup
-// launch notices, but the large-cloud kernels must not pay for a tail they never run.
-template <int KIND, int VEC, bool ONES, bool POW, bool FOLD = false>   // ONES: w_in == nullptr stands for all-ones weights; POW: MLEModel
+template <int KIND, int VEC, bool ONES, bool POW>   // ONES: w_in == nullptr stands for all-ones weights; POW: MLEModel
 __global__ __launch_bounds__(QSMC_BLOCK) void k_update_fused(
     const double *__restrict__ x, int64_t ldx, int64_t n, const double *__restrict__ w_in,
     double *__restrict__ w_out, double prev_norm, ExpArgs e, int64_t outcome, ReduceOut ro, int nt) {
@@ -464,8 +389,7 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_update_fused(
             for (int64_t k = first + threadIdx.x; k < end; k += QSMC_BLOCK) ro.tile_sums[k] = 0.0;
         }
     }
-    block_publish<UpdAcc<DMOM>::NS, FOLD>(acc.s, acc.mn, ro);
-    if constexpr (FOLD) fold_tail<UpdAcc<DMOM>::NS>(ro);     // small grid: the last workgroup reduces and publishes
+    block_publish<UpdAcc<DMOM>::NS>(acc.s, acc.mn, ro);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -481,7 +405,7 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_update_fused(
 // else in the update wants the other rows.  Same tiles, tile sums and partials as k_update_fused: everything behind
 // it (reduction, chunk prefix, speculative counts, resample) is unchanged.  Full tiles issue all their loads first.
 // ---------------------------------------------------------------------------------------------
-template <int NNZ, bool ONES, bool FOLD = false>
+template <int NNZ, bool ONES>
 __global__ __launch_bounds__(QSMC_BLOCK) void k_update_tomo(
     const double *__restrict__ x, int64_t ldx, int64_t n, const double *__restrict__ w_in,
     double *__restrict__ w_out, double prev_norm, ExpArgs e, int64_t outcome, ReduceOut ro) {
@@ -562,8 +486,7 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_update_tomo(
             for (int64_t k = first + threadIdx.x; k < end; k += QSMC_BLOCK) ro.tile_sums[k] = 0.0;
         }
     }
-    block_publish<3, FOLD>(acc.s, acc.mn, ro);
-    if constexpr (FOLD) fold_tail<3>(ro);                    // small grid: the last workgroup reduces and publishes
+    block_publish<3>(acc.s, acc.mn, ro);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -60,7 +60,7 @@ struct qsmc_ctx {
     unsigned long long *gbar;      // device: [0] arrival counter of the count kernel's barriers (only ever grows), [1] its
                                    // timeouts; [2], [3] arrivals / departures of the redraw kernel's self-resetting barrier
     unsigned long long gbar_base;  // host shadow: arrivals handed out so far
-    unsigned int *tickets;         // device: arrival words of the small-grid update (kernels/update.hpp: fold_tail), self-resetting
+    unsigned int *tickets;         // device: arrival word of k_sum_partials_publish (self-resetting)
     int cu_count;                  // compute units this process can run on (bounds the resident grids of the barrier kernels)
     int cu_reported;               // what the device attribute says
     void *sort_tmp;                // rocPRIM temporary storage + key/value staging for qsmc_argsort
@@ -168,7 +168,7 @@ struct qsmc_ctx {
     } while (0)
 
 constexpr int REDUCE_OUT_MAX = 192;
-constexpr int FOLD_TICKET_WORDS = 1 + 64 + 63;      // [0] + one word per group of 32 workgroups (grid <= QSMC_GRID_CAP = 2048), padded
+constexpr int TICKET_WORDS = 16;                    // arrival words (k_sum_partials_publish uses the last one)
 constexpr int QSMC_PROF_CAP = 4096;
 
 // Census of the compute units this process can actually run on.  hipDeviceAttributeMultiprocessorCount reports the
@@ -381,19 +381,7 @@ static ReduceOut make_reduce(qsmc_ctx *h, bool want_host, double *stats4) {
     ro.tp_ntiles = 0;
     ro.prefix_gate = nullptr;
     ro.prefix_thresh = 0.0;
-    ro.tickets = nullptr;
     return ro;
-}
-
-// The small-grid form of an update (kernels/update.hpp: fold_tail): the update kernel's last workgroup reduces and publishes,
-// no reducing launch, no speculative count launch.  For grids of at most QSMC_FOLD_MAX_GRID workgroups (default below;
-// 0 switches it off) whose sums the host waits for.  Read per call (a getenv is ~0.1 us): the tests A/B it in one process.
-constexpr int FOLD_MAX_GRID_DEFAULT = 1024;
-static bool fold_applies(int grid, bool want_host) {
-    if (!want_host) return false;
-    const char *e = getenv("QSMC_FOLD_MAX_GRID");
-    const int cap = e ? atoi(e) : FOLD_MAX_GRID_DEFAULT;
-    return grid <= cap && grid <= 32 * 64;
 }
 
 // Wait for the reduction that was armed with the current h->seq.  hipStreamSynchronize costs ~12 us
@@ -499,15 +487,7 @@ static void launch_update(qsmc_ctx *h, bool vec2, int grid, hipStream_t s, const
             hipExtLaunchKernelGGL((k_update_fused<KIND, V, O, false>), dim3(grid), dim3(QSMC_BLOCK), 0, s, e0, e1, 0, \
                                   x, ldx, n, w_in, w_out, prev_norm, e, outcome, ro, nt);                 \
     } while (0)
-    if (ro.tickets) {            // the small-grid form (16-byte lanes, plain likelihood: update_can_fold)
-        if (w_in)
-            hipExtLaunchKernelGGL((k_update_fused<KIND, 2, false, false, true>), dim3(grid), dim3(QSMC_BLOCK), 0, s, e0, e1, 0,
-                                  x, ldx, n, w_in, w_out, prev_norm, e, outcome, ro, nt);
-        else
-            hipExtLaunchKernelGGL((k_update_fused<KIND, 2, true, false, true>), dim3(grid), dim3(QSMC_BLOCK), 0, s, e0, e1, 0,
-                                  x, ldx, n, w_in, w_out, prev_norm, e, outcome, ro, nt);
-    }
-    else if (vec2 && w_in) LU(2, false);
+    if (vec2 && w_in) LU(2, false);
     else if (vec2) LU(2, true);
     else if (w_in) LU(1, false);
     else LU(1, true);
@@ -833,23 +813,39 @@ static int hyp_dispatch(qsmc_ctx *h, Chain2Queue &q, const qsmc_model_t *model, 
     return QSMC_OK;
 }
 
+// The list pass of a 2-qubit canonicalize: the eigenvector-free form (k_tomo_canon_list_fast, round 5) on the list, then
+// the eigenvector form on what that one flagged (count[1] entries of list2: none on a Ginibre-like cloud -- the launch
+// leaves at once).  QSMC_CANON_JACOBI=1 keeps the round-4 kernel on the whole list (A/B).
+template <class Basis>
+static void launch_canon_list4(Basis B, int grid, hipStream_t s, hipEvent_t l0, hipEvent_t l1, double *x, int64_t ldx,
+                               int32_t allow_sub, const unsigned int *list, unsigned int *count, unsigned int *list2) {
+    static const bool jacobi_env = getenv("QSMC_CANON_JACOBI") != nullptr;
+    if (jacobi_env) {
+        hipExtLaunchKernelGGL((k_tomo_canon_list<4, Basis>), dim3(grid), dim3(QSMC_BLOCK), 0, s, l0, l1, 0, B, x, ldx, allow_sub,
+                              list, count);
+        return;
+    }
+    hipExtLaunchKernelGGL((k_tomo_canon_list_fast<Basis>), dim3(grid), dim3(QSMC_BLOCK), 0, s, l0, l1, 0, B, x, ldx, allow_sub,
+                          list, count, list2);
+    hipLaunchKernelGGL((k_tomo_canon_list<4, Basis>), dim3(64), dim3(QSMC_BLOCK), 0, s, B, x, ldx, allow_sub, list2, count + 1);
+}
+
 template <class Basis>
 static int canon_dim4(qsmc_ctx *h, Basis B, double *x, int64_t ldx, int64_t n, int32_t allow_subnormalized, hipStream_t s) {
     if (n >= (1ll << 32)) return QSMC_ERR_UNSUPPORTED;
     const int grid = grid_for(n, QSMC_BLOCK);
-    int rc = ensure_iscratch(h, ((size_t)n + 4) * sizeof(unsigned int));
+    int rc = ensure_iscratch(h, (2 * (size_t)n + 8) * sizeof(unsigned int));
     if (rc) return rc;
-    unsigned int *count = h->iscratch;              // [0] = list length; the list starts at [4]
-    unsigned int *list = h->iscratch + 4;
-    HIP_TRY(h, hipMemsetAsync(count, 0, sizeof(unsigned int), s));
+    unsigned int *count = h->iscratch;              // [0] = list length, [1] = length of the second list; the list starts at [4]
+    unsigned int *list = h->iscratch + 4, *list2 = h->iscratch + 4 + n + 4;
+    HIP_TRY(h, hipMemsetAsync(count, 0, 2 * sizeof(unsigned int), s));
     hipEvent_t c0 = nullptr, c1 = nullptr, l0 = nullptr, l1 = nullptr;
     prof_events(h, QSMC_PROF_CANON_CLASSIFY, &c0, &c1);
     prof_events(h, QSMC_PROF_CANON_LIST, &l0, &l1);
     const int cgrid = grid < 1024 ? grid : 1024;       // (few flushes per workgroup: see k_tomo_classify)
     hipExtLaunchKernelGGL((k_tomo_classify<4, Basis>), dim3(cgrid), dim3(QSMC_BLOCK), 0, s, c0, c1, 0, B, x, ldx, n,
                           allow_subnormalized, list, count);
-    hipExtLaunchKernelGGL((k_tomo_canon_list<4, Basis>), dim3(grid), dim3(QSMC_BLOCK), 0, s, l0, l1, 0, B, x, ldx,
-                          allow_subnormalized, list, count);
+    launch_canon_list4(B, grid, s, l0, l1, x, ldx, allow_subnormalized, list, count, list2);
     HIP_TRY(h, hipGetLastError());
     return QSMC_OK;
 }
@@ -885,8 +881,8 @@ int qsmc_create(qsmc_handle_t *out, int device) {
     if (e == hipSuccess) e = hipMemset(h->counter, 0, 2 * sizeof(long long));
     if (e == hipSuccess) e = hipMalloc(&h->gbar, 4 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(h->gbar, 0, 4 * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMalloc(&h->tickets, FOLD_TICKET_WORDS * sizeof(unsigned int));
-    if (e == hipSuccess) e = hipMemset(h->tickets, 0, FOLD_TICKET_WORDS * sizeof(unsigned int));
+    if (e == hipSuccess) e = hipMalloc(&h->tickets, TICKET_WORDS * sizeof(unsigned int));
+    if (e == hipSuccess) e = hipMemset(h->tickets, 0, TICKET_WORDS * sizeof(unsigned int));
     if (e == hipSuccess) e = hipMalloc(&h->spec.gate, sizeof(int));
     if (e == hipSuccess) e = hipMemset(h->spec.gate, 0, sizeof(int));
     h->spec.prof_slot = -1;
@@ -1115,17 +1111,12 @@ int qsmc_update_fused(qsmc_handle_t h, const qsmc_model_t *model, const double *
     ++h->ts.gen;
     h->ts.armed = 0;
     h->spec.launched = 0;
-    const bool fold = vec2 && ea.lik_pow == 0.0 && fold_applies(grid, stats_host || moments_host);
-    if (fold) {
-        ro.tickets = h->tickets;           // one launch: no chunk prefix beside a reduction, no gated count launch behind it
-    } else {
-        rc = setup_tile_prefix(h, ro, n, per_block, ns);
-        if (rc) return rc;
-        if (h->spec.enabled && ro.tile_sums && ro.failed_dst) {
-            // the resampler's weight-only prefix goes out right behind the reduction, gated on the device-side ESS test
-            ro.prefix_gate = h->spec.gate;
-            ro.prefix_thresh = h->spec.thresh;
-        }
+    rc = setup_tile_prefix(h, ro, n, per_block, ns);
+    if (rc) return rc;
+    if (h->spec.enabled && ro.tile_sums && ro.failed_dst) {
+        // the resampler's weight-only prefix goes out right behind the reduction, gated on the device-side ESS test
+        ro.prefix_gate = h->spec.gate;
+        ro.prefix_thresh = h->spec.thresh;
     }
     switch (model->kind) {
 #define LAUNCH_U(K)                                                                             \
@@ -1147,13 +1138,7 @@ int qsmc_update_fused(qsmc_handle_t h, const qsmc_model_t *model, const double *
                 prof_events(h, w_in ? QSMC_PROF_UPDATE : QSMC_PROF_UPDATE_ONES, &e0, &e1);
 #define LT(NZ)                                                                                                          \
     case NZ:                                                                                                            \
-        if (w_in && fold)                                                                                               \
-            hipExtLaunchKernelGGL((k_update_tomo<NZ, false, true>), dim3(grid), dim3(QSMC_BLOCK), 0, s, e0, e1, 0, x, ldx, n, \
-                                  w_in, w_out, prev_norm, ea, outcome, ro);                                             \
-        else if (fold)                                                                                                  \
-            hipExtLaunchKernelGGL((k_update_tomo<NZ, true, true>), dim3(grid), dim3(QSMC_BLOCK), 0, s, e0, e1, 0, x, ldx, n,  \
-                                  w_in, w_out, prev_norm, ea, outcome, ro);                                             \
-        else if (w_in)                                                                                                  \
+        if (w_in)                                                                                                       \
             hipExtLaunchKernelGGL((k_update_tomo<NZ, false>), dim3(grid), dim3(QSMC_BLOCK), 0, s, e0, e1, 0, x, ldx, n, w_in, \
                                   w_out, prev_norm, ea, outcome, ro);                                                   \
         else                                                                                                            \
@@ -1170,10 +1155,8 @@ int qsmc_update_fused(qsmc_handle_t h, const qsmc_model_t *model, const double *
 #undef LAUNCH_U
     }
     HIP_TRY(h, hipGetLastError());
-    if (!fold) {
-        rc = launch_reduce(h, ns, grid, ro, s);
-        if (rc) return rc;
-    }
+    rc = launch_reduce(h, ns, grid, ro, s);
+    if (rc) return rc;
     if (ro.prefix_gate) {
         rc = resample_prefix(h, w_out, n, 0.0, h->spec.n_out, h->spec.seed, h->spec.epoch, s, true);
         if (rc) return rc;
@@ -1633,7 +1616,7 @@ static int bucket_plan_layout(qsmc_ctx *h, int64_t chunks64, int64_t n_out, Buck
     const size_t retry_b = ((size_t)n_out * sizeof(unsigned int) + 15) & ~(size_t)15;
     int rc = ensure_iscratch(h, hist_b + counts_b + slot_b + item_b + map_b + retry_b);
     if (rc) return rc;
-    if (split16) rc = ensure_anc16(h, 2 * retry_b + 16);
+    if (split16) rc = ensure_anc16(h, 3 * retry_b + 64);        // ancestors, canonicalize's list (+ 4 count words), its second list
     if (rc) return rc;
     unsigned char *basep = reinterpret_cast<unsigned char *>(h->iscratch);
     bp->chunks = chunks;
@@ -1941,12 +1924,12 @@ static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int3
                 hipEvent_t l0 = nullptr, l1 = nullptr;
                 prof_events(h, QSMC_PROF_CANON_LIST, &l0, &l1);
                 const int lgrid = grid_for(n_out, QSMC_BLOCK);
+                unsigned int *clist2 = clist + ((size_t)n_out + 3) / 4 * 4 + 4;
                 if (canon.kind == 1)
-                    hipExtLaunchKernelGGL((k_tomo_canon_list<4, TomoPauli2>), dim3(lgrid), dim3(QSMC_BLOCK), 0, s, l0, l1, 0,
-                                          TomoPauli2{}, x_out, pl.ld_m, canon.allow_sub, clist, ccount);
+                    launch_canon_list4(TomoPauli2{}, lgrid, s, l0, l1, x_out, pl.ld_m, canon.allow_sub, clist, ccount, clist2);
                 else
-                    hipExtLaunchKernelGGL((k_tomo_canon_list<4, TomoDense<4>>), dim3(lgrid), dim3(QSMC_BLOCK), 0, s, l0, l1, 0,
-                                          TomoDense<4>{canon.basis}, x_out, pl.ld_m, canon.allow_sub, clist, ccount);
+                    launch_canon_list4(TomoDense<4>{canon.basis}, lgrid, s, l0, l1, x_out, pl.ld_m, canon.allow_sub, clist,
+                                       ccount, clist2);
             }
         }
     } else {
@@ -2342,7 +2325,7 @@ int qsmc_step(qsmc_handle_t h, qsmc_step_t *st, const qsmc_model_t *model, const
             hipLaunchKernelGGL(k_sum_partials, dim3(SUM_GRID), dim3(QSMC_BLOCK), 0, s, h->partials, gridm, MFMA_MOM_K, full);
         else                      // sums and their publish to the host in one launch (round 5; two before)
             hipLaunchKernelGGL(k_sum_partials_publish, dim3(SUM_GRID), dim3(QSMC_BLOCK), 0, s, h->partials, gridm, MFMA_MOM_K,
-                               full, h->mapped_big_dev, h->flag_dev, seq, h->tickets + FOLD_TICKET_WORDS - 1);
+                               full, h->mapped_big_dev, h->flag_dev, seq, h->tickets + TICKET_WORDS - 1);
         // (round 4 built the device form -- kernels/sqrtm.hpp -- and measured it: the gap between the two sampler kernels
         //  closes, but the one wavefront that forms S is latency-bound, ~90 rounds of three dependent LDS / fp64-division
         //  steps sharing a SIMD with the ancestor kernel's own waves: k_bucket_anc16 36 -> 96 us, a d = 16 resample

@@ -88,14 +88,14 @@ def test_headline_survives_a_stage_that_overruns():
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     line = _one_json_line(r.stdout)
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["transports"]["shm"]["headline"]
-    # (the first stage behind the headline is the strong-scaling leg: the overrun is recorded against it)
-    assert "watchdog" in line["strong_scaling"]["error"] and "strong_scaling" in line["strong_scaling"]["error"]
-    r = _run_bench(["--gpus", "2"] + SHARDED, {"QSMC_BENCH_SHARE_GPU": "1", "QSMC_BENCH_DEADLINE": "0.2",
-                                               "QSMC_BENCH_NO_STRONG": "1"})
-    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
-    line = _one_json_line(r.stdout)
-    assert line["n_gpus"] == 2 and line["value"] > 0 and "strong_scaling" not in line
-    assert "watchdog" in line["sharded_configs"]["error"] and "sharded_configs" in line["sharded_configs"]["error"]
+    # (the overrun is recorded against the stage that was running: the strong-scaling leg, a few milliseconds on shrunken
+    #  shards, or -- when that one made it -- the sharded configs behind it)
+    ss = line.get("strong_scaling", {})
+    if "error" in ss:
+        assert "watchdog" in ss["error"] and "strong_scaling" in ss["error"] and "sharded_configs" not in line
+    else:
+        assert ss["scaling"] == "strong" and ss["value"] > 0
+        assert "watchdog" in line["sharded_configs"]["error"] and "sharded_configs" in line["sharded_configs"]["error"]
 
 
 @pytest.mark.gpu
@@ -106,7 +106,8 @@ def test_headline_survives_a_rank_that_dies():
     assert r.returncode != 0
     line = _one_json_line(r.stdout)
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["transports"]["shm"]["headline"]
-    assert "another rank failed" in line["strong_scaling"]["error"]
+    stage_err = line["strong_scaling"]["error"] if "error" in line.get("strong_scaling", {}) else line["sharded_configs"]["error"]
+    assert "another rank failed" in stage_err
 
 
 @pytest.mark.gpu

@@ -1563,10 +1563,6 @@ def test_speculative_prefix_same_particles(qi, monkeypatch):
             monkeypatch.setattr(smc_mod.SMCUpdater, "_prefix_key", lambda self: None)
         else:
             monkeypatch.undo()
-        # (clouds this small would take the one-launch form of round 5, which queues nothing behind an update: the
-        #  mechanism under test is the large-cloud one, so that form is switched off here -- the library reads the
-        #  variable per call)
-        monkeypatch.setenv("QSMC_FOLD_MAX_GRID", "0")
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             upd = qi.SMCUpdater(model, n, prior, device_rng=True, seed=11)
@@ -1602,87 +1598,6 @@ def test_speculative_prefix_same_particles(qi, monkeypatch):
         np.testing.assert_array_equal(a.particle_locations, b.particle_locations)
         np.testing.assert_array_equal(a.particle_weights, b.particle_weights)
         np.testing.assert_array_equal(np.asarray(a.normalization_record), np.asarray(b.normalization_record))
-
-
-def test_small_grid_one_launch_same_numbers(qi, monkeypatch):
-    """Round 5: a small cloud's datum is ONE launch -- the update kernel's last workgroup sums the partials, publishes and
-    sets the completion word (kernels/update.hpp: fold_tail); no reducing launch, no gated count launch behind it, the
-    host queues k_bucket_counts when its own n_ess test fails.  The rows are summed in the same index order by the same
-    code, so nothing may change: bit-identical clouds, weights, records, n_ess and resample decisions against the
-    two-launch form (QSMC_FOLD_MAX_GRID=0), for every update kernel that has the form (d = 1, binomial, RB, T2, sparse
-    and dense tomography), with ragged last tiles and with implicit weights; and the count of speculative prefix
-    launches says which form ran."""
-    rng = np.random.default_rng(12)
-    ts = (9 / 8) ** np.arange(70)
-    prec = [(int(rng.random() < np.sin(0.3 * t / 2) ** 2), np.array([t])) for t in ts]
-    bm = qi.BinomialModel(qi.SimplePrecessionModel())
-    binom = []
-    for k in range(30):
-        ep = np.empty((1,), dtype=bm.expparams_dtype)
-        ep["x"], ep["n_meas"] = (9 / 8) ** k, 25
-        binom.append((int(rng.binomial(25, np.sin(0.3 * (9 / 8) ** k / 2) ** 2)), ep))
-    rbm = qi.RandomizedBenchmarkingModel()
-    rb = [(int(rng.random() < 0.5), np.array([(1 + 5 * k,)], dtype=rbm.expparams_dtype)) for k in range(40)]
-    t2 = qi.UnknownT2Model()
-    t2d = []
-    for k in range(40):
-        ep = np.empty((1,), dtype=t2.expparams_dtype)
-        ep["t"] = 1.0 + 2.0 * k
-        t2d.append((int(rng.random() < 0.5), ep))
-    basis = qi.tomography.pauli_basis(2)
-    tm = qi.TomographyModel(basis)
-    tomo, tomo_dense = [], []
-    for k in range(40):
-        ep = np.zeros((1,), dtype=tm.expparams_dtype)
-        ep["meas"][0, 0], ep["meas"][0, int(rng.integers(1, 16))] = 1, 1
-        tomo.append((int(rng.random() < 0.5), ep))
-        ep = np.zeros((1,), dtype=tm.expparams_dtype)
-        ep["meas"][0, :] = rng.normal(size=16) * 0.1
-        ep["meas"][0, 0] = 1
-        tomo_dense.append((int(rng.random() < 0.5), ep))
-    np.random.seed(9)
-    gin = qi.GinibreDistribution(basis).sample(30_011)
-    cases = [
-        ("precession", lambda: qi.SimplePrecessionModel(), lambda m: qi.UniformDistribution([0, 1]), 1_250_000, prec),
-        ("precession ragged", lambda: qi.SimplePrecessionModel(), lambda m: qi.UniformDistribution([0, 1]), 70_001, prec),
-        ("precession tiny", lambda: qi.SimplePrecessionModel(), lambda m: qi.UniformDistribution([0, 1]), 900, prec[:40]),
-        ("binomial", lambda: qi.BinomialModel(qi.SimplePrecessionModel()), lambda m: qi.UniformDistribution([0, 1]), 200_003, binom),
-        ("rb", lambda: qi.RandomizedBenchmarkingModel(), lambda m: qi.PostselectedDistribution(
-            qi.UniformDistribution([[0.8, 1], [0, 1], [0, 1]]), m), 150_000, rb),
-        ("t2", lambda: qi.UnknownT2Model(), lambda m: qi.UniformDistribution([[0, 1], [0, 0.1]]), 120_000, t2d),
-        ("tomography", lambda: qi.TomographyModel(basis), lambda m: fixed_prior(qi, gin), 30_011, tomo),
-        ("tomography dense", lambda: qi.TomographyModel(basis), lambda m: fixed_prior(qi, gin), 30_011, tomo_dense),
-    ]
-
-    def run(make_model, make_prior, n, data, fold):
-        monkeypatch.setenv("QSMC_FOLD_MAX_GRID", "1024" if fold else "0")
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            m = make_model()
-            upd = qi.SMCUpdater(m, n, make_prior(m), device_rng=True, seed=21)
-            q0, _ = upd._eng.prefix_stats()
-            ess = []
-            for o, ep in data:
-                upd.update(o, ep)
-                ess.append(float(upd.n_ess))
-            q1, _ = upd._eng.prefix_stats()
-            upd._eng.torch.cuda.synchronize()
-        return upd, np.array(ess), q1 - q0
-
-    for name, make_model, make_prior, n, data in cases:
-        a, ess_a, q_a = run(make_model, make_prior, n, data, True)
-        b, ess_b, q_b = run(make_model, make_prior, n, data, False)
-        assert q_a == 0, (name, q_a)                              # one launch per datum: nothing queued behind an update
-        if a._x.shape[0] <= 4:
-            assert q_b == len(data), (name, q_b)                  # the two-launch form queues its gated prefix every time
-        assert a.resample_count == b.resample_count and a.resample_count > 0, (name, a.resample_count, b.resample_count)
-        np.testing.assert_array_equal(ess_a, ess_b, err_msg=name)
-        np.testing.assert_array_equal(np.ravel(a.normalization_record), np.ravel(b.normalization_record), err_msg=name)
-        np.testing.assert_array_equal(a.particle_locations, b.particle_locations, err_msg=name)
-        np.testing.assert_array_equal(a.particle_weights, b.particle_weights, err_msg=name)
-        np.testing.assert_array_equal(a.est_mean(), b.est_mean(), err_msg=name)
-        np.testing.assert_array_equal(a.est_covariance_mtx(), b.est_covariance_mtx(), err_msg=name)
-        assert float(a.min_n_ess) == float(b.min_n_ess), name
 
 
 def test_device_sqrt_agrees_with_host():
