@@ -304,6 +304,18 @@ int qsmc_hypothetical_sums_multi(qsmc_handle_t h, const qsmc_model_t *model,
                                  const qsmc_expparam_t *exps, int32_t n_e, const int64_t *outcomes, const int32_t *n_o,
                                  const double *shift, int32_t what, double *out_host, qsmc_stream_t stream);
 
+/* qsmc_hypothetical_sums_multi in two halves, so that a caller that prepares its experiments one after the other (a
+ * design of n_e experiments: ~10 us of host work each) need not have prepared them all before the first pass starts:
+ * _begin queues the passes of the experiments it is given -- same arguments, out_host rows must stay valid -- and returns
+ * without waiting (experiments the two-ended walk does not serve are computed at once, as in _multi); any number of
+ * _begin calls may follow one another; _collect waits for everything queued and fills the rows.  No other call on the
+ * handle between the first _begin and _collect.  _multi is _begin + _collect. */
+int qsmc_hypothetical_sums_begin(qsmc_handle_t h, const qsmc_model_t *model,
+                                 const double *x, int64_t ldx, int64_t n, const double *w, double norm,
+                                 const qsmc_expparam_t *exps, int32_t n_e, const int64_t *outcomes, const int32_t *n_o,
+                                 const double *shift, int32_t what, double *out_host, qsmc_stream_t stream);
+int qsmc_hypothetical_sums_collect(qsmc_handle_t h, qsmc_stream_t stream);
+
 /* Same update for a model without a native kernel: L[i] was produced by the user's
  * Model.likelihood on the host and uploaded (plugin slow path). */
 int qsmc_update_from_likelihood(qsmc_handle_t h, const double *L, int64_t n,

@@ -215,6 +215,31 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_sum_columns(const double *__rest
     }
 }
 
+// k_sum_columns + the publish of its K sums to pinned host memory (mapped[0 .. K)) in one launch, as k_sum_partials_publish:
+// the design kernel's passes (qsmc_hypothetical_sums_*: one such launch per pass, each publishing to its own slot).
+__global__ __launch_bounds__(QSMC_BLOCK) void k_sum_columns_publish(const double *__restrict__ partials, int nblocks, int K,
+                                                                    double *__restrict__ mapped, unsigned long long *flag,
+                                                                    unsigned long long seq, unsigned int *ticket) {
+    const int lane = threadIdx.x & (QSMC_WAVE - 1);
+    const int wave = threadIdx.x / QSMC_WAVE;
+    for (int k = blockIdx.x * QSMC_WAVES_PER_BLOCK + wave; k < K; k += gridDim.x * QSMC_WAVES_PER_BLOCK) {
+        double s = 0.0;
+        for (int g = lane; g < nblocks; g += QSMC_WAVE) s += partials[(size_t)k * nblocks + g];
+        s = wave_sum(s);
+        if (lane == 0) mapped[k] = s;
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == gridDim.x - 1u) {
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence_system();
+            *reinterpret_cast<volatile unsigned long long *>(flag) = seq;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Kernel-density cross term of est_kl_divergence (distributions.py:466-487; distances metrics.py:72-106):
 //     sum_i p_i log( sum_j q_j phi(|| sqrt(Q) (x_i - y_j) ||_2 / delta) ),   phi = standard normal pdf,

@@ -502,6 +502,11 @@ struct MultiArgs {
     int k;
     ExpArgs e[MULTI_KMAX];
     int64_t outcome[MULTI_KMAX];
+    // SimplePrecession windows (round 5): the likelihood of datum k as fma(lb, pr0, la) -- (la, lb) = (0, 1) for outcome 0,
+    // (1, -1) otherwise: pr0 and 1 - pr0 to the bit, without the two v_cndmask of a select on a double -- and what bounds
+    // every datum's cosine argument for a particle: |t_k (omega - w_k) / 2| <= (|omega| + wabs_max) half_tmax
+    unsigned int outcome_mask;      // bit k: outcome k != 0 (la = 1, lb = -1)
+    double half_tmax, wabs_max;
 };
 
 constexpr int MULTI_PER_THREAD = 8;
@@ -524,6 +529,66 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_update_multi(
     constexpr int64_t TILE = (int64_t)QSMC_BLOCK * MULTI_PER_THREAD;
     for (int64_t base = (int64_t)blockIdx.x * TILE; base < n; base += (int64_t)gridDim.x * TILE) {
         double tsum = 0.0;
+        bool done = false;
+        if constexpr (KIND == QSMC_MODEL_PRECESSION && !POW) {
+            // SimplePrecession, a full tile (round 5): the loop nest TRANSPOSED -- the lane's eight particles are loaded first
+            // (all sixteen loads in flight), then datum by datum over the eight.  What the datum-inside-particle order cost
+            // (ISA of round 4's kernel, ~46 VALU instructions per (particle, datum), 72 % VALU-busy): the window's 4 K
+            // uniforms (t, w, the outcome's two coefficients) do not fit the SGPR file next to everything else and came
+            // back through v_readlane, four per likelihood; cos_sq's |x| <= 1e10 test with its exec-mask save / restore and
+            // branch sat around every likelihood; the outcome select was two v_cndmask.  Here a datum's uniforms are read
+            // once per eight likelihoods, ONE range test covers the tile (|t_k (omega - w_k) / 2| <= (|omega| + max |w|)
+            // max |t| / 2 for every k), the select is fma(lb, pr0, la) -- (0, 1) for outcome 0, (1, -1) otherwise: pr0 and
+            // 1 - pr0 to the bit.  Per thread the particles still enter every sum in ascending order: the same bits as the
+            // other order, weights and sums (tests: the window against the per-datum loop, and the generic path below under
+            // QSMC_MULTI_GENERIC=1 bit for bit).
+            if (base + TILE <= n && ma.half_tmax >= 0.0) {
+                double xs[MULTI_PER_THREAD], ws[MULTI_PER_THREAD];
+#pragma unroll
+                for (int u = 0; u < MULTI_PER_THREAD; ++u) {
+                    const int64_t i = base + (int64_t)u * QSMC_BLOCK + threadIdx.x;
+                    xs[u] = x[i];
+                    ws[u] = w_in ? w_in[i] : 1.0;
+                }
+                bool fast = true;
+#pragma unroll
+                for (int u = 0; u < MULTI_PER_THREAD; ++u) fast = fast && ((fabs(xs[u]) + ma.wabs_max) * ma.half_tmax <= 0.99e10);
+                if (fast) {
+#pragma unroll
+                    for (int u = 0; u < MULTI_PER_THREAD; ++u) ws[u] = ws[u] * inv_norm;
+#pragma unroll
+                    for (int k = 0; k < MULTI_KMAX; ++k) {
+                        if (k < ma.k) {
+                            const double tk = ma.e[k].t, wk = ma.e[k].w_;
+                            const bool one = (ma.outcome_mask >> k) & 1u;                  // (uniform: scalar selects)
+                            const double la = one ? 1.0 : 0.0, lb = one ? -1.0 : 1.0;
+#pragma unroll
+                            for (int u = 0; u < MULTI_PER_THREAD; ++u) {
+                                const double dw = xs[u] - wk;
+                                const double w = ws[u] * fma(lb, cos_sq_inrange(tk * dw / 2.0), la);
+                                ws[u] = w;
+                                s[3 * k] += w;
+                                s[3 * k + 1] += w * w;
+                                s[3 * k + 2] += (w >= 0.0) ? 0.0 : 1.0;
+                                mn = fmin(mn, w);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < MULTI_PER_THREAD; ++u) {
+                        const int64_t i = base + (int64_t)u * QSMC_BLOCK + threadIdx.x;
+                        const double w = ws[u];
+                        w_out[i] = w;
+                        tsum += w;
+                        const double wx = w * xs[u];
+                        s[3 * MULTI_KMAX] += wx;
+                        s[3 * MULTI_KMAX + 1] += wx * xs[u];
+                    }
+                    done = true;
+                }
+            }
+        }
+        if (!done) {
 #pragma unroll 1
         for (int u = 0; u < MULTI_PER_THREAD; ++u) {
             const int64_t i = base + (int64_t)u * QSMC_BLOCK + threadIdx.x;
@@ -554,6 +619,7 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_update_multi(
                     for (int m2 = m; m2 < DMOM; ++m2) s[q++] += wx * p[m2];
                 }
             }
+        }
         }
         if (ro.tile_sums) {                      // uniform
             const double t = wave_sum(tsum);
@@ -1054,11 +1120,14 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_hyp_sums_chain2(const double *__
     }
     // partial sums of the workgroup: waves 0, 2 hold the upward slots, 1, 3 the downward ones
     const int lane = threadIdx.x & (QSMC_WAVE - 1);
+    // (one sum at a time, reduced and parked: with the 39 shuffle trees of the 26-outcome moments pass interleaved by the
+    //  scheduler this epilogue spilled 16 doubles -- 144 B of scratch per lane in a kernel held to 128 VGPRs for four
+    //  waves per SIMD; never in the walk, but scratch all the same)
 #pragma unroll
-    for (int k = 0; k < NSH; ++k) s[k] = wave_sum(s[k]);
-    if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < NSH; ++k) red[wave][k] = s[k];
+    for (int k = 0; k < NSH; ++k) {
+        const double t = wave_sum(s[k]);
+        if (lane == 0) red[wave][k] = t;
+        __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
     for (int k = threadIdx.x; k <= 2 * NSH; k += QSMC_BLOCK) {

@@ -164,6 +164,25 @@ __host__ __device__ __forceinline__ double cos_sq(double x) {
     return (kh != floor(kh)) ? s2 : 1.0 - s2;              // k odd: cos^2 x = sin^2 r
 }
 
+// cos_sq for an argument the caller has already bounded by 1e10 (k_update_multi hoists that test out of its K likelihoods
+// per particle): the same operations on the same values, so the same bits as cos_sq there.
+__host__ __device__ __forceinline__ double cos_sq_inrange(double x) {
+    const double ax = fabs(x);
+    const double k = rint(ax * 6.36619772367581382433e-01);
+    double r = fma(-k, 1.57079632679489655800e+00, ax);
+    r = fma(-k, 6.12323399573676603587e-17, r);
+    const double z = r * r;
+    double ps = fma(z, CSQ(0, 1.58969099521155010221e-10), CSQ(1, -2.50507602534068634195e-08));
+    ps = fma(z, ps, CSQ(2, 2.75573137070700676789e-06));
+    ps = fma(z, ps, CSQ(3, -1.98412698298579493134e-04));
+    ps = fma(z, ps, CSQ(4, 8.33333333332248946124e-03));
+    ps = fma(z, ps, CSQ(5, -1.66666666666666324348e-01));
+    const double sn = fma(r * z, ps, r);
+    const double s2 = sn * sn;
+    const double kh = 0.5 * k;
+    return (kh != floor(kh)) ? s2 : 1.0 - s2;
+}
+
 __host__ __device__ __forceinline__ double precession_pr0(double omega, const ExpArgs &e) {
     // test_models.py:134-141: cos(t * dw / 2) ** 2
     const double dw = omega - e.w_;

@@ -36,6 +36,7 @@ using namespace qsmc;
 // context
 // =============================================================================================
 struct LWDev;             // kernels/sqrtm.hpp
+struct Chain2Queue;       // passes of the design kernel in flight (qsmc_hypothetical_sums_begin / _collect)
 struct qsmc_ctx {
     int device;
     double *partials;      // device scratch for per-workgroup partial sums
@@ -127,6 +128,7 @@ struct qsmc_ctx {
         long long n_banked, n_rounds_leftover;   // resamples that used the bank (diagnostic)
     } bank;
     double expect_next;     // qsmc_lw_expect_redraws: consumed by the next qsmc_lw_resample_philox
+    Chain2Queue *hypq;      // design passes queued by qsmc_hypothetical_sums_begin, waiting for _collect (allocated on first use)
     LWDev *lw_dev;          // device: Liu-West arguments of a d = 16 resample formed on the device (kernels/sqrtm.hpp)
     long long n_sqrt_dev, n_sqrt_agreed;   // square roots formed on the device by qsmc_step / of those, adopted after the host's check
     unsigned int *anc16;    // device: ancestors + canonicalize list of the split d = 16 sampler
@@ -664,11 +666,11 @@ static int chain2_enqueue(qsmc_ctx *h, const qsmc_model_t *model, const double *
     hipEvent_t he0 = nullptr, he1 = nullptr;
     prof_events(h, QSMC_PROF_HYP_SUMS, &he0, &he1);
     hipExtLaunchKernelGGL((k_hyp_sums_chain2<KIND, WHAT, NH>), dim3(grid), dim3(QSMC_BLOCK), 0, s, he0, he1, 0, x, ldx, n, w, norm, ca, ro);
-    double *full = h->scratch + 256;
-    hipLaunchKernelGGL(k_sum_columns, dim3((NS + QSMC_WAVES_PER_BLOCK - 1) / QSMC_WAVES_PER_BLOCK), dim3(QSMC_BLOCK), 0, s,
-                       h->partials, grid, NS, full);
+    // column sums and their publish to the pinned block in ONE launch (round 5; k_sum_columns + k_publish_big before: two
+    // launches, ~9 us per pass): every workgroup stores its columns, fences, draws a ticket; the last sets the word
     const unsigned long long seq = ++h->seq;           // (the completion word steps through the passes; the host waits for the last)
-    hipLaunchKernelGGL(k_publish_big, dim3(1), dim3(QSMC_BLOCK), 0, s, full, NS, h->mapped_big_dev + off, h->flag_dev, seq);
+    hipLaunchKernelGGL(k_sum_columns_publish, dim3((NS + QSMC_WAVES_PER_BLOCK - 1) / QSMC_WAVES_PER_BLOCK), dim3(QSMC_BLOCK), 0, s,
+                       h->partials, grid, NS, h->mapped_big_dev + off, h->flag_dev, seq, h->tickets + TICKET_WORDS - 2);
     HIP_TRY(h, hipGetLastError());
     return QSMC_OK;
 }
@@ -922,6 +924,7 @@ int qsmc_destroy(qsmc_handle_t h) {
     if (h->pinned) (void)hipHostFree(h->pinned);
     if (h->counter) (void)hipFree(h->counter);
     if (h->gbar) (void)hipFree(h->gbar);
+    delete h->hypq;
     if (h->tickets) (void)hipFree(h->tickets);
     if (h->spec.gate) (void)hipFree(h->spec.gate);
     if (h->iscratch) (void)hipFree(h->iscratch);
@@ -1207,7 +1210,12 @@ int qsmc_update_multi(qsmc_handle_t h, const qsmc_model_t *model, const double *
     for (int j = 0; j < k; ++j) {
         make_exp_args(model, &exps[j], outcomes[j], &ma.e[j]);
         ma.outcome[j] = outcomes[j];
+        if (outcomes[j] != 0) ma.outcome_mask |= 1u << j;   // two_outcome as fma(lb, pr0, la)
+        const double ht = 0.5 * fabs(ma.e[j].t), wa = fabs(ma.e[j].w_);
+        ma.half_tmax = (ht > ma.half_tmax || ht != ht) ? ht : ma.half_tmax;      // (a NaN time: every particle takes the general path)
+        ma.wabs_max = (wa > ma.wabs_max || wa != wa) ? wa : ma.wabs_max;
     }
+    if (getenv("QSMC_MULTI_GENERIC")) ma.half_tmax = -1.0;          // (test switch, read per call: every tile through the general path)
     ReduceOut ro = make_reduce(h, true, nullptr);
     // per-tile sums of the window's final weights + their chunk prefix, as qsmc_update_fused leaves them: a resample
     // after the window (qsmc_lw_use_update_sums with this call's token) does not read the weights again
@@ -1304,7 +1312,7 @@ int qsmc_hypothetical_sums(qsmc_handle_t h, const qsmc_model_t *model, const dou
                                         QSMC_HYP_LOG | QSMC_HYP_MOMENTS, out_host, stream);
 }
 
-int qsmc_hypothetical_sums_multi(qsmc_handle_t h, const qsmc_model_t *model, const double *x, int64_t ldx, int64_t n,
+int qsmc_hypothetical_sums_begin(qsmc_handle_t h, const qsmc_model_t *model, const double *x, int64_t ldx, int64_t n,
                                  const double *w, double norm, const qsmc_expparam_t *exps, int32_t n_e,
                                  const int64_t *outcomes, const int32_t *n_o, const double *shift, int32_t what,
                                  double *out_host, qsmc_stream_t stream) {
@@ -1314,9 +1322,13 @@ int qsmc_hypothetical_sums_multi(qsmc_handle_t h, const qsmc_model_t *model, con
     for (int e = 0; e < n_e; ++e) if (n_o[e] < 1) return QSMC_ERR_INVALID;
     int rc = check_model(model);
     if (rc) return rc;
+    if (!h->hypq) {
+        h->hypq = new (std::nothrow) Chain2Queue();
+        if (!h->hypq) return QSMC_ERR_ALLOC;
+    }
     hipStream_t s = (hipStream_t)stream;
     const int per = 2 + 2 * (model->d <= 4 ? model->d : 0);
-    Chain2Queue q;
+    Chain2Queue &q = *h->hypq;
     size_t done = 0;
     for (int e = 0; e < n_e && rc == QSMC_OK; ++e) {
         const int64_t *oc = outcomes + done;
@@ -1338,9 +1350,26 @@ int qsmc_hypothetical_sums_multi(qsmc_handle_t h, const qsmc_model_t *model, con
     }
     if (rc) {                                  // leave nothing in flight that writes the pinned block behind the caller's back
         (void)hipStreamSynchronize(s);
-        return rc;
+        q.count = 0;
+        q.off = 0;
     }
-    return chain2_flush(h, q, s);
+    return rc;
+}
+
+int qsmc_hypothetical_sums_collect(qsmc_handle_t h, qsmc_stream_t stream) {
+    if (!h) return QSMC_ERR_INVALID;
+    if (!h->hypq) return QSMC_OK;
+    return chain2_flush(h, *h->hypq, (hipStream_t)stream);
+}
+
+int qsmc_hypothetical_sums_multi(qsmc_handle_t h, const qsmc_model_t *model, const double *x, int64_t ldx, int64_t n,
+                                 const double *w, double norm, const qsmc_expparam_t *exps, int32_t n_e,
+                                 const int64_t *outcomes, const int32_t *n_o, const double *shift, int32_t what,
+                                 double *out_host, qsmc_stream_t stream) {
+    const int rc = qsmc_hypothetical_sums_begin(h, model, x, ldx, n, w, norm, exps, n_e, outcomes, n_o, shift, what, out_host,
+                                                stream);
+    if (rc) return rc;
+    return qsmc_hypothetical_sums_collect(h, stream);
 }
 
 int qsmc_update_from_likelihood(qsmc_handle_t h, const double *L, int64_t n, const double *w_in,

@@ -108,6 +108,9 @@ SIGNATURES = {
                                C.POINTER(_I64), _I32, C.POINTER(_F64), C.POINTER(_F64), _P],
     "qsmc_hypothetical_sums_multi": [_P, C.POINTER(ModelDesc), _P, _I64, _I64, _P, _F64, C.POINTER(ExpParam), _I32,
                                      C.POINTER(_I64), C.POINTER(_I32), C.POINTER(_F64), _I32, C.POINTER(_F64), _P],
+    "qsmc_hypothetical_sums_begin": [_P, C.POINTER(ModelDesc), _P, _I64, _I64, _P, _F64, C.POINTER(ExpParam), _I32,
+                                     C.POINTER(_I64), C.POINTER(_I32), C.POINTER(_F64), _I32, C.POINTER(_F64), _P],
+    "qsmc_hypothetical_sums_collect": [_P, _P],
     "qsmc_update_from_likelihood": [_P, _P, _I64, _P, _P, _F64, _P, C.POINTER(UpdateStats), _P],
     "qsmc_clip_weights": [_P, _P, _I64, _F64, _P, C.POINTER(UpdateStats), _P],
     "qsmc_weight_stats": [_P, _P, _I64, _F64, _P, C.POINTER(UpdateStats), _P],

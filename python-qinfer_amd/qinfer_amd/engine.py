@@ -247,6 +247,39 @@ class Engine:
             at += c
         return res
 
+    def hypothetical_sums_begin(self, desc, x, w, norm, exps, outcomes, shift, what=3):
+        """Queue the design passes of these experiments and return without waiting (qsmc_hypothetical_sums_begin); the
+        returned job's `rows` -- one array per experiment -- are valid after `hypothetical_sums_collect`.  Several jobs may be
+        begun one after the other (a caller that prepares its experiments as it goes); nothing else may be asked of the
+        engine in between."""
+        d = x.shape[0]
+        per = 2 + 2 * d if d <= 4 else 2
+        n_e = len(exps)
+        counts = [len(o) for o in outcomes]
+        out = np.empty((sum(counts), per), dtype=np.float64)
+        oc = np.ascontiguousarray(np.concatenate([np.asarray(o).ravel() for o in outcomes]), dtype=np.int64)
+        no = np.asarray(counts, dtype=np.int32)
+        ep = (_native.ExpParam * n_e)(*exps)
+        shift = np.ascontiguousarray(shift, dtype=np.float64)
+        self._chk(self.lib.qsmc_hypothetical_sums_begin(
+            self.h, C.byref(desc), self._p(x), x.stride(0), x.shape[1],
+            self._p(w) if w is not None else None, float(norm), ep, n_e,
+            oc.ctypes.data_as(C.POINTER(C.c_int64)), no.ctypes.data_as(C.POINTER(C.c_int32)),
+            _native.f64_ptr(shift), int(what), _native.f64_ptr(out), self.stream()), "qsmc_hypothetical_sums_begin")
+        rows, at = [], 0
+        for c in counts:
+            rows.append(out[at:at + c])
+            at += c
+        job = type("DesignJob", (), {})()
+        job.rows, job._keep = rows, (out, oc, no, ep, shift)          # (the C side holds pointers into these until collect)
+        self._design_jobs = getattr(self, "_design_jobs", []) + [job]
+        return job
+
+    def hypothetical_sums_collect(self):
+        """Wait for every design pass queued by `hypothetical_sums_begin` and fill the jobs' rows."""
+        self._chk(self.lib.qsmc_hypothetical_sums_collect(self.h, self.stream()), "qsmc_hypothetical_sums_collect")
+        self._design_jobs = []
+
     def update_from_likelihood(self, L, w_in, w_out, prev_norm):
         st = _native.UpdateStats()
         self._chk(self.lib.qsmc_update_from_likelihood(

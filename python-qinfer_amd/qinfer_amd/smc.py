@@ -784,9 +784,21 @@ class SMCUpdater(ParticleDistribution):
         `what`: the columns the caller reads, Engine.HYP_LOG | Engine.HYP_MOMENTS)."""
         eng = self._eng
         shift = self.est_mean()
-        exps = self.model._native_expparams(expparams)
-        outs = [dom.values for dom in self.model.domain(expparams)]
-        sums = eng.hypothetical_sums_multi(self._desc, self._x, self._w, self._norm, exps, outs, shift, what)
+        model = self.model
+        # the first experiment is translated and queued on its own: the GPU works on its passes while the host translates
+        # the rest of the design (records -> C structs, outcome domains: ~10 us per experiment), instead of idling until
+        # the whole design has been prepared (qsmc_hypothetical_sums_begin / _collect, round 5)
+        head = expparams[:1]
+        jobs = [eng.hypothetical_sums_begin(self._desc, self._x, self._w, self._norm, model._native_expparams(head),
+                                            [dom.values for dom in model.domain(head)], shift, what)]
+        try:
+            if expparams.shape[0] > 1:
+                rest = expparams[1:]
+                jobs.append(eng.hypothetical_sums_begin(self._desc, self._x, self._w, self._norm, model._native_expparams(rest),
+                                                        [dom.values for dom in model.domain(rest)], shift, what))
+        finally:
+            eng.hypothetical_sums_collect()          # (also after an error in the second half: nothing stays in flight)
+        sums = [r for job in jobs for r in job.rows]
         if self._comm is not None:
             # every entry is a sum over particles with the GLOBAL normaliser and a shift all ranks agree on (the global
             # mean): additive over the shards (columns nobody asked for are NaN on every shard); one reduction per design

@@ -1274,6 +1274,111 @@ def test_batch_update_fused_vs_loop(qi, model_name, interval):
     np.testing.assert_allclose(fused.n_ess, loop.n_ess, rtol=1e-6)
 
 
+def test_window_kernels_round5_same_bits(qi, eng, monkeypatch):
+    """Round 5's two window kernels against the forms they replace, on ONE window from identical state:
+    * SimplePrecession / SimpleInversion: the transposed loop nest of k_update_multi (eight particles loaded, then datum by
+      datum; one range test per tile; the outcome select as an fma) against its general path (QSMC_MULTI_GENERIC=1, read
+      per call): weights AND per-datum sums bit for bit -- for K = 2 ... 8, ragged clouds, explicit and implicit weights,
+      a nonzero reference frequency, and a time so large that a tile falls back to the general path;
+    * 2-qubit tomography: the sparse-row window (k_update_multi_tomo: each datum reads the rows its measurement vector
+      touches; vectors of two to four entries, i.e. both instantiations) against the chain it stands for, formed on the
+      host with the oracle's likelihood (tomography/models.py:211-226): w_k = w_{k-1} L_k without renormalisation --
+      weights to 4e-15 relative, every datum's sums to 1e-13, the window's minimum."""
+    rs = np.random.RandomState(23)
+    m = qi.SimpleInversionModel() if hasattr(qi, "SimpleInversionModel") else qi.SimplePrecessionModel()
+    desc = m._native_desc()
+    for n, K, implicit, tbig in ((70_001, 5, False, False), (2048 * 7, 8, True, False), (5000, 2, False, False),
+                                 (300_000, 7, False, True), (4096, 3, True, False)):
+        x = eng.locs_to_soa(rs.random_sample((n, 1)))
+        w = None if implicit else eng.to_device(rs.random_sample(n) + 0.1)
+        norm = float(n) if implicit else float(w.sum().item())
+        exps, outs = [], []
+        for k in range(K):
+            ep = np.zeros((1,), dtype=m.expparams_dtype)
+            ep["t"] = (9 / 8) ** (3 * k) if not (tbig and k == K - 1) else 3.0e10
+            if "w_" in ep.dtype.names:
+                ep["w_"] = 0.05 * k
+            exps.append(m._native_expparams(ep)[0])
+            outs.append(int(rs.randint(0, 2)))
+        res = []
+        for generic in (False, True):
+            if generic:
+                monkeypatch.setenv("QSMC_MULTI_GENERIC", "1")
+            else:
+                monkeypatch.delenv("QSMC_MULTI_GENERIC", raising=False)
+            w_out = eng.empty(n)
+            stats, m1, m2 = eng.update_multi(desc, x, w, w_out, norm, exps, outs)
+            res.append((w_out.cpu().numpy().copy(), [(s_.sum, s_.sumsq, s_.n_bad, s_.min) for s_ in stats], np.array(m1), np.array(m2)))
+        monkeypatch.delenv("QSMC_MULTI_GENERIC", raising=False)
+        (wa, sa, m1a, m2a), (wb, sb, m1b, m2b) = res
+        np.testing.assert_array_equal(wa, wb, err_msg=str((n, K)))
+        assert sa == sb, (n, K, sa[:2], sb[:2])
+        np.testing.assert_array_equal(m1a, m1b)
+        np.testing.assert_array_equal(m2a, m2b)
+        assert np.isfinite(wa).all() and wa.min() >= 0
+    # ---- tomography: sparse window
+    basis = qi.tomography.pauli_basis(2)
+    tm = qi.TomographyModel(basis)
+    td = tm._native_desc()
+    for n, K, implicit in ((30_011, 5, False), (2048 * 5, 8, True), (4100, 2, False)):
+        xs = orc.ginibre_prior_sample(n, basis.data, rs)
+        x = eng.locs_to_soa(xs)
+        w0 = None if implicit else rs.random_sample(n) + 0.1
+        w = None if implicit else eng.to_device(w0)
+        norm = float(n) if implicit else float(w0.sum())
+        exps, outs, eps_np = [], [], []
+        for k in range(K):
+            ep = np.zeros((1,), dtype=tm.expparams_dtype)
+            ep["meas"][0, 0] = 1
+            ep["meas"][0, int(rs.randint(1, 16))] = 1
+            if k == 1:                                     # a three-entry vector in the window: the padded (NZ = 4) instantiation
+                ep["meas"][0, 3], ep["meas"][0, 9] = 0.25, -0.5
+            eps_np.append(ep)
+            exps.append(tm._native_expparams(ep)[0])
+            outs.append(int(rs.randint(0, 2)))
+        w_out = eng.empty(n)
+        stats, _, _ = eng.update_multi(td, x, w, w_out, norm, exps, outs)
+        got = w_out.cpu().numpy()
+        # the chain on the host: w_k = w_{k-1} L_k, L from the oracle's tomography likelihood
+        wk = (np.ones(n) if implicit else w0) * (1.0 / norm)
+        wmin = np.inf
+        for k in range(K):
+            L = orc.lik_tomography(np.array([outs[k]]), xs, eps_np[k]["meas"])[0, :, 0]
+            wk = wk * L
+            wmin = min(wmin, wk.min())
+            assert stats[k].sum == pytest.approx(wk.sum(), rel=1e-13)
+            assert stats[k].sumsq == pytest.approx((wk * wk).sum(), rel=1e-13)
+            assert stats[k].n_bad == 0
+        np.testing.assert_allclose(got, wk, rtol=4e-15, atol=1e-300)
+        assert stats[0].min == pytest.approx(wmin, rel=1e-12, abs=1e-300)
+
+
+def test_batch_update_tomography_sparse_windows(qi):
+    """batch_update over 2-qubit tomography data (random Pauli measurements: config 5's) takes the sparse-row windows and
+    agrees with the per-datum loop: same resample decisions, records to the conditioning tolerance, same posterior."""
+    rs = np.random.RandomState(29)
+    basis = qi.tomography.pauli_basis(2)
+    n, K = 40_000, 37
+    x0 = orc.ginibre_prior_sample(n, basis.data, rs)
+    tm = qi.TomographyModel(basis)
+    eps = np.zeros((K,), dtype=tm.expparams_dtype)
+    for k in range(K):
+        eps["meas"][k, 0], eps["meas"][k, int(rs.randint(1, 16))] = 1, 1
+    outcomes = rs.randint(0, 2, K)
+    for interval in (5, 8, 3):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            fused = qi.SMCUpdater(qi.TomographyModel(basis), n, fixed_prior(qi, x0), device_rng=True, seed=3)
+            fused.batch_update(outcomes, eps, resample_interval=interval)
+            loop = qi.SMCUpdater(qi.TomographyModel(basis), n, fixed_prior(qi, x0), device_rng=True, seed=3)
+            loop._batch_fast_path = False
+            loop.batch_update(outcomes, eps, resample_interval=interval)
+        assert fused.resample_count == loop.resample_count and fused.resample_count >= 1, interval
+        np.testing.assert_allclose(np.ravel(fused.normalization_record), np.ravel(loop.normalization_record), rtol=1e-9)
+        np.testing.assert_allclose(fused.est_mean(), loop.est_mean(), rtol=0, atol=1e-9)
+        np.testing.assert_allclose(fused.n_ess, loop.n_ess, rtol=1e-6)
+
+
 def test_batch_update_fused_guard_replay(qi):
     """A window that contains an impossible datum is discarded and replayed datum by datum:
     the exception comes from the same datum as in the reference's loop, earlier data are applied."""
@@ -1495,6 +1600,42 @@ def test_bayes_risk_and_eig_g7(qi, golden):
     assert ok.any() and not ok.all()
     np.testing.assert_allclose(eig[ok], g["bin_eig"][ok], rtol=1e-9)
     assert np.all(np.isfinite(eig)) and np.all(eig > 0)
+
+
+def test_design_begin_collect_equals_one_call(qi, eng):
+    """qsmc_hypothetical_sums_begin / _collect (round 5: a design's passes queued as the caller prepares its experiments)
+    return what qsmc_hypothetical_sums_multi returns for the same design in one call -- the same kernels on the same
+    cloud: bit for bit -- however the design is cut into begin calls; and bayes_risk / expected_information_gain, which
+    now queue their first experiment ahead of the rest, are unchanged (G7 pins them to the reference elsewhere)."""
+    rs = np.random.RandomState(41)
+    m = qi.BinomialModel(qi.SimplePrecessionModel())
+    n = 200_000
+    x = np.abs(0.3 + 0.05 * rs.randn(n, 1))
+    w = rs.random_sample(n) + 0.05
+    upd = _cloud_updater(qi, m, x, w / w.sum())
+    design = np.empty((5,), dtype=m.expparams_dtype)
+    design["x"], design["n_meas"] = [3.0, 9.0, 14.0, 21.0, 40.0], [25, 25, 7, 25, 70]
+    exps = m._native_expparams(design)
+    outs = [dom.values for dom in m.domain(design)]
+    shift = upd.est_mean()
+    for what in (eng.HYP_MOMENTS, eng.HYP_LOG, eng.HYP_MOMENTS | eng.HYP_LOG):
+        one = eng.hypothetical_sums_multi(upd._desc, upd._x, upd._w, upd._norm, exps, outs, shift, what)
+        for cuts in ((1, 5), (2, 3, 5), (1, 2, 3, 4, 5)):
+            jobs, at = [], 0
+            for c in cuts:
+                jobs.append(eng.hypothetical_sums_begin(upd._desc, upd._x, upd._w, upd._norm, exps[at:c], outs[at:c], shift, what))
+                at = c
+            eng.hypothetical_sums_collect()
+            rows = [r for j in jobs for r in j.rows]
+            assert len(rows) == len(one)
+            for a, b in zip(rows, one):
+                np.testing.assert_array_equal(a, b)
+    r1 = upd.bayes_risk(design)
+    r2 = np.array([upd.bayes_risk(design[k:k + 1])[0] for k in range(5)])
+    np.testing.assert_array_equal(r1, r2)
+    e1 = upd.expected_information_gain(design)
+    e2 = np.array([upd.expected_information_gain(design[k:k + 1])[0] for k in range(5)])
+    np.testing.assert_array_equal(e1, e2)
 
 
 def test_design_generic_path_matches_native(qi, golden):
