@@ -313,7 +313,7 @@ def run_other_config(qi, eng, torch, spec, warmup, comm=None, n_override=None, s
     elif "canon_list" in kt:
         # classify rides in the kick kernel (no pass of its own): what is left of canonicalize is the list pass over the
         # particles whose rho is not positive definite (about a third: read + write 16 rows of those)
-        out["canonicalize"] = {"kernel": "k_tomo_canon_list<4> (classify fused into k_bucket_kick16)",
+        out["canonicalize"] = {"kernel": "k_tomo_canon_list_fast (eigenvector-free clamp; classify fused into k_bucket_kick16)",
                                "avg_kernel_us": kt["canon_list"]["avg_us"], "timed_launches": kt["canon_list"]["launches"],
                                "classify_us": 0.0, "canon_list_us": kt["canon_list"]["avg_us"]}
     if "moments" in kt:
@@ -363,6 +363,48 @@ def other_paths(qi, eng, torch, n=10_000_000):
         out["batch_update_interval_%d" % interval] = e
         del upd
         torch.cuda.empty_cache()
+    # config 5's share through batch_update: 2-qubit tomography, random Pauli measurements, resample_interval 5 -- the window
+    # kernel reads only the rows the window's measurement vectors touch (k_update_multi_tomo, round 5)
+    try:
+        spec5 = next(s5 for s5 in other_config_specs(qi) if s5["key"] == "config5_share_tomography")
+        eps5 = np.concatenate(spec5["eps"])
+        outs5 = np.asarray(spec5["outs"])
+        n5, K5 = spec5["n"], len(outs5)
+        upd = qi.SMCUpdater(spec5["model"], n5, spec5["prior"](), device_rng=True, seed=0)
+        upd.batch_update(outs5, eps5, resample_interval=5)
+        upd.reset()
+        torch.cuda.synchronize()
+        eng.set_profiling(1)
+        upd.batch_update(outs5, eps5, resample_interval=5)
+        torch.cuda.synchronize()
+        ms, tags = eng.profile_read()
+        eng.set_profiling(0)
+        upd.reset()
+        rc0 = upd.resample_count
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        upd.batch_update(outs5, eps5, resample_interval=5)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        kt = kernel_table(ms, tags)
+        rows = float(np.mean([len({0} | {int(np.flatnonzero(eps5["meas"][k])[-1]) for k in range(i, min(i + 5, K5))})
+                              for i in range(0, K5, 5)]))
+        e = {"workload": "2-qubit TomographyModel batch_update, %.3g particles, the 60 random Pauli measurements of config 5, "
+                         "resample_interval=5" % n5,
+             "value": n5 * K5 / wall, "unit": "particle-updates/s", "ms_per_datum": wall / K5 * 1e3,
+             "resamples": upd.resample_count - rc0, "posterior_mean_head": [float(v) for v in upd.est_mean()[:3]]}
+        if "update_multi" in kt:
+            e["window_kernel"] = frac_entry("k_update_multi_tomo<5,2>", kt["update_multi"]["avg_us"], (16.0 + 8.0 * rows) * n5,
+                                            kt["update_multi"]["launches"],
+                                            {"bytes_per_particle_per_window": 16.0 + 8.0 * rows, "rows_touched_per_window": rows,
+                                             "data_per_window": 5,
+                                             "note": "sparse measurement vectors: w in, w out and the union of the window's rows "
+                                                     "(dense window: 144 B per particle)"})
+        out["batch_update_tomography_interval_5"] = e
+        del upd
+        torch.cuda.empty_cache()
+    except Exception as ex:  # noqa: BLE001
+        out["batch_update_tomography_interval_5"] = {"error": repr(ex)}
     m = qi.BinomialModel(qi.SimplePrecessionModel())
     upd = qi.SMCUpdater(m, n, qi.UniformDistribution([0, 1]), device_rng=True, seed=0)
     ep = np.empty((1,), dtype=m.expparams_dtype)

@@ -1839,7 +1839,10 @@ __global__ __launch_bounds__(KICK16_BT) void k_bucket_kick16(
 #pragma unroll
             for (int r = 0; r < 4; ++r) mine[(16 * t + n) * KICK16_ROW + g + 4 * r] = (lw_a * xa[r] + mu4[r]) + acc[r];
         }
-        __syncthreads();
+        // (the tile is this WAVE's: a wave-level fence orders its LDS stores before its own transposed reads.  Round 5 --
+        //  the two workgroup barriers per trip that stood here kept a workgroup's four waves in lockstep through a kernel
+        //  whose waves stall on gathers half the time: VALUs 54 % busy at three waves per SIMD)
+        wave_lds_sync();
         const int64_t o = k64 + lane;
         bool hard = false;
         if (o < r1) {
@@ -1873,10 +1876,11 @@ __global__ __launch_bounds__(KICK16_BT) void k_bucket_kick16(
                 if (hard) hard_buf[hb + __popcll(mk & ((1ull << lane) - 1ull))] = (unsigned int)o;
             }
         }
-        __syncthreads();                                            // the tile is rewritten by the next trip
+        wave_lds_sync();                                            // the wave's tile is rewritten by its next trip
     }
     if (CANON) {
-        const unsigned int m = bcount;                              // (read after the loop's last barrier)
+        __syncthreads();                                            // every wave's entries of hard_buf and its share of bcount
+        const unsigned int m = bcount;
         if (m) {
             if (threadIdx.x == 0) gbase = atomicAdd(count, m);
             __syncthreads();

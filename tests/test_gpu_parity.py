@@ -1283,7 +1283,8 @@ def test_window_kernels_round5_same_bits(qi, eng, monkeypatch):
     * 2-qubit tomography: the sparse-row window (k_update_multi_tomo: each datum reads the rows its measurement vector
       touches; vectors of two to four entries, i.e. both instantiations) against the chain it stands for, formed on the
       host with the oracle's likelihood (tomography/models.py:211-226): w_k = w_{k-1} L_k without renormalisation --
-      weights to 4e-15 relative, every datum's sums to 1e-13, the window's minimum."""
+      weights to 1e-12 relative (an ulp of the dot product is 1e-16 / L of a small likelihood), every datum's sums to
+      1e-13, the window's minimum."""
     rs = np.random.RandomState(23)
     m = qi.SimpleInversionModel() if hasattr(qi, "SimpleInversionModel") else qi.SimplePrecessionModel()
     desc = m._native_desc()
@@ -1349,7 +1350,9 @@ def test_window_kernels_round5_same_bits(qi, eng, monkeypatch):
             assert stats[k].sum == pytest.approx(wk.sum(), rel=1e-13)
             assert stats[k].sumsq == pytest.approx((wk * wk).sum(), rel=1e-13)
             assert stats[k].n_bad == 0
-        np.testing.assert_allclose(got, wk, rtol=4e-15, atol=1e-300)
+        # (L = 1 - clip(meas . x): an ulp in the dot product -- einsum's summation order is not the kernel's ascending one --
+        #  is an ulp of 1, i.e. up to 1e-16 / L of a small likelihood; eight of them chained)
+        np.testing.assert_allclose(got, wk, rtol=1e-12, atol=1e-300)
         assert stats[0].min == pytest.approx(wmin, rel=1e-12, abs=1e-300)
 
 
