@@ -382,6 +382,12 @@ int qsmc_comm_destroy(qsmc_handle_t h);
 int qsmc_comm_count(qsmc_handle_t h, int32_t *nranks_out, int32_t *rank_out);
 int qsmc_allreduce_sums(qsmc_handle_t h, const double *vec_dev, int32_t n, int32_t min_index, double *tot_host,
                         double *firsts_host, qsmc_stream_t stream);
+/* What every rank does with the gathered rows, on rows the caller supplies (rows_dev: nranks vectors of n doubles, rank
+ * after rank, device memory): the rank-ordered sums (entry min_index: the minimum), every rank's entry 0, published through
+ * the handle's pinned block as qsmc_allreduce_sums publishes them.  No communicator involved: for a transport that
+ * gathers by other means, and for testing the device half of the collective with any number of ranks on one GPU. */
+int qsmc_publish_rows(qsmc_handle_t h, const double *rows_dev, int32_t n, int32_t min_index, int32_t nranks,
+                      double *tot_host, double *firsts_host, qsmc_stream_t stream);
 
 /* Sorting and searching for the posterior read-outs (est_credible_region, distributions.py:558-614;
  * posterior_marginal, smc.py:672-716).  qsmc_argsort: stable radix sort (rocPRIM) of n < 2^31 keys, ascending or

@@ -186,10 +186,10 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_sum_partials_publish(const doubl
         if (lane == 0) {
             out[k] = s;
             mapped[k] = s;
-        }
+            __threadfence_system();                          // (the writing lane only: a system-scope fence in every thread of
+        }                                                    //  69 workgroups made this kernel 14 us -- slower than the two it replaced)
     }
-    __threadfence_system();                                  // this thread's pinned-memory stores are out before its ticket
-    __syncthreads();
+    __syncthreads();                                         // this workgroup's pinned-memory stores are out before its ticket
     if (threadIdx.x == 0) {
         const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         if (t == gridDim.x - 1u) {
@@ -226,9 +226,11 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_sum_columns_publish(const double
         double s = 0.0;
         for (int g = lane; g < nblocks; g += QSMC_WAVE) s += partials[(size_t)k * nblocks + g];
         s = wave_sum(s);
-        if (lane == 0) mapped[k] = s;
+        if (lane == 0) {
+            mapped[k] = s;
+            __threadfence_system();                          // (the writing lane only: see k_sum_partials_publish)
+        }
     }
-    __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);

@@ -2826,6 +2826,27 @@ int qsmc_allreduce_sums(qsmc_handle_t h, const double *vec_dev, int32_t n, int32
     return QSMC_OK;
 }
 
+// The second half of qsmc_allreduce_sums on rows the caller gathered by other means: rows_dev holds nranks vectors of n
+// doubles, rank after rank; the same one-wave kernel sums them IN RANK ORDER (entry min_index: the minimum), keeps every
+// rank's entry 0 and publishes through the pinned block.  No communicator needed -- which also makes the device half of
+// the RCCL transport testable with any number of "ranks" on one GPU (tests/test_gpu_parity.py).
+int qsmc_publish_rows(qsmc_handle_t h, const double *rows_dev, int32_t n, int32_t min_index, int32_t nranks, double *tot_host,
+                      double *firsts_host, qsmc_stream_t stream) {
+    if (!h || !rows_dev || !tot_host || n < 1 || min_index >= n || nranks < 1 || nranks > QSMC_MAX_RANKS) return QSMC_ERR_INVALID;
+    if (n + nranks > REDUCE_OUT_MAX - 4) return QSMC_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned long long seq = ++h->seq;
+    hipLaunchKernelGGL(k_publish_allgather, dim3(1), dim3(256), 0, s, rows_dev, (int)n, (int)min_index, (int)nranks,
+                       h->mapped_dev, h->flag_dev, seq, reinterpret_cast<const unsigned long long *>(h->counter),
+                       h->mapped_dev + (REDUCE_OUT_MAX - 1));
+    HIP_TRY(h, hipGetLastError());
+    const int rc = wait_reduction(h, s);
+    if (rc) return rc;
+    memcpy(tot_host, h->mapped, (size_t)n * sizeof(double));
+    if (firsts_host) memcpy(firsts_host, h->mapped + n, (size_t)nranks * sizeof(double));
+    return QSMC_OK;
+}
+
 // ---- host: the shard plan of a sharded resample ------------------------------------------------------------
 // T ~ Multinomial(n_total; W_h / sum W): how many of the n_total children descend from shard h.  Every rank draws it
 // from the same (seed, epoch) and gets the same answer, so planning a resample needs no communication (the W_h came

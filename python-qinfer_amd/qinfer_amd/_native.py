@@ -134,6 +134,7 @@ SIGNATURES = {
     "qsmc_comm_destroy": [_P],
     "qsmc_comm_count": [_P, C.POINTER(_I32), C.POINTER(_I32)],
     "qsmc_allreduce_sums": [_P, _P, _I32, _I32, _P, _P, _P],
+    "qsmc_publish_rows": [_P, _P, _I32, _I32, _I32, C.POINTER(_F64), C.POINTER(_F64), _P],
     "qsmc_argsort": [_P, _P, _I64, _I32, _P, _P, _P],
     "qsmc_searchsorted": [_P, _P, _I64, _P, _I64, _I32, _P, _P],
     "qsmc_weight_entropy": [_P, _P, _I64, _F64, C.POINTER(_F64), _P],

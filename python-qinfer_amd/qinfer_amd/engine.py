@@ -394,6 +394,15 @@ class Engine:
                                                self._cc_first.ctypes.data, self.stream()), "qsmc_allreduce_sums")
         return self._cc_tot[:n], self._cc_first
 
+    def publish_rows(self, rows_dev, n, nranks, min_index=-1):
+        """The device half of `allreduce_sums` on caller-supplied rows ([nranks][n] doubles on the device): (tot, firsts)
+        -- the rank-ordered sums (entry min_index: the minimum) and every rank's entry 0.  No communicator involved."""
+        tot = np.empty(n, dtype=np.float64)
+        firsts = np.empty(nranks, dtype=np.float64)
+        self._chk(self.lib.qsmc_publish_rows(self.h, self._p(rows_dev), int(n), int(min_index), int(nranks),
+                                             _native.f64_ptr(tot), _native.f64_ptr(firsts), self.stream()), "qsmc_publish_rows")
+        return tot, firsts
+
     # ------------------------------------------------------------------ moments
     def moments(self, x, w, norm):
         """Returns host (sum_w, S1[d], S2[d, d]) of the normalised weights."""

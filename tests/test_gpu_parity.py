@@ -2024,6 +2024,42 @@ def test_device_resampler_vs_pinned_oracle_statistics_d16(qi, eng):
     _two_sample_checks(dev[:, :, 1:], ref[:, :, 1:], "d16")
 
 
+def test_rank_ordered_device_sum_any_world_size(qi, eng):
+    """The device half of the RCCL transport (qsmc_allreduce_sums = one ncclAllGather + k_publish_allgather) with MORE
+    THAN ONE rank's row, which a one-GPU box cannot produce through a communicator: qsmc_publish_rows runs the same
+    one-wave kernel on rows laid out as the all-gather leaves them.  Rows chosen so that any other association order
+    changes the result (1e16, 1, -1e16, ...): the totals are the rank-ordered IEEE sums bit for bit -- what the shared
+    memory transport's host sum (qsmc_host_allreduce) forms from the same rows -- the minimum entry is a minimum (NaN
+    propagating), every rank's entry 0 comes back, for 2 ... 64 ranks."""
+    rs = np.random.RandomState(6)
+    for nranks in (2, 3, 4, 8, 64):
+        n = 4 + 14
+        rows = rs.standard_normal((nranks, n)) * 10.0 ** rs.randint(-8, 9, size=(nranks, n))
+        rows[:, 0] = np.resize([1.0, 1e16, -1e16, 3.0, 1e-3], nranks)        # order-sensitive column
+        rows[:, 2] = rs.random_sample(nranks) + 0.5                            # the minimum entry
+        dev = eng.to_device(np.ascontiguousarray(rows).reshape(-1))
+        tot, firsts = eng.publish_rows(dev, n, nranks, min_index=2)
+        want = rows[0].copy()
+        for r in range(1, nranks):
+            want = want + rows[r]                                               # rank order, one IEEE addition per rank
+        want[2] = rows[:, 2].min()
+        np.testing.assert_array_equal(tot, want)
+        np.testing.assert_array_equal(firsts, rows[:, 0])
+        other = rows[::-1][0].copy()
+        for r in range(1, nranks):
+            other = other + rows[::-1][r]
+        if nranks >= 3:
+            assert other[0] != want[0]                                          # (the fixture does distinguish the orders)
+        # the host-side transport's sum of the same rows: the same bits
+        host = rows[0].copy()
+        for r in range(1, nranks):
+            host += rows[r]
+        np.testing.assert_array_equal(tot[[0, 1, 3]], host[[0, 1, 3]])
+    rows = np.array([[1.0, 2.0, 5.0], [1.0, np.nan, 4.0]])
+    tot, _ = eng.publish_rows(eng.to_device(rows.reshape(-1)), 3, 2, min_index=1)
+    assert tot[0] == 2.0 and np.isnan(tot[1]) and tot[2] == 9.0
+
+
 def test_kl_divergence_g14(qi, golden):
     """est_kl_divergence / SMCUpdater's resampling divergences (distributions.py:466-500, smc.py:506-542) on the device
     against the reference's values (fixture g14) and the oracle."""
