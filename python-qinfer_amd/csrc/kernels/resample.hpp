@@ -1428,11 +1428,50 @@ __device__ __forceinline__ int upper_bound_ll(const long long *__restrict__ a, i
 
 // one workgroup: exclusive prefix of src[0..m) into dst[0..m], total returned to every thread.  ATOMIC: src was written
 // by other workgroups of THIS launch with agent-scope atomic stores (the XCDs' L2s are not coherent inside a launch).
+constexpr int SCAN_I_STAGE = 8192;             // entries block_exclusive_scan_i takes in one sweep (through LDS)
 template <bool ATOMIC>
 __device__ __forceinline__ long long block_exclusive_scan_i(const int *src, int m, long long *__restrict__ dst) {
     __shared__ long long wtot[1024 / QSMC_WAVE];
     __shared__ long long carry;
     const int lane = threadIdx.x & (QSMC_WAVE - 1), wave = threadIdx.x / QSMC_WAVE, nw = blockDim.x / QSMC_WAVE;
+    if (m <= SCAN_I_STAGE) {
+        // Round 5: ONE sweep.  The loop below takes blockDim entries per trip, each trip a dependent round of loads (agent
+        // -scope ones, ~1.5 us, when the counts were written by this very launch) and three barriers: 18 trips for the 4600
+        // work items of config 4's share in k_bank_counts' 256-thread workgroup -- most of that kernel's 18 us.  Here every
+        // load is issued at once (lane-consecutive: coalesced), the values parked in LDS, and each thread scans a contiguous
+        // run of them; integer sums, so the same prefix whatever the order.
+        __shared__ int stage[SCAN_I_STAGE];
+        __syncthreads();
+        for (int i = threadIdx.x; i < m; i += (int)blockDim.x)
+            stage[i] = ATOMIC ? __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : src[i];
+        __syncthreads();
+        const int per = (m + (int)blockDim.x - 1) / (int)blockDim.x;
+        const int i0 = (int)threadIdx.x * per;
+        long long run = 0ll;
+        for (int q = 0; q < per; ++q) run += (i0 + q < m) ? (long long)stage[i0 + q] : 0ll;
+        long long inc = run;
+#pragma unroll
+        for (int off = 1; off < QSMC_WAVE; off <<= 1) {
+            const long long t = __shfl_up(inc, off, QSMC_WAVE);
+            if (lane >= off) inc += t;
+        }
+        if (lane == QSMC_WAVE - 1) wtot[wave] = inc;
+        __syncthreads();
+        long long off0 = inc - run, total = 0ll;
+        for (int wv = 0; wv < nw; ++wv) {
+            if (wv < wave) off0 += wtot[wv];
+            total += wtot[wv];
+        }
+        for (int q = 0; q < per; ++q) {
+            if (i0 + q < m) {
+                dst[i0 + q] = off0;
+                off0 += (long long)stage[i0 + q];
+            }
+        }
+        if (threadIdx.x == 0) dst[m] = total;
+        __syncthreads();
+        return total;
+    }
     __syncthreads();
     if (threadIdx.x == 0) carry = 0ll;
     __syncthreads();
@@ -1482,7 +1521,9 @@ __global__ __launch_bounds__(1024) void k_bank_scan(BankIn bk, const int *__rest
 // one failed slot, one spare: true if the spare was invalid too (or the slot was sent to the leftover list)
 template <int DM>
 __device__ __forceinline__ bool bank_try(const BankIn &bk, long long g, long long E, int n_items, unsigned int slot, int d,
-                                         double *__restrict__ x_out, const OutPlace &pl, bool &left) {
+                                         double *__restrict__ x_out, const OutPlace &pl, bool &left,
+                                         const long long *e_off = nullptr) {
+    if (!e_off) e_off = bk.e_off;                     // (k_bank_tail hands in its LDS copy of the prefix)
     left = false;
     if (g >= E) {                                     // the bank is exhausted: the old way
         const unsigned long long at = atomicAdd(reinterpret_cast<unsigned long long *>(bk.ctr + 2), 1ull);
@@ -1491,8 +1532,8 @@ __device__ __forceinline__ bool bank_try(const BankIn &bk, long long g, long lon
         return false;
     }
     const long long pg = (long long)bank_perm((unsigned long long)g, (unsigned long long)E, bk.key);
-    const int bi = upper_bound_ll(bk.e_off, n_items + 1, pg) - 1;
-    const double *ent = bk.entries + (bk.e_base[bi] + (pg - bk.e_off[bi])) * bk.stride;
+    const int bi = upper_bound_ll(e_off, n_items + 1, pg) - 1;
+    const double *ent = bk.entries + (bk.e_base[bi] + (pg - e_off[bi])) * bk.stride;
     if (ent[bk.stride - 1] == 0.0) return true;
     const int64_t row = place_row(pl, (int64_t)slot);
 #pragma unroll
@@ -1573,6 +1614,16 @@ __global__ __launch_bounds__(1024) void k_bank_tail(BankIn bk, const int *__rest
     long long Bt = bk.ctr[24 + t0];
     const long long E = bk.ctr[0];
     const int n_items = item_off[chunks];
+    // (round 5) every try binary-searches the prefix of the items' spare counts -- 13 dependent loads; this ONE workgroup
+    // makes thousands of tries one dependent trip after the other, so the prefix is copied to LDS first when it fits
+    constexpr int TAIL_EOFF = 6144;
+    __shared__ long long s_eoff[TAIL_EOFF];
+    const long long *eoff = nullptr;
+    if (n_items + 1 <= TAIL_EOFF) {
+        for (int i = threadIdx.x; i <= n_items; i += 1024) s_eoff[i] = bk.e_off[i];
+        eoff = s_eoff;
+    }
+    __syncthreads();
     const int lane = threadIdx.x & (QSMC_WAVE - 1), wave = threadIdx.x / QSMC_WAVE;
     const int prev = (t0 - 1) & 1, cur = t0 & 1;
     const int nvb_prev = (int)((bk.ctr[8 + t0 - 1] + BANK_VB - 1) / BANK_VB);
@@ -1593,7 +1644,7 @@ __global__ __launch_bounds__(1024) void k_bank_tail(BankIn bk, const int *__rest
             if (j < Ft) {
                 slot = in[j];
                 bool left;
-                fail = bank_try<DM>(bk, Bt + j, E, n_items, slot, d, x_out, pl, left);
+                fail = bank_try<DM>(bk, Bt + j, E, n_items, slot, d, x_out, pl, left, eoff);
             }
             const unsigned long long mk = __ballot(fail);
             if (lane == 0) wcount[wave] = __popcll(mk);

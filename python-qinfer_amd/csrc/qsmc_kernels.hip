@@ -2350,9 +2350,16 @@ int qsmc_step(qsmc_handle_t h, qsmc_step_t *st, const qsmc_model_t *model, const
         const unsigned long long seq = ++h->seq;
         static const bool dev_sqrt_env = getenv("QSMC_DEVICE_SQRT") != nullptr;
         constexpr int SUM_GRID = (MFMA_MOM_K + QSMC_WAVES_PER_BLOCK - 1) / QSMC_WAVES_PER_BLOCK;
-        if (dev_sqrt_env)         // (the device square root publishes for itself, from the ancestor kernel)
+        // (Round 5 merged these sums with their publish -- every workgroup storing to pinned memory, a ticket, the last one
+        //  setting the completion word -- and measured it: 13.8-14.5 us against 7.0 + 4.7 for the pair, whether the ticket is a
+        //  release or relaxed and whether every thread or only the writing lanes fence at system scope: 273 pinned stores from
+        //  69 workgroups each wait for their own acknowledgement, where k_publish_big's one workgroup waits once.  Like the
+        //  one-launch datum: on this part a dependent launch whose packet is already queued costs about what
+        //  any in-kernel hand-over does.  QSMC_MERGED_MOMENT_PUBLISH=1 keeps the merged form for A/B.)
+        static const bool merged_publish = getenv("QSMC_MERGED_MOMENT_PUBLISH") != nullptr;
+        if (dev_sqrt_env || !merged_publish)
             hipLaunchKernelGGL(k_sum_partials, dim3(SUM_GRID), dim3(QSMC_BLOCK), 0, s, h->partials, gridm, MFMA_MOM_K, full);
-        else                      // sums and their publish to the host in one launch (round 5; two before)
+        else
             hipLaunchKernelGGL(k_sum_partials_publish, dim3(SUM_GRID), dim3(QSMC_BLOCK), 0, s, h->partials, gridm, MFMA_MOM_K,
                                full, h->mapped_big_dev, h->flag_dev, seq, h->tickets + TICKET_WORDS - 1);
         // (round 4 built the device form -- kernels/sqrtm.hpp -- and measured it: the gap between the two sampler kernels
@@ -2384,6 +2391,8 @@ int qsmc_step(qsmc_handle_t h, qsmc_step_t *st, const qsmc_model_t *model, const
             if (rc) return rc;
             ++h->n_sqrt_dev;
         } else {
+            if (!merged_publish)
+                hipLaunchKernelGGL(k_publish_big, dim3(1), dim3(QSMC_BLOCK), 0, s, full, MFMA_MOM_K, h->mapped_big_dev, h->flag_dev, seq);
             HIP_TRY(h, hipGetLastError());
             rc = resample_philox_impl(h, model, st->lw.postselect, st->x, st->ldx, st->n, d, st->w, fixed, st->lw.a, st->mean,
                                       st->S, st->lw.n_out, st->lw.seed, st->lw.epoch, st->lw.maxiter, st->lw.x_out, pl,
