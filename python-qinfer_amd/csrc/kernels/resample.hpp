@@ -1384,12 +1384,15 @@ struct BankIn {
     const double *entries;
     int stride, reserved;
     const int *e_cnt, *f_cnt;
-    const long long *e_base, *f_base;
-    long long *e_off, *f_off;                         // [max_items + 1] exclusive prefixes over the work items
+    const long long *f_base;                          // per work item: where its failed slots start in retry_list
+    long long *e_off, *f_off;                         // [max_items + 1] exclusive prefixes over the work items (an item's
+                                                      //  spares sit AT e_off[item] in the bank: entry g of the bank is spare g)
     long long *ctr;                                   // [0] E, [1] F, [2] leftover count, [8 + t] F_t, [24 + t] B_t, [40 + t] blocks done
     unsigned int *tmp[2];                             // failed slots of a round, virtual block by virtual block
     int *bcount[2];                                   // ... how many in each virtual block
     long long *boff[2];                               // ... and their exclusive prefix
+    int *vb_first[2];                                 // round t, virtual block vb: the entry of the prefix round t reads (f_off
+                                                      //  for t = 1, boff[(t - 1) & 1] after) that holds position vb * BANK_VB
     unsigned int *leftover;                           // slots for k_bucket_redraw
     unsigned long long key[4];                        // of the bijection
 };
@@ -1424,6 +1427,44 @@ __device__ __forceinline__ int upper_bound_ll(const long long *__restrict__ a, i
         if (a[mid] <= v) lo = mid + 1; else hi = mid;
     }
     return lo;
+}
+
+// Round 5: where a round's positions are, without a binary search through L2.  The j-th slot still failed is found through
+// a prefix (per work item before round 1, per virtual block of the previous round after): 12-13 DEPENDENT loads per
+// thread, and with the (redundant) search for the spare's work item behind it a try was a chain of ~30 -- k_bank_round
+// was 33-72 us for a million tries that move 60 MB.  The workgroup that forms a prefix now also notes, for every block
+// of BANK_VB consecutive positions, the entry its first position falls in (bank_block_starts: no search, every entry
+// writes the blocks that start inside it); a round's workgroup loads the BT + 1 prefix entries from there on into LDS
+// in one trip and searches those (bank_locate) -- the global search remains for a block whose positions run past the
+// window (more than BT entries with next to no failures each).  Same entry, so the same slots in the same order.
+__device__ __forceinline__ void bank_block_starts(const long long *off, int m, int *__restrict__ vb_first) {
+    for (int i = threadIdx.x; i < m; i += (int)blockDim.x) {
+        const long long lo = off[i], hi = off[i + 1];
+        for (long long vb = (lo + BANK_VB - 1) / BANK_VB; vb * BANK_VB < hi; ++vb) vb_first[vb] = i;
+    }
+}
+
+// entry i with off[i] <= j < off[i + 1] (off[0..m], off[m] = total > j); first = the entry of the block's first position.
+// Workgroup-wide (one barrier inside; the caller has one between two calls); s_win holds BT + 1 entries.
+template <int BT>
+__device__ __forceinline__ int bank_locate(const long long *__restrict__ off, int m, int first, long long j, bool live,
+                                           long long *s_win, long long &off_i) {
+    for (int t = threadIdx.x; t <= BT; t += BT) s_win[t] = first + t <= m ? off[first + t] : 0x7fffffffffffffffll;
+    __syncthreads();
+    off_i = 0ll;
+    if (!live) return 0;
+    if (s_win[BT] <= j) {
+        const int i = upper_bound_ll(off, m + 1, j) - 1;
+        off_i = off[i];
+        return i;
+    }
+    int lo = 0, hi = BT + 1;                          // # window entries <= j (s_win[0] <= j: at least one)
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (s_win[mid] <= j) lo = mid + 1; else hi = mid;
+    }
+    off_i = s_win[lo - 1];
+    return first + lo - 1;
 }
 
 // one workgroup: exclusive prefix of src[0..m) into dst[0..m], total returned to every thread.  ATOMIC: src was written
@@ -1508,6 +1549,7 @@ __device__ __forceinline__ long long block_exclusive_scan_i(const int *src, int 
 __global__ __launch_bounds__(1024) void k_bank_scan(BankIn bk, const int *__restrict__ item_off, int chunks) {
     const int n_items = item_off[chunks];
     const long long F = block_exclusive_scan_i<false>(bk.f_cnt, n_items, bk.f_off);
+    bank_block_starts(bk.f_off, n_items, bk.vb_first[1]);
     // ([0] = E: k_bank_counts.  Everything else starts from zero -- including the workgroup counters of the NEXT resample's
     //  k_bank_counts and rounds, which is why no memset is queued per resample)
     if (threadIdx.x >= 1 && threadIdx.x < 64) bk.ctr[threadIdx.x] = 0ll;
@@ -1520,10 +1562,8 @@ __global__ __launch_bounds__(1024) void k_bank_scan(BankIn bk, const int *__rest
 
 // one failed slot, one spare: true if the spare was invalid too (or the slot was sent to the leftover list)
 template <int DM>
-__device__ __forceinline__ bool bank_try(const BankIn &bk, long long g, long long E, int n_items, unsigned int slot, int d,
-                                         double *__restrict__ x_out, const OutPlace &pl, bool &left,
-                                         const long long *e_off = nullptr) {
-    if (!e_off) e_off = bk.e_off;                     // (k_bank_tail hands in its LDS copy of the prefix)
+__device__ __forceinline__ bool bank_try(const BankIn &bk, long long g, long long E, unsigned int slot, int d,
+                                         double *__restrict__ x_out, const OutPlace &pl, bool &left) {
     left = false;
     if (g >= E) {                                     // the bank is exhausted: the old way
         const unsigned long long at = atomicAdd(reinterpret_cast<unsigned long long *>(bk.ctr + 2), 1ull);
@@ -1532,8 +1572,9 @@ __device__ __forceinline__ bool bank_try(const BankIn &bk, long long g, long lon
         return false;
     }
     const long long pg = (long long)bank_perm((unsigned long long)g, (unsigned long long)E, bk.key);
-    const int bi = upper_bound_ll(e_off, n_items + 1, pg) - 1;
-    const double *ent = bk.entries + (bk.e_base[bi] + (pg - e_off[bi])) * bk.stride;
+    // (an item's spares start at the prefix of the counts, so spare pg IS entry pg: until round 5 the item was searched for
+    //  in e_off -- 13 dependent loads -- only to add e_base[item] - e_off[item] = 0)
+    const double *ent = bk.entries + pg * bk.stride;
     if (ent[bk.stride - 1] == 0.0) return true;
     const int64_t row = place_row(pl, (int64_t)slot);
 #pragma unroll
@@ -1552,6 +1593,7 @@ __global__ __launch_bounds__(BANK_VB) void k_bank_round(BankIn bk, const int *__
                                                         double *__restrict__ x_out, OutPlace pl) {
     __shared__ int wcount[BANK_VB / QSMC_WAVE];
     __shared__ int is_last;
+    __shared__ long long s_win[BANK_VB + 1];
     const long long Ft = bk.ctr[8 + t];
     if (Ft == 0ll) return;
     const long long Bt = bk.ctr[24 + t], E = bk.ctr[0];
@@ -1564,16 +1606,14 @@ __global__ __launch_bounds__(BANK_VB) void k_bank_round(BankIn bk, const int *__
         const long long j = vb * BANK_VB + threadIdx.x;
         unsigned int slot = 0u;
         bool fail = false;
+        const long long *off = t == 1 ? bk.f_off : bk.boff[prev];
+        long long off_src;
+        const int src = bank_locate<BANK_VB>(off, t == 1 ? n_items : nvb_prev, bk.vb_first[t & 1][vb], j, j < Ft, s_win, off_src);
         if (j < Ft) {
-            if (t == 1) {
-                const int it = upper_bound_ll(bk.f_off, n_items + 1, j) - 1;
-                slot = retry_list[bk.f_base[it] + (j - bk.f_off[it])];
-            } else {
-                const int pb = upper_bound_ll(bk.boff[prev], nvb_prev + 1, j) - 1;
-                slot = bk.tmp[prev][(long long)pb * BANK_VB + (j - bk.boff[prev][pb])];
-            }
+            if (t == 1) slot = retry_list[bk.f_base[src] + (j - off_src)];
+            else slot = bk.tmp[prev][(long long)src * BANK_VB + (j - off_src)];
             bool left;
-            fail = bank_try<DM>(bk, Bt + j, E, n_items, slot, d, x_out, pl, left);
+            fail = bank_try<DM>(bk, Bt + j, E, slot, d, x_out, pl, left);
         }
         const unsigned long long mk = __ballot(fail);
         if (lane == 0) wcount[wave] = __popcll(mk);
@@ -1596,6 +1636,7 @@ __global__ __launch_bounds__(BANK_VB) void k_bank_round(BankIn bk, const int *__
     __syncthreads();
     if (!is_last) return;
     const long long next = block_exclusive_scan_i<true>(bk.bcount[cur], nvb, bk.boff[cur]);
+    bank_block_starts(bk.boff[cur], nvb, bk.vb_first[(t + 1) & 1]);
     if (threadIdx.x == 0) {
         bk.ctr[8 + t + 1] = next;
         bk.ctr[24 + t + 1] = Bt + Ft;
@@ -1613,25 +1654,18 @@ __global__ __launch_bounds__(1024) void k_bank_tail(BankIn bk, const int *__rest
     if (Ft == 0ll) return;
     long long Bt = bk.ctr[24 + t0];
     const long long E = bk.ctr[0];
-    const int n_items = item_off[chunks];
-    // (round 5) every try binary-searches the prefix of the items' spare counts -- 13 dependent loads; this ONE workgroup
-    // makes thousands of tries one dependent trip after the other, so the prefix is copied to LDS first when it fits
-    constexpr int TAIL_EOFF = 6144;
-    __shared__ long long s_eoff[TAIL_EOFF];
-    const long long *eoff = nullptr;
-    if (n_items + 1 <= TAIL_EOFF) {
-        for (int i = threadIdx.x; i <= n_items; i += 1024) s_eoff[i] = bk.e_off[i];
-        eoff = s_eoff;
-    }
-    __syncthreads();
+    __shared__ long long s_win[1024 + 1];
     const int lane = threadIdx.x & (QSMC_WAVE - 1), wave = threadIdx.x / QSMC_WAVE;
     const int prev = (t0 - 1) & 1, cur = t0 & 1;
     const int nvb_prev = (int)((bk.ctr[8 + t0 - 1] + BANK_VB - 1) / BANK_VB);
     // this round's slots, densely: out of the previous round's per-block lists
     unsigned int *in = bk.tmp[cur], *out = bk.tmp[cur] + ((Ft + 1023) & ~1023ll);
-    for (long long j = threadIdx.x; j < Ft; j += 1024) {
-        const int pb = upper_bound_ll(bk.boff[prev], nvb_prev + 1, j) - 1;
-        in[j] = bk.tmp[prev][(long long)pb * BANK_VB + (j - bk.boff[prev][pb])];
+    for (long long base = 0; base < Ft; base += 1024) {
+        const long long j = base + threadIdx.x;
+        long long off_pb;
+        const int pb = bank_locate<1024>(bk.boff[prev], nvb_prev, bk.vb_first[t0 & 1][base / BANK_VB], j, j < Ft, s_win, off_pb);
+        if (j < Ft) in[j] = bk.tmp[prev][(long long)pb * BANK_VB + (j - off_pb)];
+        __syncthreads();
     }
     __syncthreads();
     for (int t = t0; t <= BANK_ROUNDS && Ft > 0ll; ++t) {
@@ -1644,7 +1678,7 @@ __global__ __launch_bounds__(1024) void k_bank_tail(BankIn bk, const int *__rest
             if (j < Ft) {
                 slot = in[j];
                 bool left;
-                fail = bank_try<DM>(bk, Bt + j, E, n_items, slot, d, x_out, pl, left, eoff);
+                fail = bank_try<DM>(bk, Bt + j, E, slot, d, x_out, pl, left);
             }
             const unsigned long long mk = __ballot(fail);
             if (lane == 0) wcount[wave] = __popcll(mk);

@@ -1808,8 +1808,8 @@ static int bank_layout(qsmc_ctx *h, double lambda, int max_items, int64_t n_out,
     const size_t items_i = up((size_t)max_items * sizeof(int)), items_l = up(((size_t)max_items + 1) * sizeof(long long));
     const size_t nvb = (size_t)(n_out / BANK_VB) + 2;
     const size_t list_b = up((2 * (size_t)n_out + 8192) * sizeof(unsigned int));   // (k_bank_tail splits a list buffer in two)
-    const size_t need = 256 /* top */ + up(64 * sizeof(long long)) + 2 * items_i + 4 * items_l + 2 * list_b +
-                        2 * up(nvb * sizeof(int)) + 2 * up((nvb + 1) * sizeof(long long)) + list_b;
+    const size_t need = 256 /* top */ + up(64 * sizeof(long long)) + 2 * items_i + 3 * items_l + 2 * list_b +
+                        4 * up(nvb * sizeof(int)) + 2 * up((nvb + 1) * sizeof(long long)) + list_b;
     if (h->bank.aux_cap < need) {
         if (h->bank.aux) HIP_TRY(h, hipFree(h->bank.aux));
         h->bank.aux = nullptr;
@@ -1828,19 +1828,18 @@ static int bank_layout(qsmc_ctx *h, double lambda, int max_items, int64_t n_out,
     bi->ctr = reinterpret_cast<long long *>(take(up(64 * sizeof(long long))));
     bo->e_cnt = reinterpret_cast<int *>(take(items_i));
     bo->f_cnt = reinterpret_cast<int *>(take(items_i));
-    bo->e_base = reinterpret_cast<long long *>(take(items_l));
     bo->f_base = reinterpret_cast<long long *>(take(items_l));
     bi->e_off = reinterpret_cast<long long *>(take(items_l));
     bi->f_off = reinterpret_cast<long long *>(take(items_l));
     for (int k = 0; k < 2; ++k) bi->tmp[k] = reinterpret_cast<unsigned int *>(take(list_b));
     for (int k = 0; k < 2; ++k) bi->bcount[k] = reinterpret_cast<int *>(take(up(nvb * sizeof(int))));
+    for (int k = 0; k < 2; ++k) bi->vb_first[k] = reinterpret_cast<int *>(take(up(nvb * sizeof(int))));
     for (int k = 0; k < 2; ++k) bi->boff[k] = reinterpret_cast<long long *>(take(up((nvb + 1) * sizeof(long long))));
     bi->leftover = reinterpret_cast<unsigned int *>(take(list_b));
     bi->entries = bo->entries;
     bi->e_cnt = bo->e_cnt;
     bi->f_cnt = bo->f_cnt;
-    bo->e_base = bi->e_off;                          // (an item's spares start at the prefix of the counts)
-    bi->e_base = bi->e_off;
+    bo->e_base = bi->e_off;                          // an item's spares start at the prefix of the counts: spare g is entry g
     bi->f_base = bo->f_base;
     unsigned long long sm = seed ^ (epoch * 0xD1342543DE82EF95ull) ^ 0x62616E6Bull;       // "bank"
     for (int k = 0; k < 4; ++k) bi->key[k] = splitmix64(sm);

@@ -429,15 +429,19 @@ def test_liu_west_philox_vs_oracle(qi, case):
     assert not np.array_equal(got, other)
 
 
-@pytest.mark.parametrize("case", ["prec", "rb", "rb-bank", "rb-bank-short", "tomo", "prec-large", "prec-one-chunk"])
+@pytest.mark.parametrize("case", ["prec", "rb", "rb-bank", "rb-bank-short", "rb-bank-sparse", "tomo", "prec-large",
+                                  "prec-one-chunk"])
 def test_liu_west_philox_bucketed_vs_oracle(qi, eng, case):
     """The bucketed (count -> plan -> LDS-staged sample) resampler on identical Philox numbers.  rb-bank: the failed
     first tries are served from the proposal bank (qsmc_lw_expect_redraws); rb-bank-short: a bank far too small, so
-    that most of them fall through to the global-CDF redraw kernel behind it."""
+    that most of them fall through to the global-CDF redraw kernel behind it; rb-bank-sparse: ~600 work items and fewer
+    failed first tries than that, so one block of the bank's first round runs over more than 512 items -- past the LDS
+    window of the prefix, onto the global search (bank_locate's two paths in one launch)."""
     import philox as ph
     rs = np.random.RandomState(12)
     n = 70001
-    expect = {"rb-bank": 9000, "rb-bank-short": 700}.get(case, 0)
+    expect = {"rb-bank": 9000, "rb-bank-short": 700, "rb-bank-sparse": 500}.get(case, 0)
+    sparse = case == "rb-bank-sparse"
     if case.startswith("rb"):
         case = "rb"
     if case.startswith("prec"):
@@ -446,7 +450,11 @@ def test_liu_west_philox_bucketed_vs_oracle(qi, eng, case):
         x = np.abs(0.04 + 0.05 * rs.randn(n, 1))
     elif case == "rb":
         model, valid = qi.RandomizedBenchmarkingModel(), orc.valid_rb
-        x = np.stack([rs.uniform(0.9, 1, n), rs.uniform(0.2, 0.5, n), rs.uniform(0.4, 0.6, n)], 1)
+        if sparse:                                       # the constraints bite in one corner only: ~400 failures in 2.4e6
+            n = 2400001
+            x = np.stack([rs.uniform(0.5, 0.8, n), rs.uniform(0.2, 0.5, n), rs.uniform(0.3, 0.44, n)], 1)
+        else:
+            x = np.stack([rs.uniform(0.9, 1, n), rs.uniform(0.2, 0.5, n), rs.uniform(0.4, 0.6, n)], 1)
     else:
         basis = qi.tomography.pauli_basis(2)
         model, valid = qi.TomographyModel(basis), (lambda z: np.ones(z.shape[0], dtype=bool))
@@ -455,7 +463,7 @@ def test_liu_west_philox_bucketed_vs_oracle(qi, eng, case):
     w = rs.random_sample(n) ** 2
     w[5000:9200] = 0.0                                   # an (almost) empty chunk
     w[20000:20100] *= 400.0 if case != "prec-large" else 8000.0    # a heavy chunk -> split into several work items
-    n_out = {"prec-large": 1200000, "prec-one-chunk": 20000}.get(case, 90000)
+    n_out = 2400000 if sparse else {"prec-large": 1200000, "prec-one-chunk": 20000}.get(case, 90000)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         pd = qi.ParticleDistribution(particle_locations=x, particle_weights=w)
@@ -470,7 +478,11 @@ def test_liu_west_philox_bucketed_vs_oracle(qi, eng, case):
                                                               expect_redraws=expect)
     got = new.particle_locations
     if expect:                                           # (the bank changes which Philox blocks a redraw consumes)
-        assert not np.array_equal(got, ph.liu_west_philox_bucketed(wn, x, valid, 0.9, np.sqrt(1 - 0.81), 4321, 1, n_out)[0])
+        plain = ph.liu_west_philox_bucketed(wn, x, valid, 0.9, np.sqrt(1 - 0.81), 4321, 1, n_out)[0]
+        assert not np.array_equal(got, plain)
+        if sparse:
+            first_try_failed = int(np.sum(np.any(plain != ref, axis=1)))
+            assert 64 < first_try_failed < len(counts), first_try_failed      # fewer failures than work items: the point
     assert counts.max() > 2 * 8192, "fixture must exercise the heavy-chunk split"
     assert counts.sum() == n_out and len(counts) == (n + 4095) // 4096
     cov = orc.particle_cov(wn, x, warn=False)
