@@ -259,8 +259,8 @@ def bank_perm(g, n, key):
 def bank_spares(x, cdf, edges, counts, cap, lam, a, mean, S, valid_fn, seed, epoch):
     """The proposal bank as k_bucket_sample_ordered fills it: per work item (chunk, part) e_i ~ Poisson(lam mass / total /
     parts) spares (block (item, attempt), round tag 0xFFFE); spare k of item i: position from word k & 1 of block
-    ((i << 12) | k >> 1, round tag 0xFFFF, slot 1), normals from the same pair id (slot 2); like the primaries, spare k
-    is kicked from the k-th smallest of the item's spare ancestors.
+    ((i << 12) | k >> 1, round tag 0xFFFF, slot 1), normals from the same pair id (slot 2); spare k is kicked from its own
+    ancestor (drawing order: unlike the primaries the spares are not sorted by ancestor -- round 5).
     Returns (values (E, d), valid (E,)) in the bank's logical order: items ascending, spares in order."""
     N, d = x.shape
     chunks = len(edges)
@@ -279,7 +279,6 @@ def bank_spares(x, cdf, edges, counts, cap, lam, a, mean, S, valid_fn, seed, epo
                 u = lo + _pair_word(ids, seed, epoch, 1, rnd=0xFFFF) * (hi - lo)
                 base, end = c * BUCKET_CHUNK, min((c + 1) * BUCKET_CHUNK, N)
                 js = np.minimum(np.maximum(np.searchsorted(cdf, u, side='right'), base), end - 1)
-                js = np.sort(js, kind='stable')          # spare k takes the k-th smallest spare ancestor of its item
                 z = np.stack([_pair_normal(ids * d + q, seed, epoch, 2, rnd=0xFFFF) for q in range(d)])
                 v = (a * x[js] + (1 - a) * mean) + (S @ z).T
                 vals.append(v)

@@ -1236,27 +1236,11 @@ __global__ __launch_bounds__(BT) void k_bucket_sample_ordered(
             }
         }
     }
-    // ---- 3x: the spares are kicked like any slot (their own normals) and banked with their validity.  Their ancestors
-    // go through the same histogram -> ascending list as the primaries' did (the counters and the list are free again):
-    // spare k takes the k-th smallest of them, so neighbouring lanes gather neighbouring particles here too.
-    if (banked) {                                             // (uniform)
-        __syncthreads();                                      // every primary has read its entry of the list
-        for (int k = threadIdx.x; k < BUCKET_CHUNK / 2; k += BT) cnt2[k] = 0u;
-        if (threadIdx.x == 0) hcount = 0;
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < BANK_MAX_PER_ITEM / (2 * BT); ++k) {
-            const int P = (int)threadIdx.x + k * BT;
-#pragma unroll
-            for (int e = 0; e < 2; ++e)
-                if (2 * P + e < e_i) {
-                    const unsigned int j = (jx[k] >> (16 * e)) & 0xffffu;
-                    atomicAdd(&cnt2[j >> 1], 1u << (16 * (j & 1u)));
-                }
-        }
-        __syncthreads();
-        expand_sorted();
-    }
+    // ---- 3x: the spares are kicked like any slot (their own normals) and banked with their validity.  Spare k is kicked
+    // from ITS OWN ancestor, in drawing order (round 5; until then the spares went through a second histogram ->
+    // ascending list like the primaries: a counter clear, an LDS atomic per spare, an integer scan and six workgroup
+    // barriers per work item, ~2 us each, to coalesce the gathers of the ~270 spares an item makes -- which hit lines
+    // the primaries have just pulled into the L2 anyway).
     if (banked && e_i > 0) {
         const long long eb = ebase_s;
 #pragma unroll
@@ -1275,7 +1259,7 @@ __global__ __launch_bounds__(BT) void k_bucket_sample_ordered(
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     if (2 * P + e < e_i) {
-                        const int jl = (int)sorted[2 * P + e];
+                        const int jl = (int)((jx[k] >> (16 * e)) & 0xffffu);
                         double *ent = bank.entries + (eb + 2 * P + e) * bank.stride;
                         double p[DM];
 #pragma unroll
