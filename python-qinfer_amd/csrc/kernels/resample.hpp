@@ -1173,12 +1173,14 @@ __global__ __launch_bounds__(BT) void k_bucket_sample_ordered(
             off0 += nk;
         }
         __syncthreads();
-        const int nh = hcount;
-        for (int h = 0; h < nh; ++h) {
-            const unsigned int st = heavy[2 * h] & 0xffffu, jj = heavy[2 * h] >> 16, cn = heavy[2 * h + 1];
-            for (unsigned int r = threadIdx.x; r < cn; r += BT) sorted[st + r] = (unsigned short)jj;
+        const int nh = hcount;                                      // (uniform: read behind the barrier, not written again)
+        if (nh) {
+            for (int h = 0; h < nh; ++h) {
+                const unsigned int st = heavy[2 * h] & 0xffffu, jj = heavy[2 * h] >> 16, cn = heavy[2 * h + 1];
+                for (unsigned int r = threadIdx.x; r < cn; r += BT) sorted[st + r] = (unsigned short)jj;
+            }
+            __syncthreads();
         }
-        __syncthreads();
     };
     expand_sorted();
     // ---- 3: the kicks
@@ -1826,12 +1828,14 @@ __global__ __launch_bounds__(BT) void k_bucket_anc16(
             off0 += nk;
         }
         __syncthreads();
-        const int nh = hcount;
-        for (int h = 0; h < nh; ++h) {
-            const unsigned int st = heavy[2 * h] & 0xffffu, jj = heavy[2 * h] >> 16, cn = heavy[2 * h + 1];
-            for (unsigned int r = threadIdx.x; r < cn; r += BT) sorted[st + r] = (unsigned short)jj;
+        const int nh = hcount;                                      // (uniform: read behind the barrier, not written again)
+        if (nh) {
+            for (int h = 0; h < nh; ++h) {
+                const unsigned int st = heavy[2 * h] & 0xffffu, jj = heavy[2 * h] >> 16, cn = heavy[2 * h + 1];
+                for (unsigned int r = threadIdx.x; r < cn; r += BT) sorted[st + r] = (unsigned short)jj;
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
     for (int k = threadIdx.x; k < q; k += BT) anc[o_begin + k] = (unsigned int)(base + (int64_t)sorted[k]);
 }
