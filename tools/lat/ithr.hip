@@ -26,6 +26,18 @@ __global__ __launch_bounds__(256) void k(double *out, double seed, long long *cy
             if (OP == 11) a[i] = (double)(int)(a[i]) + 1.5;                                         // cvt i32<->f64
             if (OP == 12) u[i] = u[i] + 0x9E3779B97F4A7C15ull;                                      // 64-bit add
             if (OP == 13) a[i] = fmin(fmax(a[i], 0.5), 2.0);
+            if (OP == 14) {     // u53 as the library forms it: two shifts, two v_cvt_f64_u32, fma, mul  (+ an xor to chain)
+                const uint32_t x = w[i], y = w[i] * 3u + (uint32_t)it;
+                a[i] = ((double)(x >> 5) * 67108864.0 + (double)(y >> 6)) / 9007199254740992.0;
+                w[i] = x ^ (uint32_t)__double2loint(a[i]);
+            }
+            if (OP == 15) {     // the same value from bits: 0.5 + low 52 bits at exponent -1, minus 0.5 unless bit 52 is set
+                const uint32_t x = w[i], y = w[i] * 3u + (uint32_t)it;
+                const uint32_t hi = 0x3FE00000u | ((x >> 11) & 0xFFFFFu), lo = ((x << 21) & 0xFC000000u) | (y >> 6);
+                const double v = __hiloint2double((int)hi, (int)lo);
+                a[i] = v - ((int)x < 0 ? 0.0 : 0.5);
+                w[i] = x ^ (uint32_t)__double2loint(a[i]);
+            }
         }
     }
     long long t1 = clock64();
@@ -56,6 +68,7 @@ int main() {
         run<4>("v_rcp_f64", wps); run<5>("v_rsq_f64", wps); run<6>("v_mul_lo_u32+add", wps); run<7>("v_mul_hi_u32+xor", wps);
         run<8>("mul_f64+rndne_f64", wps); run<9>("xor/shift/add i32 (3 ops)", wps); run<10>("v_sqrt_f64", wps);
         run<11>("cvt f64->i32->f64 + add", wps); run<12>("u64 add (2 ops)", wps); run<13>("fmax+fmin f64", wps);
+        run<14>("u53 via 2 cvt (+mul,xor chain)", wps); run<15>("u53 via bits (+mul,xor chain)", wps);
     }
     return 0;
 }
