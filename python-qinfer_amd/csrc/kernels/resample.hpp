@@ -1740,11 +1740,14 @@ __global__ __launch_bounds__(BT) void k_bucket_anc16(
     __shared__ unsigned short lguide[TGUIDE_BINS + 2];
     __shared__ double wave_tot[SCAN_WAVES];
     __shared__ int iwave_tot[SCAN_WAVES];
-    __shared__ unsigned int cnt[BUCKET_CHUNK];                      // children per source particle
-    __shared__ unsigned short sorted[BUCKET_CAP];                   // ancestors of the item's outputs, ascending
+    __shared__ unsigned int cnt2[BUCKET_CHUNK / 2];                 // children per source particle, two counters a word
     __shared__ unsigned int heavy[2 * S16_HEAVY_CAP];
     __shared__ int hcount;
     static_assert(BT == SCAN_THREADS, "one lane owns 8 consecutive source particles");
+    static_assert(BUCKET_CAP * 2 <= BUCKET_CHUNK * 8 && BUCKET_CAP < 65536, "the ancestor list overlays the CDF; 16-bit counters");
+    // (round 5: 16-bit counters and the list laid over the CDF, as in k_bucket_sample_ordered: 75 -> 51 KB of LDS, three
+    //  workgroups per CU instead of two -- config 5's share has ~1500 work items for 256 CUs, i.e. three rounds of them)
+    unsigned short *sorted = reinterpret_cast<unsigned short *>(lcdf);  // ancestors of the item's outputs, ascending
     int bid = (int)blockIdx.x;
     if (sq.full) {
         // round 4: workgroup 0 (scheduled first) carries ONE wavefront that turns the summed moments into the Liu-West
@@ -1771,7 +1774,7 @@ __global__ __launch_bounds__(BT) void k_bucket_anc16(
     const double hi_edge = offsets[c + 1];
     const double gscale = (double)TGUIDE_BINS / (hi_edge - lo_edge);
     const bool use_guide = hi_edge > lo_edge && gscale < 1e300;     // workgroup-uniform
-    for (int k = threadIdx.x; k < BUCKET_CHUNK; k += BT) cnt[k] = 0u;
+    for (int k = threadIdx.x; k < BUCKET_CHUNK / 2; k += BT) cnt2[k] = 0u;
     if (threadIdx.x == 0) hcount = 0;
     chunk_scan_block(w, n_in, inv_norm, offsets, (int64_t)c, wave_tot,
                      StoreLdsTops{lcdf, ltops, lguide, lo_edge, hi_edge, gscale, use_guide, len, -1});
@@ -1791,19 +1794,22 @@ __global__ __launch_bounds__(BT) void k_bucket_anc16(
             const double u = lo_edge + upos[e] * (hi_edge - lo_edge);
             int j = table_upper_bound(lcdf, ltops, lguide, (len + 7) >> 3, use_guide, lo_edge, gscale, u);
             j = j > len - 1 ? len - 1 : j;
-            if (o >= o_begin && o < o_end) atomicAdd(&cnt[j], 1u);
+            if (o >= o_begin && o < o_end) atomicAdd(&cnt2[j >> 1], 1u << (16 * (j & 1)));
         }
     }
     __syncthreads();
     // ---- 2: exclusive scan of the counts (lane l owns particles 8 l .. 8 l + 7), ancestors expanded in ascending order
+    // (the list overlays the CDF: the barrier inside, behind the counter reads, is also behind every CDF read above)
     {
         const int j0 = (int)threadIdx.x * 8;
         unsigned int nj[8];
         int lt = 0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            nj[k] = cnt[j0 + k];
-            lt += (int)nj[k];
+        for (int k = 0; k < 8; k += 2) {
+            const unsigned int two = cnt2[(j0 + k) >> 1];
+            nj[k] = two & 0xffffu;
+            nj[k + 1] = two >> 16;
+            lt += (int)(nj[k] + nj[k + 1]);
         }
         int inc = lt;
 #pragma unroll
