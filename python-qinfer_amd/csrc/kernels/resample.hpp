@@ -757,11 +757,21 @@ struct StoreLdsGuide {
 // over all 4096 entries -- tops[s - 1] <= u < tops[s] puts every earlier block below u and every later one above.
 // Entries past the end of a short last chunk read as +inf.
 // ---------------------------------------------------------------------------------------------
+// Round 5, late: a block of eight entries starts every 64 bytes, i.e. on LDS banks 0, 16, 32 or 48 -- the 64 random block
+// reads of a wave's search land on four bank groups (SQ_LDS_BANK_CONFLICT 1.6e7 cycles per launch of the d = 1 sampler,
+// as many as the LDS spends on its instructions), and the scan's stores (lane l -> block l) collide 16 ways.  With
+// CDF8_PAD = 2 doubles between blocks a block starts every 80 bytes: banks 0, 20, 40, 60, 16, ... -- all sixteen
+// 4-bank groups.  40 KB instead of 32; the kernels that can afford it take it (template parameter of the sink and of
+// the search), k_bucket_anc16 keeps its three workgroups per CU instead.
+template <int PAD> __device__ __forceinline__ int cdf8_pos(int j) { return j + PAD * (j >> 3); }
+template <int PAD> constexpr int cdf8_size() { return BUCKET_CHUNK + PAD * (BUCKET_CHUNK / 8); }
 constexpr int TGUIDE_BINS = 1024;
+constexpr int CDF8_PAD = 2;
 constexpr int TOPS_N = BUCKET_CHUNK / SCAN_PER_LANE;                 // 512
 constexpr int TOPS_LDS = TOPS_N + (TOPS_N >> 5) + 4;
 __device__ __forceinline__ int tops_skew(int l) { return l + (l >> 5); }
 
+template <int PAD = 0>
 struct StoreLdsTops {
     double *cdf8, *tops;
     unsigned short *G;
@@ -770,7 +780,7 @@ struct StoreLdsTops {
     int len;
     int cp;                                        // guide cell of the previous block's top
     __device__ __forceinline__ void operator()(int j, double v, double prev, bool live) {
-        cdf8[j] = live ? v : INFINITY;
+        cdf8[cdf8_pos<PAD>(j)] = live ? v : INFINITY;
         const int k = j & (SCAN_PER_LANE - 1), l = j >> 3;
         if (k == 0) cp = (j == 0 || !use_guide) ? -1 : guide_cell<TGUIDE_BINS>(prev, lo_edge, gscale);
         if (k != SCAN_PER_LANE - 1) return;
@@ -799,6 +809,7 @@ struct StoreLdsTops {
 };
 
 // number of entries of the chunk's CDF that are <= u (the caller clamps to len - 1)
+template <int PAD = 0>
 __device__ __forceinline__ int table_upper_bound(const double *cdf8, const double *tops, const unsigned short *G,
                                                  int n_blocks, bool use_guide, double lo_edge, double gscale, double u) {
     int lo = 0, hi = n_blocks;
@@ -812,9 +823,15 @@ __device__ __forceinline__ int table_upper_bound(const double *cdf8, const doubl
         if (tops[tops_skew(mid)] <= u) lo = mid + 1; else hi = mid;
     }
     const int sb = lo < n_blocks ? lo : n_blocks - 1;
-    const double4 a = *reinterpret_cast<const double4 *>(cdf8 + 8 * sb);
-    const double4 b = *reinterpret_cast<const double4 *>(cdf8 + 8 * sb + 4);
-    const int cnt = (a.x <= u) + (a.y <= u) + (a.z <= u) + (a.w <= u) + (b.x <= u) + (b.y <= u) + (b.z <= u) + (b.w <= u);
+    if (PAD == 0) {
+        const double4 a = *reinterpret_cast<const double4 *>(cdf8 + 8 * sb);
+        const double4 b = *reinterpret_cast<const double4 *>(cdf8 + 8 * sb + 4);
+        const int cnt = (a.x <= u) + (a.y <= u) + (a.z <= u) + (a.w <= u) + (b.x <= u) + (b.y <= u) + (b.z <= u) + (b.w <= u);
+        return 8 * sb + cnt;
+    }
+    const double2 *blk = reinterpret_cast<const double2 *>(cdf8 + (8 + PAD) * sb);     // (16-byte aligned: PAD is even)
+    const double2 a = blk[0], b = blk[1], c = blk[2], d = blk[3];
+    const int cnt = (a.x <= u) + (a.y <= u) + (b.x <= u) + (b.y <= u) + (c.x <= u) + (c.y <= u) + (d.x <= u) + (d.y <= u);
     return 8 * sb + cnt;
 }
 
@@ -839,7 +856,8 @@ __global__ __launch_bounds__(BT) void k_bucket_sample(
     unsigned long long *__restrict__ retry_count, int cap) {
     constexpr int DM = D > 0 ? D : QSMC_MAX_D;
     const int d = D > 0 ? D : d_rt;
-    __shared__ __attribute__((aligned(32))) double lcdf[BUCKET_CHUNK];
+    constexpr int PAD = CDF8_PAD;
+    __shared__ __attribute__((aligned(32))) double lcdf[cdf8_size<PAD>()];
     __shared__ double ltops[TOPS_LDS];
     __shared__ unsigned short lguide[TGUIDE_BINS + 2];
     __shared__ double wave_tot[SCAN_WAVES];
@@ -861,7 +879,7 @@ __global__ __launch_bounds__(BT) void k_bucket_sample(
     const double gscale = (double)TGUIDE_BINS / (hi_edge - lo_edge);
     const bool use_guide = hi_edge > lo_edge && gscale < 1e300;     // workgroup-uniform
     chunk_scan_block(w, n_in, inv_norm, offsets, (int64_t)c, wave_tot,
-                     StoreLdsTops{lcdf, ltops, lguide, lo_edge, hi_edge, gscale, use_guide, len, -1});
+                     StoreLdsTops<PAD>{lcdf, ltops, lguide, lo_edge, hi_edge, gscale, use_guide, len, -1});
     __syncthreads();
     const int64_t o_begin = slot0 + t0, o_end = slot0 + t1;         // this item's output slots
     unsigned long long failed = 0;
@@ -894,7 +912,7 @@ __global__ __launch_bounds__(BT) void k_bucket_sample(
         for (int e = 0; e < 2; ++e) {
             // position inside this chunk: given the counts, uniform on [lo_edge, hi_edge)
             const double u = lo_edge + upos[e] * (hi_edge - lo_edge);
-            int j = table_upper_bound(lcdf, ltops, lguide, (len + 7) >> 3, use_guide, lo_edge, gscale, u);
+            int j = table_upper_bound<PAD>(lcdf, ltops, lguide, (len + 7) >> 3, use_guide, lo_edge, gscale, u);
             an.jl[e] = j > len - 1 ? len - 1 : j;
             if (EARLY) {
 #pragma unroll
@@ -1053,7 +1071,8 @@ __global__ __launch_bounds__(BT) void k_bucket_sample_ordered(
     unsigned long long *__restrict__ retry_count, int cap, BankOut bank) {
     constexpr int DM = D > 0 ? D : QSMC_MAX_D;
     const int d = D > 0 ? D : d_rt;
-    __shared__ __attribute__((aligned(32))) double lcdf[BUCKET_CHUNK];
+    constexpr int PAD = CDF8_PAD;
+    __shared__ __attribute__((aligned(32))) double lcdf[cdf8_size<PAD>()];
     __shared__ double ltops[TOPS_LDS];
     __shared__ unsigned short lguide[TGUIDE_BINS + 2];
     __shared__ unsigned int cnt2[BUCKET_CHUNK / 2];             // children per source particle, two counters a word
@@ -1086,7 +1105,7 @@ __global__ __launch_bounds__(BT) void k_bucket_sample_ordered(
     const double gscale = (double)TGUIDE_BINS / (hi_edge - lo_edge);
     const bool use_guide = hi_edge > lo_edge && gscale < 1e300;     // workgroup-uniform
     chunk_scan_block(w, n_in, inv_norm, offsets, (int64_t)c, wave_tot,
-                     StoreLdsTops{lcdf, ltops, lguide, lo_edge, hi_edge, gscale, use_guide, len, -1});
+                     StoreLdsTops<PAD>{lcdf, ltops, lguide, lo_edge, hi_edge, gscale, use_guide, len, -1});
     __syncthreads();
     const int64_t o_begin = slot0 + t0, o_end = slot0 + t1;         // this item's output slots
     const int lane = threadIdx.x & (QSMC_WAVE - 1), wave = threadIdx.x / QSMC_WAVE;
@@ -1099,7 +1118,7 @@ __global__ __launch_bounds__(BT) void k_bucket_sample_ordered(
         for (int e = 0; e < 2; ++e) {
             const int64_t o = 2 * P + e;
             const double u = lo_edge + upos[e] * (hi_edge - lo_edge);
-            int j = table_upper_bound(lcdf, ltops, lguide, (len + 7) >> 3, use_guide, lo_edge, gscale, u);
+            int j = table_upper_bound<PAD>(lcdf, ltops, lguide, (len + 7) >> 3, use_guide, lo_edge, gscale, u);
             j = j > len - 1 ? len - 1 : j;
             if (o >= o_begin && o < o_end) atomicAdd(&cnt2[j >> 1], 1u << (16 * (j & 1)));
         }
@@ -1129,7 +1148,7 @@ __global__ __launch_bounds__(BT) void k_bucket_sample_ordered(
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const double u = lo_edge + upos[e] * (hi_edge - lo_edge);
-                    int j = table_upper_bound(lcdf, ltops, lguide, (len + 7) >> 3, use_guide, lo_edge, gscale, u);
+                    int j = table_upper_bound<PAD>(lcdf, ltops, lguide, (len + 7) >> 3, use_guide, lo_edge, gscale, u);
                     j = j > len - 1 ? len - 1 : j;
                     jx[k] |= (unsigned int)j << (16 * e);
                 }
@@ -1777,7 +1796,7 @@ __global__ __launch_bounds__(BT) void k_bucket_anc16(
     for (int k = threadIdx.x; k < BUCKET_CHUNK / 2; k += BT) cnt2[k] = 0u;
     if (threadIdx.x == 0) hcount = 0;
     chunk_scan_block(w, n_in, inv_norm, offsets, (int64_t)c, wave_tot,
-                     StoreLdsTops{lcdf, ltops, lguide, lo_edge, hi_edge, gscale, use_guide, len, -1});
+                     StoreLdsTops<0>{lcdf, ltops, lguide, lo_edge, hi_edge, gscale, use_guide, len, -1});
     __syncthreads();
     const int64_t o_begin = slot0 + t0, o_end = slot0 + t1;
     const int q = (int)(o_end - o_begin);
@@ -1792,7 +1811,7 @@ __global__ __launch_bounds__(BT) void k_bucket_anc16(
         for (int e = 0; e < 2; ++e) {
             const int64_t o = 2 * P + e;
             const double u = lo_edge + upos[e] * (hi_edge - lo_edge);
-            int j = table_upper_bound(lcdf, ltops, lguide, (len + 7) >> 3, use_guide, lo_edge, gscale, u);
+            int j = table_upper_bound<0>(lcdf, ltops, lguide, (len + 7) >> 3, use_guide, lo_edge, gscale, u);
             j = j > len - 1 ? len - 1 : j;
             if (o >= o_begin && o < o_end) atomicAdd(&cnt2[j >> 1], 1u << (16 * (j & 1)));
         }
