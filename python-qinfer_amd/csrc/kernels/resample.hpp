@@ -841,7 +841,7 @@ __device__ __forceinline__ int table_upper_bound(const double *cdf8, const doubl
 // k_bucket_redraw, which alone needs the (then materialised) global CDF.  With one or two coordinates per particle the
 // gather is cheap and the search's LDS round trips hide under the kick's arithmetic of the same iteration; from d = 3 on
 // the ordered kernel below wins (measured at N = 1e7, d = 1: 89 us here, 104 us ordered; d = 3, N = 1.25e7: 315 vs 259).
-// Occupancy: 44 KB of LDS allows three workgroups per CU; the small-d instantiations are held to 80
+// Occupancy: 49 KB of LDS (41 before the table was padded) allows three workgroups per CU; the small-d instantiations are held to 80
 // VGPRs (6 waves/SIMD) so that the third one fits -- the kernel is VALU-issue bound and the extra
 // waves hide the LDS search and gather latency (121 -> 110 us at N = 1e7, d = 1).
 template <int D, int BT>   // D = 0: runtime d; BT = threads per workgroup
@@ -1018,7 +1018,7 @@ __global__ __launch_bounds__(BT) void k_bucket_sample(
 //      combine, validity, store; a particle that fails postselection is queued for k_bucket_redraw, which alone needs
 //      the (then materialised) global CDF.  The loop has no search and no dependent LDS chain in it any more.
 // A pair straddling two work items is evaluated by both, each writing only its own half.
-// Occupancy: ~50 KB of LDS, 80 - 90 VGPRs at d = 3, 4: two to three workgroups per CU.
+// Occupancy: 59 KB of LDS (51 before the table was padded), 92 - 106 VGPRs at d = 3, 4: two workgroups per CU.
 // ---------------------------------------------------------------------------------------------
 // ---------------------------------------------------------------------------------------------
 // Proposal bank (round 3): postselection without global redraws, for models whose constraint bites at EVERY resample
