@@ -405,6 +405,10 @@ def other_paths(qi, eng, torch, n=10_000_000):
         torch.cuda.empty_cache()
     except Exception as ex:  # noqa: BLE001
         out["batch_update_tomography_interval_5"] = {"error": repr(ex)}
+    try:
+        out["plugin_device_hook"] = plugin_paths(qi, eng, torch, n)
+    except Exception as ex:  # noqa: BLE001
+        out["plugin_device_hook"] = {"error": repr(ex)}
     m = qi.BinomialModel(qi.SimplePrecessionModel())
     upd = qi.SMCUpdater(m, n, qi.UniformDistribution([0, 1]), device_rng=True, seed=0)
     ep = np.empty((1,), dtype=m.expparams_dtype)
@@ -441,6 +445,81 @@ def other_paths(qi, eng, torch, n=10_000_000):
     del upd
     torch.cuda.empty_cache()
     return out
+
+
+def plugin_paths(qi, eng, torch, n=10_000_000, n_data=40):
+    """The qinfer.Model plugin surface at the headline cloud size (abstract_model.py:444-468): UnknownT2Model
+    (test_models.py:222-259; two parameters) served three ways through the same SMCUpdater.update loop --
+      native        the library's own kernels (k_update_fused<UNKNOWN_T2> + the d = 2 sampler);
+      torch_plugin  a user model WITHOUT native kernels that defines `likelihood_device` / `are_models_valid_device`
+                    (eager torch on the (d, N) tensor the cloud lives in: no host copy; the update is qsmc_update_from_
+                    likelihood, the resample the Philox sampler + the model's own validity test);
+      numpy_plugin  the same model with only the reference's NumPy methods (the cloud's host copy is kept between resamples;
+                    its likelihood runs on the host: a few data only).
+    ms per datum includes every resample the data trigger."""
+    class NumpyT2(qi.FiniteOutcomeModel):
+        n_modelparams = 2
+        expparams_dtype = [('t', 'float')]
+        is_n_outcomes_constant = True
+
+        def n_outcomes(self, expparams):
+            return 2
+
+        def are_models_valid(self, modelparams):
+            return np.all(modelparams >= 0, axis=1)
+
+        def likelihood(self, outcomes, modelparams, expparams):
+            super().likelihood(outcomes, modelparams, expparams)
+            t = np.asarray(expparams['t'], dtype=float)[None, :]
+            e = np.exp(-t * modelparams[:, 1:2])
+            pr0 = e * np.cos(modelparams[:, 0:1] * t / 2) ** 2 + (1 - e) / 2
+            return qi.FiniteOutcomeModel.pr0_to_likelihood_array(outcomes, pr0)
+
+    class TorchT2(NumpyT2):
+        def likelihood_device(self, outcomes, x_dev, expparams):
+            self.count_likelihood_calls(len(outcomes), x_dev.shape[1], expparams.shape[0])
+            rows = []
+            for t in np.asarray(expparams['t'], dtype=float):
+                e = torch.exp(x_dev[1] * (-float(t)))
+                c = torch.cos(x_dev[0] * (float(t) / 2))
+                c.mul_(c).sub_(0.5).mul_(e).add_(0.5)              # pr0 = e (cos^2 - 1/2) + 1/2, in place
+                rows.append(c)
+            pr0 = torch.stack(rows)
+            return torch.stack([pr0 if int(o) == 0 else 1 - pr0 for o in outcomes])
+
+        def are_models_valid_device(self, x_dev):
+            return (x_dev >= 0).all(dim=0)
+    rs = np.random.RandomState(0)
+    ts = np.linspace(0.5, 14.0, n_data)
+    e = np.exp(-ts * 0.05)
+    outs = (rs.random_sample(n_data) >= e * np.cos(0.7 * ts / 2) ** 2 + (1 - e) / 2).astype(int)
+    eps = np.array([(t,) for t in ts], dtype=[('t', 'float')])
+    res = {"workload": "UnknownT2Model (omega, 1/T2), %.0e particles, %d data t = 0.5 .. 14, prior U[0, 1.5] x U[0, 0.2], "
+                       "Liu-West a = 0.98, device RNG; SMCUpdater.update per datum" % (n, n_data)}
+    for key, model, k_data in (("native", qi.UnknownT2Model(), n_data), ("torch_plugin", TorchT2(), n_data),
+                               ("numpy_plugin", NumpyT2(), 6)):
+        upd = qi.SMCUpdater(model, n, qi.UniformDistribution([[0.0, 1.5], [0.0, 0.2]]), device_rng=True, seed=0)
+        for k in range(min(k_data, 12)):                        # untimed: allocator, first launches (incl. one resample)
+            upd.update(int(outs[k]), eps[k:k + 1])
+        upd.resample()
+        upd.reset()
+        rc0 = upd.resample_count
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(k_data):
+            upd.update(int(outs[k]), eps[k:k + 1])
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        res[key] = {"ms_per_datum": wall / k_data * 1e3, "value": n * k_data / wall, "unit": "particle-updates/s",
+                    "data": k_data, "resamples": upd.resample_count - rc0,
+                    "posterior_mean": [float(v) for v in upd.est_mean()]}
+        del upd
+        torch.cuda.empty_cache()
+    res["torch_plugin"]["vs_native"] = res["torch_plugin"]["ms_per_datum"] / res["native"]["ms_per_datum"]
+    res["numpy_plugin"]["vs_native"] = res["numpy_plugin"]["ms_per_datum"] / res["native"]["ms_per_datum"]
+    res["note"] = ("torch_plugin: eight eager elementwise torch kernels per datum (each a pass over 80-240 MB) + the weight "
+                   "update pass, against ONE fused pass of 32 B per particle for the native kernel")
+    return res
 
 
 def beyond_l3(qi, eng, torch, n=100_000_000, steps=12):
@@ -555,12 +634,25 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    def reduce_max(w_):
+        """The slowest rank's wall time."""
+        if world == 1:
+            return float(w_)
+        wt_ = torch.tensor([w_], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
+        torch.distributed.all_reduce(wt_, op=torch.distributed.ReduceOp.MAX)
+        return float(wt_.item())
+
+    if args.only == "plugin_paths":    # (the plugin surface alone)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            print(json.dumps({"plugin_device_hook": plugin_paths(qi, eng, torch)}), flush=True)
+        return
     if args.only == "other_paths":     # (SURVEY 8(f) rows alone: profiling runs)
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             print(json.dumps({"other_paths": other_paths(qi, eng, torch)}), flush=True)
         return
-    if args.only:                      # one of the other configs alone (what the per-config rocprofv3 passes run)
+    if args.only and args.only not in ("shard_preview",):   # one of the other configs alone (what the per-config rocprofv3 passes run)
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             spec = next(s for s in other_config_specs(qi) if s["key"] == args.only)
@@ -620,32 +712,120 @@ def main():
 
     first_pass = []        # (resamples, kernel durations [ms], kernel tags, posterior mean) of each call's contract pass
 
-    def rccl_transport_pass():
-        """The same K steps once more with the library's own RCCL collective on the launch stream carrying the
-        per-datum reduction (north_star's transport; `value` is the pass with whatever ParticleShardGroup picked -- host
-        shared memory on one node).  Returns the `transports["rccl"]` entry; `ranks_in_comm` is what the communicator
-        itself reports (ncclCommCount)."""
+    def batch_pass(upd, interval):
+        """The same --steps data through `batch_update(resample_interval=interval)` (smc.py:459-487): the data between two
+        n_ess tests go through ONE pass over the cloud (k_update_multi) and -- on a sharded cloud -- ONE reduction per
+        window instead of one per datum.  One untimed rehearsal, reset, then the timed call between barriers.  Returns
+        (wall seconds of this rank, resamples, posterior mean)."""
+        import gc
+        idx = np.arange(args.steps) % N_SCHEDULE
+        chunks = [(outcomes[idx[i:i + N_SCHEDULE]], ts[idx[i:i + N_SCHEDULE]]) for i in range(0, args.steps, N_SCHEDULE)]
+
+        def go():
+            for j, (oc, tt) in enumerate(chunks):
+                if j:
+                    upd.reset()
+                upd.batch_update(oc, tt, resample_interval=interval)
+        gc.collect()
+        gc.disable()
+        try:
+            upd.reset()
+            go()
+            upd.reset()
+            upd._resample_count = 0
+            barrier()
+            t0 = time.perf_counter()
+            go()
+            barrier()
+            wall_b = time.perf_counter() - t0
+        finally:
+            gc.enable()
+        return wall_b, upd.resample_count, float(upd.est_mean()[0])
+
+    def batch_legs(upd, n_total_particles, reduce_max):
+        """`batch_update_interval_{5,8}` entries for an updater already warmed by a timed_pass."""
+        out = {}
+        for interval in (5, 8):
+            try:
+                wall_b, res_b, mean_b = batch_pass(upd, interval)
+                wall_b = reduce_max(wall_b)
+                out["batch_update_interval_%d" % interval] = {
+                    "value": n_total_particles * args.steps / wall_b, "unit": "particle-updates/s",
+                    "ms_per_datum": wall_b / args.steps * 1e3, "resamples": res_b, "posterior_mean": mean_b,
+                    "data": args.steps, "windows": -(-args.steps // interval)}
+            except Exception as e:  # noqa: BLE001
+                out["batch_update_interval_%d" % interval] = {"error": repr(e)}
+        return out
+
+    def other_transport_pass(transport):
+        """The same K steps once more under the OTHER transport of the per-datum reduction (`value` is the pass with
+        whatever ParticleShardGroup picked: `auto` measures the two at group creation when every rank has a GPU of its
+        own, else host shared memory on one node): "rccl" = the library's own RCCL collective on the launch stream
+        (north_star's transport), "shm" = host shared memory.  Returns the `transports[transport]` entry; under "rccl"
+        `ranks_in_comm` is what the communicator itself reports (ncclCommCount)."""
         try:
             from qinfer_amd.parallel import ParticleShardGroup
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore")
-                comm_r = ParticleShardGroup(transport="rccl")
+                comm_r = ParticleShardGroup(transport=transport)
                 upd_r = qi.SMCUpdater(qi.SimplePrecessionModel(), n, qi.UniformDistribution([0, 1]),
                                       device_rng=True, seed=0, comm=comm_r)
                 wall_r, _ = timed_pass(upd_r, events=False)
                 resamples_r, _, _, mean_r = first_pass[-1]
-                ranks_in_comm, rank_in_comm = comm_r.ranks_in_comm(eng)
-                wr = torch.tensor([wall_r], dtype=torch.float64, device="cuda")
-                if world > 1:
-                    torch.distributed.all_reduce(wr, op=torch.distributed.ReduceOp.MAX)
-                res = {"per_datum_collective": comm_r.transport_name, "ranks_in_comm": ranks_in_comm,
-                       "value": n * world * args.steps / float(wr.item()),
-                       "ms_per_step": float(wr.item()) / args.steps * 1e3, "resamples": resamples_r,
+                wall_r = reduce_max(wall_r)
+                res = {"per_datum_collective": comm_r.transport_name,
+                       "value": n * world * args.steps / wall_r,
+                       "ms_per_step": wall_r / args.steps * 1e3, "resamples": resamples_r,
                        "posterior_mean": mean_r}
+                if transport == "rccl":
+                    res["ranks_in_comm"] = comm_r.ranks_in_comm(eng)[0]
                 comm_r.close()
         except Exception as e:  # noqa: BLE001
             res = {"error": repr(e)}
         return res
+
+    def shard_preview(n_shard):
+        """The headline workload on ONE rank's share of a strong-scaling run (1e7 particles over 8 GPUs = 1.25e6 each):
+        what a GPU of the 8-GPU point does between two collectives, measured where it can be -- on one GPU, no
+        communication.  At this size a datum is launch / round-trip bound, not bandwidth bound."""
+        upd_p = qi.SMCUpdater(qi.SimplePrecessionModel(), n_shard, qi.UniformDistribution([0, 1]), device_rng=True, seed=0)
+        wall_p, _ = timed_pass(upd_p, events=False)
+        res_p, _, _, mean_p = first_pass[-1]
+        upd_p.reset()
+        eng.set_profiling(1)
+        for k in range(min(64, N_SCHEDULE)):
+            upd_p.update(int(outcomes[k]), ts[k:k + 1])
+        torch.cuda.synchronize()
+        p_ms, p_tags = eng.profile_read()
+        eng.set_profiling(False)
+        kt = kernel_table(p_ms, p_tags)
+        out = {"workload": "SimplePrecessionModel SMCUpdater.update, %.3g particles (one rank's share of 1e7 over 8 GPUs), "
+                           "same schedule and resampler as the headline, one GPU, no collective" % n_shard,
+               "particles": n_shard, "steps": args.steps, "value": n_shard * args.steps / wall_p,
+               "ms_per_step": wall_p / args.steps * 1e3, "resamples": res_p, "posterior_mean": mean_p,
+               "eight_of_these_without_a_collective": 8 * n_shard * args.steps / wall_p}
+        if "update" in kt:
+            out["update_kernel"] = frac_entry("k_update_fused<PRECESSION,VEC=2,ONES=false>", kt["update"]["avg_us"],
+                                              24.0 * n_shard, kt["update"]["launches"], {"bytes_per_particle": 24})
+        if "sample" in kt:
+            out["resample_kernel"] = frac_entry("k_bucket_sample<D=1,512>", kt["sample"]["avg_us"], 24.0 * n_shard,
+                                                kt["sample"]["launches"], {"bytes_per_particle": 24})
+        # the same data through batch_update: the path that amortises the per-datum fixed cost (launch + reduction + host
+        # round trip) over a window -- what bounds a shard of this size under update()
+        out.update(batch_legs(upd_p, n_shard, lambda w_: w_))
+        for k_ in ("batch_update_interval_5", "batch_update_interval_8"):
+            if "value" in out.get(k_, {}):
+                out[k_]["vs_update"] = out[k_]["value"] / out["value"]
+        del upd_p
+        torch.cuda.empty_cache()
+        return out
+
+    if args.only == "shard_preview":     # (the strong-scaling shard preview alone: tests / profiling runs)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            print(json.dumps({"strong_scaling_shard_preview": shard_preview(max(4096, int(args.strong_particles) // 8))}),
+                  flush=True)
+        return
 
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
@@ -656,6 +836,39 @@ def main():
         # pass) are read here, once
         eng.set_profiling(False)
         resamples_timed, all_ms, tags, posterior_mean = first_pass[0]
+        # C2's own schedule (k = 0..199, 70 resamples) whatever --steps says: the driver's 20-step command sees
+        # 3 resamples in 20 data (15 %), the full schedule 35 % -- both figures in the line
+        headline_200 = None
+        if args.steps != N_SCHEDULE and not os.environ.get("QSMC_BENCH_NO_EVENTS"):
+            try:
+                import gc
+                gc.collect()
+                gc.disable()
+                try:
+                    def pass_200():
+                        upd.reset()
+                        upd._resample_count = 0
+                        barrier()
+                        t0 = time.perf_counter()
+                        for k in range(N_SCHEDULE):
+                            upd.update(int(outcomes[k]), ts[k:k + 1])
+                        barrier()
+                        return time.perf_counter() - t0
+                    pass_200()                               # (rehearsal: later resamples' first launches, allocator)
+                    w200 = pass_200()
+                finally:
+                    gc.enable()
+                w200_t = torch.tensor([w200], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
+                if world > 1:
+                    torch.distributed.all_reduce(w200_t, op=torch.distributed.ReduceOp.MAX)
+                w200 = float(w200_t.item())
+                headline_200 = {"value": n * world * N_SCHEDULE / w200, "unit": "particle-updates/s",
+                                "ms_per_step": w200 / N_SCHEDULE * 1e3, "steps": N_SCHEDULE,
+                                "resamples": upd.resample_count, "posterior_mean": float(upd.est_mean()[0]),
+                                "what": "the headline workload over its whole schedule (t_k = (9/8)^k, k = 0..199), same "
+                                        "updater, right after the contract's timed region; no kernel events"}
+            except Exception as e:  # noqa: BLE001
+                headline_200 = {"error": repr(e)}
         # tag 0: update with explicit weights (24 B/particle), 2: first update after a reset/resample, weights
         # implicit (16 B/particle), 1: the resampler's sampling kernel, 6: its counts/plan launch
         full_ms, ones_ms, sampler_ms = all_ms[tags == 0], all_ms[tags == 2], all_ms[tags == 1]
@@ -690,36 +903,6 @@ def main():
     wall = float(wall_t.item())
     del upd
     torch.cuda.empty_cache()
-
-    def shard_preview(n_shard):
-        """The headline workload on ONE rank's share of a strong-scaling run (1e7 particles over 8 GPUs = 1.25e6 each):
-        what a GPU of the 8-GPU point does between two collectives, measured where it can be -- on one GPU, no
-        communication.  At this size a datum is launch / round-trip bound, not bandwidth bound."""
-        upd_p = qi.SMCUpdater(qi.SimplePrecessionModel(), n_shard, qi.UniformDistribution([0, 1]), device_rng=True, seed=0)
-        wall_p, _ = timed_pass(upd_p, events=False)
-        res_p, _, _, mean_p = first_pass[-1]
-        upd_p.reset()
-        eng.set_profiling(1)
-        for k in range(min(64, N_SCHEDULE)):
-            upd_p.update(int(outcomes[k]), ts[k:k + 1])
-        torch.cuda.synchronize()
-        p_ms, p_tags = eng.profile_read()
-        eng.set_profiling(False)
-        kt = kernel_table(p_ms, p_tags)
-        out = {"workload": "SimplePrecessionModel SMCUpdater.update, %.3g particles (one rank's share of 1e7 over 8 GPUs), "
-                           "same schedule and resampler as the headline, one GPU, no collective" % n_shard,
-               "particles": n_shard, "steps": args.steps, "value": n_shard * args.steps / wall_p,
-               "ms_per_step": wall_p / args.steps * 1e3, "resamples": res_p, "posterior_mean": mean_p,
-               "eight_of_these_without_a_collective": 8 * n_shard * args.steps / wall_p}
-        if "update" in kt:
-            out["update_kernel"] = frac_entry("k_update_fused<PRECESSION,VEC=2,ONES=false>", kt["update"]["avg_us"],
-                                              24.0 * n_shard, kt["update"]["launches"], {"bytes_per_particle": 24})
-        if "sample" in kt:
-            out["resample_kernel"] = frac_entry("k_bucket_sample<D=1,512>", kt["sample"]["avg_us"], 24.0 * n_shard,
-                                                kt["sample"]["launches"], {"bytes_per_particle": 24})
-        del upd_p
-        torch.cuda.empty_cache()
-        return out
 
     extras = {}
     if rank == 0 and world == 1 and comm is None and not args.no_other_configs:
@@ -825,6 +1008,7 @@ def main():
                                              "the HBM-only figure",
                          "implicit_uniform_weight_variant": ones_info},
             "posterior_mean": posterior_mean,
+            "headline_200_steps": headline_200,
             # the same K steps twice more right after the contract's pass (no kernel events): a record of how far one 3 ms
             # region can sit from the next on this box -- never used for `value`
             "repeat_passes_ms_per_step": [w / args.steps * 1e3 for w in repeat_walls],
@@ -893,9 +1077,16 @@ def main():
                                          "ms_per_step": None if line is None else line["ms_per_step"],
                                          "resamples": resamples_timed, "posterior_mean": posterior_mean, "headline": True}})
         set_line(("config", "headline_transport"), key)       # which transport `value` was measured under
+        # transport="auto" measures both transports at group creation when every rank has a GPU of its own
+        # (ParticleShardGroup._probe_transports): both timings and the choice, or why nothing was measured
+        set_line(("config", "transport_probe"), comm.transport_probe if comm.transport_probe is not None else {
+            "skipped": "not measured: %s" % ("QSMC_BENCH_SHARE_GPU=1 (one device, gloo)" if share_gpu else
+                                             "one rank" if world == 1 else "transport forced or no shared host")})
         want_sharded = not args.no_other_configs
         want_strong = (world > 1 or args.force_comm) and not os.environ.get("QSMC_BENCH_NO_STRONG")
-        want_rccl = ((world > 1 or os.environ.get("QSMC_BENCH_FORCE_RCCL_PASS")) and comm.transport != "rccl"
+        # the transport `value` was NOT measured under gets a pass of its own ("rccl" unless auto / QSMC_TRANSPORT picked it)
+        other = "shm" if key == "rccl" else "rccl"
+        want_rccl = ((world > 1 or os.environ.get("QSMC_BENCH_FORCE_RCCL_PASS"))
                      and not os.environ.get("QSMC_BENCH_NO_RCCL_PASS"))
         # everything after the headline (the strong-scaling leg, the sharded configs 4 and 5, the RCCL pass) runs under a
         # watchdog: a rank that hangs or a collective that never returns must not take the line with it.  Past the
@@ -916,13 +1107,13 @@ def main():
                 if name == "strong_scaling":
                     line["strong_scaling"] = msg
                 elif name == "strong_scaling_rccl":
-                    line["strong_scaling"].setdefault("transports", {})["rccl"] = msg
+                    line["strong_scaling"].setdefault("transports", {})[other] = msg
                 elif name == "sharded_configs":
                     line["sharded_configs"] = msg
                 elif name == "sharded_configs_rccl":
                     line["sharded_configs"]["rccl_transport"] = msg
                 else:
-                    line["transports"]["rccl"] = msg
+                    line["transports"][other] = msg
 
         def give_up():
             mark_stage({"error": "no result within %.0f s of the headline (watchdog), stage: %s" % (deadline, stage["name"])})
@@ -971,15 +1162,18 @@ def main():
                     rb0 = grp.n_rebalances
                     wall_s, _ = timed_pass(upd_s, events=False)
                     resamples_s, _, _, mean_s = first_pass[-1]
-                    ws = torch.tensor([wall_s], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
-                    if world > 1:
-                        torch.distributed.all_reduce(ws, op=torch.distributed.ReduceOp.MAX)
-                    wall_s = float(ws.item())
+                    wall_s = reduce_max(wall_s)
                     res = {"per_datum_collective": grp.transport_name, "value": n_strong * world * args.steps / wall_s,
                            "ms_per_step": wall_s / args.steps * 1e3, "resamples": resamples_s,
                            "rebalances": grp.n_rebalances - rb0, "posterior_mean": mean_s}
-                    if transport == "rccl":
+                    if grp.transport == "rccl":
                         res["ranks_in_comm"] = grp.ranks_in_comm(eng)[0]
+                    # the same data through batch_update windows: one pass over the shard and ONE reduction per window --
+                    # what amortises the per-datum fixed cost that bounds a 1e7 / world shard under update()
+                    res.update(batch_legs(upd_s, n_strong * world, reduce_max))
+                    for k_ in ("batch_update_interval_5", "batch_update_interval_8"):
+                        if "value" in res.get(k_, {}):
+                            res[k_]["vs_update"] = res[k_]["value"] / res["value"]
                     del upd_s
                     grp.close()
             except Exception as e:  # noqa: BLE001
@@ -987,7 +1181,7 @@ def main():
             return res
 
         if want_strong:
-            leg = strong_leg(None)
+            leg = strong_leg(key if key in ("shm", "rccl") else None)      # (the headline's transport, not a second probe)
             set_line(("strong_scaling",), {
                 "scaling": "strong", "metric": "particle-updates/sec",
                 "workload": "SimplePrecessionModel SMCUpdater.update, %.3g particles IN TOTAL over %d rank(s) (%.3g per "
@@ -996,6 +1190,8 @@ def main():
                 "particles_total": n_strong * world, "particles_per_rank": n_strong, "ranks": world, "steps": args.steps,
                 "warmup": args.warmup, "value": leg.get("value"), "ms_per_step": leg.get("ms_per_step"),
                 "value_transport": key,
+                "batch_update_interval_5": leg.get("batch_update_interval_5"),
+                "batch_update_interval_8": leg.get("batch_update_interval_8"),
                 "transports": {key: leg}})
         sharded = None
         if want_sharded:
@@ -1010,14 +1206,14 @@ def main():
             if want_strong and rank == 0 and isinstance(line.get("strong_scaling"), dict) and "transports" in line["strong_scaling"]:
                 set_line(("strong_scaling", "transports", "rccl"), skipped)
         elif want_rccl:
-            res = rccl_transport_pass()
-            set_line(("transports", "rccl"), res)
+            res = other_transport_pass(other)
+            set_line(("transports", other), res)
             if want_strong and "error" not in res:
                 stage["name"] = "strong_scaling_rccl"
-                leg_r = strong_leg("rccl")
+                leg_r = strong_leg(other)
                 if rank == 0 and isinstance(line.get("strong_scaling"), dict) and "transports" in line["strong_scaling"]:
-                    set_line(("strong_scaling", "transports", "rccl"), leg_r)
-            if sharded is not None and "error" not in res:
+                    set_line(("strong_scaling", "transports", other), leg_r)
+            if sharded is not None and "error" not in res and other == "rccl":
                 # configs 4 and 5 once more with the RCCL collective carrying the per-datum reduction
                 stage["name"] = "sharded_configs_rccl"
                 try:

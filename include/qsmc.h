@@ -38,7 +38,8 @@ enum qsmc_status {
     QSMC_ERR_INVALID = -1,       /* bad argument (null pointer, d out of range, unknown model kind) */
     QSMC_ERR_HIP = -2,           /* a HIP runtime call failed; see qsmc_last_hip_error */
     QSMC_ERR_ALLOC = -3,
-    QSMC_ERR_UNSUPPORTED = -4
+    QSMC_ERR_UNSUPPORTED = -4,
+    QSMC_ERR_TIMEOUT = -5        /* a peer of a host collective (qsmc_host_allgather / _allreduce) did not arrive in time */
 };
 
 /* Model kinds with a native likelihood kernel. */
@@ -85,8 +86,26 @@ typedef struct qsmc_update_stats {
 int         qsmc_abi_version(void);
 const char *qsmc_strerror(int status);
 const char *qsmc_last_hip_error(qsmc_handle_t h);
+/* A handle owns scratch, the pinned completion word and the arrival tickets of its reducing kernels: it is bound to ONE
+ * stream at a time.  Calls on a handle must come from one host thread at a time and their `stream` arguments must be
+ * the same stream until that stream has been synchronised (launches of one stream are serialised; two streams sharing a
+ * handle would interleave ticket arrivals and scratch use).  Use one handle per stream. */
 int         qsmc_create(qsmc_handle_t *out, int device);
 int         qsmc_destroy(qsmc_handle_t h);
+/* Test hooks (process-wide, all off by default): each selects an independent form of a kernel that the parity tests
+ * compare the default form against, or makes a rare branch common; none changes a result's law.
+ *   QSMC_HOOK_MULTI_GENERIC    value != 0: k_update_multi sends every tile through its general path
+ *   QSMC_HOOK_REDRAW_NO_SMALL  value != 0: the redraw kernel takes the global-CDF form also for short queues
+ *   QSMC_HOOK_HYP_NO_CHAIN     value != 0: design passes of binomial experiments by the thread-per-particle kernel
+ *   QSMC_HOOK_TOMO_DENSE       value != 0: tomography updates read all d rows also for sparse measurement vectors
+ *   QSMC_HOOK_POISSON_MARGIN   value = kappa in lambda = n_out - kappa sqrt(n_out) of the bucketed counts (default 5)
+ * Returns QSMC_ERR_INVALID for an unknown hook. */
+#define QSMC_HOOK_MULTI_GENERIC 1
+#define QSMC_HOOK_REDRAW_NO_SMALL 2
+#define QSMC_HOOK_HYP_NO_CHAIN 3
+#define QSMC_HOOK_TOMO_DENSE 4
+#define QSMC_HOOK_POISSON_MARGIN 5
+int         qsmc_test_hook(int32_t hook, double value);
 /* Compute units this process can actually run on (a census taken by qsmc_create: under HSA_CU_MASK or a partitioned
  * part fewer than the device attribute reports) and the reported number.  The resampler's grid-barrier kernels
  * (k_bucket_counts, k_bucket_redraw) size their resident grids by the first. */
@@ -347,7 +366,7 @@ int qsmc_shard_plan_totals(uint64_t seed, uint64_t epoch, const double *shard_we
  * every rank has published k, and copies the rank-ordered rows to rows_out[world][n].  No GPU involved: this
  * is the per-datum collective of the sharded updater (a handful of sums per rank), which is pure latency;
  * it stands where the reference gathers the whole likelihood array from its engines (parallel.py:216-224).
- * Returns QSMC_ERR_UNSUPPORTED if a peer has not arrived within timeout_s. */
+ * Returns QSMC_ERR_TIMEOUT if a peer has not arrived within timeout_s. */
 int qsmc_host_allgather(void *segment, int32_t rank, int32_t world, int32_t max_len, uint64_t k, const double *vec,
                         int32_t n, double *rows_out, double timeout_s);
 

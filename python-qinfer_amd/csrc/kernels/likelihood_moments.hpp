@@ -169,56 +169,12 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_sum_partials(const double *__res
     }
 }
 
-// k_sum_partials + the publish to pinned host memory in ONE launch (the d = 16 moments of a resample queued by qsmc_step:
-// the host waits for them before it can form S): every workgroup writes its sums to device AND pinned memory, fences at
-// system scope and draws a ticket; the last one sets the completion word.  (Two launches before: 7.3 + 4.7 us, of which
-// the second was a 273-double copy.)  The ticket word resets itself.
-__global__ __launch_bounds__(QSMC_BLOCK) void k_sum_partials_publish(const double *__restrict__ partials, int nblocks, int K,
-                                                                     double *__restrict__ out, double *__restrict__ mapped,
-                                                                     unsigned long long *flag, unsigned long long seq,
-                                                                     unsigned int *ticket) {
-    const int lane = threadIdx.x & (QSMC_WAVE - 1);
-    const int wave = threadIdx.x / QSMC_WAVE;
-    for (int k = blockIdx.x * QSMC_WAVES_PER_BLOCK + wave; k < K; k += gridDim.x * QSMC_WAVES_PER_BLOCK) {
-        double s = 0.0;
-        for (int g = lane; g < nblocks; g += QSMC_WAVE) s += partials[(size_t)g * K + k];
-        s = wave_sum(s);
-        if (lane == 0) {
-            out[k] = s;
-            mapped[k] = s;
-            __threadfence_system();                          // (the writing lane only: a system-scope fence in every thread of
-        }                                                    //  69 workgroups made this kernel 14 us -- slower than the two it replaced)
-    }
-    __syncthreads();                                         // this workgroup's pinned-memory stores are out before its ticket
-    if (threadIdx.x == 0) {
-        // (relaxed: an agent-scope RELEASE here writes back the XCD's whole L2 -- measured: the merged kernel at 14.5 us against
-        //  7.0 + 4.7 for the two it replaced; what must be ordered before the ticket is in pinned memory and already fenced)
-        const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (t == gridDim.x - 1u) {
-            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __threadfence_system();
-            *reinterpret_cast<volatile unsigned long long *>(flag) = seq;
-        }
-    }
-}
-
-// out[k] = sum_g partials[k * nblocks + g] (column-major rows of block_publish): a wave per column, lanes stride over the
-// rows (coalesced), fixed shuffle tree -> deterministic.  For the wide reductions (129 columns x 2048 rows) that one
-// workgroup (k_reduce_partials) took 269 us over.
-__global__ __launch_bounds__(QSMC_BLOCK) void k_sum_columns(const double *__restrict__ partials, int nblocks, int K,
-                                                            double *__restrict__ out) {
-    const int lane = threadIdx.x & (QSMC_WAVE - 1);
-    const int wave = threadIdx.x / QSMC_WAVE;
-    for (int k = blockIdx.x * QSMC_WAVES_PER_BLOCK + wave; k < K; k += gridDim.x * QSMC_WAVES_PER_BLOCK) {
-        double s = 0.0;
-        for (int g = lane; g < nblocks; g += QSMC_WAVE) s += partials[(size_t)k * nblocks + g];
-        s = wave_sum(s);
-        if (lane == 0) out[k] = s;
-    }
-}
-
-// k_sum_columns + the publish of its K sums to pinned host memory (mapped[0 .. K)) in one launch, as k_sum_partials_publish:
-// the design kernel's passes (qsmc_hypothetical_sums_*: one such launch per pass, each publishing to its own slot).
+// mapped[k] = sum_g partials[k * nblocks + g] (column-major rows of block_publish) for k < K, in pinned host memory, and the
+// completion word behind them, in one launch: a wave per column, lanes stride over the rows (coalesced), fixed shuffle tree
+// -> deterministic; every workgroup fences its pinned stores at system scope and draws a ticket, the last one sets the
+// word (the ticket resets itself).  The design kernel's passes (qsmc_hypothetical_sums_*: one such launch per pass, each
+// publishing to its own slot).  A handle is bound to ONE stream at a time (include/qsmc.h): the single ticket word relies
+// on launches from that stream being serialised.
 __global__ __launch_bounds__(QSMC_BLOCK) void k_sum_columns_publish(const double *__restrict__ partials, int nblocks, int K,
                                                                     double *__restrict__ mapped, unsigned long long *flag,
                                                                     unsigned long long seq, unsigned int *ticket) {
@@ -230,7 +186,7 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_sum_columns_publish(const double
         s = wave_sum(s);
         if (lane == 0) {
             mapped[k] = s;
-            __threadfence_system();                          // (the writing lane only: see k_sum_partials_publish)
+            __threadfence_system();                          // (the writing lane only: a fence in every thread cost 7 us)
         }
     }
     __syncthreads();

@@ -817,108 +817,8 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_hyp_sums(const double *__restric
 }
 
 // ---------------------------------------------------------------------------------------------
-// The same sums for a binomial experiment with MANY outcomes (n_meas + 1 of them: 26 at n_meas = 25), one LANE per
-// outcome.  k_hyp_sums gives a thread one particle and all outcomes: 26 pmfs and 26 x (2 + 2 D) running sums per
-// thread -- 256 VGPRs at 32 outcomes a pass (one wave per SIMD, spills), still 183 at 8 a pass (round 3: 0.45 ms
-// per pass of 8, 1.8 ms per experiment at N = 1e7).  Here a wave takes 64 particles: lane l first prepares particle l
-// (the likelihood's outcome-independent part: pr1 and its two logarithms; the weight; the shifted coordinates) and
-// parks it in LDS; then lane l stands for outcome l & 31 and walks the 32 particles of its half of the tile (LDS
-// broadcast reads), forming  pmf = exp(ln C + k ln p + (n - k) ln(1 - p))  -- one exponential, k and ln C per lane --
-// and adding to ITS 2 + 2 D sums.  Per (particle, outcome) ~40 instructions and no register pressure.
-// Sums come out in k_hyp_sums' layout ([o][2 + 2 D], 32 outcomes), through the same reducing kernel.
-// ---------------------------------------------------------------------------------------------
-template <int KIND>
-__global__ __launch_bounds__(QSMC_BLOCK) void k_hyp_sums_lanes(const double *__restrict__ x, int64_t ldx, int64_t n,
-                                                               const double *__restrict__ w, double norm,
-                                                               HypArgs<32> ha, ReduceOut ro) {
-    constexpr int D = Model<KIND>::D <= 4 ? Model<KIND>::D : 0;
-    constexpr int DD = Model<KIND>::D;
-    constexpr int PER = 2 + 2 * D;
-    constexpr int NS = 32 * PER;
-    constexpr int REC = 4 + D;                                    // per particle: w, lp, lq, (valid), c1[D]
-    __shared__ double rec[QSMC_WAVES_PER_BLOCK][QSMC_WAVE][REC];
-    __shared__ double comb_l[QSMC_WAVES_PER_BLOCK][PER * 32];
-    const int lane = threadIdx.x & (QSMC_WAVE - 1), wave = threadIdx.x / QSMC_WAVE;
-    const int o = lane & 31, half = lane >> 5;
-    const bool live_o = o < ha.n_o;
-    const double k_o = live_o ? (double)ha.outcome[o] : 0.0, lc_o = live_o ? ha.log_comb[o] : 0.0;
-    const double nk_o = ha.base.n_meas - k_o;
-    const bool in_range = live_o && ha.outcome[o] >= 0 && k_o <= ha.base.n_meas;
-    double s[PER];
-#pragma unroll
-    for (int q = 0; q < PER; ++q) s[q] = 0.0;
-    const int64_t tiles = (n + QSMC_WAVE - 1) / QSMC_WAVE;
-    for (int64_t tile = (int64_t)blockIdx.x * QSMC_WAVES_PER_BLOCK + wave; tile < tiles;
-         tile += (int64_t)gridDim.x * QSMC_WAVES_PER_BLOCK) {
-        const int64_t i = tile * QSMC_WAVE + lane;
-        double wi = 0.0, lp = 0.0, lq = 0.0, ok = 0.0, c1[D > 0 ? D : 1];
-#pragma unroll
-        for (int m = 0; m < D; ++m) c1[m] = 0.0;
-        if (i < n) {
-            double p[DD];
-#pragma unroll
-            for (int m = 0; m < DD; ++m) p[m] = x[m * ldx + i];
-            HypPre<KIND> pre;
-            pre.prepare(p, ha.base);
-            wi = (w ? w[i] : 1.0) / norm;
-            lp = pre.lp;
-            lq = pre.lq;
-            // pr1 outside [0, 1] (an invalid particle): the pmf is NaN, as SciPy's; exactly 0 or 1: the logs are 0 and the
-            // pmf is 1 only for the outcome that needs no factor of the vanishing probability
-            ok = (pre.pr1 >= 0.0 && pre.pr1 <= 1.0) ? (pre.pr1 == 0.0 ? 2.0 : (pre.pr1 == 1.0 ? 3.0 : 1.0)) : 0.0;
-#pragma unroll
-            for (int m = 0; m < D; ++m) c1[m] = p[m] - ha.shift[m];
-        }
-        double *mine = rec[wave][lane];
-        mine[0] = wi; mine[1] = lp; mine[2] = lq; mine[3] = ok;
-#pragma unroll
-        for (int m = 0; m < D; ++m) mine[4 + m] = c1[m];
-        __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
-        if (in_range) {
-#pragma unroll 4
-            for (int pp = 0; pp < 32; ++pp) {
-                const double *r = rec[wave][half * 32 + pp];
-                const double rw = r[0], okf = r[3];
-                double L;
-                if (okf == 1.0) L = fast_exp(lc_o + (k_o * r[1] + nk_o * r[2]));
-                else if (okf == 2.0) L = k_o == 0.0 ? 1.0 : 0.0;                    // pr1 == 0
-                else if (okf == 3.0) L = nk_o == 0.0 ? 1.0 : 0.0;                   // pr1 == 1
-                else L = rw == 0.0 ? 0.0 : NAN;                                     // (padding lanes carry weight 0)
-                const double logL = lc_o + (k_o * r[1] + nk_o * r[2]);
-                const double wl = rw * L;
-                s[0] += wl;
-                s[1] += (L > 0.0) ? wl * logL : 0.0;
-#pragma unroll
-                for (int m = 0; m < D; ++m) {
-                    s[2 + m] += wl * r[4 + m];
-                    s[2 + D + m] += wl * r[4 + m] * r[4 + m];
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-    // the two halves of a wave hold partial sums of the same outcomes; then the four waves; one row per workgroup
-#pragma unroll
-    for (int q = 0; q < PER; ++q) s[q] += __shfl_xor(s[q], 32, QSMC_WAVE);
-    if (half == 0) {
-#pragma unroll
-        for (int q = 0; q < PER; ++q) comb_l[wave][o * PER + q] = s[q];
-    }
-    __syncthreads();
-    for (int k = threadIdx.x; k <= NS; k += QSMC_BLOCK) {
-        double t = 0.0;
-        if (k < NS) {
-#pragma unroll
-            for (int wv = 0; wv < QSMC_WAVES_PER_BLOCK; ++wv) t += comb_l[wv][k];
-        }
-        ro.partials[(size_t)k * gridDim.x + blockIdx.x] = t;          // (entry NS: the unused minimum slot)
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // Round 4: binomial experiments, consecutive outcomes k_first, k_first + 1, ... -- the sums above with the pmfs of a pass
-// WALKED instead of one exponential per (particle, outcome).  k_hyp_sums_lanes is VALU-bound on fast_exp (SQ counters:
+// WALKED instead of one exponential per (particle, outcome).  The lane-per-outcome kernel of round 3 (k_hyp_sums_lanes, removed in round 6) was VALU-bound on fast_exp (SQ counters:
 // profiles/r4_*_paths_sq_counters.json): 32 outcome slots x ~46 fp64 instructions per particle.  The pmfs of consecutive
 // outcomes obey  pmf(k + 1) = pmf(k) [(n - k) / (k + 1)] [p / (1 - p)]  -- along the OUTCOME axis, which the lane-per-
 // outcome layout spreads over lanes; here a lane owns a particle (as in k_hyp_sums) and walks the outcomes of a pass.

@@ -26,7 +26,6 @@
 #include <dlfcn.h>
 
 #include <rccl/rccl.h>              // types and prototypes only: the entry points are bound with dlsym (qsmc_comm_init)
-#include <rocprim/rocprim.hpp>      // device radix sort for the posterior read-outs (a plain library op)
 
 #include "qsmc_device.h"
 
@@ -61,10 +60,10 @@ struct qsmc_ctx {
     unsigned long long *gbar;      // device: [0] arrival counter of the count kernel's barriers (only ever grows), [1] its
                                    // timeouts; [2], [3] arrivals / departures of the redraw kernel's self-resetting barrier
     unsigned long long gbar_base;  // host shadow: arrivals handed out so far
-    unsigned int *tickets;         // device: arrival word of k_sum_partials_publish (self-resetting)
+    unsigned int *tickets;         // device: arrival word of k_sum_columns_publish (self-resetting)
     int cu_count;                  // compute units this process can run on (bounds the resident grids of the barrier kernels)
     int cu_reported;               // what the device attribute says
-    void *sort_tmp;                // rocPRIM temporary storage + key/value staging for qsmc_argsort
+    void *sort_tmp;                // qsmc_argsort: the temporary (key image, index) pair + digit histograms (kernels/sort.hpp)
     size_t sort_tmp_cap;           // in bytes
     double *tile_sums;             // sum of w' per update-kernel tile, written by the last qsmc_update_fused
     size_t tile_sums_cap;
@@ -170,8 +169,16 @@ struct qsmc_ctx {
     } while (0)
 
 constexpr int REDUCE_OUT_MAX = 192;
-constexpr int TICKET_WORDS = 16;                    // arrival words (k_sum_partials_publish uses the last one)
+constexpr int TICKET_WORDS = 16;                    // arrival words (k_sum_columns_publish uses the last one)
 constexpr int QSMC_PROF_CAP = 4096;
+
+// Test hooks (qsmc_test_hook; process-wide, all off by default).  Each selects an independent form of a kernel that the
+// parity tests compare the default form against, or makes a rare branch common; none changes a result's law.
+static bool g_multi_generic = false;      // k_update_multi: every tile through the general path
+static bool g_redraw_no_small = false;    // k_bucket_redraw: the global-CDF form also for short queues
+static bool g_hyp_no_chain = false;       // design passes of binomial experiments: thread-per-particle k_hyp_sums, not the walk
+static bool g_tomo_dense = false;         // tomography updates read all d rows also for sparse measurement vectors
+static double g_poisson_margin = 5.0;     // kappa in lambda = n_out - kappa sqrt(n_out) of k_bucket_counts
 
 // Census of the compute units this process can actually run on.  hipDeviceAttributeMultiprocessorCount reports the
 // device's CUs; under a CU mask (HSA_CU_MASK / ROC_GLOBAL_CU_MASK) or other restrictions fewer are usable, and the
@@ -301,6 +308,7 @@ static inline bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; 
 #include "kernels/scan.hpp"
 #include "kernels/resample.hpp"
 #include "kernels/walk_tomo.hpp"
+#include "kernels/sort.hpp"
 
 // out[0..K) (device) -> pinned host block, then the completion word: the d > 4 moments of a resample queued by qsmc_step
 __global__ void k_publish_big(const double *__restrict__ src, int K, double *__restrict__ mapped, unsigned long long *flag,
@@ -478,8 +486,7 @@ static void launch_update(qsmc_ctx *h, bool vec2, int grid, hipStream_t s, const
     prof_events(h, w_in ? QSMC_PROF_UPDATE : QSMC_PROF_UPDATE_ONES, &e0, &e1);
     // streaming (non-temporal) hints once the pass no longer fits the 256 MB Infinity Cache: measured at N = 3e7 / 1e8
     // (d = 1) 128 -> 121 us / 455 -> 420 us; inside the cache they cost ~4 % (41.0 -> 42.5 us at N = 1e7), so not there
-    static const bool no_nt = getenv("QSMC_NO_NT") != nullptr;                    // (A/B switch)
-    const int nt = (!no_nt && (double)n * (double)(16 + 8 * e.d) > 3.0e8) ? 1 : 0;
+    const int nt = ((double)n * (double)(16 + 8 * e.d) > 3.0e8) ? 1 : 0;
 #define LU(V, O)                                                                                          \
     do {                                                                                                  \
         if (e.lik_pow != 0.0)                                                                             \
@@ -543,52 +550,6 @@ static int hyp_launch(qsmc_ctx *h, const qsmc_model_t *model, const double *x, i
     rc = wait_reduction(h, s);
     if (rc) return rc;
     memcpy(out_host, h->mapped, (size_t)n_o * PER * sizeof(double));
-    return QSMC_OK;
-}
-
-// binomial models, many outcomes: one lane per outcome (k_hyp_sums_lanes), up to 32 outcomes a pass
-template <int KIND>
-static int hyp_launch_lanes(qsmc_ctx *h, const qsmc_model_t *model, const double *x, int64_t ldx, int64_t n,
-                            const double *w, double norm, const qsmc_expparam_t *exp, const int64_t *outcomes, int n_o,
-                            const double *shift, double *out_host, hipStream_t s) {
-    constexpr int D = Model<KIND>::D <= 4 ? Model<KIND>::D : 0;
-    constexpr int PER = 2 + 2 * D;
-    constexpr int NS = 32 * PER;
-    static_assert(NS <= 512, "the pinned block of the wide sums holds 512 doubles");
-    const int grid = grid_for(n, QSMC_BLOCK * 4);
-    int rc = ensure_partials(h, (size_t)grid * (NS + 1));
-    if (rc) return rc;
-    rc = ensure_scratch(h, 256 + 512);
-    if (rc) return rc;
-    HypArgs<32> ha;
-    memset(&ha, 0, sizeof(ha));
-    ha.n_o = n_o;
-    make_exp_args(model, exp, outcomes[0], &ha.base);
-    for (int o = 0; o < n_o; ++o) {
-        ExpArgs tmp;
-        make_exp_args(model, exp, outcomes[o], &tmp);
-        ha.comb[o] = tmp.comb;
-        ha.log_comb[o] = tmp.log_comb;
-        ha.outcome[o] = outcomes[o];
-    }
-    if (shift) for (int m = 0; m < model->d && m < QSMC_MAX_D; ++m) ha.shift[m] = shift[m];
-    ReduceOut ro;
-    memset(&ro, 0, sizeof(ro));
-    ro.partials = h->partials;
-    hipEvent_t he0 = nullptr, he1 = nullptr;
-    prof_events(h, QSMC_PROF_HYP_SUMS, &he0, &he1);
-    hipExtLaunchKernelGGL((k_hyp_sums_lanes<KIND>), dim3(grid), dim3(QSMC_BLOCK), 0, s, he0, he1, 0, x, ldx, n, w, norm, ha, ro);
-    // 129 columns x 2048 rows of partials: a wave per column (k_sum_columns), then one workgroup publishes the totals
-    // behind the completion word -- the one-workgroup reduction of the narrow sums (k_reduce_partials) took 269 us here
-    double *full = h->scratch + 256;
-    hipLaunchKernelGGL(k_sum_columns, dim3((NS + QSMC_WAVES_PER_BLOCK - 1) / QSMC_WAVES_PER_BLOCK), dim3(QSMC_BLOCK), 0, s,
-                       h->partials, grid, NS, full);
-    const unsigned long long seq = ++h->seq;
-    hipLaunchKernelGGL(k_publish_big, dim3(1), dim3(QSMC_BLOCK), 0, s, full, NS, h->mapped_big_dev, h->flag_dev, seq);
-    HIP_TRY(h, hipGetLastError());
-    rc = wait_reduction(h, s);
-    if (rc) return rc;
-    memcpy(out_host, h->mapped_big, (size_t)n_o * PER * sizeof(double));
     return QSMC_OK;
 }
 
@@ -708,11 +669,13 @@ struct Chain2Queue {
 static int chain2_flush(qsmc_ctx *h, Chain2Queue &q, hipStream_t s) {
     if (q.count == 0) return QSMC_OK;
     const int rc = wait_reduction(h, s);               // (the last pass queued holds h->seq)
-    if (rc) return rc;
-    for (int i = 0; i < q.count; ++i) chain2_collect(h, q.pend[i]);
+    // (the queue lives on the handle: also on the error path nothing may stay in it -- its entries hold the CALLER's row
+    //  pointers, which a caller that got an error back is free to release)
+    if (rc == QSMC_OK)
+        for (int i = 0; i < q.count; ++i) chain2_collect(h, q.pend[i]);
     q.count = 0;
     q.off = 0;
-    return QSMC_OK;
+    return rc;
 }
 
 template <int KIND, int WHAT, int NH>
@@ -738,22 +701,16 @@ template <int KIND>
 static int hyp_dispatch(qsmc_ctx *h, Chain2Queue &q, const qsmc_model_t *model, const double *x, int64_t ldx, int64_t n,
                         const double *w, double norm, const qsmc_expparam_t *exp, const int64_t *outcomes,
                         int n_o, const double *shift, double *out_host, hipStream_t s, int what) {
-    // outcome lists longer than 32 (binomial with n_meas > 31) are processed in groups
+    // Outcome lists that are not a binomial experiment's consecutive domain go through the thread-per-particle kernel
+    // (k_hyp_sums) in groups of eight: a pass re-reads x and w (16 + 8 d bytes per particle) and the running sums (PER per
+    // outcome) live in registers.  (Rounds 3-5 also kept a 32-outcome form of it and a lane-per-outcome kernel; both lost to
+    // the two-ended walk on every binomial design and were removed in round 6.)
     constexpr int D = Model<KIND>::D <= 4 ? Model<KIND>::D : 0;
     constexpr int PER = 2 + 2 * D;
-    constexpr bool WIDE = PER * 32 <= 128;      // 32-outcome instantiation only where it fits in registers
-    // how many outcomes per pass?  A pass re-reads x and w (16 + 8 d bytes per particle: ~30 us at N = 1e7) and repeats
-    // what the outcomes share; the running sums (PER per outcome) live in registers: 32 outcomes x 4 sums = 256 VGPRs,
-    // one wave per SIMD.  QSMC_HYP_OUTCOMES_PER_PASS = 8 | 32 (measurement switch; default below)
-    static const int per_pass = [] {
-        const char *e = getenv("QSMC_HYP_OUTCOMES_PER_PASS");
-        return e ? atoi(e) : 8;
-    }();
     int done = 0;
-    static const bool no_lanes = getenv("QSMC_HYP_NO_LANES") != nullptr;            // (A/B switch)
     constexpr bool BINOMIAL = KIND == QSMC_MODEL_BINOMIAL_PRECESSION || KIND == QSMC_MODEL_BINOMIAL_RB ||
                               KIND == QSMC_MODEL_BINOMIAL_RB_INTERLEAVED;
-    static const bool no_chain = getenv("QSMC_HYP_NO_CHAIN") != nullptr;             // (A/B switch)
+    const bool no_chain = g_hyp_no_chain;                                           // (test hook: the independent form)
     // consecutive outcomes inside [0, n_meas] (the domain of a binomial experiment, in order): passes of equal size
     bool consecutive = BINOMIAL && !no_chain && n_o > 2 && model->likelihood_power == 0.0 && outcomes[0] >= 0 &&
                        (uint64_t)outcomes[n_o - 1] <= exp->n_meas;
@@ -786,24 +743,10 @@ static int hyp_dispatch(qsmc_ctx *h, Chain2Queue &q, const qsmc_model_t *model, 
                 rc = QSMC_ERR_INVALID;
         } else if ((rc = chain2_flush(h, q, s)) != QSMC_OK) {
             return rc;
-        } else if (BINOMIAL && WIDE && m > 8 && !no_lanes && model->likelihood_power == 0.0) {
-            take = m < 32 ? m : 32;
-            if constexpr (BINOMIAL && WIDE)
-                rc = hyp_launch_lanes<KIND>(h, model, x, ldx, n, w, norm, exp, outcomes + done, take, shift,
-                                            out_host + (size_t)done * PER, s);
-            else
-                rc = QSMC_ERR_INVALID;
         } else if (m <= 2) {
             take = m;
             rc = hyp_launch<KIND, 2>(h, model, x, ldx, n, w, norm, exp, outcomes + done, take, shift,
                                      out_host + (size_t)done * PER, s);
-        } else if (WIDE && m > 8 && per_pass >= 32) {
-            take = m < 32 ? m : 32;
-            if constexpr (WIDE)
-                rc = hyp_launch<KIND, 32>(h, model, x, ldx, n, w, norm, exp, outcomes + done, take, shift,
-                                          out_host + (size_t)done * PER, s);
-            else
-                rc = QSMC_ERR_INVALID;
         } else {
             take = m < 8 ? m : 8;
             rc = hyp_launch<KIND, 8>(h, model, x, ldx, n, w, norm, exp, outcomes + done, take, shift,
@@ -817,16 +760,10 @@ static int hyp_dispatch(qsmc_ctx *h, Chain2Queue &q, const qsmc_model_t *model, 
 
 // The list pass of a 2-qubit canonicalize: the eigenvector-free form (k_tomo_canon_list_fast, round 5) on the list, then
 // the eigenvector form on what that one flagged (count[1] entries of list2: none on a Ginibre-like cloud -- the launch
-// leaves at once).  QSMC_CANON_JACOBI=1 keeps the round-4 kernel on the whole list (A/B).
+// leaves at once).
 template <class Basis>
 static void launch_canon_list4(Basis B, int grid, hipStream_t s, hipEvent_t l0, hipEvent_t l1, double *x, int64_t ldx,
                                int32_t allow_sub, const unsigned int *list, unsigned int *count, unsigned int *list2) {
-    static const bool jacobi_env = getenv("QSMC_CANON_JACOBI") != nullptr;
-    if (jacobi_env) {
-        hipExtLaunchKernelGGL((k_tomo_canon_list<4, Basis>), dim3(grid), dim3(QSMC_BLOCK), 0, s, l0, l1, 0, B, x, ldx, allow_sub,
-                              list, count);
-        return;
-    }
     hipExtLaunchKernelGGL((k_tomo_canon_list_fast<Basis>), dim3(grid), dim3(QSMC_BLOCK), 0, s, l0, l1, 0, B, x, ldx, allow_sub,
                           list, count, list2);
     hipLaunchKernelGGL((k_tomo_canon_list<4, Basis>), dim3(64), dim3(QSMC_BLOCK), 0, s, B, x, ldx, allow_sub, list2, count + 1);
@@ -859,6 +796,17 @@ extern "C" {
 
 int qsmc_abi_version(void) { return QSMC_ABI_VERSION; }
 
+int qsmc_test_hook(int32_t hook, double value) {
+    switch (hook) {
+        case QSMC_HOOK_MULTI_GENERIC: g_multi_generic = value != 0.0; return QSMC_OK;
+        case QSMC_HOOK_REDRAW_NO_SMALL: g_redraw_no_small = value != 0.0; return QSMC_OK;
+        case QSMC_HOOK_HYP_NO_CHAIN: g_hyp_no_chain = value != 0.0; return QSMC_OK;
+        case QSMC_HOOK_TOMO_DENSE: g_tomo_dense = value != 0.0; return QSMC_OK;
+        case QSMC_HOOK_POISSON_MARGIN: g_poisson_margin = value; return QSMC_OK;
+        default: return QSMC_ERR_INVALID;
+    }
+}
+
 const char *qsmc_strerror(int status) {
     switch (status) {
         case QSMC_OK: return "ok";
@@ -866,6 +814,7 @@ const char *qsmc_strerror(int status) {
         case QSMC_ERR_HIP: return "HIP runtime error";
         case QSMC_ERR_ALLOC: return "allocation failed";
         case QSMC_ERR_UNSUPPORTED: return "unsupported configuration";
+        case QSMC_ERR_TIMEOUT: return "timed out waiting for a peer";
         default: return "unknown status";
     }
 }
@@ -1058,9 +1007,8 @@ static bool reduce_scan_has(int ns) {
     return ns == 3 || ns == 5 || ns == 8 || ns == 12 || ns == 17 || ns == 24 || ns == 26 || ns == 29 || ns == 33 || ns == 38;
 }
 static int setup_tile_prefix(qsmc_ctx *h, ReduceOut &ro, int64_t n, int per_block, int ns) {
-    static const bool tile_prefix_on = getenv("QSMC_NO_TILE_PREFIX") == nullptr;     // (A/B switch)
     const int64_t tp_chunks = (n + BUCKET_CHUNK - 1) / BUCKET_CHUNK;
-    if (!(tile_prefix_on && ro.tile_sums && tp_chunks <= TILE_PREFIX_MAX_CHUNKS && reduce_scan_has(ns))) return QSMC_OK;
+    if (!(ro.tile_sums && tp_chunks <= TILE_PREFIX_MAX_CHUNKS && reduce_scan_has(ns))) return QSMC_OK;
     if (h->tile_prefix_cap < (size_t)tp_chunks + 1) {
         if (h->tile_prefix) HIP_TRY(h, hipFree(h->tile_prefix));
         h->tile_prefix = nullptr;
@@ -1101,8 +1049,7 @@ int qsmc_update_fused(qsmc_handle_t h, const qsmc_model_t *model, const double *
     make_exp_args(model, exp, outcome, &ea);
     ReduceOut ro = make_reduce(h, stats_host || moments_host, stats_dev);
     // per-tile sums of the new weights: a resample that follows this update takes its chunk sums from them
-    static const bool tile_sums_on = getenv("QSMC_NO_TILE_SUMS") == nullptr;     // (A/B switch for measurements)
-    if (tile_sums_on && BUCKET_CHUNK % per_block == 0 &&
+    if (BUCKET_CHUNK % per_block == 0 &&
         ensure_tile_sums(h, (size_t)((n + BUCKET_CHUNK - 1) / BUCKET_CHUNK) * (BUCKET_CHUNK / per_block) * QSMC_WAVES_PER_BLOCK) == QSMC_OK) {   // (whole chunks: the update kernel zero-fills the last one)
         ro.tile_sums = h->tile_sums;
         h->ts.w = w_out;
@@ -1135,7 +1082,7 @@ int qsmc_update_fused(qsmc_handle_t h, const qsmc_model_t *model, const double *
         LAUNCH_U(QSMC_MODEL_UNKNOWN_T2)
         case QSMC_MODEL_TOMOGRAPHY: {
             // a measurement vector with at most four nonzero entries (a Pauli measurement has two): read those rows only
-            static const bool dense_env = getenv("QSMC_TOMO_DENSE_UPDATE") != nullptr;     // (A/B switch)
+            const bool dense_env = g_tomo_dense;                  // (test hook: the dense form, for the same-bits test)
             if (!dense_env && vec2 && ea.lik_pow == 0.0 && ea.nnz >= 1 && ea.nnz <= 4) {
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 prof_events(h, w_in ? QSMC_PROF_UPDATE : QSMC_PROF_UPDATE_ONES, &e0, &e1);
@@ -1169,8 +1116,7 @@ int qsmc_update_fused(qsmc_handle_t h, const qsmc_model_t *model, const double *
 
 int qsmc_lw_arm_prefix(qsmc_handle_t h, int32_t enabled, double ess_below, int64_t n_out, uint64_t seed, uint64_t epoch) {
     if (!h || (enabled && (n_out <= 0 || !(ess_below == ess_below)))) return QSMC_ERR_INVALID;
-    static const bool never = getenv("QSMC_NO_SPECULATIVE_PREFIX") != nullptr;     // (A/B switch)
-    h->spec.enabled = enabled && !never;
+    h->spec.enabled = enabled;
     h->spec.thresh = ess_below;
     h->spec.n_out = n_out;
     h->spec.seed = seed;
@@ -1215,12 +1161,11 @@ int qsmc_update_multi(qsmc_handle_t h, const qsmc_model_t *model, const double *
         ma.half_tmax = (ht > ma.half_tmax || ht != ht) ? ht : ma.half_tmax;      // (a NaN time: every particle takes the general path)
         ma.wabs_max = (wa > ma.wabs_max || wa != wa) ? wa : ma.wabs_max;
     }
-    if (getenv("QSMC_MULTI_GENERIC")) ma.half_tmax = -1.0;          // (test switch, read per call: every tile through the general path)
+    if (g_multi_generic) ma.half_tmax = -1.0;                      // (test hook, qsmc_test_hook: every tile through the general path)
     ReduceOut ro = make_reduce(h, true, nullptr);
     // per-tile sums of the window's final weights + their chunk prefix, as qsmc_update_fused leaves them: a resample
     // after the window (qsmc_lw_use_update_sums with this call's token) does not read the weights again
-    static const bool tile_sums_on = getenv("QSMC_NO_TILE_SUMS") == nullptr;
-    if (tile_sums_on && ensure_tile_sums(h, (size_t)((n + BUCKET_CHUNK - 1) / BUCKET_CHUNK) * (BUCKET_CHUNK / per_block) *
+    if (ensure_tile_sums(h, (size_t)((n + BUCKET_CHUNK - 1) / BUCKET_CHUNK) * (BUCKET_CHUNK / per_block) *
                                                 QSMC_WAVES_PER_BLOCK) == QSMC_OK) {
         ro.tile_sums = h->tile_sums;
         h->ts.w = w_out;
@@ -1238,7 +1183,7 @@ int qsmc_update_multi(qsmc_handle_t h, const qsmc_model_t *model, const double *
     // measurement two): the window reads those rows only (k_update_multi_tomo)
     bool sparse_tomo = false;
     if (model->kind == QSMC_MODEL_TOMOGRAPHY && k >= 2) {
-        static const bool dense_env = getenv("QSMC_TOMO_DENSE_UPDATE") != nullptr;     // (A/B switch, as for the single datum)
+        const bool dense_env = g_tomo_dense;                      // (test hook, as for the single datum)
         sparse_tomo = !dense_env && aligned16(x) && (!w_in || aligned16(w_in)) && aligned16(w_out) && (ldx % 2 == 0) &&
                       ma.e[0].lik_pow == 0.0;
         int nz_max = 0;
@@ -1616,8 +1561,7 @@ static int bucket_cap(int64_t n_out) {
 }
 
 static bool use_buckets(int64_t chunks64, int64_t n_out) {
-    static const bool forced_direct = getenv("QSMC_DIRECT_RESAMPLE") != nullptr;     // (test / measurement switch)
-    return chunks64 <= BUCKET_MAX_CHUNKS && n_out >= 4 * BUCKET_CHUNK && n_out < (1ll << 32) && !forced_direct;
+    return chunks64 <= BUCKET_MAX_CHUNKS && n_out >= 4 * BUCKET_CHUNK && n_out < (1ll << 32);
 }
 
 static int ensure_anc16(qsmc_ctx *h, size_t bytes) {
@@ -1708,10 +1652,9 @@ static int resample_prefix(qsmc_ctx *h, const double *w, int64_t n_in, double no
     BucketPlan bp;
     rc = bucket_plan_layout(h, chunks64, n_out, &bp);
     if (rc) return rc;
-    static const bool count_by_draws_env = getenv("QSMC_COUNT_BY_DRAWS") != nullptr;   // (measurement switch: the
-                                                                //  one-uniform-per-output histogram, same law)
-    // (k_bucket_counts meets at grid barriers: its 16 workgroups need a CU each -- any real part has them)
-    const bool count_by_draws = count_by_draws_env || h->cu_count < BUCKET_COUNTS_BLOCKS;
+    // (k_bucket_counts meets at grid barriers: its 16 workgroups need a CU each -- any real part has them; under a CU
+    //  mask that leaves fewer, the counts come from the one-uniform-per-output histogram instead: same law, no barrier)
+    const bool count_by_draws = h->cu_count < BUCKET_COUNTS_BLOCKS;
     // with tile sums the bucketed count kernel forms the offsets itself; otherwise: chunk sums, then the scan
     const bool scan_in_counts = ts.tiles && bp.bucketed && !count_by_draws;
     if (speculative && !scan_in_counts) return QSMC_OK;         // nothing queued (h->spec.launched stays 0)
@@ -1743,8 +1686,7 @@ static int resample_prefix(qsmc_ctx *h, const double *w, int64_t n_in, double no
             hipLaunchKernelGGL(k_bucket_plan, dim3(1), dim3(1024), 0, s, bp.counts, chunks, bp.cap, bp.slot_off, bp.item_off,
                                bp.item_chunk);
         } else {
-            const char *margin_env = getenv("QSMC_POISSON_MARGIN");          // (test switch: 0 makes the removal branch common)
-            const double kappa = margin_env ? atof(margin_env) : 5.0;
+            const double kappa = g_poisson_margin;                            // (5; test hook: 0 makes the removal branch common)
             double lambda = (double)n_out - kappa * sqrt((double)n_out);
             if (!(lambda > 0.0)) lambda = 0.0;
             // LDS: 8192 chunks need 68 KB of edges + 32 KB of counters: the opt-in beyond 64 KB is sticky
@@ -1890,8 +1832,7 @@ static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int3
     uint32_t k0, k1, ep;
     philox_keys(seed, epoch, &k0, &k1, &ep);
     const int64_t chunks64 = (n_in + BUCKET_CHUNK - 1) / BUCKET_CHUNK;
-    static const bool no_mfma16 = getenv("QSMC_NO_MFMA_SAMPLER") != nullptr;       // (A/B switch for measurements)
-    const bool split16 = d == 16 && model->kind == QSMC_MODEL_TOMOGRAPHY && !no_mfma16 && use_buckets(chunks64, n_out);
+    const bool split16 = d == 16 && model->kind == QSMC_MODEL_TOMOGRAPHY && use_buckets(chunks64, n_out);
     if (!split16 && (stages != RS_STAGE_ALL || canon.kind != 0)) return QSMC_ERR_UNSUPPORTED;
     if (canon.kind != 0 && pl.n_dest != 0) return QSMC_ERR_UNSUPPORTED;
     const bool prepared = h->prep.valid && h->prep.w == w && h->prep.n_in == n_in && h->prep.n_out == n_out &&
@@ -1938,12 +1879,15 @@ static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int3
         if (stages & RS_STAGE_KICK) {
             hipEvent_t pe0 = nullptr, pe1 = nullptr;
             prof_events(h, QSMC_PROF_SAMPLE, &pe0, &pe1);
-            const int64_t n_ranges = (n_out + KICK16_PER_BLOCK - 1) / KICK16_PER_BLOCK;
-            const unsigned kgrid = (unsigned)(((n_ranges + 7) / 8) * 8);
+            // one workgroup per (work item, 1024-slot sub-block): the item count is the device's (item_off[chunks]); the grid
+            // covers its bound and the surplus leaves at once (kernels/resample.hpp: which slots a workgroup takes)
+            const int64_t n_wg_max = (int64_t)bp.max_items * kick16_subblocks(bp.cap);
+            const unsigned kgrid = (unsigned)(((n_wg_max + 7) / 8) * 8);
             unsigned int *ccount = bp.clist, *clist = bp.clist + 4;      // (ccount was cleared by k_bucket_anc16)
 #define LAUNCH_K16(C)                                                                                                 \
     hipExtLaunchKernelGGL((k_bucket_kick16<C>), dim3(kgrid), dim3(KICK16_BT), 0, s, pe0, pe1, 0, x_in, ldx_in, bp.anc,  \
-                          n_out, lw, k0, k1, ep, x_out, pl, canon.basis, canon.allow_sub, clist, ccount, lw_dev)
+                          n_out, lw, k0, k1, ep, x_out, pl, canon.basis, canon.allow_sub, clist, ccount, lw_dev,      \
+                          bp.slot_off, bp.item_off, bp.item_chunk, chunks, bp.cap)
             if (canon.kind == 1) LAUNCH_K16(1);
             else if (canon.kind == 2) LAUNCH_K16(2);
             else LAUNCH_K16(0);
@@ -1980,13 +1924,12 @@ static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int3
         // The proposal bank (kernels/resample.hpp): when the caller expects redraws (the count of this cloud's previous
         // resample), the ordered sampler also produces ~1.25 x that many spare proposals and the failed first tries are
         // served from them; the global-CDF redraw kernel stays behind it for whatever is left.
-        static const bool no_bank = getenv("QSMC_NO_BANK") != nullptr;                   // (A/B switch)
         BankOut bo;
         memset(&bo, 0, sizeof(bo));
         BankIn bi;
         memset(&bi, 0, sizeof(bi));
         bool banked = false;
-        if (!no_bank && expect_redraws > 0.0 && postselect && maxiter > 1 && (d == 3 || d == 4)) {
+        if (expect_redraws > 0.0 && postselect && maxiter > 1 && (d == 3 || d == 4)) {
             const double m = 1.25 * expect_redraws;
             const double lambda = m + 6.0 * sqrt(m) + 64.0;
             rc = bank_layout(h, lambda, bp.max_items, n_out, seed, epoch, &bo, &bi);
@@ -2048,8 +1991,7 @@ static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int3
             // host-visible reduction), the CDF is materialised by a full-grid gated k_chunk_scan first (40 us when
             // the gate is open, ~5 us when it is not) and the redraw kernel skips its scan and its barrier.  Same CDF,
             // same particles either way.
-            static const bool never_split = getenv("QSMC_REDRAW_ONE_LAUNCH") != nullptr;      // (A/B switch)
-            const bool expect_cdf = !never_split && !banked && h->mapped[REDUCE_OUT_MAX - 2] > 0.0;
+            const bool expect_cdf = !banked && h->mapped[REDUCE_OUT_MAX - 2] > 0.0;
             if (expect_cdf)
                 hipLaunchKernelGGL(k_chunk_scan, dim3((unsigned)chunks64), dim3(SCAN_THREADS), 0, s, w, n_in, inv_norm,
                                    offsets, h->cdf_scratch, (const unsigned long long *)retry_count);
@@ -2058,7 +2000,7 @@ static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int3
             const int edges_in_lds = edges_lds <= 48 * 1024 ? 1 : 0;
             // (few queued outputs: chunk by chunk in LDS, no global CDF -- needs room for one chunk's CDF in the dynamic
             //  segment; QSMC_REDRAW_NO_SMALL keeps the global form for A/B)
-            static const bool no_small = getenv("QSMC_REDRAW_NO_SMALL") != nullptr;
+            const bool no_small = g_redraw_no_small;                   // (test hook: the global form, for the same-bits test)
             const size_t small_bytes = (size_t)SCAN_CHUNK * sizeof(double);
             size_t dyn = edges_in_lds ? edges_lds : 0;
             const int small_lds = (!no_small && !expect_cdf) ? 1 : 0;
@@ -2172,8 +2114,7 @@ int qsmc_step_sqrt_stats(qsmc_handle_t h, int64_t *n_device, int64_t *n_agreed) 
 
 int qsmc_lw_can_fuse_canonicalize(int32_t d, int64_t n_in, int64_t n_out) {
     if (d != 16 || n_in <= 0 || n_out <= 0) return 0;
-    static const bool no_mfma16 = getenv("QSMC_NO_MFMA_SAMPLER") != nullptr;
-    return (!no_mfma16 && use_buckets((n_in + BUCKET_CHUNK - 1) / BUCKET_CHUNK, n_out)) ? 1 : 0;
+    return use_buckets((n_in + BUCKET_CHUNK - 1) / BUCKET_CHUNK, n_out) ? 1 : 0;
 }
 
 int qsmc_reserve(qsmc_handle_t h, int64_t n_in, int64_t n_out, int32_t d) {
@@ -2234,8 +2175,7 @@ int qsmc_step(qsmc_handle_t h, qsmc_step_t *st, const qsmc_model_t *model, const
     const int d = model->d;
     const bool small_d = d >= 1 && d <= 4;
     if (st->lw.prefix && st->check_for_resample) {           // (qsmc_lw_arm_prefix, from the struct)
-        static const bool never = getenv("QSMC_NO_SPECULATIVE_PREFIX") != nullptr;
-        h->spec.enabled = !never && st->lw.n_out > 0;
+        h->spec.enabled = st->lw.n_out > 0;
         h->spec.thresh = st->ess_below;
         h->spec.n_out = st->lw.n_out;
         h->spec.seed = st->lw.seed;
@@ -2291,7 +2231,7 @@ int qsmc_step(qsmc_handle_t h, qsmc_step_t *st, const qsmc_model_t *model, const
     if (ess <= 10.0) st->status |= QSMC_STEP_SMALL_ESS;
     if (!(ess < st->ess_below)) return QSMC_OK;
     st->status |= QSMC_STEP_RESAMPLE_DUE;
-    static const bool no_queue = getenv("QSMC_NO_STEP_RESAMPLE") != nullptr;              // (A/B switch)
+    constexpr bool no_queue = false;
     if (st->ex_segment && st->plan_enabled && !no_queue) {
         // a shard: plan the resample (every rank draws the same plan from the shard sums it has just received) and start
         // this shard's weight-only prefix; mean / covariance / square root and the sampler are the caller's, behind it
@@ -2332,9 +2272,8 @@ int qsmc_step(qsmc_handle_t h, qsmc_step_t *st, const qsmc_model_t *model, const
     } else {
         // d = 16 tomography on the split sampler: moments (their own pass) and the ancestors are queued now; the host
         // forms S while the ancestor kernel runs and queues the kicks behind it
-        static const bool no_mfma16 = getenv("QSMC_NO_MFMA_SAMPLER") != nullptr;
         const int64_t chunks64 = (st->n + BUCKET_CHUNK - 1) / BUCKET_CHUNK;
-        if (d != 16 || model->kind != QSMC_MODEL_TOMOGRAPHY || no_mfma16 || !use_buckets(chunks64, st->lw.n_out))
+        if (d != 16 || model->kind != QSMC_MODEL_TOMOGRAPHY || !use_buckets(chunks64, st->lw.n_out))
             return QSMC_OK;
         const int gridm = grid_for(st->n, QSMC_BLOCK) < 1024 ? grid_for(st->n, QSMC_BLOCK) : 1024;
         rc = ensure_partials(h, (size_t)gridm * MFMA_MOM_K);
@@ -2354,13 +2293,8 @@ int qsmc_step(qsmc_handle_t h, qsmc_step_t *st, const qsmc_model_t *model, const
         //  release or relaxed and whether every thread or only the writing lanes fence at system scope: 273 pinned stores from
         //  69 workgroups each wait for their own acknowledgement, where k_publish_big's one workgroup waits once.  Like the
         //  one-launch datum: on this part a dependent launch whose packet is already queued costs about what
-        //  any in-kernel hand-over does.  QSMC_MERGED_MOMENT_PUBLISH=1 keeps the merged form for A/B.)
-        static const bool merged_publish = getenv("QSMC_MERGED_MOMENT_PUBLISH") != nullptr;
-        if (dev_sqrt_env || !merged_publish)
-            hipLaunchKernelGGL(k_sum_partials, dim3(SUM_GRID), dim3(QSMC_BLOCK), 0, s, h->partials, gridm, MFMA_MOM_K, full);
-        else
-            hipLaunchKernelGGL(k_sum_partials_publish, dim3(SUM_GRID), dim3(QSMC_BLOCK), 0, s, h->partials, gridm, MFMA_MOM_K,
-                               full, h->mapped_big_dev, h->flag_dev, seq, h->tickets + TICKET_WORDS - 1);
+        //  any in-kernel hand-over does.  The merged kernel was removed in round 6.)
+        hipLaunchKernelGGL(k_sum_partials, dim3(SUM_GRID), dim3(QSMC_BLOCK), 0, s, h->partials, gridm, MFMA_MOM_K, full);
         // (round 4 built the device form -- kernels/sqrtm.hpp -- and measured it: the gap between the two sampler kernels
         //  closes, but the one wavefront that forms S is latency-bound, ~90 rounds of three dependent LDS / fp64-division
         //  steps sharing a SIMD with the ancestor kernel's own waves: k_bucket_anc16 36 -> 96 us, a d = 16 resample
@@ -2390,8 +2324,7 @@ int qsmc_step(qsmc_handle_t h, qsmc_step_t *st, const qsmc_model_t *model, const
             if (rc) return rc;
             ++h->n_sqrt_dev;
         } else {
-            if (!merged_publish)
-                hipLaunchKernelGGL(k_publish_big, dim3(1), dim3(QSMC_BLOCK), 0, s, full, MFMA_MOM_K, h->mapped_big_dev, h->flag_dev, seq);
+            hipLaunchKernelGGL(k_publish_big, dim3(1), dim3(QSMC_BLOCK), 0, s, full, MFMA_MOM_K, h->mapped_big_dev, h->flag_dev, seq);
             HIP_TRY(h, hipGetLastError());
             rc = resample_philox_impl(h, model, st->lw.postselect, st->x, st->ldx, st->n, d, st->w, fixed, st->lw.a, st->mean,
                                       st->S, st->lw.n_out, st->lw.seed, st->lw.epoch, st->lw.maxiter, st->lw.x_out, pl,
@@ -2620,11 +2553,6 @@ int qsmc_tomo_canonicalize(qsmc_handle_t h, const double *basis, int32_t dim, do
 }
 
 // ---- posterior read-outs: sort by weight / by location, search a sorted table -------
-__global__ __launch_bounds__(QSMC_BLOCK) void k_iota(int64_t *__restrict__ v, int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * QSMC_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * QSMC_BLOCK) v[i] = i;
-}
-
-// out[k] = number of entries of the non-decreasing a[0..n) that are < q[k] (side 0, 'left') or <= q[k] (side 1)
 __global__ __launch_bounds__(QSMC_BLOCK) void k_searchsorted(const double *__restrict__ a, int64_t n,
                                                              const double *__restrict__ q, int64_t m, int side,
                                                              int64_t *__restrict__ out) {
@@ -2644,14 +2572,14 @@ int qsmc_argsort(qsmc_handle_t h, const double *keys, int64_t n, int32_t descend
                  int64_t *idx_out, qsmc_stream_t stream) {
     if (!h || !keys || !keys_out || !idx_out || n <= 0 || n >= (1ll << 31)) return QSMC_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
-    size_t tmp_bytes = 0;
-    // (size query: null temporary storage)
-    hipError_t e = descending
-        ? rocprim::radix_sort_pairs_desc(nullptr, tmp_bytes, keys, keys_out, (const int64_t *)nullptr, idx_out, (size_t)n, 0, 64, s)
-        : rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys_out, (const int64_t *)nullptr, idx_out, (size_t)n, 0, 64, s);
-    HIP_TRY(h, e);
-    const size_t iota_bytes = (size_t)n * sizeof(int64_t);
-    const size_t need = iota_bytes + tmp_bytes + 256;
+    // kernels/sort.hpp: eight 8-bit passes ping-ponging between a temporary pair and the output pair (which holds key
+    // images until the last pass writes doubles); pass 0 reads the caller's keys, index = position
+    const int ntiles = (int)((n + SORT_TILE - 1) / SORT_TILE);
+    const long long m = 256ll * ntiles;
+    const int nchunks = (int)((m + SORT_SCAN_CHUNK - 1) / SORT_SCAN_CHUNK);
+    const size_t pair_bytes = (((size_t)n * 8) + 255) & ~(size_t)255;
+    const size_t hist_bytes = (((size_t)m * sizeof(unsigned int)) + 255) & ~(size_t)255;
+    const size_t need = 2 * pair_bytes + hist_bytes + (size_t)nchunks * sizeof(unsigned int) + 256;
     if (h->sort_tmp_cap < need) {
         if (h->sort_tmp) HIP_TRY(h, hipFree(h->sort_tmp));
         h->sort_tmp = nullptr;
@@ -2659,13 +2587,35 @@ int qsmc_argsort(qsmc_handle_t h, const double *keys, int64_t n, int32_t descend
         HIP_TRY(h, hipMalloc(&h->sort_tmp, need));
         h->sort_tmp_cap = need;
     }
-    int64_t *iota = static_cast<int64_t *>(h->sort_tmp);
-    void *tmp = static_cast<char *>(h->sort_tmp) + ((iota_bytes + 255) & ~(size_t)255);
-    hipLaunchKernelGGL(k_iota, dim3(grid_for(n, QSMC_BLOCK)), dim3(QSMC_BLOCK), 0, s, iota, n);
-    e = descending
-        ? rocprim::radix_sort_pairs_desc(tmp, tmp_bytes, keys, keys_out, (const int64_t *)iota, idx_out, (size_t)n, 0, 64, s)
-        : rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys_out, (const int64_t *)iota, idx_out, (size_t)n, 0, 64, s);
-    HIP_TRY(h, e);
+    char *base = static_cast<char *>(h->sort_tmp);
+    void *tk = base;
+    long long *ti = reinterpret_cast<long long *>(base + pair_bytes);
+    unsigned int *hist = reinterpret_cast<unsigned int *>(base + 2 * pair_bytes);
+    unsigned int *totals = reinterpret_cast<unsigned int *>(base + 2 * pair_bytes + hist_bytes);
+    const int desc = descending ? 1 : 0;
+    for (int pass = 0; pass < 8; ++pass) {
+        const int shift = 8 * pass;
+        const void *kin = pass == 0 ? (const void *)keys : ((pass & 1) ? (const void *)tk : (const void *)keys_out);
+        const long long *iin = pass == 0 ? nullptr : ((pass & 1) ? ti : (const long long *)idx_out);
+        void *kout = (pass & 1) ? (void *)keys_out : tk;
+        long long *iout = (pass & 1) ? (long long *)idx_out : ti;
+        if (pass == 0)
+            hipLaunchKernelGGL((k_sort_hist<true>), dim3(ntiles), dim3(QSMC_BLOCK), 0, s, kin, (long long)n, shift, desc, hist, ntiles);
+        else
+            hipLaunchKernelGGL((k_sort_hist<false>), dim3(ntiles), dim3(QSMC_BLOCK), 0, s, kin, (long long)n, shift, desc, hist, ntiles);
+        hipLaunchKernelGGL(k_sort_scan, dim3(nchunks), dim3(1024), 0, s, hist, m, totals);
+        hipLaunchKernelGGL(k_sort_scan_top, dim3(1), dim3(1024), 0, s, totals, nchunks);
+        if (pass == 0)
+            hipLaunchKernelGGL((k_sort_scatter<true, false>), dim3(ntiles), dim3(QSMC_BLOCK), 0, s, kin, iin, kout, iout,
+                               (long long)n, shift, desc, hist, totals, ntiles);
+        else if (pass == 7)
+            hipLaunchKernelGGL((k_sort_scatter<false, true>), dim3(ntiles), dim3(QSMC_BLOCK), 0, s, kin, iin, kout, iout,
+                               (long long)n, shift, desc, hist, totals, ntiles);
+        else
+            hipLaunchKernelGGL((k_sort_scatter<false, false>), dim3(ntiles), dim3(QSMC_BLOCK), 0, s, kin, iin, kout, iout,
+                               (long long)n, shift, desc, hist, totals, ntiles);
+    }
+    HIP_TRY(h, hipGetLastError());
     return QSMC_OK;
 }
 
@@ -3014,7 +2964,7 @@ int qsmc_host_allgather(void *segment, int32_t rank, int32_t world, int32_t max_
             __builtin_ia32_pause();
             if ((spins & 0xffff) == 0xffff &&
                 std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s)
-                return QSMC_ERR_UNSUPPORTED;                   // a peer did not arrive
+                return QSMC_ERR_TIMEOUT;                       // a peer did not arrive
         }
     }
     std::atomic_thread_fence(std::memory_order_acquire);

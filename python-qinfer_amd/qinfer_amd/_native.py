@@ -83,6 +83,7 @@ SIGNATURES = {
     "qsmc_strerror": [C.c_int],
     "qsmc_last_hip_error": [_P],
     "qsmc_create": [C.POINTER(_P), C.c_int],
+    "qsmc_test_hook": [_I32, _F64],
     "qsmc_destroy": [_P],
     "qsmc_device_cus": [_P, C.POINTER(_I32), C.POINTER(_I32)],
     "qsmc_set_profiling": [_P, C.c_int],
@@ -184,6 +185,8 @@ def load():
     if lib.qsmc_abi_version() != 2:
         raise NativeLibraryError("ABI version mismatch")
     _lib = lib
+    if os.environ.get("QSMC_TEST_HOOKS"):
+        _hooks_from_env()
     return lib
 
 
@@ -191,10 +194,37 @@ def lib_path():
     return _LIB_PATH
 
 
+HOOKS = {"multi_generic": 1, "redraw_no_small": 2, "hyp_no_chain": 3, "tomo_dense": 4, "poisson_margin": 5}
+
+
+def test_hook(name, value):
+    """qsmc_test_hook (include/qsmc.h): process-wide switches the parity tests use to reach an independent form of a
+    kernel or a rare branch.  `value`: on / off (or kappa for "poisson_margin", default 5)."""
+    check(None, load().qsmc_test_hook(HOOKS[name], float(value)), "qsmc_test_hook")
+
+
+# hooks named in QSMC_TEST_HOOKS ("name=value,name=value") are applied at load time: the tests that compare whole runs in
+# subprocesses set them through the environment
+def _hooks_from_env():
+    spec = os.environ.get("QSMC_TEST_HOOKS", "")
+    for item in filter(None, (t.strip() for t in spec.split(","))):
+        name, _, val = item.partition("=")
+        test_hook(name, float(val or 1))
+
+
+ERR_TIMEOUT = -5         # qsmc.h: QSMC_ERR_TIMEOUT (a peer of a host collective did not arrive in time)
+
+
+class PeerTimeoutError(RuntimeError):
+    """A host collective inside the library (qsmc_host_allreduce on a shard's per-datum path) gave up on a peer."""
+
+
 def check(handle, rc, what):
     if rc:
         lib = load()
         msg = lib.qsmc_strerror(rc).decode()
+        if rc == ERR_TIMEOUT:
+            raise PeerTimeoutError("{} failed: {}".format(what, msg))
         detail = lib.qsmc_last_hip_error(handle).decode() if handle else ""
         raise RuntimeError("{} failed: {} {}".format(what, msg, detail))
 

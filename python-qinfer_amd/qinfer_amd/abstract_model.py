@@ -19,6 +19,22 @@ are served entirely by the HIP kernels; `NativeModelMixin` then also routes the 
 `likelihood` / `are_models_valid` through the same kernels, so there is a single source of truth
 for the model arithmetic.  A model without the hooks still works with `SMCUpdater` through the
 plugin slow path (its own `likelihood` runs on the host, the weight update stays on the GPU).
+
+Device-side plugin hooks (optional; a user model written against torch tensors stays in HBM -- the updater then
+makes no host copy of the cloud at all).  `x_dev` is the cloud as the updater holds it: a float64 torch tensor of
+shape (n_modelparams, n_particles) on the GPU, structure-of-arrays (row m = parameter m of every particle); treat
+it as read-only.
+
+    likelihood_device(outcomes, x_dev, expparams)   -> float64 device tensor L[n_outcomes, n_experiments, n_particles]
+                                                       (the contract of `likelihood`, abstract_model.py:444-468, with
+                                                       the particle axis last)
+    are_models_valid_device(x_dev)                  -> bool / uint8 device tensor [n_particles]
+    update_timestep_device(x_dev, expparams)        -> float64 device tensor (n_modelparams, n_particles): the cloud
+                                                       after one experiment's time step
+    canonicalize_device(x_dev)                      -> float64 device tensor (n_modelparams, n_particles)
+
+Each is used in place of its NumPy namesake when present (and the model is not served by native kernels); a model
+may define any subset.  `Model.count_likelihood_calls` keeps `call_count` meaningful from `likelihood_device`.
 """
 import abc
 
@@ -161,6 +177,11 @@ class Model(Simulatable):
 
     def is_model_valid(self, modelparams):
         return bool(self.are_models_valid(np.asarray(modelparams)[np.newaxis, :])[0])
+
+    def count_likelihood_calls(self, n_outcomes, n_models, n_experiments):
+        """What the base `likelihood` adds to `call_count` (abstract_model.py:466-468), for a `likelihood_device`
+        that never sees host arrays."""
+        self._call_count += int(n_outcomes) * int(n_models) * int(n_experiments)
 
 
 class FiniteOutcomeModel(Model):

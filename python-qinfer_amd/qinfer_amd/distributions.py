@@ -278,12 +278,17 @@ class ParticleDistribution(Distribution):
         self._moments_cache = None
 
     _view_version = 0
+    _host_locs = None
 
-    def _invalidate(self):
+    def _invalidate(self, locations=True):
+        """Something about the cloud changed.  `locations=False`: only the weights did (an update's commit, a weight
+        assignment) -- the host copy of the locations kept for plugin callbacks (`SMCUpdater._host_locations`) stays."""
         self._moments_cache = None
         self._w_token = 0            # the weights are no longer (known to be) the output of a fused update
         self._view_version += 1      # host snapshots handed out so far are stale from here on
         self._step_synced = False    # (SMCUpdater: the qsmc_step_t mirror of the cloud must be refilled)
+        if locations:
+            self._host_locs = None
 
     def _write_back(self, what, arr):
         """Upload an edited host snapshot (DeviceBackedArray._push)."""
@@ -340,7 +345,7 @@ class ParticleDistribution(Distribution):
         self._norm = 1.0
         self._sumsq = None
         self._shard_sums = None      # (sharded updater: per-rank weight totals must be gathered again)
-        self._invalidate()
+        self._invalidate(locations=False)
 
     @property
     def n_particles(self):

@@ -5,7 +5,6 @@ Layout contract: particle locations are SoA `x[d, N]` float64 co
 weights `w[N]` float64, kept unnormalised with a host-side normaliser.
 """
 import ctypes as C
-import os
 import threading
 
 import numpy as np
@@ -37,9 +36,6 @@ def get_engine(device=None):
         return _engines[idx]
 
 
-_NO_SPECULATIVE_PREFIX = bool(os.environ.get("QSMC_NO_SPECULATIVE_PREFIX"))     # (A/B switch, read by the library too)
-
-
 class Engine:
     def __init__(self, index):
         import torch
@@ -62,6 +58,13 @@ class Engine:
         self._armed_prefix = None    # what qsmc_lw_arm_prefix was last told (arm_resample_prefix)
         self._qsmc_step = self.lib.qsmc_step
         self._h_int = h.value        # (the handle as a plain int: marshalled fastest on the per-datum call)
+        self._design_jobs = []       # design passes begun and not yet collected (hypothetical_sums_begin / _collect)
+
+    def _no_design_in_flight(self, what):
+        """Between `hypothetical_sums_begin` and `_collect` the pinned block belongs to the queued design passes: nothing
+        else that reduces through it may be asked of the engine."""
+        if self._design_jobs:
+            raise RuntimeError("{} while design passes are in flight: call hypothetical_sums_collect() first".format(what))
 
     # ------------------------------------------------------------------ memory / streams
     def stream(self):
@@ -161,6 +164,8 @@ class Engine:
         """Returns UpdateStats (or (UpdateStats, s1, s2) with moments=True, d <= 4: UNNORMALISED
         sum w' x and sum w' x x^T of the new weights, produced by the same kernel).  The returned
         UpdateStats object is reused by the next call: read it before updating again."""
+        if self._design_jobs:
+            self._no_design_in_flight("update_fused")
         d = x.shape[0]
         self.update_gen += 1                        # mirrors the handle's generation counter (qsmc_update_token)
         self._chk(self.lib.qsmc_update_fused(
@@ -181,6 +186,8 @@ class Engine:
     def step(self, st_ref, desc_ref, ep_ref, outcome):
         """One datum through qsmc_step (see include/qsmc.h): fused update + the no-guard tail of SMCUpdater.update
         + (when allowed and due) the Liu-West resample queued in C.  Results are in the qsmc_step_t behind st_ref."""
+        if self._design_jobs:
+            self._no_design_in_flight("step")
         rc = self._qsmc_step(self._h_int, st_ref, desc_ref, ep_ref, outcome, self._raw_stream(self.index))
         if rc:
             self._chk(rc, "qsmc_step")
@@ -188,7 +195,7 @@ class Engine:
 
     def step_adopted(self):
         """The caller has taken the resample queued by the latest `step` as its own (counted by qsmc_step_stats)."""
-        self.lib.qsmc_step_adopted(self.h)
+        self._chk(self.lib.qsmc_step_adopted(self.h), "qsmc_step_adopted")
 
     def step_stats(self):
         """(resamples queued by qsmc_step, resamples whose caller-side call adopted the queued one)."""
@@ -201,6 +208,8 @@ class Engine:
     def update_multi(self, desc, x, w_in, w_out, prev_norm, exps, outcomes):
         """K <= 8 data in one pass.  Returns (list of UpdateStats per datum, s1, s2) -- s1/s2 are the
         unnormalised moment sums of the final weights (None for d > 4)."""
+        if self._design_jobs:
+            self._no_design_in_flight("update_multi")
         k = len(exps)
         d = x.shape[0]
         ep = (_native.ExpParam * k)(*exps)
@@ -272,13 +281,15 @@ class Engine:
             at += c
         job = type("DesignJob", (), {})()
         job.rows, job._keep = rows, (out, oc, no, ep, shift)          # (the C side holds pointers into these until collect)
-        self._design_jobs = getattr(self, "_design_jobs", []) + [job]
+        self._design_jobs = self._design_jobs + [job]
         return job
 
     def hypothetical_sums_collect(self):
         """Wait for every design pass queued by `hypothetical_sums_begin` and fill the jobs' rows."""
-        self._chk(self.lib.qsmc_hypothetical_sums_collect(self.h, self.stream()), "qsmc_hypothetical_sums_collect")
-        self._design_jobs = []
+        try:
+            self._chk(self.lib.qsmc_hypothetical_sums_collect(self.h, self.stream()), "qsmc_hypothetical_sums_collect")
+        finally:
+            self._design_jobs = []           # (also after an error: the library has dropped its queue -- chain2_flush)
 
     def update_from_likelihood(self, L, w_in, w_out, prev_norm):
         st = _native.UpdateStats()
@@ -406,6 +417,8 @@ class Engine:
     # ------------------------------------------------------------------ moments
     def moments(self, x, w, norm):
         """Returns host (sum_w, S1[d], S2[d, d]) of the normalised weights."""
+        if self._design_jobs:
+            self._no_design_in_flight("moments")
         d, n = x.shape
         k = 1 + d + d * (d + 1) // 2
         out = np.empty(k, dtype=np.float64)
@@ -461,6 +474,8 @@ class Engine:
         view to fill (row stride arbitrary) instead of a fresh tensor; x_in may be a column slice of a cloud.
         `canon` = (kind, basis_dev, allow_subnormalized) from TomographyModel._native_canonicalize_fused: the new cloud
         comes out canonicalized (qsmc_lw_fuse_canonicalize)."""
+        if self._design_jobs:
+            self._no_design_in_flight("lw_resample_philox")
         d = x_in.shape[0]
         if expect_redraws:
             # (how many first tries of this cloud's previous resample failed postselection: the library then banks
@@ -522,8 +537,6 @@ class Engine:
         """key = (ess_below, n_out, seed, epoch) or None: from now on every host-visible `update_fused` queues the
         resampler's weight-only prefix for that resample behind itself, gated on the device-side ESS test
         (qsmc_lw_arm_prefix).  Called only when the key changes -- once per resample."""
-        if key is not None and _NO_SPECULATIVE_PREFIX:
-            key = None
         if key == self._armed_prefix:
             return
         self._armed_prefix = key

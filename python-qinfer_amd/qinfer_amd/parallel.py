@@ -184,14 +184,19 @@ class ParticleShardGroup:
     """The ranks that share one sharded particle cloud.
 
     `transport` selects what carries the per-datum reduction (a dozen doubles per rank):
-      "auto"     host shared memory when every rank runs on this host (measured ~4 us per datum), else "backend";
+      "auto"     MEASURED at group creation when it can be (every rank on this host, each with a GPU of its own, RCCL
+                 backend): ~50 per-datum reductions of a small probe cloud under host shared memory and under the library's
+                 RCCL collective, the faster one taken (both timings kept in `transport_probe`; `probe=False` or
+                 QSMC_TRANSPORT_PROBE=0 skips the measurement).  Otherwise host shared memory when every rank runs on this
+                 host, else "backend";
       "shm"      host shared memory (HostExchange) or fail;
       "rccl"     the library's own RCCL communicator: all-gather on the launch stream, right behind the update kernel,
                  and a rank-ordered sum on the device (`qsmc_allreduce_sums`; needs one GPU per rank);
       "backend"  torch.distributed's all-gather (gloo on CPU, RCCL through torch on GPUs).
     The environment variable QSMC_TRANSPORT overrides the argument."""
 
-    def __init__(self, group=None, seed=0, placement="local", rebalance_tol=0.05, host_exchange=True, transport=None):
+    def __init__(self, group=None, seed=0, placement="local", rebalance_tol=0.05, host_exchange=True, transport=None,
+                 probe=None):
         import os
         import torch
         import torch.distributed as dist
@@ -220,6 +225,102 @@ class ParticleShardGroup:
         self._host = self._open_host_exchange() if transport in ("auto", "shm") else None
         if transport == "shm" and self._host is None:
             raise RuntimeError("transport='shm': the ranks do not share a host (or /dev/shm is unavailable)")
+        self.transport_probe = None       # what `auto` measured: {"shm_us", "rccl_us", "chosen", ...} (None: not measured)
+        if transport == "auto" and self._host is not None:
+            mode = os.environ.get("QSMC_TRANSPORT_PROBE", "")
+            want = (probe if probe is not None else True) and mode != "0"
+            if want and self._probe_applies(force=(mode == "force")):
+                self._probe_transports()
+
+    # ------------------------------------------------------------------ transport="auto": a measured choice
+    def _probe_applies(self, force=False):
+        """Every rank has a GPU of its own and the group talks RCCL (collective: every rank answers the same)."""
+        t = self.torch
+        if self.backend != "nccl" or not t.cuda.is_available():
+            return False
+        if self.world_size < 2 and not force:
+            return False
+        try:
+            devs = [None] * self.world_size
+            self.dist.all_gather_object(devs, int(t.cuda.current_device()), group=self.group)
+        except Exception:  # noqa: BLE001
+            return False
+        return len(set(devs)) == self.world_size          # (one host -- `_host` is open -- so distinct indices = distinct GPUs)
+
+    def _probe_transports(self, n_data=50, timeout=30.0):
+        """Time `n_data` per-datum reductions of a 4096-particle-per-rank probe cloud (SimplePrecessionModel, no
+        resampling: the update kernel is ~3 us, the rest is the transport) under each transport and keep the faster.
+        The RCCL leg runs in a helper thread with a deadline: a communicator that cannot be built, or never returns,
+        leaves the group on shared memory instead of hanging it.  The decision is made from numbers every rank has seen
+        (exchanged through the shared-memory segment): the slowest rank's time per transport, and RCCL only if every rank
+        finished its leg and both legs produced the same normalisations bit for bit."""
+        import threading
+        import time
+        import warnings
+        from .engine import get_engine
+        from .models import SimplePrecessionModel
+        from .distributions import UniformDistribution
+        from .smc import SMCUpdater
+        t = self.torch
+        dev = int(t.cuda.current_device())
+        ts = 0.5 + 0.05 * np.arange(n_data + 10)
+
+        def leg(transport):
+            t.cuda.set_device(dev)                       # (the current device is per thread)
+            self.transport = transport
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                upd = SMCUpdater(SimplePrecessionModel(), 4096, UniformDistribution([0, 1]), device_rng=True, seed=1,
+                                 comm=self, resample_thresh=0.0)
+                for k in range(10):
+                    upd.update(k & 1, ts[k:k + 1], check_for_resample=False)
+                t.cuda.synchronize()
+                t0 = time.perf_counter()
+                for k in range(10, 10 + n_data):
+                    upd.update(k & 1, ts[k:k + 1], check_for_resample=False)
+                dt = time.perf_counter() - t0
+            return dt / n_data * 1e6, np.ravel(upd.normalization_record).copy()
+
+        shm_us, shm_rec = leg("shm")
+        box = {}
+
+        def work():
+            try:
+                box["ok"] = leg("rccl")
+            except BaseException as e:  # noqa: BLE001
+                box["err"] = repr(e)
+        th = threading.Thread(target=work, daemon=True, name="qsmc-transport-probe")
+        th.start()
+        th.join(timeout)
+        rccl_us, same, err = float("nan"), False, None
+        if th.is_alive():
+            err = "no result within %.0f s" % timeout
+        elif "err" in box:
+            err = box["err"]
+        else:
+            rccl_us, rccl_rec = box["ok"]
+            same = bool(np.array_equal(shm_rec, rccl_rec))
+        self.transport = "auto"
+        rows = self._host.all_gather(np.array([shm_us, rccl_us if err is None else np.inf, float(same), float(err is None)]))
+        shm_max, rccl_max = float(rows[:, 0].max()), float(rows[:, 1].max())
+        all_ok = bool(rows[:, 3].min() == 1.0) and bool(rows[:, 2].min() == 1.0)
+        chosen = "rccl" if (all_ok and rccl_max < shm_max) else "shm"
+        self.transport_probe = {"what": "%d per-datum reductions of a 4096-particle-per-rank probe cloud, us per datum, "
+                                        "slowest rank" % n_data,
+                                "shm_us": shm_max, "rccl_us": (rccl_max if np.isfinite(rccl_max) else None),
+                                "same_bits": bool(rows[:, 2].min() == 1.0), "chosen": chosen, "ranks": self.world_size}
+        if err is not None:
+            self.transport_probe["rccl_error"] = err
+        if chosen == "rccl":
+            self.transport = "rccl"
+        else:
+            if not th.is_alive() and self._rccl is not None:
+                try:
+                    self._rccl.comm_destroy()
+                except Exception:  # noqa: BLE001
+                    pass
+            if not th.is_alive():
+                self._rccl = None
 
     def _open_host_exchange(self):
         """Shared-memory exchange if (and only if) every rank runs on this host and every rank can map the
@@ -480,8 +581,17 @@ class ParticleShardGroup:
         eng = updater._eng
         model = updater.model
         from .abstract_model import native_ok
-        if not native_ok(model):
-            raise NotImplementedError("sharded resampling needs a model with native kernels")
+        from . import _native
+        # a model without native kernels (a user plugin, what the reference's DirectViewParallelizedModel shards:
+        # parallel.py:196-224): nothing in the two-level multinomial or the Liu-West kick depends on the model -- only the
+        # validity test does.  The shard's draw then runs on the same Philox samplers without a test of their own, and the
+        # model's test (its device hook or its NumPy one) drives the redraw rounds (LiuWestResampler._plugin_device_draw).
+        native = native_ok(model)
+        if not native and updater.n_rvs > _native.QSMC_MAX_D:
+            raise NotImplementedError("sharded resampling: the device samplers take at most {} model parameters".format(
+                _native.QSMC_MAX_D))
+        desc = model._native_desc() if native else _native.ModelDesc(_native.MODEL_TOMOGRAPHY, updater.n_rvs, 0.0, 1, 0)
+        postselect = bool(resampler._postselect) and native       # (the kernels' own test: a native model's only)
         self._epoch += 1
         epoch = self._epoch
         d = updater.n_rvs
@@ -539,14 +649,20 @@ class ParticleShardGroup:
             raise ResamplerError("Infinite error in computing the square root of the covariance "
                                  "matrix. Check that n_ess is not too small.")
         canonicalized = False
+        if not native:
+            defer = False                              # (the redraw rounds of a plugin model read their counts back)
         if stay and big:
             resampler._epoch = epoch                   # (the segment split is keyed by the resampler's seed and epoch)
             seed0, resampler._seed = resampler._seed, seed_r
+            ps0, resampler._postselect = resampler._postselect, postselect
             try:
-                x_new, n_failed = resampler._segmented_resample(eng, model._native_desc(), updater._x, updater._w, a,
+                x_new, n_failed = resampler._segmented_resample(eng, desc, updater._x, updater._w, a,
                                                                 mean, S, int(totals[self.rank]))
             finally:
-                resampler._seed = seed0
+                resampler._seed, resampler._postselect = seed0, ps0
+            if not native and resampler._postselect:
+                n_failed = self._plugin_redraw_rounds(eng, model, resampler, updater, x_new, float(W[self.rank]), a, mean, S,
+                                                      seed_r, epoch)
             defer = False
             self.last_shard_sizes = totals
             self.last_resample_path = "segmented local draw"
@@ -559,15 +675,20 @@ class ParticleShardGroup:
             canon = getattr(updater, "_fused_canon", None)
             if canon is not None and not eng.fused_canon_applies(d, n_local, n_new):
                 canon = None
-            x_new, n_failed = eng.lw_resample_philox(model._native_desc(), resampler._postselect, updater._x,
-                                                     updater._w, float(W[self.rank]), a, mean, S,
-                                                     n_new, seed_r, epoch, resampler._maxiter,
-                                                     sync=not defer, canon=canon, expect_redraws=expect)
-            canonicalized = canon is not None
+            if native:
+                x_new, n_failed = eng.lw_resample_philox(desc, postselect, updater._x,
+                                                         updater._w, float(W[self.rank]), a, mean, S,
+                                                         n_new, seed_r, epoch, resampler._maxiter,
+                                                         sync=not defer, canon=canon, expect_redraws=expect)
+            else:
+                x_new, n_failed = resampler._plugin_device_draw(eng, model, updater._x, updater._w, float(W[self.rank]), a,
+                                                                mean, S, n_new, seed_r, epoch)
+            canonicalized = canon is not None and native
             self.last_shard_sizes = totals
-            self.last_resample_path = ("local draw%s%s" % (
+            self.last_resample_path = ("local draw%s%s%s" % (
                 ", canonicalize fused into the split d = 16 sampler" if canonicalized else "",
-                ", proposal bank for %d expected redraws" % expect if expect > 0 else ""))
+                ", proposal bank for %d expected redraws" % expect if expect > 0 and native else "",
+                "" if native else ", plugin model: its own validity test drives the redraw rounds"))
         else:
             # rebalance (or placement="mixed"): this shard draws, kicks and postselects the particles every
             # destination takes from it; finished rows travel by one all-to-all
@@ -578,10 +699,14 @@ class ParticleShardGroup:
                 counts = self.plan_counts(W, target, epoch)
                 if n_total != target * G:
                     raise ValueError("placement='mixed' needs equal shard sizes")
-            rows, n_failed = eng.lw_resample_philox_sharded(model._native_desc(), resampler._postselect,
+            rows, n_failed = eng.lw_resample_philox_sharded(desc, postselect,
                                                             updater._x, updater._w, float(W[self.rank]),
                                                             a, mean, S, counts[:, self.rank], seed_r, epoch,
                                                             resampler._maxiter, sync=not defer)
+            if not native and resampler._postselect:
+                # (the finished rows are AoS (n, d): the rounds work on their SoA view and fix them in place, before they travel)
+                n_failed = self._plugin_redraw_rounds(eng, model, resampler, updater, rows.t(), float(W[self.rank]), a, mean, S,
+                                                      seed_r, epoch)
             recv = self.exchange_rows(rows, counts)                  # the only bandwidth step
             x_new = recv.to(eng.device).t().contiguous()             # back to SoA
             self.last_shard_sizes = counts.sum(axis=1)
@@ -595,6 +720,25 @@ class ParticleShardGroup:
         new = ParticleDistribution._from_device(eng, x_new, None, norm=float(n_total), sumsq=float(n_total))
         new._canonicalized = canonicalized
         return new
+
+    @staticmethod
+    def _plugin_redraw_rounds(eng, model, resampler, updater, x_new, W_local, a, mean, S, seed, epoch):
+        """Postselection of a plugin model on particles this shard has already drawn (`x_new`: a (d, n) device view,
+        fixed in place): the model's own validity test, then redraw rounds from the shard's cloud like
+        LiuWestResampler._plugin_device_draw.  Returns how many stayed invalid after `maxiter` rounds."""
+        bad = (~resampler._plugin_valid(eng, model, x_new)).nonzero(as_tuple=False).reshape(-1)
+        rounds = 1
+        while bad.numel() and rounds < resampler._maxiter:
+            ps0, resampler._postselect = resampler._postselect, False          # (round `rounds`: a plain draw, tested below)
+            try:
+                x_r, _ = resampler._plugin_device_draw(eng, model, updater._x, updater._w, W_local, a, mean, S, int(bad.numel()),
+                                                       seed ^ (0xA0761D6478BD642F * rounds & (2 ** 64 - 1)), epoch)
+            finally:
+                resampler._postselect = ps0
+            x_new[:, bad] = x_r
+            bad = bad[~resampler._plugin_valid(eng, model, x_r)]
+            rounds += 1
+        return int(bad.numel())
 
     def _balanced_sizes(self, n_total):
         G = self.world_size

@@ -25,6 +25,8 @@ from .distributions import ParticleDistribution
 
 __all__ = ["Resampler", "LiuWestResampler"]
 
+_MAX_D = 16          # _native.QSMC_MAX_D: the widest cloud the device samplers take
+
 
 class Resampler(metaclass=abc.ABCMeta):
     @abc.abstractmethod
@@ -145,6 +147,13 @@ class LiuWestResampler(Resampler):
             if defer:                  # stay asynchronous: the count is read at the caller's next sync
                 self._pending_failed = eng
                 n_failed = 0
+        elif self._device_rng and d <= _MAX_D and particle_dist.n_particles <= self._segment_limit:
+            # a model without native kernels (a user plugin) under the device generator: ancestors and kicks from the same
+            # Philox sampler, no validity test of its own; the MODEL's test -- on the device if it has
+            # `are_models_valid_device`, else its NumPy one on a host copy of the new particles -- then redraw rounds
+            self._epoch += 1
+            x_new, n_failed = self._plugin_device_draw(eng, model, x_in, particle_dist._w, norm, a, mean, S, n_particles,
+                                                       self._seed, self._epoch)
         else:
             cdf = eng.cumsum(particle_dist._weights(), norm)
             x_new, n_failed = self._legacy_draw(eng, model, desc, x_in, cdf, a, mean, S, n_particles)
@@ -157,6 +166,45 @@ class LiuWestResampler(Resampler):
         new = ParticleDistribution._from_device(eng, x_new, None, norm=float(n_particles), sumsq=float(n_particles))
         new._canonicalized = bool(self._device_rng and native and canon is not None)
         return new
+
+    @staticmethod
+    def _plugin_valid(eng, model, x):
+        """bool device tensor [n]: the model's own validity test of the SoA particles x (d, n) -- its device hook when it
+        has one, else `are_models_valid` on a host copy (the plugin contract, abstract_model.py:286-300)."""
+        t = eng.torch
+        fn = getattr(model, "are_models_valid_device", None)
+        if fn is not None:
+            ok = fn(x)
+            if not isinstance(ok, t.Tensor) or tuple(ok.shape) != (x.shape[1],):
+                raise TypeError("are_models_valid_device must return a device tensor of shape (n_particles,)")
+            return ok.to(device=x.device, dtype=t.bool)
+        ok = np.asarray(model.are_models_valid(np.ascontiguousarray(x.cpu().numpy().T)), dtype=bool)
+        assert ok.ndim == 1, "are_models_valid returned tensor, expected vector."
+        return eng.to_device(ok)
+
+    def _plugin_device_draw(self, eng, model, x_in, w, norm, a, mean, S, n_out, seed, epoch, out=None):
+        """Liu-West draw of `n_out` particles for a model WITHOUT native kernels, on the device generator.  Round 0 draws
+        every output; each further round redraws (ancestor and kick, like the native device path) the outputs the model
+        declared invalid, from a Philox stream of its own, up to `maxiter` rounds.  Returns (x_new, n_failed); fills
+        `out` ((d, n_out) device view) when given."""
+        from . import _native
+        d = x_in.shape[0]
+        plain = _native.ModelDesc(_native.MODEL_TOMOGRAPHY, d, 0.0, 1, 0)      # (kind only sizes the sampler: no validity test)
+        x_new, _ = eng.lw_resample_philox(plain, False, x_in, w, norm, a, mean, S, n_out, seed, epoch, self._maxiter,
+                                          sync=True, out=out)
+        if not self._postselect or n_out == 0:
+            return x_new, 0
+        bad = (~self._plugin_valid(eng, model, x_new)).nonzero(as_tuple=False).reshape(-1)
+        rounds = 1
+        while bad.numel() and rounds < self._maxiter:
+            k = int(bad.numel())
+            x_r, _ = eng.lw_resample_philox(plain, False, x_in, w, norm, a, mean, S, k,
+                                            seed ^ (0xD1B54A32D192ED03 * rounds & (2 ** 64 - 1)), epoch, self._maxiter,
+                                            sync=True)
+            x_new[:, bad] = x_r
+            bad = bad[~self._plugin_valid(eng, model, x_r)]
+            rounds += 1
+        return x_new, int(bad.numel())
 
     def _expected_redraws(self, particle_dist, eng):
         """How many first tries of the previous resample of THIS cloud failed postselection: what the library is told to

@@ -27,9 +27,10 @@ from .resamplers import LiuWestResampler
 __all__ = ["SMCUpdater"]
 
 _EPS = float(np.spacing(1))
-_NO_STEP = bool(__import__("os").environ.get("QSMC_NO_STEP"))      # (A/B switch: the round-2 per-datum path in Python)
-_NO_FUSED_CANON = bool(__import__("os").environ.get("QSMC_NO_FUSED_CANON"))      # (A/B switch)
-_NO_ADOPT = bool(__import__("os").environ.get("QSMC_NO_ADOPT"))      # (A/B switch: the resampler's own call re-derives a queued resample)
+# test hooks (module attributes the parity tests patch; never read from the environment by the product):
+_NO_STEP = False       # True: `update` takes the Python per-datum path instead of qsmc_step -- the independent form of the C path
+_NO_ADOPT = False      # True: the resampler's own call re-derives a resample qsmc_step has queued
+_NO_FUSED_CANON = False   # True: canonicalize after a d = 16 resample as its own passes, not inside the kick kernel
 _U64 = 2 ** 64 - 1
 
 
@@ -42,8 +43,6 @@ def _as_int_outcome(outcome):
     return int(arr.reshape(-1)[0])
 
 
-_NO_SHARDED_PLAN = bool(__import__("os").environ.get("QSMC_NO_SHARDED_PLAN"))    # (A/B switch: the shard plan and prefix from Python)
-_NO_SHARDED_STEP = bool(__import__("os").environ.get("QSMC_NO_SHARDED_STEP"))    # (A/B switch: a shard's update through the Python path)
 _FROM_STEP = ("moments in the qsmc_step_t",)
 
 
@@ -100,10 +99,11 @@ class SMCUpdater(ParticleDistribution):
         # (a user subclass overriding likelihood / are_models_valid / update_timestep takes the plugin path)
         self._native = native_ok(model)
         self._desc = model._native_desc() if self._native else None
-        self._timestep_identity = self._timestep_is_identity(model)
+        self._timestep_identity = (self._timestep_is_identity(model)
+                                   and (self._native or getattr(model, "update_timestep_device", None) is None))
         # the per-datum C path (qsmc_step): native model; one cloud, or a shard whose per-datum reduction goes through
         # shared memory (the C call then makes that collective too)
-        self._st_exchange = None if (comm is None or _NO_SHARDED_STEP) else comm.step_exchange()
+        self._st_exchange = None if comm is None else comm.step_exchange()
         self._st = _native.Step() if (self._native and not _NO_STEP
                                       and (comm is None or self._st_exchange is not None)) else None
         if self._st is not None:
@@ -122,8 +122,8 @@ class SMCUpdater(ParticleDistribution):
         self._x_spare = None
         # canonicalize after a resample (smc.py:529) done by the resample's own kernels where the library can
         fc = getattr(model, "_native_canonicalize_fused", None)
-        self._fused_canon = (fc(self._eng) if (fc is not None and self._native and self._canonicalize
-                                               and not _NO_FUSED_CANON) else None)
+        self._fused_canon = (fc(self._eng) if (fc is not None and self._native and self._canonicalize and not _NO_FUSED_CANON)
+                             else None)
         self.reset(n_particles)
 
     # ------------------------------------------------------------------ bookkeeping properties
@@ -284,22 +284,44 @@ class SMCUpdater(ParticleDistribution):
 
     def _canonicalize_device(self, rows=slice(None)):
         model = self.model
-        if self._canonicalize_is_identity(model):
+        if self._canonicalize_is_identity(model) and (native_ok(model) or getattr(model, "canonicalize_device", None) is None):
             return                                    # every hot-path model except tomography
         whole = isinstance(rows, slice) and rows == slice(None)
+        dev_fn = None if native_ok(model) else getattr(model, "canonicalize_device", None)
         if native_ok(model) and whole and getattr(model, "_native_canonicalize_ok", lambda: False)():
             model._native_canonicalize_(self._eng, self._x)
+        elif dev_fn is not None and whole:            # device-side plugin hook: the cloud never leaves HBM
+            self._x = self._check_cloud(dev_fn(self._x), "canonicalize_device")
         else:                                         # plugin slow path (plain host arrays: no write-through uploads)
-            locs = self._host_locations()
+            locs = self._host_locations(private=True)
             locs[:, rows] = model.canonicalize(locs[:, rows])
             self._x = self._eng.locs_to_soa(locs)
         self._invalidate()
 
-    def _host_locations(self):
+    def _host_locations(self, private=False):
         """(N, d) bare ndarray copy of the cloud for the library's own host paths and for user model callbacks
         (`likelihood`, `canonicalize`, `update_timestep`): an in-place operation inside a plugin must not trigger a
-        whole-cloud upload per statement, as it would on the write-through snapshot `particle_locations` returns."""
-        return np.ascontiguousarray(self._x.cpu().numpy().T)
+        whole-cloud upload per statement, as it would on the write-through snapshot `particle_locations` returns.
+
+        The copy is kept until the locations change (`_invalidate`): an update moves weights, not particles, so a
+        NumPy-plugin model pays the 8 d N-byte D2H + transpose once per resample, not once per datum.  The kept array is
+        read-only (a plugin that wrote into its `modelparams` argument would silently fork it from the device cloud);
+        `private=True` returns a writable copy the caller owns."""
+        locs = self._host_locs
+        if locs is None:
+            locs = np.ascontiguousarray(self._x.cpu().numpy().T)
+            locs.flags.writeable = False
+            self._host_locs = locs
+        return locs.copy() if private else locs
+
+    def _check_cloud(self, x_new, what):
+        """A device-side plugin hook's returned cloud: float64 (d, N) on this device, made contiguous."""
+        t = self._eng.torch
+        if not isinstance(x_new, t.Tensor) or x_new.dtype != t.float64 or x_new.device != self._x.device \
+                or tuple(x_new.shape) != tuple(self._x.shape):
+            raise TypeError("{} must return a float64 tensor of shape {} on {}".format(
+                what, tuple(self._x.shape), self._x.device))
+        return x_new.contiguous()
 
     # ------------------------------------------------------------------ updates
     def hypothetical_update(self, outcomes, expparams, return_likelihood=False, return_normalization=False):
@@ -338,6 +360,18 @@ class SMCUpdater(ParticleDistribution):
         if self._native:
             return self._eng.likelihood(self._desc, self._x, self.model._native_expparams(expparams),
                                         outcomes.astype(np.int64))
+        dev_fn = getattr(self.model, "likelihood_device", None)
+        if dev_fn is not None:
+            # device-side plugin hook: the model evaluates its likelihood on the (d, N) tensor the cloud lives in -- no
+            # host copy of the cloud, no upload of L
+            t = self._eng.torch
+            L = dev_fn(outcomes, self._x, expparams)
+            n_e = int(np.shape(expparams)[0]) if np.ndim(expparams) else 1
+            if (not isinstance(L, t.Tensor) or L.dtype != t.float64 or L.device != self._x.device
+                    or tuple(L.shape) != (len(outcomes), n_e, self._x.shape[1])):
+                raise TypeError("likelihood_device must return a float64 tensor of shape (n_outcomes, n_experiments, "
+                                "n_particles) = {} on {}".format((len(outcomes), n_e, self._x.shape[1]), self._x.device))
+            return L.contiguous()
         L = np.asarray(self.model.likelihood(outcomes, self._host_locations(), expparams), dtype=np.float64)
         return self._eng.to_device(np.ascontiguousarray(L.transpose(0, 2, 1)))
 
@@ -370,7 +404,7 @@ class SMCUpdater(ParticleDistribution):
             # ancestors, this shard's weight-only prefix (ParticleShardGroup.resample finds both done)
             comm = self._comm
             st.plan_enabled = int(comm.placement == "local" and type(r) is LiuWestResampler
-                                  and getattr(r, "_device_rng", False) and n <= r._segment_limit and not _NO_SHARDED_PLAN)
+                                  and getattr(r, "_device_rng", False) and n <= r._segment_limit)
             if st.plan_enabled:
                 st.plan_seed, st.plan_epoch = comm.seed & _U64, comm._epoch + 1
                 st.plan_prefix_seed = (r._seed + 0x9E3779B97F4A7C15 * (comm.rank + 1)) & _U64
@@ -433,11 +467,9 @@ class SMCUpdater(ParticleDistribution):
         else:
             try:
                 eng.step(self._st_ref, self._desc_ref, ep_ref, _as_int_outcome(outcome))
-            except RuntimeError as e:
-                if "unsupported" in str(e):           # (qsmc_host_allreduce's time-out status)
-                    raise RuntimeError("HostExchange: a peer did not arrive within {} s".format(
-                        self._st_exchange.timeout)) from None
-                raise
+            except _native.PeerTimeoutError:          # (qsmc_host_allreduce's own status: QSMC_ERR_TIMEOUT)
+                raise RuntimeError("HostExchange: a peer did not arrive within {} s".format(
+                    self._st_exchange.timeout)) from None
             self._shard_sums = self._shard_view.copy()       # every shard's sum w' (the next resample plan's input)
             if st.status & _native.STEP_PLAN_READY:
                 self._step_plan = (st.plan_epoch, self._plan_view.copy(), bool(st.status & _native.STEP_PREFIX_QUEUED),
@@ -644,7 +676,7 @@ class SMCUpdater(ParticleDistribution):
         self._w, self._w_alt = w_out, self._w
         self._norm = float(new_norm)
         self._sumsq = float(sumsq)
-        self._invalidate()
+        self._invalidate(locations=False)
         if self._native and n_bad == 0:
             # these weights are exactly what update number `update_gen` of the engine wrote: a resample that
             # follows may take its chunk sums from that kernel's tile sums (resamplers._arm_update_sums)
@@ -667,11 +699,17 @@ class SMCUpdater(ParticleDistribution):
             # a random-walk model with device kernels: the cloud takes its step in place
             step(self, expparams)
             self._moments_cache = None
+            self._host_locs = None
         elif not self._timestep_identity:
-            # plugin slow path: a model that moves particles between data and has no device step -- a user
-            # model, or a decorator over one (DerivedModel forwards update_timestep)
-            locs = self.model.update_timestep(self._host_locations(), expparams)[:, :, 0]
-            self._x = self._eng.locs_to_soa(locs)
+            dev_fn = getattr(self.model, "update_timestep_device", None)
+            if dev_fn is not None and not self._native:
+                # device-side plugin hook: the model moves the cloud where it lives
+                self._x = self._check_cloud(dev_fn(self._x, expparams), "update_timestep_device")
+            else:
+                # plugin slow path: a model that moves particles between data and has no device step -- a user
+                # model, or a decorator over one (DerivedModel forwards update_timestep)
+                locs = self.model.update_timestep(self._host_locations(), expparams)[:, :, 0]
+                self._x = self._eng.locs_to_soa(locs)
             self._invalidate()
 
     def batch_update(self, outcomes, expparams, resample_interval=5):
@@ -768,7 +806,7 @@ class SMCUpdater(ParticleDistribution):
         self._w, self._w_alt = w_out, self._w
         self._norm = float(stats[-1].sum)
         self._sumsq = float(stats[-1].sumsq)
-        self._invalidate()
+        self._invalidate(locations=False)
         # (these weights are what update number `update_gen` -- the window's pass -- wrote: a resample that follows takes its
         #  chunk sums from that kernel's tile sums, resamplers._arm_update_sums)
         self._w_token = eng.update_gen
@@ -788,6 +826,11 @@ class SMCUpdater(ParticleDistribution):
         # the first experiment is translated and queued on its own: the GPU works on its passes while the host translates
         # the rest of the design (records -> C structs, outcome domains: ~10 us per experiment), instead of idling until
         # the whole design has been prepared (qsmc_hypothetical_sums_begin / _collect, round 5)
+        if expparams.shape[0] == 1:
+            # one experiment: nothing to overlap the translation of a "rest" with -- one call, one wait
+            sums = eng.hypothetical_sums_multi(self._desc, self._x, self._w, self._norm, model._native_expparams(expparams),
+                                               [dom.values for dom in model.domain(expparams)], shift, what)
+            return self._reduce_design_sums(sums)
         head = expparams[:1]
         jobs = [eng.hypothetical_sums_begin(self._desc, self._x, self._w, self._norm, model._native_expparams(head),
                                             [dom.values for dom in model.domain(head)], shift, what)]
@@ -798,7 +841,9 @@ class SMCUpdater(ParticleDistribution):
                                                         [dom.values for dom in model.domain(rest)], shift, what))
         finally:
             eng.hypothetical_sums_collect()          # (also after an error in the second half: nothing stays in flight)
-        sums = [r for job in jobs for r in job.rows]
+        return self._reduce_design_sums([r for job in jobs for r in job.rows])
+
+    def _reduce_design_sums(self, sums):
         if self._comm is not None:
             # every entry is a sum over particles with the GLOBAL normaliser and a shift all ranks agree on (the global
             # mean): additive over the shards (columns nobody asked for are NaN on every shard); one reduction per design

@@ -77,6 +77,17 @@ def test_launcherless_shared_gpu(n_ranks):
     assert leg["value"] == pytest.approx(ss["particles_total"] * 12 / (leg["ms_per_step"] * 1e-3 * 12), rel=1e-9)
     assert leg["resamples"] >= 1 and leg["rebalances"] >= 0 and abs(leg["posterior_mean"] - 0.3) < 0.2
     assert "skipped" in ss["transports"]["rccl"]
+    # round 6: the same data through batch_update windows on the sharded updater (one reduction per window), beside update()
+    for interval in (5, 8):
+        b = ss["batch_update_interval_%d" % interval]
+        assert b == leg["batch_update_interval_%d" % interval] and "error" not in b, b
+        assert b["value"] > 0 and b["data"] == 12 and b["windows"] == -(-12 // interval)
+        assert b["value"] == pytest.approx(ss["particles_total"] * 12 / (b["ms_per_datum"] * 1e-3 * 12), rel=1e-9)
+        assert abs(b["posterior_mean"] - 0.3) < 0.2 and b["vs_update"] == pytest.approx(b["value"] / leg["value"])
+    # ... what `auto` measured (nothing here: one shared device), and the headline workload over its whole schedule
+    assert "skipped" in line["config"]["transport_probe"]
+    h200 = line["headline_200_steps"]
+    assert h200["steps"] == 200 and h200["value"] > 0 and h200["resamples"] >= 20 and abs(h200["posterior_mean"] - 0.3) < 1e-3
 
 
 @pytest.mark.gpu
@@ -131,6 +142,27 @@ def test_driver_command_headline_is_steady_state():
     assert line["value"] == pytest.approx(1e7 * 20 / (line["ms_per_step"] * 1e-3 * 20), rel=1e-9)
     assert line["roofline"]["bound"] == "hbm" and 0.3 < line["roofline"]["frac"] < 1.0
     assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["value"] > 0
+    # round 6: C2's own 200-datum schedule (70 resamples) rides in the driver's 20-step line
+    h200 = line["headline_200_steps"]
+    assert h200["steps"] == 200 and 60 <= h200["resamples"] <= 80 and abs(h200["posterior_mean"] - 0.3) < 1e-3
+    assert h200["value"] == pytest.approx(1e7 * 200 / (h200["ms_per_step"] * 1e-3 * 200), rel=1e-9)
+    assert 0.5 * line["value"] < h200["value"] < 1.2 * line["value"]
+
+
+@pytest.mark.gpu
+def test_shard_preview_batch_update_legs():
+    """One rank's share of the strong-scaling configuration (1e7 / 8 particles) on one GPU: update() and, beside it, the
+    same data through batch_update windows of 5 and 8 -- the path that amortises the per-datum fixed cost."""
+    r = _run_bench(["--gpus", "1", "--steps", "40", "--warmup", "5", "--only", "shard_preview"], {})
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    sp = _one_json_line(r.stdout)["strong_scaling_shard_preview"]
+    assert sp["particles"] == 1250000 and sp["steps"] == 40 and sp["value"] > 0
+    for interval in (5, 8):
+        b = sp["batch_update_interval_%d" % interval]
+        assert "error" not in b, b
+        assert b["data"] == 40 and b["windows"] == 40 // interval and b["resamples"] >= 1
+        assert abs(b["posterior_mean"] - sp["posterior_mean"]) < 1e-2
+        assert b["vs_update"] > 1.0, (b, sp["value"])                # windows beat per-datum updates on a shard this small
 
 
 @pytest.mark.gpu

@@ -25,6 +25,14 @@ def eng(qi):
     return get_engine()
 
 
+@pytest.fixture(autouse=True)
+def _reset_test_hooks(qi):
+    """qsmc_test_hook switches are process-wide: whatever a test set is cleared behind it."""
+    yield
+    for name in qi._native.HOOKS:
+        qi._native.test_hook(name, 5.0 if name == "poisson_margin" else 0.0)
+
+
 class Replay:
     """Monkeypatches np.random.random and provides `kernel` so the product consumes recorded draws."""
 
@@ -499,10 +507,10 @@ def test_liu_west_philox_bucketed_vs_oracle(qi, eng, case):
 @pytest.mark.parametrize("margin", ["0", "-3"])
 def test_bucketed_counts_removal_branch(qi, eng, margin, monkeypatch):
     """The chunk counts' rare branch -- the Poisson total overshoots n_out and the surplus is removed item by
-    item -- made common by shrinking the safety margin (QSMC_POISSON_MARGIN, read per call): same particles as the
+    item -- made common by shrinking the safety margin (qsmc_test_hook QSMC_HOOK_POISSON_MARGIN): same particles as the
     oracle twin run with that margin, exact total, valid outputs."""
     import philox as ph
-    monkeypatch.setenv("QSMC_POISSON_MARGIN", margin)
+    qi._native.test_hook("poisson_margin", float(margin))       # (reset after the test: _reset_test_hooks)
     rs = np.random.RandomState(21)
     n, n_out = 50021, 40000
     x = np.abs(0.04 + 0.05 * rs.randn(n, 1))
@@ -557,7 +565,7 @@ def test_every_output_slot_is_written(qi, eng, monkeypatch):
             w[: n_in // 2] = 0.0
         if trial % 4 == 1:
             w *= np.exp(-0.5 * ((np.arange(n_in) / n_in - 0.7) / 0.003) ** 2) + 1e-300
-        monkeypatch.setenv("QSMC_POISSON_MARGIN", ["5", "5", "0", "-4"][trial % 4])
+        qi._native.test_hook("poisson_margin", [5.0, 5.0, 0.0, -4.0][trial % 4])
         x = eng.to_device(rs.randn(4, n_in))
         wd = eng.to_device(w)
         norm = float(w.sum())
@@ -1289,8 +1297,8 @@ def test_batch_update_fused_vs_loop(qi, model_name, interval):
 def test_window_kernels_round5_same_bits(qi, eng, monkeypatch):
     """Round 5's two window kernels against the forms they replace, on ONE window from identical state:
     * SimplePrecession / SimpleInversion: the transposed loop nest of k_update_multi (eight particles loaded, then datum by
-      datum; one range test per tile; the outcome select as an fma) against its general path (QSMC_MULTI_GENERIC=1, read
-      per call): weights AND per-datum sums bit for bit -- for K = 2 ... 8, ragged clouds, explicit and implicit weights,
+      datum; one range test per tile; the outcome select as an fma) against its general path (qsmc_test_hook
+      QSMC_HOOK_MULTI_GENERIC): weights AND per-datum sums bit for bit -- for K = 2 ... 8, ragged clouds, explicit and implicit weights,
       a nonzero reference frequency, and a time so large that a tile falls back to the general path;
     * 2-qubit tomography: the sparse-row window (k_update_multi_tomo: each datum reads the rows its measurement vector
       touches; vectors of two to four entries, i.e. both instantiations) against the chain it stands for, formed on the
@@ -1315,14 +1323,11 @@ def test_window_kernels_round5_same_bits(qi, eng, monkeypatch):
             outs.append(int(rs.randint(0, 2)))
         res = []
         for generic in (False, True):
-            if generic:
-                monkeypatch.setenv("QSMC_MULTI_GENERIC", "1")
-            else:
-                monkeypatch.delenv("QSMC_MULTI_GENERIC", raising=False)
+            qi._native.test_hook("multi_generic", generic)
             w_out = eng.empty(n)
             stats, m1, m2 = eng.update_multi(desc, x, w, w_out, norm, exps, outs)
             res.append((w_out.cpu().numpy().copy(), [(s_.sum, s_.sumsq, s_.n_bad, s_.min) for s_ in stats], np.array(m1), np.array(m2)))
-        monkeypatch.delenv("QSMC_MULTI_GENERIC", raising=False)
+        qi._native.test_hook("multi_generic", False)
         (wa, sa, m1a, m2a), (wb, sb, m1b, m2b) = res
         np.testing.assert_array_equal(wa, wb, err_msg=str((n, K)))
         assert sa == sb, (n, K, sa[:2], sb[:2])
@@ -2790,7 +2795,7 @@ def test_reserve_and_fuse_rule(qi, eng):
 
 def test_sparse_tomography_update_same_bits():
     """The tomography update reads only the rows its measurement vector touches (k_update_tomo<NNZ>, NNZ <= 4; round 4).
-    Against the dense kernel (QSMC_TOMO_DENSE_UPDATE=1, read once per process: subprocesses): weights, sums and the
+    Against the dense kernel (QSMC_TEST_HOOKS=tomo_dense=1 in a subprocess: qsmc_test_hook): weights, sums and the
     trajectories of a resampling updater bit for bit, for 1-4 nonzero entries, a dense vector (which takes the dense
     kernel either way), one- and two-qubit bases."""
     import hashlib
@@ -2827,7 +2832,7 @@ for nq, n in ((2, 70_001), (1, 40_000)):
 print("digest", h.hexdigest())
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for env_extra in ({}, {"QSMC_TOMO_DENSE_UPDATE": "1"}):
+    for env_extra in ({}, {"QSMC_TEST_HOOKS": "tomo_dense=1"}):
         env = dict(os.environ, **env_extra)
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
@@ -2839,8 +2844,8 @@ print("digest", h.hexdigest())
 def test_design_chain_kernel_vs_lanes_kernel_edges():
     """bayes_risk / expected_information_gain of binomial experiments through k_hyp_sums_chain2 (the geometric walk from
     both ends of a pass, binomial coefficients applied on the host, only the columns the caller reads; round 4) against
-    k_hyp_sums_lanes (one exponential per particle and outcome; QSMC_HYP_NO_CHAIN=1, read once per process:
-    subprocesses), on clouds with the cases the walk
+    the thread-per-particle kernel k_hyp_sums (every outcome's pmf on its own, eight outcomes a pass;
+    QSMC_TEST_HOOKS=hyp_no_chain=1 in a subprocess: qsmc_test_hook), on clouds with the cases the walk
     folds into its start value: pr1 exactly 0 (omega = 0), weights that are exactly 0, very small and very large pr1, for
     n_meas from 1 to 200 (integer-power and exponential start values; one to eight passes, queued over the experiments of
     a call and collected after one wait) and designs that mix n_meas; and for Binomial(RB), d = 3 (eight slots a
@@ -2884,7 +2889,7 @@ for n_meas in (1, 2, 12, 13, 14, 25, 26, 40, 64, 65, 100, (5, 25, 70), (200, 3, 
             assert part.shape == full.shape
             scale = np.abs(full).max()
             assert np.allclose(part[:, cols], full[:, cols], rtol=1e-10, atol=1e-12 * scale), (n_meas, what)
-# d = 3: Binomial(RB) -- the walk against the thread-per-particle kernel (k_hyp_sums; the lanes kernel is d = 1 only)
+# d = 3: Binomial(RB)
 xr = np.column_stack([0.8 + 0.2 * rs.random_sample(20_000), 0.5 * rs.random_sample(20_000), 0.5 * rs.random_sample(20_000)])
 xr[:40, 0] = 1.0
 xr[40:80, 1] = 0.0
@@ -2905,7 +2910,7 @@ np.save(sys.argv[1], np.concatenate(out))
     import tempfile
     res = []
     with tempfile.TemporaryDirectory() as td:
-        for tag, env_extra in (("chain2", {}), ("lanes", {"QSMC_HYP_NO_CHAIN": "1"})):
+        for tag, env_extra in (("chain2", {}), ("plain", {"QSMC_TEST_HOOKS": "hyp_no_chain=1"})):
             path = os.path.join(td, tag + ".npy")
             r = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True,
                                env=dict(os.environ, **env_extra), timeout=600)
@@ -2920,7 +2925,7 @@ def test_small_redraw_queue_same_particles():
     """A resample whose postselection queue holds only a few outputs (precession: omega > 0 bites at the early resamples)
     redraws them chunk by chunk in LDS instead of materialising the global CDF (k_bucket_redraw's small form, round 4).
     Same Philox blocks, same CDF entries: the clouds of whole trajectories are bit-identical to the global form
-    (QSMC_REDRAW_NO_SMALL=1, read once per process: subprocesses), for d = 1, the binomial model and RB without a bank."""
+    (QSMC_TEST_HOOKS=redraw_no_small=1 in a subprocess: qsmc_test_hook), for d = 1, the binomial model and RB without a bank."""
     import subprocess
     import sys
     code = r'''
@@ -2955,7 +2960,7 @@ print("redraws", redraws)
 print("digest", h.hexdigest())
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for env_extra in ({}, {"QSMC_REDRAW_NO_SMALL": "1"}):
+    for env_extra in ({}, {"QSMC_TEST_HOOKS": "redraw_no_small=1"}):
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **env_extra),
                            timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]

@@ -495,6 +495,89 @@ def test_sharded_fast_paths_two_ranks_one_gpu(tmp_path):
     _run("_check_sharded_fast_paths", tmp_path, world=2)
 
 
+def _check_sharded_plugin_model(comm, rank, world, tmpdir):
+    """Round 6: a model WITHOUT native kernels shards too (the reference's DirectViewParallelizedModel shards any model's
+    likelihood, parallel.py:196-224).  Two ranks against ONE updater holding the union cloud: the updates agree to
+    rounding; a resample conserves the global count, leaves only valid particles and the same global estimate on every
+    rank, where the single cloud's is -- for the NumPy plugin and for the torch (device-hook) one."""
+    import warnings
+    import torch
+    import qinfer_amd as qi
+    from test_plugin_device import plugin_models, t2_data
+    torch.cuda.set_device(0)
+    NumpyT2, TorchT2 = plugin_models(qi)
+    n_local = 20000
+    rs = np.random.RandomState(4)
+    x_all = np.column_stack([1.5 * rs.random_sample(n_local * world), 0.2 * rs.random_sample(n_local * world)])
+
+    class Slice(qi.Distribution):
+        n_rvs = 2
+
+        def __init__(self, lo, hi):
+            self.lo, self.hi = lo, hi
+
+        def sample(self, n=1):
+            assert n == self.hi - self.lo
+            return x_all[self.lo:self.hi].copy()
+    outcomes, eps = t2_data(30, seed=2)
+    for cls in (NumpyT2, TorchT2):
+        model = cls()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            shard = qi.SMCUpdater(model, n_local, Slice(rank * n_local, (rank + 1) * n_local), device_rng=True, seed=5,
+                                  comm=comm, resample_thresh=0.0)
+            whole = qi.SMCUpdater(cls(), n_local * world, Slice(0, n_local * world), device_rng=True, seed=5,
+                                  resample_thresh=0.0)
+            assert not shard._native and shard._st is None
+            for k in range(12):
+                shard.update(int(outcomes[k]), eps[k:k + 1])
+                whole.update(int(outcomes[k]), eps[k:k + 1])
+            np.testing.assert_allclose(np.ravel(shard.normalization_record), np.ravel(whole.normalization_record), rtol=1e-12)
+            np.testing.assert_allclose(shard.n_ess, whole.n_ess, rtol=1e-11)
+            np.testing.assert_allclose(shard.est_mean(), whole.est_mean(), rtol=0, atol=1e-13)
+            np.testing.assert_allclose(shard.est_covariance_mtx(), whole.est_covariance_mtx(), rtol=1e-7, atol=1e-18)
+            mean0, sd0 = whole.est_mean(), np.sqrt(np.diag(whole.est_covariance_mtx()))
+            shard.resample()                                             # used to raise NotImplementedError
+            whole.resample()
+            assert "plugin model" in comm.last_resample_path, comm.last_resample_path
+            sizes = comm.gather_rows(np.array([float(shard.n_particles)]))[:, 0]
+            assert sizes.sum() == n_local * world == shard.n_particles_global
+            locs = np.asarray(shard.particle_locations)
+            assert (locs >= 0).all()
+            # the resampled global estimate sits where the single cloud's resample put it (Monte Carlo error of 4e4 draws;
+            # both carry the same small upward push of 1/T2 from postselection at the x >= 0 boundary), and near where it was
+            mean1, sd1 = whole.est_mean(), np.sqrt(np.diag(whole.est_covariance_mtx()))
+            assert np.all(np.abs(shard.est_mean() - mean1) < 0.03 * sd0), (shard.est_mean(), mean1, mean0, sd0)
+            assert np.all(np.abs(np.sqrt(np.diag(shard.est_covariance_mtx())) / sd1 - 1) < 0.03)
+            assert np.all(np.abs(shard.est_mean() - mean0) < 0.15 * sd0)
+            for k in range(12, 30):
+                shard.update(int(outcomes[k]), eps[k:k + 1])
+                whole.update(int(outcomes[k]), eps[k:k + 1])
+            sd = np.sqrt(np.diag(whole.est_covariance_mtx()))
+            assert np.all(np.abs(shard.est_mean() - whole.est_mean()) < 0.1 * sd)
+        rec = np.concatenate([[shard.resample_count, shard.n_ess], np.ravel(shard.normalization_record), shard.est_mean()])
+        rows = comm.gather_rows(torch.from_numpy(rec))
+        for r in range(1, world):
+            assert np.array_equal(rows[0], rows[r]), "ranks disagree on the global quantities"
+    # rebalance path (finished rows travel): every resample moves particles, the plugin's rounds run before the exchange
+    from qinfer_amd.parallel import ParticleShardGroup
+    comm_r = ParticleShardGroup(seed=99, rebalance_tol=-1.0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        shard = qi.SMCUpdater(TorchT2(), n_local, Slice(rank * n_local, (rank + 1) * n_local), device_rng=True, seed=5,
+                              comm=comm_r)
+        for k in range(30):
+            shard.update(int(outcomes[k]), eps[k:k + 1])
+        assert shard.resample_count > 0 and comm_r.n_rebalances == shard.resample_count
+        assert shard.n_particles == n_local and (np.asarray(shard.particle_locations) >= 0).all()
+    comm_r.close()
+
+
+@pytest.mark.gpu
+def test_sharded_plugin_model_two_ranks_one_gpu(tmp_path):
+    _run("_check_sharded_plugin_model", tmp_path, world=2)
+
+
 def _check_sharded_resample_vs_twin(comm, rank, world, tmpdir):
     """The sharded Liu-West step of configs 4 and 5 (RB, 2-qubit tomography) on `world` ranks, particle for particle
     against the oracle on IDENTICAL Philox streams: the shard totals are the shared-seed host multinomial, and each
@@ -774,3 +857,55 @@ def _rccl_transport_world1(rank, port, tmpdir):
 def test_rccl_transport_world1(tmp_path):
     import torch.multiprocessing as mp
     mp.spawn(_rccl_transport_world1, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+
+
+def _auto_probe_world1(rank, port, tmpdir):
+    """transport="auto" as a MEASURED choice (round 6): with every rank on a GPU of its own the group times the per-datum
+    reduction under shared memory and under RCCL at creation and keeps the faster -- forced here for the one rank a
+    1-GPU box has (QSMC_TRANSPORT_PROBE=force); whichever wins, a run under it equals a run under the other bit for bit."""
+    for p in (os.path.join(ROOT, "python-qinfer_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import warnings
+    import torch
+    import torch.distributed as dist
+    import qinfer_amd as qi
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from qinfer_amd.parallel import ParticleShardGroup
+    plain = ParticleShardGroup(seed=1234)                        # one rank, not forced: nothing measured, shared memory
+    assert plain.transport_probe is None and plain.transport_name == "host shared memory"
+    os.environ["QSMC_TRANSPORT_PROBE"] = "force"
+    comm = ParticleShardGroup(seed=1234)
+    os.environ.pop("QSMC_TRANSPORT_PROBE")
+    pr = comm.transport_probe
+    assert pr is not None and "rccl_error" not in pr, pr
+    assert pr["chosen"] in ("shm", "rccl") and pr["same_bits"] and pr["ranks"] == 1
+    assert 0 < pr["shm_us"] < 1e4 and 0 < pr["rccl_us"] < 1e4, pr
+    assert pr["chosen"] == ("rccl" if pr["rccl_us"] < pr["shm_us"] else "shm")
+    assert (comm.transport == "rccl") == (pr["chosen"] == "rccl")
+    assert comm._epoch == 0                                       # the probe clouds never resampled: the plan stream is untouched
+    assert ParticleShardGroup(seed=1, probe=False).transport_probe is None
+    ts = (9 / 8) ** np.arange(40.0)
+    rs = np.random.RandomState(0)
+    outcomes = (rs.random_sample(40) >= np.cos(0.3 * ts / 2) ** 2).astype(int)
+    recs = []
+    for c in (comm, plain):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            upd = qi.SMCUpdater(qi.SimplePrecessionModel(), 50000, qi.UniformDistribution([0, 1]), device_rng=True,
+                                seed=5, comm=c)
+            for k in range(40):
+                upd.update(int(outcomes[k]), ts[k:k + 1])
+        recs.append(np.array([upd.resample_count, upd.n_ess] + list(np.ravel(upd.normalization_record)) + list(upd.est_mean())))
+    np.testing.assert_array_equal(recs[0], recs[1])
+    comm.close()
+    plain.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_transport_auto_is_measured_world1(tmp_path):
+    import torch.multiprocessing as mp
+    mp.spawn(_auto_probe_world1, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)

@@ -1,0 +1,206 @@
+"""Round 6: the device-side plugin hooks of a user model (`likelihood_device`, `are_models_valid_device`,
+`update_timestep_device`, `canonicalize_device`: qinfer_amd/abstract_model.py) and the host copy of the cloud a
+NumPy-plugin model is served from (kept between resamples, not re-made per datum).
+
+The contract these stand for is the reference's `Model.likelihood` / `are_models_valid` / `update_timestep` /
+`canonicalize` (abstract_model.py:444-468, 286-300, 302-330, 332-352); the toy model is the reference's
+`UnknownT2Model` (test_models.py:222-259) restated three ways: native kernels, NumPy plugin, torch plugin."""
+import os
+import sys
+import warnings
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "python-qinfer_amd"))
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def qi():
+    import qinfer_amd
+    return qinfer_amd
+
+
+def plugin_models(qi):
+    class NumpyT2(qi.FiniteOutcomeModel):
+        """UnknownT2Model as a user would write it against the reference: NumPy in, NumPy out."""
+        n_modelparams = 2
+        expparams_dtype = [('t', 'float')]
+        is_n_outcomes_constant = True
+
+        def n_outcomes(self, expparams):
+            return 2
+
+        def are_models_valid(self, modelparams):
+            return np.all(modelparams >= 0, axis=1)
+
+        def likelihood(self, outcomes, modelparams, expparams):
+            super().likelihood(outcomes, modelparams, expparams)
+            t = np.asarray(expparams['t'], dtype=float)[None, :]
+            e = np.exp(-t * modelparams[:, 1:2])
+            pr0 = e * np.cos(modelparams[:, 0:1] * t / 2) ** 2 + (1 - e) / 2
+            return qi.FiniteOutcomeModel.pr0_to_likelihood_array(outcomes, pr0)
+
+    class TorchT2(NumpyT2):
+        """The same model with the device hooks: the cloud never leaves HBM."""
+
+        def likelihood_device(self, outcomes, x_dev, expparams):
+            import torch
+            self.count_likelihood_calls(len(outcomes), x_dev.shape[1], expparams.shape[0])
+            t = torch.as_tensor(np.asarray(expparams['t'], dtype=float), device=x_dev.device)[:, None]
+            e = torch.exp(-t * x_dev[1][None, :])
+            pr0 = e * torch.cos(x_dev[0][None, :] * t / 2) ** 2 + (1 - e) / 2
+            return torch.stack([pr0 if int(o) == 0 else 1 - pr0 for o in outcomes])
+
+        def are_models_valid_device(self, x_dev):
+            return (x_dev >= 0).all(dim=0)
+    return NumpyT2, TorchT2
+
+
+def t2_data(n_exp=40, seed=0):
+    rs = np.random.RandomState(seed)
+    ts = np.linspace(0.5, 12.0, n_exp)
+    omega, t2inv = 0.7, 0.05
+    e = np.exp(-ts * t2inv)
+    pr0 = e * np.cos(omega * ts / 2) ** 2 + (1 - e) / 2
+    outcomes = (rs.random_sample(n_exp) >= pr0).astype(int)
+    eps = np.array([(t,) for t in ts], dtype=[('t', 'float')])
+    return outcomes, eps
+
+
+def prior(qi):
+    return qi.UniformDistribution([[0.0, 1.5], [0.0, 0.2]])
+
+
+def test_torch_plugin_equals_numpy_plugin_and_native(qi):
+    """Same seeds, legacy RNG (every draw from np.random, as the reference): the torch plugin, the NumPy plugin and the
+    native kernels walk the same trajectory (rtol 1e-12 on the per-datum normalisations and n_ess, 1e-10 on the mean)."""
+    NumpyT2, TorchT2 = plugin_models(qi)
+    outcomes, eps = t2_data()
+    runs = {}
+    for name, model in (("numpy", NumpyT2()), ("torch", TorchT2()), ("native", qi.UnknownT2Model())):
+        np.random.seed(11)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            upd = qi.SMCUpdater(model, 3000, prior(qi))
+            ess = []
+            for k in range(len(outcomes)):
+                upd.update(int(outcomes[k]), eps[k:k + 1])
+                ess.append(float(upd.n_ess))
+        runs[name] = (np.ravel(upd.normalization_record), np.array(ess), upd.est_mean(), upd.resample_count, model.call_count)
+    assert runs["torch"][3] == runs["numpy"][3] == runs["native"][3] > 0
+    for other in ("torch", "native"):
+        np.testing.assert_allclose(runs[other][0], runs["numpy"][0], rtol=1e-12)
+        np.testing.assert_allclose(runs[other][1], runs["numpy"][1], rtol=1e-10)
+        np.testing.assert_allclose(runs[other][2], runs["numpy"][2], rtol=1e-10)
+    assert runs["torch"][4] == runs["numpy"][4] == 3000 * len(outcomes)      # call_count kept by the device hook too
+
+
+def test_no_whole_cloud_host_copy_per_datum(qi, monkeypatch):
+    """NumPy plugin: one D2H of the cloud per resample, not per datum; torch plugin: none at all."""
+    import torch
+    NumpyT2, TorchT2 = plugin_models(qi)
+    outcomes, eps = t2_data(12)
+    n = 5000
+    big = []
+    real_cpu = torch.Tensor.cpu
+
+    def counting_cpu(self, *a, **k):
+        if self.numel() >= n:
+            big.append(tuple(self.shape))
+        return real_cpu(self, *a, **k)
+    monkeypatch.setattr(torch.Tensor, "cpu", counting_cpu)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        np.random.seed(1)
+        upd = qi.SMCUpdater(NumpyT2(), n, prior(qi), resample_thresh=0.0)
+        del big[:]
+        for k in range(12):
+            upd.update(int(outcomes[k]), eps[k:k + 1])
+        assert len(big) == 1, big                                   # the first datum's copy serves all twelve
+        upd.resample()                                              # the cloud moved: one more copy, at the next datum
+        del big[:]
+        upd.update(int(outcomes[0]), eps[0:1])
+        upd.update(int(outcomes[1]), eps[1:2])
+        assert len(big) == 1, big
+        # the kept copy is read-only: a plugin writing into its argument fails loudly instead of forking the cloud
+        with pytest.raises(ValueError):
+            upd._host_locations()[0, 0] = 1.0
+        np.random.seed(1)
+        upd_t = qi.SMCUpdater(TorchT2(), n, prior(qi), resample_thresh=0.0)
+        del big[:]
+        for k in range(12):
+            upd_t.update(int(outcomes[k]), eps[k:k + 1])
+        assert big == []
+    np.testing.assert_allclose(np.ravel(upd_t.normalization_record), np.ravel(upd.normalization_record)[:12], rtol=1e-12)
+
+
+def test_torch_plugin_device_rng_resample(qi):
+    """Device generator + a plugin model: the Philox sampler draws, the model's own (device) validity test drives the
+    redraw rounds -- every particle valid afterwards, the posterior where the native model's is."""
+    NumpyT2, TorchT2 = plugin_models(qi)
+    outcomes, eps = t2_data(60, seed=3)
+    n = 40000
+    means = {}
+    for name, model in (("torch", TorchT2()), ("numpy", NumpyT2()), ("native", qi.UnknownT2Model())):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            upd = qi.SMCUpdater(model, n, prior(qi), device_rng=True, seed=7)
+            for k in range(len(outcomes)):
+                upd.update(int(outcomes[k]), eps[k:k + 1])
+        assert upd.resample_count > 0
+        locs = np.asarray(upd.particle_locations)
+        assert locs.shape == (n, 2) and (locs >= 0).all()
+        means[name] = (upd.est_mean(), np.sqrt(np.diag(upd.est_covariance_mtx())), upd.resample_count)
+    for other in ("torch", "numpy"):
+        # (different Philox draws than the native sampler's in-thread redraws: statistical agreement, in posterior sigmas)
+        assert np.all(np.abs(means[other][0] - means["native"][0]) < 0.3 * means["native"][1]), means
+        assert abs(means[other][2] - means["native"][2]) <= 2, means
+    # a prior hugging the boundary: most first tries of the kick are invalid for the second parameter, the rounds fix them
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        upd = qi.SMCUpdater(TorchT2(), 20000, qi.UniformDistribution([[0.6, 0.8], [0.0, 1e-3]]), device_rng=True, seed=2,
+                            resampler=qi.LiuWestResampler(a=0.5, device_rng=True, seed=2))
+        upd.update(0, eps[0:1])
+        upd.resample()
+        locs = np.asarray(upd.particle_locations)
+        assert (locs >= 0).all() and locs.shape == (20000, 2)
+
+
+def test_timestep_and_canonicalize_device_hooks(qi):
+    NumpyT2, TorchT2 = plugin_models(qi)
+
+    class Moving(TorchT2):
+        def update_timestep_device(self, x_dev, expparams):
+            import torch
+            return x_dev + torch.tensor([[0.01], [0.0]], dtype=x_dev.dtype, device=x_dev.device)
+
+        def canonicalize_device(self, x_dev):
+            out = x_dev.clone()
+            out[1].clamp_(min=0.01)
+            return out
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        np.random.seed(5)
+        upd = qi.SMCUpdater(Moving(), 1000, prior(qi))
+        assert float(np.asarray(upd.particle_locations)[:, 1].min()) >= 0.01       # reset() canonicalized on the device
+        m0 = upd.est_mean()[0]
+        ep0 = np.array([(0.0,)], dtype=[('t', 'float')])
+        upd.update(0, ep0, check_for_resample=False)                              # t = 0: likelihood 1 / 2 .. 1 for everyone
+        np.testing.assert_allclose(upd.est_mean()[0], m0 + 0.01, rtol=1e-12)
+
+
+def test_likelihood_device_shape_is_checked(qi):
+    NumpyT2, TorchT2 = plugin_models(qi)
+
+    class Wrong(TorchT2):
+        def likelihood_device(self, outcomes, x_dev, expparams):
+            return super().likelihood_device(outcomes, x_dev, expparams).transpose(1, 2)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        upd = qi.SMCUpdater(Wrong(), 100, prior(qi))
+        with pytest.raises(TypeError):
+            upd.update(0, np.array([(1.0,)], dtype=[('t', 'float')]))
