@@ -451,6 +451,8 @@ def plugin_paths(qi, eng, torch, n=10_000_000, n_data=40):
     """The qinfer.Model plugin surface at the headline cloud size (abstract_model.py:444-468): UnknownT2Model
     (test_models.py:222-259; two parameters) served three ways through the same SMCUpdater.update loop --
       native        the library's own kernels (k_update_fused<UNKNOWN_T2> + the d = 2 sampler);
+      hip_plugin    a user model WITHOUT native kernels that states its likelihood as HIP device source (`likelihood_hip`):
+                    hiprtc compiles it into the fused update kernel (csrc/kernels/user_jit.hpp) -- one pass per datum;
       torch_plugin  a user model WITHOUT native kernels that defines `likelihood_device` / `are_models_valid_device`
                     (eager torch on the (d, N) tensor the cloud lives in: no host copy; the update is qsmc_update_from_
                     likelihood, the resample the Philox sampler + the model's own validity test);
@@ -489,6 +491,16 @@ def plugin_paths(qi, eng, torch, n=10_000_000, n_data=40):
 
         def are_models_valid_device(self, x_dev):
             return (x_dev >= 0).all(dim=0)
+    class HipT2(NumpyT2):
+        likelihood_hip = r"""
+__device__ double likelihood(const double *x, const double *ep, long long outcome) {
+    const double t = ep[0], e = exp(-t * x[1]), c = cos(x[0] * t / 2);
+    const double pr0 = e * (c * c) + (1 - e) / 2;
+    return outcome == 0 ? pr0 : 1 - pr0;
+}
+#define QSMC_USER_HAS_VALID 1
+__device__ bool valid(const double *x) { return x[0] >= 0 && x[1] >= 0; }
+"""
     rs = np.random.RandomState(0)
     ts = np.linspace(0.5, 14.0, n_data)
     e = np.exp(-ts * 0.05)
@@ -496,8 +508,8 @@ def plugin_paths(qi, eng, torch, n=10_000_000, n_data=40):
     eps = np.array([(t,) for t in ts], dtype=[('t', 'float')])
     res = {"workload": "UnknownT2Model (omega, 1/T2), %.0e particles, %d data t = 0.5 .. 14, prior U[0, 1.5] x U[0, 0.2], "
                        "Liu-West a = 0.98, device RNG; SMCUpdater.update per datum" % (n, n_data)}
-    for key, model, k_data in (("native", qi.UnknownT2Model(), n_data), ("torch_plugin", TorchT2(), n_data),
-                               ("numpy_plugin", NumpyT2(), 6)):
+    for key, model, k_data in (("native", qi.UnknownT2Model(), n_data), ("hip_plugin", HipT2(), n_data),
+                               ("torch_plugin", TorchT2(), n_data), ("numpy_plugin", NumpyT2(), 6)):
         upd = qi.SMCUpdater(model, n, qi.UniformDistribution([[0.0, 1.5], [0.0, 0.2]]), device_rng=True, seed=0)
         for k in range(min(k_data, 12)):                        # untimed: allocator, first launches (incl. one resample)
             upd.update(int(outs[k]), eps[k:k + 1])
@@ -515,9 +527,12 @@ def plugin_paths(qi, eng, torch, n=10_000_000, n_data=40):
                     "posterior_mean": [float(v) for v in upd.est_mean()]}
         del upd
         torch.cuda.empty_cache()
+    res["hip_plugin"]["vs_native"] = res["hip_plugin"]["ms_per_datum"] / res["native"]["ms_per_datum"]
     res["torch_plugin"]["vs_native"] = res["torch_plugin"]["ms_per_datum"] / res["native"]["ms_per_datum"]
     res["numpy_plugin"]["vs_native"] = res["numpy_plugin"]["ms_per_datum"] / res["native"]["ms_per_datum"]
-    res["note"] = ("torch_plugin: eight eager elementwise torch kernels per datum (each a pass over 80-240 MB) + the weight "
+    res["note"] = ("hip_plugin: the model's own device function inlined into one fused pass (32 B per particle), moments and "
+                   "sums in the same pass; the resample runs on the Philox sampler with the model's compiled valid(); "
+                   "torch_plugin: eight eager elementwise torch kernels per datum (each a pass over 80-240 MB) + the weight "
                    "update pass, against ONE fused pass of 32 B per particle for the native kernel")
     return res
 

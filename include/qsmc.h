@@ -335,6 +335,34 @@ int qsmc_hypothetical_sums_begin(qsmc_handle_t h, const qsmc_model_t *model,
                                  const double *shift, int32_t what, double *out_host, qsmc_stream_t stream);
 int qsmc_hypothetical_sums_collect(qsmc_handle_t h, qsmc_stream_t stream);
 
+/* ---- user models compiled at run time ------------------------------------------------------------------------------------
+ * The plugin contract Model.likelihood(outcomes, modelparams, expparams) (abstract_model.py:444-468) for a model the
+ * library has no kernel for, at the speed of one that it has: the model states its per-particle likelihood as HIP device
+ * source,
+ *     __device__ double likelihood(const double *x, const double *ep, long long outcome);   // Pr(outcome | x; ep)
+ *     __device__ bool valid(const double *x);     // optional (are_models_valid); announce: #define QSMC_USER_HAS_VALID 1
+ * with x[0 .. d) one particle and ep[0 .. n_ep) the experiment's record fields as doubles in dtype order (QSMC_D and QSMC_NEP
+ * are predefined).  qsmc_user_kernel_build compiles it with hiprtc INTO the fused update kernel for the handle's device
+ * (python-qinfer_amd/csrc/kernels/user_jit.hpp; hiprtc_path: optional path of the libhiprtc.so to use when none is loaded
+ * yet; log_out receives the compiler's log -- also on success, warnings).  d <= QSMC_MAX_D, n_ep <= 32.
+ * QSMC_ERR_INVALID: the source does not compile; QSMC_ERR_UNSUPPORTED: no hiprtc on this machine. */
+typedef struct qsmc_user_kernel *qsmc_user_kernel_t;
+int qsmc_user_kernel_build(qsmc_handle_t h, const char *user_source, int32_t d, int32_t n_ep, const char *hiprtc_path,
+                           qsmc_user_kernel_t *out, char *log_out, int32_t log_cap);
+int qsmc_user_kernel_destroy(qsmc_user_kernel_t uk);
+/* qsmc_update_fused for a compiled user model: one pass, w_out = (w_in / prev_norm) * likelihood(x; ep, outcome)
+ * (w_in == NULL: all-ones weights), [sum, sum of squares, min, #bad] in stats_host and, for d <= 4, the packed weighted
+ * moment sums in moments_host (same layout as qsmc_update_fused).  ep: n_ep doubles on the host. */
+int qsmc_update_user(qsmc_handle_t h, qsmc_user_kernel_t uk, const double *x, int64_t ldx, int64_t n, const double *w_in,
+                     double *w_out, double prev_norm, const double *ep, int64_t outcome, double *stats_dev,
+                     qsmc_update_stats_t *stats_host, double *moments_host, qsmc_stream_t stream);
+/* qsmc_likelihood for a compiled user model: L_out[n_o][n_e][n]; eps: n_e rows of n_ep doubles on the host. */
+int qsmc_likelihood_user(qsmc_handle_t h, qsmc_user_kernel_t uk, const double *x, int64_t ldx, int64_t n, const double *eps,
+                         int32_t n_e, const int64_t *outcomes, int32_t n_o, double *L_out, qsmc_stream_t stream);
+/* qsmc_are_models_valid for a compiled user model (all ones if the source defines no valid()). */
+int qsmc_valid_user(qsmc_handle_t h, qsmc_user_kernel_t uk, const double *x, int64_t ldx, int64_t n, uint8_t *mask_out,
+                    qsmc_stream_t stream);
+
 /* Same update for a model without a native kernel: L[i] was produced by the user's
  * Model.likelihood on the host and uploaded (plugin slow path). */
 int qsmc_update_from_likelihood(qsmc_handle_t h, const double *L, int64_t n,

@@ -1882,29 +1882,25 @@ __global__ __launch_bounds__(BT) void k_bucket_anc16(
 //   * the particle is written once, row by row: 64 consecutive slots of one coordinate per store instruction (512 B),
 //     where the MFMA layout's own stores were 16 slots x 4 coordinates (128 B segments; 1.27x the algorithmic bytes).
 // Same arithmetic per particle as before the split: (a x_a + (1 - a) mu) + (S z), then p * inv -- bit-identical clouds.
-// Which slots a workgroup takes (round 6).  A chunk's outputs are split into P = ceil(n_c / cap) work items ("parts"), each
-// with ITS OWN ascending ancestor list over the WHOLE chunk (k_bucket_anc16), so P streams run through the same 16 x 32 KB
-// source window.  Rounds 3-5 gave a workgroup 1024 CONSECUTIVE slots -- one part: the chunk's P streams ran in P workgroups
-// that drifted apart, each L2 fetched a source line once per stream that reached it after the others had been evicted
-// (TCC_EA0_RDREQ: 212.7 MB fetched for 165 MB of payload at N = 1.25e6, 1.29 x).  Now workgroup g of the G = P R that a
-// chunk gets (R = cap / 1024 sub-blocks per item, >= 1) takes the g-th of G FRACTIONS of EVERY part: its wave-trips are
-// ordered (position-major, part-minor), so the four waves of a step sit on the same few source lines of up to four parts,
-// and every source line of the chunk is wanted by one workgroup only (plus the ragged edges of the fractions).  The slots
-// themselves -- ancestor, normals, output row -- are what they were: bit-identical clouds.  Chunks with one part, or more than
-// KICK16_MAX_PARTS (a cloud whose weight sits in a few chunks), keep consecutive slots.
-// Workgroup b -> index r = (b & 7) per + (b >> 3): neighbours in that order (the fractions of one chunk) go to ONE XCD
-// (b % 8) back to back, so each source window is fetched by one L2 instead of eight.
+// Workgroup b takes slots [r per_block, (r + 1) per_block), r = (b & 7) per + (b >> 3): ranges adjacent in slot order
+// (whose ancestors are neighbours) go to ONE XCD (b % 8) back to back, so each 16 x 32 KB source window is fetched by
+// one L2 instead of eight.
+// Round 6 built the "bytes lever" the round-5 counters pointed at (212.7 MB of read requests for 165 MB of payload: a chunk's
+// work items each stream through the chunk's whole source window): workgroups aligned to work items, each taking the same
+// FRACTION of every item of its chunk, four waves side by side on the same source lines.  Read requests fell to 128.9 MB
+// (TCC_EA0_RDREQ x 64 B; below the payload, because lines without a child are never wanted) -- and the kernel went from 101
+// to 115 us on the same box, as did plain item-aligned workgroups (115) while the same loop over fixed 1024-slot ranges
+// stayed at 104: workgroups that start at the start of their chunk's window walk it in a convoy and wait on the same
+// lines in flight; ranges that straddle items are spread over the window.  The re-read lines come out of the Infinity Cache,
+// not HBM, and do not bound this kernel (VALU 54 % busy, gathers).  Not adopted: tools/experiments/
+// r6_kick16_fractions_of_every_item.patch, profiles/r6_g_kick16_modes.txt.
 constexpr int KICK16_BT = 256, KICK16_WAVES = KICK16_BT / QSMC_WAVE, KICK16_ROW = 17, KICK16_PER_BLOCK = 1024;
-constexpr int KICK16_MAX_PARTS = 16, KICK16_HARD_CAP = KICK16_PER_BLOCK + QSMC_WAVE * KICK16_MAX_PARTS;
-__host__ __device__ inline int kick16_subblocks(int cap) { return cap > KICK16_PER_BLOCK ? cap / KICK16_PER_BLOCK : 1; }
 template <int CANON>       // 0: no canonicalize; 1: the 2-qubit Pauli basis (sparse contraction); 2: dense basis
 __global__ __launch_bounds__(KICK16_BT) void k_bucket_kick16(
     const double *__restrict__ x_in, int64_t ldx_in, const unsigned int *__restrict__ anc, int64_t n_out, LWArgs lw,
     uint32_t k0, uint32_t k1, uint32_t epoch, double *__restrict__ x_out, OutPlace pl,
     const double *__restrict__ basis, int allow_subnormalized, unsigned int *__restrict__ list,
-    unsigned int *__restrict__ count, const LWDev *__restrict__ lwd,
-    const long long *__restrict__ slot_off, const int *__restrict__ item_off, const int *__restrict__ item_chunk, int chunks,
-    int cap) {
+    unsigned int *__restrict__ count, const LWDev *__restrict__ lwd) {
     constexpr int DM = 16;
     // lwd != nullptr: a, mean and S come from device memory (written by lw_sqrt16_wave in the kernel before this one);
     // a block marked invalid (covariance or square-root error not finite) means the host will not adopt this resample
@@ -1912,62 +1908,39 @@ __global__ __launch_bounds__(KICK16_BT) void k_bucket_kick16(
     const double lw_a = lwd ? lwd->a : lw.a;
     __shared__ double tile[KICK16_WAVES][QSMC_WAVE * KICK16_ROW];
     __shared__ double sS[DM * DM + DM];                             // S (row-major) and the mean
-    __shared__ unsigned int hard_buf[KICK16_HARD_CAP];
+    __shared__ unsigned int hard_buf[KICK16_PER_BLOCK];
     __shared__ unsigned int bcount, gbase;
-    const int R = kick16_subblocks(cap);
-    const int n_wg = item_off[chunks] * R;
-    const int per = (n_wg + 7) >> 3;
-    const int widx = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
-    if (((int)blockIdx.x >> 3) >= per || widx >= n_wg) return;
-    const int it = widx / R;
-    const int c = item_chunk[it], P = item_off[c + 1] - item_off[c], q = it - item_off[c];
-    const long long slot0 = slot_off[c], n_c = slot_off[c + 1] - slot0;
-    const bool inter = P > 1 && P <= KICK16_MAX_PARTS;
-    const int G = P * R, g = q * R + (widx - it * R);             // this workgroup's fraction of every part (interleaved form)
-    const int n_seg = inter ? P : 1;
-    // trips (64 slots) a segment can have at most: a part's fraction is <= cap / G + 63 slots
-    const int jmax = inter ? (cap / G + 2 * QSMC_WAVE - 1) / QSMC_WAVE : KICK16_PER_BLOCK / QSMC_WAVE;
+    const int64_t n_ranges = (n_out + KICK16_PER_BLOCK - 1) / KICK16_PER_BLOCK;
+    const int per = ((int)gridDim.x + 7) >> 3;
+    const int64_t rb = (int64_t)((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+    if (((int)blockIdx.x >> 3) >= per || rb >= n_ranges) return;
+    const int64_t r0 = rb * KICK16_PER_BLOCK;
+    const int64_t r1 = r0 + KICK16_PER_BLOCK < n_out ? r0 + KICK16_PER_BLOCK : n_out;
     for (int k = threadIdx.x; k < DM * DM; k += KICK16_BT) sS[k] = lwd ? lwd->S[k] : lw.S[k];
     if (threadIdx.x < DM) sS[DM * DM + threadIdx.x] = lwd ? lwd->mean[threadIdx.x] : lw.mean[threadIdx.x];
     if (threadIdx.x == 0) bcount = 0u;
     __syncthreads();
     const int lane = threadIdx.x & (QSMC_WAVE - 1), wave = threadIdx.x / QSMC_WAVE;
-    const int n = lane & 15, gq = lane >> 4;
+    const int n = lane & 15, g = lane >> 4;
     double aS[4], mu4[4];
 #pragma unroll
-    for (int sidx = 0; sidx < 4; ++sidx) aS[sidx] = sS[(lane & 15) * DM + 4 * gq + sidx];
+    for (int sidx = 0; sidx < 4; ++sidx) aS[sidx] = sS[(lane & 15) * DM + 4 * g + sidx];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) mu4[r] = (1.0 - lw_a) * sS[DM * DM + gq + 4 * r];
+    for (int r = 0; r < 4; ++r) mu4[r] = (1.0 - lw_a) * sS[DM * DM + g + 4 * r];
     double *mine = tile[wave];
-    for (int tau = wave; tau < jmax * n_seg; tau += KICK16_WAVES) {   // (a wave's own trips: no workgroup barrier inside)
-        const int seg = tau % n_seg, j = tau / n_seg;
-        // the segment's slots [lo, hi) of the chunk's outputs
-        long long lo, hi;
-        if (inter) {
-            const long long base = (long long)seg * cap;
-            const long long len = n_c - base < (long long)cap ? n_c - base : (long long)cap;
-            lo = base + ((len * g / G) & ~(long long)(QSMC_WAVE - 1));
-            hi = g == G - 1 ? base + len : base + ((len * (g + 1) / G) & ~(long long)(QSMC_WAVE - 1));
-        } else {
-            const long long base = (long long)q * cap;
-            const long long len = n_c - base < (long long)cap ? n_c - base : (long long)cap;
-            lo = base + (long long)(widx - it * R) * KICK16_PER_BLOCK;
-            hi = lo + KICK16_PER_BLOCK < base + len ? lo + KICK16_PER_BLOCK : base + len;
-        }
-        const int64_t k64 = slot0 + lo + (int64_t)j * QSMC_WAVE;
-        const int64_t r1 = slot0 + hi;
-        if (k64 >= r1) continue;                                    // (wave-uniform)
+    for (int64_t kb = r0; kb < r1; kb += KICK16_BT) {               // (uniform over the workgroup)
+        const int64_t k64 = kb + (int64_t)wave * QSMC_WAVE;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int64_t k = k64 + 16 * t + n;
             const int64_t oc = k < r1 ? k : r1 - 1;                 // (idle columns shadow the last slot: no divergence)
-            const int64_t jj = (int64_t)anc[oc];
+            const int64_t j = (int64_t)anc[oc];
             double xa[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) xa[r] = x_in[(int64_t)(gq + 4 * r) * ldx_in + jj];
+            for (int r = 0; r < 4; ++r) xa[r] = x_in[(int64_t)(g + 4 * r) * ldx_in + j];
             // the four normals 4 g .. 4 g + 3 of slot oc: pairs 2 g and 2 g + 1 (blocks oc * 8 + 2 g, + 1; slot 2)
             double z[4];
-            PhiloxStream nrm{(uint64_t)oc * 8u + (uint64_t)(2 * gq), (epoch << 16), k0, k1};
+            PhiloxStream nrm{(uint64_t)oc * 8u + (uint64_t)(2 * g), (epoch << 16), k0, k1};
             nrm.normals(2, z[0], z[1]);
             nrm.particle += 1;
             nrm.normals(2, z[2], z[3]);
@@ -1975,7 +1948,7 @@ __global__ __launch_bounds__(KICK16_BT) void k_bucket_kick16(
 #pragma unroll
             for (int sidx = 0; sidx < 4; ++sidx) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aS[sidx], z[sidx], acc, 0, 0, 0);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) mine[(16 * t + n) * KICK16_ROW + gq + 4 * r] = (lw_a * xa[r] + mu4[r]) + acc[r];
+            for (int r = 0; r < 4; ++r) mine[(16 * t + n) * KICK16_ROW + g + 4 * r] = (lw_a * xa[r] + mu4[r]) + acc[r];
         }
         // (the tile is this WAVE's: a wave-level fence orders its LDS stores before its own transposed reads.  Round 5 --
         //  the two workgroup barriers per trip that stood here kept a workgroup's four waves in lockstep through a kernel

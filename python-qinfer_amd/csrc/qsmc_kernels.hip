@@ -179,6 +179,7 @@ static bool g_redraw_no_small = false;    // k_bucket_redraw: the global-CDF for
 static bool g_hyp_no_chain = false;       // design passes of binomial experiments: thread-per-particle k_hyp_sums, not the walk
 static bool g_tomo_dense = false;         // tomography updates read all d rows also for sparse measurement vectors
 static double g_poisson_margin = 5.0;     // kappa in lambda = n_out - kappa sqrt(n_out) of k_bucket_counts
+   // k_bucket_kick16: a workgroup takes consecutive slots of ONE part (the rounds 3-5 form)
 
 // Census of the compute units this process can actually run on.  hipDeviceAttributeMultiprocessorCount reports the
 // device's CUs; under a CU mask (HSA_CU_MASK / ROC_GLOBAL_CU_MASK) or other restrictions fewer are usable, and the
@@ -309,6 +310,7 @@ static inline bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; 
 #include "kernels/resample.hpp"
 #include "kernels/walk_tomo.hpp"
 #include "kernels/sort.hpp"
+#include "kernels/user_jit.hpp"
 
 // out[0..K) (device) -> pinned host block, then the completion word: the d > 4 moments of a resample queued by qsmc_step
 __global__ void k_publish_big(const double *__restrict__ src, int K, double *__restrict__ mapped, unsigned long long *flag,
@@ -1879,15 +1881,12 @@ static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int3
         if (stages & RS_STAGE_KICK) {
             hipEvent_t pe0 = nullptr, pe1 = nullptr;
             prof_events(h, QSMC_PROF_SAMPLE, &pe0, &pe1);
-            // one workgroup per (work item, 1024-slot sub-block): the item count is the device's (item_off[chunks]); the grid
-            // covers its bound and the surplus leaves at once (kernels/resample.hpp: which slots a workgroup takes)
-            const int64_t n_wg_max = (int64_t)bp.max_items * kick16_subblocks(bp.cap);
-            const unsigned kgrid = (unsigned)(((n_wg_max + 7) / 8) * 8);
+            const int64_t n_ranges = (n_out + KICK16_PER_BLOCK - 1) / KICK16_PER_BLOCK;
+            const unsigned kgrid = (unsigned)(((n_ranges + 7) / 8) * 8);
             unsigned int *ccount = bp.clist, *clist = bp.clist + 4;      // (ccount was cleared by k_bucket_anc16)
 #define LAUNCH_K16(C)                                                                                                 \
     hipExtLaunchKernelGGL((k_bucket_kick16<C>), dim3(kgrid), dim3(KICK16_BT), 0, s, pe0, pe1, 0, x_in, ldx_in, bp.anc,  \
-                          n_out, lw, k0, k1, ep, x_out, pl, canon.basis, canon.allow_sub, clist, ccount, lw_dev,      \
-                          bp.slot_off, bp.item_off, bp.item_chunk, chunks, bp.cap)
+                          n_out, lw, k0, k1, ep, x_out, pl, canon.basis, canon.allow_sub, clist, ccount, lw_dev)
             if (canon.kind == 1) LAUNCH_K16(1);
             else if (canon.kind == 2) LAUNCH_K16(2);
             else LAUNCH_K16(0);
@@ -2802,6 +2801,200 @@ int qsmc_publish_rows(qsmc_handle_t h, const double *rows_dev, int32_t n, int32_
     if (rc) return rc;
     memcpy(tot_host, h->mapped, (size_t)n * sizeof(double));
     if (firsts_host) memcpy(firsts_host, h->mapped + n, (size_t)nranks * sizeof(double));
+    return QSMC_OK;
+}
+
+// ---- user models compiled at run time (kernels/user_jit.hpp) ---------------------------------------------------------------
+// hiprtc is bound with dlopen: the copy already in the process if there is one, else the path the caller names (the Python
+// side passes the one that ships with its torch, so that code object and runtime come from one ROCm), else by soname.
+struct qsmc_user_kernel {
+    hipModule_t mod;
+    hipFunction_t upd, lik, valid;
+    int d, n_ep, has_valid;
+};
+
+constexpr int USER_MAX_EP = 32;
+
+namespace {
+struct Hiprtc {
+    void *lib = nullptr;
+    int (*CreateProgram)(void **, const char *, const char *, int, const char **, const char **) = nullptr;
+    int (*CompileProgram)(void *, int, const char **) = nullptr;
+    int (*GetProgramLogSize)(void *, size_t *) = nullptr;
+    int (*GetProgramLog)(void *, char *) = nullptr;
+    int (*GetCodeSize)(void *, size_t *) = nullptr;
+    int (*GetCode)(void *, char *) = nullptr;
+    int (*DestroyProgram)(void **) = nullptr;
+};
+Hiprtc g_rtc;
+
+bool hiprtc_open(const char *path_hint) {
+    if (g_rtc.lib) return true;
+    const char *names[] = {"libhiprtc.so", "libhiprtc.so.7", "libhiprtc.so.6"};
+    void *l = nullptr;
+    for (const char *n : names)
+        if (!l) l = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+    if (!l && path_hint && *path_hint) l = dlopen(path_hint, RTLD_NOW | RTLD_LOCAL);
+    for (const char *n : names)
+        if (!l) l = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    if (!l) return false;
+#define RTC_BIND(NAME)                                                                       \
+    g_rtc.NAME = reinterpret_cast<decltype(g_rtc.NAME)>(dlsym(l, "hiprtc" #NAME));           \
+    if (!g_rtc.NAME) return false;
+    RTC_BIND(CreateProgram) RTC_BIND(CompileProgram) RTC_BIND(GetProgramLogSize) RTC_BIND(GetProgramLog)
+    RTC_BIND(GetCodeSize) RTC_BIND(GetCode) RTC_BIND(DestroyProgram)
+#undef RTC_BIND
+    g_rtc.lib = l;
+    return true;
+}
+}  // namespace
+
+int qsmc_user_kernel_build(qsmc_handle_t h, const char *user_source, int32_t d, int32_t n_ep, const char *hiprtc_path,
+                           qsmc_user_kernel_t *out, char *log_out, int32_t log_cap) {
+    if (log_out && log_cap > 0) log_out[0] = 0;
+    if (!h || !user_source || !out || d < 1 || d > QSMC_MAX_D || n_ep < 0 || n_ep > USER_MAX_EP) return QSMC_ERR_INVALID;
+    *out = nullptr;
+    if (!hiprtc_open(hiprtc_path)) {
+        snprintf(h->hip_err, sizeof(h->hip_err), "hiprtc not found (libhiprtc.so)");
+        return QSMC_ERR_UNSUPPORTED;
+    }
+    char defs[128];
+    snprintf(defs, sizeof(defs), "#define QSMC_D %d\n#define QSMC_NEP %d\n", (int)d, (int)n_ep);
+    const size_t len = strlen(defs) + strlen(USER_JIT_PRELUDE) + strlen(user_source) + strlen(USER_JIT_KERNELS) + 8;
+    char *src = static_cast<char *>(malloc(len));
+    if (!src) return QSMC_ERR_ALLOC;
+    snprintf(src, len, "%s%s\n%s\n%s", defs, USER_JIT_PRELUDE, user_source, USER_JIT_KERNELS);
+    void *prog = nullptr;
+    int rc = g_rtc.CreateProgram(&prog, src, "qsmc_user_model.hip", 0, nullptr, nullptr);
+    free(src);
+    if (rc != 0 || !prog) return QSMC_ERR_HIP;
+    // the device this handle lives on decides the target; -ffp-contract=off as for the library's own kernels (a user model
+    // checked against its NumPy twin must not differ by fused multiply-adds the host never made)
+    hipDeviceProp_t prop;
+    char arch[96] = "--offload-arch=gfx950";
+    if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.gcnArchName[0]) {
+        char name[64];
+        snprintf(name, sizeof(name), "%s", prop.gcnArchName);
+        if (char *colon = strchr(name, ':')) *colon = 0;                      // ("gfx950:sramecc+:xnack-" -> "gfx950")
+        snprintf(arch, sizeof(arch), "--offload-arch=%s", name);
+    }
+    const char *opts[] = {arch, "-O3", "-ffp-contract=off", "-std=c++17"};
+    rc = g_rtc.CompileProgram(prog, 4, opts);
+    if (log_out && log_cap > 1) {
+        size_t ls = 0;
+        if (g_rtc.GetProgramLogSize(prog, &ls) == 0 && ls > 1) {
+            char *tmp = static_cast<char *>(malloc(ls + 1));
+            if (tmp && g_rtc.GetProgramLog(prog, tmp) == 0) {
+                tmp[ls] = 0;
+                snprintf(log_out, (size_t)log_cap, "%s", tmp);
+            }
+            free(tmp);
+        }
+    }
+    if (rc != 0) {
+        (void)g_rtc.DestroyProgram(&prog);
+        snprintf(h->hip_err, sizeof(h->hip_err), "hiprtc: the user model does not compile (see the log)");
+        return QSMC_ERR_INVALID;
+    }
+    size_t cs = 0;
+    if (g_rtc.GetCodeSize(prog, &cs) != 0 || cs == 0) { (void)g_rtc.DestroyProgram(&prog); return QSMC_ERR_HIP; }
+    char *code = static_cast<char *>(malloc(cs));
+    if (!code) { (void)g_rtc.DestroyProgram(&prog); return QSMC_ERR_ALLOC; }
+    rc = g_rtc.GetCode(prog, code);
+    (void)g_rtc.DestroyProgram(&prog);
+    if (rc != 0) { free(code); return QSMC_ERR_HIP; }
+    qsmc_user_kernel *uk = new (std::nothrow) qsmc_user_kernel();
+    if (!uk) { free(code); return QSMC_ERR_ALLOC; }
+    uk->d = d;
+    uk->n_ep = n_ep;
+    uk->has_valid = strstr(user_source, "QSMC_USER_HAS_VALID") != nullptr;
+    hipError_t e = hipModuleLoadData(&uk->mod, code);
+    free(code);
+    if (e == hipSuccess) e = hipModuleGetFunction(&uk->upd, uk->mod, "qsmc_user_update");
+    if (e == hipSuccess) e = hipModuleGetFunction(&uk->lik, uk->mod, "qsmc_user_likelihood");
+    if (e == hipSuccess) e = hipModuleGetFunction(&uk->valid, uk->mod, "qsmc_user_valid");
+    if (e != hipSuccess) {
+        snprintf(h->hip_err, sizeof(h->hip_err), "loading the compiled user model: %s", hipGetErrorString(e));
+        delete uk;
+        return QSMC_ERR_HIP;
+    }
+    *out = uk;
+    return QSMC_OK;
+}
+
+int qsmc_user_kernel_destroy(qsmc_user_kernel_t uk) {
+    if (!uk) return QSMC_OK;
+    (void)hipModuleUnload(uk->mod);
+    delete uk;
+    return QSMC_OK;
+}
+
+struct UserEpArg { double v[USER_MAX_EP]; };
+
+// qsmc_update_fused's contract for a compiled user model: same sums, same host-visible results, same completion-word wait
+int qsmc_update_user(qsmc_handle_t h, qsmc_user_kernel_t uk, const double *x, int64_t ldx, int64_t n, const double *w_in,
+                     double *w_out, double prev_norm, const double *ep, int64_t outcome, double *stats_dev,
+                     qsmc_update_stats_t *stats_host, double *moments_host, qsmc_stream_t stream) {
+    if (h) { h->prep.valid = 0; h->rsq.valid = 0; h->canon_next.kind = 0; h->expect_next = 0.0; h->ts.w = nullptr; }
+    if (!h || !uk || !x || !w_out || n <= 0 || (uk->n_ep > 0 && !ep)) return QSMC_ERR_INVALID;
+    const int d = uk->d, dmom = d <= 4 ? d : 0;
+    if (moments_host && !dmom) return QSMC_ERR_UNSUPPORTED;
+    const int n_mom = dmom + dmom * (dmom + 1) / 2, ns = 3 + n_mom;
+    hipStream_t s = (hipStream_t)stream;
+    const int unroll = d <= 2 ? 4 : (d <= 4 ? 2 : 1);                // (QSMC_JIT_UNROLL of kernels/user_jit.hpp)
+    const int grid = grid_for(n, 256 * 2 * unroll);
+    int vec = (aligned16(x) && (!w_in || aligned16(w_in)) && aligned16(w_out) && (ldx % 2 == 0)) ? 1 : 0;
+    int rc = ensure_partials(h, (size_t)grid * (ns + 1));
+    if (rc) return rc;
+    ReduceOut ro = make_reduce(h, stats_host || moments_host, stats_dev);
+    ++h->ts.gen;                                   // (no tile sums: a resample that follows reads the weights itself)
+    h->ts.armed = 0;
+    h->spec.launched = 0;
+    // the kernel's struct argument is sized by the model (QSMC_NEP doubles, at least one): pass exactly those bytes
+    UserEpArg epa;
+    memset(&epa, 0, sizeof(epa));
+    for (int k = 0; k < uk->n_ep; ++k) epa.v[k] = ep[k];
+    long long ldx_ = ldx, n_ = n, outcome_ = outcome;
+    double *partials = h->partials;
+    void *args[] = {(void *)&x, (void *)&ldx_, (void *)&n_, (void *)&w_in, (void *)&w_out, (void *)&prev_norm, (void *)&epa,
+                    (void *)&outcome_, (void *)&partials, (void *)&vec};
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    prof_events(h, w_in ? QSMC_PROF_UPDATE : QSMC_PROF_UPDATE_ONES, &e0, &e1);
+    if (e0) HIP_TRY(h, hipEventRecord(e0, s));
+    HIP_TRY(h, hipModuleLaunchKernel(uk->upd, (unsigned)grid, 1, 1, 256, 1, 1, 0, s, args, nullptr));
+    if (e1) HIP_TRY(h, hipEventRecord(e1, s));
+    rc = launch_reduce(h, ns, grid, ro, s);
+    if (rc) return rc;
+    return collect_stats(h, ns, stats_host, moments_host, n_mom, s);
+}
+
+// L_out[o][e][i] = likelihood(x_i; eps[e], outcomes[o]): qsmc_likelihood's layout for a compiled user model
+int qsmc_likelihood_user(qsmc_handle_t h, qsmc_user_kernel_t uk, const double *x, int64_t ldx, int64_t n, const double *eps,
+                         int32_t n_e, const int64_t *outcomes, int32_t n_o, double *L_out, qsmc_stream_t stream) {
+    if (!h || !uk || !x || !outcomes || !L_out || n <= 0 || n_e < 1 || n_o < 1 || (uk->n_ep > 0 && !eps)) return QSMC_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = grid_for(n, 256 * 4);
+    long long ldx_ = ldx, n_ = n;
+    for (int o = 0; o < n_o; ++o)
+        for (int e = 0; e < n_e; ++e) {
+            UserEpArg epa;
+            memset(&epa, 0, sizeof(epa));
+            for (int k = 0; k < uk->n_ep; ++k) epa.v[k] = eps[(size_t)e * uk->n_ep + k];
+            long long outcome_ = outcomes[o];
+            double *dst = L_out + ((size_t)o * n_e + e) * (size_t)n;
+            void *args[] = {(void *)&x, (void *)&ldx_, (void *)&n_, (void *)&epa, (void *)&outcome_, (void *)&dst};
+            HIP_TRY(h, hipModuleLaunchKernel(uk->lik, (unsigned)grid, 1, 1, 256, 1, 1, 0, s, args, nullptr));
+        }
+    return QSMC_OK;
+}
+
+int qsmc_valid_user(qsmc_handle_t h, qsmc_user_kernel_t uk, const double *x, int64_t ldx, int64_t n, uint8_t *mask_out,
+                    qsmc_stream_t stream) {
+    if (!h || !uk || !x || !mask_out || n <= 0) return QSMC_ERR_INVALID;
+    const int grid = grid_for(n, 256 * 4);
+    long long ldx_ = ldx, n_ = n;
+    void *args[] = {(void *)&x, (void *)&ldx_, (void *)&n_, (void *)&mask_out};
+    HIP_TRY(h, hipModuleLaunchKernel(uk->valid, (unsigned)grid, 1, 1, 256, 1, 1, 0, (hipStream_t)stream, args, nullptr));
     return QSMC_OK;
 }
 

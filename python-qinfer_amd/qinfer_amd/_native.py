@@ -113,6 +113,12 @@ SIGNATURES = {
                                      C.POINTER(_I64), C.POINTER(_I32), C.POINTER(_F64), _I32, C.POINTER(_F64), _P],
     "qsmc_hypothetical_sums_collect": [_P, _P],
     "qsmc_update_from_likelihood": [_P, _P, _I64, _P, _P, _F64, _P, C.POINTER(UpdateStats), _P],
+    "qsmc_user_kernel_build": [_P, C.c_char_p, _I32, _I32, C.c_char_p, C.POINTER(_P), C.c_char_p, _I32],
+    "qsmc_user_kernel_destroy": [_P],
+    "qsmc_update_user": [_P, _P, _P, _I64, _I64, _P, _P, _F64, C.POINTER(_F64), _I64, _P, C.POINTER(UpdateStats),
+                         C.POINTER(_F64), _P],
+    "qsmc_likelihood_user": [_P, _P, _P, _I64, _I64, C.POINTER(_F64), _I32, C.POINTER(_I64), _I32, _P, _P],
+    "qsmc_valid_user": [_P, _P, _P, _I64, _I64, _P, _P],
     "qsmc_clip_weights": [_P, _P, _I64, _F64, _P, C.POINTER(UpdateStats), _P],
     "qsmc_weight_stats": [_P, _P, _I64, _F64, _P, C.POINTER(UpdateStats), _P],
     "qsmc_normalize_weights": [_P, _P, _P, _I64, _F64, _P],

@@ -35,6 +35,24 @@ it as read-only.
 
 Each is used in place of its NumPy namesake when present (and the model is not served by native kernels); a model
 may define any subset.  `Model.count_likelihood_calls` keeps `call_count` meaningful from `likelihood_device`.
+
+A user model at the speed of a native one: `likelihood_hip` (a class or instance attribute, a string of HIP device
+source).  The updater compiles it with hiprtc INTO the fused update kernel (qsmc_user_kernel_build,
+csrc/kernels/user_jit.hpp): one pass of 16 + 8 d bytes per particle per datum, like the library's own models.
+
+    likelihood_hip = r'''
+    __device__ double likelihood(const double *x, const double *ep, long long outcome) {   // Pr(outcome | x; ep)
+        const double t = ep[0], e = exp(-t * x[1]), c = cos(0.5 * x[0] * t);
+        const double pr0 = e * c * c + 0.5 * (1.0 - e);
+        return outcome == 0 ? pr0 : 1.0 - pr0;
+    }
+    #define QSMC_USER_HAS_VALID 1                                                          // optional: are_models_valid
+    __device__ bool valid(const double *x) { return x[0] >= 0.0 && x[1] >= 0.0; }
+    '''
+
+`x[0 .. QSMC_D)` is one particle, `ep[0 .. QSMC_NEP)` the experiment record's fields as doubles in dtype order (vector
+fields flattened; a plain-dtype experiment is one double).  The NumPy methods stay the contract (simulate_experiment and
+the host-side callers use them); the source must state the same function.
 """
 import abc
 

@@ -291,6 +291,72 @@ class Engine:
         finally:
             self._design_jobs = []           # (also after an error: the library has dropped its queue -- chain2_flush)
 
+    # ------------------------------------------------------------------ user models compiled at run time
+    def user_kernel(self, source, d, n_ep):
+        """Compile a model's `likelihood_hip` source into the fused update kernel (qsmc_user_kernel_build; cached per
+        source).  Returns an object with `.ptr`, `.d`, `.n_ep`, `.has_valid`."""
+        key = (source, int(d), int(n_ep))
+        cache = self.__dict__.setdefault("_user_kernels", {})
+        uk = cache.get(key)
+        if uk is not None:
+            return uk
+        import os
+        hint = os.path.join(os.path.dirname(self.torch.__file__), "lib", "libhiprtc.so")
+        log = C.create_string_buffer(1 << 16)
+        ptr = C.c_void_p()
+        rc = self.lib.qsmc_user_kernel_build(self.h, source.encode(), int(d), int(n_ep),
+                                             hint.encode() if os.path.exists(hint) else None, C.byref(ptr), log, len(log))
+        if rc:
+            msg = self.lib.qsmc_strerror(rc).decode()
+            raise RuntimeError("likelihood_hip: qsmc_user_kernel_build failed ({}; {})\n{}".format(
+                msg, self.lib.qsmc_last_hip_error(self.h).decode(), log.value.decode(errors="replace")))
+        uk = type("UserKernel", (), {})()
+        uk.ptr, uk.d, uk.n_ep, uk.has_valid, uk.log = ptr, int(d), int(n_ep), "QSMC_USER_HAS_VALID" in source, log.value.decode(errors="replace")
+        cache[key] = uk
+        return uk
+
+    def update_user(self, uk, x, w_in, w_out, prev_norm, ep_vec, outcome, moments=False):
+        """`update_fused` for a compiled user model (qsmc_update_user); ep_vec: the experiment as n_ep float64."""
+        if self._design_jobs:
+            self._no_design_in_flight("update_user")
+        d = x.shape[0]
+        self.update_gen += 1
+        ep_vec = np.ascontiguousarray(ep_vec, dtype=np.float64)
+        self._chk(self.lib.qsmc_update_user(
+            self.h, uk.ptr, x.data_ptr(), x.stride(0), x.shape[1], w_in.data_ptr() if w_in is not None else None,
+            w_out.data_ptr(), float(prev_norm), ep_vec.ctypes.data_as(C.POINTER(C.c_double)), int(outcome),
+            self._stats.data_ptr(), self._st_ref, self._mom_ptr[d] if moments else None, self.stream()), "qsmc_update_user")
+        return self._st
+
+    def likelihood_user(self, uk, x, eps, outcomes):
+        """L[n_o, n_e, N] on the device from a compiled user model; eps: (n_e, n_ep) float64."""
+        n = x.shape[1]
+        eps = np.ascontiguousarray(eps, dtype=np.float64)
+        if eps.ndim != 2 or eps.shape[1] != uk.n_ep:
+            raise ValueError("likelihood_user: experiments must be an (n_e, {}) array".format(uk.n_ep))
+        n_e, n_o = eps.shape[0], len(outcomes)
+        out = self.empty(n_o, n_e, n)
+        if n == 0 or n_e == 0 or n_o == 0:
+            return out
+        oc = (C.c_int64 * n_o)(*[int(o) for o in outcomes])
+        flat = np.ascontiguousarray(eps.reshape(-1)) if eps.size else np.zeros(1)
+        self._chk(self.lib.qsmc_likelihood_user(self.h, uk.ptr, self._p(x), x.stride(0), n,
+                                                flat.ctypes.data_as(C.POINTER(C.c_double)), n_e, oc, n_o, self._p(out),
+                                                self.stream()), "qsmc_likelihood_user")
+        return out
+
+    def valid_user(self, uk, x):
+        """uint8 device mask [n] from a compiled user model's valid() (all ones if it defines none); x: (d, n) SoA, any
+        row stride, unit column stride."""
+        if x.stride(1) != 1:
+            x = x.contiguous()
+        n = x.shape[1]
+        out = self.empty(n, dtype=self.torch.uint8)
+        if n:
+            self._chk(self.lib.qsmc_valid_user(self.h, uk.ptr, self._p(x), x.stride(0), n, self._p(out), self.stream()),
+                      "qsmc_valid_user")
+        return out
+
     def update_from_likelihood(self, L, w_in, w_out, prev_norm):
         st = _native.UpdateStats()
         self._chk(self.lib.qsmc_update_from_likelihood(

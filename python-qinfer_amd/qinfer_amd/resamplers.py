@@ -172,6 +172,9 @@ class LiuWestResampler(Resampler):
         """bool device tensor [n]: the model's own validity test of the SoA particles x (d, n) -- its device hook when it
         has one, else `are_models_valid` on a host copy (the plugin contract, abstract_model.py:286-300)."""
         t = eng.torch
+        uk = getattr(model, "_qsmc_user_kernel", None)
+        if uk is not None and uk.has_valid:               # the model's compiled valid() (likelihood_hip)
+            return eng.valid_user(uk, x).to(t.bool)
         fn = getattr(model, "are_models_valid_device", None)
         if fn is not None:
             ok = fn(x)
@@ -182,25 +185,54 @@ class LiuWestResampler(Resampler):
         assert ok.ndim == 1, "are_models_valid returned tensor, expected vector."
         return eng.to_device(ok)
 
-    def _plugin_device_draw(self, eng, model, x_in, w, norm, a, mean, S, n_out, seed, epoch, out=None):
-        """Liu-West draw of `n_out` particles for a model WITHOUT native kernels, on the device generator.  Round 0 draws
-        every output; each further round redraws (ancestor and kick, like the native device path) the outputs the model
-        declared invalid, from a Philox stream of its own, up to `maxiter` rounds.  Returns (x_new, n_failed); fills
-        `out` ((d, n_out) device view) when given."""
+    def _plugin_device_draw(self, eng, model, x_in, w, norm, a, mean, S, n_out, seed, epoch):
+        """Liu-West draw of `n_out` particles for a model WITHOUT native kernels, on the device generator.  The Philox sampler
+        draws (no validity test of its own), the MODEL tests (`_plugin_valid`), and what it rejects is replaced by rejection
+        sampling -- ancestor and kick drawn again, like the native device path:
+          * from SPARES drawn in the same sampler call: 1.5 x the rejections this resampler saw last time (+ 1024) extra
+            outputs behind the n_out wanted ones -- i.i.d. draws of the same proposal, so the valid ones among them are
+            exactly what a redraw would have produced -- one validity pass over all of them, one indexed copy;
+          * then, for what is still invalid (the first resample, or more rejections than spares), in rounds of fresh draws
+            from Philox streams of their own, up to `maxiter`.
+        Returns (x_new, n_failed); x_new is a (d, n_out) view whose row stride may exceed n_out (the spares sit behind it)."""
         from . import _native
         d = x_in.shape[0]
         plain = _native.ModelDesc(_native.MODEL_TOMOGRAPHY, d, 0.0, 1, 0)      # (kind only sizes the sampler: no validity test)
-        x_new, _ = eng.lw_resample_philox(plain, False, x_in, w, norm, a, mean, S, n_out, seed, epoch, self._maxiter,
-                                          sync=True, out=out)
         if not self._postselect or n_out == 0:
+            x_new, _ = eng.lw_resample_philox(plain, False, x_in, w, norm, a, mean, S, n_out, seed, epoch, self._maxiter,
+                                              sync=False)
             return x_new, 0
-        bad = (~self._plugin_valid(eng, model, x_new)).nonzero(as_tuple=False).reshape(-1)
+        seen = int(getattr(self, "_plugin_bad_seen", 0))
+        spares = 0
+        if seen:
+            # (in coarse steps -- 1/64 of the cloud, at least 65536 -- so that successive resamples ask the allocator for the
+            #  same few sizes: a new size per resample is a fresh hipMalloc of the whole cloud each time, milliseconds)
+            q = 1 << max(16, (max(n_out, 2) - 1).bit_length() - 6)
+            spares = -(-(int(1.5 * seen) + 1024) // q) * q
+            # ... and never fewer than before for this output size: the buffer's size only ever steps up
+            kept = getattr(self, "_plugin_spares", (0, 0))
+            if kept[0] == n_out:
+                spares = max(spares, kept[1])
+            self._plugin_spares = (n_out, spares)
+        spares += (n_out + spares) & 1                                          # (an even row stride: 16-byte loads downstream)
+        x_all, _ = eng.lw_resample_philox(plain, False, x_in, w, norm, a, mean, S, n_out + spares, seed, epoch, self._maxiter,
+                                          sync=False)
+        ok = self._plugin_valid(eng, model, x_all)
+        bad = (~ok[:n_out]).nonzero(as_tuple=False).reshape(-1)
+        self._plugin_bad_seen = int(bad.numel())
+        x_new = x_all[:, :n_out] if spares else x_all
+        if bad.numel() and spares:
+            good = ok[n_out:].nonzero(as_tuple=False).reshape(-1)[:bad.numel()] + n_out
+            k = int(good.numel())
+            if k:
+                x_all[:, bad[:k]] = x_all[:, good]
+                bad = bad[k:]
         rounds = 1
         while bad.numel() and rounds < self._maxiter:
             k = int(bad.numel())
             x_r, _ = eng.lw_resample_philox(plain, False, x_in, w, norm, a, mean, S, k,
                                             seed ^ (0xD1B54A32D192ED03 * rounds & (2 ** 64 - 1)), epoch, self._maxiter,
-                                            sync=True)
+                                            sync=False)
             x_new[:, bad] = x_r
             bad = bad[~self._plugin_valid(eng, model, x_r)]
             rounds += 1

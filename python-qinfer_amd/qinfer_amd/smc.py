@@ -34,6 +34,16 @@ _NO_FUSED_CANON = False   # True: canonicalize after a d = 16 resample as its ow
 _U64 = 2 ** 64 - 1
 
 
+def _user_ep_matrix(expparams):
+    """(n_experiments, n_ep) float64: an experiment record as the doubles a compiled user model reads (`likelihood_hip`:
+    the fields in dtype order, vector fields flattened; a plain-dtype array is one double per experiment)."""
+    ep = np.atleast_1d(expparams)
+    if ep.dtype.names is None:
+        return np.ascontiguousarray(ep.astype(np.float64).reshape(len(ep), -1))
+    cols = [np.asarray(ep[name], dtype=np.float64).reshape(len(ep), -1) for name in ep.dtype.names]
+    return np.ascontiguousarray(np.hstack(cols))
+
+
 def _as_int_outcome(outcome):
     if type(outcome) is int:
         return outcome
@@ -99,6 +109,13 @@ class SMCUpdater(ParticleDistribution):
         # (a user subclass overriding likelihood / are_models_valid / update_timestep takes the plugin path)
         self._native = native_ok(model)
         self._desc = model._native_desc() if self._native else None
+        # a user model that states its likelihood as HIP source (`likelihood_hip`): compiled into the fused update kernel now
+        self._uk = None
+        src = None if self._native else getattr(model, "likelihood_hip", None)
+        if src:
+            n_ep = _user_ep_matrix(np.zeros((1,), dtype=model.expparams_dtype)).shape[1]
+            self._uk = self._eng.user_kernel(src, model.n_modelparams, n_ep)
+            model._qsmc_user_kernel = self._uk          # (the resampler's postselection asks the model: _plugin_valid)
         self._timestep_identity = (self._timestep_is_identity(model)
                                    and (self._native or getattr(model, "update_timestep_device", None) is None))
         # the per-datum C path (qsmc_step): native model; one cloud, or a shard whose per-datum reduction goes through
@@ -360,6 +377,11 @@ class SMCUpdater(ParticleDistribution):
         if self._native:
             return self._eng.likelihood(self._desc, self._x, self.model._native_expparams(expparams),
                                         outcomes.astype(np.int64))
+        if self._uk is not None:
+            # the model's own HIP source, compiled (kernels/user_jit.hpp): L on the device, nothing crosses the bus
+            if hasattr(self.model, "count_likelihood_calls"):
+                self.model.count_likelihood_calls(len(outcomes), self._x.shape[1], np.atleast_1d(expparams).shape[0])
+            return self._eng.likelihood_user(self._uk, self._x, _user_ep_matrix(expparams), outcomes.astype(np.int64))
         dev_fn = getattr(self.model, "likelihood_device", None)
         if dev_fn is not None:
             # device-side plugin hook: the model evaluates its likelihood on the (d, N) tensor the cloud lives in -- no
@@ -625,6 +647,20 @@ class SMCUpdater(ParticleDistribution):
                 eng.arm_resample_prefix(self._prefix_key() if check_for_resample else None)
                 st = eng.update_fused(self._desc, self._x, self._w, w_out, self._norm, exps[0],
                                       _as_int_outcome(outcome))
+        elif self._uk is not None:
+            # a user model compiled into the fused update kernel: ONE pass over the cloud, like a native model
+            eng.arm_resample_prefix(None)
+            epm = _user_ep_matrix(expparams)
+            if epm.shape[0] != 1:
+                raise ValueError("update() takes exactly one experiment")
+            d = self._x.shape[0]
+            want_mom = d <= 4 and self._comm is None
+            st = eng.update_user(self._uk, self._x, self._w, w_out, self._norm, epm[0], _as_int_outcome(outcome),
+                                 moments=want_mom)
+            if want_mom:
+                fused_moments = eng._mom[d].copy()
+            if hasattr(self.model, "count_likelihood_calls"):
+                self.model.count_likelihood_calls(1, self._x.shape[1], 1)
         else:
             eng.arm_resample_prefix(None)             # (no fused update on this path: nothing may stay armed on the handle)
             L = self._device_likelihood(outcome, expparams)

@@ -2968,3 +2968,4 @@ print("digest", h.hexdigest())
     assert outs[0] == outs[1] and len(outs[0]) == 4, outs
     n_redraws = int(outs[0][2].split()[1])
     assert n_redraws > 0, outs[0]                       # (the queue was in use: the test saw the path it is about)
+

@@ -499,13 +499,14 @@ def _check_sharded_plugin_model(comm, rank, world, tmpdir):
     """Round 6: a model WITHOUT native kernels shards too (the reference's DirectViewParallelizedModel shards any model's
     likelihood, parallel.py:196-224).  Two ranks against ONE updater holding the union cloud: the updates agree to
     rounding; a resample conserves the global count, leaves only valid particles and the same global estimate on every
-    rank, where the single cloud's is -- for the NumPy plugin and for the torch (device-hook) one."""
+    rank, where the single cloud's is -- for the NumPy plugin, the torch (device-hook) one and the compiled (likelihood_hip) one."""
     import warnings
     import torch
     import qinfer_amd as qi
-    from test_plugin_device import plugin_models, t2_data
+    from test_plugin_device import hip_model, plugin_models, t2_data
     torch.cuda.set_device(0)
     NumpyT2, TorchT2 = plugin_models(qi)
+    HipT2 = hip_model(qi)                            # (its likelihood compiled into the fused update kernel: likelihood_hip)
     n_local = 20000
     rs = np.random.RandomState(4)
     x_all = np.column_stack([1.5 * rs.random_sample(n_local * world), 0.2 * rs.random_sample(n_local * world)])
@@ -520,7 +521,7 @@ def _check_sharded_plugin_model(comm, rank, world, tmpdir):
             assert n == self.hi - self.lo
             return x_all[self.lo:self.hi].copy()
     outcomes, eps = t2_data(30, seed=2)
-    for cls in (NumpyT2, TorchT2):
+    for cls in (NumpyT2, TorchT2, HipT2):
         model = cls()
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")

@@ -60,6 +60,26 @@ def plugin_models(qi):
     return NumpyT2, TorchT2
 
 
+T2_HIP = r"""
+__device__ double likelihood(const double *x, const double *ep, long long outcome) {
+    const double t = ep[0], e = exp(-t * x[1]), c = cos(x[0] * t / 2);
+    const double pr0 = e * (c * c) + (1 - e) / 2;
+    return outcome == 0 ? pr0 : 1 - pr0;
+}
+#define QSMC_USER_HAS_VALID 1
+__device__ bool valid(const double *x) { return x[0] >= 0 && x[1] >= 0; }
+"""
+
+
+def hip_model(qi):
+    """The NumPy plugin + its likelihood as HIP source: compiled into the fused update kernel (likelihood_hip)."""
+    NumpyT2, _ = plugin_models(qi)
+
+    class HipT2(NumpyT2):
+        likelihood_hip = T2_HIP
+    return HipT2
+
+
 def t2_data(n_exp=40, seed=0):
     rs = np.random.RandomState(seed)
     ts = np.linspace(0.5, 12.0, n_exp)
@@ -81,7 +101,7 @@ def test_torch_plugin_equals_numpy_plugin_and_native(qi):
     NumpyT2, TorchT2 = plugin_models(qi)
     outcomes, eps = t2_data()
     runs = {}
-    for name, model in (("numpy", NumpyT2()), ("torch", TorchT2()), ("native", qi.UnknownT2Model())):
+    for name, model in (("numpy", NumpyT2()), ("torch", TorchT2()), ("hip", hip_model(qi)()), ("native", qi.UnknownT2Model())):
         np.random.seed(11)
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
@@ -91,12 +111,12 @@ def test_torch_plugin_equals_numpy_plugin_and_native(qi):
                 upd.update(int(outcomes[k]), eps[k:k + 1])
                 ess.append(float(upd.n_ess))
         runs[name] = (np.ravel(upd.normalization_record), np.array(ess), upd.est_mean(), upd.resample_count, model.call_count)
-    assert runs["torch"][3] == runs["numpy"][3] == runs["native"][3] > 0
-    for other in ("torch", "native"):
+    assert runs["torch"][3] == runs["numpy"][3] == runs["native"][3] == runs["hip"][3] > 0
+    for other in ("torch", "hip", "native"):
         np.testing.assert_allclose(runs[other][0], runs["numpy"][0], rtol=1e-12)
         np.testing.assert_allclose(runs[other][1], runs["numpy"][1], rtol=1e-10)
         np.testing.assert_allclose(runs[other][2], runs["numpy"][2], rtol=1e-10)
-    assert runs["torch"][4] == runs["numpy"][4] == 3000 * len(outcomes)      # call_count kept by the device hook too
+    assert runs["torch"][4] == runs["numpy"][4] == runs["hip"][4] == 3000 * len(outcomes)      # call_count kept by the hooks too
 
 
 def test_no_whole_cloud_host_copy_per_datum(qi, monkeypatch):
@@ -135,7 +155,17 @@ def test_no_whole_cloud_host_copy_per_datum(qi, monkeypatch):
         for k in range(12):
             upd_t.update(int(outcomes[k]), eps[k:k + 1])
         assert big == []
+        np.random.seed(1)
+        upd_h = qi.SMCUpdater(hip_model(qi)(), n, prior(qi), resample_thresh=0.0)
+        assert upd_h._uk is not None
+        del big[:]
+        for k in range(12):
+            upd_h.update(int(outcomes[k]), eps[k:k + 1])
+        assert big == []
     np.testing.assert_allclose(np.ravel(upd_t.normalization_record), np.ravel(upd.normalization_record)[:12], rtol=1e-12)
+    np.testing.assert_allclose(np.ravel(upd_h.normalization_record), np.ravel(upd.normalization_record)[:12], rtol=1e-12)
+    np.testing.assert_allclose(upd_h.est_mean(), upd_t.est_mean(), rtol=1e-11)
+    np.testing.assert_allclose(upd_h.est_covariance_mtx(), upd_t.est_covariance_mtx(), rtol=1e-8)
 
 
 def test_torch_plugin_device_rng_resample(qi):
@@ -145,7 +175,7 @@ def test_torch_plugin_device_rng_resample(qi):
     outcomes, eps = t2_data(60, seed=3)
     n = 40000
     means = {}
-    for name, model in (("torch", TorchT2()), ("numpy", NumpyT2()), ("native", qi.UnknownT2Model())):
+    for name, model in (("torch", TorchT2()), ("numpy", NumpyT2()), ("hip", hip_model(qi)()), ("native", qi.UnknownT2Model())):
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             upd = qi.SMCUpdater(model, n, prior(qi), device_rng=True, seed=7)
@@ -155,7 +185,7 @@ def test_torch_plugin_device_rng_resample(qi):
         locs = np.asarray(upd.particle_locations)
         assert locs.shape == (n, 2) and (locs >= 0).all()
         means[name] = (upd.est_mean(), np.sqrt(np.diag(upd.est_covariance_mtx())), upd.resample_count)
-    for other in ("torch", "numpy"):
+    for other in ("torch", "numpy", "hip"):
         # (different Philox draws than the native sampler's in-thread redraws: statistical agreement, in posterior sigmas)
         assert np.all(np.abs(means[other][0] - means["native"][0]) < 0.3 * means["native"][1]), means
         assert abs(means[other][2] - means["native"][2]) <= 2, means
@@ -204,3 +234,33 @@ def test_likelihood_device_shape_is_checked(qi):
         upd = qi.SMCUpdater(Wrong(), 100, prior(qi))
         with pytest.raises(TypeError):
             upd.update(0, np.array([(1.0,)], dtype=[('t', 'float')]))
+
+
+def test_likelihood_hip_contract_paths(qi):
+    """A compiled user model serves every caller of the likelihood: hypothetical_update (n_o x n_e), bayes_risk through the
+    generic design path, batch_update; a source that does not compile raises with the compiler's log."""
+    NumpyT2, _ = plugin_models(qi)
+    HipT2 = hip_model(qi)
+    outcomes, eps = t2_data(10)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        np.random.seed(3)
+        a = qi.SMCUpdater(NumpyT2(), 4000, prior(qi))
+        np.random.seed(3)
+        b = qi.SMCUpdater(HipT2(), 4000, prior(qi))
+        ha = a.hypothetical_update(np.array([0, 1]), eps[:3], return_likelihood=True, return_normalization=True)
+        hb = b.hypothetical_update(np.array([0, 1]), eps[:3], return_likelihood=True, return_normalization=True)
+        for u, v in zip(ha, hb):
+            np.testing.assert_allclose(v, u, rtol=1e-12, atol=1e-300)
+        np.testing.assert_allclose(b.bayes_risk(eps[:3]), a.bayes_risk(eps[:3]), rtol=1e-10)
+        np.random.seed(4)
+        a.batch_update(outcomes, eps, resample_interval=4)
+        np.random.seed(4)
+        b.batch_update(outcomes, eps, resample_interval=4)
+        np.testing.assert_allclose(np.ravel(b.normalization_record), np.ravel(a.normalization_record), rtol=1e-12)
+
+        class Broken(NumpyT2):
+            likelihood_hip = "__device__ double likelihood(const double *x, const double *ep, long long o) { return nope; }"
+        with pytest.raises(RuntimeError) as ei:
+            qi.SMCUpdater(Broken(), 100, prior(qi))
+        assert "nope" in str(ei.value)
