@@ -527,6 +527,21 @@ __device__ bool valid(const double *x) { return x[0] >= 0 && x[1] >= 0; }
                     "posterior_mean": [float(v) for v in upd.est_mean()]}
         del upd
         torch.cuda.empty_cache()
+    # the same data through batch_update(resample_interval=5): fused windows for the native model AND for the compiled one
+    for key, model in (("native", qi.UnknownT2Model()), ("hip_plugin", HipT2())):
+        upd = qi.SMCUpdater(model, n, qi.UniformDistribution([[0.0, 1.5], [0.0, 0.2]]), device_rng=True, seed=0)
+        upd.batch_update(outs[:15], eps[:15], resample_interval=5)
+        upd.reset()
+        rc0 = upd.resample_count
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        upd.batch_update(outs, eps, resample_interval=5)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        res[key]["batch_update_interval_5"] = {"ms_per_datum": wall / n_data * 1e3, "value": n * n_data / wall,
+                                               "resamples": upd.resample_count - rc0}
+        del upd
+        torch.cuda.empty_cache()
     res["hip_plugin"]["vs_native"] = res["hip_plugin"]["ms_per_datum"] / res["native"]["ms_per_datum"]
     res["torch_plugin"]["vs_native"] = res["torch_plugin"]["ms_per_datum"] / res["native"]["ms_per_datum"]
     res["numpy_plugin"]["vs_native"] = res["numpy_plugin"]["ms_per_datum"] / res["native"]["ms_per_datum"]

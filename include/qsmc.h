@@ -356,6 +356,11 @@ int qsmc_user_kernel_destroy(qsmc_user_kernel_t uk);
 int qsmc_update_user(qsmc_handle_t h, qsmc_user_kernel_t uk, const double *x, int64_t ldx, int64_t n, const double *w_in,
                      double *w_out, double prev_norm, const double *ep, int64_t outcome, double *stats_dev,
                      qsmc_update_stats_t *stats_host, double *moments_host, qsmc_stream_t stream);
+/* qsmc_update_multi for a compiled user model: the k <= 8 data of one batch_update window in one pass (eps: k rows of
+ * n_ep doubles; stats_host[k]; moments_host as above, of the window's final weights). */
+int qsmc_update_multi_user(qsmc_handle_t h, qsmc_user_kernel_t uk, const double *x, int64_t ldx, int64_t n, const double *w_in,
+                           double *w_out, double prev_norm, const double *eps, const int64_t *outcomes, int32_t k,
+                           qsmc_update_stats_t *stats_host, double *moments_host, qsmc_stream_t stream);
 /* qsmc_likelihood for a compiled user model: L_out[n_o][n_e][n]; eps: n_e rows of n_ep doubles on the host. */
 int qsmc_likelihood_user(qsmc_handle_t h, qsmc_user_kernel_t uk, const double *x, int64_t ldx, int64_t n, const double *eps,
                          int32_t n_e, const int64_t *outcomes, int32_t n_o, double *L_out, qsmc_stream_t stream);

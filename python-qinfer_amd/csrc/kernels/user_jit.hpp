@@ -128,6 +128,76 @@ extern "C" __global__ __launch_bounds__(QSMC_JIT_BLOCK) void qsmc_user_update(
     }
 }
 
+// A batch_update window (smc.py:459-487; k_update_multi's contract): k <= 8 data in ONE pass, w_j = w_{j-1} L_j without
+// renormalisation, per-datum sums [S_j, Q_j, #bad_j] at s[3 j ..], the moments of the final weights behind them, the
+// window's minimum last -- the layout qsmc_update_multi's host side reads.
+struct QsmcUserWindow {
+    double ep[8][QSMC_NEP > 0 ? QSMC_NEP : 1];
+    long long outcome[8];
+    int k;
+};
+#define QSMC_NSW (24 + QSMC_DMOM + QSMC_DMOM * (QSMC_DMOM + 1) / 2)
+extern "C" __global__ __launch_bounds__(QSMC_JIT_BLOCK) void qsmc_user_update_multi(
+    const double *__restrict__ x, long long ldx, long long n, const double *__restrict__ w_in,
+    double *__restrict__ w_out, double prev_norm, QsmcUserWindow win, double *__restrict__ partials) {
+    __shared__ double lds[(QSMC_JIT_BLOCK / 64) * (QSMC_NSW + 1)];
+    double s[QSMC_NSW];
+#pragma unroll
+    for (int q = 0; q < QSMC_NSW; ++q) s[q] = 0.0;
+    double mn = __builtin_huge_val();
+    const double inv_norm = 1.0 / prev_norm;
+    const long long tile = (long long)QSMC_JIT_BLOCK * 8;
+    for (long long base = (long long)blockIdx.x * tile; base < n; base += (long long)gridDim.x * tile) {
+#pragma unroll 1
+        for (int u = 0; u < 8; ++u) {
+            const long long i = base + (long long)u * QSMC_JIT_BLOCK + threadIdx.x;
+            if (i < n) {
+                double p[QSMC_D];
+#pragma unroll
+                for (int m = 0; m < QSMC_D; ++m) p[m] = x[(long long)m * ldx + i];
+                double w = (w_in ? w_in[i] : 1.0) * inv_norm;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (j < win.k) {
+                        w = w * likelihood(p, win.ep[j], win.outcome[j]);
+                        s[3 * j] += w;
+                        s[3 * j + 1] += w * w;
+                        s[3 * j + 2] += (w >= 0.0) ? 0.0 : 1.0;
+                        mn = fmin(mn, w);
+                    }
+                }
+                w_out[i] = w;
+                int q = 24 + QSMC_DMOM;
+#pragma unroll
+                for (int m = 0; m < QSMC_DMOM; ++m) {
+                    const double wx = w * p[m];
+                    s[24 + m] += wx;
+#pragma unroll
+                    for (int m2 = m; m2 < QSMC_DMOM; ++m2) s[q++] += wx * p[m2];
+                }
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < QSMC_NSW; ++q) s[q] = qsmc_wave_sum(s[q]);
+    mn = qsmc_wave_min(mn);
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < QSMC_NSW; ++q) lds[wave * (QSMC_NSW + 1) + q] = s[q];
+        lds[wave * (QSMC_NSW + 1) + QSMC_NSW] = mn;
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q <= QSMC_NSW; q += QSMC_JIT_BLOCK) {
+        double t = lds[q];
+        for (int wv2 = 1; wv2 < QSMC_JIT_BLOCK / 64; ++wv2) {
+            const double o = lds[wv2 * (QSMC_NSW + 1) + q];
+            t = (q < QSMC_NSW) ? t + o : fmin(t, o);
+        }
+        partials[(unsigned long long)q * gridDim.x + blockIdx.x] = t;
+    }
+}
+
 // L_out[i] = likelihood(x_i) for one (outcome, experiment) pair
 extern "C" __global__ __launch_bounds__(QSMC_JIT_BLOCK) void qsmc_user_likelihood(
     const double *__restrict__ x, long long ldx, long long n, QsmcUserEp ep, long long outcome, double *__restrict__ L_out) {

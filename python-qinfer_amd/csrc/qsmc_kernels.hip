@@ -2809,7 +2809,7 @@ int qsmc_publish_rows(qsmc_handle_t h, const double *rows_dev, int32_t n, int32_
 // side passes the one that ships with its torch, so that code object and runtime come from one ROCm), else by soname.
 struct qsmc_user_kernel {
     hipModule_t mod;
-    hipFunction_t upd, lik, valid;
+    hipFunction_t upd, upd_multi, lik, valid;
     int d, n_ep, has_valid;
 };
 
@@ -2911,6 +2911,7 @@ int qsmc_user_kernel_build(qsmc_handle_t h, const char *user_source, int32_t d, 
     hipError_t e = hipModuleLoadData(&uk->mod, code);
     free(code);
     if (e == hipSuccess) e = hipModuleGetFunction(&uk->upd, uk->mod, "qsmc_user_update");
+    if (e == hipSuccess) e = hipModuleGetFunction(&uk->upd_multi, uk->mod, "qsmc_user_update_multi");
     if (e == hipSuccess) e = hipModuleGetFunction(&uk->lik, uk->mod, "qsmc_user_likelihood");
     if (e == hipSuccess) e = hipModuleGetFunction(&uk->valid, uk->mod, "qsmc_user_valid");
     if (e != hipSuccess) {
@@ -2966,6 +2967,58 @@ int qsmc_update_user(qsmc_handle_t h, qsmc_user_kernel_t uk, const double *x, in
     rc = launch_reduce(h, ns, grid, ro, s);
     if (rc) return rc;
     return collect_stats(h, ns, stats_host, moments_host, n_mom, s);
+}
+
+// qsmc_update_multi's contract for a compiled user model: k <= 8 data of one batch_update window in one pass
+int qsmc_update_multi_user(qsmc_handle_t h, qsmc_user_kernel_t uk, const double *x, int64_t ldx, int64_t n, const double *w_in,
+                           double *w_out, double prev_norm, const double *eps, const int64_t *outcomes, int32_t k,
+                           qsmc_update_stats_t *stats_host, double *moments_host, qsmc_stream_t stream) {
+    if (h) { h->prep.valid = 0; h->rsq.valid = 0; h->canon_next.kind = 0; h->expect_next = 0.0; h->ts.w = nullptr; }
+    if (!h || !uk || !x || !w_out || !outcomes || !stats_host || n <= 0 || k < 1 || k > MULTI_KMAX || (uk->n_ep > 0 && !eps))
+        return QSMC_ERR_INVALID;
+    const int d = uk->d, dmom = d <= 4 ? d : 0;
+    if (moments_host && !dmom) return QSMC_ERR_UNSUPPORTED;
+    const int n_mom = dmom + dmom * (dmom + 1) / 2, ns = 3 * MULTI_KMAX + n_mom;
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = grid_for(n, 256 * 8);
+    int rc = ensure_partials(h, (size_t)grid * (ns + 1));
+    if (rc) return rc;
+    ReduceOut ro = make_reduce(h, true, nullptr);
+    ++h->ts.gen;
+    h->ts.armed = 0;
+    h->spec.launched = 0;
+    // QsmcUserWindow of kernels/user_jit.hpp: ep[8][max(n_ep, 1)], outcome[8], k -- built to that layout here
+    const int nep1 = uk->n_ep > 0 ? uk->n_ep : 1;
+    unsigned char win[8 * USER_MAX_EP * sizeof(double) + 8 * sizeof(long long) + 16];
+    memset(win, 0, sizeof(win));
+    double *wep = reinterpret_cast<double *>(win);
+    for (int j = 0; j < k; ++j)
+        for (int q = 0; q < uk->n_ep; ++q) wep[(size_t)j * nep1 + q] = eps[(size_t)j * uk->n_ep + q];
+    long long *woc = reinterpret_cast<long long *>(win + (size_t)8 * nep1 * sizeof(double));
+    for (int j = 0; j < k; ++j) woc[j] = outcomes[j];
+    int *wk = reinterpret_cast<int *>(win + (size_t)8 * nep1 * sizeof(double) + 8 * sizeof(long long));
+    *wk = k;
+    long long ldx_ = ldx, n_ = n;
+    double *partials = h->partials;
+    void *args[] = {(void *)&x, (void *)&ldx_, (void *)&n_, (void *)&w_in, (void *)&w_out, (void *)&prev_norm, (void *)win,
+                    (void *)&partials};
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    prof_events(h, QSMC_PROF_UPDATE_MULTI, &e0, &e1);
+    if (e0) HIP_TRY(h, hipEventRecord(e0, s));
+    HIP_TRY(h, hipModuleLaunchKernel(uk->upd_multi, (unsigned)grid, 1, 1, 256, 1, 1, 0, s, args, nullptr));
+    if (e1) HIP_TRY(h, hipEventRecord(e1, s));
+    rc = launch_reduce(h, ns, grid, ro, s);
+    if (rc) return rc;
+    rc = wait_reduction(h, s);
+    if (rc) return rc;
+    for (int j = 0; j < k; ++j) {
+        stats_host[j].sum = h->mapped[3 * j];
+        stats_host[j].sumsq = h->mapped[3 * j + 1];
+        stats_host[j].n_bad = h->mapped[3 * j + 2];
+        stats_host[j].min = h->mapped[ns];
+    }
+    if (moments_host) memcpy(moments_host, h->mapped + 3 * MULTI_KMAX, (size_t)n_mom * sizeof(double));
+    return QSMC_OK;
 }
 
 // L_out[o][e][i] = likelihood(x_i; eps[e], outcomes[o]): qsmc_likelihood's layout for a compiled user model

@@ -117,6 +117,8 @@ SIGNATURES = {
     "qsmc_user_kernel_destroy": [_P],
     "qsmc_update_user": [_P, _P, _P, _I64, _I64, _P, _P, _F64, C.POINTER(_F64), _I64, _P, C.POINTER(UpdateStats),
                          C.POINTER(_F64), _P],
+    "qsmc_update_multi_user": [_P, _P, _P, _I64, _I64, _P, _P, _F64, C.POINTER(_F64), C.POINTER(_I64), _I32,
+                               C.POINTER(UpdateStats), C.POINTER(_F64), _P],
     "qsmc_likelihood_user": [_P, _P, _P, _I64, _I64, C.POINTER(_F64), _I32, C.POINTER(_I64), _I32, _P, _P],
     "qsmc_valid_user": [_P, _P, _P, _I64, _I64, _P, _P],
     "qsmc_clip_weights": [_P, _P, _I64, _F64, _P, C.POINTER(UpdateStats), _P],

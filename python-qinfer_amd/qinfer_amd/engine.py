@@ -328,6 +328,25 @@ class Engine:
             self._stats.data_ptr(), self._st_ref, self._mom_ptr[d] if moments else None, self.stream()), "qsmc_update_user")
         return self._st
 
+    def update_multi_user(self, uk, x, w_in, w_out, prev_norm, eps, outcomes):
+        """`update_multi` for a compiled user model (qsmc_update_multi_user): eps (k, n_ep) float64, k <= 8 data."""
+        if self._design_jobs:
+            self._no_design_in_flight("update_multi_user")
+        eps = np.ascontiguousarray(eps, dtype=np.float64)
+        k, d = eps.shape[0], x.shape[0]
+        oc = (C.c_int64 * k)(*[int(o) for o in outcomes])
+        st = (_native.UpdateStats * k)()
+        mom = np.empty(d + d * (d + 1) // 2, dtype=np.float64) if d <= 4 else None
+        flat = np.ascontiguousarray(eps.reshape(-1)) if eps.size else np.zeros(1)
+        self._chk(self.lib.qsmc_update_multi_user(
+            self.h, uk.ptr, self._p(x), x.stride(0), x.shape[1], self._p(w_in) if w_in is not None else None, self._p(w_out),
+            float(prev_norm), flat.ctypes.data_as(C.POINTER(C.c_double)), oc, k, st,
+            _native.f64_ptr(mom) if mom is not None else None, self.stream()), "qsmc_update_multi_user")
+        self.update_gen += 1
+        if mom is None:
+            return list(st), None, None
+        return list(st), mom[:d].copy(), self._unpack_upper(mom[d:], d)
+
     def likelihood_user(self, uk, x, eps, outcomes):
         """L[n_o, n_e, N] on the device from a compiled user model; eps: (n_e, n_ep) float64."""
         n = x.shape[1]

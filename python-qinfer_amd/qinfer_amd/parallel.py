@@ -286,7 +286,11 @@ class ParticleShardGroup:
 
         def work():
             try:
-                box["ok"] = leg("rccl")
+                t.cuda.set_device(dev)
+                # (a stream of its own: should a peer never join the collective, the kernel that waits for it blocks this
+                #  side stream, not the one every later launch of the process goes to)
+                with t.cuda.stream(t.cuda.Stream()):
+                    box["ok"] = leg("rccl")
             except BaseException as e:  # noqa: BLE001
                 box["err"] = repr(e)
         th = threading.Thread(target=work, daemon=True, name="qsmc-transport-probe")

@@ -765,7 +765,7 @@ class SMCUpdater(ParticleDistribution):
             raise ValueError("The number of outcomes and experiments must match.")
         if len(expparams.shape) == 1:
             expparams = expparams[:, None]
-        fast = (self._native and self._batch_fast_path
+        fast = ((self._native or (self._uk is not None and self._timestep_identity)) and self._batch_fast_path
                 and getattr(self.model, "_native_timestep", None) is None)   # moving particles: one datum at a time
         idx = 0
         kmax = self._eng.MULTI_KMAX
@@ -787,15 +787,25 @@ class SMCUpdater(ParticleDistribution):
         guard of the per-datum loop would have fired, so the caller can replay it faithfully."""
         eng = self._eng
         k = len(outcomes)
-        exps, outs = [], []
-        for j in range(k):
-            e = self.model._native_expparams(expparams[j])
-            if len(e) != 1:
-                return False
-            exps.append(e[0])
-            outs.append(_as_int_outcome(outcomes[j]))
         w_out = self._scratch_weights()
-        stats, m1, m2 = eng.update_multi(self._desc, self._x, self._w, w_out, self._norm, exps, outs)
+        if self._uk is not None:
+            # a compiled user model (likelihood_hip): the window through its own JIT window kernel
+            epm = np.vstack([_user_ep_matrix(expparams[j]) for j in range(k)])
+            if epm.shape[0] != k:
+                return False
+            outs = [_as_int_outcome(outcomes[j]) for j in range(k)]
+            stats, m1, m2 = eng.update_multi_user(self._uk, self._x, self._w, w_out, self._norm, epm, outs)
+            if hasattr(self.model, "count_likelihood_calls"):
+                self.model.count_likelihood_calls(1, self._x.shape[1], k)
+        else:
+            exps, outs = [], []
+            for j in range(k):
+                e = self.model._native_expparams(expparams[j])
+                if len(e) != 1:
+                    return False
+                exps.append(e[0])
+                outs.append(_as_int_outcome(outcomes[j]))
+            stats, m1, m2 = eng.update_multi(self._desc, self._x, self._w, w_out, self._norm, exps, outs)
         if self._comm is not None:
             # sharded: the window's per-datum sums (and the moment sums of its last datum) are additive over the
             # shards -- one small reduction for the whole window instead of one per datum

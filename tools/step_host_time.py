@@ -10,6 +10,10 @@ import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'python-qinfer_amd'))
 import torch  # noqa: E402
 import qinfer_amd as qi  # noqa: E402
+import qinfer_amd.smc as _smc  # noqa: E402
+
+if os.environ.get("QSMC_NO_STEP"):            # (this tool's own switch: the Python per-datum path, a module attribute since round 6)
+    _smc._NO_STEP = True
 
 warnings.simplefilter('ignore')
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000

@@ -60,8 +60,8 @@ with warnings.catch_warnings():
             print("interval %d %-14s %.3e p-u/s  %.4f ms/datum  resamples %d  window kernel %s us (%d)  single-datum kernel %s us (%d)  dense=%s" % (
                 interval, "windows" if fast else "per-datum loop", n * K / wall, wall / K * 1e3, upd.resample_count - rc0,
                 "%.1f" % (win.mean() * 1e3) if len(win) else "-", len(win), "%.1f" % (one.mean() * 1e3) if len(one) else "-", len(one),
-                bool(os.environ.get("QSMC_TOMO_DENSE_UPDATE"))), flush=True)
+                "tomo_dense" in os.environ.get("QSMC_TEST_HOOKS", "")), flush=True)
             del upd
-if not os.environ.get("QSMC_TOMO_DENSE_UPDATE"):
+if "tomo_dense" not in os.environ.get("QSMC_TEST_HOOKS", ""):
     import subprocess
-    subprocess.run([sys.executable, os.path.abspath(__file__)], env=dict(os.environ, QSMC_TOMO_DENSE_UPDATE="1"))
+    subprocess.run([sys.executable, os.path.abspath(__file__)], env=dict(os.environ, QSMC_TEST_HOOKS="tomo_dense=1"))
