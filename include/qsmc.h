@@ -27,8 +27,15 @@
 extern "C" {
 #endif
 
-#define QSMC_ABI_VERSION 2
-#define QSMC_MAX_D 16            /* largest n_modelparams with a native kernel (2-qubit tomography) */
+#define QSMC_ABI_VERSION 3
+#define QSMC_MAX_D 16            /* largest n_modelparams the narrow kernels take (2-qubit tomography): a particle, the mean and
+                                    S ride in registers / the kernarg segment */
+#define QSMC_MAX_D_WIDE 64       /* largest n_modelparams with native kernels at all: QSMC_MODEL_TOMOGRAPHY with 16 < d <= 64
+                                    (dim 5 .. 8; three qubits: d = 64) takes the wide kernels (csrc/kernels/wide.hpp) in
+                                    qsmc_likelihood, qsmc_update_fused, qsmc_step (update and tests; a due resample is the
+                                    caller's), qsmc_moments, qsmc_lw_centres / _perturb, qsmc_lw_resample_philox (+ _prepare)
+                                    and qsmc_tomo_canonicalize2; qsmc_update_multi and the qsmc_hypothetical_sums_* family
+                                    return QSMC_ERR_UNSUPPORTED above QSMC_MAX_D (callers loop / use qsmc_likelihood) */
 
 typedef struct qsmc_ctx *qsmc_handle_t;
 typedef void *qsmc_stream_t;     /* hipStream_t */
@@ -71,7 +78,9 @@ typedef struct qsmc_expparam {
     uint64_t m;                  /* RB: sequence length expparams['m']                             */
     int32_t  reference;          /* RB interleaved: expparams['reference']                         */
     int32_t  reserved;
-    double   meas[QSMC_MAX_D];   /* tomography: expparams['meas'] (length d)                       */
+    double   meas[QSMC_MAX_D];   /* tomography: expparams['meas'] (length d), d <= QSMC_MAX_D       */
+    const double *meas_wide;     /* tomography, d > QSMC_MAX_D: expparams['meas'] (length d), HOST memory read during
+                                    the call; meas[] is ignored then.  NULL otherwise.               */
 } qsmc_expparam_t;
 
 /* Per-update reduction results (all over the UNNORMALISED new weights w' = (w/norm) * L). */
@@ -474,7 +483,8 @@ int qsmc_fill(qsmc_handle_t h, double *w, int64_t n, double value, qsmc_stream_t
 
 /* ---- weighted moments (distributions.py:337-399, utils.py:216-287; a11-a12) --------------- */
 /* out_host / out_dev: [ sum w~, sum w~ x_m (d), sum w~ x_m x_n for m <= n row-major (d(d+1)/2) ]
- * with w~ = w / norm.  Synchronises if out_host != NULL. */
+ * with w~ = w / norm.  Synchronises if out_host != NULL.  d <= 4: VALU; 4 < d <= 16 and 16 < d <= QSMC_MAX_D_WIDE: the
+ * contraction X diag(w) X^T on the f64 matrix cores (k_moments_mfma; k_moments_wide in 16 x 16 blocks). */
 int qsmc_moments(qsmc_handle_t h, const double *x, int64_t ldx, int64_t n, int32_t d,
                  const double *w, double norm, double *out_dev, double *out_host,
                  qsmc_stream_t stream);
@@ -493,7 +503,7 @@ int qsmc_cumsum(qsmc_handle_t h, const double *w, int64_t n, double norm, double
 int qsmc_lw_ancestors(qsmc_handle_t h, const double *cdf, int64_t n_in,
                       const double *u, int64_t n_out, int64_t *js, qsmc_stream_t stream);
 
-/* mus[m][i] = a * x_in[m][js[i]] + (1 - a) * mean[m]   (:325).  mean is HOST (d). */
+/* mus[m][i] = a * x_in[m][js[i]] + (1 - a) * mean[m]   (:325).  mean is HOST (d).  d <= QSMC_MAX_D_WIDE. */
 int qsmc_lw_centres(qsmc_handle_t h, const double *x_in, int64_t ldx_in, int32_t d,
                     const int64_t *js, int64_t n_out, double a, const double *mean,
                     double *mus, int64_t ld_mus, qsmc_stream_t stream);
@@ -503,7 +513,7 @@ int qsmc_lw_centres(qsmc_handle_t h, const double *x_in, int64_t ldx_in, int32_t
  *     c   = centre_by_idx ? dst : r          (r = the reference's `mus[:k]` truncation, quirk Q1)
  *     x_out[:, dst] = mus[:, c] + S @ z[:, r]        z is DEVICE [d][k] (param-major, :332)
  *     valid_out[r]  = model.are_models_valid(x_out[:, dst])   (1 if !postselect)
- * S is HOST d x d row-major (already scaled by h, :300). */
+ * S is HOST d x d row-major (already scaled by h, :300).  d > QSMC_MAX_D (tomography): no validity test, valid_out = 1. */
 int qsmc_lw_perturb(qsmc_handle_t h, const qsmc_model_t *model, int32_t postselect,
                     const double *mus, int64_t ld_mus, const int64_t *idxs, int64_t k,
                     int32_t centre_by_idx, const double *S, const double *z, int64_t ldz,
@@ -520,7 +530,10 @@ int qsmc_lw_perturb(qsmc_handle_t h, const qsmc_model_t *model, int32_t postsele
  * resamplers.py:308-316, without n_out uniforms), then one workgroup per chunk scans ITS weights in LDS,
  * so the CDF is never written to HBM; outputs come ordered by ancestor chunk (particles are
  * exchangeable; same joint law).  The global CDF is materialised only if a particle needs a global
- * redraw.  Otherwise: CDF + one binary search per particle. */
+ * redraw.  Otherwise: CDF + one binary search per particle.
+ * 16 < d <= QSMC_MAX_D_WIDE (QSMC_MODEL_TOMOGRAPHY; no validity test): the same ancestors -- k_bucket_anc16 where the
+ * bucketed sampler applies, else the direct search -- and the kicks S z on the f64 matrix cores (k_kick_wide); mean and S
+ * are copied to the device by the call.  Canonicalize is a call of its own (qsmc_tomo_canonicalize2). */
 int qsmc_lw_resample_philox(qsmc_handle_t h, const qsmc_model_t *model, int32_t postselect,
                             const double *x_in, int64_t ldx_in, int64_t n_in, int32_t d,
                             const double *w, double norm, double a, const double *mean, const double *S,
@@ -641,7 +654,8 @@ int qsmc_prior_uniform_philox(qsmc_handle_t h, const qsmc_model_t *model, int32_
 int qsmc_random_walk(qsmc_handle_t h, double *x, int64_t ldx, int64_t n, int32_t d, const double *scale,
                      const double *z, int64_t ldz, uint64_t seed, uint64_t epoch, qsmc_stream_t stream);
 
-/* basis: DEVICE complex128 (d, dim, dim) row-major as interleaved (re, im), d = dim*dim, dim = 2, 3 or 4.
+/* basis: DEVICE complex128 (d, dim, dim) row-major as interleaved (re, im), d = dim*dim, dim = 2 .. 8
+ * (dim 5 .. 8: two passes -- an LDL^H pivot test sorts out the positive-definite particles, the rest take the Jacobi form).
  * In place: clamp negative eigenvalues of rho(x), then x /= x_0 sqrt(dim) unless allow_subnormalized. */
 int qsmc_tomo_canonicalize(qsmc_handle_t h, const double *basis, int32_t dim,
                            double *x, int64_t ldx, int64_t n, int32_t allow_subnormalized,

@@ -80,7 +80,7 @@ class Recorder:
 
 
 def run_trajectory(name, model, prior, n_particles, expparams, outcomes_fn, seed=0,
-                   batch_interval=None, **lw_kwargs):
+                   batch_interval=None, cov_stride=None, **lw_kwargs):
     """Run reference SMCUpdater over a schedule, recording draws and the per-datum state."""
     np.random.seed(seed)
     rec = Recorder()
@@ -106,7 +106,8 @@ def run_trajectory(name, model, prior, n_particles, expparams, outcomes_fn, seed
                 if (k + 1) % batch_interval == 0:
                     upd._maybe_resample()
             means.append(upd.est_mean())
-            covs.append(upd.est_covariance_mtx())
+            if cov_stride is None or k % cov_stride == 0:     # (wide clouds: a 64 x 64 covariance per datum is 32 KB)
+                covs.append(upd.est_covariance_mtx())
             esss.append(upd.n_ess)
             rcs.append(upd.resample_count)
             norms.append(upd.normalization_record[-1])
@@ -115,6 +116,8 @@ def run_trajectory(name, model, prior, n_particles, expparams, outcomes_fn, seed
                resample_count=np.array(rcs), norms=np.array(norms),
                final_locs=upd.particle_locations, final_weights=upd.particle_weights,
                min_n_ess=upd.min_n_ess, n_prior_draws=n_prior_draws, **rec.arrays())
+    if cov_stride is not None:
+        out["cov_stride"] = cov_stride                        # covs[j] belongs to datum j * cov_stride
     for fname in (expparams.dtype.names or ()):
         out["ep_" + fname] = expparams[fname]
     if expparams.dtype.names is None:
@@ -824,6 +827,104 @@ def g14_kl_divergence():
     print("g14_kl_divergence", out['d1_kl'], out['d3_kl'], out['prec_divergences'][:3], out['rb_divergences'][:3])
 
 
+
+# ------------------------------------------------------------------------------------------
+# Round 6: tomography beyond two qubits (dim 5 .. 8, d = dim^2 up to 64: the wide kernels, csrc/kernels/wide.hpp).  The
+# reference handles any dim (tomography/models.py:82-226); these fixtures pin likelihood, moments, canonicalize and a whole
+# SMCUpdater trajectory of a three-qubit model.
+def _pauli_meas(m, paulis):
+    ep = np.zeros((len(paulis),), dtype=m.expparams_dtype)
+    for k, p in enumerate(paulis):
+        ep['meas'][k, 0] = 1.0            # (I + P) / 2 = B_0 + B_p up to the basis' normalisation: e_0 + e_p
+        ep['meas'][k, p] = 1.0
+    return ep
+
+
+def g1_tomography_3q():
+    basis = pauli_basis(3)
+    m = TomographyModel(basis)
+    rng = np.random.RandomState(17)
+    x0 = orc.ginibre_prior_sample(200, basis.data, rng)
+    true = orc.ginibre_prior_sample(1, basis.data, rng)
+    ep = _pauli_meas(m, rng.randint(1, 64, size=240))
+    sim = lambda k, e: m.simulate_experiment(true, e)
+    run_trajectory("g1_tomography_3q_n200", m, FixedPrior(x0), 200, ep, sim, cov_stride=40)
+
+
+def g2_tomography_wide():
+    out = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for tag, basis in (("3q", pauli_basis(3)), ("gm5", gell_mann_basis(5)),
+                           ("q2xq3", qinfer.tomography.tensor_product_basis(gell_mann_basis(2), gell_mann_basis(3)))):
+            tm = TomographyModel(basis)
+            d = basis.data.shape[0]
+            rs = np.random.RandomState(100 + d)
+            xt = orc.ginibre_prior_sample(48, basis.data, rs)
+            xt[::7] *= 1.3                               # some unphysical ones: exercises the clip
+            ep = np.zeros((8,), dtype=tm.expparams_dtype)
+            for k in range(5):                            # sparse: e_0 + e_p
+                ep['meas'][k, 0] = 1.0
+                ep['meas'][k, rs.randint(1, d)] = 1.0
+            for k in range(5, 8):                         # dense: a random pure-state projector's coefficients
+                v = rs.randn(basis.data.shape[1]) + 1j * rs.randn(basis.data.shape[1])
+                v /= np.linalg.norm(v)
+                ep['meas'][k] = np.real(np.einsum('aij,ij->a', basis.data.conj(), np.outer(v, v.conj())))
+            out[tag + '_x'], out[tag + '_meas'] = xt, ep['meas']
+            out[tag + '_L'] = tm.likelihood(np.array([0, 1]), xt, ep)
+            out[tag + '_basis'] = basis.data
+    np.savez_compressed(os.path.join(OUT, "g2_tomography_wide.npz"), **out)
+    print("g2_tomography_wide")
+
+
+def g3_moments_wide():
+    out = {}
+    rs = np.random.RandomState(23)
+    cases = []
+    for d, n in [(17, 33), (25, 300), (36, 1), (49, 257), (64, 7), (64, 520)]:
+        x = rs.randn(n, d) * rs.uniform(0.1, 2, size=d) + rs.uniform(-1, 1, size=d)
+        w = rs.random_sample(n) ** 3
+        w /= w.sum()
+        cases.append(("d%d_n%d" % (d, n), w, x))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for tag, w, x in cases:
+            pd = qinfer.ParticleDistribution(particle_locations=x, particle_weights=w)
+            out[tag + "_w"], out[tag + "_x"] = pd.particle_weights, x
+            out[tag + "_mean"] = pd.est_mean()
+            cov = pd.est_covariance_mtx()
+            out[tag + "_cov"] = cov
+            out[tag + "_ess"] = pd.n_ess
+            S, err = qinfer.utils.sqrtm_psd(cov)
+            out[tag + "_sqrt"], out[tag + "_sqrt_err"] = S, err
+    out['tags'] = np.array([c[0] for c in cases])
+    np.savez_compressed(os.path.join(OUT, "g3_moments_wide.npz"), **out)
+    print("g3_moments_wide")
+
+
+def g5_canonicalize_wide():
+    """tomography/models.py:149-209 at dim 5, 6, 7, 8 (three qubits)."""
+    out = {}
+    bases = (("gm5", gell_mann_basis(5), 64), ("q2xq3", qinfer.tomography.tensor_product_basis(gell_mann_basis(2), gell_mann_basis(3)), 64),
+             ("gm7", gell_mann_basis(7), 48), ("3q", pauli_basis(3), 128))
+    for tag, basis, n in bases:
+        dim = basis.data.shape[1]
+        d = dim * dim
+        tm = TomographyModel(basis)
+        rs = np.random.RandomState(50 + dim)
+        x = orc.ginibre_prior_sample(n, basis.data, rs)
+        x[:, 1:] += (0.2 / dim) * rs.randn(n, d - 1) * (rs.random_sample((n, 1)) < 0.7)   # ~70 % pushed out of the cone
+        x[:, 0] = 1 / np.sqrt(dim) + 0.01 * rs.randn(n)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            y = tm.canonicalize(x.copy())
+            y2 = TomographyModel(basis, allow_subnormalized=True).canonicalize(x.copy())
+        rho = np.tensordot(x, basis.data, 1)
+        n_bad = int((np.linalg.eigvalsh(rho).min(axis=1) < 0).sum())
+        out[tag + '_x'], out[tag + '_y'], out[tag + '_y_subnorm'], out[tag + '_basis'] = x, y, y2, basis.data
+        print("g5_canonicalize_wide", tag, n_bad, "of", n, "not PSD")
+    np.savez_compressed(os.path.join(OUT, "g5_canonicalize_wide.npz"), **out)
+
 if __name__ == "__main__":
     g1_precession()
     g1_binomial()
@@ -847,4 +948,8 @@ if __name__ == "__main__":
     g2_edges()
     g1_clouds()
     g14_kl_divergence()
+    g1_tomography_3q()
+    g2_tomography_wide()
+    g3_moments_wide()
+    g5_canonicalize_wide()
     print("total bytes:", sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT)))

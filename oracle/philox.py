@@ -319,12 +319,13 @@ def bank_serve(failed_slots, bank_vals, bank_ok, out, seed, epoch):
 
 def liu_west_philox_bucketed(w, x, valid_fn, a, h, seed, epoch, n_out, maxiter=1000, postselect=True,
                              mean=None, cov=None, zero_cov_comp=1e-10, cdf=None, margin=5.0, sort_items=None,
-                             expect_redraws=0):
+                             expect_redraws=0, z_stride=None):
     """Oracle of the bucketed device-RNG resampler (k_bucket_counts / k_bucket_sample).  Outputs are
     ordered by ancestor CHUNK.  Stream layout (round 0, two outputs per Philox block):
       slot 0: the Poisson chunk counts, slots 3 / 4 their top-up / removal (poissonised_counts); slot 1:
       within-chunk position of slot o (independent of the counts);
-      slot 2: normal n = o * d + q.  Retries (round r >= 1) are per output and redraw a GLOBAL
+      slot 2: normal n = o * z_stride + q (z_stride = d; the wide kick kernel, 16 < d <= 64, pads it to a multiple of
+      16: 16 ceil(d / 16), csrc/kernels/wide.hpp).  Retries (round r >= 1) are per output and redraw a GLOBAL
       ancestor from block (o, r, 0) and normals from (o, r, 1 + q // 2)."""
     import np_oracle as orc
     N, d = x.shape
@@ -359,7 +360,8 @@ def liu_west_philox_bucketed(w, x, valid_fn, a, h, seed, epoch, n_out, maxiter=1
             for b in range(int(slot0[c]), int(slot0[c + 1]), cap):
                 e = min(b + cap, int(slot0[c + 1]))
                 js[b:e] = np.sort(js[b:e], kind='stable')
-    z = np.stack([_pair_normal(ids * d + q, seed, epoch, 2) for q in range(d)])      # (d, n_out)
+    z_stride = d if z_stride is None else int(z_stride)
+    z = np.stack([_pair_normal(ids * z_stride + q, seed, epoch, 2) for q in range(d)])      # (d, n_out)
     out = (a * x[js] + (1 - a) * mean) + (S @ z).T
     ok = valid_fn(out) if postselect else np.ones(n_out, dtype=bool)
     todo = ids[~ok]

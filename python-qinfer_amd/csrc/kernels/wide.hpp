@@ -1,0 +1,471 @@
+// kernels/wide.hpp -- clouds of 16 < d <= 64 parameters: tomography beyond two qubits (dim 5 .. 8, d = dim^2; three qubits:
+// dim 8, d = 64).  The reference's TomographyModel takes any dim (tomography/models.py:82-226); rounds 1-5 stopped at
+// QSMC_MAX_D = 16 because the narrow kernels carry a particle (and S, the mean, the measurement vector) in registers /
+// the kernarg segment.  Here nothing of size d lives in a lane across a loop and nothing of size d^2 rides in a kernarg:
+//   k_update_tomo_wide / k_likelihood_wide   Pr(1 | x) = clip(meas . x, 0, 1) over the NONZERO entries of meas (a Pauli
+//                         measurement touches 2 of 64 rows: 16 + 8 nnz bytes per particle), rows streamed one at a time;
+//   k_moments_wide<NB>    sum w x x^T as NB (NB + 1) / 2 blocks of 16 x 16 on v_mfma_f64_16x16x4 (NB = ceil(d / 16));
+//   k_anc_direct + k_kick_wide<NB>   Liu-West: ancestors (small clouds; large ones reuse k_bucket_anc16, which needs the
+//                         weights only) and the kicks S z as NB x NB chains of the same MFMA, S and the mean from device memory;
+//   k_centres_wide / k_perturb_wide   the legacy-RNG pieces (resamplers.py:318-372) for d > 16;
+//   k_tomo_classify_wide<DIM> / k_tomo_canon_list_wide<DIM>   canonicalize (tomography/models.py:149-209), dim 5 .. 8.
+// Part of the single translation unit qsmc_kernels.hip (included there after resample.hpp and walk_tomo.hpp).
+#pragma once
+
+constexpr int WIDE_D = QSMC_MAX_D_WIDE;
+struct TomoWideArgs {
+    int32_t d, nnz;
+    double lik_pow;              // MLEModel power (0 = plain)
+    int32_t idx[WIDE_D];         // the rows meas does not vanish on, ascending
+    double val[WIDE_D];          // ... and its entries there
+};
+
+__device__ __forceinline__ double tomo_wide_lik(double s, int64_t outcome, double lik_pow) {
+    // tomography/models.py:216-226: pr1 = clip(sum_i meas_i x_i, 0, 1); outcome 0 -> 1 - pr1
+    const double pr1 = fmin(fmax(s, 0.0), 1.0);
+    const double L = two_outcome(1.0 - pr1, outcome);
+    return lik_pow == 0.0 ? L : pow(L, lik_pow);
+}
+
+// Same tiles, tile sums and partial rows as k_update_tomo (update.hpp): everything behind it (reduction, chunk prefix,
+// speculative counts, resample prefix) is unchanged.  The sum runs over the nonzero entries in ascending row order -- the
+// skipped terms are +-0 -- in separate multiplies and adds (-ffp-contract=off), like the narrow kernels.
+template <int VEC, bool ONES>
+__global__ __launch_bounds__(QSMC_BLOCK) void k_update_tomo_wide(
+    const double *__restrict__ x, int64_t ldx, int64_t n, const double *__restrict__ w_in,
+    double *__restrict__ w_out, double prev_norm, TomoWideArgs e, int64_t outcome, ReduceOut ro) {
+    constexpr int64_t TILE = (int64_t)QSMC_BLOCK * VEC * UPD_UNROLL;
+    UpdAcc<0> acc;
+    acc.init();
+    const double inv_norm = 1.0 / prev_norm;
+    for (int64_t base = (int64_t)blockIdx.x * TILE; base < n; base += (int64_t)gridDim.x * TILE) {
+        double tsum = 0.0;
+        if (VEC == 2 && base + TILE <= n) {
+            double s0[UPD_UNROLL], s1[UPD_UNROLL];
+#pragma unroll
+            for (int u = 0; u < UPD_UNROLL; ++u) { s0[u] = 0.0; s1[u] = 0.0; }
+#pragma unroll 2
+            for (int j = 0; j < e.nnz; ++j) {                  // (uniform: idx / val come out of the kernarg segment)
+                const double *row = x + (int64_t)e.idx[j] * ldx + base;
+                const double mv = e.val[j];
+#pragma unroll
+                for (int u = 0; u < UPD_UNROLL; ++u) {
+                    const double2 xv = *reinterpret_cast<const double2 *>(row + ((int64_t)u * QSMC_BLOCK + threadIdx.x) * 2);
+                    s0[u] += mv * xv.x;
+                    s1[u] += mv * xv.y;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UPD_UNROLL; ++u) {
+                const int64_t i = base + ((int64_t)u * QSMC_BLOCK + threadIdx.x) * 2;
+                double2 wi;
+                if (ONES) { wi.x = 1.0; wi.y = 1.0; } else wi = *reinterpret_cast<const double2 *>(w_in + i);
+                double2 wo;
+                wo.x = (wi.x * inv_norm) * tomo_wide_lik(s0[u], outcome, e.lik_pow);
+                wo.y = (wi.y * inv_norm) * tomo_wide_lik(s1[u], outcome, e.lik_pow);
+                *reinterpret_cast<double2 *>(w_out + i) = wo;
+                acc.add(wo.x, nullptr);
+                acc.add(wo.y, nullptr);
+                tsum += wo.x + wo.y;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < UPD_UNROLL; ++u) {
+#pragma unroll
+                for (int hh = 0; hh < VEC; ++hh) {
+                    const int64_t i = base + ((int64_t)u * QSMC_BLOCK + threadIdx.x) * VEC + hh;
+                    if (i < n) {
+                        double s = 0.0;
+                        for (int j = 0; j < e.nnz; ++j) s += e.val[j] * x[(int64_t)e.idx[j] * ldx + i];
+                        const double wo = ((ONES ? 1.0 : w_in[i]) * inv_norm) * tomo_wide_lik(s, outcome, e.lik_pow);
+                        w_out[i] = wo;
+                        acc.add(wo, nullptr);
+                        tsum += wo;
+                    }
+                }
+            }
+        }
+        if (ro.tile_sums) {                      // uniform
+            const double t = wave_sum(tsum);
+            if ((threadIdx.x & (QSMC_WAVE - 1)) == 0)
+                ro.tile_sums[(base / TILE) * QSMC_WAVES_PER_BLOCK + threadIdx.x / QSMC_WAVE] = t;
+        }
+    }
+    if (ro.tile_sums) {                          // (as in k_update_fused: zero the last chunk's missing tiles)
+        static_assert(4096 % TILE == 0, "tiles per chunk");
+        constexpr int64_t PER_CHUNK = 4096 / TILE * QSMC_WAVES_PER_BLOCK;
+        const int64_t last = (n - 1) / TILE;
+        if ((int64_t)blockIdx.x == last % (int64_t)gridDim.x) {
+            const int64_t first = (last + 1) * QSMC_WAVES_PER_BLOCK;
+            const int64_t end = (first + PER_CHUNK - 1) / PER_CHUNK * PER_CHUNK;
+            for (int64_t k = first + threadIdx.x; k < end; k += QSMC_BLOCK) ro.tile_sums[k] = 0.0;
+        }
+    }
+    block_publish<3>(acc.s, acc.mn, ro);
+}
+
+__global__ __launch_bounds__(QSMC_BLOCK) void k_likelihood_wide(const double *__restrict__ x, int64_t ldx, int64_t n,
+                                                                TomoWideArgs e, int64_t outcome, double *__restrict__ L) {
+    for (int64_t i = (int64_t)blockIdx.x * QSMC_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * QSMC_BLOCK) {
+        double s = 0.0;
+        for (int j = 0; j < e.nnz; ++j) s += e.val[j] * x[(int64_t)e.idx[j] * ldx + i];
+        L[i] = tomo_wide_lik(s, outcome, e.lik_pow);
+    }
+}
+
+// =============================================================================================
+// weighted moments, 16 < d <= 64: X diag(w) X^T in 16 x 16 blocks (upper block triangle) on the f64 matrix cores.
+// Operand layout as in k_moments_mfma: lane l = (m = l & 15, kq = l >> 4) holds A[m][kq] and B[kq][m] of one MFMA step;
+// with rows = parameters and the 4 k-slots = particles both are x values of the lane's own row -- for block pair
+// (bi, bj): A = w x_{16 bi + m}, B = x_{16 bj + m} of particle 4 kq + q (step q).  A lane reads one double4 (4 consecutive
+// particles) of its row in each of the NB row blocks per 16 particles and feeds 4 NB (NB + 1) / 2 MFMAs.
+// d = 64: 40 MFMAs (64 cycles each at 78.6 TFLOP/s) per 2.1 KB read -- 65 us of matrix time per 1e6 particles against 66 us
+// of HBM time for the 528 B per particle: balanced.  Partial sums leave a workgroup block pair by block pair through 8 KB of LDS.
+// Per-workgroup row: [pair 0: 256 (row-major 16 x 16) | pair 1 | ... | sum w x (16 NB) | sum w].
+// =============================================================================================
+constexpr int wide_pairs(int nb) { return nb * (nb + 1) / 2; }
+constexpr int wide_mom_k(int nb) { return wide_pairs(nb) * 256 + 16 * nb + 1; }
+
+template <int NB>
+__global__ __launch_bounds__(QSMC_BLOCK) void k_moments_wide(const double *__restrict__ x, int64_t ldx, int64_t n, int d,
+                                                             const double *__restrict__ w, double norm,
+                                                             double *__restrict__ partials) {
+    constexpr int NP = wide_pairs(NB), K = wide_mom_k(NB);
+    __shared__ double lds[QSMC_WAVES_PER_BLOCK * 256];
+    const int lane = threadIdx.x & (QSMC_WAVE - 1), wave = threadIdx.x / QSMC_WAVE;
+    const int m = lane & 15, kq = lane >> 4;
+    v4d acc[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) acc[p] = v4d{0.0, 0.0, 0.0, 0.0};
+    double s1[NB], s0 = 0.0;
+    bool row_ok[NB];
+    const double *xrow[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        s1[b] = 0.0;
+        row_ok[b] = 16 * b + m < d;
+        xrow[b] = x + (int64_t)(row_ok[b] ? 16 * b + m : 0) * ldx;
+    }
+    const int64_t tiles = (n + 15) / 16;
+    const int64_t wave_id = (int64_t)blockIdx.x * QSMC_WAVES_PER_BLOCK + wave;
+    const int64_t n_waves = (int64_t)gridDim.x * QSMC_WAVES_PER_BLOCK;
+    const bool vec_ok = (ldx & 3) == 0 && (((uintptr_t)x | (uintptr_t)w) & 31) == 0;
+    const double inv_norm = 1.0 / norm;
+    for (int64_t tile = wave_id; tile < tiles; tile += n_waves) {
+        const int64_t base = tile * 16 + 4 * kq;
+        double xv[NB][4], wv[4];
+        if (vec_ok && tile * 16 + 16 <= n) {
+            if (w) {
+                const double4 ww = *reinterpret_cast<const double4 *>(w + base);
+                wv[0] = ww.x; wv[1] = ww.y; wv[2] = ww.z; wv[3] = ww.w;
+            } else {
+                wv[0] = wv[1] = wv[2] = wv[3] = 1.0;
+            }
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const double4 xx = *reinterpret_cast<const double4 *>(xrow[b] + base);
+                xv[b][0] = xx.x; xv[b][1] = xx.y; xv[b][2] = xx.z; xv[b][3] = xx.w;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t p = base + q;
+                const bool ok = p < n;
+                wv[q] = ok ? (w ? w[p] : 1.0) : 0.0;
+#pragma unroll
+                for (int b = 0; b < NB; ++b) xv[b][q] = ok ? xrow[b][p] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double wq = wv[q] * inv_norm;
+            double a[NB], xq[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                xq[b] = row_ok[b] ? xv[b][q] : 0.0;
+                a[b] = wq * xq[b];
+                s1[b] += a[b];
+            }
+            s0 += wq;
+            int p = 0;
+#pragma unroll
+            for (int bi = 0; bi < NB; ++bi)
+#pragma unroll
+                for (int bj = bi; bj < NB; ++bj) {
+                    acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[bi], xq[bj], acc[p], 0, 0, 0);
+                    ++p;
+                }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        s1[b] += __shfl_xor(s1[b], 16, QSMC_WAVE);
+        s1[b] += __shfl_xor(s1[b], 32, QSMC_WAVE);
+    }
+    s0 += __shfl_xor(s0, 16, QSMC_WAVE);
+    s0 += __shfl_xor(s0, 32, QSMC_WAVE);
+    double *row_out = partials + (size_t)blockIdx.x * K;
+    double *mine = lds + wave * 256;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        // C/D layout: value r of lane l = C[(l >> 4) + 4 r][l & 15]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mine[(kq + 4 * r) * 16 + m] = acc[p][r];
+        __syncthreads();
+        {
+            const int k = threadIdx.x;                      // QSMC_BLOCK == 256 entries of the block
+            double t = lds[k];
+#pragma unroll
+            for (int wv2 = 1; wv2 < QSMC_WAVES_PER_BLOCK; ++wv2) t += lds[wv2 * 256 + k];
+            row_out[p * 256 + k] = t;
+        }
+        __syncthreads();
+    }
+    // first moments and sum w: through the same LDS block
+    if (kq == 0) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) mine[16 * b + m] = s1[b];
+    }
+    if (lane == 0) mine[16 * NB] = s0;
+    __syncthreads();
+    if (threadIdx.x <= 16 * NB) {
+        const int k = threadIdx.x;
+        double t = lds[k];
+#pragma unroll
+        for (int wv2 = 1; wv2 < QSMC_WAVES_PER_BLOCK; ++wv2) t += lds[wv2 * 256 + k];
+        row_out[NP * 256 + k] = t;
+    }
+}
+
+// =============================================================================================
+// Liu-West for 16 < d <= 64.  a, the mean and S = h sqrtm(cov) come from device memory (LWWide: 33 KB do not fit a kernarg
+// segment), uploaded by the host call; rows and columns beyond d are zero.
+// =============================================================================================
+struct LWWide {
+    double a, pad[3];
+    double mean[WIDE_D];
+    double S[WIDE_D * WIDE_D];           // row-major d x d, row stride d
+};
+
+// ancestors straight from the global CDF (clouds the bucketed sampler does not take): the draw of k_resample_philox's
+// round 0 -- uniform 0 of block (slot, epoch << 16, 0)
+__global__ __launch_bounds__(QSMC_BLOCK) void k_anc_direct(const double *__restrict__ cdf, int64_t n_in, int64_t n_out,
+                                                           uint32_t k0, uint32_t k1, uint32_t epoch,
+                                                           unsigned int *__restrict__ anc) {
+    for (int64_t i = (int64_t)blockIdx.x * QSMC_BLOCK + threadIdx.x; i < n_out; i += (int64_t)gridDim.x * QSMC_BLOCK) {
+        PhiloxStream rng{(uint64_t)i, (epoch << 16), k0, k1};
+        double u, unused;
+        rng.uniforms(0, u, unused);
+        anc[i] = (unsigned int)search_right(cdf, n_in, u);
+    }
+}
+
+// The kicks of all output slots, 16 per wave trip.  Lane l = (g = l >> 4, n = l & 15) works on slot k0 + n.  K = S Z for
+// the 16 slots is NB x NB chains of four v_mfma_f64_16x16x4: for row block rb and column block t, step s multiplies
+// A = S[16 rb + (l & 15)][16 t + 4 g + s] (from LDS, stored transposed: lanes of a step read consecutive words) with
+// B = Z[16 t + 4 g + s][n] -- so lane (g, n) draws the Box-Muller pairs 8 t + 2 g, 8 t + 2 g + 1 of slot n for every t.
+// D: value r of lane l = K[16 rb + g + 4 r][n]: the lane adds the Liu-West centre of those coordinates (a gather from the
+// ancestor's rows) and stores them.
+// Normals: DIRECT = true (small clouds, ancestors by k_anc_direct) pair p of slot o is block (o, epoch << 16, 1 + p), the
+// stream of k_resample_philox; DIRECT = false (ancestors by k_bucket_anc16) pair p of slot o is block (o * 8 NB + p,
+// epoch << 16, 2): the bucketed samplers' "normal n = o * stride + q", stride = 16 NB (oracle/philox.py).
+constexpr int KICKW_BT = 256, KICKW_WAVES = KICKW_BT / QSMC_WAVE, KICKW_PER_BLOCK = 512;
+template <int NB, bool DIRECT>
+__global__ __launch_bounds__(KICKW_BT) void k_kick_wide(
+    const double *__restrict__ x_in, int64_t ldx_in, const unsigned int *__restrict__ anc, int64_t n_out, int d,
+    const LWWide *__restrict__ lw, uint32_t k0, uint32_t k1, uint32_t epoch, double *__restrict__ x_out, OutPlace pl) {
+    constexpr int DP = 16 * NB, ST = DP + 4;                       // padded d; row stride of the transposed S in LDS
+    __shared__ double sST[DP * ST];                                // sST[k * ST + row] = S[row][k]
+    __shared__ double sMu[DP];
+    const double lw_a = lw->a;
+    for (int t = threadIdx.x; t < DP * DP; t += KICKW_BT) {
+        const int row = t / DP, k = t % DP;
+        sST[k * ST + row] = (row < d && k < d) ? lw->S[row * d + k] : 0.0;
+    }
+    for (int t = threadIdx.x; t < DP; t += KICKW_BT) sMu[t] = t < d ? (1.0 - lw_a) * lw->mean[t] : 0.0;
+    __syncthreads();
+    const int lane = threadIdx.x & (QSMC_WAVE - 1), wave = threadIdx.x / QSMC_WAVE;
+    const int n = lane & 15, g = lane >> 4;
+    const int64_t r0 = (int64_t)blockIdx.x * KICKW_PER_BLOCK;
+    const int64_t r1 = r0 + KICKW_PER_BLOCK < n_out ? r0 + KICKW_PER_BLOCK : n_out;
+    for (int64_t kb = r0 + (int64_t)wave * 16; kb < r1; kb += KICKW_WAVES * 16) {
+        const int64_t k = kb + n;
+        const int64_t oc = k < r1 ? k : r1 - 1;                     // (idle columns shadow the last slot: no divergence)
+        const int64_t j = (int64_t)anc[oc];
+        v4d acc[NB];
+#pragma unroll
+        for (int rb = 0; rb < NB; ++rb) acc[rb] = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int t = 0; t < NB; ++t) {
+            double z[4];
+            if (DIRECT) {
+                PhiloxStream nrm{(uint64_t)oc, (epoch << 16), k0, k1};
+                nrm.normals(1 + 8 * t + 2 * g, z[0], z[1]);
+                nrm.normals(1 + 8 * t + 2 * g + 1, z[2], z[3]);
+            } else {
+                PhiloxStream nrm{(uint64_t)oc * (uint64_t)(8 * NB) + (uint64_t)(8 * t + 2 * g), (epoch << 16), k0, k1};
+                nrm.normals(2, z[0], z[1]);
+                nrm.particle += 1;
+                nrm.normals(2, z[2], z[3]);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const double *col = sST + (16 * t + 4 * g + s) * ST + n;      // S[16 rb + n][16 t + 4 g + s]
+#pragma unroll
+                for (int rb = 0; rb < NB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(col[16 * rb], z[s], acc[rb], 0, 0, 0);
+            }
+        }
+        if (k < r1) {
+            const int64_t row_o = place_row(pl, k);
+#pragma unroll
+            for (int rb = 0; rb < NB; ++rb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = 16 * rb + g + 4 * r;
+                    if (m < d) {
+                        const double xa = x_in[(int64_t)m * ldx_in + j];
+                        x_out[(int64_t)m * pl.ld_m + row_o * pl.ld_s] = (lw_a * xa + sMu[m]) + acc[rb][r];
+                    }
+                }
+        }
+    }
+}
+
+// legacy-RNG pieces (host draws replayed: resamplers.py:318-372), 16 < d <= 64
+__global__ __launch_bounds__(QSMC_BLOCK) void k_centres_wide(const double *__restrict__ x_in, int64_t ldx_in, int d,
+                                                             const int64_t *__restrict__ js, int64_t n_out,
+                                                             const LWWide *__restrict__ lw, double *__restrict__ mus,
+                                                             int64_t ld_mus) {
+    const double a = lw->a;
+    for (int64_t i = (int64_t)blockIdx.x * QSMC_BLOCK + threadIdx.x; i < n_out; i += (int64_t)gridDim.x * QSMC_BLOCK) {
+        const int64_t j = js[i];
+        for (int m = 0; m < d; ++m) mus[m * ld_mus + i] = a * x_in[m * ldx_in + j] + (1.0 - a) * lw->mean[m];   // :325
+    }
+}
+
+__global__ __launch_bounds__(QSMC_BLOCK) void k_perturb_wide(int d, const double *__restrict__ mus, int64_t ld_mus,
+                                                             const int64_t *__restrict__ idxs, int64_t k, int centre_by_idx,
+                                                             const LWWide *__restrict__ lw, const double *__restrict__ z,
+                                                             int64_t ldz, double *__restrict__ x_out, int64_t ldx_out,
+                                                             uint8_t *__restrict__ valid) {
+    __shared__ double sS[WIDE_D * WIDE_D];
+    for (int t = threadIdx.x; t < d * d; t += QSMC_BLOCK) sS[t] = lw->S[t];
+    __syncthreads();
+    for (int64_t r = (int64_t)blockIdx.x * QSMC_BLOCK + threadIdx.x; r < k; r += (int64_t)gridDim.x * QSMC_BLOCK) {
+        const int64_t dst = idxs ? idxs[r] : r;
+        const int64_t c = centre_by_idx ? dst : r;
+        for (int m = 0; m < d; ++m) {
+            double s = 0.0;                     // (S @ z)[m, r], summed in column order like np.dot
+            for (int q = 0; q < d; ++q) s += sS[m * d + q] * z[q * ldz + r];
+            x_out[m * ldx_out + dst] = mus[m * ld_mus + c] + s;
+        }
+        valid[r] = 1;                           // (tomography: are_models_valid is all-true, tomography/models.py:143-147)
+    }
+}
+
+// =============================================================================================
+// canonicalize, dim 5 .. 8 (tomography/models.py:149-209).  A lane never holds the particle: rho's lower triangle is
+// accumulated coefficient by coefficient (x_a from global memory -- coalesced over the lanes --, the basis element from
+// scalar loads: its address is uniform), and the re-expansion x_a = Re tr(B_a^H R) is written coefficient by coefficient.
+// Pass 1 (every particle): LDL^H pivot test; a positive-definite rho only needs x / (x_0 sqrt dim); the rest is listed.
+// Pass 2 (the list): jacobi_clamp<DIM> (the eigenvector form; at dim 8 its iterate and eigenvectors exceed the register
+// file and live in scratch -- correct, and the price of the particles that need it), re-expansion, renormalisation.
+// =============================================================================================
+template <int DIM>
+__device__ __forceinline__ void wide_build_lower(const double *__restrict__ basis, const double *__restrict__ x, int64_t ldx,
+                                                 int64_t i, double (&Ar)[DIM][DIM], double (&Ai)[DIM][DIM]) {
+    constexpr int D = DIM * DIM;
+#pragma unroll
+    for (int r = 0; r < DIM; ++r)
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) { Ar[r][c] = 0.0; Ai[r][c] = 0.0; }
+    for (int a = 0; a < D; ++a) {
+        const double pa = x[(int64_t)a * ldx + i];
+        const double *B = basis + (size_t)2 * a * DIM * DIM;
+#pragma unroll
+        for (int r = 0; r < DIM; ++r)
+#pragma unroll
+            for (int c = 0; c <= r; ++c) {
+                Ar[r][c] += pa * B[2 * (r * DIM + c)];
+                Ai[r][c] += pa * B[2 * (r * DIM + c) + 1];
+            }
+    }
+}
+
+template <int DIM>
+__global__ __launch_bounds__(QSMC_BLOCK) void k_tomo_classify_wide(const double *__restrict__ basis, double *__restrict__ x,
+                                                                   int64_t ldx, int64_t n, int allow_subnormalized,
+                                                                   unsigned int *__restrict__ list,
+                                                                   unsigned int *__restrict__ count) {
+    constexpr int D = DIM * DIM;
+    for (int64_t i = (int64_t)blockIdx.x * QSMC_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * QSMC_BLOCK) {
+        double Ar[DIM][DIM], Ai[DIM][DIM];
+        wide_build_lower<DIM>(basis, x, ldx, i, Ar, Ai);
+        bool ok = true;
+        {
+#pragma clang fp contract(on)                             // (a verdict, not a reproduced value: as tomo_clearly_positive)
+#pragma unroll
+            for (int j = 0; j < DIM; ++j) {
+                double dj = Ar[j][j];
+#pragma unroll
+                for (int k = 0; k < j; ++k) dj -= (Ar[j][k] * Ar[j][k] + Ai[j][k] * Ai[j][k]) * Ar[k][k];
+                ok = ok && (dj > 0.0);
+                Ar[j][j] = dj;
+                const double inv = 1.0 / dj;
+#pragma unroll
+                for (int r = j + 1; r < DIM; ++r) {
+                    double sr = Ar[r][j], si = Ai[r][j];
+#pragma unroll
+                    for (int k = 0; k < j; ++k) {
+                        const double tr = Ar[r][k] * Ar[j][k] + Ai[r][k] * Ai[j][k];
+                        const double ti = Ai[r][k] * Ar[j][k] - Ar[r][k] * Ai[j][k];
+                        sr -= tr * Ar[k][k];
+                        si -= ti * Ar[k][k];
+                    }
+                    Ar[r][j] = sr * inv;
+                    Ai[r][j] = si * inv;
+                }
+            }
+        }
+        if (ok) {
+            if (!allow_subnormalized) {                   // tomography/models.py:194-209
+                const double inv = 1.0 / (x[i] * sqrt((double)DIM));
+                for (int a = 0; a < D; ++a) x[(int64_t)a * ldx + i] = x[(int64_t)a * ldx + i] * inv;
+            }
+        } else {
+            list[atomicAdd(count, 1u)] = (unsigned int)i;
+        }
+    }
+}
+
+template <int DIM>
+__global__ __launch_bounds__(64) void k_tomo_canon_list_wide(const double *__restrict__ basis, double *__restrict__ x,
+                                                             int64_t ldx, int allow_subnormalized,
+                                                             const unsigned int *__restrict__ list,
+                                                             const unsigned int *__restrict__ count) {
+    constexpr int D = DIM * DIM;
+    const unsigned int m = *count;
+    for (unsigned int t = blockIdx.x * 64u + threadIdx.x; t < m; t += gridDim.x * 64u) {
+        const int64_t i = (int64_t)list[t];
+        double Ar[DIM][DIM], Ai[DIM][DIM], Rr[DIM][DIM], Ri[DIM][DIM];
+        wide_build_lower<DIM>(basis, x, ldx, i, Ar, Ai);
+        const bool any_neg = jacobi_clamp<DIM>(Ar, Ai, Rr, Ri);
+        if (any_neg) {
+            // x_a = Re sum_rc conj(B_a[r][c]) R[r][c]; a = 0 first: the trace renormalisation divides by ITS new value
+            double inv = 1.0;
+            for (int a = 0; a < D; ++a) {
+                const double *B = basis + (size_t)2 * a * DIM * DIM;
+                double s = 0.0;
+#pragma unroll
+                for (int r = 0; r < DIM; ++r)
+#pragma unroll
+                    for (int c = 0; c < DIM; ++c) s += B[2 * (r * DIM + c)] * Rr[r][c] + B[2 * (r * DIM + c) + 1] * Ri[r][c];
+                if (a == 0 && !allow_subnormalized) inv = 1.0 / (s * sqrt((double)DIM));
+                x[(int64_t)a * ldx + i] = allow_subnormalized ? s : s * inv;
+            }
+        } else if (!allow_subnormalized) {
+            const double inv = 1.0 / (x[i] * sqrt((double)DIM));
+            for (int a = 0; a < D; ++a) x[(int64_t)a * ldx + i] = x[(int64_t)a * ldx + i] * inv;
+        }
+    }
+}

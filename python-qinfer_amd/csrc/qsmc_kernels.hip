@@ -35,6 +35,8 @@ using namespace qsmc;
 // context
 // =============================================================================================
 struct LWDev;             // kernels/sqrtm.hpp
+struct LWWide;            // kernels/wide.hpp
+constexpr int WIDE_RING = 8;
 struct Chain2Queue;       // passes of the design kernel in flight (qsmc_hypothetical_sums_begin / _collect)
 struct qsmc_ctx {
     int device;
@@ -130,6 +132,9 @@ struct qsmc_ctx {
     Chain2Queue *hypq;      // design passes queued by qsmc_hypothetical_sums_begin, waiting for _collect (allocated on first use)
     LWDev *lw_dev;          // device: Liu-West arguments of a d = 16 resample formed on the device (kernels/sqrtm.hpp)
     long long n_sqrt_dev, n_sqrt_agreed;   // square roots formed on the device by qsmc_step / of those, adopted after the host's check
+    LWWide *lw_wide;        // device: a, mean, S of a d > 16 resample (kernels/wide.hpp), copied from ...
+    LWWide *lw_wide_host;   // ... pinned host slots, WIDE_RING of them used in turn (a slot is rewritten eight calls later)
+    int lw_wide_next;
     unsigned int *anc16;    // device: ancestors + canonicalize list of the split d = 16 sampler
     size_t anc16_cap;       // in bytes
     unsigned int *iscratch; // device integer scratch for the bucketed resampler
@@ -309,6 +314,7 @@ static inline bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; 
 #include "kernels/scan.hpp"
 #include "kernels/resample.hpp"
 #include "kernels/walk_tomo.hpp"
+#include "kernels/wide.hpp"
 #include "kernels/sort.hpp"
 #include "kernels/user_jit.hpp"
 
@@ -362,6 +368,21 @@ static int make_exp_args(const qsmc_model_t *model, const qsmc_expparam_t *ep, i
     return QSMC_OK;
 }
 
+// d > QSMC_MAX_D (tomography): the measurement vector's nonzero entries from the host array the experiment points at
+static int make_wide_args(const qsmc_model_t *model, const qsmc_expparam_t *ep, TomoWideArgs *out) {
+    if (model->kind != QSMC_MODEL_TOMOGRAPHY || model->d <= QSMC_MAX_D || model->d > QSMC_MAX_D_WIDE) return QSMC_ERR_UNSUPPORTED;
+    if (!ep->meas_wide) return QSMC_ERR_INVALID;
+    memset(out, 0, sizeof(*out));
+    out->d = model->d;
+    out->lik_pow = (model->likelihood_power == 1.0) ? 0.0 : model->likelihood_power;
+    for (int i = 0; i < model->d; ++i)
+        if (!(ep->meas_wide[i] == 0.0)) {                    // (a NaN entry counts as present)
+            out->idx[out->nnz] = i;
+            out->val[out->nnz++] = ep->meas_wide[i];
+        }
+    return QSMC_OK;
+}
+
 static int check_model(const qsmc_model_t *m) {
     if (!m) return QSMC_ERR_INVALID;
     switch (m->kind) {
@@ -371,7 +392,7 @@ static int check_model(const qsmc_model_t *m) {
         case QSMC_MODEL_BINOMIAL_RB: return m->d == 3 ? QSMC_OK : QSMC_ERR_INVALID;
         case QSMC_MODEL_RB_INTERLEAVED:
         case QSMC_MODEL_BINOMIAL_RB_INTERLEAVED: return m->d == 4 ? QSMC_OK : QSMC_ERR_INVALID;
-        case QSMC_MODEL_TOMOGRAPHY: return (m->d >= 1 && m->d <= QSMC_MAX_D) ? QSMC_OK : QSMC_ERR_INVALID;
+        case QSMC_MODEL_TOMOGRAPHY: return (m->d >= 1 && m->d <= QSMC_MAX_D_WIDE) ? QSMC_OK : QSMC_ERR_INVALID;
         case QSMC_MODEL_UNKNOWN_T2: return m->d == 2 ? QSMC_OK : QSMC_ERR_INVALID;
         default: return QSMC_ERR_INVALID;
     }
@@ -794,6 +815,29 @@ static int canon_dim4(qsmc_ctx *h, Basis B, double *x, int64_t ldx, int64_t n, i
 // =============================================================================================
 // C ABI
 // =============================================================================================
+extern "C" { static int ensure_anc16(qsmc_ctx *h, size_t bytes); }
+// dim 5 .. 8: classify (LDL^H pivots; positive-definite particles are finished there), then the listed rest (Jacobi)
+template <int DIM>
+static int canon_wide(qsmc_ctx *h, const double *basis, double *x, int64_t ldx, int64_t n, int32_t allow_subnormalized,
+                      hipStream_t s) {
+    if (!basis) return QSMC_ERR_INVALID;                     // (dense contraction with the basis tensor, whatever the basis)
+    if (n >= (1ll << 32)) return QSMC_ERR_UNSUPPORTED;
+    int rc = ensure_anc16(h, ((size_t)n + 16) * sizeof(unsigned int));
+    if (rc) return rc;
+    unsigned int *count = h->anc16, *list = h->anc16 + 4;
+    HIP_TRY(h, hipMemsetAsync(count, 0, 4 * sizeof(unsigned int), s));
+    hipEvent_t c0 = nullptr, c1 = nullptr, l0 = nullptr, l1 = nullptr;
+    prof_events(h, QSMC_PROF_CANON_CLASSIFY, &c0, &c1);
+    hipExtLaunchKernelGGL((k_tomo_classify_wide<DIM>), dim3(grid_for(n, QSMC_BLOCK)), dim3(QSMC_BLOCK), 0, s, c0, c1, 0, basis, x,
+                          ldx, n, allow_subnormalized, list, count);
+    prof_events(h, QSMC_PROF_CANON_LIST, &l0, &l1);
+    hipExtLaunchKernelGGL((k_tomo_canon_list_wide<DIM>), dim3(grid_for(n, 64)), dim3(64), 0, s, l0, l1, 0, basis, x, ldx,
+                          allow_subnormalized, list, count);
+    HIP_TRY(h, hipGetLastError());
+    return QSMC_OK;
+}
+
+
 extern "C" {
 
 int qsmc_abi_version(void) { return QSMC_ABI_VERSION; }
@@ -845,6 +889,8 @@ int qsmc_create(qsmc_handle_t *out, int device) {
     if (e == hipSuccess) e = hipHostMalloc(&h->mapped_big, SQRT_MAPPED_DOUBLES * sizeof(double), hipHostMallocMapped);
     if (e == hipSuccess) e = hipMalloc(&h->lw_dev, sizeof(LWDev));
     if (e == hipSuccess) e = hipMemset(h->lw_dev, 0, sizeof(LWDev));
+    if (e == hipSuccess) e = hipMalloc(&h->lw_wide, sizeof(LWWide));
+    if (e == hipSuccess) e = hipHostMalloc(&h->lw_wide_host, WIDE_RING * sizeof(LWWide), hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&h->mapped_big_dev, h->mapped_big, 0);
     if (e == hipSuccess) e = hipHostMalloc(&h->flag, 64, hipHostMallocMapped);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&h->flag_dev, h->flag, 0);
@@ -881,6 +927,8 @@ int qsmc_destroy(qsmc_handle_t h) {
     if (h->iscratch) (void)hipFree(h->iscratch);
     if (h->anc16) (void)hipFree(h->anc16);
     if (h->lw_dev) (void)hipFree(h->lw_dev);
+    if (h->lw_wide) (void)hipFree(h->lw_wide);
+    if (h->lw_wide_host) (void)hipHostFree(h->lw_wide_host);
     if (h->bank.entries) (void)hipFree(h->bank.entries);
     if (h->bank.aux) (void)hipFree(h->bank.aux);
     if (h->cdf_scratch) (void)hipFree(h->cdf_scratch);
@@ -963,6 +1011,18 @@ int qsmc_likelihood(qsmc_handle_t h, const qsmc_model_t *model, const double *x,
     if (n == 0) return QSMC_OK;
     hipStream_t s = (hipStream_t)stream;
     const int grid = grid_for(n, QSMC_BLOCK);
+    if (model->d > QSMC_MAX_D) {                             // three-qubit tomography and its like: kernels/wide.hpp
+        for (int e = 0; e < n_e; ++e) {
+            TomoWideArgs wa;
+            rc = make_wide_args(model, &exps[e], &wa);
+            if (rc) return rc;
+            for (int o = 0; o < n_o; ++o)
+                hipLaunchKernelGGL(k_likelihood_wide, dim3(grid), dim3(QSMC_BLOCK), 0, s, x, ldx, n, wa, outcomes[o],
+                                   L_out + ((size_t)o * n_e + e) * (size_t)n);
+        }
+        HIP_TRY(h, hipGetLastError());
+        return QSMC_OK;
+    }
     for (int o = 0; o < n_o; ++o)
         for (int e = 0; e < n_e; ++e) {
             ExpArgs ea;
@@ -1047,8 +1107,15 @@ int qsmc_update_fused(qsmc_handle_t h, const qsmc_model_t *model, const double *
     const int grid = grid_for(n, per_block);
     rc = ensure_partials(h, (size_t)grid * (ns + 1));
     if (rc) return rc;
+    const bool wide = d > QSMC_MAX_D;
     ExpArgs ea;
-    make_exp_args(model, exp, outcome, &ea);
+    TomoWideArgs wa;
+    if (wide) {
+        rc = make_wide_args(model, exp, &wa);
+        if (rc) return rc;
+    } else {
+        make_exp_args(model, exp, outcome, &ea);
+    }
     ReduceOut ro = make_reduce(h, stats_host || moments_host, stats_dev);
     // per-tile sums of the new weights: a resample that follows this update takes its chunk sums from them
     if (BUCKET_CHUNK % per_block == 0 &&
@@ -1083,6 +1150,19 @@ int qsmc_update_fused(qsmc_handle_t h, const qsmc_model_t *model, const double *
         LAUNCH_U(QSMC_MODEL_BINOMIAL_RB_INTERLEAVED)
         LAUNCH_U(QSMC_MODEL_UNKNOWN_T2)
         case QSMC_MODEL_TOMOGRAPHY: {
+            if (wide) {
+                // 16 < d <= 64: the rows the measurement vector touches, streamed (kernels/wide.hpp)
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                prof_events(h, w_in ? QSMC_PROF_UPDATE : QSMC_PROF_UPDATE_ONES, &e0, &e1);
+#define LW_(V, O) hipExtLaunchKernelGGL((k_update_tomo_wide<V, O>), dim3(grid), dim3(QSMC_BLOCK), 0, s, e0, e1, 0, x, ldx, n, \
+                                       w_in, w_out, prev_norm, wa, outcome, ro)
+                if (vec2 && w_in) LW_(2, false);
+                else if (vec2) LW_(2, true);
+                else if (w_in) LW_(1, false);
+                else LW_(1, true);
+#undef LW_
+                break;
+            }
             // a measurement vector with at most four nonzero entries (a Pauli measurement has two): read those rows only
             const bool dense_env = g_tomo_dense;                  // (test hook: the dense form, for the same-bits test)
             if (!dense_env && vec2 && ea.lik_pow == 0.0 && ea.nnz >= 1 && ea.nnz <= 4) {
@@ -1142,6 +1222,7 @@ int qsmc_update_multi(qsmc_handle_t h, const qsmc_model_t *model, const double *
         return QSMC_ERR_INVALID;
     int rc = check_model(model);
     if (rc) return rc;
+    if (model->d > QSMC_MAX_D) return QSMC_ERR_UNSUPPORTED;   // (wide clouds: the caller loops qsmc_update_fused)
     const int d = model->d;
     const int dmom = d <= 4 ? d : 0;
     if (moments_host && !dmom) return QSMC_ERR_UNSUPPORTED;
@@ -1269,6 +1350,7 @@ int qsmc_hypothetical_sums_begin(qsmc_handle_t h, const qsmc_model_t *model, con
     for (int e = 0; e < n_e; ++e) if (n_o[e] < 1) return QSMC_ERR_INVALID;
     int rc = check_model(model);
     if (rc) return rc;
+    if (model->d > QSMC_MAX_D) return QSMC_ERR_UNSUPPORTED;   // (wide clouds: design through qsmc_likelihood)
     if (!h->hypq) {
         h->hypq = new (std::nothrow) Chain2Queue();
         if (!h->hypq) return QSMC_ERR_ALLOC;
@@ -1397,11 +1479,60 @@ int qsmc_fill(qsmc_handle_t h, double *w, int64_t n, double value, qsmc_stream_t
     return QSMC_OK;
 }
 
+// 16 < d <= 64: k_moments_wide<NB> (upper block triangle on the matrix cores), partial rows summed by k_sum_partials,
+// packed on the host into qsmc_moments' layout
+static int moments_wide(qsmc_ctx *h, const double *x, int64_t ldx, int64_t n, int d, const double *w, double norm,
+                        double *out_dev, double *out_host, hipStream_t s) {
+    const int nb = (d + 15) / 16, np = wide_pairs(nb), KW = wide_mom_k(nb), K = 1 + d + d * (d + 1) / 2;
+    int gridm = grid_for(n, QSMC_WAVES_PER_BLOCK * 16 * 4);
+    gridm = gridm < 768 ? gridm : 768;
+    int rc = ensure_partials(h, (size_t)gridm * KW);
+    if (rc) return rc;
+    rc = ensure_scratch(h, 256 + (size_t)KW);
+    if (rc) return rc;
+    hipEvent_t m0 = nullptr, m1 = nullptr;
+    prof_events(h, QSMC_PROF_MOMENTS, &m0, &m1);
+    switch (nb) {
+        case 2: hipExtLaunchKernelGGL((k_moments_wide<2>), dim3(gridm), dim3(QSMC_BLOCK), 0, s, m0, m1, 0, x, ldx, n, d, w, norm, h->partials); break;
+        case 3: hipExtLaunchKernelGGL((k_moments_wide<3>), dim3(gridm), dim3(QSMC_BLOCK), 0, s, m0, m1, 0, x, ldx, n, d, w, norm, h->partials); break;
+        default: hipExtLaunchKernelGGL((k_moments_wide<4>), dim3(gridm), dim3(QSMC_BLOCK), 0, s, m0, m1, 0, x, ldx, n, d, w, norm, h->partials); break;
+    }
+    double *full = h->scratch + 256;
+    hipLaunchKernelGGL(k_sum_partials, dim3((KW + QSMC_WAVES_PER_BLOCK - 1) / QSMC_WAVES_PER_BLOCK), dim3(QSMC_BLOCK), 0, s,
+                       h->partials, gridm, KW, full);
+    HIP_TRY(h, hipGetLastError());
+    double *hostfull = static_cast<double *>(malloc(((size_t)KW + (size_t)K) * sizeof(double)));
+    if (!hostfull) return QSMC_ERR_ALLOC;
+    rc = read_back(h, full, hostfull, (size_t)KW, s);
+    if (rc) { free(hostfull); return rc; }
+    double *packed = hostfull + KW;
+    packed[0] = hostfull[np * 256 + 16 * nb];
+    int k = 1 + d;
+    for (int m = 0; m < d; ++m) {
+        packed[1 + m] = hostfull[np * 256 + m];
+        const int bi = m >> 4;
+        for (int q = m; q < d; ++q) {
+            const int bj = q >> 4;
+            const int pair = bi * nb - bi * (bi - 1) / 2 + (bj - bi);          // (bi, bj), bi <= bj, row-major over the upper triangle
+            packed[k++] = hostfull[pair * 256 + (m & 15) * 16 + (q & 15)];
+        }
+    }
+    if (out_host) memcpy(out_host, packed, (size_t)K * sizeof(double));
+    if (out_dev) {
+        hipError_t e = hipMemcpyAsync(out_dev, packed, (size_t)K * sizeof(double), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) { free(hostfull); HIP_TRY(h, e); }
+    }
+    free(hostfull);
+    return QSMC_OK;
+}
+
 int qsmc_moments(qsmc_handle_t h, const double *x, int64_t ldx, int64_t n, int32_t d, const double *w,
                  double norm, double *out_dev, double *out_host, qsmc_stream_t stream) {
-    if (!h || !x || !w || n <= 0 || d < 1 || d > QSMC_MAX_D) return QSMC_ERR_INVALID;
+    if (!h || !x || !w || n <= 0 || d < 1 || d > QSMC_MAX_D_WIDE) return QSMC_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
     const int K = 1 + d + d * (d + 1) / 2;
+    if (d > QSMC_MAX_D) return moments_wide(h, x, ldx, n, d, w, norm, out_dev, out_host, s);
     int rc = ensure_scratch(h, 256 + (size_t)QSMC_MAX_D * (2 + QSMC_MAX_D));
     if (rc) return rc;
     double *dst = out_dev ? out_dev : h->scratch;
@@ -1499,11 +1630,32 @@ static void fill_lw(LWArgs *lw, int d, double a, const double *mean, const doubl
     if (S) for (int k = 0; k < d * d; ++k) lw->S[k] = S[k];
 }
 
+// a, mean (d) and S (d x d, row stride d) of a d > 16 resample: into the next pinned slot, then one H2D copy on `s`.  The
+// slots are used in turn: a slot is rewritten WIDE_RING calls later, long after its copy has run (every resample is
+// followed by a host-visible reduction or a read of its failure count).  Null pointers leave that part of the slot zero.
+static int upload_lw_wide(qsmc_ctx *h, int d, double a, const double *mean, const double *S, hipStream_t s) {
+    LWWide *slot = h->lw_wide_host + (h->lw_wide_next++ % WIDE_RING);
+    memset(slot, 0, sizeof(*slot));
+    slot->a = a;
+    if (mean) memcpy(slot->mean, mean, sizeof(double) * d);
+    if (S) memcpy(slot->S, S, sizeof(double) * d * d);
+    HIP_TRY(h, hipMemcpyAsync(h->lw_wide, slot, sizeof(LWWide), hipMemcpyHostToDevice, s));
+    return QSMC_OK;
+}
+
 int qsmc_lw_centres(qsmc_handle_t h, const double *x_in, int64_t ldx_in, int32_t d, const int64_t *js,
                     int64_t n_out, double a, const double *mean, double *mus, int64_t ld_mus,
                     qsmc_stream_t stream) {
-    if (!h || !x_in || !js || !mean || !mus || d < 1 || d > QSMC_MAX_D || n_out < 0) return QSMC_ERR_INVALID;
+    if (!h || !x_in || !js || !mean || !mus || d < 1 || d > QSMC_MAX_D_WIDE || n_out < 0) return QSMC_ERR_INVALID;
     if (n_out == 0) return QSMC_OK;
+    if (d > QSMC_MAX_D) {
+        int rc = upload_lw_wide(h, d, a, mean, nullptr, (hipStream_t)stream);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_centres_wide, dim3(grid_for(n_out, QSMC_BLOCK)), dim3(QSMC_BLOCK), 0, (hipStream_t)stream,
+                           x_in, ldx_in, d, js, n_out, h->lw_wide, mus, ld_mus);
+        HIP_TRY(h, hipGetLastError());
+        return QSMC_OK;
+    }
     LWArgs lw;
     fill_lw(&lw, d, a, mean, nullptr);
     hipLaunchKernelGGL(k_centres, dim3(grid_for(n_out, QSMC_BLOCK)), dim3(QSMC_BLOCK), 0, (hipStream_t)stream,
@@ -1517,8 +1669,17 @@ int qsmc_lw_perturb(qsmc_handle_t h, const qsmc_model_t *model, int32_t postsele
                     const double *z, int64_t ldz, double *x_out, int64_t ldx_out, uint8_t *valid_out,
                     qsmc_stream_t stream) {
     if (!h || !model || !mus || !S || !z || !x_out || !valid_out || k < 0) return QSMC_ERR_INVALID;
-    if (model->d < 1 || model->d > QSMC_MAX_D) return QSMC_ERR_INVALID;
+    if (model->d < 1 || model->d > QSMC_MAX_D_WIDE) return QSMC_ERR_INVALID;
     if (k == 0) return QSMC_OK;
+    if (model->d > QSMC_MAX_D) {
+        if (model->kind != QSMC_MODEL_TOMOGRAPHY) return QSMC_ERR_UNSUPPORTED;      // (no validity test above QSMC_MAX_D)
+        int rc = upload_lw_wide(h, model->d, 0.0, nullptr, S, (hipStream_t)stream);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_perturb_wide, dim3(grid_for(k, QSMC_BLOCK)), dim3(QSMC_BLOCK), 0, (hipStream_t)stream,
+                           model->d, mus, ld_mus, idxs, k, centre_by_idx, h->lw_wide, z, ldz, x_out, ldx_out, valid_out);
+        HIP_TRY(h, hipGetLastError());
+        return QSMC_OK;
+    }
     LWArgs lw;
     fill_lw(&lw, model->d, 0.0, nullptr, S);
     hipLaunchKernelGGL(k_perturb, dim3(grid_for(k, QSMC_BLOCK)), dim3(QSMC_BLOCK), 0, (hipStream_t)stream,
@@ -1799,6 +1960,72 @@ constexpr int RS_STAGE_ANCESTORS = 1, RS_STAGE_KICK = 2, RS_STAGE_ALL = 3;
 
 // stages: the split d = 16 sampler may be queued in two halves (qsmc_step: ancestors while the host forms S, kicks after);
 // every other caller passes RS_STAGE_ALL.
+// 16 < d <= 64 (tomography: no validity test, so no redraws and no failures).  Ancestors as for d = 16 -- the weight-only
+// prefix (or the one already queued: qsmc_lw_resample_prepare / the speculative one) and k_bucket_anc16 where the bucketed
+// sampler applies, else the global CDF and one search per slot --, then the kicks on the matrix cores (k_kick_wide).
+static int resample_philox_wide(qsmc_ctx *h, const double *x_in, int64_t ldx_in, int64_t n_in, int d, const double *w,
+                                double norm, double a, const double *mean, const double *S, int64_t n_out, uint64_t seed,
+                                uint64_t epoch, double *x_out, const OutPlace &pl, int64_t *n_failed_host, hipStream_t s) {
+    if (n_in >= (1ll << 32)) return QSMC_ERR_UNSUPPORTED;          // (ancestors travel as 32-bit indices)
+    uint32_t k0, k1, ep;
+    philox_keys(seed, epoch, &k0, &k1, &ep);
+    const int64_t chunks64 = (n_in + BUCKET_CHUNK - 1) / BUCKET_CHUNK;
+    const bool prepared = h->prep.valid && h->prep.w == w && h->prep.n_in == n_in && h->prep.n_out == n_out &&
+                          h->prep.norm == norm && h->prep.seed == seed && h->prep.epoch == epoch && h->prep.stream == s;
+    h->prep.valid = 0;
+    int rc = QSMC_OK;
+    if (!prepared) {
+        rc = resample_prefix(h, w, n_in, norm, n_out, seed, epoch, s, false);
+        if (rc) return rc;
+    }
+    rc = upload_lw_wide(h, d, a, mean, S, s);
+    if (rc) return rc;
+    const double inv_norm = 1.0 / norm;
+    BucketPlan bp;
+    rc = bucket_plan_layout(h, chunks64, n_out, &bp, true);
+    if (rc) return rc;
+    const unsigned int *anc = nullptr;
+    if (bp.bucketed) {
+        hipEvent_t a0 = nullptr, a1 = nullptr;
+        prof_events(h, QSMC_PROF_ANCESTORS, &a0, &a1);
+        SqrtJob sj;
+        memset(&sj, 0, sizeof(sj));
+        hipExtLaunchKernelGGL((k_bucket_anc16<512>), dim3(bp.max_items), dim3(512), 0, s, a0, a1, 0, n_in, w, inv_norm,
+                              h->rs_offsets, bp.chunks, bp.slot_off, bp.item_off, bp.item_chunk, k0, k1, ep, bp.anc, bp.cap,
+                              bp.clist, sj);
+        anc = bp.anc;
+    } else {
+        rc = ensure_cdf(h, (size_t)n_in);
+        if (rc) return rc;
+        rc = ensure_anc16(h, (size_t)n_out * sizeof(unsigned int) + 64);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_chunk_scan, dim3((unsigned)chunks64), dim3(SCAN_THREADS), 0, s, w, n_in, inv_norm, h->rs_offsets,
+                           h->cdf_scratch, (const unsigned long long *)nullptr);
+        hipLaunchKernelGGL(k_anc_direct, dim3(grid_for(n_out, QSMC_BLOCK)), dim3(QSMC_BLOCK), 0, s, h->cdf_scratch, n_in,
+                           n_out, k0, k1, ep, h->anc16);
+        anc = h->anc16;
+    }
+    hipEvent_t pe0 = nullptr, pe1 = nullptr;
+    prof_events(h, QSMC_PROF_SAMPLE, &pe0, &pe1);
+    const unsigned kgrid = (unsigned)((n_out + KICKW_PER_BLOCK - 1) / KICKW_PER_BLOCK);
+    const int nb = (d + 15) / 16;
+#define LAUNCH_KW(NB_, DIRECT_)                                                                                       \
+    hipExtLaunchKernelGGL((k_kick_wide<NB_, DIRECT_>), dim3(kgrid), dim3(KICKW_BT), 0, s, pe0, pe1, 0, x_in, ldx_in, anc, \
+                          n_out, d, h->lw_wide, k0, k1, ep, x_out, pl)
+    if (bp.bucketed) {
+        if (nb == 2) LAUNCH_KW(2, false); else if (nb == 3) LAUNCH_KW(3, false); else LAUNCH_KW(4, false);
+    } else {
+        if (nb == 2) LAUNCH_KW(2, true); else if (nb == 3) LAUNCH_KW(3, true); else LAUNCH_KW(4, true);
+    }
+#undef LAUNCH_KW
+    HIP_TRY(h, hipGetLastError());
+    if (n_failed_host) {
+        HIP_TRY(h, hipStreamSynchronize(s));
+        *n_failed_host = 0;
+    }
+    return QSMC_OK;
+}
+
 static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int32_t postselect,
                                 const double *x_in, int64_t ldx_in, int64_t n_in, int32_t d, const double *w,
                                 double norm, double a, const double *mean, const double *S, int64_t n_out,
@@ -1807,8 +2034,15 @@ static int resample_philox_impl(qsmc_handle_t h, const qsmc_model_t *model, int3
                                 int stages = RS_STAGE_ALL, double expect_redraws = 0.0,
                                 const SqrtJob *sqrt_job = nullptr, const LWDev *lw_dev = nullptr) {
     if (!h || !model || !x_in || !mean || !S || !x_out || n_in <= 0 || n_out <= 0) return QSMC_ERR_INVALID;
-    if (d != model->d || d < 1 || d > QSMC_MAX_D || maxiter < 1) return QSMC_ERR_INVALID;
+    if (d != model->d || d < 1 || d > QSMC_MAX_D_WIDE || maxiter < 1) return QSMC_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
+    if (d > QSMC_MAX_D) {
+        if (model->kind != QSMC_MODEL_TOMOGRAPHY || stages != RS_STAGE_ALL || canon.kind != 0 || sqrt_job || lw_dev)
+            return QSMC_ERR_UNSUPPORTED;
+        h->rsq.valid = 0;
+        return resample_philox_wide(h, x_in, ldx_in, n_in, d, w, norm, a, mean, S, n_out, seed, epoch, x_out, pl,
+                                    n_failed_host, s);
+    }
     if (h->rsq.valid && stages == RS_STAGE_ALL) {
         // qsmc_step queued a resample when its n_ess test failed: if this is that very call -- every argument equal,
         // mean and S bit for bit -- the work is done (or under way on `stream`); anything else runs as if nothing had
@@ -2117,7 +2351,7 @@ int qsmc_lw_can_fuse_canonicalize(int32_t d, int64_t n_in, int64_t n_out) {
 }
 
 int qsmc_reserve(qsmc_handle_t h, int64_t n_in, int64_t n_out, int32_t d) {
-    if (!h || n_in <= 0 || n_out <= 0 || d < 1 || d > QSMC_MAX_D) return QSMC_ERR_INVALID;
+    if (!h || n_in <= 0 || n_out <= 0 || d < 1 || d > QSMC_MAX_D_WIDE) return QSMC_ERR_INVALID;
     HIP_TRY(h, hipSetDevice(h->device));
     // every buffer the update and a resample of this shape grow on first use, grown now
     const int per_block = QSMC_BLOCK * 2 * UPD_UNROLL;
@@ -2138,9 +2372,23 @@ int qsmc_reserve(qsmc_handle_t h, int64_t n_in, int64_t n_out, int32_t d) {
     if (rc) return rc;
     const bool split16 = qsmc_lw_can_fuse_canonicalize(d, n_in, n_out) != 0;
     BucketPlan bp;
-    rc = bucket_plan_layout(h, chunks64, n_out, &bp, split16);
+    rc = bucket_plan_layout(h, chunks64, n_out, &bp, split16 || d > QSMC_MAX_D);
     if (rc) return rc;
-    if (!split16) {
+    if (d > QSMC_MAX_D) {
+        const int KW = wide_mom_k((d + 15) / 16);
+        rc = ensure_partials(h, (size_t)768 * KW);
+        if (rc) return rc;
+        rc = ensure_scratch(h, 256 + (size_t)KW);
+        if (rc) return rc;
+        rc = ensure_anc16(h, ((size_t)(n_out > n_in ? n_out : n_in) + 16) * sizeof(unsigned int));
+        if (rc) return rc;
+        if (!bp.bucketed) {
+            rc = ensure_cdf(h, (size_t)n_in);
+            if (rc) return rc;
+        }
+        rc = ensure_pinned(h, (size_t)KW);
+        if (rc) return rc;
+    } else if (!split16) {
         rc = ensure_cdf(h, (size_t)n_in);
         if (rc) return rc;
     } else {
@@ -2540,6 +2788,10 @@ int qsmc_tomo_canonicalize2(qsmc_handle_t h, const double *basis, int32_t dim, i
         case 4:
             if (basis_kind == QSMC_BASIS_PAULI) return canon_dim4(h, TomoPauli2{}, x, ldx, n, allow_subnormalized, s);
             return canon_dim4(h, TomoDense<4>{basis}, x, ldx, n, allow_subnormalized, s);
+        case 5: return canon_wide<5>(h, basis, x, ldx, n, allow_subnormalized, s);
+        case 6: return canon_wide<6>(h, basis, x, ldx, n, allow_subnormalized, s);
+        case 7: return canon_wide<7>(h, basis, x, ldx, n, allow_subnormalized, s);
+        case 8: return canon_wide<8>(h, basis, x, ldx, n, allow_subnormalized, s);   // three qubits
         default: return QSMC_ERR_UNSUPPORTED;
     }
     HIP_TRY(h, hipGetLastError());

@@ -10,7 +10,8 @@ import numpy as np
 
 from ._exceptions import NativeLibraryError
 
-QSMC_MAX_D = 16
+QSMC_MAX_D = 16          # the narrow kernels (a particle in registers)
+QSMC_MAX_D_WIDE = 64     # tomography of dim 5 .. 8 (three qubits: d = 64) through csrc/kernels/wide.hpp
 MODEL_PRECESSION, MODEL_BINOMIAL_PRECESSION, MODEL_RB, MODEL_RB_INTERLEAVED, MODEL_TOMOGRAPHY = 1, 2, 3, 4, 5
 MODEL_BINOMIAL_RB, MODEL_BINOMIAL_RB_INTERLEAVED, MODEL_UNKNOWN_T2 = 6, 7, 8
 
@@ -26,7 +27,8 @@ class ModelDesc(C.Structure):
 
 class ExpParam(C.Structure):
     _fields_ = [("t", C.c_double), ("w_", C.c_double), ("n_meas", C.c_uint64), ("m", C.c_uint64),
-                ("reference", C.c_int32), ("reserved", C.c_int32), ("meas", C.c_double * QSMC_MAX_D)]
+                ("reference", C.c_int32), ("reserved", C.c_int32), ("meas", C.c_double * QSMC_MAX_D),
+                ("meas_wide", C.c_void_p)]      # d > QSMC_MAX_D: host pointer to expparams['meas'] (kept alive in `_wide`)
 
 
 class UpdateStats(C.Structure):
@@ -190,7 +192,7 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = _RESTYPE.get(name, C.c_int)
-    if lib.qsmc_abi_version() != 2:
+    if lib.qsmc_abi_version() != 3:
         raise NativeLibraryError("ABI version mismatch")
     _lib = lib
     if os.environ.get("QSMC_TEST_HOOKS"):
@@ -258,7 +260,12 @@ def make_expparam(t=0.0, w_=0.0, n_meas=0, m=0, reference=0, meas=None):
     ep.t, ep.w_, ep.n_meas, ep.m, ep.reference = float(t), float(w_), int(n_meas), int(m), int(reference)
     if meas is not None:
         meas = np.asarray(meas, dtype=np.float64).ravel()
+        if meas.size > QSMC_MAX_D_WIDE:
+            raise ValueError("native tomography kernels support at most {} model parameters".format(QSMC_MAX_D_WIDE))
         if meas.size > QSMC_MAX_D:
-            raise ValueError("native tomography kernels support at most {} model parameters".format(QSMC_MAX_D))
-        ep.meas[:meas.size] = meas.tolist()          # (one slice assignment: the per-element loop cost 4 us per datum)
+            # wide clouds: the struct carries a pointer to a host array of its own (alive as long as the struct is)
+            ep._wide = np.ascontiguousarray(meas, dtype=np.float64).copy()
+            ep.meas_wide = ep._wide.ctypes.data
+        else:
+            ep.meas[:meas.size] = meas.tolist()      # (one slice assignment: the per-element loop cost 4 us per datum)
     return ep

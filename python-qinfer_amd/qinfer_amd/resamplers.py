@@ -25,7 +25,7 @@ from .distributions import ParticleDistribution
 
 __all__ = ["Resampler", "LiuWestResampler"]
 
-_MAX_D = 16          # _native.QSMC_MAX_D: the widest cloud the device samplers take
+_MAX_D = 64          # _native.QSMC_MAX_D_WIDE: the widest cloud the device samplers take (above 16: no validity test of their own)
 
 
 class Resampler(metaclass=abc.ABCMeta):

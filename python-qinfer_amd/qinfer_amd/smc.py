@@ -766,7 +766,8 @@ class SMCUpdater(ParticleDistribution):
         if len(expparams.shape) == 1:
             expparams = expparams[:, None]
         fast = ((self._native or (self._uk is not None and self._timestep_identity)) and self._batch_fast_path
-                and getattr(self.model, "_native_timestep", None) is None)   # moving particles: one datum at a time
+                and getattr(self.model, "_native_timestep", None) is None    # moving particles: one datum at a time
+                and self._x.shape[0] <= _native.QSMC_MAX_D)                  # (d > 16: no window kernel, the loop)
         idx = 0
         kmax = self._eng.MULTI_KMAX
         while idx < n_exps:
@@ -934,7 +935,7 @@ class SMCUpdater(ParticleDistribution):
         """Expected KL divergence posterior||prior over the outcomes of each hypothetical
         experiment,  sum_o N[o] KLD[o]  (smc.py:613-663).  `0 log 0` is taken as 0."""
         expparams = np.atleast_1d(expparams).reshape(-1)
-        if self._native:
+        if self._native and self._x.shape[0] <= _native.QSMC_MAX_D:      # (d > 16: through qsmc_likelihood, below)
             eig = np.empty(expparams.shape[0])
             sums = self._hyp_sums(expparams, self._eng.HYP_LOG)
             if len({a.shape for a in sums}) == 1:

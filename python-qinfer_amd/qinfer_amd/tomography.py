@@ -123,7 +123,8 @@ class TomographyModel(NativeModelMixin, FiniteOutcomeModel):
         self._basis_dev = None
         self._is_pauli = None
         super().__init__()
-        self._native = self.n_modelparams <= _native.QSMC_MAX_D
+        # d <= 16: the narrow kernels; 16 < d <= 64 (dim 5 .. 8, three qubits): the wide ones (csrc/kernels/wide.hpp)
+        self._native = self.n_modelparams <= _native.QSMC_MAX_D_WIDE
 
     @property
     def dim(self):
@@ -158,12 +159,16 @@ class TomographyModel(NativeModelMixin, FiniteOutcomeModel):
 
     def _native_fill_expparam(self, ep, expparams):
         d = self.n_modelparams
-        if type(expparams) is np.ndarray and expparams.shape == (1,) and d <= _native.QSMC_MAX_D:
+        if type(expparams) is np.ndarray and expparams.shape == (1,) and d <= _native.QSMC_MAX_D_WIDE:
             # (a NumPy view of the struct's array, made once per struct: 0.5 us per datum against 1.6 us for a list
             #  assigned to a ctypes slice -- this sits inside every update() of a 38 us step)
             view = ep.__dict__.get("_meas_view")
             if view is None:
-                view = ep._meas_view = np.ctypeslib.as_array(ep.meas)
+                if d <= _native.QSMC_MAX_D:
+                    view = ep._meas_view = np.ctypeslib.as_array(ep.meas)
+                else:                        # wide: the struct points at a host array that lives with it
+                    view = ep._meas_view = ep._wide = np.zeros(d, dtype=np.float64)
+                    ep.meas_wide = view.ctypes.data
             view[:d] = expparams['meas'][0]
             return True
         return False
@@ -180,9 +185,9 @@ class TomographyModel(NativeModelMixin, FiniteOutcomeModel):
         return self._basis_dev
 
     def _native_canonicalize_ok(self):
-        """Device canonicalize kernels exist for dim 2, 3, 4 (one qubit, a qutrit, two qubits: every dimension whose
-        d = dim^2 fits QSMC_MAX_D = 16); larger systems take `canonicalize` on the host."""
-        return self._dim in (2, 3, 4)
+        """Device canonicalize kernels exist for dim 2 .. 8 (dim 2, 3, 4: the narrow kernels; dim 5 .. 8, up to three
+        qubits: classify + Jacobi list, csrc/kernels/wide.hpp); larger systems take `canonicalize` on the host."""
+        return 2 <= self._dim <= 8
 
     def _pauli(self):
         if self._is_pauli is None:               # is this the reference's Pauli basis, element for element?
@@ -193,7 +198,7 @@ class TomographyModel(NativeModelMixin, FiniteOutcomeModel):
     def _native_canonicalize_(self, eng, x):
         """In-place canonicalize of a device SoA cloud."""
         if not self._native_canonicalize_ok():
-            raise NotImplementedError("native canonicalize supports dim 2, 3 and 4")
+            raise NotImplementedError("native canonicalize supports dim 2 .. 8")
         eng.tomo_canonicalize(self._device_basis(eng), self._dim, x, self._allow_subnormalized, pauli=self._pauli())
 
     def _native_canonicalize_fused(self, eng):

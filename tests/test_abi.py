@@ -40,7 +40,7 @@ def test_header_symbols_exported(lib):
 def test_ctypes_table_matches_header(lib):
     from qinfer_amd import _native
     assert sorted(_native.SIGNATURES) == _header_functions()
-    assert lib.qsmc_abi_version() == 2
+    assert lib.qsmc_abi_version() == 3
     assert lib.qsmc_strerror(0) == b"ok"
     assert lib.qsmc_strerror(-1) == b"invalid argument"
 

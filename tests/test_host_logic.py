@@ -93,10 +93,18 @@ def test_expparam_translation():
     ep['meas'][0] = [1, 0, 0, 1]
     e = tm._native_expparams(ep)[0]
     assert list(e.meas)[:4] == [1, 0, 0, 1]
+    wide = _native.make_expparam(meas=np.arange(17.0))           # d > QSMC_MAX_D: a host array of its own behind a pointer
+    assert wide.meas_wide and list(wide._wide) == list(np.arange(17.0)) and list(wide.meas) == [0.0] * 16
     with pytest.raises(ValueError):
-        _native.make_expparam(meas=np.zeros(17))
-    big = qi.TomographyModel(qi.tomography.gell_mann_basis(5))   # d = 25 > QSMC_MAX_D: plugin path
-    assert big._native is False
+        _native.make_expparam(meas=np.zeros(65))
+    big = qi.TomographyModel(qi.tomography.gell_mann_basis(5))   # d = 25: the wide kernels (csrc/kernels/wide.hpp)
+    assert big._native is True and big._native_canonicalize_ok()
+    ep = np.zeros((1,), dtype=big.expparams_dtype)
+    ep['meas'][0, 3] = 0.25
+    e = _native.ExpParam()
+    assert big._native_fill_expparam(e, ep) and e.meas_wide and e._wide[3] == 0.25
+    huge = qi.TomographyModel(qi.tomography.gell_mann_basis(9))  # d = 81 > QSMC_MAX_D_WIDE: plugin path
+    assert huge._native is False and not huge._native_canonicalize_ok()
 
 
 def test_bases_match_oracle():

@@ -424,3 +424,54 @@ def test_g14_kl_divergence(golden):
                                     g["%s_r%d_old_x" % (tag, i)], g["%s_r%d_old_w" % (tag, i)], Q=g[tag + "_Q"])
             np.testing.assert_allclose(val, g["%s_r%d_kl" % (tag, i)], rtol=1e-12)
             np.testing.assert_allclose(val, g[tag + "_divergences"][i], rtol=1e-12)
+
+
+# ------------------------------------------------------------------ round 6: tomography beyond two qubits (d up to 64)
+def test_g2_tomography_wide(golden):
+    g = golden("g2_tomography_wide")
+    np.testing.assert_allclose(g["3q_basis"], orc.pauli_data(3), atol=1e-15)
+    np.testing.assert_allclose(g["gm5_basis"], orc.gell_mann_data(5), atol=1e-15)
+    for tag in ("3q", "gm5", "q2xq3"):
+        L = orc.lik_tomography([0, 1], g[tag + "_x"], g[tag + "_meas"])
+        np.testing.assert_allclose(L, g[tag + "_L"], rtol=0, atol=2e-15, err_msg=tag)
+
+
+def test_g3_moments_wide(golden):
+    g = golden("g3_moments_wide")
+    for tag in g["tags"]:
+        w, x = g[tag + "_w"], g[tag + "_x"]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            mean, cov = orc.particle_mean(w, x), orc.particle_cov(w, x)
+        scale = np.abs(mean).max() ** 2 + np.einsum('i,ij->', w, x * x)
+        np.testing.assert_allclose(mean, g[tag + "_mean"], rtol=1e-14, atol=1e-16)
+        np.testing.assert_allclose(cov, g[tag + "_cov"], rtol=0, atol=8 * orc.EPS * scale)
+        S, err = orc.sqrtm_psd(cov)
+        np.testing.assert_allclose(S, g[tag + "_sqrt"], rtol=0, atol=1e-12 * max(1.0, np.abs(S).max()))
+
+
+def test_g5_canonicalize_wide(golden):
+    g = golden("g5_canonicalize_wide")
+    for tag in ("gm5", "q2xq3", "gm7", "3q"):
+        x, basis = g[tag + "_x"], g[tag + "_basis"]
+        np.testing.assert_allclose(orc.tomo_canonicalize(x, basis), g[tag + "_y"], rtol=0, atol=1e-13, err_msg=tag)
+        np.testing.assert_allclose(orc.tomo_canonicalize(x, basis, allow_subnormalized=True), g[tag + "_y_subnorm"], rtol=0,
+                                   atol=1e-13, err_msg=tag)
+
+
+def test_g1_tomography_3q(golden):
+    """A three-qubit SMCUpdater trajectory of the reference (d = 64, 240 data, 2 resamples + canonicalize), draws replayed."""
+    g = golden("g1_tomography_3q_n200")
+    model = orc.tomography_model(orc.pauli_data(3))
+    rng = _replay(g)
+    n, stride = int(g["n_particles"]), int(g["cov_stride"])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        smc = orc.OracleSMC(model, n, lambda nn: g["x0"], rng=rng, canonicalize=True)
+        for k in range(len(g["outcomes"])):
+            smc.update(g["outcomes"][k], {"meas": g["ep_meas"][k:k + 1]})
+            assert smc.resample_count == g["resample_count"][k], "datum %d" % k
+            at = tol.atol_sqrtm_psd(g["covs"][k // stride])
+            np.testing.assert_allclose(smc.est_mean(), g["means"][k], rtol=0, atol=at, err_msg="datum %d" % k)
+    assert smc.resample_count == 2
+    np.testing.assert_allclose(smc.x, g["final_locs"], rtol=0, atol=10 * at)
