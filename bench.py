@@ -212,6 +212,29 @@ def other_config_specs(qi):
                       # two of the 16 rows, writes w' (the dense form, 16 + 8 d = 144 B, multiplies 14 rows by zero)
                       update_bpp=32, update_note="sparse measurement vector: 16 + 8 nnz = 32 B per particle "
                                                  "(dense form: 144 B; QSMC_TOMO_DENSE_UPDATE=1)"))
+    # Not a BASELINE config -- the widening of round 6: THREE-qubit tomography (d = 64; the reference's TomographyModel takes
+    # any dim, tomography/models.py:82-226) on the wide kernels (csrc/kernels/wide.hpp), N = 5e5 (256 MB of cloud), Ginibre
+    # prior, 150 random Pauli measurements (a schedule long enough for resamples at this dimension)
+    basis3 = qi.tomography.pauli_basis(3)
+    m = qi.TomographyModel(basis3)
+    gin3 = qi.GinibreDistribution(basis3)
+    true3 = gin3.sample(1)[0]
+    eps, outs = [], []
+    for k in range(150):
+        ep = np.zeros((1,), dtype=m.expparams_dtype)
+        p = rs.randint(1, 64)
+        ep['meas'][0, 0] = np.sqrt(8) / 2                    # (I + P) / 2 = (sqrt 8 / 2)(B_0 + B_P), B_a = P_a / sqrt 8
+        ep['meas'][0, p] = np.sqrt(8) / 2
+        eps.append(ep)
+        outs.append(int(rs.random_sample() < np.clip(ep['meas'][0] @ true3, 0, 1)))
+    gin3_cached = cached_prior(qi, gin3)
+    specs.append(dict(key="widening_tomography_3q", model=m, n=500_000, d=64, prior=lambda: gin3_cached, eps=eps, outs=outs,
+                      workload="3-qubit TomographyModel (63 free params, d = 64), 5e5 particles, Ginibre prior, 150 random Pauli "
+                               "measurements; NOT a BASELINE config: the reference's any-dim tomography on the wide kernels",
+                      update_kernel="k_update_tomo_wide<2,false>", sampler="k_bucket_anc16<512> + k_kick_wide<4,false>",
+                      sampler_split_label="k_bucket_anc16<512> + k_kick_wide<4> (S z on v_mfma_f64_16x16x4, S from device memory)",
+                      canon_label="k_tomo_classify_wide<8> + k_tomo_canon_list_wide<8>", moments_label="k_moments_wide<4>",
+                      update_bpp=32, update_note="sparse measurement vector: 16 + 8 nnz = 32 B per particle (dense: 528 B)"))
     # (not a BASELINE config, not in the default run: `--only extra_binomial_rb` -- the model simple_est_rb builds)
     m = qi.BinomialModel(qi.RandomizedBenchmarkingModel())
     eps, outs = [], []
@@ -297,7 +320,8 @@ def run_other_config(qi, eng, torch, spec, warmup, comm=None, n_override=None, s
         if "ancestors" in kt:
             # d = 16: the sampler is two kernels (ancestors, then the kicks with canonicalize's classify pass folded in)
             us = kt["sample"]["avg_us"] + kt["ancestors"]["avg_us"]
-            out["resample_kernel"] = frac_entry("k_bucket_anc16<512> + k_bucket_kick16 (classify fused)", us, (8 + 16 * d) * n,
+            out["resample_kernel"] = frac_entry(spec.get("sampler_split_label", "k_bucket_anc16<512> + k_bucket_kick16 (classify fused)"),
+                                                us, (8 + 16 * d) * n,
                                                 kt["sample"]["launches"],
                                                 {"bytes_per_particle": 8 + 16 * d, "ancestors_us": kt["ancestors"]["avg_us"],
                                                  "kick_us": kt["sample"]["avg_us"]})
@@ -306,7 +330,7 @@ def run_other_config(qi, eng, torch, spec, warmup, comm=None, n_override=None, s
                                                 kt["sample"]["launches"], {"bytes_per_particle": 8 + 16 * d})
     if "canon_classify" in kt:
         cus = kt["canon_classify"]["avg_us"] + kt.get("canon_list", {"avg_us": 0.0})["avg_us"]
-        out["canonicalize"] = frac_entry("k_tomo_classify<4> + k_tomo_canon_list<4>", cus, 16 * d * n,
+        out["canonicalize"] = frac_entry(spec.get("canon_label", "k_tomo_classify<4> + k_tomo_canon_list<4>"), cus, 16 * d * n,
                                          kt["canon_classify"]["launches"],
                                          {"bytes_per_particle": 16 * d, "classify_us": kt["canon_classify"]["avg_us"],
                                           "canon_list_us": kt.get("canon_list", {"avg_us": 0.0})["avg_us"]})
@@ -317,7 +341,7 @@ def run_other_config(qi, eng, torch, spec, warmup, comm=None, n_override=None, s
                                "avg_kernel_us": kt["canon_list"]["avg_us"], "timed_launches": kt["canon_list"]["launches"],
                                "classify_us": 0.0, "canon_list_us": kt["canon_list"]["avg_us"]}
     if "moments" in kt:
-        out["moments_kernel"] = frac_entry("k_moments_mfma", kt["moments"]["avg_us"], (8 + 8 * d) * n,
+        out["moments_kernel"] = frac_entry(spec.get("moments_label", "k_moments_mfma"), kt["moments"]["avg_us"], (8 + 8 * d) * n,
                                            kt["moments"]["launches"], {"bytes_per_particle": 8 + 8 * d})
     del upd
     torch.cuda.empty_cache()

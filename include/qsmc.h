@@ -108,12 +108,15 @@ int         qsmc_destroy(qsmc_handle_t h);
  *   QSMC_HOOK_HYP_NO_CHAIN     value != 0: design passes of binomial experiments by the thread-per-particle kernel
  *   QSMC_HOOK_TOMO_DENSE       value != 0: tomography updates read all d rows also for sparse measurement vectors
  *   QSMC_HOOK_POISSON_MARGIN   value = kappa in lambda = n_out - kappa sqrt(n_out) of the bucketed counts (default 5)
+ *   QSMC_HOOK_CANON_WIDE_JACOBI value != 0: canonicalize of dim 5 .. 8 takes the one-lane eigenvector form for its listed
+ *                              particles (k_tomo_canon_list_wide), not the one-sided form without eigenvectors (k_tomo_canon_list_os)
  * Returns QSMC_ERR_INVALID for an unknown hook. */
 #define QSMC_HOOK_MULTI_GENERIC 1
 #define QSMC_HOOK_REDRAW_NO_SMALL 2
 #define QSMC_HOOK_HYP_NO_CHAIN 3
 #define QSMC_HOOK_TOMO_DENSE 4
 #define QSMC_HOOK_POISSON_MARGIN 5
+#define QSMC_HOOK_CANON_WIDE_JACOBI 6
 int         qsmc_test_hook(int32_t hook, double value);
 /* Compute units this process can actually run on (a census taken by qsmc_create: under HSA_CU_MASK or a partitioned
  * part fewer than the device attribute reports) and the reported number.  The resampler's grid-barrier kernels

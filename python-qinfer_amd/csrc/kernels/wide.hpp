@@ -295,7 +295,9 @@ __global__ __launch_bounds__(KICKW_BT) void k_kick_wide(
         v4d acc[NB];
 #pragma unroll
         for (int rb = 0; rb < NB; ++rb) acc[rb] = v4d{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
+        // (one column block at a time, not unrolled: unrolled, the eight Box-Muller pairs and 16 NB operands of a trip were
+        //  live together -- 290 VGPRs at NB = 4, one wave per SIMD, 945 us at N = 1e6)
+#pragma unroll 1
         for (int t = 0; t < NB; ++t) {
             double z[4];
             if (DIRECT) {
@@ -461,6 +463,162 @@ __global__ __launch_bounds__(64) void k_tomo_canon_list_wide(const double *__res
 #pragma unroll
                     for (int c = 0; c < DIM; ++c) s += B[2 * (r * DIM + c)] * Rr[r][c] + B[2 * (r * DIM + c) + 1] * Ri[r][c];
                 if (a == 0 && !allow_subnormalized) inv = 1.0 / (s * sqrt((double)DIM));
+                x[(int64_t)a * ldx + i] = allow_subnormalized ? s : s * inv;
+            }
+        } else if (!allow_subnormalized) {
+            const double inv = 1.0 / (x[i] * sqrt((double)DIM));
+            for (int a = 0; a < D; ++a) x[(int64_t)a * ldx + i] = x[(int64_t)a * ldx + i] * inv;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pass 2, the default form: ONE-SIDED Jacobi, no eigenvectors.  The clamp of tomography/models.py:185-192,
+// V max(Lambda, 0) V^H, is (A + |A|) / 2 with |A| = (A A^H)^(1/2) the Hermitian polar factor -- and |A| = G Sigma^-1 G^H for
+// G = A W with orthogonal columns of norms Sigma: Hestenes' Jacobi on the COLUMNS of A.  Only G is iterated (DIM^2 complex
+// numbers: 256 VGPRs at dim 8, against iterate + eigenvectors + reconstruction of the eigenvector form: 510 and AGPR traffic
+// on every access), the Gram entry of a pivot is a sum down two columns, the column norms follow a rotation by
+// alpha' = alpha - t |gamma|, beta' = beta + t |gamma| (recomputed exactly at every sweep), and since the basis is orthonormal
+// (checked by the caller) the re-expansion is x' = x / 2 + expand(G Sigma^-1 G^H) / 2: A itself is not needed again.
+// Convergence is to ABSOLUTE accuracy -- a pivot is rotated while |gamma|^2 > 1e-30 ||A||_F^2 max(alpha, beta): the error of
+// |A| from a residual gamma is |gamma| / (sigma_p + sigma_q) -- because the clouds this runs on sit ON the boundary of the
+// cone: a zero eigenvalue leaves a column of rounding noise whose RELATIVE orthogonality never converges (measured with a
+// relative test: every particle ran to the sweep limit).  Degenerate |lambda| pairs of opposite sign mix in G's columns --
+// |A| restricted to that subspace is |lambda| times the identity, so the sum over the pair is right whatever the mixture.
+// A particle whose tr |A| - tr A vanishes to rounding has no negative eigenvalue: left as it is but for the trace.
+// (A four-lanes-per-particle form of the same iteration -- two rows per lane, Gram sums by DPP quad_perm, 166 VGPRs, three
+//  waves per SIMD -- was built first and measured: the basis entries a lane needs depend on its rows, so rho and the
+//  re-expansion became 3072 sixteen-byte vector loads per lane where this form has scalar loads; texture-addresser-bound,
+//  slower than the eigenvector form.  Removed.)
+// ---------------------------------------------------------------------------------------------
+template <int DIM>
+__global__ __launch_bounds__(64) void k_tomo_canon_list_os(const double *__restrict__ basis, double *__restrict__ x, int64_t ldx,
+                                                           int allow_subnormalized, const unsigned int *__restrict__ list,
+                                                           const unsigned int *__restrict__ count) {
+#pragma clang fp contract(on)                                 // (as in jacobi_clamp: nothing reproduces these intermediates)
+    constexpr int D = DIM * DIM;
+    const unsigned int m = *count;
+    for (unsigned int t = blockIdx.x * 64u + threadIdx.x; t < m; t += gridDim.x * 64u) {
+        const int64_t i = (int64_t)list[t];
+        double Gr[DIM][DIM], Gi[DIM][DIM];
+#pragma unroll
+        for (int r = 0; r < DIM; ++r)
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) { Gr[r][c] = 0.0; Gi[r][c] = 0.0; }
+#pragma unroll 1
+        for (int a = 0; a < D; ++a) {
+            const double pa = x[(int64_t)a * ldx + i];
+            const double *B = basis + (size_t)2 * a * DIM * DIM;
+#pragma unroll
+            for (int r = 0; r < DIM; ++r)
+#pragma unroll
+                for (int c = 0; c <= r; ++c) {
+                    Gr[r][c] += pa * B[2 * (r * DIM + c)];
+                    Gi[r][c] += pa * B[2 * (r * DIM + c) + 1];
+                }
+        }
+        double tr_a = 0.0, frob2 = 0.0;
+#pragma unroll
+        for (int r = 0; r < DIM; ++r) {
+            Gi[r][r] = 0.0;
+            tr_a += Gr[r][r];
+            frob2 += Gr[r][r] * Gr[r][r];
+#pragma unroll
+            for (int c = 0; c < r; ++c) {
+                Gr[c][r] = Gr[r][c];
+                Gi[c][r] = -Gi[r][c];
+                frob2 += 2.0 * (Gr[r][c] * Gr[r][c] + Gi[r][c] * Gi[r][c]);
+            }
+        }
+        const double tiny2 = 1e-28 * frob2, conv2 = 1e-30 * frob2;
+        double nrm[DIM];
+        for (int sweep = 0; sweep < 30; ++sweep) {
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) {
+                double s2 = 0.0;
+#pragma unroll
+                for (int r = 0; r < DIM; ++r) s2 += Gr[r][c] * Gr[r][c] + Gi[r][c] * Gi[r][c];
+                nrm[c] = s2;
+            }
+            bool rotated = false;
+#pragma unroll
+            for (int p = 0; p < DIM; ++p)
+#pragma unroll
+                for (int q = p + 1; q < DIM; ++q) {
+                    const double big = fmax(nrm[p], nrm[q]);
+                    if (!(big > tiny2)) continue;             // two columns of rounding noise
+                    double gr = 0.0, gi = 0.0;                // g_p^H g_q
+#pragma unroll
+                    for (int r = 0; r < DIM; ++r) {
+                        gr += Gr[r][p] * Gr[r][q] + Gi[r][p] * Gi[r][q];
+                        gi += Gr[r][p] * Gi[r][q] - Gi[r][p] * Gr[r][q];
+                    }
+                    const double mag2 = gr * gr + gi * gi;
+                    if (!(mag2 > conv2 * big) || mag2 < 1e-290) continue;
+                    const double imag = j_rsqrt(mag2);
+                    const double er = gr * imag, ei = gi * imag;              // e^{i phi} = gamma / |gamma|
+                    const double zeta = (nrm[q] - nrm[p]) * (0.5 * imag);
+                    const double z2 = 1.0 + zeta * zeta;
+                    const double rt = z2 * j_rsqrt(z2);
+                    const double tt = (zeta >= 0.0 ? 1.0 : -1.0) * j_rcp(fabs(zeta) + rt);
+                    const double cs = j_rsqrt(1.0 + tt * tt);
+                    const double sn = tt * cs;
+                    const double th = tt * (mag2 * imag);                     // t |gamma|
+#pragma unroll
+                    for (int r = 0; r < DIM; ++r) {
+                        const double pr = Gr[r][p], pi = Gi[r][p], qr = Gr[r][q], qi = Gi[r][q];
+                        Gr[r][p] = cs * pr - sn * (er * qr + ei * qi);        // g_p' = c g_p - s e^{-i phi} g_q
+                        Gi[r][p] = cs * pi - sn * (er * qi - ei * qr);
+                        Gr[r][q] = sn * (er * pr - ei * pi) + cs * qr;        // g_q' = s e^{i phi} g_p + c g_q
+                        Gi[r][q] = sn * (er * pi + ei * pr) + cs * qi;
+                    }
+                    nrm[p] -= th;
+                    nrm[q] += th;
+                    rotated = true;
+                }
+            if (!rotated) break;
+        }
+        // column norms = |lambda|; H = G Sigma^(-1/2), so that |A| = H H^H
+        double sum_sigma = 0.0;
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) {
+            double s2 = 0.0;
+#pragma unroll
+            for (int r = 0; r < DIM; ++r) s2 += Gr[r][c] * Gr[r][c] + Gi[r][c] * Gi[r][c];
+            const double sg = sqrt(s2);
+            sum_sigma += sg;
+            const double isg = sg > 1e-300 ? 1.0 / sqrt(sg) : 0.0;
+#pragma unroll
+            for (int r = 0; r < DIM; ++r) { Gr[r][c] *= isg; Gi[r][c] *= isg; }
+        }
+        const bool neg = (sum_sigma - tr_a) > 64.0 * 2.220446049250313e-16 * sum_sigma;
+        if (neg) {
+            // P = H H^H / 2, lower triangle; x'_a = x_a / 2 + Re sum_rc conj(B_a[r][c]) P[r][c]  (orthonormal basis)
+            double Pr[DIM][DIM], Pi[DIM][DIM];
+#pragma unroll
+            for (int r = 0; r < DIM; ++r)
+#pragma unroll
+                for (int c = 0; c <= r; ++c) {
+                    double sr = 0.0, si = 0.0;
+#pragma unroll
+                    for (int k = 0; k < DIM; ++k) {
+                        sr += Gr[r][k] * Gr[c][k] + Gi[r][k] * Gi[c][k];
+                        si += Gi[r][k] * Gr[c][k] - Gr[r][k] * Gi[c][k];
+                    }
+                    Pr[r][c] = (r == c ? 0.5 : 1.0) * sr;      // (off-diagonal entries count twice in the real trace)
+                    Pi[r][c] = si;
+                }
+            double inv = 1.0;
+#pragma unroll 1
+            for (int a = 0; a < D; ++a) {
+                const double *B = basis + (size_t)2 * a * DIM * DIM;
+                double s = 0.5 * x[(int64_t)a * ldx + i];
+#pragma unroll
+                for (int r = 0; r < DIM; ++r)
+#pragma unroll
+                    for (int c = 0; c <= r; ++c)
+                        s += B[2 * (r * DIM + c)] * Pr[r][c] + (c < r ? B[2 * (r * DIM + c) + 1] * Pi[r][c] : 0.0);
+                if (a == 0 && !allow_subnormalized) inv = 1.0 / (s * sqrt((double)DIM));     // tomography/models.py:194-209
                 x[(int64_t)a * ldx + i] = allow_subnormalized ? s : s * inv;
             }
         } else if (!allow_subnormalized) {

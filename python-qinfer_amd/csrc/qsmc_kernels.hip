@@ -182,6 +182,7 @@ constexpr int QSMC_PROF_CAP = 4096;
 static bool g_multi_generic = false;      // k_update_multi: every tile through the general path
 static bool g_redraw_no_small = false;    // k_bucket_redraw: the global-CDF form also for short queues
 static bool g_hyp_no_chain = false;       // design passes of binomial experiments: thread-per-particle k_hyp_sums, not the walk
+static bool g_canon_wide_jacobi = false;  // dim 5 .. 8 canonicalize: the one-lane eigenvector form for the listed particles
 static bool g_tomo_dense = false;         // tomography updates read all d rows also for sparse measurement vectors
 static double g_poisson_margin = 5.0;     // kappa in lambda = n_out - kappa sqrt(n_out) of k_bucket_counts
    // k_bucket_kick16: a workgroup takes consecutive slots of ONE part (the rounds 3-5 form)
@@ -831,8 +832,12 @@ static int canon_wide(qsmc_ctx *h, const double *basis, double *x, int64_t ldx, 
     hipExtLaunchKernelGGL((k_tomo_classify_wide<DIM>), dim3(grid_for(n, QSMC_BLOCK)), dim3(QSMC_BLOCK), 0, s, c0, c1, 0, basis, x,
                           ldx, n, allow_subnormalized, list, count);
     prof_events(h, QSMC_PROF_CANON_LIST, &l0, &l1);
-    hipExtLaunchKernelGGL((k_tomo_canon_list_wide<DIM>), dim3(grid_for(n, 64)), dim3(64), 0, s, l0, l1, 0, basis, x, ldx,
-                          allow_subnormalized, list, count);
+    if (g_canon_wide_jacobi)                                 // (test hook: the independent form)
+        hipExtLaunchKernelGGL((k_tomo_canon_list_wide<DIM>), dim3(grid_for(n, 64)), dim3(64), 0, s, l0, l1, 0, basis, x, ldx,
+                              allow_subnormalized, list, count);
+    else
+        hipExtLaunchKernelGGL((k_tomo_canon_list_os<DIM>), dim3(grid_for(n, 64)), dim3(64), 0, s, l0, l1, 0, basis, x, ldx,
+                              allow_subnormalized, list, count);
     HIP_TRY(h, hipGetLastError());
     return QSMC_OK;
 }
@@ -849,6 +854,7 @@ int qsmc_test_hook(int32_t hook, double value) {
         case QSMC_HOOK_HYP_NO_CHAIN: g_hyp_no_chain = value != 0.0; return QSMC_OK;
         case QSMC_HOOK_TOMO_DENSE: g_tomo_dense = value != 0.0; return QSMC_OK;
         case QSMC_HOOK_POISSON_MARGIN: g_poisson_margin = value; return QSMC_OK;
+        case QSMC_HOOK_CANON_WIDE_JACOBI: g_canon_wide_jacobi = value != 0.0; return QSMC_OK;
         default: return QSMC_ERR_INVALID;
     }
 }

@@ -204,7 +204,8 @@ def lib_path():
     return _LIB_PATH
 
 
-HOOKS = {"multi_generic": 1, "redraw_no_small": 2, "hyp_no_chain": 3, "tomo_dense": 4, "poisson_margin": 5}
+HOOKS = {"multi_generic": 1, "redraw_no_small": 2, "hyp_no_chain": 3, "tomo_dense": 4, "poisson_margin": 5,
+         "canon_wide_jacobi": 6}
 
 
 def test_hook(name, value):

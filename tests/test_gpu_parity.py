@@ -2778,8 +2778,9 @@ def test_reserve_and_fuse_rule(qi, eng):
     eng.reserve(300_000, 250_000, 16)
     with pytest.raises(RuntimeError):
         eng.reserve(0, 10, 1)
+    eng.reserve(50_000, 50_000, 64)                 # (round 6: the wide kernels' scratch, 16 < d <= 64)
     with pytest.raises(RuntimeError):
-        eng.reserve(10, 10, 17)
+        eng.reserve(10, 10, 65)
     assert eng.fused_canon_applies(16, 1_250_000, 1_250_000)
     assert not eng.fused_canon_applies(16, 1_250_000, 4 * 4096 - 1)         # fewer than four chunks' worth of outputs
     assert not eng.fused_canon_applies(16, 8193 * 4096, 1_000_000)           # more than 8192 chunks

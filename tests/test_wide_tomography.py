@@ -26,6 +26,12 @@ def eng(qi):
     return get_engine()
 
 
+@pytest.fixture(autouse=True)
+def _reset_test_hooks(qi):
+    yield
+    qi._native.test_hook("canon_wide_jacobi", 0.0)
+
+
 def _bases(qi):
     t = qi.tomography
     return {"3q": t.pauli_basis(3), "gm5": t.gell_mann_basis(5), "gm7": t.gell_mann_basis(7),
@@ -129,6 +135,33 @@ def test_wide_canonicalize_g5(qi, golden):
         xx[::2, 1:] += (0.25 / dim) * rs.randn(1501, dim * dim - 1)
         np.testing.assert_allclose(qi.TomographyModel(b).canonicalize(xx), orc.tomo_canonicalize(xx, b.data), rtol=0,
                                    atol=1e-12, err_msg=tag)
+
+
+def test_wide_canonicalize_two_forms(qi, golden):
+    """The listed particles of a dim 5 .. 8 canonicalize through both forms: four lanes per particle, one-sided Jacobi,
+    (A + |A|) / 2 (the default) and one lane per particle, eigenvector Jacobi (qsmc_test_hook canon_wide_jacobi) -- each
+    against the reference's fixture, and against each other."""
+    g = golden("g5_canonicalize_wide")
+    for tag, b in _bases(qi).items():
+        x = g[tag + "_x"]
+        rs = np.random.RandomState(b.dim)
+        xx = orc.ginibre_prior_sample(2000, b.data, rs)
+        xx[:, 1:] += (0.3 / b.dim) * rs.randn(2000, b.dim ** 2 - 1)
+        # rank-deficient states: zero eigenvalues and clusters (the degenerate corner of the one-sided form)
+        pure = orc.ginibre_prior_sample(64, b.data, rs)
+        v = rs.randn(64, b.dim) + 1j * rs.randn(64, b.dim)
+        v /= np.linalg.norm(v, axis=1)[:, None]
+        pure = np.real(np.einsum('aij,nij->na', b.data.conj(), v[:, :, None] * v[:, None, :].conj()))
+        xx = np.concatenate([xx, pure, pure + 1e-9 * rs.randn(*pure.shape)])
+        outs = {}
+        for form in ("coop", "jacobi"):
+            qi._native.test_hook("canon_wide_jacobi", 1.0 if form == "jacobi" else 0.0)
+            m = qi.TomographyModel(b)
+            np.testing.assert_allclose(m.canonicalize(x), g[tag + "_y"], rtol=0, atol=1e-12, err_msg=tag + form)
+            outs[form] = m.canonicalize(xx)
+            np.testing.assert_allclose(outs[form], orc.tomo_canonicalize(xx, b.data), rtol=0, atol=1e-12, err_msg=tag + form)
+        qi._native.test_hook("canon_wide_jacobi", 0.0)
+        np.testing.assert_allclose(outs["coop"], outs["jacobi"], rtol=0, atol=1e-13, err_msg=tag)
 
 
 def test_traj_tomography_3q(qi, golden):
