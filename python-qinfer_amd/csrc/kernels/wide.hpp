@@ -381,16 +381,26 @@ __device__ __forceinline__ void wide_build_lower(const double *__restrict__ basi
     for (int r = 0; r < DIM; ++r)
 #pragma unroll
         for (int c = 0; c < DIM; ++c) { Ar[r][c] = 0.0; Ai[r][c] = 0.0; }
-    for (int a = 0; a < D; ++a) {
-        const double pa = x[(int64_t)a * ldx + i];
-        const double *B = basis + (size_t)2 * a * DIM * DIM;
+    // eight coefficients fetched ahead of their use: one load in flight at a time made this loop a chain of memory
+    // latencies (the particles of a wave are a gather) -- most of the 4.2 ms of the first list kernels
+#pragma unroll 1
+    for (int a0 = 0; a0 < D; a0 += 8) {
+        double pa[8];
 #pragma unroll
-        for (int r = 0; r < DIM; ++r)
+        for (int u = 0; u < 8; ++u) pa[u] = x[(int64_t)(a0 + u < D ? a0 + u : D - 1) * ldx + i];
 #pragma unroll
-            for (int c = 0; c <= r; ++c) {
-                Ar[r][c] += pa * B[2 * (r * DIM + c)];
-                Ai[r][c] += pa * B[2 * (r * DIM + c) + 1];
+        for (int u = 0; u < 8; ++u) {
+            if (a0 + u < D) {                               // (uniform)
+                const double *B = basis + (size_t)2 * (a0 + u) * DIM * DIM;
+#pragma unroll
+                for (int r = 0; r < DIM; ++r)
+#pragma unroll
+                    for (int c = 0; c <= r; ++c) {
+                        Ar[r][c] += pa[u] * B[2 * (r * DIM + c)];
+                        Ai[r][c] += pa[u] * B[2 * (r * DIM + c) + 1];
+                    }
             }
+        }
     }
 }
 
@@ -400,10 +410,16 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_tomo_classify_wide(const double 
                                                                    unsigned int *__restrict__ list,
                                                                    unsigned int *__restrict__ count) {
     constexpr int D = DIM * DIM;
-    for (int64_t i = (int64_t)blockIdx.x * QSMC_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * QSMC_BLOCK) {
+    // (uniform trip count: the list is appended to a wave at a time -- one atomic per wave, its entries in lane order, so
+    //  that a wave of the list pass reads neighbouring particles; single appends left the list in arrival order and every
+    //  load of the list pass a 64-line gather)
+    for (int64_t i0 = (int64_t)blockIdx.x * QSMC_BLOCK; i0 < n; i0 += (int64_t)gridDim.x * QSMC_BLOCK) {
+        const int64_t i = i0 + threadIdx.x;
+        const bool live = i < n;
+        bool ok = true;
+        if (live) {
         double Ar[DIM][DIM], Ai[DIM][DIM];
         wide_build_lower<DIM>(basis, x, ldx, i, Ar, Ai);
-        bool ok = true;
         {
 #pragma clang fp contract(on)                             // (a verdict, not a reproduced value: as tomo_clearly_positive)
 #pragma unroll
@@ -429,13 +445,19 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_tomo_classify_wide(const double 
                 }
             }
         }
-        if (ok) {
-            if (!allow_subnormalized) {                   // tomography/models.py:194-209
-                const double inv = 1.0 / (x[i] * sqrt((double)DIM));
-                for (int a = 0; a < D; ++a) x[(int64_t)a * ldx + i] = x[(int64_t)a * ldx + i] * inv;
-            }
-        } else {
-            list[atomicAdd(count, 1u)] = (unsigned int)i;
+        if (ok && !allow_subnormalized) {                 // tomography/models.py:194-209
+            const double inv = 1.0 / (x[i] * sqrt((double)DIM));
+            for (int a = 0; a < D; ++a) x[(int64_t)a * ldx + i] = x[(int64_t)a * ldx + i] * inv;
+        }
+        }
+        const bool listed = live && !ok;
+        const unsigned long long mk = __ballot(listed);
+        if (mk) {
+            const int lane = threadIdx.x & (QSMC_WAVE - 1);
+            unsigned int base = 0;
+            if (lane == 0) base = atomicAdd(count, (unsigned int)__popcll(mk));
+            base = __shfl(base, 0, QSMC_WAVE);
+            if (listed) list[base + __popcll(mk & ((1ull << lane) - 1ull))] = (unsigned int)i;
         }
     }
 }
@@ -496,26 +518,33 @@ __global__ __launch_bounds__(64) void k_tomo_canon_list_os(const double *__restr
                                                            int allow_subnormalized, const unsigned int *__restrict__ list,
                                                            const unsigned int *__restrict__ count) {
 #pragma clang fp contract(on)                                 // (as in jacobi_clamp: nothing reproduces these intermediates)
-    constexpr int D = DIM * DIM;
+    constexpr int D = DIM * DIM, NC = 8;                      // columns padded to 8 (zero columns are never rotated)
     const unsigned int m = *count;
     for (unsigned int t = blockIdx.x * 64u + threadIdx.x; t < m; t += gridDim.x * 64u) {
         const int64_t i = (int64_t)list[t];
-        double Gr[DIM][DIM], Gi[DIM][DIM];
+        double Gr[DIM][NC], Gi[DIM][NC];
 #pragma unroll
         for (int r = 0; r < DIM; ++r)
 #pragma unroll
-            for (int c = 0; c < DIM; ++c) { Gr[r][c] = 0.0; Gi[r][c] = 0.0; }
+            for (int c = 0; c < NC; ++c) { Gr[r][c] = 0.0; Gi[r][c] = 0.0; }
 #pragma unroll 1
-        for (int a = 0; a < D; ++a) {
-            const double pa = x[(int64_t)a * ldx + i];
-            const double *B = basis + (size_t)2 * a * DIM * DIM;
+        for (int a0 = 0; a0 < D; a0 += 8) {                   // (eight coefficients ahead: see wide_build_lower)
+            double pa[8];
 #pragma unroll
-            for (int r = 0; r < DIM; ++r)
+            for (int u = 0; u < 8; ++u) pa[u] = x[(int64_t)(a0 + u < D ? a0 + u : D - 1) * ldx + i];
 #pragma unroll
-                for (int c = 0; c <= r; ++c) {
-                    Gr[r][c] += pa * B[2 * (r * DIM + c)];
-                    Gi[r][c] += pa * B[2 * (r * DIM + c) + 1];
+            for (int u = 0; u < 8; ++u) {
+                if (a0 + u < D) {
+                    const double *B = basis + (size_t)2 * (a0 + u) * DIM * DIM;
+#pragma unroll
+                    for (int r = 0; r < DIM; ++r)
+#pragma unroll
+                        for (int c = 0; c <= r; ++c) {
+                            Gr[r][c] += pa[u] * B[2 * (r * DIM + c)];
+                            Gi[r][c] += pa[u] * B[2 * (r * DIM + c) + 1];
+                        }
                 }
+            }
         }
         double tr_a = 0.0, frob2 = 0.0;
 #pragma unroll
@@ -531,57 +560,81 @@ __global__ __launch_bounds__(64) void k_tomo_canon_list_os(const double *__restr
             }
         }
         const double tiny2 = 1e-28 * frob2, conv2 = 1e-30 * frob2;
-        double nrm[DIM];
+        // Round-robin of 8: every round rotates the FIXED position pairs (0, 7), (1, 6), (2, 5), (3, 4), then the columns at
+        // positions 1 .. 7 move on by one place (|A| = sum_k g_k g_k^H / sigma_k does not care where a column sits); seven
+        // rounds meet all 28 pairs.  The round is a loop body of four pivots + 7 DIM register moves -- ~10 KB of code; the
+        // first cut unrolled all 28 pivots of a sweep (p, q must be compile-time: register indices), 45 KB that one wave per
+        // SIMD streamed through the instruction cache every sweep: 4.2 ms where the arithmetic is worth ~1.7.
+        double nrm[NC];
         for (int sweep = 0; sweep < 30; ++sweep) {
 #pragma unroll
-            for (int c = 0; c < DIM; ++c) {
+            for (int c = 0; c < NC; ++c) {
                 double s2 = 0.0;
 #pragma unroll
                 for (int r = 0; r < DIM; ++r) s2 += Gr[r][c] * Gr[r][c] + Gi[r][c] * Gi[r][c];
                 nrm[c] = s2;
             }
             bool rotated = false;
+#pragma unroll 1
+            for (int round = 0; round < 7; ++round) {
 #pragma unroll
-            for (int p = 0; p < DIM; ++p)
-#pragma unroll
-                for (int q = p + 1; q < DIM; ++q) {
+                for (int j = 0; j < 4; ++j) {
+                    const int p = j, q = 7 - j;
                     const double big = fmax(nrm[p], nrm[q]);
-                    if (!(big > tiny2)) continue;             // two columns of rounding noise
-                    double gr = 0.0, gi = 0.0;                // g_p^H g_q
+                    if (big > tiny2) {
+                        double gr = 0.0, gi = 0.0;            // g_p^H g_q
 #pragma unroll
-                    for (int r = 0; r < DIM; ++r) {
-                        gr += Gr[r][p] * Gr[r][q] + Gi[r][p] * Gi[r][q];
-                        gi += Gr[r][p] * Gi[r][q] - Gi[r][p] * Gr[r][q];
-                    }
-                    const double mag2 = gr * gr + gi * gi;
-                    if (!(mag2 > conv2 * big) || mag2 < 1e-290) continue;
-                    const double imag = j_rsqrt(mag2);
-                    const double er = gr * imag, ei = gi * imag;              // e^{i phi} = gamma / |gamma|
-                    const double zeta = (nrm[q] - nrm[p]) * (0.5 * imag);
-                    const double z2 = 1.0 + zeta * zeta;
-                    const double rt = z2 * j_rsqrt(z2);
-                    const double tt = (zeta >= 0.0 ? 1.0 : -1.0) * j_rcp(fabs(zeta) + rt);
-                    const double cs = j_rsqrt(1.0 + tt * tt);
-                    const double sn = tt * cs;
-                    const double th = tt * (mag2 * imag);                     // t |gamma|
+                        for (int r = 0; r < DIM; ++r) {
+                            gr += Gr[r][p] * Gr[r][q] + Gi[r][p] * Gi[r][q];
+                            gi += Gr[r][p] * Gi[r][q] - Gi[r][p] * Gr[r][q];
+                        }
+                        const double mag2 = gr * gr + gi * gi;
+                        if (mag2 > conv2 * big && mag2 > 1e-290) {
+                            const double imag = j_rsqrt(mag2);
+                            const double er = gr * imag, ei = gi * imag;      // e^{i phi} = gamma / |gamma|
+                            const double zeta = (nrm[q] - nrm[p]) * (0.5 * imag);
+                            const double z2 = 1.0 + zeta * zeta;
+                            const double rt = z2 * j_rsqrt(z2);
+                            const double tt = (zeta >= 0.0 ? 1.0 : -1.0) * j_rcp(fabs(zeta) + rt);
+                            const double cs = j_rsqrt(1.0 + tt * tt);
+                            const double sn = tt * cs;
+                            const double th = tt * (mag2 * imag);             // t |gamma|
 #pragma unroll
-                    for (int r = 0; r < DIM; ++r) {
-                        const double pr = Gr[r][p], pi = Gi[r][p], qr = Gr[r][q], qi = Gi[r][q];
-                        Gr[r][p] = cs * pr - sn * (er * qr + ei * qi);        // g_p' = c g_p - s e^{-i phi} g_q
-                        Gi[r][p] = cs * pi - sn * (er * qi - ei * qr);
-                        Gr[r][q] = sn * (er * pr - ei * pi) + cs * qr;        // g_q' = s e^{i phi} g_p + c g_q
-                        Gi[r][q] = sn * (er * pi + ei * pr) + cs * qi;
+                            for (int r = 0; r < DIM; ++r) {
+                                const double pr = Gr[r][p], pi = Gi[r][p], qr = Gr[r][q], qi = Gi[r][q];
+                                Gr[r][p] = cs * pr - sn * (er * qr + ei * qi);        // g_p' = c g_p - s e^{-i phi} g_q
+                                Gi[r][p] = cs * pi - sn * (er * qi - ei * qr);
+                                Gr[r][q] = sn * (er * pr - ei * pi) + cs * qr;        // g_q' = s e^{i phi} g_p + c g_q
+                                Gi[r][q] = sn * (er * pi + ei * pr) + cs * qi;
+                            }
+                            nrm[p] -= th;
+                            nrm[q] += th;
+                            rotated = true;
+                        }
                     }
-                    nrm[p] -= th;
-                    nrm[q] += th;
-                    rotated = true;
                 }
+                // positions 1 .. 7 move on: new[1] = old[7], new[c] = old[c - 1]
+                {
+                    const double n7 = nrm[7];
+#pragma unroll
+                    for (int c = 7; c > 1; --c) nrm[c] = nrm[c - 1];
+                    nrm[1] = n7;
+#pragma unroll
+                    for (int r = 0; r < DIM; ++r) {
+                        const double a7 = Gr[r][7], b7 = Gi[r][7];
+#pragma unroll
+                        for (int c = 7; c > 1; --c) { Gr[r][c] = Gr[r][c - 1]; Gi[r][c] = Gi[r][c - 1]; }
+                        Gr[r][1] = a7;
+                        Gi[r][1] = b7;
+                    }
+                }
+            }
             if (!rotated) break;
         }
         // column norms = |lambda|; H = G Sigma^(-1/2), so that |A| = H H^H
         double sum_sigma = 0.0;
 #pragma unroll
-        for (int c = 0; c < DIM; ++c) {
+        for (int c = 0; c < NC; ++c) {
             double s2 = 0.0;
 #pragma unroll
             for (int r = 0; r < DIM; ++r) s2 += Gr[r][c] * Gr[r][c] + Gi[r][c] * Gi[r][c];
@@ -601,7 +654,7 @@ __global__ __launch_bounds__(64) void k_tomo_canon_list_os(const double *__restr
                 for (int c = 0; c <= r; ++c) {
                     double sr = 0.0, si = 0.0;
 #pragma unroll
-                    for (int k = 0; k < DIM; ++k) {
+                    for (int k = 0; k < NC; ++k) {
                         sr += Gr[r][k] * Gr[c][k] + Gi[r][k] * Gi[c][k];
                         si += Gi[r][k] * Gr[c][k] - Gr[r][k] * Gi[c][k];
                     }
@@ -610,16 +663,25 @@ __global__ __launch_bounds__(64) void k_tomo_canon_list_os(const double *__restr
                 }
             double inv = 1.0;
 #pragma unroll 1
-            for (int a = 0; a < D; ++a) {
-                const double *B = basis + (size_t)2 * a * DIM * DIM;
-                double s = 0.5 * x[(int64_t)a * ldx + i];
+            for (int a0 = 0; a0 < D; a0 += 8) {
+                double xa[8];
 #pragma unroll
-                for (int r = 0; r < DIM; ++r)
+                for (int u = 0; u < 8; ++u) xa[u] = x[(int64_t)(a0 + u < D ? a0 + u : D - 1) * ldx + i];
 #pragma unroll
-                    for (int c = 0; c <= r; ++c)
-                        s += B[2 * (r * DIM + c)] * Pr[r][c] + (c < r ? B[2 * (r * DIM + c) + 1] * Pi[r][c] : 0.0);
-                if (a == 0 && !allow_subnormalized) inv = 1.0 / (s * sqrt((double)DIM));     // tomography/models.py:194-209
-                x[(int64_t)a * ldx + i] = allow_subnormalized ? s : s * inv;
+                for (int u = 0; u < 8; ++u) {
+                    if (a0 + u < D) {
+                        const int a = a0 + u;
+                        const double *B = basis + (size_t)2 * a * DIM * DIM;
+                        double s = 0.5 * xa[u];
+#pragma unroll
+                        for (int r = 0; r < DIM; ++r)
+#pragma unroll
+                            for (int c = 0; c <= r; ++c)
+                                s += B[2 * (r * DIM + c)] * Pr[r][c] + (c < r ? B[2 * (r * DIM + c) + 1] * Pi[r][c] : 0.0);
+                        if (a == 0 && !allow_subnormalized) inv = 1.0 / (s * sqrt((double)DIM));     // tomography/models.py:194-209
+                        x[(int64_t)a * ldx + i] = allow_subnormalized ? s : s * inv;
+                    }
+                }
             }
         } else if (!allow_subnormalized) {
             const double inv = 1.0 / (x[i] * sqrt((double)DIM));

@@ -592,7 +592,7 @@ def _check_sharded_resample_vs_twin(comm, rank, world, tmpdir):
     import parity_tols as tol
     torch.cuda.set_device(0)
     n_local = 40000
-    for case in ("rb", "tomo"):
+    for case in ("rb", "tomo", "tomo3q"):       # (tomo3q, round 6: d = 64 on the wide kernels, csrc/kernels/wide.hpp)
         rs = np.random.RandomState(17)
         if case == "rb":
             model, valid = qi.RandomizedBenchmarkingModel(), orc.valid_rb
@@ -605,8 +605,10 @@ def _check_sharded_resample_vs_twin(comm, rank, world, tmpdir):
                 eps.append(ep)
             canon = None
         else:
-            basis = qi.tomography.pauli_basis(2)
+            basis = qi.tomography.pauli_basis(2 if case == "tomo" else 3)
             model, valid = qi.TomographyModel(basis), (lambda z: np.ones(z.shape[0], dtype=bool))
+            if case == "tomo3q":
+                n_local = 20000
             x_all = orc.ginibre_prior_sample(world * n_local, basis.data, rs)
             eps = []
             for pp in (3, 7, 12):
@@ -644,7 +646,7 @@ def _check_sharded_resample_vs_twin(comm, rank, world, tmpdir):
                 w_host, x_before, valid, res.a, res.h, seed_r, epoch, int(totals[rank]), mean=mean, cov=cov)
             if canon is not None:
                 ref = orc.tomo_canonicalize(ref, canon)
-        at = 1e-12 + (tol.atol_sqrtm_psd(cov) * 10 if case == "tomo" else 0)
+        at = 1e-12 + (tol.atol_sqrtm_psd(cov) * 10 if case.startswith("tomo") else 0)
         bad = np.abs(got - ref).max(axis=1) > at
         assert bad.sum() <= tol.max_js_flips(got.shape[0]), (case, int(bad.sum()))
         assert np.all(valid(got)) and failed == 0
