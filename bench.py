@@ -233,7 +233,7 @@ def other_config_specs(qi):
                                "measurements; NOT a BASELINE config: the reference's any-dim tomography on the wide kernels",
                       update_kernel="k_update_tomo_wide<2,false>", sampler="k_bucket_anc16<512> + k_kick_wide<4,false>",
                       sampler_split_label="k_bucket_anc16<512> + k_kick_wide<4> (S z on v_mfma_f64_16x16x4, S from device memory)",
-                      canon_label="k_tomo_classify_wide<8> + k_tomo_canon_list_wide<8>", moments_label="k_moments_wide<4>",
+                      canon_label="k_tomo_classify_wide<8> + k_tomo_canon_list_os<8> (one-sided Jacobi, no eigenvectors)", moments_label="k_moments_wide<4>",
                       update_bpp=32, update_note="sparse measurement vector: 16 + 8 nnz = 32 B per particle (dense: 528 B)"))
     # (not a BASELINE config, not in the default run: `--only extra_binomial_rb` -- the model simple_est_rb builds)
     m = qi.BinomialModel(qi.RandomizedBenchmarkingModel())
