@@ -34,8 +34,10 @@ extern "C" {
                                     (dim 5 .. 8; three qubits: d = 64) takes the wide kernels (csrc/kernels/wide.hpp) in
                                     qsmc_likelihood, qsmc_update_fused, qsmc_step (update and tests; a due resample is the
                                     caller's), qsmc_moments, qsmc_lw_centres / _perturb, qsmc_lw_resample_philox (+ _prepare)
-                                    and qsmc_tomo_canonicalize2; qsmc_update_multi and the qsmc_hypothetical_sums_* family
-                                    return QSMC_ERR_UNSUPPORTED above QSMC_MAX_D (callers loop / use qsmc_likelihood) */
+                                    and qsmc_tomo_canonicalize2; qsmc_update_multi takes windows whose measurement vectors have at
+                                    most four nonzero entries each (a Pauli measurement has two) and answers
+                                    QSMC_ERR_UNSUPPORTED otherwise, as the qsmc_hypothetical_sums_* family does above
+                                    QSMC_MAX_D (callers loop qsmc_update_fused / use qsmc_likelihood) */
 
 typedef struct qsmc_ctx *qsmc_handle_t;
 typedef void *qsmc_stream_t;     /* hipStream_t */
@@ -108,7 +110,7 @@ int         qsmc_destroy(qsmc_handle_t h);
  *   QSMC_HOOK_HYP_NO_CHAIN     value != 0: design passes of binomial experiments by the thread-per-particle kernel
  *   QSMC_HOOK_TOMO_DENSE       value != 0: tomography updates read all d rows also for sparse measurement vectors
  *   QSMC_HOOK_POISSON_MARGIN   value = kappa in lambda = n_out - kappa sqrt(n_out) of the bucketed counts (default 5)
- *   QSMC_HOOK_CANON_WIDE_JACOBI value != 0: canonicalize of dim 5 .. 8 takes the one-lane eigenvector form for its listed
+ *   QSMC_HOOK_CANON_WIDE_JACOBI value != 0: canonicalize of dim 5 and 8 takes the one-lane eigenvector form for its listed
  *                              particles (k_tomo_canon_list_wide), not the one-sided form without eigenvectors (k_tomo_canon_list_os)
  * Returns QSMC_ERR_INVALID for an unknown hook. */
 #define QSMC_HOOK_MULTI_GENERIC 1

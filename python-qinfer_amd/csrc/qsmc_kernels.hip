@@ -832,12 +832,18 @@ static int canon_wide(qsmc_ctx *h, const double *basis, double *x, int64_t ldx, 
     hipExtLaunchKernelGGL((k_tomo_classify_wide<DIM>), dim3(grid_for(n, QSMC_BLOCK)), dim3(QSMC_BLOCK), 0, s, c0, c1, 0, basis, x,
                           ldx, n, allow_subnormalized, list, count);
     prof_events(h, QSMC_PROF_CANON_LIST, &l0, &l1);
-    if (g_canon_wide_jacobi)                                 // (test hook: the independent form)
-        hipExtLaunchKernelGGL((k_tomo_canon_list_wide<DIM>), dim3(grid_for(n, 64)), dim3(64), 0, s, l0, l1, 0, basis, x, ldx,
-                              allow_subnormalized, list, count);
-    else
+    if constexpr (DIM == 8 || DIM == 5) {                    // (test hook: the independent form, built for dim 5 and 8)
+        if (g_canon_wide_jacobi) {
+            hipExtLaunchKernelGGL((k_tomo_canon_list_wide<DIM>), dim3(grid_for(n, 64)), dim3(64), 0, s, l0, l1, 0, basis, x, ldx,
+                                  allow_subnormalized, list, count);
+            HIP_TRY(h, hipGetLastError());
+            return QSMC_OK;
+        }
+    }
+    {
         hipExtLaunchKernelGGL((k_tomo_canon_list_os<DIM>), dim3(grid_for(n, 64)), dim3(64), 0, s, l0, l1, 0, basis, x, ldx,
                               allow_subnormalized, list, count);
+    }
     HIP_TRY(h, hipGetLastError());
     return QSMC_OK;
 }
@@ -1228,8 +1234,20 @@ int qsmc_update_multi(qsmc_handle_t h, const qsmc_model_t *model, const double *
         return QSMC_ERR_INVALID;
     int rc = check_model(model);
     if (rc) return rc;
-    if (model->d > QSMC_MAX_D) return QSMC_ERR_UNSUPPORTED;   // (wide clouds: the caller loops qsmc_update_fused)
     const int d = model->d;
+    const bool wide = d > QSMC_MAX_D;
+    // wide clouds (16 < d <= 64): windows of SPARSE measurement vectors only -- k_update_multi_tomo reads rows by index and
+    // does not care how many there are; anything else: QSMC_ERR_UNSUPPORTED, the caller loops qsmc_update_fused
+    TomoWideArgs wa[MULTI_KMAX];
+    if (wide) {
+        if (k < 2 || !(aligned16(x) && (!w_in || aligned16(w_in)) && aligned16(w_out) && (ldx % 2 == 0)))
+            return QSMC_ERR_UNSUPPORTED;
+        for (int j = 0; j < k; ++j) {
+            rc = make_wide_args(model, &exps[j], &wa[j]);
+            if (rc) return rc;
+            if (wa[j].nnz < 1 || wa[j].nnz > MULTI_TOMO_NZ || wa[j].lik_pow != 0.0) return QSMC_ERR_UNSUPPORTED;
+        }
+    }
     const int dmom = d <= 4 ? d : 0;
     if (moments_host && !dmom) return QSMC_ERR_UNSUPPORTED;
     const int n_mom = dmom + dmom * (dmom + 1) / 2;
@@ -1242,7 +1260,7 @@ int qsmc_update_multi(qsmc_handle_t h, const qsmc_model_t *model, const double *
     MultiArgs ma;
     memset(&ma, 0, sizeof(ma));
     ma.k = k;
-    for (int j = 0; j < k; ++j) {
+    for (int j = 0; j < k && !wide; ++j) {
         make_exp_args(model, &exps[j], outcomes[j], &ma.e[j]);
         ma.outcome[j] = outcomes[j];
         if (outcomes[j] != 0) ma.outcome_mask |= 1u << j;   // two_outcome as fma(lb, pr0, la)
@@ -1271,18 +1289,28 @@ int qsmc_update_multi(qsmc_handle_t h, const qsmc_model_t *model, const double *
     // tomography with sparse measurement vectors (every datum of the window touches at most four rows -- a Pauli
     // measurement two): the window reads those rows only (k_update_multi_tomo)
     bool sparse_tomo = false;
-    if (model->kind == QSMC_MODEL_TOMOGRAPHY && k >= 2) {
+    int nz_max = 0;
+    MultiTomoArgs mt;
+    memset(&mt, 0, sizeof(mt));
+    if (wide) {
+        sparse_tomo = true;
+        for (int j = 0; j < k; ++j) {
+            for (int q = 0; q < wa[j].nnz; ++q) {
+                mt.idx[j][q] = wa[j].idx[q];
+                mt.mv[j][q] = wa[j].val[q];
+            }
+            mt.outcome[j] = outcomes[j];
+            nz_max = wa[j].nnz > nz_max ? wa[j].nnz : nz_max;
+        }
+    } else if (model->kind == QSMC_MODEL_TOMOGRAPHY && k >= 2) {
         const bool dense_env = g_tomo_dense;                      // (test hook, as for the single datum)
         sparse_tomo = !dense_env && aligned16(x) && (!w_in || aligned16(w_in)) && aligned16(w_out) && (ldx % 2 == 0) &&
                       ma.e[0].lik_pow == 0.0;
-        int nz_max = 0;
         for (int j = 0; j < k && sparse_tomo; ++j) {
             if (ma.e[j].nnz < 1 || ma.e[j].nnz > MULTI_TOMO_NZ) sparse_tomo = false;
             nz_max = ma.e[j].nnz > nz_max ? ma.e[j].nnz : nz_max;
         }
         if (sparse_tomo) {
-            MultiTomoArgs mt;
-            memset(&mt, 0, sizeof(mt));
             for (int j = 0; j < k; ++j) {
                 for (int q = 0; q < ma.e[j].nnz; ++q) {
                     mt.idx[j][q] = ma.e[j].nz_idx[q];
@@ -1290,6 +1318,9 @@ int qsmc_update_multi(qsmc_handle_t h, const qsmc_model_t *model, const double *
                 }
                 mt.outcome[j] = outcomes[j];                    // (padding: row 0, coefficient +0 -- the memset)
             }
+        }
+    }
+    if (sparse_tomo) {
 #define LMT(KK)                                                                                                       \
     case KK:                                                                                                          \
         if (nz_max <= 2)                                                                                              \
@@ -1301,7 +1332,6 @@ int qsmc_update_multi(qsmc_handle_t h, const qsmc_model_t *model, const double *
         break;
             switch (k) { LMT(2) LMT(3) LMT(4) LMT(5) LMT(6) LMT(7) LMT(8) }
 #undef LMT
-        }
     }
     if (!sparse_tomo)
     switch (model->kind) {

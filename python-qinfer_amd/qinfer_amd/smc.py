@@ -766,8 +766,7 @@ class SMCUpdater(ParticleDistribution):
         if len(expparams.shape) == 1:
             expparams = expparams[:, None]
         fast = ((self._native or (self._uk is not None and self._timestep_identity)) and self._batch_fast_path
-                and getattr(self.model, "_native_timestep", None) is None    # moving particles: one datum at a time
-                and self._x.shape[0] <= _native.QSMC_MAX_D)                  # (d > 16: no window kernel, the loop)
+                and getattr(self.model, "_native_timestep", None) is None)   # moving particles: one datum at a time
         idx = 0
         kmax = self._eng.MULTI_KMAX
         while idx < n_exps:
@@ -799,6 +798,13 @@ class SMCUpdater(ParticleDistribution):
             if hasattr(self.model, "count_likelihood_calls"):
                 self.model.count_likelihood_calls(1, self._x.shape[1], k)
         else:
+            if self._x.shape[0] > _native.QSMC_MAX_D:
+                # wide clouds (16 < d <= 64): the window kernel takes sparse measurement vectors only (at most four rows
+                # per datum: qsmc_update_multi); anything else goes datum by datum
+                meas = np.asarray(expparams['meas']).reshape(k, -1)
+                if meas.shape[1] != self._x.shape[0] or np.count_nonzero(meas, axis=1).max() > 4 \
+                        or np.count_nonzero(meas, axis=1).min() < 1 or getattr(self.model, "_pow", None) is not None:
+                    return False
             exps, outs = [], []
             for j in range(k):
                 e = self.model._native_expparams(expparams[j])
