@@ -1166,8 +1166,16 @@ int qsmc_update_fused(qsmc_handle_t h, const qsmc_model_t *model, const double *
                 // 16 < d <= 64: the rows the measurement vector touches, streamed (kernels/wide.hpp)
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 prof_events(h, w_in ? QSMC_PROF_UPDATE : QSMC_PROF_UPDATE_ONES, &e0, &e1);
-#define LW_(V, O) hipExtLaunchKernelGGL((k_update_tomo_wide<V, O>), dim3(grid), dim3(QSMC_BLOCK), 0, s, e0, e1, 0, x, ldx, n, \
-                                       w_in, w_out, prev_norm, wa, outcome, ro)
+                const bool nt_w = (double)n * (double)(16 + 8 * wa.nnz) > 3.0e8;
+#define LW_(V, O)                                                                                                          \
+    do {                                                                                                                   \
+        if (nt_w)                                                                                                          \
+            hipExtLaunchKernelGGL((k_update_tomo_wide<V, O, true>), dim3(grid), dim3(QSMC_BLOCK), 0, s, e0, e1, 0, x, ldx, n, \
+                                  w_in, w_out, prev_norm, wa, outcome, ro);                                                \
+        else                                                                                                               \
+            hipExtLaunchKernelGGL((k_update_tomo_wide<V, O, false>), dim3(grid), dim3(QSMC_BLOCK), 0, s, e0, e1, 0, x, ldx, n, \
+                                  w_in, w_out, prev_norm, wa, outcome, ro);                                                \
+    } while (0)
                 if (vec2 && w_in) LW_(2, false);
                 else if (vec2) LW_(2, true);
                 else if (w_in) LW_(1, false);
@@ -1528,10 +1536,11 @@ static int moments_wide(qsmc_ctx *h, const double *x, int64_t ldx, int64_t n, in
     if (rc) return rc;
     hipEvent_t m0 = nullptr, m1 = nullptr;
     prof_events(h, QSMC_PROF_MOMENTS, &m0, &m1);
+    const int nt_m = ((double)n * 8.0 * (double)(d + 1) > 3.0e8) ? 1 : 0;
     switch (nb) {
-        case 2: hipExtLaunchKernelGGL((k_moments_wide<2>), dim3(gridm), dim3(QSMC_BLOCK), 0, s, m0, m1, 0, x, ldx, n, d, w, norm, h->partials); break;
-        case 3: hipExtLaunchKernelGGL((k_moments_wide<3>), dim3(gridm), dim3(QSMC_BLOCK), 0, s, m0, m1, 0, x, ldx, n, d, w, norm, h->partials); break;
-        default: hipExtLaunchKernelGGL((k_moments_wide<4>), dim3(gridm), dim3(QSMC_BLOCK), 0, s, m0, m1, 0, x, ldx, n, d, w, norm, h->partials); break;
+        case 2: hipExtLaunchKernelGGL((k_moments_wide<2>), dim3(gridm), dim3(QSMC_BLOCK), 0, s, m0, m1, 0, x, ldx, n, d, w, norm, h->partials, nt_m); break;
+        case 3: hipExtLaunchKernelGGL((k_moments_wide<3>), dim3(gridm), dim3(QSMC_BLOCK), 0, s, m0, m1, 0, x, ldx, n, d, w, norm, h->partials, nt_m); break;
+        default: hipExtLaunchKernelGGL((k_moments_wide<4>), dim3(gridm), dim3(QSMC_BLOCK), 0, s, m0, m1, 0, x, ldx, n, d, w, norm, h->partials, nt_m); break;
     }
     double *full = h->scratch + 256;
     hipLaunchKernelGGL(k_sum_partials, dim3((KW + QSMC_WAVES_PER_BLOCK - 1) / QSMC_WAVES_PER_BLOCK), dim3(QSMC_BLOCK), 0, s,
