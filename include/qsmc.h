@@ -655,7 +655,8 @@ int qsmc_prior_uniform_philox(qsmc_handle_t h, const qsmc_model_t *model, int32_
  * with scale[m] == 0 do not move.  z != NULL: device array, row r of the WALKING parameters (in index
  * order) at z + r * ldz -- steps the host drew (the reference's np.random.normal stream in parity mode,
  * or any step distribution).  z == NULL: standard normals from Philox4x32-10 keyed by (seed, epoch).
- * `scale` is a HOST array of d doubles (std per parameter times the experiment's scale multiplier). */
+ * `scale` is a HOST array of d doubles (std per parameter times the experiment's scale multiplier).
+ * d <= QSMC_MAX_D_WIDE. */
 int qsmc_random_walk(qsmc_handle_t h, double *x, int64_t ldx, int64_t n, int32_t d, const double *scale,
                      const double *z, int64_t ldz, uint64_t seed, uint64_t epoch, qsmc_stream_t stream);
 

@@ -12,8 +12,8 @@
 // HBM-bound: reads and writes the walking rows once (16 B per particle per walking parameter).
 // =============================================================================================
 struct WalkArgs {
-    double scale[QSMC_MAX_D];
-    int row[QSMC_MAX_D];        // parameter index of walking row r
+    double scale[QSMC_MAX_D_WIDE];      // (wide clouds walk too: up to 64 rows)
+    int row[QSMC_MAX_D_WIDE];           // parameter index of walking row r
     int n_rw;
 };
 

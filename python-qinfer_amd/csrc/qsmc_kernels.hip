@@ -2788,7 +2788,7 @@ int qsmc_prior_uniform_philox(qsmc_handle_t h, const qsmc_model_t *model, int32_
 
 int qsmc_random_walk(qsmc_handle_t h, double *x, int64_t ldx, int64_t n, int32_t d, const double *scale,
                      const double *z, int64_t ldz, uint64_t seed, uint64_t epoch, qsmc_stream_t stream) {
-    if (!h || !x || !scale || n < 0 || d < 1 || d > QSMC_MAX_D) return QSMC_ERR_INVALID;
+    if (!h || !x || !scale || n < 0 || d < 1 || d > QSMC_MAX_D_WIDE) return QSMC_ERR_INVALID;
     WalkArgs wa;
     memset(&wa, 0, sizeof(wa));
     for (int m = 0; m < d; ++m) {

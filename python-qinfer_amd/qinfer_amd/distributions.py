@@ -469,6 +469,23 @@ class ParticleDistribution(Distribution):
             with np.errstate(divide="ignore"):
                 inner = np.log(np.sum(v * K, axis=1))
             return -self.est_entropy() - (1 / delta) * np.sum(self.particle_weights * inner, axis=0)
+        from . import _native
+        if self._x.shape[0] > _native.QSMC_MAX_D:
+            # wide clouds (16 < d <= 64): the kernel-density kernel keeps a particle in registers (d <= 16); above that the
+            # reference's own evaluation with its default kernel (the standard normal pdf), in blocks of rows on the host
+            y = np.ascontiguousarray(other_x.cpu().numpy().T)
+            v = (np.full(y.shape[0], 1.0 / other_norm) if other_w is None else other_w.cpu().numpy() / other_norm)
+            x, w, sc = self.particle_locations, self.particle_weights, self._kl_scale()
+            ys, y2 = y * sc, None
+            y2 = np.sum(ys * ys, axis=1)
+            total = 0.0
+            for i0 in range(0, x.shape[0], 1024):
+                xs = x[i0:i0 + 1024] * sc
+                r2 = np.maximum(np.sum(xs * xs, axis=1)[:, None] + y2[None, :] - 2.0 * xs @ ys.T, 0.0)
+                K = np.exp(-0.5 * r2 / (delta * delta)) / np.sqrt(2 * np.pi)
+                with np.errstate(divide="ignore"):
+                    total += np.sum(w[i0:i0 + 1024] * np.log(np.sum(v * K, axis=1)))
+            return -self.est_entropy() - (1 / delta) * total
         cross = self._eng.kde_cross_entropy(self._x, self._w, self._norm, other_x, other_w, other_norm,
                                             self._kl_scale() / delta)
         return -self.est_entropy() - (1 / delta) * cross

@@ -349,3 +349,38 @@ def test_wide_end_to_end_three_qubits(qi):
     # expected information gain of a wide model goes through the likelihood kernel (no design kernel above d = 16)
     eig = b1.expected_information_gain(ep10[:2])
     assert eig.shape == (2,) and np.all(np.isfinite(eig)) and np.all(eig >= -1e-12)
+
+
+def test_wide_random_walk_and_kl(qi, eng):
+    """Read-outs and decorators on a wide cloud: qsmc_random_walk moves up to 64 rows (host-drawn steps bit for bit, Philox
+    steps against the twin), est_kl_divergence takes the reference's own evaluation above d = 16 (against the oracle)."""
+    import philox as ph
+    rs = np.random.RandomState(9)
+    n, d = 3001, 64
+    x0 = rs.randn(n, d)
+    scale = np.where(np.arange(d) % 3 == 0, 0.0, 0.1 + 0.01 * np.arange(d))
+    x = eng.locs_to_soa(x0)
+    z = rs.randn(int(np.count_nonzero(scale)), n)
+    eng.random_walk(x, scale, z=eng.to_device(z))
+    want = x0.copy()
+    want[:, scale != 0] += (scale[scale != 0][:, None] * z).T
+    np.testing.assert_array_equal(x.cpu().numpy().T, want)
+    x = eng.locs_to_soa(x0)
+    eng.random_walk(x, scale, seed=77, epoch=3)
+    zz = ph.random_walk_normals(n, int(np.count_nonzero(scale)), 77, 3)
+    want = x0.copy()
+    want[:, scale != 0] += (scale[scale != 0][:, None] * zz).T
+    np.testing.assert_allclose(x.cpu().numpy().T, want, rtol=0, atol=1e-13)
+    # KL divergence of two wide clouds
+    b = qi.tomography.pauli_basis(3)
+    xa = orc.ginibre_prior_sample(300, b.data, rs)
+    xb = orc.ginibre_prior_sample(200, b.data, rs)
+    wa, wb = rs.random_sample(300), rs.random_sample(200)
+    wa /= wa.sum()
+    wb /= wb.sum()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        p = qi.ParticleDistribution(particle_locations=xa, particle_weights=wa)
+        q = qi.ParticleDistribution(particle_locations=xb, particle_weights=wb)
+        got = p.est_kl_divergence(q, delta=0.5)
+    np.testing.assert_allclose(got, orc.kl_divergence(xa, wa, xb, wb, delta=0.5), rtol=1e-10)
