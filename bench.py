@@ -555,6 +555,9 @@ __device__ bool valid(const double *x) { return x[0] >= 0 && x[1] >= 0; }
     for key, model in (("native", qi.UnknownT2Model()), ("hip_plugin", HipT2())):
         upd = qi.SMCUpdater(model, n, qi.UniformDistribution([[0.0, 1.5], [0.0, 0.2]]), device_rng=True, seed=0)
         upd.batch_update(outs[:15], eps[:15], resample_interval=5)
+        for _ in range(3):                                      # untimed, as in the per-datum legs: a plugin resample's buffer
+            upd.resample()                                      # with spares is allocated at its second call
+            upd.update(int(outs[0]), eps[0:1], check_for_resample=False)
         upd.reset()
         rc0 = upd.resample_count
         torch.cuda.synchronize()

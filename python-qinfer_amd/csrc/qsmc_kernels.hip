@@ -133,7 +133,8 @@ struct qsmc_ctx {
     LWDev *lw_dev;          // device: Liu-West arguments of a d = 16 resample formed on the device (kernels/sqrtm.hpp)
     long long n_sqrt_dev, n_sqrt_agreed;   // square roots formed on the device by qsmc_step / of those, adopted after the host's check
     LWWide *lw_wide;        // device: a, mean, S of a d > 16 resample (kernels/wide.hpp), copied from ...
-    LWWide *lw_wide_host;   // ... pinned host slots, WIDE_RING of them used in turn (a slot is rewritten eight calls later)
+    LWWide *lw_wide_host;   // ... pinned host slots, WIDE_RING of them used in turn; a slot is rewritten only after the
+    hipEvent_t lw_wide_ev[WIDE_RING];   // event recorded behind its copy has completed
     int lw_wide_next;
     unsigned int *anc16;    // device: ancestors + canonicalize list of the split d = 16 sampler
     size_t anc16_cap;       // in bytes
@@ -941,6 +942,8 @@ int qsmc_destroy(qsmc_handle_t h) {
     if (h->lw_dev) (void)hipFree(h->lw_dev);
     if (h->lw_wide) (void)hipFree(h->lw_wide);
     if (h->lw_wide_host) (void)hipHostFree(h->lw_wide_host);
+    for (int i = 0; i < WIDE_RING; ++i)
+        if (h->lw_wide_ev[i]) (void)hipEventDestroy(h->lw_wide_ev[i]);
     if (h->bank.entries) (void)hipFree(h->bank.entries);
     if (h->bank.aux) (void)hipFree(h->bank.aux);
     if (h->cdf_scratch) (void)hipFree(h->cdf_scratch);
@@ -1676,15 +1679,19 @@ static void fill_lw(LWArgs *lw, int d, double a, const double *mean, const doubl
 }
 
 // a, mean (d) and S (d x d, row stride d) of a d > 16 resample: into the next pinned slot, then one H2D copy on `s`.  The
-// slots are used in turn: a slot is rewritten WIDE_RING calls later, long after its copy has run (every resample is
-// followed by a host-visible reduction or a read of its failure count).  Null pointers leave that part of the slot zero.
+// slots are used in turn; an event behind each copy says when its slot may be rewritten (WIDE_RING calls later: the wait is
+// a formality).  Null pointers leave that part of the slot zero.
 static int upload_lw_wide(qsmc_ctx *h, int d, double a, const double *mean, const double *S, hipStream_t s) {
-    LWWide *slot = h->lw_wide_host + (h->lw_wide_next++ % WIDE_RING);
+    const int si = h->lw_wide_next++ % WIDE_RING;
+    LWWide *slot = h->lw_wide_host + si;
+    if (!h->lw_wide_ev[si]) HIP_TRY(h, hipEventCreateWithFlags(&h->lw_wide_ev[si], hipEventDisableTiming));
+    else HIP_TRY(h, hipEventSynchronize(h->lw_wide_ev[si]));        // (the copy that last read this slot has run)
     memset(slot, 0, sizeof(*slot));
     slot->a = a;
     if (mean) memcpy(slot->mean, mean, sizeof(double) * d);
     if (S) memcpy(slot->S, S, sizeof(double) * d * d);
     HIP_TRY(h, hipMemcpyAsync(h->lw_wide, slot, sizeof(LWWide), hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipEventRecord(h->lw_wide_ev[si], s));
     return QSMC_OK;
 }
 

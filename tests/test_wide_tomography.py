@@ -384,3 +384,29 @@ def test_wide_random_walk_and_kl(qi, eng):
         q = qi.ParticleDistribution(particle_locations=xb, particle_weights=wb)
         got = p.est_kl_divergence(q, delta=0.5)
     np.testing.assert_allclose(got, orc.kl_divergence(xa, wa, xb, wb, delta=0.5), rtol=1e-10)
+
+
+@pytest.mark.parametrize("counts", [[12000, 20000, 8000], [0, 9000, 9000, 1], [2999]])
+def test_wide_sharded_resample_placement(qi, eng, counts):
+    """qsmc_lw_resample_philox_sharded of a wide cloud == the single-cloud sampler's particles dealt to the destination
+    ranks with exact quotas (AoS rows grouped by destination): k_kick_wide through OutPlace, bucketed and direct forms."""
+    from test_gpu_parity import _deal_rows
+    b = qi.tomography.pauli_basis(3)
+    rs = np.random.RandomState(15)
+    n = 30000
+    x = orc.ginibre_prior_sample(n, b.data, rs)
+    w = rs.random_sample(n) ** 2
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        pd = qi.ParticleDistribution(particle_locations=x, particle_weights=w)
+        mean, cov = pd.est_mean(), pd.est_covariance_mtx()
+    S, _ = eng.sqrtm_psd(cov, scale=0.3)
+    desc = qi.TomographyModel(b)._native_desc()
+    n_out = int(np.sum(counts))
+    ref, f1 = eng.lw_resample_philox(desc, True, pd._x, pd._w, 1.0, 0.95, mean, S, n_out, 77, 3, 1000)
+    rows, f2 = eng.lw_resample_philox_sharded(desc, True, pd._x, pd._w, 1.0, 0.95, mean, S, counts, 77, 3, 1000)
+    ref = ref.cpu().numpy().T
+    rows = rows.cpu().numpy()
+    assert rows.shape == (n_out, 64) and f1 == f2 == 0
+    place = _deal_rows(counts)
+    np.testing.assert_array_equal(rows[place], ref)
