@@ -282,7 +282,7 @@ __global__ __launch_bounds__(QSMC_BLOCK) void k_anc_direct(const double *__restr
 // Normals: DIRECT = true (small clouds, ancestors by k_anc_direct) pair p of slot o is block (o, epoch << 16, 1 + p), the
 // stream of k_resample_philox; DIRECT = false (ancestors by k_bucket_anc16) pair p of slot o is block (o * 8 NB + p,
 // epoch << 16, 2): the bucketed samplers' "normal n = o * stride + q", stride = 16 NB (oracle/philox.py).
-constexpr int KICKW_BT = 256, KICKW_WAVES = KICKW_BT / QSMC_WAVE, KICKW_PER_BLOCK = 512;
+constexpr int KICKW_BT = 256, KICKW_WAVES = KICKW_BT / QSMC_WAVE, KICKW_PER_BLOCK = 256;     // (slots per workgroup: 512 -> 586 us at N = 1e6, 2048 -> 661, 256 -> 530, 128 -> 550)
 template <int NB, bool DIRECT>
 __global__ __launch_bounds__(KICKW_BT, 3) void k_kick_wide(
     const double *__restrict__ x_in, int64_t ldx_in, const unsigned int *__restrict__ anc, int64_t n_out, int d,
