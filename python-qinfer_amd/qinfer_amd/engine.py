@@ -512,8 +512,19 @@ class Engine:
         return float(out[0]), out[1:1 + d].copy(), self._unpack_upper(out[1 + d:], d)
 
     def sqrtm_psd(self, A, scale=1.0):
+        """(scale * sqrtm_psd(A), || sqrt sqrt - A ||_F): utils.py:593-607.  d <= 16: the library's round-robin Jacobi (the
+        routine qsmc_step and the device wavefront run: one set of bits); wide clouds (d > 16): LAPACK's eigh through NumPy --
+        the C loop takes 2.2 ms at d = 64 with the GPU waiting for S, eigh 0.2 -- to the same tolerance (nothing compares the
+        wide square root bit for bit)."""
         A = np.ascontiguousarray(A, dtype=np.float64)
         d = A.shape[0]
+        if d > _native.QSMC_MAX_D:
+            try:
+                lam, V = np.linalg.eigh(0.5 * (A + A.T))
+            except np.linalg.LinAlgError:
+                return np.full((d, d), np.nan), float("inf")
+            sq = (V * np.sqrt(np.maximum(lam, 0.0))) @ V.T
+            return float(scale) * sq, float(np.linalg.norm(sq @ sq - A))
         S = np.empty((d, d))
         err = C.c_double()
         self._chk(self.lib.qsmc_sqrtm_psd(_native.f64_ptr(A), d, float(scale), _native.f64_ptr(S),
