@@ -45,7 +45,7 @@ sys.path.insert(0, os.path.join(ROOT, "python-qinfer_amd"))
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 N_SCHEDULE = 200
 TAGS = {0: "update", 1: "sample", 2: "update_ones", 3: "canon_classify", 4: "canon_list", 5: "moments", 6: "counts",
-        8: "ancestors", 10: "update_multi", 11: "hyp_sums"}
+        8: "ancestors", 10: "update_multi", 11: "hyp_sums", 12: "canon_build", 13: "canon_expand"}
 
 
 def schedule():
@@ -233,7 +233,7 @@ def other_config_specs(qi):
                                "measurements; NOT a BASELINE config: the reference's any-dim tomography on the wide kernels",
                       update_kernel="k_update_tomo_wide<2,false>", sampler="k_bucket_anc16<512> + k_kick_wide<4,false>",
                       sampler_split_label="k_bucket_anc16<512> + k_kick_wide<4> (S z on v_mfma_f64_16x16x4, S from device memory)",
-                      canon_label="k_tomo_classify_wide<8> + k_tomo_canon_list_os<8> (one-sided Jacobi, no eigenvectors)", moments_label="k_moments_wide<4>",
+                      canon_label="k_gemm_wide<4,0> + k_tomo_ldl_wide<8> + k_tomo_jacobi_wide<8> + k_gemm_wide<4,1> (rho packed on the matrix cores; one-sided Jacobi, no eigenvectors)", moments_label="k_moments_wide<4>",
                       update_bpp=32, update_note="sparse measurement vector: 16 + 8 nnz = 32 B per particle (dense: 528 B)"))
     # (not a BASELINE config, not in the default run: `--only extra_binomial_rb` -- the model simple_est_rb builds)
     m = qi.BinomialModel(qi.RandomizedBenchmarkingModel())
@@ -329,11 +329,15 @@ def run_other_config(qi, eng, torch, spec, warmup, comm=None, n_override=None, s
             out["resample_kernel"] = frac_entry(spec["sampler"], kt["sample"]["avg_us"], (8 + 16 * d) * n,
                                                 kt["sample"]["launches"], {"bytes_per_particle": 8 + 16 * d})
     if "canon_classify" in kt:
-        cus = kt["canon_classify"]["avg_us"] + kt.get("canon_list", {"avg_us": 0.0})["avg_us"]
+        zero = {"avg_us": 0.0}
+        cus = (kt["canon_classify"]["avg_us"] + kt.get("canon_list", zero)["avg_us"] + kt.get("canon_build", zero)["avg_us"]
+               + kt.get("canon_expand", zero)["avg_us"])
+        extra = {"bytes_per_particle": 16 * d, "classify_us": kt["canon_classify"]["avg_us"],
+                 "canon_list_us": kt.get("canon_list", zero)["avg_us"]}
+        if "canon_build" in kt:                 # the wide form: two products on the matrix cores around the pivot test / Jacobi
+            extra.update({"build_us": kt["canon_build"]["avg_us"], "expand_us": kt.get("canon_expand", zero)["avg_us"]})
         out["canonicalize"] = frac_entry(spec.get("canon_label", "k_tomo_classify<4> + k_tomo_canon_list<4>"), cus, 16 * d * n,
-                                         kt["canon_classify"]["launches"],
-                                         {"bytes_per_particle": 16 * d, "classify_us": kt["canon_classify"]["avg_us"],
-                                          "canon_list_us": kt.get("canon_list", {"avg_us": 0.0})["avg_us"]})
+                                         kt["canon_classify"]["launches"], extra)
     elif "canon_list" in kt:
         # classify rides in the kick kernel (no pass of its own): what is left of canonicalize is the list pass over the
         # particles whose rho is not positive definite (about a third: read + write 16 rows of those)

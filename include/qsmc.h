@@ -152,6 +152,9 @@ int         qsmc_profile_read(qsmc_handle_t h, float *ms_out, int32_t *tags_out,
 #define QSMC_PROF_ANCESTORS 8      /* d = 16 sampler, first half: ancestors of every slot (k_bucket_anc16); tag 1 is its kick kernel */
 #define QSMC_PROF_UPDATE_MULTI 10   /* k_update_multi: up to 8 data in one pass (batch_update's fused windows) */
 #define QSMC_PROF_HYP_SUMS 11       /* k_hyp_sums: one hypothetical experiment, all outcomes (bayes_risk / expected_information_gain) */
+#define QSMC_PROF_CANON_BUILD 12    /* canonicalize of dim 5 .. 8: rho_packed = Mb x on the matrix cores (k_gemm_wide<NB, 0>); tags 3 / 4 are its
+                                       pivot test (k_tomo_ldl_wide) and its Jacobi pass (k_tomo_jacobi_wide) */
+#define QSMC_PROF_CANON_EXPAND 13   /* ... and x = Me R_packed with the trace renormalisation (k_gemm_wide<NB, 1>) */
 #define QSMC_PROF_NTAGS 16
 
 /* ---- likelihood, contract form (abstract_model.py:444-468 + :666-686; a6-a10) ------------ */

@@ -508,30 +508,213 @@ __global__ __launch_bounds__(64) void k_tomo_canon_list_wide(const double *__res
 }
 
 // ---------------------------------------------------------------------------------------------
-// Pass 2, the default form: ONE-SIDED Jacobi, no eigenvectors.  The clamp of tomography/models.py:185-192,
-// V max(Lambda, 0) V^H, is (A + |A|) / 2 with |A| = (A A^H)^(1/2) the Hermitian polar factor -- and |A| = G Sigma^-1 G^H for
-// G = A W with orthogonal columns of norms Sigma: Hestenes' Jacobi on the COLUMNS of A.  Only G is iterated (DIM^2 complex
-// numbers: 256 VGPRs at dim 8, against iterate + eigenvectors + reconstruction of the eigenvector form: 510 and AGPR traffic
-// on every access), the Gram entry of a pivot is a sum down two columns, the column norms follow a rotation by
-// alpha' = alpha - t |gamma|, beta' = beta + t |gamma| (recomputed exactly at every sweep), and since the basis is orthonormal
-// (checked by the caller) the re-expansion is x' = x / 2 + expand(G Sigma^-1 G^H) / 2: A itself is not needed again.
-// Convergence is to ABSOLUTE accuracy -- a pivot is rotated while |gamma|^2 > 1e-30 ||A||_F^2 max(alpha, beta): the error of
-// |A| from a residual gamma is |gamma| / (sigma_p + sigma_q) -- because the clouds this runs on sit ON the boundary of the
-// cone: a zero eigenvalue leaves a column of rounding noise whose RELATIVE orthogonality never converges (measured with a
-// relative test: every particle ran to the sweep limit).  Degenerate |lambda| pairs of opposite sign mix in G's columns --
-// |A| restricted to that subspace is |lambda| times the identity, so the sum over the pair is right whatever the mixture.
-// A particle whose tr |A| - tr A vanishes to rounding has no negative eigenvalue: left as it is but for the trace.
-// (A four-lanes-per-particle form of the same iteration -- two rows per lane, Gram sums by DPP quad_perm, 166 VGPRs, three
-//  waves per SIMD -- was built first and measured: the basis entries a lane needs depend on its rows, so rho and the
-//  re-expansion became 3072 sixteen-byte vector loads per lane where this form has scalar loads; texture-addresser-bound,
-//  slower than the eigenvector form.  Removed.)
+// canonicalize, dim 5 .. 8, the default form: FOUR kernels around a scratch copy of rho in packed Hermitian form.
+//
+// The first forms of this file had every lane build rho = sum_a x_a B_a itself -- DIM^2 coefficients times DIM (DIM + 1) / 2
+// complex entries, the basis through scalar loads -- and re-expand x'_a = Re tr(B_a^H R) the same way.  Measured with the
+// Jacobi sweeps switched off (profiles/r6_i_canon_list_sweep_cap_experiment.txt): 3.15 of the list kernel's 4.4 ms at
+// N = 1e6 were those two loops -- one wave per SIMD waiting on scalar loads of a 64 KB basis that does not fit the 16 KB scalar
+// cache -- and the sweeps themselves 1.2 ms.  But rho in packed form (DIM real diagonal entries, then (re, im) of the
+// strict lower triangle: E = DIM^2 reals) is a REAL LINEAR MAP of x: rho_packed = Mb x with Mb[e][a] = Re / Im B_a[r][c],
+// and the re-expansion its transpose with the off-diagonal rows doubled.  For all particles at once these are two
+// (E x E) (E x N) products -- the shape of the Liu-West kick S Z -- and run on the f64 matrix cores like it:
+//   k_canon_mats<DIM>      Mb and Me (padded to 16 NB) from the basis tensor, on the device, per call (4096 entries);
+//   k_gemm_wide<NB, 0>     rho_packed[e][i] = sum_a Mb[e][a] x[a][i] for every particle -> scratch (E x N doubles);
+//   k_tomo_ldl_wide<DIM>   LDL^H pivot test on the packed rho (64 coalesced loads per lane): positive definite -> x / (x_0 sqrt dim),
+//                          else listed (a wave at a time, in lane order);
+//   k_tomo_jacobi_wide<DIM>  the listed: ONE-SIDED Jacobi, no eigenvectors (below), R = (A + |A|) / 2 written back packed;
+//   k_gemm_wide<NB, 1>     x'[a][i] = sum_e Me[a][e] R_packed[e][i] for the listed, trace renormalisation in its epilogue.
+//
+// The clamp of tomography/models.py:185-192, V max(Lambda, 0) V^H, is (A + |A|) / 2 with |A| = (A A^H)^(1/2) the Hermitian
+// polar factor -- and |A| = G Sigma^-1 G^H for G = A W with orthogonal columns of norms Sigma: Hestenes' Jacobi on the COLUMNS
+// of A.  Only G is iterated (256 VGPRs at dim 8, against iterate + eigenvectors + reconstruction of the eigenvector form:
+// 510 and AGPR traffic on every access); the Gram entry of a pivot is a sum down two columns; the column norms follow a
+// rotation by alpha' = alpha - t |gamma|, beta' = beta + t |gamma| (recomputed exactly at every sweep).  A sweep is seven rounds
+// of the fixed position pairs (0,7), (1,6), (2,5), (3,4) followed by a cyclic move of the columns at positions 1 .. 7 (|A| does
+// not care where a column sits): a loop body of four pivots.  Convergence is to ABSOLUTE accuracy -- a pivot is rotated
+// while |gamma|^2 > 1e-30 ||A||_F^2 max(alpha, beta): the error of |A| from a residual gamma is |gamma| / (sigma_p + sigma_q) --
+// because the clouds this runs on sit ON the boundary of the cone: a zero eigenvalue leaves a column of rounding noise
+// whose RELATIVE orthogonality never converges (measured: every particle ran to the sweep limit).  Degenerate |lambda|
+// pairs of opposite sign mix in G's columns -- |A| restricted to that subspace is |lambda| times the identity, so the sum
+// over the pair is right whatever the mixture.  A particle whose tr |A| - tr A vanishes to rounding has no negative
+// eigenvalue: left as it is but for the trace (its list entry gets bit 31).
+// (Also built and measured on the way: four lanes per particle with DPP Gram sums -- texture-addresser-bound on the basis
+//  entries its lanes need, 19.7 ms, removed)
 // ---------------------------------------------------------------------------------------------
+template <int DIM> __host__ __device__ constexpr int pk_re(int r, int c) { return DIM + 2 * (r * (r - 1) / 2 + c); }   // r > c
+
 template <int DIM>
-__global__ __launch_bounds__(64) void k_tomo_canon_list_os(const double *__restrict__ basis, double *__restrict__ x, int64_t ldx,
-                                                           int allow_subnormalized, const unsigned int *__restrict__ list,
-                                                           const unsigned int *__restrict__ count) {
+__global__ __launch_bounds__(QSMC_BLOCK) void k_canon_mats(const double *__restrict__ basis, double *__restrict__ Mb,
+                                                           double *__restrict__ Me) {
+    constexpr int E = DIM * DIM, DP = 16 * ((E + 15) / 16);
+    for (int t = blockIdx.x * QSMC_BLOCK + threadIdx.x; t < DP * DP; t += gridDim.x * QSMC_BLOCK) {
+        const int e = t / DP, a = t % DP;
+        double v = 0.0, mult = 1.0;
+        if (e < E && a < E) {
+            int r = e, c = e, part = 0;
+            if (e >= DIM) {
+                const int q = e - DIM, p = q >> 1;
+                part = q & 1;
+                r = 1;
+                while (r * (r + 1) / 2 <= p) ++r;
+                c = p - r * (r - 1) / 2;
+                mult = 2.0;
+            }
+            v = basis[2 * ((a * DIM + r) * DIM + c) + part];
+        }
+        Mb[e * DP + a] = v;                                   // rho_packed = Mb x
+        Me[a * DP + e] = mult * v;                            // x = Me R_packed (Re tr(B_a^H R): off-diagonal entries twice)
+    }
+}
+
+// out = M in for 16 particles per wave trip (the kick kernel's MFMA chains with M in the place of S).
+// MODE 0: in = the cloud x (every particle i < n), out = scratch[e * ld + i].
+// MODE 1: in = scratch (the listed particles: list[t] & 0x7fffffff; bit 31: nothing was clamped), out = x with the trace
+//         renormalisation x / (x_0 sqrt dim) unless allow_subnormalized (tomography/models.py:194-209); a particle with
+//         bit 31 keeps its own coefficients (the reference returns it untouched) and is only renormalised.
+constexpr int GEMMW_BT = 256, GEMMW_WAVES = GEMMW_BT / QSMC_WAVE, GEMMW_PER_BLOCK = 256;
+template <int NB, int MODE>
+__global__ __launch_bounds__(GEMMW_BT, 3) void k_gemm_wide(const double *__restrict__ M, int E, double *__restrict__ x,
+                                                           int64_t ldx, int64_t n, double *__restrict__ scratch, int64_t ld,
+                                                           const unsigned int *__restrict__ list,
+                                                           const unsigned int *__restrict__ count, int dim,
+                                                           int allow_subnormalized) {
+    constexpr int DP = 16 * NB, ST = DP + 4;
+    __shared__ double sMT[DP * ST];                                // sMT[k * ST + row] = M[row][k]
+    const int64_t n_items = MODE == 0 ? n : (int64_t)*count;
+    const int64_t r0 = (int64_t)blockIdx.x * GEMMW_PER_BLOCK;
+    if (r0 >= n_items) return;
+    for (int t = threadIdx.x; t < DP * DP; t += GEMMW_BT) {
+        const int row = t / DP, k = t % DP;
+        sMT[k * ST + row] = M[row * DP + k];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & (QSMC_WAVE - 1), wave = threadIdx.x / QSMC_WAVE;
+    const int nn = lane & 15, g = lane >> 4;
+    const int64_t r1 = r0 + GEMMW_PER_BLOCK < n_items ? r0 + GEMMW_PER_BLOCK : n_items;
+    for (int64_t kb = r0 + (int64_t)wave * 16; kb < r1; kb += GEMMW_WAVES * 16) {
+        const int64_t t = kb + nn;
+        const int64_t tc = t < r1 ? t : r1 - 1;                     // (idle columns shadow the last item: no divergence)
+        unsigned int entry = 0u;
+        if (MODE == 1) entry = list[tc];
+        const int64_t i = MODE == 0 ? tc : (int64_t)(entry & 0x7fffffffu);
+        v4d acc[NB];
+#pragma unroll
+        for (int rb = 0; rb < NB; ++rb) acc[rb] = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1                                                 // (unrolled: 168 VGPRs + 300 B of scratch at NB = 4)
+        for (int tt = 0; tt < NB; ++tt) {
+            double z[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int k = 16 * tt + 4 * g + s;
+                z[s] = k < E ? (MODE == 0 ? x[(int64_t)k * ldx + i] : scratch[(int64_t)k * ld + i]) : 0.0;
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const double *col = sMT + (16 * tt + 4 * g + s) * ST + nn;    // M[16 rb + nn][16 tt + 4 g + s]
+#pragma unroll
+                for (int rb = 0; rb < NB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(col[16 * rb], z[s], acc[rb], 0, 0, 0);
+            }
+        }
+        // D: value r of lane (g, nn) = out[16 rb + g + 4 r][item nn]
+        if (MODE == 0) {
+            if (t < r1) {
+#pragma unroll
+                for (int rb = 0; rb < NB; ++rb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int e = 16 * rb + g + 4 * r;
+                        if (e < E) scratch[(int64_t)e * ld + i] = acc[rb][r];
+                    }
+            }
+        } else {
+            const bool clamped = (entry >> 31) == 0u;
+            // coefficient 0 of the item: value 0 of block 0 on lane (g = 0, nn)
+            const double k0 = __shfl(acc[0][0], nn, QSMC_WAVE);
+            const double x0 = clamped ? k0 : x[i];
+            const double inv = allow_subnormalized ? 1.0 : 1.0 / (x0 * sqrt((double)dim));
+            if (t < r1 && (clamped || !allow_subnormalized)) {
+#pragma unroll
+                for (int rb = 0; rb < NB; ++rb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int a = 16 * rb + g + 4 * r;
+                        if (a < E) {
+                            double *dst = x + (int64_t)a * ldx + i;
+                            *dst = (clamped ? acc[rb][r] : *dst) * inv;
+                        }
+                    }
+            }
+        }
+    }
+}
+
+// LDL^H pivot test on the packed rho of every particle: positive definite -> only the trace renormalisation, else listed
+template <int DIM>
+__global__ __launch_bounds__(QSMC_BLOCK) void k_tomo_ldl_wide(const double *__restrict__ scratch, int64_t ld, double *__restrict__ x,
+                                                              int64_t ldx, int64_t n, int allow_subnormalized,
+                                                              unsigned int *__restrict__ list, unsigned int *__restrict__ count) {
+    constexpr int D = DIM * DIM;
+    for (int64_t i0 = (int64_t)blockIdx.x * QSMC_BLOCK; i0 < n; i0 += (int64_t)gridDim.x * QSMC_BLOCK) {
+        const int64_t i = i0 + threadIdx.x;
+        const bool live = i < n;
+        bool ok = true;
+        if (live) {
+#pragma clang fp contract(on)                             // (a verdict, not a reproduced value: as tomo_clearly_positive)
+            double Ar[DIM][DIM], Ai[DIM][DIM];
+#pragma unroll
+            for (int r = 0; r < DIM; ++r) {
+                Ar[r][r] = scratch[(int64_t)r * ld + i];
+#pragma unroll
+                for (int c = 0; c < r; ++c) {
+                    Ar[r][c] = scratch[(int64_t)pk_re<DIM>(r, c) * ld + i];
+                    Ai[r][c] = scratch[(int64_t)(pk_re<DIM>(r, c) + 1) * ld + i];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < DIM; ++j) {
+                double dj = Ar[j][j];
+#pragma unroll
+                for (int k = 0; k < j; ++k) dj -= (Ar[j][k] * Ar[j][k] + Ai[j][k] * Ai[j][k]) * Ar[k][k];
+                ok = ok && (dj > 0.0);
+                Ar[j][j] = dj;
+                const double inv = 1.0 / dj;
+#pragma unroll
+                for (int r = j + 1; r < DIM; ++r) {
+                    double sr = Ar[r][j], si = Ai[r][j];
+#pragma unroll
+                    for (int k = 0; k < j; ++k) {
+                        const double tr = Ar[r][k] * Ar[j][k] + Ai[r][k] * Ai[j][k];
+                        const double ti = Ai[r][k] * Ar[j][k] - Ar[r][k] * Ai[j][k];
+                        sr -= tr * Ar[k][k];
+                        si -= ti * Ar[k][k];
+                    }
+                    Ar[r][j] = sr * inv;
+                    Ai[r][j] = si * inv;
+                }
+            }
+            if (ok && !allow_subnormalized) {             // tomography/models.py:194-209
+                const double inv = 1.0 / (x[i] * sqrt((double)DIM));
+                for (int a = 0; a < D; ++a) x[(int64_t)a * ldx + i] = x[(int64_t)a * ldx + i] * inv;
+            }
+        }
+        const bool listed = live && !ok;
+        const unsigned long long mk = __ballot(listed);
+        if (mk) {                                         // one atomic per wave, entries in lane order
+            const int lane = threadIdx.x & (QSMC_WAVE - 1);
+            unsigned int base = 0;
+            if (lane == 0) base = atomicAdd(count, (unsigned int)__popcll(mk));
+            base = __shfl(base, 0, QSMC_WAVE);
+            if (listed) list[base + __popcll(mk & ((1ull << lane) - 1ull))] = (unsigned int)i;
+        }
+    }
+}
+
+template <int DIM>
+__global__ __launch_bounds__(64) void k_tomo_jacobi_wide(double *__restrict__ scratch, int64_t ld, unsigned int *__restrict__ list,
+                                                         const unsigned int *__restrict__ count) {
 #pragma clang fp contract(on)                                 // (as in jacobi_clamp: nothing reproduces these intermediates)
-    constexpr int D = DIM * DIM, NC = 8;                      // columns padded to 8 (zero columns are never rotated)
+    constexpr int NC = 8;                                     // columns padded to 8 (zero columns are never rotated)
     const unsigned int m = *count;
     for (unsigned int t = blockIdx.x * 64u + threadIdx.x; t < m; t += gridDim.x * 64u) {
         const int64_t i = (int64_t)list[t];
@@ -539,45 +722,25 @@ __global__ __launch_bounds__(64) void k_tomo_canon_list_os(const double *__restr
 #pragma unroll
         for (int r = 0; r < DIM; ++r)
 #pragma unroll
-            for (int c = 0; c < NC; ++c) { Gr[r][c] = 0.0; Gi[r][c] = 0.0; }
-#pragma unroll 1
-        for (int a0 = 0; a0 < D; a0 += 8) {                   // (eight coefficients ahead: see wide_build_lower)
-            double pa[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) pa[u] = x[(int64_t)(a0 + u < D ? a0 + u : D - 1) * ldx + i];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (a0 + u < D) {
-                    const double *B = basis + (size_t)2 * (a0 + u) * DIM * DIM;
-#pragma unroll
-                    for (int r = 0; r < DIM; ++r)
-#pragma unroll
-                        for (int c = 0; c <= r; ++c) {
-                            Gr[r][c] += pa[u] * B[2 * (r * DIM + c)];
-                            Gi[r][c] += pa[u] * B[2 * (r * DIM + c) + 1];
-                        }
-                }
-            }
-        }
+            for (int c = DIM; c < NC; ++c) { Gr[r][c] = 0.0; Gi[r][c] = 0.0; }
         double tr_a = 0.0, frob2 = 0.0;
 #pragma unroll
         for (int r = 0; r < DIM; ++r) {
+            Gr[r][r] = scratch[(int64_t)r * ld + i];
             Gi[r][r] = 0.0;
             tr_a += Gr[r][r];
             frob2 += Gr[r][r] * Gr[r][r];
 #pragma unroll
             for (int c = 0; c < r; ++c) {
-                Gr[c][r] = Gr[r][c];
-                Gi[c][r] = -Gi[r][c];
-                frob2 += 2.0 * (Gr[r][c] * Gr[r][c] + Gi[r][c] * Gi[r][c]);
+                const double re = scratch[(int64_t)pk_re<DIM>(r, c) * ld + i], im = scratch[(int64_t)(pk_re<DIM>(r, c) + 1) * ld + i];
+                Gr[r][c] = re;
+                Gi[r][c] = im;
+                Gr[c][r] = re;
+                Gi[c][r] = -im;
+                frob2 += 2.0 * (re * re + im * im);
             }
         }
         const double tiny2 = 1e-28 * frob2, conv2 = 1e-30 * frob2;
-        // Round-robin of 8: every round rotates the FIXED position pairs (0, 7), (1, 6), (2, 5), (3, 4), then the columns at
-        // positions 1 .. 7 move on by one place (|A| = sum_k g_k g_k^H / sigma_k does not care where a column sits); seven
-        // rounds meet all 28 pairs.  The round is a loop body of four pivots + 7 DIM register moves -- ~10 KB of code; the
-        // first cut unrolled all 28 pivots of a sweep (p, q must be compile-time: register indices), 45 KB that one wave per
-        // SIMD streamed through the instruction cache every sweep: 4.2 ms where the arithmetic is worth ~1.7.
         double nrm[NC];
         for (int sweep = 0; sweep < 30; ++sweep) {
 #pragma unroll
@@ -658,47 +821,29 @@ __global__ __launch_bounds__(64) void k_tomo_canon_list_os(const double *__restr
             for (int r = 0; r < DIM; ++r) { Gr[r][c] *= isg; Gi[r][c] *= isg; }
         }
         const bool neg = (sum_sigma - tr_a) > 64.0 * 2.220446049250313e-16 * sum_sigma;
-        if (neg) {
-            // P = H H^H / 2, lower triangle; x'_a = x_a / 2 + Re sum_rc conj(B_a[r][c]) P[r][c]  (orthonormal basis)
-            double Pr[DIM][DIM], Pi[DIM][DIM];
+        if (!neg) {
+            list[t] = (unsigned int)i | 0x80000000u;          // nothing to clamp: the expand pass only renormalises
+            continue;
+        }
+        // R = (A + H H^H) / 2, packed, entry by entry over A's own scratch
 #pragma unroll
-            for (int r = 0; r < DIM; ++r)
+        for (int r = 0; r < DIM; ++r)
 #pragma unroll
-                for (int c = 0; c <= r; ++c) {
-                    double sr = 0.0, si = 0.0;
+            for (int c = 0; c <= r; ++c) {
+                double sr = 0.0, si = 0.0;
 #pragma unroll
-                    for (int k = 0; k < NC; ++k) {
-                        sr += Gr[r][k] * Gr[c][k] + Gi[r][k] * Gi[c][k];
-                        si += Gi[r][k] * Gr[c][k] - Gr[r][k] * Gi[c][k];
-                    }
-                    Pr[r][c] = (r == c ? 0.5 : 1.0) * sr;      // (off-diagonal entries count twice in the real trace)
-                    Pi[r][c] = si;
+                for (int k = 0; k < NC; ++k) {
+                    sr += Gr[r][k] * Gr[c][k] + Gi[r][k] * Gi[c][k];
+                    si += Gi[r][k] * Gr[c][k] - Gr[r][k] * Gi[c][k];
                 }
-            double inv = 1.0;
-#pragma unroll 1
-            for (int a0 = 0; a0 < D; a0 += 8) {
-                double xa[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) xa[u] = x[(int64_t)(a0 + u < D ? a0 + u : D - 1) * ldx + i];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    if (a0 + u < D) {
-                        const int a = a0 + u;
-                        const double *B = basis + (size_t)2 * a * DIM * DIM;
-                        double s = 0.5 * xa[u];
-#pragma unroll
-                        for (int r = 0; r < DIM; ++r)
-#pragma unroll
-                            for (int c = 0; c <= r; ++c)
-                                s += B[2 * (r * DIM + c)] * Pr[r][c] + (c < r ? B[2 * (r * DIM + c) + 1] * Pi[r][c] : 0.0);
-                        if (a == 0 && !allow_subnormalized) inv = 1.0 / (s * sqrt((double)DIM));     // tomography/models.py:194-209
-                        x[(int64_t)a * ldx + i] = allow_subnormalized ? s : s * inv;
-                    }
+                if (r == c) {
+                    double *dst = scratch + (int64_t)r * ld + i;
+                    *dst = 0.5 * (*dst + sr);
+                } else {
+                    double *dre = scratch + (int64_t)pk_re<DIM>(r, c) * ld + i, *dim_ = scratch + (int64_t)(pk_re<DIM>(r, c) + 1) * ld + i;
+                    *dre = 0.5 * (*dre + sr);
+                    *dim_ = 0.5 * (*dim_ + si);
                 }
             }
-        } else if (!allow_subnormalized) {
-            const double inv = 1.0 / (x[i] * sqrt((double)DIM));
-            for (int a = 0; a < D; ++a) x[(int64_t)a * ldx + i] = x[(int64_t)a * ldx + i] * inv;
-        }
     }
 }

@@ -136,6 +136,8 @@ struct qsmc_ctx {
     LWWide *lw_wide_host;   // ... pinned host slots, WIDE_RING of them used in turn; a slot is rewritten only after the
     hipEvent_t lw_wide_ev[WIDE_RING];   // event recorded behind its copy has completed
     int lw_wide_next;
+    double *wide_rho;       // device: the wide canonicalize's packed rho of every particle + its two E x E maps
+    size_t wide_rho_cap;    // in doubles
     unsigned int *anc16;    // device: ancestors + canonicalize list of the split d = 16 sampler
     size_t anc16_cap;       // in bytes
     unsigned int *iscratch; // device integer scratch for the bucketed resampler
@@ -818,33 +820,61 @@ static int canon_dim4(qsmc_ctx *h, Basis B, double *x, int64_t ldx, int64_t n, i
 // C ABI
 // =============================================================================================
 extern "C" { static int ensure_anc16(qsmc_ctx *h, size_t bytes); }
-// dim 5 .. 8: classify (LDL^H pivots; positive-definite particles are finished there), then the listed rest (Jacobi)
+// device scratch of the wide canonicalize: rho of every particle in packed Hermitian form (E x n doubles) + the two E x E maps
+static int ensure_wide_rho(qsmc_ctx *h, size_t doubles) {
+    if (h->wide_rho_cap >= doubles) return QSMC_OK;
+    if (h->wide_rho) HIP_TRY(h, hipFree(h->wide_rho));
+    h->wide_rho = nullptr;
+    h->wide_rho_cap = 0;
+    HIP_TRY(h, hipMalloc(&h->wide_rho, doubles * sizeof(double)));
+    h->wide_rho_cap = doubles;
+    return QSMC_OK;
+}
+
+// dim 5 .. 8 (kernels/wide.hpp): rho_packed = Mb x for every particle on the matrix cores, LDL^H pivot test (positive-definite
+// particles are finished there), one-sided Jacobi for the listed rest, x = Me R_packed + the trace renormalisation
 template <int DIM>
 static int canon_wide(qsmc_ctx *h, const double *basis, double *x, int64_t ldx, int64_t n, int32_t allow_subnormalized,
                       hipStream_t s) {
     if (!basis) return QSMC_ERR_INVALID;                     // (dense contraction with the basis tensor, whatever the basis)
-    if (n >= (1ll << 32)) return QSMC_ERR_UNSUPPORTED;
+    if (n >= (1ll << 31)) return QSMC_ERR_UNSUPPORTED;       // (list entries: 31 bits of index + a flag)
     int rc = ensure_anc16(h, ((size_t)n + 16) * sizeof(unsigned int));
     if (rc) return rc;
     unsigned int *count = h->anc16, *list = h->anc16 + 4;
     HIP_TRY(h, hipMemsetAsync(count, 0, 4 * sizeof(unsigned int), s));
     hipEvent_t c0 = nullptr, c1 = nullptr, l0 = nullptr, l1 = nullptr;
-    prof_events(h, QSMC_PROF_CANON_CLASSIFY, &c0, &c1);
-    hipExtLaunchKernelGGL((k_tomo_classify_wide<DIM>), dim3(grid_for(n, QSMC_BLOCK)), dim3(QSMC_BLOCK), 0, s, c0, c1, 0, basis, x,
-                          ldx, n, allow_subnormalized, list, count);
-    prof_events(h, QSMC_PROF_CANON_LIST, &l0, &l1);
-    if constexpr (DIM == 8 || DIM == 5) {                    // (test hook: the independent form, built for dim 5 and 8)
+    if constexpr (DIM == 8 || DIM == 5) {                    // (test hook: the independent, eigenvector form, built for dim 5 and 8)
         if (g_canon_wide_jacobi) {
+            prof_events(h, QSMC_PROF_CANON_CLASSIFY, &c0, &c1);
+            hipExtLaunchKernelGGL((k_tomo_classify_wide<DIM>), dim3(grid_for(n, QSMC_BLOCK)), dim3(QSMC_BLOCK), 0, s, c0, c1, 0,
+                                  basis, x, ldx, n, allow_subnormalized, list, count);
+            prof_events(h, QSMC_PROF_CANON_LIST, &l0, &l1);
             hipExtLaunchKernelGGL((k_tomo_canon_list_wide<DIM>), dim3(grid_for(n, 64)), dim3(64), 0, s, l0, l1, 0, basis, x, ldx,
                                   allow_subnormalized, list, count);
             HIP_TRY(h, hipGetLastError());
             return QSMC_OK;
         }
     }
-    {
-        hipExtLaunchKernelGGL((k_tomo_canon_list_os<DIM>), dim3(grid_for(n, 64)), dim3(64), 0, s, l0, l1, 0, basis, x, ldx,
-                              allow_subnormalized, list, count);
-    }
+    constexpr int E = DIM * DIM, NB = (E + 15) / 16, DP = 16 * NB;
+    const int64_t ld = (n + 3) / 4 * 4;
+    rc = ensure_wide_rho(h, (size_t)E * (size_t)ld + 2 * (size_t)DP * DP);
+    if (rc) return rc;
+    double *rho = h->wide_rho, *Mb = h->wide_rho + (size_t)E * (size_t)ld, *Me = Mb + (size_t)DP * DP;
+    hipLaunchKernelGGL((k_canon_mats<DIM>), dim3((DP * DP + QSMC_BLOCK - 1) / QSMC_BLOCK), dim3(QSMC_BLOCK), 0, s, basis, Mb, Me);
+    hipEvent_t b0 = nullptr, b1 = nullptr, e0 = nullptr, e1 = nullptr;
+    prof_events(h, QSMC_PROF_CANON_BUILD, &b0, &b1);
+    const unsigned ggrid = (unsigned)((n + GEMMW_PER_BLOCK - 1) / GEMMW_PER_BLOCK);
+    hipExtLaunchKernelGGL((k_gemm_wide<NB, 0>), dim3(ggrid), dim3(GEMMW_BT), 0, s, b0, b1, 0, (const double *)Mb, E, x, ldx, n, rho,
+                          ld, (const unsigned int *)nullptr, (const unsigned int *)nullptr, DIM, allow_subnormalized);
+    prof_events(h, QSMC_PROF_CANON_CLASSIFY, &c0, &c1);
+    hipExtLaunchKernelGGL((k_tomo_ldl_wide<DIM>), dim3(grid_for(n, QSMC_BLOCK)), dim3(QSMC_BLOCK), 0, s, c0, c1, 0,
+                          (const double *)rho, ld, x, ldx, n, allow_subnormalized, list, count);
+    prof_events(h, QSMC_PROF_CANON_LIST, &l0, &l1);
+    hipExtLaunchKernelGGL((k_tomo_jacobi_wide<DIM>), dim3(grid_for(n, 64)), dim3(64), 0, s, l0, l1, 0, rho, ld, list,
+                          (const unsigned int *)count);
+    prof_events(h, QSMC_PROF_CANON_EXPAND, &e0, &e1);
+    hipExtLaunchKernelGGL((k_gemm_wide<NB, 1>), dim3(ggrid), dim3(GEMMW_BT), 0, s, e0, e1, 0, (const double *)Me, E, x, ldx, n, rho,
+                          ld, (const unsigned int *)list, (const unsigned int *)count, DIM, allow_subnormalized);
     HIP_TRY(h, hipGetLastError());
     return QSMC_OK;
 }
@@ -941,6 +971,7 @@ int qsmc_destroy(qsmc_handle_t h) {
     if (h->anc16) (void)hipFree(h->anc16);
     if (h->lw_dev) (void)hipFree(h->lw_dev);
     if (h->lw_wide) (void)hipFree(h->lw_wide);
+    if (h->wide_rho) (void)hipFree(h->wide_rho);
     if (h->lw_wide_host) (void)hipHostFree(h->lw_wide_host);
     for (int i = 0; i < WIDE_RING; ++i)
         if (h->lw_wide_ev[i]) (void)hipEventDestroy(h->lw_wide_ev[i]);

@@ -122,7 +122,6 @@ class TomographyModel(NativeModelMixin, FiniteOutcomeModel):
         self._allow_subnormalized = bool(allow_subnormalized)
         self._basis_dev = None
         self._is_pauli = None
-        self._orthonormal = None
         super().__init__()
         # d <= 16: the narrow kernels; 16 < d <= 64 (dim 5 .. 8, three qubits): the wide ones (csrc/kernels/wide.hpp)
         self._native = self.n_modelparams <= _native.QSMC_MAX_D_WIDE
@@ -188,16 +187,7 @@ class TomographyModel(NativeModelMixin, FiniteOutcomeModel):
     def _native_canonicalize_ok(self):
         """Device canonicalize kernels exist for dim 2 .. 8 (dim 2, 3, 4: the narrow kernels; dim 5 .. 8, up to three
         qubits: classify + Jacobi list, csrc/kernels/wide.hpp); larger systems take `canonicalize` on the host."""
-        if not 2 <= self._dim <= 8:
-            return False
-        if self._dim >= 5:
-            # the wide list pass re-expands x' = x / 2 + expand(|rho|) / 2: exact for an orthonormal basis (every basis the
-            # reference builds is: bases.py:71-154); any other basis takes the host path
-            if self._orthonormal is None:
-                flat = self._basis.flat()
-                self._orthonormal = bool(np.allclose(flat.conj() @ flat.T, np.eye(flat.shape[0]), rtol=0, atol=1e-13))
-            return self._orthonormal
-        return True
+        return 2 <= self._dim <= 8
 
     def _pauli(self):
         if self._is_pauli is None:               # is this the reference's Pauli basis, element for element?

@@ -35,7 +35,7 @@ def dense_ep():
 
 
 names = {0: "update", 1: "kick", 2: "update_ones", 3: "canon_classify", 4: "canon_list", 5: "moments", 6: "counts",
-         7: "counts_skipped", 8: "ancestors"}
+         7: "counts_skipped", 8: "ancestors", 12: "canon_build", 13: "canon_expand"}
 for label, mk in (("sparse (Pauli, nnz = 2)", pauli_ep), ("dense (nnz = 64)", dense_ep)):
     for _ in range(3):
         upd.update(int(rs.randint(2)), mk(), check_for_resample=False)
