@@ -529,9 +529,12 @@ __global__ __launch_bounds__(64) void k_tomo_canon_list_wide(const double *__res
 // polar factor -- and |A| = G Sigma^-1 G^H for G = A W with orthogonal columns of norms Sigma: Hestenes' Jacobi on the COLUMNS
 // of A.  Only G is iterated (256 VGPRs at dim 8, against iterate + eigenvectors + reconstruction of the eigenvector form:
 // 510 and AGPR traffic on every access); the Gram entry of a pivot is a sum down two columns; the column norms follow a
-// rotation by alpha' = alpha - t |gamma|, beta' = beta + t |gamma| (recomputed exactly at every sweep).  A sweep is seven rounds
-// of the fixed position pairs (0,7), (1,6), (2,5), (3,4) followed by a cyclic move of the columns at positions 1 .. 7 (|A| does
-// not care where a column sits): a loop body of four pivots.  Convergence is to ABSOLUTE accuracy -- a pivot is rotated
+// rotation by alpha' = alpha - t |gamma|, beta' = beta + t |gamma| (recomputed exactly at every sweep).  The 28 pivots of a sweep are
+// unrolled (register indices must be compile-time); as seven rounds of the fixed position pairs (0,7), (1,6), (2,5), (3,4) with a
+// cyclic move of columns 1 .. 7 in between -- a loop body of four pivots, |A| does not care where a column sits -- the pass takes
+// 2.18 ms against 1.96: the moves cost more than the instruction cache.  The kernel issues ~11 000 instructions per particle and
+// sweep, a sixth of them v_accvgpr moves: an 8 x 8 complex iterate IS the 256 architectural VGPRs, everything else lives in
+// AGPRs.  Convergence is to ABSOLUTE accuracy -- a pivot is rotated
 // while |gamma|^2 > 1e-30 ||A||_F^2 max(alpha, beta): the error of |A| from a residual gamma is |gamma| / (sigma_p + sigma_q) --
 // because the clouds this runs on sit ON the boundary of the cone: a zero eigenvalue leaves a column of rounding noise
 // whose RELATIVE orthogonality never converges (measured: every particle ran to the sweep limit).  Degenerate |lambda|
@@ -751,11 +754,11 @@ __global__ __launch_bounds__(64) void k_tomo_jacobi_wide(double *__restrict__ sc
                 nrm[c] = s2;
             }
             bool rotated = false;
-#pragma unroll 1
-            for (int round = 0; round < 7; ++round) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int p = j, q = 7 - j;
+            for (int p = 0; p < NC; ++p)
+#pragma unroll
+                for (int q = p + 1; q < NC; ++q) {
+                    if (p >= DIM || q >= DIM) continue;       // (padding columns: compile-time)
                     const double big = fmax(nrm[p], nrm[q]);
                     if (big > tiny2) {
                         double gr = 0.0, gi = 0.0;            // g_p^H g_q
@@ -789,22 +792,6 @@ __global__ __launch_bounds__(64) void k_tomo_jacobi_wide(double *__restrict__ sc
                         }
                     }
                 }
-                // positions 1 .. 7 move on: new[1] = old[7], new[c] = old[c - 1]
-                {
-                    const double n7 = nrm[7];
-#pragma unroll
-                    for (int c = 7; c > 1; --c) nrm[c] = nrm[c - 1];
-                    nrm[1] = n7;
-#pragma unroll
-                    for (int r = 0; r < DIM; ++r) {
-                        const double a7 = Gr[r][7], b7 = Gi[r][7];
-#pragma unroll
-                        for (int c = 7; c > 1; --c) { Gr[r][c] = Gr[r][c - 1]; Gi[r][c] = Gi[r][c - 1]; }
-                        Gr[r][1] = a7;
-                        Gi[r][1] = b7;
-                    }
-                }
-            }
             if (!rotated) break;
         }
         // column norms = |lambda|; H = G Sigma^(-1/2), so that |A| = H H^H
@@ -825,7 +812,12 @@ __global__ __launch_bounds__(64) void k_tomo_jacobi_wide(double *__restrict__ sc
             list[t] = (unsigned int)i | 0x80000000u;          // nothing to clamp: the expand pass only renormalises
             continue;
         }
-        // R = (A + H H^H) / 2, packed, entry by entry over A's own scratch
+        // R = (A + H H^H) / 2, packed, entry by entry over A's own scratch.  (The particle index goes through an empty asm: left
+        // visible, the 64 addresses of this write-back are formed BEFORE the sweeps and kept live through them -- 476 VGPRs
+        // instead of 352 at dim 8, 226 instead of 160 at dim 5 (two waves per SIMD there); no difference in time at dim 8)
+        long long i2 = (long long)i;
+        asm volatile("" : "+v"(i2));
+        double *const sc2 = scratch + i2;
 #pragma unroll
         for (int r = 0; r < DIM; ++r)
 #pragma unroll
@@ -837,10 +829,10 @@ __global__ __launch_bounds__(64) void k_tomo_jacobi_wide(double *__restrict__ sc
                     si += Gi[r][k] * Gr[c][k] - Gr[r][k] * Gi[c][k];
                 }
                 if (r == c) {
-                    double *dst = scratch + (int64_t)r * ld + i;
+                    double *dst = sc2 + (int64_t)r * ld;
                     *dst = 0.5 * (*dst + sr);
                 } else {
-                    double *dre = scratch + (int64_t)pk_re<DIM>(r, c) * ld + i, *dim_ = scratch + (int64_t)(pk_re<DIM>(r, c) + 1) * ld + i;
+                    double *dre = sc2 + (int64_t)pk_re<DIM>(r, c) * ld, *dim_ = sc2 + (int64_t)(pk_re<DIM>(r, c) + 1) * ld;
                     *dre = 0.5 * (*dre + sr);
                     *dim_ = 0.5 * (*dim_ + si);
                 }
