@@ -212,6 +212,18 @@ def other_config_specs(qi):
                       # two of the 16 rows, writes w' (the dense form, 16 + 8 d = 144 B, multiplies 14 rows by zero)
                       update_bpp=32, update_note="sparse measurement vector: 16 + 8 nnz = 32 B per particle "
                                                  "(dense form: 144 B; QSMC_TOMO_DENSE_UPDATE=1)"))
+    # C4 and C5 at their FULL sizes on ONE GPU (BASELINE quotes them on 8; both fit one MI355X's HBM: 3.2 GB and 1.36 GB of
+    # cloud): the same schedules as the shares above, so the two entries show what the per-datum fixed cost does to a share.
+    # C4's resample runs in segments (more than 8192 x 4096 particles); C5's prior is drawn on the device
+    # (GinibreDistribution.sample_device: 1e7 states on the host take half a minute).
+    c4 = specs[-2]
+    specs.append(dict(c4, key="config4_full_rb_1gpu", n=100_000_000,
+                      workload="RandomizedBenchmarkingModel (p, A, B), 1e8 particles on ONE GPU (BASELINE config 4's total), "
+                               "m_k = 1 + 5k"))
+    c5 = specs[-2]
+    specs.append(dict(c5, key="config5_full_tomography_1gpu", n=10_000_000, prior=lambda: qi.GinibreDistribution(basis, device=True),
+                      workload="2-qubit TomographyModel (15 free params), 1e7 particles on ONE GPU (BASELINE config 5's "
+                               "total), Ginibre prior (device draw), random Pauli measurements"))
     # Not a BASELINE config -- the widening of round 6: THREE-qubit tomography (d = 64; the reference's TomographyModel takes
     # any dim, tomography/models.py:82-226) on the wide kernels (csrc/kernels/wide.hpp), N = 5e5 (256 MB of cloud), Ginibre
     # prior, 150 random Pauli measurements (a schedule long enough for resamples at this dimension)
@@ -326,8 +338,14 @@ def run_other_config(qi, eng, torch, spec, warmup, comm=None, n_override=None, s
                                                 {"bytes_per_particle": 8 + 16 * d, "ancestors_us": kt["ancestors"]["avg_us"],
                                                  "kick_us": kt["sample"]["avg_us"]})
         else:
-            out["resample_kernel"] = frac_entry(spec["sampler"], kt["sample"]["avg_us"], (8 + 16 * d) * n,
-                                                kt["sample"]["launches"], {"bytes_per_particle": 8 + 16 * d})
+            # beyond the resampler's segment limit a resample is one sampler launch per SEGMENT: a launch's bytes are its
+            # segment's
+            segs = -(-n // qi.LiuWestResampler._segment_limit)
+            extra = {"bytes_per_particle": 8 + 16 * d}
+            if segs > 1:
+                extra["segments_per_resample"] = segs
+            out["resample_kernel"] = frac_entry(spec["sampler"], kt["sample"]["avg_us"], (8 + 16 * d) * n // segs,
+                                                kt["sample"]["launches"], extra)
     if "canon_classify" in kt:
         zero = {"avg_us": 0.0}
         cus = (kt["canon_classify"]["avg_us"] + kt.get("canon_list", zero)["avg_us"] + kt.get("canon_build", zero)["avg_us"]

@@ -251,10 +251,11 @@ class TomographyModel(NativeModelMixin, FiniteOutcomeModel):
 class GinibreDistribution(Distribution):
     """Ginibre-ensemble prior over density operators of a given rank, as coefficient vectors."""
 
-    def __init__(self, basis, rank=None):
+    def __init__(self, basis, rank=None, device=False):
         self._basis = basis
         self._dim = basis.dim
         self._rank = self._dim if rank is None else int(rank)
+        self._device = bool(device)          # extension: `SMCUpdater(device_rng=True)` draws the prior on the GPU (sample_device)
 
     @property
     def n_rvs(self):
@@ -273,3 +274,27 @@ class GinibreDistribution(Distribution):
             rho /= np.trace(rho, axis1=1, axis2=2).real[:, None, None]
             out[i0:i0 + m] = np.real(rho.reshape(m, -1) @ flat.conj().T)
         return out
+
+    def sample_device(self, engine, n, seed, epoch, maxiter=None):
+        """The same ensemble drawn on the device (`SMCUpdater(device_rng=True)`): torch's own generator keyed by
+        (seed, epoch), the states built in blocks by torch products, written straight into the (d, N) cloud.  Prior
+        sampling is outside the path (once per `reset`); the host form above is the one the reference's stream
+        replays.  Not the same numbers as `sample` -- the same law (invariants tested: trace, positivity, moments)."""
+        if not self._device:
+            raise NotImplementedError      # (the updater then takes `sample`: the host draw, the default)
+        import torch
+        dev = engine.device
+        gen = torch.Generator(device=dev)
+        gen.manual_seed((int(seed) * 0x9E3779B97F4A7C15 + int(epoch)) & (2 ** 63 - 1))
+        flat_h = torch.from_numpy(np.ascontiguousarray(self._basis.flat().conj().T)).to(dev)     # (dim^2, d) complex
+        x_out = engine.empty(self.n_rvs, n)
+        block = 1 << 20
+        for i0 in range(0, n, block):
+            m = min(block, n - i0)
+            z = torch.randn(m, 2, self._dim, self._rank, dtype=torch.float64, device=dev, generator=gen)
+            g = torch.complex(z[:, 0], z[:, 1])
+            rho = g @ g.conj().transpose(1, 2)
+            tr = torch.diagonal(rho, dim1=1, dim2=2).sum(1).real
+            rho = rho / tr[:, None, None]
+            x_out[:, i0:i0 + m] = (rho.reshape(m, -1) @ flat_h).real.T
+        return x_out, 0

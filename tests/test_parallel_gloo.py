@@ -495,6 +495,61 @@ def test_sharded_fast_paths_two_ranks_one_gpu(tmp_path):
     _run("_check_sharded_fast_paths", tmp_path, world=2)
 
 
+def _check_sharded_c1_against_reference(comm, rank, world, tmpdir):
+    """A SHARDED run held to the REFERENCE's own numbers, not to another updater of ours: config C1 (N = 1000, 200 data,
+    fixture g1_precession_n1000_clouds recorded from /root/reference) with the cloud split over the ranks.  As in the
+    single-GPU teacher-forced test, every shard is put back on its slice of the reference's cloud after each resample
+    (weights are uniform there, so any split by the shards' sizes is the same cloud): every datum's global
+    normalisation, n_ess and mean, every resample DECISION and the final state must be the reference's on every rank."""
+    import warnings
+    import torch
+    import qinfer_amd as qi
+    import parity_tols as tol
+    torch.cuda.set_device(0)
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g1_precession_n1000_clouds.npz"))
+    ts, outcomes, at = g["ep_t"], g["outcomes"], list(g["resample_at"])
+    x0 = g["x0"]
+    bounds = np.linspace(0, 1000, world + 1).astype(int)
+
+    class Slice(qi.Distribution):
+        n_rvs = 1
+
+        def sample(self, n=1):
+            assert n == bounds[rank + 1] - bounds[rank]
+            return x0[bounds[rank]:bounds[rank + 1]].copy()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        upd = qi.SMCUpdater(qi.SimplePrecessionModel(), int(bounds[rank + 1] - bounds[rank]), Slice(), device_rng=True,
+                            seed=9, comm=comm)
+        assert upd.n_particles_global == 1000
+        for k in range(200):
+            upd.update(int(outcomes[k]), ts[k:k + 1])
+            assert upd.resample_count == g["resample_count"][k], "datum %d: resample decision differs" % k
+            np.testing.assert_allclose(np.ravel(upd.normalization_record[-1])[0], g["norms"][k], rtol=1e-11,
+                                       err_msg="datum %d" % k)
+            if k in at:
+                sizes = comm.gather_rows(np.array([float(upd.n_particles)]))[:, 0].astype(int)
+                assert sizes.sum() == 1000
+                off = np.concatenate([[0], np.cumsum(sizes)])
+                upd.particle_locations = g["clouds"][at.index(k)][off[rank]:off[rank + 1]]
+            np.testing.assert_allclose(upd.n_ess, g["n_ess"][k], rtol=1e-10, err_msg="datum %d" % k)
+            np.testing.assert_allclose(upd.est_mean(), g["means"][k], rtol=0, atol=1e-13, err_msg="datum %d" % k)
+    assert upd.resample_count == 38 == len(at)
+    np.testing.assert_allclose(upd.est_mean(), g["final_mean"], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(upd.est_covariance_mtx(), g["final_cov"], rtol=0,
+                               atol=tol.atol_cov(g["final_mean"], np.sum(g["final_mean"] ** 2), 1000))
+    import torch.distributed as dist
+    parts = [None] * world
+    dist.all_gather_object(parts, np.array(upd.particle_weights))            # (shards in rank order = the cloud's order)
+    np.testing.assert_allclose(np.concatenate(parts), g["final_weights"], rtol=1e-9, atol=1e-18)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])       # (equal nominal shards: N = 1000 over 2 or 4 ranks)
+def test_sharded_c1_against_reference(tmp_path, world):
+    _run("_check_sharded_c1_against_reference", tmp_path, world=world)
+
+
 def _check_sharded_plugin_model(comm, rank, world, tmpdir):
     """Round 6: a model WITHOUT native kernels shards too (the reference's DirectViewParallelizedModel shards any model's
     likelihood, parallel.py:196-224).  Two ranks against ONE updater holding the union cloud: the updates agree to

@@ -410,3 +410,31 @@ def test_wide_sharded_resample_placement(qi, eng, counts):
     assert rows.shape == (n_out, 64) and f1 == f2 == 0
     place = _deal_rows(counts)
     np.testing.assert_array_equal(rows[place], ref)
+
+
+def test_ginibre_prior_device_draw(qi):
+    """`GinibreDistribution(basis, device=True)` under `SMCUpdater(device_rng=True)`: the prior drawn on the GPU (bench's
+    full-size C5: 1e7 states take half a minute on the host).  The Ginibre prior is unpinned (qutip is absent):
+    invariants -- every particle a state (trace 1, positive), the same seed the same cloud, another seed another -- and
+    the ensemble's moments against the host draw's (the restated Ginibre the oracle tests use) within sampling error."""
+    for basis in (qi.tomography.pauli_basis(2), qi.tomography.pauli_basis(3), qi.tomography.gell_mann_basis(3)):
+        m = qi.TomographyModel(basis)
+        d = basis.dim ** 2
+        n = 40000
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            a = qi.SMCUpdater(m, n, qi.GinibreDistribution(basis, device=True), device_rng=True, seed=7)
+            b = qi.SMCUpdater(m, n, qi.GinibreDistribution(basis, device=True), device_rng=True, seed=7)
+            c = qi.SMCUpdater(m, n, qi.GinibreDistribution(basis, device=True), device_rng=True, seed=8)
+        xa, xb, xc = (np.asarray(u.particle_locations) for u in (a, b, c))
+        assert xa.shape == (n, d)
+        assert np.array_equal(xa, xb) and not np.array_equal(xa, xc)
+        rho = np.tensordot(xa[::7], basis.data, 1)
+        np.testing.assert_allclose(np.trace(rho, axis1=1, axis2=2).real, 1.0, atol=1e-12)
+        assert np.linalg.eigvalsh(rho).min() > -1e-12
+        np.random.seed(3)
+        xh = qi.GinibreDistribution(basis).sample(n)
+        se = np.sqrt((xa.var(0) + xh.var(0)) / n) + 1e-15
+        assert np.all(np.abs(xa.mean(0) - xh.mean(0)) < 5 * se)
+        v_a, v_h = xa[:, 1:].var(0), xh[:, 1:].var(0)
+        assert np.all(np.abs(v_a / v_h - 1) < 0.08), (v_a / v_h)
