@@ -2970,3 +2970,63 @@ print("digest", h.hexdigest())
     n_redraws = int(outs[0][2].split()[1])
     assert n_redraws > 0, outs[0]                       # (the queue was in use: the test saw the path it is about)
 
+
+
+# ================================================================== tiny and odd cloud sizes
+@pytest.mark.parametrize("device_rng", [False, True])
+def test_tiny_and_odd_cloud_sizes(qi, device_rng):
+    """Edge sizes the kernels' tiling must not care about (one particle; fewer than a wave; one more or less than a wave, a
+    workgroup, a tile, a chunk): 25 data with resamples on the way for every model family with native kernels -- the run
+    completes, the estimate is finite and inside the prior's support, RB children satisfy the model's constraints, every
+    tomography particle is a state.  Then the update itself at those sizes against the oracle (no resampling)."""
+    rs = np.random.RandomState(0)
+    ts = (9 / 8) ** np.arange(40.0)
+    outs = (rs.random_sample(40) >= np.cos(0.3 * ts / 2) ** 2).astype(int)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for n in (1, 2, 3, 63, 64, 65, 255, 257, 4095, 4097, 65537):
+            np.random.seed(1)
+            u = qi.SMCUpdater(qi.SimplePrecessionModel(), n, qi.UniformDistribution([0, 1]), device_rng=device_rng, seed=3)
+            for k in range(25):
+                u.update(int(outs[k]), ts[k:k + 1])
+            assert u.n_particles == n and 0 < u.est_mean()[0] < 1 and 1 <= u.n_ess <= n * (1 + 1e-12)
+            if n >= 63:
+                assert u.resample_count >= 2 and abs(u.est_mean()[0] - 0.3) < 0.05
+        m = qi.RandomizedBenchmarkingModel()
+        prior = qi.PostselectedDistribution(qi.UniformDistribution([[0.8, 1], [0, 1], [0, 1]]), m)
+        for n in (1, 7, 65, 1000):
+            np.random.seed(2)
+            u = qi.SMCUpdater(m, n, prior, device_rng=device_rng, seed=2)
+            for k in range(30):
+                u.update(int(rs.random_sample() < 0.6), np.array([(1 + 5 * k,)], dtype=m.expparams_dtype))
+            assert m.are_models_valid(np.asarray(u.particle_locations)).all()
+        for basis in (qi.tomography.pauli_basis(1), qi.tomography.pauli_basis(2), qi.tomography.gell_mann_basis(3),
+                      qi.tomography.pauli_basis(3)):
+            m = qi.TomographyModel(basis)
+            for n in (1, 5, 70, 3000):
+                np.random.seed(2)
+                u = qi.SMCUpdater(m, n, qi.GinibreDistribution(basis), device_rng=device_rng, seed=2)
+                for k in range(12):
+                    ep = np.zeros((1,), dtype=m.expparams_dtype)
+                    ep['meas'][0, 0] = np.sqrt(basis.dim) / 2
+                    ep['meas'][0, 1 + k % (basis.dim ** 2 - 1)] = np.sqrt(basis.dim) / 2
+                    u.update(int(rs.random_sample() < 0.5), ep)
+                u.resample()
+                rho = np.tensordot(np.asarray(u.particle_locations), basis.data, 1)
+                np.testing.assert_allclose(np.trace(rho, axis1=1, axis2=2).real, 1.0, atol=1e-9)
+                assert np.linalg.eigvalsh(rho).min() > -1e-9
+        if device_rng:
+            return
+        for n in (1, 2, 5, 64, 65, 1023, 1025, 4097, 100003):
+            np.random.seed(7)
+            x0 = np.random.random((n, 1))
+            u = qi.SMCUpdater(qi.SimplePrecessionModel(), n, fixed_prior(qi, x0), resample_thresh=0.0)
+            ref = orc.OracleSMC(orc.precession_model(), n, lambda m_: x0.copy(), resample_thresh=0.0)
+            for k in range(12):
+                u.update(int(outs[k]), ts[k:k + 1])
+                ref.update(int(outs[k]), {"t": ts[k:k + 1]})
+            np.testing.assert_allclose(u.est_mean(), ref.est_mean(), rtol=0, atol=1e-13)
+            np.testing.assert_allclose(u.n_ess, ref.n_ess, rtol=1e-10)
+            # (a likelihood differs by <= 1e-15 ABSOLUTE, cos's ulp: weights near a zero of cos^2 carry it as a large
+            #  relative difference of a negligible number)
+            np.testing.assert_allclose(np.asarray(u.particle_weights), ref.w, rtol=1e-11, atol=1e-14 / n)
