@@ -70,6 +70,13 @@ class SMCUpdater(ParticleDistribution):
         self._norm, self._sumsq = 1.0, None
 
         self._resample_count = 0
+        if comm is not None and comm.world_size > 1:
+            # every rank holds the same nominal share (the global count, the n_ess threshold and the rebalance target are
+            # formed from it on every rank without a collective): a mismatch would desynchronise the ranks' decisions
+            counts = np.asarray(comm.gather_rows(np.array([float(n_particles)])))[:, 0]
+            if not np.all(counts == counts[0]):
+                raise ValueError("sharded SMCUpdater: every rank must pass the same per-rank n_particles, got %s"
+                                 % counts.astype(np.int64).tolist())
         self._min_n_ess = n_particles if comm is None else n_particles * comm.world_size
         self.model = model
         self.prior = prior

@@ -517,6 +517,8 @@ def _check_sharded_c1_against_reference(comm, rank, world, tmpdir):
         def sample(self, n=1):
             assert n == bounds[rank + 1] - bounds[rank]
             return x0[bounds[rank]:bounds[rank + 1]].copy()
+    with pytest.raises(ValueError, match="same per-rank n_particles"):          # (on every rank: the counts are gathered)
+        qi.SMCUpdater(qi.SimplePrecessionModel(), 100 + rank, qi.UniformDistribution([0, 1]), comm=comm)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         upd = qi.SMCUpdater(qi.SimplePrecessionModel(), int(bounds[rank + 1] - bounds[rank]), Slice(), device_rng=True,
