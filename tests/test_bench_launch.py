@@ -147,6 +147,10 @@ def test_driver_command_headline_is_steady_state():
     assert h200["steps"] == 200 and 60 <= h200["resamples"] <= 80 and abs(h200["posterior_mean"] - 0.3) < 1e-3
     assert h200["value"] == pytest.approx(1e7 * 200 / (h200["ms_per_step"] * 1e-3 * 200), rel=1e-9)
     assert 0.5 * line["value"] < h200["value"] < 1.2 * line["value"]
+    # the same two figures on the reference's own outcome sequence (G1's data): the filter tracks to the end
+    ref_seq = h200["reference_outcome_sequence"]
+    assert 30 <= ref_seq["steps_200"]["resamples"] <= 50 and abs(ref_seq["steps_200"]["posterior_mean"] - 0.3) < 1e-6
+    assert ref_seq["steps_20"]["resamples"] >= 4 and ref_seq["steps_200"]["value"] > 0.5 * line["value"]
 
 
 @pytest.mark.gpu
