@@ -3094,3 +3094,66 @@ def test_device_rng_trajectory_statistics_vs_oracle(qi, golden):
             if seq == 0:                                                               # the alias, on both sides
                 assert np.median(np.abs(ref[:, 6])) > 2e-5 and np.median(np.abs(dev[:, 6])) > 2e-5
                 assert np.median(ref[:, 8]) == 70 == np.median(dev[:, 8])
+
+
+def test_device_rng_trajectory_statistics_c3_c4(qi):
+    """The same comparison for the models of configs 3 and 4 (60 data of bench.py's schedules, N = 2000, ten seeds of the
+    device-RNG path against ten of the restatement): resample counts, n_ess scale, posterior mean and spread agree in
+    distribution (`profiles/r6_d_trajectory_statistics_c3_c4.txt`)."""
+    K, N, S = 60, 2000, 10
+    ts = (9 / 8) ** np.arange(K)
+    rs = np.random.RandomState(0)
+    c3_out = [int(rs.binomial(25, np.sin(0.3 * t / 2) ** 2)) for t in ts]
+    rb_out = [int(rs.random_sample() >= 1 - (0.3 * 0.95 ** (1 + 5 * k) + 0.5)) for k in range(K)]
+
+    def rb_prior(n):
+        out = np.empty((0, 3))
+        while out.shape[0] < n:
+            c = np.random.random((n, 3)) * np.array([0.2, 1, 1]) + np.array([0.8, 0, 0])
+            out = np.concatenate([out, c[orc.valid_rb(c)]])
+        return out[:n]
+
+    def summary(u):
+        return [u.resample_count] + list(u.est_mean()) + list(np.sqrt(np.abs(np.diag(u.est_covariance_mtx()))))
+    bm = qi.BinomialModel(qi.SimplePrecessionModel())
+    rbm = qi.RandomizedBenchmarkingModel()
+
+    def ep3(k):
+        e = np.empty((1,), dtype=bm.expparams_dtype)
+        e['x'], e['n_meas'] = ts[k], 25
+        return e
+
+    def ep4(k):
+        e = np.empty((1,), dtype=rbm.expparams_dtype)
+        e['m'] = 1 + 5 * k
+        return e
+    cases = [
+        ("C3", orc.binomial_precession_model(), lambda m: np.random.random((m, 1)),
+         lambda k: {"t": ts[k:k + 1], "n_meas": np.array([25])}, c3_out,
+         bm, lambda: qi.UniformDistribution([0, 1]), ep3),
+        ("C4", orc.rb_model(), rb_prior, lambda k: {"m": np.array([1 + 5 * k])}, rb_out,
+         rbm, lambda: qi.PostselectedDistribution(qi.UniformDistribution([[0.8, 1], [0, 1], [0, 1]]), rbm), ep4),
+    ]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for name, omodel, oprior, oep, outs, model, prior, ep in cases:
+            ref, dev = [], []
+            for seed in range(S):
+                np.random.seed(seed)
+                o = orc.OracleSMC(omodel, N, oprior)
+                for k in range(K):
+                    o.update(outs[k], oep(k))
+                ref.append(summary(o))
+                np.random.seed(seed)
+                u = qi.SMCUpdater(model, N, prior(), device_rng=True, seed=seed)
+                for k in range(K):
+                    u.update(outs[k], ep(k))
+                dev.append(summary(u))
+            ref, dev = np.array(ref), np.array(dev)
+            d = (ref.shape[1] - 1) // 2
+            assert abs(np.median(dev[:, 0]) - np.median(ref[:, 0])) <= 1, name
+            assert ref[:, 0].min() - 2 <= dev[:, 0].min() and dev[:, 0].max() <= ref[:, 0].max() + 2, name
+            sd_r, sd_d = np.median(ref[:, 1 + d:], 0), np.median(dev[:, 1 + d:], 0)
+            assert np.all(np.abs(np.log(sd_d / sd_r)) < 0.25), (name, sd_d, sd_r)
+            # the seeds' posterior means scatter by a fraction of the posterior spread around a common value
+            assert np.all(np.abs(np.median(dev[:, 1:1 + d], 0) - np.median(ref[:, 1:1 + d], 0)) < 0.35 * sd_r), name
