@@ -552,6 +552,56 @@ def test_sharded_c1_against_reference(tmp_path, world):
     _run("_check_sharded_c1_against_reference", tmp_path, world=world)
 
 
+def _check_sharded_trajectory_statistics(comm, rank, world, tmpdir):
+    """The SHARDED perf-mode path (device Philox, the exact two-level multinomial, children kept with their ancestors)
+    against the G1-pinned restatement of the reference, statistically, at equal total N: config C1's first 120 data
+    (inside the conditioning horizon) with 1000 particles over the ranks, eight seeds each side -- resample counts and the
+    cloud's spread at k = 60 and 120 agree in distribution, every estimate inside its own posterior, every rank holding
+    the same global numbers."""
+    import warnings
+    import torch
+    import qinfer_amd as qi
+    import np_oracle as orc
+    torch.cuda.set_device(0)
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g1_precession_n1000.npz"))
+    ts, outs = g["ep_t"], g["outcomes"]
+    marks, S = (60, 120), 8
+    ref, dev = [], []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for seed in range(S):
+            np.random.seed(seed)
+            o = orc.OracleSMC(orc.precession_model(), 1000, lambda m: np.random.random((m, 1)))
+            u = qi.SMCUpdater(qi.SimplePrecessionModel(), 1000 // world, qi.UniformDistribution([0, 1]), device_rng=True,
+                              seed=100 + seed, comm=comm)
+            r_row, d_row = [], []
+            for k in range(marks[-1]):
+                o.update(int(outs[k]), {"t": ts[k:k + 1]})
+                u.update(int(outs[k]), ts[k:k + 1])
+                if k + 1 in marks:
+                    r_row += [o.est_mean()[0] - 0.3, float(np.sqrt(o.est_covariance_mtx()[0, 0])), o.resample_count]
+                    d_row += [u.est_mean()[0] - 0.3, float(np.sqrt(u.est_covariance_mtx()[0, 0])), u.resample_count]
+            assert u.n_particles_global == 1000
+            ref.append(r_row)
+            dev.append(d_row)
+    ref, dev = np.array(ref), np.array(dev)
+    rows = comm.gather_rows(torch.from_numpy(dev.ravel().copy()))
+    for r in range(1, world):
+        assert np.array_equal(rows[0], rows[r]), "ranks disagree on the global quantities"
+    for i, k in enumerate(marks):
+        e_d, sd_r, sd_d, rc_r, rc_d = dev[:, 3 * i], ref[:, 3 * i + 1], dev[:, 3 * i + 1], ref[:, 3 * i + 2], dev[:, 3 * i + 2]
+        assert abs(np.median(rc_d) - np.median(rc_r)) <= 2, (k, rc_d, rc_r)
+        assert rc_r.min() - 3 <= rc_d.min() and rc_d.max() <= rc_r.max() + 3, (k, rc_d, rc_r)
+        assert abs(np.log(np.median(sd_d) / np.median(sd_r))) < 0.15, (k, sd_d, sd_r)
+        assert np.all(np.abs(e_d) < 5 * sd_d), (k, e_d, sd_d)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_trajectory_statistics_vs_oracle(tmp_path, world):
+    _run("_check_sharded_trajectory_statistics", tmp_path, world=world)
+
+
 def _check_sharded_plugin_model(comm, rank, world, tmpdir):
     """Round 6: a model WITHOUT native kernels shards too (the reference's DirectViewParallelizedModel shards any model's
     likelihood, parallel.py:196-224).  Two ranks against ONE updater holding the union cloud: the updates agree to
