@@ -64,7 +64,9 @@ class LiuWestResampler(Resampler):
         self._postselect = postselect
         self._zero_cov_comp = zero_cov_comp
         self._kernel = kernel
-        self._device_rng = bool(device_rng)
+        # (maxiter < 1 -- "draw nothing": the reference leaves every new location at zero and warns, resamplers.py:322-381 --
+        #  has no device form, the samplers take at least one round: that degenerate setting runs the host-replay path)
+        self._device_rng = bool(device_rng) and int(maxiter) >= 1
         self._seed = int(seed)
         self._epoch = 0
         self._legacy_q1 = bool(legacy_mus_truncation)

@@ -3157,3 +3157,16 @@ def test_device_rng_trajectory_statistics_c3_c4(qi):
             assert np.all(np.abs(np.log(sd_d / sd_r)) < 0.25), (name, sd_d, sd_r)
             # the seeds' posterior means scatter by a fraction of the posterior spread around a common value
             assert np.all(np.abs(np.median(dev[:, 1:1 + d], 0) - np.median(ref[:, 1:1 + d], 0)) < 0.35 * sd_r), name
+
+
+def test_maxiter_zero_takes_the_host_path(qi):
+    """`LiuWestResampler(maxiter=0)` draws nothing: the reference hands back `np.empty` locations with a ResamplerWarning
+    (resamplers.py:307, 322-381).  The device samplers take at least one round (the C ABI rejects maxiter < 1), so that
+    degenerate setting runs the host-replay path also under device_rng=True -- same warning, no 'invalid argument'."""
+    r = qi.LiuWestResampler(maxiter=0, device_rng=True, seed=1)
+    assert not r._device_rng
+    np.random.seed(0)
+    upd = qi.SMCUpdater(qi.SimplePrecessionModel(), 5000, qi.UniformDistribution([0, 1]), resampler=r, device_rng=True, seed=1)
+    with pytest.warns(qi.ResamplerWarning, match="failed to find valid models for 5000 particles within 0 iterations"):
+        upd.resample()
+    assert upd.n_particles == 5000 and upd.n_ess == pytest.approx(5000)
