@@ -70,14 +70,11 @@ class SMCUpdater(ParticleDistribution):
         self._norm, self._sumsq = 1.0, None
 
         self._resample_count = 0
-        if comm is not None and comm.world_size > 1:
-            # every rank holds the same nominal share (the global count, the n_ess threshold and the rebalance target are
-            # formed from it on every rank without a collective): a mismatch would desynchronise the ranks' decisions
-            counts = np.asarray(comm.gather_rows(np.array([float(n_particles)])))[:, 0]
-            if not np.all(counts == counts[0]):
-                raise ValueError("sharded SMCUpdater: every rank must pass the same per-rank n_particles, got %s"
-                                 % counts.astype(np.int64).tolist())
-        self._min_n_ess = n_particles if comm is None else n_particles * comm.world_size
+        # sharded: a rank passes ITS share; the shares need not be equal (np.array_split's remainders, as the reference's
+        # DirectViewParallelizedModel splits a cloud: parallel.py:216-224) -- the ranks' counts are gathered once per
+        # explicit size (here and in reset(n)), their sum is the global count every rank works with
+        self._shard_counts = None
+        self._min_n_ess = n_particles                      # (sharded: the global count, once reset() below has gathered the shares)
         self.model = model
         self.prior = prior
         self._canonicalize = bool(canonicalize)
@@ -149,6 +146,8 @@ class SMCUpdater(ParticleDistribution):
         self._fused_canon = (fc(self._eng) if (fc is not None and self._native and self._canonicalize and not _NO_FUSED_CANON)
                              else None)
         self.reset(n_particles)
+        if comm is not None:
+            self._min_n_ess = self._n_global
 
     # ------------------------------------------------------------------ bookkeeping properties
     @property
@@ -186,6 +185,14 @@ class SMCUpdater(ParticleDistribution):
         return self.n_particles if self._comm is None else self._n_global
 
     # ------------------------------------------------------------------ sharding hooks
+    def _gather_shard_counts(self, n_local):
+        """Every rank's nominal share, rank-ordered (one small all-gather); cached until the next explicit size."""
+        rows = np.asarray(self._comm.gather_rows(np.array([float(n_local)])))[:, 0]
+        if not np.all((rows >= 1) & (rows == np.floor(rows))):
+            raise ValueError("sharded SMCUpdater: every rank needs at least one particle, got %s" % rows.tolist())
+        self._shard_counts = rows.astype(np.int64)
+        return self._shard_counts
+
     def _reduce_stats(self, st, extra=None):
         """Combine per-shard update sums across ranks (one all-gather per datum; see parallel.py)."""
         if self._comm is None:
@@ -235,10 +242,12 @@ class SMCUpdater(ParticleDistribution):
             # sharded: the nominal per-rank size, not the current (floating) one, so that every rank
             # agrees on the global count
             n_particles = self.n_particles if self._comm is None else self._n_local_nominal
+        elif self._comm is not None:
+            self._gather_shard_counts(n_particles)              # (a collective: every rank resets with its own size)
         self._n_local_nominal = n_particles
         eng = self._eng
         d = self.model.n_modelparams
-        n_total = n_particles if self._comm is None else n_particles * self._comm.world_size
+        n_total = n_particles if self._comm is None else int(self._shard_counts.sum())
         self._n_global = n_total
         if reset_weights:
             # uniform weights 1/N (smc.py:307), held implicitly: all-ones with normaliser N
@@ -246,7 +255,7 @@ class SMCUpdater(ParticleDistribution):
             self._w_alt = None
             self._norm = float(n_total)
             self._sumsq = float(n_particles) if self._comm is None else float(n_total)
-            self._shard_sums = None if self._comm is None else np.full(self._comm.world_size, float(n_particles))
+            self._shard_sums = None if self._comm is None else self._shard_counts.astype(np.float64)
         x_new = None
         if self._device_rng and hasattr(self.prior, "sample_device"):
             try:
