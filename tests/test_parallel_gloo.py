@@ -600,6 +600,64 @@ def test_sharded_trajectory_statistics_vs_oracle(tmp_path, world):
     _run("_check_sharded_trajectory_statistics", tmp_path, world=world)
 
 
+def _check_sharded_unequal_shares(comm, rank, world, tmpdir):
+    """Shares that differ a lot (70 % / 30 % at two ranks), in perf mode: the global count is the sum of the shares and
+    survives resamples (children stay with their ancestors, sizes float) and rebalances; every rank holds the same global
+    numbers; `reset(n)` with new shares regathers them, `reset()` returns to the nominal ones; the estimate lands where
+    one updater holding the union cloud puts it."""
+    import warnings
+    import torch
+    import qinfer_amd as qi
+    torch.cuda.set_device(0)
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g1_precession_n1000.npz"))
+    ts, outs = g["ep_t"], g["outcomes"]
+    shares = [int(v) for v in np.diff(np.round(np.linspace(0, 1, world + 1) ** 0.5 * 20000).astype(int))]
+    assert sum(shares) == 20000 and shares[0] > 1.5 * shares[-1]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        u = qi.SMCUpdater(qi.SimplePrecessionModel(), shares[rank], qi.UniformDistribution([0, 1]), device_rng=True, seed=3,
+                          comm=comm)
+        whole = qi.SMCUpdater(qi.SimplePrecessionModel(), 20000, qi.UniformDistribution([0, 1]), device_rng=True, seed=3)
+        assert u.n_particles_global == 20000 and u.n_particles == shares[rank] and u.min_n_ess == 20000
+
+        def run(upd, k0, k1):
+            for k in range(k0, k1):
+                upd.update(int(outs[k]), ts[k:k + 1])
+        run(u, 0, 60)
+        run(whole, 0, 60)
+        sizes = comm.gather_rows(np.array([float(u.n_particles)]))[:, 0]
+        assert sizes.sum() == 20000 and u.resample_count >= 8
+        sd = np.sqrt(whole.est_covariance_mtx()[0, 0])
+        assert abs(u.est_mean()[0] - whole.est_mean()[0]) < 0.2 * sd and abs(u.resample_count - whole.resample_count) <= 2
+        np.testing.assert_allclose(np.sqrt(u.est_covariance_mtx()[0, 0]), sd, rtol=0.1)
+        rec = np.concatenate([[u.resample_count, u.n_ess], np.ravel(u.normalization_record), u.est_mean()])
+        rows = comm.gather_rows(torch.from_numpy(rec))
+        for r in range(1, world):
+            assert np.array_equal(rows[0], rows[r]), "ranks disagree on the global quantities"
+        # new shares (reversed), regathered by reset(n); then back to them by reset()
+        u.reset(shares[world - 1 - rank])
+        assert u.n_particles == shares[world - 1 - rank] and u.n_particles_global == 20000
+        run(u, 0, 40)
+        assert comm.gather_rows(np.array([float(u.n_particles)]))[:, 0].sum() == 20000
+        u.reset()
+        assert u.n_particles == shares[world - 1 - rank] and u.n_ess == pytest.approx(20000)
+        # always-rebalance: finished rows travel, the shares come back to balanced sizes
+        from qinfer_amd.parallel import ParticleShardGroup
+        grp = ParticleShardGroup(seed=77, rebalance_tol=0.0)
+        v = qi.SMCUpdater(qi.SimplePrecessionModel(), shares[rank], qi.UniformDistribution([0, 1]), device_rng=True, seed=5,
+                          comm=grp)
+        run(v, 0, 30)
+        sizes = grp.gather_rows(np.array([float(v.n_particles)]))[:, 0]
+        assert sizes.sum() == 20000 and grp.n_rebalances >= 1 and sizes.max() - sizes.min() <= 1, sizes
+        assert abs(v.est_mean()[0] - 0.3) < 0.05
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_unequal_shares(tmp_path, world):
+    _run("_check_sharded_unequal_shares", tmp_path, world=world)
+
+
 def _check_sharded_plugin_model(comm, rank, world, tmpdir):
     """Round 6: a model WITHOUT native kernels shards too (the reference's DirectViewParallelizedModel shards any model's
     likelihood, parallel.py:196-224).  Two ranks against ONE updater holding the union cloud: the updates agree to
