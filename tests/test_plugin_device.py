@@ -264,3 +264,90 @@ def test_likelihood_hip_contract_paths(qi):
         with pytest.raises(RuntimeError) as ei:
             qi.SMCUpdater(Broken(), 100, prior(qi))
         assert "nope" in str(ei.value)
+
+
+def test_three_outcome_two_field_user_model_three_ways(qi):
+    """A user model that is NOT two-outcome and whose experiment record has two fields -- a tilted three-sided die --
+    through the plugin surface three ways (NumPy methods, torch hooks, HIP source compiled into the update kernel):
+    twelve updates without resampling equal plain NumPy Bayes on the initial cloud (weights to 1e-9); the design
+    quantities (`hypothetical_update` over three outcomes, `bayes_risk`, `expected_information_gain`) agree across
+    the three forms to 1e-9; with resampling and a `batch_update` on top every particle stays valid."""
+    class Die(qi.FiniteOutcomeModel):
+        """Pr(k | p0, p1; s, b): a three-sided die whose faces are tilted by the experiment: q_k ~ p_k^(s) * (1 + b [k == 0])."""
+        n_modelparams = 2
+        expparams_dtype = [('s', 'float'), ('b', 'float')]
+        is_n_outcomes_constant = True
+        def n_outcomes(self, expparams): return 3
+        def are_models_valid(self, mp): return np.all(mp >= 0, axis=1) & (mp.sum(1) <= 1)
+        @staticmethod
+        def probs(mp, ep):
+            p = np.stack([mp[:, 0], mp[:, 1], 1 - mp[:, 0] - mp[:, 1]])              # (3, N)
+            q = np.clip(p, 0, 1)[:, :, None] ** ep['s'][None, None, :]               # (3, N, E)
+            q[0] = q[0] * (1 + ep['b'][None, :])
+            return q / q.sum(0, keepdims=True)
+        def likelihood(self, outcomes, mp, ep):
+            super().likelihood(outcomes, mp, ep)
+            q = self.probs(mp, ep)
+            return np.stack([q[int(o)] for o in np.ravel(outcomes)])
+    class TorchDie(Die):
+        def likelihood_device(self, outcomes, x, ep):
+            import torch
+            self.count_likelihood_calls(len(outcomes), x.shape[1], ep.shape[0])
+            s = torch.as_tensor(np.asarray(ep['s'], float), device=x.device)[:, None]
+            b = torch.as_tensor(np.asarray(ep['b'], float), device=x.device)[:, None]
+            p = torch.stack([x[0], x[1], 1 - x[0] - x[1]]).clamp(0, 1)                # (3, N)
+            q = p[:, None, :] ** s[None]                                             # (3, E, N)
+            q = torch.cat([(q[0] * (1 + b))[None], q[1:]])
+            q = q / q.sum(0, keepdim=True)
+            return torch.stack([q[int(o)] for o in np.ravel(outcomes)])
+        def are_models_valid_device(self, x): return (x >= 0).all(0) & (x.sum(0) <= 1)
+    class HipDie(Die):
+        likelihood_hip = r"""
+        __device__ double likelihood(const double *x, const double *ep, long long outcome) {
+            const double s = ep[0], b = ep[1];
+            double p[3] = {x[0], x[1], 1 - x[0] - x[1]};
+            double q[3], tot = 0;
+            for (int k = 0; k < 3; ++k) { double c = fmin(fmax(p[k], 0.0), 1.0); q[k] = pow(c, s); }
+            q[0] *= 1 + b;
+            tot = q[0] + q[1] + q[2];
+            return q[outcome] / tot;
+        }
+        #define QSMC_USER_HAS_VALID 1
+        __device__ bool valid(const double *x) { return x[0] >= 0 && x[1] >= 0 && x[0] + x[1] <= 1; }
+        """
+    rs = np.random.RandomState(1)
+    x0 = rs.dirichlet([1, 1, 1], 20000)[:, :2]
+
+    class Fixed(qi.Distribution):
+        n_rvs = 2
+
+        def sample(self, n=1):
+            return x0[:n].copy()
+    eps = np.zeros(12, dtype=Die.expparams_dtype)
+    eps['s'], eps['b'] = rs.uniform(0.5, 2.0, 12), rs.uniform(0, 1, 12)
+    outs = rs.randint(0, 3, 12)
+    w = np.ones(20000) / 20000
+    for k in range(12):
+        w = w * Die.probs(x0, eps[k:k + 1])[outs[k], :, 0]
+        w /= w.sum()
+    res = []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for cls, form in ((Die, "plugin"), (TorchDie, "plugin"), (HipDie, "jit")):
+            u = qi.SMCUpdater(cls(), 20000, Fixed(), resample_thresh=0.0, device_rng=True, seed=1)
+            assert not u._native and (u._uk is not None) == (form == "jit")
+            for k in range(12):
+                u.update(int(outs[k]), eps[k:k + 1])
+            np.testing.assert_allclose(u.est_mean(), w @ x0, rtol=1e-10)
+            np.testing.assert_allclose(np.asarray(u.particle_weights), w, rtol=1e-9, atol=1e-300)
+            hw, norm = u.hypothetical_update(np.arange(3), eps[:2], return_normalization=True)
+            assert hw.shape == (3, 2, 20000) and abs(norm.sum(0) - 1).max() < 1e-12
+            res.append((np.ravel(u.bayes_risk(eps[:3])), np.ravel(u.expected_information_gain(eps[:3]))))
+            v = qi.SMCUpdater(cls(), 20000, Fixed(), device_rng=True, seed=1)
+            for k in range(12):
+                v.update(int(outs[k]), eps[k:k + 1])
+            v.batch_update(outs, eps, resample_interval=4)
+            assert v.resample_count >= 1 and Die().are_models_valid(np.asarray(v.particle_locations)).all()
+    for br, eig in res[1:]:
+        np.testing.assert_allclose(br, res[0][0], rtol=1e-9)
+        np.testing.assert_allclose(eig, res[0][1], rtol=1e-9)
