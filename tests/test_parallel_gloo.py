@@ -754,8 +754,10 @@ def _check_sharded_resample_vs_twin(comm, rank, world, tmpdir):
     import philox as ph
     import parity_tols as tol
     torch.cuda.set_device(0)
-    n_local = 40000
-    for case in ("rb", "tomo", "tomo3q"):       # (tomo3q, round 6: d = 64 on the wide kernels, csrc/kernels/wide.hpp)
+    # (eight processes share the test box's one GPU and its host cores, and every rank builds the union cloud and its twin:
+    #  at eight ranks half the shard size, and the three-qubit case left to the two- and four-rank runs)
+    n_local = 40000 if world <= 4 else 20000
+    for case in (("rb", "tomo", "tomo3q") if world <= 4 else ("rb", "tomo")):   # (tomo3q, round 6: d = 64, csrc/kernels/wide.hpp)
         rs = np.random.RandomState(17)
         if case == "rb":
             model, valid = qi.RandomizedBenchmarkingModel(), orc.valid_rb
@@ -851,7 +853,7 @@ def _check_sharded_resample_statistics(comm, rank, world, tmpdir):
     dev, ref = [], []
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        for s_ in STAT_SEEDS:
+        for s_ in (STAT_SEEDS if world <= 4 else STAT_SEEDS[:12]):   # (eight ranks: every one restates the union cloud's resample)
             upd = qi.SMCUpdater(model, n_local, Slice(), device_rng=True, seed=s_, comm=comm, resample_thresh=0.0)
             for o, ep in zip(outs, eps):
                 upd.update(o, ep)
@@ -865,8 +867,9 @@ def _check_sharded_resample_statistics(comm, rank, world, tmpdir):
             union = np.concatenate([rows[r].reshape(-1, 3)[:sizes[r]] for r in range(world)])
             assert union.shape[0] == world * n_local and np.all(orc.valid_rb(union))
             dev.append(union)
-            np.random.seed(1000 + s_)
-            ref.append(orc.liu_west(w_all, x_all, orc.valid_rb, orc.LegacyRNG(), a=0.98)[0])
+            if rank == 0:                                  # (the reference side is needed where the checks run, once)
+                np.random.seed(1000 + s_)
+                ref.append(orc.liu_west(w_all, x_all, orc.valid_rb, orc.LegacyRNG(), a=0.98)[0])
     if rank == 0:
         _two_sample_checks(np.stack(dev), np.stack(ref), "sharded x%d" % world)
 
