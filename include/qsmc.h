@@ -319,7 +319,8 @@ int qsmc_update_multi(qsmc_handle_t h, const qsmc_model_t *model,
  *   out_host[o][1]         = sum w~ L_o log L_o  (0 log 0 := 0)        N KLD = [1] - [0] log [0]
  *   out_host[o][2 + m]     = sum w~ L_o (x_m - c_m)           (d <= 4 only)
  *   out_host[o][2 + d + m] = sum w~ L_o (x_m - c_m)^2         N var = sum_m Q_m ([2+d+m] - [2+m]^2 / [0])
- * Row length is 2 + 2 d for d <= 4, else 2.  Synchronises. */
+ * Row length is 2 + 2 d for d <= 4, else 2; a tomography model's rows have 2 columns whatever its d (its kernels are built
+ * for the maximal dimension: a one-qubit model, d = 4, included).  Synchronises. */
 int qsmc_hypothetical_sums(qsmc_handle_t h, const qsmc_model_t *model,
                            const double *x, int64_t ldx, int64_t n, const double *w, double norm,
                            const qsmc_expparam_t *exp, const int64_t *outcomes, int32_t n_o,

@@ -1434,7 +1434,9 @@ int qsmc_hypothetical_sums_begin(qsmc_handle_t h, const qsmc_model_t *model, con
         if (!h->hypq) return QSMC_ERR_ALLOC;
     }
     hipStream_t s = (hipStream_t)stream;
-    const int per = 2 + 2 * (model->d <= 4 ? model->d : 0);
+    // a row: [N, sum w L ln L] and, where the kernels carry them (Model<KIND>::D <= 4 -- a compile-time dimension: tomography's
+    // is its maximum, so a ONE-qubit tomography model, d = 4, has two columns like every other tomography model), the moments
+    const int per = 2 + 2 * ((model->kind != QSMC_MODEL_TOMOGRAPHY && model->d <= 4) ? model->d : 0);
     Chain2Queue &q = *h->hypq;
     size_t done = 0;
     for (int e = 0; e < n_e && rc == QSMC_OK; ++e) {

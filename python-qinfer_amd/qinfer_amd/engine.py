@@ -227,6 +227,12 @@ class Engine:
 
     HYP_LOG, HYP_MOMENTS = 1, 2                     # qsmc.h: QSMC_HYP_LOG / QSMC_HYP_MOMENTS
 
+    @staticmethod
+    def hyp_row_width(desc, d):
+        """Columns of a design row (include/qsmc.h: qsmc_hypothetical_sums_multi): [N, sum w L ln L] and, for the models whose
+        kernels carry them (d <= 4, not tomography: its kernels are built for the maximal dimension), 2 d moment sums."""
+        return 2 + 2 * d if (d <= 4 and desc.kind != _native.MODEL_TOMOGRAPHY) else 2
+
     def hypothetical_sums(self, desc, x, w, norm, exp, outcomes, shift, what=3):
         """(n_o, 2 + 2d) array [N, sum wL log L, sum wL (x-c), sum wL (x-c)^2] (d <= 4; else (n_o, 2)) of one experiment.
         `what`: the columns the caller reads (HYP_LOG: [1], HYP_MOMENTS: [2:]); binomial experiments leave the others NaN."""
@@ -236,7 +242,7 @@ class Engine:
         """The same for several experiments in one call (qsmc_hypothetical_sums_multi: binomial experiments' passes queue
         back to back, one wait): `exps` ExpParam records, `outcomes` one outcome list per experiment; a list of arrays."""
         d = x.shape[0]
-        per = 2 + 2 * d if d <= 4 else 2
+        per = self.hyp_row_width(desc, d)
         n_e = len(exps)
         counts = [len(o) for o in outcomes]
         total = sum(counts)
@@ -262,7 +268,7 @@ class Engine:
         begun one after the other (a caller that prepares its experiments as it goes); nothing else may be asked of the
         engine in between."""
         d = x.shape[0]
-        per = 2 + 2 * d if d <= 4 else 2
+        per = self.hyp_row_width(desc, d)
         n_e = len(exps)
         counts = [len(o) for o in outcomes]
         out = np.empty((sum(counts), per), dtype=np.float64)
@@ -505,6 +511,14 @@ class Engine:
         if self._design_jobs:
             self._no_design_in_flight("moments")
         d, n = x.shape
+        if d > _native.QSMC_MAX_D_WIDE:
+            # beyond the library's kernels (a plugin model with more than 64 parameters, e.g. four-qubit tomography): the
+            # same sums as torch products on the device -- (d x N)(N x d) on the matrix cores through rocBLAS
+            t = self.torch
+            wn = (t.ones(n, dtype=t.float64, device=x.device) if w is None else w) / float(norm)
+            s0 = float(wn.sum().item())
+            xw = x * wn
+            return s0, xw.sum(dim=1).cpu().numpy(), (xw @ x.T).cpu().numpy()
         k = 1 + d + d * (d + 1) // 2
         out = np.empty(k, dtype=np.float64)
         self._chk(self.lib.qsmc_moments(self.h, self._p(x), x.stride(0), n, d, self._p(w), float(norm),
@@ -546,6 +560,8 @@ class Engine:
 
     def lw_centres(self, x_in, js, a, mean):
         d = x_in.shape[0]
+        if d > _native.QSMC_MAX_D_WIDE:        # (beyond the kernels: a plugin model with more than 64 parameters -- torch, on the device)
+            return float(a) * x_in[:, js] + (1.0 - float(a)) * self.to_device(np.asarray(mean, dtype=np.float64))[:, None]
         mus = self.empty(d, js.shape[0])
         mean = np.ascontiguousarray(mean, dtype=np.float64)
         self._chk(self.lib.qsmc_lw_centres(self.h, self._p(x_in), x_in.stride(0), d, self._p(js),
@@ -554,6 +570,16 @@ class Engine:
         return mus
 
     def lw_perturb(self, desc, postselect, mus, idxs, k, centre_by_idx, S, z, x_out):
+        if mus.shape[0] > _native.QSMC_MAX_D_WIDE:
+            # the same round in torch (resamplers.py:325-338): x_i = mu_i + S z_i for the k particles still to be drawn; the
+            # model's own validity test decides (the caller's: no kernel knows a model of this size)
+            kick = self.to_device(np.asarray(S, dtype=np.float64)) @ z[:, :k]
+            centre = mus[:, :k] if (idxs is None or not centre_by_idx) else mus[:, idxs]
+            if idxs is None:
+                x_out[:, :k] = centre + kick
+            else:
+                x_out[:, idxs] = centre + kick
+            return self.torch.ones(k, dtype=self.torch.uint8, device=x_out.device)
         valid = self.empty(k, dtype=self.torch.uint8)
         S = np.ascontiguousarray(S, dtype=np.float64)
         self._chk(self.lib.qsmc_lw_perturb(

@@ -933,7 +933,7 @@ class SMCUpdater(ParticleDistribution):
         normalisation and the (mean-shifted) first and second moments; nothing of size
         n_outcomes x N is materialised.  Other models go through `hypothetical_update`."""
         expparams = np.atleast_1d(expparams).reshape(-1)
-        if self._native and self._x.shape[0] <= 4:
+        if self._native and self._eng.hyp_row_width(self._desc, self._x.shape[0]) > 2:      # (the kernels carry the moments)
             d = self._x.shape[0]
             Q = np.asarray(self.model.Q, dtype=np.float64)
             risk = np.empty(expparams.shape[0])

@@ -218,7 +218,52 @@ class TomographyModel(NativeModelMixin, FiniteOutcomeModel):
 
     def likelihood(self, outcomes, modelparams, expparams):
         super().likelihood(outcomes, modelparams, expparams)
+        if not self._native:
+            # d > 64 (four qubits and up): no kernels of the library's own.  Host arrays in, host arrays out -- what
+            # `simulate_experiment` and other host callers ask for; an updater keeps its cloud on the GPU through the
+            # torch hooks below (`likelihood_device`, `canonicalize_device`: the plugin surface's device form)
+            meas = np.asarray(np.atleast_1d(expparams)['meas'], dtype=np.float64).reshape(-1, self.n_modelparams)
+            pr1 = np.clip(np.asarray(modelparams, dtype=np.float64) @ meas.T, 0, 1)
+            return FiniteOutcomeModel.pr0_to_likelihood_array(outcomes, 1 - pr1)
         return self._native_likelihood(outcomes, modelparams, expparams)
+
+    def __getattr__(self, name):
+        # the device hooks exist only for models WITHOUT native kernels (an updater asks with getattr(model, hook, None));
+        # a native model must not grow them: its kernels are the path
+        if name in ("likelihood_device", "canonicalize_device") and not self.__dict__.get("_native", True):
+            return getattr(self, "_torch_" + name)
+        raise AttributeError(name)
+
+    def _torch_likelihood_device(self, outcomes, x_dev, expparams):
+        """(n_o, n_e, N) device tensor: Pr(outcome | x) = clip(<<meas | x>>, 0, 1) or one minus it (tomography/models.py:211-226)
+        by a torch product on the (d, N) cloud."""
+        import torch
+        self.count_likelihood_calls(len(np.ravel(outcomes)), x_dev.shape[1], np.atleast_1d(expparams).shape[0])
+        meas = torch.as_tensor(np.asarray(np.atleast_1d(expparams)['meas'], dtype=np.float64).reshape(-1, self.n_modelparams),
+                               device=x_dev.device)
+        pr1 = (meas @ x_dev).clamp_(0, 1)                                   # (n_e, N)
+        return torch.stack([pr1 if int(o) == 1 else 1 - pr1 for o in np.ravel(outcomes)])
+
+    def _torch_canonicalize_device(self, x_dev):
+        """tomography/models.py:149-209 on the device: rho of every particle, batched Hermitian eigendecomposition, negative
+        eigenvalues clamped, re-expanded, trace renormalised -- in blocks (a block of 4096 sixteen-by-sixteen matrices)."""
+        import torch
+        d, n = x_dev.shape
+        flat = torch.as_tensor(np.ascontiguousarray(self._basis.flat()), device=x_dev.device)        # (d, dim^2) complex
+        out = x_dev.clone()
+        for i0 in range(0, n, 4096):
+            xb = x_dev[:, i0:i0 + 4096].T.to(torch.complex128)                                       # (m, d)
+            rho = (xb @ flat).reshape(-1, self._dim, self._dim)
+            rho = 0.5 * (rho + rho.conj().transpose(1, 2))
+            lam, v = torch.linalg.eigh(rho)
+            fixed = (v * lam.clamp(min=0).to(v.dtype)[:, None, :]) @ v.conj().transpose(1, 2)
+            xb_new = (fixed.reshape(fixed.shape[0], -1) @ flat.conj().T).real                        # (m, d)
+            neg = (lam < 0).any(dim=1)
+            blk = out[:, i0:i0 + 4096]
+            blk[:, neg] = xb_new[neg].T
+        if not self._allow_subnormalized:
+            out = out / (out[0:1] * np.sqrt(self._dim))
+        return out
 
     def canonicalize(self, modelparams):
         """Clamp negative eigenvalues of rho(x), re-expand, renormalise the trace (tomography/models.py:149-209)."""

@@ -438,3 +438,101 @@ def test_ginibre_prior_device_draw(qi):
         assert np.all(np.abs(xa.mean(0) - xh.mean(0)) < 5 * se)
         v_a, v_h = xa[:, 1:].var(0), xh[:, 1:].var(0)
         assert np.all(np.abs(v_a / v_h - 1) < 0.08), (v_a / v_h)
+
+
+@pytest.mark.parametrize("make_basis", [lambda q: q.tomography.pauli_basis(1), lambda q: q.tomography.gell_mann_basis(3),
+                                        lambda q: q.tomography.pauli_basis(2), lambda q: q.tomography.gell_mann_basis(6),
+                                        lambda q: q.tomography.pauli_basis(3)],
+                         ids=["pauli-1q", "gell-mann-3", "pauli-2q", "gell-mann-6", "pauli-3q"])
+def test_tomography_design_quantities_every_dim(qi, make_basis):
+    """`hypothetical_update`, `bayes_risk` and `expected_information_gain` of a tomography model against their definitions
+    (smc.py:324-386, 553-663) evaluated in NumPy on the cloud's host snapshot, dense and sparse measurement vectors, for
+    dim 2 ... 8.  (A ONE-qubit model, d = 4, used to read its design rows with the moment layout of the d <= 4 kernels --
+    tomography's kernels carry no moments: rows of two columns; bayes_risk came back negative / -inf.)"""
+    basis = make_basis(qi)
+    m = qi.TomographyModel(basis)
+    rs = np.random.RandomState(3)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        np.random.seed(1)
+        u = qi.SMCUpdater(m, 3000, qi.GinibreDistribution(basis), device_rng=True, seed=2)
+        eps = np.zeros(5, dtype=m.expparams_dtype)
+        for i in range(3):
+            v = rs.randn(basis.dim) + 1j * rs.randn(basis.dim)
+            v /= np.linalg.norm(v)
+            eps['meas'][i] = np.real(np.einsum('aij,ij->a', basis.data.conj(), np.outer(v, v.conj())))
+        for i in range(3, 5):
+            eps['meas'][i, 0] = eps['meas'][i, i - 2] = np.sqrt(basis.dim) / 2
+        for k in range(5):
+            u.update(int(rs.randint(2)), eps[k:k + 1])
+        x, w = np.asarray(u.particle_locations), np.asarray(u.particle_weights)
+        pr1 = np.clip(x @ eps['meas'].T, 0, 1)
+        L = np.stack([1 - pr1, pr1]).transpose(0, 2, 1)                       # (2, n_e, N)
+        norm_ref = (L * w).sum(-1, keepdims=True)
+        hw, norm = u.hypothetical_update(np.array([0, 1]), eps, return_normalization=True)
+        np.testing.assert_allclose(norm, norm_ref, rtol=1e-10)
+        np.testing.assert_allclose(hw, L * w / norm_ref, rtol=1e-8, atol=1e-300)
+        risk_ref, eig_ref = [], []
+        for e in range(5):
+            r = g = 0.0
+            for o in range(2):
+                hwe = L[o, e] * w / norm_ref[o, e, 0]
+                mu = hwe @ x
+                r += norm_ref[o, e, 0] * float((m.Q * (hwe @ (x - mu) ** 2)).sum())
+                nz = hwe > 0
+                g += norm_ref[o, e, 0] * float((hwe[nz] * np.log(hwe[nz] / w[nz])).sum())
+            risk_ref.append(r)
+            eig_ref.append(g)
+        np.testing.assert_allclose(np.ravel(u.bayes_risk(eps)), risk_ref, rtol=1e-7)
+        np.testing.assert_allclose(np.ravel(u.expected_information_gain(eps)), eig_ref, rtol=1e-6, atol=1e-12)
+
+
+@pytest.mark.parametrize("which", ["gell-mann-9", "pauli-4q"])
+def test_tomography_beyond_the_kernels_through_device_hooks(qi, which):
+    """d > 64 (dim 9: d = 81; FOUR qubits: d = 256) has no kernels of the library's own: the model then offers the plugin
+    surface's device hooks (`likelihood_device`, `canonicalize_device`: torch on the (d, N) cloud) and the engine forms
+    moments, centres and kicks of that size by torch products -- the cloud never leaves the GPU.  Against the restatement
+    of the reference on the same draws: 30 updates (norms, mean to rounding), a resample with canonicalize (locations to
+    1e-8: two eigensolvers), physical states, further updates, a window, the design quantities."""
+    basis = qi.tomography.gell_mann_basis(9) if which == "gell-mann-9" else qi.tomography.pauli_basis(4)
+    m = qi.TomographyModel(basis)
+    d, n = basis.dim ** 2, 250
+    assert not m._native and m.likelihood_device is not None and m.canonicalize_device is not None
+    assert getattr(qi.TomographyModel(qi.tomography.pauli_basis(3)), "likelihood_device", None) is None     # (native: its kernels)
+    rs = np.random.RandomState(3)
+    np.random.seed(1)
+    true = qi.GinibreDistribution(basis).sample(1)[0]
+    eps, outs = [], []
+    for k in range(30):
+        ep = np.zeros(1, dtype=m.expparams_dtype)
+        ep['meas'][0, 0] = ep['meas'][0, 1 + rs.randint(d - 1)] = np.sqrt(basis.dim) / 2
+        eps.append(ep)
+        outs.append(int(rs.random_sample() < np.clip(ep['meas'][0] @ true, 0, 1)))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        np.random.seed(2)
+        u = qi.SMCUpdater(m, n, qi.GinibreDistribution(basis))
+        x0 = np.asarray(u.particle_locations).copy()
+        o = orc.OracleSMC(orc.tomography_model(basis.data), n, lambda mm: x0.copy())
+        for k in range(30):
+            u.update(outs[k], eps[k], check_for_resample=False)
+            o.update(outs[k], {"meas": eps[k]['meas']}, check_for_resample=False)
+        np.testing.assert_allclose(np.ravel(u.normalization_record), np.ravel(o.normalization_record), rtol=1e-12)
+        np.testing.assert_allclose(u.est_mean(), o.est_mean(), rtol=0, atol=1e-13)
+        assert u.resample_count == o.resample_count
+        np.random.seed(11)
+        u.resample()
+        np.random.seed(11)
+        o.resample()
+        xn = np.asarray(u.particle_locations)
+        np.testing.assert_allclose(xn, o.x, rtol=0, atol=1e-8)
+        rho = np.tensordot(xn, basis.data, 1)
+        np.testing.assert_allclose(np.trace(rho, axis1=1, axis2=2).real, 1.0, atol=1e-12)
+        assert np.linalg.eigvalsh(rho).min() > -1e-12
+        for k in range(5):
+            u.update(outs[k], eps[k])
+            o.update(outs[k], {"meas": eps[k]['meas']})
+        np.testing.assert_allclose(u.est_mean(), o.est_mean(), rtol=0, atol=1e-9)
+        u.batch_update(np.array(outs[:6]), np.concatenate(eps[:6]), resample_interval=3)
+        assert np.all(np.isfinite(u.bayes_risk(np.concatenate(eps[:2])))) and np.all(
+            np.asarray(u.expected_information_gain(np.concatenate(eps[:2]))) >= -1e-12)
