@@ -3170,3 +3170,66 @@ def test_maxiter_zero_takes_the_host_path(qi):
     with pytest.warns(qi.ResamplerWarning, match="failed to find valid models for 5000 particles within 0 iterations"):
         upd.resample()
     assert upd.n_particles == 5000 and upd.n_ess == pytest.approx(5000)
+
+
+def test_design_quantities_every_native_family(qi):
+    """`bayes_risk` and `expected_information_gain` of every model family with native kernels against their definitions
+    (smc.py:553-663) evaluated with the model's own `likelihood` on the cloud's host snapshot: precession, UnknownT2, RB,
+    interleaved RB (d = 4: the widest moment rows), Binomial over interleaved RB, an MLE power, binomial experiments of 1,
+    2, 40 and 200 shots (the one-pass walk and its splits)."""
+    def rec(model_, **kw):
+        n = len(next(iter(kw.values())))
+        ep = np.zeros(n, dtype=model_.expparams_dtype)
+        for k, v in kw.items():
+            ep[k] = v
+        return ep
+
+    def check(tag, model, prior, eps, warm):
+        np.random.seed(1)
+        u = qi.SMCUpdater(model, 4000, prior, device_rng=True, seed=2)
+        assert u._native, tag
+        for o, ep in warm:
+            u.update(o, ep)
+        x, w = np.asarray(u.particle_locations), np.asarray(u.particle_weights)
+        risk_ref, eig_ref = [], []
+        for e in range(len(eps)):
+            os_ = model.domain(eps[e:e + 1])[0].values
+            L = model.likelihood(os_, x, eps[e:e + 1])[:, :, 0]
+            r = g = 0.0
+            for o in range(len(os_)):
+                n_o = float((L[o] * w).sum())
+                if n_o <= 0:
+                    continue
+                hw = L[o] * w / n_o
+                mu = hw @ x
+                r += n_o * float((model.Q * (hw @ (x - mu) ** 2)).sum())
+                nz = hw > 0
+                g += n_o * float((hw[nz] * np.log(hw[nz] / w[nz])).sum())
+            risk_ref.append(r)
+            eig_ref.append(g)
+        np.testing.assert_allclose(np.ravel(u.bayes_risk(eps)), risk_ref, rtol=1e-6, err_msg=tag)
+        np.testing.assert_allclose(np.ravel(u.expected_information_gain(eps)), eig_ref, rtol=1e-6, atol=1e-12, err_msg=tag)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = qi.SimplePrecessionModel()
+        check("precession", m, qi.UniformDistribution([0, 1]), np.array([1.0, 3.0, 9.0]),
+              [(0, np.array([1.5])), (1, np.array([2.5]))])
+        m = qi.UnknownT2Model()
+        check("unknown T2", m, qi.UniformDistribution([[0, 1], [0, 0.2]]), rec(m, t=[1.0, 3.0, 9.0]),
+              [(0, rec(m, t=[1.5])), (1, rec(m, t=[2.5]))])
+        m = qi.RandomizedBenchmarkingModel()
+        pr = qi.PostselectedDistribution(qi.UniformDistribution([[0.8, 1], [0, 1], [0, 1]]), m)
+        check("RB", m, pr, rec(m, m=[1, 10, 100]), [(0, rec(m, m=[5])), (1, rec(m, m=[20]))])
+        m = qi.RandomizedBenchmarkingModel(interleaved=True)
+        pr = qi.PostselectedDistribution(qi.UniformDistribution([[0.8, 1], [0.8, 1], [0, 1], [0, 1]]), m)
+        check("RB interleaved", m, pr, rec(m, m=[1, 10, 100], reference=[True, False, True]),
+              [(0, rec(m, m=[5], reference=[True])), (1, rec(m, m=[20], reference=[False]))])
+        m = qi.BinomialModel(qi.RandomizedBenchmarkingModel(interleaved=True))
+        pr = qi.PostselectedDistribution(qi.UniformDistribution([[0.8, 1], [0.8, 1], [0, 1], [0, 1]]), m)
+        check("Binomial(RB interleaved)", m, pr, rec(m, m=[1, 10, 100], reference=[True, False, True], n_meas=[10, 30, 5]),
+              [(3, rec(m, m=[5], reference=[True], n_meas=[10]))])
+        m = qi.MLEModel(qi.SimplePrecessionModel(), 2.0)
+        check("MLE(precession, 2)", m, qi.UniformDistribution([0, 1]), np.array([1.0, 3.0, 9.0]), [(0, np.array([1.5]))])
+        m = qi.BinomialModel(qi.SimplePrecessionModel())
+        check("Binomial(precession)", m, qi.UniformDistribution([0, 1]),
+              rec(m, x=[1.0, 2.0, 3.0, 4.0], n_meas=[1, 2, 40, 200]), [(3, rec(m, x=[1.5], n_meas=[10]))])
