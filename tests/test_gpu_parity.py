@@ -3233,3 +3233,30 @@ def test_design_quantities_every_native_family(qi):
         m = qi.BinomialModel(qi.SimplePrecessionModel())
         check("Binomial(precession)", m, qi.UniformDistribution([0, 1]),
               rec(m, x=[1.0, 2.0, 3.0, 4.0], n_meas=[1, 2, 40, 200]), [(3, rec(m, x=[1.5], n_meas=[10]))])
+
+
+def test_cloud_sizes_around_the_segment_limit(qi):
+    """The bucketed sampler takes up to 8192 x 4096 particles in one pass; beyond that a resample runs in segments (the
+    two-level multinomial inside one GPU).  One below, at, one above the limit and a ragged three-segment size: the count
+    is conserved, postselection holds, Liu-West keeps mean and variance, the run continues."""
+    limit = qi.LiuWestResampler._segment_limit
+    ts = (9 / 8) ** np.arange(40.0)
+    rs = np.random.RandomState(0)
+    outs = (rs.random_sample(40) >= np.cos(0.3 * ts / 2) ** 2).astype(int)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for n in (limit - 1, limit, limit + 1, 2 * limit + 4097):
+            u = qi.SMCUpdater(qi.SimplePrecessionModel(), n, qi.UniformDistribution([0, 1]), device_rng=True, seed=3)
+            for k in range(14):
+                u.update(int(outs[k]), ts[k:k + 1])
+            m1, c1 = u.est_mean()[0], u.est_covariance_mtx()[0, 0]
+            u.resample()
+            m2, c2 = u.est_mean()[0], u.est_covariance_mtx()[0, 0]
+            assert u.n_particles == n and u.n_ess == pytest.approx(n, rel=1e-12) and float(u._x.min().item()) > 0
+            assert abs(m2 - m1) < 8 * np.sqrt(c1 / n) + 0.02 * np.sqrt(c1) and abs(c2 / c1 - 1) < 0.02, (n, m1, m2, c1, c2)
+            for k in range(14, 20):
+                u.update(int(outs[k]), ts[k:k + 1])
+            assert np.isfinite(u.est_mean()[0])
+            del u
+            import torch
+            torch.cuda.empty_cache()
