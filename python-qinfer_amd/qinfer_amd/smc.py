@@ -974,7 +974,8 @@ class SMCUpdater(ParticleDistribution):
 
     def _design_generic(self, expparams, what):
         """Plugin path (any Model): the reference's formulas on `hypothetical_update` output."""
-        self._single_cloud_only("bayes_risk / expected_information_gain of a model without native kernels")
+        self._single_cloud_only("bayes_risk / expected_information_gain through hypothetical_update (a model whose kernels carry no "
+                                "design sums: plugin models, tomography's risk, wide tomography)")
         n_eps = expparams.shape[0]
         if n_eps > 1 and not self.model.is_n_outcomes_constant:
             return np.array([self._design_generic(expparams[i:i + 1], what)[0] for i in range(n_eps)])
