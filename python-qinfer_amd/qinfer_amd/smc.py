@@ -973,25 +973,58 @@ class SMCUpdater(ParticleDistribution):
         return self._design_generic(expparams, "eig")
 
     def _design_generic(self, expparams, what):
-        """Plugin path (any Model): the reference's formulas on `hypothetical_update` output."""
-        self._single_cloud_only("bayes_risk / expected_information_gain through hypothetical_update (a model whose kernels carry no "
-                                "design sums: plugin models, tomography's risk, wide tomography)")
+        """Any model whose kernels carry no design sums (plugin models three ways, tomography's risk, wide tomography):
+        the same one-pass sums the native design kernels form -- per (outcome, experiment) N = sum w L, sum w L ln L,
+        sum w L (x - c), sum w L (x - c)^2 with c the current mean -- as torch products on the device from the model's
+        likelihood tensor; a sharded updater adds the shards' sums (they are sums over particles with the global
+        normaliser and a shift every rank agrees on), then the reference's formulas (smc.py:586-611, 640-663) on the totals."""
         n_eps = expparams.shape[0]
         if n_eps > 1 and not self.model.is_n_outcomes_constant:
             return np.array([self._design_generic(expparams[i:i + 1], what)[0] for i in range(n_eps)])
+        Q = np.asarray(self.model.Q, dtype=np.float64)
+        if what == "risk" and Q.ndim != 1:
+            return self._design_generic_host(expparams, what)
+        t = self._eng.torch
+        os_ = self.model.domain(expparams[0:1])[0].values
+        n_o, (d, n) = len(os_), self._x.shape
+        w = self._eng.normalized_weights(self._weights(), self._norm)
+        per = 1 + (2 * d if what == "risk" else 1)
+        rows = np.empty((n_o, n_eps, per))
+        if what == "risk":
+            xc = self._x - self._eng.to_device(np.asarray(self.est_mean(), dtype=np.float64))[:, None]
+            xc2 = xc * xc
+        group = max(1, int(1e8 // max(1, n_o * n))) if n_eps > 1 else 1        # (the likelihood tensor: <= ~1e8 doubles at a time)
+        for e0 in range(0, n_eps, group):
+            L = self._device_likelihood(os_, expparams[e0:e0 + group])          # (n_o, g, N) device
+            g = L.shape[1]
+            wl = L * w
+            cols = [wl.sum(dim=2, keepdim=True)]
+            if what == "risk":
+                flat = wl.reshape(n_o * g, n)
+                cols += [(flat @ xc.T).reshape(n_o, g, d), (flat @ xc2.T).reshape(n_o, g, d)]
+            else:
+                cols.append((wl * t.where(L > 0, t.log(L), t.zeros_like(L))).sum(dim=2, keepdim=True))
+            rows[:, e0:e0 + g] = t.cat(cols, dim=2).cpu().numpy()
+        if self._comm is not None:
+            rows = self._comm.allreduce_host_vector(rows.reshape(-1))[0].reshape(rows.shape)
+        N = rows[..., 0]
+        with np.errstate(divide='ignore', invalid='ignore'):
+            if what == "risk":
+                s1, s2 = rows[..., 1:1 + d], rows[..., 1 + d:]
+                var = np.where(N[..., None] > 0, s2 - s1 * s1 / N[..., None], 0.0)      # N var, per coordinate
+                return (var @ Q).sum(axis=0)
+            return np.sum(np.where(N > 0, rows[..., 1] - N * np.log(N), 0.0), axis=0)
+
+    def _design_generic_host(self, expparams, what):
+        """The reference's formulas on `hypothetical_update` output (a square scale matrix Q: one cloud only)."""
+        self._single_cloud_only("bayes_risk with a matrix-valued Q")
         os_ = self.model.domain(expparams[0:1])[0].values
         w_hyp, N = self.hypothetical_update(os_, expparams, return_normalization=True)
         N = N[:, :, 0]
-        if what == "risk":
-            locs = self.particle_locations
-            mu = np.dot(w_hyp, locs)
-            var = np.sum(w_hyp * np.sum(self.model.Q * (locs[None, None, :, :] - mu[:, :, None, :]) ** 2, axis=3),
-                         axis=2)
-            return np.sum(N * var, axis=0)
-        w = self.particle_weights
-        with np.errstate(divide='ignore', invalid='ignore'):
-            terms = np.where(w_hyp > 0, w_hyp * np.log(w_hyp / w), 0.0)
-        return np.sum(N * np.sum(terms, axis=2), axis=0)
+        locs = self.particle_locations
+        mu = np.dot(w_hyp, locs)
+        var = np.sum(w_hyp * np.sum(self.model.Q * (locs[None, None, :, :] - mu[:, :, None, :]) ** 2, axis=3), axis=2)
+        return np.sum(N * var, axis=0)
 
     def risk(self, x0):
         return self.bayes_risk(np.array([(x0,)], dtype=self.model.expparams_dtype))

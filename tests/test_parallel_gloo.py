@@ -658,6 +658,60 @@ def test_sharded_unequal_shares(tmp_path, world):
     _run("_check_sharded_unequal_shares", tmp_path, world=world)
 
 
+def _check_sharded_design_generic(comm, rank, world, tmpdir):
+    """`bayes_risk` / `expected_information_gain` of models whose kernels carry no design sums -- two-qubit tomography (its
+    risk), three-qubit tomography (both), a NumPy plugin model -- on a sharded updater: the shards' one-pass sums added,
+    against ONE updater holding the union cloud (which the single-GPU tests hold to the definitions)."""
+    import warnings
+    import torch
+    import qinfer_amd as qi
+    from test_plugin_device import plugin_models
+    torch.cuda.set_device(0)
+    NumpyT2, _ = plugin_models(qi)
+    rs = np.random.RandomState(9)
+    n_local = 3000
+    cases = []
+    for basis in (qi.tomography.pauli_basis(2), qi.tomography.pauli_basis(3)):
+        m = qi.TomographyModel(basis)
+        np.random.seed(4)
+        x_all = qi.GinibreDistribution(basis).sample(n_local * world)
+        eps = np.zeros(5, dtype=m.expparams_dtype)
+        for i in range(5):
+            eps['meas'][i, 0] = eps['meas'][i, 1 + 2 * i] = np.sqrt(basis.dim) / 2
+        cases.append((m, x_all, eps, rs.randint(0, 2, 5)))
+    m = NumpyT2()
+    eps = np.zeros(5, dtype=m.expparams_dtype)
+    eps['t'] = 1.5 ** np.arange(5)
+    cases.append((m, np.column_stack([rs.random_sample(n_local * world), 0.2 * rs.random_sample(n_local * world)]), eps,
+                  rs.randint(0, 2, 5)))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for model, x_all, eps, outs in cases:
+            class Slice(qi.Distribution):
+                n_rvs = x_all.shape[1]
+
+                def __init__(self, lo, hi):
+                    self.lo, self.hi = lo, hi
+
+                def sample(self, n=1):
+                    return x_all[self.lo:self.hi].copy()
+            shard = qi.SMCUpdater(model, n_local, Slice(rank * n_local, (rank + 1) * n_local), device_rng=True, seed=5,
+                                  comm=comm, resample_thresh=0.0)
+            whole = qi.SMCUpdater(type(model)(model.basis) if hasattr(model, "basis") else type(model)(), n_local * world,
+                                  Slice(0, n_local * world), device_rng=True, seed=5, resample_thresh=0.0)
+            for k in range(3):
+                shard.update(int(outs[k]), eps[k:k + 1])
+                whole.update(int(outs[k]), eps[k:k + 1])
+            np.testing.assert_allclose(shard.bayes_risk(eps), whole.bayes_risk(eps), rtol=1e-9)
+            np.testing.assert_allclose(shard.expected_information_gain(eps), whole.expected_information_gain(eps),
+                                       rtol=1e-9, atol=1e-14)
+
+
+@pytest.mark.gpu
+def test_sharded_design_quantities_without_kernel_sums(tmp_path):
+    _run("_check_sharded_design_generic", tmp_path, world=2)
+
+
 def _check_sharded_plugin_model(comm, rank, world, tmpdir):
     """Round 6: a model WITHOUT native kernels shards too (the reference's DirectViewParallelizedModel shards any model's
     likelihood, parallel.py:196-224).  Two ranks against ONE updater holding the union cloud: the updates agree to
