@@ -591,9 +591,9 @@ class ParticleShardGroup:
         # validity test does.  The shard's draw then runs on the same Philox samplers without a test of their own, and the
         # model's test (its device hook or its NumPy one) drives the redraw rounds (LiuWestResampler._plugin_device_draw).
         native = native_ok(model)
-        if not native and updater.n_rvs > _native.QSMC_MAX_D:
+        if not native and updater.n_rvs > _native.QSMC_MAX_D_WIDE:
             raise NotImplementedError("sharded resampling: the device samplers take at most {} model parameters".format(
-                _native.QSMC_MAX_D))
+                _native.QSMC_MAX_D_WIDE))
         desc = model._native_desc() if native else _native.ModelDesc(_native.MODEL_TOMOGRAPHY, updater.n_rvs, 0.0, 1, 0)
         postselect = bool(resampler._postselect) and native       # (the kernels' own test: a native model's only)
         self._epoch += 1

@@ -712,6 +712,77 @@ def test_sharded_design_quantities_without_kernel_sums(tmp_path):
     _run("_check_sharded_design_generic", tmp_path, world=2)
 
 
+def _check_sharded_plugin_model_25_params(comm, rank, world, tmpdir):
+    """A plugin model with MORE than 16 parameters (25: a user's own tomography-like model with a validity constraint) on a
+    sharded updater: the shard's draw runs on the wide samplers (no test of their own), the model's test drives the redraw
+    rounds; children kept with their ancestors, and always-rebalance.  Updates equal one updater on the union cloud to
+    rounding; after a resample the count is conserved, every particle valid, mean and spread where the union cloud's are."""
+    import warnings
+    import torch
+    import qinfer_amd as qi
+    from qinfer_amd.parallel import ParticleShardGroup
+    torch.cuda.set_device(0)
+    basis = qi.tomography.gell_mann_basis(5)
+
+    class UserTomo(qi.FiniteOutcomeModel):
+        n_modelparams = 25
+        expparams_dtype = [('meas', float, 25)]
+        is_n_outcomes_constant = True
+
+        def n_outcomes(self, ep):
+            return 2
+
+        def are_models_valid(self, mp):
+            return mp[:, 0] > 0.4
+
+        def likelihood(self, outcomes, mp, ep):
+            super().likelihood(outcomes, mp, ep)
+            pr1 = np.clip(mp @ ep['meas'].reshape(-1, 25).T, 0, 1)
+            return qi.FiniteOutcomeModel.pr0_to_likelihood_array(outcomes, 1 - pr1)
+    n_local = 20000
+    np.random.seed(4)
+    x_all = qi.GinibreDistribution(basis).sample(n_local * world)
+
+    class Slice(qi.Distribution):
+        n_rvs = 25
+
+        def __init__(self, lo, hi):
+            self.lo, self.hi = lo, hi
+
+        def sample(self, n=1):
+            return x_all[self.lo:self.hi].copy()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for grp in (comm, ParticleShardGroup(seed=12, rebalance_tol=0.0)):
+            rs = np.random.RandomState(9)
+            shard = qi.SMCUpdater(UserTomo(), n_local, Slice(rank * n_local, (rank + 1) * n_local), device_rng=True, seed=5,
+                                  comm=grp, resample_thresh=0.0)
+            whole = qi.SMCUpdater(UserTomo(), n_local * world, Slice(0, n_local * world), device_rng=True, seed=5,
+                                  resample_thresh=0.0)
+            assert not shard._native
+            for k in range(6):
+                ep = np.zeros(1, dtype=UserTomo.expparams_dtype)
+                ep['meas'][0, 0] = ep['meas'][0, 1 + 3 * k] = np.sqrt(5) / 2
+                o = int(rs.randint(2))
+                shard.update(o, ep)
+                whole.update(o, ep)
+            np.testing.assert_allclose(shard.est_mean(), whole.est_mean(), rtol=0, atol=1e-12)
+            sd0 = np.sqrt(np.diag(whole.est_covariance_mtx()))
+            shard.resample()
+            whole.resample()
+            assert grp.gather_rows(np.array([float(shard.n_particles)]))[:, 0].sum() == n_local * world
+            assert (np.asarray(shard.particle_locations)[:, 0] > 0.4).all()
+            assert np.all(np.abs(shard.est_mean() - whole.est_mean())[1:] < 0.06 * sd0[1:])
+            ratio = np.sqrt(np.diag(shard.est_covariance_mtx()))[1:] / np.sqrt(np.diag(whole.est_covariance_mtx()))[1:]
+            assert np.all(np.abs(ratio - 1) < 0.03), ratio
+        assert "rebalance" in grp.last_resample_path and "plugin model" in comm.last_resample_path
+
+
+@pytest.mark.gpu
+def test_sharded_plugin_model_25_parameters(tmp_path):
+    _run("_check_sharded_plugin_model_25_params", tmp_path, world=2)
+
+
 def _check_sharded_plugin_model(comm, rank, world, tmpdir):
     """Round 6: a model WITHOUT native kernels shards too (the reference's DirectViewParallelizedModel shards any model's
     likelihood, parallel.py:196-224).  Two ranks against ONE updater holding the union cloud: the updates agree to
